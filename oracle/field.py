@@ -1,0 +1,160 @@
+"""Oracle: Instant-NGP radiance field (contraction, hash grid, SH, two MLPs).
+
+TEST INFRASTRUCTURE ONLY (see ``oracle/__init__.py``).
+
+Follows ``robust_e_nerf/external/ngp.py:45-106,230-280`` (field),
+``robust_e_nerf/external/mlp.py:99-113`` (MLP forward),
+``robust_e_nerf/external/sh_encoder.py:28-93`` (real SH, tcnn sign convention) and the
+activation tables of ``robust_e_nerf/models/nerf.py:8-29``.  PINNED against the
+reference's own Python via ``tests/golden`` (hash grid excepted -- see hashgrid.py).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F_
+
+from . import hashgrid
+
+AABB, UN_BOUNDED_TANH, UN_BOUNDED_SPHERE = 0, 1, 2       # nerfacc.ContractionType order
+
+
+# ----------------------------------------------------------------------------- activations
+class _TruncExp(torch.autograd.Function):
+    """exp with backward g*exp(clamp(x, max=15)) -- ngp.py:45-61."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return torch.exp(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return g * torch.exp(torch.clamp(x, max=15))
+
+
+def shifted_trunc_exp(x, shift=1.0):                       # ngp.py:64-65
+    return _TruncExp.apply(x - shift)
+
+
+def softplus(x, beta: float, threshold: float = 20.0):     # nerf.py:17-29 (torch softplus)
+    return F_.softplus(x, beta, threshold)
+
+
+# ----------------------------------------------------------------------------- contraction
+def contract(x: torch.Tensor, aabb: torch.Tensor, contraction_type: int) -> torch.Tensor:
+    """World -> unit cube.  ngp.py:230-237, 68-106."""
+    aabb_min, aabb_max = aabb[:3], aabb[3:]
+    x = (x - aabb_min) / (aabb_max - aabb_min)
+    if contraction_type == UN_BOUNDED_SPHERE:              # ngp.py:76-93
+        x = x * 2 - 1
+        mag = x.norm(dim=-1, keepdim=True)
+        x = torch.where(mag > 1, (2 - 1 / mag) * (x / mag), x)
+        x = x / 4 + 0.5
+    elif contraction_type == UN_BOUNDED_TANH:              # ngp.py:96-106
+        x = (torch.tanh(x - 0.5) + 1) / 2
+    return x
+
+
+def selector(x_unit: torch.Tensor) -> torch.Tensor:        # ngp.py:238
+    return ((x_unit > 0.0) & (x_unit < 1.0)).all(dim=-1)
+
+
+# ----------------------------------------------------------------------------- SH encoder
+def sh_encode(d: torch.Tensor, degree: int = 4) -> torch.Tensor:
+    """Real spherical harmonics, degree <= 4 (16 outputs).  sh_encoder.py:28-93."""
+    assert 1 <= degree <= 4, "oracle restates degrees 1..4 (configs use 4)"
+    x, y, z = d.unbind(-1)
+    xy, xz, yz = x * y, x * z, y * z
+    x2, y2, z2 = x * x, y * y, z * z
+    out = [torch.full_like(x, 0.28209479177387814)]
+    if degree > 1:
+        out += [-0.48860251190291987 * y, 0.48860251190291987 * z, -0.48860251190291987 * x]
+    if degree > 2:
+        out += [
+            1.0925484305920792 * xy,
+            -1.0925484305920792 * yz,
+            0.94617469575755997 * z2 - 0.31539156525251999,
+            -1.0925484305920792 * xz,
+            0.54627421529603959 * x2 - 0.54627421529603959 * y2,
+        ]
+    if degree > 3:
+        out += [
+            0.59004358992664352 * y * (-3.0 * x2 + y2),
+            2.8906114426405538 * xy * z,
+            0.45704579946446572 * y * (1.0 - 5.0 * z2),
+            0.3731763325901154 * z * (5.0 * z2 - 3.0),
+            0.45704579946446572 * x * (1.0 - 5.0 * z2),
+            1.4453057213202769 * z * (x2 - y2),
+            0.59004358992664352 * x * (-x2 + 3.0 * y2),
+        ]
+    return torch.stack(out, dim=-1)
+
+
+# ----------------------------------------------------------------------------- parameters
+def init_params(
+    spec: hashgrid.HashGridSpec,
+    radiance_dim: int = 1,
+    seed: int = 0,
+    table_kind: str = "uniform",
+    table_scale: float = 1e-4,
+    dtype=torch.float32,
+) -> Dict[str, torch.Tensor]:
+    """torch.nn.Linear default init U(+-1/sqrt(fan_in)) (ngp.py:179-185,198-204 pass
+    hidden_init=None...bias_init=None so the nn.Linear defaults stay)."""
+    g = torch.Generator().manual_seed(seed)
+
+    def lin(out_f, in_f):
+        bound = 1.0 / math.sqrt(in_f)
+        w = (torch.rand(out_f, in_f, generator=g) * 2 - 1) * bound
+        b = (torch.rand(out_f, generator=g) * 2 - 1) * bound
+        return w.to(dtype), b.to(dtype)
+
+    p = {}
+    p["hash"] = hashgrid.init_table(spec, seed + 1000, table_scale, table_kind).to(dtype)
+    p["base.w0"], p["base.b0"] = lin(64, spec.n_output_dims)
+    p["base.wo"], p["base.bo"] = lin(16, 64)
+    p["head.w0"], p["head.b0"] = lin(64, 31)
+    p["head.w1"], p["head.b1"] = lin(64, 64)
+    p["head.wo"], p["head.bo"] = lin(radiance_dim, 64)
+    return p
+
+
+PARAM_ORDER = (
+    "hash", "base.w0", "base.b0", "base.wo", "base.bo",
+    "head.w0", "head.b0", "head.w1", "head.b1", "head.wo", "head.bo",
+)
+
+
+# ----------------------------------------------------------------------------- field
+def query_density(
+    x_world: torch.Tensor, p: Dict[str, torch.Tensor], spec, aabb: torch.Tensor,
+    contraction_type: int = AABB, return_feat: bool = False,
+):
+    """ngp.py:230-254: sigma = exp(raw0 - 1) * selector, geo = raw[1:16]."""
+    xu = contract(x_world, aabb, contraction_type)
+    sel = selector(xu)
+    enc = hashgrid.encode(xu, p["hash"], spec)
+    h = softplus(enc @ p["base.w0"].T + p["base.b0"], 100.0)
+    raw = h @ p["base.wo"].T + p["base.bo"]
+    sigma = shifted_trunc_exp(raw[:, :1]) * sel[:, None].to(raw.dtype)
+    if return_feat:
+        return sigma, raw[:, 1:]
+    return sigma
+
+
+def query_rgb(dirs: torch.Tensor, geo: torch.Tensor, p: Dict[str, torch.Tensor]) -> torch.Tensor:
+    """ngp.py:256-267: head([SH16(dir) | geo15]) with softplus(100) hidden, softplus(1) out."""
+    h = torch.cat([sh_encode(dirs, 4), geo], dim=-1)
+    h = softplus(h @ p["head.w0"].T + p["head.b0"], 100.0)
+    h = softplus(h @ p["head.w1"].T + p["head.b1"], 100.0)
+    return softplus(h @ p["head.wo"].T + p["head.bo"], 1.0)
+
+
+def field_forward(x_world, dirs, p, spec, aabb, contraction_type: int = AABB):
+    """ngp.py:269-280 -> (rgb (n,C), sigma (n,1))."""
+    sigma, geo = query_density(x_world, p, spec, aabb, contraction_type, return_feat=True)
+    return query_rgb(dirs, geo, p), sigma

@@ -1,0 +1,133 @@
+"""Oracle: one render / one training step of the hot path, end to end, on the CPU.
+
+TEST INFRASTRUCTURE ONLY.  Composition follows
+``robust_e_nerf/models/robust_e_nerf.py:301-517`` (training_step), ``:849-885``
+(render_pixels), ``robust_e_nerf/models/nerf.py:230-286`` (NeRF.forward) and
+``robust_e_nerf/external/utils.py:38-140`` (render_image, training = one chunk).
+Also the ``cpu_baseline`` leg of bench.py.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field as dc_field
+from typing import Dict, Optional
+
+import torch
+
+from . import events, field, hashgrid, render, sampling, trajectory
+
+
+@dataclass
+class SceneCfg:
+    """Subset of configs/train/*.yaml model.nerf.* that shapes the hot path."""
+    aabb: tuple = (-1.5, -1.5, -1.5, 1.5, 1.5, 1.5)
+    contraction_type: int = field.AABB
+    occ_res: tuple = (128, 128, 128)
+    near_plane: Optional[float] = None
+    far_plane: Optional[float] = None
+    render_step_size: float = 3 ** 0.5 * 3.0 / 1024        # robust_e_nerf.py:220-226 "auto"
+    cone_angle: float = 0.0
+    early_stop_eps: float = 1e-4
+    alpha_thre: float = 0.0
+    min_modeled_intensity: float = 1e-3
+    opacity_eps: float = 1e-10
+    bkgd_is_param: bool = True                              # alpha_over_white_bg
+    sampler: str = "occgrid"                                # "occgrid" | "uniform"
+    n_uniform: int = 64
+
+
+def render_rays(o, d, p: Dict[str, torch.Tensor], spec, cfg: SceneCfg, *,
+                binary: Optional[torch.Tensor], jitter: Optional[torch.Tensor],
+                bkgd: Optional[torch.Tensor], training: bool = True):
+    """NeRF.forward (nerf.py:230-286) -> radiance (R,C), opacity (R,), depth (R,), n, packed."""
+    aabb = torch.tensor(cfg.aabb, dtype=torch.float32)
+    n_rays = o.shape[0]
+
+    def positions(ts, te, ri):
+        return o[ri] + d[ri] * (ts + te) / 2.0             # external/utils.py:68-72
+
+    def sigma_fn(ts, te, ri):
+        return field.query_density(positions(ts, te, ri), p, spec, aabb, cfg.contraction_type)
+
+    def rgb_sigma_fn(ts, te, ri):
+        return field.field_forward(positions(ts, te, ri), d[ri], p, spec, aabb, cfg.contraction_type)
+
+    scene_aabb = aabb if cfg.contraction_type == field.AABB else None   # nerf.py:248-251
+    if cfg.sampler == "occgrid":
+        ri, ts, te = sampling.ray_marching(
+            o.detach(), d.detach(), scene_aabb=scene_aabb, grid_binary=binary, grid_roi=aabb,
+            contraction_type=cfg.contraction_type, sigma_fn=sigma_fn,
+            near_plane=cfg.near_plane, far_plane=cfg.far_plane,
+            render_step_size=cfg.render_step_size, stratified=training, cone_angle=cfg.cone_angle,
+            early_stop_eps=cfg.early_stop_eps, alpha_thre=cfg.alpha_thre, jitter=jitter)
+    else:
+        # the build's fixed-S sampler: S equal intervals over the ray/AABB slab, comb shifted
+        # by u * delta when training (SURVEY 8(d) sampling mode (i)).
+        t_min, t_max = sampling.ray_aabb_intersect(o.detach(), d.detach(), aabb)
+        if cfg.near_plane is not None:
+            t_min = t_min.clamp(min=cfg.near_plane)
+        if cfg.far_plane is not None:
+            t_max = t_max.clamp(max=cfg.far_plane)
+        _, _, ri, ts, te = sampling.march(o.detach(), d.detach(), t_min, t_max, aabb, None,
+                                          cfg.contraction_type, cfg.render_step_size, 0.0,
+                                          mode=1, n_uniform=cfg.n_uniform,
+                                          jitter=jitter if training else None)
+        ts, te = ts[:, None], te[:, None]
+    colors, opac, depth = render.rendering(ts, te, ri, n_rays, rgb_sigma_fn, render_bkgd=bkgd)
+    opac = opac.squeeze(-1)
+    depth = depth.squeeze(-1) / (opac + cfg.opacity_eps)    # nerf.py:279-282
+    return colors, opac, depth, ts.shape[0], (ri, ts, te)
+
+
+def render_pixels(Kinv, px, pos, R, p, spec, cfg: SceneCfg, **kw):
+    """robust_e_nerf.py:849-885 (monochrome): intensity, opacity, depth*cos, n, is_valid."""
+    o, d = trajectory.pixel_params_to_ray(Kinv, px, pos, R)
+    colors, opac, depth, n, packed = render_rays(o, d, p, spec, cfg, **kw)
+    intensity = colors.squeeze(-1) + cfg.min_modeled_intensity
+    is_valid = torch.ones_like(opac, dtype=torch.bool) if cfg.bkgd_is_param else opac > 0
+    depth = depth * (d * R[..., 2]).sum(-1)
+    return intensity, opac, depth, n, is_valid, packed
+
+
+@dataclass
+class EventBatch:
+    position: torch.Tensor          # (B,2) f32
+    start_ts: torch.Tensor          # (B,) i64
+    end_ts: torch.Tensor            # (B,) i64
+    num_pos: torch.Tensor           # (B,) i64
+    num_neg: torch.Tensor           # (B,) i64
+    u_ts_diff: torch.Tensor         # (B,) f64
+    u_diff_start: torch.Tensor      # (B,) f64
+    u_grad: torch.Tensor            # (B,) f64
+
+
+def training_forward(batch: EventBatch, p, spec, cfg: SceneCfg, *, Kinv, tab_ts, tab_pos, tab_quat,
+                     p2n_raw, neg_ct, tau_raw, tau_max, bkgd_raw, binary,
+                     jitter_start, jitter_end, loss_cfg: Optional[dict] = None):
+    """training_step with the log-intensity-difference loss (two renders).
+
+    Returns (loss, aux) where aux holds every intermediate the parity tests compare."""
+    lc = dict(err_diff="mse", w_diff=1.0, pw_diff="mean_contrast_reciprocal_sq")
+    lc.update(loss_cfg or {})
+    c_p, c_n, mean_c = events.contrast_thresholds(p2n_raw, neg_ct)
+    ev_diff = events.event_log_intensity_diff(batch.num_pos, batch.num_neg, c_p, c_n)
+    tau = events.refractory_period(events.clamp_tau_raw(tau_raw, tau_max), tau_max)
+    tsd = events.supervision_timestamps(batch.start_ts, batch.end_ts, batch.u_ts_diff,
+                                        batch.u_diff_start, batch.u_grad, tau)
+    bkgd = torch.nn.functional.softplus(bkgd_raw) if cfg.bkgd_is_param else None
+    out = {}
+    for name, ts, jit in (("start", tsd["diff_start_ts"], jitter_start),
+                          ("end", tsd["diff_end_ts"], jitter_end)):
+        pos, R = trajectory.linear_trajectory(ts, tab_ts, tab_pos, tab_quat)
+        out[name] = render_pixels(Kinv, batch.position, pos, R, p, spec, cfg,
+                                  binary=binary, jitter=jit, bkgd=bkgd, training=True)
+    log_s, log_e = out["start"][0].log(), out["end"][0].log()
+    pred = log_e - log_s
+    valid = out["start"][4] | out["end"][4]
+    loss, terms = events.event_loss(
+        ev_diff, tsd["start_ts"], batch.end_ts, pred_log_diff=pred, ts_diff=tsd["ts_diff"],
+        diff_valid=valid, mean_c=mean_c, **lc)
+    aux = dict(ts=tsd, intensity_start=out["start"][0], intensity_end=out["end"][0],
+               opacity_start=out["start"][1], opacity_end=out["end"][1],
+               n_start=out["start"][3], n_end=out["end"][3], pred_log_diff=pred, terms=terms,
+               packed_start=out["start"][5], packed_end=out["end"][5])
+    return loss, aux

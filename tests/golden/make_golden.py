@@ -1,0 +1,514 @@
+"""Generate golden vectors from the REFERENCE'S OWN PYTHON (build container only).
+
+Usage (in the build container, where /root/reference exists):
+    python tests/golden/make_golden.py
+
+The reference package cannot be imported as shipped (pytorch_lightning / nerfacc /
+tinycudann / roma / easydict / cv2 / lpips / torchmetrics are absent and CUDA-only), so
+small stand-in modules are injected into ``sys.modules``: the
+third-party *kernels* are served by this repo's CPU oracle, everything else that runs is
+the reference's unmodified code imported from /root/reference:
+``NGPradianceField`` (MLPs, SH, contraction, trunc_exp), ``NeRF`` (pixel_params_to_ray,
+forward, update_occ_grid), ``render_image`` / ``rendering`` glue, ``LinearTrajectory`` +
+``unitquat_slerp``, ``ContrastThreshold``, ``RefractoryPeriod``, ``Loss`` and the real
+``RobustENeRF.training_step`` / ``render_pixels``.
+
+Outputs are small ``.npz`` files (inputs, seeds, expected outputs) committed next to this
+script.  Nothing from /root/reference is copied: fixtures are data only.  The 50 MB hash
+table is regenerated from a seed (``oracle.hashgrid.init_table(kind='mix32')``).
+"""
+import enum
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+REF = "/root/reference"
+
+from oracle import events as o_events  # noqa: E402
+from oracle import field as o_field  # noqa: E402
+from oracle import hashgrid, occgrid, render, sampling, trajectory  # noqa: E402
+
+JITTER_LOG = []          # per-ray uniforms consumed by the nerfacc stub, in call order
+TABLE_SEED, TABLE_SCALE = 7, 0.5
+
+
+# --------------------------------------------------------------------------- stubs
+class EasyDict(dict):
+    def __init__(self, d=None, **kw):
+        super().__init__()
+        d = {} if d is None else dict(d)
+        d.update(kw)
+        for k, v in d.items():
+            setattr(self, k, v)
+
+    def __setattr__(self, k, v):
+        if isinstance(v, (list, tuple)):
+            v = type(v)(EasyDict(x) if isinstance(x, dict) and not isinstance(x, EasyDict) else x for x in v)
+        elif isinstance(v, dict) and not isinstance(v, EasyDict):
+            v = EasyDict(v)
+        super().__setattr__(k, v)
+        super().__setitem__(k, v)
+
+    __setitem__ = __setattr__
+
+    def pop(self, k, *a):
+        if k in self.__dict__:
+            super().__delattr__(k)
+        return super().pop(k, *a)
+
+    def update(self, e=None, **f):
+        d = dict(e or {})
+        d.update(f)
+        for k, v in d.items():
+            setattr(self, k, v)
+
+
+def install_stubs():
+    ed = types.ModuleType("easydict")
+    ed.EasyDict = EasyDict
+    sys.modules["easydict"] = ed
+
+    # ---- nerfacc ---------------------------------------------------------------
+    na = types.ModuleType("nerfacc")
+
+    class ContractionType(enum.Enum):
+        AABB = 0
+        UN_BOUNDED_TANH = 1
+        UN_BOUNDED_SPHERE = 2
+
+    class OccupancyGrid(torch.nn.Module):
+        def __init__(self, roi_aabb, resolution=128, contraction_type=ContractionType.AABB):
+            super().__init__()
+            if isinstance(resolution, int):
+                resolution = [resolution] * 3
+            self.resolution = list(resolution)
+            self.contraction_type = contraction_type
+            self.register_buffer("_roi_aabb", torch.tensor(roi_aabb, dtype=torch.float32))
+            self.register_buffer("_binary", torch.zeros(self.resolution, dtype=torch.bool))
+            self.register_buffer("occs", torch.zeros(int(np.prod(self.resolution))))
+            self.updates = []
+
+        def every_n_step(self, step, occ_eval_fn, occ_thre=1e-2, ema_decay=0.95, warmup_steps=256, n=16):
+            if not self.training:
+                raise RuntimeError("not training")
+            if step % n == 0:
+                cells = self.occs.numel()
+                assert step < warmup_steps, "golden generator only exercises the warm-up policy"
+                idx = torch.arange(cells)
+                jit = torch.rand(cells, 3)
+                self.updates.append(dict(indices=idx, jitter=jit))
+                self.occs, b = occgrid.update(self.occs, tuple(self.resolution), self._roi_aabb,
+                                              self.contraction_type.value, idx, jit, occ_eval_fn,
+                                              occ_thre, ema_decay)
+                self._binary = b
+
+    def ray_marching(rays_o, rays_d, t_min=None, t_max=None, scene_aabb=None, grid=None,
+                     sigma_fn=None, alpha_fn=None, near_plane=None, far_plane=None,
+                     render_step_size=1e-3, stratified=False, cone_angle=0.0,
+                     early_stop_eps=1e-4, alpha_thre=0.0):
+        jit = None
+        if stratified:
+            jit = torch.rand(rays_o.shape[0])
+            JITTER_LOG.append(jit.clone())
+        ri, ts, te = sampling.ray_marching(
+            rays_o.detach(), rays_d.detach(), scene_aabb=scene_aabb,
+            grid_binary=None if grid is None else grid._binary,
+            grid_roi=None if grid is None else grid._roi_aabb,
+            contraction_type=0 if grid is None else grid.contraction_type.value,
+            sigma_fn=sigma_fn, near_plane=near_plane, far_plane=far_plane,
+            render_step_size=float(render_step_size), stratified=stratified,
+            cone_angle=cone_angle, early_stop_eps=early_stop_eps, alpha_thre=alpha_thre,
+            jitter=jit)
+        return ri, ts, te
+
+    na.ContractionType = ContractionType
+    na.OccupancyGrid = OccupancyGrid
+    na.ray_marching = ray_marching
+    na.render_weight_from_density = lambda t_starts, t_ends, sigmas, ray_indices=None, n_rays=None: \
+        render.render_weight_from_density(t_starts, t_ends, sigmas, ray_indices, n_rays)
+    na.render_weight_from_alpha = None
+    na.accumulate_along_rays = lambda weights, ray_indices, values=None, n_rays=None: \
+        render.accumulate_along_rays(weights, ray_indices, values, n_rays)
+    sys.modules["nerfacc"] = na
+
+    # ---- tinycudann --------------------------------------------------------------
+    tc = types.ModuleType("tinycudann")
+
+    class Encoding(torch.nn.Module):
+        def __init__(self, n_input_dims, encoding_config, dtype=torch.float32):
+            super().__init__()
+            assert encoding_config["otype"] == "HashGrid" and encoding_config["interpolation"] == "Linear"
+            self.spec = hashgrid.make_spec(
+                encoding_config["n_levels"], encoding_config["n_features_per_level"],
+                encoding_config["log2_hashmap_size"], encoding_config["base_resolution"],
+                encoding_config["per_level_scale"])
+            self.n_output_dims = self.spec.n_output_dims
+            self.params = torch.nn.Parameter(
+                hashgrid.init_table(self.spec, TABLE_SEED, TABLE_SCALE, "mix32"))
+
+        def forward(self, x):
+            return hashgrid.encode(x, self.params, self.spec)
+
+    tc.Encoding = Encoding
+    sys.modules["tinycudann"] = tc
+
+    # ---- roma --------------------------------------------------------------------
+    ro = types.ModuleType("roma")
+    ro.quat_conjugation = trajectory.quat_conjugation
+    ro.quat_product = trajectory.quat_product
+    ro.rotvec_to_unitquat = trajectory.rotvec_to_unitquat
+    ro.unitquat_to_rotmat = trajectory.unitquat_to_rotmat
+    internal = types.ModuleType("roma.internal")
+
+    def flatten_batch_dims(t, end_dim):
+        batch_shape = t.shape[: end_dim + 1]
+        return t.reshape(-1, *t.shape[end_dim + 1:]) if len(batch_shape) > 0 else t.unsqueeze(0), batch_shape
+
+    def unflatten_batch_dims(t, batch_shape):
+        return t.reshape(*batch_shape, *t.shape[1:]) if len(batch_shape) > 0 else t.squeeze(0)
+
+    internal.flatten_batch_dims = flatten_batch_dims
+    internal.unflatten_batch_dims = unflatten_batch_dims
+    ro.internal = internal
+    sys.modules["roma"] = ro
+    sys.modules["roma.internal"] = internal
+
+    # ---- pytorch_lightning & eval-only deps ------------------------------------------
+    pl = types.ModuleType("pytorch_lightning")
+    pl.LightningModule = torch.nn.Module
+    pl.LightningDataModule = object
+    sys.modules["pytorch_lightning"] = pl
+    for name in ("cv2", "lpips", "tqdm"):
+        if name not in sys.modules:
+            try:
+                __import__(name)
+            except ImportError:
+                sys.modules[name] = types.ModuleType(name)
+    tm = types.ModuleType("torchmetrics")
+    tm.functional = types.ModuleType("torchmetrics.functional")
+    sys.modules["torchmetrics"] = tm
+    sys.modules["torchmetrics.functional"] = tm.functional
+    sys.path.insert(0, REF)
+
+
+# --------------------------------------------------------------------------- synthetic inputs
+def orbit_poses(n_poses=201, radius=4.0, period_ns=1_000_000, seed=0):
+    """Camera on a circular orbit looking at the origin; x-right / y-down / z-forward."""
+    k = np.arange(n_poses)
+    ang = 2 * np.pi * k / (n_poses - 1) * 0.35
+    pos = np.stack([radius * np.cos(ang), radius * np.sin(ang), 0.6 * np.sin(3 * ang)], -1)
+    fwd = -pos / np.linalg.norm(pos, axis=-1, keepdims=True)
+    up = np.array([0.0, 0.0, 1.0])
+    right = np.cross(fwd, up)
+    right /= np.linalg.norm(right, axis=-1, keepdims=True)
+    down = np.cross(fwd, right)
+    Rm = np.stack([right, down, fwd], -1)                   # columns = camera axes in world
+    from scipy.spatial.transform import Rotation
+    quat = Rotation.from_matrix(Rm).as_quat()               # XYZW
+    ts = (k * period_ns).astype(np.int64)
+    return ts, pos.astype(np.float32), quat.astype(np.float32)
+
+
+def make_events(B, t_end_ns, seed=1, width=346, height=260):
+    g = np.random.default_rng(seed)
+    px = np.stack([g.integers(0, width, B), g.integers(0, height, B)], -1).astype(np.float32)
+    end = g.integers(20_000_000, t_end_ns, B).astype(np.int64)
+    delta = np.exp(g.uniform(np.log(2e5), np.log(2e7), B)).astype(np.int64)
+    start = end - delta
+    pol = g.random(B) < 0.5
+    return px, start, end, pol.astype(np.int64), (~pol).astype(np.int64)
+
+
+def ball_binary(res, radius=1.0, aabb=(-1.5, -1.5, -1.5, 1.5, 1.5, 1.5)):
+    lo, hi = np.array(aabb[:3]), np.array(aabb[3:])
+    g = np.stack(np.meshgrid(*[np.arange(res)] * 3, indexing="ij"), -1)
+    c = (g + 0.5) / res * (hi - lo) + lo
+    return torch.from_numpy(np.linalg.norm(c, axis=-1) < radius)
+
+
+NGP_CFG = dict(
+    pos_encoding=dict(otype="HashGrid", n_levels=16, n_features_per_level=2, log2_hashmap_size=19,
+                      base_resolution=16, per_level_scale=1.4472692012786865, interpolation="Linear"),
+    dir_encoding=dict(degree=4),
+    mlp_base=dict(hidden_activation="softplus", density_activation="shifted_trunc_exp",
+                  n_neurons=64, n_hidden_layers=1, geo_feat_dim=15, weight_norm=False),
+    mlp_head=dict(hidden_activation="softplus", radiance_activation="softplus",
+                  n_neurons=64, n_hidden_layers=2, weight_norm=False),
+)
+
+
+def field_params_np(rf):
+    sd = rf.state_dict()
+    return {
+        "base.w0": sd["mlp_base.1.hidden_layers.0.weight"], "base.b0": sd["mlp_base.1.hidden_layers.0.bias"],
+        "base.wo": sd["mlp_base.1.output_layer.weight"], "base.bo": sd["mlp_base.1.output_layer.bias"],
+        "head.w0": sd["mlp_head.hidden_layers.0.weight"], "head.b0": sd["mlp_head.hidden_layers.0.bias"],
+        "head.w1": sd["mlp_head.hidden_layers.1.weight"], "head.b1": sd["mlp_head.hidden_layers.1.bias"],
+        "head.wo": sd["mlp_head.output_layer.weight"], "head.bo": sd["mlp_head.output_layer.bias"],
+    }
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+# --------------------------------------------------------------------------- generators
+def gen_field(ngp, nerfacc):
+    """Reference NGPradianceField forward + first derivatives, three contraction types."""
+    torch.manual_seed(10)
+    for ct_name, ct, aabb in (("aabb", nerfacc.ContractionType.AABB, [-1.5] * 3 + [1.5] * 3),
+                              ("sphere", nerfacc.ContractionType.UN_BOUNDED_SPHERE, [0.5, -2.1, 0.6, 2.0, -0.6, 1.6]),
+                              ("tanh", nerfacc.ContractionType.UN_BOUNDED_TANH, [-1.0] * 3 + [1.0] * 3)):
+        torch.manual_seed(11)
+        act = dict(softplus=torch.nn.Softplus(beta=100))
+        base = EasyDict(NGP_CFG["mlp_base"])
+        base.hidden_activation = act["softplus"]
+        base.density_activation = ngp.shifted_trunc_exp
+        head = EasyDict(NGP_CFG["mlp_head"])
+        head.hidden_activation = act["softplus"]
+        head.radiance_activation = torch.nn.Softplus(beta=1)
+        head.output_dim = 1
+        rf = ngp.NGPradianceField(aabb=aabb, num_dim=3, use_viewdirs=True, contraction_type=ct,
+                                  pos_encoding_config=NGP_CFG["pos_encoding"],
+                                  dir_encoding_config=NGP_CFG["dir_encoding"],
+                                  mlp_base_config=base, mlp_head_config=head)
+        n = 384
+        lo, hi = torch.tensor(aabb[:3]), torch.tensor(aabb[3:])
+        span = 1.2 if ct_name == "aabb" else 3.0            # some points outside the box
+        x = (torch.rand(n, 3) - 0.5) * span * (hi - lo) + (hi + lo) / 2
+        d = torch.randn(n, 3)
+        d = d / d.norm(dim=-1, keepdim=True)
+        rgb, sigma = rf(x, d)
+        g_rgb, g_sig = torch.randn_like(rgb), torch.randn_like(sigma)
+        rf.zero_grad()
+        ((rgb * g_rgb).sum() + (sigma * g_sig).sum()).backward()
+        sd = dict(rf.named_parameters())
+        grads = {"g." + k: dict(rf.named_parameters())[v].grad for k, v in {
+            "base.w0": "mlp_base.1.hidden_layers.0.weight", "base.b0": "mlp_base.1.hidden_layers.0.bias",
+            "base.wo": "mlp_base.1.output_layer.weight", "base.bo": "mlp_base.1.output_layer.bias",
+            "head.w0": "mlp_head.hidden_layers.0.weight", "head.b0": "mlp_head.hidden_layers.0.bias",
+            "head.w1": "mlp_head.hidden_layers.1.weight", "head.b1": "mlp_head.hidden_layers.1.bias",
+            "head.wo": "mlp_head.output_layer.weight", "head.bo": "mlp_head.output_layer.bias"}.items()}
+        gt = sd["mlp_base.0.params"].grad
+        nz = torch.nonzero(gt)[:, 0]
+        pick = nz[torch.linspace(0, len(nz) - 1, 256).long()]
+        save(f"field_{ct_name}", aabb=np.array(aabb, np.float32), contraction_type=ct.value,
+             table_seed=TABLE_SEED, table_scale=TABLE_SCALE, x=x, d=d, rgb=rgb, sigma=sigma,
+             g_rgb=g_rgb, g_sigma=g_sig, g_table_sum=gt.double().sum(), g_table_abs=gt.double().abs().sum(),
+             g_table_idx=pick, g_table_val=gt[pick], **field_params_np(rf), **grads)
+
+
+def gen_sh(sh_encoder):
+    torch.manual_seed(20)
+    d = torch.randn(256, 3)
+    d = d / d.norm(dim=-1, keepdim=True)
+    save("sh4", d=d, out=sh_encoder.SHEncoder(3, 4)(d))
+
+
+def gen_rendering(vol_rendering):
+    """Reference `rendering` glue over the packed ops (pins the glue + monochrome branch)."""
+    torch.manual_seed(30)
+    n_rays = 48
+    counts = torch.randint(0, 24, (n_rays,))
+    counts[5] = 0
+    ri = torch.repeat_interleave(torch.arange(n_rays), counts).int()
+    n = int(counts.sum())
+    ts = torch.rand(n, 1) * 0.01 + torch.cat([torch.arange(c) for c in counts])[:, None] * 0.02 + 2.0
+    te = ts + 0.015
+    rgb_v, sig_v = torch.rand(n, 1), torch.rand(n, 1) * 30
+    bk = torch.tensor([0.7])
+    c, o, z = vol_rendering.rendering(ts, te, ri, n_rays, rgb_sigma_fn=lambda a, b, i: (rgb_v, sig_v),
+                                      render_bkgd=bk)
+    save("rendering", ray_indices=ri, t_starts=ts, t_ends=te, rgb=rgb_v, sigma=sig_v, bkgd=bk,
+         colors=c, opacities=o, depths=z, n_rays=n_rays)
+
+
+def gen_trajectory(trajectories, nerf_mod):
+    ts_tab, pos, quat = orbit_poses()
+    cam = EasyDict(camera_poses=EasyDict(
+        T_wc_position=torch.from_numpy(pos), T_wc_orientation=torch.from_numpy(quat),
+        T_wc_timestamp=torch.from_numpy(ts_tab)))
+    traj = trajectories.LinearTrajectory(cam)
+    g = np.random.default_rng(40)
+    ts = g.uniform(0, ts_tab[-1], 300)
+    ts[:4] = [0.0, float(ts_tab[-1]), float(ts_tab[7]), float(ts_tab[7]) + 0.5]
+    ts = torch.from_numpy(ts).requires_grad_()
+    p, R = traj(ts)
+    K = torch.tensor([[480.0, 0, 172.5], [0, 480.0, 129.5], [0, 0, 1]])
+    px = torch.from_numpy(np.stack([g.integers(0, 346, 300), g.integers(0, 260, 300)], -1).astype(np.float32))
+    o, d = nerf_mod.NeRF.pixel_params_to_ray(torch.linalg.inv(K), px, p, R)
+    wd = torch.from_numpy(g.standard_normal((300, 3)).astype(np.float32))
+    wp = torch.from_numpy(g.standard_normal((300, 3)).astype(np.float32))
+    (dts,) = torch.autograd.grad((d * wd).sum() + (o * wp).sum(), ts)
+    save("trajectory", tab_ts=ts_tab, tab_pos=pos, tab_quat=quat, ts=ts, p=p, R=R, Kinv=torch.linalg.inv(K),
+         px=px, o=o, d=d, wd=wd, wp=wp, dts=dts)
+    return ts_tab, pos, quat, K
+
+
+def gen_training_step(mods, with_grad_loss: bool):
+    """The reference's real RobustENeRF.training_step over the oracle-backed stubs."""
+    rmod, nerf_mod, trajectories, egp, loss_mod, nerfacc = mods
+    JITTER_LOG.clear()
+    torch.manual_seed(50 + int(with_grad_loss))
+    ts_tab, pos, quat = orbit_poses()
+    K = np.array([[480.0, 0, 172.5], [0, 480.0, 129.5], [0, 0, 1]], np.float32)
+    tmp = tempfile.mkdtemp()
+    np.savez(os.path.join(tmp, "camera_calibration.npz"), intrinsics=K,
+             pos_contrast_threshold=np.float32(0.3), neg_contrast_threshold=np.float32(0.25),
+             refractory_period=np.float32(0.0 if not with_grad_loss else 3.0e4), bayer_pattern="")
+    torch.save(torch.tensor(2.0e5, dtype=torch.float32), os.path.join(tmp, "max_refractory_period.pt"))
+
+    B, occ_res = 96, 32
+    m = rmod.RobustENeRF.__new__(rmod.RobustENeRF)
+    torch.nn.Module.__init__(m)
+    w_grad = 1.0e-3 if with_grad_loss else 0.0
+    m.hparams = EasyDict(
+        min_modeled_intensity=1e-3,
+        loss=dict(weight=dict(log_intensity_grad=w_grad, log_intensity_diff=1.0, nerf_mlp_weight_decay=1e-6),
+                  error_fn=dict(log_intensity_grad="mape", log_intensity_diff="mse"),
+                  param_weight=dict(log_intensity_grad=None, log_intensity_diff="mean_contrast_reciprocal_sq")),
+        contrast_threshold=dict(freeze=not with_grad_loss), refractory_period=dict(freeze=not with_grad_loss))
+    m.has_bayer_filter = False
+    m.register_buffer("train_intrinsics_inv", torch.linalg.inv(torch.from_numpy(K)), persistent=False)
+    m.render_bkgd = "parameter"
+    m.contrast_threshold = egp.ContrastThreshold(tmp)
+    m.refractory_period = egp.RefractoryPeriod(tmp)
+    occ_cfg = EasyDict(resolution=occ_res, occ_thre=1e-2, ema_decay=0.95, warmup_steps=256, n=16)
+    step = 3 ** 0.5 * 3.0 / 1024
+    m.nerf = nerf_mod.NeRF([-1.5] * 3 + [1.5] * 3, nerfacc.ContractionType.AABB, occ_cfg, None, None, step,
+                           "parameter", 0.0, 1e-4, 0.0, 16384, "ngp", EasyDict(NGP_CFG), 3, 1)
+    m.nerf.occupancy_grid._binary = ball_binary(occ_res)
+    cam = EasyDict(camera_poses=EasyDict(
+        T_wc_position=torch.from_numpy(pos), T_wc_orientation=torch.from_numpy(quat),
+        T_wc_timestamp=torch.from_numpy(ts_tab)))
+    m.trajectory = trajectories.LinearTrajectory(cam)
+    m.loss = loss_mod.Loss(m.hparams.loss.weight, m.hparams.loss.error_fn)
+    m.train_ray_sample_batch_size = 1 << 14
+    ns = types.SimpleNamespace
+    m.trainer = ns(accumulate_grad_batches=1,
+                   datamodule=ns(train_dataset=ns(batch_size=B), train_normalized_sampler=ns(datasets=[])))
+    m.global_step = 1                                      # not a multiple of n=16: no grid refresh
+    logged = {}
+    m.log = lambda k, v, **kw: logged.__setitem__(k, float(v))
+    m.all_gather = lambda t: t.unsqueeze(0)
+    m.train()
+
+    px, start, end, npos, nneg = make_events(B, int(ts_tab[-1]))
+    g = np.random.default_rng(51)
+    u1 = np.ones(B) if not with_grad_loss else g.uniform(0.3, 1.0, B)
+    u2, u3 = g.uniform(0, 1, B), g.uniform(0, 1, B)
+    batch = {"event": {"position": torch.from_numpy(px)[None], "start_ts": torch.from_numpy(start)[None],
+                       "end_ts": torch.from_numpy(end)[None], "num_pos": torch.from_numpy(npos)[None],
+                       "num_neg": torch.from_numpy(nneg)[None]},
+             "normalized": {"ts_diff": torch.from_numpy(u1)[None], "diff_start_ts": torch.from_numpy(u2)[None],
+                            "grad_ts": torch.from_numpy(u3)[None]}}
+    loss = m.training_step(batch, 0)
+    m.zero_grad()
+    loss.backward()
+    named = dict(m.named_parameters())
+    rf = m.nerf.radiance_field
+    gmap = {"base.w0": "mlp_base.1.hidden_layers.0.weight", "base.b0": "mlp_base.1.hidden_layers.0.bias",
+            "base.wo": "mlp_base.1.output_layer.weight", "base.bo": "mlp_base.1.output_layer.bias",
+            "head.w0": "mlp_head.hidden_layers.0.weight", "head.b0": "mlp_head.hidden_layers.0.bias",
+            "head.w1": "mlp_head.hidden_layers.1.weight", "head.b1": "mlp_head.hidden_layers.1.bias",
+            "head.wo": "mlp_head.output_layer.weight", "head.bo": "mlp_head.output_layer.bias"}
+    rfp = dict(rf.named_parameters())
+    grads = {"g." + k: rfp[v].grad for k, v in gmap.items()}
+    gt = rfp["mlp_base.0.params"].grad
+    nz = torch.nonzero(gt)[:, 0]
+    pick = nz[torch.linspace(0, len(nz) - 1, 256).long()]
+    extra = {}
+    if with_grad_loss:
+        extra = dict(
+            g_p2n_raw=named["contrast_threshold.parametrizations.p2n_contrast_threshold_ratio.original"].grad,
+            g_tau_raw=named["refractory_period.parametrizations._refractory_period.original"].grad)
+    save("training_step_grad" if with_grad_loss else "training_step_diff",
+         table_seed=TABLE_SEED, table_scale=TABLE_SCALE, occ_res=occ_res,
+         binary=np.packbits(m.nerf.occupancy_grid._binary.numpy().reshape(-1)),
+         tab_ts=ts_tab, tab_pos=pos, tab_quat=quat, Kinv=m.train_intrinsics_inv,
+         position=px, start_ts=start, end_ts=end, num_pos=npos, num_neg=nneg,
+         u_ts_diff=u1, u_diff_start=u2, u_grad=u3,
+         jitters=torch.stack(JITTER_LOG), render_step_size=step,
+         p2n_raw=named["contrast_threshold.parametrizations.p2n_contrast_threshold_ratio.original"],
+         neg_ct=m.contrast_threshold.neg_contrast_threshold,
+         tau_raw=named["refractory_period.parametrizations._refractory_period.original"],
+         tau_max=m.refractory_period.max_refractory_period,
+         bkgd_raw=named["nerf.parametrizations.render_bkgd.original"],
+         loss=loss, w_grad=w_grad,
+         logged_keys=np.array(sorted(logged)), logged_vals=np.array([logged[k] for k in sorted(logged)]),
+         g_bkgd_raw=named["nerf.parametrizations.render_bkgd.original"].grad,
+         g_table_sum=gt.double().sum(), g_table_abs=gt.double().abs().sum(), g_table_idx=pick,
+         g_table_val=gt[pick], **field_params_np(rf), **grads, **extra)
+
+
+def gen_events(egp, loss_mod):
+    """ContrastThreshold / RefractoryPeriod / Loss on their own (incl. l1 + mape)."""
+    tmp = tempfile.mkdtemp()
+    np.savez(os.path.join(tmp, "camera_calibration.npz"),
+             pos_contrast_threshold=np.float32(0.31), neg_contrast_threshold=np.float32(0.22),
+             refractory_period=np.float32(1.0e4), bayer_pattern="")
+    torch.save(torch.tensor(5.0e4, dtype=torch.float32), os.path.join(tmp, "max_refractory_period.pt"))
+    ct, rp = egp.ContrastThreshold(tmp), egp.RefractoryPeriod(tmp)
+    g = np.random.default_rng(60)
+    B = 200
+    _, start, end, npos, nneg = make_events(B, 200_000_000, seed=61)
+    ev = EasyDict(start_ts=torch.from_numpy(start), end_ts=torch.from_numpy(end),
+                  num_pos=torch.from_numpy(npos), num_neg=torch.from_numpy(nneg))
+    ev = rp(ct(ev))
+    pred_diff = torch.from_numpy(g.standard_normal(B).astype(np.float32)) * 0.3
+    pred_grad = torch.from_numpy(g.standard_normal(B)) * 1e-8
+    ts_diff = (ev.end_ts - ev.start_ts) * torch.from_numpy(g.uniform(0.2, 1, B))
+    valid = torch.from_numpy(g.random(B) < 0.8)
+    out = {}
+    for fn in ("l1", "mse", "mape"):
+        L = loss_mod.Loss(EasyDict(log_intensity_grad=1.0, log_intensity_diff=1.0),
+                          EasyDict(log_intensity_grad=fn, log_intensity_diff=fn))
+        r = L.compute(EasyDict(ev), EasyDict(log_intensity_grad=pred_grad, is_valid=valid),
+                      EasyDict(log_intensity_diff=pred_diff, ts_diff=ts_diff, is_valid=valid))
+        out[f"loss_diff_{fn}"], out[f"loss_grad_{fn}"] = r.log_intensity_diff, r.log_intensity_grad
+    named = dict(list(ct.named_parameters()) + list(rp.named_parameters()))
+    save("events", start_ts=start, end_ts=end, num_pos=npos, num_neg=nneg,
+         p2n_raw=named["parametrizations.p2n_contrast_threshold_ratio.original"], neg_ct=ct.neg_contrast_threshold,
+         tau_raw=named["parametrizations._refractory_period.original"], tau_max=rp.max_refractory_period,
+         c_p=ct.pos_contrast_threshold, mean_c=ct.mean_contrast_threshold, tau=rp.refractory_period,
+         ev_log_diff=ev.log_intensity_diff, ev_start_ts=ev.start_ts,
+         pred_diff=pred_diff, pred_grad=pred_grad, ts_diff=ts_diff, valid=valid, **out)
+
+
+def main():
+    assert os.path.isdir(REF), "golden vectors can only be regenerated where /root/reference exists"
+    install_stubs()
+    import nerfacc
+    from robust_e_nerf.external import ngp, sh_encoder, vol_rendering
+    from robust_e_nerf.loss_metric import loss as loss_mod
+    from robust_e_nerf.models import event_generation_params as egp
+    from robust_e_nerf.models import nerf as nerf_mod
+    from robust_e_nerf.models import robust_e_nerf as rmod
+    from robust_e_nerf.models import trajectories
+
+    gen_sh(sh_encoder)
+    gen_rendering(vol_rendering)
+    gen_trajectory(trajectories, nerf_mod)
+    gen_events(egp, loss_mod)
+    gen_field(ngp, nerfacc)
+    mods = (rmod, nerf_mod, trajectories, egp, loss_mod, nerfacc)
+    gen_training_step(mods, with_grad_loss=False)
+    gen_training_step(mods, with_grad_loss=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,112 @@
+"""CPU: the oracle against golden vectors produced by the reference's own Python
+(tests/golden/make_golden.py).  This is what PINS the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import FIELD_KEYS, field_params_from, load_golden, rel_err, t
+from oracle import events, field, hashgrid, render, step, trajectory
+
+SPEC = hashgrid.make_spec()
+
+
+def test_level_table_matches_survey():
+    assert SPEC.resolutions == (16, 24, 34, 49, 71, 102, 148, 213, 308, 446, 646, 934, 1352, 1956, 2831, 4096)
+    assert SPEC.sizes[:5] == (4096, 13824, 39304, 117656, 357912) and all(s == 524288 for s in SPEC.sizes[5:])
+    assert SPEC.hashed == (False,) * 5 + (True,) * 11
+    assert SPEC.n_params == 12_599_920
+
+
+def test_sh4():
+    g = load_golden("sh4")
+    assert rel_err(field.sh_encode(t(g["d"]), 4), g["out"]) < 1e-6
+
+
+def test_rendering_glue():
+    g = load_golden("rendering")
+    c, o, z = render.rendering(t(g["t_starts"]), t(g["t_ends"]), t(g["ray_indices"]), int(g["n_rays"]),
+                               lambda a, b, i: (t(g["rgb"]), t(g["sigma"])), render_bkgd=t(g["bkgd"]))
+    assert rel_err(c, g["colors"]) < 1e-6 and rel_err(o, g["opacities"]) < 1e-6 and rel_err(z, g["depths"]) < 1e-6
+
+
+def test_trajectory_and_raygen():
+    g = load_golden("trajectory")
+    ts = t(g["ts"]).requires_grad_()
+    p, R = trajectory.linear_trajectory(ts, t(g["tab_ts"]), t(g["tab_pos"]), t(g["tab_quat"]))
+    assert rel_err(p, g["p"]) < 1e-6 and rel_err(R, g["R"]) < 1e-6
+    o, d = trajectory.pixel_params_to_ray(t(g["Kinv"]), t(g["px"]), p, R)
+    assert rel_err(o, g["o"]) < 1e-6 and rel_err(d, g["d"]) < 1e-6
+    (dts,) = torch.autograd.grad((d * t(g["wd"])).sum() + (o * t(g["wp"])).sum(), ts)
+    assert dts.dtype == torch.float64 and rel_err(dts, g["dts"]) < 1e-5
+
+
+def test_event_params_and_loss():
+    g = load_golden("events")
+    c_p, c_n, mean_c = events.contrast_thresholds(t(g["p2n_raw"]), t(g["neg_ct"]))
+    assert rel_err(c_p, g["c_p"]) < 1e-6 and rel_err(mean_c, g["mean_c"]) < 1e-6
+    tau_raw = events.clamp_tau_raw(t(g["tau_raw"]), t(g["tau_max"]))
+    tau = events.refractory_period(tau_raw, t(g["tau_max"]))
+    assert tau.dtype == torch.float64 and rel_err(tau, g["tau"]) < 1e-12
+    ev = events.event_log_intensity_diff(t(g["num_pos"]), t(g["num_neg"]), c_p, c_n)
+    assert ev.dtype == torch.float32 and rel_err(ev, g["ev_log_diff"]) < 1e-6
+    start = t(g["start_ts"]) + tau
+    assert rel_err(start, g["ev_start_ts"]) < 1e-15
+    valid = t(g["valid"])
+    for fn in ("l1", "mse", "mape"):
+        _, terms = events.event_loss(
+            ev, start, t(g["end_ts"]), pred_log_diff=t(g["pred_diff"]), ts_diff=t(g["ts_diff"]),
+            diff_valid=valid, pred_log_grad=t(g["pred_grad"]), grad_valid=valid,
+            err_diff=fn, err_grad=fn, w_diff=1.0, w_grad=1.0, pw_diff=None, pw_grad=None, mean_c=mean_c)
+        assert rel_err(terms["log_intensity_diff"], g[f"loss_diff_{fn}"]) < 1e-6
+        assert rel_err(terms["log_intensity_grad"], g[f"loss_grad_{fn}"]) < 1e-10
+
+
+@pytest.mark.parametrize("ct", ["aabb", "sphere", "tanh"])
+def test_field_forward_backward(ct, full_table_cache):
+    g = load_golden(f"field_{ct}")
+    table = full_table_cache(g["table_seed"], g["table_scale"]).clone().requires_grad_()
+    p = field_params_from(g, table)
+    for k in FIELD_KEYS:
+        p[k].requires_grad_()
+    rgb, sigma = field.field_forward(t(g["x"]), t(g["d"]), p, SPEC, t(g["aabb"]), int(g["contraction_type"]))
+    assert rel_err(rgb, g["rgb"]) < 1e-5 and rel_err(sigma, g["sigma"]) < 1e-5
+    ((rgb * t(g["g_rgb"])).sum() + (sigma * t(g["g_sigma"])).sum()).backward()
+    for k in FIELD_KEYS:
+        assert rel_err(p[k].grad, g["g." + k]) < 1e-4, k
+    assert rel_err(table.grad[t(g["g_table_idx"])], g["g_table_val"]) < 1e-4
+    assert abs(float(table.grad.double().abs().sum()) - float(g["g_table_abs"])) < 1e-4 * float(g["g_table_abs"])
+
+
+def _run_training_step(g, table, with_grad):
+    p = field_params_from(g, table)
+    for v in p.values():
+        v.requires_grad_()
+    occ_res = int(g["occ_res"])
+    binary = t(np.unpackbits(g["binary"])[: occ_res ** 3].astype(bool)).view(occ_res, occ_res, occ_res)
+    cfg = step.SceneCfg(occ_res=(occ_res,) * 3, render_step_size=float(g["render_step_size"]), sampler="occgrid")
+    batch = step.EventBatch(t(g["position"]), t(g["start_ts"]), t(g["end_ts"]), t(g["num_pos"]), t(g["num_neg"]),
+                            t(g["u_ts_diff"]), t(g["u_diff_start"]), t(g["u_grad"]))
+    bkgd_raw = t(g["bkgd_raw"]).requires_grad_()
+    jit = t(g["jitters"])
+    loss, aux = step.training_forward(
+        batch, p, SPEC, cfg, Kinv=t(g["Kinv"]), tab_ts=t(g["tab_ts"]), tab_pos=t(g["tab_pos"]),
+        tab_quat=t(g["tab_quat"]), p2n_raw=t(g["p2n_raw"]), neg_ct=t(g["neg_ct"]), tau_raw=t(g["tau_raw"]),
+        tau_max=t(g["tau_max"]), bkgd_raw=bkgd_raw, binary=binary,
+        jitter_start=jit[-2], jitter_end=jit[-1])
+    return loss, aux, p, bkgd_raw
+
+
+def test_training_step_diff(full_table_cache):
+    """The reference's real training_step (l_diff only) vs the oracle's composition."""
+    g = load_golden("training_step_diff")
+    table = full_table_cache(g["table_seed"], g["table_scale"]).clone()
+    loss, aux, p, bkgd_raw = _run_training_step(g, table, False)
+    assert rel_err(loss, g["loss"]) < 1e-5
+    logged = dict(zip(g["logged_keys"].tolist(), g["logged_vals"].tolist()))
+    mean_s = (aux["n_start"] + aux["n_end"]) / 2 / len(g["start_ts"])
+    assert abs(mean_s - logged["train/mean_num_samples_per_ray"]) < 1e-3
+    loss.backward()
+    for k in FIELD_KEYS:
+        assert rel_err(p[k].grad, g["g." + k]) < 2e-4, k
+    assert rel_err(bkgd_raw.grad, g["g_bkgd_raw"]) < 1e-4
+    assert rel_err(p["hash"].grad[t(g["g_table_idx"])], g["g_table_val"]) < 2e-4
