@@ -1,0 +1,240 @@
+/* ren_amd.h -- C ABI of the MI355X-native (gfx950) Robust e-NeRF volume-rendering path.
+ *
+ * One shared object (robust_e_nerf_amd/csrc/libren_amd.so, built by
+ * `hipcc --offload-arch=gfx950 -shared -fPIC`), `extern "C"` only, POD arguments.
+ *
+ * Conventions:
+ *  - every `*_d` / unnamed array pointer is a DEVICE pointer owned by the caller
+ *    (PyTorch-ROCm allocations); pointers documented "host" are read on the host
+ *    before the launch (small descriptors: aabb, level table, scalars);
+ *  - the library never allocates, frees or synchronises; kernels are enqueued on the
+ *    `stream` argument (a hipStream_t passed as void*, 0 = default stream) and outputs
+ *    are valid in stream order;
+ *  - return value: REN_OK (0) or a negative ren_status; nothing throws across the ABI;
+ *  - no mutable global state: the library is re-entrant, one process per GPU.
+ *
+ * Each entry point cites the reference interface (file:line under the reference repo)
+ * it replaces.  Third-party ops the reference imports (nerfacc 0.3.1, tinycudann,
+ * roma 1.2.7) are cited through their reference call sites.
+ */
+#ifndef REN_AMD_H
+#define REN_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum ren_status {
+    REN_OK = 0,
+    REN_ERR_BAD_ARG = -1,      /* null pointer / negative size / bad enum            */
+    REN_ERR_UNSUPPORTED = -2,  /* configuration outside what the kernels implement   */
+    REN_ERR_LAUNCH = -3        /* hipGetLastError() != hipSuccess after the launch   */
+} ren_status;
+
+/* nerfacc.ContractionType (robust_e_nerf/models/robust_e_nerf.py:214-218) */
+enum { REN_CT_AABB = 0, REN_CT_TANH = 1, REN_CT_SPHERE = 2 };
+
+#define REN_MAX_LEVELS 16
+
+/* Multi-resolution hash grid level table (tcnn HashGrid; robust_e_nerf/external/ngp.py:166-170,
+ * configs/train/synthetic.yaml:62-69).  Host struct, passed by pointer, copied into the
+ * kernel arguments.  n_features_per_level is fixed at 2. */
+typedef struct ren_grid_desc {
+    int32_t  n_levels;                 /* <= REN_MAX_LEVELS; fused MLP kernels need 16     */
+    float    scale[REN_MAX_LEVELS];    /* exp2f(l*log2f(b))*N_min - 1                      */
+    uint32_t res[REN_MAX_LEVELS];      /* ceilf(scale)+1                                   */
+    uint32_t size[REN_MAX_LEVELS];     /* entries in the level                             */
+    uint32_t offset[REN_MAX_LEVELS];   /* first entry of the level                         */
+    uint32_t hashed[REN_MAX_LEVELS];   /* 1 = spatial hash, 0 = dense index                */
+} ren_grid_desc;
+
+/* Scene / field geometry shared by the field kernels.  Host struct. */
+typedef struct ren_scene_desc {
+    float   aabb[6];                   /* NGPradianceField.aabb (ngp.py:152)               */
+    int32_t contraction_type;          /* REN_CT_*  (ngp.py:231-237)                       */
+} ren_scene_desc;
+
+/* Packed sample stream (nerfacc packed layout; external/utils.py:106-119):
+ *   ray_indices[n] int32, t_starts[n], t_ends[n] float32, sorted by ray.
+ * rays_o / rays_d are (n_rays,3) float32.  Sample position = o + d*(t0+t1)/2
+ * (external/utils.py:68-72). */
+
+/* ---- library info ------------------------------------------------------------------ */
+int ren_abi_version(void);                       /* bumps when a signature changes      */
+const char *ren_build_info(void);                /* "gfx950 ..."                        */
+
+/* ---- pose interpolation + ray generation ------------------------------------------
+ * Replaces LinearTrajectory.forward (robust_e_nerf/models/trajectories.py:30-91, with
+ * utils/tensor_ops.py:83-180 and roma 1.2.7) and NeRF.pixel_params_to_ray
+ * (robust_e_nerf/models/nerf.py:206-228).
+ * ts[B] float64 ns; tab_ts[C] int64; tab_pos[C,3], tab_quat[C,4] (XYZW) float32.
+ * Outputs (any may be NULL): pos[B,3], rot[B,9] row-major. */
+int ren_trajectory_fwd(const double *ts, int64_t B, const int64_t *tab_ts, const float *tab_pos,
+                       const float *tab_quat, int64_t C, float *pos, float *rot, void *stream);
+/* Kinv[9] device, px[B,2], pos[B,3], rot[B,9] -> rays_o[B,3], rays_d[B,3] */
+int ren_raygen_fwd(const float *Kinv, const float *px, const float *pos, const float *rot,
+                   int64_t B, float *rays_o, float *rays_d, void *stream);
+
+/* ---- sampling ---------------------------------------------------------------------
+ * nerfacc.ray_marching as called at robust_e_nerf/external/utils.py:106-119. */
+/* ray_aabb_intersect: aabb host[6]; miss => t_min=t_max=1e10; t_min clamped >= 0.
+ * near/far: pass NaN for "None" (external/utils.py:112-113).                          */
+int ren_ray_aabb_intersect(const float *rays_o, const float *rays_d, int64_t n_rays,
+                           const float *aabb_host, float near_plane, float far_plane,
+                           float *t_min, float *t_max, void *stream);
+/* Two-pass marching.  mode 0: occupancy-grid marching (reference semantics), mode 1:
+ * uniform comb of n_uniform intervals over [t_min,t_max) (fixed-S sampler).
+ * jitter[n_rays] (may be NULL): mode 0 -> t_min += u*step (stratified);
+ *                               mode 1 -> comb shifted by u*delta.
+ * binary: uint8/bool grid (res[0]*res[1]*res[2]), x-major.  roi host[6], res host[3].
+ * Pass 1 (t_starts==NULL): writes counts[n_rays].  Pass 2: offsets[n_rays] (int64,
+ * exclusive cumsum of counts) given, writes ray_indices/t_starts/t_ends. */
+int ren_ray_march(const float *rays_o, const float *rays_d, const float *t_min,
+                  const float *t_max, const float *jitter, int64_t n_rays,
+                  const float *roi_host, const int32_t *res_host, const uint8_t *binary,
+                  int32_t contraction_type, float step_size, float cone_angle,
+                  int32_t mode, int32_t n_uniform,
+                  const int64_t *offsets, int32_t *counts,
+                  int32_t *ray_indices, float *t_starts, float *t_ends, void *stream);
+/* exclusive cumsum of counts[n] (int32) -> offsets[n] (int64), total[1] (int64) */
+int ren_exclusive_scan(const int32_t *counts, int64_t n, int64_t *offsets, int64_t *total,
+                       void *stream);
+/* nerfacc.render_visibility inside ray_marching (sigma_fn branch): per ray
+ * T = excl. cumprod(1-alpha); keep = T >= early_stop_eps (& alpha >= alpha_thre if >0).
+ * Writes keep[n] (uint8) and kept_counts[n_rays]. */
+int ren_visibility(const int64_t *offsets, const int32_t *counts, int64_t n_rays,
+                   const float *sigmas, const float *t_starts, const float *t_ends,
+                   float early_stop_eps, float alpha_thre, uint8_t *keep, int32_t *kept_counts,
+                   void *stream);
+/* stream compaction of the packed sample arrays by keep[] using new_offsets (exclusive
+ * cumsum of kept_counts) */
+int ren_compact_samples(const int64_t *offsets, const int32_t *counts, const int64_t *new_offsets,
+                        int64_t n_rays, const uint8_t *keep, const float *t_starts,
+                        const float *t_ends, int32_t *out_ray_indices, float *out_t_starts,
+                        float *out_t_ends, void *stream);
+/* (offsets, counts) from sorted ray_indices[n] (nerfacc unpack_info inverse) */
+int ren_pack_info(const int32_t *ray_indices, int64_t n, int64_t n_rays, int64_t *offsets,
+                  int32_t *counts, void *stream);
+
+/* ---- multi-resolution hash grid ------------------------------------------------------
+ * tcnn.Encoding HashGrid/Linear (robust_e_nerf/external/ngp.py:166-170,240).
+ * Input either x_unit[n,3] (unit-cube positions; seam API) or, when x_unit==NULL, the
+ * packed sample stream (positions formed and contracted in-kernel, ngp.py:231-237).
+ * layout 0: feat[n, 2L] row-major (tcnn output);  layout 1: MFMA fragment order
+ *   feat[((i>>5)*16 + l)*64 + f*32 + (i&31)]  (i sample, l level, f feature), n padded to 32. */
+int ren_hashgrid_fwd(const ren_grid_desc *grid, const float *table, const float *x_unit,
+                     const ren_scene_desc *scene, const float *rays_o, const float *rays_d,
+                     const int32_t *ray_indices, const float *t_starts, const float *t_ends,
+                     int64_t n, int32_t layout, float *feat, void *stream);
+/* d(table) += scatter of dfeat (same layouts); atomics, non-deterministic order */
+int ren_hashgrid_bwd(const ren_grid_desc *grid, float *grad_table, const float *x_unit,
+                     const ren_scene_desc *scene, const float *rays_o, const float *rays_d,
+                     const int32_t *ray_indices, const float *t_starts, const float *t_ends,
+                     int64_t n, int32_t layout, const float *dfeat, void *stream);
+
+/* ---- fused NGP MLPs --------------------------------------------------------------------
+ * NGPradianceField.query_density / _query_rgb / forward (robust_e_nerf/external/ngp.py:230-280)
+ * with MLP.forward (external/mlp.py:99-113), SHEncoder degree 4 (external/sh_encoder.py:28-93),
+ * Softplus(beta=100) hidden, shifted_trunc_exp density, Softplus(beta=1) radiance
+ * (models/nerf.py:17-29; configs/train/synthetic.yaml:72-84).
+ * mlp_params: one device array of float32 in torch nn.Linear layout, concatenated:
+ *   base.w0[64,32] base.b0[64] base.wo[16,64] base.bo[16]
+ *   head.w0[64,31] head.b0[64] head.w1[64,64] head.b1[64] head.wo[C,64] head.bo[C]
+ * feat: fragment layout (layout 1 above).  Per-sample geometry (selector ngp.py:238, view
+ * direction) comes either from x_world[n,3] (+ dirs[n,3], may be NULL when density_only) -- the
+ * field(x, dirs) seam -- or, when x_world==NULL, from the packed sample stream.
+ * density_only!=0: only sigma is produced (sigma_fn pre-pass, external/utils.py:68-81;
+ * occ_eval_fn, models/nerf.py:197-198).
+ * base_out (may be NULL): raw base-MLP outputs, fragment layout [((i>>5)*8+g)*64+lane]
+ * (ceil(n/32)*512 floats), saved for the backward pass. */
+int ren_mlp_fwd(const float *mlp_params, int32_t radiance_dim, const float *feat,
+                const ren_scene_desc *scene, const float *x_world, const float *dirs,
+                const float *rays_o, const float *rays_d, const int32_t *ray_indices,
+                const float *t_starts, const float *t_ends, int64_t n, int32_t density_only,
+                float *rgb, float *sigma, float *base_out, void *stream);
+/* floats of device scratch ren_mlp_bwd needs for the per-wave weight-gradient slabs */
+int64_t ren_mlp_bwd_workspace_floats(int32_t radiance_dim);
+/* backward of ren_mlp_fwd: d_rgb[n,C], d_sigma[n] -> dfeat (fragment layout, ceil(n/32)*1024
+ * floats) and grad_mlp_params (+=, same concatenated layout).  rgb = forward output;
+ * d_base: scratch of ceil(n/32)*512 floats (gradient w.r.t. base_out, fragment layout);
+ * workspace: ren_mlp_bwd_workspace_floats() floats.  Deterministic (no atomics). */
+int ren_mlp_bwd(const float *mlp_params, int32_t radiance_dim, const float *feat,
+                const float *base_out, const ren_scene_desc *scene,
+                const float *x_world, const float *dirs,
+                const float *rays_o, const float *rays_d, const int32_t *ray_indices,
+                const float *t_starts, const float *t_ends, int64_t n,
+                const float *rgb, const float *d_rgb, const float *d_sigma,
+                float *d_base, float *dfeat, float *grad_mlp_params, float *workspace, void *stream);
+
+/* ---- volume rendering (packed) ----------------------------------------------------------
+ * rendering() (robust_e_nerf/external/vol_rendering.py:16-128): nerfacc
+ * render_weight_from_density + 3x accumulate_along_rays + background compose.
+ * Outputs colors[n_rays,C], opacities[n_rays], depths[n_rays] (un-normalised, :111-126);
+ * weights[n] and trans[n] (may be NULL) are saved for the backward pass / seam API.
+ * bkgd[C] device (NULL = no background). */
+int ren_composite_fwd(const int64_t *offsets, const int32_t *counts, int64_t n_rays,
+                      const float *t_starts, const float *t_ends, const float *sigmas,
+                      const float *rgbs, int32_t C, const float *bkgd,
+                      float *colors, float *opacities, float *depths,
+                      float *weights, float *trans, void *stream);
+/* backward: g_colors[n_rays,C], g_opac[n_rays] (NULL=0), g_depth[n_rays] (NULL=0)
+ * -> d_sigmas[n], d_rgbs[n,C], d_bkgd_per_ray[n_rays,C] (NULL ok). */
+int ren_composite_bwd(const int64_t *offsets, const int32_t *counts, int64_t n_rays,
+                      const float *t_starts, const float *t_ends, const float *sigmas,
+                      const float *rgbs, int32_t C, const float *bkgd,
+                      const float *weights, const float *trans, const float *opacities,
+                      const float *g_colors, const float *g_opac, const float *g_depth,
+                      float *d_sigmas, float *d_rgbs, float *d_bkgd_per_ray, void *stream);
+
+/* ---- event loss ------------------------------------------------------------------------------
+ * ContrastThreshold.forward (models/event_generation_params.py:72-84), Loss.log_intensity_diff
+ * (loss_metric/loss.py:32-74) and the 1/C^k normalisation + weighting of
+ * RobustENeRF.training_step (models/robust_e_nerf.py:432-443,470-486), fused with its own
+ * backward.  Inputs per event i: intensity_start/end[B] (render + min_modeled_intensity,
+ * :867), target[B] (= ts_diff * ev_log_diff/(end-start), float32), valid[B] (uint8, NULL =
+ * all valid).  err_fn: 0 l1, 1 mse, 2 mape.
+ * fwd: loss_sum[2] (device) = {sum of errors over valid events, number of valid events}; the
+ *      mean loss is loss_sum[0]/loss_sum[1] (an empty mask gives 0/0 = NaN like the reference).
+ * bwd: g_start[B], g_end[B] = d(scale * mean error)/d(intensity); reads the count from
+ *      loss_sum[1] on the device (no host sync); scale = param weight * loss weight. */
+int ren_event_loss_fwd(const float *intensity_start, const float *intensity_end, const float *target,
+                       const uint8_t *valid, int64_t B, int32_t err_fn, float *loss_sum, void *stream);
+int ren_event_loss_bwd(const float *intensity_start, const float *intensity_end, const float *target,
+                       const uint8_t *valid, int64_t B, int32_t err_fn, float scale,
+                       const float *loss_sum, float *g_start, float *g_end, void *stream);
+
+/* ---- optimiser ----------------------------------------------------------------------------------
+ * torch.optim.Adam step as configured by RobustENeRF.configure_optimizers
+ * (models/robust_e_nerf.py:782-813): L2-style weight decay (grad += wd*p), bias correction.
+ * grad_scale multiplies the gradient first (1/world_size after an all-reduce SUM).
+ * zero_grad != 0: the gradient buffer is cleared in the same pass. */
+int ren_adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
+                  float lr, float beta1, float beta2, float eps, float weight_decay,
+                  int64_t step, float grad_scale, int32_t zero_grad, void *stream);
+
+/* ---- occupancy grid -------------------------------------------------------------------------------
+ * nerfacc.OccupancyGrid._update as driven by NeRF.update_occ_grid (models/nerf.py:170-204). */
+/* cell indices[m] (int64) + jitter[m,3] -> world positions x[m,3] (contract_inv) and
+ * valid[m] (sphere contraction drops |x-0.5| >= 0.5).  roi host[6], res host[3]. */
+int ren_occgrid_cell_points(const int64_t *indices, const float *jitter, int64_t m,
+                            const float *roi_host, const int32_t *res_host,
+                            int32_t contraction_type, float *x_world, uint8_t *valid, void *stream);
+/* occs[idx] = max(occs[idx]*decay, sigma*step) for valid cells (models/nerf.py:197-198).
+ * step_sizes[m] may be NULL (then `step_size` is used; cone_angle == 0). */
+int ren_occgrid_ema(float *occs, const int64_t *indices, const uint8_t *valid, const float *sigma,
+                    const float *step_sizes, float step_size, int64_t m, float ema_decay,
+                    void *stream);
+/* binary = occs > min(mean(occs), occ_thre);  scratch[2] device floats. */
+int ren_occgrid_binarize(const float *occs, int64_t cells, float occ_thre, uint8_t *binary,
+                         float *scratch, void *stream);
+
+/* ---- utilities ------------------------------------------------------------------------------------- */
+/* out[c] = sum_r in[r*C + c]   (C <= 4) */
+int ren_column_sum(const float *in, int64_t rows, int32_t C, float *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REN_AMD_H */

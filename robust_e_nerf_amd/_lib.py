@@ -1,0 +1,97 @@
+"""ctypes binding of the C-ABI HIP library (include/ren_amd.h).
+
+The product path fails loudly when ``csrc/libren_amd.so`` is missing or a symbol is absent:
+there is NO CPU fallback and the oracle is never imported from here.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint32, c_void_p
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libren_amd.so")
+MAX_LEVELS = 16
+
+REN_OK, REN_ERR_BAD_ARG, REN_ERR_UNSUPPORTED, REN_ERR_LAUNCH = 0, -1, -2, -3
+
+
+class RenError(RuntimeError):
+    pass
+
+
+class GridDesc(Structure):
+    _fields_ = [("n_levels", c_int32), ("scale", c_float * MAX_LEVELS), ("res", c_uint32 * MAX_LEVELS),
+                ("size", c_uint32 * MAX_LEVELS), ("offset", c_uint32 * MAX_LEVELS),
+                ("hashed", c_uint32 * MAX_LEVELS)]
+
+
+class SceneDesc(Structure):
+    _fields_ = [("aabb", c_float * 6), ("contraction_type", c_int32)]
+
+
+P = c_void_p
+# name -> (restype, argtypes); mirrors include/ren_amd.h one to one
+SIGNATURES = {
+    "ren_abi_version": (c_int, []),
+    "ren_build_info": (c_char_p, []),
+    "ren_trajectory_fwd": (c_int, [P, c_int64, P, P, P, c_int64, P, P, P]),
+    "ren_raygen_fwd": (c_int, [P, P, P, P, c_int64, P, P, P]),
+    "ren_ray_aabb_intersect": (c_int, [P, P, c_int64, POINTER(c_float), c_float, c_float, P, P, P]),
+    "ren_ray_march": (c_int, [P, P, P, P, P, c_int64, POINTER(c_float), POINTER(c_int32), P, c_int32,
+                              c_float, c_float, c_int32, c_int32, P, P, P, P, P, P]),
+    "ren_exclusive_scan": (c_int, [P, c_int64, P, P, P]),
+    "ren_visibility": (c_int, [P, P, c_int64, P, P, P, c_float, c_float, P, P, P]),
+    "ren_compact_samples": (c_int, [P, P, P, c_int64, P, P, P, P, P, P, P]),
+    "ren_pack_info": (c_int, [P, c_int64, c_int64, P, P, P]),
+    "ren_hashgrid_fwd": (c_int, [POINTER(GridDesc), P, P, POINTER(SceneDesc), P, P, P, P, P, c_int64, c_int32, P, P]),
+    "ren_hashgrid_bwd": (c_int, [POINTER(GridDesc), P, P, POINTER(SceneDesc), P, P, P, P, P, c_int64, c_int32, P, P]),
+    "ren_mlp_fwd": (c_int, [P, c_int32, P, POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, c_int32, P, P, P, P]),
+    "ren_mlp_bwd_workspace_floats": (c_int64, [c_int32]),
+    "ren_mlp_bwd": (c_int, [P, c_int32, P, P, POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, P, P, P, P, P, P, P, P]),
+    "ren_composite_fwd": (c_int, [P, P, c_int64, P, P, P, P, c_int32, P, P, P, P, P, P, P]),
+    "ren_composite_bwd": (c_int, [P, P, c_int64, P, P, P, P, c_int32, P, P, P, P, P, P, P, P, P, P, P]),
+    "ren_event_loss_fwd": (c_int, [P, P, P, P, c_int64, c_int32, P, P]),
+    "ren_event_loss_bwd": (c_int, [P, P, P, P, c_int64, c_int32, c_float, P, P, P, P]),
+    "ren_adam_step": (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int64,
+                              c_float, c_int32, P]),
+    "ren_occgrid_cell_points": (c_int, [P, P, c_int64, POINTER(c_float), POINTER(c_int32), c_int32, P, P, P]),
+    "ren_occgrid_ema": (c_int, [P, P, P, P, P, c_float, c_int64, c_float, P]),
+    "ren_occgrid_binarize": (c_int, [P, c_int64, c_float, P, P, P]),
+    "ren_column_sum": (c_int, [P, c_int64, c_int32, P, P]),
+}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load libren_amd.so, bind every symbol of include/ren_amd.h, fail loudly otherwise."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RenError(
+            f"{LIB_PATH} is missing: build it with `python -m robust_e_nerf_amd.build` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise RenError(f"{LIB_PATH} does not export {name}; rebuild the library") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+_ERR = {REN_ERR_BAD_ARG: (ValueError, "bad argument"),
+        REN_ERR_UNSUPPORTED: (NotImplementedError, "unsupported configuration"),
+        REN_ERR_LAUNCH: (RenError, "HIP launch failed")}
+
+
+def check(rc: int, what: str):
+    """Map C error codes to the Python exception types the reference raises."""
+    if rc != REN_OK:
+        exc, msg = _ERR.get(rc, (RenError, f"error {rc}"))
+        raise exc(f"{what}: {msg} (ren_status {rc})")

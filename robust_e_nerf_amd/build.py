@@ -1,0 +1,46 @@
+"""Build the C-ABI HIP library in-tree: robust_e_nerf_amd/csrc/libren_amd.so (gfx950 only)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(CSRC, "libren_amd.so")
+SOURCES = ["ren_api.hip", "ren_pose.hip", "ren_sampling.hip", "ren_composite.hip", "ren_train.hip",
+           "ren_hashgrid.hip", "ren_mlp.hip"]
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
+          "-Wno-unused-result"]
+# the sampler must match the sequential oracle bit for bit: no FMA contraction there
+PER_FILE = {"ren_sampling.hip": ["-ffp-contract=off"]}
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    hipcc = os.environ.get("HIPCC", "hipcc")
+    headers = [os.path.join(CSRC, "ren_common.h"), os.path.join(HERE, "..", "include", "ren_amd.h")]
+    objs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        if force or _stale(o, [s] + headers):
+            cmd = [hipcc] + COMMON + PER_FILE.get(src, []) + ["-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        objs.append(o)
+    if force or _stale(OUT, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", OUT]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,193 @@
+// Packed alpha compositing, forward and backward: one 64-lane wavefront per ray, wave-level
+// exclusive prefix scan of sigma*dt for the transmittance (forward) and a reverse suffix scan of
+// w*v (backward).  Replaces nerfacc render_weight_from_density + 3x accumulate_along_rays +
+// background compose as composed by rendering(), robust_e_nerf/external/vol_rendering.py:16-128.
+//
+// HBM traffic per sample: fwd reads t0,t1,sigma,rgb (12+4C B) and writes w,T (8 B);
+// bwd reads those plus w,T and writes d_sigma,d_rgb.  Strictly coalesced: the samples of a ray
+// are contiguous in the packed stream and a wave walks them 64 at a time.
+#include "ren_common.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_incl_scan(float v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        float t = __shfl_up(v, off, 64);
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+
+__device__ __forceinline__ float wave_incl_suffix_scan(float v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        float t = __shfl_down(v, off, 64);
+        if (lane + off < 64) v += t;
+    }
+    return v;
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void composite_fwd_kernel(
+    const int64_t *__restrict__ offsets, const int32_t *__restrict__ counts, int64_t n_rays,
+    const float *__restrict__ t_starts, const float *__restrict__ t_ends,
+    const float *__restrict__ sigmas, const float *__restrict__ rgbs, const float *__restrict__ bkgd,
+    float *__restrict__ colors, float *__restrict__ opacities, float *__restrict__ depths,
+    float *__restrict__ weights, float *__restrict__ trans) {
+    const int lane = threadIdx.x & 63;
+    const int64_t ray = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (ray >= n_rays) return;
+    const int64_t base = offsets[ray];
+    const int cnt = counts[ray];
+    float carry = 0.f;                    // sum of sigma*dt of all previous chunks
+    float acc_c[C], acc_o = 0.f, acc_d = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc_c[c] = 0.f;
+    for (int s = 0; s < cnt; s += 64) {
+        const int j = s + lane;
+        const bool act = j < cnt;
+        float t0 = 0.f, t1 = 0.f, sg = 0.f;
+        if (act) { t0 = t_starts[base + j]; t1 = t_ends[base + j]; sg = sigmas[base + j]; }
+        const float sd = sg * (t1 - t0);
+        const float inc = wave_incl_scan(sd, lane);
+        const float excl = carry + (inc - sd);
+        const float T = expf(-excl);
+        const float w = T * (1.f - expf(-sd));
+        if (act) {
+            if (weights) weights[base + j] = w;
+            if (trans) trans[base + j] = T;
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc_c[c] += w * rgbs[(base + j) * C + c];
+            acc_o += w;
+            acc_d += w * ((t0 + t1) * 0.5f);
+        }
+        carry += __shfl(inc, 63, 64);
+    }
+    acc_o = ren_wave_sum(acc_o);
+    acc_d = ren_wave_sum(acc_d);
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc_c[c] = ren_wave_sum(acc_c[c]);
+    if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+            colors[ray * C + c] = bkgd ? acc_c[c] + bkgd[c] * (1.f - acc_o) : acc_c[c];
+        opacities[ray] = acc_o;
+        depths[ray] = acc_d;
+    }
+}
+
+// L = sum_j w_j v_j + const,  v_j = sum_c g_c (rgb_jc - bkgd_c) + g_o + g_d * tmid_j
+// dL/dsigma_i = dt_i * (T_{i+1} v_i - sum_{j>i} w_j v_j),  dL/drgb_ic = w_i g_c
+template <int C>
+__global__ __launch_bounds__(256) void composite_bwd_kernel(
+    const int64_t *__restrict__ offsets, const int32_t *__restrict__ counts, int64_t n_rays,
+    const float *__restrict__ t_starts, const float *__restrict__ t_ends,
+    const float *__restrict__ sigmas, const float *__restrict__ rgbs, const float *__restrict__ bkgd,
+    const float *__restrict__ weights, const float *__restrict__ trans,
+    const float *__restrict__ opacities, const float *__restrict__ g_colors,
+    const float *__restrict__ g_opac, const float *__restrict__ g_depth,
+    float *__restrict__ d_sigmas, float *__restrict__ d_rgbs, float *__restrict__ d_bkgd_per_ray) {
+    const int lane = threadIdx.x & 63;
+    const int64_t ray = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (ray >= n_rays) return;
+    const int64_t base = offsets[ray];
+    const int cnt = counts[ray];
+    float gc[C], bk[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) { gc[c] = g_colors[ray * C + c]; bk[c] = bkgd ? bkgd[c] : 0.f; }
+    const float go = g_opac ? g_opac[ray] : 0.f;
+    const float gd = g_depth ? g_depth[ray] : 0.f;
+    if (d_bkgd_per_ray && lane == 0) {
+        const float om = 1.f - opacities[ray];
+#pragma unroll
+        for (int c = 0; c < C; ++c) d_bkgd_per_ray[ray * C + c] = gc[c] * om;
+    }
+    float carry = 0.f;                    // sum of w*v over all later chunks
+    const int n_chunks = (cnt + 63) >> 6;
+    for (int ch = n_chunks - 1; ch >= 0; --ch) {
+        const int j = ch * 64 + lane;
+        const bool act = j < cnt;
+        float t0 = 0.f, t1 = 0.f, sg = 0.f, w = 0.f, T = 0.f, v = 0.f;
+        if (act) {
+            t0 = t_starts[base + j]; t1 = t_ends[base + j]; sg = sigmas[base + j];
+            w = weights[base + j]; T = trans[base + j];
+            v = go + gd * ((t0 + t1) * 0.5f);
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                v += gc[c] * (rgbs[(base + j) * C + c] - bk[c]);
+                d_rgbs[(base + j) * C + c] = w * gc[c];
+            }
+        }
+        const float wv = w * v;
+        const float suf = wave_incl_suffix_scan(wv, lane);
+        const float after = carry + (suf - wv);          // sum_{j>i} w_j v_j
+        if (act) {
+            const float dt = t1 - t0;
+            const float Tn = T * expf(-sg * dt);          // T_{i+1}
+            d_sigmas[base + j] = dt * (Tn * v - after);
+        }
+        carry += __shfl(suf, 0, 64);
+    }
+}
+
+__global__ void column_sum_kernel(const float *__restrict__ in, int64_t rows, int C, float *__restrict__ out) {
+    // one block per column, grid-stride rows; rows*C is small (per-ray quantities)
+    __shared__ float part[4];
+    const int c = blockIdx.x;
+    float s = 0.f;
+    for (int64_t r = threadIdx.x; r < rows; r += blockDim.x) s += in[r * C + c];
+    s = ren_wave_sum(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[c] = part[0] + part[1] + part[2] + part[3];
+}
+
+}  // namespace
+
+extern "C" int ren_composite_fwd(const int64_t *offsets, const int32_t *counts, int64_t n_rays,
+                                 const float *t_starts, const float *t_ends, const float *sigmas,
+                                 const float *rgbs, int32_t C, const float *bkgd, float *colors,
+                                 float *opacities, float *depths, float *weights, float *trans,
+                                 void *stream) {
+    if (!offsets || !counts || !colors || !opacities || !depths || n_rays < 0) return REN_ERR_BAD_ARG;
+    if (C != 1 && C != 3) return REN_ERR_UNSUPPORTED;   // vol_rendering.py:83-84
+    if (n_rays == 0) return REN_OK;
+    dim3 grid(ren_blocks(n_rays, 4)), block(256);
+    if (C == 1)
+        hipLaunchKernelGGL(composite_fwd_kernel<1>, grid, block, 0, (hipStream_t)stream, offsets, counts,
+                           n_rays, t_starts, t_ends, sigmas, rgbs, bkgd, colors, opacities, depths, weights, trans);
+    else
+        hipLaunchKernelGGL(composite_fwd_kernel<3>, grid, block, 0, (hipStream_t)stream, offsets, counts,
+                           n_rays, t_starts, t_ends, sigmas, rgbs, bkgd, colors, opacities, depths, weights, trans);
+    REN_CHECK_LAUNCH();
+}
+
+extern "C" int ren_composite_bwd(const int64_t *offsets, const int32_t *counts, int64_t n_rays,
+                                 const float *t_starts, const float *t_ends, const float *sigmas,
+                                 const float *rgbs, int32_t C, const float *bkgd, const float *weights,
+                                 const float *trans, const float *opacities, const float *g_colors,
+                                 const float *g_opac, const float *g_depth, float *d_sigmas,
+                                 float *d_rgbs, float *d_bkgd_per_ray, void *stream) {
+    if (!offsets || !counts || !weights || !trans || !g_colors || !d_sigmas || !d_rgbs || n_rays < 0)
+        return REN_ERR_BAD_ARG;
+    if (d_bkgd_per_ray && !opacities) return REN_ERR_BAD_ARG;
+    if (C != 1 && C != 3) return REN_ERR_UNSUPPORTED;
+    if (n_rays == 0) return REN_OK;
+    dim3 grid(ren_blocks(n_rays, 4)), block(256);
+    if (C == 1)
+        hipLaunchKernelGGL(composite_bwd_kernel<1>, grid, block, 0, (hipStream_t)stream, offsets, counts,
+                           n_rays, t_starts, t_ends, sigmas, rgbs, bkgd, weights, trans, opacities, g_colors,
+                           g_opac, g_depth, d_sigmas, d_rgbs, d_bkgd_per_ray);
+    else
+        hipLaunchKernelGGL(composite_bwd_kernel<3>, grid, block, 0, (hipStream_t)stream, offsets, counts,
+                           n_rays, t_starts, t_ends, sigmas, rgbs, bkgd, weights, trans, opacities, g_colors,
+                           g_opac, g_depth, d_sigmas, d_rgbs, d_bkgd_per_ray);
+    REN_CHECK_LAUNCH();
+}
+
+extern "C" int ren_column_sum(const float *in, int64_t rows, int32_t C, float *out, void *stream) {
+    if (!in || !out || rows < 0 || C < 1 || C > 4) return REN_ERR_BAD_ARG;
+    hipLaunchKernelGGL(column_sum_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, in, rows, C, out);
+    REN_CHECK_LAUNCH();
+}

@@ -1,0 +1,208 @@
+// Multi-resolution hash-grid encoding (tcnn HashGrid, Linear interpolation, F=2), forward and
+// parameter backward.  Replaces tcnn.Encoding as instantiated at
+// robust_e_nerf/external/ngp.py:166-170 (config configs/train/synthetic.yaml:62-69).
+//
+// Work decomposition: one thread per (sample, level); blockIdx.y = level so that all
+// workgroups in flight gather from the same level's <= 4 MiB table slice (one XCD L2 holds it),
+// blockIdx.x walks 256 consecutive packed samples, which along a ray are spatially adjacent, so
+// coarse levels hit L1/L2.  Per sample-level: 8 x 8-byte random gathers (forward) or 16 f32
+// atomics (backward); the sample position is recomputed from the ray (24 B, cache resident) and
+// its (t0,t1) instead of being staged through HBM.
+//
+// Output layout 1 ("fragment order") is what the fused MLP kernels consume directly as MFMA
+// B-operands: feat[((i>>5)*16 + level)*64 + f*32 + (i&31)].
+#include "ren_common.h"
+
+namespace {
+
+struct GridDev {
+    int n_levels;
+    float scale[REN_MAX_LEVELS];
+    uint32_t res[REN_MAX_LEVELS], size[REN_MAX_LEVELS], offset[REN_MAX_LEVELS], hashed[REN_MAX_LEVELS];
+};
+
+__device__ __forceinline__ uint32_t corner_index(uint32_t cx, uint32_t cy, uint32_t cz, uint32_t res,
+                                                 uint32_t size, bool hashed) {
+    if (hashed) {
+        uint32_t h = cx ^ (cy * 2654435761u) ^ (cz * 805459861u);
+        return h & (size - 1u);                      // hashed levels have power-of-two size
+    }
+    uint32_t idx = cx + cy * res + cz * res * res;
+    if (idx >= size) { idx -= size; if (idx >= size) idx %= size; }
+    return idx;
+}
+
+struct LevelPos {
+    uint32_t c[3];
+    float w[3];
+};
+
+__device__ __forceinline__ LevelPos level_pos(float x, float y, float z, float scale) {
+    LevelPos p;
+    const float in[3] = {x, y, z};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float pos = fmaf(scale, in[k], 0.5f);
+        float fl = floorf(pos);
+        p.w[k] = pos - fl;
+        p.c[k] = (uint32_t)(int)fl;
+    }
+    return p;
+}
+
+template <int LAYOUT, bool FROM_RAYS>
+__global__ __launch_bounds__(256) void hashgrid_fwd_kernel(
+    GridDev g, const float2 *__restrict__ table, const float *__restrict__ x_unit, ren_scene_dev sc,
+    const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+    const int32_t *__restrict__ ray_indices, const float *__restrict__ t_starts,
+    const float *__restrict__ t_ends, int64_t n, int64_t n_pad, float *__restrict__ feat) {
+    const int lvl = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pad) return;
+    float f0 = 0.f, f1 = 0.f;
+    if (i < n) {
+        float ux, uy, uz;
+        if (FROM_RAYS) {
+            float x, y, z; int ray;
+            ren_sample_pos(rays_o, rays_d, ray_indices, t_starts, t_ends, i, x, y, z, ray);
+            ren_contract(sc, x, y, z, ux, uy, uz);
+        } else {
+            ux = x_unit[3 * i]; uy = x_unit[3 * i + 1]; uz = x_unit[3 * i + 2];
+        }
+        const LevelPos p = level_pos(ux, uy, uz, g.scale[lvl]);
+        const uint32_t res = g.res[lvl], size = g.size[lvl];
+        const bool hashed = g.hashed[lvl] != 0;
+        const float2 *tab = table + g.offset[lvl];
+        float2 v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const uint32_t idx = corner_index(p.c[0] + (c & 1), p.c[1] + ((c >> 1) & 1), p.c[2] + (c >> 2),
+                                              res, size, hashed);
+            v[c] = tab[idx];
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float wx = (c & 1) ? p.w[0] : 1.f - p.w[0];
+            const float wy = (c & 2) ? p.w[1] : 1.f - p.w[1];
+            const float wz = (c & 4) ? p.w[2] : 1.f - p.w[2];
+            const float w = wx * wy * wz;
+            f0 += w * v[c].x;
+            f1 += w * v[c].y;
+        }
+    }
+    if (LAYOUT == 0) {
+        if (i < n) reinterpret_cast<float2 *>(feat)[i * g.n_levels + lvl] = make_float2(f0, f1);
+    } else {
+        const int64_t b = ((i >> 5) * REN_MAX_LEVELS + lvl) * 64 + (i & 31);
+        feat[b] = f0;
+        feat[b + 32] = f1;
+    }
+}
+
+template <int LAYOUT, bool FROM_RAYS>
+__global__ __launch_bounds__(256) void hashgrid_bwd_kernel(
+    GridDev g, float *__restrict__ grad_table, const float *__restrict__ x_unit, ren_scene_dev sc,
+    const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+    const int32_t *__restrict__ ray_indices, const float *__restrict__ t_starts,
+    const float *__restrict__ t_ends, int64_t n, const float *__restrict__ dfeat) {
+    const int lvl = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float d0, d1;
+    if (LAYOUT == 0) {
+        const float2 d = reinterpret_cast<const float2 *>(dfeat)[i * g.n_levels + lvl];
+        d0 = d.x; d1 = d.y;
+    } else {
+        const int64_t b = ((i >> 5) * REN_MAX_LEVELS + lvl) * 64 + (i & 31);
+        d0 = dfeat[b];
+        d1 = dfeat[b + 32];
+    }
+    if (d0 == 0.f && d1 == 0.f) return;
+    float ux, uy, uz;
+    if (FROM_RAYS) {
+        float x, y, z; int ray;
+        ren_sample_pos(rays_o, rays_d, ray_indices, t_starts, t_ends, i, x, y, z, ray);
+        ren_contract(sc, x, y, z, ux, uy, uz);
+    } else {
+        ux = x_unit[3 * i]; uy = x_unit[3 * i + 1]; uz = x_unit[3 * i + 2];
+    }
+    const LevelPos p = level_pos(ux, uy, uz, g.scale[lvl]);
+    const uint32_t res = g.res[lvl], size = g.size[lvl];
+    const bool hashed = g.hashed[lvl] != 0;
+    float *gt = grad_table + 2 * (size_t)g.offset[lvl];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const uint32_t idx = corner_index(p.c[0] + (c & 1), p.c[1] + ((c >> 1) & 1), p.c[2] + (c >> 2),
+                                          res, size, hashed);
+        const float wx = (c & 1) ? p.w[0] : 1.f - p.w[0];
+        const float wy = (c & 2) ? p.w[1] : 1.f - p.w[1];
+        const float wz = (c & 4) ? p.w[2] : 1.f - p.w[2];
+        const float w = wx * wy * wz;
+        atomicAdd(gt + 2 * (size_t)idx, w * d0);
+        atomicAdd(gt + 2 * (size_t)idx + 1, w * d1);
+    }
+}
+
+int make_grid(const ren_grid_desc *grid, GridDev &g) {
+    if (!grid || grid->n_levels < 1 || grid->n_levels > REN_MAX_LEVELS) return REN_ERR_BAD_ARG;
+    g.n_levels = grid->n_levels;
+    for (int l = 0; l < REN_MAX_LEVELS; ++l) {
+        g.scale[l] = grid->scale[l]; g.res[l] = grid->res[l]; g.size[l] = grid->size[l];
+        g.offset[l] = grid->offset[l]; g.hashed[l] = grid->hashed[l];
+        if (l < grid->n_levels && grid->hashed[l] && (grid->size[l] & (grid->size[l] - 1)))
+            return REN_ERR_UNSUPPORTED;              // hashed level sizes are 2^log2_hashmap_size
+    }
+    return REN_OK;
+}
+
+}  // namespace
+
+extern "C" int ren_hashgrid_fwd(const ren_grid_desc *grid, const float *table, const float *x_unit,
+                                const ren_scene_desc *scene, const float *rays_o, const float *rays_d,
+                                const int32_t *ray_indices, const float *t_starts, const float *t_ends,
+                                int64_t n, int32_t layout, float *feat, void *stream) {
+    GridDev g;
+    int rc = make_grid(grid, g);
+    if (rc) return rc;
+    if (!table || !feat || n < 0 || (layout != 0 && layout != 1)) return REN_ERR_BAD_ARG;
+    const bool from_rays = x_unit == nullptr;
+    if (from_rays && (!scene || !rays_o || !rays_d || !ray_indices || !t_starts || !t_ends)) return REN_ERR_BAD_ARG;
+    if (layout == 1 && g.n_levels != REN_MAX_LEVELS) return REN_ERR_UNSUPPORTED;
+    if (n == 0) return REN_OK;
+    ren_scene_dev sc = {};
+    if (scene) sc = ren_make_scene(scene);
+    const int64_t n_pad = layout == 1 ? ((n + 31) / 32) * 32 : n;
+    dim3 grd(ren_blocks(n_pad, 256), g.n_levels), blk(256);
+    const float2 *tab = reinterpret_cast<const float2 *>(table);
+#define LAUNCH(L, R)                                                                                     \
+    hipLaunchKernelGGL((hashgrid_fwd_kernel<L, R>), grd, blk, 0, (hipStream_t)stream, g, tab, x_unit, sc, \
+                       rays_o, rays_d, ray_indices, t_starts, t_ends, n, n_pad, feat)
+    if (layout == 0) { if (from_rays) LAUNCH(0, true); else LAUNCH(0, false); }
+    else             { if (from_rays) LAUNCH(1, true); else LAUNCH(1, false); }
+#undef LAUNCH
+    REN_CHECK_LAUNCH();
+}
+
+extern "C" int ren_hashgrid_bwd(const ren_grid_desc *grid, float *grad_table, const float *x_unit,
+                                const ren_scene_desc *scene, const float *rays_o, const float *rays_d,
+                                const int32_t *ray_indices, const float *t_starts, const float *t_ends,
+                                int64_t n, int32_t layout, const float *dfeat, void *stream) {
+    GridDev g;
+    int rc = make_grid(grid, g);
+    if (rc) return rc;
+    if (!grad_table || !dfeat || n < 0 || (layout != 0 && layout != 1)) return REN_ERR_BAD_ARG;
+    const bool from_rays = x_unit == nullptr;
+    if (from_rays && (!scene || !rays_o || !rays_d || !ray_indices || !t_starts || !t_ends)) return REN_ERR_BAD_ARG;
+    if (layout == 1 && g.n_levels != REN_MAX_LEVELS) return REN_ERR_UNSUPPORTED;
+    if (n == 0) return REN_OK;
+    ren_scene_dev sc = {};
+    if (scene) sc = ren_make_scene(scene);
+    dim3 grd(ren_blocks(n, 256), g.n_levels), blk(256);
+#define LAUNCH(L, R)                                                                                          \
+    hipLaunchKernelGGL((hashgrid_bwd_kernel<L, R>), grd, blk, 0, (hipStream_t)stream, g, grad_table, x_unit, \
+                       sc, rays_o, rays_d, ray_indices, t_starts, t_ends, n, dfeat)
+    if (layout == 0) { if (from_rays) LAUNCH(0, true); else LAUNCH(0, false); }
+    else             { if (from_rays) LAUNCH(1, true); else LAUNCH(1, false); }
+#undef LAUNCH
+    REN_CHECK_LAUNCH();
+}

@@ -1,0 +1,722 @@
+// Fused Instant-NGP MLPs (base 32->64->16, head [SH16|geo15]->64->64->C) on the gfx950 matrix
+// cores in exact fp32 (v_mfma_f32_32x32x2_f32), forward and backward.
+// Replaces NGPradianceField.query_density/_query_rgb/forward
+// (robust_e_nerf/external/ngp.py:230-280) = 5 torch sgemms + SH + ~20 elementwise launches and
+// ~1.2 KB/sample of HBM intermediates with one forward launch and two backward launches whose
+// only HBM traffic is the 128 B/sample hash features, 64 B/sample of saved base outputs and the
+// per-sample (rgb, sigma) results.
+//
+// Data layout ("lane = sample").  A wavefront works on blocks of 32 samples.  For
+// D = A.B with the 32x32x2 f32 MFMA, lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31]
+// and receives D[row(g, l>>5)][col = l&31], row(g,hi) = (g&3) + 8*(g>>2) + 4*hi, g = 0..15.
+// With A = weights (i = output neuron) and B = activations (j = sample) the accumulator
+// registers of one layer ARE the B operands of the next layer: register g of lane (sample, hi)
+// holds neuron row(g,hi), so k-step g pairs the neurons {row(g,0), row(g,1)} and the weight
+// fragment is read with the same pairing.  No cross-lane movement, no LDS round trip for
+// activations in the forward chain.  Weights live in LDS once per workgroup, row-major with the
+// row stride padded to K+1 words so both the "lanes = output rows" (forward) and "lanes = input
+// columns" (backward, W^T) fragment reads are bank-conflict free.
+//
+// Weight gradients need the transposed layout (lane = neuron, k = sample): activations and
+// their gradients are staged once per layer through a per-wave LDS tile [neuron][33] and the
+// 32x32 dW tiles accumulate in registers over the whole kernel; every wave writes its partial
+// dW to a slab in HBM and a small kernel reduces the slabs (deterministic, no atomics).
+#include "ren_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+// ---- parameter block offsets (floats), torch nn.Linear layout ------------------------------
+constexpr int P_BW0 = 0;          // base.w0 [64,32]
+constexpr int P_BB0 = 2048;       // base.b0 [64]
+constexpr int P_BWO = 2112;       // base.wo [16,64]
+constexpr int P_BBO = 3136;       // base.bo [16]
+constexpr int P_HW0 = 3152;       // head.w0 [64,31]
+constexpr int P_HB0 = 5136;       // head.b0 [64]
+constexpr int P_HW1 = 5200;       // head.w1 [64,64]
+constexpr int P_HB1 = 9296;       // head.b1 [64]
+constexpr int P_HWO = 9360;       // head.wo [C,64]   ; head.bo [C] follows
+constexpr int P_BASE_N = 3152;    // number of base-MLP parameters
+__host__ __device__ constexpr int p_total(int C) { return P_HWO + 65 * C; }
+
+// ---- LDS weight image (floats) -----------------------------------------------------------
+constexpr int L_W1 = 0;                    // [64][33]
+constexpr int L_W2 = L_W1 + 64 * 33;       // [32][65]  rows >= 16 are zero
+constexpr int L_WH1 = L_W2 + 32 * 65;      // [64][33]  input order v: 0 = sigma slot (w=0), 1..15 geo, 16..31 SH
+constexpr int L_WH2 = L_WH1 + 64 * 33;     // [64][65]
+constexpr int L_WH3 = L_WH2 + 64 * 65;     // [3][64]
+constexpr int L_B1 = L_WH3 + 192;          // [64]
+constexpr int L_B2 = L_B1 + 64;            // [32]  >= 16 zero
+constexpr int L_BH1 = L_B2 + 32;           // [64]
+constexpr int L_BH2 = L_BH1 + 64;          // [64]
+constexpr int L_BH3 = L_BH2 + 64;          // [4]
+constexpr int L_WEIGHTS_END = L_BH3 + 4;   // 10884 floats = 43 536 B
+
+__device__ __forceinline__ constexpr int rowc(int g) { return (g & 3) + 8 * (g >> 2); }   // + 4*hi
+
+__device__ __forceinline__ float log1p_fast(float e) {       // e >= 0
+    return e < 1e-3f ? e * (1.f - e * (0.5f - e * 0.33333333f)) : __logf(1.f + e);
+}
+// torch softplus(beta, threshold=20): x if beta*x > 20 else log1p(exp(beta*x))/beta
+__device__ __forceinline__ float softplus100(float x) {
+    const float z = 100.f * x;
+    return z > 20.f ? x : log1p_fast(__expf(z)) * 0.01f;
+}
+__device__ __forceinline__ float softplus1(float x) { return x > 20.f ? x : log1p_fast(__expf(x)); }
+// derivative of softplus(beta) expressed through its OUTPUT y: sigmoid(beta x) = 1 - exp(-beta y)
+__device__ __forceinline__ float dsoftplus_from_out(float y, float beta) {
+    const float t = beta * y;
+    return t < 1e-3f ? t * (1.f - t * (0.5f - t * 0.16666667f)) : 1.f - __expf(-t);
+}
+
+__device__ void fill_base(float *lds, const float *__restrict__ P, int oW1, int oW2, int oB1, int oB2) {
+    const int t = threadIdx.x, nt = blockDim.x;
+    for (int i = t; i < 64 * 32; i += nt) lds[oW1 + (i >> 5) * 33 + (i & 31)] = P[P_BW0 + i];
+    for (int i = t; i < 32 * 64; i += nt) {
+        const int o = i >> 6, k = i & 63;
+        lds[oW2 + o * 65 + k] = o < 16 ? P[P_BWO + o * 64 + k] : 0.f;
+    }
+    for (int i = t; i < 64; i += nt) lds[oB1 + i] = P[P_BB0 + i];
+    for (int i = t; i < 32; i += nt) lds[oB2 + i] = i < 16 ? P[P_BBO + i] : 0.f;
+}
+
+__device__ void fill_head(float *lds, const float *__restrict__ P, int C, int oWH1, int oWH2, int oWH3,
+                          int oBH1, int oBH2, int oBH3) {
+    const int t = threadIdx.x, nt = blockDim.x;
+    for (int i = t; i < 64 * 32; i += nt) {
+        const int o = i >> 5, v = i & 31;
+        float w;
+        if (v == 0) w = 0.f;                                   // sigma_raw is not a head input (ngp.py:244-246)
+        else if (v < 16) w = P[P_HW0 + o * 31 + 15 + v];       // geo feature v-1 -> column 16 + (v-1)
+        else w = P[P_HW0 + o * 31 + (v - 16)];                 // SH component v-16 -> column v-16 (ngp.py:259)
+        lds[oWH1 + o * 33 + v] = w;
+    }
+    for (int i = t; i < 64 * 64; i += nt) lds[oWH2 + (i >> 6) * 65 + (i & 63)] = P[P_HW1 + i];
+    for (int i = t; i < 64 * C; i += nt) lds[oWH3 + i] = P[P_HWO + i];
+    for (int i = t; i < 64; i += nt) { lds[oBH1 + i] = P[P_HB0 + i]; lds[oBH2 + i] = P[P_HB1 + i]; }
+    for (int i = t; i < C; i += nt) lds[oBH3 + i] = P[P_HWO + 64 * C + i];
+}
+
+// compact LDS images for the two backward kernels
+constexpr int LH_WH1 = 0, LH_WH2 = LH_WH1 + 64 * 33, LH_WH3 = LH_WH2 + 64 * 65, LH_BH1 = LH_WH3 + 192,
+              LH_BH2 = LH_BH1 + 64, LH_BH3 = LH_BH2 + 64, LH_END = LH_BH3 + 4;       // 6596 floats
+constexpr int LB_W1 = 0, LB_W2 = LB_W1 + 64 * 33, LB_B1 = LB_W2 + 32 * 65, LB_B2 = LB_B1 + 64,
+              LB_END = LB_B2 + 32;                                                     // 4288 floats
+
+// real SH degree 4, tcnn sign convention (external/sh_encoder.py:56-77); returns the 8
+// components of parity `hi` (component 2j+hi in out[j]).
+__device__ __forceinline__ void sh4_select(float x, float y, float z, int hi, float *out) {
+    const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+    float s[16];
+    s[0] = 0.28209479177387814f;
+    s[1] = -0.48860251190291987f * y;
+    s[2] = 0.48860251190291987f * z;
+    s[3] = -0.48860251190291987f * x;
+    s[4] = 1.0925484305920792f * xy;
+    s[5] = -1.0925484305920792f * yz;
+    s[6] = 0.94617469575755997f * z2 - 0.31539156525251999f;
+    s[7] = -1.0925484305920792f * xz;
+    s[8] = 0.54627421529603959f * x2 - 0.54627421529603959f * y2;
+    s[9] = 0.59004358992664352f * y * (-3.0f * x2 + y2);
+    s[10] = 2.8906114426405538f * xy * z;
+    s[11] = 0.45704579946446572f * y * (1.0f - 5.0f * z2);
+    s[12] = 0.3731763325901154f * z * (5.0f * z2 - 3.0f);
+    s[13] = 0.45704579946446572f * x * (1.0f - 5.0f * z2);
+    s[14] = 1.4453057213202769f * z * (x2 - y2);
+    s[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) out[j] = hi ? s[2 * j + 1] : s[2 * j];
+}
+
+struct SampleSrc {
+    const float *x_world, *dirs;                 // per-sample (seam API) -- or --
+    const float *rays_o, *rays_d;                // packed stream
+    const int32_t *ray_indices;
+    const float *t_starts, *t_ends;
+};
+
+// position (contracted -> selector) and view direction of sample i
+__device__ __forceinline__ void sample_geom(const SampleSrc &s, const ren_scene_dev &sc, int64_t i,
+                                            bool &sel, float &dx, float &dy, float &dz) {
+    float x, y, z;
+    if (s.ray_indices) {
+        int ray;
+        ren_sample_pos(s.rays_o, s.rays_d, s.ray_indices, s.t_starts, s.t_ends, i, x, y, z, ray);
+        const float *d = s.rays_d + 3 * (int64_t)ray;
+        dx = d[0]; dy = d[1]; dz = d[2];
+    } else {
+        x = s.x_world[3 * i]; y = s.x_world[3 * i + 1]; z = s.x_world[3 * i + 2];
+        if (s.dirs) { dx = s.dirs[3 * i]; dy = s.dirs[3 * i + 1]; dz = s.dirs[3 * i + 2]; }
+        else { dx = 0.f; dy = 0.f; dz = 1.f; }
+    }
+    float ux, uy, uz;
+    ren_contract(sc, x, y, z, ux, uy, uz);
+    sel = ux > 0.f && ux < 1.f && uy > 0.f && uy < 1.f && uz > 0.f && uz < 1.f;   // ngp.py:238
+}
+
+// ============================================================================ forward
+struct FwdArgs {
+    const float *params, *feat;
+    SampleSrc src;
+    ren_scene_dev sc;
+    int64_t n;
+    float *rgb, *sigma, *base_out;
+};
+
+template <int C, bool DENSITY_ONLY>
+__global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(FwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds_base[];
+    fill_base(lds_base, a.params, L_W1, L_W2, L_B1, L_B2);
+    if (!DENSITY_ONLY) fill_head(lds_base, a.params, C, L_WH1, L_WH2, L_WH3, L_BH1, L_BH2, L_BH3);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hi = lane >> 5, sl = lane & 31;
+    const int64_t n_blk = (a.n + 31) >> 5;
+
+    for (int64_t blk = (int64_t)blockIdx.x * 4 + wave; blk < n_blk; blk += (int64_t)gridDim.x * 4) {
+        // The weight image is loop invariant; without this opaque offset LICM hoists every LDS
+        // read (~400 values) out of the persistent loop and spills them.
+        int zo = 0;
+        asm volatile("" : "+v"(zo));
+        const float *lds = lds_base + zo;
+        const float *W1 = lds + L_W1, *W2 = lds + L_W2, *WH1 = lds + L_WH1, *WH2 = lds + L_WH2;
+        const int64_t i = blk * 32 + sl;
+        const bool live = i < a.n;
+        // ---- hash features as B operands: k-step s = level s, lane hi = feature parity
+        float x[16];
+        {
+            const float *f = a.feat + blk * (16 * 64) + lane;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) x[s] = f[s * 64];
+        }
+        // ---- base layer 0: 32 -> 64, softplus(beta=100)
+        f32x16 h[2];
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            h[0][g] = lds[L_B1 + rowc(g) + 4 * hi];
+            h[1][g] = lds[L_B1 + 32 + rowc(g) + 4 * hi];
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            h[0] = MFMA(W1[sl * 33 + 2 * s + hi], x[s], h[0]);
+            h[1] = MFMA(W1[(32 + sl) * 33 + 2 * s + hi], x[s], h[1]);
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) h[r][g] = softplus100(h[r][g]);
+        // ---- base output: 64 -> 16 (rows 16..31 of the tile are zero padding)
+        f32x16 o;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) o[g] = lds[L_B2 + rowc(g) + 4 * hi];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int g = 0; g < 16; ++g)
+                o = MFMA(W2[sl * 65 + 32 * r + rowc(g) + 4 * hi], h[r][g], o);
+        // ---- density + per-sample geometry
+        bool sel = false;
+        float dx = 0.f, dy = 0.f, dz = 1.f;
+        if (live) sample_geom(a.src, a.sc, i, sel, dx, dy, dz);
+        if (live && hi == 0) a.sigma[i] = sel ? __expf(o[0] - 1.f) : 0.f;          // ngp.py:247-250
+        if (a.base_out) {
+            float *bo = a.base_out + blk * (8 * 64) + lane;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) bo[g * 64] = o[g];
+        }
+        if (DENSITY_ONLY) continue;
+        float shs[8];
+        sh4_select(dx, dy, dz, hi, shs);
+        // ---- head layer 0: v = [base_out(16) | SH(16)] -> 64
+        f32x16 p[2];
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            p[0][g] = lds[L_BH1 + rowc(g) + 4 * hi];
+            p[1][g] = lds[L_BH1 + 32 + rowc(g) + 4 * hi];
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int col = s < 8 ? rowc(s) + 4 * hi : 16 + 2 * (s - 8) + hi;
+            const float bv = s < 8 ? o[s] : shs[s < 8 ? 0 : s - 8];
+            p[0] = MFMA(WH1[sl * 33 + col], bv, p[0]);
+            p[1] = MFMA(WH1[(32 + sl) * 33 + col], bv, p[1]);
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) p[r][g] = softplus100(p[r][g]);
+        // ---- head layer 1: 64 -> 64
+        f32x16 q[2];
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            q[0][g] = lds[L_BH2 + rowc(g) + 4 * hi];
+            q[1][g] = lds[L_BH2 + 32 + rowc(g) + 4 * hi];
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int col = 32 * r + rowc(g) + 4 * hi;
+                q[0] = MFMA(WH2[sl * 65 + col], p[r][g], q[0]);
+                q[1] = MFMA(WH2[(32 + sl) * 65 + col], p[r][g], q[1]);
+            }
+        // ---- head output: 64 -> C on the VALU (each lane holds 32 of its sample's 64 neurons)
+        float acc[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[c] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const float qa = softplus100(q[r][g]);
+#pragma unroll
+                for (int c = 0; c < C; ++c) acc[c] += qa * lds[L_WH3 + c * 64 + 32 * r + rowc(g) + 4 * hi];
+            }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float t = acc[c] + __shfl_xor(acc[c], 32, 64);
+            if (hi == 0 && live) a.rgb[i * C + c] = softplus1(t + lds[L_BH3 + c]);
+        }
+    }
+}
+
+// ============================================================================ backward, head
+constexpr int GRID_H = 256, GRID_B = 512;          // persistent workgroups (4 waves each)
+
+struct BwdHArgs {
+    const float *params, *base_out;
+    SampleSrc src;
+    ren_scene_dev sc;
+    int64_t n;
+    const float *rgb, *d_rgb, *d_sigma;
+    float *d_base, *slab;                           // d_base: fragment layout [blk][8][64]
+};
+
+template <int C>
+__global__ __launch_bounds__(256, 1) void mlp_bwd_head_kernel(BwdHArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds_base[];
+    fill_head(lds_base, a.params, C, LH_WH1, LH_WH2, LH_WH3, LH_BH1, LH_BH2, LH_BH3);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hi = lane >> 5, sl = lane & 31;
+    float *T_dz = lds_base + LH_END + wave * (2 * 64 * 33);      // [64][33]
+    float *T_act = T_dz + 64 * 33;                                 // [64][33]
+    __syncthreads();
+    const int64_t n_blk = (a.n + 31) >> 5;
+
+    f32x16 acc_wh2[2][2], acc_wh1[2];
+    float acc_w3[C][32], acc_bh2[2] = {0.f, 0.f}, acc_bh1[2] = {0.f, 0.f}, acc_bh3[C];
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        acc_wh2[0][0][g] = 0.f; acc_wh2[0][1][g] = 0.f; acc_wh2[1][0][g] = 0.f; acc_wh2[1][1][g] = 0.f;
+        acc_wh1[0][g] = 0.f; acc_wh1[1][g] = 0.f;
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        acc_bh3[c] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) acc_w3[c][k] = 0.f;
+    }
+
+    for (int64_t blk = (int64_t)blockIdx.x * 4 + wave; blk < n_blk; blk += (int64_t)gridDim.x * 4) {
+        int zo = 0;                                     // defeat LICM of LDS weight reads (see forward)
+        asm volatile("" : "+v"(zo));
+        const float *lds = lds_base + zo;
+        const float *WH1 = lds + LH_WH1, *WH2 = lds + LH_WH2;
+        const int64_t i = blk * 32 + sl;
+        const bool live = i < a.n;
+        bool sel = false;
+        float dx = 0.f, dy = 0.f, dz = 1.f;
+        if (live) sample_geom(a.src, a.sc, i, sel, dx, dy, dz);
+        float shs[8], o[8];
+        sh4_select(dx, dy, dz, hi, shs);
+        {
+            const float *bo = a.base_out + blk * (8 * 64) + lane;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) o[g] = bo[g * 64];
+        }
+        // ---- recompute head forward
+        f32x16 p[2], q[2];
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            p[0][g] = lds[LH_BH1 + rowc(g) + 4 * hi];
+            p[1][g] = lds[LH_BH1 + 32 + rowc(g) + 4 * hi];
+            q[0][g] = lds[LH_BH2 + rowc(g) + 4 * hi];
+            q[1][g] = lds[LH_BH2 + 32 + rowc(g) + 4 * hi];
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int col = s < 8 ? rowc(s) + 4 * hi : 16 + 2 * (s - 8) + hi;
+            const float b = s < 8 ? o[s] : shs[s - 8];
+            p[0] = MFMA(WH1[sl * 33 + col], b, p[0]);
+            p[1] = MFMA(WH1[(32 + sl) * 33 + col], b, p[1]);
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) p[r][g] = softplus100(p[r][g]);
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int col = 32 * r + rowc(g) + 4 * hi;
+                q[0] = MFMA(WH2[sl * 65 + col], p[r][g], q[0]);
+                q[1] = MFMA(WH2[(32 + sl) * 65 + col], p[r][g], q[1]);
+            }
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) q[r][g] = softplus100(q[r][g]);
+        // ---- output layer backward: d z3 = d rgb * softplus1'(z3) = d rgb * (1 - exp(-rgb))
+        float dz3[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            dz3[c] = live ? a.d_rgb[i * C + c] * dsoftplus_from_out(a.rgb[i * C + c], 1.f) : 0.f;
+            if (hi == 0) acc_bh3[c] += dz3[c];
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) acc_w3[c][r * 16 + g] += dz3[c] * q[r][g];
+        }
+        // d q -> d z2 (in place in q)
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                float dq = 0.f;
+#pragma unroll
+                for (int c = 0; c < C; ++c) dq += dz3[c] * lds[LH_WH3 + c * 64 + 32 * r + rowc(g) + 4 * hi];
+                q[r][g] = dq * dsoftplus_from_out(q[r][g], 100.f);
+            }
+        // ---- dW(head.w1) += dZ2 . P^T  (stage both as [neuron][sample])
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int row = 32 * r + rowc(g) + 4 * hi;
+                T_dz[row * 33 + sl] = q[r][g];
+                T_act[row * 33 + sl] = p[r][g];
+            }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const float az0 = T_dz[sl * 33 + 2 * s + hi], az1 = T_dz[(32 + sl) * 33 + 2 * s + hi];
+            const float bp0 = T_act[sl * 33 + 2 * s + hi], bp1 = T_act[(32 + sl) * 33 + 2 * s + hi];
+            acc_bh2[0] += az0; acc_bh2[1] += az1;
+            acc_wh2[0][0] = MFMA(az0, bp0, acc_wh2[0][0]);
+            acc_wh2[0][1] = MFMA(az0, bp1, acc_wh2[0][1]);
+            acc_wh2[1][0] = MFMA(az1, bp0, acc_wh2[1][0]);
+            acc_wh2[1][1] = MFMA(az1, bp1, acc_wh2[1][1]);
+        }
+        // ---- d p = W2^T dZ2 ; dZ1 = d p * softplus'(p)
+        f32x16 dp[2];
+#pragma unroll
+        for (int g = 0; g < 16; ++g) { dp[0][g] = 0.f; dp[1][g] = 0.f; }
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int orow = 32 * r + rowc(g) + 4 * hi;
+                dp[0] = MFMA(WH2[orow * 65 + sl], q[r][g], dp[0]);
+                dp[1] = MFMA(WH2[orow * 65 + 32 + sl], q[r][g], dp[1]);
+            }
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) dp[r][g] *= dsoftplus_from_out(p[r][g], 100.f);
+        // ---- dW(head.w0) += dZ1 . V^T,  V = [base_out(16) | SH(16)]
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) T_dz[(32 * r + rowc(g) + 4 * hi) * 33 + sl] = dp[r][g];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            T_act[(rowc(g) + 4 * hi) * 33 + sl] = o[g];
+            T_act[(16 + 2 * g + hi) * 33 + sl] = shs[g];
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const float az0 = T_dz[sl * 33 + 2 * s + hi], az1 = T_dz[(32 + sl) * 33 + 2 * s + hi];
+            const float bv = T_act[sl * 33 + 2 * s + hi];
+            acc_bh1[0] += az0; acc_bh1[1] += az1;
+            acc_wh1[0] = MFMA(az0, bv, acc_wh1[0]);
+            acc_wh1[1] = MFMA(az1, bv, acc_wh1[1]);
+        }
+        // ---- d V (rows 0..15 = d base_out) = WH1^T dZ1 ; row 0 takes the density gradient
+        f32x16 dv;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) dv[g] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int g = 0; g < 16; ++g)
+                dv = MFMA(WH1[(32 * r + rowc(g) + 4 * hi) * 33 + sl], dp[r][g], dv);
+        if (hi == 0) {
+            // d sigma / d raw = exp(clamp(raw - 1, max=15)) * selector   (ngp.py:54-58,247-250)
+            const float ds = live ? a.d_sigma[i] : 0.f;
+            dv[0] = sel ? ds * __expf(fminf(o[0] - 1.f, 15.f)) : 0.f;
+        }
+        {
+            float *db = a.d_base + blk * (8 * 64) + lane;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) db[g * 64] = dv[g];
+        }
+    }
+    // ---- write this wave's partial weight gradients (head part of the parameter block)
+    float *slab = a.slab + ((int64_t)blockIdx.x * 4 + wave) * (p_total(C) - P_BASE_N);
+    constexpr int O = -P_BASE_N;                         // slab holds the head part only
+#pragma unroll
+    for (int ob = 0; ob < 2; ++ob) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const int out = 32 * ob + rowc(g) + 4 * hi;
+            slab[O + P_HW1 + out * 64 + sl] = acc_wh2[ob][0][g];
+            slab[O + P_HW1 + out * 64 + 32 + sl] = acc_wh2[ob][1][g];
+            // head.w0: v = sl -> column (v==0: none, v<16: 15+v, else v-16)
+            if (sl != 0) slab[O + P_HW0 + out * 31 + (sl < 16 ? 15 + sl : sl - 16)] = acc_wh1[ob][g];
+        }
+        const float b2 = acc_bh2[ob] + __shfl_xor(acc_bh2[ob], 32, 64);
+        const float b1 = acc_bh1[ob] + __shfl_xor(acc_bh1[ob], 32, 64);
+        if (hi == 0) { slab[O + P_HB1 + 32 * ob + sl] = b2; slab[O + P_HB0 + 32 * ob + sl] = b1; }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            float v = acc_w3[c][k];
+#pragma unroll
+            for (int off = 1; off < 32; off <<= 1) v += __shfl_xor(v, off, 64);
+            if (sl == 0) slab[O + P_HWO + c * 64 + 32 * (k >> 4) + rowc(k & 15) + 4 * hi] = v;
+        }
+        const float b3 = ren_wave_sum(acc_bh3[c]);
+        if (lane == 0) slab[O + P_HWO + 64 * C + c] = b3;
+    }
+}
+
+// ============================================================================ backward, base
+struct BwdBArgs {
+    const float *params, *feat, *d_base;
+    int64_t n;
+    float *dfeat, *slab;
+};
+
+__global__ __launch_bounds__(256, 1) void mlp_bwd_base_kernel(BwdBArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds_base[];
+    fill_base(lds_base, a.params, LB_W1, LB_W2, LB_B1, LB_B2);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hi = lane >> 5, sl = lane & 31;
+    float *T_a = lds_base + LB_END + wave * (96 * 33);           // [64][33]: h, later dZ0
+    float *T_b = T_a + 64 * 33;                                    // [32][33]: d base_out, later x
+    for (int k = lane; k < 32 * 33; k += 64) T_b[k] = 0.f;         // rows 16..31 stay zero
+    __syncthreads();
+    const int64_t n_blk = (a.n + 31) >> 5;
+
+    f32x16 acc_w2[2], acc_w1[2];
+    float acc_b2 = 0.f, acc_b1[2] = {0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < 16; ++g) { acc_w2[0][g] = 0.f; acc_w2[1][g] = 0.f; acc_w1[0][g] = 0.f; acc_w1[1][g] = 0.f; }
+
+    for (int64_t blk = (int64_t)blockIdx.x * 4 + wave; blk < n_blk; blk += (int64_t)gridDim.x * 4) {
+        int zo = 0;                                     // defeat LICM of LDS weight reads (see forward)
+        asm volatile("" : "+v"(zo));
+        const float *lds = lds_base + zo;
+        const float *W1 = lds + LB_W1, *W2 = lds + LB_W2;
+        float x[16], dob[8];
+        {
+            const float *f = a.feat + blk * (16 * 64) + lane;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) x[s] = f[s * 64];
+            const float *db = a.d_base + blk * (8 * 64) + lane;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) dob[g] = db[g * 64];
+        }
+        // ---- recompute hidden layer
+        f32x16 h[2];
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            h[0][g] = lds[LB_B1 + rowc(g) + 4 * hi];
+            h[1][g] = lds[LB_B1 + 32 + rowc(g) + 4 * hi];
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            h[0] = MFMA(W1[sl * 33 + 2 * s + hi], x[s], h[0]);
+            h[1] = MFMA(W1[(32 + sl) * 33 + 2 * s + hi], x[s], h[1]);
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) h[r][g] = softplus100(h[r][g]);
+        // ---- dW(base.wo) += dO . H^T
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) T_a[(32 * r + rowc(g) + 4 * hi) * 33 + sl] = h[r][g];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) T_b[(rowc(g) + 4 * hi) * 33 + sl] = dob[g];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const float az = T_b[sl * 33 + 2 * s + hi];
+            acc_b2 += az;
+            acc_w2[0] = MFMA(az, T_a[sl * 33 + 2 * s + hi], acc_w2[0]);
+            acc_w2[1] = MFMA(az, T_a[(32 + sl) * 33 + 2 * s + hi], acc_w2[1]);
+        }
+        // ---- d h = Wo^T dO (only 16 real output rows = 8 k-steps); dZ0 = d h * softplus'(h)
+        f32x16 dh[2];
+#pragma unroll
+        for (int g = 0; g < 16; ++g) { dh[0][g] = 0.f; dh[1][g] = 0.f; }
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const int orow = rowc(g) + 4 * hi;
+            dh[0] = MFMA(W2[orow * 65 + sl], dob[g], dh[0]);
+            dh[1] = MFMA(W2[orow * 65 + 32 + sl], dob[g], dh[1]);
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) dh[r][g] *= dsoftplus_from_out(h[r][g], 100.f);
+        // ---- dW(base.w0) += dZ0 . X^T
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) T_a[(32 * r + rowc(g) + 4 * hi) * 33 + sl] = dh[r][g];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) T_b[(2 * s + hi) * 33 + sl] = x[s];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const float az0 = T_a[sl * 33 + 2 * s + hi], az1 = T_a[(32 + sl) * 33 + 2 * s + hi];
+            const float bx = T_b[sl * 33 + 2 * s + hi];
+            acc_b1[0] += az0; acc_b1[1] += az1;
+            acc_w1[0] = MFMA(az0, bx, acc_w1[0]);
+            acc_w1[1] = MFMA(az1, bx, acc_w1[1]);
+        }
+        // T_b rows 16..31 now hold x; restore the zero padding the dO staging relies on
+#pragma unroll
+        for (int s = 8; s < 16; ++s) T_b[(2 * s + hi) * 33 + sl] = 0.f;
+        // ---- d x = W0^T dZ0 -> hash-feature gradient, fragment layout
+        f32x16 dxv;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) dxv[g] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int g = 0; g < 16; ++g)
+                dxv = MFMA(W1[(32 * r + rowc(g) + 4 * hi) * 33 + sl], dh[r][g], dxv);
+        {
+            float *df = a.dfeat + blk * (16 * 64) + sl;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int f = rowc(g) + 4 * hi;                    // feature index = 2*level + parity
+                df[(f >> 1) * 64 + (f & 1) * 32] = dxv[g];
+            }
+        }
+    }
+    float *slab = a.slab + ((int64_t)blockIdx.x * 4 + wave) * P_BASE_N;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        const int out = rowc(g) + 4 * hi;
+        if (out < 16) {
+            slab[P_BWO + out * 64 + sl] = acc_w2[0][g];
+            slab[P_BWO + out * 64 + 32 + sl] = acc_w2[1][g];
+        }
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob) slab[P_BW0 + (32 * ob + out) * 32 + sl] = acc_w1[ob][g];
+    }
+    const float b2 = acc_b2 + __shfl_xor(acc_b2, 32, 64);
+    if (hi == 0 && sl < 16) slab[P_BBO + sl] = b2;
+#pragma unroll
+    for (int ob = 0; ob < 2; ++ob) {
+        const float b1 = acc_b1[ob] + __shfl_xor(acc_b1[ob], 32, 64);
+        if (hi == 0) slab[P_BB0 + 32 * ob + sl] = b1;
+    }
+}
+
+// grad[off + j] += sum_w slab[w * len + j]
+__global__ void reduce_slabs_kernel(const float *__restrict__ slab, int n_slabs, int len,
+                                    float *__restrict__ grad) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= len) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int w = 0;
+    for (; w + 3 < n_slabs; w += 4) {
+        s0 += slab[(int64_t)w * len + j];
+        s1 += slab[(int64_t)(w + 1) * len + j];
+        s2 += slab[(int64_t)(w + 2) * len + j];
+        s3 += slab[(int64_t)(w + 3) * len + j];
+    }
+    for (; w < n_slabs; ++w) s0 += slab[(int64_t)w * len + j];
+    grad[j] += (s0 + s1) + (s2 + s3);
+}
+
+constexpr size_t FWD_LDS = (size_t)L_WEIGHTS_END * 4;
+constexpr size_t BWD_H_LDS = (size_t)(LH_END + 4 * 2 * 64 * 33) * 4;      //  93 968 B -> 1 WG/CU
+constexpr size_t BWD_B_LDS = (size_t)(LB_END + 4 * 96 * 33) * 4;          //  67 840 B -> 2 WG/CU
+
+}  // namespace
+
+extern "C" int64_t ren_mlp_bwd_workspace_floats(int32_t C) {
+    if (C != 1 && C != 3) return -1;
+    // d_base (fragment layout) is sized by the caller; this is the slab area only
+    return (int64_t)GRID_H * 4 * (p_total(C) - P_BASE_N) + (int64_t)GRID_B * 4 * P_BASE_N;
+}
+
+extern "C" int ren_mlp_fwd(const float *mlp_params, int32_t C, const float *feat,
+                           const ren_scene_desc *scene, const float *x_world, const float *dirs,
+                           const float *rays_o, const float *rays_d, const int32_t *ray_indices,
+                           const float *t_starts, const float *t_ends, int64_t n, int32_t density_only,
+                           float *rgb, float *sigma, float *base_out, void *stream) {
+    if (!mlp_params || !feat || !scene || !sigma || n < 0) return REN_ERR_BAD_ARG;
+    if (C != 1 && C != 3) return REN_ERR_UNSUPPORTED;          // robust_e_nerf.py:230-233
+    if (!density_only && !rgb) return REN_ERR_BAD_ARG;
+    if (!x_world && (!rays_o || !rays_d || !ray_indices || !t_starts || !t_ends)) return REN_ERR_BAD_ARG;
+    if (n == 0) return REN_OK;
+    FwdArgs a;
+    a.params = mlp_params; a.feat = feat;
+    a.src = SampleSrc{x_world, dirs, rays_o, rays_d, x_world ? nullptr : ray_indices, t_starts, t_ends};
+    a.sc = ren_make_scene(scene);
+    a.n = n; a.rgb = rgb; a.sigma = sigma; a.base_out = base_out;
+    const int64_t n_blk = (n + 31) / 32;
+    int64_t blocks = (n_blk + 3) / 4;
+    if (blocks > 768) blocks = 768;                            // 3 workgroups / CU (43.5 KB LDS each)
+    dim3 grd((int)blocks), blk(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (density_only) hipLaunchKernelGGL((mlp_fwd_kernel<1, true>), grd, blk, FWD_LDS, st, a);
+    else if (C == 1)  hipLaunchKernelGGL((mlp_fwd_kernel<1, false>), grd, blk, FWD_LDS, st, a);
+    else              hipLaunchKernelGGL((mlp_fwd_kernel<3, false>), grd, blk, FWD_LDS, st, a);
+    REN_CHECK_LAUNCH();
+}
+
+extern "C" int ren_mlp_bwd(const float *mlp_params, int32_t C, const float *feat, const float *base_out,
+                           const ren_scene_desc *scene, const float *x_world, const float *dirs,
+                           const float *rays_o, const float *rays_d, const int32_t *ray_indices,
+                           const float *t_starts, const float *t_ends, int64_t n, const float *rgb,
+                           const float *d_rgb, const float *d_sigma, float *d_base, float *dfeat,
+                           float *grad_mlp_params, float *workspace, void *stream) {
+    if (!mlp_params || !feat || !base_out || !scene || !rgb || !d_rgb || !d_sigma || !d_base || !dfeat ||
+        !grad_mlp_params || !workspace || n < 0)
+        return REN_ERR_BAD_ARG;
+    if (C != 1 && C != 3) return REN_ERR_UNSUPPORTED;
+    if (!x_world && (!rays_o || !rays_d || !ray_indices || !t_starts || !t_ends)) return REN_ERR_BAD_ARG;
+    if (n == 0) return REN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    // > 64 KiB of dynamic LDS needs the attribute; setting it is idempotent (no library state)
+    (void)hipFuncSetAttribute((const void *)mlp_bwd_head_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_H_LDS);
+    (void)hipFuncSetAttribute((const void *)mlp_bwd_head_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_H_LDS);
+    (void)hipFuncSetAttribute((const void *)mlp_bwd_base_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_B_LDS);
+    const int head_len = p_total(C) - P_BASE_N;
+    float *slab_h = workspace, *slab_b = workspace + (int64_t)GRID_H * 4 * head_len;
+    BwdHArgs h;
+    h.params = mlp_params; h.base_out = base_out;
+    h.src = SampleSrc{x_world, dirs, rays_o, rays_d, x_world ? nullptr : ray_indices, t_starts, t_ends};
+    h.sc = ren_make_scene(scene);
+    h.n = n; h.rgb = rgb; h.d_rgb = d_rgb; h.d_sigma = d_sigma; h.d_base = d_base; h.slab = slab_h;
+    if (C == 1) hipLaunchKernelGGL((mlp_bwd_head_kernel<1>), dim3(GRID_H), dim3(256), BWD_H_LDS, st, h);
+    else        hipLaunchKernelGGL((mlp_bwd_head_kernel<3>), dim3(GRID_H), dim3(256), BWD_H_LDS, st, h);
+    BwdBArgs b;
+    b.params = mlp_params; b.feat = feat; b.d_base = d_base; b.n = n; b.dfeat = dfeat; b.slab = slab_b;
+    hipLaunchKernelGGL(mlp_bwd_base_kernel, dim3(GRID_B), dim3(256), BWD_B_LDS, st, b);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((head_len + 255) / 256), dim3(256), 0, st, slab_h,
+                       GRID_H * 4, head_len, grad_mlp_params + P_BASE_N);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((P_BASE_N + 255) / 256), dim3(256), 0, st, slab_b,
+                       GRID_B * 4, P_BASE_N, grad_mlp_params);
+    REN_CHECK_LAUNCH();
+}

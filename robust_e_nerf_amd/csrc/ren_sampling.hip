@@ -1,0 +1,366 @@
+// Ray / AABB intersection, occupancy-grid ray marching (two passes), visibility filtering and
+// packed-stream bookkeeping.  Replaces nerfacc==0.3.1 `ray_marching` (+ `ray_aabb_intersect`,
+// `render_visibility`, pack/unpack_info) as called at robust_e_nerf/external/utils.py:106-119.
+//
+// Compiled with -ffp-contract=off: interval endpoints and sample counts are a pure function of
+// un-fused float32 arithmetic so they match the sequential oracle (oracle/csrc/march.c) bit for
+// bit.  One thread per ray: rays are independent, the 2 MiB (128^3) / 16 MiB (256^3) occupancy
+// grid is L2 / Infinity-Cache resident, and the march is latency- not bandwidth-bound.
+#include "ren_common.h"
+
+namespace {
+
+struct MarchArgs {
+    float roi[6];
+    int res[3];
+    int type;
+    float step_size, cone_angle;
+    int mode, n_uniform;
+};
+
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+__global__ void ray_aabb_kernel(const float *__restrict__ o, const float *__restrict__ d, int64_t n,
+                                float a0, float a1, float a2, float a3, float a4, float a5,
+                                float near_plane, float far_plane,
+                                float *__restrict__ t_min, float *__restrict__ t_max) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *ro = o + 3 * i, *rd = d + 3 * i;
+    float tmin = (a0 - ro[0]) / rd[0], tmax = (a3 - ro[0]) / rd[0];
+    if (tmin > tmax) { float t = tmin; tmin = tmax; tmax = t; }
+    float tymin = (a1 - ro[1]) / rd[1], tymax = (a4 - ro[1]) / rd[1];
+    if (tymin > tymax) { float t = tymin; tymin = tymax; tymax = t; }
+    bool miss = (tmin > tymax) || (tymin > tmax);
+    if (!miss) {
+        if (tymin > tmin) tmin = tymin;
+        if (tymax < tmax) tmax = tymax;
+        float tzmin = (a2 - ro[2]) / rd[2], tzmax = (a5 - ro[2]) / rd[2];
+        if (tzmin > tzmax) { float t = tzmin; tzmin = tzmax; tzmax = t; }
+        miss = (tmin > tzmax) || (tzmin > tmax);
+        if (!miss) {
+            if (tzmin > tmin) tmin = tzmin;
+            if (tzmax < tmax) tmax = tzmax;
+        }
+    }
+    float lo, hi;
+    if (miss) { lo = 1e10f; hi = 1e10f; }
+    else { lo = tmin > 0.f ? tmin : 0.f; hi = tmax; }
+    if (near_plane == near_plane) lo = lo < near_plane ? near_plane : lo;   // torch.clamp(min=near)
+    if (far_plane == far_plane) hi = hi > far_plane ? far_plane : hi;       // torch.clamp(max=far)
+    t_min[i] = lo;
+    t_max[i] = hi;
+}
+
+__device__ __forceinline__ void roi_to_unit(const float *p, const float *roi, float *u) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) u[k] = (p[k] - roi[k]) / (roi[3 + k] - roi[k]);
+}
+
+__device__ __forceinline__ bool grid_occupied_at(const float *p, const MarchArgs &a,
+                                                 const uint8_t *__restrict__ binary) {
+    if (a.type == REN_CT_AABB) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (p[k] < a.roi[k] || p[k] > a.roi[3 + k]) return false;
+    }
+    float u[3];
+    roi_to_unit(p, a.roi, u);
+    if (a.type == REN_CT_SPHERE) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) u[k] = u[k] * 2.f - 1.f;
+        float norm = sqrtf(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+        if (norm > 1.f) {
+            float s = (2.f - 1.f / norm);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) u[k] = s * (u[k] / norm);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) u[k] = u[k] * 0.25f + 0.5f;
+    } else if (a.type == REN_CT_TANH) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) u[k] = tanhf(u[k] - 0.5f) * 0.5f + 0.5f;
+    }
+    int idx = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        int c = (int)(u[k] * (float)a.res[k]);
+        c = c < 0 ? 0 : (c > a.res[k] - 1 ? a.res[k] - 1 : c);
+        idx = idx * a.res[k] + c;
+    }
+    return binary[idx] != 0;
+}
+
+__device__ __forceinline__ float sgnf(float v) { return (float)((v > 0.f) - (v < 0.f)); }
+
+__device__ __forceinline__ float distance_to_next_voxel(const float *p, const float *dir,
+                                                        const float *inv_dir, const MarchArgs &a) {
+    float u[3], t = 1e30f;
+    roi_to_unit(p, a.roi, u);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float r = (float)a.res[k];
+        float x = u[k] * r;
+        float tx = ((floorf(x + 0.5f + 0.5f * sgnf(dir[k])) - x) * inv_dir[k]) / r * (a.roi[3 + k] - a.roi[k]);
+        if (tx < t) t = tx;
+    }
+    return t > 0.f ? t : 0.f;
+}
+
+__device__ __forceinline__ float calc_dt(float t, float cone_angle, float dt_min, float dt_max) {
+    return clampf(t * cone_angle, dt_min, dt_max);
+}
+
+template <bool WRITE>
+__global__ void ray_march_kernel(const float *__restrict__ o, const float *__restrict__ d,
+                                 const float *__restrict__ t_min, const float *__restrict__ t_max,
+                                 const float *__restrict__ jitter, int64_t n_rays, MarchArgs a,
+                                 const uint8_t *__restrict__ binary,
+                                 const int64_t *__restrict__ offsets, int32_t *__restrict__ counts,
+                                 int32_t *__restrict__ ray_indices, float *__restrict__ t_starts,
+                                 float *__restrict__ t_ends) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rays) return;
+    const float ro[3] = {o[3 * i], o[3 * i + 1], o[3 * i + 2]};
+    const float rd[3] = {d[3 * i], d[3 * i + 1], d[3 * i + 2]};
+    float near = t_min[i];
+    const float far = t_max[i];
+    const int64_t base = WRITE ? offsets[i] : 0;
+    int j = 0;
+    if (a.mode == 1) {
+        if (near < far) {
+            float delta = (far - near) / (float)a.n_uniform;
+            float first = jitter ? near + jitter[i] * delta : near;
+            if (WRITE) {
+                for (j = 0; j < a.n_uniform; ++j) {
+                    float t0 = first + (float)j * delta;
+                    t_starts[base + j] = t0;
+                    t_ends[base + j] = t0 + delta;
+                    ray_indices[base + j] = (int32_t)i;
+                }
+            }
+            j = a.n_uniform;
+        }
+        if (!WRITE) counts[i] = j;
+        return;
+    }
+    if (jitter) near = near + jitter[i] * a.step_size;      // stratified: one uniform per ray
+    const float inv_dir[3] = {1.f / rd[0], 1.f / rd[1], 1.f / rd[2]};
+    const float dt_min = a.step_size, dt_max = 1e10f;
+    float t0 = near;
+    float dt = calc_dt(t0, a.cone_angle, dt_min, dt_max);
+    float t1 = t0 + dt;
+    float t_mid = (t0 + t1) * 0.5f;
+    while (t_mid < far) {
+        float p[3] = {ro[0] + t_mid * rd[0], ro[1] + t_mid * rd[1], ro[2] + t_mid * rd[2]};
+        if (grid_occupied_at(p, a, binary)) {
+            if (WRITE) {
+                t_starts[base + j] = t0;
+                t_ends[base + j] = t1;
+                ray_indices[base + j] = (int32_t)i;
+            }
+            ++j;
+            t0 = t1;
+            t1 = t0 + calc_dt(t0, a.cone_angle, dt_min, dt_max);
+            t_mid = (t0 + t1) * 0.5f;
+        } else if (a.type == REN_CT_AABB) {
+            float t_target = t_mid + distance_to_next_voxel(p, rd, inv_dir, a);
+            do { t_mid += dt_min; } while (t_mid < t_target);
+            dt = calc_dt(t_mid, a.cone_angle, dt_min, dt_max);
+            t0 = t_mid - dt * 0.5f;
+            t1 = t_mid + dt * 0.5f;
+        } else {
+            t0 = t1;
+            t1 = t0 + calc_dt(t0, a.cone_angle, dt_min, dt_max);
+            t_mid = (t0 + t1) * 0.5f;
+        }
+    }
+    if (!WRITE) counts[i] = j;
+}
+
+// Single-workgroup exclusive scan (n_rays <= a few 100k: a handful of microseconds).
+__global__ __launch_bounds__(1024) void exclusive_scan_kernel(const int32_t *__restrict__ counts, int64_t n,
+                                                              int64_t *__restrict__ offsets,
+                                                              int64_t *__restrict__ total) {
+    __shared__ int64_t part[1024];
+    const int tid = threadIdx.x;
+    const int64_t per = (n + 1023) / 1024;
+    const int64_t b = tid * per, e = (b + per < n) ? b + per : n;
+    int64_t s = 0;
+    for (int64_t i = b; i < e; ++i) s += counts[i];
+    part[tid] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        int64_t v = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int64_t run = part[tid] - s;
+    for (int64_t i = b; i < e; ++i) { offsets[i] = run; run += counts[i]; }
+    if (tid == 1023 && total) total[0] = part[1023];
+}
+
+__global__ void visibility_kernel(const int64_t *__restrict__ offsets, const int32_t *__restrict__ counts,
+                                  int64_t n_rays, const float *__restrict__ sigmas,
+                                  const float *__restrict__ t_starts, const float *__restrict__ t_ends,
+                                  float eps, float alpha_thre, uint8_t *__restrict__ keep,
+                                  int32_t *__restrict__ kept_counts) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rays) return;
+    float T = 1.f;
+    int kept = 0;
+    const int64_t b = offsets[i], e = b + counts[i];
+    for (int64_t j = b; j < e; ++j) {
+        float alpha = 1.f - expf(-sigmas[j] * (t_ends[j] - t_starts[j]));
+        bool k = T >= eps;
+        if (alpha_thre > 0.f) k = k && (alpha >= alpha_thre);
+        keep[j] = (uint8_t)k;
+        kept += k;
+        T = T * (1.f - alpha);
+    }
+    kept_counts[i] = kept;
+}
+
+__global__ void compact_kernel(const int64_t *__restrict__ offsets, const int32_t *__restrict__ counts,
+                               const int64_t *__restrict__ new_offsets, int64_t n_rays,
+                               const uint8_t *__restrict__ keep, const float *__restrict__ t_starts,
+                               const float *__restrict__ t_ends, int32_t *__restrict__ out_ri,
+                               float *__restrict__ out_ts, float *__restrict__ out_te) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rays) return;
+    const int64_t b = offsets[i], e = b + counts[i];
+    int64_t w = new_offsets[i];
+    for (int64_t j = b; j < e; ++j) {
+        if (keep[j]) {
+            out_ri[w] = (int32_t)i;
+            out_ts[w] = t_starts[j];
+            out_te[w] = t_ends[j];
+            ++w;
+        }
+    }
+}
+
+__global__ void zero_i32_kernel(int32_t *p, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0;
+}
+
+__global__ void pack_info_kernel(const int32_t *__restrict__ ri, int64_t n, int64_t *__restrict__ offsets,
+                                 int32_t *__restrict__ counts) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t r = ri[i];
+    if (i == 0 || ri[i - 1] != r) {
+        // first sample of ray r: find run length by scanning forward is O(run); instead let the
+        // last sample of the run write the count.
+        offsets[r] = i;
+    }
+    if (i == n - 1 || ri[i + 1] != r) {
+        // run end: count = end - start; start is found by walking back (runs are <= 1024 long)
+        int64_t s = i;
+        while (s > 0 && ri[s - 1] == r) --s;
+        counts[r] = (int32_t)(i + 1 - s);
+    }
+}
+
+__global__ void fill_empty_offsets_kernel(int64_t *offsets, const int32_t *counts, int64_t n_rays) {
+    // rays without samples get offset 0 (never dereferenced since count == 0)
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_rays && counts[i] == 0) offsets[i] = 0;
+}
+
+}  // namespace
+
+extern "C" int ren_ray_aabb_intersect(const float *rays_o, const float *rays_d, int64_t n_rays,
+                                      const float *aabb, float near_plane, float far_plane,
+                                      float *t_min, float *t_max, void *stream) {
+    if (!rays_o || !rays_d || !aabb || !t_min || !t_max || n_rays < 0) return REN_ERR_BAD_ARG;
+    if (n_rays == 0) return REN_OK;
+    hipLaunchKernelGGL(ray_aabb_kernel, dim3(ren_blocks(n_rays, 256)), dim3(256), 0, (hipStream_t)stream,
+                       rays_o, rays_d, n_rays, aabb[0], aabb[1], aabb[2], aabb[3], aabb[4], aabb[5],
+                       near_plane, far_plane, t_min, t_max);
+    REN_CHECK_LAUNCH();
+}
+
+extern "C" int ren_ray_march(const float *rays_o, const float *rays_d, const float *t_min,
+                             const float *t_max, const float *jitter, int64_t n_rays,
+                             const float *roi, const int32_t *res, const uint8_t *binary,
+                             int32_t contraction_type, float step_size, float cone_angle,
+                             int32_t mode, int32_t n_uniform, const int64_t *offsets, int32_t *counts,
+                             int32_t *ray_indices, float *t_starts, float *t_ends, void *stream) {
+    if (!rays_o || !rays_d || !t_min || !t_max || n_rays < 0) return REN_ERR_BAD_ARG;
+    if (mode != 0 && mode != 1) return REN_ERR_BAD_ARG;
+    if (mode == 0 && (!roi || !res || !binary || step_size <= 0.f)) return REN_ERR_BAD_ARG;
+    if (mode == 1 && n_uniform <= 0) return REN_ERR_BAD_ARG;
+    if (contraction_type < 0 || contraction_type > 2) return REN_ERR_BAD_ARG;
+    const bool write = t_starts != nullptr;
+    if (write && (!offsets || !t_ends || !ray_indices)) return REN_ERR_BAD_ARG;
+    if (!write && !counts) return REN_ERR_BAD_ARG;
+    if (n_rays == 0) return REN_OK;
+    MarchArgs a;
+    for (int k = 0; k < 6; ++k) a.roi[k] = roi ? roi[k] : (k < 3 ? -1e10f : 1e10f);
+    for (int k = 0; k < 3; ++k) a.res[k] = res ? res[k] : 1;
+    a.type = contraction_type; a.step_size = step_size; a.cone_angle = cone_angle;
+    a.mode = mode; a.n_uniform = n_uniform;
+    dim3 grid(ren_blocks(n_rays, 64)), block(64);   // short blocks: ray lengths vary a lot
+    if (write)
+        hipLaunchKernelGGL(ray_march_kernel<true>, grid, block, 0, (hipStream_t)stream, rays_o, rays_d,
+                           t_min, t_max, jitter, n_rays, a, binary, offsets, counts, ray_indices,
+                           t_starts, t_ends);
+    else
+        hipLaunchKernelGGL(ray_march_kernel<false>, grid, block, 0, (hipStream_t)stream, rays_o, rays_d,
+                           t_min, t_max, jitter, n_rays, a, binary, offsets, counts, ray_indices,
+                           t_starts, t_ends);
+    REN_CHECK_LAUNCH();
+}
+
+extern "C" int ren_exclusive_scan(const int32_t *counts, int64_t n, int64_t *offsets, int64_t *total,
+                                  void *stream) {
+    if (!counts || !offsets || n < 0) return REN_ERR_BAD_ARG;
+    hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, counts, n,
+                       offsets, total);
+    REN_CHECK_LAUNCH();
+}
+
+extern "C" int ren_visibility(const int64_t *offsets, const int32_t *counts, int64_t n_rays,
+                              const float *sigmas, const float *t_starts, const float *t_ends,
+                              float early_stop_eps, float alpha_thre, uint8_t *keep,
+                              int32_t *kept_counts, void *stream) {
+    if (!offsets || !counts || !sigmas || !t_starts || !t_ends || !keep || !kept_counts || n_rays < 0)
+        return REN_ERR_BAD_ARG;
+    if (n_rays == 0) return REN_OK;
+    hipLaunchKernelGGL(visibility_kernel, dim3(ren_blocks(n_rays, 64)), dim3(64), 0, (hipStream_t)stream,
+                       offsets, counts, n_rays, sigmas, t_starts, t_ends, early_stop_eps, alpha_thre, keep,
+                       kept_counts);
+    REN_CHECK_LAUNCH();
+}
+
+extern "C" int ren_compact_samples(const int64_t *offsets, const int32_t *counts,
+                                   const int64_t *new_offsets, int64_t n_rays, const uint8_t *keep,
+                                   const float *t_starts, const float *t_ends,
+                                   int32_t *out_ray_indices, float *out_t_starts, float *out_t_ends,
+                                   void *stream) {
+    if (!offsets || !counts || !new_offsets || !keep || !t_starts || !t_ends || !out_ray_indices ||
+        !out_t_starts || !out_t_ends || n_rays < 0)
+        return REN_ERR_BAD_ARG;
+    if (n_rays == 0) return REN_OK;
+    hipLaunchKernelGGL(compact_kernel, dim3(ren_blocks(n_rays, 64)), dim3(64), 0, (hipStream_t)stream,
+                       offsets, counts, new_offsets, n_rays, keep, t_starts, t_ends, out_ray_indices,
+                       out_t_starts, out_t_ends);
+    REN_CHECK_LAUNCH();
+}
+
+extern "C" int ren_pack_info(const int32_t *ray_indices, int64_t n, int64_t n_rays, int64_t *offsets,
+                             int32_t *counts, void *stream) {
+    if (!offsets || !counts || n < 0 || n_rays < 0 || (n > 0 && !ray_indices)) return REN_ERR_BAD_ARG;
+    if (n_rays == 0) return REN_OK;
+    hipLaunchKernelGGL(zero_i32_kernel, dim3(ren_blocks(n_rays, 256)), dim3(256), 0, (hipStream_t)stream,
+                       counts, n_rays);
+    if (n > 0)
+        hipLaunchKernelGGL(pack_info_kernel, dim3(ren_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                           ray_indices, n, offsets, counts);
+    hipLaunchKernelGGL(fill_empty_offsets_kernel, dim3(ren_blocks(n_rays, 256)), dim3(256), 0,
+                       (hipStream_t)stream, offsets, counts, n_rays);
+    REN_CHECK_LAUNCH();
+}

@@ -1,0 +1,354 @@
+"""Fused fast path: the whole render / training step as explicit HIP launches (no autograd).
+
+This is the "one level up" seam of SURVEY.md 8b: ``Renderer.forward`` replaces
+``NeRF.forward`` -> ``render_image`` -> {``ray_marching``, ``rendering``} -> field
+(robust_e_nerf/models/nerf.py:230-286, external/utils.py:38-140) and ``Trainer.step`` replaces
+``RobustENeRF.training_step`` + backward + optimiser step
+(robust_e_nerf/models/robust_e_nerf.py:301-517, 782-813) for the log-intensity-difference loss.
+Gradients are written straight into one flat buffer ([hash table | MLPs]) so the data-parallel
+all-reduce is a single RCCL call and Adam a single fused pass.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field as dc_field
+from typing import Dict, Optional, Sequence, Tuple
+
+import torch
+
+from . import ops
+
+
+@dataclass
+class RenderCfg:
+    """model.nerf.* of configs/train/*.yaml that shapes the hot path."""
+    aabb: Tuple[float, ...] = (-1.5, -1.5, -1.5, 1.5, 1.5, 1.5)
+    contraction_type: int = ops.AABB
+    occ_res: Tuple[int, int, int] = (128, 128, 128)
+    near_plane: Optional[float] = None
+    far_plane: Optional[float] = None
+    render_step_size: float = math.sqrt(3) * 3.0 / 1024         # robust_e_nerf.py:220-226 ("auto")
+    cone_angle: float = 0.0
+    early_stop_eps: float = 1e-4
+    alpha_thre: float = 0.0
+    min_modeled_intensity: float = 1e-3
+    opacity_eps: float = 1e-10
+    radiance_dim: int = 1
+    sampler: str = "occgrid"                                     # "occgrid" | "uniform"
+    n_uniform: int = 128
+    occ_thre: float = 1e-2
+    ema_decay: float = 0.95
+    warmup_steps: int = 256
+    occ_n: int = 16
+
+
+class NGPField:
+    """Device-resident Instant-NGP parameters: one flat float32 buffer [hash table | MLP block]
+    plus an identically shaped gradient buffer (robust_e_nerf/external/ngp.py:166-205)."""
+
+    def __init__(self, device, radiance_dim: int = 1, pos_encoding: Optional[dict] = None):
+        pe = dict(n_levels=16, n_features_per_level=2, log2_hashmap_size=19, base_resolution=16,
+                  per_level_scale=1.4472692012786865)
+        if pos_encoding:
+            pe.update({k: v for k, v in pos_encoding.items() if k in pe})
+        self.grid, self.n_table = ops.make_grid_desc(**pe)
+        if self.grid.n_levels != 16:
+            raise NotImplementedError("the fused MLP kernels are built for 16 levels x 2 features")
+        self.C = radiance_dim
+        self.n_mlp = ops.mlp_param_count(radiance_dim)
+        n = self.n_table + self.n_mlp
+        self.n_params = n
+        n_pad = (n + 3) // 4 * 4
+        self.flat = torch.zeros(n_pad, device=device, dtype=torch.float32)
+        self.grad = torch.zeros(n_pad, device=device, dtype=torch.float32)
+        self.table = self.flat[: self.n_table]
+        self.mlp = self.flat[self.n_table: n]
+        self.g_table = self.grad[: self.n_table]
+        self.g_mlp = self.grad[self.n_table: n]
+
+    def load(self, p: Dict[str, torch.Tensor]):
+        """p: {"hash", "base.w0", ...} (torch nn.Linear layout, the oracle's / reference's names)."""
+        self.table.copy_(p["hash"].to(self.flat.device, torch.float32).reshape(-1))
+        for k, (off, shape) in ops.mlp_slices(self.C).items():
+            self.mlp[off: off + math.prod(shape)].copy_(p[k].to(self.flat.device, torch.float32).reshape(-1))
+
+    def mlp_views(self, grad: bool = False) -> Dict[str, torch.Tensor]:
+        buf = self.g_mlp if grad else self.mlp
+        return {k: buf[off: off + math.prod(shape)].view(shape) for k, (off, shape) in ops.mlp_slices(self.C).items()}
+
+
+@dataclass
+class Packed:
+    ray_indices: torch.Tensor
+    t_starts: torch.Tensor
+    t_ends: torch.Tensor
+    offsets: torch.Tensor
+    counts: torch.Tensor
+    n: int
+    n_marched: int = 0
+
+
+class Renderer:
+    def __init__(self, fld: NGPField, cfg: RenderCfg):
+        self.field = fld
+        self.cfg = cfg
+        self.scene = ops.make_scene_desc(cfg.aabb, cfg.contraction_type)
+        dev = fld.flat.device
+        cells = cfg.occ_res[0] * cfg.occ_res[1] * cfg.occ_res[2]
+        # nerfacc.OccupancyGrid buffers (models/nerf.py:98-102): zero until the first update
+        self.occs = torch.zeros(cells, device=dev, dtype=torch.float32)
+        self.binary = torch.zeros(cells, device=dev, dtype=torch.uint8)
+        self._scratch = torch.zeros(4, device=dev, dtype=torch.float32)
+        self._ws = torch.empty(ops.mlp_bwd_workspace_floats(fld.C), device=dev, dtype=torch.float32)
+
+    # ---- sampling (K1-K3): ray/AABB, two-pass march, no-grad density pre-pass + visibility --------
+    def sample(self, o, d, jitter: Optional[torch.Tensor], training: bool) -> Packed:
+        c = self.cfg
+        scene_aabb = c.aabb if c.contraction_type == ops.AABB else None           # nerf.py:248-251
+        if scene_aabb is not None:
+            t_min, t_max = ops.ray_aabb_intersect(o, d, scene_aabb, c.near_plane, c.far_plane)
+        else:
+            n = o.shape[0]
+            t_min = torch.full((n,), 0.0 if c.near_plane is None else c.near_plane, device=o.device)
+            t_max = torch.full((n,), 1e10 if c.far_plane is None else c.far_plane, device=o.device)
+        mode = 0 if c.sampler == "occgrid" else 1
+        jit = jitter if training else None
+        args = (o, d, t_min, t_max, jit, c.aabb, c.occ_res, self.binary, c.contraction_type,
+                c.render_step_size, c.cone_angle, mode, c.n_uniform)
+        counts = ops.ray_march_count(*args)
+        offsets, total = ops.exclusive_scan(counts)
+        n0 = int(total.item())                      # host sync, as in the reference (H4: next round)
+        ri, ts, te = ops.ray_march_write(*args, offsets, n0)
+        if mode == 1 or n0 == 0:
+            return Packed(ri, ts, te, offsets, counts, n0, n0)
+        # sigma_fn pre-pass (external/utils.py:68-81) + render_visibility
+        feat = ops.hashgrid_fwd(self.field.grid, self.field.table, scene=self.scene, rays=(o, d),
+                                samples=(ri, ts, te), n=n0, layout=1)
+        _, sigma, _ = ops.mlp_fwd(self.field.mlp, self.field.C, feat, self.scene, rays=(o, d),
+                                  samples=(ri, ts, te), n=n0, density_only=True)
+        keep, kept = ops.visibility(offsets, counts, sigma, ts, te, c.early_stop_eps, c.alpha_thre)
+        new_offsets, total2 = ops.exclusive_scan(kept)
+        n1 = int(total2.item())
+        ri2, ts2, te2 = ops.compact_samples(offsets, counts, new_offsets, keep, ts, te, n1)
+        return Packed(ri2, ts2, te2, new_offsets, kept, n1, n0)
+
+    # ---- forward render ---------------------------------------------------------------------------
+    def forward(self, o, d, jitter=None, bkgd: Optional[torch.Tensor] = None, training: bool = True,
+                save: bool = True):
+        f = self.field
+        pk = self.sample(o, d, jitter, training)
+        n_rays = o.shape[0]
+        if pk.n == 0:
+            colors = torch.zeros(n_rays, f.C, device=o.device)
+            if bkgd is not None:
+                colors = colors + bkgd
+            zero = torch.zeros(n_rays, device=o.device)
+            return colors, zero, zero.clone(), dict(pk=pk, empty=True)
+        feat = ops.hashgrid_fwd(f.grid, f.table, scene=self.scene, rays=(o, d),
+                                samples=(pk.ray_indices, pk.t_starts, pk.t_ends), n=pk.n, layout=1)
+        rgb, sigma, base = ops.mlp_fwd(f.mlp, f.C, feat, self.scene, rays=(o, d),
+                                       samples=(pk.ray_indices, pk.t_starts, pk.t_ends), n=pk.n,
+                                       save_base=save)
+        colors, opac, depth, w, T = ops.composite_fwd(pk.offsets, pk.counts, pk.t_starts, pk.t_ends, sigma, rgb,
+                                                      f.C, bkgd, save=save)
+        ctx = dict(pk=pk, o=o, d=d, feat=feat, rgb=rgb, sigma=sigma, base=base, w=w, T=T, opac=opac, bkgd=bkgd,
+                   empty=False)
+        return colors, opac, depth, ctx
+
+    # ---- backward: accumulates into field.grad, returns d(bkgd) -------------------------------------
+    def backward(self, ctx, g_colors, g_opac=None, g_depth=None):
+        f = self.field
+        if ctx["empty"]:
+            return g_colors.sum(0) if ctx.get("bkgd") is not None else None
+        pk = ctx["pk"]
+        d_sig, d_rgb, d_bk = ops.composite_bwd(pk.offsets, pk.counts, pk.t_starts, pk.t_ends, ctx["sigma"],
+                                               ctx["rgb"], f.C, ctx["bkgd"], ctx["w"], ctx["T"], ctx["opac"],
+                                               g_colors, g_opac, g_depth, want_bkgd=ctx["bkgd"] is not None)
+        samples = (pk.ray_indices, pk.t_starts, pk.t_ends)
+        dfeat = ops.mlp_bwd(f.mlp, f.C, ctx["feat"], ctx["base"], self.scene, rays=(ctx["o"], ctx["d"]),
+                            samples=samples, n=pk.n, rgb=ctx["rgb"], d_rgb=d_rgb, d_sigma=d_sig,
+                            grad_mlp_params=f.g_mlp, workspace=self._ws)
+        ops.hashgrid_bwd(f.grid, f.g_table, dfeat, scene=self.scene, rays=(ctx["o"], ctx["d"]), samples=samples,
+                         n=pk.n, layout=1)
+        return ops.column_sum(d_bk) if d_bk is not None else None
+
+    # ---- density query (occ_eval_fn / query_density) ----------------------------------------------------
+    def query_density(self, x_world: torch.Tensor) -> torch.Tensor:
+        """NGPradianceField.query_density(x) (ngp.py:230-254) for arbitrary world points."""
+        f = self.field
+        n = x_world.shape[0]
+        xu = contract_points(x_world, self.cfg.aabb, self.cfg.contraction_type)
+        feat = ops.hashgrid_fwd(f.grid, f.table, x_unit=xu, n=n, layout=1)
+        _, sigma, _ = ops.mlp_fwd(f.mlp, f.C, feat, self.scene, x_world=x_world, n=n, density_only=True)
+        return sigma
+
+    # ---- occupancy grid (K14): nerfacc OccupancyGrid.every_n_step as driven by nerf.py:170-204 ------------
+    def update_occ_grid(self, step: int, cam_positions: Optional[torch.Tensor] = None,
+                        generator: Optional[torch.Generator] = None, indices=None, jitter=None, cam_ids=None):
+        c = self.cfg
+        if step % c.occ_n != 0:
+            return False
+        dev = self.occs.device
+        cells = self.occs.numel()
+        if indices is None:
+            if step < c.warmup_steps:
+                indices = torch.arange(cells, device=dev)
+            else:
+                n = cells // 4
+                uni = torch.randint(cells, (n,), device=dev, generator=generator)
+                occ_idx = torch.nonzero(self.binary)[:, 0]
+                if n < occ_idx.numel():
+                    occ_idx = occ_idx[torch.randint(occ_idx.numel(), (n,), device=dev, generator=generator)]
+                indices = torch.cat([uni, occ_idx])
+        if jitter is None:
+            jitter = torch.rand(indices.shape[0], 3, device=dev, generator=generator)
+        x, valid = ops.occgrid_cell_points(indices, jitter, c.aabb, c.occ_res, c.contraction_type)
+        sigma = self.query_density(x)
+        step_sizes = None
+        if c.cone_angle > 0.0:                                                    # nerf.py:175-193
+            if cam_ids is None:
+                cam_ids = torch.randint(0, cam_positions.shape[0], (x.shape[0],), device=dev, generator=generator)
+            t = (cam_positions[cam_ids] - x).norm(dim=-1)
+            step_sizes = torch.clamp(t * c.cone_angle, min=c.render_step_size)
+            if c.near_plane is not None and c.far_plane is not None:
+                step_sizes = torch.where((t > c.near_plane) & (t < c.far_plane), step_sizes,
+                                         torch.zeros_like(step_sizes))
+            step_sizes = step_sizes.contiguous()
+        ops.occgrid_ema(self.occs, indices, valid, sigma, step_sizes, c.render_step_size, c.ema_decay)
+        ops.occgrid_binarize(self.occs, c.occ_thre, self.binary, self._scratch)
+        return True
+
+
+def contract_points(x_world: torch.Tensor, aabb: Sequence[float], ct: int) -> torch.Tensor:
+    """World -> unit cube for free-standing point queries (ngp.py:230-237); plumbing-level torch."""
+    ab = torch.tensor(aabb, device=x_world.device, dtype=torch.float32)
+    lo, hi = ab[:3], ab[3:]
+    x = (x_world - lo) / (hi - lo)
+    if ct == ops.UN_BOUNDED_SPHERE:
+        x = x * 2 - 1
+        mag = x.norm(dim=-1, keepdim=True)
+        x = torch.where(mag > 1, (2 - 1 / mag) * (x / mag), x)
+        x = x / 4 + 0.5
+    elif ct == ops.UN_BOUNDED_TANH:
+        x = (torch.tanh(x - 0.5) + 1) / 2
+    return x.contiguous()
+
+
+# ===================================================================================================
+@dataclass
+class TrainCfg:
+    """loss.* / optimizer.* of configs/train/synthetic.yaml."""
+    err_diff: str = "mse"
+    w_diff: float = 1.0
+    pw_diff: Optional[str] = "mean_contrast_reciprocal_sq"
+    lr: float = 0.01
+    weight_decay: float = 1e-6
+    betas: Tuple[float, float] = (0.9, 0.999)
+    eps: float = 1e-8
+    bkgd_is_param: bool = True
+
+
+class Trainer:
+    """Training step for the log-intensity-difference loss (two renders batched into one pass)."""
+
+    def __init__(self, renderer: Renderer, tcfg: TrainCfg, *, Kinv, tab_ts, tab_pos, tab_quat,
+                 p2n_raw, neg_ct, tau_raw, tau_max, bkgd_raw, world_size: int = 1, process_group=None):
+        self.r = renderer
+        self.t = tcfg
+        dev = renderer.field.flat.device
+        self.Kinv = Kinv.to(dev, torch.float32).contiguous()
+        self.tab_ts = tab_ts.to(dev).contiguous()
+        self.tab_pos = tab_pos.to(dev, torch.float32).contiguous()
+        self.tab_quat = tab_quat.to(dev, torch.float32).contiguous()
+        # C_p / C_n ratio and refractory period are frozen on this path (configs/train/synthetic.yaml:
+        # 31-36), so their parametrisations are evaluated once on the host:
+        ratio = torch.nn.functional.softplus(p2n_raw.detach().cpu().to(torch.float32))   # event_generation_params.py:51-70
+        neg = neg_ct.detach().cpu().to(torch.float32)
+        self.c_p, self.c_n = float(ratio * neg), float(neg)
+        self.mean_c = float((ratio * neg + neg) / 2)
+        traw, tmax = tau_raw.detach().cpu().to(torch.float64), tau_max.detach().cpu()
+        lim = torch.tensor(1e-4, dtype=torch.float64).logit().abs()
+        traw = tmax * (traw / tmax).clamp(-lim, lim)                          # :170-185
+        self.tau = float(tmax * torch.sigmoid(traw / tmax))                   # modules.py:58-74 (float64)
+        # small-parameter block: [bkgd_raw (C) | pad] with its own Adam state (group "others", lr default)
+        self.small = torch.zeros(4, device=dev, dtype=torch.float32)
+        self.small[: renderer.field.C] = bkgd_raw.to(dev, torch.float32).reshape(-1)
+        self.small_grad = torch.zeros_like(self.small)
+        f = renderer.field
+        self.m = torch.zeros_like(f.flat)
+        self.v = torch.zeros_like(f.flat)
+        self.sm = torch.zeros_like(self.small)
+        self.sv = torch.zeros_like(self.small)
+        self.step_count = 0
+        self.world_size = world_size
+        self.pg = process_group
+        self.lr_scale = 1.0
+
+    # ---- a2-a4: event correction + supervision timestamps (float64 elementwise, negligible) -------
+    def _prepare(self, batch):
+        ev_diff = batch["num_pos"] * self.c_p - batch["num_neg"] * self.c_n   # :72-84 (float32)
+        start = batch["start_ts"].to(torch.float64) + self.tau            # :196-203 (float64)
+        end = batch["end_ts"]
+        ts_diff = (end - start) * batch["u_ts_diff"]                      # robust_e_nerf.py:322-336
+        d_start = torch.lerp(start, torch.max(end - ts_diff, start), batch["u_diff_start"])
+        d_end = torch.min(d_start + ts_diff, end.to(torch.float64))
+        target_grad = ev_diff / (end - start)                             # loss.py:39-42 (float64)
+        target = (ts_diff * target_grad).to(torch.float32)                # loss.py:63-66
+        return d_start.contiguous(), d_end.contiguous(), target.contiguous()
+
+    def forward_backward(self, batch, jitter_start=None, jitter_end=None):
+        """Loss + gradients (no optimiser step).  Returns (loss tensor (device scalar), aux)."""
+        r, t, f = self.r, self.t, self.r.field
+        B = batch["position"].shape[0]
+        d_start, d_end, target = self._prepare(batch)
+        ts_all = torch.cat([d_start, d_end])
+        pos, rot = ops.trajectory(ts_all, self.tab_ts, self.tab_pos, self.tab_quat)
+        px = torch.cat([batch["position"], batch["position"]]).contiguous()
+        o, d = ops.raygen(self.Kinv, px, pos, rot)
+        jitter = None
+        if jitter_start is not None:
+            jitter = torch.cat([jitter_start, jitter_end]).to(torch.float32).contiguous()
+        bkgd = torch.nn.functional.softplus(self.small[: f.C]) if t.bkgd_is_param else None   # nerf.py:81-88
+        colors, opac, depth, ctx = r.forward(o, d, jitter, bkgd, training=True, save=True)
+        inten = colors[:, 0] + r.cfg.min_modeled_intensity               # robust_e_nerf.py:867 (monochrome)
+        i_s, i_e = inten[:B].contiguous(), inten[B:].contiguous()
+        valid = None
+        if not t.bkgd_is_param:                                           # :868-871, 442-443
+            valid = ((opac[:B] > 0) | (opac[B:] > 0)).to(torch.uint8).contiguous()
+        loss_sum = ops.event_loss_fwd(i_s, i_e, target, valid, t.err_diff)
+        inv_c = 1.0 / self.mean_c                                         # robust_e_nerf.py:470-486
+        pw = {None: 1.0, "mean_contrast_reciprocal": inv_c, "mean_contrast_reciprocal_sq": inv_c ** 2}[t.pw_diff]
+        scale = pw * t.w_diff
+        loss = loss_sum[0] / loss_sum[1] * scale
+        g_s, g_e = ops.event_loss_bwd(i_s, i_e, target, valid, t.err_diff, scale, loss_sum)
+        g_colors = torch.cat([g_s, g_e])[:, None].contiguous()
+        d_bkgd = r.backward(ctx, g_colors)
+        if d_bkgd is not None:
+            self.small_grad[: f.C] += d_bkgd * torch.sigmoid(self.small[: f.C])     # d softplus
+        aux = dict(intensity_start=i_s, intensity_end=i_e, n=ctx["pk"].n, n_marched=ctx["pk"].n_marched,
+                   opacity=opac, rays=2 * B)
+        return loss, aux
+
+    def optimizer_step(self):
+        """Adam on [hash table | MLPs] (lr default, L2 decay 1e-6: robust_e_nerf.py:786-813) and on the
+        background scalar (no decay).  Under data parallelism gradients are summed over ranks (RCCL
+        all-reduce of the single flat buffer) and scaled by 1/world inside the Adam kernel."""
+        f = self.r.field
+        if self.world_size > 1:
+            import torch.distributed as dist
+            dist.all_reduce(f.grad, group=self.pg)
+            dist.all_reduce(self.small_grad, group=self.pg)
+        self.step_count += 1
+        gs = 1.0 / self.world_size
+        lr = self.t.lr * self.lr_scale
+        ops.adam_step(f.flat, f.grad, self.m, self.v, lr=lr, betas=self.t.betas, eps=self.t.eps,
+                      weight_decay=self.t.weight_decay, step=self.step_count, grad_scale=gs, zero_grad=True)
+        ops.adam_step(self.small, self.small_grad, self.sm, self.sv, lr=lr, betas=self.t.betas, eps=self.t.eps,
+                      weight_decay=0.0, step=self.step_count, grad_scale=gs, zero_grad=True)
+
+    def step(self, batch, jitter_start=None, jitter_end=None, global_step: Optional[int] = None):
+        if global_step is not None:
+            self.r.update_occ_grid(global_step, self.tab_pos)
+        loss, aux = self.forward_backward(batch, jitter_start, jitter_end)
+        self.optimizer_step()
+        return loss, aux

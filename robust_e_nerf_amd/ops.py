@@ -1,0 +1,358 @@
+"""Thin tensor-level wrappers over the C ABI: torch owns memory and streams, the HIP library does
+the arithmetic.  Every function enqueues on ``torch.cuda.current_stream()`` and never syncs.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import GridDesc, SceneDesc, check
+
+AABB, UN_BOUNDED_TANH, UN_BOUNDED_SPHERE = 0, 1, 2
+FRAG_FLOATS_PER_BLOCK = 16 * 64          # hash features, fragment layout, per 32 samples
+BASE_FLOATS_PER_BLOCK = 8 * 64           # saved base-MLP outputs, per 32 samples
+
+_DT = {torch.float32: 4, torch.float64: 8, torch.int32: 4, torch.int64: 8, torch.uint8: 1, torch.bool: 1}
+
+
+def _ptr(t: Optional[torch.Tensor], dtype=None):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise ValueError("robust_e_nerf_amd kernels take device (ROCm) tensors; got a CPU tensor")
+    if not t.is_contiguous():
+        raise ValueError("tensor must be contiguous")
+    if dtype is not None and t.dtype not in (dtype if isinstance(dtype, tuple) else (dtype,)):
+        raise ValueError(f"expected dtype {dtype}, got {t.dtype}")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f(x):
+    return ctypes.c_float(float(x))
+
+
+NAN = float("nan")
+
+
+# ------------------------------------------------------------------------------- descriptors
+def make_grid_desc(n_levels=16, n_features_per_level=2, log2_hashmap_size=19, base_resolution=16,
+                   per_level_scale=1.4472692012786865) -> Tuple[GridDesc, int]:
+    """tcnn HashGrid level table (float32 arithmetic) -> (descriptor, number of float params)."""
+    import numpy as np
+    if n_features_per_level != 2:
+        raise NotImplementedError("n_features_per_level must be 2")
+    if n_levels > _lib.MAX_LEVELS:
+        raise NotImplementedError("n_levels must be <= 16")
+    g = GridDesc()
+    g.n_levels = n_levels
+    log2_pls = np.log2(np.float32(per_level_scale)).astype(np.float32)
+    offset = 0
+    for lvl in range(n_levels):
+        scale = np.float32(np.exp2(np.float32(lvl) * log2_pls).astype(np.float32) * np.float32(base_resolution)
+                           - np.float32(1.0))
+        res = int(np.ceil(scale)) + 1
+        dense = res ** 3
+        size = (min(dense, 2 ** 31 - 1) + 7) // 8 * 8
+        size = min(size, 1 << log2_hashmap_size)
+        g.scale[lvl] = float(scale)
+        g.res[lvl] = res
+        g.size[lvl] = size
+        g.offset[lvl] = offset
+        g.hashed[lvl] = 1 if dense > size else 0
+        offset += size
+    return g, offset * 2
+
+
+def make_scene_desc(aabb: Sequence[float], contraction_type: int) -> SceneDesc:
+    s = SceneDesc()
+    for k in range(6):
+        s.aabb[k] = float(aabb[k])
+    s.contraction_type = int(contraction_type)
+    return s
+
+
+def mlp_param_count(radiance_dim: int = 1) -> int:
+    return 9360 + 65 * radiance_dim
+
+
+MLP_SLICES = {  # name -> (offset, shape) for radiance_dim C (filled by mlp_slices)
+}
+
+
+def mlp_slices(C: int = 1):
+    """Views of the concatenated MLP parameter block in torch nn.Linear layout."""
+    return {
+        "base.w0": (0, (64, 32)), "base.b0": (2048, (64,)), "base.wo": (2112, (16, 64)), "base.bo": (3136, (16,)),
+        "head.w0": (3152, (64, 31)), "head.b0": (5136, (64,)), "head.w1": (5200, (64, 64)), "head.b1": (9296, (64,)),
+        "head.wo": (9360, (C, 64)), "head.bo": (9360 + 64 * C, (C,)),
+    }
+
+
+def n_blocks32(n: int) -> int:
+    return (n + 31) // 32
+
+
+# ------------------------------------------------------------------------------- pose / rays
+def trajectory(ts: torch.Tensor, tab_ts, tab_pos, tab_quat):
+    B = ts.shape[0]
+    pos = torch.empty(B, 3, device=ts.device, dtype=torch.float32)
+    rot = torch.empty(B, 3, 3, device=ts.device, dtype=torch.float32)
+    check(_lib.load().ren_trajectory_fwd(_ptr(ts, torch.float64), B, _ptr(tab_ts, torch.int64),
+                                         _ptr(tab_pos, torch.float32), _ptr(tab_quat, torch.float32),
+                                         tab_ts.shape[0], _ptr(pos), _ptr(rot), _stream()), "ren_trajectory_fwd")
+    return pos, rot
+
+
+def raygen(Kinv, px, pos, rot):
+    B = px.shape[0]
+    o = torch.empty(B, 3, device=px.device, dtype=torch.float32)
+    d = torch.empty(B, 3, device=px.device, dtype=torch.float32)
+    check(_lib.load().ren_raygen_fwd(_ptr(Kinv, torch.float32), _ptr(px, torch.float32), _ptr(pos, torch.float32),
+                                     _ptr(rot, torch.float32), B, _ptr(o), _ptr(d), _stream()), "ren_raygen_fwd")
+    return o, d
+
+
+# ------------------------------------------------------------------------------- sampling
+def ray_aabb_intersect(o, d, aabb: Sequence[float], near: Optional[float] = None, far: Optional[float] = None):
+    n = o.shape[0]
+    tmin = torch.empty(n, device=o.device, dtype=torch.float32)
+    tmax = torch.empty(n, device=o.device, dtype=torch.float32)
+    ab = (ctypes.c_float * 6)(*[float(v) for v in aabb])
+    check(_lib.load().ren_ray_aabb_intersect(_ptr(o, torch.float32), _ptr(d, torch.float32), n, ab,
+                                             _f(NAN if near is None else near), _f(NAN if far is None else far),
+                                             _ptr(tmin), _ptr(tmax), _stream()), "ren_ray_aabb_intersect")
+    return tmin, tmax
+
+
+def exclusive_scan(counts: torch.Tensor):
+    n = counts.shape[0]
+    offsets = torch.empty(n, device=counts.device, dtype=torch.int64)
+    total = torch.empty(1, device=counts.device, dtype=torch.int64)
+    check(_lib.load().ren_exclusive_scan(_ptr(counts, torch.int32), n, _ptr(offsets), _ptr(total), _stream()),
+          "ren_exclusive_scan")
+    return offsets, total
+
+
+def ray_march_count(o, d, t_min, t_max, jitter, roi, res, binary, ct, step, cone, mode, n_uniform):
+    n = o.shape[0]
+    counts = torch.empty(n, device=o.device, dtype=torch.int32)
+    roi_c = (ctypes.c_float * 6)(*[float(v) for v in roi])
+    res_c = (ctypes.c_int32 * 3)(*[int(v) for v in res])
+    check(_lib.load().ren_ray_march(_ptr(o), _ptr(d), _ptr(t_min), _ptr(t_max), _ptr(jitter), n, roi_c, res_c,
+                                    _ptr(binary, (torch.uint8, torch.bool)), ct, _f(step), _f(cone), mode, n_uniform,
+                                    None, _ptr(counts), None, None, None, _stream()), "ren_ray_march(count)")
+    return counts
+
+
+def ray_march_write(o, d, t_min, t_max, jitter, roi, res, binary, ct, step, cone, mode, n_uniform,
+                    offsets, n_total: int, out=None):
+    n = o.shape[0]
+    if out is None:
+        ri = torch.empty(n_total, device=o.device, dtype=torch.int32)
+        ts = torch.empty(n_total, device=o.device, dtype=torch.float32)
+        te = torch.empty(n_total, device=o.device, dtype=torch.float32)
+    else:
+        ri, ts, te = out
+    roi_c = (ctypes.c_float * 6)(*[float(v) for v in roi])
+    res_c = (ctypes.c_int32 * 3)(*[int(v) for v in res])
+    check(_lib.load().ren_ray_march(_ptr(o), _ptr(d), _ptr(t_min), _ptr(t_max), _ptr(jitter), n, roi_c, res_c,
+                                    _ptr(binary, (torch.uint8, torch.bool)), ct, _f(step), _f(cone), mode, n_uniform,
+                                    _ptr(offsets, torch.int64), None, _ptr(ri), _ptr(ts), _ptr(te), _stream()),
+          "ren_ray_march(write)")
+    return ri, ts, te
+
+
+def visibility(offsets, counts, sigmas, ts, te, eps: float, alpha_thre: float):
+    n_rays = counts.shape[0]
+    keep = torch.empty(ts.shape[0], device=ts.device, dtype=torch.uint8)
+    kept = torch.empty(n_rays, device=ts.device, dtype=torch.int32)
+    check(_lib.load().ren_visibility(_ptr(offsets, torch.int64), _ptr(counts, torch.int32), n_rays,
+                                     _ptr(sigmas, torch.float32), _ptr(ts), _ptr(te), _f(eps), _f(alpha_thre),
+                                     _ptr(keep), _ptr(kept), _stream()), "ren_visibility")
+    return keep, kept
+
+
+def compact_samples(offsets, counts, new_offsets, keep, ts, te, n_new: int):
+    n_rays = counts.shape[0]
+    ri2 = torch.empty(n_new, device=ts.device, dtype=torch.int32)
+    ts2 = torch.empty(n_new, device=ts.device, dtype=torch.float32)
+    te2 = torch.empty(n_new, device=ts.device, dtype=torch.float32)
+    check(_lib.load().ren_compact_samples(_ptr(offsets), _ptr(counts), _ptr(new_offsets), n_rays, _ptr(keep),
+                                          _ptr(ts), _ptr(te), _ptr(ri2), _ptr(ts2), _ptr(te2), _stream()),
+          "ren_compact_samples")
+    return ri2, ts2, te2
+
+
+def pack_info(ray_indices: torch.Tensor, n_rays: int):
+    n = ray_indices.shape[0]
+    offsets = torch.empty(n_rays, device=ray_indices.device, dtype=torch.int64)
+    counts = torch.empty(n_rays, device=ray_indices.device, dtype=torch.int32)
+    check(_lib.load().ren_pack_info(_ptr(ray_indices, torch.int32), n, n_rays, _ptr(offsets), _ptr(counts),
+                                    _stream()), "ren_pack_info")
+    return offsets, counts
+
+
+# ------------------------------------------------------------------------------- hash grid
+def hashgrid_fwd(grid: GridDesc, table, *, x_unit=None, scene: Optional[SceneDesc] = None, rays=None,
+                 samples=None, n: int, layout: int, out=None):
+    L = grid.n_levels
+    dev = table.device
+    if out is None:
+        out = (torch.empty(n, 2 * L, device=dev, dtype=torch.float32) if layout == 0
+               else torch.empty(n_blocks32(n) * FRAG_FLOATS_PER_BLOCK, device=dev, dtype=torch.float32))
+    o, d = rays if rays is not None else (None, None)
+    ri, ts, te = samples if samples is not None else (None, None, None)
+    check(_lib.load().ren_hashgrid_fwd(ctypes.byref(grid), _ptr(table, torch.float32), _ptr(x_unit),
+                                       ctypes.byref(scene) if scene is not None else None,
+                                       _ptr(o), _ptr(d), _ptr(ri), _ptr(ts), _ptr(te), n, layout, _ptr(out),
+                                       _stream()), "ren_hashgrid_fwd")
+    return out
+
+
+def hashgrid_bwd(grid: GridDesc, grad_table, dfeat, *, x_unit=None, scene=None, rays=None, samples=None,
+                 n: int, layout: int):
+    o, d = rays if rays is not None else (None, None)
+    ri, ts, te = samples if samples is not None else (None, None, None)
+    check(_lib.load().ren_hashgrid_bwd(ctypes.byref(grid), _ptr(grad_table, torch.float32), _ptr(x_unit),
+                                       ctypes.byref(scene) if scene is not None else None,
+                                       _ptr(o), _ptr(d), _ptr(ri), _ptr(ts), _ptr(te), n, layout,
+                                       _ptr(dfeat, torch.float32), _stream()), "ren_hashgrid_bwd")
+
+
+# ------------------------------------------------------------------------------- fused MLPs
+def mlp_fwd(mlp_params, C: int, feat, scene: SceneDesc, *, x_world=None, dirs=None, rays=None, samples=None,
+            n: int, density_only: bool = False, save_base: bool = False, out=None):
+    dev = feat.device
+    o, d = rays if rays is not None else (None, None)
+    ri, ts, te = samples if samples is not None else (None, None, None)
+    if out is None:
+        sigma = torch.empty(n, device=dev, dtype=torch.float32)
+        rgb = None if density_only else torch.empty(n, C, device=dev, dtype=torch.float32)
+        base = torch.empty(n_blocks32(n) * BASE_FLOATS_PER_BLOCK, device=dev, dtype=torch.float32) if save_base else None
+    else:
+        rgb, sigma, base = out
+    check(_lib.load().ren_mlp_fwd(_ptr(mlp_params, torch.float32), C, _ptr(feat, torch.float32), ctypes.byref(scene),
+                                  _ptr(x_world), _ptr(dirs), _ptr(o), _ptr(d), _ptr(ri), _ptr(ts), _ptr(te), n,
+                                  1 if density_only else 0, _ptr(rgb), _ptr(sigma), _ptr(base), _stream()),
+          "ren_mlp_fwd")
+    return rgb, sigma, base
+
+
+def mlp_bwd_workspace_floats(C: int) -> int:
+    return int(_lib.load().ren_mlp_bwd_workspace_floats(C))
+
+
+def mlp_bwd(mlp_params, C: int, feat, base_out, scene: SceneDesc, *, x_world=None, dirs=None, rays=None,
+            samples=None, n: int, rgb, d_rgb, d_sigma, grad_mlp_params, workspace, d_base=None, dfeat=None):
+    dev = feat.device
+    o, d = rays if rays is not None else (None, None)
+    ri, ts, te = samples if samples is not None else (None, None, None)
+    if d_base is None:
+        d_base = torch.empty(n_blocks32(n) * BASE_FLOATS_PER_BLOCK, device=dev, dtype=torch.float32)
+    if dfeat is None:
+        dfeat = torch.empty(n_blocks32(n) * FRAG_FLOATS_PER_BLOCK, device=dev, dtype=torch.float32)
+    check(_lib.load().ren_mlp_bwd(_ptr(mlp_params, torch.float32), C, _ptr(feat), _ptr(base_out),
+                                  ctypes.byref(scene), _ptr(x_world), _ptr(dirs), _ptr(o), _ptr(d), _ptr(ri),
+                                  _ptr(ts), _ptr(te), n, _ptr(rgb), _ptr(d_rgb), _ptr(d_sigma), _ptr(d_base),
+                                  _ptr(dfeat), _ptr(grad_mlp_params, torch.float32), _ptr(workspace), _stream()),
+          "ren_mlp_bwd")
+    return dfeat
+
+
+# ------------------------------------------------------------------------------- compositing
+def composite_fwd(offsets, counts, ts, te, sigmas, rgbs, C: int, bkgd, save: bool = True):
+    n_rays = counts.shape[0]
+    dev = ts.device
+    colors = torch.empty(n_rays, C, device=dev, dtype=torch.float32)
+    opac = torch.empty(n_rays, device=dev, dtype=torch.float32)
+    depth = torch.empty(n_rays, device=dev, dtype=torch.float32)
+    w = torch.empty(ts.shape[0], device=dev, dtype=torch.float32) if save else None
+    T = torch.empty(ts.shape[0], device=dev, dtype=torch.float32) if save else None
+    check(_lib.load().ren_composite_fwd(_ptr(offsets, torch.int64), _ptr(counts, torch.int32), n_rays, _ptr(ts),
+                                        _ptr(te), _ptr(sigmas), _ptr(rgbs), C, _ptr(bkgd), _ptr(colors), _ptr(opac),
+                                        _ptr(depth), _ptr(w), _ptr(T), _stream()), "ren_composite_fwd")
+    return colors, opac, depth, w, T
+
+
+def composite_bwd(offsets, counts, ts, te, sigmas, rgbs, C: int, bkgd, w, T, opac, g_colors, g_opac=None,
+                  g_depth=None, want_bkgd: bool = False):
+    n_rays = counts.shape[0]
+    dev = ts.device
+    d_sig = torch.empty(ts.shape[0], device=dev, dtype=torch.float32)
+    d_rgb = torch.empty(ts.shape[0], C, device=dev, dtype=torch.float32)
+    d_bk = torch.empty(n_rays, C, device=dev, dtype=torch.float32) if want_bkgd else None
+    check(_lib.load().ren_composite_bwd(_ptr(offsets), _ptr(counts), n_rays, _ptr(ts), _ptr(te), _ptr(sigmas),
+                                        _ptr(rgbs), C, _ptr(bkgd), _ptr(w), _ptr(T), _ptr(opac),
+                                        _ptr(g_colors, torch.float32), _ptr(g_opac), _ptr(g_depth), _ptr(d_sig),
+                                        _ptr(d_rgb), _ptr(d_bk), _stream()), "ren_composite_bwd")
+    return d_sig, d_rgb, d_bk
+
+
+def column_sum(x: torch.Tensor):
+    rows, C = x.shape
+    out = torch.empty(C, device=x.device, dtype=torch.float32)
+    check(_lib.load().ren_column_sum(_ptr(x, torch.float32), rows, C, _ptr(out), _stream()), "ren_column_sum")
+    return out
+
+
+# ------------------------------------------------------------------------------- loss / optimiser
+ERR_FN = {"l1": 0, "mse": 1, "mape": 2}
+
+
+def event_loss_fwd(i_start, i_end, target, valid, err_fn: str):
+    if err_fn not in ERR_FN:
+        raise NotImplementedError(err_fn)
+    loss_sum = torch.empty(2, device=i_start.device, dtype=torch.float32)
+    check(_lib.load().ren_event_loss_fwd(_ptr(i_start, torch.float32), _ptr(i_end, torch.float32),
+                                         _ptr(target, torch.float32), _ptr(valid), i_start.shape[0], ERR_FN[err_fn],
+                                         _ptr(loss_sum), _stream()), "ren_event_loss_fwd")
+    return loss_sum
+
+
+def event_loss_bwd(i_start, i_end, target, valid, err_fn: str, scale: float, loss_sum):
+    g_s = torch.empty_like(i_start)
+    g_e = torch.empty_like(i_end)
+    check(_lib.load().ren_event_loss_bwd(_ptr(i_start), _ptr(i_end), _ptr(target), _ptr(valid), i_start.shape[0],
+                                         ERR_FN[err_fn], _f(scale), _ptr(loss_sum), _ptr(g_s), _ptr(g_e), _stream()),
+          "ren_event_loss_bwd")
+    return g_s, g_e
+
+
+def adam_step(p, g, m, v, *, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, step: int, grad_scale=1.0,
+              zero_grad=True):
+    check(_lib.load().ren_adam_step(_ptr(p, torch.float32), _ptr(g, torch.float32), _ptr(m, torch.float32),
+                                    _ptr(v, torch.float32), p.numel(), _f(lr), _f(betas[0]), _f(betas[1]), _f(eps),
+                                    _f(weight_decay), int(step), _f(grad_scale), 1 if zero_grad else 0, _stream()),
+          "ren_adam_step")
+
+
+# ------------------------------------------------------------------------------- occupancy grid
+def occgrid_cell_points(indices, jitter, roi, res, ct):
+    m = indices.shape[0]
+    x = torch.empty(m, 3, device=indices.device, dtype=torch.float32)
+    valid = torch.empty(m, device=indices.device, dtype=torch.uint8)
+    roi_c = (ctypes.c_float * 6)(*[float(v) for v in roi])
+    res_c = (ctypes.c_int32 * 3)(*[int(v) for v in res])
+    check(_lib.load().ren_occgrid_cell_points(_ptr(indices, torch.int64), _ptr(jitter, torch.float32), m, roi_c, res_c,
+                                              ct, _ptr(x), _ptr(valid), _stream()), "ren_occgrid_cell_points")
+    return x, valid
+
+
+def occgrid_ema(occs, indices, valid, sigma, step_sizes, step_size: float, decay: float):
+    check(_lib.load().ren_occgrid_ema(_ptr(occs, torch.float32), _ptr(indices, torch.int64), _ptr(valid),
+                                      _ptr(sigma, torch.float32), _ptr(step_sizes), _f(step_size), indices.shape[0],
+                                      _f(decay), _stream()), "ren_occgrid_ema")
+
+
+def occgrid_binarize(occs, occ_thre: float, binary, scratch):
+    check(_lib.load().ren_occgrid_binarize(_ptr(occs, torch.float32), occs.numel(), _f(occ_thre),
+                                           _ptr(binary, (torch.uint8, torch.bool)), _ptr(scratch, torch.float32),
+                                           _stream()), "ren_occgrid_binarize")
