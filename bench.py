@@ -1,0 +1,245 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path: one training step = event batch -> poses -> rays -> sampling ->
+hash grid -> fused MLPs -> compositing -> event loss -> backward -> (all-reduce) -> Adam.
+
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 is launched by the driver through torch.distributed.run (one process per GPU, RCCL).
+Workload = BASELINE.json configs[1]: synthetic 'ficus'-like event stream, 65 536 events per step
+(two renders = 131 072 rays), 128 samples per ray, fp32, default synthetic.yaml NGP model.
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant
+kernel (HIP-event timed inside the timed region) and `cpu_baseline` (the CPU oracle on a bounded
+sample of the same workload, rank 0, N = 1 only).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+# algorithmic bytes per differentiable sample (DESIGN.md "Roofline"):
+BYTES = {"hashgrid_fwd": 1024 + 12, "hashgrid_bwd": 2048 + 12}
+
+
+def synthetic_scene(n_poses=2001, seed=0):
+    """radius-4 orbit with slow z oscillation looking at the origin, 1 ms pose spacing,
+    346x260 camera, K = [[480,0,172.5],[0,480,129.5],[0,0,1]]."""
+    k = np.arange(n_poses)
+    ang = 2 * np.pi * k / (n_poses - 1) * 1.5
+    pos = np.stack([4 * np.cos(ang), 4 * np.sin(ang), 0.6 * np.sin(3 * ang)], -1)
+    fwd = -pos / np.linalg.norm(pos, axis=-1, keepdims=True)
+    right = np.cross(fwd, np.array([0.0, 0.0, 1.0]))
+    right /= np.linalg.norm(right, axis=-1, keepdims=True)
+    down = np.cross(fwd, right)
+    Rm = np.stack([right, down, fwd], -1)
+    from scipy.spatial.transform import Rotation
+    quat = Rotation.from_matrix(Rm).as_quat().astype(np.float32)
+    ts = (k * 1_000_000).astype(np.int64)
+    K = np.array([[480.0, 0, 172.5], [0, 480.0, 129.5], [0, 0, 1]], np.float32)
+    return ts, pos.astype(np.float32), quat, np.linalg.inv(K).astype(np.float32)
+
+
+def synthetic_events(B, t_end_ns, seed):
+    g = np.random.default_rng(seed)
+    px = np.stack([g.integers(0, 346, B), g.integers(0, 260, B)], -1).astype(np.float32)
+    end = g.integers(20_000_000, t_end_ns, B).astype(np.int64)
+    delta = np.exp(g.uniform(np.log(2e5), np.log(2e7), B)).astype(np.int64)
+    pol = g.random(B) < 0.5
+    return dict(position=px, start_ts=end - delta, end_ts=end, num_pos=pol.astype(np.int64),
+                num_neg=(~pol).astype(np.int64), u_ts_diff=np.ones(B), u_diff_start=g.uniform(0, 1, B))
+
+
+def ball_binary(res, radius, aabb):
+    lo, hi = np.array(aabb[:3]), np.array(aabb[3:])
+    g = np.stack(np.meshgrid(*[np.arange(res)] * 3, indexing="ij"), -1)
+    c = (g + 0.5) / res * (hi - lo) + lo
+    return (np.linalg.norm(c, axis=-1) < radius).astype(np.uint8).reshape(-1)
+
+
+def cpu_baseline(args, scene, params_cpu, table_seed):
+    """The CPU oracle (kind 'port': the reference itself cannot execute on a CPU) on a bounded
+    sample: config A = 2 x 2048 rays x 64 samples, forward + backward + Adam, all host cores."""
+    from oracle import field as ofield, hashgrid, step as ostep
+    torch.set_num_threads(os.cpu_count())
+    tab_ts, tab_pos, tab_quat, Kinv = scene
+    spec = hashgrid.make_spec()
+    p = {k: v.clone().requires_grad_() for k, v in params_cpu.items()}
+    bk = torch.tensor([0.5413]).requires_grad_()
+    B, S = 2048, 64
+    opt = torch.optim.Adam([{"params": list(p.values()), "weight_decay": 1e-6}, {"params": [bk]}], lr=0.01)
+    cfg = ostep.SceneCfg(sampler="uniform", n_uniform=S)
+    T = torch.from_numpy
+    times, n_samples = [], 0
+    for it in range(3):
+        ev = synthetic_events(B, int(tab_ts[-1]), seed=100 + it)
+        batch = ostep.EventBatch(*(T(ev[k]) for k in ("position", "start_ts", "end_ts", "num_pos", "num_neg",
+                                                       "u_ts_diff", "u_diff_start")), T(np.zeros(B)))
+        g = torch.Generator().manual_seed(it)
+        t0 = time.perf_counter()
+        loss, aux = ostep.training_forward(
+            batch, p, spec, cfg, Kinv=T(Kinv), tab_ts=T(tab_ts), tab_pos=T(tab_pos), tab_quat=T(tab_quat),
+            p2n_raw=torch.tensor(0.5413), neg_ct=torch.tensor(0.25), tau_raw=torch.tensor(0.0, dtype=torch.float64),
+            tau_max=torch.tensor(1e5), bkgd_raw=bk, binary=None, jitter_start=torch.rand(B, generator=g),
+            jitter_end=torch.rand(B, generator=g))
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+        n_samples = aux["n_start"] + aux["n_end"]
+    best = min(times[1:]) if len(times) > 1 else times[0]
+    return {"value": 2 * B / best, "unit": "rays/s", "samples_per_sec": n_samples / best, "cores": torch.get_num_threads(),
+            "kind": "port", "sample": f"3 steps of 2x{B} rays x {S} samples (config A), fwd+bwd+Adam, best of last 2: {best:.2f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--events", type=int, default=65536, help="events per step per GPU (2 rays each)")
+    ap.add_argument("--samples", type=int, default=128, help="samples per ray (uniform sampler)")
+    ap.add_argument("--sampler", default="uniform", choices=["uniform", "occgrid"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verbose", action="store_true")
+    args = ap.parse_args()
+    import faulthandler
+    faulthandler.enable()
+    faulthandler.dump_traceback_later(900, exit=False, file=sys.stderr)
+
+    def log(*a):
+        if args.verbose:
+            print(f"[bench {time.perf_counter():.1f}]", *a, file=sys.stderr, flush=True)
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("for --gpus N > 1 launch with torch.distributed.run --nproc-per-node N")
+    import torch.distributed as dist
+    pg = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl")
+    dev = f"cuda:{local_rank}"
+    torch.cuda.set_device(local_rank)
+
+    from oracle import hashgrid                      # only for the portable seeded table generator
+    from robust_e_nerf_amd import engine, ops
+
+    scene = synthetic_scene()
+    tab_ts, tab_pos, tab_quat, Kinv = scene
+    T = torch.from_numpy
+    # field parameters: torch nn.Linear default init, hash table U(+-0.1) ("trained-like": random
+    # operands keep clocks honest, MI355X_MICROARCH.md DVFS note)
+    gen = torch.Generator().manual_seed(0)
+
+    def lin(o, i):
+        b = 1 / math.sqrt(i)
+        return (torch.rand(o, i, generator=gen) * 2 - 1) * b, (torch.rand(o, generator=gen) * 2 - 1) * b
+    p = {}
+    p["base.w0"], p["base.b0"] = lin(64, 32)
+    p["base.wo"], p["base.bo"] = lin(16, 64)
+    p["head.w0"], p["head.b0"] = lin(64, 31)
+    p["head.w1"], p["head.b1"] = lin(64, 64)
+    p["head.wo"], p["head.bo"] = lin(1, 64)
+    p["hash"] = hashgrid.init_table(hashgrid.make_spec(), 0, 0.1, "mix32")
+
+    aabb = (-1.5, -1.5, -1.5, 1.5, 1.5, 1.5)
+    cfg = engine.RenderCfg(aabb=aabb, sampler=args.sampler, n_uniform=args.samples)
+    fld = engine.NGPField(dev)
+    fld.load(p)
+    r = engine.Renderer(fld, cfg)
+    if args.sampler == "occgrid":
+        r.binary.copy_(T(ball_binary(128, 0.42, aabb)).to(dev))
+    tr = engine.Trainer(r, engine.TrainCfg(), Kinv=T(Kinv), tab_ts=T(tab_ts), tab_pos=T(tab_pos), tab_quat=T(tab_quat),
+                        p2n_raw=torch.tensor(0.5413), neg_ct=torch.tensor(0.25),
+                        tau_raw=torch.tensor(0.0, dtype=torch.float64), tau_max=torch.tensor(1e5),
+                        bkgd_raw=torch.tensor([0.5413]), world_size=world, process_group=pg)
+
+    B = args.events
+    n_batches = 4                                    # pre-staged in HBM; per-rank seeds (datamodule.py:85-89)
+    batches = []
+    for b in range(n_batches):
+        ev = synthetic_events(B, int(tab_ts[-1]), seed=1 + 1000 * rank + b)
+        batches.append({k: T(v).to(dev).contiguous() for k, v in ev.items()})
+    jgen = torch.Generator(device=dev).manual_seed(3 + rank)
+
+    def one_step(i):
+        j0 = torch.rand(B, device=dev, generator=jgen)
+        j1 = torch.rand(B, device=dev, generator=jgen)
+        loss, aux = tr.forward_backward(batches[i % n_batches], j0, j1)
+        tr.optimizer_step()
+        return loss, aux
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    log("setup done")
+    for i in range(args.warmup):
+        one_step(i)
+        if args.verbose:
+            torch.cuda.synchronize()
+            log("warmup step", i)
+    barrier()
+    ops.profile_start()
+    t0 = time.perf_counter()
+    n_samples = 0
+    for i in range(args.steps):
+        loss, aux = one_step(i)
+        n_samples += aux["n"]
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = ops.profile_stop()
+    log("timed region done", dt)
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
+        ns = torch.tensor([n_samples], device=dev, dtype=torch.float64)
+        dist.all_reduce(ns)
+        n_samples = float(ns)
+    rays = 2 * B * args.steps * world
+
+    if rank == 0:
+        kern = {k: {"launches": c, "avg_ms": ms / max(c, 1)} for k, (c, ms) in prof.items()}
+        dom = max(BYTES, key=lambda k: prof.get(k, (0, 0.0))[1])
+        c, ms = prof[dom]
+        samples_per_launch = n_samples / world / args.steps
+        achieved = BYTES[dom] * samples_per_launch / (ms / c * 1e-3) / 1e9
+        out = {
+            "metric": "train_rays_per_sec", "value": rays / dt, "unit": "rays/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "mlp_samples_per_sec": n_samples / dt, "mean_samples_per_ray": n_samples / rays,
+            "loss": float(loss),
+            "config": {"workload": "BASELINE configs[1]: synthetic ficus-like event stream, "
+                                   f"{B} events/step/GPU = {2 * B} rays x {args.samples} samples, arch ngp, fp32, "
+                                   f"l_diff (2 renders), fwd+bwd+Adam; sampler={args.sampler}",
+                       "events_per_step_per_gpu": B, "rays_per_step_per_gpu": 2 * B, "sampler": args.sampler,
+                       "samples_per_ray": args.samples, "parallelism": f"dp{world}"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_sample": BYTES[dom], "avg_launch_ms": ms / c},
+            "kernels": kern,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, scene, {k: v.clone() for k, v in p.items()}, 0)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -104,7 +104,7 @@ def _corner_index(cx, cy, cz, res: int, size: int, is_hashed: bool):
     return idx % size
 
 
-def encode(x: torch.Tensor, table: torch.Tensor, spec: HashGridSpec) -> torch.Tensor:
+def encode(x: torch.Tensor, table: torch.Tensor, spec: HashGridSpec, chunk: int = 1 << 19) -> torch.Tensor:
     """x: (n,3) in the unit cube (float32 or float64); table: (n_params,) -> (n, L*F).
 
     Differentiable w.r.t. ``table`` and ``x`` (and twice differentiable), which is what
@@ -112,9 +112,11 @@ def encode(x: torch.Tensor, table: torch.Tensor, spec: HashGridSpec) -> torch.Te
     (``robust_e_nerf/models/robust_e_nerf.py:395-398``).
     """
     assert x.dim() == 2 and x.shape[-1] == 3
+    if x.shape[0] > chunk:
+        return torch.cat([encode(x[i:i + chunk], table, spec, chunk) for i in range(0, x.shape[0], chunk)], 0)
     F = spec.n_features_per_level
     tab = table.view(-1, F)
-    outs: List[torch.Tensor] = []
+    idx_all, w_all = [], []
     for lvl in range(spec.n_levels):
         scale = spec.scales[lvl]
         if x.dtype == torch.float32:
@@ -127,19 +129,21 @@ def encode(x: torch.Tensor, table: torch.Tensor, spec: HashGridSpec) -> torch.Te
         cell_f = torch.floor(pos.detach())
         w = pos - cell_f                                   # (n,3)
         cell = cell_f.to(torch.int64)
-        feat = torch.zeros(x.shape[0], F, dtype=table.dtype, device=x.device)
         for corner in range(8):
             bx, by, bz = corner & 1, (corner >> 1) & 1, (corner >> 2) & 1
             wx = w[:, 0] if bx else 1 - w[:, 0]
             wy = w[:, 1] if by else 1 - w[:, 1]
             wz = w[:, 2] if bz else 1 - w[:, 2]
-            idx = _corner_index(
+            idx_all.append(spec.offsets[lvl] + _corner_index(
                 cell[:, 0] + bx, cell[:, 1] + by, cell[:, 2] + bz,
-                spec.resolutions[lvl], spec.sizes[lvl], spec.hashed[lvl],
-            )
-            feat = feat + (wx * wy * wz).to(table.dtype)[:, None] * tab[spec.offsets[lvl] + idx]
-        outs.append(feat)
-    return torch.cat(outs, dim=-1)
+                spec.resolutions[lvl], spec.sizes[lvl], spec.hashed[lvl]))
+            w_all.append((wx * wy * wz).to(table.dtype))
+    # ONE gather for all levels x corners: autograd's backward is then a single dense
+    # index_add instead of 128 (each of which would allocate a 50 MB gradient).
+    idx = torch.stack(idx_all, dim=1)                      # (n, L*8)
+    wts = torch.stack(w_all, dim=1)                        # (n, L*8)
+    feats = tab[idx.reshape(-1)].view(x.shape[0], spec.n_levels, 8, F)
+    return (wts.view(x.shape[0], spec.n_levels, 8, 1) * feats).sum(dim=2).reshape(x.shape[0], -1)
 
 
 def mix32_uniform(n: int, seed: int) -> np.ndarray:

@@ -73,6 +73,10 @@ def load() -> ctypes.CDLL:
         raise RenError(
             f"{LIB_PATH} is missing: build it with `python -m robust_e_nerf_amd.build` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    # PyTorch-ROCm bundles its own libamdhip64; it must be in the process BEFORE this library so
+    # both resolve to the SAME HIP runtime (otherwise torch's device pointers are foreign to our
+    # launches and every kernel fails with a launch error).
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         try:

@@ -3,13 +3,25 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
+#include <stdio.h>
 #include "../../include/ren_amd.h"
 
 #define REN_WAVE 64
 
+// hipGetLastError() is sticky per thread: PyTorch's own runtime calls may leave a benign error
+// behind, so clear it right before every launch and report only what our launch produced.
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)            \
+    do {                                                                        \
+        (void)hipGetLastError();                                                \
+        kernel<<<(grid), (block), (shmem), (stream)>>>(__VA_ARGS__);            \
+    } while (0)
+
 #define REN_CHECK_LAUNCH()                                   \
     do {                                                     \
         hipError_t e__ = hipGetLastError();                  \
+        if (e__ != hipSuccess)                               \
+            fprintf(stderr, "[ren_amd] %s:%d launch error: %s\n", __FILE__, __LINE__, hipGetErrorString(e__)); \
         return e__ == hipSuccess ? REN_OK : REN_ERR_LAUNCH;  \
     } while (0)
 

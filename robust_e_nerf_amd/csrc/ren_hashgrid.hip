@@ -12,6 +12,7 @@
 // Output layout 1 ("fragment order") is what the fused MLP kernels consume directly as MFMA
 // B-operands: feat[((i>>5)*16 + level)*64 + f*32 + (i&31)].
 #include "ren_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -50,14 +51,30 @@ __device__ __forceinline__ LevelPos level_pos(float x, float y, float z, float s
     return p;
 }
 
+// Block -> (level, sample chunk).  XCD-affine mode: workgroup b runs on XCD b % 8 (observed
+// dispatch order; used for speed only), so giving XCD x the levels {x, x+8} keeps each level's
+// <= 4 MiB table slice in ONE XCD's 4 MiB L2: gathers hit that L2 and -- more importantly --
+// atomics on a cache line are never issued from two different (mutually incoherent) L2s.
+__device__ __forceinline__ bool block_to_work(int xcd_affine, int n_levels, int64_t n_chunks, int &lvl,
+                                              int64_t &chunk) {
+    if (!xcd_affine) { lvl = blockIdx.y; chunk = blockIdx.x; return true; }
+    const int64_t b = blockIdx.x;
+    const int64_t j = b >> 3;
+    const int slot = (int)(j / n_chunks);
+    chunk = j - slot * n_chunks;
+    lvl = (int)(b & 7) + 8 * slot;
+    return lvl < n_levels;
+}
+
 template <int LAYOUT, bool FROM_RAYS>
 __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(
     GridDev g, const float2 *__restrict__ table, const float *__restrict__ x_unit, ren_scene_dev sc,
     const float *__restrict__ rays_o, const float *__restrict__ rays_d,
     const int32_t *__restrict__ ray_indices, const float *__restrict__ t_starts,
-    const float *__restrict__ t_ends, int64_t n, int64_t n_pad, float *__restrict__ feat) {
-    const int lvl = blockIdx.y;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const float *__restrict__ t_ends, int64_t n, int64_t n_pad, float *__restrict__ feat, int xcd_affine) {
+    int lvl; int64_t chunk;
+    if (!block_to_work(xcd_affine, g.n_levels, (n_pad + 255) / 256, lvl, chunk)) return;
+    const int64_t i = chunk * blockDim.x + threadIdx.x;
     if (i >= n_pad) return;
     float f0 = 0.f, f1 = 0.f;
     if (i < n) {
@@ -99,14 +116,22 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(
     }
 }
 
-template <int LAYOUT, bool FROM_RAYS>
+template <int LAYOUT, bool FROM_RAYS, bool PAIR>
 __global__ __launch_bounds__(256) void hashgrid_bwd_kernel(
     GridDev g, float *__restrict__ grad_table, const float *__restrict__ x_unit, ren_scene_dev sc,
     const float *__restrict__ rays_o, const float *__restrict__ rays_d,
     const int32_t *__restrict__ ray_indices, const float *__restrict__ t_starts,
-    const float *__restrict__ t_ends, int64_t n, const float *__restrict__ dfeat) {
-    const int lvl = blockIdx.y;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const float *__restrict__ t_ends, int64_t n, const float *__restrict__ dfeat, int xcd_affine) {
+    int lvl; int64_t chunk;
+    if (PAIR) {
+        if (!block_to_work(xcd_affine, g.n_levels, (n + 127) / 128, lvl, chunk)) return;
+    } else {
+        if (!block_to_work(xcd_affine, g.n_levels, (n + 255) / 256, lvl, chunk)) return;
+    }
+    // PAIR: two adjacent lanes share a sample and take one feature each, so one atomic
+    // instruction covers 32 (sample, corner) pairs x 2 features with 8-byte contiguous targets.
+    const int64_t i = PAIR ? chunk * 128 + (threadIdx.x >> 1) : chunk * blockDim.x + threadIdx.x;
+    const int feat_sel = PAIR ? (threadIdx.x & 1) : 0;
     if (i >= n) return;
     float d0, d1;
     if (LAYOUT == 0) {
@@ -117,7 +142,8 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_kernel(
         d0 = dfeat[b];
         d1 = dfeat[b + 32];
     }
-    if (d0 == 0.f && d1 == 0.f) return;
+    if (PAIR) { d0 = feat_sel ? d1 : d0; if (d0 == 0.f) return; }
+    else if (d0 == 0.f && d1 == 0.f) return;
     float ux, uy, uz;
     if (FROM_RAYS) {
         float x, y, z; int ray;
@@ -138,9 +164,20 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_kernel(
         const float wy = (c & 2) ? p.w[1] : 1.f - p.w[1];
         const float wz = (c & 4) ? p.w[2] : 1.f - p.w[2];
         const float w = wx * wy * wz;
-        atomicAdd(gt + 2 * (size_t)idx, w * d0);
-        atomicAdd(gt + 2 * (size_t)idx + 1, w * d1);
+        if (PAIR) {
+            atomicAdd(gt + 2 * (size_t)idx + feat_sel, w * d0);
+        } else {
+            atomicAdd(gt + 2 * (size_t)idx, w * d0);
+            atomicAdd(gt + 2 * (size_t)idx + 1, w * d1);
+        }
     }
+}
+
+// Tuning knob (REN_HG_VARIANT environment variable, read per call): bit 0 = XCD-affine level
+// mapping, bit 1 = lane-pair feature split in the backward kernel.
+int hg_variant() {
+    const char *e = getenv("REN_HG_VARIANT");
+    return e ? atoi(e) : 3;
 }
 
 int make_grid(const ren_grid_desc *grid, GridDev &g) {
@@ -172,11 +209,15 @@ extern "C" int ren_hashgrid_fwd(const ren_grid_desc *grid, const float *table, c
     ren_scene_dev sc = {};
     if (scene) sc = ren_make_scene(scene);
     const int64_t n_pad = layout == 1 ? ((n + 31) / 32) * 32 : n;
-    dim3 grd(ren_blocks(n_pad, 256), g.n_levels), blk(256);
+    const int variant = hg_variant();
+    const int affine = variant & 1;
+    const int64_t n_chunks = (n_pad + 255) / 256;
+    dim3 grd = affine ? dim3((unsigned)(8 * ((g.n_levels + 7) / 8) * n_chunks)) : dim3((unsigned)n_chunks, g.n_levels);
+    dim3 blk(256);
     const float2 *tab = reinterpret_cast<const float2 *>(table);
 #define LAUNCH(L, R)                                                                                     \
     hipLaunchKernelGGL((hashgrid_fwd_kernel<L, R>), grd, blk, 0, (hipStream_t)stream, g, tab, x_unit, sc, \
-                       rays_o, rays_d, ray_indices, t_starts, t_ends, n, n_pad, feat)
+                       rays_o, rays_d, ray_indices, t_starts, t_ends, n, n_pad, feat, affine)
     if (layout == 0) { if (from_rays) LAUNCH(0, true); else LAUNCH(0, false); }
     else             { if (from_rays) LAUNCH(1, true); else LAUNCH(1, false); }
 #undef LAUNCH
@@ -197,12 +238,19 @@ extern "C" int ren_hashgrid_bwd(const ren_grid_desc *grid, float *grad_table, co
     if (n == 0) return REN_OK;
     ren_scene_dev sc = {};
     if (scene) sc = ren_make_scene(scene);
-    dim3 grd(ren_blocks(n, 256), g.n_levels), blk(256);
-#define LAUNCH(L, R)                                                                                          \
-    hipLaunchKernelGGL((hashgrid_bwd_kernel<L, R>), grd, blk, 0, (hipStream_t)stream, g, grad_table, x_unit, \
-                       sc, rays_o, rays_d, ray_indices, t_starts, t_ends, n, dfeat)
-    if (layout == 0) { if (from_rays) LAUNCH(0, true); else LAUNCH(0, false); }
-    else             { if (from_rays) LAUNCH(1, true); else LAUNCH(1, false); }
+    const int variant = hg_variant();
+    const int affine = variant & 1;
+    const bool pair = (variant & 2) != 0;
+    const int64_t n_chunks = pair ? (n + 127) / 128 : (n + 255) / 256;
+    dim3 grd = affine ? dim3((unsigned)(8 * ((g.n_levels + 7) / 8) * n_chunks)) : dim3((unsigned)n_chunks, g.n_levels);
+    dim3 blk(256);
+#define LAUNCH(L, R, P)                                                                                          \
+    hipLaunchKernelGGL((hashgrid_bwd_kernel<L, R, P>), grd, blk, 0, (hipStream_t)stream, g, grad_table, x_unit, \
+                       sc, rays_o, rays_d, ray_indices, t_starts, t_ends, n, dfeat, affine)
+#define LAUNCH2(L, R) do { if (pair) LAUNCH(L, R, true); else LAUNCH(L, R, false); } while (0)
+    if (layout == 0) { if (from_rays) LAUNCH2(0, true); else LAUNCH2(0, false); }
+    else             { if (from_rays) LAUNCH2(1, true); else LAUNCH2(1, false); }
+#undef LAUNCH2
 #undef LAUNCH
     REN_CHECK_LAUNCH();
 }

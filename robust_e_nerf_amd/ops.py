@@ -356,3 +356,45 @@ def occgrid_binarize(occs, occ_thre: float, binary, scratch):
     check(_lib.load().ren_occgrid_binarize(_ptr(occs, torch.float32), occs.numel(), _f(occ_thre),
                                            _ptr(binary, (torch.uint8, torch.bool)), _ptr(scratch, torch.float32),
                                            _stream()), "ren_occgrid_binarize")
+
+
+# ------------------------------------------------------------------------------- per-kernel timing
+# HIP-event timing of individual launches on the stream they are enqueued on (torch's current
+# stream, which is the stream handed to the C ABI).  Used by bench.py for the roofline numbers;
+# disabled (zero overhead) otherwise.
+_PROFILE = None
+_TIMED = ("ray_aabb_intersect", "ray_march_count", "ray_march_write", "exclusive_scan", "visibility",
+          "compact_samples", "hashgrid_fwd", "hashgrid_bwd", "mlp_fwd", "mlp_bwd", "composite_fwd",
+          "composite_bwd", "column_sum", "event_loss_fwd", "event_loss_bwd", "adam_step", "trajectory", "raygen")
+
+
+def profile_start():
+    global _PROFILE
+    _PROFILE = {}
+
+
+def profile_stop():
+    """-> {kernel family: (launches, total milliseconds)}; synchronises once."""
+    global _PROFILE
+    prof, _PROFILE = _PROFILE, None
+    torch.cuda.synchronize()
+    return {k: (len(v), sum(a.elapsed_time(b) for a, b in v)) for k, v in (prof or {}).items()}
+
+
+def _wrap(name, fn):
+    def timed(*a, **kw):
+        if _PROFILE is None:
+            return fn(*a, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn(*a, **kw)
+        e1.record()
+        _PROFILE.setdefault(name, []).append((e0, e1))
+        return out
+    timed.__name__ = fn.__name__
+    timed.__doc__ = fn.__doc__
+    return timed
+
+
+for _n in _TIMED:
+    globals()[_n] = _wrap(_n, globals()[_n])
