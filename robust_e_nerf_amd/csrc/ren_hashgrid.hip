@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_kernel(
 // mapping, bit 1 = lane-pair feature split in the backward kernel.
 int hg_variant() {
     const char *e = getenv("REN_HG_VARIANT");
-    return e ? atoi(e) : 3;
+    return e ? atoi(e) : 2;
 }
 
 int make_grid(const ren_grid_desc *grid, GridDev &g) {

@@ -1,7 +1,7 @@
 """Micro-benchmark of the hash-grid kernels at config-B size (GPU only; tuning aid)."""
 import os, sys, time, math
 import torch
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from robust_e_nerf_amd import ops, engine
 from oracle import hashgrid
 dev = "cuda:0"
