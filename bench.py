@@ -26,7 +26,7 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
 # algorithmic bytes per differentiable sample (DESIGN.md "Roofline"):
-BYTES = {"hashgrid_fwd": 1024 + 12, "hashgrid_bwd": 2048 + 12}
+BYTES = {"hashgrid_fwd": 1024 + 12, "hashgrid_bwd": 2048 + 12, "hashgrid_bwd_binned": 2048 + 12}
 
 
 def synthetic_scene(n_poses=2001, seed=0):
@@ -68,7 +68,7 @@ def cpu_baseline(args, scene, params_cpu, table_seed):
     """The CPU oracle (kind 'port': the reference itself cannot execute on a CPU) on a bounded
     sample: config A = 2 x 2048 rays x 64 samples, forward + backward + Adam, all host cores."""
     from oracle import field as ofield, hashgrid, step as ostep
-    torch.set_num_threads(os.cpu_count())
+    torch.set_num_threads(min(os.cpu_count(), 32))
     tab_ts, tab_pos, tab_quat, Kinv = scene
     spec = hashgrid.make_spec()
     p = {k: v.clone().requires_grad_() for k, v in params_cpu.items()}

@@ -134,6 +134,19 @@ int ren_hashgrid_bwd(const ren_grid_desc *grid, float *grad_table, const float *
                      const int32_t *ray_indices, const float *t_starts, const float *t_ends,
                      int64_t n, int32_t layout, const float *dfeat, void *stream);
 
+/* Same result as ren_hashgrid_bwd (grad_table += scatter of dfeat) but WITHOUT per-update global
+ * atomics: the updates are counting-sorted by 16 384-entry table bin into `workspace` (HBM) and
+ * each bin is accumulated in LDS, then added to the table with plain coalesced read-modify-writes
+ * (see csrc/ren_hashgrid_binned.hip).  ~5x faster than the atomic scatter on MI355X, where global
+ * atomics execute at the memory side.  workspace: ren_hashgrid_bwd_binned_workspace_bytes(n)
+ * bytes of device scratch (1 280 B per sample + 64 KiB).  Needs level sizes <= 2^19. */
+int64_t ren_hashgrid_bwd_binned_workspace_bytes(int64_t n);
+int ren_hashgrid_bwd_binned(const ren_grid_desc *grid, float *grad_table, const float *x_unit,
+                            const ren_scene_desc *scene, const float *rays_o, const float *rays_d,
+                            const int32_t *ray_indices, const float *t_starts, const float *t_ends,
+                            int64_t n, int32_t layout, const float *dfeat, void *workspace,
+                            void *stream);
+
 /* ---- fused NGP MLPs --------------------------------------------------------------------
  * NGPradianceField.query_density / _query_rgb / forward (robust_e_nerf/external/ngp.py:230-280)
  * with MLP.forward (external/mlp.py:99-113), SHEncoder degree 4 (external/sh_encoder.py:28-93),

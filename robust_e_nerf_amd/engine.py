@@ -40,6 +40,7 @@ class RenderCfg:
     ema_decay: float = 0.95
     warmup_steps: int = 256
     occ_n: int = 16
+    binned_scatter: bool = True        # LDS-binned hash-grid backward (False: per-update global atomics)
 
 
 class NGPField:
@@ -100,6 +101,7 @@ class Renderer:
         self.binary = torch.zeros(cells, device=dev, dtype=torch.uint8)
         self._scratch = torch.zeros(4, device=dev, dtype=torch.float32)
         self._ws = torch.empty(ops.mlp_bwd_workspace_floats(fld.C), device=dev, dtype=torch.float32)
+        self._bin_ws = None
 
     # ---- sampling (K1-K3): ray/AABB, two-pass march, no-grad density pre-pass + visibility --------
     def sample(self, o, d, jitter: Optional[torch.Tensor], training: bool) -> Packed:
@@ -168,8 +170,16 @@ class Renderer:
         dfeat = ops.mlp_bwd(f.mlp, f.C, ctx["feat"], ctx["base"], self.scene, rays=(ctx["o"], ctx["d"]),
                             samples=samples, n=pk.n, rgb=ctx["rgb"], d_rgb=d_rgb, d_sigma=d_sig,
                             grad_mlp_params=f.g_mlp, workspace=self._ws)
-        ops.hashgrid_bwd(f.grid, f.g_table, dfeat, scene=self.scene, rays=(ctx["o"], ctx["d"]), samples=samples,
-                         n=pk.n, layout=1)
+        if self.cfg.binned_scatter:
+            need = ops.hashgrid_bwd_binned_workspace_bytes(pk.n)
+            if self._bin_ws is None or self._bin_ws.numel() < need:
+                self._bin_ws = None                                   # release before growing
+                self._bin_ws = torch.empty(need, device=dfeat.device, dtype=torch.uint8)
+            ops.hashgrid_bwd_binned(f.grid, f.g_table, dfeat, self._bin_ws, scene=self.scene,
+                                    rays=(ctx["o"], ctx["d"]), samples=samples, n=pk.n, layout=1)
+        else:
+            ops.hashgrid_bwd(f.grid, f.g_table, dfeat, scene=self.scene, rays=(ctx["o"], ctx["d"]), samples=samples,
+                             n=pk.n, layout=1)
         return ops.column_sum(d_bk) if d_bk is not None else None
 
     # ---- density query (occ_eval_fn / query_density) ----------------------------------------------------

@@ -227,6 +227,25 @@ def hashgrid_bwd(grid: GridDesc, grad_table, dfeat, *, x_unit=None, scene=None, 
                                        _ptr(dfeat, torch.float32), _stream()), "ren_hashgrid_bwd")
 
 
+def hashgrid_bwd_binned_workspace_bytes(n: int) -> int:
+    return int(_lib.load().ren_hashgrid_bwd_binned_workspace_bytes(n))
+
+
+def hashgrid_bwd_binned(grid: GridDesc, grad_table, dfeat, workspace, *, x_unit=None, scene=None, rays=None,
+                        samples=None, n: int, layout: int):
+    """LDS-binned (atomic-free) variant of hashgrid_bwd; workspace: uint8 tensor of
+    hashgrid_bwd_binned_workspace_bytes(n) bytes."""
+    if workspace.numel() * workspace.element_size() < hashgrid_bwd_binned_workspace_bytes(n):
+        raise ValueError("hashgrid_bwd_binned: workspace too small")
+    o, d = rays if rays is not None else (None, None)
+    ri, ts, te = samples if samples is not None else (None, None, None)
+    check(_lib.load().ren_hashgrid_bwd_binned(ctypes.byref(grid), _ptr(grad_table, torch.float32), _ptr(x_unit),
+                                              ctypes.byref(scene) if scene is not None else None,
+                                              _ptr(o), _ptr(d), _ptr(ri), _ptr(ts), _ptr(te), n, layout,
+                                              _ptr(dfeat, torch.float32), _ptr(workspace), _stream()),
+          "ren_hashgrid_bwd_binned")
+
+
 # ------------------------------------------------------------------------------- fused MLPs
 def mlp_fwd(mlp_params, C: int, feat, scene: SceneDesc, *, x_world=None, dirs=None, rays=None, samples=None,
             n: int, density_only: bool = False, save_base: bool = False, out=None):
@@ -364,7 +383,7 @@ def occgrid_binarize(occs, occ_thre: float, binary, scratch):
 # disabled (zero overhead) otherwise.
 _PROFILE = None
 _TIMED = ("ray_aabb_intersect", "ray_march_count", "ray_march_write", "exclusive_scan", "visibility",
-          "compact_samples", "hashgrid_fwd", "hashgrid_bwd", "mlp_fwd", "mlp_bwd", "composite_fwd",
+          "compact_samples", "hashgrid_fwd", "hashgrid_bwd", "hashgrid_bwd_binned", "mlp_fwd", "mlp_bwd", "composite_fwd",
           "composite_bwd", "column_sum", "event_loss_fwd", "event_loss_bwd", "adam_step", "trajectory", "raygen")
 
 

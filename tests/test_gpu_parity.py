@@ -189,6 +189,12 @@ def test_hashgrid_fwd_bwd(amd, spec, full_table_cache):
     gt2 = torch.zeros_like(td)
     ops.hashgrid_bwd(grid, gt2, dev(frag), x_unit=dev(x), n=n, layout=1)
     assert rel_err(gt2.cpu(), tab.grad) < 1e-5
+    # LDS-binned (atomic-free) scatter: same result, accumulates (+=) into the table gradient
+    ws = torch.empty(ops.hashgrid_bwd_binned_workspace_bytes(n), device=DEV, dtype=torch.uint8)
+    for layout, df in ((0, dev(gout)), (1, dev(frag))):
+        gt3 = torch.ones_like(td)
+        ops.hashgrid_bwd_binned(grid, gt3, df, ws, x_unit=dev(x), n=n, layout=layout)
+        assert rel_err(gt3.cpu() - 1.0, tab.grad) < 1e-5, layout
 
 
 # ------------------------------------------------------------------------------------------ field (hash + MLPs)

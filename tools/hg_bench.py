@@ -35,3 +35,16 @@ for v in os.environ.get("VARIANTS", "0,1,2,3").split(","):
     tf = timeit(lambda: ops.hashgrid_fwd(grid, table, scene=scene, rays=(o, d), samples=samples, n=n, layout=1))
     tb = timeit(lambda: ops.hashgrid_bwd(grid, gt, dfeat, scene=scene, rays=(o, d), samples=samples, n=n, layout=1))
     print(f"variant {v}: fwd {tf:.2f} ms ({1036*n/tf/1e6:.0f} GB/s alg)  bwd {tb:.2f} ms ({2060*n/tb/1e6:.0f} GB/s alg)", flush=True)
+
+ws = torch.empty(ops.hashgrid_bwd_binned_workspace_bytes(n), device=dev, dtype=torch.uint8)
+tb = timeit(lambda: ops.hashgrid_bwd_binned(grid, gt, dfeat, ws, scene=scene, rays=(o, d), samples=samples, n=n, layout=1))
+print(f"binned: bwd {tb:.2f} ms ({2060*n/tb/1e6:.0f} GB/s alg)", flush=True)
+gt.zero_(); os.environ["REN_HG_VARIANT"] = "2"
+ops.hashgrid_bwd(grid, gt, dfeat, scene=scene, rays=(o, d), samples=samples, n=n, layout=1)
+ga = gt.clone(); gt.zero_()
+ops.hashgrid_bwd_binned(grid, gt, dfeat, ws, scene=scene, rays=(o, d), samples=samples, n=n, layout=1)
+print("max abs diff atomic vs binned", float((ga - gt).abs().max()), "max", float(ga.abs().max()))
+ops.profile_start()
+for _ in range(3):
+    ops.hashgrid_bwd_binned(grid, gt, dfeat, ws, scene=scene, rays=(o, d), samples=samples, n=n, layout=1)
+print(ops.profile_stop())
