@@ -345,9 +345,8 @@ class Trainer:
         all-reduce of the single flat buffer) and scaled by 1/world inside the Adam kernel."""
         f = self.r.field
         if self.world_size > 1:
-            import torch.distributed as dist
-            dist.all_reduce(f.grad, group=self.pg)
-            dist.all_reduce(self.small_grad, group=self.pg)
+            from . import parallel
+            parallel.allreduce_sum_([f.grad, self.small_grad], group=self.pg, world_size=self.world_size)
         self.step_count += 1
         gs = 1.0 / self.world_size
         lr = self.t.lr * self.lr_scale

@@ -1,0 +1,65 @@
+"""Data parallelism over event-ray shards: one process per GPU, `torch.distributed` with backend
+"nccl" (= RCCL over xGMI on ROCm), or "gloo" for the CPU tests.
+
+The reference uses Lightning DDP (scripts/run.py:81-93): every rank draws its own i.i.d. event
+batch (data/datamodule.py:85-89, seed + rank) and DDP averages the gradients of the replicated
+parameters.  Here the parameters live in ONE flat buffer, so the exchange is a single all-reduce
+(SUM) of 50.4 MB (+ a 16-byte scalar block); the 1/world factor is applied inside the fused Adam
+kernel (`ren_adam_step(grad_scale=1/world)`), so no extra pass touches the gradient.
+"""
+from __future__ import annotations
+
+import os
+from typing import Iterable, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: Optional[str] = None):
+    """Initialise the default process group from RANK / WORLD_SIZE / MASTER_* (torchrun contract)."""
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world == 1 or dist.is_initialized():
+        return int(os.environ.get("RANK", 0)), world
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on these hosts
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    dist.init_process_group(backend=backend)
+    return dist.get_rank(), world
+
+
+def allreduce_sum_(buffers: Iterable[torch.Tensor], group=None, world_size: Optional[int] = None) -> None:
+    """In-place SUM all-reduce of each flat gradient buffer (C1 of SURVEY 2.3)."""
+    if world_size is None:
+        world_size = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world_size <= 1:
+        return
+    for b in buffers:
+        dist.all_reduce(b, op=dist.ReduceOp.SUM, group=group)
+
+
+def rank_seed(base_seed: int, rank: int) -> int:
+    """Per-rank data seed (data/datamodule.py:85-89: process_seed = initial_seed + rank)."""
+    return base_seed + rank
+
+
+def shard_bounds(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous shard of a global batch (used by the 1-vs-N equivalence tests)."""
+    per = (n + world - 1) // world
+    return min(rank * per, n), min((rank + 1) * per, n)
+
+
+def per_rank_budget(eff_ray_sample_batch_size: int, world: int) -> int:
+    """train_eff_ray_sample_batch_size // num_gpus (models/robust_e_nerf.py:63-66)."""
+    return eff_ray_sample_batch_size // world
+
+
+def allgather_mean(value: float, group=None) -> float:
+    """mean over ranks of a python scalar (C2: mean_num_samples_per_ray, robust_e_nerf.py:916-919)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return float(value)
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    t = torch.tensor([float(value)], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, group=group)
+    return float(t) / dist.get_world_size(group)
