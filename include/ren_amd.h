@@ -192,13 +192,17 @@ int ren_composite_fwd(const int64_t *offsets, const int32_t *counts, int64_t n_r
                       const float *rgbs, int32_t C, const float *bkgd,
                       float *colors, float *opacities, float *depths,
                       float *weights, float *trans, void *stream);
-/* backward: g_colors[n_rays,C], g_opac[n_rays] (NULL=0), g_depth[n_rays] (NULL=0)
- * -> d_sigmas[n], d_rgbs[n,C], d_bkgd_per_ray[n_rays,C] (NULL ok). */
+/* backward: g_colors[n_rays,C], g_opac[n_rays] (NULL=0), g_depth[n_rays] (NULL=0) and/or
+ * g_weights[n] (NULL=0: per-sample upstream gradient of the weights themselves, i.e. the backward of
+ * nerfacc.render_weight_from_density used on its own; then rgbs/g_colors/d_rgbs may be NULL)
+ * -> d_sigmas[n], d_rgbs[n,C], d_bkgd_per_ray[n_rays,C] (NULL ok).
+ * ren_composite_fwd with rgbs==NULL computes weights/trans/opacities/depths only. */
 int ren_composite_bwd(const int64_t *offsets, const int32_t *counts, int64_t n_rays,
                       const float *t_starts, const float *t_ends, const float *sigmas,
                       const float *rgbs, int32_t C, const float *bkgd,
                       const float *weights, const float *trans, const float *opacities,
                       const float *g_colors, const float *g_opac, const float *g_depth,
+                      const float *g_weights,
                       float *d_sigmas, float *d_rgbs, float *d_bkgd_per_ray, void *stream);
 
 /* ---- event loss ------------------------------------------------------------------------------

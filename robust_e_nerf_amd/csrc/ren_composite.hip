@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
             if (weights) weights[base + j] = w;
             if (trans) trans[base + j] = T;
 #pragma unroll
-            for (int c = 0; c < C; ++c) acc_c[c] += w * rgbs[(base + j) * C + c];
+            for (int c = 0; c < C; ++c) acc_c[c] += rgbs ? w * rgbs[(base + j) * C + c] : 0.f;
             acc_o += w;
             acc_d += w * ((t0 + t1) * 0.5f);
         }
@@ -69,11 +69,13 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
 #pragma unroll
     for (int c = 0; c < C; ++c) acc_c[c] = ren_wave_sum(acc_c[c]);
     if (lane == 0) {
+        if (colors) {
 #pragma unroll
-        for (int c = 0; c < C; ++c)
-            colors[ray * C + c] = bkgd ? acc_c[c] + bkgd[c] * (1.f - acc_o) : acc_c[c];
-        opacities[ray] = acc_o;
-        depths[ray] = acc_d;
+            for (int c = 0; c < C; ++c)
+                colors[ray * C + c] = bkgd ? acc_c[c] + bkgd[c] * (1.f - acc_o) : acc_c[c];
+        }
+        if (opacities) opacities[ray] = acc_o;
+        if (depths) depths[ray] = acc_d;
     }
 }
 
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
     const float *__restrict__ sigmas, const float *__restrict__ rgbs, const float *__restrict__ bkgd,
     const float *__restrict__ weights, const float *__restrict__ trans,
     const float *__restrict__ opacities, const float *__restrict__ g_colors,
-    const float *__restrict__ g_opac, const float *__restrict__ g_depth,
+    const float *__restrict__ g_opac, const float *__restrict__ g_depth, const float *__restrict__ g_weights,
     float *__restrict__ d_sigmas, float *__restrict__ d_rgbs, float *__restrict__ d_bkgd_per_ray) {
     const int lane = threadIdx.x & 63;
     const int64_t ray = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
     const int cnt = counts[ray];
     float gc[C], bk[C];
 #pragma unroll
-    for (int c = 0; c < C; ++c) { gc[c] = g_colors[ray * C + c]; bk[c] = bkgd ? bkgd[c] : 0.f; }
+    for (int c = 0; c < C; ++c) { gc[c] = g_colors ? g_colors[ray * C + c] : 0.f; bk[c] = bkgd ? bkgd[c] : 0.f; }
     const float go = g_opac ? g_opac[ray] : 0.f;
     const float gd = g_depth ? g_depth[ray] : 0.f;
     if (d_bkgd_per_ray && lane == 0) {
@@ -112,11 +114,13 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
         if (act) {
             t0 = t_starts[base + j]; t1 = t_ends[base + j]; sg = sigmas[base + j];
             w = weights[base + j]; T = trans[base + j];
-            v = go + gd * ((t0 + t1) * 0.5f);
+            v = go + gd * ((t0 + t1) * 0.5f) + (g_weights ? g_weights[base + j] : 0.f);
+            if (rgbs) {
 #pragma unroll
-            for (int c = 0; c < C; ++c) {
-                v += gc[c] * (rgbs[(base + j) * C + c] - bk[c]);
-                d_rgbs[(base + j) * C + c] = w * gc[c];
+                for (int c = 0; c < C; ++c) {
+                    v += gc[c] * (rgbs[(base + j) * C + c] - bk[c]);
+                    if (d_rgbs) d_rgbs[(base + j) * C + c] = w * gc[c];
+                }
             }
         }
         const float wv = w * v;
@@ -150,7 +154,8 @@ extern "C" int ren_composite_fwd(const int64_t *offsets, const int32_t *counts, 
                                  const float *rgbs, int32_t C, const float *bkgd, float *colors,
                                  float *opacities, float *depths, float *weights, float *trans,
                                  void *stream) {
-    if (!offsets || !counts || !colors || !opacities || !depths || n_rays < 0) return REN_ERR_BAD_ARG;
+    if (!offsets || !counts || n_rays < 0) return REN_ERR_BAD_ARG;
+    if (rgbs && !colors) return REN_ERR_BAD_ARG;
     if (C != 1 && C != 3) return REN_ERR_UNSUPPORTED;   // vol_rendering.py:83-84
     if (n_rays == 0) return REN_OK;
     dim3 grid(ren_blocks(n_rays, 4)), block(256);
@@ -167,10 +172,10 @@ extern "C" int ren_composite_bwd(const int64_t *offsets, const int32_t *counts, 
                                  const float *t_starts, const float *t_ends, const float *sigmas,
                                  const float *rgbs, int32_t C, const float *bkgd, const float *weights,
                                  const float *trans, const float *opacities, const float *g_colors,
-                                 const float *g_opac, const float *g_depth, float *d_sigmas,
-                                 float *d_rgbs, float *d_bkgd_per_ray, void *stream) {
-    if (!offsets || !counts || !weights || !trans || !g_colors || !d_sigmas || !d_rgbs || n_rays < 0)
-        return REN_ERR_BAD_ARG;
+                                 const float *g_opac, const float *g_depth, const float *g_weights,
+                                 float *d_sigmas, float *d_rgbs, float *d_bkgd_per_ray, void *stream) {
+    if (!offsets || !counts || !weights || !trans || !d_sigmas || n_rays < 0) return REN_ERR_BAD_ARG;
+    if (rgbs && (!g_colors || !d_rgbs)) return REN_ERR_BAD_ARG;
     if (d_bkgd_per_ray && !opacities) return REN_ERR_BAD_ARG;
     if (C != 1 && C != 3) return REN_ERR_UNSUPPORTED;
     if (n_rays == 0) return REN_OK;
@@ -178,11 +183,11 @@ extern "C" int ren_composite_bwd(const int64_t *offsets, const int32_t *counts, 
     if (C == 1)
         hipLaunchKernelGGL(composite_bwd_kernel<1>, grid, block, 0, (hipStream_t)stream, offsets, counts,
                            n_rays, t_starts, t_ends, sigmas, rgbs, bkgd, weights, trans, opacities, g_colors,
-                           g_opac, g_depth, d_sigmas, d_rgbs, d_bkgd_per_ray);
+                           g_opac, g_depth, g_weights, d_sigmas, d_rgbs, d_bkgd_per_ray);
     else
         hipLaunchKernelGGL(composite_bwd_kernel<3>, grid, block, 0, (hipStream_t)stream, offsets, counts,
                            n_rays, t_starts, t_ends, sigmas, rgbs, bkgd, weights, trans, opacities, g_colors,
-                           g_opac, g_depth, d_sigmas, d_rgbs, d_bkgd_per_ray);
+                           g_opac, g_depth, g_weights, d_sigmas, d_rgbs, d_bkgd_per_ray);
     REN_CHECK_LAUNCH();
 }
 

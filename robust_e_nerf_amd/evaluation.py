@@ -1,0 +1,74 @@
+"""Inference render + image metrics: the step after the hot path.
+
+Mirrors ``RobustENeRF.evaluation_step`` / ``render_pixels`` (robust_e_nerf/models/robust_e_nerf.py:
+533-571, 849-885): one camera pose, a full pixel grid, rays rendered in chunks of
+``test_chunk_size`` without jitter (external/utils.py:99-105,115), then the affine alignment in
+log space and PSNR of ``evaluation_epoch_end`` (:634-677) / ``Metric.compute`` (loss_metric/metric.py:60-72).
+The render runs on the HIP kernels; alignment / PSNR are a handful of reductions on (H*W,) tensors.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import ops
+from .engine import Renderer
+
+
+def pixel_grid(height: int, width: int, device) -> torch.Tensor:
+    """(H, W, 2) pixel positions (x, y), float32 — robust_e_nerf.py:110-117."""
+    xs, ys = torch.meshgrid(torch.arange(width, device=device), torch.arange(height, device=device), indexing="xy")
+    return torch.stack([xs, ys], dim=2).to(torch.float32)
+
+
+@torch.no_grad()
+def render_pixels(r: Renderer, Kinv: torch.Tensor, px: torch.Tensor, pos: torch.Tensor, rot: torch.Tensor,
+                  bkgd: Optional[torch.Tensor] = None, training: bool = False, jitter=None):
+    """robust_e_nerf.py:849-885 for (N,2) pixels with per-pixel poses (N,3), (N,3,3):
+    -> intensity (N,) [monochrome], opacity, depth (z-depth), samples used, is_valid."""
+    o, d = ops.raygen(Kinv, px.contiguous(), pos.contiguous(), rot.contiguous())
+    colors, opac, depth, ctx = r.forward(o, d, jitter, bkgd, training=training, save=False)
+    intensity = colors[:, 0] + r.cfg.min_modeled_intensity
+    is_valid = torch.ones_like(opac, dtype=torch.bool) if bkgd is not None else opac > 0
+    depth = depth / (opac + r.cfg.opacity_eps)                         # nerf.py:279-282
+    depth = depth * (d * rot[:, :, 2]).sum(-1)                        # ray distance -> z depth (:873-884)
+    return intensity, opac, depth, ctx["pk"].n, is_valid
+
+
+@torch.no_grad()
+def render_image(r: Renderer, Kinv: torch.Tensor, cam_pos: torch.Tensor, cam_rot: torch.Tensor, height: int,
+                 width: int, bkgd: Optional[torch.Tensor] = None, chunk: int = 16384):
+    """evaluation_step: (H, W) predicted intensity, opacity, depth for one pose."""
+    dev = Kinv.device
+    px = pixel_grid(height, width, dev).reshape(-1, 2)
+    n = px.shape[0]
+    out_i = torch.empty(n, device=dev)
+    out_o = torch.empty(n, device=dev)
+    out_d = torch.empty(n, device=dev)
+    for s in range(0, n, chunk):                                       # external/utils.py:99-105
+        e = min(s + chunk, n)
+        pos = cam_pos.reshape(1, 3).expand(e - s, 3).contiguous()
+        rot = cam_rot.reshape(1, 3, 3).expand(e - s, 3, 3).contiguous()
+        i, o, d, _, _ = render_pixels(r, Kinv, px[s:e], pos, rot, bkgd)
+        out_i[s:e], out_o[s:e], out_d[s:e] = i, o, d
+    return out_i.view(height, width), out_o.view(height, width), out_d.view(height, width)
+
+
+def affine_align_log(pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """Least-squares a, b with a*log(pred)+b ~= log(target), float64 (robust_e_nerf.py:634-677);
+    returns the aligned prediction exp(a*log(pred)+b) in target's dtype."""
+    lp = pred.reshape(-1).log().to(torch.float64)
+    A = torch.stack([lp, torch.ones_like(lp)], dim=1)
+    sol = torch.linalg.lstsq(A.cpu(), target.reshape(-1, 1).log().to(torch.float64).cpu()).solution
+    return (A.cpu() @ sol).reshape(pred.shape).exp().to(target.dtype).to(target.device)
+
+
+def psnr(pred: torch.Tensor, target: torch.Tensor, data_range: float) -> float:
+    """10 log10(range^2 / MSE) — torchmetrics.functional.psnr as used at metric.py:68-72."""
+    mse = ((pred.double() - target.double()) ** 2).mean()
+    return float(10.0 * torch.log10(torch.tensor(data_range, dtype=torch.float64) ** 2 / mse))
+
+
+def l1(pred: torch.Tensor, target: torch.Tensor) -> float:
+    return float((pred.double() - target.double()).abs().mean())

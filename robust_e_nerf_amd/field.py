@@ -1,0 +1,163 @@
+"""``NGPradianceField``-shaped module (robust_e_nerf/external/ngp.py:109-280) on the fused kernels.
+
+Same constructor arguments, same parameter / state-dict names as the reference
+(``mlp_base.0.params``, ``mlp_base.1.hidden_layers.0.weight`` ... ``mlp_head.output_layer.bias``,
+buffer ``aabb``), same methods (``query_density(x, return_feat)``, ``forward(positions, directions)``)
+so the reference's ``render_image`` closures (``external/utils.py:68-96``) call it unchanged; the
+arithmetic is two launches (hash grid, fused MLPs) instead of ~40, with a hand-written backward.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Union
+
+import torch
+
+from . import ops
+from .engine import contract_points
+from .nerfacc_api import ContractionType
+from .tcnn_api import Encoding
+
+
+class _Linear(torch.nn.Module):
+    """Parameter holder with nn.Linear's names and default initialisation (ngp.py:179-185)."""
+
+    def __init__(self, in_f: int, out_f: int):
+        super().__init__()
+        lin = torch.nn.Linear(in_f, out_f)
+        self.weight, self.bias = lin.weight, lin.bias
+
+
+class _MLPParams(torch.nn.Module):
+    """Mirrors external/mlp.py:26-97's attribute layout: hidden_layers (ModuleList) + output_layer."""
+
+    def __init__(self, dims: List[int]):
+        super().__init__()
+        self.hidden_layers = torch.nn.ModuleList([_Linear(dims[i], dims[i + 1]) for i in range(len(dims) - 2)])
+        self.output_layer = _Linear(dims[-2], dims[-1])
+
+    def tensors(self):
+        out = []
+        for layer in list(self.hidden_layers) + [self.output_layer]:
+            out += [layer.weight, layer.bias]
+        return out
+
+
+class _FieldFn(torch.autograd.Function):
+    """(x_world, dirs, table, *mlp tensors) -> (rgb (n,C), sigma (n,1)) with analytic backward to the
+    table and MLP parameters (positions / directions are not differentiated on this path)."""
+
+    @staticmethod
+    def forward(ctx, x_world, dirs, table, module, density_only, *mlp_tensors):
+        m = module
+        x_world = x_world.contiguous().float()
+        n = x_world.shape[0]
+        mlp = torch.cat([t.reshape(-1) for t in mlp_tensors]).contiguous().float()
+        xu = contract_points(x_world, m.aabb.tolist(), m.contraction_type.value)
+        feat = ops.hashgrid_fwd(m.encoding.grid, table, x_unit=xu, n=n, layout=1)
+        dirs_c = None if dirs is None else dirs.contiguous().float()
+        rgb, sigma, base = ops.mlp_fwd(mlp, m.radiance_dim, feat, m.scene, x_world=x_world, dirs=dirs_c, n=n,
+                                       density_only=density_only, save_base=not density_only)
+        ctx.module, ctx.n, ctx.density_only = m, n, density_only
+        ctx.shapes = [t.shape for t in mlp_tensors]
+        if not density_only:
+            ctx.save_for_backward(x_world, dirs_c, xu, feat, base, rgb, mlp)
+            return rgb, sigma[:, None]
+        return sigma[:, None]
+
+    @staticmethod
+    def backward(ctx, *grads):
+        m = ctx.module
+        if ctx.density_only:
+            raise NotImplementedError("query_density is used without gradients (sigma_fn / occ_eval_fn)")
+        g_rgb, g_sigma = grads
+        x_world, dirs, xu, feat, base, rgb, mlp = ctx.saved_tensors
+        n = ctx.n
+        dev = x_world.device
+        g_rgb = torch.zeros_like(rgb) if g_rgb is None else g_rgb.contiguous().float()
+        g_sigma = torch.zeros(n, device=dev) if g_sigma is None else g_sigma.reshape(-1).contiguous().float()
+        g_mlp = torch.zeros_like(mlp)
+        ws = torch.empty(ops.mlp_bwd_workspace_floats(m.radiance_dim), device=dev, dtype=torch.float32)
+        dfeat = ops.mlp_bwd(mlp, m.radiance_dim, feat, base, m.scene, x_world=x_world, dirs=dirs, n=n, rgb=rgb,
+                            d_rgb=g_rgb, d_sigma=g_sigma, grad_mlp_params=g_mlp, workspace=ws)
+        g_table = torch.zeros(m.encoding.n_params, device=dev, dtype=torch.float32)
+        bws = torch.empty(ops.hashgrid_bwd_binned_workspace_bytes(n), device=dev, dtype=torch.uint8)
+        ops.hashgrid_bwd_binned(m.encoding.grid, g_table, dfeat, bws, x_unit=xu, n=n, layout=1)
+        outs, off = [], 0
+        for shp in ctx.shapes:
+            k = math.prod(shp)
+            outs.append(g_mlp[off: off + k].view(shp))
+            off += k
+        return (None, None, g_table, None, None, *outs)
+
+
+class NGPradianceField(torch.nn.Module):
+    """Instant-NGP radiance field with the reference's interface (external/ngp.py:109-280)."""
+
+    def __init__(self, aabb: Union[torch.Tensor, List[float]], num_dim: int = 3, use_viewdirs: bool = True,
+                 contraction_type: ContractionType = ContractionType.AABB, pos_encoding_config: dict = None,
+                 dir_encoding_config: dict = None, mlp_base_config: dict = None, mlp_head_config: dict = None):
+        super().__init__()
+        assert num_dim == 3
+        assert isinstance(contraction_type, ContractionType)
+        pos_encoding_config = pos_encoding_config or dict(
+            otype="HashGrid", n_levels=16, n_features_per_level=2, log2_hashmap_size=19, base_resolution=16,
+            per_level_scale=1.4472692012786865, interpolation="Linear")
+        dir_encoding_config = dir_encoding_config or dict(degree=4)
+        mlp_base_config = mlp_base_config or {}
+        mlp_head_config = mlp_head_config or {}
+        # the fused kernels implement exactly configs/train/*.yaml's network; anything else is refused loudly
+        if not use_viewdirs or dir_encoding_config.get("degree", 4) != 4:
+            raise NotImplementedError("fused kernels: view directions with SH degree 4")
+        if (mlp_base_config.get("n_neurons", 64), mlp_base_config.get("n_hidden_layers", 1),
+                mlp_base_config.get("geo_feat_dim", 15)) != (64, 1, 15):
+            raise NotImplementedError("fused kernels: base MLP 32->64->16")
+        if (mlp_head_config.get("n_neurons", 64), mlp_head_config.get("n_hidden_layers", 2)) != (64, 2):
+            raise NotImplementedError("fused kernels: head MLP 31->64->64->C")
+        if mlp_base_config.get("weight_norm", False) or mlp_head_config.get("weight_norm", False):
+            raise NotImplementedError("weight_norm")
+        for cfg, key, want in ((mlp_base_config, "hidden_activation", "softplus"),
+                               (mlp_base_config, "density_activation", "shifted_trunc_exp"),
+                               (mlp_head_config, "hidden_activation", "softplus"),
+                               (mlp_head_config, "radiance_activation", "softplus")):
+            v = cfg.get(key, want)
+            if isinstance(v, str) and v != want:
+                raise NotImplementedError(f"{key}={v}: fused kernels implement {want} (configs/train/*.yaml)")
+        self.radiance_dim = int(mlp_head_config.get("output_dim", 1))
+        if self.radiance_dim not in (1, 3):
+            raise NotImplementedError("radiance_dim must be 1 or 3")
+        if not isinstance(aabb, torch.Tensor):
+            aabb = torch.tensor(aabb, dtype=torch.float32)
+        self.register_buffer("aabb", aabb)
+        self.num_dim, self.use_viewdirs, self.contraction_type = 3, True, contraction_type
+        self.geo_feat_dim = 15
+        encoding = Encoding(3, pos_encoding_config)
+        if encoding.grid.n_levels != 16:
+            raise NotImplementedError("fused kernels: 16 levels x 2 features")
+        # names as in the reference: mlp_base = Sequential(encoding, MLP), mlp_head = MLP
+        self.mlp_base = torch.nn.Sequential(encoding, _MLPParams([32, 64, 16]))
+        self.mlp_head = _MLPParams([31, 64, 64, self.radiance_dim])
+        self.scene = ops.make_scene_desc(aabb.tolist(), contraction_type.value)
+
+    @property
+    def encoding(self) -> Encoding:
+        return self.mlp_base[0]
+
+    def _mlp_tensors(self):
+        return self.mlp_base[1].tensors() + self.mlp_head.tensors()
+
+    def query_density(self, x, return_feat: bool = False):
+        if return_feat:
+            raise NotImplementedError("return_feat=True is internal to forward() in the fused path")
+        shp = x.shape[:-1]
+        with torch.no_grad():
+            sigma = _FieldFn.apply(x.reshape(-1, 3), None, self.encoding.params, self, True, *self._mlp_tensors())
+        return sigma.view(*shp, 1)
+
+    def forward(self, positions: torch.Tensor, directions: torch.Tensor = None):
+        assert directions is not None and positions.shape == directions.shape, \
+            f"{positions.shape} v.s. {None if directions is None else directions.shape}"
+        shp = positions.shape[:-1]
+        rgb, sigma = _FieldFn.apply(positions.reshape(-1, 3), directions.reshape(-1, 3), self.encoding.params, self,
+                                    False, *self._mlp_tensors())
+        return rgb.view(*shp, self.radiance_dim), sigma.view(*shp, 1)

@@ -290,7 +290,7 @@ def mlp_bwd(mlp_params, C: int, feat, base_out, scene: SceneDesc, *, x_world=Non
 def composite_fwd(offsets, counts, ts, te, sigmas, rgbs, C: int, bkgd, save: bool = True):
     n_rays = counts.shape[0]
     dev = ts.device
-    colors = torch.empty(n_rays, C, device=dev, dtype=torch.float32)
+    colors = torch.empty(n_rays, C, device=dev, dtype=torch.float32) if rgbs is not None else None
     opac = torch.empty(n_rays, device=dev, dtype=torch.float32)
     depth = torch.empty(n_rays, device=dev, dtype=torch.float32)
     w = torch.empty(ts.shape[0], device=dev, dtype=torch.float32) if save else None
@@ -302,16 +302,16 @@ def composite_fwd(offsets, counts, ts, te, sigmas, rgbs, C: int, bkgd, save: boo
 
 
 def composite_bwd(offsets, counts, ts, te, sigmas, rgbs, C: int, bkgd, w, T, opac, g_colors, g_opac=None,
-                  g_depth=None, want_bkgd: bool = False):
+                  g_depth=None, want_bkgd: bool = False, g_weights=None):
     n_rays = counts.shape[0]
     dev = ts.device
     d_sig = torch.empty(ts.shape[0], device=dev, dtype=torch.float32)
-    d_rgb = torch.empty(ts.shape[0], C, device=dev, dtype=torch.float32)
+    d_rgb = torch.empty(ts.shape[0], C, device=dev, dtype=torch.float32) if rgbs is not None else None
     d_bk = torch.empty(n_rays, C, device=dev, dtype=torch.float32) if want_bkgd else None
     check(_lib.load().ren_composite_bwd(_ptr(offsets), _ptr(counts), n_rays, _ptr(ts), _ptr(te), _ptr(sigmas),
                                         _ptr(rgbs), C, _ptr(bkgd), _ptr(w), _ptr(T), _ptr(opac),
-                                        _ptr(g_colors, torch.float32), _ptr(g_opac), _ptr(g_depth), _ptr(d_sig),
-                                        _ptr(d_rgb), _ptr(d_bk), _stream()), "ren_composite_bwd")
+                                        _ptr(g_colors, torch.float32), _ptr(g_opac), _ptr(g_depth), _ptr(g_weights),
+                                        _ptr(d_sig), _ptr(d_rgb), _ptr(d_bk), _stream()), "ren_composite_bwd")
     return d_sig, d_rgb, d_bk
 
 

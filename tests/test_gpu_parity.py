@@ -515,3 +515,93 @@ def test_config_b_properties(amd, full_table_cache):
     r.backward(ctx, 2 * gc)
     assert rel_err(fld.g_mlp.cpu(), 2 * g1.cpu()) < 1e-6
     assert abs(float(fld.g_table.double().abs().sum()) - 2 * t1) < 1e-4 * 2 * t1
+
+
+# ------------------------------------------------------------------------------------------ op-by-op seam + eval
+def _seam_field(amd, g, table):
+    from robust_e_nerf_amd import field as fld_mod, nerfacc_api
+    rf = fld_mod.NGPradianceField([-1.5] * 3 + [1.5] * 3, contraction_type=nerfacc_api.ContractionType.AABB,
+                                  mlp_head_config=dict(output_dim=1)).to(DEV)
+    sd = {"mlp_base.0.params": table,
+          "mlp_base.1.hidden_layers.0.weight": t(g["base.w0"]), "mlp_base.1.hidden_layers.0.bias": t(g["base.b0"]),
+          "mlp_base.1.output_layer.weight": t(g["base.wo"]), "mlp_base.1.output_layer.bias": t(g["base.bo"]),
+          "mlp_head.hidden_layers.0.weight": t(g["head.w0"]), "mlp_head.hidden_layers.0.bias": t(g["head.b0"]),
+          "mlp_head.hidden_layers.1.weight": t(g["head.w1"]), "mlp_head.hidden_layers.1.bias": t(g["head.b1"]),
+          "mlp_head.output_layer.weight": t(g["head.wo"]), "mlp_head.output_layer.bias": t(g["head.bo"]),
+          "aabb": torch.tensor([-1.5] * 3 + [1.5] * 3)}
+    assert set(rf.state_dict().keys()) == set(sd.keys()), "state-dict keys must match the reference (SURVEY B.3)"
+    rf.load_state_dict(sd)
+    return rf
+
+
+def test_opwise_seam_matches_fused_engine_and_reference(amd, full_table_cache):
+    """nerfacc-/tcnn-shaped ops + reference-shaped glue (autograd) == fused engine == reference golden."""
+    ops, engine = amd
+    from robust_e_nerf_amd import nerfacc_api, render_glue
+    g = load_golden("training_step_diff")
+    table = full_table_cache(g["table_seed"], g["table_scale"])
+    rf = _seam_field(amd, g, table)
+    rf.train()
+    occ_res = int(g["occ_res"])
+    grid = nerfacc_api.OccupancyGrid([-1.5] * 3 + [1.5] * 3, occ_res).to(DEV)
+    grid._binary = dev(np.unpackbits(g["binary"])[: occ_res ** 3].astype(bool)).view(occ_res, occ_res, occ_res)
+    tr, batch = _trainer_from_golden(engine, g, table)
+    d_start, d_end, target = tr._prepare(batch)
+    pos, rot = ops.trajectory(torch.cat([d_start, d_end]), tr.tab_ts, tr.tab_pos, tr.tab_quat)
+    px = torch.cat([batch["position"], batch["position"]]).contiguous()
+    o, d = ops.raygen(tr.Kinv, px, pos, rot)
+    jit = torch.cat([dev(t(g["jitters"])[-2]), dev(t(g["jitters"])[-1])]).float()
+    bk_raw = dev(g["bkgd_raw"]).clone().requires_grad_()
+    bkgd = torch.nn.functional.softplus(bk_raw)
+    colors, opac, depth, n = render_glue.render_image(
+        rf, grid, o, d, scene_aabb=torch.tensor([-1.5] * 3 + [1.5] * 3, device=DEV),
+        render_step_size=float(g["render_step_size"]), render_bkgd=bkgd, jitter=jit)
+    # fused engine on the same rays
+    c2, o2, z2, ctx = tr.r.forward(o, d, jit, bkgd.detach(), training=True)
+    assert n == ctx["pk"].n
+    assert rel_err(colors.detach().cpu(), c2.cpu()) < 1e-5 and rel_err(opac.detach().cpu()[:, 0], o2.cpu()) < 1e-5
+    # reference loss through the seam path
+    B = batch["position"].shape[0]
+    inten = colors[:, 0] + 1e-3
+    pred = inten[B:].log() - inten[:B].log()
+    loss = ((pred - target) ** 2).mean() / tr.mean_c ** 2
+    assert rel_err(loss.detach().cpu(), g["loss"]) < 1e-4
+    loss.backward()
+    names = {"base.w0": "mlp_base.1.hidden_layers.0.weight", "head.w1": "mlp_head.hidden_layers.1.weight",
+             "head.bo": "mlp_head.output_layer.bias", "base.bo": "mlp_base.1.output_layer.bias"}
+    params = dict(rf.named_parameters())
+    for k, nm in names.items():
+        assert rel_err(params[nm].grad.cpu(), g["g." + k]) < 2e-3, k
+    assert rel_err(params["mlp_base.0.params"].grad.cpu()[t(g["g_table_idx"])], g["g_table_val"]) < 2e-3
+    assert rel_err(bk_raw.grad.cpu(), g["g_bkgd_raw"]) < 1e-3
+
+
+def test_eval_render_psnr_vs_oracle(amd, spec, full_table_cache):
+    """evaluation_step-shaped chunked render of a 40x30 view; PSNR of HIP vs the CPU oracle render."""
+    from oracle import step as ostep, trajectory as otraj
+    from robust_e_nerf_amd import evaluation
+    ops, engine = amd
+    g = load_golden("training_step_diff")
+    table = full_table_cache(g["table_seed"], g["table_scale"])
+    tr, _ = _trainer_from_golden(engine, g, table)
+    H, W = 30, 40
+    K = torch.tensor([[50.0, 0, 20.0], [0, 50.0, 15.0], [0, 0, 1]])
+    Kinv = torch.linalg.inv(K)
+    cam_pos, cam_q = t(g["tab_pos"])[40], t(g["tab_quat"])[40]
+    cam_R = otraj.unitquat_to_rotmat(cam_q[None])[0]
+    bk = torch.tensor([1.0])
+    img, opac, depth = evaluation.render_image(tr.r, dev(Kinv), dev(cam_pos), dev(cam_R), H, W, bkgd=dev(bk), chunk=512)
+    # oracle
+    px = evaluation.pixel_grid(H, W, "cpu").reshape(-1, 2)
+    occ_res = int(g["occ_res"])
+    binary = t(np.unpackbits(g["binary"])[: occ_res ** 3].astype(bool)).view(occ_res, occ_res, occ_res)
+    cfg = ostep.SceneCfg(occ_res=(occ_res,) * 3, render_step_size=float(g["render_step_size"]))
+    with torch.no_grad():
+        i_o, o_o, d_o, n_o, _, _ = ostep.render_pixels(
+            Kinv, px, cam_pos[None].expand(H * W, 3), cam_R[None].expand(H * W, 3, 3), field_params_from(g, table),
+            spec, cfg, binary=binary, jitter=None, bkgd=bk, training=False)
+    p = evaluation.psnr(img.cpu().reshape(-1), i_o, data_range=float(i_o.max() - i_o.min()))
+    assert p > 70.0, f"PSNR vs oracle render {p:.1f} dB"
+    assert rel_err(depth.cpu().reshape(-1), d_o) < 1e-3
+    aligned = evaluation.affine_align_log(img.cpu().reshape(-1) * 1.7, i_o)      # affine ambiguity removed
+    assert evaluation.psnr(aligned, i_o, data_range=float(i_o.max() - i_o.min())) > 60.0
