@@ -7,27 +7,27 @@
 // samples of one training step = 105 ms, 88 % of the step.  11 of the 16 levels are spatial hashes
 // whose updates have no locality at all, so nothing short of a sort can aggregate them on chip.
 //
-// What: a counting sort of the updates by 16 384-entry table bin (128 KiB of float2 = one LDS),
-// then one workgroup per bin(-part) accumulates its updates with LDS float atomics and adds the
+// What: a counting sort of the updates by 8 192-entry table bin (2 features x int64 = 128 KiB = one
+// LDS), then one workgroup per bin(-part) accumulates its updates with LDS atomics and adds the
 // finished 128 KiB slice to the gradient table with plain coalesced read-modify-writes:
 //   1. count    per (level, bin) number of updates                      (index math only)
-//   2. offsets  exclusive scan of the 387 bin counts + work partition   (one workgroup)
+//   2. offsets  exclusive scan of the ~770 bin counts + work partition  (one workgroup)
 //   3. scatter  each workgroup sorts its 512 samples x 8 corners by bin in LDS and appends the
 //               runs to the bins' regions of an HBM staging buffer {u16 local index, f32 v0, f32 v1}
 //               with fully coalesced stores (288 GB of HBM is what makes a 10 B x 128 x n buffer
 //               -- 21.5 GB at n = 16.8 M -- a reasonable thing to do)
-//   4. accumulate  stream a bin part (coalesced), ds_add_f32 into LDS, flush to the table.
+//   4. accumulate  stream a bin part (coalesced), 64-bit fixed-point ds_add_u64 into LDS, flush.
 // HBM traffic: 10 B written + 10 B read per update = 2.56 KB/sample (vs 2 KB of atomic RMW it
 // replaces) but all of it streaming; global atomic requests drop from 128 to ~0.3 per sample.
 #include "ren_hashgrid_common.h"
 
 namespace {
 
-constexpr int BIN_SHIFT = 14;
-constexpr int BIN_ENTRIES = 1 << BIN_SHIFT;          // 16 384 table entries (x2 floats = 128 KiB LDS)
-constexpr int MAX_BINS_PER_LEVEL = 32;
+constexpr int BIN_SHIFT = 13;
+constexpr int BIN_ENTRIES = 1 << BIN_SHIFT;          // 8 192 table entries (x2 features x int64 = 128 KiB LDS)
+constexpr int MAX_BINS_PER_LEVEL = 64;
 constexpr int MAX_BINS = REN_MAX_LEVELS * MAX_BINS_PER_LEVEL;
-constexpr int SCATTER_SAMPLES = 512;                 // samples per scatter workgroup (2 per thread)
+constexpr int SCATTER_SAMPLES = 256;                 // samples per scatter workgroup (1 per thread)
 constexpr int64_t PART_ENTRIES = 1 << 21;            // updates per accumulate workgroup
 
 struct BinTab {
@@ -40,7 +40,7 @@ struct Part {
 };
 
 struct Workspace {
-    uint32_t *counts, *cursors, *n_parts;
+    uint32_t *counts, *level_max, *cursors, *n_parts;     // level_max: float bits of max |update| per level
     uint64_t *bin_start;
     Part *parts;
     uint16_t *out_idx;
@@ -203,6 +203,7 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(
     __shared__ uint64_t gpos[MAX_BINS_PER_LEVEL];
     __shared__ uint32_t st_key[SC_ENTRIES];
     __shared__ float st_v0[SC_ENTRIES], st_v1[SC_ENTRIES];
+    __shared__ float wave_max[4];
     const int lvl = blockIdx.x % g.n_levels;
     const int64_t chunk = blockIdx.x / g.n_levels;
     const int tid = threadIdx.x;
@@ -212,9 +213,10 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(
     const bool hashed = g.hashed[lvl] != 0;
     constexpr int SPT = SCATTER_SAMPLES / 256;
     const int lane = tid & 63;
-    uint32_t key[SPT][8];                                          // rank << 19 | bin << 14 | local index
+    uint32_t key[SPT][8];                                          // rank << 19 | table index in level
     float v0[SPT][8], v1[SPT][8];
     bool have[SPT];
+    float vmax = 0.f;
 #pragma unroll
     for (int k = 0; k < SPT; ++k) {
         const int64_t i = chunk * SCATTER_SAMPLES + k * 256 + tid;
@@ -234,25 +236,37 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(
         bool head;
         have[k] = run_tail(!hashed, valid, cell_key(p), lane, head);
         if (!hashed) run_merge(head, lane, v0[k], v1[k]);
+        if (have[k]) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) vmax = fmaxf(vmax, fmaxf(fabsf(v0[k][c]), fabsf(v1[k][c])));
+        }
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const uint32_t rank = bin_rank(!hashed, have[k], idx[c] >> BIN_SHIFT, lane, hist);
             key[k][c] = (rank << 19) | idx[c];                     // idx < 2^19: bin = idx >> 14, local = idx & 16383
         }
     }
+    // max |update| of the level: scales the 64-bit fixed-point accumulation of the next kernel
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
+    if (lane == 0) wave_max[tid >> 6] = vmax;
     __syncthreads();
+    if (tid == 0) {
+        const float m = fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]));
+        if (m > 0.f) atomicMax(&ws.level_max[lvl], __float_as_uint(m));      // non-negative floats order like uints
+    }
     const int nb = bt.bin_base[lvl + 1] - bt.bin_base[lvl];
     if (tid < MAX_BINS_PER_LEVEL) {
         const uint32_t cnt = hist[tid];
-        // inclusive wave scan over the 32 bins -> local offsets
+        // inclusive wave scan over the 64 bins -> local offsets
         uint32_t inc = cnt;
 #pragma unroll
-        for (int off = 1; off < 32; off <<= 1) {
+        for (int off = 1; off < 64; off <<= 1) {
             const uint32_t t = __shfl_up(inc, off, 64);
             if (tid >= off) inc += t;
         }
         loc[tid] = inc - cnt;
-        if (tid == 31) loc[32] = inc;
+        if (tid == MAX_BINS_PER_LEVEL - 1) loc[MAX_BINS_PER_LEVEL] = inc;
         uint64_t base = 0;
         if (tid < nb && cnt) {
             const int gb = bt.bin_base[lvl] + tid;
@@ -275,7 +289,7 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(
         }
     }
     __syncthreads();
-    const uint32_t total = loc[32];
+    const uint32_t total = loc[MAX_BINS_PER_LEVEL];
     for (uint32_t p = tid; p < total; p += 256) {
         const uint32_t idx = st_key[p];
         const uint32_t b = idx >> BIN_SHIFT;
@@ -287,13 +301,26 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(
 }
 
 // ---- 4. accumulate one bin part in LDS, flush to the gradient table -------------------------------------------
+// LDS float atomics are lane-serialised on gfx950 (ds_add_f32: 0.37 lanes/clk/CU measured), integer
+// ones are 3x faster, so the sums are formed in 64-bit fixed point: q = round(v * 2^k) with
+// 2^k * max|v| ~ 2^38, i.e. a quantum of 4e-12 of the level's largest update; 2^21 updates per part
+// cannot overflow, and the result is MORE accurate than an fp32 running sum.
+__device__ __forceinline__ long long to_fixed(float v, double scale) {
+    return __double2ll_rn((double)v * scale);
+}
+
 __global__ __launch_bounds__(1024) void bin_accumulate_kernel(GridDev g, BinTab bt, Workspace ws,
                                                               float *__restrict__ grad_table) {
-    extern __shared__ __attribute__((aligned(16))) float acc[];    // acc0[16384] | acc1[16384]
+    extern __shared__ __attribute__((aligned(16))) unsigned long long acc[];   // acc0[8192] | acc1[8192]
     if (blockIdx.x >= ws.n_parts[0]) return;
     const Part part = ws.parts[blockIdx.x];
-    float *acc0 = acc, *acc1 = acc + BIN_ENTRIES;
-    for (int e = threadIdx.x; e < 2 * BIN_ENTRIES; e += 1024) acc[e] = 0.f;
+    unsigned long long *acc0 = acc, *acc1 = acc + BIN_ENTRIES;
+    for (int e = threadIdx.x; e < 2 * BIN_ENTRIES; e += 1024) acc[e] = 0ull;
+    int lvl = 0;
+    while (lvl + 1 < g.n_levels && (int)part.gbin >= bt.bin_base[lvl + 1]) ++lvl;
+    int ex;
+    (void)frexpf(__uint_as_float(ws.level_max[lvl]), &ex);         // level_max < 2^ex
+    const double scale = ldexp(1.0, 38 - ex), inv_scale = ldexp(1.0, ex - 38);
     __syncthreads();
     uint64_t e = part.begin + threadIdx.x;
     for (; e + 3 * 1024 < part.end; e += 4 * 1024) {               // 4 independent loads in flight per lane
@@ -301,43 +328,46 @@ __global__ __launch_bounds__(1024) void bin_accumulate_kernel(GridDev g, BinTab 
 #pragma unroll
         for (int u = 0; u < 4; ++u) { ix[u] = ws.out_idx[e + u * 1024]; a[u] = ws.out_v0[e + u * 1024]; b[u] = ws.out_v1[e + u * 1024]; }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { atomicAdd(&acc0[ix[u]], a[u]); atomicAdd(&acc1[ix[u]], b[u]); }   // ds_add_f32
+        for (int u = 0; u < 4; ++u) {
+            atomicAdd(&acc0[ix[u]], (unsigned long long)to_fixed(a[u], scale));    // ds_add_u64
+            atomicAdd(&acc1[ix[u]], (unsigned long long)to_fixed(b[u], scale));
+        }
     }
     for (; e < part.end; e += 1024) {
         const uint32_t idx = ws.out_idx[e];
-        atomicAdd(&acc0[idx], ws.out_v0[e]);
-        atomicAdd(&acc1[idx], ws.out_v1[e]);
+        atomicAdd(&acc0[idx], (unsigned long long)to_fixed(ws.out_v0[e], scale));
+        atomicAdd(&acc1[idx], (unsigned long long)to_fixed(ws.out_v1[e], scale));
     }
     __syncthreads();
-    int lvl = 0;
-    while (lvl + 1 < g.n_levels && (int)part.gbin >= bt.bin_base[lvl + 1]) ++lvl;
     const uint32_t first = ((uint32_t)part.gbin - bt.bin_base[lvl]) << BIN_SHIFT;   // first entry of the bin in its level
     const uint32_t lim = g.size[lvl] > first ? g.size[lvl] - first : 0;
     float2 *gt = reinterpret_cast<float2 *>(grad_table) + g.offset[lvl] + first;
-    for (uint32_t e = threadIdx.x; e < BIN_ENTRIES && e < lim; e += 1024) {
-        const float a = acc0[e], b = acc1[e];
-        if (a == 0.f && b == 0.f) continue;
+    for (uint32_t k = threadIdx.x; k < BIN_ENTRIES && k < lim; k += 1024) {
+        const long long qa = (long long)acc0[k], qb = (long long)acc1[k];
+        if (qa == 0 && qb == 0) continue;
+        const float a = (float)((double)qa * inv_scale), b = (float)((double)qb * inv_scale);
         if (part.single) {                                         // exclusive owner: plain coalesced RMW
-            float2 v = gt[e];
+            float2 v = gt[k];
             v.x += a; v.y += b;
-            gt[e] = v;
+            gt[k] = v;
         } else {
-            atomicAdd(&gt[e].x, a);
-            atomicAdd(&gt[e].y, b);
+            atomicAdd(&gt[k].x, a);
+            atomicAdd(&gt[k].y, b);
         }
     }
 }
 
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-struct Layout { size_t counts, cursors, n_parts, bin_start, parts, out_idx, out_v0, out_v1, total; int64_t max_parts; };
+struct Layout { size_t counts, level_max, cursors, n_parts, bin_start, parts, out_idx, out_v0, out_v1, total; int64_t max_parts; };
 
 Layout make_layout(int64_t n) {
     Layout L;
     const size_t E = (size_t)n * 128;
     L.max_parts = (int64_t)(E / PART_ENTRIES) + MAX_BINS + 1;
     size_t o = 0;
-    L.counts = o; o = align256(o + MAX_BINS * 4);
+    L.counts = o; o += MAX_BINS * 4;                       // counts | level_max are cleared by one memset
+    L.level_max = o; o = align256(o + REN_MAX_LEVELS * 4);
     L.cursors = o; o = align256(o + MAX_BINS * 4);
     L.n_parts = o; o = align256(o + 4);
     L.bin_start = o; o = align256(o + (MAX_BINS + 1) * 8);
@@ -386,12 +416,13 @@ extern "C" int ren_hashgrid_bwd_binned(const ren_grid_desc *grid, float *grad_ta
     const Layout L = make_layout(n);
     char *w = (char *)workspace;
     Workspace ws;
-    ws.counts = (uint32_t *)(w + L.counts); ws.cursors = (uint32_t *)(w + L.cursors);
+    ws.counts = (uint32_t *)(w + L.counts); ws.level_max = (uint32_t *)(w + L.level_max);
+    ws.cursors = (uint32_t *)(w + L.cursors);
     ws.n_parts = (uint32_t *)(w + L.n_parts); ws.bin_start = (uint64_t *)(w + L.bin_start);
     ws.parts = (Part *)(w + L.parts); ws.out_idx = (uint16_t *)(w + L.out_idx);
     ws.out_v0 = (float *)(w + L.out_v0); ws.out_v1 = (float *)(w + L.out_v1);
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(ws.counts, 0, MAX_BINS * 4, st) != hipSuccess) return REN_ERR_LAUNCH;
+    if (hipMemsetAsync(ws.counts, 0, (MAX_BINS + REN_MAX_LEVELS) * 4, st) != hipSuccess) return REN_ERR_LAUNCH;
     const int64_t chunks = (n + SCATTER_SAMPLES - 1) / SCATTER_SAMPLES;
     dim3 grd((unsigned)(chunks * g.n_levels)), blk(256);
     hipLaunchKernelGGL(bin_count_kernel, grd, blk, 0, st, g, bt, layout, dfeat, x_unit, sc, rays_o, rays_d,
@@ -400,7 +431,7 @@ extern "C" int ren_hashgrid_bwd_binned(const ren_grid_desc *grid, float *grad_ta
                        ws.parts, ws.n_parts);
     hipLaunchKernelGGL(bin_scatter_kernel, grd, blk, 0, st, g, bt, layout, dfeat, x_unit, sc, rays_o, rays_d,
                        ray_indices, t_starts, t_ends, n, ws);
-    const size_t acc_lds = 2 * BIN_ENTRIES * sizeof(float);
+    const size_t acc_lds = 2 * BIN_ENTRIES * sizeof(unsigned long long);
     (void)hipFuncSetAttribute((const void *)bin_accumulate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)acc_lds);
     hipLaunchKernelGGL(bin_accumulate_kernel, dim3((unsigned)L.max_parts), dim3(1024), acc_lds, st, g, bt, ws, grad_table);
     REN_CHECK_LAUNCH();
