@@ -102,19 +102,33 @@ class EventBatch:
 
 def training_forward(batch: EventBatch, p, spec, cfg: SceneCfg, *, Kinv, tab_ts, tab_pos, tab_quat,
                      p2n_raw, neg_ct, tau_raw, tau_max, bkgd_raw, binary,
-                     jitter_start, jitter_end, loss_cfg: Optional[dict] = None):
-    """training_step with the log-intensity-difference loss (two renders).
+                     jitter_start, jitter_end, loss_cfg: Optional[dict] = None, jitter_grad=None):
+    """training_step: log-intensity-difference loss (two renders) and, when loss_cfg["w_grad"] > 0,
+    the log-intensity-gradient loss (a third render differentiated w.r.t. its timestamp with
+    create_graph=True, robust_e_nerf.py:383-409).
 
     Returns (loss, aux) where aux holds every intermediate the parity tests compare."""
     lc = dict(err_diff="mse", w_diff=1.0, pw_diff="mean_contrast_reciprocal_sq")
     lc.update(loss_cfg or {})
+    w_grad = lc.get("w_grad", 0.0)
     c_p, c_n, mean_c = events.contrast_thresholds(p2n_raw, neg_ct)
     ev_diff = events.event_log_intensity_diff(batch.num_pos, batch.num_neg, c_p, c_n)
     tau = events.refractory_period(events.clamp_tau_raw(tau_raw, tau_max), tau_max)
     tsd = events.supervision_timestamps(batch.start_ts, batch.end_ts, batch.u_ts_diff,
-                                        batch.u_diff_start, batch.u_grad, tau)
+                                        batch.u_diff_start, batch.u_grad, tau, want_grad=w_grad > 0)
     bkgd = torch.nn.functional.softplus(bkgd_raw) if cfg.bkgd_is_param else None
     out = {}
+    grad_kw = {}
+    if w_grad > 0:
+        ts_g = tsd["grad_ts"]
+        if not ts_g.requires_grad:
+            ts_g = ts_g.detach().requires_grad_()               # robust_e_nerf.py:355
+        pos, R = trajectory.linear_trajectory(ts_g, tab_ts, tab_pos, tab_quat)
+        out["grad"] = render_pixels(Kinv, batch.position, pos, R, p, spec, cfg,
+                                    binary=binary, jitter=jitter_grad, bkgd=bkgd, training=True)
+        log_g = out["grad"][0].log()
+        (dlog,) = torch.autograd.grad(log_g, ts_g, torch.ones_like(log_g), create_graph=True)   # utils/autograd.py:4-34
+        grad_kw = dict(pred_log_grad=dlog, grad_valid=out["grad"][4])
     for name, ts, jit in (("start", tsd["diff_start_ts"], jitter_start),
                           ("end", tsd["diff_end_ts"], jitter_end)):
         pos, R = trajectory.linear_trajectory(ts, tab_ts, tab_pos, tab_quat)
@@ -125,8 +139,8 @@ def training_forward(batch: EventBatch, p, spec, cfg: SceneCfg, *, Kinv, tab_ts,
     valid = out["start"][4] | out["end"][4]
     loss, terms = events.event_loss(
         ev_diff, tsd["start_ts"], batch.end_ts, pred_log_diff=pred, ts_diff=tsd["ts_diff"],
-        diff_valid=valid, mean_c=mean_c, **lc)
-    aux = dict(ts=tsd, intensity_start=out["start"][0], intensity_end=out["end"][0],
+        diff_valid=valid, mean_c=mean_c, **lc, **grad_kw)
+    aux = dict(ts=tsd, grad=out.get("grad"), pred_log_grad=grad_kw.get("pred_log_grad"), intensity_start=out["start"][0], intensity_end=out["end"][0],
                opacity_start=out["start"][1], opacity_end=out["end"][1],
                n_start=out["start"][3], n_end=out["end"][3], pred_log_diff=pred, terms=terms,
                packed_start=out["start"][5], packed_end=out["end"][5])

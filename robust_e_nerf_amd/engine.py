@@ -355,6 +355,20 @@ class Trainer:
         ops.adam_step(self.small, self.small_grad, self.sm, self.sv, lr=lr, betas=self.t.betas, eps=self.t.eps,
                       weight_decay=0.0, step=self.step_count, grad_scale=gs, zero_grad=True)
 
+    def update_train_batch_size(self, aux, eff_ray_sample_batch_size: int = 1 << 20) -> int:
+        """Dynamic batch size (robust_e_nerf.py:907-950): keep rays x samples per render near the budget.
+        mean_S = mean over this step's renders of n/R, averaged over ranks (C2); budget = eff // num_gpus
+        (:63-66).  Returns the new per-rank event batch size."""
+        from . import parallel
+        mean_s = parallel.allgather_mean(aux["n"] / max(aux["rays"], 1), self.pg) if self.world_size > 1 \
+            else aux["n"] / max(aux["rays"], 1)
+        budget = parallel.per_rank_budget(eff_ray_sample_batch_size, self.world_size)
+        return int(budget / max(mean_s, 1e-9))
+
+    def set_epoch(self, epoch: int, milestones=(20, 30, 36), gamma: float = 0.33):
+        """MultiStepLR stepped per epoch (robust_e_nerf.py:818-832, synthetic.yaml:113-128)."""
+        self.lr_scale = gamma ** sum(1 for m in milestones if epoch >= m)
+
     def step(self, batch, jitter_start=None, jitter_end=None, global_step: Optional[int] = None):
         if global_step is not None:
             self.r.update_occ_grid(global_step, self.tab_pos)

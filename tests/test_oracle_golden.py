@@ -88,11 +88,19 @@ def _run_training_step(g, table, with_grad):
                             t(g["u_ts_diff"]), t(g["u_diff_start"]), t(g["u_grad"]))
     bkgd_raw = t(g["bkgd_raw"]).requires_grad_()
     jit = t(g["jitters"])
+    extra = {}
+    lc = None
+    if with_grad:
+        extra = dict(p2n_raw=t(g["p2n_raw"]).requires_grad_(), tau_raw=t(g["tau_raw"]).requires_grad_())
+        lc = dict(w_grad=float(g["w_grad"]), err_grad="mape", pw_grad=None)
+    kw = dict(p2n_raw=t(g["p2n_raw"]), tau_raw=t(g["tau_raw"]))
+    kw.update(extra)
     loss, aux = step.training_forward(
         batch, p, SPEC, cfg, Kinv=t(g["Kinv"]), tab_ts=t(g["tab_ts"]), tab_pos=t(g["tab_pos"]),
-        tab_quat=t(g["tab_quat"]), p2n_raw=t(g["p2n_raw"]), neg_ct=t(g["neg_ct"]), tau_raw=t(g["tau_raw"]),
+        tab_quat=t(g["tab_quat"]), neg_ct=t(g["neg_ct"]),
         tau_max=t(g["tau_max"]), bkgd_raw=bkgd_raw, binary=binary,
-        jitter_start=jit[-2], jitter_end=jit[-1])
+        jitter_start=jit[-2], jitter_end=jit[-1], jitter_grad=jit[0] if with_grad else None, loss_cfg=lc, **kw)
+    aux["leaves"] = kw
     return loss, aux, p, bkgd_raw
 
 
@@ -110,3 +118,19 @@ def test_training_step_diff(full_table_cache):
         assert rel_err(p[k].grad, g["g." + k]) < 2e-4, k
     assert rel_err(bkgd_raw.grad, g["g_bkgd_raw"]) < 1e-4
     assert rel_err(p["hash"].grad[t(g["g_table_idx"])], g["g_table_val"]) < 2e-4
+
+
+def test_training_step_grad(full_table_cache):
+    """The reference's real training_step with l_diff + l_grad (C_p and tau trainable): the second-order
+    path (autograd.gradient(..., create_graph=True), robust_e_nerf.py:395-398) through the oracle."""
+    g = load_golden("training_step_grad")
+    table = full_table_cache(g["table_seed"], g["table_scale"]).clone()
+    loss, aux, p, bkgd_raw = _run_training_step(g, table, True)
+    assert rel_err(loss, g["loss"]) < 1e-5
+    loss.backward()
+    for k in FIELD_KEYS:
+        assert rel_err(p[k].grad, g["g." + k]) < 5e-4, k
+    assert rel_err(bkgd_raw.grad, g["g_bkgd_raw"]) < 1e-4
+    assert rel_err(p["hash"].grad[t(g["g_table_idx"])], g["g_table_val"]) < 5e-4
+    assert rel_err(aux["leaves"]["p2n_raw"].grad, g["g_p2n_raw"]) < 1e-4
+    assert rel_err(aux["leaves"]["tau_raw"].grad, g["g_tau_raw"]) < 1e-3
