@@ -247,6 +247,66 @@ int ren_occgrid_ema(float *occs, const int64_t *indices, const uint8_t *valid, c
 int ren_occgrid_binarize(const float *occs, int64_t cells, float occ_thre, uint8_t *binary,
                          float *scratch, void *stream);
 
+/* ---- forward-mode tangent path for the log-intensity-GRADIENT loss ---------------------------------
+ * The reference computes d(log I)/d(timestamp) per ray with autograd.gradient(..., create_graph=True)
+ * (robust_e_nerf/models/robust_e_nerf.py:383-409, utils/autograd.py:4-34) and back-propagates through
+ * it.  Here every stage carries a tangent ("*d" arrays = d/dt, per unit of the timestamp) next to its
+ * value, and the *_bwd_jvp entry points are the reverse pass over the (value, tangent) pair.  Sample
+ * placement is not differentiated (external/vol_rendering.py:36-37).  Fragment layouts as above. */
+/* LinearTrajectory.forward + d/dt: dpos[B,3], drot[B,9] */
+int ren_trajectory_jvp(const double *ts, int64_t B, const int64_t *tab_ts, const float *tab_pos,
+                       const float *tab_quat, int64_t C, float *pos, float *rot, float *dpos, float *drot,
+                       void *stream);
+/* pixel_params_to_ray + d/dt: rays_do[B,3], rays_dd[B,3] */
+int ren_raygen_jvp(const float *Kinv, const float *px, const float *pos, const float *rot, const float *dpos,
+                   const float *drot, int64_t B, float *rays_o, float *rays_d, float *rays_do, float *rays_dd,
+                   void *stream);
+/* hash features and their tangent (x = o + d tm, xd = od + dd tm) */
+int ren_hashgrid_fwd_jvp(const ren_grid_desc *grid, const float *table, const ren_scene_desc *scene,
+                         const float *rays_o, const float *rays_d, const float *rays_do, const float *rays_dd,
+                         const int32_t *ray_indices, const float *t_starts, const float *t_ends, int64_t n,
+                         float *feat, float *featd, void *stream);
+/* grad_table += w dfeat + wd dfeatd (per-update atomics) */
+int ren_hashgrid_bwd_jvp(const ren_grid_desc *grid, float *grad_table, const ren_scene_desc *scene,
+                         const float *rays_o, const float *rays_d, const float *rays_do, const float *rays_dd,
+                         const int32_t *ray_indices, const float *t_starts, const float *t_ends, int64_t n,
+                         const float *dfeat, const float *dfeatd, void *stream);
+/* fused MLPs with tangent: rgb, rgbd [n,C]; sigma, sigmad [n]; base_out, base_outd (ceil(n/32)*512 floats) */
+int ren_mlp_fwd_jvp(const float *mlp_params, int32_t radiance_dim, const float *feat, const float *featd,
+                    const ren_scene_desc *scene, const float *rays_o, const float *rays_d, const float *rays_dd,
+                    const int32_t *ray_indices, const float *t_starts, const float *t_ends, int64_t n,
+                    float *rgb, float *rgbd, float *sigma, float *sigmad, float *base_out, float *base_outd,
+                    void *stream);
+int64_t ren_mlp_bwd_jvp_workspace_floats(int32_t radiance_dim);
+/* reverse pass: (d_rgb, d_rgbd, d_sigma, d_sigmad) -> dfeat, dfeatd (fragment) and grad_mlp_params (+=).
+ * scratch: ceil(n/32)*5120 floats; workspace: ren_mlp_bwd_jvp_workspace_floats() floats. */
+int ren_mlp_bwd_jvp(const float *mlp_params, int32_t radiance_dim, const float *feat, const float *featd,
+                    const float *base_out, const float *base_outd, const ren_scene_desc *scene,
+                    const float *rays_o, const float *rays_d, const float *rays_dd, const int32_t *ray_indices,
+                    const float *t_starts, const float *t_ends, int64_t n, const float *rgb,
+                    const float *d_rgb, const float *d_rgbd, const float *d_sigma, const float *d_sigmad,
+                    float *scratch, float *dfeat, float *dfeatd, float *grad_mlp_params, float *workspace,
+                    void *stream);
+/* compositing with tangent: colors/colords [n_rays,C], opacities/opacds [n_rays]; saves weights, trans,
+ * eds (exclusive prefix of sigmad*dt) [n] for the reverse pass */
+int ren_composite_fwd_jvp(const int64_t *offsets, const int32_t *counts, int64_t n_rays, const float *t_starts,
+                          const float *t_ends, const float *sigmas, const float *sigmads, const float *rgbs,
+                          const float *rgbds, int32_t C, const float *bkgd, float *colors, float *colords,
+                          float *opacities, float *opacds, float *weights, float *trans, float *eds, void *stream);
+int ren_composite_bwd_jvp(const int64_t *offsets, const int32_t *counts, int64_t n_rays, const float *t_starts,
+                          const float *t_ends, const float *sigmas, const float *sigmads, const float *rgbs,
+                          const float *rgbds, int32_t C, const float *bkgd, const float *weights,
+                          const float *trans, const float *eds, const float *opacities, const float *opacds,
+                          const float *g_colors, const float *g_colords, float *d_sigmas, float *d_sigmads,
+                          float *d_rgbs, float *d_rgbds, float *d_bkgd_per_ray, void *stream);
+/* Loss.log_intensity_grad (loss_metric/loss.py:43-57): pred = intensity_dot / intensity vs target;
+ * same loss_sum / scale conventions as ren_event_loss_fwd/bwd */
+int ren_grad_loss_fwd(const float *intensity, const float *intensity_dot, const float *target,
+                      const uint8_t *valid, int64_t B, int32_t err_fn, float *loss_sum, void *stream);
+int ren_grad_loss_bwd(const float *intensity, const float *intensity_dot, const float *target,
+                      const uint8_t *valid, int64_t B, int32_t err_fn, float scale, const float *loss_sum,
+                      float *g_intensity, float *g_intensity_dot, void *stream);
+
 /* ---- utilities ------------------------------------------------------------------------------------- */
 /* out[c] = sum_r in[r*C + c]   (C <= 4) */
 int ren_column_sum(const float *in, int64_t rows, int32_t C, float *out, void *stream);

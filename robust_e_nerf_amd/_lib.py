@@ -61,6 +61,18 @@ SIGNATURES = {
     "ren_occgrid_ema": (c_int, [P, P, P, P, P, c_float, c_int64, c_float, P]),
     "ren_occgrid_binarize": (c_int, [P, c_int64, c_float, P, P, P]),
     "ren_column_sum": (c_int, [P, c_int64, c_int32, P, P]),
+    "ren_trajectory_jvp": (c_int, [P, c_int64, P, P, P, c_int64, P, P, P, P, P]),
+    "ren_raygen_jvp": (c_int, [P, P, P, P, P, P, c_int64, P, P, P, P, P]),
+    "ren_hashgrid_fwd_jvp": (c_int, [POINTER(GridDesc), P, POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, P, P, P]),
+    "ren_hashgrid_bwd_jvp": (c_int, [POINTER(GridDesc), P, POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, P, P, P]),
+    "ren_mlp_fwd_jvp": (c_int, [P, c_int32, P, P, POINTER(SceneDesc), P, P, P, P, P, P, c_int64, P, P, P, P, P, P, P]),
+    "ren_mlp_bwd_jvp_workspace_floats": (c_int64, [c_int32]),
+    "ren_mlp_bwd_jvp": (c_int, [P, c_int32, P, P, P, P, POINTER(SceneDesc), P, P, P, P, P, P, c_int64, P, P, P, P, P,
+                                P, P, P, P, P, P]),
+    "ren_composite_fwd_jvp": (c_int, [P, P, c_int64, P, P, P, P, P, P, c_int32, P, P, P, P, P, P, P, P, P]),
+    "ren_composite_bwd_jvp": (c_int, [P, P, c_int64, P, P, P, P, P, P, c_int32, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "ren_grad_loss_fwd": (c_int, [P, P, P, P, c_int64, c_int32, P, P]),
+    "ren_grad_loss_bwd": (c_int, [P, P, P, P, c_int64, c_int32, c_float, P, P, P, P]),
 }
 
 _lib = None

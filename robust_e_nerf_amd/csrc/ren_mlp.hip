@@ -21,140 +21,9 @@
 // their gradients are staged once per layer through a per-wave LDS tile [neuron][33] and the
 // 32x32 dW tiles accumulate in registers over the whole kernel; every wave writes its partial
 // dW to a slab in HBM and a small kernel reduces the slabs (deterministic, no atomics).
-#include "ren_common.h"
+#include "ren_mlp_common.h"
 
 namespace {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
-
-// ---- parameter block offsets (floats), torch nn.Linear layout ------------------------------
-constexpr int P_BW0 = 0;          // base.w0 [64,32]
-constexpr int P_BB0 = 2048;       // base.b0 [64]
-constexpr int P_BWO = 2112;       // base.wo [16,64]
-constexpr int P_BBO = 3136;       // base.bo [16]
-constexpr int P_HW0 = 3152;       // head.w0 [64,31]
-constexpr int P_HB0 = 5136;       // head.b0 [64]
-constexpr int P_HW1 = 5200;       // head.w1 [64,64]
-constexpr int P_HB1 = 9296;       // head.b1 [64]
-constexpr int P_HWO = 9360;       // head.wo [C,64]   ; head.bo [C] follows
-constexpr int P_BASE_N = 3152;    // number of base-MLP parameters
-__host__ __device__ constexpr int p_total(int C) { return P_HWO + 65 * C; }
-
-// ---- LDS weight image (floats) -----------------------------------------------------------
-constexpr int L_W1 = 0;                    // [64][33]
-constexpr int L_W2 = L_W1 + 64 * 33;       // [32][65]  rows >= 16 are zero
-constexpr int L_WH1 = L_W2 + 32 * 65;      // [64][33]  input order v: 0 = sigma slot (w=0), 1..15 geo, 16..31 SH
-constexpr int L_WH2 = L_WH1 + 64 * 33;     // [64][65]
-constexpr int L_WH3 = L_WH2 + 64 * 65;     // [3][64]
-constexpr int L_B1 = L_WH3 + 192;          // [64]
-constexpr int L_B2 = L_B1 + 64;            // [32]  >= 16 zero
-constexpr int L_BH1 = L_B2 + 32;           // [64]
-constexpr int L_BH2 = L_BH1 + 64;          // [64]
-constexpr int L_BH3 = L_BH2 + 64;          // [4]
-constexpr int L_WEIGHTS_END = L_BH3 + 4;   // 10884 floats = 43 536 B
-
-__device__ __forceinline__ constexpr int rowc(int g) { return (g & 3) + 8 * (g >> 2); }   // + 4*hi
-
-__device__ __forceinline__ float log1p_fast(float e) {       // e >= 0
-    return e < 1e-3f ? e * (1.f - e * (0.5f - e * 0.33333333f)) : __logf(1.f + e);
-}
-// torch softplus(beta, threshold=20): x if beta*x > 20 else log1p(exp(beta*x))/beta
-__device__ __forceinline__ float softplus100(float x) {
-    const float z = 100.f * x;
-    return z > 20.f ? x : log1p_fast(__expf(z)) * 0.01f;
-}
-__device__ __forceinline__ float softplus1(float x) { return x > 20.f ? x : log1p_fast(__expf(x)); }
-// derivative of softplus(beta) expressed through its OUTPUT y: sigmoid(beta x) = 1 - exp(-beta y)
-__device__ __forceinline__ float dsoftplus_from_out(float y, float beta) {
-    const float t = beta * y;
-    return t < 1e-3f ? t * (1.f - t * (0.5f - t * 0.16666667f)) : 1.f - __expf(-t);
-}
-
-__device__ void fill_base(float *lds, const float *__restrict__ P, int oW1, int oW2, int oB1, int oB2) {
-    const int t = threadIdx.x, nt = blockDim.x;
-    for (int i = t; i < 64 * 32; i += nt) lds[oW1 + (i >> 5) * 33 + (i & 31)] = P[P_BW0 + i];
-    for (int i = t; i < 32 * 64; i += nt) {
-        const int o = i >> 6, k = i & 63;
-        lds[oW2 + o * 65 + k] = o < 16 ? P[P_BWO + o * 64 + k] : 0.f;
-    }
-    for (int i = t; i < 64; i += nt) lds[oB1 + i] = P[P_BB0 + i];
-    for (int i = t; i < 32; i += nt) lds[oB2 + i] = i < 16 ? P[P_BBO + i] : 0.f;
-}
-
-__device__ void fill_head(float *lds, const float *__restrict__ P, int C, int oWH1, int oWH2, int oWH3,
-                          int oBH1, int oBH2, int oBH3) {
-    const int t = threadIdx.x, nt = blockDim.x;
-    for (int i = t; i < 64 * 32; i += nt) {
-        const int o = i >> 5, v = i & 31;
-        float w;
-        if (v == 0) w = 0.f;                                   // sigma_raw is not a head input (ngp.py:244-246)
-        else if (v < 16) w = P[P_HW0 + o * 31 + 15 + v];       // geo feature v-1 -> column 16 + (v-1)
-        else w = P[P_HW0 + o * 31 + (v - 16)];                 // SH component v-16 -> column v-16 (ngp.py:259)
-        lds[oWH1 + o * 33 + v] = w;
-    }
-    for (int i = t; i < 64 * 64; i += nt) lds[oWH2 + (i >> 6) * 65 + (i & 63)] = P[P_HW1 + i];
-    for (int i = t; i < 64 * C; i += nt) lds[oWH3 + i] = P[P_HWO + i];
-    for (int i = t; i < 64; i += nt) { lds[oBH1 + i] = P[P_HB0 + i]; lds[oBH2 + i] = P[P_HB1 + i]; }
-    for (int i = t; i < C; i += nt) lds[oBH3 + i] = P[P_HWO + 64 * C + i];
-}
-
-// compact LDS images for the two backward kernels
-constexpr int LH_WH1 = 0, LH_WH2 = LH_WH1 + 64 * 33, LH_WH3 = LH_WH2 + 64 * 65, LH_BH1 = LH_WH3 + 192,
-              LH_BH2 = LH_BH1 + 64, LH_BH3 = LH_BH2 + 64, LH_END = LH_BH3 + 4;       // 6596 floats
-constexpr int LB_W1 = 0, LB_W2 = LB_W1 + 64 * 33, LB_B1 = LB_W2 + 32 * 65, LB_B2 = LB_B1 + 64,
-              LB_END = LB_B2 + 32;                                                     // 4288 floats
-
-// real SH degree 4, tcnn sign convention (external/sh_encoder.py:56-77); returns the 8
-// components of parity `hi` (component 2j+hi in out[j]).
-__device__ __forceinline__ void sh4_select(float x, float y, float z, int hi, float *out) {
-    const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
-    float s[16];
-    s[0] = 0.28209479177387814f;
-    s[1] = -0.48860251190291987f * y;
-    s[2] = 0.48860251190291987f * z;
-    s[3] = -0.48860251190291987f * x;
-    s[4] = 1.0925484305920792f * xy;
-    s[5] = -1.0925484305920792f * yz;
-    s[6] = 0.94617469575755997f * z2 - 0.31539156525251999f;
-    s[7] = -1.0925484305920792f * xz;
-    s[8] = 0.54627421529603959f * x2 - 0.54627421529603959f * y2;
-    s[9] = 0.59004358992664352f * y * (-3.0f * x2 + y2);
-    s[10] = 2.8906114426405538f * xy * z;
-    s[11] = 0.45704579946446572f * y * (1.0f - 5.0f * z2);
-    s[12] = 0.3731763325901154f * z * (5.0f * z2 - 3.0f);
-    s[13] = 0.45704579946446572f * x * (1.0f - 5.0f * z2);
-    s[14] = 1.4453057213202769f * z * (x2 - y2);
-    s[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) out[j] = hi ? s[2 * j + 1] : s[2 * j];
-}
-
-struct SampleSrc {
-    const float *x_world, *dirs;                 // per-sample (seam API) -- or --
-    const float *rays_o, *rays_d;                // packed stream
-    const int32_t *ray_indices;
-    const float *t_starts, *t_ends;
-};
-
-// position (contracted -> selector) and view direction of sample i
-__device__ __forceinline__ void sample_geom(const SampleSrc &s, const ren_scene_dev &sc, int64_t i,
-                                            bool &sel, float &dx, float &dy, float &dz) {
-    float x, y, z;
-    if (s.ray_indices) {
-        int ray;
-        ren_sample_pos(s.rays_o, s.rays_d, s.ray_indices, s.t_starts, s.t_ends, i, x, y, z, ray);
-        const float *d = s.rays_d + 3 * (int64_t)ray;
-        dx = d[0]; dy = d[1]; dz = d[2];
-    } else {
-        x = s.x_world[3 * i]; y = s.x_world[3 * i + 1]; z = s.x_world[3 * i + 2];
-        if (s.dirs) { dx = s.dirs[3 * i]; dy = s.dirs[3 * i + 1]; dz = s.dirs[3 * i + 2]; }
-        else { dx = 0.f; dy = 0.f; dz = 1.f; }
-    }
-    float ux, uy, uz;
-    ren_contract(sc, x, y, z, ux, uy, uz);
-    sel = ux > 0.f && ux < 1.f && uy > 0.f && uy < 1.f && uz > 0.f && uz < 1.f;   // ngp.py:238
-}
 
 // ============================================================================ forward
 struct FwdArgs {
@@ -628,23 +497,6 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_base_kernel(BwdBArgs a) {
         const float b1 = acc_b1[ob] + __shfl_xor(acc_b1[ob], 32, 64);
         if (hi == 0) slab[P_BB0 + 32 * ob + sl] = b1;
     }
-}
-
-// grad[off + j] += sum_w slab[w * len + j]
-__global__ void reduce_slabs_kernel(const float *__restrict__ slab, int n_slabs, int len,
-                                    float *__restrict__ grad) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= len) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int w = 0;
-    for (; w + 3 < n_slabs; w += 4) {
-        s0 += slab[(int64_t)w * len + j];
-        s1 += slab[(int64_t)(w + 1) * len + j];
-        s2 += slab[(int64_t)(w + 2) * len + j];
-        s3 += slab[(int64_t)(w + 3) * len + j];
-    }
-    for (; w < n_slabs; ++w) s0 += slab[(int64_t)w * len + j];
-    grad[j] += (s0 + s1) + (s2 + s3);
 }
 
 constexpr size_t FWD_LDS = (size_t)L_WEIGHTS_END * 4;

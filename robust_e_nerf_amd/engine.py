@@ -256,6 +256,9 @@ class TrainCfg:
     betas: Tuple[float, float] = (0.9, 0.999)
     eps: float = 1e-8
     bkgd_is_param: bool = True
+    err_grad: str = "mape"                       # loss.error_fn.log_intensity_grad
+    w_grad: float = 0.0                          # loss.weight.log_intensity_grad (1e-3 in the real-data configs)
+    pw_grad: Optional[str] = None                # loss.param_weight.log_intensity_grad
 
 
 class Trainer:
@@ -339,6 +342,38 @@ class Trainer:
                    opacity=opac, rays=2 * B)
         return loss, aux
 
+    def grad_loss_forward_backward(self, batch, jitter_grad=None):
+        """Log-intensity-GRADIENT loss term (robust_e_nerf.py:340-357,383-409; loss.py:43-57): a third
+        render at grad.ts = lerp(diff.start, diff.end, u_grad) carrying d/dt in forward mode, compared
+        with the event rate C/dt.  Accumulates gradients; returns (weighted loss term, aux)."""
+        from . import jvp
+        r, t, f = self.r, self.t, self.r.field
+        B = batch["position"].shape[0]
+        d_start, d_end, _ = self._prepare(batch)
+        ts_g = torch.lerp(d_start, d_end, batch["u_grad"]).contiguous()
+        ev_diff = batch["num_pos"] * self.c_p - batch["num_neg"] * self.c_n
+        start = batch["start_ts"].to(torch.float64) + self.tau
+        target = (ev_diff / (batch["end_ts"] - start)).to(torch.float32).contiguous()      # loss.py:39-42
+        pos, rot, dpos, drot = jvp.trajectory_jvp(ts_g, self.tab_ts, self.tab_pos, self.tab_quat)
+        o, d, od, dd = jvp.raygen_jvp(self.Kinv, batch["position"].contiguous(), pos, rot, dpos, drot)
+        bkgd = torch.nn.functional.softplus(self.small[: f.C]) if t.bkgd_is_param else None
+        jit = None if jitter_grad is None else jitter_grad.to(torch.float32).contiguous()
+        colors, colords, opac, ctx = jvp.render_forward(r, o, d, od, dd, jit, bkgd, training=True)
+        inten = (colors[:, 0] + r.cfg.min_modeled_intensity).contiguous()
+        intend = colords[:, 0].contiguous()                                   # d I/dt ; d log I/dt = Id / I
+        valid = None if t.bkgd_is_param else (opac > 0).to(torch.uint8).contiguous()
+        loss_sum = jvp.grad_loss_fwd(inten, intend, target, valid, t.err_grad)
+        inv_c = 1.0 / self.mean_c
+        pw = {None: 1.0, "mean_contrast_reciprocal": inv_c, "mean_contrast_reciprocal_sq": inv_c ** 2}[t.pw_grad]
+        scale = pw * t.w_grad
+        loss = loss_sum[0] / loss_sum[1] * scale
+        g_i, g_id = jvp.grad_loss_bwd(inten, intend, target, valid, t.err_grad, scale, loss_sum)
+        d_bkgd = jvp.render_backward(r, ctx, g_i[:, None].contiguous(), g_id[:, None].contiguous())
+        if d_bkgd is not None:
+            self.small_grad[: f.C] += d_bkgd * torch.sigmoid(self.small[: f.C])
+        aux = dict(intensity=inten, dlog_dt=intend / inten, n=ctx["pk"].n, rays=B)
+        return loss, aux
+
     def optimizer_step(self):
         """Adam on [hash table | MLPs] (lr default, L2 decay 1e-6: robust_e_nerf.py:786-813) and on the
         background scalar (no decay).  Under data parallelism gradients are summed over ranks (RCCL
@@ -369,9 +404,13 @@ class Trainer:
         """MultiStepLR stepped per epoch (robust_e_nerf.py:818-832, synthetic.yaml:113-128)."""
         self.lr_scale = gamma ** sum(1 for m in milestones if epoch >= m)
 
-    def step(self, batch, jitter_start=None, jitter_end=None, global_step: Optional[int] = None):
+    def step(self, batch, jitter_start=None, jitter_end=None, global_step: Optional[int] = None, jitter_grad=None):
         if global_step is not None:
             self.r.update_occ_grid(global_step, self.tab_pos)
         loss, aux = self.forward_backward(batch, jitter_start, jitter_end)
+        if self.t.w_grad > 0:
+            lg, aux_g = self.grad_loss_forward_backward(batch, jitter_grad)
+            loss = loss + lg
+            aux = dict(aux, grad=aux_g)
         self.optimizer_step()
         return loss, aux

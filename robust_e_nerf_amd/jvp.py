@@ -1,0 +1,115 @@
+"""Log-intensity-gradient supervision: render + d(render)/d(timestamp) in one forward-mode pass and
+the reverse pass over the (value, tangent) pair.  Replaces the reference's
+``autograd.gradient(log_intensity, ts, create_graph=True)`` second-order path
+(robust_e_nerf/models/robust_e_nerf.py:383-409, utils/autograd.py:4-34).  See csrc/ren_jvp.hip.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import _lib, ops
+from ._lib import check
+from .ops import _f, _ptr, _stream
+
+
+def trajectory_jvp(ts, tab_ts, tab_pos, tab_quat):
+    B, dev = ts.shape[0], ts.device
+    pos, dpos = torch.empty(B, 3, device=dev), torch.empty(B, 3, device=dev)
+    rot, drot = torch.empty(B, 3, 3, device=dev), torch.empty(B, 3, 3, device=dev)
+    check(_lib.load().ren_trajectory_jvp(_ptr(ts, torch.float64), B, _ptr(tab_ts, torch.int64), _ptr(tab_pos),
+                                         _ptr(tab_quat), tab_ts.shape[0], _ptr(pos), _ptr(rot), _ptr(dpos),
+                                         _ptr(drot), _stream()), "ren_trajectory_jvp")
+    return pos, rot, dpos, drot
+
+
+def raygen_jvp(Kinv, px, pos, rot, dpos, drot):
+    B, dev = px.shape[0], px.device
+    o, d, od, dd = (torch.empty(B, 3, device=dev) for _ in range(4))
+    check(_lib.load().ren_raygen_jvp(_ptr(Kinv), _ptr(px), _ptr(pos), _ptr(rot), _ptr(dpos), _ptr(drot), B,
+                                     _ptr(o), _ptr(d), _ptr(od), _ptr(dd), _stream()), "ren_raygen_jvp")
+    return o, d, od, dd
+
+
+def render_forward(r, o, d, od, dd, jitter, bkgd, training: bool = True):
+    """-> colors (R,C), colords (R,C) [d/dt], opacity (R,), ctx."""
+    f, lib = r.field, _lib.load()
+    pk = r.sample(o, d, jitter, training)
+    n, R, dev = pk.n, o.shape[0], o.device
+    if n == 0:
+        colors = torch.zeros(R, f.C, device=dev) + (bkgd if bkgd is not None else 0.0)
+        return colors, torch.zeros(R, f.C, device=dev), torch.zeros(R, device=dev), dict(pk=pk, empty=True, bkgd=bkgd)
+    nb = ops.n_blocks32(n)
+    feat = torch.empty(nb * 1024, device=dev)
+    featd = torch.empty(nb * 1024, device=dev)
+    ri, ts, te = pk.ray_indices, pk.t_starts, pk.t_ends
+    check(lib.ren_hashgrid_fwd_jvp(ctypes.byref(f.grid), _ptr(f.table), ctypes.byref(r.scene), _ptr(o), _ptr(d),
+                                   _ptr(od), _ptr(dd), _ptr(ri), _ptr(ts), _ptr(te), n, _ptr(feat), _ptr(featd),
+                                   _stream()), "ren_hashgrid_fwd_jvp")
+    rgb, rgbd = torch.empty(n, f.C, device=dev), torch.empty(n, f.C, device=dev)
+    sigma, sigmad = torch.empty(n, device=dev), torch.empty(n, device=dev)
+    base, based = torch.empty(nb * 512, device=dev), torch.empty(nb * 512, device=dev)
+    check(lib.ren_mlp_fwd_jvp(_ptr(f.mlp), f.C, _ptr(feat), _ptr(featd), ctypes.byref(r.scene), _ptr(o), _ptr(d),
+                              _ptr(dd), _ptr(ri), _ptr(ts), _ptr(te), n, _ptr(rgb), _ptr(rgbd), _ptr(sigma),
+                              _ptr(sigmad), _ptr(base), _ptr(based), _stream()), "ren_mlp_fwd_jvp")
+    colors, colords = torch.empty(R, f.C, device=dev), torch.empty(R, f.C, device=dev)
+    opac, opacd = torch.empty(R, device=dev), torch.empty(R, device=dev)
+    w, T, eds = (torch.empty(n, device=dev) for _ in range(3))
+    check(lib.ren_composite_fwd_jvp(_ptr(pk.offsets), _ptr(pk.counts), R, _ptr(ts), _ptr(te), _ptr(sigma),
+                                    _ptr(sigmad), _ptr(rgb), _ptr(rgbd), f.C, _ptr(bkgd), _ptr(colors),
+                                    _ptr(colords), _ptr(opac), _ptr(opacd), _ptr(w), _ptr(T), _ptr(eds), _stream()),
+          "ren_composite_fwd_jvp")
+    ctx = dict(pk=pk, o=o, d=d, od=od, dd=dd, feat=feat, featd=featd, rgb=rgb, rgbd=rgbd, sigma=sigma,
+               sigmad=sigmad, base=base, based=based, w=w, T=T, eds=eds, opac=opac, opacd=opacd, bkgd=bkgd,
+               empty=False)
+    return colors, colords, opac, ctx
+
+
+def render_backward(r, ctx, g_colors, g_colords):
+    """Accumulates into r.field.grad; returns d(bkgd) (C,) or None."""
+    f, lib = r.field, _lib.load()
+    if ctx["empty"]:
+        return g_colors.sum(0) if ctx.get("bkgd") is not None else None
+    pk = ctx["pk"]
+    n, R, dev = pk.n, ctx["o"].shape[0], ctx["o"].device
+    nb = ops.n_blocks32(n)
+    ri, ts, te = pk.ray_indices, pk.t_starts, pk.t_ends
+    d_sig, d_sigd = torch.empty(n, device=dev), torch.empty(n, device=dev)
+    d_rgb, d_rgbd = torch.empty(n, f.C, device=dev), torch.empty(n, f.C, device=dev)
+    bk = ctx["bkgd"]
+    d_bk = torch.empty(R, f.C, device=dev) if bk is not None else None
+    check(lib.ren_composite_bwd_jvp(_ptr(pk.offsets), _ptr(pk.counts), R, _ptr(ts), _ptr(te), _ptr(ctx["sigma"]),
+                                    _ptr(ctx["sigmad"]), _ptr(ctx["rgb"]), _ptr(ctx["rgbd"]), f.C, _ptr(bk),
+                                    _ptr(ctx["w"]), _ptr(ctx["T"]), _ptr(ctx["eds"]), _ptr(ctx["opac"]),
+                                    _ptr(ctx["opacd"]), _ptr(g_colors.contiguous()), _ptr(g_colords.contiguous()),
+                                    _ptr(d_sig), _ptr(d_sigd), _ptr(d_rgb), _ptr(d_rgbd), _ptr(d_bk), _stream()),
+          "ren_composite_bwd_jvp")
+    scratch = torch.empty(nb * 5120, device=dev)
+    dfeat, dfeatd = torch.empty(nb * 1024, device=dev), torch.empty(nb * 1024, device=dev)
+    ws = torch.empty(int(lib.ren_mlp_bwd_jvp_workspace_floats(f.C)), device=dev)
+    check(lib.ren_mlp_bwd_jvp(_ptr(f.mlp), f.C, _ptr(ctx["feat"]), _ptr(ctx["featd"]), _ptr(ctx["base"]),
+                              _ptr(ctx["based"]), ctypes.byref(r.scene), _ptr(ctx["o"]), _ptr(ctx["d"]),
+                              _ptr(ctx["dd"]), _ptr(ri), _ptr(ts), _ptr(te), n, _ptr(ctx["rgb"]), _ptr(d_rgb),
+                              _ptr(d_rgbd), _ptr(d_sig), _ptr(d_sigd), _ptr(scratch), _ptr(dfeat), _ptr(dfeatd),
+                              _ptr(f.g_mlp), _ptr(ws), _stream()), "ren_mlp_bwd_jvp")
+    check(lib.ren_hashgrid_bwd_jvp(ctypes.byref(f.grid), _ptr(f.g_table), ctypes.byref(r.scene), _ptr(ctx["o"]),
+                                   _ptr(ctx["d"]), _ptr(ctx["od"]), _ptr(ctx["dd"]), _ptr(ri), _ptr(ts), _ptr(te), n,
+                                   _ptr(dfeat), _ptr(dfeatd), _stream()), "ren_hashgrid_bwd_jvp")
+    return ops.column_sum(d_bk) if d_bk is not None else None
+
+
+def grad_loss_fwd(inten, intend, target, valid, err_fn: str):
+    loss_sum = torch.empty(2, device=inten.device)
+    check(_lib.load().ren_grad_loss_fwd(_ptr(inten), _ptr(intend), _ptr(target), _ptr(valid), inten.shape[0],
+                                        ops.ERR_FN[err_fn], _ptr(loss_sum), _stream()), "ren_grad_loss_fwd")
+    return loss_sum
+
+
+def grad_loss_bwd(inten, intend, target, valid, err_fn: str, scale: float, loss_sum):
+    g_i, g_id = torch.empty_like(inten), torch.empty_like(intend)
+    check(_lib.load().ren_grad_loss_bwd(_ptr(inten), _ptr(intend), _ptr(target), _ptr(valid), inten.shape[0],
+                                        ops.ERR_FN[err_fn], _f(scale), _ptr(loss_sum), _ptr(g_i), _ptr(g_id),
+                                        _stream()), "ren_grad_loss_bwd")
+    return g_i, g_id

@@ -605,3 +605,45 @@ def test_eval_render_psnr_vs_oracle(amd, spec, full_table_cache):
     assert rel_err(depth.cpu().reshape(-1), d_o) < 1e-3
     aligned = evaluation.affine_align_log(img.cpu().reshape(-1) * 1.7, i_o)      # affine ambiguity removed
     assert evaluation.psnr(aligned, i_o, data_range=float(i_o.max() - i_o.min())) > 60.0
+
+
+# ------------------------------------------------------------------------------------------ log-intensity-gradient loss
+def test_pose_tangent_vs_oracle_autograd(amd):
+    from oracle import trajectory as otraj
+    from robust_e_nerf_amd import jvp
+    g = load_golden("trajectory")
+    ts = t(g["ts"])[4:].clone().requires_grad_()
+    p, R = otraj.linear_trajectory(ts, t(g["tab_ts"]), t(g["tab_pos"]), t(g["tab_quat"]))
+    o, d = otraj.pixel_params_to_ray(t(g["Kinv"]), t(g["px"])[4:], p, R)
+    pos, rot, dpos, drot = jvp.trajectory_jvp(dev(ts.detach()), dev(g["tab_ts"]), dev(g["tab_pos"]), dev(g["tab_quat"]))
+    o2, d2, od, dd = jvp.raygen_jvp(dev(g["Kinv"]), dev(g["px"])[4:].contiguous(), pos, rot, dpos, drot)
+    assert rel_err(o2.cpu(), o) < 1e-5 and rel_err(d2.cpu(), d) < 1e-5
+    for k in range(3):
+        (go,) = torch.autograd.grad(o[:, k].sum(), ts, retain_graph=True)
+        (gd,) = torch.autograd.grad(d[:, k].sum(), ts, retain_graph=True)
+        assert rel_err(od[:, k].cpu(), go) < 1e-4 and rel_err(dd[:, k].cpu(), gd) < 1e-3
+
+
+def test_grad_loss_step_vs_reference_golden(amd, full_table_cache):
+    """Forward-mode d(log I)/dt + reverse pass vs the reference's autograd.gradient(create_graph=True)
+    training_step (l_diff + l_grad).  The golden run has C_p and tau trainable; their values enter here as
+    the (frozen) constants of that step, and the field / background gradients are compared."""
+    ops, engine = amd
+    g = load_golden("training_step_grad")
+    table = full_table_cache(g["table_seed"], g["table_scale"])
+    tr, batch = _trainer_from_golden(engine, g, table)
+    tr.t.w_grad, tr.t.err_grad, tr.t.pw_grad = float(g["w_grad"]), "mape", None
+    batch["u_grad"] = dev(g["u_grad"])
+    jit = t(g["jitters"])
+    loss_d, aux = tr.forward_backward(batch, dev(jit[1]), dev(jit[2]))
+    loss_g, aux_g = tr.grad_loss_forward_backward(batch, dev(jit[0]))
+    loss = float(loss_d) + float(loss_g)
+    assert abs(loss - float(g["loss"])) < 1e-4 * abs(float(g["loss"])), (loss, float(g["loss"]))
+    logged = dict(zip(g["logged_keys"].tolist(), g["logged_vals"].tolist()))
+    assert abs(float(loss_g) / float(g["w_grad"]) - logged["train/log_intensity_grad"]) < 1e-3 * logged["train/log_intensity_grad"]
+    f = tr.r.field
+    for k, v in f.mlp_views(grad=True).items():
+        assert rel_err(v.cpu(), g["g." + k]) < 3e-3, k
+    assert rel_err(tr.small_grad[:1].cpu(), g["g_bkgd_raw"]) < 2e-3
+    idx = t(g["g_table_idx"])
+    assert rel_err(f.g_table.cpu()[idx], g["g_table_val"]) < 3e-3
