@@ -54,7 +54,8 @@ def synthetic_events(B, t_end_ns, seed):
     delta = np.exp(g.uniform(np.log(2e5), np.log(2e7), B)).astype(np.int64)
     pol = g.random(B) < 0.5
     return dict(position=px, start_ts=end - delta, end_ts=end, num_pos=pol.astype(np.int64),
-                num_neg=(~pol).astype(np.int64), u_ts_diff=np.ones(B), u_diff_start=g.uniform(0, 1, B))
+                num_neg=(~pol).astype(np.int64), u_ts_diff=np.ones(B), u_diff_start=g.uniform(0, 1, B),
+                u_grad=g.uniform(0, 1, B))
 
 
 def ball_binary(res, radius, aabb):
@@ -107,6 +108,8 @@ def main():
     ap.add_argument("--events", type=int, default=65536, help="events per step per GPU (2 rays each)")
     ap.add_argument("--samples", type=int, default=128, help="samples per ray (uniform sampler)")
     ap.add_argument("--sampler", default="uniform", choices=["uniform", "occgrid"])
+    ap.add_argument("--loss-grad", type=float, default=0.0,
+                    help="weight of the log-intensity-gradient loss (adds a third render with d/dt; 1e-3 in the real-data configs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
@@ -161,7 +164,7 @@ def main():
     r = engine.Renderer(fld, cfg)
     if args.sampler == "occgrid":
         r.binary.copy_(T(ball_binary(128, 0.42, aabb)).to(dev))
-    tr = engine.Trainer(r, engine.TrainCfg(), Kinv=T(Kinv), tab_ts=T(tab_ts), tab_pos=T(tab_pos), tab_quat=T(tab_quat),
+    tr = engine.Trainer(r, engine.TrainCfg(w_grad=args.loss_grad), Kinv=T(Kinv), tab_ts=T(tab_ts), tab_pos=T(tab_pos), tab_quat=T(tab_quat),
                         p2n_raw=torch.tensor(0.5413), neg_ct=torch.tensor(0.25),
                         tau_raw=torch.tensor(0.0, dtype=torch.float64), tau_max=torch.tensor(1e5),
                         bkgd_raw=torch.tensor([0.5413]), world_size=world, process_group=pg)
@@ -178,6 +181,11 @@ def main():
         j0 = torch.rand(B, device=dev, generator=jgen)
         j1 = torch.rand(B, device=dev, generator=jgen)
         loss, aux = tr.forward_backward(batches[i % n_batches], j0, j1)
+        if args.loss_grad > 0:
+            j2 = torch.rand(B, device=dev, generator=jgen)
+            lg, aux_g = tr.grad_loss_forward_backward(batches[i % n_batches], j2)
+            loss = loss + lg
+            aux = dict(aux, n=aux["n"] + aux_g["n"], rays=aux["rays"] + aux_g["rays"])
         tr.optimizer_step()
         return loss, aux
 
@@ -210,7 +218,7 @@ def main():
         ns = torch.tensor([n_samples], device=dev, dtype=torch.float64)
         dist.all_reduce(ns)
         n_samples = float(ns)
-    rays = 2 * B * args.steps * world
+    rays = (3 if args.loss_grad > 0 else 2) * B * args.steps * world
 
     if rank == 0:
         kern = {k: {"launches": c, "avg_ms": ms / max(c, 1)} for k, (c, ms) in prof.items()}
@@ -226,7 +234,7 @@ def main():
             "loss": float(loss),
             "config": {"workload": "BASELINE configs[1]: synthetic ficus-like event stream, "
                                    f"{B} events/step/GPU = {2 * B} rays x {args.samples} samples, arch ngp, fp32, "
-                                   f"l_diff (2 renders), fwd+bwd+Adam; sampler={args.sampler}",
+                                   f"{'l_diff + l_grad (3 renders)' if args.loss_grad > 0 else 'l_diff (2 renders)'}, fwd+bwd+Adam; sampler={args.sampler}",
                        "events_per_step_per_gpu": B, "rays_per_step_per_gpu": 2 * B, "sampler": args.sampler,
                        "samples_per_ray": args.samples, "parallelism": f"dp{world}"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

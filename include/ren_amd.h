@@ -271,6 +271,12 @@ int ren_hashgrid_bwd_jvp(const ren_grid_desc *grid, float *grad_table, const ren
                          const float *rays_o, const float *rays_d, const float *rays_do, const float *rays_dd,
                          const int32_t *ray_indices, const float *t_starts, const float *t_ends, int64_t n,
                          const float *dfeat, const float *dfeatd, void *stream);
+/* the same through the LDS-binned scatter (workspace as for ren_hashgrid_bwd_binned) */
+int ren_hashgrid_bwd_binned_jvp(const ren_grid_desc *grid, float *grad_table, const ren_scene_desc *scene,
+                                const float *rays_o, const float *rays_d, const float *rays_do,
+                                const float *rays_dd, const int32_t *ray_indices, const float *t_starts,
+                                const float *t_ends, int64_t n, const float *dfeat, const float *dfeatd,
+                                void *workspace, void *stream);
 /* fused MLPs with tangent: rgb, rgbd [n,C]; sigma, sigmad [n]; base_out, base_outd (ceil(n/32)*512 floats) */
 int ren_mlp_fwd_jvp(const float *mlp_params, int32_t radiance_dim, const float *feat, const float *featd,
                     const ren_scene_desc *scene, const float *rays_o, const float *rays_d, const float *rays_dd,

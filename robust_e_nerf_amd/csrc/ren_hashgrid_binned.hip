@@ -47,13 +47,32 @@ struct Workspace {
     float *out_v0, *out_v1;
 };
 
+// optional tangent inputs (log-intensity-gradient loss): update = w * dfeat + wdot * dfeatd
+struct TanSrc {
+    const float *rays_do, *rays_dd, *dfeatd;
+};
+
 __device__ __forceinline__ bool load_sample(const GridDev &g, int lvl, int layout, const float *__restrict__ dfeat,
                                             const float *__restrict__ x_unit, const ren_scene_dev &sc,
                                             const float *__restrict__ rays_o, const float *__restrict__ rays_d,
                                             const int32_t *__restrict__ ray_indices, const float *__restrict__ t_starts,
                                             const float *__restrict__ t_ends, int64_t i, int64_t n, float &d0, float &d1,
-                                            LevelPos &p) {
+                                            LevelPos &p, const TanSrc &tan, float &e0, float &e1, float *wd) {
+    e0 = 0.f; e1 = 0.f; wd[0] = 0.f; wd[1] = 0.f; wd[2] = 0.f;
     if (i >= n) return false;
+    if (tan.dfeatd) {                                               // fragment layout, packed rays only
+        const int64_t b = ((i >> 5) * REN_MAX_LEVELS + lvl) * 64 + (i & 31);
+        d0 = dfeat[b]; d1 = dfeat[b + 32];
+        e0 = tan.dfeatd[b]; e1 = tan.dfeatd[b + 32];
+        if (d0 == 0.f && d1 == 0.f && e0 == 0.f && e1 == 0.f) return false;
+        float x[3], xd[3], u[3], ud[3];
+        sample_pos_jvp(rays_o, rays_d, tan.rays_do, tan.rays_dd, ray_indices, t_starts, t_ends, i, x, xd);
+        contract_jvp(sc, x, xd, u, ud);
+        const float scale = g.scale[lvl];
+        p = level_pos(u[0], u[1], u[2], scale);
+        wd[0] = scale * ud[0]; wd[1] = scale * ud[1]; wd[2] = scale * ud[2];
+        return true;
+    }
     if (layout == 0) {
         const float2 d = reinterpret_cast<const float2 *>(dfeat)[i * g.n_levels + lvl];
         d0 = d.x; d1 = d.y;
@@ -131,7 +150,7 @@ __global__ __launch_bounds__(256) void bin_count_kernel(
     GridDev g, BinTab bt, int layout, const float *__restrict__ dfeat, const float *__restrict__ x_unit,
     ren_scene_dev sc, const float *__restrict__ rays_o, const float *__restrict__ rays_d,
     const int32_t *__restrict__ ray_indices, const float *__restrict__ t_starts,
-    const float *__restrict__ t_ends, int64_t n, uint32_t *__restrict__ counts) {
+    const float *__restrict__ t_ends, int64_t n, uint32_t *__restrict__ counts, TanSrc tan) {
     __shared__ uint32_t hist[MAX_BINS_PER_LEVEL];
     const int lvl = blockIdx.x % g.n_levels;                      // level fastest: spreads the counter atomics
     const int64_t chunk = blockIdx.x / g.n_levels;
@@ -143,8 +162,8 @@ __global__ __launch_bounds__(256) void bin_count_kernel(
 #pragma unroll
     for (int k = 0; k < SCATTER_SAMPLES / 256; ++k) {
         const int64_t i = chunk * SCATTER_SAMPLES + k * 256 + threadIdx.x;
-        float d0, d1; LevelPos p = {};
-        const bool have = load_sample(g, lvl, layout, dfeat, x_unit, sc, rays_o, rays_d, ray_indices, t_starts, t_ends, i, n, d0, d1, p);
+        float d0, d1, e0, e1, wdp[3]; LevelPos p = {};
+        const bool have = load_sample(g, lvl, layout, dfeat, x_unit, sc, rays_o, rays_d, ray_indices, t_starts, t_ends, i, n, d0, d1, p, tan, e0, e1, wdp);
         bool head;
         const bool emit = run_tail(!hashed, have, cell_key(p), lane, head);
 #pragma unroll
@@ -198,7 +217,7 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(
     GridDev g, BinTab bt, int layout, const float *__restrict__ dfeat, const float *__restrict__ x_unit,
     ren_scene_dev sc, const float *__restrict__ rays_o, const float *__restrict__ rays_d,
     const int32_t *__restrict__ ray_indices, const float *__restrict__ t_starts,
-    const float *__restrict__ t_ends, int64_t n, Workspace ws) {
+    const float *__restrict__ t_ends, int64_t n, Workspace ws, TanSrc tan) {
     __shared__ uint32_t hist[MAX_BINS_PER_LEVEL], loc[MAX_BINS_PER_LEVEL + 1];
     __shared__ uint64_t gpos[MAX_BINS_PER_LEVEL];
     __shared__ uint32_t st_key[SC_ENTRIES];
@@ -220,8 +239,8 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(
 #pragma unroll
     for (int k = 0; k < SPT; ++k) {
         const int64_t i = chunk * SCATTER_SAMPLES + k * 256 + tid;
-        float d0 = 0.f, d1 = 0.f; LevelPos p = {};
-        const bool valid = load_sample(g, lvl, layout, dfeat, x_unit, sc, rays_o, rays_d, ray_indices, t_starts, t_ends, i, n, d0, d1, p);
+        float d0 = 0.f, d1 = 0.f, e0, e1, wdp[3]; LevelPos p = {};
+        const bool valid = load_sample(g, lvl, layout, dfeat, x_unit, sc, rays_o, rays_d, ray_indices, t_starts, t_ends, i, n, d0, d1, p, tan, e0, e1, wdp);
         uint32_t idx[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
@@ -230,8 +249,10 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(
             const float wy = (c & 2) ? p.w[1] : 1.f - p.w[1];
             const float wz = (c & 4) ? p.w[2] : 1.f - p.w[2];
             const float w = valid ? wx * wy * wz : 0.f;
-            v0[k][c] = w * d0;
-            v1[k][c] = w * d1;
+            const float bx = (c & 1) ? wdp[0] : -wdp[0], by = (c & 2) ? wdp[1] : -wdp[1], bz = (c & 4) ? wdp[2] : -wdp[2];
+            const float wdc = bx * wy * wz + wx * by * wz + wx * wy * bz;       // d w / dt (0 without tangent)
+            v0[k][c] = w * d0 + wdc * e0;
+            v1[k][c] = w * d1 + wdc * e1;
         }
         bool head;
         have[k] = run_tail(!hashed, valid, cell_key(p), lane, head);
@@ -386,11 +407,11 @@ extern "C" int64_t ren_hashgrid_bwd_binned_workspace_bytes(int64_t n) {
     return (int64_t)make_layout(n).total;
 }
 
-extern "C" int ren_hashgrid_bwd_binned(const ren_grid_desc *grid, float *grad_table, const float *x_unit,
-                                       const ren_scene_desc *scene, const float *rays_o, const float *rays_d,
-                                       const int32_t *ray_indices, const float *t_starts, const float *t_ends,
-                                       int64_t n, int32_t layout, const float *dfeat, void *workspace,
-                                       void *stream) {
+static int binned_impl(const ren_grid_desc *grid, float *grad_table, const float *x_unit,
+                       const ren_scene_desc *scene, const float *rays_o, const float *rays_d,
+                       const int32_t *ray_indices, const float *t_starts, const float *t_ends,
+                       int64_t n, int32_t layout, const float *dfeat, void *workspace,
+                       void *stream, TanSrc tan) {
     GridDev g;
     int rc = make_grid(grid, g);
     if (rc) return rc;
@@ -426,13 +447,32 @@ extern "C" int ren_hashgrid_bwd_binned(const ren_grid_desc *grid, float *grad_ta
     const int64_t chunks = (n + SCATTER_SAMPLES - 1) / SCATTER_SAMPLES;
     dim3 grd((unsigned)(chunks * g.n_levels)), blk(256);
     hipLaunchKernelGGL(bin_count_kernel, grd, blk, 0, st, g, bt, layout, dfeat, x_unit, sc, rays_o, rays_d,
-                       ray_indices, t_starts, t_ends, n, ws.counts);
+                       ray_indices, t_starts, t_ends, n, ws.counts, tan);
     hipLaunchKernelGGL(bin_offsets_kernel, dim3(1), dim3(MAX_BINS), 0, st, nb, ws.counts, ws.cursors, ws.bin_start,
                        ws.parts, ws.n_parts);
     hipLaunchKernelGGL(bin_scatter_kernel, grd, blk, 0, st, g, bt, layout, dfeat, x_unit, sc, rays_o, rays_d,
-                       ray_indices, t_starts, t_ends, n, ws);
+                       ray_indices, t_starts, t_ends, n, ws, tan);
     const size_t acc_lds = 2 * BIN_ENTRIES * sizeof(unsigned long long);
     (void)hipFuncSetAttribute((const void *)bin_accumulate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)acc_lds);
     hipLaunchKernelGGL(bin_accumulate_kernel, dim3((unsigned)L.max_parts), dim3(1024), acc_lds, st, g, bt, ws, grad_table);
     REN_CHECK_LAUNCH();
+}
+
+extern "C" int ren_hashgrid_bwd_binned(const ren_grid_desc *grid, float *grad_table, const float *x_unit,
+                                       const ren_scene_desc *scene, const float *rays_o, const float *rays_d,
+                                       const int32_t *ray_indices, const float *t_starts, const float *t_ends,
+                                       int64_t n, int32_t layout, const float *dfeat, void *workspace,
+                                       void *stream) {
+    return binned_impl(grid, grad_table, x_unit, scene, rays_o, rays_d, ray_indices, t_starts, t_ends, n, layout,
+                       dfeat, workspace, stream, TanSrc{nullptr, nullptr, nullptr});
+}
+
+extern "C" int ren_hashgrid_bwd_binned_jvp(const ren_grid_desc *grid, float *grad_table,
+                                           const ren_scene_desc *scene, const float *rays_o, const float *rays_d,
+                                           const float *rays_do, const float *rays_dd, const int32_t *ray_indices,
+                                           const float *t_starts, const float *t_ends, int64_t n,
+                                           const float *dfeat, const float *dfeatd, void *workspace, void *stream) {
+    if (!rays_do || !rays_dd || !dfeatd) return REN_ERR_BAD_ARG;
+    return binned_impl(grid, grad_table, nullptr, scene, rays_o, rays_d, ray_indices, t_starts, t_ends, n, 1, dfeat,
+                       workspace, stream, TanSrc{rays_do, rays_dd, dfeatd});
 }

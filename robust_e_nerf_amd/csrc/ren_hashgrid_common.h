@@ -39,6 +39,55 @@ __device__ __forceinline__ LevelPos level_pos(float x, float y, float z, float s
     return p;
 }
 
+// contraction with tangent: (x, xd) world -> (u, ud) unit cube   (ngp.py:68-106,230-237)
+__device__ __forceinline__ void contract_jvp(const ren_scene_dev &sc, const float *x, const float *xd, float *u, float *ud) {
+    float y[3], yd[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float ext = sc.hi[k] - sc.lo[k];
+        y[k] = (x[k] - sc.lo[k]) / ext;
+        yd[k] = xd[k] / ext;
+    }
+    if (sc.ct == REN_CT_SPHERE) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { y[k] = y[k] * 2.f - 1.f; yd[k] *= 2.f; }
+        const float m = sqrtf(y[0] * y[0] + y[1] * y[1] + y[2] * y[2]);
+        if (m > 1.f) {
+            const float g = (2.f - 1.f / m) / m;                       // 2/m - 1/m^2
+            const float gp = (-2.f + 2.f / m) / (m * m);               // -2/m^2 + 2/m^3
+            const float md = (y[0] * yd[0] + y[1] * yd[1] + y[2] * yd[2]) / m;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { const float yk = y[k]; y[k] = yk * g; yd[k] = yd[k] * g + yk * gp * md; }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { u[k] = y[k] * 0.25f + 0.5f; ud[k] = yd[k] * 0.25f; }
+    } else if (sc.ct == REN_CT_TANH) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float th = tanhf(y[k] - 0.5f);
+            u[k] = (th + 1.f) * 0.5f;
+            ud[k] = (1.f - th * th) * yd[k] * 0.5f;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { u[k] = y[k]; ud[k] = yd[k]; }
+    }
+}
+
+// sample position and its time derivative: x = o + d tm, xd = od + dd tm (tm fixed)
+__device__ __forceinline__ void sample_pos_jvp(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                               const float *__restrict__ rays_do, const float *__restrict__ rays_dd,
+                                               const int32_t *__restrict__ ri, const float *__restrict__ ts,
+                                               const float *__restrict__ te, int64_t i, float *x, float *xd) {
+    const int64_t ray = ri[i];
+    const float tm = (ts[i] + te[i]) * 0.5f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        x[k] = rays_o[3 * ray + k] + rays_d[3 * ray + k] * tm;
+        xd[k] = rays_do[3 * ray + k] + rays_dd[3 * ray + k] * tm;
+    }
+}
+
 inline int make_grid(const ren_grid_desc *grid, GridDev &g) {
     if (!grid || grid->n_levels < 1 || grid->n_levels > REN_MAX_LEVELS) return REN_ERR_BAD_ARG;
     g.n_levels = grid->n_levels;

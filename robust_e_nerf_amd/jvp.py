@@ -94,9 +94,19 @@ def render_backward(r, ctx, g_colors, g_colords):
                               _ptr(ctx["dd"]), _ptr(ri), _ptr(ts), _ptr(te), n, _ptr(ctx["rgb"]), _ptr(d_rgb),
                               _ptr(d_rgbd), _ptr(d_sig), _ptr(d_sigd), _ptr(scratch), _ptr(dfeat), _ptr(dfeatd),
                               _ptr(f.g_mlp), _ptr(ws), _stream()), "ren_mlp_bwd_jvp")
-    check(lib.ren_hashgrid_bwd_jvp(ctypes.byref(f.grid), _ptr(f.g_table), ctypes.byref(r.scene), _ptr(ctx["o"]),
-                                   _ptr(ctx["d"]), _ptr(ctx["od"]), _ptr(ctx["dd"]), _ptr(ri), _ptr(ts), _ptr(te), n,
-                                   _ptr(dfeat), _ptr(dfeatd), _stream()), "ren_hashgrid_bwd_jvp")
+    if r.cfg.binned_scatter:
+        need = ops.hashgrid_bwd_binned_workspace_bytes(n)
+        if r._bin_ws is None or r._bin_ws.numel() < need:
+            r._bin_ws = None
+            r._bin_ws = torch.empty(need, device=dev, dtype=torch.uint8)
+        check(lib.ren_hashgrid_bwd_binned_jvp(ctypes.byref(f.grid), _ptr(f.g_table), ctypes.byref(r.scene),
+                                              _ptr(ctx["o"]), _ptr(ctx["d"]), _ptr(ctx["od"]), _ptr(ctx["dd"]),
+                                              _ptr(ri), _ptr(ts), _ptr(te), n, _ptr(dfeat), _ptr(dfeatd),
+                                              _ptr(r._bin_ws), _stream()), "ren_hashgrid_bwd_binned_jvp")
+    else:
+        check(lib.ren_hashgrid_bwd_jvp(ctypes.byref(f.grid), _ptr(f.g_table), ctypes.byref(r.scene), _ptr(ctx["o"]),
+                                       _ptr(ctx["d"]), _ptr(ctx["od"]), _ptr(ctx["dd"]), _ptr(ri), _ptr(ts),
+                                       _ptr(te), n, _ptr(dfeat), _ptr(dfeatd), _stream()), "ren_hashgrid_bwd_jvp")
     return ops.column_sum(d_bk) if d_bk is not None else None
 
 
