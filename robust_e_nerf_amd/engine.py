@@ -259,6 +259,8 @@ class TrainCfg:
     err_grad: str = "mape"                       # loss.error_fn.log_intensity_grad
     w_grad: float = 0.0                          # loss.weight.log_intensity_grad (1e-3 in the real-data configs)
     pw_grad: Optional[str] = None                # loss.param_weight.log_intensity_grad
+    train_contrast_threshold: bool = False       # model.contrast_threshold.freeze == false
+    lr_contrast_threshold: float = 0.1           # optimizer.lr.contrast_threshold
 
 
 class Trainer:
@@ -296,6 +298,41 @@ class Trainer:
         self.world_size = world_size
         self.pg = process_group
         self.lr_scale = 1.0
+        # trainable C_p / C_n ratio (softplus-parametrised scalar, its own Adam group with lr 0.1:
+        # robust_e_nerf.py:800-803).  Its loss dependence is through the per-event targets and the 1/C^k
+        # normalisation only, i.e. O(B) elementwise work on already rendered predictions.
+        self.ct = torch.zeros(4, device=dev, dtype=torch.float32)
+        self.ct[0] = p2n_raw.detach().reshape(-1)[0].to(dev, torch.float32)
+        self.ct_grad, self.ct_m, self.ct_v = torch.zeros_like(self.ct), torch.zeros_like(self.ct), torch.zeros_like(self.ct)
+
+    def _refresh_contrast_threshold(self):
+        if self.t.train_contrast_threshold:
+            ratio = float(torch.nn.functional.softplus(self.ct[0]))      # 4-byte host read per step
+            self.c_p = ratio * self.c_n
+            self.mean_c = (self.c_p + self.c_n) / 2
+
+    def _contrast_threshold_grad(self, batch, pred, kind: str, valid=None):
+        """d(loss term)/d(raw ratio) with the rendered prediction held fixed (event_generation_params.py:
+        51-84, loss.py:32-74, robust_e_nerf.py:470-486), by autograd on (B,) device tensors."""
+        t = self.t
+        raw = self.ct[0].detach().clone().requires_grad_()
+        c_p = torch.nn.functional.softplus(raw) * self.c_n
+        mean_c = (c_p + self.c_n) / 2
+        ev = batch["num_pos"] * c_p - batch["num_neg"] * self.c_n
+        start = batch["start_ts"].to(torch.float64) + self.tau
+        rate = ev / (batch["end_ts"] - start)
+        if kind == "diff":
+            ts_diff = (batch["end_ts"] - start) * batch["u_ts_diff"]
+            target, err, w, pwk = (ts_diff * rate).to(torch.float32), t.err_diff, t.w_diff, t.pw_diff
+        else:
+            target, err, w, pwk = rate.to(torch.float32), t.err_grad, t.w_grad, t.pw_grad
+        d = pred.detach() - target
+        e = {"l1": d.abs(), "mse": d * d, "mape": d.abs() / target.abs().clamp(min=2.220446049250313e-16)}[err]
+        if valid is not None:
+            e = e[valid.bool()]
+        pw = {None: 1.0, "mean_contrast_reciprocal": 1 / mean_c, "mean_contrast_reciprocal_sq": 1 / mean_c ** 2}[pwk]
+        (g,) = torch.autograd.grad(w * pw * e.mean(), raw)
+        self.ct_grad[0] += g.to(torch.float32)
 
     # ---- a2-a4: event correction + supervision timestamps (float64 elementwise, negligible) -------
     def _prepare(self, batch):
@@ -313,6 +350,7 @@ class Trainer:
         """Loss + gradients (no optimiser step).  Returns (loss tensor (device scalar), aux)."""
         r, t, f = self.r, self.t, self.r.field
         B = batch["position"].shape[0]
+        self._refresh_contrast_threshold()
         d_start, d_end, target = self._prepare(batch)
         ts_all = torch.cat([d_start, d_end])
         pos, rot = ops.trajectory(ts_all, self.tab_ts, self.tab_pos, self.tab_quat)
@@ -335,6 +373,8 @@ class Trainer:
         loss = loss_sum[0] / loss_sum[1] * scale
         g_s, g_e = ops.event_loss_bwd(i_s, i_e, target, valid, t.err_diff, scale, loss_sum)
         g_colors = torch.cat([g_s, g_e])[:, None].contiguous()
+        if t.train_contrast_threshold:
+            self._contrast_threshold_grad(batch, i_e.log() - i_s.log(), "diff", valid)
         d_bkgd = r.backward(ctx, g_colors)
         if d_bkgd is not None:
             self.small_grad[: f.C] += d_bkgd * torch.sigmoid(self.small[: f.C])     # d softplus
@@ -349,6 +389,7 @@ class Trainer:
         from . import jvp
         r, t, f = self.r, self.t, self.r.field
         B = batch["position"].shape[0]
+        self._refresh_contrast_threshold()
         d_start, d_end, _ = self._prepare(batch)
         ts_g = torch.lerp(d_start, d_end, batch["u_grad"]).contiguous()
         ev_diff = batch["num_pos"] * self.c_p - batch["num_neg"] * self.c_n
@@ -368,6 +409,8 @@ class Trainer:
         scale = pw * t.w_grad
         loss = loss_sum[0] / loss_sum[1] * scale
         g_i, g_id = jvp.grad_loss_bwd(inten, intend, target, valid, t.err_grad, scale, loss_sum)
+        if t.train_contrast_threshold:
+            self._contrast_threshold_grad(batch, intend / inten, "grad", valid)
         d_bkgd = jvp.render_backward(r, ctx, g_i[:, None].contiguous(), g_id[:, None].contiguous())
         if d_bkgd is not None:
             self.small_grad[: f.C] += d_bkgd * torch.sigmoid(self.small[: f.C])
@@ -389,6 +432,13 @@ class Trainer:
                       weight_decay=self.t.weight_decay, step=self.step_count, grad_scale=gs, zero_grad=True)
         ops.adam_step(self.small, self.small_grad, self.sm, self.sv, lr=lr, betas=self.t.betas, eps=self.t.eps,
                       weight_decay=0.0, step=self.step_count, grad_scale=gs, zero_grad=True)
+        if self.t.train_contrast_threshold:
+            if self.world_size > 1:
+                from . import parallel
+                parallel.allreduce_sum_([self.ct_grad], group=self.pg, world_size=self.world_size)
+            ops.adam_step(self.ct, self.ct_grad, self.ct_m, self.ct_v, lr=self.t.lr_contrast_threshold * self.lr_scale,
+                          betas=self.t.betas, eps=self.t.eps, weight_decay=0.0, step=self.step_count, grad_scale=gs,
+                          zero_grad=True)
 
     def update_train_batch_size(self, aux, eff_ray_sample_batch_size: int = 1 << 20) -> int:
         """Dynamic batch size (robust_e_nerf.py:907-950): keep rays x samples per render near the budget.

@@ -633,6 +633,7 @@ def test_grad_loss_step_vs_reference_golden(amd, full_table_cache):
     table = full_table_cache(g["table_seed"], g["table_scale"])
     tr, batch = _trainer_from_golden(engine, g, table)
     tr.t.w_grad, tr.t.err_grad, tr.t.pw_grad = float(g["w_grad"]), "mape", None
+    tr.t.train_contrast_threshold = True
     batch["u_grad"] = dev(g["u_grad"])
     jit = t(g["jitters"])
     loss_d, aux = tr.forward_backward(batch, dev(jit[1]), dev(jit[2]))
@@ -647,3 +648,6 @@ def test_grad_loss_step_vs_reference_golden(amd, full_table_cache):
     assert rel_err(tr.small_grad[:1].cpu(), g["g_bkgd_raw"]) < 2e-3
     idx = t(g["g_table_idx"])
     assert rel_err(f.g_table.cpu()[idx], g["g_table_val"]) < 3e-3
+    assert rel_err(tr.ct_grad[:1].cpu(), g["g_p2n_raw"]) < 1e-3, "d loss / d (C_p/C_n ratio parameter)"
+    tr.optimizer_step()                                     # three Adam groups incl. the lr-0.1 ratio group
+    assert float(tr.ct_grad.abs().max()) == 0.0 and float(tr.ct[0]) != float(g["p2n_raw"].reshape(-1)[0])
