@@ -261,6 +261,8 @@ class TrainCfg:
     pw_grad: Optional[str] = None                # loss.param_weight.log_intensity_grad
     train_contrast_threshold: bool = False       # model.contrast_threshold.freeze == false
     lr_contrast_threshold: float = 0.1           # optimizer.lr.contrast_threshold
+    train_refractory_period: bool = False        # model.refractory_period.freeze == false
+    relative_lr_refractory_period: float = 50.0  # optimizer.relative_lr.refractory_period (x tau_max)
 
 
 class Trainer:
@@ -285,6 +287,12 @@ class Trainer:
         lim = torch.tensor(1e-4, dtype=torch.float64).logit().abs()
         traw = tmax * (traw / tmax).clamp(-lim, lim)                          # :170-185
         self.tau = float(tmax * torch.sigmoid(traw / tmax))                   # modules.py:58-74 (float64)
+        # trainable refractory period: a float64 scalar (event_generation_params.py:162-164) kept on the
+        # host side of the step -- its gradient is assembled from per-ray forward-mode tangents dI/dt.
+        self.tau_raw = traw.clone().requires_grad_(False)
+        self.tau_max = tmax.to(torch.float64)
+        self.tau_grad = torch.zeros((), dtype=torch.float64)
+        self._tau_opt = None
         # small-parameter block: [bkgd_raw (C) | pad] with its own Adam state (group "others", lr default)
         self.small = torch.zeros(4, device=dev, dtype=torch.float32)
         self.small[: renderer.field.C] = bkgd_raw.to(dev, torch.float32).reshape(-1)
@@ -305,6 +313,30 @@ class Trainer:
         self.ct[0] = p2n_raw.detach().reshape(-1)[0].to(dev, torch.float32)
         self.ct_grad, self.ct_m, self.ct_v = torch.zeros_like(self.ct), torch.zeros_like(self.ct), torch.zeros_like(self.ct)
 
+    def _tau_chain(self, batch, which):
+        """d(supervision timestamp)/d(tau) per event, float64, for which in {"start", "end", "grad"}
+        (robust_e_nerf.py:319-357 differentiated w.r.t. the refractory period).  Every timestamp depends
+        on tau through its own event only, so the gradient of the sum w.r.t. a per-event copy of tau is the
+        per-event derivative."""
+        end = batch["end_ts"].to(torch.float64)
+        tau_v = torch.full_like(end, self.tau).requires_grad_()
+        start = batch["start_ts"].to(torch.float64) + tau_v
+        ts_diff = (end - start) * batch["u_ts_diff"]
+        d_start = torch.lerp(start, torch.max(end - ts_diff, start), batch["u_diff_start"])
+        d_end = torch.min(d_start + ts_diff, end)
+        out = {"start": d_start, "end": d_end}
+        if which == "grad":
+            out["grad"] = torch.lerp(d_start, d_end, batch["u_grad"])
+        (gv,) = torch.autograd.grad(out[which].sum(), tau_v)
+        return gv
+
+    def _refresh_tau(self):
+        if self.t.train_refractory_period:
+            lim = torch.tensor(1e-4, dtype=torch.float64).logit().abs()
+            with torch.no_grad():                                         # clamp_refractory_period (:170-185)
+                self.tau_raw.copy_(self.tau_max * (self.tau_raw / self.tau_max).clamp(-lim, lim))
+            self.tau = float(self.tau_max * torch.sigmoid(self.tau_raw / self.tau_max))
+
     def _refresh_contrast_threshold(self):
         if self.t.train_contrast_threshold:
             ratio = float(torch.nn.functional.softplus(self.ct[0]))      # 4-byte host read per step
@@ -312,14 +344,17 @@ class Trainer:
             self.mean_c = (self.c_p + self.c_n) / 2
 
     def _contrast_threshold_grad(self, batch, pred, kind: str, valid=None):
-        """d(loss term)/d(raw ratio) with the rendered prediction held fixed (event_generation_params.py:
-        51-84, loss.py:32-74, robust_e_nerf.py:470-486), by autograd on (B,) device tensors."""
+        """d(loss term)/d(raw ratio) and the DIRECT d(loss term)/d(tau) (through the event rate target),
+        with the rendered prediction held fixed (event_generation_params.py:51-84,196-203, loss.py:32-74,
+        robust_e_nerf.py:470-486), by autograd on (B,) device tensors."""
         t = self.t
+        dev = pred.device
         raw = self.ct[0].detach().clone().requires_grad_()
+        tau = torch.tensor(self.tau, dtype=torch.float64, device=dev, requires_grad=True)
         c_p = torch.nn.functional.softplus(raw) * self.c_n
         mean_c = (c_p + self.c_n) / 2
         ev = batch["num_pos"] * c_p - batch["num_neg"] * self.c_n
-        start = batch["start_ts"].to(torch.float64) + self.tau
+        start = batch["start_ts"].to(torch.float64) + tau
         rate = ev / (batch["end_ts"] - start)
         if kind == "diff":
             ts_diff = (batch["end_ts"] - start) * batch["u_ts_diff"]
@@ -331,8 +366,11 @@ class Trainer:
         if valid is not None:
             e = e[valid.bool()]
         pw = {None: 1.0, "mean_contrast_reciprocal": 1 / mean_c, "mean_contrast_reciprocal_sq": 1 / mean_c ** 2}[pwk]
-        (g,) = torch.autograd.grad(w * pw * e.mean(), raw)
-        self.ct_grad[0] += g.to(torch.float32)
+        g_raw, g_tau = torch.autograd.grad(w * pw * e.mean(), [raw, tau], allow_unused=True)
+        if t.train_contrast_threshold and g_raw is not None:
+            self.ct_grad[0] += g_raw.to(torch.float32)
+        if t.train_refractory_period and g_tau is not None:
+            self.tau_grad = self.tau_grad + g_tau.detach().cpu()
 
     # ---- a2-a4: event correction + supervision timestamps (float64 elementwise, negligible) -------
     def _prepare(self, batch):
@@ -351,16 +389,25 @@ class Trainer:
         r, t, f = self.r, self.t, self.r.field
         B = batch["position"].shape[0]
         self._refresh_contrast_threshold()
+        self._refresh_tau()
         d_start, d_end, target = self._prepare(batch)
         ts_all = torch.cat([d_start, d_end])
-        pos, rot = ops.trajectory(ts_all, self.tab_ts, self.tab_pos, self.tab_quat)
         px = torch.cat([batch["position"], batch["position"]]).contiguous()
-        o, d = ops.raygen(self.Kinv, px, pos, rot)
         jitter = None
         if jitter_start is not None:
             jitter = torch.cat([jitter_start, jitter_end]).to(torch.float32).contiguous()
         bkgd = torch.nn.functional.softplus(self.small[: f.C]) if t.bkgd_is_param else None   # nerf.py:81-88
-        colors, opac, depth, ctx = r.forward(o, d, jitter, bkgd, training=True, save=True)
+        colords = None
+        if t.train_refractory_period:
+            # d loss/d tau needs dI/dt of both renders: carry the tangent forward (value path unchanged)
+            from . import jvp
+            pos, rot, dpos, drot = jvp.trajectory_jvp(ts_all, self.tab_ts, self.tab_pos, self.tab_quat)
+            o, d, od, dd = jvp.raygen_jvp(self.Kinv, px, pos, rot, dpos, drot)
+            colors, colords, opac, ctx = jvp.render_forward(r, o, d, od, dd, jitter, bkgd, training=True)
+        else:
+            pos, rot = ops.trajectory(ts_all, self.tab_ts, self.tab_pos, self.tab_quat)
+            o, d = ops.raygen(self.Kinv, px, pos, rot)
+            colors, opac, depth, ctx = r.forward(o, d, jitter, bkgd, training=True, save=True)
         inten = colors[:, 0] + r.cfg.min_modeled_intensity               # robust_e_nerf.py:867 (monochrome)
         i_s, i_e = inten[:B].contiguous(), inten[B:].contiguous()
         valid = None
@@ -373,8 +420,14 @@ class Trainer:
         loss = loss_sum[0] / loss_sum[1] * scale
         g_s, g_e = ops.event_loss_bwd(i_s, i_e, target, valid, t.err_diff, scale, loss_sum)
         g_colors = torch.cat([g_s, g_e])[:, None].contiguous()
-        if t.train_contrast_threshold:
+        if t.train_contrast_threshold or t.train_refractory_period:
             self._contrast_threshold_grad(batch, i_e.log() - i_s.log(), "diff", valid)
+        if t.train_refractory_period:
+            # through the poses: sum_i dL/dI_i * dI_i/dt_i * dt_i/dtau  (start and end renders)
+            idot = colords[:, 0].double()
+            g_tau = (g_s.double() * idot[:B] * self._tau_chain(batch, "start")).sum() \
+                + (g_e.double() * idot[B:] * self._tau_chain(batch, "end")).sum()
+            self.tau_grad = self.tau_grad + g_tau.detach().cpu()
         d_bkgd = r.backward(ctx, g_colors)
         if d_bkgd is not None:
             self.small_grad[: f.C] += d_bkgd * torch.sigmoid(self.small[: f.C])     # d softplus
@@ -388,6 +441,8 @@ class Trainer:
         with the event rate C/dt.  Accumulates gradients; returns (weighted loss term, aux)."""
         from . import jvp
         r, t, f = self.r, self.t, self.r.field
+        if t.train_refractory_period:
+            raise NotImplementedError("d(l_grad)/d(tau) through the pose needs a second-order tangent (next round)")
         B = batch["position"].shape[0]
         self._refresh_contrast_threshold()
         d_start, d_end, _ = self._prepare(batch)
@@ -432,6 +487,24 @@ class Trainer:
                       weight_decay=self.t.weight_decay, step=self.step_count, grad_scale=gs, zero_grad=True)
         ops.adam_step(self.small, self.small_grad, self.sm, self.sv, lr=lr, betas=self.t.betas, eps=self.t.eps,
                       weight_decay=0.0, step=self.step_count, grad_scale=gs, zero_grad=True)
+        if self.t.train_refractory_period:
+            # float64 scalar, Adam group with lr = tau_max * relative lr (robust_e_nerf.py:804-807);
+            # tau = tau_max sigmoid(raw / tau_max)  =>  d tau / d raw = sigmoid'(raw / tau_max)
+            if self._tau_opt is None:
+                self.tau_raw.requires_grad_(True)
+                self._tau_opt = torch.optim.Adam([self.tau_raw], lr=float(self.tau_max) * self.t.relative_lr_refractory_period)
+            g = self.tau_grad
+            if self.world_size > 1:
+                import torch.distributed as dist
+                gd = g.to(f.flat.device)
+                dist.all_reduce(gd, group=self.pg)
+                g = gd.cpu()
+            sg = torch.sigmoid(self.tau_raw.detach() / self.tau_max)
+            self.tau_raw.grad = (g * gs * sg * (1 - sg)).to(torch.float64).reshape(self.tau_raw.shape)
+            for grp in self._tau_opt.param_groups:
+                grp["lr"] = float(self.tau_max) * self.t.relative_lr_refractory_period * self.lr_scale
+            self._tau_opt.step()
+            self.tau_grad = torch.zeros((), dtype=torch.float64)
         if self.t.train_contrast_threshold:
             if self.world_size > 1:
                 from . import parallel

@@ -651,3 +651,34 @@ def test_grad_loss_step_vs_reference_golden(amd, full_table_cache):
     assert rel_err(tr.ct_grad[:1].cpu(), g["g_p2n_raw"]) < 1e-3, "d loss / d (C_p/C_n ratio parameter)"
     tr.optimizer_step()                                     # three Adam groups incl. the lr-0.1 ratio group
     assert float(tr.ct_grad.abs().max()) == 0.0 and float(tr.ct[0]) != float(g["p2n_raw"].reshape(-1)[0])
+
+
+def test_refractory_period_gradient_vs_oracle(amd, spec, full_table_cache):
+    """d(l_diff)/d(tau): assembled from forward-mode dI/dt of the start / end renders (no reverse pass
+    through the poses) vs the oracle's autograd through LinearTrajectory and the whole render."""
+    from oracle import step as ostep
+    ops, engine = amd
+    g = load_golden("training_step_grad")                 # tau != 0, u_ts_diff < 1 in this fixture
+    table = full_table_cache(g["table_seed"], g["table_scale"])
+    tr, batch = _trainer_from_golden(engine, g, table)
+    tr.t.train_refractory_period = True
+    jit = t(g["jitters"])
+    loss, aux = tr.forward_backward(batch, dev(jit[1]), dev(jit[2]))
+    # oracle: l_diff only, tau trainable
+    occ_res = int(g["occ_res"])
+    binary = t(np.unpackbits(g["binary"])[: occ_res ** 3].astype(bool)).view(occ_res, occ_res, occ_res)
+    cfg = ostep.SceneCfg(occ_res=(occ_res,) * 3, render_step_size=float(g["render_step_size"]))
+    ob = ostep.EventBatch(t(g["position"]), t(g["start_ts"]), t(g["end_ts"]), t(g["num_pos"]), t(g["num_neg"]),
+                          t(g["u_ts_diff"]), t(g["u_diff_start"]), t(g["u_grad"]))
+    tau_raw = t(g["tau_raw"]).clone().requires_grad_()
+    loss_o, _ = ostep.training_forward(
+        ob, field_params_from(g, table), spec, cfg, Kinv=t(g["Kinv"]), tab_ts=t(g["tab_ts"]), tab_pos=t(g["tab_pos"]),
+        tab_quat=t(g["tab_quat"]), p2n_raw=t(g["p2n_raw"]), neg_ct=t(g["neg_ct"]), tau_raw=tau_raw,
+        tau_max=t(g["tau_max"]), bkgd_raw=t(g["bkgd_raw"]), binary=binary, jitter_start=jit[1], jitter_end=jit[2])
+    loss_o.backward()
+    assert rel_err(loss.cpu(), loss_o) < 1e-4
+    sg = torch.sigmoid(tr.tau_raw.detach() / tr.tau_max)
+    got = tr.tau_grad * sg * (1 - sg)                       # d tau / d raw
+    assert rel_err(got, tau_raw.grad) < 5e-3, (float(got), float(tau_raw.grad))
+    tr.optimizer_step()
+    assert float(tr.tau_grad) == 0.0
