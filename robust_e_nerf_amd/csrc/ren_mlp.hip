@@ -67,15 +67,15 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(FwdArgs a) {
             h[0][g] = lds[L_B1 + rowc(g) + 4 * hi];
             h[1][g] = lds[L_B1 + 32 + rowc(g) + 4 * hi];
         }
+        // tile-major: tile 1's MFMAs cover tile 0's activation on the VALU, and the next layer's
+        // k-steps over tile 0 cover tile 1's (a 32x32x2 f32 MFMA leaves 60 issue cycles free)
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            h[0] = MFMA(W1[sl * 33 + 2 * s + hi], x[s], h[0]);
-            h[1] = MFMA(W1[(32 + sl) * 33 + 2 * s + hi], x[s], h[1]);
-        }
+        for (int r = 0; r < 2; ++r) {
 #pragma unroll
-        for (int r = 0; r < 2; ++r)
+            for (int s = 0; s < 16; ++s) h[r] = MFMA(W1[(32 * r + sl) * 33 + 2 * s + hi], x[s], h[r]);
 #pragma unroll
             for (int g = 0; g < 16; ++g) h[r][g] = softplus100(h[r][g]);
+        }
         // ---- base output: 64 -> 16 (rows 16..31 of the tile are zero padding)
         f32x16 o;
 #pragma unroll
@@ -106,16 +106,16 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(FwdArgs a) {
             p[1][g] = lds[L_BH1 + 32 + rowc(g) + 4 * hi];
         }
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const int col = s < 8 ? rowc(s) + 4 * hi : 16 + 2 * (s - 8) + hi;
-            const float bv = s < 8 ? o[s] : shs[s < 8 ? 0 : s - 8];
-            p[0] = MFMA(WH1[sl * 33 + col], bv, p[0]);
-            p[1] = MFMA(WH1[(32 + sl) * 33 + col], bv, p[1]);
-        }
+        for (int r = 0; r < 2; ++r) {
 #pragma unroll
-        for (int r = 0; r < 2; ++r)
+            for (int s = 0; s < 16; ++s) {
+                const int col = s < 8 ? rowc(s) + 4 * hi : 16 + 2 * (s - 8) + hi;
+                const float bv = s < 8 ? o[s] : shs[s < 8 ? 0 : s - 8];
+                p[r] = MFMA(WH1[(32 * r + sl) * 33 + col], bv, p[r]);
+            }
 #pragma unroll
             for (int g = 0; g < 16; ++g) p[r][g] = softplus100(p[r][g]);
+        }
         // ---- head layer 1: 64 -> 64
         f32x16 q[2];
 #pragma unroll
@@ -124,13 +124,12 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(FwdArgs a) {
             q[1][g] = lds[L_BH2 + 32 + rowc(g) + 4 * hi];
         }
 #pragma unroll
-        for (int r = 0; r < 2; ++r)
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const int col = 32 * r + rowc(g) + 4 * hi;
-                q[0] = MFMA(WH2[sl * 65 + col], p[r][g], q[0]);
-                q[1] = MFMA(WH2[(32 + sl) * 65 + col], p[r][g], q[1]);
-            }
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int g = 0; g < 16; ++g)
+                    q[t] = MFMA(WH2[(32 * t + sl) * 65 + 32 * r + rowc(g) + 4 * hi], p[r][g], q[t]);
         // ---- head output: 64 -> C on the VALU (each lane holds 32 of its sample's 64 neurons)
         float acc[C];
 #pragma unroll
@@ -152,7 +151,12 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(FwdArgs a) {
 }
 
 // ============================================================================ backward, head
-constexpr int GRID_H = 256, GRID_B = 512;          // persistent workgroups (4 waves each)
+// f32 MFMA and VALU share one issue pipe on gfx950 (tools/mfma_valu_bench.hip: their times add, also
+// across two waves of one SIMD), so a second wave per SIMD buys nothing here and would need spills.
+#ifndef REN_HEAD_OCC
+#define REN_HEAD_OCC 1
+#endif
+constexpr int GRID_H = 256 * REN_HEAD_OCC, GRID_B = 512;   // persistent workgroups (4 waves each)
 
 struct BwdHArgs {
     const float *params, *base_out;
@@ -164,13 +168,13 @@ struct BwdHArgs {
 };
 
 template <int C>
-__global__ __launch_bounds__(256, 1) void mlp_bwd_head_kernel(BwdHArgs a) {
+__global__ __launch_bounds__(256, REN_HEAD_OCC) void mlp_bwd_head_kernel(BwdHArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds_base[];
     fill_head(lds_base, a.params, C, LH_WH1, LH_WH2, LH_WH3, LH_BH1, LH_BH2, LH_BH3);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int hi = lane >> 5, sl = lane & 31;
-    float *T_dz = lds_base + LH_END + wave * (2 * 64 * 33);      // [64][33]
-    float *T_act = T_dz + 64 * 33;                                 // [64][33]
+    float *T_dz = lds_base + LH_END + wave * (96 * 33);          // [64][33]
+    float *T_act = T_dz + 64 * 33;                                 // [32][33]
     __syncthreads();
     const int64_t n_blk = (a.n + 31) >> 5;
 
@@ -258,24 +262,24 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_head_kernel(BwdHArgs a) {
                 for (int c = 0; c < C; ++c) dq += dz3[c] * lds[LH_WH3 + c * 64 + 32 * r + rowc(g) + 4 * hi];
                 q[r][g] = dq * dsoftplus_from_out(q[r][g], 100.f);
             }
-        // ---- dW(head.w1) += dZ2 . P^T  (stage both as [neuron][sample])
+        // ---- dW(head.w1) += dZ2 . P^T  (stage both as [neuron][sample]; P in two 32-row halves so
+        //      the per-wave staging area stays at 96 rows and two workgroups fit one CU)
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const int row = 32 * r + rowc(g) + 4 * hi;
-                T_dz[row * 33 + sl] = q[r][g];
-                T_act[row * 33 + sl] = p[r][g];
-            }
+            for (int g = 0; g < 16; ++g) T_dz[(32 * r + rowc(g) + 4 * hi) * 33 + sl] = q[r][g];
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const float az0 = T_dz[sl * 33 + 2 * s + hi], az1 = T_dz[(32 + sl) * 33 + 2 * s + hi];
-            const float bp0 = T_act[sl * 33 + 2 * s + hi], bp1 = T_act[(32 + sl) * 33 + 2 * s + hi];
-            acc_bh2[0] += az0; acc_bh2[1] += az1;
-            acc_wh2[0][0] = MFMA(az0, bp0, acc_wh2[0][0]);
-            acc_wh2[0][1] = MFMA(az0, bp1, acc_wh2[0][1]);
-            acc_wh2[1][0] = MFMA(az1, bp0, acc_wh2[1][0]);
-            acc_wh2[1][1] = MFMA(az1, bp1, acc_wh2[1][1]);
+        for (int r = 0; r < 2; ++r) {
+#pragma unroll
+            for (int g = 0; g < 16; ++g) T_act[(rowc(g) + 4 * hi) * 33 + sl] = p[r][g];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const float az0 = T_dz[sl * 33 + 2 * s + hi], az1 = T_dz[(32 + sl) * 33 + 2 * s + hi];
+                const float bp = T_act[sl * 33 + 2 * s + hi];
+                if (r == 0) { acc_bh2[0] += az0; acc_bh2[1] += az1; }
+                acc_wh2[0][r] = MFMA(az0, bp, acc_wh2[0][r]);
+                acc_wh2[1][r] = MFMA(az1, bp, acc_wh2[1][r]);
+            }
         }
         // ---- d p = W2^T dZ2 ; dZ1 = d p * softplus'(p)
         f32x16 dp[2];
@@ -500,7 +504,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_base_kernel(BwdBArgs a) {
 }
 
 constexpr size_t FWD_LDS = (size_t)L_WEIGHTS_END * 4;
-constexpr size_t BWD_H_LDS = (size_t)(LH_END + 4 * 2 * 64 * 33) * 4;      //  93 968 B -> 1 WG/CU
+constexpr size_t BWD_H_LDS = (size_t)(LH_END + 4 * 96 * 33) * 4;          //  77 072 B -> 2 WG/CU
 constexpr size_t BWD_B_LDS = (size_t)(LB_END + 4 * 96 * 33) * 4;          //  67 840 B -> 2 WG/CU
 
 }  // namespace

@@ -39,14 +39,37 @@ __device__ __forceinline__ constexpr int rowc(int g) { return (g & 3) + 8 * (g >
 __device__ __forceinline__ float log1p_fast(float e) {       // e >= 0
     return e < 1e-3f ? e * (1.f - e * (0.5f - e * 0.33333333f)) : __logf(1.f + e);
 }
-// torch softplus(beta, threshold=20): x if beta*x > 20 else log1p(exp(beta*x))/beta
+// torch softplus(beta=100, threshold=20) = max(x,0) + log1p(exp(-100|x|))/100 up to 2e-11 (the
+// threshold branch drops exactly that term).  One v_exp_f32 + one v_log_f32, no branches; the
+// absolute error of log2(1+t) near t -> 0 (6e-8 * ln2/100 = 4e-10) is far below the fp32 noise of
+// the layer sums it feeds.  REN_ACT_VARIANT 0 keeps the branchy log1p form for A/B timing.
+#ifndef REN_ACT_VARIANT
+#define REN_ACT_VARIANT 1
+#endif
 __device__ __forceinline__ float softplus100(float x) {
+#if REN_ACT_VARIANT == 0
     const float z = 100.f * x;
     return z > 20.f ? x : log1p_fast(__expf(z)) * 0.01f;
+#elif REN_ACT_VARIANT == 2
+    return x;                                                  // timing experiment only
+#else
+    const float t = __builtin_amdgcn_exp2f(fabsf(x) * -144.26950408889634f);
+    // fmed3 instead of fmaxf: no IEEE canonicalisation (an extra v_max per value) of the MFMA output
+    return fmaf(__builtin_amdgcn_logf(1.f + t), 0.006931471805599453f, __builtin_amdgcn_fmed3f(x, 0.f, 3.0e38f));
+#endif
 }
+// output activation (beta = 1): small outputs matter relatively (log intensity), keep log1p exact
 __device__ __forceinline__ float softplus1(float x) { return x > 20.f ? x : log1p_fast(__expf(x)); }
 // derivative of softplus(beta) expressed through its OUTPUT y: sigmoid(beta x) = 1 - exp(-beta y)
 __device__ __forceinline__ float dsoftplus_from_out(float y, float beta) {
+#if REN_ACT_VARIANT != 0
+    if (beta == 100.f) {
+#if REN_ACT_VARIANT == 2
+        return 1.f;
+#endif
+        return 1.f - __builtin_amdgcn_exp2f(y * -144.26950408889634f);
+    }
+#endif
     const float t = beta * y;
     return t < 1e-3f ? t * (1.f - t * (0.5f - t * 0.16666667f)) : 1.f - __expf(-t);
 }
