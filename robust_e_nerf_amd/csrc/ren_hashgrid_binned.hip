@@ -27,8 +27,21 @@ constexpr int BIN_SHIFT = 13;
 constexpr int BIN_ENTRIES = 1 << BIN_SHIFT;          // 8 192 table entries (x2 features x int64 = 128 KiB LDS)
 constexpr int MAX_BINS_PER_LEVEL = 64;
 constexpr int MAX_BINS = REN_MAX_LEVELS * MAX_BINS_PER_LEVEL;
-constexpr int SCATTER_SAMPLES = 256;                 // samples per scatter workgroup (1 per thread)
+#ifndef REN_SC_THREADS
+#define REN_SC_THREADS 512
+#endif
+#ifndef REN_LEVEL_GROUPS
+#define REN_LEVEL_GROUPS 1
+#endif
+constexpr int SC_THREADS = REN_SC_THREADS;           // scatter workgroup: one sample per thread
+constexpr int SC_ENTRIES = SC_THREADS * 8;           // staged updates per level pass = 48 KiB
+constexpr int LEVEL_GROUPS = REN_LEVEL_GROUPS;      // a scatter workgroup walks lvl = group, group + LEVEL_GROUPS, ...
+constexpr int CNT_THREADS = 256, CNT_SAMPLES = 1024; // count workgroup: 4 samples per thread, all levels
 constexpr int64_t PART_ENTRIES = 1 << 21;            // updates per accumulate workgroup
+// max |update| per level is published with atomicMax: spread over LMAX_SLOTS cache lines per level and
+// only raised when the value actually grows, so the workgroups do not queue on one memory channel.
+constexpr int LMAX_SLOTS = 8, LMAX_STRIDE = 32;      // u32 words between slots (128 B)
+constexpr int LMAX_WORDS = REN_MAX_LEVELS * LMAX_SLOTS * LMAX_STRIDE;
 
 struct BinTab {
     int bin_base[REN_MAX_LEVELS + 1];                // first global bin of each level
@@ -40,11 +53,11 @@ struct Part {
 };
 
 struct Workspace {
-    uint32_t *counts, *level_max, *cursors, *n_parts;     // level_max: float bits of max |update| per level
+    uint32_t *counts, *level_max, *cursors, *n_parts;     // level_max: float bits of max |update|, [level][slot] one line each
     uint64_t *bin_start;
     Part *parts;
     uint16_t *out_idx;
-    float *out_v0, *out_v1;
+    float2 *out_v;
 };
 
 // optional tangent inputs (log-intensity-gradient loss): update = w * dfeat + wdot * dfeatd
@@ -52,46 +65,53 @@ struct TanSrc {
     const float *rays_do, *rays_dd, *dfeatd;
 };
 
-__device__ __forceinline__ bool load_sample(const GridDev &g, int lvl, int layout, const float *__restrict__ dfeat,
-                                            const float *__restrict__ x_unit, const ren_scene_dev &sc,
-                                            const float *__restrict__ rays_o, const float *__restrict__ rays_d,
-                                            const int32_t *__restrict__ ray_indices, const float *__restrict__ t_starts,
-                                            const float *__restrict__ t_ends, int64_t i, int64_t n, float &d0, float &d1,
-                                            LevelPos &p, const TanSrc &tan, float &e0, float &e1, float *wd) {
-    e0 = 0.f; e1 = 0.f; wd[0] = 0.f; wd[1] = 0.f; wd[2] = 0.f;
-    if (i >= n) return false;
-    if (tan.dfeatd) {                                               // fragment layout, packed rays only
-        const int64_t b = ((i >> 5) * REN_MAX_LEVELS + lvl) * 64 + (i & 31);
-        d0 = dfeat[b]; d1 = dfeat[b + 32];
-        e0 = tan.dfeatd[b]; e1 = tan.dfeatd[b + 32];
-        if (d0 == 0.f && d1 == 0.f && e0 == 0.f && e1 == 0.f) return false;
-        float x[3], xd[3], u[3], ud[3];
-        sample_pos_jvp(rays_o, rays_d, tan.rays_do, tan.rays_dd, ray_indices, t_starts, t_ends, i, x, xd);
-        contract_jvp(sc, x, xd, u, ud);
-        const float scale = g.scale[lvl];
-        p = level_pos(u[0], u[1], u[2], scale);
-        wd[0] = scale * ud[0]; wd[1] = scale * ud[1]; wd[2] = scale * ud[2];
-        return true;
-    }
-    if (layout == 0) {
-        const float2 d = reinterpret_cast<const float2 *>(dfeat)[i * g.n_levels + lvl];
-        d0 = d.x; d1 = d.y;
-    } else {
-        const int64_t b = ((i >> 5) * REN_MAX_LEVELS + lvl) * 64 + (i & 31);
-        d0 = dfeat[b];
-        d1 = dfeat[b + 32];
-    }
-    if (d0 == 0.f && d1 == 0.f) return false;
-    float ux, uy, uz;
-    if (x_unit) {
-        ux = x_unit[3 * i]; uy = x_unit[3 * i + 1]; uz = x_unit[3 * i + 2];
+// workgroup barrier that orders LDS traffic only: global loads/stores/atomics stay in flight across it
+// (__syncthreads() also drains vmcnt, which would put every HBM round trip on the per-level critical path)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+struct SampleArgs {
+    int layout;                                      // 0: dfeat[i][level][2], 1: MFMA fragment order
+    const float *dfeat, *x_unit;
+    ren_scene_dev sc;
+    const float *rays_o, *rays_d;
+    const int32_t *ray_indices;
+    const float *t_starts, *t_ends;
+    int64_t n;
+    TanSrc tan;
+};
+
+// unit-cube position (and its time derivative) of sample i: computed ONCE per thread, every level of
+// the thread's level walk reuses it (the per-level recomputation was most of the old scatter's time)
+template <bool TAN>
+__device__ __forceinline__ void unit_pos(const SampleArgs &a, int64_t i, float *u, float *ud) {
+    ud[0] = 0.f; ud[1] = 0.f; ud[2] = 0.f;
+    if (TAN) {
+        float x[3], xd[3];
+        sample_pos_jvp(a.rays_o, a.rays_d, a.tan.rays_do, a.tan.rays_dd, a.ray_indices, a.t_starts, a.t_ends, i, x, xd);
+        contract_jvp(a.sc, x, xd, u, ud);
+    } else if (a.x_unit) {
+        u[0] = a.x_unit[3 * i]; u[1] = a.x_unit[3 * i + 1]; u[2] = a.x_unit[3 * i + 2];
     } else {
         float x, y, z; int ray;
-        ren_sample_pos(rays_o, rays_d, ray_indices, t_starts, t_ends, i, x, y, z, ray);
-        ren_contract(sc, x, y, z, ux, uy, uz);
+        ren_sample_pos(a.rays_o, a.rays_d, a.ray_indices, a.t_starts, a.t_ends, i, x, y, z, ray);
+        ren_contract(a.sc, x, y, z, u[0], u[1], u[2]);
     }
-    p = level_pos(ux, uy, uz, g.scale[lvl]);
-    return true;
+}
+
+// feature gradients of (sample i, level): false when there is nothing to scatter
+template <bool TAN>
+__device__ __forceinline__ bool load_dfeat(const SampleArgs &a, int n_levels, int lvl, int64_t i, float &d0, float &d1,
+                                           float &e0, float &e1) {
+    e0 = 0.f; e1 = 0.f;
+    if (TAN || a.layout == 1) {
+        const int64_t b = ((i >> 5) * REN_MAX_LEVELS + lvl) * 64 + (i & 31);
+        d0 = a.dfeat[b]; d1 = a.dfeat[b + 32];
+        if (TAN) { e0 = a.tan.dfeatd[b]; e1 = a.tan.dfeatd[b + 32]; }
+    } else {
+        const float2 d = reinterpret_cast<const float2 *>(a.dfeat)[i * n_levels + lvl];
+        d0 = d.x; d1 = d.y;
+    }
+    return d0 != 0.f || d1 != 0.f || e0 != 0.f || e1 != 0.f;
 }
 
 // ---- dense (non-hashed) levels: consecutive samples of a ray sit in the same cell, so all 8 corner
@@ -102,28 +122,43 @@ __device__ __forceinline__ uint64_t cell_key(const LevelPos &p) {
     return ((uint64_t)p.c[2] << 42) ^ ((uint64_t)p.c[1] << 21) ^ (uint64_t)p.c[0];
 }
 
+// Runs are confined to aligned groups of RUN_LANES = 8 lanes so the merge is three DPP row shifts (no LDS).
 // emit = this lane is the LAST lane of a run of valid lanes with equal cell (always true for hashed levels)
+constexpr int RUN_LANES = 8;
+
+template <int OFF>
+__device__ __forceinline__ float dpp_shr(float v) {               // value of lane - OFF in the 16-lane row, else 0
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x110 | OFF, 0xf, 0xf, true));
+}
+template <int OFF>
+__device__ __forceinline__ int dpp_shr_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x110 | OFF, 0xf, 0xf, true); }
+
 __device__ __forceinline__ bool run_tail(bool dense, bool have, uint64_t key, int lane, bool &head) {
     if (!dense) { head = true; return have; }
     const uint64_t kp = __shfl_up(key, 1, 64), kn = __shfl_down(key, 1, 64);
     const int hp = __shfl_up((int)have, 1, 64), hn = __shfl_down((int)have, 1, 64);
-    head = !(lane > 0 && hp && have && kp == key);
-    return have && (lane == 63 || !(hn && kn == key));
+    const int sub = lane & (RUN_LANES - 1);
+    head = !(sub > 0 && hp && have && kp == key);
+    return have && (sub == RUN_LANES - 1 || !(hn && kn == key));
+}
+
+// segmented inclusive scan: after it the tail lane of every run holds the run's sums
+template <int OFF>
+__device__ __forceinline__ void run_merge_step(int &f, float (&v0)[8], float (&v1)[8]) {
+    const float take = f ? 0.f : 1.f;                             // heads (and lanes already joined to one) keep their value
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        v0[c] = fmaf(dpp_shr<OFF>(v0[c]), take, v0[c]);
+        v1[c] = fmaf(dpp_shr<OFF>(v1[c]), take, v1[c]);
+    }
+    f |= dpp_shr_i<OFF>(f);
 }
 
 __device__ __forceinline__ void run_merge(bool head, int lane, float (&v0)[8], float (&v1)[8]) {
     int f = head ? 1 : 0;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int pf = __shfl_up(f, off, 64);
-        const bool take = lane >= off && !f;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const float a = __shfl_up(v0[c], off, 64), b = __shfl_up(v1[c], off, 64);
-            if (take) { v0[c] += a; v1[c] += b; }
-        }
-        if (lane >= off) f |= pf;
-    }
+    run_merge_step<1>(f, v0, v1);
+    run_merge_step<2>(f, v0, v1);
+    run_merge_step<4>(f, v0, v1);
 }
 
 // LDS counter bump with one atomic per distinct bin in the wave (dense levels: the lanes of a wave
@@ -146,35 +181,42 @@ __device__ __forceinline__ uint32_t bin_rank(bool dense, bool emit, uint32_t bin
 }
 
 // ---- 1. count ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bin_count_kernel(
-    GridDev g, BinTab bt, int layout, const float *__restrict__ dfeat, const float *__restrict__ x_unit,
-    ren_scene_dev sc, const float *__restrict__ rays_o, const float *__restrict__ rays_d,
-    const int32_t *__restrict__ ray_indices, const float *__restrict__ t_starts,
-    const float *__restrict__ t_ends, int64_t n, uint32_t *__restrict__ counts, TanSrc tan) {
-    __shared__ uint32_t hist[MAX_BINS_PER_LEVEL];
-    const int lvl = blockIdx.x % g.n_levels;                      // level fastest: spreads the counter atomics
-    const int64_t chunk = blockIdx.x / g.n_levels;
-    if (threadIdx.x < MAX_BINS_PER_LEVEL) hist[threadIdx.x] = 0;
+// One thread walks all levels of its 4 samples; the per-(level, bin) histogram lives in LDS and reaches
+// the global counters once per workgroup (the counters are memory-side atomics, ~18 G/s chip-wide).
+template <bool TAN>
+__global__ __launch_bounds__(CNT_THREADS) void bin_count_kernel(GridDev g, BinTab bt, SampleArgs a,
+                                                                uint32_t *__restrict__ counts) {
+    __shared__ uint32_t hist[MAX_BINS];
+    for (int t = threadIdx.x; t < MAX_BINS; t += CNT_THREADS) hist[t] = 0;
     __syncthreads();
-    const uint32_t res = g.res[lvl], size = g.size[lvl];
-    const bool hashed = g.hashed[lvl] != 0;
     const int lane = threadIdx.x & 63;
+#pragma unroll 1
+    for (int k = 0; k < CNT_SAMPLES / CNT_THREADS; ++k) {
+        const int64_t i = (int64_t)blockIdx.x * CNT_SAMPLES + k * CNT_THREADS + threadIdx.x;
+        const bool inb = i < a.n;
+        float u[3] = {0.f, 0.f, 0.f}, ud[3];
+        if (inb) unit_pos<TAN>(a, i, u, ud);
+#pragma unroll 1
+        for (int lvl = 0; lvl < g.n_levels; ++lvl) {
+            float d0, d1, e0, e1;
+            const bool have = inb && load_dfeat<TAN>(a, g.n_levels, lvl, i, d0, d1, e0, e1);
+            const LevelPos p = level_pos(u[0], u[1], u[2], g.scale[lvl]);
+            const uint32_t res = g.res[lvl], size = g.size[lvl];
+            const bool hashed = g.hashed[lvl] != 0;
+            bool head;
+            const bool emit = run_tail(!hashed, have, cell_key(p), lane, head);
+            uint32_t idx[8];
+            corner_indices8(p.c[0], p.c[1], p.c[2], res, size, hashed, idx);
 #pragma unroll
-    for (int k = 0; k < SCATTER_SAMPLES / 256; ++k) {
-        const int64_t i = chunk * SCATTER_SAMPLES + k * 256 + threadIdx.x;
-        float d0, d1, e0, e1, wdp[3]; LevelPos p = {};
-        const bool have = load_sample(g, lvl, layout, dfeat, x_unit, sc, rays_o, rays_d, ray_indices, t_starts, t_ends, i, n, d0, d1, p, tan, e0, e1, wdp);
-        bool head;
-        const bool emit = run_tail(!hashed, have, cell_key(p), lane, head);
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const uint32_t idx = corner_index(p.c[0] + (c & 1), p.c[1] + ((c >> 1) & 1), p.c[2] + (c >> 2), res, size, hashed);
-            (void)bin_rank(!hashed, emit, idx >> BIN_SHIFT, lane, hist);
+            for (int c = 0; c < 8; ++c) (void)bin_rank(!hashed, emit, idx[c] >> BIN_SHIFT, lane, hist + lvl * MAX_BINS_PER_LEVEL);
         }
     }
     __syncthreads();
-    const int nb = bt.bin_base[lvl + 1] - bt.bin_base[lvl];
-    if ((int)threadIdx.x < nb && hist[threadIdx.x]) atomicAdd(&counts[bt.bin_base[lvl] + threadIdx.x], hist[threadIdx.x]);
+    for (int t = threadIdx.x; t < MAX_BINS; t += CNT_THREADS) {
+        const int lvl = t / MAX_BINS_PER_LEVEL, bin = t % MAX_BINS_PER_LEVEL;
+        if (lvl < g.n_levels && bin < bt.bin_base[lvl + 1] - bt.bin_base[lvl] && hist[t])
+            atomicAdd(&counts[bt.bin_base[lvl] + bin], hist[t]);
+    }
 }
 
 // ---- 2. offsets + work partition -----------------------------------------------------------------------
@@ -211,113 +253,115 @@ __global__ __launch_bounds__(MAX_BINS) void bin_offsets_kernel(int n_bins, const
 }
 
 // ---- 3. scatter (counting sort by bin inside the workgroup, coalesced append) ----------------------------
-constexpr int SC_ENTRIES = SCATTER_SAMPLES * 8;      // 4096 staged updates = 48 KiB
-
-__global__ __launch_bounds__(256) void bin_scatter_kernel(
-    GridDev g, BinTab bt, int layout, const float *__restrict__ dfeat, const float *__restrict__ x_unit,
-    ren_scene_dev sc, const float *__restrict__ rays_o, const float *__restrict__ rays_d,
-    const int32_t *__restrict__ ray_indices, const float *__restrict__ t_starts,
-    const float *__restrict__ t_ends, int64_t n, Workspace ws, TanSrc tan) {
+// One sample per thread; the workgroup walks the levels {group, group + 4, ...} and runs one
+// rank -> offsets -> LDS placement -> coalesced append pass per level over the same staging area.
+template <bool TAN>
+__global__ __launch_bounds__(SC_THREADS) void bin_scatter_kernel(GridDev g, BinTab bt, SampleArgs a, Workspace ws) {
     __shared__ uint32_t hist[MAX_BINS_PER_LEVEL], loc[MAX_BINS_PER_LEVEL + 1];
-    __shared__ uint64_t gpos[MAX_BINS_PER_LEVEL];
+    __shared__ uint64_t gdelta[MAX_BINS_PER_LEVEL];               // global position - staging position, per bin
     __shared__ uint32_t st_key[SC_ENTRIES];
-    __shared__ float st_v0[SC_ENTRIES], st_v1[SC_ENTRIES];
-    __shared__ float wave_max[4];
-    const int lvl = blockIdx.x % g.n_levels;
-    const int64_t chunk = blockIdx.x / g.n_levels;
-    const int tid = threadIdx.x;
-    if (tid < MAX_BINS_PER_LEVEL) hist[tid] = 0;
-    __syncthreads();
-    const uint32_t res = g.res[lvl], size = g.size[lvl];
-    const bool hashed = g.hashed[lvl] != 0;
-    constexpr int SPT = SCATTER_SAMPLES / 256;
-    const int lane = tid & 63;
-    uint32_t key[SPT][8];                                          // rank << 19 | table index in level
-    float v0[SPT][8], v1[SPT][8];
-    bool have[SPT];
-    float vmax = 0.f;
-#pragma unroll
-    for (int k = 0; k < SPT; ++k) {
-        const int64_t i = chunk * SCATTER_SAMPLES + k * 256 + tid;
-        float d0 = 0.f, d1 = 0.f, e0, e1, wdp[3]; LevelPos p = {};
-        const bool valid = load_sample(g, lvl, layout, dfeat, x_unit, sc, rays_o, rays_d, ray_indices, t_starts, t_ends, i, n, d0, d1, p, tan, e0, e1, wdp);
-        uint32_t idx[8];
+    __shared__ float2 st_v[SC_ENTRIES];
+    __shared__ float wave_max[SC_THREADS / 64];
+    const int group = blockIdx.x % LEVEL_GROUPS;
+    const int64_t chunk = blockIdx.x / LEVEL_GROUPS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int64_t i = chunk * SC_THREADS + tid;
+    const bool inb = i < a.n;
+    float u[3] = {0.f, 0.f, 0.f}, ud[3] = {0.f, 0.f, 0.f};
+    if (inb) unit_pos<TAN>(a, i, u, ud);
+#pragma unroll 1
+    for (int lvl = group; lvl < g.n_levels; lvl += LEVEL_GROUPS) {
+        if (tid < MAX_BINS_PER_LEVEL) hist[tid] = 0;
+        lds_barrier();                                           // also: previous level's append is done
+        const uint32_t res = g.res[lvl], size = g.size[lvl];
+        const bool hashed = g.hashed[lvl] != 0;
+        const float scale = g.scale[lvl];
+        float d0 = 0.f, d1 = 0.f, e0 = 0.f, e1 = 0.f;
+        const bool valid = inb && load_dfeat<TAN>(a, g.n_levels, lvl, i, d0, d1, e0, e1);
+        const LevelPos p = level_pos(u[0], u[1], u[2], scale);
+        const float wx1 = p.w[0], wy1 = p.w[1], wz1 = p.w[2], wx0 = 1.f - wx1, wy0 = 1.f - wy1, wz0 = 1.f - wz1;
+        if (!valid) { d0 = 0.f; d1 = 0.f; e0 = 0.f; e1 = 0.f; }
+        const float wxy[4] = {wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};
+        uint32_t key[8];                                           // rank << 19 | table index in level
+        float v0[8], v1[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-            idx[c] = corner_index(p.c[0] + (c & 1), p.c[1] + ((c >> 1) & 1), p.c[2] + (c >> 2), res, size, hashed);
-            const float wx = (c & 1) ? p.w[0] : 1.f - p.w[0];
-            const float wy = (c & 2) ? p.w[1] : 1.f - p.w[1];
-            const float wz = (c & 4) ? p.w[2] : 1.f - p.w[2];
-            const float w = valid ? wx * wy * wz : 0.f;
-            const float bx = (c & 1) ? wdp[0] : -wdp[0], by = (c & 2) ? wdp[1] : -wdp[1], bz = (c & 4) ? wdp[2] : -wdp[2];
-            const float wdc = bx * wy * wz + wx * by * wz + wx * wy * bz;       // d w / dt (0 without tangent)
-            v0[k][c] = w * d0 + wdc * e0;
-            v1[k][c] = w * d1 + wdc * e1;
+            const float wz = (c & 4) ? wz1 : wz0;
+            const float w = wxy[c & 3] * wz;
+            v0[c] = w * d0; v1[c] = w * d1;
+            if (TAN) {                                             // + d w / dt * d(feature tangent)
+                const float wx = (c & 1) ? wx1 : wx0, wy = (c & 2) ? wy1 : wy0;
+                const float bx = (c & 1) ? ud[0] : -ud[0], by = (c & 2) ? ud[1] : -ud[1], bz = (c & 4) ? ud[2] : -ud[2];
+                const float wdc = scale * (bx * wy * wz + wx * by * wz + wxy[c & 3] * bz);
+                v0[c] += wdc * e0; v1[c] += wdc * e1;
+            }
         }
         bool head;
-        have[k] = run_tail(!hashed, valid, cell_key(p), lane, head);
-        if (!hashed) run_merge(head, lane, v0[k], v1[k]);
-        if (have[k]) {
+        const bool have = run_tail(!hashed, valid, cell_key(p), lane, head);
+        if (!hashed) run_merge(head, lane, v0, v1);
+        float vmax = 0.f;
+        if (have) {
 #pragma unroll
-            for (int c = 0; c < 8; ++c) vmax = fmaxf(vmax, fmaxf(fabsf(v0[k][c]), fabsf(v1[k][c])));
+            for (int c = 0; c < 8; ++c) vmax = fmaxf(vmax, fmaxf(fabsf(v0[c]), fabsf(v1[c])));
         }
+        {
+            uint32_t idx[8];
+            corner_indices8(p.c[0], p.c[1], p.c[2], res, size, hashed, idx);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const uint32_t rank = bin_rank(!hashed, have[k], idx[c] >> BIN_SHIFT, lane, hist);
-            key[k][c] = (rank << 19) | idx[c];                     // idx < 2^19: bin = idx >> 14, local = idx & 16383
+            for (int c = 0; c < 8; ++c) {
+                const uint32_t rank = bin_rank(!hashed, have, idx[c] >> BIN_SHIFT, lane, hist);
+                key[c] = (rank << 19) | idx[c];                    // idx < 2^19, rank < 4096
+            }
         }
-    }
-    // max |update| of the level: scales the 64-bit fixed-point accumulation of the next kernel
+        // max |update| of the level: scales the 64-bit fixed-point accumulation of the next kernel
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
-    if (lane == 0) wave_max[tid >> 6] = vmax;
-    __syncthreads();
-    if (tid == 0) {
-        const float m = fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]));
-        if (m > 0.f) atomicMax(&ws.level_max[lvl], __float_as_uint(m));      // non-negative floats order like uints
-    }
-    const int nb = bt.bin_base[lvl + 1] - bt.bin_base[lvl];
-    if (tid < MAX_BINS_PER_LEVEL) {
-        const uint32_t cnt = hist[tid];
-        // inclusive wave scan over the 64 bins -> local offsets
-        uint32_t inc = cnt;
+        for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
+        if (lane == 0) wave_max[tid >> 6] = vmax;
+        lds_barrier();
+        if (tid == SC_THREADS - 1) {
+            float m = 0.f;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t t = __shfl_up(inc, off, 64);
-            if (tid >= off) inc += t;
+            for (int w = 0; w < SC_THREADS / 64; ++w) m = fmaxf(m, wave_max[w]);
+            uint32_t *slot = ws.level_max + (lvl * LMAX_SLOTS + (int)(chunk % LMAX_SLOTS)) * LMAX_STRIDE;
+            // non-negative floats order like uints; the plain read may be stale (that only costs an atomic)
+            if (__float_as_uint(m) > __builtin_nontemporal_load(slot)) atomicMax(slot, __float_as_uint(m));
         }
-        loc[tid] = inc - cnt;
-        if (tid == MAX_BINS_PER_LEVEL - 1) loc[MAX_BINS_PER_LEVEL] = inc;
-        uint64_t base = 0;
-        if (tid < nb && cnt) {
-            const int gb = bt.bin_base[lvl] + tid;
-            base = ws.bin_start[gb] + atomicAdd(&ws.cursors[gb], cnt);   // reserve the run in the bin's region
-        }
-        gpos[tid] = base;
-    }
-    __syncthreads();
+        if (tid < MAX_BINS_PER_LEVEL) {
+            const int nb = bt.bin_base[lvl + 1] - bt.bin_base[lvl];
+            const uint32_t cnt = hist[tid];
+            uint32_t inc = cnt;                                    // inclusive wave scan over the 64 bins -> local offsets
 #pragma unroll
-    for (int k = 0; k < SPT; ++k) {
-        if (!have[k]) continue;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const uint32_t kk = key[k][c];
-            const uint32_t idx = kk & 0x7FFFFu;
-            const uint32_t pos = loc[idx >> BIN_SHIFT] + (kk >> 19);
-            st_key[pos] = idx;
-            st_v0[pos] = v0[k][c];
-            st_v1[pos] = v1[k][c];
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t t = __shfl_up(inc, off, 64);
+                if (tid >= off) inc += t;
+            }
+            loc[tid] = inc - cnt;
+            if (tid == MAX_BINS_PER_LEVEL - 1) loc[MAX_BINS_PER_LEVEL] = inc;
+            uint64_t base = 0;
+            if (tid < nb && cnt) {
+                const int gb = bt.bin_base[lvl] + tid;
+                base = ws.bin_start[gb] + atomicAdd(&ws.cursors[gb], cnt);   // reserve the run in the bin's region
+            }
+            gdelta[tid] = base - (inc - cnt);
         }
-    }
-    __syncthreads();
-    const uint32_t total = loc[MAX_BINS_PER_LEVEL];
-    for (uint32_t p = tid; p < total; p += 256) {
-        const uint32_t idx = st_key[p];
-        const uint32_t b = idx >> BIN_SHIFT;
-        const uint64_t gp = gpos[b] + (p - loc[b]);
-        ws.out_idx[gp] = (uint16_t)(idx & (BIN_ENTRIES - 1));
-        ws.out_v0[gp] = st_v0[p];
-        ws.out_v1[gp] = st_v1[p];
+        lds_barrier();
+        if (have) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const uint32_t idx = key[c] & 0x7FFFFu;
+                const uint32_t pos = loc[idx >> BIN_SHIFT] + (key[c] >> 19);
+                st_key[pos] = idx;
+                st_v[pos] = make_float2(v0[c], v1[c]);
+            }
+        }
+        lds_barrier();
+        const uint32_t total = loc[MAX_BINS_PER_LEVEL];
+        for (uint32_t q = tid; q < total; q += SC_THREADS) {
+            const uint32_t idx = st_key[q];
+            const uint64_t gp = gdelta[idx >> BIN_SHIFT] + q;
+            ws.out_idx[gp] = (uint16_t)(idx & (BIN_ENTRIES - 1));
+            ws.out_v[gp] = st_v[q];
+        }
     }
 }
 
@@ -340,24 +384,27 @@ __global__ __launch_bounds__(1024) void bin_accumulate_kernel(GridDev g, BinTab 
     int lvl = 0;
     while (lvl + 1 < g.n_levels && (int)part.gbin >= bt.bin_base[lvl + 1]) ++lvl;
     int ex;
-    (void)frexpf(__uint_as_float(ws.level_max[lvl]), &ex);         // level_max < 2^ex
+    uint32_t lmax = 0;
+    for (int k = 0; k < LMAX_SLOTS; ++k) lmax = max(lmax, ws.level_max[(lvl * LMAX_SLOTS + k) * LMAX_STRIDE]);
+    (void)frexpf(__uint_as_float(lmax), &ex);                     // level max < 2^ex
     const double scale = ldexp(1.0, 38 - ex), inv_scale = ldexp(1.0, ex - 38);
     __syncthreads();
     uint64_t e = part.begin + threadIdx.x;
     for (; e + 3 * 1024 < part.end; e += 4 * 1024) {               // 4 independent loads in flight per lane
-        uint32_t ix[4]; float a[4], b[4];
+        uint32_t ix[4]; float2 v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { ix[u] = ws.out_idx[e + u * 1024]; a[u] = ws.out_v0[e + u * 1024]; b[u] = ws.out_v1[e + u * 1024]; }
+        for (int u = 0; u < 4; ++u) { ix[u] = ws.out_idx[e + u * 1024]; v[u] = ws.out_v[e + u * 1024]; }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            atomicAdd(&acc0[ix[u]], (unsigned long long)to_fixed(a[u], scale));    // ds_add_u64
-            atomicAdd(&acc1[ix[u]], (unsigned long long)to_fixed(b[u], scale));
+            atomicAdd(&acc0[ix[u]], (unsigned long long)to_fixed(v[u].x, scale));    // ds_add_u64
+            atomicAdd(&acc1[ix[u]], (unsigned long long)to_fixed(v[u].y, scale));
         }
     }
     for (; e < part.end; e += 1024) {
         const uint32_t idx = ws.out_idx[e];
-        atomicAdd(&acc0[idx], (unsigned long long)to_fixed(ws.out_v0[e], scale));
-        atomicAdd(&acc1[idx], (unsigned long long)to_fixed(ws.out_v1[e], scale));
+        const float2 v = ws.out_v[e];
+        atomicAdd(&acc0[idx], (unsigned long long)to_fixed(v.x, scale));
+        atomicAdd(&acc1[idx], (unsigned long long)to_fixed(v.y, scale));
     }
     __syncthreads();
     const uint32_t first = ((uint32_t)part.gbin - bt.bin_base[lvl]) << BIN_SHIFT;   // first entry of the bin in its level
@@ -380,7 +427,7 @@ __global__ __launch_bounds__(1024) void bin_accumulate_kernel(GridDev g, BinTab 
 
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-struct Layout { size_t counts, level_max, cursors, n_parts, bin_start, parts, out_idx, out_v0, out_v1, total; int64_t max_parts; };
+struct Layout { size_t counts, level_max, cursors, n_parts, bin_start, parts, out_idx, out_v, total; int64_t max_parts; };
 
 Layout make_layout(int64_t n) {
     Layout L;
@@ -388,14 +435,13 @@ Layout make_layout(int64_t n) {
     L.max_parts = (int64_t)(E / PART_ENTRIES) + MAX_BINS + 1;
     size_t o = 0;
     L.counts = o; o += MAX_BINS * 4;                       // counts | level_max are cleared by one memset
-    L.level_max = o; o = align256(o + REN_MAX_LEVELS * 4);
+    L.level_max = o; o = align256(o + LMAX_WORDS * 4);
     L.cursors = o; o = align256(o + MAX_BINS * 4);
     L.n_parts = o; o = align256(o + 4);
     L.bin_start = o; o = align256(o + (MAX_BINS + 1) * 8);
     L.parts = o; o = align256(o + (size_t)L.max_parts * sizeof(Part));
     L.out_idx = o; o = align256(o + E * 2);
-    L.out_v0 = o; o = align256(o + E * 4);
-    L.out_v1 = o; o = align256(o + E * 4);
+    L.out_v = o; o = align256(o + E * 8);
     L.total = o;
     return L;
 }
@@ -441,17 +487,20 @@ static int binned_impl(const ren_grid_desc *grid, float *grad_table, const float
     ws.cursors = (uint32_t *)(w + L.cursors);
     ws.n_parts = (uint32_t *)(w + L.n_parts); ws.bin_start = (uint64_t *)(w + L.bin_start);
     ws.parts = (Part *)(w + L.parts); ws.out_idx = (uint16_t *)(w + L.out_idx);
-    ws.out_v0 = (float *)(w + L.out_v0); ws.out_v1 = (float *)(w + L.out_v1);
+    ws.out_v = (float2 *)(w + L.out_v);
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(ws.counts, 0, (MAX_BINS + REN_MAX_LEVELS) * 4, st) != hipSuccess) return REN_ERR_LAUNCH;
-    const int64_t chunks = (n + SCATTER_SAMPLES - 1) / SCATTER_SAMPLES;
-    dim3 grd((unsigned)(chunks * g.n_levels)), blk(256);
-    hipLaunchKernelGGL(bin_count_kernel, grd, blk, 0, st, g, bt, layout, dfeat, x_unit, sc, rays_o, rays_d,
-                       ray_indices, t_starts, t_ends, n, ws.counts, tan);
+    if (hipMemsetAsync(ws.counts, 0, (MAX_BINS + LMAX_WORDS) * 4, st) != hipSuccess) return REN_ERR_LAUNCH;
+    SampleArgs a;
+    a.layout = layout; a.dfeat = dfeat; a.x_unit = x_unit; a.sc = sc; a.rays_o = rays_o; a.rays_d = rays_d;
+    a.ray_indices = ray_indices; a.t_starts = t_starts; a.t_ends = t_ends; a.n = n; a.tan = tan;
+    const dim3 cgrd((unsigned)((n + CNT_SAMPLES - 1) / CNT_SAMPLES)), cblk(CNT_THREADS);
+    const dim3 sgrd((unsigned)((n + SC_THREADS - 1) / SC_THREADS * LEVEL_GROUPS)), sblk(SC_THREADS);
+    if (tan.dfeatd) hipLaunchKernelGGL(bin_count_kernel<true>, cgrd, cblk, 0, st, g, bt, a, ws.counts);
+    else            hipLaunchKernelGGL(bin_count_kernel<false>, cgrd, cblk, 0, st, g, bt, a, ws.counts);
     hipLaunchKernelGGL(bin_offsets_kernel, dim3(1), dim3(MAX_BINS), 0, st, nb, ws.counts, ws.cursors, ws.bin_start,
                        ws.parts, ws.n_parts);
-    hipLaunchKernelGGL(bin_scatter_kernel, grd, blk, 0, st, g, bt, layout, dfeat, x_unit, sc, rays_o, rays_d,
-                       ray_indices, t_starts, t_ends, n, ws, tan);
+    if (tan.dfeatd) hipLaunchKernelGGL(bin_scatter_kernel<true>, sgrd, sblk, 0, st, g, bt, a, ws);
+    else            hipLaunchKernelGGL(bin_scatter_kernel<false>, sgrd, sblk, 0, st, g, bt, a, ws);
     const size_t acc_lds = 2 * BIN_ENTRIES * sizeof(unsigned long long);
     (void)hipFuncSetAttribute((const void *)bin_accumulate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)acc_lds);
     hipLaunchKernelGGL(bin_accumulate_kernel, dim3((unsigned)L.max_parts), dim3(1024), acc_lds, st, g, bt, ws, grad_table);

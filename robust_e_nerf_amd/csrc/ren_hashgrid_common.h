@@ -21,6 +21,31 @@ __device__ __forceinline__ uint32_t corner_index(uint32_t cx, uint32_t cy, uint3
     return idx;
 }
 
+// all 8 corner indices of a cell, corner c = (c&1, (c>>1)&1, c>>2).  Same values as corner_index();
+// the hash products / dense strides are formed once instead of per corner.
+__device__ __forceinline__ void corner_indices8(uint32_t cx, uint32_t cy, uint32_t cz, uint32_t res, uint32_t size,
+                                                bool hashed, uint32_t *idx) {
+    if (hashed) {
+        const uint32_t hy0 = cy * 2654435761u, hy1 = hy0 + 2654435761u;
+        const uint32_t hz0 = cz * 805459861u, hz1 = hz0 + 805459861u;
+        const uint32_t m = size - 1u, x1 = cx + 1u;
+        idx[0] = (cx ^ hy0 ^ hz0) & m; idx[1] = (x1 ^ hy0 ^ hz0) & m;
+        idx[2] = (cx ^ hy1 ^ hz0) & m; idx[3] = (x1 ^ hy1 ^ hz0) & m;
+        idx[4] = (cx ^ hy0 ^ hz1) & m; idx[5] = (x1 ^ hy0 ^ hz1) & m;
+        idx[6] = (cx ^ hy1 ^ hz1) & m; idx[7] = (x1 ^ hy1 ^ hz1) & m;
+    } else {
+        const uint32_t sy = res, sz = res * res;
+        const uint32_t b = cx + cy * sy + cz * sz;
+        idx[0] = b; idx[1] = b + 1u; idx[2] = b + sy; idx[3] = b + sy + 1u;
+        idx[4] = b + sz; idx[5] = b + sz + 1u; idx[6] = b + sz + sy; idx[7] = b + sz + sy + 1u;
+        // idx[] ascends unless it wraps 2^32 (negative cell), and then idx[0] is huge: two tests cover all 8
+        if (idx[0] >= size || idx[7] >= size) {      // only positions outside the unit cube get here
+#pragma unroll
+            for (int c = 0; c < 8; ++c) idx[c] %= size;
+        }
+    }
+}
+
 struct LevelPos {
     uint32_t c[3];
     float w[3];
