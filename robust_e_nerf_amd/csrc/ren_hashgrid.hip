@@ -56,12 +56,9 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(
         const bool hashed = g.hashed[lvl] != 0;
         const float2 *tab = table + g.offset[lvl];
         float2 v[8];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const uint32_t idx = corner_index(p.c[0] + (c & 1), p.c[1] + ((c >> 1) & 1), p.c[2] + (c >> 2),
-                                              res, size, hashed);
-            v[c] = tab[idx];
-        }
+        uint32_t idx[8];
+        corner_indices8(p.c[0], p.c[1], p.c[2], res, size, hashed, idx);
+        gather_corners8(tab, idx, v);
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const float wx = (c & 1) ? p.w[0] : 1.f - p.w[0];

@@ -46,6 +46,34 @@ __device__ __forceinline__ void corner_indices8(uint32_t cx, uint32_t cy, uint32
     }
 }
 
+// Gather the 8 corner entries of a cell.  The texture addresser handles divergent lanes at about one
+// lane per clock whatever the access size, and it is the unit that bounds the encoder (TA_BUSY 84 %), so
+// corners (x, y, z) and (x+1, y, z) are fetched with ONE 16-byte load whenever their entries are
+// neighbours in the table: always on dense levels, and on hashed levels whenever x is even (x+1 then
+// only flips bit 0 of the hash).  Lanes without that luck issue the two 8-byte loads.
+__device__ __forceinline__ void gather_corners8(const float2 *__restrict__ tab, const uint32_t *idx, float2 *v) {
+    const bool up = idx[1] == idx[0] + 1u, down = idx[0] == idx[1] + 1u;   // same relation for all 4 x-pairs
+    const bool pair = (up || down) && idx[3] - idx[2] == idx[1] - idx[0] && idx[5] - idx[4] == idx[1] - idx[0] &&
+                      idx[7] - idx[6] == idx[1] - idx[0];
+    if (pair) {
+        float4 q[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t lo = up ? idx[2 * j] : idx[2 * j + 1];
+            q[j] = *reinterpret_cast<const float4 *>(tab + lo);             // 8-byte aligned 16-byte load
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float2 a = make_float2(q[j].x, q[j].y), b = make_float2(q[j].z, q[j].w);
+            v[2 * j] = up ? a : b;
+            v[2 * j + 1] = up ? b : a;
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = tab[idx[c]];
+    }
+}
+
 struct LevelPos {
     uint32_t c[3];
     float w[3];
