@@ -25,8 +25,28 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak (= f32 vector peak)
 # algorithmic bytes per differentiable sample (DESIGN.md "Roofline"):
 BYTES = {"hashgrid_fwd": 1024 + 12, "hashgrid_bwd": 2048 + 12, "hashgrid_bwd_binned": 2048 + 12}
+# algorithmic flops per sample of the fused MLPs, C = 1 (DESIGN.md "Roofline"): 2 x MACs of
+# base 32-64-16 + head 31-64-64-1 forward; backward = data + weight gradients = 2 x forward (no recompute counted)
+MLP_MACS = 32 * 64 + 64 * 16 + 31 * 64 + 64 * 64 + 64
+FLOPS = {"mlp_fwd": 2 * MLP_MACS, "mlp_bwd": 4 * MLP_MACS}
+PMC_TRAFFIC = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
+
+
+def pmc_traffic(call, args):
+    """HBM bytes per launch of `call` from the committed rocprofv3 PMC passes (tools/pmc_traffic.py), or None
+    when they were taken on a different workload."""
+    try:
+        t = json.load(open(PMC_TRAFFIC))
+    except OSError:
+        return None
+    w = t.get("workload", {})
+    same = (w.get("events") == args.events and w.get("samples") == args.samples and
+            w.get("sampler") == args.sampler and float(w.get("loss_grad", 0.0)) == float(args.loss_grad))
+    c = t.get("calls", {}).get(call)
+    return c["hbm_bytes_per_launch"] if (same and c) else None
 
 
 def synthetic_scene(n_poses=2001, seed=0):
@@ -222,10 +242,19 @@ def main():
 
     if rank == 0:
         kern = {k: {"launches": c, "avg_ms": ms / max(c, 1)} for k, (c, ms) in prof.items()}
-        dom = max(BYTES, key=lambda k: prof.get(k, (0, 0.0))[1])
+        dom = max(list(BYTES) + list(FLOPS), key=lambda k: prof.get(k, (0, 0.0))[1])
         c, ms = prof[dom]
         samples_per_launch = n_samples / world / args.steps
-        achieved = BYTES[dom] * samples_per_launch / (ms / c * 1e-3) / 1e9
+        if dom in BYTES:
+            achieved = BYTES[dom] * samples_per_launch / (ms / c * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, args),
+                    "algorithmic_bytes_per_sample": BYTES[dom], "avg_launch_ms": ms / c}
+        else:
+            achieved = FLOPS[dom] * samples_per_launch / (ms / c * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": pmc_traffic(dom, args),
+                    "algorithmic_flops_per_sample": FLOPS[dom], "avg_launch_ms": ms / c}
         out = {
             "metric": "train_rays_per_sec", "value": rays / dt, "unit": "rays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -237,9 +266,7 @@ def main():
                                    f"{'l_diff + l_grad (3 renders)' if args.loss_grad > 0 else 'l_diff (2 renders)'}, fwd+bwd+Adam; sampler={args.sampler}",
                        "events_per_step_per_gpu": B, "rays_per_step_per_gpu": 2 * B, "sampler": args.sampler,
                        "samples_per_ray": args.samples, "parallelism": f"dp{world}"},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_sample": BYTES[dom], "avg_launch_ms": ms / c},
+            "roofline": roof,
             "kernels": kern,
         }
         if world == 1 and not args.no_cpu_baseline:

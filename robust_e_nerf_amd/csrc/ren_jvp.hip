@@ -132,9 +132,9 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_jvp_kernel(
         const bool hashed = g.hashed[lvl] != 0;
         const float2 *tab = table + g.offset[lvl];
         float2 v[8];
-#pragma unroll
-        for (int c = 0; c < 8; ++c)
-            v[c] = tab[corner_index(p.c[0] + (c & 1), p.c[1] + ((c >> 1) & 1), p.c[2] + (c >> 2), res, size, hashed)];
+        uint32_t idx[8];
+        corner_indices8(p.c[0], p.c[1], p.c[2], res, size, hashed, idx);
+        gather_corners8(tab, idx, v);
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const float ax = (c & 1) ? p.w[0] : 1.f - p.w[0], bx = (c & 1) ? wd[0] : -wd[0];
