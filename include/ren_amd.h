@@ -313,6 +313,32 @@ int ren_grad_loss_bwd(const float *intensity, const float *intensity_dot, const 
                       const uint8_t *valid, int64_t B, int32_t err_fn, float scale, const float *loss_sum,
                       float *g_intensity, float *g_intensity_dot, void *stream);
 
+/* ---- second-order forward tangent (value, d/dt, d2/dt2): d(l_grad)/d(tau) --------------------------- *
+ * The gradient-loss prediction d(log I)/dt is evaluated at ts_g(tau); its derivative w.r.t. the refractory
+ * period needs d2 I/dt2 per ray (models/robust_e_nerf.py:340-357,383-409 differentiated through
+ * `grad.ts`; the reference obtains it as a third-order autograd graph).  Forward only, same sample
+ * stream as the first-order render.  Arrays with suffix dd hold second time derivatives. */
+int ren_trajectory_jvp2(const double *ts, int64_t B, const int64_t *tab_ts, const float *tab_pos,
+                        const float *tab_quat, int64_t C, float *pos, float *rot, float *dpos, float *drot,
+                        float *ddrot, void *stream);
+int ren_raygen_jvp2(const float *Kinv, const float *px, const float *pos, const float *rot, const float *dpos,
+                    const float *drot, const float *ddrot, int64_t B, float *rays_o, float *rays_d,
+                    float *rays_do, float *rays_dd, float *rays_ddd, void *stream);
+int ren_hashgrid_fwd_jvp2(const ren_grid_desc *grid, const float *table, const ren_scene_desc *scene,
+                          const float *rays_o, const float *rays_d, const float *rays_do, const float *rays_dd,
+                          const float *rays_ddd, const int32_t *ray_indices, const float *t_starts,
+                          const float *t_ends, int64_t n, float *feat, float *featd, float *featdd, void *stream);
+int ren_mlp_fwd_jvp2(const float *mlp_params, int32_t C, const float *feat, const float *featd,
+                     const float *featdd, const ren_scene_desc *scene, const float *rays_o, const float *rays_d,
+                     const float *rays_do, const float *rays_dd, const float *rays_ddd,
+                     const int32_t *ray_indices, const float *t_starts, const float *t_ends, int64_t n,
+                     float *rgb, float *rgbd, float *rgbdd, float *sigma, float *sigmad, float *sigmadd,
+                     void *stream);
+int ren_composite_fwd_jvp2(const int64_t *offsets, const int32_t *counts, int64_t n_rays, const float *t_starts,
+                           const float *t_ends, const float *sigmas, const float *sigmads, const float *sigmadds,
+                           const float *rgbs, const float *rgbds, const float *rgbdds, int32_t C,
+                           const float *bkgd, float *colors, float *colords, float *colorsdd, void *stream);
+
 /* ---- utilities ------------------------------------------------------------------------------------- */
 /* out[c] = sum_r in[r*C + c]   (C <= 4) */
 int ren_column_sum(const float *in, int64_t rows, int32_t C, float *out, void *stream);

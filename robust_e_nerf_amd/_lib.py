@@ -72,6 +72,11 @@ SIGNATURES = {
                                 P, P, P, P, P, P]),
     "ren_composite_fwd_jvp": (c_int, [P, P, c_int64, P, P, P, P, P, P, c_int32, P, P, P, P, P, P, P, P, P]),
     "ren_composite_bwd_jvp": (c_int, [P, P, c_int64, P, P, P, P, P, P, c_int32, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "ren_trajectory_jvp2": (c_int, [P, c_int64, P, P, P, c_int64, P, P, P, P, P, P]),
+    "ren_raygen_jvp2": (c_int, [P, P, P, P, P, P, P, c_int64, P, P, P, P, P, P]),
+    "ren_hashgrid_fwd_jvp2": (c_int, [POINTER(GridDesc), P, POINTER(SceneDesc), P, P, P, P, P, P, P, P, c_int64, P, P, P, P]),
+    "ren_mlp_fwd_jvp2": (c_int, [P, c_int32, P, P, P, POINTER(SceneDesc), P, P, P, P, P, P, P, P, c_int64, P, P, P, P, P, P, P]),
+    "ren_composite_fwd_jvp2": (c_int, [P, P, c_int64, P, P, P, P, P, P, P, P, c_int32, P, P, P, P, P]),
     "ren_grad_loss_fwd": (c_int, [P, P, P, P, c_int64, c_int32, P, P]),
     "ren_grad_loss_bwd": (c_int, [P, P, P, P, c_int64, c_int32, c_float, P, P, P, P]),
 }

@@ -441,17 +441,21 @@ class Trainer:
         with the event rate C/dt.  Accumulates gradients; returns (weighted loss term, aux)."""
         from . import jvp
         r, t, f = self.r, self.t, self.r.field
-        if t.train_refractory_period:
-            raise NotImplementedError("d(l_grad)/d(tau) through the pose needs a second-order tangent (next round)")
         B = batch["position"].shape[0]
         self._refresh_contrast_threshold()
+        self._refresh_tau()
         d_start, d_end, _ = self._prepare(batch)
         ts_g = torch.lerp(d_start, d_end, batch["u_grad"]).contiguous()
         ev_diff = batch["num_pos"] * self.c_p - batch["num_neg"] * self.c_n
         start = batch["start_ts"].to(torch.float64) + self.tau
         target = (ev_diff / (batch["end_ts"] - start)).to(torch.float32).contiguous()      # loss.py:39-42
-        pos, rot, dpos, drot = jvp.trajectory_jvp(ts_g, self.tab_ts, self.tab_pos, self.tab_quat)
-        o, d, od, dd = jvp.raygen_jvp(self.Kinv, batch["position"].contiguous(), pos, rot, dpos, drot)
+        ddd = None
+        if t.train_refractory_period:                                  # tau moves ts_g: second-order tangent
+            pos, rot, dpos, drot, ddrot = jvp.trajectory_jvp2(ts_g, self.tab_ts, self.tab_pos, self.tab_quat)
+            o, d, od, dd, ddd = jvp.raygen_jvp2(self.Kinv, batch["position"].contiguous(), pos, rot, dpos, drot, ddrot)
+        else:
+            pos, rot, dpos, drot = jvp.trajectory_jvp(ts_g, self.tab_ts, self.tab_pos, self.tab_quat)
+            o, d, od, dd = jvp.raygen_jvp(self.Kinv, batch["position"].contiguous(), pos, rot, dpos, drot)
         bkgd = torch.nn.functional.softplus(self.small[: f.C]) if t.bkgd_is_param else None
         jit = None if jitter_grad is None else jitter_grad.to(torch.float32).contiguous()
         colors, colords, opac, ctx = jvp.render_forward(r, o, d, od, dd, jit, bkgd, training=True)
@@ -464,8 +468,14 @@ class Trainer:
         scale = pw * t.w_grad
         loss = loss_sum[0] / loss_sum[1] * scale
         g_i, g_id = jvp.grad_loss_bwd(inten, intend, target, valid, t.err_grad, scale, loss_sum)
-        if t.train_contrast_threshold:
+        if t.train_contrast_threshold or t.train_refractory_period:
             self._contrast_threshold_grad(batch, intend / inten, "grad", valid)
+        if t.train_refractory_period:
+            # d L/d tau through the pose: dL/dI * dI/dt + dL/dI' * d2I/dt2, times d ts_g/d tau  (per event)
+            _, _, colorsdd = jvp.render_forward2(r, o, d, od, dd, ddd, ctx["pk"], bkgd)
+            dts = self._tau_chain(batch, "grad")
+            per_ev = g_i.double() * intend.double() + g_id.double() * colorsdd[:, 0].double()
+            self.tau_grad = self.tau_grad + (per_ev * dts.to(per_ev.device)).sum().cpu()
         d_bkgd = jvp.render_backward(r, ctx, g_i[:, None].contiguous(), g_id[:, None].contiguous())
         if d_bkgd is not None:
             self.small_grad[: f.C] += d_bkgd * torch.sigmoid(self.small[: f.C])

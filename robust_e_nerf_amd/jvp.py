@@ -33,6 +33,53 @@ def raygen_jvp(Kinv, px, pos, rot, dpos, drot):
     return o, d, od, dd
 
 
+def trajectory_jvp2(ts, tab_ts, tab_pos, tab_quat):
+    """-> pos, rot, d pos/dt, d rot/dt, d2 rot/dt2 (d2 pos/dt2 = 0 inside a pose segment)."""
+    B, dev = ts.shape[0], ts.device
+    pos, dpos = torch.empty(B, 3, device=dev), torch.empty(B, 3, device=dev)
+    rot, drot, ddrot = (torch.empty(B, 3, 3, device=dev) for _ in range(3))
+    check(_lib.load().ren_trajectory_jvp2(_ptr(ts, torch.float64), B, _ptr(tab_ts, torch.int64), _ptr(tab_pos),
+                                          _ptr(tab_quat), tab_ts.shape[0], _ptr(pos), _ptr(rot), _ptr(dpos),
+                                          _ptr(drot), _ptr(ddrot), _stream()), "ren_trajectory_jvp2")
+    return pos, rot, dpos, drot, ddrot
+
+
+def raygen_jvp2(Kinv, px, pos, rot, dpos, drot, ddrot):
+    B, dev = px.shape[0], px.device
+    o, d, od, dd, ddd = (torch.empty(B, 3, device=dev) for _ in range(5))
+    check(_lib.load().ren_raygen_jvp2(_ptr(Kinv), _ptr(px), _ptr(pos), _ptr(rot), _ptr(dpos), _ptr(drot),
+                                      _ptr(ddrot), B, _ptr(o), _ptr(d), _ptr(od), _ptr(dd), _ptr(ddd), _stream()),
+          "ren_raygen_jvp2")
+    return o, d, od, dd, ddd
+
+
+def render_forward2(r, o, d, od, dd, ddd, pk, bkgd):
+    """Second-order forward render over an EXISTING sample stream `pk` (sample placement is not
+    differentiated): -> colors, d colors/dt, d2 colors/dt2, each (R, C).  Forward only."""
+    f, lib = r.field, _lib.load()
+    n, R, dev = pk.n, o.shape[0], o.device
+    if n == 0:
+        z = torch.zeros(R, f.C, device=dev)
+        return z + (bkgd if bkgd is not None else 0.0), z.clone(), z.clone()
+    nb = ops.n_blocks32(n)
+    feat, featd, featdd = (torch.empty(nb * 1024, device=dev) for _ in range(3))
+    ri, ts, te = pk.ray_indices, pk.t_starts, pk.t_ends
+    check(lib.ren_hashgrid_fwd_jvp2(ctypes.byref(f.grid), _ptr(f.table), ctypes.byref(r.scene), _ptr(o), _ptr(d),
+                                    _ptr(od), _ptr(dd), _ptr(ddd), _ptr(ri), _ptr(ts), _ptr(te), n, _ptr(feat),
+                                    _ptr(featd), _ptr(featdd), _stream()), "ren_hashgrid_fwd_jvp2")
+    rgb, rgbd, rgbdd = (torch.empty(n, f.C, device=dev) for _ in range(3))
+    sg, sgd, sgdd = (torch.empty(n, device=dev) for _ in range(3))
+    check(lib.ren_mlp_fwd_jvp2(_ptr(f.mlp), f.C, _ptr(feat), _ptr(featd), _ptr(featdd), ctypes.byref(r.scene),
+                               _ptr(o), _ptr(d), _ptr(od), _ptr(dd), _ptr(ddd), _ptr(ri), _ptr(ts), _ptr(te), n,
+                               _ptr(rgb), _ptr(rgbd), _ptr(rgbdd), _ptr(sg), _ptr(sgd), _ptr(sgdd), _stream()),
+          "ren_mlp_fwd_jvp2")
+    colors, colords, colorsdd = (torch.empty(R, f.C, device=dev) for _ in range(3))
+    check(lib.ren_composite_fwd_jvp2(_ptr(pk.offsets), _ptr(pk.counts), R, _ptr(ts), _ptr(te), _ptr(sg), _ptr(sgd),
+                                     _ptr(sgdd), _ptr(rgb), _ptr(rgbd), _ptr(rgbdd), f.C, _ptr(bkgd), _ptr(colors),
+                                     _ptr(colords), _ptr(colorsdd), _stream()), "ren_composite_fwd_jvp2")
+    return colors, colords, colorsdd
+
+
 def render_forward(r, o, d, od, dd, jitter, bkgd, training: bool = True):
     """-> colors (R,C), colords (R,C) [d/dt], opacity (R,), ctx."""
     f, lib = r.field, _lib.load()

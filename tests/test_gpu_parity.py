@@ -653,6 +653,34 @@ def test_grad_loss_step_vs_reference_golden(amd, full_table_cache):
     assert float(tr.ct_grad.abs().max()) == 0.0 and float(tr.ct[0]) != float(g["p2n_raw"].reshape(-1)[0])
 
 
+def test_refractory_period_gradient_full_step_vs_reference_golden(amd, full_table_cache):
+    """d(l_diff + l_grad)/d(tau) vs the REFERENCE's own training_step (C_p and tau trainable, golden
+    `g_tau_raw`).  The l_grad part needs d2I/dt2 per ray: second-order forward tangent (csrc/ren_jvp2.hip)
+    instead of the reference's third-order autograd graph."""
+    ops, engine = amd
+    g = load_golden("training_step_grad")
+    table = full_table_cache(g["table_seed"], g["table_scale"])
+    tr, batch = _trainer_from_golden(engine, g, table)
+    tr.t.w_grad, tr.t.err_grad, tr.t.pw_grad = float(g["w_grad"]), "mape", None
+    tr.t.train_contrast_threshold = True
+    tr.t.train_refractory_period = True
+    batch["u_grad"] = dev(g["u_grad"])
+    jit = t(g["jitters"])
+    loss_d, _ = tr.forward_backward(batch, dev(jit[1]), dev(jit[2]))
+    g_diff = tr.tau_grad.clone()
+    loss_g, _ = tr.grad_loss_forward_backward(batch, dev(jit[0]))
+    loss = float(loss_d) + float(loss_g)
+    assert abs(loss - float(g["loss"])) < 1e-4 * abs(float(g["loss"])), (loss, float(g["loss"]))
+    sg = torch.sigmoid(tr.tau_raw.detach() / tr.tau_max)
+    got = tr.tau_grad * sg * (1 - sg)                       # d tau / d raw
+    ref = torch.as_tensor(g["g_tau_raw"]).double()
+    print("d loss/d tau_raw: got", float(got), "ref", float(ref), "l_diff part", float(g_diff * sg * (1 - sg)))
+    assert rel_err(got, ref) < 5e-3, (float(got), float(ref))
+    assert rel_err(tr.ct_grad[:1].cpu(), g["g_p2n_raw"]) < 1e-3
+    tr.optimizer_step()
+    assert float(tr.tau_grad) == 0.0
+
+
 def test_refractory_period_gradient_vs_oracle(amd, spec, full_table_cache):
     """d(l_diff)/d(tau): assembled from forward-mode dI/dt of the start / end renders (no reverse pass
     through the poses) vs the oracle's autograd through LinearTrajectory and the whole render."""
