@@ -31,7 +31,9 @@ BYTES = {"hashgrid_fwd": 1024 + 12, "hashgrid_bwd": 2048 + 12, "hashgrid_bwd_bin
 # algorithmic flops per sample of the fused MLPs, C = 1 (DESIGN.md "Roofline"): 2 x MACs of
 # base 32-64-16 + head 31-64-64-1 forward; backward = data + weight gradients = 2 x forward (no recompute counted)
 MLP_MACS = 32 * 64 + 64 * 16 + 31 * 64 + 64 * 64 + 64
-FLOPS = {"mlp_fwd": 2 * MLP_MACS, "mlp_bwd": 4 * MLP_MACS}
+VANILLA_MACS = 593152            # 63-256x4-(+63)-256x3, sigma, bottleneck, 283-128-1
+FLOPS = {"mlp_fwd": 2 * MLP_MACS, "mlp_bwd": 4 * MLP_MACS, "dense_fwd": 2 * VANILLA_MACS,
+         "dense_bwd_data": 2 * VANILLA_MACS, "dense_bwd_weight": 2 * VANILLA_MACS}
 PMC_TRAFFIC = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
 
 
@@ -128,6 +130,9 @@ def main():
     ap.add_argument("--events", type=int, default=65536, help="events per step per GPU (2 rays each)")
     ap.add_argument("--samples", type=int, default=128, help="samples per ray (uniform sampler)")
     ap.add_argument("--sampler", default="uniform", choices=["uniform", "occgrid"])
+    ap.add_argument("--arch", default="ngp", choices=["ngp", "mlp"],
+                    help="ngp = hash grid (BASELINE configs[1], default); mlp = frequency encoding + 8x256 MLP "
+                         "(10.4 KB of saved activations per sample: use --events 8192 or less)")
     ap.add_argument("--loss-grad", type=float, default=0.0,
                     help="weight of the log-intensity-gradient loss (adds a third render with d/dt; 1e-3 in the real-data configs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -179,9 +184,16 @@ def main():
 
     aabb = (-1.5, -1.5, -1.5, 1.5, 1.5, 1.5)
     cfg = engine.RenderCfg(aabb=aabb, sampler=args.sampler, n_uniform=args.samples)
-    fld = engine.NGPField(dev)
-    fld.load(p)
-    r = engine.Renderer(fld, cfg)
+    if args.arch == "mlp":
+        from robust_e_nerf_amd import vanilla
+        fld = vanilla.VanillaField(dev, 1)
+        fld.load({k: v for name, o, i in vanilla.layer_shapes(1)
+                  for k, v in zip((name + ".weight", name + ".bias"), lin(o, i))})
+        r = vanilla.VanillaRenderer(fld, cfg)
+    else:
+        fld = engine.NGPField(dev)
+        fld.load(p)
+        r = engine.Renderer(fld, cfg)
     if args.sampler == "occgrid":
         r.binary.copy_(T(ball_binary(128, 0.42, aabb)).to(dev))
     tr = engine.Trainer(r, engine.TrainCfg(w_grad=args.loss_grad), Kinv=T(Kinv), tab_ts=T(tab_ts), tab_pos=T(tab_pos), tab_quat=T(tab_quat),
@@ -251,7 +263,9 @@ def main():
                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, args),
                     "algorithmic_bytes_per_sample": BYTES[dom], "avg_launch_ms": ms / c}
         else:
-            achieved = FLOPS[dom] * samples_per_launch / (ms / c * 1e-3) / 1e12
+            # dense_* families: one launch per layer, so price the whole family per step
+            per = (ms / args.steps) if dom.startswith("dense") else (ms / c)
+            achieved = FLOPS[dom] * samples_per_launch / (per * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": pmc_traffic(dom, args),
                     "algorithmic_flops_per_sample": FLOPS[dom], "avg_launch_ms": ms / c}
@@ -262,7 +276,7 @@ def main():
             "mlp_samples_per_sec": n_samples / dt, "mean_samples_per_ray": n_samples / rays,
             "loss": float(loss),
             "config": {"workload": "BASELINE configs[1]: synthetic ficus-like event stream, "
-                                   f"{B} events/step/GPU = {2 * B} rays x {args.samples} samples, arch ngp, fp32, "
+                                   f"{B} events/step/GPU = {2 * B} rays x {args.samples} samples, arch {args.arch}, fp32, "
                                    f"{'l_diff + l_grad (3 renders)' if args.loss_grad > 0 else 'l_diff (2 renders)'}, fwd+bwd+Adam; sampler={args.sampler}",
                        "events_per_step_per_gpu": B, "rays_per_step_per_gpu": 2 * B, "sampler": args.sampler,
                        "samples_per_ray": args.samples, "parallelism": f"dp{world}"},

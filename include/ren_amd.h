@@ -339,6 +339,40 @@ int ren_composite_fwd_jvp2(const int64_t *offsets, const int32_t *counts, int64_
                            const float *rgbs, const float *rgbds, const float *rgbdds, int32_t C,
                            const float *bkgd, float *colors, float *colords, float *colorsdd, void *stream);
 
+/* ---- vanilla-NeRF field, `arch: mlp` (external/mlp.py:26-113,126-205,208-243,246-358) ----------------- *
+ * Activations are row-major [n_pad][ld] f32, n_pad = n rounded up to 32, ld a multiple of 4 and at least
+ * the layer width rounded up to 32, padding columns ZERO (they are read as part of the reduction).
+ * Concatenations are column ranges of one buffer.  Weights are torch nn.Linear [n_out][n_in] + bias. */
+#define REN_ACT_NONE 0
+#define REN_ACT_SOFTPLUS100 1          /* Softplus(beta=100), models/nerf.py:17-29          */
+#define REN_ACT_SOFTPLUS1 2            /* Softplus(beta=1)                                  */
+#define REN_ACT_TRUNC_EXP_SEL 3        /* selector * exp(z - 1), external/ngp.py:45-65, mlp.py:343 */
+/* SinusoidalEncoder of the contracted position (63 features -> enc[:, :64], col 63 = 0; optional copy at
+ * cat[:, cat_col:cat_col+64]) and of pi*direction (27 features, padded to 32, at view[:, view_col:]);
+ * selector[i] = all(0 < contracted x < 1).  Positions from x_world/dirs or from the packed sample stream. */
+int ren_freq_encode(const ren_scene_desc *scene, const float *x_world, const float *dirs, const float *rays_o,
+                    const float *rays_d, const int32_t *ray_indices, const float *t_starts,
+                    const float *t_ends, int64_t n, float *enc, int32_t ld_enc, float *cat, int32_t ld_cat,
+                    int32_t cat_col, float *view, int32_t ld_view, int32_t view_col, uint8_t *selector,
+                    void *stream);
+/* Y[:, :n_out] = act(X[:, :n_in] W^T + b)  (nn.Linear + activation, mlp.py:99-113), n_out <= 256 */
+int ren_dense_fwd(const float *X, int32_t ldx, const float *W, const float *bias, int32_t n_out, int32_t n_in,
+                  int32_t act, const uint8_t *selector, float *Y, int32_t ldy, int64_t n, void *stream);
+/* dX[:, :n_store] (+)= dZ[:, :n_out] W[:, :n_store], then multiplied by prev_act'(Yprev) -> the dZ of the
+ * layer below (n_store <= n_in: gradients of concatenated encodings are not needed) */
+int ren_dense_bwd_data(const float *dZ, int32_t ldz, const float *W, int32_t n_out, int32_t n_in, int32_t n_store,
+                       int32_t prev_act, const float *Yprev, int32_t ldyp, int32_t accumulate, float *dX,
+                       int32_t ldx, int64_t n, void *stream);
+/* grad_w[n_out][n_in] += dZ^T X, grad_b[n_out] += column sums of dZ (slab-reduced, deterministic) */
+int64_t ren_dense_bwd_weight_workspace_floats(int32_t n_out, int32_t n_in, int32_t n_splits);
+int ren_dense_bwd_weight(const float *dZ, int32_t ldz, const float *X, int32_t ldx, int32_t n_out, int32_t n_in,
+                         int64_t n, int32_t n_splits, float *grad_w, float *grad_b, float *workspace,
+                         void *stream);
+/* output activations backward: dz_rgb[n_pad][32] = g_rgb * softplus1'(rgb), dz_sigma[n_pad][32] (col 0) =
+ * g_sigma * d sigma/d raw; padding zeroed */
+int ren_vanilla_heads_bwd(const float *g_rgb, const float *rgb, const float *g_sigma, const float *sigma,
+                          int64_t n, int32_t C, float *dz_rgb, float *dz_sigma, void *stream);
+
 /* ---- utilities ------------------------------------------------------------------------------------- */
 /* out[c] = sum_r in[r*C + c]   (C <= 4) */
 int ren_column_sum(const float *in, int64_t rows, int32_t C, float *out, void *stream);

@@ -77,6 +77,14 @@ SIGNATURES = {
     "ren_hashgrid_fwd_jvp2": (c_int, [POINTER(GridDesc), P, POINTER(SceneDesc), P, P, P, P, P, P, P, P, c_int64, P, P, P, P]),
     "ren_mlp_fwd_jvp2": (c_int, [P, c_int32, P, P, P, POINTER(SceneDesc), P, P, P, P, P, P, P, P, c_int64, P, P, P, P, P, P, P]),
     "ren_composite_fwd_jvp2": (c_int, [P, P, c_int64, P, P, P, P, P, P, P, P, c_int32, P, P, P, P, P]),
+    "ren_freq_encode": (c_int, [POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, P, c_int32, P, c_int32, c_int32, P,
+                                c_int32, c_int32, P, P]),
+    "ren_dense_fwd": (c_int, [P, c_int32, P, P, c_int32, c_int32, c_int32, P, P, c_int32, c_int64, P]),
+    "ren_dense_bwd_data": (c_int, [P, c_int32, P, c_int32, c_int32, c_int32, c_int32, P, c_int32, c_int32, P, c_int32,
+                                   c_int64, P]),
+    "ren_dense_bwd_weight_workspace_floats": (c_int64, [c_int32, c_int32, c_int32]),
+    "ren_dense_bwd_weight": (c_int, [P, c_int32, P, c_int32, c_int32, c_int32, c_int64, c_int32, P, P, P, P]),
+    "ren_vanilla_heads_bwd": (c_int, [P, P, P, P, c_int64, c_int32, P, P, P]),
     "ren_grad_loss_fwd": (c_int, [P, P, P, P, c_int64, c_int32, P, P]),
     "ren_grad_loss_bwd": (c_int, [P, P, P, P, c_int64, c_int32, c_float, P, P, P, P]),
 }

@@ -1,0 +1,484 @@
+// Vanilla-NeRF radiance field (`arch: mlp`): frequency positional encoding and dense layers on the f32
+// matrix cores.  Replaces SinusoidalEncoder / MLP / NerfMLP / VanillaNeRFRadianceField
+// (robust_e_nerf/external/mlp.py:26-113,126-205,208-243,246-358): every nn.Linear (+ activation) of the
+// 8 x 256 trunk, the sigma / bottleneck layers and the 283 -> 128 -> C colour head is one launch of
+// `dense_kernel` (forward, or backward-data with the previous layer's activation derivative fused into the
+// epilogue) and one of `dense_dw_kernel` (weight/bias gradient, slab-reduced: deterministic, no atomics).
+//
+// Layout: activations are row-major [n_pad][ld] f32 with zero padding columns up to a multiple of 32
+// (concatenations are column ranges of one buffer: [h4 | enc] and [bottleneck | view enc] are never
+// copied).  As in ren_mlp.hip a wavefront owns 32 samples = the MFMA columns; the weight chunk
+// W[:, k0:k0+32] is staged in LDS (double buffered, row stride 33 words: conflict-free for the A-operand
+// read) and shared by the four waves of the workgroup; the 32 x N output tile of a wave lives in
+// N/32 x 16 accumulator registers.  This is 593 k MACs per sample -- the one MFMA-bound variant of the
+// model; exact fp32 (v_mfma_f32_32x32x2_f32), bf16 mode is a later round.
+#include "ren_mlp_common.h"
+
+namespace {
+
+constexpr int ACT_NONE = 0, ACT_SOFTPLUS100 = 1, ACT_SOFTPLUS1 = 2, ACT_TRUNC_EXP_SEL = 3;
+constexpr int KC = 32;                                 // reduction chunk staged in LDS
+
+struct DenseArgs {
+    const float *X; int ldx;                           // [n_pad][ldx]: B operand rows (inputs, or dZ for backward-data)
+    const float *W; int w_rows, w_cols;                // torch nn.Linear weight [w_rows][w_cols]
+    int red;                                           // reduction length: w_cols (forward) / w_rows (backward)
+    int out0;                                          // first output feature of this launch (wide layers run as two
+                                                       // 128-output launches: 64 accumulator registers, two waves/SIMD)
+    int n_out;                                         // outputs stored (absolute bound)
+    const float *bias;                                 // forward only (may be null)
+    int act;                                           // forward: this layer's activation; backward: the PREVIOUS layer's
+    const float *Yprev; int ldyp;                      // backward: saved outputs of the previous layer
+    const uint8_t *sel;                                // ACT_TRUNC_EXP_SEL: per-sample selector
+    int accumulate;                                    // backward: add to what is already in Y before the derivative
+    float *Y; int ldy;
+    int64_t n;
+};
+
+template <int NT, bool BWD>
+__device__ __forceinline__ void load_chunk(const DenseArgs &a, int c, float (&pre)[NT * 4]) {
+    const int k0 = c * KC;
+#pragma unroll
+    for (int j = 0; j < NT * 4; ++j) {
+        const int e = threadIdx.x + 256 * j;
+        float v = 0.f;
+        if (!BWD) {                                    // out row = W row, reduction col = W col
+            const int row = a.out0 + (e >> 5), col = e & 31;
+            if (row < a.w_rows && k0 + col < a.w_cols) v = a.W[(int64_t)row * a.w_cols + k0 + col];
+        } else {                                       // out row = W col, reduction col = W row (W^T), coalesced along W cols
+            const int col = e / (NT * 32), row = a.out0 + e % (NT * 32);
+            if (k0 + col < a.w_rows && row < a.w_cols) v = a.W[(int64_t)(k0 + col) * a.w_cols + row];
+        }
+        pre[j] = v;
+    }
+}
+
+template <int NT, bool BWD>
+__device__ __forceinline__ void store_chunk(float *buf, const float (&pre)[NT * 4]) {
+#pragma unroll
+    for (int j = 0; j < NT * 4; ++j) {
+        const int e = threadIdx.x + 256 * j;
+        const int row = BWD ? e % (NT * 32) : e >> 5, col = BWD ? e / (NT * 32) : e & 31;
+        buf[row * 33 + col] = pre[j];
+    }
+}
+
+template <int NT, bool BWD>
+__global__ __launch_bounds__(256, 2) void dense_kernel(DenseArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];        // 2 x [NT*32][33]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hi = lane >> 5, sl = lane & 31;
+    const int64_t n_blk = (a.n + 31) >> 5;
+    const int64_t blk = (int64_t)blockIdx.x * 4 + wave;
+    const bool active = blk < n_blk;
+    const int64_t row = blk * 32 + sl;
+    const int n_chunks = (a.red + KC - 1) / KC;
+    constexpr int BUF = NT * 32 * 33;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const int o = a.out0 + t * 32 + rowc(g) + 4 * hi;
+            float bv = 0.f;
+            if (!BWD && a.bias) { bv = a.bias[min(o, a.w_rows - 1)]; bv = o < a.w_rows ? bv : 0.f; }   // branch-free: loads batch
+            acc[t][g] = bv;
+        }
+    {
+        float pre[NT * 4];
+        load_chunk<NT, BWD>(a, 0, pre);
+        store_chunk<NT, BWD>(lds, pre);
+    }
+    __syncthreads();
+    // both operands of chunk c+1 are fetched while chunk c is on the matrix cores (one wave per SIMD at
+    // NT = 8: nothing else would hide the latency)
+    float4 xv[8];
+    auto load_x = [&](int c, float4 (&dst)[8]) {
+        if (active) {
+            const float4 *xp = reinterpret_cast<const float4 *>(a.X + row * a.ldx + c * KC);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dst[j] = xp[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dst[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    load_x(0, xv);
+    for (int c = 0; c < n_chunks; ++c) {
+        float pre[NT * 4];
+        float4 xn[8];
+        const bool more = c + 1 < n_chunks;
+        if (more) { load_chunk<NT, BWD>(a, c + 1, pre); load_x(c + 1, xn); }
+        const float *buf = lds + (c & 1) * BUF;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const float4 q = xv[s >> 1];
+            const float b = (s & 1) ? (hi ? q.w : q.z) : (hi ? q.y : q.x);       // X[row][k0 + 2 s + hi]
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = MFMA(buf[(t * 32 + sl) * 33 + 2 * s + hi], b, acc[t]);
+        }
+        if (more) {
+            store_chunk<NT, BWD>(lds + ((c + 1) & 1) * BUF, pre);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xv[j] = xn[j];
+        }
+        __syncthreads();
+    }
+    if (!active || row >= ((a.n + 31) & ~(int64_t)31)) return;
+    const bool live = row < a.n;
+    const bool selv = (!BWD && a.act == ACT_TRUNC_EXP_SEL && live) ? a.sel[row] != 0 : false;
+    // epilogue in two halves of NT/2 tiles: all loads of a half (saved activations / accumulate target) are
+    // issued as float4 before any arithmetic, so their latencies overlap instead of queueing per element
+    constexpr int HT = NT > 1 ? NT / 2 : 1;
+#pragma unroll
+    for (int half = 0; half < NT / HT; ++half) {
+        float4 yp4[HT][4], yo4[HT][4];
+        if (BWD) {
+#pragma unroll
+            for (int u = 0; u < HT; ++u)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int o0 = a.out0 + (half * HT + u) * 32 + 8 * q + 4 * hi;
+                    const bool in = o0 + 3 < a.n_out;                 // n_out is a multiple of 4 on this path (host check)
+                    yp4[u][q] = (in && a.act == ACT_SOFTPLUS100) ? *reinterpret_cast<const float4 *>(a.Yprev + row * a.ldyp + o0)
+                                                                : make_float4(0.f, 0.f, 0.f, 0.f);
+                    yo4[u][q] = (in && a.accumulate) ? *reinterpret_cast<const float4 *>(a.Y + row * a.ldy + o0)
+                                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+        }
+#pragma unroll
+        for (int u = 0; u < HT; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int t = half * HT + u;
+                const int o0 = a.out0 + t * 32 + 8 * q + 4 * hi;
+                if (o0 >= a.n_out) continue;
+                float v[4];
+                const float yp[4] = {yp4[u][q].x, yp4[u][q].y, yp4[u][q].z, yp4[u][q].w};
+                const float yo[4] = {yo4[u][q].x, yo4[u][q].y, yo4[u][q].z, yo4[u][q].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float z = acc[t][4 * q + j];
+                    if (!BWD) {
+                        if (a.act == ACT_SOFTPLUS100) z = softplus100(z);
+                        else if (a.act == ACT_SOFTPLUS1) z = softplus1(z);
+                        else if (a.act == ACT_TRUNC_EXP_SEL) z = selv ? __expf(z - 1.f) : 0.f;      // ngp.py:45-65
+                    } else {
+                        z += yo[j];
+                        if (a.act == ACT_SOFTPLUS100) z *= dsoftplus_from_out(yp[j], 100.f);
+                    }
+                    v[j] = live ? z : 0.f;
+                }
+                float *yptr = a.Y + row * a.ldy + o0;
+                if (o0 + 3 < a.n_out) *reinterpret_cast<float4 *>(yptr) = make_float4(v[0], v[1], v[2], v[3]);
+                else
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (o0 + j < a.n_out) yptr[j] = v[j];
+            }
+    }
+}
+
+// ---- weight / bias gradient:  dW[N][K] += dZ^T X,  db[N] += sum dZ ------------------------------------
+// One workgroup of 8 waves per sample split.  Per 32-sample stage the rows of dZ (<= 256 columns) and X
+// (<= 320 columns) are loaded ONCE, coalesced, into LDS and every wave takes one 32-row tile of dW
+// (wave = N tile; a second N-tile round covers N = 256 with 8 waves each owning one tile, smaller N leaves
+// waves idle) against up to 8 K tiles: A = dZ^T (lane = neuron, k = sample), B = X (k = sample, lane =
+// input feature), both read conflict-free from the row-major LDS tiles.  HBM traffic is therefore one
+// pass over dZ and X per layer (per K group of 256 columns).  Partial sums go to per-split slabs.
+struct DwArgs {
+    const float *dZ; int ldz; int N;
+    const float *X; int ldx; int K;
+    int64_t n;
+    float *slab_w, *slab_b;                              // [n_splits][N][K], [n_splits][N]
+};
+
+constexpr int DW_LDZ = 256, DW_LDX = 256;                // LDS tile widths (one K group = 256 columns)
+
+__global__ __launch_bounds__(512, 1) void dense_dw_kernel(DwArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];       // 2 x ([32][256] dZ + [32][256] X)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hi = lane >> 5, sl = lane & 31;
+    const int n_splits = gridDim.x;
+    const int64_t n_blk = (a.n + 31) >> 5;
+    const int k_tiles = (a.K + 31) >> 5, n_tiles = (a.N + 31) >> 5;
+    const bool has_tile = wave < n_tiles;
+    float *sw = a.slab_w + (int64_t)blockIdx.x * a.N * a.K, *sb = a.slab_b + (int64_t)blockIdx.x * a.N;
+    constexpr int TILE = 32 * 256;                                    // floats per operand tile
+    for (int kg = 0; kg * 8 < k_tiles; ++kg) {
+        const int kt = min(8, k_tiles - kg * 8);                      // K tiles of this group
+        f32x16 acc[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[t][g] = 0.f;
+        float accb = 0.f;
+        // cooperative stage loader: 32 rows x 256 columns of each operand = 2 x 2048 float4, 512 threads
+        float4 pz[4], px[4];
+        auto fetch = [&](int64_t blk) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int e = threadIdx.x + 512 * j;                  // float4 index in the [32][64] float4 tile
+                const int r = e >> 6, c4 = (e & 63) * 4;
+                const int64_t row = blk * 32 + r;
+                pz[j] = (row < a.n && c4 < a.ldz && c4 < ((a.N + 3) & ~3))
+                            ? *reinterpret_cast<const float4 *>(a.dZ + row * a.ldz + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const int cx = kg * 256 + c4;
+                px[j] = (row < a.n && cx < a.ldx && c4 < kt * 32)
+                            ? *reinterpret_cast<const float4 *>(a.X + row * a.ldx + cx) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        auto stash = [&](float *buf) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int e = threadIdx.x + 512 * j;
+                reinterpret_cast<float4 *>(buf)[e] = pz[j];
+                reinterpret_cast<float4 *>(buf + TILE)[e] = px[j];
+            }
+        };
+        int64_t blk = blockIdx.x;
+        int cur = 0;
+        if (blk < n_blk) { fetch(blk); stash(lds); }
+        __syncthreads();
+        for (; blk < n_blk; blk += n_splits) {
+            const int64_t nxt = blk + n_splits;
+            if (nxt < n_blk) fetch(nxt);
+            const float *tz = lds + cur * 2 * TILE, *tx = tz + TILE;
+            if (has_tile) {
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const float az = tz[(2 * s + hi) * DW_LDZ + wave * 32 + sl];
+                    accb += az;
+#pragma unroll
+                    for (int t = 0; t < 8; ++t)
+                        if (t < kt) acc[t] = MFMA(az, tx[(2 * s + hi) * DW_LDX + t * 32 + sl], acc[t]);   // wave-uniform
+                }
+            }
+            if (nxt < n_blk) stash(lds + (1 - cur) * 2 * TILE);
+            cur = 1 - cur;
+            __syncthreads();
+        }
+        if (has_tile) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int k = (kg * 8 + t) * 32 + sl;
+                if (t >= kt || k >= a.K) continue;
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int o = wave * 32 + rowc(g) + 4 * hi;
+                    if (o < a.N) sw[(int64_t)o * a.K + k] = acc[t][g];
+                }
+            }
+            if (kg == 0) {
+                const float bsum = accb + __shfl_xor(accb, 32, 64);
+                const int neuron = wave * 32 + sl;
+                if (hi == 0 && neuron < a.N) sb[neuron] = bsum;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---- frequency encodings (SinusoidalEncoder, mlp.py:208-243) ---------------------------------------------------
+struct EncArgs {
+    SampleSrc src;
+    ren_scene_dev sc;
+    int64_t n;
+    float *enc; int ld_enc;                              // [n_pad][>= 64]: 63 position features, rest zero
+    float *cat; int ld_cat, cat_col;                     // optional second copy at columns cat_col.. of the skip buffer
+    float *view; int ld_view, view_col;                  // optional 27 direction features (padded to 32)
+    uint8_t *sel;
+};
+
+template <int deg>
+__device__ __forceinline__ void sin_enc(const float *x, float *out) {            // [x, sin(2^k x), sin(2^k x + pi/2)]
+    out[0] = x[0]; out[1] = x[1]; out[2] = x[2];
+#pragma unroll
+    for (int k = 0; k < deg; ++k) {
+        const float sc = (float)(1 << k);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float xb = x[j] * sc;
+            out[3 + 3 * k + j] = sinf(xb);
+            out[3 + 3 * deg + 3 * k + j] = sinf(xb + 1.5707963267948966f);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void freq_encode_kernel(EncArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    float x, y, z, dx = 0.f, dy = 0.f, dz = 1.f;
+    if (a.src.ray_indices) {
+        int ray;
+        ren_sample_pos(a.src.rays_o, a.src.rays_d, a.src.ray_indices, a.src.t_starts, a.src.t_ends, i, x, y, z, ray);
+        const float *d = a.src.rays_d + 3 * (int64_t)ray;
+        dx = d[0]; dy = d[1]; dz = d[2];
+    } else {
+        x = a.src.x_world[3 * i]; y = a.src.x_world[3 * i + 1]; z = a.src.x_world[3 * i + 2];
+        if (a.src.dirs) { dx = a.src.dirs[3 * i]; dy = a.src.dirs[3 * i + 1]; dz = a.src.dirs[3 * i + 2]; }
+    }
+    float u[3];
+    ren_contract(a.sc, x, y, z, u[0], u[1], u[2]);
+    a.sel[i] = u[0] > 0.f && u[0] < 1.f && u[1] > 0.f && u[1] < 1.f && u[2] > 0.f && u[2] < 1.f;    // mlp.py:333
+    const float TWO_PI = 6.283185307179586f;
+    const float p[3] = {TWO_PI * (u[0] - 0.5f), TWO_PI * (u[1] - 0.5f), TWO_PI * (u[2] - 0.5f)};  // mlp.py:335
+    float e[64];
+    sin_enc<10>(p, e);
+    e[63] = 0.f;
+    float4 *o1 = reinterpret_cast<float4 *>(a.enc + i * a.ld_enc);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) o1[j] = make_float4(e[4 * j], e[4 * j + 1], e[4 * j + 2], e[4 * j + 3]);
+    if (a.cat) {
+        float4 *o2 = reinterpret_cast<float4 *>(a.cat + i * a.ld_cat + a.cat_col);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) o2[j] = make_float4(e[4 * j], e[4 * j + 1], e[4 * j + 2], e[4 * j + 3]);
+    }
+    if (a.view) {
+        const float PI = 3.141592653589793f;
+        const float c[3] = {dx * PI, dy * PI, dz * PI};                                              // mlp.py:352
+        float v[32];
+        sin_enc<4>(c, v);
+#pragma unroll
+        for (int j = 27; j < 32; ++j) v[j] = 0.f;
+        float4 *o3 = reinterpret_cast<float4 *>(a.view + i * a.ld_view + a.view_col);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o3[j] = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+    }
+}
+
+// ---- output activations, backward:  dz_rgb = g_rgb softplus1'(rgb),  dz_sigma = g_sigma exp(min(z - 1, 15)) sel --
+__global__ __launch_bounds__(256) void heads_bwd_kernel(const float *__restrict__ g_rgb, const float *__restrict__ rgb,
+                                                        const float *__restrict__ g_sigma,
+                                                        const float *__restrict__ sigma, int64_t n, int64_t n_pad, int C,
+                                                        float *__restrict__ dz_rgb, float *__restrict__ dz_sigma) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pad) return;
+    float4 *zr = reinterpret_cast<float4 *>(dz_rgb + i * 32), *zs = reinterpret_cast<float4 *>(dz_sigma + i * 32);
+    float r[4] = {0.f, 0.f, 0.f, 0.f}, s0 = 0.f;
+    if (i < n) {
+        for (int c = 0; c < C; ++c) r[c] = g_rgb[i * C + c] * dsoftplus_from_out(rgb[i * C + c], 1.f);
+        s0 = g_sigma[i] * fminf(sigma[i], 3269017.3724721107f);                 // sigma = sel exp(z-1); d/dz clamps at e^15
+    }
+    zr[0] = make_float4(r[0], r[1], r[2], r[3]);
+    zs[0] = make_float4(s0, 0.f, 0.f, 0.f);
+    for (int j = 1; j < 8; ++j) { zr[j] = make_float4(0.f, 0.f, 0.f, 0.f); zs[j] = make_float4(0.f, 0.f, 0.f, 0.f); }
+}
+
+template <bool BWD>
+int launch_dense(DenseArgs a, int tiles, hipStream_t st) {
+    if (tiles == 8) {                                   // two launches of 4 tiles: see DenseArgs::out0
+        a.out0 = 0;
+        int rc = launch_dense<BWD>(a, 4, st);
+        if (rc != REN_OK) return rc;
+        a.out0 = 128;
+        return launch_dense<BWD>(a, 4, st);
+    }
+    const int64_t n_blk = (a.n + 31) / 32;
+    const dim3 grd((unsigned)((n_blk + 3) / 4)), blk(256);
+#define REN_DENSE_CASE(NT)                                                                                   \
+    case NT: {                                                                                               \
+        const size_t lds = 2 * (size_t)NT * 32 * 33 * 4;                                                     \
+        (void)hipFuncSetAttribute((const void *)dense_kernel<NT, BWD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((dense_kernel<NT, BWD>), grd, blk, lds, st, a);                                   \
+        break;                                                                                               \
+    }
+    switch (tiles) {
+        REN_DENSE_CASE(1) REN_DENSE_CASE(2) REN_DENSE_CASE(4)
+        default: return REN_ERR_UNSUPPORTED;
+    }
+#undef REN_DENSE_CASE
+    REN_CHECK_LAUNCH();
+}
+
+inline int tiles_for(int n_out) { return n_out <= 32 ? 1 : n_out <= 64 ? 2 : n_out <= 128 ? 4 : n_out <= 256 ? 8 : -1; }
+
+}  // namespace
+
+extern "C" int ren_freq_encode(const ren_scene_desc *scene, const float *x_world, const float *dirs,
+                               const float *rays_o, const float *rays_d, const int32_t *ray_indices,
+                               const float *t_starts, const float *t_ends, int64_t n, float *enc, int32_t ld_enc,
+                               float *cat, int32_t ld_cat, int32_t cat_col, float *view, int32_t ld_view,
+                               int32_t view_col, uint8_t *selector, void *stream) {
+    if (!scene || !enc || !selector || n < 0 || ld_enc < 64 || (ld_enc & 3)) return REN_ERR_BAD_ARG;
+    if (!x_world && (!rays_o || !rays_d || !ray_indices || !t_starts || !t_ends)) return REN_ERR_BAD_ARG;
+    if (cat && (ld_cat < cat_col + 64 || (ld_cat & 3) || (cat_col & 3))) return REN_ERR_BAD_ARG;
+    if (view && (ld_view < view_col + 32 || (ld_view & 3) || (view_col & 3))) return REN_ERR_BAD_ARG;
+    if (n == 0) return REN_OK;
+    EncArgs a;
+    a.src = SampleSrc{x_world, dirs, rays_o, rays_d, x_world ? nullptr : ray_indices, t_starts, t_ends};
+    a.sc = ren_make_scene(scene);
+    a.n = n; a.enc = enc; a.ld_enc = ld_enc; a.cat = cat; a.ld_cat = ld_cat; a.cat_col = cat_col;
+    a.view = view; a.ld_view = ld_view; a.view_col = view_col; a.sel = selector;
+    hipLaunchKernelGGL(freq_encode_kernel, dim3(ren_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    REN_CHECK_LAUNCH();
+}
+
+extern "C" int ren_dense_fwd(const float *X, int32_t ldx, const float *W, const float *bias, int32_t n_out,
+                             int32_t n_in, int32_t act, const uint8_t *selector, float *Y, int32_t ldy, int64_t n,
+                             void *stream) {
+    if (!X || !W || !Y || n < 0 || n_out < 1 || n_in < 1 || (ldx & 3) || (ldy & 3)) return REN_ERR_BAD_ARG;
+    if (ldx < ((n_in + KC - 1) / KC) * KC) return REN_ERR_BAD_ARG;           // X rows are read in whole 32-wide chunks
+    if (act < ACT_NONE || act > ACT_TRUNC_EXP_SEL || (act == ACT_TRUNC_EXP_SEL && !selector)) return REN_ERR_BAD_ARG;
+    const int tiles = tiles_for(n_out);
+    if (tiles < 0) return REN_ERR_UNSUPPORTED;
+    if (n == 0) return REN_OK;
+    DenseArgs a = {};
+    a.X = X; a.ldx = ldx; a.W = W; a.w_rows = n_out; a.w_cols = n_in; a.red = n_in; a.n_out = n_out; a.bias = bias;
+    a.act = act; a.sel = selector; a.Y = Y; a.ldy = ldy; a.n = n;
+    return launch_dense<false>(a, tiles, (hipStream_t)stream);
+}
+
+extern "C" int ren_dense_bwd_data(const float *dZ, int32_t ldz, const float *W, int32_t n_out, int32_t n_in,
+                                  int32_t n_store, int32_t prev_act, const float *Yprev, int32_t ldyp,
+                                  int32_t accumulate, float *dX, int32_t ldx, int64_t n, void *stream) {
+    if (!dZ || !W || !dX || n < 0 || n_out < 1 || n_in < 1 || n_store < 1 || n_store > n_in || (ldz & 3) || (ldx & 3) ||
+        (n_store & 3) || (Yprev && (ldyp & 3)))
+        return REN_ERR_BAD_ARG;
+    if (ldz < ((n_out + KC - 1) / KC) * KC) return REN_ERR_BAD_ARG;
+    if (prev_act != ACT_NONE && prev_act != ACT_SOFTPLUS100) return REN_ERR_UNSUPPORTED;
+    if (prev_act == ACT_SOFTPLUS100 && !Yprev) return REN_ERR_BAD_ARG;
+    const int tiles = tiles_for(n_store);
+    if (tiles < 0) return REN_ERR_UNSUPPORTED;
+    if (n == 0) return REN_OK;
+    DenseArgs a = {};
+    a.X = dZ; a.ldx = ldz; a.W = W; a.w_rows = n_out; a.w_cols = n_in; a.red = n_out; a.n_out = n_store;
+    a.act = prev_act; a.Yprev = Yprev; a.ldyp = ldyp; a.accumulate = accumulate; a.Y = dX; a.ldy = ldx; a.n = n;
+    return launch_dense<true>(a, tiles, (hipStream_t)stream);
+}
+
+extern "C" int64_t ren_dense_bwd_weight_workspace_floats(int32_t n_out, int32_t n_in, int32_t n_splits) {
+    if (n_out < 1 || n_in < 1 || n_splits < 1) return -1;
+    return (int64_t)n_splits * ((int64_t)n_out * n_in + n_out);
+}
+
+extern "C" int ren_dense_bwd_weight(const float *dZ, int32_t ldz, const float *X, int32_t ldx, int32_t n_out,
+                                    int32_t n_in, int64_t n, int32_t n_splits, float *grad_w, float *grad_b,
+                                    float *workspace, void *stream) {
+    if (!dZ || !X || !grad_w || !grad_b || !workspace || n < 0 || n_out < 1 || n_in < 1 || n_splits < 1)
+        return REN_ERR_BAD_ARG;
+    if (ldx < ((n_in + 31) / 32) * 32 || ldz < n_out || (ldx & 3) || (ldz & 3) || n_out > 256) return REN_ERR_BAD_ARG;
+    if (n == 0) return REN_OK;
+    DwArgs a;
+    a.dZ = dZ; a.ldz = ldz; a.N = n_out; a.X = X; a.ldx = ldx; a.K = n_in; a.n = n;
+    a.slab_w = workspace; a.slab_b = workspace + (int64_t)n_splits * n_out * n_in;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = 2 * 2 * 32 * 256 * sizeof(float);                       // 128 KiB: one workgroup per CU
+    (void)hipFuncSetAttribute((const void *)dense_dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(dense_dw_kernel, dim3(n_splits), dim3(512), lds, st, a);
+    const int len_w = n_out * n_in;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((len_w + 255) / 256), dim3(256), 0, st, a.slab_w, n_splits, len_w, grad_w);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((n_out + 255) / 256), dim3(256), 0, st, a.slab_b, n_splits, n_out, grad_b);
+    REN_CHECK_LAUNCH();
+}
+
+extern "C" int ren_vanilla_heads_bwd(const float *g_rgb, const float *rgb, const float *g_sigma, const float *sigma,
+                                     int64_t n, int32_t C, float *dz_rgb, float *dz_sigma, void *stream) {
+    if (!g_rgb || !rgb || !g_sigma || !sigma || !dz_rgb || !dz_sigma || n < 0) return REN_ERR_BAD_ARG;
+    if (C != 1 && C != 3) return REN_ERR_UNSUPPORTED;
+    if (n == 0) return REN_OK;
+    const int64_t n_pad = (n + 31) / 32 * 32;
+    hipLaunchKernelGGL(heads_bwd_kernel, dim3(ren_blocks(n_pad, 256)), dim3(256), 0, (hipStream_t)stream, g_rgb, rgb,
+                       g_sigma, sigma, n, n_pad, C, dz_rgb, dz_sigma);
+    REN_CHECK_LAUNCH();
+}

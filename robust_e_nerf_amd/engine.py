@@ -124,48 +124,31 @@ class Renderer:
         if mode == 1 or n0 == 0:
             return Packed(ri, ts, te, offsets, counts, n0, n0)
         # sigma_fn pre-pass (external/utils.py:68-81) + render_visibility
-        feat = ops.hashgrid_fwd(self.field.grid, self.field.table, scene=self.scene, rays=(o, d),
-                                samples=(ri, ts, te), n=n0, layout=1)
-        _, sigma, _ = ops.mlp_fwd(self.field.mlp, self.field.C, feat, self.scene, rays=(o, d),
-                                  samples=(ri, ts, te), n=n0, density_only=True)
+        sigma = self._density_stream(o, d, (ri, ts, te), n0)
         keep, kept = ops.visibility(offsets, counts, sigma, ts, te, c.early_stop_eps, c.alpha_thre)
         new_offsets, total2 = ops.exclusive_scan(kept)
         n1 = int(total2.item())
         ri2, ts2, te2 = ops.compact_samples(offsets, counts, new_offsets, keep, ts, te, n1)
         return Packed(ri2, ts2, te2, new_offsets, kept, n1, n0)
 
-    # ---- forward render ---------------------------------------------------------------------------
-    def forward(self, o, d, jitter=None, bkgd: Optional[torch.Tensor] = None, training: bool = True,
-                save: bool = True):
-        f = self.field
-        pk = self.sample(o, d, jitter, training)
-        n_rays = o.shape[0]
-        if pk.n == 0:
-            colors = torch.zeros(n_rays, f.C, device=o.device)
-            if bkgd is not None:
-                colors = colors + bkgd
-            zero = torch.zeros(n_rays, device=o.device)
-            return colors, zero, zero.clone(), dict(pk=pk, empty=True)
-        feat = ops.hashgrid_fwd(f.grid, f.table, scene=self.scene, rays=(o, d),
-                                samples=(pk.ray_indices, pk.t_starts, pk.t_ends), n=pk.n, layout=1)
-        rgb, sigma, base = ops.mlp_fwd(f.mlp, f.C, feat, self.scene, rays=(o, d),
-                                       samples=(pk.ray_indices, pk.t_starts, pk.t_ends), n=pk.n,
-                                       save_base=save)
-        colors, opac, depth, w, T = ops.composite_fwd(pk.offsets, pk.counts, pk.t_starts, pk.t_ends, sigma, rgb,
-                                                      f.C, bkgd, save=save)
-        ctx = dict(pk=pk, o=o, d=d, feat=feat, rgb=rgb, sigma=sigma, base=base, w=w, T=T, opac=opac, bkgd=bkgd,
-                   empty=False)
-        return colors, opac, depth, ctx
+    # ---- field evaluation over a packed sample stream (overridden by vanilla.VanillaRenderer) ----------
+    def _density_stream(self, o, d, samples, n):
+        feat = ops.hashgrid_fwd(self.field.grid, self.field.table, scene=self.scene, rays=(o, d),
+                                samples=samples, n=n, layout=1)
+        _, sigma, _ = ops.mlp_fwd(self.field.mlp, self.field.C, feat, self.scene, rays=(o, d),
+                                  samples=samples, n=n, density_only=True)
+        return sigma
 
-    # ---- backward: accumulates into field.grad, returns d(bkgd) -------------------------------------
-    def backward(self, ctx, g_colors, g_opac=None, g_depth=None):
+    def _field_forward(self, o, d, pk, save):
         f = self.field
-        if ctx["empty"]:
-            return g_colors.sum(0) if ctx.get("bkgd") is not None else None
-        pk = ctx["pk"]
-        d_sig, d_rgb, d_bk = ops.composite_bwd(pk.offsets, pk.counts, pk.t_starts, pk.t_ends, ctx["sigma"],
-                                               ctx["rgb"], f.C, ctx["bkgd"], ctx["w"], ctx["T"], ctx["opac"],
-                                               g_colors, g_opac, g_depth, want_bkgd=ctx["bkgd"] is not None)
+        samples = (pk.ray_indices, pk.t_starts, pk.t_ends)
+        feat = ops.hashgrid_fwd(f.grid, f.table, scene=self.scene, rays=(o, d), samples=samples, n=pk.n, layout=1)
+        rgb, sigma, base = ops.mlp_fwd(f.mlp, f.C, feat, self.scene, rays=(o, d), samples=samples, n=pk.n,
+                                       save_base=save)
+        return rgb, sigma, dict(feat=feat, base=base)
+
+    def _field_backward(self, ctx, d_rgb, d_sig):
+        f, pk = self.field, ctx["pk"]
         samples = (pk.ray_indices, pk.t_starts, pk.t_ends)
         dfeat = ops.mlp_bwd(f.mlp, f.C, ctx["feat"], ctx["base"], self.scene, rays=(ctx["o"], ctx["d"]),
                             samples=samples, n=pk.n, rgb=ctx["rgb"], d_rgb=d_rgb, d_sigma=d_sig,
@@ -180,6 +163,35 @@ class Renderer:
         else:
             ops.hashgrid_bwd(f.grid, f.g_table, dfeat, scene=self.scene, rays=(ctx["o"], ctx["d"]), samples=samples,
                              n=pk.n, layout=1)
+
+    # ---- forward render ---------------------------------------------------------------------------
+    def forward(self, o, d, jitter=None, bkgd: Optional[torch.Tensor] = None, training: bool = True,
+                save: bool = True):
+        f = self.field
+        pk = self.sample(o, d, jitter, training)
+        n_rays = o.shape[0]
+        if pk.n == 0:
+            colors = torch.zeros(n_rays, f.C, device=o.device)
+            if bkgd is not None:
+                colors = colors + bkgd
+            zero = torch.zeros(n_rays, device=o.device)
+            return colors, zero, zero.clone(), dict(pk=pk, empty=True)
+        rgb, sigma, fctx = self._field_forward(o, d, pk, save)
+        colors, opac, depth, w, T = ops.composite_fwd(pk.offsets, pk.counts, pk.t_starts, pk.t_ends, sigma, rgb,
+                                                      f.C, bkgd, save=save)
+        ctx = dict(pk=pk, o=o, d=d, rgb=rgb, sigma=sigma, w=w, T=T, opac=opac, bkgd=bkgd, empty=False, **fctx)
+        return colors, opac, depth, ctx
+
+    # ---- backward: accumulates into field.grad, returns d(bkgd) -------------------------------------
+    def backward(self, ctx, g_colors, g_opac=None, g_depth=None):
+        f = self.field
+        if ctx["empty"]:
+            return g_colors.sum(0) if ctx.get("bkgd") is not None else None
+        pk = ctx["pk"]
+        d_sig, d_rgb, d_bk = ops.composite_bwd(pk.offsets, pk.counts, pk.t_starts, pk.t_ends, ctx["sigma"],
+                                               ctx["rgb"], f.C, ctx["bkgd"], ctx["w"], ctx["T"], ctx["opac"],
+                                               g_colors, g_opac, g_depth, want_bkgd=ctx["bkgd"] is not None)
+        self._field_backward(ctx, d_rgb, d_sig)
         return ops.column_sum(d_bk) if d_bk is not None else None
 
     # ---- density query (occ_eval_fn / query_density) ----------------------------------------------------

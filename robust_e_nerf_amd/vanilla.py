@@ -1,0 +1,226 @@
+"""`arch: mlp`: vanilla-NeRF radiance field (frequency positional encoding + 8 x 256 MLP with skip, sigma
+layer, bottleneck, 283 -> 128 -> C colour head) on the HIP dense-layer kernels (csrc/ren_dense.hip).
+
+Replaces ``VanillaNeRFRadianceField`` / ``NerfMLP`` / ``MLP`` / ``SinusoidalEncoder``
+(robust_e_nerf/external/mlp.py:26-113,126-205,208-243,246-358) as instantiated at
+robust_e_nerf/models/nerf.py:143-160 with configs/train/synthetic.yaml:85-96.  Parameters live in one flat
+float32 buffer in the order (and torch nn.Linear layout) of the reference state dict, so
+``VanillaField.load(reference_state_dict)`` is a straight copy and data parallelism / Adam work exactly as
+for the NGP field (``engine.Trainer``).  ``VanillaRenderer`` plugs the field into the same sampling,
+compositing and loss path as the hash-grid field.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import _lib, ops
+from ._lib import check
+from .engine import RenderCfg, Renderer, contract_points
+from .ops import _ptr, _stream
+
+POS_DIM, VIEW_DIM = 63, 27                      # SinusoidalEncoder(3, 0, 10) / (3, 0, 4), mlp.py:208-243
+DEPTH, WIDTH, SKIP, WIDTH_COND = 8, 256, 4, 128
+ACT_NONE, ACT_SOFTPLUS100, ACT_SOFTPLUS1, ACT_TRUNC_EXP_SEL = 0, 1, 2, 3
+
+
+def layer_shapes(C: int = 1) -> List[Tuple[str, int, int]]:
+    """(reference state-dict stem, out_features, in_features) in parameter-block order."""
+    out, fin = [], POS_DIM
+    for i in range(DEPTH):
+        out.append((f"mlp.base.hidden_layers.{i}", WIDTH, fin))
+        fin = WIDTH + POS_DIM if (i % SKIP == 0 and i > 0) else WIDTH          # mlp.py:60-71
+    out += [("mlp.sigma_layer.output_layer", 1, WIDTH), ("mlp.bottleneck_layer.output_layer", WIDTH, WIDTH),
+            ("mlp.rgb_layer.hidden_layers.0", WIDTH_COND, WIDTH + VIEW_DIM), ("mlp.rgb_layer.output_layer", C, WIDTH_COND)]
+    return out
+
+
+class VanillaField:
+    """Flat parameter / gradient buffers with per-layer (weight, bias) views."""
+
+    def __init__(self, device, radiance_dim: int = 1):
+        if radiance_dim not in (1, 3):
+            raise NotImplementedError("radiance_dim must be 1 or 3 (robust_e_nerf.py:230-233)")
+        self.C = radiance_dim
+        self.layers = layer_shapes(radiance_dim)
+        n = sum(o * i + o for _, o, i in self.layers)
+        self.n_params = n
+        n_pad = (n + 3) // 4 * 4
+        self.flat = torch.zeros(n_pad, device=device, dtype=torch.float32)
+        self.grad = torch.zeros(n_pad, device=device, dtype=torch.float32)
+        self.w, self.b, self.gw, self.gb = {}, {}, {}, {}
+        off = 0
+        for name, o, i in self.layers:
+            self.w[name], self.gw[name] = self.flat[off: off + o * i].view(o, i), self.grad[off: off + o * i].view(o, i)
+            off += o * i
+            self.b[name], self.gb[name] = self.flat[off: off + o], self.grad[off: off + o]
+            off += o
+
+    def load(self, sd: Dict[str, torch.Tensor]):
+        """sd: reference state dict (keys ``mlp.base.hidden_layers.0.weight`` ...; extra keys ignored)."""
+        for name, _, _ in self.layers:
+            self.w[name].copy_(sd[name + ".weight"].to(self.flat.device, torch.float32))
+            self.b[name].copy_(sd[name + ".bias"].to(self.flat.device, torch.float32))
+
+    def state_dict(self, grad: bool = False) -> Dict[str, torch.Tensor]:
+        w, b = (self.gw, self.gb) if grad else (self.w, self.b)
+        out = {}
+        for name, _, _ in self.layers:
+            out[name + ".weight"], out[name + ".bias"] = w[name], b[name]
+        return out
+
+
+class _Buffers:
+    """Activation buffers for n samples: row-major [n_pad][ld], zero padding columns."""
+
+    def __init__(self, n: int, dev, C: int, full: bool, backward: bool):
+        self.n, self.n_pad = n, (n + 31) // 32 * 32
+        # no pre-zeroing: every kernel writes all rows < n_pad of its output columns and the encoder writes the
+        # zero padding columns; rows >= n only ever feed their own (discarded) output rows
+        z = lambda ld: torch.empty(self.n_pad, ld, device=dev, dtype=torch.float32)
+        self.enc = z(64)
+        self.cat = z(320)                                   # [h4 (256) | enc (63) | 0]
+        self.h = {i: (None if i == SKIP else z(WIDTH)) for i in range(DEPTH)}
+        self.sel = torch.zeros(self.n_pad, device=dev, dtype=torch.uint8)
+        self.s4 = z(4)
+        if full:
+            self.rin = z(288)                               # [bottleneck (256) | view enc (27) | 0]
+            self.r = z(WIDTH_COND)
+            self.rgb4 = z(4)
+        if backward:
+            self.dz_rgb, self.dz_sig = z(32), z(32)
+            self.dr, self.db = z(WIDTH_COND), z(WIDTH)
+            self.dh = [z(WIDTH), z(WIDTH)]
+
+    def out_of(self, i):                                    # (buffer, ld) holding the output of trunk layer i
+        return (self.cat, 320) if i == SKIP else (self.h[i], WIDTH)
+
+
+class VanillaRenderer(Renderer):
+    """Renderer over a VanillaField: same sampler / compositing / losses, dense-layer field kernels."""
+
+    def __init__(self, fld: VanillaField, cfg: RenderCfg, n_splits: int = 256):
+        super().__init__(fld, cfg)
+        self.n_splits = n_splits
+        self._dw_ws = None
+        # HIP-event timing per kernel family when ops.profile_start() is active (bench.py)
+        self._fwd = ops._wrap("dense_fwd", self._fwd)
+        self._bwd_data = ops._wrap("dense_bwd_data", self._bwd_data)
+        self._bwd_weight = ops._wrap("dense_bwd_weight", self._bwd_weight)
+        self._encode = ops._wrap("freq_encode", self._encode)
+
+    # ---- kernels ------------------------------------------------------------------------------------
+    def _fwd(self, X, ldx, name, act, Y, ldy, n, sel=None):
+        f = self.field
+        o, i = f.w[name].shape
+        check(_lib.load().ren_dense_fwd(_ptr(X), ldx, _ptr(f.w[name]), _ptr(f.b[name]), o, i, act,
+                                        _ptr(sel, torch.uint8) if sel is not None else None, _ptr(Y), ldy, n, _stream()),
+              "ren_dense_fwd")
+
+    def _bwd_data(self, dZ, ldz, name, n_store, prev_act, Yprev, ldyp, accumulate, dX, ldx, n):
+        f = self.field
+        o, i = f.w[name].shape
+        check(_lib.load().ren_dense_bwd_data(_ptr(dZ), ldz, _ptr(f.w[name]), o, i, n_store, prev_act,
+                                             _ptr(Yprev) if Yprev is not None else None, ldyp, int(accumulate),
+                                             _ptr(dX), ldx, n, _stream()), "ren_dense_bwd_data")
+
+    def _bwd_weight(self, dZ, ldz, X, ldx, name, n):
+        f, lib = self.field, _lib.load()
+        o, i = f.w[name].shape
+        splits = max(1, min(self.n_splits, (n + 31) // 32))      # one workgroup (= one slab) per split
+        need = int(lib.ren_dense_bwd_weight_workspace_floats(o, i, splits))
+        if self._dw_ws is None or self._dw_ws.numel() < need:
+            self._dw_ws = None
+            self._dw_ws = torch.empty(need, device=dZ.device, dtype=torch.float32)
+        check(lib.ren_dense_bwd_weight(_ptr(dZ), ldz, _ptr(X), ldx, o, i, n, splits, _ptr(f.gw[name]), _ptr(f.gb[name]),
+                                       _ptr(self._dw_ws), _stream()), "ren_dense_bwd_weight")
+
+    def _encode(self, B: _Buffers, full: bool, *, rays=None, samples=None, x_world=None, dirs=None):
+        n = B.n
+        o, d = rays if rays is not None else (None, None)
+        ri, ts, te = samples if samples is not None else (None, None, None)
+        check(_lib.load().ren_freq_encode(ctypes.byref(self.scene), _ptr(x_world), _ptr(dirs), _ptr(o), _ptr(d),
+                                          _ptr(ri, torch.int32), _ptr(ts), _ptr(te), n, _ptr(B.enc), 64, _ptr(B.cat), 320,
+                                          256, _ptr(B.rin) if full else None, 288, 256, _ptr(B.sel, torch.uint8), _stream()),
+              "ren_freq_encode")
+
+    def _trunk(self, B: _Buffers):
+        n = B.n
+        X, ldx = B.enc, 64
+        for i in range(DEPTH):                                             # mlp.py:99-113
+            Y, ldy = B.out_of(i)
+            self._fwd(X, ldx, f"mlp.base.hidden_layers.{i}", ACT_SOFTPLUS100, Y, ldy, n)
+            X, ldx = Y, ldy
+        self._fwd(B.h[DEPTH - 1], WIDTH, "mlp.sigma_layer.output_layer", ACT_TRUNC_EXP_SEL, B.s4, 4, n, sel=B.sel)
+        return B.s4[:n, 0].contiguous()
+
+    def _field_eval(self, B: _Buffers, full: bool):
+        sigma = self._trunk(B)
+        if not full:
+            return None, sigma
+        n, C = B.n, self.field.C
+        self._fwd(B.h[DEPTH - 1], WIDTH, "mlp.bottleneck_layer.output_layer", ACT_NONE, B.rin, 288, n)
+        self._fwd(B.rin, 288, "mlp.rgb_layer.hidden_layers.0", ACT_SOFTPLUS100, B.r, WIDTH_COND, n)
+        self._fwd(B.r, WIDTH_COND, "mlp.rgb_layer.output_layer", ACT_SOFTPLUS1, B.rgb4, 4, n)
+        return B.rgb4[:n, :C].contiguous(), sigma
+
+    # ---- Renderer hooks ---------------------------------------------------------------------------------
+    def _density_stream(self, o, d, samples, n):
+        B = _Buffers(n, o.device, self.field.C, full=False, backward=False)
+        self._encode(B, False, rays=(o, d), samples=samples)
+        return self._trunk(B)
+
+    def _field_forward(self, o, d, pk, save):
+        B = _Buffers(pk.n, o.device, self.field.C, full=True, backward=False)
+        self._encode(B, True, rays=(o, d), samples=(pk.ray_indices, pk.t_starts, pk.t_ends))
+        rgb, sigma = self._field_eval(B, True)
+        return rgb, sigma, dict(buffers=B if save else None)
+
+    def _field_backward(self, ctx, d_rgb, d_sig):
+        B, n, C = ctx["buffers"], ctx["pk"].n, self.field.C
+        dev = d_rgb.device
+        z = lambda ld: torch.empty(B.n_pad, ld, device=dev, dtype=torch.float32)
+        dz_rgb, dz_sig, dr, db, dh = z(32), z(32), z(WIDTH_COND), z(WIDTH), [z(WIDTH), z(WIDTH)]
+        check(_lib.load().ren_vanilla_heads_bwd(_ptr(d_rgb.contiguous()), _ptr(ctx["rgb"]), _ptr(d_sig.contiguous()),
+                                                _ptr(ctx["sigma"]), n, C, _ptr(dz_rgb), _ptr(dz_sig), _stream()),
+              "ren_vanilla_heads_bwd")
+        h7 = B.h[DEPTH - 1]
+        # colour head: 128 -> C, [bottleneck | view] -> 128, bottleneck 256 -> 256 (no activation)
+        self._bwd_weight(dz_rgb, 32, B.r, WIDTH_COND, "mlp.rgb_layer.output_layer", n)
+        self._bwd_data(dz_rgb, 32, "mlp.rgb_layer.output_layer", WIDTH_COND, ACT_SOFTPLUS100, B.r, WIDTH_COND, False, dr,
+                       WIDTH_COND, n)
+        self._bwd_weight(dr, WIDTH_COND, B.rin, 288, "mlp.rgb_layer.hidden_layers.0", n)
+        self._bwd_data(dr, WIDTH_COND, "mlp.rgb_layer.hidden_layers.0", WIDTH, ACT_NONE, None, 0, False, db, WIDTH, n)
+        self._bwd_weight(db, WIDTH, h7, WIDTH, "mlp.bottleneck_layer.output_layer", n)
+        self._bwd_data(db, WIDTH, "mlp.bottleneck_layer.output_layer", WIDTH, ACT_NONE, None, 0, False, dh[0], WIDTH, n)
+        # sigma layer joins at h7; its data gradient is accumulated, then the trunk activation derivative applied
+        self._bwd_weight(dz_sig, 32, h7, WIDTH, "mlp.sigma_layer.output_layer", n)
+        self._bwd_data(dz_sig, 32, "mlp.sigma_layer.output_layer", WIDTH, ACT_SOFTPLUS100, h7, WIDTH, True, dh[0], WIDTH, n)
+        cur = 0
+        for i in range(DEPTH - 1, -1, -1):
+            name = f"mlp.base.hidden_layers.{i}"
+            if i == 0:
+                X, ldx = B.enc, 64
+            else:
+                X, ldx = B.out_of(i - 1)
+            self._bwd_weight(dh[cur], WIDTH, X, ldx, name, n)
+            if i > 0:
+                self._bwd_data(dh[cur], WIDTH, name, WIDTH, ACT_SOFTPLUS100, X, ldx, False, dh[1 - cur], WIDTH, n)
+                cur = 1 - cur
+
+    def query_density(self, x_world: torch.Tensor) -> torch.Tensor:
+        """VanillaNeRFRadianceField.query_density (mlp.py:343-347) for arbitrary world points."""
+        n = x_world.shape[0]
+        B = _Buffers(n, x_world.device, self.field.C, full=False, backward=False)
+        self._encode(B, False, x_world=x_world.contiguous())
+        return self._trunk(B)
+
+    def query(self, x_world: torch.Tensor, dirs: torch.Tensor):
+        """field(x, d) -> (rgb (n, C), sigma (n,), buffers) for free-standing points (mlp.py:349-358)."""
+        n = x_world.shape[0]
+        B = _Buffers(n, x_world.device, self.field.C, full=True, backward=False)
+        self._encode(B, True, x_world=x_world.contiguous(), dirs=dirs.contiguous())
+        rgb, sigma = self._field_eval(B, True)
+        return rgb, sigma, B

@@ -312,6 +312,45 @@ def gen_field(ngp, nerfacc):
              g_table_idx=pick, g_table_val=gt[pick], **field_params_np(rf), **grads)
 
 
+def gen_field_mlp(mlp_mod, ngp, nerfacc):
+    """Reference VanillaNeRFRadianceField (`arch: mlp`) forward + parameter gradients.  The 593 k parameters
+    are regenerated from a seed (oracle.vanilla.init_params) instead of being stored."""
+    from oracle import vanilla
+    for ct_name, ct, aabb in (("aabb", nerfacc.ContractionType.AABB, [-1.5] * 3 + [1.5] * 3),
+                              ("sphere", nerfacc.ContractionType.UN_BOUNDED_SPHERE, [0.5, -2.1, 0.6, 2.0, -0.6, 1.6])):
+        torch.manual_seed(12)
+        rf = mlp_mod.VanillaNeRFRadianceField(
+            aabb=aabb, num_dim=3, contraction_type=ct, radiance_dim=1, hidden_activation=torch.nn.Softplus(beta=100),
+            density_activation=ngp.shifted_trunc_exp, radiance_activation=torch.nn.Softplus(beta=1),
+            net_depth=8, net_width=256, skip_layer=4, net_depth_condition=1, net_width_condition=128,
+            pos_encoder_max_deg=10, view_encoder_max_deg=4, weight_norm=False)
+        seed = 21
+        params = vanilla.init_params(seed, C=1, gain=1.6)
+        sd = rf.state_dict()
+        assert set(params) == {k for k in sd if k.startswith("mlp.")}, sorted(set(sd) ^ set(params))
+        rf.load_state_dict({**sd, **params})
+        n = 160
+        lo, hi = torch.tensor(aabb[:3]), torch.tensor(aabb[3:])
+        span = 1.2 if ct_name == "aabb" else 3.0
+        x = (torch.rand(n, 3) - 0.5) * span * (hi - lo) + (hi + lo) / 2
+        d = torch.randn(n, 3)
+        d = d / d.norm(dim=-1, keepdim=True)
+        rgb, sigma = rf(x, d)
+        dens = rf.query_density(x)
+        g_rgb, g_sig = torch.randn_like(rgb), torch.randn_like(sigma)
+        rf.zero_grad()
+        ((rgb * g_rgb).sum() + (sigma * g_sig).sum()).backward()
+        grads, gsum = {}, {}
+        for k, v in rf.named_parameters():
+            g = v.grad.reshape(-1)
+            pick = torch.linspace(0, g.numel() - 1, min(64, g.numel())).long()
+            grads["gi." + k] = pick
+            grads["gv." + k] = g[pick]
+            gsum["gs." + k] = g.double().abs().sum()
+        save(f"field_mlp_{ct_name}", aabb=np.array(aabb, np.float32), contraction_type=ct.value, param_seed=seed,
+             param_gain=1.6, x=x, d=d, rgb=rgb, sigma=sigma, density=dens, g_rgb=g_rgb, g_sigma=g_sig, **grads, **gsum)
+
+
 def gen_sh(sh_encoder):
     torch.manual_seed(20)
     d = torch.randn(256, 3)
@@ -505,6 +544,8 @@ def main():
     gen_trajectory(trajectories, nerf_mod)
     gen_events(egp, loss_mod)
     gen_field(ngp, nerfacc)
+    from robust_e_nerf.external import mlp as mlp_mod
+    gen_field_mlp(mlp_mod, ngp, nerfacc)
     mods = (rmod, nerf_mod, trajectories, egp, loss_mod, nerfacc)
     gen_training_step(mods, with_grad_loss=False)
     gen_training_step(mods, with_grad_loss=True)

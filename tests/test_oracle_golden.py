@@ -134,3 +134,22 @@ def test_training_step_grad(full_table_cache):
     assert rel_err(p["hash"].grad[t(g["g_table_idx"])], g["g_table_val"]) < 5e-4
     assert rel_err(aux["leaves"]["p2n_raw"].grad, g["g_p2n_raw"]) < 1e-4
     assert rel_err(aux["leaves"]["tau_raw"].grad, g["g_tau_raw"]) < 1e-3
+
+
+@pytest.mark.parametrize("ct", ["aabb", "sphere"])
+def test_vanilla_field_forward_backward(ct):
+    """`arch: mlp` oracle (frequency encoding + 8x256 MLP with skip) vs the reference's
+    VanillaNeRFRadianceField run on seed-generated parameters."""
+    from oracle import vanilla
+    g = load_golden(f"field_mlp_{ct}")
+    p = {k: v.requires_grad_() for k, v in vanilla.init_params(int(g["param_seed"]), 1, float(g["param_gain"])).items()}
+    aabb = t(g["aabb"])
+    rgb, sigma = vanilla.forward(p, t(g["x"]), t(g["d"]), aabb, int(g["contraction_type"]))
+    assert rel_err(rgb, g["rgb"]) < 2e-6 and rel_err(sigma, g["sigma"]) < 2e-6
+    dens = vanilla.forward(p, t(g["x"]), None, aabb, int(g["contraction_type"]), density_only=True)
+    assert rel_err(dens, g["density"]) < 2e-6
+    ((rgb * t(g["g_rgb"])).sum() + (sigma * t(g["g_sigma"])).sum()).backward()
+    for k, v in p.items():
+        gr = v.grad.reshape(-1)
+        assert rel_err(gr[t(g["gi." + k])], g["gv." + k]) < 1e-5, k
+        assert abs(float(gr.double().abs().sum()) - float(g["gs." + k])) < 1e-5 * float(g["gs." + k]) + 1e-12, k
