@@ -1,0 +1,194 @@
+#!/usr/bin/env python
+"""Minimal trainer shell over the HIP hot path, driven by the reference's YAML schema.
+
+    python scripts/train.py --config /path/to/configs/train/synthetic.yaml [--dataset-dir DIR] [--out DIR]
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 scripts/train.py --config ...
+
+Replaces ``scripts/run.py`` + the PyTorch-Lightning fit loop for training (robust_e_nerf/models/robust_e_nerf.py:
+301-517,782-950): epochs x ``limit_train_batches`` steps, MultiStepLR stepped per epoch, occupancy-grid update
+every step, dynamic event batch size from the ray-sample budget, one process per GPU with an RCCL all-reduce of
+the flat gradient.  Checkpoints carry the reference's state-dict key names so weights move both ways.
+``--synthetic N`` trains on the benchmark's synthetic orbit instead of a dataset directory.
+"""
+import argparse
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import yaml
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+NGP_KEYS = {"hash": "mlp_base.0.params", "base.w0": "mlp_base.1.hidden_layers.0.weight",
+            "base.b0": "mlp_base.1.hidden_layers.0.bias", "base.wo": "mlp_base.1.output_layer.weight",
+            "base.bo": "mlp_base.1.output_layer.bias", "head.w0": "mlp_head.hidden_layers.0.weight",
+            "head.b0": "mlp_head.hidden_layers.0.bias", "head.w1": "mlp_head.hidden_layers.1.weight",
+            "head.b1": "mlp_head.hidden_layers.1.bias", "head.wo": "mlp_head.output_layer.weight",
+            "head.bo": "mlp_head.output_layer.bias"}
+PREFIX = "nerf.radiance_field."                       # RobustENeRF.nerf (models/nerf.py) . radiance_field
+
+
+def softplus_inv(y):
+    return float(y + math.log(-math.expm1(-y)))
+
+
+def field_state_dict(fld, arch):
+    if arch == "mlp":
+        return {PREFIX + k: v.detach().cpu().clone() for k, v in fld.state_dict().items()}
+    sd = {PREFIX + NGP_KEYS["hash"]: fld.table.detach().cpu().clone()}
+    for k, v in fld.mlp_views().items():
+        sd[PREFIX + NGP_KEYS[k]] = v.detach().cpu().clone()
+    return sd
+
+
+def load_field_state_dict(fld, arch, sd):
+    sd = {k[len(PREFIX):]: v for k, v in sd.items() if k.startswith(PREFIX)}
+    if arch == "mlp":
+        fld.load(sd)
+    else:
+        fld.load({ours: sd[theirs] for ours, theirs in NGP_KEYS.items()})
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", required=True)
+    ap.add_argument("--dataset-dir")
+    ap.add_argument("--synthetic", type=int, default=0, help="train on N synthetic events (no dataset directory)")
+    ap.add_argument("--out", default="runs/train")
+    ap.add_argument("--max-epochs", type=int)
+    ap.add_argument("--limit-train-batches", type=int)
+    ap.add_argument("--resume")
+    args = ap.parse_args()
+    cfg = yaml.safe_load(open(args.config))
+    rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("LOCAL_RANK", 0), ("WORLD_SIZE", 1)))
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl")
+    dev = f"cuda:{local_rank}"
+    torch.cuda.set_device(local_rank)
+    seed = cfg.get("seed") or 0
+    torch.manual_seed(seed)
+
+    from robust_e_nerf_amd import data, engine, ops
+
+    # ---- data: event table in HBM, poses, calibration --------------------------------------------------
+    dcfg, mcfg, ncfg = cfg["data"], cfg["model"], cfg["model"]["nerf"]
+    if args.synthetic:
+        import bench
+        tab_ts, tab_pos, tab_quat, Kinv = (torch.from_numpy(a) for a in bench.synthetic_scene())
+        ev = bench.synthetic_events(args.synthetic, int(tab_ts[-1]), seed=1)
+        events = {k: torch.from_numpy(ev[k]) for k in ("position", "start_ts", "end_ts", "num_pos", "num_neg")}
+        pos_ct, neg_ct, tau0, tau_max = 0.25, 0.25, 0.0, torch.tensor(1e5, dtype=torch.float64)
+    else:
+        root = args.dataset_dir or dcfg["dataset_directory"]
+        events = data.load_events(root, dcfg.get("train_dataset_perm_seed"))
+        tab_ts, tab_pos, tab_quat = data.load_camera_poses(root)
+        calib = data.load_calibration(root)
+        Kinv = calib["Kinv"]
+        pos_ct, neg_ct = float(calib["pos_contrast_threshold"]), float(calib["neg_contrast_threshold"])
+        tau_max = data.load_max_refractory_period(root).to(torch.float64)
+        tau0 = float(calib["refractory_period"])
+        if not (0 <= tau0 < float(tau_max)):               # event_generation_params.py:123-139
+            tau0 = 0.5 * float(tau_max)
+    budget = int(dcfg["train_eff_ray_sample_batch_size"])
+    batch_size = max(1, int(dcfg["train_init_eff_batch_size"]) // world)
+    batcher = data.EventBatcher(events, batch_size, dev, seed=seed, rank=rank,
+                                dataset_ratio=dcfg.get("train_dataset_ratio", 1.0))
+
+    # ---- model ----------------------------------------------------------------------------------------------
+    aabb = ncfg["aabb"]
+    if aabb == "auto":                                       # robust_e_nerf.py:206-212
+        aabb = torch.cat([tab_pos.min(0).values, tab_pos.max(0).values]).tolist()
+    ct = {"aabb": ops.AABB, "tanh": ops.UN_BOUNDED_TANH, "sphere": ops.UN_BOUNDED_SPHERE}[ncfg["contraction_type"]]
+    step_size = ncfg["render_step_size"]
+    if step_size == "auto":                                  # robust_e_nerf.py:220-226
+        ext = max(aabb[3 + k] - aabb[k] for k in range(3))
+        step_size = ext * math.sqrt(3) / 1024
+    og = ncfg["occ_grid"]
+    rcfg = engine.RenderCfg(aabb=tuple(float(v) for v in aabb), contraction_type=ct, occ_res=(int(og["resolution"]),) * 3,
+                            near_plane=ncfg.get("near_plane"), far_plane=ncfg.get("far_plane"),
+                            render_step_size=float(step_size), cone_angle=float(ncfg["cone_angle"]),
+                            early_stop_eps=float(ncfg["early_stop_eps"]), alpha_thre=float(ncfg["alpha_thre"]),
+                            min_modeled_intensity=float(mcfg["min_modeled_intensity"]), occ_thre=float(og["occ_thre"]),
+                            ema_decay=float(og["ema_decay"]), warmup_steps=int(og["warmup_steps"]), occ_n=int(og["n"]))
+    arch = ncfg.get("arch", "ngp")
+    gen = torch.Generator().manual_seed(seed)
+
+    def lin(o, i):                                           # nn.Linear default init (hidden_init=None, ngp.py:179-185)
+        b = 1 / math.sqrt(i)
+        return (torch.rand(o, i, generator=gen) * 2 - 1) * b, (torch.rand(o, generator=gen) * 2 - 1) * b
+    if arch == "mlp":
+        from robust_e_nerf_amd import vanilla
+        fld = vanilla.VanillaField(dev, 1)
+        fld.load({k: v for name, o, i in vanilla.layer_shapes(1) for k, v in zip((name + ".weight", name + ".bias"), lin(o, i))})
+        renderer = vanilla.VanillaRenderer(fld, rcfg)
+    else:
+        fld = engine.NGPField(dev, 1, ncfg.get("ngp", {}).get("pos_encoding"))
+        p = {"hash": (torch.rand(fld.n_table, generator=gen) * 2 - 1) * 1e-4}          # tcnn grid init U(+-1e-4)
+        for k, (o, i) in {"base.w0": (64, 32), "base.wo": (16, 64), "head.w0": (64, 31), "head.w1": (64, 64), "head.wo": (1, 64)}.items():
+            p[k], p[k.replace(".w", ".b")] = lin(o, i)
+        fld.load(p)
+        renderer = engine.Renderer(fld, rcfg)
+    lcfg, ocfg = cfg["loss"], cfg["optimizer"]
+    tcfg = engine.TrainCfg(
+        err_diff=lcfg["error_fn"]["log_intensity_diff"], w_diff=float(lcfg["weight"]["log_intensity_diff"]),
+        pw_diff=lcfg["param_weight"].get("log_intensity_diff"), err_grad=lcfg["error_fn"]["log_intensity_grad"],
+        w_grad=float(lcfg["weight"]["log_intensity_grad"]), pw_grad=lcfg["param_weight"].get("log_intensity_grad"),
+        lr=float(ocfg["lr"]["default"]), weight_decay=float(lcfg["weight"]["nerf_mlp_weight_decay"]),
+        train_contrast_threshold=not mcfg["contrast_threshold"]["freeze"],
+        lr_contrast_threshold=float(ocfg["lr"]["contrast_threshold"]),
+        train_refractory_period=not mcfg["refractory_period"]["freeze"],
+        relative_lr_refractory_period=float(ocfg["relative_lr"]["refractory_period"]))
+    tau_raw = float(tau_max) * torch.logit(torch.tensor(max(tau0, 1e-9) / float(tau_max), dtype=torch.float64)) if tau0 > 0 \
+        else torch.tensor(-1e30, dtype=torch.float64)
+    tr = engine.Trainer(renderer, tcfg, Kinv=Kinv, tab_ts=tab_ts, tab_pos=tab_pos, tab_quat=tab_quat,
+                        p2n_raw=torch.tensor(softplus_inv(pos_ct / neg_ct)), neg_ct=torch.tensor(neg_ct),
+                        tau_raw=tau_raw, tau_max=tau_max, bkgd_raw=torch.tensor([softplus_inv(1.0)]),
+                        world_size=world, process_group=None)
+    if args.resume:
+        load_field_state_dict(fld, arch, torch.load(args.resume, map_location="cpu")["state_dict"])
+
+    # ---- fit loop ---------------------------------------------------------------------------------------------
+    tcf, sched = cfg["trainer"], cfg["lr_scheduler"]["multi_step_lr"]
+    max_epochs = args.max_epochs or int(tcf["max_epochs"])
+    per_epoch = args.limit_train_batches or int(tcf["limit_train_batches"])
+    log_every = int(tcf.get("log_every_n_steps", 100))
+    jgen = torch.Generator(device=dev).manual_seed(seed + 17 + rank)
+    os.makedirs(args.out, exist_ok=True)
+    step, t0, rays = 0, time.perf_counter(), 0
+    for epoch in range(max_epochs):
+        tr.set_epoch(epoch, tuple(sched["milestones"]), float(sched["gamma"]))
+        for _ in range(per_epoch):
+            batch = batcher.next()
+            B = batch["position"].shape[0]
+            j = torch.rand(3, B, device=dev, generator=jgen)
+            loss, aux = tr.step(batch, j[0], j[1], global_step=step, jitter_grad=j[2])
+            rays += (3 if tcfg.w_grad > 0 else 2) * B
+            batcher.set_batch_size(tr.update_train_batch_size(aux, budget))      # robust_e_nerf.py:907-950
+            step += 1
+            if rank == 0 and step % log_every == 0:
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                print(f"epoch {epoch} step {step}  loss {float(loss):.5f}  batch {B}  samples/ray {aux['n'] / max(aux['rays'], 1):.1f}"
+                      f"  {rays * world / dt / 1e6:.2f} M rays/s", flush=True)
+                t0, rays = time.perf_counter(), 0
+        if rank == 0:
+            sd = field_state_dict(fld, arch)
+            sd["contrast_threshold.parametrizations.p2n_contrast_threshold_ratio.original"] = tr.ct[:1].detach().cpu().clone()
+            sd["refractory_period.parametrizations._refractory_period.original"] = tr.tau_raw.detach().clone()
+            sd["nerf.occ_grid.occs"] = renderer.occs.detach().cpu().clone()
+            sd["nerf.occ_grid._binary"] = renderer.binary.detach().cpu().bool().view(*rcfg.occ_res)
+            torch.save({"state_dict": sd, "epoch": epoch, "global_step": step}, os.path.join(args.out, "last.ckpt"))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

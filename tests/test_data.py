@@ -1,0 +1,100 @@
+"""CPU: event dataset schema + batcher (robust_e_nerf_amd/data.py) against a direct restatement of the
+reference's per-event loops (data/datasets.py:133-284) on small random streams."""
+import collections
+import os
+
+import numpy as np
+import torch
+
+from robust_e_nerf_amd import data
+
+
+def _stream(seed, n=4000, w=7, h=5, dup=0.15):
+    g = np.random.default_rng(seed)
+    pos = np.stack([g.integers(0, w, n), g.integers(0, h, n)], -1).astype(np.uint16)
+    ts = np.sort(g.integers(0, 2000, n)).astype(np.int64)            # plenty of equal timestamps
+    pol = g.random(n) < 0.5
+    return pos, ts, pol, w
+
+
+def _loop_queue(pos, ts, pol, w, h):
+    win_t = [[collections.deque(maxlen=2) for _ in range(w)] for _ in range(h)]
+    win_p = [[collections.deque(maxlen=2) for _ in range(w)] for _ in range(h)]
+    out = []
+    for i in range(len(ts)):
+        x, y = int(pos[i, 0]), int(pos[i, 1])
+        win_t[y][x].append(int(ts[i])); win_p[y][x].append(int(pol[i]))
+        if len(win_t[y][x]) < 2 or win_t[y][x][0] == win_t[y][x][-1]:
+            continue
+        npos = sum(win_p[y][x]) - win_p[y][x][0]
+        out.append((x, y, win_t[y][x][0], int(ts[i]), npos, 1 - npos))
+    return np.array(out, np.int64)
+
+
+def _loop_max_refractory(pos, ts, w, h):
+    win = [[collections.deque(maxlen=2) for _ in range(w)] for _ in range(h)]
+    best = float("inf")
+    for i in range(len(ts)):
+        d = win[int(pos[i, 1])][int(pos[i, 0])]
+        if len(d) > 0 and int(ts[i]) == d[-1]:
+            continue
+        d.append(int(ts[i]))
+        if len(d) == 2:
+            best = min(best, d[1] - d[0])
+    return best
+
+
+def test_queue_and_refractory_match_event_loop():
+    for seed in range(4):
+        pos, ts, pol, w = _stream(seed)
+        ev = data.queue_raw_events(pos, ts, pol, w)
+        ref = _loop_queue(pos, ts, pol, w, 5)
+        got = torch.stack([ev["position"][:, 0], ev["position"][:, 1], ev["start_ts"], ev["end_ts"], ev["num_pos"],
+                           ev["num_neg"]], -1).numpy()
+        assert got.shape == ref.shape and (got == ref).all()
+        assert float(data.max_refractory_period(pos, ts, w)) == _loop_max_refractory(pos, ts, w, 5)
+
+
+def test_colorize_and_cache_roundtrip(tmp_path):
+    pos, ts, pol, w = _stream(9)
+    np.savez(os.path.join(tmp_path, data.RAW_EVENTS), position=pos, timestamp=ts, polarity=pol)
+    np.savez(os.path.join(tmp_path, data.CAMERA_CALIBRATION), intrinsics=np.eye(3, dtype=np.float32),
+             distortion_params=np.zeros(0, np.float32), distortion_model="plumb_bob", img_height=np.uint16(5),
+             img_width=np.uint16(w), bayer_pattern="RGGB")
+    ev = data.load_events(str(tmp_path), permutation_seed=3)
+    assert os.path.isfile(os.path.join(tmp_path, data.TF_EVENTS))
+    ev2 = data.load_events(str(tmp_path), permutation_seed=3)           # from the cache
+    assert all(torch.equal(ev[k], ev2[k]) for k in ev)
+    assert ev["position"].dtype == torch.float32 and ev["channel_idx"].dtype == torch.uint8
+    x, y = ev["position"][:, 0].long(), ev["position"][:, 1].long()
+    expect = torch.tensor([0, 1, 1, 2], dtype=torch.uint8)[(x % 2) + 2 * (y % 2)]      # R G / G B
+    assert torch.equal(ev["channel_idx"], expect)
+
+
+def test_undistort_inverts_plumb_bob():
+    K = np.array([[300.0, 0, 160], [0, 310.0, 120], [0, 0, 1]])
+    dist = np.array([-0.25, 0.08, 1e-3, -2e-3])
+    g = np.random.default_rng(0)
+    und = np.stack([g.uniform(20, 300, 200), g.uniform(20, 220, 200)], -1)
+    x, y = (und[:, 0] - 160) / 300, (und[:, 1] - 120) / 310
+    r2 = x * x + y * y
+    rad = 1 + dist[0] * r2 + dist[1] * r2 * r2
+    xd = x * rad + 2 * dist[2] * x * y + dist[3] * (r2 + 2 * x * x)
+    yd = y * rad + dist[2] * (r2 + 2 * y * y) + 2 * dist[3] * x * y
+    dis = np.stack([xd * 300 + 160, yd * 310 + 120], -1)
+    assert np.abs(data.undistort_points(dis, K, dist, "plumb_bob") - und).max() < 1e-6
+
+
+def test_batcher_shapes_ranges_and_rank_seeding():
+    pos, ts, pol, w = _stream(1)
+    ev = data.undistort_events(data.queue_raw_events(pos, ts, pol, w), dict(distortion_params=np.zeros(0)))
+    b0 = data.EventBatcher(ev, 256, "cpu", seed=5, rank=0).next()
+    b0b = data.EventBatcher(ev, 256, "cpu", seed=5, rank=0).next()
+    b1 = data.EventBatcher(ev, 256, "cpu", seed=5, rank=1).next()
+    assert all(torch.equal(b0[k], b0b[k]) for k in b0) and not torch.equal(b0["end_ts"], b1["end_ts"])
+    assert b0["position"].shape == (256, 2) and b0["position"].dtype == torch.float32
+    for k in ("u_ts_diff", "u_diff_start", "u_grad"):
+        assert b0[k].dtype == torch.float64 and float(b0[k].min()) >= 0 and float(b0[k].max()) <= 1
+    assert float(b0["u_ts_diff"].min()) == 1.0 and (b0["start_ts"] < b0["end_ts"]).all()
+    big = data.trunc_normal(0.0, 1.0, 200000, 0.5, 0.25, torch.float64, torch.Generator().manual_seed(0), "cpu")
+    assert abs(float(big.mean()) - 0.5) < 5e-3 and 0.19 < float(big.std()) < 0.23      # truncated at 2 sigma

@@ -710,3 +710,25 @@ def test_refractory_period_gradient_vs_oracle(amd, spec, full_table_cache):
     assert rel_err(got, tau_raw.grad) < 5e-3, (float(got), float(tau_raw.grad))
     tr.optimizer_step()
     assert float(tr.tau_grad) == 0.0
+
+
+def test_train_cli_smoke_and_checkpoint_keys(tmp_path):
+    """scripts/train.py on the reference's YAML schema (synthetic events): runs l_diff + l_grad with a
+    trainable C_p for a few steps, writes a checkpoint with the reference's state-dict key names, resumes."""
+    import os, subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(repo, "scripts", "train.py"), "--config", os.path.join(repo, "configs", "synthetic_smoke.yaml"),
+           "--synthetic", "100000", "--out", str(tmp_path)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "M rays/s" in out.stdout
+    ck = torch.load(os.path.join(tmp_path, "last.ckpt"), map_location="cpu")
+    sd = ck["state_dict"]
+    for k in ("nerf.radiance_field.mlp_base.0.params", "nerf.radiance_field.mlp_base.1.hidden_layers.0.weight",
+              "nerf.radiance_field.mlp_head.output_layer.bias", "nerf.occ_grid.occs", "nerf.occ_grid._binary",
+              "contrast_threshold.parametrizations.p2n_contrast_threshold_ratio.original"):
+        assert k in sd, k
+    assert sd["nerf.radiance_field.mlp_base.0.params"].numel() == 12_599_920 and ck["global_step"] == 48
+    out2 = subprocess.run(cmd + ["--resume", os.path.join(tmp_path, "last.ckpt"), "--max-epochs", "1", "--limit-train-batches", "8"],
+                          capture_output=True, text=True, timeout=600)
+    assert out2.returncode == 0, out2.stderr[-2000:]
