@@ -135,6 +135,8 @@ def main():
                          "(10.4 KB of saved activations per sample: use --events 8192 or less)")
     ap.add_argument("--loss-grad", type=float, default=0.0,
                     help="weight of the log-intensity-gradient loss (adds a third render with d/dt; 1e-3 in the real-data configs)")
+    ap.add_argument("--mlp-bf16", action="store_true",
+                    help="BASELINE configs[2] numerics: bf16-rounded linear inputs/weights, fp32 accumulate + composite")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
@@ -183,7 +185,7 @@ def main():
     p["hash"] = hashgrid.init_table(hashgrid.make_spec(), 0, 0.1, "mix32")
 
     aabb = (-1.5, -1.5, -1.5, 1.5, 1.5, 1.5)
-    cfg = engine.RenderCfg(aabb=aabb, sampler=args.sampler, n_uniform=args.samples)
+    cfg = engine.RenderCfg(aabb=aabb, sampler=args.sampler, n_uniform=args.samples, mlp_bf16=args.mlp_bf16)
     if args.arch == "mlp":
         from robust_e_nerf_amd import vanilla
         fld = vanilla.VanillaField(dev, 1)
@@ -272,7 +274,8 @@ def main():
         out = {
             "metric": "train_rays_per_sec", "value": rays / dt, "unit": "rays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16-operand/f32-accumulate MLP, f32 elsewhere" if args.mlp_bf16 else "f32", "data": "synthetic",
             "mlp_samples_per_sec": n_samples / dt, "mean_samples_per_ray": n_samples / rays,
             "loss": float(loss),
             "config": {"workload": "BASELINE configs[1]: synthetic ficus-like event stream, "

@@ -313,6 +313,21 @@ int ren_grad_loss_bwd(const float *intensity, const float *intensity_dot, const 
                       const uint8_t *valid, int64_t B, int32_t err_fn, float scale, const float *loss_sum,
                       float *g_intensity, float *g_intensity_dot, void *stream);
 
+/* ---- bf16 MLP mode (BASELINE configs[2]: "bf16 MLP with fp32 composite") ------------------------------ *
+ * Same arguments as ren_mlp_fwd / ren_mlp_bwd.  Every linear layer sees bf16-rounded (nearest-even) inputs;
+ * `mlp_params_bf16` is the caller's bf16-rounded copy of the parameter block (still f32 storage); products
+ * accumulate in fp32, bias and activations stay fp32.  The backward is the exact derivative of that forward
+ * (straight-through rounding) and accumulates into the fp32 master gradient. */
+int ren_mlp_fwd_bf16(const float *mlp_params_bf16, int32_t C, const float *feat, const ren_scene_desc *scene,
+                     const float *x_world, const float *dirs, const float *rays_o, const float *rays_d,
+                     const int32_t *ray_indices, const float *t_starts, const float *t_ends, int64_t n,
+                     int32_t density_only, float *rgb, float *sigma, float *base_out, void *stream);
+int ren_mlp_bwd_bf16(const float *mlp_params_bf16, int32_t C, const float *feat, const float *base_out,
+                     const ren_scene_desc *scene, const float *x_world, const float *dirs, const float *rays_o,
+                     const float *rays_d, const int32_t *ray_indices, const float *t_starts,
+                     const float *t_ends, int64_t n, const float *rgb, const float *d_rgb, const float *d_sigma,
+                     float *d_base, float *dfeat, float *grad_mlp_params, float *workspace, void *stream);
+
 /* ---- second-order forward tangent (value, d/dt, d2/dt2): d(l_grad)/d(tau) --------------------------- *
  * The gradient-loss prediction d(log I)/dt is evaluated at ts_g(tau); its derivative w.r.t. the refractory
  * period needs d2 I/dt2 per ray (models/robust_e_nerf.py:340-357,383-409 differentiated through

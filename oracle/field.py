@@ -44,6 +44,41 @@ def softplus(x, beta: float, threshold: float = 20.0):     # nerf.py:17-29 (torc
     return F_.softplus(x, beta, threshold)
 
 
+# ----------------------------------------------------------------------------- bf16 MLP mode
+class _BRound(torch.autograd.Function):
+    """Round to bfloat16 (nearest even) and back, straight-through gradient."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+BF16_LINEAR = False          # BASELINE configs[2] "bf16 MLP with fp32 composite": see bf16_linear()
+
+
+class bf16_linear:
+    """Context manager: every nn.Linear of the field sees bf16-rounded inputs and weights, fp32 accumulation,
+    fp32 bias / activations; the backward pass is the exact derivative (straight-through rounding)."""
+
+    def __enter__(self):
+        global BF16_LINEAR
+        self._old, BF16_LINEAR = BF16_LINEAR, True
+
+    def __exit__(self, *a):
+        global BF16_LINEAR
+        BF16_LINEAR = self._old
+
+
+def linear(x, w, b):
+    if BF16_LINEAR:
+        x, w = _BRound.apply(x), _BRound.apply(w)
+    return x @ w.T + b
+
+
 # ----------------------------------------------------------------------------- contraction
 def contract(x: torch.Tensor, aabb: torch.Tensor, contraction_type: int) -> torch.Tensor:
     """World -> unit cube.  ngp.py:230-237, 68-106."""
@@ -138,8 +173,8 @@ def query_density(
     xu = contract(x_world, aabb, contraction_type)
     sel = selector(xu)
     enc = hashgrid.encode(xu, p["hash"], spec)
-    h = softplus(enc @ p["base.w0"].T + p["base.b0"], 100.0)
-    raw = h @ p["base.wo"].T + p["base.bo"]
+    h = softplus(linear(enc, p["base.w0"], p["base.b0"]), 100.0)
+    raw = linear(h, p["base.wo"], p["base.bo"])
     sigma = shifted_trunc_exp(raw[:, :1]) * sel[:, None].to(raw.dtype)
     if return_feat:
         return sigma, raw[:, 1:]
@@ -149,9 +184,9 @@ def query_density(
 def query_rgb(dirs: torch.Tensor, geo: torch.Tensor, p: Dict[str, torch.Tensor]) -> torch.Tensor:
     """ngp.py:256-267: head([SH16(dir) | geo15]) with softplus(100) hidden, softplus(1) out."""
     h = torch.cat([sh_encode(dirs, 4), geo], dim=-1)
-    h = softplus(h @ p["head.w0"].T + p["head.b0"], 100.0)
-    h = softplus(h @ p["head.w1"].T + p["head.b1"], 100.0)
-    return softplus(h @ p["head.wo"].T + p["head.bo"], 1.0)
+    h = softplus(linear(h, p["head.w0"], p["head.b0"]), 100.0)
+    h = softplus(linear(h, p["head.w1"], p["head.b1"]), 100.0)
+    return softplus(linear(h, p["head.wo"], p["head.bo"]), 1.0)
 
 
 def field_forward(x_world, dirs, p, spec, aabb, contraction_type: int = AABB):

@@ -51,6 +51,8 @@ SIGNATURES = {
     "ren_mlp_fwd": (c_int, [P, c_int32, P, POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, c_int32, P, P, P, P]),
     "ren_mlp_bwd_workspace_floats": (c_int64, [c_int32]),
     "ren_mlp_bwd": (c_int, [P, c_int32, P, P, POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, P, P, P, P, P, P, P, P]),
+    "ren_mlp_fwd_bf16": (c_int, [P, c_int32, P, POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, c_int32, P, P, P, P]),
+    "ren_mlp_bwd_bf16": (c_int, [P, c_int32, P, P, POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, P, P, P, P, P, P, P, P]),
     "ren_composite_fwd": (c_int, [P, P, c_int64, P, P, P, P, c_int32, P, P, P, P, P, P, P]),
     "ren_composite_bwd": (c_int, [P, P, c_int64, P, P, P, P, c_int32, P, P, P, P, P, P, P, P, P, P, P, P]),
     "ren_event_loss_fwd": (c_int, [P, P, P, P, c_int64, c_int32, P, P]),

@@ -34,7 +34,7 @@ struct FwdArgs {
     float *rgb, *sigma, *base_out;
 };
 
-template <int C, bool DENSITY_ONLY>
+template <int C, bool DENSITY_ONLY, bool RB>
 __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(FwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds_base[];
     fill_base(lds_base, a.params, L_W1, L_W2, L_B1, L_B2);
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(FwdArgs a) {
         {
             const float *f = a.feat + blk * (16 * 64) + lane;
 #pragma unroll
-            for (int s = 0; s < 16; ++s) x[s] = f[s * 64];
+            for (int s = 0; s < 16; ++s) x[s] = lin_in<RB>(f[s * 64]);
         }
         // ---- base layer 0: 32 -> 64, softplus(beta=100)
         f32x16 h[2];
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(FwdArgs a) {
 #pragma unroll
             for (int s = 0; s < 16; ++s) h[r] = MFMA(W1[(32 * r + sl) * 33 + 2 * s + hi], x[s], h[r]);
 #pragma unroll
-            for (int g = 0; g < 16; ++g) h[r][g] = softplus100(h[r][g]);
+            for (int g = 0; g < 16; ++g) h[r][g] = lin_in<RB>(softplus100(h[r][g]));
         }
         // ---- base output: 64 -> 16 (rows 16..31 of the tile are zero padding)
         f32x16 o;
@@ -110,11 +110,11 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(FwdArgs a) {
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
                 const int col = s < 8 ? rowc(s) + 4 * hi : 16 + 2 * (s - 8) + hi;
-                const float bv = s < 8 ? o[s] : shs[s < 8 ? 0 : s - 8];
+                const float bv = lin_in<RB>(s < 8 ? o[s] : shs[s < 8 ? 0 : s - 8]);
                 p[r] = MFMA(WH1[(32 * r + sl) * 33 + col], bv, p[r]);
             }
 #pragma unroll
-            for (int g = 0; g < 16; ++g) p[r][g] = softplus100(p[r][g]);
+            for (int g = 0; g < 16; ++g) p[r][g] = lin_in<RB>(softplus100(p[r][g]));
         }
         // ---- head layer 1: 64 -> 64
         f32x16 q[2];
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(FwdArgs a) {
         for (int r = 0; r < 2; ++r)
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
-                const float qa = softplus100(q[r][g]);
+                const float qa = lin_in<RB>(softplus100(q[r][g]));
 #pragma unroll
                 for (int c = 0; c < C; ++c) acc[c] += qa * lds[L_WH3 + c * 64 + 32 * r + rowc(g) + 4 * hi];
             }
@@ -167,7 +167,7 @@ struct BwdHArgs {
     float *d_base, *slab;                           // d_base: fragment layout [blk][8][64]
 };
 
-template <int C>
+template <int C, bool RB>
 __global__ __launch_bounds__(256, REN_HEAD_OCC) void mlp_bwd_head_kernel(BwdHArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds_base[];
     fill_head(lds_base, a.params, C, LH_WH1, LH_WH2, LH_WH3, LH_BH1, LH_BH2, LH_BH3);
@@ -221,14 +221,21 @@ __global__ __launch_bounds__(256, REN_HEAD_OCC) void mlp_bwd_head_kernel(BwdHArg
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const int col = s < 8 ? rowc(s) + 4 * hi : 16 + 2 * (s - 8) + hi;
-            const float b = s < 8 ? o[s] : shs[s - 8];
+            const float b = lin_in<RB>(s < 8 ? o[s] : shs[s - 8]);
             p[0] = MFMA(WH1[sl * 33 + col], b, p[0]);
             p[1] = MFMA(WH1[(32 + sl) * 33 + col], b, p[1]);
         }
+        // bf16 mode: the activation VALUE that feeds the next linear layer (and its weight gradient) is
+        // rounded, the softplus derivative is taken at the unrounded output: s1/s2 are formed here
+        f32x16 s1[2], s2[2];
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
-            for (int g = 0; g < 16; ++g) p[r][g] = softplus100(p[r][g]);
+            for (int g = 0; g < 16; ++g) {
+                const float y = softplus100(p[r][g]);
+                if (RB) s1[r][g] = dsoftplus_from_out(y, 100.f);
+                p[r][g] = lin_in<RB>(y);
+            }
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
@@ -240,7 +247,11 @@ __global__ __launch_bounds__(256, REN_HEAD_OCC) void mlp_bwd_head_kernel(BwdHArg
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
-            for (int g = 0; g < 16; ++g) q[r][g] = softplus100(q[r][g]);
+            for (int g = 0; g < 16; ++g) {
+                const float y = softplus100(q[r][g]);
+                if (RB) s2[r][g] = dsoftplus_from_out(y, 100.f);
+                q[r][g] = lin_in<RB>(y);
+            }
         // ---- output layer backward: d z3 = d rgb * softplus1'(z3) = d rgb * (1 - exp(-rgb))
         float dz3[C];
 #pragma unroll
@@ -260,7 +271,7 @@ __global__ __launch_bounds__(256, REN_HEAD_OCC) void mlp_bwd_head_kernel(BwdHArg
                 float dq = 0.f;
 #pragma unroll
                 for (int c = 0; c < C; ++c) dq += dz3[c] * lds[LH_WH3 + c * 64 + 32 * r + rowc(g) + 4 * hi];
-                q[r][g] = dq * dsoftplus_from_out(q[r][g], 100.f);
+                q[r][g] = dq * (RB ? s2[r][g] : dsoftplus_from_out(q[r][g], 100.f));
             }
         // ---- dW(head.w1) += dZ2 . P^T  (stage both as [neuron][sample]; P in two 32-row halves so
         //      the per-wave staging area stays at 96 rows and two workgroups fit one CU)
@@ -296,7 +307,7 @@ __global__ __launch_bounds__(256, REN_HEAD_OCC) void mlp_bwd_head_kernel(BwdHArg
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
-            for (int g = 0; g < 16; ++g) dp[r][g] *= dsoftplus_from_out(p[r][g], 100.f);
+            for (int g = 0; g < 16; ++g) dp[r][g] *= RB ? s1[r][g] : dsoftplus_from_out(p[r][g], 100.f);
         // ---- dW(head.w0) += dZ1 . V^T,  V = [base_out(16) | SH(16)]
 #pragma unroll
         for (int r = 0; r < 2; ++r)
@@ -304,8 +315,8 @@ __global__ __launch_bounds__(256, REN_HEAD_OCC) void mlp_bwd_head_kernel(BwdHArg
             for (int g = 0; g < 16; ++g) T_dz[(32 * r + rowc(g) + 4 * hi) * 33 + sl] = dp[r][g];
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
-            T_act[(rowc(g) + 4 * hi) * 33 + sl] = o[g];
-            T_act[(16 + 2 * g + hi) * 33 + sl] = shs[g];
+            T_act[(rowc(g) + 4 * hi) * 33 + sl] = lin_in<RB>(o[g]);
+            T_act[(16 + 2 * g + hi) * 33 + sl] = lin_in<RB>(shs[g]);
         }
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
@@ -373,6 +384,7 @@ struct BwdBArgs {
     float *dfeat, *slab;
 };
 
+template <bool RB>
 __global__ __launch_bounds__(256, 1) void mlp_bwd_base_kernel(BwdBArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds_base[];
     fill_base(lds_base, a.params, LB_W1, LB_W2, LB_B1, LB_B2);
@@ -398,7 +410,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_base_kernel(BwdBArgs a) {
         {
             const float *f = a.feat + blk * (16 * 64) + lane;
 #pragma unroll
-            for (int s = 0; s < 16; ++s) x[s] = f[s * 64];
+            for (int s = 0; s < 16; ++s) x[s] = lin_in<RB>(f[s * 64]);
             const float *db = a.d_base + blk * (8 * 64) + lane;
 #pragma unroll
             for (int g = 0; g < 8; ++g) dob[g] = db[g * 64];
@@ -415,10 +427,15 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_base_kernel(BwdBArgs a) {
             h[0] = MFMA(W1[sl * 33 + 2 * s + hi], x[s], h[0]);
             h[1] = MFMA(W1[(32 + sl) * 33 + 2 * s + hi], x[s], h[1]);
         }
+        f32x16 s0[2];
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
-            for (int g = 0; g < 16; ++g) h[r][g] = softplus100(h[r][g]);
+            for (int g = 0; g < 16; ++g) {
+                const float y = softplus100(h[r][g]);
+                if (RB) s0[r][g] = dsoftplus_from_out(y, 100.f);
+                h[r][g] = lin_in<RB>(y);
+            }
         // ---- dW(base.wo) += dO . H^T
 #pragma unroll
         for (int r = 0; r < 2; ++r)
@@ -446,7 +463,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_base_kernel(BwdBArgs a) {
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
-            for (int g = 0; g < 16; ++g) dh[r][g] *= dsoftplus_from_out(h[r][g], 100.f);
+            for (int g = 0; g < 16; ++g) dh[r][g] *= RB ? s0[r][g] : dsoftplus_from_out(h[r][g], 100.f);
         // ---- dW(base.w0) += dZ0 . X^T
 #pragma unroll
         for (int r = 0; r < 2; ++r)
@@ -515,11 +532,11 @@ extern "C" int64_t ren_mlp_bwd_workspace_floats(int32_t C) {
     return (int64_t)GRID_H * 4 * (p_total(C) - P_BASE_N) + (int64_t)GRID_B * 4 * P_BASE_N;
 }
 
-extern "C" int ren_mlp_fwd(const float *mlp_params, int32_t C, const float *feat,
-                           const ren_scene_desc *scene, const float *x_world, const float *dirs,
-                           const float *rays_o, const float *rays_d, const int32_t *ray_indices,
-                           const float *t_starts, const float *t_ends, int64_t n, int32_t density_only,
-                           float *rgb, float *sigma, float *base_out, void *stream) {
+static int mlp_fwd_impl(bool rb, const float *mlp_params, int32_t C, const float *feat,
+                        const ren_scene_desc *scene, const float *x_world, const float *dirs,
+                        const float *rays_o, const float *rays_d, const int32_t *ray_indices,
+                        const float *t_starts, const float *t_ends, int64_t n, int32_t density_only,
+                        float *rgb, float *sigma, float *base_out, void *stream) {
     if (!mlp_params || !feat || !scene || !sigma || n < 0) return REN_ERR_BAD_ARG;
     if (C != 1 && C != 3) return REN_ERR_UNSUPPORTED;          // robust_e_nerf.py:230-233
     if (!density_only && !rgb) return REN_ERR_BAD_ARG;
@@ -535,9 +552,78 @@ extern "C" int ren_mlp_fwd(const float *mlp_params, int32_t C, const float *feat
     if (blocks > 768) blocks = 768;                            // 3 workgroups / CU (43.5 KB LDS each)
     dim3 grd((int)blocks), blk(256);
     hipStream_t st = (hipStream_t)stream;
-    if (density_only) hipLaunchKernelGGL((mlp_fwd_kernel<1, true>), grd, blk, FWD_LDS, st, a);
-    else if (C == 1)  hipLaunchKernelGGL((mlp_fwd_kernel<1, false>), grd, blk, FWD_LDS, st, a);
-    else              hipLaunchKernelGGL((mlp_fwd_kernel<3, false>), grd, blk, FWD_LDS, st, a);
+#define REN_FWD(CC, DO)                                                                               \
+    do {                                                                                              \
+        if (rb) hipLaunchKernelGGL((mlp_fwd_kernel<CC, DO, true>), grd, blk, FWD_LDS, st, a);         \
+        else    hipLaunchKernelGGL((mlp_fwd_kernel<CC, DO, false>), grd, blk, FWD_LDS, st, a);        \
+    } while (0)
+    if (density_only) REN_FWD(1, true);
+    else if (C == 1)  REN_FWD(1, false);
+    else              REN_FWD(3, false);
+#undef REN_FWD
+    REN_CHECK_LAUNCH();
+}
+
+extern "C" int ren_mlp_fwd(const float *mlp_params, int32_t C, const float *feat,
+                           const ren_scene_desc *scene, const float *x_world, const float *dirs,
+                           const float *rays_o, const float *rays_d, const int32_t *ray_indices,
+                           const float *t_starts, const float *t_ends, int64_t n, int32_t density_only,
+                           float *rgb, float *sigma, float *base_out, void *stream) {
+    return mlp_fwd_impl(false, mlp_params, C, feat, scene, x_world, dirs, rays_o, rays_d, ray_indices, t_starts, t_ends,
+                        n, density_only, rgb, sigma, base_out, stream);
+}
+
+extern "C" int ren_mlp_fwd_bf16(const float *mlp_params_bf16, int32_t C, const float *feat,
+                                const ren_scene_desc *scene, const float *x_world, const float *dirs,
+                                const float *rays_o, const float *rays_d, const int32_t *ray_indices,
+                                const float *t_starts, const float *t_ends, int64_t n, int32_t density_only,
+                                float *rgb, float *sigma, float *base_out, void *stream) {
+    return mlp_fwd_impl(true, mlp_params_bf16, C, feat, scene, x_world, dirs, rays_o, rays_d, ray_indices, t_starts,
+                        t_ends, n, density_only, rgb, sigma, base_out, stream);
+}
+
+static int mlp_bwd_impl(bool rb, const float *mlp_params, int32_t C, const float *feat, const float *base_out,
+                        const ren_scene_desc *scene, const float *x_world, const float *dirs,
+                        const float *rays_o, const float *rays_d, const int32_t *ray_indices,
+                        const float *t_starts, const float *t_ends, int64_t n, const float *rgb,
+                        const float *d_rgb, const float *d_sigma, float *d_base, float *dfeat,
+                        float *grad_mlp_params, float *workspace, void *stream) {
+    if (!mlp_params || !feat || !base_out || !scene || !rgb || !d_rgb || !d_sigma || !d_base || !dfeat ||
+        !grad_mlp_params || !workspace || n < 0)
+        return REN_ERR_BAD_ARG;
+    if (C != 1 && C != 3) return REN_ERR_UNSUPPORTED;
+    if (!x_world && (!rays_o || !rays_d || !ray_indices || !t_starts || !t_ends)) return REN_ERR_BAD_ARG;
+    if (n == 0) return REN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    // > 64 KiB of dynamic LDS needs the attribute; setting it is idempotent (no library state)
+    (void)hipFuncSetAttribute((const void *)mlp_bwd_head_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_H_LDS);
+    (void)hipFuncSetAttribute((const void *)mlp_bwd_head_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_H_LDS);
+    (void)hipFuncSetAttribute((const void *)mlp_bwd_base_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_B_LDS);
+    (void)hipFuncSetAttribute((const void *)mlp_bwd_head_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_H_LDS);
+    (void)hipFuncSetAttribute((const void *)mlp_bwd_head_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_H_LDS);
+    (void)hipFuncSetAttribute((const void *)mlp_bwd_base_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_B_LDS);
+    const int head_len = p_total(C) - P_BASE_N;
+    float *slab_h = workspace, *slab_b = workspace + (int64_t)GRID_H * 4 * head_len;
+    BwdHArgs h;
+    h.params = mlp_params; h.base_out = base_out;
+    h.src = SampleSrc{x_world, dirs, rays_o, rays_d, x_world ? nullptr : ray_indices, t_starts, t_ends};
+    h.sc = ren_make_scene(scene);
+    h.n = n; h.rgb = rgb; h.d_rgb = d_rgb; h.d_sigma = d_sigma; h.d_base = d_base; h.slab = slab_h;
+    if (C == 1) {
+        if (rb) hipLaunchKernelGGL((mlp_bwd_head_kernel<1, true>), dim3(GRID_H), dim3(256), BWD_H_LDS, st, h);
+        else    hipLaunchKernelGGL((mlp_bwd_head_kernel<1, false>), dim3(GRID_H), dim3(256), BWD_H_LDS, st, h);
+    } else {
+        if (rb) hipLaunchKernelGGL((mlp_bwd_head_kernel<3, true>), dim3(GRID_H), dim3(256), BWD_H_LDS, st, h);
+        else    hipLaunchKernelGGL((mlp_bwd_head_kernel<3, false>), dim3(GRID_H), dim3(256), BWD_H_LDS, st, h);
+    }
+    BwdBArgs b;
+    b.params = mlp_params; b.feat = feat; b.d_base = d_base; b.n = n; b.dfeat = dfeat; b.slab = slab_b;
+    if (rb) hipLaunchKernelGGL(mlp_bwd_base_kernel<true>, dim3(GRID_B), dim3(256), BWD_B_LDS, st, b);
+    else    hipLaunchKernelGGL(mlp_bwd_base_kernel<false>, dim3(GRID_B), dim3(256), BWD_B_LDS, st, b);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((head_len + 255) / 256), dim3(256), 0, st, slab_h,
+                       GRID_H * 4, head_len, grad_mlp_params + P_BASE_N);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((P_BASE_N + 255) / 256), dim3(256), 0, st, slab_b,
+                       GRID_B * 4, P_BASE_N, grad_mlp_params);
     REN_CHECK_LAUNCH();
 }
 
@@ -547,32 +633,16 @@ extern "C" int ren_mlp_bwd(const float *mlp_params, int32_t C, const float *feat
                            const float *t_starts, const float *t_ends, int64_t n, const float *rgb,
                            const float *d_rgb, const float *d_sigma, float *d_base, float *dfeat,
                            float *grad_mlp_params, float *workspace, void *stream) {
-    if (!mlp_params || !feat || !base_out || !scene || !rgb || !d_rgb || !d_sigma || !d_base || !dfeat ||
-        !grad_mlp_params || !workspace || n < 0)
-        return REN_ERR_BAD_ARG;
-    if (C != 1 && C != 3) return REN_ERR_UNSUPPORTED;
-    if (!x_world && (!rays_o || !rays_d || !ray_indices || !t_starts || !t_ends)) return REN_ERR_BAD_ARG;
-    if (n == 0) return REN_OK;
-    hipStream_t st = (hipStream_t)stream;
-    // > 64 KiB of dynamic LDS needs the attribute; setting it is idempotent (no library state)
-    (void)hipFuncSetAttribute((const void *)mlp_bwd_head_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_H_LDS);
-    (void)hipFuncSetAttribute((const void *)mlp_bwd_head_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_H_LDS);
-    (void)hipFuncSetAttribute((const void *)mlp_bwd_base_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_B_LDS);
-    const int head_len = p_total(C) - P_BASE_N;
-    float *slab_h = workspace, *slab_b = workspace + (int64_t)GRID_H * 4 * head_len;
-    BwdHArgs h;
-    h.params = mlp_params; h.base_out = base_out;
-    h.src = SampleSrc{x_world, dirs, rays_o, rays_d, x_world ? nullptr : ray_indices, t_starts, t_ends};
-    h.sc = ren_make_scene(scene);
-    h.n = n; h.rgb = rgb; h.d_rgb = d_rgb; h.d_sigma = d_sigma; h.d_base = d_base; h.slab = slab_h;
-    if (C == 1) hipLaunchKernelGGL((mlp_bwd_head_kernel<1>), dim3(GRID_H), dim3(256), BWD_H_LDS, st, h);
-    else        hipLaunchKernelGGL((mlp_bwd_head_kernel<3>), dim3(GRID_H), dim3(256), BWD_H_LDS, st, h);
-    BwdBArgs b;
-    b.params = mlp_params; b.feat = feat; b.d_base = d_base; b.n = n; b.dfeat = dfeat; b.slab = slab_b;
-    hipLaunchKernelGGL(mlp_bwd_base_kernel, dim3(GRID_B), dim3(256), BWD_B_LDS, st, b);
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((head_len + 255) / 256), dim3(256), 0, st, slab_h,
-                       GRID_H * 4, head_len, grad_mlp_params + P_BASE_N);
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((P_BASE_N + 255) / 256), dim3(256), 0, st, slab_b,
-                       GRID_B * 4, P_BASE_N, grad_mlp_params);
-    REN_CHECK_LAUNCH();
+    return mlp_bwd_impl(false, mlp_params, C, feat, base_out, scene, x_world, dirs, rays_o, rays_d, ray_indices, t_starts,
+                        t_ends, n, rgb, d_rgb, d_sigma, d_base, dfeat, grad_mlp_params, workspace, stream);
+}
+
+extern "C" int ren_mlp_bwd_bf16(const float *mlp_params_bf16, int32_t C, const float *feat, const float *base_out,
+                                const ren_scene_desc *scene, const float *x_world, const float *dirs,
+                                const float *rays_o, const float *rays_d, const int32_t *ray_indices,
+                                const float *t_starts, const float *t_ends, int64_t n, const float *rgb,
+                                const float *d_rgb, const float *d_sigma, float *d_base, float *dfeat,
+                                float *grad_mlp_params, float *workspace, void *stream) {
+    return mlp_bwd_impl(true, mlp_params_bf16, C, feat, base_out, scene, x_world, dirs, rays_o, rays_d, ray_indices,
+                        t_starts, t_ends, n, rgb, d_rgb, d_sigma, d_base, dfeat, grad_mlp_params, workspace, stream);
 }

@@ -74,6 +74,17 @@ __device__ __forceinline__ float dsoftplus_from_out(float y, float beta) {
     return t < 1e-3f ? t * (1.f - t * (0.5f - t * 0.16666667f)) : 1.f - __expf(-t);
 }
 
+// bf16 MLP mode (BASELINE configs[2]: "bf16 MLP with fp32 composite"): every nn.Linear sees bf16-rounded
+// inputs and bf16-rounded weights (the host passes a rounded copy of the parameter block), products are
+// exact in fp32 and accumulate in fp32 -- numerically what a bf16 MFMA with fp32 accumulation computes, here
+// still issued on the f32 pipe (true bf16 MFMA kernels are a later round).  The backward pass is the exact
+// derivative of that forward (straight-through rounding).
+template <bool RB>
+__device__ __forceinline__ float lin_in(float v) {
+    if (!RB) return v;
+    return (float)(__bf16)v;                                   // round-to-nearest-even, v_cvt_pk_bf16_f32
+}
+
 __device__ void fill_base(float *lds, const float *__restrict__ P, int oW1, int oW2, int oB1, int oB2) {
     const int t = threadIdx.x, nt = blockDim.x;
     for (int i = t; i < 64 * 32; i += nt) lds[oW1 + (i >> 5) * 33 + (i & 31)] = P[P_BW0 + i];

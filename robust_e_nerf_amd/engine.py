@@ -41,6 +41,7 @@ class RenderCfg:
     warmup_steps: int = 256
     occ_n: int = 16
     binned_scatter: bool = True        # LDS-binned hash-grid backward (False: per-update global atomics)
+    mlp_bf16: bool = False             # BASELINE configs[2]: bf16 MLP (rounded linear inputs/weights, fp32 accumulate), fp32 composite
 
 
 class NGPField:
@@ -132,27 +133,36 @@ class Renderer:
         return Packed(ri2, ts2, te2, new_offsets, kept, n1, n0)
 
     # ---- field evaluation over a packed sample stream (overridden by vanilla.VanillaRenderer) ----------
+    def _mlp_params(self):
+        """Parameter block handed to the MLP kernels: the fp32 master copy, or (bf16 mode) its bf16-rounded
+        image -- 9 425 floats, re-rounded per call so it always follows the optimiser."""
+        m = self.field.mlp
+        return m.to(torch.bfloat16).to(torch.float32) if self.cfg.mlp_bf16 else m
+
     def _density_stream(self, o, d, samples, n):
         feat = ops.hashgrid_fwd(self.field.grid, self.field.table, scene=self.scene, rays=(o, d),
                                 samples=samples, n=n, layout=1)
-        _, sigma, _ = ops.mlp_fwd(self.field.mlp, self.field.C, feat, self.scene, rays=(o, d),
-                                  samples=samples, n=n, density_only=True)
+        _, sigma, _ = ops.mlp_fwd(self._mlp_params(), self.field.C, feat, self.scene, rays=(o, d),
+                                  samples=samples, n=n, density_only=True, bf16=self.cfg.mlp_bf16)
         return sigma
 
     def _field_forward(self, o, d, pk, save):
         f = self.field
         samples = (pk.ray_indices, pk.t_starts, pk.t_ends)
         feat = ops.hashgrid_fwd(f.grid, f.table, scene=self.scene, rays=(o, d), samples=samples, n=pk.n, layout=1)
-        rgb, sigma, base = ops.mlp_fwd(f.mlp, f.C, feat, self.scene, rays=(o, d), samples=samples, n=pk.n,
-                                       save_base=save)
-        return rgb, sigma, dict(feat=feat, base=base)
+        mp = self._mlp_params()
+        rgb, sigma, base = ops.mlp_fwd(mp, f.C, feat, self.scene, rays=(o, d), samples=samples, n=pk.n,
+                                       save_base=save, bf16=self.cfg.mlp_bf16)
+        return rgb, sigma, dict(feat=feat, base=base, mlp_params=mp)
 
     def _field_backward(self, ctx, d_rgb, d_sig):
         f, pk = self.field, ctx["pk"]
         samples = (pk.ray_indices, pk.t_starts, pk.t_ends)
-        dfeat = ops.mlp_bwd(f.mlp, f.C, ctx["feat"], ctx["base"], self.scene, rays=(ctx["o"], ctx["d"]),
-                            samples=samples, n=pk.n, rgb=ctx["rgb"], d_rgb=d_rgb, d_sigma=d_sig,
-                            grad_mlp_params=f.g_mlp, workspace=self._ws)
+        mp = ctx.get("mlp_params")                      # absent when the forward ran on the (fp32) tangent kernels
+        dfeat = ops.mlp_bwd(f.mlp if mp is None else mp, f.C, ctx["feat"], ctx["base"], self.scene,
+                            rays=(ctx["o"], ctx["d"]), samples=samples, n=pk.n, rgb=ctx["rgb"], d_rgb=d_rgb,
+                            d_sigma=d_sig, grad_mlp_params=f.g_mlp, workspace=self._ws,
+                            bf16=self.cfg.mlp_bf16 and mp is not None)
         if self.cfg.binned_scatter:
             need = ops.hashgrid_bwd_binned_workspace_bytes(pk.n)
             if self._bin_ws is None or self._bin_ws.numel() < need:
@@ -201,7 +211,8 @@ class Renderer:
         n = x_world.shape[0]
         xu = contract_points(x_world, self.cfg.aabb, self.cfg.contraction_type)
         feat = ops.hashgrid_fwd(f.grid, f.table, x_unit=xu, n=n, layout=1)
-        _, sigma, _ = ops.mlp_fwd(f.mlp, f.C, feat, self.scene, x_world=x_world, n=n, density_only=True)
+        _, sigma, _ = ops.mlp_fwd(self._mlp_params(), f.C, feat, self.scene, x_world=x_world, n=n, density_only=True,
+                                  bf16=self.cfg.mlp_bf16)
         return sigma
 
     # ---- occupancy grid (K14): nerfacc OccupancyGrid.every_n_step as driven by nerf.py:170-204 ------------

@@ -248,7 +248,8 @@ def hashgrid_bwd_binned(grid: GridDesc, grad_table, dfeat, workspace, *, x_unit=
 
 # ------------------------------------------------------------------------------- fused MLPs
 def mlp_fwd(mlp_params, C: int, feat, scene: SceneDesc, *, x_world=None, dirs=None, rays=None, samples=None,
-            n: int, density_only: bool = False, save_base: bool = False, out=None):
+            n: int, density_only: bool = False, save_base: bool = False, out=None, bf16: bool = False):
+    """bf16=True: `mlp_params` must be the bf16-rounded copy of the block (see ren_mlp_fwd_bf16)."""
     dev = feat.device
     o, d = rays if rays is not None else (None, None)
     ri, ts, te = samples if samples is not None else (None, None, None)
@@ -258,9 +259,10 @@ def mlp_fwd(mlp_params, C: int, feat, scene: SceneDesc, *, x_world=None, dirs=No
         base = torch.empty(n_blocks32(n) * BASE_FLOATS_PER_BLOCK, device=dev, dtype=torch.float32) if save_base else None
     else:
         rgb, sigma, base = out
-    check(_lib.load().ren_mlp_fwd(_ptr(mlp_params, torch.float32), C, _ptr(feat, torch.float32), ctypes.byref(scene),
-                                  _ptr(x_world), _ptr(dirs), _ptr(o), _ptr(d), _ptr(ri), _ptr(ts), _ptr(te), n,
-                                  1 if density_only else 0, _ptr(rgb), _ptr(sigma), _ptr(base), _stream()),
+    fn = _lib.load().ren_mlp_fwd_bf16 if bf16 else _lib.load().ren_mlp_fwd
+    check(fn(_ptr(mlp_params, torch.float32), C, _ptr(feat, torch.float32), ctypes.byref(scene),
+             _ptr(x_world), _ptr(dirs), _ptr(o), _ptr(d), _ptr(ri), _ptr(ts), _ptr(te), n,
+             1 if density_only else 0, _ptr(rgb), _ptr(sigma), _ptr(base), _stream()),
           "ren_mlp_fwd")
     return rgb, sigma, base
 
@@ -270,7 +272,8 @@ def mlp_bwd_workspace_floats(C: int) -> int:
 
 
 def mlp_bwd(mlp_params, C: int, feat, base_out, scene: SceneDesc, *, x_world=None, dirs=None, rays=None,
-            samples=None, n: int, rgb, d_rgb, d_sigma, grad_mlp_params, workspace, d_base=None, dfeat=None):
+            samples=None, n: int, rgb, d_rgb, d_sigma, grad_mlp_params, workspace, d_base=None, dfeat=None,
+            bf16: bool = False):
     dev = feat.device
     o, d = rays if rays is not None else (None, None)
     ri, ts, te = samples if samples is not None else (None, None, None)
@@ -278,7 +281,8 @@ def mlp_bwd(mlp_params, C: int, feat, base_out, scene: SceneDesc, *, x_world=Non
         d_base = torch.empty(n_blocks32(n) * BASE_FLOATS_PER_BLOCK, device=dev, dtype=torch.float32)
     if dfeat is None:
         dfeat = torch.empty(n_blocks32(n) * FRAG_FLOATS_PER_BLOCK, device=dev, dtype=torch.float32)
-    check(_lib.load().ren_mlp_bwd(_ptr(mlp_params, torch.float32), C, _ptr(feat), _ptr(base_out),
+    fn = _lib.load().ren_mlp_bwd_bf16 if bf16 else _lib.load().ren_mlp_bwd
+    check(fn(_ptr(mlp_params, torch.float32), C, _ptr(feat), _ptr(base_out),
                                   ctypes.byref(scene), _ptr(x_world), _ptr(dirs), _ptr(o), _ptr(d), _ptr(ri),
                                   _ptr(ts), _ptr(te), n, _ptr(rgb), _ptr(d_rgb), _ptr(d_sigma), _ptr(d_base),
                                   _ptr(dfeat), _ptr(grad_mlp_params, torch.float32), _ptr(workspace), _stream()),

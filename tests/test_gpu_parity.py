@@ -244,6 +244,53 @@ def test_field_vs_reference_golden(amd, ct_name, full_table_cache):
     assert abs(float(gt.double().abs().sum()) - float(g["g_table_abs"])) < 1e-3 * float(g["g_table_abs"])
 
 
+def test_field_bf16_mode_vs_oracle(amd, spec, full_table_cache):
+    """BASELINE configs[2] 'bf16 MLP with fp32 composite': bf16-rounded linear inputs and weights, fp32
+    accumulation.  The HIP kernels must equal the oracle's emulation of exactly that (forward and the
+    straight-through backward), and the deviation from the fp32 field is reported."""
+    from oracle import field
+    ops, _ = amd
+    g = load_golden("field_aabb")
+    table = full_table_cache(g["table_seed"], g["table_scale"])
+    td = dev(table)
+    aabb, ct = [float(v) for v in g["aabb"]], int(g["contraction_type"])
+    x, d = t(g["x"]), t(g["d"])
+    n = x.shape[0]
+    p = field_params_from(g, table)
+    for k in FIELD_KEYS + ("hash",):
+        p[k] = p[k].clone().requires_grad_()
+    with field.bf16_linear():
+        rgb_o, sig_o = field.field_forward(x, d, p, spec, t(aabb), ct)
+    ((rgb_o * t(g["g_rgb"])).sum() + (sig_o * t(g["g_sigma"])).sum()).backward()
+    grid, n_table = ops.make_grid_desc()
+    scene = ops.make_scene_desc(aabb, ct)
+    mlp = torch.zeros(ops.mlp_param_count(1), device=DEV)
+    for k, (off, shape) in ops.mlp_slices(1).items():
+        mlp[off: off + math.prod(shape)] = dev(g[k]).reshape(-1)
+    mlp_b = mlp.to(torch.bfloat16).to(torch.float32)
+    from robust_e_nerf_amd.engine import contract_points
+    xu = contract_points(dev(x), aabb, ct)
+    feat = ops.hashgrid_fwd(grid, td, x_unit=xu, n=n, layout=1)
+    rgb, sigma, base = ops.mlp_fwd(mlp_b, 1, feat, scene, x_world=dev(x), dirs=dev(d), n=n, save_base=True, bf16=True)
+    # not bit-comparable: a pre-activation that differs in the last fp32 ulp (fast exp/log vs libm) can round to
+    # the neighbouring bf16 value (2^-8 relative) in one of the 64 inputs of the next layer
+    assert rel_err(rgb.cpu(), rgb_o) < 1e-3 and rel_err(sigma.cpu()[:, None], sig_o) < 1e-3, "bf16 kernels vs emulation"
+    dev_fp32 = rel_err(rgb.cpu(), g["rgb"])
+    print("bf16 MLP mode: max relative deviation of the radiance from the fp32 reference:", dev_fp32)
+    assert 1e-5 < dev_fp32 < 5e-2
+    gm = torch.zeros_like(mlp)
+    ws = torch.empty(ops.mlp_bwd_workspace_floats(1), device=DEV)
+    dfeat = ops.mlp_bwd(mlp_b, 1, feat, base, scene, x_world=dev(x), dirs=dev(d), n=n, rgb=rgb, d_rgb=dev(g["g_rgb"]),
+                        d_sigma=dev(g["g_sigma"]).reshape(-1).contiguous(), grad_mlp_params=gm, workspace=ws, bf16=True)
+    for k, (off, shape) in ops.mlp_slices(1).items():
+        got = gm[off: off + math.prod(shape)].view(shape).cpu()
+        assert rel_err(got, p[k].grad) < 1e-2, k
+    gt = torch.zeros_like(td)
+    ops.hashgrid_bwd(grid, gt, dfeat, x_unit=xu, n=n, layout=1)
+    idx = torch.nonzero(p["hash"].grad)[:, 0][::97]
+    assert rel_err(gt.cpu()[idx], p["hash"].grad[idx]) < 1e-2
+
+
 def test_field_rgb3_vs_oracle(amd, spec, full_table_cache):
     """radiance_dim = 3 (Bayer sensor, robust_e_nerf.py:230-233) against the oracle."""
     from oracle import field
