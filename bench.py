@@ -32,7 +32,7 @@ BYTES = {"hashgrid_fwd": 1024 + 12, "hashgrid_bwd": 2048 + 12, "hashgrid_bwd_bin
 # base 32-64-16 + head 31-64-64-1 forward; backward = data + weight gradients = 2 x forward (no recompute counted)
 MLP_MACS = 32 * 64 + 64 * 16 + 31 * 64 + 64 * 64 + 64
 VANILLA_MACS = 593152            # 63-256x4-(+63)-256x3, sigma, bottleneck, 283-128-1
-FLOPS = {"mlp_fwd": 2 * MLP_MACS, "mlp_bwd": 4 * MLP_MACS, "dense_fwd": 2 * VANILLA_MACS,
+FLOPS = {"mlp_fwd": 2 * MLP_MACS, "mlp_bwd": 4 * MLP_MACS, "mlp_fwd_save": 2 * MLP_MACS, "mlp_bwd_saved": 4 * MLP_MACS, "dense_fwd": 2 * VANILLA_MACS,
          "dense_bwd_data": 2 * VANILLA_MACS, "dense_bwd_weight": 2 * VANILLA_MACS}
 PMC_TRAFFIC = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
 

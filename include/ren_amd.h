@@ -328,6 +328,23 @@ int ren_mlp_bwd_bf16(const float *mlp_params_bf16, int32_t C, const float *feat,
                      const float *t_ends, int64_t n, const float *rgb, const float *d_rgb, const float *d_sigma,
                      float *d_base, float *dfeat, float *grad_mlp_params, float *workspace, void *stream);
 
+/* ---- saved-activation variants (the training fast path) -------------------------------------------------- *
+ * ren_mlp_fwd_save additionally stores the post-activation values of the three hidden layers
+ * (ren_mlp_act_save_floats(n) floats, 768 B/sample); ren_mlp_bwd_saved reads them instead of recomputing
+ * the forward (128 f32 MFMAs + 192 softplus per 32 samples).  bf16 != 0 selects the bf16 numerics mode
+ * (mlp_params is then the rounded copy).  Otherwise the arguments of ren_mlp_fwd / ren_mlp_bwd. */
+int64_t ren_mlp_act_save_floats(int64_t n);
+int ren_mlp_fwd_save(const float *mlp_params, int32_t C, int32_t bf16, const float *feat,
+                     const ren_scene_desc *scene, const float *x_world, const float *dirs, const float *rays_o,
+                     const float *rays_d, const int32_t *ray_indices, const float *t_starts,
+                     const float *t_ends, int64_t n, float *rgb, float *sigma, float *base_out, float *act_save,
+                     void *stream);
+int ren_mlp_bwd_saved(const float *mlp_params, int32_t C, int32_t bf16, const float *feat, const float *base_out,
+                      const float *act_save, const ren_scene_desc *scene, const float *x_world, const float *dirs,
+                      const float *rays_o, const float *rays_d, const int32_t *ray_indices, const float *t_starts,
+                      const float *t_ends, int64_t n, const float *rgb, const float *d_rgb, const float *d_sigma,
+                      float *d_base, float *dfeat, float *grad_mlp_params, float *workspace, void *stream);
+
 /* ---- second-order forward tangent (value, d/dt, d2/dt2): d(l_grad)/d(tau) --------------------------- *
  * The gradient-loss prediction d(log I)/dt is evaluated at ts_g(tau); its derivative w.r.t. the refractory
  * period needs d2 I/dt2 per ray (models/robust_e_nerf.py:340-357,383-409 differentiated through

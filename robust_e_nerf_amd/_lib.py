@@ -53,6 +53,10 @@ SIGNATURES = {
     "ren_mlp_bwd": (c_int, [P, c_int32, P, P, POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, P, P, P, P, P, P, P, P]),
     "ren_mlp_fwd_bf16": (c_int, [P, c_int32, P, POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, c_int32, P, P, P, P]),
     "ren_mlp_bwd_bf16": (c_int, [P, c_int32, P, P, POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, P, P, P, P, P, P, P, P]),
+    "ren_mlp_act_save_floats": (c_int64, [c_int64]),
+    "ren_mlp_fwd_save": (c_int, [P, c_int32, c_int32, P, POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, P, P, P, P, P]),
+    "ren_mlp_bwd_saved": (c_int, [P, c_int32, c_int32, P, P, P, POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, P, P, P,
+                                  P, P, P, P, P]),
     "ren_composite_fwd": (c_int, [P, P, c_int64, P, P, P, P, c_int32, P, P, P, P, P, P, P]),
     "ren_composite_bwd": (c_int, [P, P, c_int64, P, P, P, P, c_int32, P, P, P, P, P, P, P, P, P, P, P, P]),
     "ren_event_loss_fwd": (c_int, [P, P, P, P, c_int64, c_int32, P, P]),

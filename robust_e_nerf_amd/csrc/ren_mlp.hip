@@ -25,6 +25,12 @@
 
 namespace {
 
+// post-activation values of the three hidden layers (h, p, q) saved by the forward for ren_mlp_bwd_saved:
+// 3 x 2 x 16 registers x 64 lanes per 32-sample block = 768 B/sample.  Recomputing them in the backward
+// costs 128 f32 MFMAs + 192 softplus per block (~40 % of the backward); on a chip whose f32 MFMA and VALU
+// share a pipe while HBM idles, the 13 GB round trip per render is the cheaper side.
+constexpr int ACT_SAVE_FLOATS = 3 * 2 * 16 * 64;
+
 // ============================================================================ forward
 struct FwdArgs {
     const float *params, *feat;
@@ -32,6 +38,7 @@ struct FwdArgs {
     ren_scene_dev sc;
     int64_t n;
     float *rgb, *sigma, *base_out;
+    float *acts;                                    // optional [blk][3 = h,p,q][2][16][64]: post-activation values for ren_mlp_bwd_saved
 };
 
 template <int C, bool DENSITY_ONLY, bool RB>
@@ -74,7 +81,11 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(FwdArgs a) {
 #pragma unroll
             for (int s = 0; s < 16; ++s) h[r] = MFMA(W1[(32 * r + sl) * 33 + 2 * s + hi], x[s], h[r]);
 #pragma unroll
-            for (int g = 0; g < 16; ++g) h[r][g] = lin_in<RB>(softplus100(h[r][g]));
+            for (int g = 0; g < 16; ++g) {
+                const float y = softplus100(h[r][g]);
+                if (a.acts) a.acts[blk * ACT_SAVE_FLOATS + (r * 16 + g) * 64 + lane] = y;
+                h[r][g] = lin_in<RB>(y);
+            }
         }
         // ---- base output: 64 -> 16 (rows 16..31 of the tile are zero padding)
         f32x16 o;
@@ -114,7 +125,11 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(FwdArgs a) {
                 p[r] = MFMA(WH1[(32 * r + sl) * 33 + col], bv, p[r]);
             }
 #pragma unroll
-            for (int g = 0; g < 16; ++g) p[r][g] = lin_in<RB>(softplus100(p[r][g]));
+            for (int g = 0; g < 16; ++g) {
+                const float y = softplus100(p[r][g]);
+                if (a.acts) a.acts[blk * ACT_SAVE_FLOATS + (32 + r * 16 + g) * 64 + lane] = y;
+                p[r][g] = lin_in<RB>(y);
+            }
         }
         // ---- head layer 1: 64 -> 64
         f32x16 q[2];
@@ -138,7 +153,9 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(FwdArgs a) {
         for (int r = 0; r < 2; ++r)
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
-                const float qa = lin_in<RB>(softplus100(q[r][g]));
+                const float qy = softplus100(q[r][g]);
+                if (a.acts) a.acts[blk * ACT_SAVE_FLOATS + (64 + r * 16 + g) * 64 + lane] = qy;
+                const float qa = lin_in<RB>(qy);
 #pragma unroll
                 for (int c = 0; c < C; ++c) acc[c] += qa * lds[L_WH3 + c * 64 + 32 * r + rowc(g) + 4 * hi];
             }
@@ -165,9 +182,10 @@ struct BwdHArgs {
     int64_t n;
     const float *rgb, *d_rgb, *d_sigma;
     float *d_base, *slab;                           // d_base: fragment layout [blk][8][64]
+    const float *acts;                              // SAVED: forward's post-activation values (see ACT_SAVE_FLOATS)
 };
 
-template <int C, bool RB>
+template <int C, bool RB, bool SAVED>
 __global__ __launch_bounds__(256, REN_HEAD_OCC) void mlp_bwd_head_kernel(BwdHArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds_base[];
     fill_head(lds_base, a.params, C, LH_WH1, LH_WH2, LH_WH3, LH_BH1, LH_BH2, LH_BH3);
@@ -192,6 +210,18 @@ __global__ __launch_bounds__(256, REN_HEAD_OCC) void mlp_bwd_head_kernel(BwdHArg
         for (int k = 0; k < 32; ++k) acc_w3[c][k] = 0.f;
     }
 
+    // SAVED: one wave per SIMD means nothing hides a load, so the 64 saved activations of the NEXT block
+    // are requested before this block's arithmetic starts
+    f32x16 pn[2], qn[2];
+    auto fetch_acts = [&](int64_t b) {
+        const float *ac = a.acts + b * ACT_SAVE_FLOATS + lane;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) { pn[r][g] = ac[(32 + r * 16 + g) * 64]; qn[r][g] = ac[(64 + r * 16 + g) * 64]; }
+    };
+    if (SAVED && (int64_t)blockIdx.x * 4 + wave < n_blk) fetch_acts((int64_t)blockIdx.x * 4 + wave);
+
     for (int64_t blk = (int64_t)blockIdx.x * 4 + wave; blk < n_blk; blk += (int64_t)gridDim.x * 4) {
         int zo = 0;                                     // defeat LICM of LDS weight reads (see forward)
         asm volatile("" : "+v"(zo));
@@ -209,8 +239,25 @@ __global__ __launch_bounds__(256, REN_HEAD_OCC) void mlp_bwd_head_kernel(BwdHArg
 #pragma unroll
             for (int g = 0; g < 8; ++g) o[g] = bo[g * 64];
         }
-        // ---- recompute head forward
+        // ---- head activations: saved by the forward (SAVED) or recomputed
         f32x16 p[2], q[2];
+        // bf16 mode: the activation VALUE that feeds the next linear layer (and its weight gradient) is
+        // rounded, the softplus derivative is taken at the unrounded output: s1/s2 are formed here
+        f32x16 s1[2], s2[2];
+        if (SAVED) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) { p[r] = pn[r]; q[r] = qn[r]; }
+            const int64_t nxt = blk + (int64_t)gridDim.x * 4;
+            if (nxt < n_blk) fetch_acts(nxt);
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    if (RB) { s1[r][g] = dsoftplus_from_out(p[r][g], 100.f); s2[r][g] = dsoftplus_from_out(q[r][g], 100.f); }
+                    p[r][g] = lin_in<RB>(p[r][g]);
+                    q[r][g] = lin_in<RB>(q[r][g]);
+                }
+        } else {
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
             p[0][g] = lds[LH_BH1 + rowc(g) + 4 * hi];
@@ -225,9 +272,6 @@ __global__ __launch_bounds__(256, REN_HEAD_OCC) void mlp_bwd_head_kernel(BwdHArg
             p[0] = MFMA(WH1[sl * 33 + col], b, p[0]);
             p[1] = MFMA(WH1[(32 + sl) * 33 + col], b, p[1]);
         }
-        // bf16 mode: the activation VALUE that feeds the next linear layer (and its weight gradient) is
-        // rounded, the softplus derivative is taken at the unrounded output: s1/s2 are formed here
-        f32x16 s1[2], s2[2];
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
@@ -252,6 +296,7 @@ __global__ __launch_bounds__(256, REN_HEAD_OCC) void mlp_bwd_head_kernel(BwdHArg
                 if (RB) s2[r][g] = dsoftplus_from_out(y, 100.f);
                 q[r][g] = lin_in<RB>(y);
             }
+        }
         // ---- output layer backward: d z3 = d rgb * softplus1'(z3) = d rgb * (1 - exp(-rgb))
         float dz3[C];
 #pragma unroll
@@ -382,9 +427,10 @@ struct BwdBArgs {
     const float *params, *feat, *d_base;
     int64_t n;
     float *dfeat, *slab;
+    const float *acts;
 };
 
-template <bool RB>
+template <bool RB, bool SAVED>
 __global__ __launch_bounds__(256, 1) void mlp_bwd_base_kernel(BwdBArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds_base[];
     fill_base(lds_base, a.params, LB_W1, LB_W2, LB_B1, LB_B2);
@@ -415,8 +461,20 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_base_kernel(BwdBArgs a) {
 #pragma unroll
             for (int g = 0; g < 8; ++g) dob[g] = db[g * 64];
         }
-        // ---- recompute hidden layer
+        // ---- hidden layer: saved by the forward (SAVED) or recomputed
         f32x16 h[2];
+        f32x16 s0[2];
+        if (SAVED) {
+            const float *ac = a.acts + blk * ACT_SAVE_FLOATS + lane;
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const float y = ac[(r * 16 + g) * 64];
+                    if (RB) s0[r][g] = dsoftplus_from_out(y, 100.f);
+                    h[r][g] = lin_in<RB>(y);
+                }
+        } else {
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
             h[0][g] = lds[LB_B1 + rowc(g) + 4 * hi];
@@ -427,7 +485,6 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_base_kernel(BwdBArgs a) {
             h[0] = MFMA(W1[sl * 33 + 2 * s + hi], x[s], h[0]);
             h[1] = MFMA(W1[(32 + sl) * 33 + 2 * s + hi], x[s], h[1]);
         }
-        f32x16 s0[2];
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
@@ -436,6 +493,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_base_kernel(BwdBArgs a) {
                 if (RB) s0[r][g] = dsoftplus_from_out(y, 100.f);
                 h[r][g] = lin_in<RB>(y);
             }
+        }
         // ---- dW(base.wo) += dO . H^T
 #pragma unroll
         for (int r = 0; r < 2; ++r)
@@ -536,8 +594,9 @@ static int mlp_fwd_impl(bool rb, const float *mlp_params, int32_t C, const float
                         const ren_scene_desc *scene, const float *x_world, const float *dirs,
                         const float *rays_o, const float *rays_d, const int32_t *ray_indices,
                         const float *t_starts, const float *t_ends, int64_t n, int32_t density_only,
-                        float *rgb, float *sigma, float *base_out, void *stream) {
+                        float *rgb, float *sigma, float *base_out, float *acts, void *stream) {
     if (!mlp_params || !feat || !scene || !sigma || n < 0) return REN_ERR_BAD_ARG;
+    if (acts && (density_only || !base_out)) return REN_ERR_BAD_ARG;
     if (C != 1 && C != 3) return REN_ERR_UNSUPPORTED;          // robust_e_nerf.py:230-233
     if (!density_only && !rgb) return REN_ERR_BAD_ARG;
     if (!x_world && (!rays_o || !rays_d || !ray_indices || !t_starts || !t_ends)) return REN_ERR_BAD_ARG;
@@ -546,7 +605,7 @@ static int mlp_fwd_impl(bool rb, const float *mlp_params, int32_t C, const float
     a.params = mlp_params; a.feat = feat;
     a.src = SampleSrc{x_world, dirs, rays_o, rays_d, x_world ? nullptr : ray_indices, t_starts, t_ends};
     a.sc = ren_make_scene(scene);
-    a.n = n; a.rgb = rgb; a.sigma = sigma; a.base_out = base_out;
+    a.n = n; a.rgb = rgb; a.sigma = sigma; a.base_out = base_out; a.acts = acts;
     const int64_t n_blk = (n + 31) / 32;
     int64_t blocks = (n_blk + 3) / 4;
     if (blocks > 768) blocks = 768;                            // 3 workgroups / CU (43.5 KB LDS each)
@@ -570,7 +629,19 @@ extern "C" int ren_mlp_fwd(const float *mlp_params, int32_t C, const float *feat
                            const float *t_starts, const float *t_ends, int64_t n, int32_t density_only,
                            float *rgb, float *sigma, float *base_out, void *stream) {
     return mlp_fwd_impl(false, mlp_params, C, feat, scene, x_world, dirs, rays_o, rays_d, ray_indices, t_starts, t_ends,
-                        n, density_only, rgb, sigma, base_out, stream);
+                        n, density_only, rgb, sigma, base_out, nullptr, stream);
+}
+
+extern "C" int64_t ren_mlp_act_save_floats(int64_t n) { return n < 0 ? -1 : (n + 31) / 32 * ACT_SAVE_FLOATS; }
+
+extern "C" int ren_mlp_fwd_save(const float *mlp_params, int32_t C, int32_t bf16, const float *feat,
+                                const ren_scene_desc *scene, const float *x_world, const float *dirs,
+                                const float *rays_o, const float *rays_d, const int32_t *ray_indices,
+                                const float *t_starts, const float *t_ends, int64_t n, float *rgb, float *sigma,
+                                float *base_out, float *act_save, void *stream) {
+    if (!act_save) return REN_ERR_BAD_ARG;
+    return mlp_fwd_impl(bf16 != 0, mlp_params, C, feat, scene, x_world, dirs, rays_o, rays_d, ray_indices, t_starts,
+                        t_ends, n, 0, rgb, sigma, base_out, act_save, stream);
 }
 
 extern "C" int ren_mlp_fwd_bf16(const float *mlp_params_bf16, int32_t C, const float *feat,
@@ -579,7 +650,7 @@ extern "C" int ren_mlp_fwd_bf16(const float *mlp_params_bf16, int32_t C, const f
                                 const float *t_starts, const float *t_ends, int64_t n, int32_t density_only,
                                 float *rgb, float *sigma, float *base_out, void *stream) {
     return mlp_fwd_impl(true, mlp_params_bf16, C, feat, scene, x_world, dirs, rays_o, rays_d, ray_indices, t_starts,
-                        t_ends, n, density_only, rgb, sigma, base_out, stream);
+                        t_ends, n, density_only, rgb, sigma, base_out, nullptr, stream);
 }
 
 static int mlp_bwd_impl(bool rb, const float *mlp_params, int32_t C, const float *feat, const float *base_out,
@@ -587,7 +658,7 @@ static int mlp_bwd_impl(bool rb, const float *mlp_params, int32_t C, const float
                         const float *rays_o, const float *rays_d, const int32_t *ray_indices,
                         const float *t_starts, const float *t_ends, int64_t n, const float *rgb,
                         const float *d_rgb, const float *d_sigma, float *d_base, float *dfeat,
-                        float *grad_mlp_params, float *workspace, void *stream) {
+                        float *grad_mlp_params, float *workspace, const float *acts, void *stream) {
     if (!mlp_params || !feat || !base_out || !scene || !rgb || !d_rgb || !d_sigma || !d_base || !dfeat ||
         !grad_mlp_params || !workspace || n < 0)
         return REN_ERR_BAD_ARG;
@@ -596,30 +667,39 @@ static int mlp_bwd_impl(bool rb, const float *mlp_params, int32_t C, const float
     if (n == 0) return REN_OK;
     hipStream_t st = (hipStream_t)stream;
     // > 64 KiB of dynamic LDS needs the attribute; setting it is idempotent (no library state)
-    (void)hipFuncSetAttribute((const void *)mlp_bwd_head_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_H_LDS);
-    (void)hipFuncSetAttribute((const void *)mlp_bwd_head_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_H_LDS);
-    (void)hipFuncSetAttribute((const void *)mlp_bwd_base_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_B_LDS);
-    (void)hipFuncSetAttribute((const void *)mlp_bwd_head_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_H_LDS);
-    (void)hipFuncSetAttribute((const void *)mlp_bwd_head_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_H_LDS);
-    (void)hipFuncSetAttribute((const void *)mlp_bwd_base_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_B_LDS);
+#define REN_BWD_ATTR(K) (void)hipFuncSetAttribute((const void *)K, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_H_LDS)
+    REN_BWD_ATTR((mlp_bwd_head_kernel<1, false, false>)); REN_BWD_ATTR((mlp_bwd_head_kernel<3, false, false>));
+    REN_BWD_ATTR((mlp_bwd_head_kernel<1, true, false>));  REN_BWD_ATTR((mlp_bwd_head_kernel<3, true, false>));
+    REN_BWD_ATTR((mlp_bwd_head_kernel<1, false, true>));  REN_BWD_ATTR((mlp_bwd_head_kernel<3, false, true>));
+    REN_BWD_ATTR((mlp_bwd_head_kernel<1, true, true>));   REN_BWD_ATTR((mlp_bwd_head_kernel<3, true, true>));
+#undef REN_BWD_ATTR
+#define REN_BWD_ATTR(K) (void)hipFuncSetAttribute((const void *)K, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_B_LDS)
+    REN_BWD_ATTR((mlp_bwd_base_kernel<false, false>)); REN_BWD_ATTR((mlp_bwd_base_kernel<true, false>));
+    REN_BWD_ATTR((mlp_bwd_base_kernel<false, true>));  REN_BWD_ATTR((mlp_bwd_base_kernel<true, true>));
+#undef REN_BWD_ATTR
     const int head_len = p_total(C) - P_BASE_N;
     float *slab_h = workspace, *slab_b = workspace + (int64_t)GRID_H * 4 * head_len;
     BwdHArgs h;
     h.params = mlp_params; h.base_out = base_out;
     h.src = SampleSrc{x_world, dirs, rays_o, rays_d, x_world ? nullptr : ray_indices, t_starts, t_ends};
     h.sc = ren_make_scene(scene);
-    h.n = n; h.rgb = rgb; h.d_rgb = d_rgb; h.d_sigma = d_sigma; h.d_base = d_base; h.slab = slab_h;
+    h.n = n; h.rgb = rgb; h.d_rgb = d_rgb; h.d_sigma = d_sigma; h.d_base = d_base; h.slab = slab_h; h.acts = acts;
+    const bool sv = acts != nullptr;
+#define REN_HEAD(CC, R, S) hipLaunchKernelGGL((mlp_bwd_head_kernel<CC, R, S>), dim3(GRID_H), dim3(256), BWD_H_LDS, st, h)
     if (C == 1) {
-        if (rb) hipLaunchKernelGGL((mlp_bwd_head_kernel<1, true>), dim3(GRID_H), dim3(256), BWD_H_LDS, st, h);
-        else    hipLaunchKernelGGL((mlp_bwd_head_kernel<1, false>), dim3(GRID_H), dim3(256), BWD_H_LDS, st, h);
+        if (rb) { if (sv) REN_HEAD(1, true, true); else REN_HEAD(1, true, false); }
+        else    { if (sv) REN_HEAD(1, false, true); else REN_HEAD(1, false, false); }
     } else {
-        if (rb) hipLaunchKernelGGL((mlp_bwd_head_kernel<3, true>), dim3(GRID_H), dim3(256), BWD_H_LDS, st, h);
-        else    hipLaunchKernelGGL((mlp_bwd_head_kernel<3, false>), dim3(GRID_H), dim3(256), BWD_H_LDS, st, h);
+        if (rb) { if (sv) REN_HEAD(3, true, true); else REN_HEAD(3, true, false); }
+        else    { if (sv) REN_HEAD(3, false, true); else REN_HEAD(3, false, false); }
     }
+#undef REN_HEAD
     BwdBArgs b;
-    b.params = mlp_params; b.feat = feat; b.d_base = d_base; b.n = n; b.dfeat = dfeat; b.slab = slab_b;
-    if (rb) hipLaunchKernelGGL(mlp_bwd_base_kernel<true>, dim3(GRID_B), dim3(256), BWD_B_LDS, st, b);
-    else    hipLaunchKernelGGL(mlp_bwd_base_kernel<false>, dim3(GRID_B), dim3(256), BWD_B_LDS, st, b);
+    b.params = mlp_params; b.feat = feat; b.d_base = d_base; b.n = n; b.dfeat = dfeat; b.slab = slab_b; b.acts = acts;
+#define REN_BASE(R, S) hipLaunchKernelGGL((mlp_bwd_base_kernel<R, S>), dim3(GRID_B), dim3(256), BWD_B_LDS, st, b)
+    if (rb) { if (sv) REN_BASE(true, true); else REN_BASE(true, false); }
+    else    { if (sv) REN_BASE(false, true); else REN_BASE(false, false); }
+#undef REN_BASE
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3((head_len + 255) / 256), dim3(256), 0, st, slab_h,
                        GRID_H * 4, head_len, grad_mlp_params + P_BASE_N);
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3((P_BASE_N + 255) / 256), dim3(256), 0, st, slab_b,
@@ -634,7 +714,7 @@ extern "C" int ren_mlp_bwd(const float *mlp_params, int32_t C, const float *feat
                            const float *d_rgb, const float *d_sigma, float *d_base, float *dfeat,
                            float *grad_mlp_params, float *workspace, void *stream) {
     return mlp_bwd_impl(false, mlp_params, C, feat, base_out, scene, x_world, dirs, rays_o, rays_d, ray_indices, t_starts,
-                        t_ends, n, rgb, d_rgb, d_sigma, d_base, dfeat, grad_mlp_params, workspace, stream);
+                        t_ends, n, rgb, d_rgb, d_sigma, d_base, dfeat, grad_mlp_params, workspace, nullptr, stream);
 }
 
 extern "C" int ren_mlp_bwd_bf16(const float *mlp_params_bf16, int32_t C, const float *feat, const float *base_out,
@@ -644,5 +724,17 @@ extern "C" int ren_mlp_bwd_bf16(const float *mlp_params_bf16, int32_t C, const f
                                 const float *d_rgb, const float *d_sigma, float *d_base, float *dfeat,
                                 float *grad_mlp_params, float *workspace, void *stream) {
     return mlp_bwd_impl(true, mlp_params_bf16, C, feat, base_out, scene, x_world, dirs, rays_o, rays_d, ray_indices,
-                        t_starts, t_ends, n, rgb, d_rgb, d_sigma, d_base, dfeat, grad_mlp_params, workspace, stream);
+                        t_starts, t_ends, n, rgb, d_rgb, d_sigma, d_base, dfeat, grad_mlp_params, workspace, nullptr, stream);
+}
+
+extern "C" int ren_mlp_bwd_saved(const float *mlp_params, int32_t C, int32_t bf16, const float *feat,
+                                 const float *base_out, const float *act_save, const ren_scene_desc *scene,
+                                 const float *x_world, const float *dirs, const float *rays_o, const float *rays_d,
+                                 const int32_t *ray_indices, const float *t_starts, const float *t_ends, int64_t n,
+                                 const float *rgb, const float *d_rgb, const float *d_sigma, float *d_base,
+                                 float *dfeat, float *grad_mlp_params, float *workspace, void *stream) {
+    if (!act_save) return REN_ERR_BAD_ARG;
+    return mlp_bwd_impl(bf16 != 0, mlp_params, C, feat, base_out, scene, x_world, dirs, rays_o, rays_d, ray_indices,
+                        t_starts, t_ends, n, rgb, d_rgb, d_sigma, d_base, dfeat, grad_mlp_params, workspace, act_save,
+                        stream);
 }

@@ -41,6 +41,8 @@ class RenderCfg:
     warmup_steps: int = 256
     occ_n: int = 16
     binned_scatter: bool = True        # LDS-binned hash-grid backward (False: per-update global atomics)
+    save_activations: bool = True      # training forward stores the hidden activations (768 B/sample) instead of
+                                       # recomputing them in the backward (128 f32 MFMAs + 192 softplus per 32 samples)
     mlp_bf16: bool = False             # BASELINE configs[2]: bf16 MLP (rounded linear inputs/weights, fp32 accumulate), fp32 composite
 
 
@@ -151,6 +153,10 @@ class Renderer:
         samples = (pk.ray_indices, pk.t_starts, pk.t_ends)
         feat = ops.hashgrid_fwd(f.grid, f.table, scene=self.scene, rays=(o, d), samples=samples, n=pk.n, layout=1)
         mp = self._mlp_params()
+        if save and self.cfg.save_activations:
+            rgb, sigma, base, acts = ops.mlp_fwd_save(mp, f.C, feat, self.scene, rays=(o, d), samples=samples, n=pk.n,
+                                                      bf16=self.cfg.mlp_bf16)
+            return rgb, sigma, dict(feat=feat, base=base, mlp_params=mp, acts=acts)
         rgb, sigma, base = ops.mlp_fwd(mp, f.C, feat, self.scene, rays=(o, d), samples=samples, n=pk.n,
                                        save_base=save, bf16=self.cfg.mlp_bf16)
         return rgb, sigma, dict(feat=feat, base=base, mlp_params=mp)
@@ -159,10 +165,15 @@ class Renderer:
         f, pk = self.field, ctx["pk"]
         samples = (pk.ray_indices, pk.t_starts, pk.t_ends)
         mp = ctx.get("mlp_params")                      # absent when the forward ran on the (fp32) tangent kernels
-        dfeat = ops.mlp_bwd(f.mlp if mp is None else mp, f.C, ctx["feat"], ctx["base"], self.scene,
-                            rays=(ctx["o"], ctx["d"]), samples=samples, n=pk.n, rgb=ctx["rgb"], d_rgb=d_rgb,
-                            d_sigma=d_sig, grad_mlp_params=f.g_mlp, workspace=self._ws,
-                            bf16=self.cfg.mlp_bf16 and mp is not None)
+        if ctx.get("acts") is not None:
+            dfeat = ops.mlp_bwd_saved(mp, f.C, ctx["feat"], ctx["base"], ctx["acts"], self.scene, rays=(ctx["o"], ctx["d"]),
+                                      samples=samples, n=pk.n, rgb=ctx["rgb"], d_rgb=d_rgb, d_sigma=d_sig,
+                                      grad_mlp_params=f.g_mlp, workspace=self._ws, bf16=self.cfg.mlp_bf16)
+        else:
+            dfeat = ops.mlp_bwd(f.mlp if mp is None else mp, f.C, ctx["feat"], ctx["base"], self.scene,
+                                rays=(ctx["o"], ctx["d"]), samples=samples, n=pk.n, rgb=ctx["rgb"], d_rgb=d_rgb,
+                                d_sigma=d_sig, grad_mlp_params=f.g_mlp, workspace=self._ws,
+                                bf16=self.cfg.mlp_bf16 and mp is not None)
         if self.cfg.binned_scatter:
             need = ops.hashgrid_bwd_binned_workspace_bytes(pk.n)
             if self._bin_ws is None or self._bin_ws.numel() < need:

@@ -267,6 +267,39 @@ def mlp_fwd(mlp_params, C: int, feat, scene: SceneDesc, *, x_world=None, dirs=No
     return rgb, sigma, base
 
 
+def mlp_fwd_save(mlp_params, C: int, feat, scene: SceneDesc, *, rays=None, samples=None, x_world=None, dirs=None,
+                 n: int, bf16: bool = False):
+    """Training forward: also saves base outputs and the hidden activations (768 B/sample) for mlp_bwd_saved.
+    -> rgb, sigma, base, acts"""
+    dev = feat.device
+    o, d = rays if rays is not None else (None, None)
+    ri, ts, te = samples if samples is not None else (None, None, None)
+    sigma = torch.empty(n, device=dev, dtype=torch.float32)
+    rgb = torch.empty(n, C, device=dev, dtype=torch.float32)
+    base = torch.empty(n_blocks32(n) * BASE_FLOATS_PER_BLOCK, device=dev, dtype=torch.float32)
+    lib = _lib.load()
+    acts = torch.empty(int(lib.ren_mlp_act_save_floats(n)), device=dev, dtype=torch.float32)
+    check(lib.ren_mlp_fwd_save(_ptr(mlp_params, torch.float32), C, 1 if bf16 else 0, _ptr(feat, torch.float32),
+                               ctypes.byref(scene), _ptr(x_world), _ptr(dirs), _ptr(o), _ptr(d), _ptr(ri), _ptr(ts),
+                               _ptr(te), n, _ptr(rgb), _ptr(sigma), _ptr(base), _ptr(acts), _stream()), "ren_mlp_fwd_save")
+    return rgb, sigma, base, acts
+
+
+def mlp_bwd_saved(mlp_params, C: int, feat, base_out, acts, scene: SceneDesc, *, rays=None, samples=None, x_world=None,
+                  dirs=None, n: int, rgb, d_rgb, d_sigma, grad_mlp_params, workspace, bf16: bool = False):
+    dev = feat.device
+    o, d = rays if rays is not None else (None, None)
+    ri, ts, te = samples if samples is not None else (None, None, None)
+    d_base = torch.empty(n_blocks32(n) * BASE_FLOATS_PER_BLOCK, device=dev, dtype=torch.float32)
+    dfeat = torch.empty(n_blocks32(n) * FRAG_FLOATS_PER_BLOCK, device=dev, dtype=torch.float32)
+    check(_lib.load().ren_mlp_bwd_saved(_ptr(mlp_params, torch.float32), C, 1 if bf16 else 0, _ptr(feat), _ptr(base_out),
+                                        _ptr(acts), ctypes.byref(scene), _ptr(x_world), _ptr(dirs), _ptr(o), _ptr(d),
+                                        _ptr(ri), _ptr(ts), _ptr(te), n, _ptr(rgb), _ptr(d_rgb), _ptr(d_sigma),
+                                        _ptr(d_base), _ptr(dfeat), _ptr(grad_mlp_params, torch.float32), _ptr(workspace),
+                                        _stream()), "ren_mlp_bwd_saved")
+    return dfeat
+
+
 def mlp_bwd_workspace_floats(C: int) -> int:
     return int(_lib.load().ren_mlp_bwd_workspace_floats(C))
 
@@ -387,7 +420,8 @@ def occgrid_binarize(occs, occ_thre: float, binary, scratch):
 # disabled (zero overhead) otherwise.
 _PROFILE = None
 _TIMED = ("ray_aabb_intersect", "ray_march_count", "ray_march_write", "exclusive_scan", "visibility",
-          "compact_samples", "hashgrid_fwd", "hashgrid_bwd", "hashgrid_bwd_binned", "mlp_fwd", "mlp_bwd", "composite_fwd",
+          "compact_samples", "hashgrid_fwd", "hashgrid_bwd", "hashgrid_bwd_binned", "mlp_fwd", "mlp_bwd", "mlp_fwd_save",
+          "mlp_bwd_saved", "composite_fwd",
           "composite_bwd", "column_sum", "event_loss_fwd", "event_loss_bwd", "adam_step", "trajectory", "raygen")
 
 
