@@ -219,7 +219,7 @@ def main():
             j2 = torch.rand(B, device=dev, generator=jgen)
             lg, aux_g = tr.grad_loss_forward_backward(batches[i % n_batches], j2)
             loss = loss + lg
-            aux = dict(aux, n=aux["n"] + aux_g["n"], rays=aux["rays"] + aux_g["rays"])
+            aux = dict(aux, n=aux["n"] + aux_g["n"], rays=aux["rays"] + aux_g["rays"], n_main=aux["n"])
         tr.optimizer_step()
         return loss, aux
 
@@ -237,10 +237,11 @@ def main():
     barrier()
     ops.profile_start()
     t0 = time.perf_counter()
-    n_samples = 0
+    n_samples = n_main = 0
     for i in range(args.steps):
         loss, aux = one_step(i)
         n_samples += aux["n"]
+        n_main += aux.get("n_main", aux["n"])        # samples seen by the profiled (non-tangent) kernel families
     barrier()
     dt = time.perf_counter() - t0
     prof = ops.profile_stop()
@@ -258,7 +259,7 @@ def main():
         kern = {k: {"launches": c, "avg_ms": ms / max(c, 1)} for k, (c, ms) in prof.items()}
         dom = max(list(BYTES) + list(FLOPS), key=lambda k: prof.get(k, (0, 0.0))[1])
         c, ms = prof[dom]
-        samples_per_launch = n_samples / world / args.steps
+        samples_per_launch = n_main / args.steps     # this rank's samples per launch of the profiled kernels
         if dom in BYTES:
             achieved = BYTES[dom] * samples_per_launch / (ms / c * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

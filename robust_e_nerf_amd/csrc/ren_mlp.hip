@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(FwdArgs a) {
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
                 const float y = softplus100(h[r][g]);
-                if (a.acts) a.acts[blk * ACT_SAVE_FLOATS + (r * 16 + g) * 64 + lane] = y;
+                if (a.acts) __builtin_nontemporal_store(y, a.acts + blk * ACT_SAVE_FLOATS + (r * 16 + g) * 64 + lane);
                 h[r][g] = lin_in<RB>(y);
             }
         }
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(FwdArgs a) {
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
                 const float y = softplus100(p[r][g]);
-                if (a.acts) a.acts[blk * ACT_SAVE_FLOATS + (32 + r * 16 + g) * 64 + lane] = y;
+                if (a.acts) __builtin_nontemporal_store(y, a.acts + blk * ACT_SAVE_FLOATS + (32 + r * 16 + g) * 64 + lane);
                 p[r][g] = lin_in<RB>(y);
             }
         }
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(FwdArgs a) {
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
                 const float qy = softplus100(q[r][g]);
-                if (a.acts) a.acts[blk * ACT_SAVE_FLOATS + (64 + r * 16 + g) * 64 + lane] = qy;
+                if (a.acts) __builtin_nontemporal_store(qy, a.acts + blk * ACT_SAVE_FLOATS + (64 + r * 16 + g) * 64 + lane);
                 const float qa = lin_in<RB>(qy);
 #pragma unroll
                 for (int c = 0; c < C; ++c) acc[c] += qa * lds[L_WH3 + c * 64 + 32 * r + rowc(g) + 4 * hi];
