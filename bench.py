@@ -32,7 +32,8 @@ BYTES = {"hashgrid_fwd": 1024 + 12, "hashgrid_bwd": 2048 + 12, "hashgrid_bwd_bin
 # base 32-64-16 + head 31-64-64-1 forward; backward = data + weight gradients = 2 x forward (no recompute counted)
 MLP_MACS = 32 * 64 + 64 * 16 + 31 * 64 + 64 * 64 + 64
 VANILLA_MACS = 593152            # 63-256x4-(+63)-256x3, sigma, bottleneck, 283-128-1
-FLOPS = {"mlp_fwd": 2 * MLP_MACS, "mlp_bwd": 4 * MLP_MACS, "mlp_fwd_save": 2 * MLP_MACS, "mlp_bwd_saved": 4 * MLP_MACS, "dense_fwd": 2 * VANILLA_MACS,
+FLOPS = {"mlp_fwd": 2 * MLP_MACS, "mlp_bwd": 4 * MLP_MACS, "mlp_fwd_save": 2 * MLP_MACS, "mlp_bwd_saved": 4 * MLP_MACS,
+         "mlp_fwd_x": 2 * MLP_MACS, "mlp_bwd_x": 4 * MLP_MACS, "dense_fwd": 2 * VANILLA_MACS,
          "dense_bwd_data": 2 * VANILLA_MACS, "dense_bwd_weight": 2 * VANILLA_MACS}
 PMC_TRAFFIC = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
 
@@ -137,6 +138,8 @@ def main():
                     help="weight of the log-intensity-gradient loss (adds a third render with d/dt; 1e-3 in the real-data configs)")
     ap.add_argument("--mlp-bf16", action="store_true",
                     help="BASELINE configs[2] numerics: bf16-rounded linear inputs/weights, fp32 accumulate + composite")
+    ap.add_argument("--mlp-kernels", default="x", choices=["x", "f32"],
+                    help="x = split-bf16 matrix-core MLP kernels at fp32 accuracy (default), f32 = exact f32-MFMA kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
@@ -185,7 +188,8 @@ def main():
     p["hash"] = hashgrid.init_table(hashgrid.make_spec(), 0, 0.1, "mix32")
 
     aabb = (-1.5, -1.5, -1.5, 1.5, 1.5, 1.5)
-    cfg = engine.RenderCfg(aabb=aabb, sampler=args.sampler, n_uniform=args.samples, mlp_bf16=args.mlp_bf16)
+    cfg = engine.RenderCfg(aabb=aabb, sampler=args.sampler, n_uniform=args.samples, mlp_bf16=args.mlp_bf16,
+                           mlp_kernels=args.mlp_kernels)
     if args.arch == "mlp":
         from robust_e_nerf_amd import vanilla
         fld = vanilla.VanillaField(dev, 1)

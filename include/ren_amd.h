@@ -345,6 +345,23 @@ int ren_mlp_bwd_saved(const float *mlp_params, int32_t C, int32_t bf16, const fl
                       const float *t_ends, int64_t n, const float *rgb, const float *d_rgb, const float *d_sigma,
                       float *d_base, float *dfeat, float *grad_mlp_params, float *workspace, void *stream);
 
+/* ---- split-bf16 MLP kernels (csrc/ren_mlp_x.hip) ------------------------------------------------------------- *
+ * The same fused MLPs on the bf16 matrix cores.  mode 6: every fp32 operand is split exactly into three bf16
+ * pieces and six bf16 MFMAs per k-chunk reproduce the fp32 product to fp32 round-off (the default training
+ * path: the f32 MFMA shares its pipe with the VALU on gfx950, the bf16 MFMA does not).  mode 1: plain bf16
+ * operands (BASELINE configs[2]); takes the fp32 parameter block and rounds it itself.
+ * Arguments as ren_mlp_fwd_save / ren_mlp_bwd_saved; act_save may be NULL in the forward (inference). */
+int ren_mlp_fwd_x(const float *mlp_params, int32_t C, int32_t mode, const float *feat, const ren_scene_desc *scene,
+                  const float *x_world, const float *dirs, const float *rays_o, const float *rays_d,
+                  const int32_t *ray_indices, const float *t_starts, const float *t_ends, int64_t n,
+                  int32_t density_only, float *rgb, float *sigma, float *base_out, float *act_save, void *stream);
+int64_t ren_mlp_bwd_x_workspace_floats(int32_t C);
+int ren_mlp_bwd_x(const float *mlp_params, int32_t C, int32_t mode, const float *feat, const float *base_out,
+                  const float *act_save, const ren_scene_desc *scene, const float *x_world, const float *dirs,
+                  const float *rays_o, const float *rays_d, const int32_t *ray_indices, const float *t_starts,
+                  const float *t_ends, int64_t n, const float *rgb, const float *d_rgb, const float *d_sigma,
+                  float *d_base, float *dfeat, float *grad_mlp_params, float *workspace, void *stream);
+
 /* ---- second-order forward tangent (value, d/dt, d2/dt2): d(l_grad)/d(tau) --------------------------- *
  * The gradient-loss prediction d(log I)/dt is evaluated at ts_g(tau); its derivative w.r.t. the refractory
  * period needs d2 I/dt2 per ray (models/robust_e_nerf.py:340-357,383-409 differentiated through

@@ -57,6 +57,10 @@ SIGNATURES = {
     "ren_mlp_fwd_save": (c_int, [P, c_int32, c_int32, P, POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, P, P, P, P, P]),
     "ren_mlp_bwd_saved": (c_int, [P, c_int32, c_int32, P, P, P, POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, P, P, P,
                                   P, P, P, P, P]),
+    "ren_mlp_fwd_x": (c_int, [P, c_int32, c_int32, P, POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, c_int32, P, P, P, P, P]),
+    "ren_mlp_bwd_x_workspace_floats": (c_int64, [c_int32]),
+    "ren_mlp_bwd_x": (c_int, [P, c_int32, c_int32, P, P, P, POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, P, P, P, P, P,
+                              P, P, P]),
     "ren_composite_fwd": (c_int, [P, P, c_int64, P, P, P, P, c_int32, P, P, P, P, P, P, P]),
     "ren_composite_bwd": (c_int, [P, P, c_int64, P, P, P, P, c_int32, P, P, P, P, P, P, P, P, P, P, P, P]),
     "ren_event_loss_fwd": (c_int, [P, P, P, P, c_int64, c_int32, P, P]),

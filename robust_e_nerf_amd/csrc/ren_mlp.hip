@@ -81,11 +81,14 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(FwdArgs a) {
 #pragma unroll
             for (int s = 0; s < 16; ++s) h[r] = MFMA(W1[(32 * r + sl) * 33 + 2 * s + hi], x[s], h[r]);
 #pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const float y = softplus100(h[r][g]);
-                if (a.acts) __builtin_nontemporal_store(y, a.acts + blk * ACT_SAVE_FLOATS + (r * 16 + g) * 64 + lane);
-                h[r][g] = lin_in<RB>(y);
+            for (int g = 0; g < 16; ++g) h[r][g] = softplus100(h[r][g]);
+            if (a.acts) {                                       // ONE branch, constant offsets
+                float *ap = a.acts + blk * ACT_SAVE_FLOATS + r * 1024 + lane;
+#pragma unroll
+                for (int g = 0; g < 16; ++g) __builtin_nontemporal_store(h[r][g], ap + g * 64);
             }
+#pragma unroll
+            for (int g = 0; g < 16; ++g) h[r][g] = lin_in<RB>(h[r][g]);
         }
         // ---- base output: 64 -> 16 (rows 16..31 of the tile are zero padding)
         f32x16 o;
@@ -125,11 +128,14 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(FwdArgs a) {
                 p[r] = MFMA(WH1[(32 * r + sl) * 33 + col], bv, p[r]);
             }
 #pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const float y = softplus100(p[r][g]);
-                if (a.acts) __builtin_nontemporal_store(y, a.acts + blk * ACT_SAVE_FLOATS + (32 + r * 16 + g) * 64 + lane);
-                p[r][g] = lin_in<RB>(y);
+            for (int g = 0; g < 16; ++g) p[r][g] = softplus100(p[r][g]);
+            if (a.acts) {
+                float *ap = a.acts + blk * ACT_SAVE_FLOATS + (2 + r) * 1024 + lane;
+#pragma unroll
+                for (int g = 0; g < 16; ++g) __builtin_nontemporal_store(p[r][g], ap + g * 64);
             }
+#pragma unroll
+            for (int g = 0; g < 16; ++g) p[r][g] = lin_in<RB>(p[r][g]);
         }
         // ---- head layer 1: 64 -> 64
         f32x16 q[2];
@@ -150,12 +156,20 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(FwdArgs a) {
 #pragma unroll
         for (int c = 0; c < C; ++c) acc[c] = 0.f;
 #pragma unroll
+        for (int r = 0; r < 2; ++r) {
+#pragma unroll
+            for (int g = 0; g < 16; ++g) q[r][g] = softplus100(q[r][g]);
+            if (a.acts) {
+                float *ap = a.acts + blk * ACT_SAVE_FLOATS + (4 + r) * 1024 + lane;
+#pragma unroll
+                for (int g = 0; g < 16; ++g) __builtin_nontemporal_store(q[r][g], ap + g * 64);
+            }
+        }
+#pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
-                const float qy = softplus100(q[r][g]);
-                if (a.acts) __builtin_nontemporal_store(qy, a.acts + blk * ACT_SAVE_FLOATS + (64 + r * 16 + g) * 64 + lane);
-                const float qa = lin_in<RB>(qy);
+                const float qa = lin_in<RB>(q[r][g]);
 #pragma unroll
                 for (int c = 0; c < C; ++c) acc[c] += qa * lds[L_WH3 + c * 64 + 32 * r + rowc(g) + 4 * hi];
             }

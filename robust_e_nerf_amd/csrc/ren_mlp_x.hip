@@ -1,0 +1,782 @@
+// Fused Instant-NGP MLPs on the bf16 matrix cores at fp32 accuracy ("split-bf16").
+//
+// Why: on gfx950 the f32 MFMA runs at the f32 vector rate and its cycles ADD to the VALU's (tools/
+// mfma_valu_bench.hip), so the exact-fp32 kernels of ren_mlp.hip cost MFMA + VALU.  The bf16 MFMA
+// (v_mfma_f32_32x32x16_bf16) is 16x faster per multiply-add and does co-issue with VALU work.  An fp32 value
+// splits exactly into three bf16 pieces v = v1 + v2 + v3 (8 + 8 + 8 significant bits, residual <= 2^-27 |v|);
+// bf16 x bf16 products are exact in the fp32 accumulator, so
+//     a b  =  a1 b1 + a1 b2 + a2 b1 + a1 b3 + a3 b1 + a2 b2  + O(2^-25 |a b|)
+// i.e. six bf16 MFMAs per 16-wide k-chunk (192 matrix-pipe cycles) reproduce the fp32 product to fp32
+// round-off, against 8 f32 MFMAs (512 cycles on the shared pipe).  MODE 1 keeps only a1 b1: the plain bf16
+// numerics of BASELINE configs[2].
+//
+// Layout: as in ren_mlp.hip a wavefront owns 32 samples = MFMA columns and the accumulator registers of one
+// layer feed the next: register g of lane (sample, hi) holds neuron (g&3) + 8 (g>>2) + 4 hi, so k-chunk
+// (tile t', half h) of the next layer takes registers 8h..8h+7 of accumulator t' as its 8 k-slots and the
+// weight fragments are stored with the SAME slot -> neuron map.  Fragments live in LDS pre-split and
+// pre-permuted: [tile][chunk][term][lane] x 8 bf16 = one ds_read_b128 per MFMA operand.
+#include "ren_mlp_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define MFMAB(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+// ---- split / pack ---------------------------------------------------------------------------------------------
+template <int NT>
+__device__ __forceinline__ void split(float v, __bf16 (&t)[3]) {
+    t[0] = (__bf16)v;
+    if (NT > 1) {
+        const float r = v - (float)t[0];
+        t[1] = (__bf16)r;
+        if (NT > 2) t[2] = (__bf16)(r - (float)t[1]);
+    }
+}
+
+// 8 fp32 values -> NT bf16x8 operands
+template <int NT>
+__device__ __forceinline__ void split8(const float *v, bf16x8 (&out)[3]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        __bf16 t[3];
+        split<NT>(v[j], t);
+#pragma unroll
+        for (int k = 0; k < NT; ++k) out[k][j] = t[k];
+    }
+}
+
+// (weight term, activation term) pairs, smallest products first
+template <int MODE> struct Pairs;
+template <> struct Pairs<1> { static constexpr int N = 1, NT = 1; static constexpr int W[1] = {0}, A[1] = {0}; };
+template <> struct Pairs<6> {
+    static constexpr int N = 6, NT = 3;
+    static constexpr int W[6] = {2, 0, 1, 1, 0, 0}, A[6] = {0, 2, 1, 0, 1, 0};
+};
+
+// ---- logical weights (torch layouts inside the parameter block) ---------------------------------------------
+__device__ __forceinline__ float w_base0(const float *P, int out, int k) { return P[P_BW0 + out * 32 + k]; }
+__device__ __forceinline__ float w_base1(const float *P, int out, int k) { return out < 16 ? P[P_BWO + out * 64 + k] : 0.f; }
+// head layer 0 input order v: 0 = sigma slot (weight 0), 1..15 geo features, 16..31 SH components (ngp.py:244-259)
+__device__ __forceinline__ float w_head0(const float *P, int out, int v) {
+    return v == 0 ? 0.f : v < 16 ? P[P_HW0 + out * 31 + 15 + v] : P[P_HW0 + out * 31 + (v - 16)];
+}
+__device__ __forceinline__ float w_head1(const float *P, int out, int k) { return P[P_HW1 + out * 64 + k]; }
+
+// k-slot (chunk c, lane half hi, element j) -> input index of the layer
+__device__ __forceinline__ int ksrc_x(int c, int hi, int j) { return 2 * (8 * c + j) + hi; }                   // hash features
+__device__ __forceinline__ int ksrc_h(int c, int hi, int j) { return 32 * (c >> 1) + rowc(8 * (c & 1) + j) + 4 * hi; }  // D layout
+__device__ __forceinline__ int ksrc_v(int c, int hi, int j) { return c == 0 ? rowc(j) + 4 * hi : 16 + 2 * j + hi; }      // [base | SH]
+
+// layer ids: 0 base.w0 (x input), 1 base.wo (h input), 2 head.w0 (v input), 3 head.w1 (p input)
+template <int LAYER>
+__device__ __forceinline__ float w_of(const float *P, int out, int k) {
+    return LAYER == 0 ? w_base0(P, out, k) : LAYER == 1 ? w_base1(P, out, k) : LAYER == 2 ? w_head0(P, out, k) : w_head1(P, out, k);
+}
+template <int LAYER>
+__device__ __forceinline__ int k_of(int c, int hi, int j) {
+    return LAYER == 0 ? ksrc_x(c, hi, j) : LAYER == 2 ? ksrc_v(c, hi, j) : ksrc_h(c, hi, j);
+}
+
+// fragment store: frag[((t * NC + c) * NT + term) * 64 + lane] (8 bf16 each)
+template <int NT, int LAYER>
+__device__ void fill_frags(__bf16 *frag, const float *__restrict__ P, int tiles, int chunks) {
+    const int total = tiles * chunks * 64 * 8;
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {
+        const int j = e & 7, lane = (e >> 3) & 63, tc = e >> 9;
+        const int c = tc % chunks, t = tc / chunks;
+        const float w = w_of<LAYER>(P, t * 32 + (lane & 31), k_of<LAYER>(c, lane >> 5, j));
+        __bf16 s[3];
+        split<NT>(w, s);
+#pragma unroll
+        for (int k = 0; k < NT; ++k) frag[(((t * chunks + c) * NT + k) * 64 + lane) * 8 + j] = s[k];
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ bf16x8 ldfrag(const __bf16 *frag, int t, int chunks, int c, int term, int lane) {
+    return *reinterpret_cast<const bf16x8 *>(frag + (((t * chunks + c) * NT + term) * 64 + lane) * 8);
+}
+
+// acc += W(tile t, chunk c) . B   over the MODE's term pairs
+template <int MODE>
+__device__ __forceinline__ void mma(f32x16 &acc, const __bf16 *frag, int t, int chunks, int c, const bf16x8 (&b)[3], int lane) {
+    using PR = Pairs<MODE>;
+#pragma unroll
+    for (int k = 0; k < PR::N; ++k)
+        acc = MFMAB(ldfrag<PR::NT>(frag, t, chunks, c, PR::W[k], lane), b[PR::A[k]], acc);
+}
+
+// LDS image (bytes): fragments, then f32 biases and the output layer
+template <int NT> struct XL {
+    static constexpr int F_W1 = 0;                              // 2 tiles x 2 chunks
+    static constexpr int F_W2 = F_W1 + 2 * 2 * NT * 512;        // 1 x 4
+    static constexpr int F_WH1 = F_W2 + 1 * 4 * NT * 512;       // 2 x 2
+    static constexpr int F_WH2 = F_WH1 + 2 * 2 * NT * 512;      // 2 x 4
+    static constexpr int F_END = F_WH2 + 2 * 4 * NT * 512;      // bf16 elements
+    static constexpr int BYTES_F = F_END * 2;
+    // f32 tail: b1[64] b2[32] bh1[64] bh2[64] wh3[3*64] bh3[4]
+    static constexpr int T_B1 = 0, T_B2 = 64, T_BH1 = 96, T_BH2 = 160, T_WH3 = 224, T_BH3 = 416, T_END = 420;
+    static constexpr size_t BYTES = (size_t)BYTES_F + T_END * 4;
+};
+
+struct FwdXArgs {
+    const float *params, *feat;
+    SampleSrc src;
+    ren_scene_dev sc;
+    int64_t n;
+    float *rgb, *sigma, *base_out, *acts;
+};
+
+constexpr int ACT_SAVE_FLOATS_X = 3 * 2 * 16 * 64;            // same layout as ren_mlp.hip's ACT_SAVE_FLOATS
+
+template <int C, int MODE, bool DENSITY_ONLY>
+__global__ __launch_bounds__(256, 2) void mlp_fwd_x_kernel(FwdXArgs a) {
+    using PR = Pairs<MODE>;
+    constexpr int NT = PR::NT;
+    using L = XL<NT>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __bf16 *frag = reinterpret_cast<__bf16 *>(smem);
+    float *tail = reinterpret_cast<float *>(smem + L::BYTES_F);
+    fill_frags<NT, 0>(frag + L::F_W1, a.params, 2, 2);
+    fill_frags<NT, 1>(frag + L::F_W2, a.params, 1, 4);
+    if (!DENSITY_ONLY) {
+        fill_frags<NT, 2>(frag + L::F_WH1, a.params, 2, 2);
+        fill_frags<NT, 3>(frag + L::F_WH2, a.params, 2, 4);
+    }
+    for (int i = threadIdx.x; i < 64; i += blockDim.x) {
+        tail[L::T_B1 + i] = a.params[P_BB0 + i];
+        tail[L::T_BH1 + i] = a.params[P_HB0 + i];
+        tail[L::T_BH2 + i] = a.params[P_HB1 + i];
+        if (i < 32) tail[L::T_B2 + i] = i < 16 ? a.params[P_BBO + i] : 0.f;
+    }
+    for (int i = threadIdx.x; i < 64 * C; i += blockDim.x) tail[L::T_WH3 + i] = a.params[P_HWO + i];
+    if (threadIdx.x < C) tail[L::T_BH3 + threadIdx.x] = a.params[P_HWO + 64 * C + threadIdx.x];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hi = lane >> 5, sl = lane & 31;
+    const int64_t n_blk = (a.n + 31) >> 5;
+
+    for (int64_t blk = (int64_t)blockIdx.x * 4 + wave; blk < n_blk; blk += (int64_t)gridDim.x * 4) {
+        int zo = 0;                                             // keep the (loop-invariant) LDS reads inside the loop
+        asm volatile("" : "+v"(zo));
+        const __bf16 *fr = frag + zo;
+        const float *tl = tail + zo;
+        const int64_t i = blk * 32 + sl;
+        const bool live = i < a.n;
+        // ---- hash features -> two k-chunks
+        bf16x8 bx[2][3];
+        {
+            const float *f = a.feat + blk * (16 * 64) + lane;
+            float x[16];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) x[s] = f[s * 64];
+            split8<NT>(x, bx[0]);
+            split8<NT>(x + 8, bx[1]);
+        }
+        // ---- base layer 0: 32 -> 64, softplus(beta = 100)
+        f32x16 h[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int g = 0; g < 16; ++g) h[t][g] = tl[L::T_B1 + 32 * t + rowc(g) + 4 * hi];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) mma<MODE>(h[t], fr + L::F_W1, t, 2, c, bx[c], lane);
+        }
+        bf16x8 bh[4][3];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float y[16];
+#pragma unroll
+            for (int g = 0; g < 16; ++g) y[g] = softplus100(h[t][g]);
+            if (a.acts) {                                       // ONE branch, constant offsets
+                float *ap = a.acts + blk * ACT_SAVE_FLOATS_X + t * 1024 + lane;
+#pragma unroll
+                for (int g = 0; g < 16; ++g) __builtin_nontemporal_store(y[g], ap + g * 64);
+            }
+            split8<NT>(y, bh[2 * t]);
+            split8<NT>(y + 8, bh[2 * t + 1]);
+        }
+        // ---- base output: 64 -> 16 (rows 16..31 of the tile are zero)
+        f32x16 o;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) o[g] = tl[L::T_B2 + rowc(g) + 4 * hi];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) mma<MODE>(o, fr + L::F_W2, 0, 4, c, bh[c], lane);
+        bool sel = false;
+        float dx = 0.f, dy = 0.f, dz = 1.f;
+        if (live) sample_geom(a.src, a.sc, i, sel, dx, dy, dz);
+        if (live && hi == 0) a.sigma[i] = sel ? __expf(o[0] - 1.f) : 0.f;          // ngp.py:247-250
+        if (a.base_out) {
+            float *bo = a.base_out + blk * (8 * 64) + lane;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) bo[g * 64] = o[g];
+        }
+        if (DENSITY_ONLY) continue;
+        // ---- head layer 0: [base_out(16) | SH(16)] -> 64
+        bf16x8 bv[2][3];
+        {
+            float v0[8], shs[8];
+#pragma unroll
+            for (int g = 0; g < 8; ++g) v0[g] = o[g];
+            sh4_select(dx, dy, dz, hi, shs);
+            split8<NT>(v0, bv[0]);
+            split8<NT>(shs, bv[1]);
+        }
+        f32x16 p[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int g = 0; g < 16; ++g) p[t][g] = tl[L::T_BH1 + 32 * t + rowc(g) + 4 * hi];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) mma<MODE>(p[t], fr + L::F_WH1, t, 2, c, bv[c], lane);
+        }
+        bf16x8 bp[4][3];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float y[16];
+#pragma unroll
+            for (int g = 0; g < 16; ++g) y[g] = softplus100(p[t][g]);
+            if (a.acts) {
+                float *ap = a.acts + blk * ACT_SAVE_FLOATS_X + (2 + t) * 1024 + lane;
+#pragma unroll
+                for (int g = 0; g < 16; ++g) __builtin_nontemporal_store(y[g], ap + g * 64);
+            }
+            split8<NT>(y, bp[2 * t]);
+            split8<NT>(y + 8, bp[2 * t + 1]);
+        }
+        // ---- head layer 1: 64 -> 64
+        f32x16 q[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int g = 0; g < 16; ++g) q[t][g] = tl[L::T_BH2 + 32 * t + rowc(g) + 4 * hi];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) mma<MODE>(q[t], fr + L::F_WH2, t, 4, c, bp[c], lane);
+        }
+        // ---- head output: 64 -> C on the VALU in fp32 (MODE 1: bf16-rounded operands, as every other layer)
+        float acc[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[c] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int g = 0; g < 16; ++g) q[t][g] = softplus100(q[t][g]);
+            if (a.acts) {
+                float *ap = a.acts + blk * ACT_SAVE_FLOATS_X + (4 + t) * 1024 + lane;
+#pragma unroll
+                for (int g = 0; g < 16; ++g) __builtin_nontemporal_store(q[t][g], ap + g * 64);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const float qy = q[t][g];
+                const float qa = MODE == 1 ? (float)(__bf16)qy : qy;
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const float w3 = tl[L::T_WH3 + c * 64 + 32 * t + rowc(g) + 4 * hi];
+                    acc[c] += qa * (MODE == 1 ? (float)(__bf16)w3 : w3);
+                }
+            }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float s = acc[c] + __shfl_xor(acc[c], 32, 64);
+            if (hi == 0 && live) a.rgb[i * C + c] = softplus1(s + tl[L::T_BH3 + c]);
+        }
+    }
+}
+
+template <int MODE>
+int launch_fwd_x(const FwdXArgs &a, int C, bool density_only, hipStream_t st) {
+    using L = XL<Pairs<MODE>::NT>;
+    const int64_t n_blk = (a.n + 31) / 32;
+    int64_t blocks = (n_blk + 3) / 4;
+    if (blocks > 512) blocks = 512;                             // two workgroups per CU
+    const dim3 grd((int)blocks), blk(256);
+#define REN_X(CC, DO)                                                                                       \
+    do {                                                                                                    \
+        (void)hipFuncSetAttribute((const void *)mlp_fwd_x_kernel<CC, MODE, DO>,                             \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::BYTES);               \
+        hipLaunchKernelGGL((mlp_fwd_x_kernel<CC, MODE, DO>), grd, blk, L::BYTES, st, a);                    \
+    } while (0)
+    if (density_only) REN_X(1, true);
+    else if (C == 1)  REN_X(1, false);
+    else              REN_X(3, false);
+#undef REN_X
+    REN_CHECK_LAUNCH();
+}
+
+}  // namespace
+
+// mode: 6 = split-bf16 at fp32 accuracy (fp32 parameter block), 1 = plain bf16 operands (BASELINE configs[2])
+extern "C" int ren_mlp_fwd_x(const float *mlp_params, int32_t C, int32_t mode, const float *feat,
+                             const ren_scene_desc *scene, const float *x_world, const float *dirs,
+                             const float *rays_o, const float *rays_d, const int32_t *ray_indices,
+                             const float *t_starts, const float *t_ends, int64_t n, int32_t density_only,
+                             float *rgb, float *sigma, float *base_out, float *act_save, void *stream) {
+    if (!mlp_params || !feat || !scene || !sigma || n < 0) return REN_ERR_BAD_ARG;
+    if (C != 1 && C != 3) return REN_ERR_UNSUPPORTED;
+    if (mode != 1 && mode != 6) return REN_ERR_UNSUPPORTED;
+    if (!density_only && !rgb) return REN_ERR_BAD_ARG;
+    if (act_save && (density_only || !base_out)) return REN_ERR_BAD_ARG;
+    if (!x_world && (!rays_o || !rays_d || !ray_indices || !t_starts || !t_ends)) return REN_ERR_BAD_ARG;
+    if (n == 0) return REN_OK;
+    FwdXArgs a;
+    a.params = mlp_params; a.feat = feat;
+    a.src = SampleSrc{x_world, dirs, rays_o, rays_d, x_world ? nullptr : ray_indices, t_starts, t_ends};
+    a.sc = ren_make_scene(scene);
+    a.n = n; a.rgb = rgb; a.sigma = sigma; a.base_out = base_out; a.acts = act_save;
+    return mode == 6 ? launch_fwd_x<6>(a, C, density_only != 0, (hipStream_t)stream)
+                     : launch_fwd_x<1>(a, C, density_only != 0, (hipStream_t)stream);
+}
+
+// ================================================================================================ backward
+// Saved-activation backward (the forward stored h, p, q), two persistent kernels as in ren_mlp.hip.
+// Data gradients (W^T dZ chains) use the same 6-term products as the forward.  Weight gradients are sums
+// over all samples of dz . act products: they use two pieces per operand and three terms (2^-16 per product,
+// far below the fp32 round-off of a 16.8 M-term fp32 sum), which halves the LDS transpose traffic:
+// each lane writes its sample's 16 tile values as bf16 pieces into T[piece][neuron][sample] and reads them
+// back along the sample axis as MFMA operands (k = sample).
+namespace {
+
+constexpr int ST = 40;                                   // staging row stride in bf16 (32 samples + pad, 80 B)
+template <int NP> struct StageBytes { static constexpr int TILE = NP * 32 * ST * 2; };   // one 32-neuron tile
+
+// write 16 D-layout register values (neurons rowc(g) + 4 hi of one tile) as NP bf16 pieces
+template <int NP>
+__device__ __forceinline__ void stage_tile(__bf16 *T, const float *v, int hi, int sl) {
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        __bf16 s[3];
+        split<NP>(v[g], s);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) T[(k * 32 + rowc(g) + 4 * hi) * ST + sl] = s[k];
+    }
+}
+// write one value for an explicit neuron row
+template <int NP>
+__device__ __forceinline__ void stage_one(__bf16 *T, int row, float v, int sl) {
+    __bf16 s[3];
+    split<NP>(v, s);
+#pragma unroll
+    for (int k = 0; k < NP; ++k) T[(k * 32 + row) * ST + sl] = s[k];
+}
+
+// acc[32 x 32] += Tz(32 neurons x 32 samples) . Ta(32 neurons x 32 samples)^T
+template <int NP>
+__device__ __forceinline__ void dw_tile(f32x16 &acc, const __bf16 *Tz, const __bf16 *Ta, int hi, int sl) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        bf16x8 az[NP], ba[NP];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            az[k] = *reinterpret_cast<const bf16x8 *>(Tz + (k * 32 + sl) * ST + 16 * c + 8 * hi);
+            ba[k] = *reinterpret_cast<const bf16x8 *>(Ta + (k * 32 + sl) * ST + 16 * c + 8 * hi);
+        }
+        if (NP == 2) { acc = MFMAB(az[1], ba[0], acc); acc = MFMAB(az[0], ba[1], acc); }
+        acc = MFMAB(az[0], ba[0], acc);
+    }
+}
+
+// transposed fragments: rows = INPUT index of the layer (tile t_in), k-slots = output neurons in D-layout order
+// layer ids as above; value = W(out = ksrc_h(c, hi, j), in = row)
+template <int NT, int LAYER>
+__device__ void fill_frags_t(__bf16 *frag, const float *__restrict__ P, int tiles, int chunks) {
+    const int total = tiles * chunks * 64 * 8;
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {
+        const int j = e & 7, lane = (e >> 3) & 63, tc = e >> 9;
+        const int c = tc % chunks, t = tc / chunks;
+        const int row = t * 32 + (lane & 31), hi = lane >> 5;
+        // base.wo has 16 real outputs: its single chunk maps slot j -> neuron rowc(j) + 4 hi
+        const int out = LAYER == 1 ? rowc(j) + 4 * hi : ksrc_h(c, hi, j);
+        const float w = w_of<LAYER>(P, out, row);
+        __bf16 s[3];
+        split<NT>(w, s);
+#pragma unroll
+        for (int k = 0; k < NT; ++k) frag[(((t * chunks + c) * NT + k) * 64 + lane) * 8 + j] = s[k];
+    }
+}
+
+constexpr int GRID_XH = 256, GRID_XB = 256;               // persistent workgroups (4 waves, one per SIMD)
+
+struct BwdXHArgs {
+    const float *params, *base_out, *acts;
+    SampleSrc src;
+    ren_scene_dev sc;
+    int64_t n;
+    const float *rgb, *d_rgb, *d_sigma;
+    float *d_base, *slab;
+};
+
+template <int C, int MODE>
+__global__ __launch_bounds__(256, 1) void mlp_bwd_head_x_kernel(BwdXHArgs a) {
+    using PR = Pairs<MODE>;
+    constexpr int NT = PR::NT, NP = MODE == 1 ? 1 : 2;
+    constexpr int F_WH2T = 0, F_WH1T = 2 * 4 * NT * 512, F_END = F_WH1T + 1 * 4 * NT * 512;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __bf16 *frag = reinterpret_cast<__bf16 *>(smem);
+    float *w3 = reinterpret_cast<float *>(smem + F_END * 2);                       // [C][64] (+ pad)
+    fill_frags_t<NT, 3>(frag + F_WH2T, a.params, 2, 4);                            // head.w1^T : rows = p index
+    fill_frags_t<NT, 2>(frag + F_WH1T, a.params, 1, 4);                            // head.w0^T : rows = v index
+    for (int i = threadIdx.x; i < 64 * C; i += blockDim.x) {
+        const float w = a.params[P_HWO + i];
+        w3[i] = MODE == 1 ? (float)(__bf16)w : w;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hi = lane >> 5, sl = lane & 31;
+    __bf16 *Tz = reinterpret_cast<__bf16 *>(smem + F_END * 2 + 256 * 4) + wave * (3 * NP * 32 * ST);
+    __bf16 *Ta = Tz + NP * 32 * ST, *Ta2 = Ta + NP * 32 * ST;
+    __syncthreads();
+    const int64_t n_blk = (a.n + 31) >> 5;
+
+    // bias gradients = sums of dz over samples: kept per lane (= per sample slot) and reduced over the 32 lanes of
+    // a half once at the end, like the output-layer weights
+    f32x16 acc_wh2[2][2], acc_wh1[2];
+    float acc_w3[C][32], acc_bh2[2][16], acc_bh1[2][16], acc_bh3[C];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) { acc_bh2[t][g] = 0.f; acc_bh1[t][g] = 0.f; }
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        acc_wh2[0][0][g] = 0.f; acc_wh2[0][1][g] = 0.f; acc_wh2[1][0][g] = 0.f; acc_wh2[1][1][g] = 0.f;
+        acc_wh1[0][g] = 0.f; acc_wh1[1][g] = 0.f;
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        acc_bh3[c] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) acc_w3[c][k] = 0.f;
+    }
+
+    for (int64_t blk = (int64_t)blockIdx.x * 4 + wave; blk < n_blk; blk += (int64_t)gridDim.x * 4) {
+        int zo = 0;
+        asm volatile("" : "+v"(zo));
+        const __bf16 *fr = frag + zo;
+        const float *W3 = w3 + zo;
+        const int64_t i = blk * 32 + sl;
+        const bool live = i < a.n;
+        bool sel = false;
+        float dx = 0.f, dy = 0.f, dz = 1.f;
+        if (live) sample_geom(a.src, a.sc, i, sel, dx, dy, dz);
+        float shs[8], o[8];
+        sh4_select(dx, dy, dz, hi, shs);
+        {
+            const float *bo = a.base_out + blk * (8 * 64) + lane;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) o[g] = bo[g * 64];
+        }
+        float p[2][16], q[2][16];
+        {
+            const float *ac = a.acts + blk * ACT_SAVE_FLOATS_X + lane;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) { p[t][g] = ac[((2 + t) * 16 + g) * 64]; q[t][g] = ac[((4 + t) * 16 + g) * 64]; }
+        }
+        // ---- output layer: dz3, dW3, dq -> dz2 (fp32 VALU)
+        float dz3[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            dz3[c] = live ? a.d_rgb[i * C + c] * dsoftplus_from_out(a.rgb[i * C + c], 1.f) : 0.f;
+            if (hi == 0) acc_bh3[c] += dz3[c];
+        }
+        float dz2[2][16];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const float qv = MODE == 1 ? (float)(__bf16)q[t][g] : q[t][g];
+                float dq = 0.f;
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    acc_w3[c][t * 16 + g] += dz3[c] * qv;
+                    dq += dz3[c] * W3[c * 64 + 32 * t + rowc(g) + 4 * hi];
+                }
+                dz2[t][g] = dq * dsoftplus_from_out(q[t][g], 100.f);
+                acc_bh2[t][g] += dz2[t][g];
+            }
+        // ---- dW(head.w1)[ot][it] += dz2(ot) . p(it)^T
+        stage_tile<NP>(Ta, p[0], hi, sl);
+        stage_tile<NP>(Ta2, p[1], hi, sl);
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot) {
+            stage_tile<NP>(Tz, dz2[ot], hi, sl);
+            dw_tile<NP>(acc_wh2[ot][0], Tz, Ta, hi, sl);
+            dw_tile<NP>(acc_wh2[ot][1], Tz, Ta2, hi, sl);
+        }
+        // ---- d p = W1^T dz2 ; dz1 = d p * softplus'(p)
+        f32x16 dp[2];
+#pragma unroll
+        for (int g = 0; g < 16; ++g) { dp[0][g] = 0.f; dp[1][g] = 0.f; }
+        {
+            bf16x8 bz[4][3];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) { split8<NT>(dz2[t], bz[2 * t]); split8<NT>(dz2[t] + 8, bz[2 * t + 1]); }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) mma<MODE>(dp[t], fr + F_WH2T, t, 4, c, bz[c], lane);
+        }
+        float dz1[2][16];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                dz1[t][g] = dp[t][g] * dsoftplus_from_out(p[t][g], 100.f);
+                acc_bh1[t][g] += dz1[t][g];
+            }
+        // ---- dW(head.w0)[ot] += dz1(ot) . V^T, V = [base_out(16) | SH(16)] in v order
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            stage_one<NP>(Ta, rowc(g) + 4 * hi, o[g], sl);
+            stage_one<NP>(Ta, 16 + 2 * g + hi, shs[g], sl);
+        }
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot) {
+            stage_tile<NP>(Tz, dz1[ot], hi, sl);
+            dw_tile<NP>(acc_wh1[ot], Tz, Ta, hi, sl);
+        }
+        // ---- d V = W0^T dz1 (rows 0..15 = d base_out); row 0 takes the density gradient
+        f32x16 dv;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) dv[g] = 0.f;
+        {
+            bf16x8 bz[4][3];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) { split8<NT>(dz1[t], bz[2 * t]); split8<NT>(dz1[t] + 8, bz[2 * t + 1]); }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) mma<MODE>(dv, fr + F_WH1T, 0, 4, c, bz[c], lane);
+        }
+        if (hi == 0) {
+            const float ds = live ? a.d_sigma[i] : 0.f;
+            dv[0] = sel ? ds * __expf(fminf(o[0] - 1.f, 15.f)) : 0.f;              // ngp.py:54-58,247-250
+        }
+        {
+            float *db = a.d_base + blk * (8 * 64) + lane;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) db[g * 64] = dv[g];
+        }
+    }
+    // ---- slab (head part of the parameter block), same layout as ren_mlp.hip
+    float *slab = a.slab + ((int64_t)blockIdx.x * 4 + wave) * (p_total(C) - P_BASE_N);
+    constexpr int O = -P_BASE_N;
+#pragma unroll
+    for (int ob = 0; ob < 2; ++ob) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const int out = 32 * ob + rowc(g) + 4 * hi;
+            slab[O + P_HW1 + out * 64 + sl] = acc_wh2[ob][0][g];
+            slab[O + P_HW1 + out * 64 + 32 + sl] = acc_wh2[ob][1][g];
+            if (sl != 0) slab[O + P_HW0 + out * 31 + (sl < 16 ? 15 + sl : sl - 16)] = acc_wh1[ob][g];
+        }
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {                              // bias: sum over the 32 sample lanes of this half
+            float b2 = acc_bh2[ob][g], b1 = acc_bh1[ob][g];
+#pragma unroll
+            for (int off = 1; off < 32; off <<= 1) { b2 += __shfl_xor(b2, off, 64); b1 += __shfl_xor(b1, off, 64); }
+            if (sl == 0) { slab[O + P_HB1 + 32 * ob + rowc(g) + 4 * hi] = b2; slab[O + P_HB0 + 32 * ob + rowc(g) + 4 * hi] = b1; }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            float v = acc_w3[c][k];
+#pragma unroll
+            for (int off = 1; off < 32; off <<= 1) v += __shfl_xor(v, off, 64);
+            if (sl == 0) slab[O + P_HWO + c * 64 + 32 * (k >> 4) + rowc(k & 15) + 4 * hi] = v;
+        }
+        const float b3 = ren_wave_sum(acc_bh3[c]);
+        if (lane == 0) slab[O + P_HWO + 64 * C + c] = b3;
+    }
+}
+
+struct BwdXBArgs {
+    const float *params, *feat, *d_base, *acts;
+    int64_t n;
+    float *dfeat, *slab;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void mlp_bwd_base_x_kernel(BwdXBArgs a) {
+    using PR = Pairs<MODE>;
+    constexpr int NT = PR::NT, NP = MODE == 1 ? 1 : 2;
+    constexpr int F_W2T = 0, F_W1T = 2 * 1 * NT * 512, F_END = F_W1T + 1 * 4 * NT * 512;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __bf16 *frag = reinterpret_cast<__bf16 *>(smem);
+    fill_frags_t<NT, 1>(frag + F_W2T, a.params, 2, 1);                             // base.wo^T : rows = h index, 1 chunk (16 outs)
+    fill_frags_t<NT, 0>(frag + F_W1T, a.params, 1, 4);                             // base.w0^T : rows = feature index
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hi = lane >> 5, sl = lane & 31;
+    __bf16 *Tz = reinterpret_cast<__bf16 *>(smem + F_END * 2) + wave * (2 * NP * 32 * ST);
+    __bf16 *Ta = Tz + NP * 32 * ST;
+    for (int k = lane; k < 2 * NP * 32 * ST; k += 64) Tz[k] = (__bf16)0.f;          // dO rows 16..31 stay zero
+    __syncthreads();
+    const int64_t n_blk = (a.n + 31) >> 5;
+    f32x16 acc_w2[2], acc_w1[2];
+    float acc_b2[8], acc_b1[2][16];
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        acc_w2[0][g] = 0.f; acc_w2[1][g] = 0.f; acc_w1[0][g] = 0.f; acc_w1[1][g] = 0.f;
+        acc_b1[0][g] = 0.f; acc_b1[1][g] = 0.f;
+        if (g < 8) acc_b2[g] = 0.f;
+    }
+
+    for (int64_t blk = (int64_t)blockIdx.x * 4 + wave; blk < n_blk; blk += (int64_t)gridDim.x * 4) {
+        int zo = 0;
+        asm volatile("" : "+v"(zo));
+        const __bf16 *fr = frag + zo;
+        float x[16], dob[8], h[2][16];
+        {
+            const float *f = a.feat + blk * (16 * 64) + lane;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) x[s] = f[s * 64];
+            const float *db = a.d_base + blk * (8 * 64) + lane;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) dob[g] = db[g * 64];
+            const float *ac = a.acts + blk * ACT_SAVE_FLOATS_X + lane;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) h[t][g] = ac[(t * 16 + g) * 64];
+        }
+        // ---- dW(base.wo)[it] += dO . h(it)^T   (dO: 16 real rows of a 32-row tile)
+#pragma unroll
+        for (int g = 0; g < 8; ++g) { stage_one<NP>(Tz, rowc(g) + 4 * hi, dob[g], sl); acc_b2[g] += dob[g]; }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            stage_tile<NP>(Ta, h[it], hi, sl);
+            dw_tile<NP>(acc_w2[it], Tz, Ta, hi, sl);
+        }
+        // ---- d h = Wo^T dO (one k-chunk: slot j -> base_out neuron rowc(j) + 4 hi) ; dz0 = d h * softplus'(h)
+        f32x16 dh[2];
+#pragma unroll
+        for (int g = 0; g < 16; ++g) { dh[0][g] = 0.f; dh[1][g] = 0.f; }
+        {
+            bf16x8 bo[3];
+            split8<NT>(dob, bo);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) mma<MODE>(dh[t], fr + F_W2T, t, 1, 0, bo, lane);
+        }
+        float dz0[2][16];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                dz0[t][g] = dh[t][g] * dsoftplus_from_out(h[t][g], 100.f);
+                acc_b1[t][g] += dz0[t][g];
+            }
+        // ---- dW(base.w0)[ot] += dz0(ot) . x^T   (x row = feature index 2 s + hi)
+#pragma unroll
+        for (int s = 0; s < 16; ++s) stage_one<NP>(Ta, 2 * s + hi, x[s], sl);
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot) {
+            // Tz rows 16..31 are overwritten here; the dO staging of the next block rewrites rows 0..15 only,
+            // so the zero rows are restored below
+            stage_tile<NP>(Tz, dz0[ot], hi, sl);
+            dw_tile<NP>(acc_w1[ot], Tz, Ta, hi, sl);
+        }
+#pragma unroll
+        for (int g = 8; g < 16; ++g) stage_one<NP>(Tz, rowc(g) + 4 * hi, 0.f, sl);
+        // ---- d x = W0^T dz0 -> hash-feature gradient, fragment layout
+        f32x16 dxv;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) dxv[g] = 0.f;
+        {
+            bf16x8 bz[4][3];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) { split8<NT>(dz0[t], bz[2 * t]); split8<NT>(dz0[t] + 8, bz[2 * t + 1]); }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) mma<MODE>(dxv, fr + F_W1T, 0, 4, c, bz[c], lane);
+        }
+        {
+            float *df = a.dfeat + blk * (16 * 64) + sl;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int f = rowc(g) + 4 * hi;                    // feature index = 2*level + parity
+                df[(f >> 1) * 64 + (f & 1) * 32] = dxv[g];
+            }
+        }
+    }
+    float *slab = a.slab + ((int64_t)blockIdx.x * 4 + wave) * P_BASE_N;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        const int out = rowc(g) + 4 * hi;
+        if (out < 16) {
+            slab[P_BWO + out * 64 + sl] = acc_w2[0][g];
+            slab[P_BWO + out * 64 + 32 + sl] = acc_w2[1][g];
+        }
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob) slab[P_BW0 + (32 * ob + out) * 32 + sl] = acc_w1[ob][g];
+    }
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        float b2 = g < 8 ? acc_b2[g] : 0.f, b10 = acc_b1[0][g], b11 = acc_b1[1][g];
+#pragma unroll
+        for (int off = 1; off < 32; off <<= 1) {
+            b2 += __shfl_xor(b2, off, 64); b10 += __shfl_xor(b10, off, 64); b11 += __shfl_xor(b11, off, 64);
+        }
+        if (sl == 0) {
+            if (g < 8) slab[P_BBO + rowc(g) + 4 * hi] = b2;
+            slab[P_BB0 + rowc(g) + 4 * hi] = b10;
+            slab[P_BB0 + 32 + rowc(g) + 4 * hi] = b11;
+        }
+    }
+}
+
+template <int MODE>
+int launch_bwd_x(const BwdXHArgs &h, const BwdXBArgs &b, int C, float *grad, hipStream_t st) {
+    constexpr int NT = Pairs<MODE>::NT, NP = MODE == 1 ? 1 : 2;
+    const size_t tile = (size_t)NP * 32 * ST * 2;
+    const size_t lds_h = (size_t)(2 * 4 + 4) * NT * 512 * 2 + 256 * 4 + 4 * 3 * tile;
+    const size_t lds_b = (size_t)(2 * 1 + 4) * NT * 512 * 2 + 4 * 2 * tile;
+    if (C == 1) {
+        (void)hipFuncSetAttribute((const void *)mlp_bwd_head_x_kernel<1, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h);
+        hipLaunchKernelGGL((mlp_bwd_head_x_kernel<1, MODE>), dim3(GRID_XH), dim3(256), lds_h, st, h);
+    } else {
+        (void)hipFuncSetAttribute((const void *)mlp_bwd_head_x_kernel<3, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h);
+        hipLaunchKernelGGL((mlp_bwd_head_x_kernel<3, MODE>), dim3(GRID_XH), dim3(256), lds_h, st, h);
+    }
+    (void)hipFuncSetAttribute((const void *)mlp_bwd_base_x_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
+    hipLaunchKernelGGL((mlp_bwd_base_x_kernel<MODE>), dim3(GRID_XB), dim3(256), lds_b, st, b);
+    const int head_len = p_total(C) - P_BASE_N;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((head_len + 255) / 256), dim3(256), 0, st, h.slab, GRID_XH * 4, head_len,
+                       grad + P_BASE_N);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((P_BASE_N + 255) / 256), dim3(256), 0, st, b.slab, GRID_XB * 4, P_BASE_N, grad);
+    REN_CHECK_LAUNCH();
+}
+
+}  // namespace
+
+extern "C" int64_t ren_mlp_bwd_x_workspace_floats(int32_t C) {
+    if (C != 1 && C != 3) return -1;
+    return (int64_t)GRID_XH * 4 * (p_total(C) - P_BASE_N) + (int64_t)GRID_XB * 4 * P_BASE_N;
+}
+
+extern "C" int ren_mlp_bwd_x(const float *mlp_params, int32_t C, int32_t mode, const float *feat, const float *base_out,
+                             const float *act_save, const ren_scene_desc *scene, const float *x_world,
+                             const float *dirs, const float *rays_o, const float *rays_d, const int32_t *ray_indices,
+                             const float *t_starts, const float *t_ends, int64_t n, const float *rgb,
+                             const float *d_rgb, const float *d_sigma, float *d_base, float *dfeat,
+                             float *grad_mlp_params, float *workspace, void *stream) {
+    if (!mlp_params || !feat || !base_out || !act_save || !scene || !rgb || !d_rgb || !d_sigma || !d_base || !dfeat ||
+        !grad_mlp_params || !workspace || n < 0)
+        return REN_ERR_BAD_ARG;
+    if (C != 1 && C != 3) return REN_ERR_UNSUPPORTED;
+    if (mode != 1 && mode != 6) return REN_ERR_UNSUPPORTED;
+    if (!x_world && (!rays_o || !rays_d || !ray_indices || !t_starts || !t_ends)) return REN_ERR_BAD_ARG;
+    if (n == 0) return REN_OK;
+    const int head_len = p_total(C) - P_BASE_N;
+    BwdXHArgs h;
+    h.params = mlp_params; h.base_out = base_out; h.acts = act_save;
+    h.src = SampleSrc{x_world, dirs, rays_o, rays_d, x_world ? nullptr : ray_indices, t_starts, t_ends};
+    h.sc = ren_make_scene(scene);
+    h.n = n; h.rgb = rgb; h.d_rgb = d_rgb; h.d_sigma = d_sigma; h.d_base = d_base; h.slab = workspace;
+    BwdXBArgs b;
+    b.params = mlp_params; b.feat = feat; b.d_base = d_base; b.acts = act_save; b.n = n; b.dfeat = dfeat;
+    b.slab = workspace + (int64_t)GRID_XH * 4 * head_len;
+    return mode == 6 ? launch_bwd_x<6>(h, b, C, grad_mlp_params, (hipStream_t)stream)
+                     : launch_bwd_x<1>(h, b, C, grad_mlp_params, (hipStream_t)stream);
+}

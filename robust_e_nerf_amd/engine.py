@@ -41,6 +41,8 @@ class RenderCfg:
     warmup_steps: int = 256
     occ_n: int = 16
     binned_scatter: bool = True        # LDS-binned hash-grid backward (False: per-update global atomics)
+    mlp_kernels: str = "x"             # "x": split-bf16 matrix-core kernels at fp32 accuracy (csrc/ren_mlp_x.hip);
+                                       # "f32": exact f32-MFMA kernels (csrc/ren_mlp.hip)
     save_activations: bool = True      # training forward stores the hidden activations (768 B/sample) instead of
                                        # recomputing them in the backward (128 f32 MFMAs + 192 softplus per 32 samples)
     mlp_bf16: bool = False             # BASELINE configs[2]: bf16 MLP (rounded linear inputs/weights, fp32 accumulate), fp32 composite
@@ -103,7 +105,8 @@ class Renderer:
         self.occs = torch.zeros(cells, device=dev, dtype=torch.float32)
         self.binary = torch.zeros(cells, device=dev, dtype=torch.uint8)
         self._scratch = torch.zeros(4, device=dev, dtype=torch.float32)
-        self._ws = torch.empty(ops.mlp_bwd_workspace_floats(fld.C), device=dev, dtype=torch.float32)
+        self._ws = torch.empty(max(ops.mlp_bwd_workspace_floats(fld.C), ops.mlp_bwd_x_workspace_floats(fld.C)),
+                               device=dev, dtype=torch.float32)
         self._bin_ws = None
 
     # ---- sampling (K1-K3): ray/AABB, two-pass march, no-grad density pre-pass + visibility --------
@@ -144,14 +147,25 @@ class Renderer:
     def _density_stream(self, o, d, samples, n):
         feat = ops.hashgrid_fwd(self.field.grid, self.field.table, scene=self.scene, rays=(o, d),
                                 samples=samples, n=n, layout=1)
+        if self.cfg.mlp_kernels == "x":
+            _, sigma, _, _ = ops.mlp_fwd_x(self.field.mlp, self.field.C, self._xmode(), feat, self.scene, rays=(o, d),
+                                           samples=samples, n=n, density_only=True)
+            return sigma
         _, sigma, _ = ops.mlp_fwd(self._mlp_params(), self.field.C, feat, self.scene, rays=(o, d),
                                   samples=samples, n=n, density_only=True, bf16=self.cfg.mlp_bf16)
         return sigma
+
+    def _xmode(self) -> int:
+        return 1 if self.cfg.mlp_bf16 else 6
 
     def _field_forward(self, o, d, pk, save):
         f = self.field
         samples = (pk.ray_indices, pk.t_starts, pk.t_ends)
         feat = ops.hashgrid_fwd(f.grid, f.table, scene=self.scene, rays=(o, d), samples=samples, n=pk.n, layout=1)
+        if self.cfg.mlp_kernels == "x":
+            rgb, sigma, base, acts = ops.mlp_fwd_x(f.mlp, f.C, self._xmode(), feat, self.scene, rays=(o, d), samples=samples,
+                                                   n=pk.n, save=save)
+            return rgb, sigma, dict(feat=feat, base=base, acts=acts, xmode=self._xmode() if save else None)
         mp = self._mlp_params()
         if save and self.cfg.save_activations:
             rgb, sigma, base, acts = ops.mlp_fwd_save(mp, f.C, feat, self.scene, rays=(o, d), samples=samples, n=pk.n,
@@ -165,7 +179,11 @@ class Renderer:
         f, pk = self.field, ctx["pk"]
         samples = (pk.ray_indices, pk.t_starts, pk.t_ends)
         mp = ctx.get("mlp_params")                      # absent when the forward ran on the (fp32) tangent kernels
-        if ctx.get("acts") is not None:
+        if ctx.get("xmode") is not None:
+            dfeat = ops.mlp_bwd_x(f.mlp, f.C, ctx["xmode"], ctx["feat"], ctx["base"], ctx["acts"], self.scene,
+                                  rays=(ctx["o"], ctx["d"]), samples=samples, n=pk.n, rgb=ctx["rgb"], d_rgb=d_rgb,
+                                  d_sigma=d_sig, grad_mlp_params=f.g_mlp, workspace=self._ws)
+        elif ctx.get("acts") is not None:
             dfeat = ops.mlp_bwd_saved(mp, f.C, ctx["feat"], ctx["base"], ctx["acts"], self.scene, rays=(ctx["o"], ctx["d"]),
                                       samples=samples, n=pk.n, rgb=ctx["rgb"], d_rgb=d_rgb, d_sigma=d_sig,
                                       grad_mlp_params=f.g_mlp, workspace=self._ws, bf16=self.cfg.mlp_bf16)
@@ -222,6 +240,8 @@ class Renderer:
         n = x_world.shape[0]
         xu = contract_points(x_world, self.cfg.aabb, self.cfg.contraction_type)
         feat = ops.hashgrid_fwd(f.grid, f.table, x_unit=xu, n=n, layout=1)
+        if self.cfg.mlp_kernels == "x":
+            return ops.mlp_fwd_x(f.mlp, f.C, self._xmode(), feat, self.scene, x_world=x_world, n=n, density_only=True)[1]
         _, sigma, _ = ops.mlp_fwd(self._mlp_params(), f.C, feat, self.scene, x_world=x_world, n=n, density_only=True,
                                   bf16=self.cfg.mlp_bf16)
         return sigma

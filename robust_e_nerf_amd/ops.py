@@ -300,6 +300,43 @@ def mlp_bwd_saved(mlp_params, C: int, feat, base_out, acts, scene: SceneDesc, *,
     return dfeat
 
 
+def mlp_fwd_x(mlp_params, C: int, mode: int, feat, scene: SceneDesc, *, rays=None, samples=None, x_world=None, dirs=None,
+              n: int, density_only: bool = False, save: bool = False):
+    """Split-bf16 matrix-core kernels (csrc/ren_mlp_x.hip).  mode 6: fp32 accuracy; mode 1: plain bf16 operands.
+    -> rgb, sigma, base, acts (base/acts None unless save)"""
+    dev = feat.device
+    o, d = rays if rays is not None else (None, None)
+    ri, ts, te = samples if samples is not None else (None, None, None)
+    lib = _lib.load()
+    sigma = torch.empty(n, device=dev, dtype=torch.float32)
+    rgb = None if density_only else torch.empty(n, C, device=dev, dtype=torch.float32)
+    base = torch.empty(n_blocks32(n) * BASE_FLOATS_PER_BLOCK, device=dev, dtype=torch.float32) if save else None
+    acts = torch.empty(int(lib.ren_mlp_act_save_floats(n)), device=dev, dtype=torch.float32) if save else None
+    check(lib.ren_mlp_fwd_x(_ptr(mlp_params, torch.float32), C, mode, _ptr(feat, torch.float32), ctypes.byref(scene),
+                            _ptr(x_world), _ptr(dirs), _ptr(o), _ptr(d), _ptr(ri), _ptr(ts), _ptr(te), n,
+                            1 if density_only else 0, _ptr(rgb), _ptr(sigma), _ptr(base), _ptr(acts), _stream()),
+          "ren_mlp_fwd_x")
+    return rgb, sigma, base, acts
+
+
+def mlp_bwd_x_workspace_floats(C: int) -> int:
+    return int(_lib.load().ren_mlp_bwd_x_workspace_floats(C))
+
+
+def mlp_bwd_x(mlp_params, C: int, mode: int, feat, base_out, acts, scene: SceneDesc, *, rays=None, samples=None,
+              x_world=None, dirs=None, n: int, rgb, d_rgb, d_sigma, grad_mlp_params, workspace):
+    dev = feat.device
+    o, d = rays if rays is not None else (None, None)
+    ri, ts, te = samples if samples is not None else (None, None, None)
+    d_base = torch.empty(n_blocks32(n) * BASE_FLOATS_PER_BLOCK, device=dev, dtype=torch.float32)
+    dfeat = torch.empty(n_blocks32(n) * FRAG_FLOATS_PER_BLOCK, device=dev, dtype=torch.float32)
+    check(_lib.load().ren_mlp_bwd_x(_ptr(mlp_params, torch.float32), C, mode, _ptr(feat), _ptr(base_out), _ptr(acts),
+                                    ctypes.byref(scene), _ptr(x_world), _ptr(dirs), _ptr(o), _ptr(d), _ptr(ri), _ptr(ts),
+                                    _ptr(te), n, _ptr(rgb), _ptr(d_rgb), _ptr(d_sigma), _ptr(d_base), _ptr(dfeat),
+                                    _ptr(grad_mlp_params, torch.float32), _ptr(workspace), _stream()), "ren_mlp_bwd_x")
+    return dfeat
+
+
 def mlp_bwd_workspace_floats(C: int) -> int:
     return int(_lib.load().ren_mlp_bwd_workspace_floats(C))
 
@@ -421,7 +458,7 @@ def occgrid_binarize(occs, occ_thre: float, binary, scratch):
 _PROFILE = None
 _TIMED = ("ray_aabb_intersect", "ray_march_count", "ray_march_write", "exclusive_scan", "visibility",
           "compact_samples", "hashgrid_fwd", "hashgrid_bwd", "hashgrid_bwd_binned", "mlp_fwd", "mlp_bwd", "mlp_fwd_save",
-          "mlp_bwd_saved", "composite_fwd",
+          "mlp_bwd_saved", "mlp_fwd_x", "mlp_bwd_x", "composite_fwd",
           "composite_bwd", "column_sum", "event_loss_fwd", "event_loss_bwd", "adam_step", "trajectory", "raygen")
 
 
