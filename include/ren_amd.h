@@ -100,7 +100,7 @@ int ren_ray_march(const float *rays_o, const float *rays_d, const float *t_min,
                   int32_t *ray_indices, float *t_starts, float *t_ends, void *stream);
 /* exclusive cumsum of counts[n] (int32) -> offsets[n] (int64), total[1] (int64) */
 int ren_exclusive_scan(const int32_t *counts, int64_t n, int64_t *offsets, int64_t *total,
-                       void *stream);
+                       int64_t *scratch1024 /* int64[1024] device scratch, may be NULL (slow path) */, void *stream);
 /* nerfacc.render_visibility inside ray_marching (sigma_fn branch): per ray
  * T = excl. cumprod(1-alpha); keep = T >= early_stop_eps (& alpha >= alpha_thre if >0).
  * Writes keep[n] (uint8) and kept_counts[n_rays]. */
@@ -423,8 +423,8 @@ int ren_vanilla_heads_bwd(const float *g_rgb, const float *rgb, const float *g_s
                           int64_t n, int32_t C, float *dz_rgb, float *dz_sigma, void *stream);
 
 /* ---- utilities ------------------------------------------------------------------------------------- */
-/* out[c] = sum_r in[r*C + c]   (C <= 4) */
-int ren_column_sum(const float *in, int64_t rows, int32_t C, float *out, void *stream);
+/* out[c] = sum_r in[r*C + c]   (C <= 4); scratch512: 512 floats of device scratch (two-stage, deterministic) */
+int ren_column_sum(const float *in, int64_t rows, int32_t C, float *out, float *scratch512, void *stream);
 
 #ifdef __cplusplus
 }

@@ -40,7 +40,7 @@ SIGNATURES = {
     "ren_ray_aabb_intersect": (c_int, [P, P, c_int64, POINTER(c_float), c_float, c_float, P, P, P]),
     "ren_ray_march": (c_int, [P, P, P, P, P, c_int64, POINTER(c_float), POINTER(c_int32), P, c_int32,
                               c_float, c_float, c_int32, c_int32, P, P, P, P, P, P]),
-    "ren_exclusive_scan": (c_int, [P, c_int64, P, P, P]),
+    "ren_exclusive_scan": (c_int, [P, c_int64, P, P, P, P]),
     "ren_visibility": (c_int, [P, P, c_int64, P, P, P, c_float, c_float, P, P, P]),
     "ren_compact_samples": (c_int, [P, P, P, c_int64, P, P, P, P, P, P, P]),
     "ren_pack_info": (c_int, [P, c_int64, c_int64, P, P, P]),
@@ -70,7 +70,7 @@ SIGNATURES = {
     "ren_occgrid_cell_points": (c_int, [P, P, c_int64, POINTER(c_float), POINTER(c_int32), c_int32, P, P, P]),
     "ren_occgrid_ema": (c_int, [P, P, P, P, P, c_float, c_int64, c_float, P]),
     "ren_occgrid_binarize": (c_int, [P, c_int64, c_float, P, P, P]),
-    "ren_column_sum": (c_int, [P, c_int64, c_int32, P, P]),
+    "ren_column_sum": (c_int, [P, c_int64, c_int32, P, P, P]),
     "ren_trajectory_jvp": (c_int, [P, c_int64, P, P, P, c_int64, P, P, P, P, P]),
     "ren_raygen_jvp": (c_int, [P, P, P, P, P, P, c_int64, P, P, P, P, P]),
     "ren_hashgrid_fwd_jvp": (c_int, [POINTER(GridDesc), P, POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, P, P, P]),

@@ -129,8 +129,12 @@ struct FwdXArgs {
 
 constexpr int ACT_SAVE_FLOATS_X = 3 * 2 * 16 * 64;            // same layout as ren_mlp.hip's ACT_SAVE_FLOATS
 
+// 8 waves share one 63 KB fragment image, two workgroups per CU: four waves per SIMD, so one wave's split /
+// softplus VALU work runs under another's bf16 MFMAs (which, unlike the f32 MFMA, do co-issue with the VALU)
+constexpr int FWD_X_WAVES = 8;
+
 template <int C, int MODE, bool DENSITY_ONLY>
-__global__ __launch_bounds__(256, 2) void mlp_fwd_x_kernel(FwdXArgs a) {
+__global__ __launch_bounds__(64 * FWD_X_WAVES, 2) void mlp_fwd_x_kernel(FwdXArgs a) {
     using PR = Pairs<MODE>;
     constexpr int NT = PR::NT;
     using L = XL<NT>;
@@ -156,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_x_kernel(FwdXArgs a) {
     const int hi = lane >> 5, sl = lane & 31;
     const int64_t n_blk = (a.n + 31) >> 5;
 
-    for (int64_t blk = (int64_t)blockIdx.x * 4 + wave; blk < n_blk; blk += (int64_t)gridDim.x * 4) {
+    for (int64_t blk = (int64_t)blockIdx.x * FWD_X_WAVES + wave; blk < n_blk; blk += (int64_t)gridDim.x * FWD_X_WAVES) {
         int zo = 0;                                             // keep the (loop-invariant) LDS reads inside the loop
         asm volatile("" : "+v"(zo));
         const __bf16 *fr = frag + zo;
@@ -291,9 +295,9 @@ template <int MODE>
 int launch_fwd_x(const FwdXArgs &a, int C, bool density_only, hipStream_t st) {
     using L = XL<Pairs<MODE>::NT>;
     const int64_t n_blk = (a.n + 31) / 32;
-    int64_t blocks = (n_blk + 3) / 4;
+    int64_t blocks = (n_blk + FWD_X_WAVES - 1) / FWD_X_WAVES;
     if (blocks > 512) blocks = 512;                             // two workgroups per CU
-    const dim3 grd((int)blocks), blk(256);
+    const dim3 grd((int)blocks), blk(64 * FWD_X_WAVES);
 #define REN_X(CC, DO)                                                                                       \
     do {                                                                                                    \
         (void)hipFuncSetAttribute((const void *)mlp_fwd_x_kernel<CC, MODE, DO>,                             \

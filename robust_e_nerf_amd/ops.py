@@ -136,8 +136,9 @@ def exclusive_scan(counts: torch.Tensor):
     n = counts.shape[0]
     offsets = torch.empty(n, device=counts.device, dtype=torch.int64)
     total = torch.empty(1, device=counts.device, dtype=torch.int64)
-    check(_lib.load().ren_exclusive_scan(_ptr(counts, torch.int32), n, _ptr(offsets), _ptr(total), _stream()),
-          "ren_exclusive_scan")
+    scratch = torch.empty(1024, device=counts.device, dtype=torch.int64)
+    check(_lib.load().ren_exclusive_scan(_ptr(counts, torch.int32), n, _ptr(offsets), _ptr(total), _ptr(scratch),
+                                         _stream()), "ren_exclusive_scan")
     return offsets, total
 
 
@@ -392,7 +393,9 @@ def composite_bwd(offsets, counts, ts, te, sigmas, rgbs, C: int, bkgd, w, T, opa
 def column_sum(x: torch.Tensor):
     rows, C = x.shape
     out = torch.empty(C, device=x.device, dtype=torch.float32)
-    check(_lib.load().ren_column_sum(_ptr(x, torch.float32), rows, C, _ptr(out), _stream()), "ren_column_sum")
+    scratch = torch.empty(512, device=x.device, dtype=torch.float32)
+    check(_lib.load().ren_column_sum(_ptr(x, torch.float32), rows, C, _ptr(out), _ptr(scratch), _stream()),
+          "ren_column_sum")
     return out
 
 

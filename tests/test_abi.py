@@ -34,14 +34,14 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_abi_version_and_build_info(lib):
-    assert lib.ren_abi_version() == 8
+    assert lib.ren_abi_version() == 9
     assert b"gfx950" in lib.ren_build_info()
 
 
 def test_argument_validation_without_gpu(lib):
     """Error conventions: bad arguments return REN_ERR_BAD_ARG / UNSUPPORTED before any launch."""
     from robust_e_nerf_amd import _lib
-    assert lib.ren_exclusive_scan(None, 4, None, None, None) == _lib.REN_ERR_BAD_ARG
+    assert lib.ren_exclusive_scan(None, 4, None, None, None, None) == _lib.REN_ERR_BAD_ARG
     assert lib.ren_mlp_bwd_workspace_floats(2) == -1
     assert lib.ren_mlp_bwd_workspace_floats(1) > 0
     assert lib.ren_column_sum(None, 1, 1, None, None) == _lib.REN_ERR_BAD_ARG
