@@ -44,7 +44,7 @@ def test_argument_validation_without_gpu(lib):
     assert lib.ren_exclusive_scan(None, 4, None, None, None, None) == _lib.REN_ERR_BAD_ARG
     assert lib.ren_mlp_bwd_workspace_floats(2) == -1
     assert lib.ren_mlp_bwd_workspace_floats(1) > 0
-    assert lib.ren_column_sum(None, 1, 1, None, None) == _lib.REN_ERR_BAD_ARG
+    assert lib.ren_column_sum(None, 1, 1, None, None, None) == _lib.REN_ERR_BAD_ARG
     with pytest.raises(ValueError):
         _lib.check(_lib.REN_ERR_BAD_ARG, "x")
     with pytest.raises(NotImplementedError):
