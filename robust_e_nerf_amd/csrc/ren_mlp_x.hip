@@ -106,6 +106,30 @@ __device__ __forceinline__ void mma(f32x16 &acc, const __bf16 *frag, int t, int 
         acc = MFMAB(ldfrag<PR::NT>(frag, t, chunks, c, PR::W[k], lane), b[PR::A[k]], acc);
 }
 
+// two output tiles that share the B operand, interleaved: consecutive MFMAs never hit the same accumulator,
+// so the matrix pipe does not wait on the dependent-accumulate latency
+template <int MODE>
+__device__ __forceinline__ void mma2(f32x16 &acc0, f32x16 &acc1, const __bf16 *frag, int chunks, int c,
+                                     const bf16x8 (&b)[3], int lane) {
+    using PR = Pairs<MODE>;
+#pragma unroll
+    for (int k = 0; k < PR::N; ++k) {
+        acc0 = MFMAB(ldfrag<PR::NT>(frag, 0, chunks, c, PR::W[k], lane), b[PR::A[k]], acc0);
+        acc1 = MFMAB(ldfrag<PR::NT>(frag, 1, chunks, c, PR::W[k], lane), b[PR::A[k]], acc1);
+    }
+}
+// one output tile, two k-chunks into two independent partial accumulators
+template <int MODE>
+__device__ __forceinline__ void mma1x2(f32x16 &acca, f32x16 &accb, const __bf16 *frag, int chunks, int ca, int cb,
+                                       const bf16x8 (&ba)[3], const bf16x8 (&bb)[3], int lane) {
+    using PR = Pairs<MODE>;
+#pragma unroll
+    for (int k = 0; k < PR::N; ++k) {
+        acca = MFMAB(ldfrag<PR::NT>(frag, 0, chunks, ca, PR::W[k], lane), ba[PR::A[k]], acca);
+        accb = MFMAB(ldfrag<PR::NT>(frag, 0, chunks, cb, PR::W[k], lane), bb[PR::A[k]], accb);
+    }
+}
+
 // LDS image (bytes): fragments, then f32 biases and the output layer
 template <int NT> struct XL {
     static constexpr int F_W1 = 0;                              // 2 tiles x 2 chunks
@@ -180,12 +204,11 @@ __global__ __launch_bounds__(64 * FWD_X_WAVES, 2) void mlp_fwd_x_kernel(FwdXArgs
         // ---- base layer 0: 32 -> 64, softplus(beta = 100)
         f32x16 h[2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int g = 0; g < 16; ++g) h[t][g] = tl[L::T_B1 + 32 * t + rowc(g) + 4 * hi];
 #pragma unroll
-            for (int c = 0; c < 2; ++c) mma<MODE>(h[t], fr + L::F_W1, t, 2, c, bx[c], lane);
-        }
+        for (int c = 0; c < 2; ++c) mma2<MODE>(h[0], h[1], fr + L::F_W1, 2, c, bx[c], lane);
         bf16x8 bh[4][3];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -201,11 +224,13 @@ __global__ __launch_bounds__(64 * FWD_X_WAVES, 2) void mlp_fwd_x_kernel(FwdXArgs
             split8<NT>(y + 8, bh[2 * t + 1]);
         }
         // ---- base output: 64 -> 16 (rows 16..31 of the tile are zero)
-        f32x16 o;
+        f32x16 o, o2;
 #pragma unroll
-        for (int g = 0; g < 16; ++g) o[g] = tl[L::T_B2 + rowc(g) + 4 * hi];
+        for (int g = 0; g < 16; ++g) { o[g] = tl[L::T_B2 + rowc(g) + 4 * hi]; o2[g] = 0.f; }
+        mma1x2<MODE>(o, o2, fr + L::F_W2, 4, 0, 1, bh[0], bh[1], lane);
+        mma1x2<MODE>(o, o2, fr + L::F_W2, 4, 2, 3, bh[2], bh[3], lane);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) mma<MODE>(o, fr + L::F_W2, 0, 4, c, bh[c], lane);
+        for (int g = 0; g < 16; ++g) o[g] += o2[g];
         bool sel = false;
         float dx = 0.f, dy = 0.f, dz = 1.f;
         if (live) sample_geom(a.src, a.sc, i, sel, dx, dy, dz);
@@ -228,12 +253,11 @@ __global__ __launch_bounds__(64 * FWD_X_WAVES, 2) void mlp_fwd_x_kernel(FwdXArgs
         }
         f32x16 p[2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int g = 0; g < 16; ++g) p[t][g] = tl[L::T_BH1 + 32 * t + rowc(g) + 4 * hi];
 #pragma unroll
-            for (int c = 0; c < 2; ++c) mma<MODE>(p[t], fr + L::F_WH1, t, 2, c, bv[c], lane);
-        }
+        for (int c = 0; c < 2; ++c) mma2<MODE>(p[0], p[1], fr + L::F_WH1, 2, c, bv[c], lane);
         bf16x8 bp[4][3];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -251,12 +275,11 @@ __global__ __launch_bounds__(64 * FWD_X_WAVES, 2) void mlp_fwd_x_kernel(FwdXArgs
         // ---- head layer 1: 64 -> 64
         f32x16 q[2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int g = 0; g < 16; ++g) q[t][g] = tl[L::T_BH2 + 32 * t + rowc(g) + 4 * hi];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) mma<MODE>(q[t], fr + L::F_WH2, t, 4, c, bp[c], lane);
-        }
+        for (int c = 0; c < 4; ++c) mma2<MODE>(q[0], q[1], fr + L::F_WH2, 4, c, bp[c], lane);
         // ---- head output: 64 -> C on the VALU in fp32 (MODE 1: bf16-rounded operands, as every other layer)
         float acc[C];
 #pragma unroll
@@ -519,9 +542,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_head_x_kernel(BwdXHArgs a) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) { split8<NT>(dz2[t], bz[2 * t]); split8<NT>(dz2[t] + 8, bz[2 * t + 1]); }
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) mma<MODE>(dp[t], fr + F_WH2T, t, 4, c, bz[c], lane);
+            for (int c = 0; c < 4; ++c) mma2<MODE>(dp[0], dp[1], fr + F_WH2T, 4, c, bz[c], lane);
         }
         float dz1[2][16];
 #pragma unroll
@@ -543,15 +564,17 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_head_x_kernel(BwdXHArgs a) {
             dw_tile<NP>(acc_wh1[ot], Tz, Ta, hi, sl);
         }
         // ---- d V = W0^T dz1 (rows 0..15 = d base_out); row 0 takes the density gradient
-        f32x16 dv;
+        f32x16 dv, dv2;
 #pragma unroll
-        for (int g = 0; g < 16; ++g) dv[g] = 0.f;
+        for (int g = 0; g < 16; ++g) { dv[g] = 0.f; dv2[g] = 0.f; }
         {
             bf16x8 bz[4][3];
 #pragma unroll
             for (int t = 0; t < 2; ++t) { split8<NT>(dz1[t], bz[2 * t]); split8<NT>(dz1[t] + 8, bz[2 * t + 1]); }
+            mma1x2<MODE>(dv, dv2, fr + F_WH1T, 4, 0, 1, bz[0], bz[1], lane);
+            mma1x2<MODE>(dv, dv2, fr + F_WH1T, 4, 2, 3, bz[2], bz[3], lane);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) mma<MODE>(dv, fr + F_WH1T, 0, 4, c, bz[c], lane);
+            for (int g = 0; g < 16; ++g) dv[g] += dv2[g];
         }
         if (hi == 0) {
             const float ds = live ? a.d_sigma[i] : 0.f;
@@ -661,8 +684,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_base_x_kernel(BwdXBArgs a) {
         {
             bf16x8 bo[3];
             split8<NT>(dob, bo);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) mma<MODE>(dh[t], fr + F_W2T, t, 1, 0, bo, lane);
+            mma2<MODE>(dh[0], dh[1], fr + F_W2T, 1, 0, bo, lane);
         }
         float dz0[2][16];
 #pragma unroll
@@ -685,15 +707,17 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_base_x_kernel(BwdXBArgs a) {
 #pragma unroll
         for (int g = 8; g < 16; ++g) stage_one<NP>(Tz, rowc(g) + 4 * hi, 0.f, sl);
         // ---- d x = W0^T dz0 -> hash-feature gradient, fragment layout
-        f32x16 dxv;
+        f32x16 dxv, dxv2;
 #pragma unroll
-        for (int g = 0; g < 16; ++g) dxv[g] = 0.f;
+        for (int g = 0; g < 16; ++g) { dxv[g] = 0.f; dxv2[g] = 0.f; }
         {
             bf16x8 bz[4][3];
 #pragma unroll
             for (int t = 0; t < 2; ++t) { split8<NT>(dz0[t], bz[2 * t]); split8<NT>(dz0[t] + 8, bz[2 * t + 1]); }
+            mma1x2<MODE>(dxv, dxv2, fr + F_W1T, 4, 0, 1, bz[0], bz[1], lane);
+            mma1x2<MODE>(dxv, dxv2, fr + F_W1T, 4, 2, 3, bz[2], bz[3], lane);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) mma<MODE>(dxv, fr + F_W1T, 0, 4, c, bz[c], lane);
+            for (int g = 0; g < 16; ++g) dxv[g] += dxv2[g];
         }
         {
             float *df = a.dfeat + blk * (16 * 64) + sl;

@@ -18,6 +18,8 @@ GROUPS = {  # C-ABI call -> (kernel-name fragment, launches of that kernel per c
                             ("bin_accumulate_kernel", 1)],
     "mlp_fwd": [("mlp_fwd_kernel", 1)],
     "mlp_bwd": [("mlp_bwd_head_kernel", 1), ("mlp_bwd_base_kernel", 1), ("reduce_slabs_kernel", 2)],
+    "mlp_fwd_x": [("mlp_fwd_x_kernel", 1)],
+    "mlp_bwd_x": [("mlp_bwd_head_x_kernel", 1), ("mlp_bwd_base_x_kernel", 1), ("reduce_slabs_kernel", 2)],
     "mlp_fwd_save": [("mlp_fwd_kernel", 1)],
     "mlp_bwd_saved": [("mlp_bwd_head_kernel", 1), ("mlp_bwd_base_kernel", 1), ("reduce_slabs_kernel", 2)],
 }
