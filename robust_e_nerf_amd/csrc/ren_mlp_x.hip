@@ -381,6 +381,18 @@ __device__ __forceinline__ void stage_tile(__bf16 *T, const float *v, int hi, in
         for (int k = 0; k < NP; ++k) T[(k * 32 + rowc(g) + 4 * hi) * ST + sl] = s[k];
     }
 }
+// the same from already split operands (b0 = registers 0..7, b1 = registers 8..15 of the tile): the first NP
+// pieces of the 3-way split ARE the NP-way split, so values that also feed a data-gradient MFMA are split once
+template <int NP>
+__device__ __forceinline__ void stage_pieces(__bf16 *T, const bf16x8 (&b0)[3], const bf16x8 (&b1)[3], int hi, int sl) {
+#pragma unroll
+    for (int k = 0; k < NP; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            T[(k * 32 + rowc(j) + 4 * hi) * ST + sl] = b0[k][j];
+            T[(k * 32 + rowc(8 + j) + 4 * hi) * ST + sl] = b1[k][j];
+        }
+}
 // write one value for an explicit neuron row
 template <int NP>
 __device__ __forceinline__ void stage_one(__bf16 *T, int row, float v, int sl) {
@@ -524,16 +536,9 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_head_x_kernel(BwdXHArgs a) {
                 dz2[t][g] = dq * dsoftplus_from_out(q[t][g], 100.f);
                 acc_bh2[t][g] += dz2[t][g];
             }
-        // ---- dW(head.w1)[ot][it] += dz2(ot) . p(it)^T
+        // ---- dW(head.w1)[ot][it] += dz2(ot) . p(it)^T ;  d p = W1^T dz2   (dz2 is split once for both)
         stage_tile<NP>(Ta, p[0], hi, sl);
         stage_tile<NP>(Ta2, p[1], hi, sl);
-#pragma unroll
-        for (int ot = 0; ot < 2; ++ot) {
-            stage_tile<NP>(Tz, dz2[ot], hi, sl);
-            dw_tile<NP>(acc_wh2[ot][0], Tz, Ta, hi, sl);
-            dw_tile<NP>(acc_wh2[ot][1], Tz, Ta2, hi, sl);
-        }
-        // ---- d p = W1^T dz2 ; dz1 = d p * softplus'(p)
         f32x16 dp[2];
 #pragma unroll
         for (int g = 0; g < 16; ++g) { dp[0][g] = 0.f; dp[1][g] = 0.f; }
@@ -541,6 +546,12 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_head_x_kernel(BwdXHArgs a) {
             bf16x8 bz[4][3];
 #pragma unroll
             for (int t = 0; t < 2; ++t) { split8<NT>(dz2[t], bz[2 * t]); split8<NT>(dz2[t] + 8, bz[2 * t + 1]); }
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot) {
+                stage_pieces<NP>(Tz, bz[2 * ot], bz[2 * ot + 1], hi, sl);
+                dw_tile<NP>(acc_wh2[ot][0], Tz, Ta, hi, sl);
+                dw_tile<NP>(acc_wh2[ot][1], Tz, Ta2, hi, sl);
+            }
 #pragma unroll
             for (int c = 0; c < 4; ++c) mma2<MODE>(dp[0], dp[1], fr + F_WH2T, 4, c, bz[c], lane);
         }
@@ -558,11 +569,6 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_head_x_kernel(BwdXHArgs a) {
             stage_one<NP>(Ta, rowc(g) + 4 * hi, o[g], sl);
             stage_one<NP>(Ta, 16 + 2 * g + hi, shs[g], sl);
         }
-#pragma unroll
-        for (int ot = 0; ot < 2; ++ot) {
-            stage_tile<NP>(Tz, dz1[ot], hi, sl);
-            dw_tile<NP>(acc_wh1[ot], Tz, Ta, hi, sl);
-        }
         // ---- d V = W0^T dz1 (rows 0..15 = d base_out); row 0 takes the density gradient
         f32x16 dv, dv2;
 #pragma unroll
@@ -571,6 +577,11 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_head_x_kernel(BwdXHArgs a) {
             bf16x8 bz[4][3];
 #pragma unroll
             for (int t = 0; t < 2; ++t) { split8<NT>(dz1[t], bz[2 * t]); split8<NT>(dz1[t] + 8, bz[2 * t + 1]); }
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot) {
+                stage_pieces<NP>(Tz, bz[2 * ot], bz[2 * ot + 1], hi, sl);
+                dw_tile<NP>(acc_wh1[ot], Tz, Ta, hi, sl);
+            }
             mma1x2<MODE>(dv, dv2, fr + F_WH1T, 4, 0, 1, bz[0], bz[1], lane);
             mma1x2<MODE>(dv, dv2, fr + F_WH1T, 4, 2, 3, bz[2], bz[3], lane);
 #pragma unroll
@@ -697,16 +708,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_base_x_kernel(BwdXBArgs a) {
         // ---- dW(base.w0)[ot] += dz0(ot) . x^T   (x row = feature index 2 s + hi)
 #pragma unroll
         for (int s = 0; s < 16; ++s) stage_one<NP>(Ta, 2 * s + hi, x[s], sl);
-#pragma unroll
-        for (int ot = 0; ot < 2; ++ot) {
-            // Tz rows 16..31 are overwritten here; the dO staging of the next block rewrites rows 0..15 only,
-            // so the zero rows are restored below
-            stage_tile<NP>(Tz, dz0[ot], hi, sl);
-            dw_tile<NP>(acc_w1[ot], Tz, Ta, hi, sl);
-        }
-#pragma unroll
-        for (int g = 8; g < 16; ++g) stage_one<NP>(Tz, rowc(g) + 4 * hi, 0.f, sl);
-        // ---- d x = W0^T dz0 -> hash-feature gradient, fragment layout
+        // ---- d x = W0^T dz0 -> hash-feature gradient, fragment layout (dz0 is split once for both uses)
         f32x16 dxv, dxv2;
 #pragma unroll
         for (int g = 0; g < 16; ++g) { dxv[g] = 0.f; dxv2[g] = 0.f; }
@@ -714,6 +716,15 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_base_x_kernel(BwdXBArgs a) {
             bf16x8 bz[4][3];
 #pragma unroll
             for (int t = 0; t < 2; ++t) { split8<NT>(dz0[t], bz[2 * t]); split8<NT>(dz0[t] + 8, bz[2 * t + 1]); }
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot) {
+                // Tz rows 16..31 are overwritten here; the dO staging of the next block rewrites rows 0..15 only,
+                // so the zero rows are restored below
+                stage_pieces<NP>(Tz, bz[2 * ot], bz[2 * ot + 1], hi, sl);
+                dw_tile<NP>(acc_w1[ot], Tz, Ta, hi, sl);
+            }
+#pragma unroll
+            for (int g = 8; g < 16; ++g) stage_one<NP>(Tz, rowc(g) + 4 * hi, 0.f, sl);
             mma1x2<MODE>(dxv, dxv2, fr + F_W1T, 4, 0, 1, bz[0], bz[1], lane);
             mma1x2<MODE>(dxv, dxv2, fr + F_W1T, 4, 2, 3, bz[2], bz[3], lane);
 #pragma unroll
