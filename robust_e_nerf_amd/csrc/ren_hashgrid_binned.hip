@@ -21,6 +21,7 @@
 //   4. accumulate  stream a bin part (coalesced), 64-bit fixed-point ds_add_u64 into LDS, flush.
 // HBM traffic: 10 B written + 10 B read per update = 2.56 KB/sample (vs 2 KB of atomic RMW it
 // replaces) but all of it streaming; global atomic requests drop from 128 to ~0.1 per sample.
+#include <cstdlib>
 #include "ren_hashgrid_common.h"
 
 namespace {
@@ -47,6 +48,15 @@ constexpr int LMAX_WORDS = REN_MAX_LEVELS * LMAX_SLOTS * LMAX_STRIDE;
 
 struct BinTab {
     int bin_base[REN_MAX_LEVELS + 1];                // first global bin of each level
+    // Hashed levels are NOT counted: the hash spreads the 8 n updates of a level evenly over its bins (binomial,
+    // sigma/mean ~ 7e-4 at config B), so every bin of a hashed level gets a region of `cap` entries (mean + 2 %
+    // + 4096); an update that would not fit falls back to a global atomic (never seen, kept for correctness).
+    // cap = 0: dense level, regions sized by the count pass.  The count pass looks at one sample block in
+    // `cnt_stride` (rays of a batch are i.i.d., so blocks are exchangeable) and the offsets kernel scales the
+    // sampled count back up with a 25 % + 4096 margin; the same overflow fallback keeps it exact.
+    uint32_t cap[REN_MAX_LEVELS];
+    int cnt_stride;
+    int halve;                                       // test hook (REN_HGB_HALVE_REGIONS=1): force the overflow path
 };
 
 struct Part {
@@ -194,12 +204,13 @@ __global__ __launch_bounds__(CNT_THREADS) void bin_count_kernel(GridDev g, BinTa
     const int lane = threadIdx.x & 63;
 #pragma unroll 1
     for (int k = 0; k < CNT_SAMPLES / CNT_THREADS; ++k) {
-        const int64_t i = (int64_t)blockIdx.x * CNT_SAMPLES + k * CNT_THREADS + threadIdx.x;
+        const int64_t i = (int64_t)blockIdx.x * bt.cnt_stride * CNT_SAMPLES + k * CNT_THREADS + threadIdx.x;
         const bool inb = i < a.n;
         float u[3] = {0.f, 0.f, 0.f}, ud[3];
         if (inb) unit_pos<TAN>(a, i, u, ud);
 #pragma unroll 1
         for (int lvl = 0; lvl < g.n_levels; ++lvl) {
+            if (bt.cap[lvl]) continue;                               // hashed level: capacity-sized regions, no count
             float d0, d1, e0, e1;
             const bool have = inb && load_dfeat<TAN>(a, g.n_levels, lvl, i, d0, d1, e0, e1);
             const LevelPos p = level_pos(u[0], u[1], u[2], g.scale[lvl]);
@@ -221,29 +232,57 @@ __global__ __launch_bounds__(CNT_THREADS) void bin_count_kernel(GridDev g, BinTa
     }
 }
 
-// ---- 2. offsets + work partition -----------------------------------------------------------------------
-__global__ __launch_bounds__(MAX_BINS) void bin_offsets_kernel(int n_bins, const uint32_t *__restrict__ counts,
+// ---- 2. offsets: exclusive scan of the region sizes (count for dense bins, capacity for hashed bins) ------
+__global__ __launch_bounds__(MAX_BINS) void bin_offsets_kernel(int n_bins, BinTab bt, uint64_t capacity,
+                                                               const uint32_t *__restrict__ counts,
                                                                uint32_t *__restrict__ cursors,
-                                                               uint64_t *__restrict__ bin_start,
-                                                               Part *__restrict__ parts, uint32_t *__restrict__ n_parts) {
+                                                               uint64_t *__restrict__ bin_start) {
     __shared__ uint64_t s_cnt[MAX_BINS];
-    __shared__ uint32_t s_np[MAX_BINS];
     const int t = threadIdx.x;
-    const uint64_t c = t < n_bins ? counts[t] : 0;
-    const uint32_t np = (uint32_t)((c + PART_ENTRIES - 1) / PART_ENTRIES);
-    s_cnt[t] = c; s_np[t] = np;
-    if (t < n_bins) cursors[t] = 0;
+    uint64_t c = 0;
+    if (t < n_bins) {
+        int lvl = 0;
+        while (lvl + 1 < REN_MAX_LEVELS && t >= bt.bin_base[lvl + 1]) ++lvl;
+        c = bt.cap[lvl] ? bt.cap[lvl] : counts[t];
+        if (!bt.cap[lvl] && bt.cnt_stride > 1) c = c * bt.cnt_stride + c * bt.cnt_stride / 4 + 4096;
+        if (bt.halve) c = c / 2;
+        cursors[t] = 0;
+    }
+    s_cnt[t] = c;
     __syncthreads();
     for (int off = 1; off < MAX_BINS; off <<= 1) {
         const uint64_t a = t >= off ? s_cnt[t - off] : 0;
-        const uint32_t b = t >= off ? s_np[t - off] : 0;
         __syncthreads();
-        s_cnt[t] += a; s_np[t] += b;
+        s_cnt[t] += a;
         __syncthreads();
     }
-    const uint64_t start = s_cnt[t] - c;
-    if (t < n_bins) bin_start[t] = start;
-    if (t == n_bins - 1) { bin_start[n_bins] = s_cnt[t]; n_parts[0] = s_np[t]; }
+    // regions never leave the workspace: whatever does not fit takes the overflow path of the scatter
+    if (t < n_bins) bin_start[t] = s_cnt[t] - c < capacity ? s_cnt[t] - c : capacity;
+    if (t == n_bins - 1) bin_start[n_bins] = s_cnt[t] < capacity ? s_cnt[t] : capacity;
+}
+
+// ---- 3b. work partition of the accumulate pass, from the ACTUAL fill of every bin region ---------------------
+__global__ __launch_bounds__(MAX_BINS) void bin_partition_kernel(int n_bins, const uint32_t *__restrict__ cursors,
+                                                                 const uint64_t *__restrict__ bin_start,
+                                                                 Part *__restrict__ parts, uint32_t *__restrict__ n_parts) {
+    __shared__ uint32_t s_np[MAX_BINS];
+    const int t = threadIdx.x;
+    uint64_t c = 0, start = 0;
+    if (t < n_bins) {
+        start = bin_start[t];
+        const uint64_t room = bin_start[t + 1] - start;
+        c = cursors[t] < room ? cursors[t] : room;                   // overflowing updates went to the table directly
+    }
+    const uint32_t np = (uint32_t)((c + PART_ENTRIES - 1) / PART_ENTRIES);
+    s_np[t] = np;
+    __syncthreads();
+    for (int off = 1; off < MAX_BINS; off <<= 1) {
+        const uint32_t b = t >= off ? s_np[t - off] : 0;
+        __syncthreads();
+        s_np[t] += b;
+        __syncthreads();
+    }
+    if (t == n_bins - 1) n_parts[0] = s_np[t];
     const uint32_t pbase = s_np[t] - np;
     for (uint32_t k = 0; k < np; ++k) {
         Part p;
@@ -258,8 +297,9 @@ __global__ __launch_bounds__(MAX_BINS) void bin_offsets_kernel(int n_bins, const
 // One sample per thread; the workgroup walks the levels {group, group + 4, ...} and runs one
 // rank -> offsets -> LDS placement -> coalesced append pass per level over the same staging area.
 template <bool TAN>
-__global__ __launch_bounds__(SC_THREADS) void bin_scatter_kernel(GridDev g, BinTab bt, SampleArgs a, Workspace ws) {
-    __shared__ uint32_t hist[MAX_BINS_PER_LEVEL], loc[MAX_BINS_PER_LEVEL + 1];
+__global__ __launch_bounds__(SC_THREADS) void bin_scatter_kernel(GridDev g, BinTab bt, SampleArgs a, Workspace ws,
+                                                                 float *__restrict__ grad_table) {
+    __shared__ uint32_t hist[MAX_BINS_PER_LEVEL], loc[MAX_BINS_PER_LEVEL + 1], fit[MAX_BINS_PER_LEVEL];
     __shared__ uint64_t gdelta[MAX_BINS_PER_LEVEL];               // global position - staging position, per bin
     __shared__ uint32_t st_key[SC_ENTRIES];
     __shared__ float2 st_v[SC_ENTRIES];
@@ -340,10 +380,15 @@ __global__ __launch_bounds__(SC_THREADS) void bin_scatter_kernel(GridDev g, BinT
             loc[tid] = inc - cnt;
             if (tid == MAX_BINS_PER_LEVEL - 1) loc[MAX_BINS_PER_LEVEL] = inc;
             uint64_t base = 0;
+            uint32_t room = cnt;
             if (tid < nb && cnt) {
                 const int gb = bt.bin_base[lvl] + tid;
-                base = ws.bin_start[gb] + atomicAdd(&ws.cursors[gb], cnt);   // reserve the run in the bin's region
+                const uint32_t at = atomicAdd(&ws.cursors[gb], cnt);         // reserve the run in the bin's region
+                const uint64_t cap = ws.bin_start[gb + 1] - ws.bin_start[gb];
+                room = at >= cap ? 0u : (uint32_t)(cap - at < cnt ? cap - at : cnt);
+                base = ws.bin_start[gb] + at;
             }
+            fit[tid] = room;                                           // entries of this run that fit the region
             gdelta[tid] = base - (inc - cnt);
         }
         lds_barrier();
@@ -359,10 +404,17 @@ __global__ __launch_bounds__(SC_THREADS) void bin_scatter_kernel(GridDev g, BinT
         lds_barrier();
         const uint32_t total = loc[MAX_BINS_PER_LEVEL];
         for (uint32_t q = tid; q < total; q += SC_THREADS) {
-            const uint32_t idx = st_key[q];
-            const uint64_t gp = gdelta[idx >> BIN_SHIFT] + q;
-            ws.out_idx[gp] = (uint16_t)(idx & (BIN_ENTRIES - 1));
-            ws.out_v[gp] = st_v[q];
+            const uint32_t idx = st_key[q], b = idx >> BIN_SHIFT;
+            const float2 v = st_v[q];
+            if (q - loc[b] < fit[b]) {
+                const uint64_t gp = gdelta[b] + q;
+                ws.out_idx[gp] = (uint16_t)(idx & (BIN_ENTRIES - 1));
+                ws.out_v[gp] = v;
+            } else {                                                   // region full (capacity-sized hashed bins only)
+                float *gt = grad_table + 2 * ((size_t)g.offset[lvl] + idx);
+                atomicAdd(gt, v.x);
+                atomicAdd(gt + 1, v.y);
+            }
         }
     }
 }
@@ -429,11 +481,14 @@ __global__ __launch_bounds__(1024) void bin_accumulate_kernel(GridDev g, BinTab 
 
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-struct Layout { size_t counts, level_max, cursors, n_parts, bin_start, parts, out_idx, out_v, total; int64_t max_parts; };
+struct Layout { size_t counts, level_max, cursors, n_parts, bin_start, parts, out_idx, out_v, total, entries; int64_t max_parts; };
 
 Layout make_layout(int64_t n) {
     Layout L;
-    const size_t E = (size_t)n * 128;
+    // at most 128 n updates (16 levels x 8 corners) + capacity slack: 2 % of the hashed and 25 % of the dense
+    // levels, 4096 per bin, one stride of count blocks; the offsets kernel clamps the regions to this total
+    const size_t E = (size_t)n * 140 + (size_t)MAX_BINS * 4096 + 16 * 8 * 16 * CNT_SAMPLES;
+    L.entries = E;
     L.max_parts = (int64_t)(E / PART_ENTRIES) + MAX_BINS + 1;
     size_t o = 0;
     L.counts = o; o += MAX_BINS * 4;                       // counts | level_max are cleared by one memset
@@ -479,6 +534,14 @@ static int binned_impl(const ren_grid_desc *grid, float *grad_table, const float
     }
     bt.bin_base[REN_MAX_LEVELS] = nb;
     for (int l = g.n_levels; l < REN_MAX_LEVELS; ++l) bt.bin_base[l] = nb;
+    for (int l = 0; l < REN_MAX_LEVELS; ++l) {
+        bt.cap[l] = 0;
+        if (l < g.n_levels && g.hashed[l]) {
+            const int64_t bins = (g.size[l] + BIN_ENTRIES - 1) >> BIN_SHIFT;
+            const int64_t mean = (8 * n + bins - 1) / bins;
+            bt.cap[l] = (uint32_t)(mean + mean / 50 + 4096);
+        }
+    }
     if (n == 0) return REN_OK;
     ren_scene_dev sc = {};
     if (scene) sc = ren_make_scene(scene);
@@ -495,14 +558,20 @@ static int binned_impl(const ren_grid_desc *grid, float *grad_table, const float
     SampleArgs a;
     a.layout = layout; a.dfeat = dfeat; a.x_unit = x_unit; a.sc = sc; a.rays_o = rays_o; a.rays_d = rays_d;
     a.ray_indices = ray_indices; a.t_starts = t_starts; a.t_ends = t_ends; a.n = n; a.tan = tan;
-    const dim3 cgrd((unsigned)((n + CNT_SAMPLES - 1) / CNT_SAMPLES)), cblk(CNT_THREADS);
+    const char *halve = getenv("REN_HGB_HALVE_REGIONS");
+    bt.halve = halve && halve[0] == '1';
+    const int64_t cnt_blocks = (n + CNT_SAMPLES - 1) / CNT_SAMPLES;
+    bt.cnt_stride = cnt_blocks >= 4096 ? 16 : 1;                      // >= 256 sampled blocks (2048 rays) or exact
+    const dim3 cgrd((unsigned)((cnt_blocks + bt.cnt_stride - 1) / bt.cnt_stride)), cblk(CNT_THREADS);
     const dim3 sgrd((unsigned)((n + SC_THREADS - 1) / SC_THREADS * LEVEL_GROUPS)), sblk(SC_THREADS);
     if (tan.dfeatd) hipLaunchKernelGGL(bin_count_kernel<true>, cgrd, cblk, 0, st, g, bt, a, ws.counts);
     else            hipLaunchKernelGGL(bin_count_kernel<false>, cgrd, cblk, 0, st, g, bt, a, ws.counts);
-    hipLaunchKernelGGL(bin_offsets_kernel, dim3(1), dim3(MAX_BINS), 0, st, nb, ws.counts, ws.cursors, ws.bin_start,
-                       ws.parts, ws.n_parts);
-    if (tan.dfeatd) hipLaunchKernelGGL(bin_scatter_kernel<true>, sgrd, sblk, 0, st, g, bt, a, ws);
-    else            hipLaunchKernelGGL(bin_scatter_kernel<false>, sgrd, sblk, 0, st, g, bt, a, ws);
+    hipLaunchKernelGGL(bin_offsets_kernel, dim3(1), dim3(MAX_BINS), 0, st, nb, bt, (uint64_t)L.entries, ws.counts,
+                       ws.cursors, ws.bin_start);
+    if (tan.dfeatd) hipLaunchKernelGGL(bin_scatter_kernel<true>, sgrd, sblk, 0, st, g, bt, a, ws, grad_table);
+    else            hipLaunchKernelGGL(bin_scatter_kernel<false>, sgrd, sblk, 0, st, g, bt, a, ws, grad_table);
+    hipLaunchKernelGGL(bin_partition_kernel, dim3(1), dim3(MAX_BINS), 0, st, nb, ws.cursors, ws.bin_start, ws.parts,
+                       ws.n_parts);
     const size_t acc_lds = 2 * BIN_ENTRIES * sizeof(unsigned long long);
     (void)hipFuncSetAttribute((const void *)bin_accumulate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)acc_lds);
     hipLaunchKernelGGL(bin_accumulate_kernel, dim3((unsigned)L.max_parts), dim3(1024), acc_lds, st, g, bt, ws, grad_table);

@@ -6,6 +6,7 @@ Tolerances: bit-exact for integer / index work (sample counts, ray indices, inte
 relative to the largest entry (float atomics reorder sums).
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -195,6 +196,41 @@ def test_hashgrid_fwd_bwd(amd, spec, full_table_cache):
         gt3 = torch.ones_like(td)
         ops.hashgrid_bwd_binned(grid, gt3, df, ws, x_unit=dev(x), n=n, layout=layout)
         assert rel_err(gt3.cpu() - 1.0, tab.grad) < 1e-5, layout
+    # bin regions of hashed levels are capacity-sized, not counted: with the regions halved about half of the
+    # updates must take the overflow path (global atomics) and the result is still the same
+    os.environ["REN_HGB_HALVE_REGIONS"] = "1"
+    try:
+        gt4 = torch.zeros_like(td)
+        ops.hashgrid_bwd_binned(grid, gt4, dev(gout), ws, x_unit=dev(x), n=n, layout=0)
+        torch.cuda.synchronize()
+    finally:
+        del os.environ["REN_HGB_HALVE_REGIONS"]
+    assert rel_err(gt4.cpu(), tab.grad) < 1e-5
+
+
+def test_hashgrid_bwd_binned_sampled_count_vs_atomics(amd):
+    """n large enough (>= 4096 count blocks) that dense-level regions are sized from 1 sample block in 16:
+    compare with the atomic scatter on clustered points (uneven bins), regular and with halved regions."""
+    ops, _ = amd
+    grid, n_table = ops.make_grid_desc()
+    n = 4096 * 1024 + 777
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.rand(n, 3, generator=g, device=DEV)
+    x[: n // 2] = 0.3 + 0.05 * x[: n // 2]                      # half of the points in one 5 % corner of the cube
+    x = x[torch.randperm(n, generator=g, device=DEV)].contiguous()
+    gout = torch.randn(n, 32, generator=g, device=DEV)
+    gt = torch.zeros(n_table, device=DEV)
+    ops.hashgrid_bwd(grid, gt, gout, x_unit=x, n=n, layout=0)
+    ws = torch.empty(ops.hashgrid_bwd_binned_workspace_bytes(n), device=DEV, dtype=torch.uint8)
+    for halve in ("0", "1"):
+        os.environ["REN_HGB_HALVE_REGIONS"] = halve
+        try:
+            gb = torch.zeros(n_table, device=DEV)
+            ops.hashgrid_bwd_binned(grid, gb, gout, ws, x_unit=x, n=n, layout=0)
+            torch.cuda.synchronize()
+        finally:
+            del os.environ["REN_HGB_HALVE_REGIONS"]
+        assert rel_err(gb, gt) < 1e-4, halve          # fp32 sums of up to ~2 M terms per entry, in different orders
 
 
 # ------------------------------------------------------------------------------------------ field (hash + MLPs)
