@@ -138,6 +138,8 @@ def main():
                     help="weight of the log-intensity-gradient loss (adds a third render with d/dt; 1e-3 in the real-data configs)")
     ap.add_argument("--mlp-bf16", action="store_true",
                     help="BASELINE configs[2] numerics: bf16-rounded linear inputs/weights, fp32 accumulate + composite")
+    ap.add_argument("--fwd-chunks", type=int, default=16,
+                    help="> 1: hash encoding and MLP forward of alternate sample chunks on two HIP streams")
     ap.add_argument("--mlp-kernels", default="x", choices=["x", "f32"],
                     help="x = split-bf16 matrix-core MLP kernels at fp32 accuracy (default), f32 = exact f32-MFMA kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -189,7 +191,7 @@ def main():
 
     aabb = (-1.5, -1.5, -1.5, 1.5, 1.5, 1.5)
     cfg = engine.RenderCfg(aabb=aabb, sampler=args.sampler, n_uniform=args.samples, mlp_bf16=args.mlp_bf16,
-                           mlp_kernels=args.mlp_kernels)
+                           mlp_kernels=args.mlp_kernels, fwd_chunks=args.fwd_chunks)
     if args.arch == "mlp":
         from robust_e_nerf_amd import vanilla
         fld = vanilla.VanillaField(dev, 1)

@@ -350,11 +350,16 @@ int ren_mlp_bwd_saved(const float *mlp_params, int32_t C, int32_t bf16, const fl
  * pieces and six bf16 MFMAs per k-chunk reproduce the fp32 product to fp32 round-off (the default training
  * path: the f32 MFMA shares its pipe with the VALU on gfx950, the bf16 MFMA does not).  mode 1: plain bf16
  * operands (BASELINE configs[2]); takes the fp32 parameter block and rounds it itself.
- * Arguments as ren_mlp_fwd_save / ren_mlp_bwd_saved; act_save may be NULL in the forward (inference). */
+ * Arguments as ren_mlp_fwd_save / ren_mlp_bwd_saved; act_save may be NULL in the forward (inference).
+ * flags: REN_MLP_DENSITY_ONLY (base network and sigma only; rgb may be NULL), REN_MLP_SHARE_CU (one persistent
+ * workgroup per CU instead of two, leaving half of each CU to a kernel running on another stream: the engine
+ * runs the hash encoding of the next sample chunk beside the MLP of the current one). */
+#define REN_MLP_DENSITY_ONLY 1
+#define REN_MLP_SHARE_CU 2
 int ren_mlp_fwd_x(const float *mlp_params, int32_t C, int32_t mode, const float *feat, const ren_scene_desc *scene,
                   const float *x_world, const float *dirs, const float *rays_o, const float *rays_d,
                   const int32_t *ray_indices, const float *t_starts, const float *t_ends, int64_t n,
-                  int32_t density_only, float *rgb, float *sigma, float *base_out, float *act_save, void *stream);
+                  int32_t flags, float *rgb, float *sigma, float *base_out, float *act_save, void *stream);
 int64_t ren_mlp_bwd_x_workspace_floats(int32_t C);
 int ren_mlp_bwd_x(const float *mlp_params, int32_t C, int32_t mode, const float *feat, const float *base_out,
                   const float *act_save, const ren_scene_desc *scene, const float *x_world, const float *dirs,

@@ -315,17 +315,20 @@ __global__ __launch_bounds__(64 * FWD_X_WAVES, 2) void mlp_fwd_x_kernel(FwdXArgs
 }
 
 template <int MODE>
-int launch_fwd_x(const FwdXArgs &a, int C, bool density_only, hipStream_t st) {
+int launch_fwd_x(const FwdXArgs &a, int C, bool density_only, bool one, hipStream_t st) {
     using L = XL<Pairs<MODE>::NT>;
     const int64_t n_blk = (a.n + 31) / 32;
     int64_t blocks = (n_blk + FWD_X_WAVES - 1) / FWD_X_WAVES;
-    if (blocks > 512) blocks = 512;                             // two workgroups per CU
+    // two workgroups per CU; REN_MLP_SHARE_CU: one (the LDS request keeps a second one out), so that a kernel on
+    // another stream finds half of every CU's registers and wave slots free
+    if (blocks > (one ? 256 : 512)) blocks = one ? 256 : 512;
+    const size_t lds = one ? (L::BYTES > 84 * 1024 ? L::BYTES : 84 * 1024) : L::BYTES;
     const dim3 grd((int)blocks), blk(64 * FWD_X_WAVES);
 #define REN_X(CC, DO)                                                                                       \
     do {                                                                                                    \
         (void)hipFuncSetAttribute((const void *)mlp_fwd_x_kernel<CC, MODE, DO>,                             \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::BYTES);               \
-        hipLaunchKernelGGL((mlp_fwd_x_kernel<CC, MODE, DO>), grd, blk, L::BYTES, st, a);                    \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
+        hipLaunchKernelGGL((mlp_fwd_x_kernel<CC, MODE, DO>), grd, blk, lds, st, a);                    \
     } while (0)
     if (density_only) REN_X(1, true);
     else if (C == 1)  REN_X(1, false);
@@ -340,11 +343,13 @@ int launch_fwd_x(const FwdXArgs &a, int C, bool density_only, hipStream_t st) {
 extern "C" int ren_mlp_fwd_x(const float *mlp_params, int32_t C, int32_t mode, const float *feat,
                              const ren_scene_desc *scene, const float *x_world, const float *dirs,
                              const float *rays_o, const float *rays_d, const int32_t *ray_indices,
-                             const float *t_starts, const float *t_ends, int64_t n, int32_t density_only,
+                             const float *t_starts, const float *t_ends, int64_t n, int32_t flags,
                              float *rgb, float *sigma, float *base_out, float *act_save, void *stream) {
     if (!mlp_params || !feat || !scene || !sigma || n < 0) return REN_ERR_BAD_ARG;
     if (C != 1 && C != 3) return REN_ERR_UNSUPPORTED;
     if (mode != 1 && mode != 6) return REN_ERR_UNSUPPORTED;
+    const bool density_only = (flags & REN_MLP_DENSITY_ONLY) != 0, share = (flags & REN_MLP_SHARE_CU) != 0;
+    if (flags & ~(REN_MLP_DENSITY_ONLY | REN_MLP_SHARE_CU)) return REN_ERR_BAD_ARG;
     if (!density_only && !rgb) return REN_ERR_BAD_ARG;
     if (act_save && (density_only || !base_out)) return REN_ERR_BAD_ARG;
     if (!x_world && (!rays_o || !rays_d || !ray_indices || !t_starts || !t_ends)) return REN_ERR_BAD_ARG;
@@ -354,8 +359,8 @@ extern "C" int ren_mlp_fwd_x(const float *mlp_params, int32_t C, int32_t mode, c
     a.src = SampleSrc{x_world, dirs, rays_o, rays_d, x_world ? nullptr : ray_indices, t_starts, t_ends};
     a.sc = ren_make_scene(scene);
     a.n = n; a.rgb = rgb; a.sigma = sigma; a.base_out = base_out; a.acts = act_save;
-    return mode == 6 ? launch_fwd_x<6>(a, C, density_only != 0, (hipStream_t)stream)
-                     : launch_fwd_x<1>(a, C, density_only != 0, (hipStream_t)stream);
+    return mode == 6 ? launch_fwd_x<6>(a, C, density_only, share, (hipStream_t)stream)
+                     : launch_fwd_x<1>(a, C, density_only, share, (hipStream_t)stream);
 }
 
 // ================================================================================================ backward

@@ -45,6 +45,7 @@ class RenderCfg:
                                        # "f32": exact f32-MFMA kernels (csrc/ren_mlp.hip)
     save_activations: bool = True      # training forward stores the hidden activations (768 B/sample) instead of
                                        # recomputing them in the backward (128 f32 MFMAs + 192 softplus per 32 samples)
+    fwd_chunks: int = 16               # > 1: hash encoding and MLP of alternate sample chunks on two HIP streams
     mlp_bf16: bool = False             # BASELINE configs[2]: bf16 MLP (rounded linear inputs/weights, fp32 accumulate), fp32 composite
 
 
@@ -108,6 +109,7 @@ class Renderer:
         self._ws = torch.empty(max(ops.mlp_bwd_workspace_floats(fld.C), ops.mlp_bwd_x_workspace_floats(fld.C)),
                                device=dev, dtype=torch.float32)
         self._bin_ws = None
+        self._fwd_streams = None
 
     # ---- sampling (K1-K3): ray/AABB, two-pass march, no-grad density pre-pass + visibility --------
     def sample(self, o, d, jitter: Optional[torch.Tensor], training: bool) -> Packed:
@@ -161,6 +163,9 @@ class Renderer:
     def _field_forward(self, o, d, pk, save):
         f = self.field
         samples = (pk.ray_indices, pk.t_starts, pk.t_ends)
+        chunks = min(self.cfg.fwd_chunks, pk.n >> 17)                  # >= 4 096 blocks of 32 samples per chunk
+        if self.cfg.mlp_kernels == "x" and chunks > 1:
+            return self._field_forward_chunked(o, d, pk, save, chunks)
         feat = ops.hashgrid_fwd(f.grid, f.table, scene=self.scene, rays=(o, d), samples=samples, n=pk.n, layout=1)
         if self.cfg.mlp_kernels == "x":
             rgb, sigma, base, acts = ops.mlp_fwd_x(f.mlp, f.C, self._xmode(), feat, self.scene, rays=(o, d), samples=samples,
@@ -174,6 +179,48 @@ class Renderer:
         rgb, sigma, base = ops.mlp_fwd(mp, f.C, feat, self.scene, rays=(o, d), samples=samples, n=pk.n,
                                        save_base=save, bf16=self.cfg.mlp_bf16)
         return rgb, sigma, dict(feat=feat, base=base, mlp_params=mp)
+
+    def _field_forward_chunked(self, o, d, pk, save, K):
+        """Encoding (texture-addresser bound) and MLP (VALU / matrix-core bound) of different sample chunks on two
+        HIP streams, so the two kernels share the CUs instead of running back to back.  Every output layout is
+        local to a 32-sample block, so chunk k writes a slice of the full tensors."""
+        f, n = self.field, pk.n
+        dev = o.device
+        lib_acts = ops.mlp_act_save_floats(32)
+        nblk = ops.n_blocks32(n)
+        per = -(-nblk // K)
+        feat = torch.empty(nblk * ops.FRAG_FLOATS_PER_BLOCK, device=dev)
+        sigma = torch.empty(n, device=dev)
+        rgb = torch.empty(n, f.C, device=dev)
+        base = torch.empty(nblk * ops.BASE_FLOATS_PER_BLOCK, device=dev) if save else None
+        acts = torch.empty(nblk * lib_acts, device=dev) if save else None
+        if self._fwd_streams is None:
+            self._fwd_streams = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+        main = torch.cuda.current_stream()
+        s_enc, s_mlp = self._fwd_streams
+        s_enc.wait_stream(main)
+        s_mlp.wait_stream(main)
+        for k in range(K):
+            b0, b1 = k * per, min(nblk, (k + 1) * per)
+            if b0 >= b1:
+                break
+            lo, hi = b0 * 32, min(n, b1 * 32)
+            smp = (pk.ray_indices[lo:hi], pk.t_starts[lo:hi], pk.t_ends[lo:hi])
+            fk = feat[b0 * ops.FRAG_FLOATS_PER_BLOCK: b1 * ops.FRAG_FLOATS_PER_BLOCK]
+            with torch.cuda.stream(s_enc):
+                ops.hashgrid_fwd(f.grid, f.table, scene=self.scene, rays=(o, d), samples=smp, n=hi - lo, layout=1, out=fk)
+                ev = torch.cuda.Event()
+                ev.record(s_enc)
+            with torch.cuda.stream(s_mlp):
+                s_mlp.wait_event(ev)
+                out = (rgb[lo:hi], sigma[lo:hi],
+                       base[b0 * ops.BASE_FLOATS_PER_BLOCK: b1 * ops.BASE_FLOATS_PER_BLOCK] if save else None,
+                       acts[b0 * lib_acts: b1 * lib_acts] if save else None)
+                ops.mlp_fwd_x(f.mlp, f.C, self._xmode(), fk, self.scene, rays=(o, d), samples=smp, n=hi - lo, save=save,
+                              out=out, share_cu=True)
+        main.wait_stream(s_enc)
+        main.wait_stream(s_mlp)
+        return rgb, sigma, dict(feat=feat, base=base, acts=acts, xmode=self._xmode() if save else None)
 
     def _field_backward(self, ctx, d_rgb, d_sig):
         f, pk = self.field, ctx["pk"]

@@ -464,6 +464,39 @@ def test_occgrid_update(amd, spec, full_table_cache):
     assert not r.update_occ_grid(3)                       # only every n-th step
 
 
+def test_chunked_two_stream_forward_equals_single_launch(amd, spec, full_table_cache):
+    """RenderCfg.fwd_chunks: hash encoding / MLP of alternate sample chunks on two HIP streams (with the MLP kernel
+    in its one-workgroup-per-CU mode) give bit-identical renders and gradients that agree to summation order."""
+    from oracle import field
+    ops, engine = amd
+    p = field.init_params(spec, seed=5)
+    p["hash"] = full_table_cache(7, 0.5)
+    R = 8192                                                     # x 128 samples = 1 M samples -> 8 chunks
+    gen = torch.Generator().manual_seed(3)
+    ang = torch.rand(R, generator=gen) * 2 * math.pi
+    o = torch.stack([4 * torch.cos(ang), 4 * torch.sin(ang), torch.rand(R, generator=gen) - 0.5], -1)
+    d = (torch.rand(R, 3, generator=gen) - 0.5) * 1.6 - o
+    d = d / d.norm(dim=-1, keepdim=True)
+    o, d = dev(o.float()), dev(d.float())
+    jit = dev(torch.rand(R, generator=gen))
+    g_col = dev(torch.randn(R, 1, generator=gen))
+    out = []
+    for chunks in (1, 16):
+        fld = engine.NGPField(DEV)
+        fld.load(p)
+        r = engine.Renderer(fld, engine.RenderCfg(sampler="uniform", n_uniform=128, fwd_chunks=chunks))
+        colors, opac, depth, ctx = r.forward(o, d, jit, None, True)
+        assert ctx["pk"].n >> 17 >= 2
+        r.backward(ctx, g_col)
+        torch.cuda.synchronize()
+        out.append((colors.clone(), opac.clone(), ctx["sigma"].clone(), ctx["feat"].clone(), ctx["acts"].clone(),
+                    fld.g_mlp.clone(), fld.g_table.clone()))
+    a, b = out
+    for k in range(5):
+        assert torch.equal(a[k], b[k]), k
+    assert rel_err(b[5], a[5]) < 1e-5 and rel_err(b[6], a[6]) < 1e-5
+
+
 # ------------------------------------------------------------------------------------------ whole training step
 def _trainer_from_golden(engine, g, table, sampler="occgrid"):
     occ_res = int(g["occ_res"])
