@@ -265,7 +265,8 @@ def main():
         kern = {k: {"launches": c, "avg_ms": ms / max(c, 1)} for k, (c, ms) in prof.items()}
         dom = max(list(BYTES) + list(FLOPS), key=lambda k: prof.get(k, (0, 0.0))[1])
         c, ms = prof[dom]
-        samples_per_launch = n_main / args.steps     # this rank's samples per launch of the profiled kernels
+        # this rank's samples per launch of the dominant kernel (chunked calls: one launch per chunk)
+        samples_per_launch = n_main / (args.steps if dom.startswith("dense") else max(c, 1))
         if dom in BYTES:
             achieved = BYTES[dom] * samples_per_launch / (ms / c * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

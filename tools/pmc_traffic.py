@@ -1,7 +1,7 @@
 """HBM traffic per C-ABI call from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs).
 
-    rocprofv3 --pmc FETCH_SIZE --kernel-trace -d gpurun_out/pmc_FETCH_SIZE -o pmc -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline
-    rocprofv3 --pmc WRITE_SIZE --kernel-trace -d gpurun_out/pmc_WRITE_SIZE -o pmc -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace -d gpurun_out/pmc_FETCH_SIZE -o pmc -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --fwd-chunks 1
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace -d gpurun_out/pmc_WRITE_SIZE -o pmc -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --fwd-chunks 1
     python tools/pmc_traffic.py gpurun_out/pmc_FETCH_SIZE/pmc_results.db gpurun_out/pmc_WRITE_SIZE/pmc_results.db profiles/rNN_pmc_traffic.json
 
 Units and corrections follow MI355X_MICROARCH.md "HBM": both counters are in KiB-ish units of 1 KB; on
@@ -15,7 +15,7 @@ import json, sqlite3, sys
 GROUPS = {  # C-ABI call -> (kernel-name fragment, launches of that kernel per call)
     "hashgrid_fwd": [("hashgrid_fwd_kernel", 1)],
     "hashgrid_bwd_binned": [("bin_count_kernel", 1), ("bin_offsets_kernel", 1), ("bin_scatter_kernel", 1),
-                            ("bin_accumulate_kernel", 1)],
+                            ("bin_partition_kernel", 1), ("bin_accumulate_kernel", 1)],
     "mlp_fwd": [("mlp_fwd_kernel", 1)],
     "mlp_bwd": [("mlp_bwd_head_kernel", 1), ("mlp_bwd_base_kernel", 1), ("reduce_slabs_kernel", 2)],
     "mlp_fwd_x": [("mlp_fwd_x_kernel", 1)],
@@ -38,7 +38,7 @@ def per_kernel(db):
 def main():
     fetch, write, dst = per_kernel(sys.argv[1]), per_kernel(sys.argv[2]), sys.argv[3]
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) around "
-                     "`python bench.py --steps 2 --warmup 1 --no-cpu-baseline`",
+                     "`python bench.py --steps 2 --warmup 1 --no-cpu-baseline --fwd-chunks 1`",
            "corrections": "bytes = 1024 x counter; FETCH_SIZE doubled (gfx950, MI355X_MICROARCH.md HBM section)",
            "workload": {"events": 65536, "samples": 128, "sampler": "uniform", "loss_grad": 0.0}, "calls": {}}
     for call, parts in GROUPS.items():
