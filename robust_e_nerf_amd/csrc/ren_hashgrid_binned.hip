@@ -40,7 +40,14 @@ constexpr int SC_THREADS = REN_SC_THREADS;           // scatter workgroup: one s
 constexpr int SC_ENTRIES = SC_THREADS * 8;           // staged updates per level pass = 48 KiB
 constexpr int LEVEL_GROUPS = REN_LEVEL_GROUPS;      // a scatter workgroup walks lvl = group, group + LEVEL_GROUPS, ...
 constexpr int CNT_THREADS = 256, CNT_SAMPLES = 1024; // count workgroup: 4 samples per thread, all levels
-constexpr int64_t PART_ENTRIES = 1 << 21;            // updates per accumulate workgroup
+constexpr int64_t PART_ENTRIES_MAX = 1 << 21;        // updates per accumulate workgroup (large n)
+// ~1 024 parts whatever n is: one workgroup walks its part serially, so a fixed 2 M-entry part is a ~1 ms tail
+// when the whole call is only a few million updates (occupancy-grid sampling: ~10 samples per ray)
+inline int64_t part_entries_for(int64_t n) {
+    int64_t p = 1 << 16;
+    while (p < PART_ENTRIES_MAX && p * 1024 < n * 128) p <<= 1;
+    return p;
+}
 // max |update| per level is published with atomicMax: spread over LMAX_SLOTS cache lines per level and
 // only raised when the value actually grows, so the workgroups do not queue on one memory channel.
 constexpr int LMAX_SLOTS = 8, LMAX_STRIDE = 32;      // u32 words between slots (128 B)
@@ -262,7 +269,8 @@ __global__ __launch_bounds__(MAX_BINS) void bin_offsets_kernel(int n_bins, BinTa
 }
 
 // ---- 3b. work partition of the accumulate pass, from the ACTUAL fill of every bin region ---------------------
-__global__ __launch_bounds__(MAX_BINS) void bin_partition_kernel(int n_bins, const uint32_t *__restrict__ cursors,
+__global__ __launch_bounds__(MAX_BINS) void bin_partition_kernel(int n_bins, uint64_t PART_ENTRIES,
+                                                                 const uint32_t *__restrict__ cursors,
                                                                  const uint64_t *__restrict__ bin_start,
                                                                  Part *__restrict__ parts, uint32_t *__restrict__ n_parts) {
     __shared__ uint32_t s_np[MAX_BINS];
@@ -481,7 +489,7 @@ __global__ __launch_bounds__(1024) void bin_accumulate_kernel(GridDev g, BinTab 
 
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-struct Layout { size_t counts, level_max, cursors, n_parts, bin_start, parts, out_idx, out_v, total, entries; int64_t max_parts; };
+struct Layout { size_t counts, level_max, cursors, n_parts, bin_start, parts, out_idx, out_v, total, entries; int64_t max_parts, part_entries; };
 
 Layout make_layout(int64_t n) {
     Layout L;
@@ -489,7 +497,8 @@ Layout make_layout(int64_t n) {
     // levels, 4096 per bin, one stride of count blocks; the offsets kernel clamps the regions to this total
     const size_t E = (size_t)n * 140 + (size_t)MAX_BINS * 4096 + 16 * 8 * 16 * CNT_SAMPLES;
     L.entries = E;
-    L.max_parts = (int64_t)(E / PART_ENTRIES) + MAX_BINS + 1;
+    L.part_entries = part_entries_for(n);
+    L.max_parts = (int64_t)(E / L.part_entries) + MAX_BINS + 1;
     size_t o = 0;
     L.counts = o; o += MAX_BINS * 4;                       // counts | level_max are cleared by one memset
     L.level_max = o; o = align256(o + LMAX_WORDS * 4);
@@ -570,7 +579,7 @@ static int binned_impl(const ren_grid_desc *grid, float *grad_table, const float
                        ws.cursors, ws.bin_start);
     if (tan.dfeatd) hipLaunchKernelGGL(bin_scatter_kernel<true>, sgrd, sblk, 0, st, g, bt, a, ws, grad_table);
     else            hipLaunchKernelGGL(bin_scatter_kernel<false>, sgrd, sblk, 0, st, g, bt, a, ws, grad_table);
-    hipLaunchKernelGGL(bin_partition_kernel, dim3(1), dim3(MAX_BINS), 0, st, nb, ws.cursors, ws.bin_start, ws.parts,
+    hipLaunchKernelGGL(bin_partition_kernel, dim3(1), dim3(MAX_BINS), 0, st, nb, (uint64_t)L.part_entries, ws.cursors, ws.bin_start, ws.parts,
                        ws.n_parts);
     const size_t acc_lds = 2 * BIN_ENTRIES * sizeof(unsigned long long);
     (void)hipFuncSetAttribute((const void *)bin_accumulate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)acc_lds);

@@ -178,6 +178,29 @@ __global__ void ray_march_kernel(const float *__restrict__ o, const float *__res
     if (!WRITE) counts[i] = j;
 }
 
+// Fixed-S stratified sampler, write pass: one thread per (ray, sample) so the three packed streams are written
+// with coalesced stores (one thread per ray wrote 128 samples 512 B apart: 0.54 ms for 200 MB; this: ~0.06 ms).
+// Same expressions as the per-ray loop above.
+__global__ __launch_bounds__(256) void uniform_write_kernel(const float *__restrict__ t_min, const float *__restrict__ t_max,
+                                                            const float *__restrict__ jitter, int64_t n_rays, int n_uniform,
+                                                            const int64_t *__restrict__ offsets,
+                                                            int32_t *__restrict__ ray_indices, float *__restrict__ t_starts,
+                                                            float *__restrict__ t_ends) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = g / n_uniform;
+    const int j = (int)(g - i * n_uniform);
+    if (i >= n_rays) return;
+    const float near = t_min[i], far = t_max[i];
+    if (!(near < far)) return;
+    const float delta = (far - near) / (float)n_uniform;
+    const float first = jitter ? near + jitter[i] * delta : near;
+    const float t0 = first + (float)j * delta;
+    const int64_t at = offsets[i] + j;
+    t_starts[at] = t0;
+    t_ends[at] = t0 + delta;
+    ray_indices[at] = (int32_t)i;
+}
+
 // Exclusive scan of the per-ray sample counts, up to SCAN_TILE * 1024 elements, in three coalesced stages:
 // scan inside 1024-element tiles; one workgroup scans the tile sums (tile sum = local offset + count of the
 // tile's last element) into the caller's int64[1024] scratch; add the tile bases.  (One workgroup walking
@@ -358,7 +381,11 @@ extern "C" int ren_ray_march(const float *rays_o, const float *rays_d, const flo
     a.type = contraction_type; a.step_size = step_size; a.cone_angle = cone_angle;
     a.mode = mode; a.n_uniform = n_uniform;
     dim3 grid(ren_blocks(n_rays, 64)), block(64);   // short blocks: ray lengths vary a lot
-    if (write)
+    if (write && mode == 1)
+        hipLaunchKernelGGL(uniform_write_kernel, dim3(ren_blocks(n_rays * n_uniform, 256)), dim3(256), 0,
+                           (hipStream_t)stream, t_min, t_max, jitter, n_rays, n_uniform, offsets, ray_indices,
+                           t_starts, t_ends);
+    else if (write)
         hipLaunchKernelGGL(ray_march_kernel<true>, grid, block, 0, (hipStream_t)stream, rays_o, rays_d,
                            t_min, t_max, jitter, n_rays, a, binary, offsets, counts, ray_indices,
                            t_starts, t_ends);
