@@ -1,0 +1,26 @@
+"""Idle gaps of the GPU inside one training step (rocprofv3 --kernel-trace csv): busy union vs span, largest gaps."""
+import csv, re, sys
+rows = []
+for r in csv.DictReader(open(sys.argv[1])):
+    m = re.search(r"(\w+_kernel)", r["Kernel_Name"])
+    rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), m.group(1) if m else r["Kernel_Name"][:40]))
+rows.sort()
+# one step = from one adam_kernel pair's end to the next
+adam_ends = [e for s, e, n in rows if "adam_kernel" in n]
+steps = list(zip(adam_ends[1::2], adam_ends[3::2]))
+t0, t1 = steps[-2]
+ks = [x for x in rows if x[0] >= t0 and x[1] <= t1 + 1]
+busy, cur_s, cur_e, gaps = 0, None, None, []
+for s, e, n in ks:
+    if cur_e is None or s > cur_e:
+        if cur_e is not None:
+            busy += cur_e - cur_s
+            gaps.append((s - cur_e, prev, n))
+        cur_s, cur_e = s, e
+    else:
+        cur_e = max(cur_e, e)
+    prev = n
+busy += cur_e - cur_s
+print("step %.3f ms, busy %.3f ms, idle %.3f ms over %d kernels" % ((t1 - t0) / 1e6, busy / 1e6, (t1 - t0 - busy) / 1e6, len(ks)))
+for g, a, b in sorted(gaps, reverse=True)[:12]:
+    print("  gap %.1f us between %s -> %s" % (g / 1e3, a, b))

@@ -1,6 +1,7 @@
 set -x
 mkdir -p gpurun_out/r01b
 python bench.py > gpurun_out/r01b/r01_bench.json 2> gpurun_out/r01b/bench.err
+python bench.py --no-cpu-baseline --events 65536 > gpurun_out/r01b/r01_bench_2x.json 2>>gpurun_out/r01b/bench.err
 python bench.py --no-cpu-baseline --sampler occgrid > gpurun_out/r01b/r01_bench_occgrid.json 2>>gpurun_out/r01b/bench.err
 python bench.py --no-cpu-baseline --arch mlp --events 4096 > gpurun_out/r01b/r01_bench_arch_mlp.json 2>>gpurun_out/r01b/bench.err
 python bench.py --no-cpu-baseline --loss-grad 1 > gpurun_out/r01b/r01_bench_lossgrad.json 2>>gpurun_out/r01b/bench.err
