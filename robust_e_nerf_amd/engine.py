@@ -261,7 +261,7 @@ class Renderer:
             if bkgd is not None:
                 colors = colors + bkgd
             zero = torch.zeros(n_rays, device=o.device)
-            return colors, zero, zero.clone(), dict(pk=pk, empty=True)
+            return colors, zero, zero.clone(), dict(pk=pk, empty=True, bkgd=bkgd)
         rgb, sigma, fctx = self._field_forward(o, d, pk, save)
         colors, opac, depth, w, T = ops.composite_fwd(pk.offsets, pk.counts, pk.t_starts, pk.t_ends, sigma, rgb,
                                                       f.C, bkgd, save=save)

@@ -162,6 +162,8 @@ def ray_march_write(o, d, t_min, t_max, jitter, roi, res, binary, ct, step, cone
         te = torch.empty(n_total, device=o.device, dtype=torch.float32)
     else:
         ri, ts, te = out
+    if n_total == 0:                                  # no ray meets an occupied cell: nothing to write
+        return ri, ts, te
     roi_c = (ctypes.c_float * 6)(*[float(v) for v in roi])
     res_c = (ctypes.c_int32 * 3)(*[int(v) for v in res])
     check(_lib.load().ren_ray_march(_ptr(o), _ptr(d), _ptr(t_min), _ptr(t_max), _ptr(jitter), n, roi_c, res_c,

@@ -464,6 +464,39 @@ def test_occgrid_update(amd, spec, full_table_cache):
     assert not r.update_occ_grid(3)                       # only every n-th step
 
 
+def test_rays_without_samples_render_background(amd, spec, full_table_cache):
+    """A ray chunk that meets no occupied cell (image rows above the object) renders the background, opacity 0,
+    and back-propagates nothing but d(bkgd) -- both samplers, training and inference."""
+    from oracle import field
+    ops, engine = amd
+    p = field.init_params(spec, seed=5)
+    p["hash"] = full_table_cache(7, 0.5)
+    R = 257
+    o = dev(torch.tensor([[4.0, 0.0, 0.0]]).repeat(R, 1))
+    d = dev(torch.tensor([[1.0, 0.0, 0.0]]).repeat(R, 1))          # looking away from the box
+    bk = dev(torch.tensor([0.7]))
+    for sampler in ("occgrid", "uniform"):
+        fld = engine.NGPField(DEV)
+        fld.load(p)
+        r = engine.Renderer(fld, engine.RenderCfg(sampler=sampler, n_uniform=16))
+        r.binary.fill_(1)
+        for training in (True, False):
+            colors, opac, depth, ctx = r.forward(o, d, dev(torch.rand(R)), bk, training=training, save=training)
+            assert ctx["pk"].n == 0 and torch.equal(colors, bk.expand(R, 1)) and float(opac.abs().max()) == 0.0
+        g = r.backward(ctx, torch.ones(R, 1, device=DEV))
+        assert float(g) == R and float(fld.g_table.abs().max()) == 0.0 and float(fld.g_mlp.abs().max()) == 0.0
+    # an image chunk with no hit among chunks with hits (evaluation.render_image)
+    from robust_e_nerf_amd import evaluation
+    r.binary.fill_(1)
+    Kinv = dev(torch.linalg.inv(torch.tensor([[20.0, 0, 31.5], [0, 20.0, 23.5], [0, 0, 1]])))
+    pos = dev(torch.tensor([0.0, 0.0, 6.0]))
+    rot = dev(torch.tensor([[1.0, 0, 0], [0, -1.0, 0], [0, 0, -1.0]]))          # looking down -z at the box
+    img_a, op_a, _ = evaluation.render_image(r, Kinv, pos, rot, 48, 64, bkgd=bk, chunk=64)      # one row per chunk
+    img_b, op_b, _ = evaluation.render_image(r, Kinv, pos, rot, 48, 64, bkgd=bk, chunk=48 * 64)
+    assert float(op_b[0].max()) == 0.0 and float(op_b[24].max()) > 0.0                           # empty and hit rows
+    assert torch.equal(img_a, img_b) and torch.equal(op_a, op_b)
+
+
 def test_chunked_two_stream_forward_equals_single_launch(amd, spec, full_table_cache):
     """RenderCfg.fwd_chunks: hash encoding / MLP of alternate sample chunks on two HIP streams (with the MLP kernel
     in its one-workgroup-per-CU mode) give bit-identical renders and gradients that agree to summation order."""

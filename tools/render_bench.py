@@ -1,0 +1,36 @@
+"""Novel-view inference render (BASELINE configs[4] shape: 640x480, occupancy-grid marching, no jitter): ms per image
+for different ray-chunk sizes.  Synthetic scene as bench.py.  GPU only."""
+import math, os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from oracle import hashgrid
+from robust_e_nerf_amd import engine, evaluation
+dev = "cuda:0"
+H, W = 480, 640
+gen = torch.Generator().manual_seed(0)
+def lin(o, i):
+    b = 1 / math.sqrt(i)
+    return (torch.rand(o, i, generator=gen) * 2 - 1) * b, (torch.rand(o, generator=gen) * 2 - 1) * b
+p = {}
+p["base.w0"], p["base.b0"] = lin(64, 32); p["base.wo"], p["base.bo"] = lin(16, 64)
+p["head.w0"], p["head.b0"] = lin(64, 31); p["head.w1"], p["head.b1"] = lin(64, 64); p["head.wo"], p["head.bo"] = lin(1, 64)
+p["hash"] = hashgrid.init_table(hashgrid.make_spec(), 0, 0.1, "mix32")
+aabb = (-1.5,) * 3 + (1.5,) * 3
+fld = engine.NGPField(dev); fld.load(p)
+r = engine.Renderer(fld, engine.RenderCfg(aabb=aabb, sampler="occgrid"))
+r.binary.copy_(torch.from_numpy(bench.ball_binary(128, 0.42, aabb)).to(dev))
+K = np.array([[480.0 * W / 346, 0, W / 2 - 0.5], [0, 480.0 * W / 346, H / 2 - 0.5], [0, 0, 1]])
+Kinv = torch.from_numpy(np.linalg.inv(K)).float().to(dev)
+pos = torch.tensor([4.0, 0.0, 0.3], device=dev)
+z = -pos / pos.norm(); x = torch.linalg.cross(torch.tensor([0.0, 0.0, 1.0], device=dev), z); x = x / x.norm(); y = torch.linalg.cross(z, x)
+rot = torch.stack([x, y, z], 1)
+bk = torch.tensor([0.7], device=dev)
+for chunk in (16384, 65536, H * W):
+    out = evaluation.render_image(r, Kinv, pos, rot, H, W, bkgd=bk, chunk=chunk); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        out = evaluation.render_image(r, Kinv, pos, rot, H, W, bkgd=bk, chunk=chunk)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 5
+    print(f"chunk {chunk:7d}: {dt * 1e3:7.2f} ms / image = {H * W / dt / 1e6:6.2f} M rays/s   (mean intensity {float(out[0].mean()):.4f})")
