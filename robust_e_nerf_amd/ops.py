@@ -188,6 +188,8 @@ def compact_samples(offsets, counts, new_offsets, keep, ts, te, n_new: int):
     ri2 = torch.empty(n_new, device=ts.device, dtype=torch.int32)
     ts2 = torch.empty(n_new, device=ts.device, dtype=torch.float32)
     te2 = torch.empty(n_new, device=ts.device, dtype=torch.float32)
+    if n_new == 0:                                    # everything culled by the visibility test
+        return ri2, ts2, te2
     check(_lib.load().ren_compact_samples(_ptr(offsets), _ptr(counts), _ptr(new_offsets), n_rays, _ptr(keep),
                                           _ptr(ts), _ptr(te), _ptr(ri2), _ptr(ts2), _ptr(te2), _stream()),
           "ren_compact_samples")

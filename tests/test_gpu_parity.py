@@ -485,8 +485,18 @@ def test_rays_without_samples_render_background(amd, spec, full_table_cache):
             assert ctx["pk"].n == 0 and torch.equal(colors, bk.expand(R, 1)) and float(opac.abs().max()) == 0.0
         g = r.backward(ctx, torch.ones(R, 1, device=DEV))
         assert float(g) == R and float(fld.g_table.abs().max()) == 0.0 and float(fld.g_mlp.abs().max()) == 0.0
+    # every marched sample culled by the visibility test (alpha threshold above any alpha the field produces)
+    fld = engine.NGPField(DEV)
+    fld.load(p)
+    r2 = engine.Renderer(fld, engine.RenderCfg(sampler="occgrid", alpha_thre=0.999999))
+    r2.binary.fill_(1)
+    oo = dev(torch.tensor([[4.0, 0.1, 0.2]]).repeat(R, 1))
+    dd = dev(torch.tensor([[-1.0, 0.0, 0.0]]).repeat(R, 1))
+    colors, opac, depth, ctx = r2.forward(oo, dd, dev(torch.rand(R)), bk, training=True)
+    assert ctx["pk"].n == 0 and ctx["pk"].n_marched > 0 and torch.equal(colors, bk.expand(R, 1))
     # an image chunk with no hit among chunks with hits (evaluation.render_image)
     from robust_e_nerf_amd import evaluation
+    r = engine.Renderer(fld, engine.RenderCfg(sampler="occgrid"))
     r.binary.fill_(1)
     Kinv = dev(torch.linalg.inv(torch.tensor([[20.0, 0, 31.5], [0, 20.0, 23.5], [0, 0, 1]])))
     pos = dev(torch.tensor([0.0, 0.0, 6.0]))
