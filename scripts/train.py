@@ -153,7 +153,13 @@ def main():
                         tau_raw=tau_raw, tau_max=tau_max, bkgd_raw=torch.tensor([softplus_inv(1.0)]),
                         world_size=world, process_group=None)
     if args.resume:
-        load_field_state_dict(fld, arch, torch.load(args.resume, map_location="cpu")["state_dict"])
+        rsd = torch.load(args.resume, map_location="cpu")["state_dict"]
+        load_field_state_dict(fld, arch, rsd)
+        if "nerf.parametrizations.render_bkgd.original" in rsd:
+            tr.small[: fld.C] = rsd["nerf.parametrizations.render_bkgd.original"].to(dev, torch.float32).reshape(-1)
+        if "nerf.occ_grid._binary" in rsd:
+            renderer.occs.copy_(rsd["nerf.occ_grid.occs"].to(dev).reshape(-1))
+            renderer.binary.copy_(rsd["nerf.occ_grid._binary"].reshape(-1).to(torch.uint8).to(dev))
 
     # ---- fit loop ---------------------------------------------------------------------------------------------
     tcf, sched = cfg["trainer"], cfg["lr_scheduler"]["multi_step_lr"]
@@ -183,6 +189,8 @@ def main():
             sd = field_state_dict(fld, arch)
             sd["contrast_threshold.parametrizations.p2n_contrast_threshold_ratio.original"] = tr.ct[:1].detach().cpu().clone()
             sd["refractory_period.parametrizations._refractory_period.original"] = tr.tau_raw.detach().clone()
+            if tcfg.bkgd_is_param:                      # models/nerf.py:81-88 (softplus-parametrised parameter)
+                sd["nerf.parametrizations.render_bkgd.original"] = tr.small[: fld.C].detach().cpu().clone()
             sd["nerf.occ_grid.occs"] = renderer.occs.detach().cpu().clone()
             sd["nerf.occ_grid._binary"] = renderer.binary.detach().cpu().bool().view(*rcfg.occ_res)
             torch.save({"state_dict": sd, "epoch": epoch, "global_step": step}, os.path.join(args.out, "last.ckpt"))
