@@ -467,8 +467,8 @@ extern "C" int ren_dense_bwd_weight(const float *dZ, int32_t ldz, const float *X
     (void)hipFuncSetAttribute((const void *)dense_dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(dense_dw_kernel, dim3(n_splits), dim3(512), lds, st, a);
     const int len_w = n_out * n_in;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((len_w + 255) / 256), dim3(256), 0, st, a.slab_w, n_splits, len_w, grad_w);
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((n_out + 255) / 256), dim3(256), 0, st, a.slab_b, n_splits, n_out, grad_b);
+    launch_reduce_slabs(a.slab_w, n_splits, len_w, grad_w, st);
+    launch_reduce_slabs(a.slab_b, n_splits, n_out, grad_b, st);
     REN_CHECK_LAUNCH();
 }
 

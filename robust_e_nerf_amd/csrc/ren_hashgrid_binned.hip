@@ -40,13 +40,19 @@ constexpr int SC_THREADS = REN_SC_THREADS;           // scatter workgroup: one s
 constexpr int SC_ENTRIES = SC_THREADS * 8;           // staged updates per level pass = 48 KiB
 constexpr int LEVEL_GROUPS = REN_LEVEL_GROUPS;      // a scatter workgroup walks lvl = group, group + LEVEL_GROUPS, ...
 constexpr int CNT_THREADS = 256, CNT_SAMPLES = 1024; // count workgroup: 4 samples per thread, all levels
-constexpr int64_t PART_ENTRIES_MAX = 1 << 21;        // updates per accumulate workgroup (large n)
-// ~1 024 parts whatever n is: one workgroup walks its part serially, so a fixed 2 M-entry part is a ~1 ms tail
-// when the whole call is only a few million updates (occupancy-grid sampling: ~10 samples per ray)
-inline int64_t part_entries_for(int64_t n) {
-    int64_t p = 1 << 16;
-    while (p < PART_ENTRIES_MAX && p * 1024 < n * 128) p <<= 1;
-    return p;
+// Updates per accumulate workgroup ("part").  A part follows n (a fixed 2 M-entry part is a ~1 ms single-workgroup
+// tail when the whole call is only a few million updates: occupancy-grid sampling, ~10 samples per ray), and it is
+// the capacity of a hashed bin whenever there are hashed levels, so that every hashed bin is ONE part: a bin cut
+// in two flushes both halves with 16 384 float atomics (memory-side, ~18 G/s chip-wide) instead of one coalesced
+// read-modify-write.  <= 2^23 updates of magnitude < 2^38 cannot overflow the 64-bit fixed-point sums.
+constexpr int64_t PART_ENTRIES_MIN = 1 << 16, PART_ENTRIES_MAX = 1 << 23;
+inline int64_t part_entries_for(int64_t n, int64_t hashed_cap) {
+    int64_t p = hashed_cap;
+    if (p == 0) {                                    // dense levels only: ~1 024 parts
+        p = PART_ENTRIES_MIN;
+        while (p < (1 << 21) && p * 1024 < n * 128) p <<= 1;
+    }
+    return p < PART_ENTRIES_MIN ? PART_ENTRIES_MIN : (p > PART_ENTRIES_MAX ? PART_ENTRIES_MAX : p);
 }
 // max |update| per level is published with atomicMax: spread over LMAX_SLOTS cache lines per level and
 // only raised when the value actually grows, so the workgroups do not queue on one memory channel.
@@ -489,7 +495,7 @@ __global__ __launch_bounds__(1024) void bin_accumulate_kernel(GridDev g, BinTab 
 
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-struct Layout { size_t counts, level_max, cursors, n_parts, bin_start, parts, out_idx, out_v, total, entries; int64_t max_parts, part_entries; };
+struct Layout { size_t counts, level_max, cursors, n_parts, bin_start, parts, out_idx, out_v, total, entries; int64_t max_parts; };
 
 Layout make_layout(int64_t n) {
     Layout L;
@@ -497,8 +503,7 @@ Layout make_layout(int64_t n) {
     // levels, 4096 per bin, one stride of count blocks; the offsets kernel clamps the regions to this total
     const size_t E = (size_t)n * 140 + (size_t)MAX_BINS * 4096 + 16 * 8 * 16 * CNT_SAMPLES;
     L.entries = E;
-    L.part_entries = part_entries_for(n);
-    L.max_parts = (int64_t)(E / L.part_entries) + MAX_BINS + 1;
+    L.max_parts = (int64_t)(E / PART_ENTRIES_MIN) + MAX_BINS + 1;   // room for the smallest part size
     size_t o = 0;
     L.counts = o; o += MAX_BINS * 4;                       // counts | level_max are cleared by one memset
     L.level_max = o; o = align256(o + LMAX_WORDS * 4);
@@ -543,14 +548,17 @@ static int binned_impl(const ren_grid_desc *grid, float *grad_table, const float
     }
     bt.bin_base[REN_MAX_LEVELS] = nb;
     for (int l = g.n_levels; l < REN_MAX_LEVELS; ++l) bt.bin_base[l] = nb;
+    int64_t hashed_cap = 0;
     for (int l = 0; l < REN_MAX_LEVELS; ++l) {
         bt.cap[l] = 0;
         if (l < g.n_levels && g.hashed[l]) {
             const int64_t bins = (g.size[l] + BIN_ENTRIES - 1) >> BIN_SHIFT;
             const int64_t mean = (8 * n + bins - 1) / bins;
             bt.cap[l] = (uint32_t)(mean + mean / 50 + 4096);
+            if ((int64_t)bt.cap[l] > hashed_cap) hashed_cap = bt.cap[l];
         }
     }
+    const int64_t part_entries = part_entries_for(n, hashed_cap);
     if (n == 0) return REN_OK;
     ren_scene_dev sc = {};
     if (scene) sc = ren_make_scene(scene);
@@ -570,7 +578,7 @@ static int binned_impl(const ren_grid_desc *grid, float *grad_table, const float
     const char *halve = getenv("REN_HGB_HALVE_REGIONS");
     bt.halve = halve && halve[0] == '1';
     const int64_t cnt_blocks = (n + CNT_SAMPLES - 1) / CNT_SAMPLES;
-    bt.cnt_stride = cnt_blocks >= 4096 ? 16 : 1;                      // >= 256 sampled blocks (2048 rays) or exact
+    bt.cnt_stride = cnt_blocks >= 4096 ? 16 : cnt_blocks >= 2048 ? 8 : cnt_blocks >= 1024 ? 4 : 1;   // >= 256 sampled blocks or exact
     const dim3 cgrd((unsigned)((cnt_blocks + bt.cnt_stride - 1) / bt.cnt_stride)), cblk(CNT_THREADS);
     const dim3 sgrd((unsigned)((n + SC_THREADS - 1) / SC_THREADS * LEVEL_GROUPS)), sblk(SC_THREADS);
     if (tan.dfeatd) hipLaunchKernelGGL(bin_count_kernel<true>, cgrd, cblk, 0, st, g, bt, a, ws.counts);
@@ -579,11 +587,12 @@ static int binned_impl(const ren_grid_desc *grid, float *grad_table, const float
                        ws.cursors, ws.bin_start);
     if (tan.dfeatd) hipLaunchKernelGGL(bin_scatter_kernel<true>, sgrd, sblk, 0, st, g, bt, a, ws, grad_table);
     else            hipLaunchKernelGGL(bin_scatter_kernel<false>, sgrd, sblk, 0, st, g, bt, a, ws, grad_table);
-    hipLaunchKernelGGL(bin_partition_kernel, dim3(1), dim3(MAX_BINS), 0, st, nb, (uint64_t)L.part_entries, ws.cursors, ws.bin_start, ws.parts,
+    hipLaunchKernelGGL(bin_partition_kernel, dim3(1), dim3(MAX_BINS), 0, st, nb, (uint64_t)part_entries, ws.cursors, ws.bin_start, ws.parts,
                        ws.n_parts);
     const size_t acc_lds = 2 * BIN_ENTRIES * sizeof(unsigned long long);
     (void)hipFuncSetAttribute((const void *)bin_accumulate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)acc_lds);
-    hipLaunchKernelGGL(bin_accumulate_kernel, dim3((unsigned)L.max_parts), dim3(1024), acc_lds, st, g, bt, ws, grad_table);
+    const int64_t acc_grid = (int64_t)(L.entries / part_entries) + nb + 1;
+    hipLaunchKernelGGL(bin_accumulate_kernel, dim3((unsigned)acc_grid), dim3(1024), acc_lds, st, g, bt, ws, grad_table);
     REN_CHECK_LAUNCH();
 }
 

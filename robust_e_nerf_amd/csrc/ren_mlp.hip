@@ -714,10 +714,8 @@ static int mlp_bwd_impl(bool rb, const float *mlp_params, int32_t C, const float
     if (rb) { if (sv) REN_BASE(true, true); else REN_BASE(true, false); }
     else    { if (sv) REN_BASE(false, true); else REN_BASE(false, false); }
 #undef REN_BASE
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((head_len + 255) / 256), dim3(256), 0, st, slab_h,
-                       GRID_H * 4, head_len, grad_mlp_params + P_BASE_N);
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((P_BASE_N + 255) / 256), dim3(256), 0, st, slab_b,
-                       GRID_B * 4, P_BASE_N, grad_mlp_params);
+    launch_reduce_slabs(slab_h, GRID_H * 4, head_len, grad_mlp_params + P_BASE_N, st);
+    launch_reduce_slabs(slab_b, GRID_B * 4, P_BASE_N, grad_mlp_params, st);
     REN_CHECK_LAUNCH();
 }
 

@@ -170,21 +170,36 @@ __device__ __forceinline__ void sample_geom(const SampleSrc &s, const ren_scene_
     sel = ux > 0.f && ux < 1.f && uy > 0.f && uy < 1.f && uz > 0.f && uz < 1.f;   // ngp.py:238
 }
 
-// grad[off + j] += sum_w slab[w * len + j]
-__global__ void reduce_slabs_kernel(const float *__restrict__ slab, int n_slabs, int len,
-                                    float *__restrict__ grad) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= len) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int w = 0;
-    for (; w + 3 < n_slabs; w += 4) {
-        s0 += slab[(int64_t)w * len + j];
-        s1 += slab[(int64_t)(w + 1) * len + j];
-        s2 += slab[(int64_t)(w + 2) * len + j];
-        s3 += slab[(int64_t)(w + 3) * len + j];
+// grad[j] += sum_w slab[w * len + j], deterministic (fixed summation tree, no atomics).  16 parameters x 16
+// slab groups per workgroup: with one thread per parameter walking all ~1 024 slabs the kernel was a 0.1 ms
+// latency chain, five of them per training step.
+constexpr int RS_P = 16, RS_Q = 16;
+__global__ __launch_bounds__(RS_P * RS_Q) void reduce_slabs_kernel(const float *__restrict__ slab, int n_slabs, int len,
+                                                                   float *__restrict__ grad) {
+    __shared__ float part[RS_Q][RS_P + 1];
+    const int p = threadIdx.x % RS_P, q = threadIdx.x / RS_P;
+    const int j = blockIdx.x * RS_P + p;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    if (j < len) {
+        int w = q;
+        for (; w + 3 * RS_Q < n_slabs; w += 4 * RS_Q) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s[u] += slab[(int64_t)(w + u * RS_Q) * len + j];
+        }
+        for (; w < n_slabs; w += RS_Q) s[0] += slab[(int64_t)w * len + j];
     }
-    for (; w < n_slabs; ++w) s0 += slab[(int64_t)w * len + j];
-    grad[j] += (s0 + s1) + (s2 + s3);
+    part[q][p] = (s[0] + s[1]) + (s[2] + s[3]);
+    __syncthreads();
+    if (q == 0 && j < len) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < RS_Q; ++k) t += part[k][p];
+        grad[j] += t;
+    }
+}
+
+inline void launch_reduce_slabs(const float *slab, int n_slabs, int len, float *grad, hipStream_t st) {
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((len + RS_P - 1) / RS_P), dim3(RS_P * RS_Q), 0, st, slab, n_slabs, len, grad);
 }
 
 }  // namespace

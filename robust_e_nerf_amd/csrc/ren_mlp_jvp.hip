@@ -743,11 +743,8 @@ extern "C" int ren_mlp_bwd_jvp(const float *mlp_params, int32_t C, const float *
     ab.params = mlp_params; ab.feat = feat; ab.featd = featd; ab.d_base = d_base; ab.d_based = d_based; ab.n = n;
     ab.dfeat = dfeat; ab.dfeatd = dfeatd; ab.slab = slabb;
     hipLaunchKernelGGL(mlp_bwd_jvp_base_kernel, dim3(GRID_J), dim3(256), JB_LDS, st, ab);
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((len_h2(C) + 255) / 256), dim3(256), 0, st, slab2, GRID_J * 4,
-                       len_h2(C), grad_mlp_params + P_HW1);
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((LEN_H1 + 255) / 256), dim3(256), 0, st, slab1, GRID_J * 4, LEN_H1,
-                       grad_mlp_params + P_HW0);
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((P_BASE_N + 255) / 256), dim3(256), 0, st, slabb, GRID_J * 4,
-                       P_BASE_N, grad_mlp_params);
+    launch_reduce_slabs(slab2, GRID_J * 4, len_h2(C), grad_mlp_params + P_HW1, st);
+    launch_reduce_slabs(slab1, GRID_J * 4, LEN_H1, grad_mlp_params + P_HW0, st);
+    launch_reduce_slabs(slabb, GRID_J * 4, P_BASE_N, grad_mlp_params, st);
     REN_CHECK_LAUNCH();
 }

@@ -786,9 +786,8 @@ int launch_bwd_x(const BwdXHArgs &h, const BwdXBArgs &b, int C, float *grad, hip
     (void)hipFuncSetAttribute((const void *)mlp_bwd_base_x_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
     hipLaunchKernelGGL((mlp_bwd_base_x_kernel<MODE>), dim3(GRID_XB), dim3(256), lds_b, st, b);
     const int head_len = p_total(C) - P_BASE_N;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((head_len + 255) / 256), dim3(256), 0, st, h.slab, GRID_XH * 4, head_len,
-                       grad + P_BASE_N);
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((P_BASE_N + 255) / 256), dim3(256), 0, st, b.slab, GRID_XB * 4, P_BASE_N, grad);
+    launch_reduce_slabs(h.slab, GRID_XH * 4, head_len, grad + P_BASE_N, st);
+    launch_reduce_slabs(b.slab, GRID_XB * 4, P_BASE_N, grad, st);
     REN_CHECK_LAUNCH();
 }
 

@@ -163,7 +163,7 @@ class Renderer:
     def _field_forward(self, o, d, pk, save):
         f = self.field
         samples = (pk.ray_indices, pk.t_starts, pk.t_ends)
-        chunks = min(self.cfg.fwd_chunks, pk.n >> 20)                  # >= 1 M samples (128 blocks per wave) per chunk
+        chunks = min(self.cfg.fwd_chunks, pk.n >> 20) if pk.n >= (1 << 23) else 1   # pays from ~8 M samples, >= 1 M per chunk
         if self.cfg.mlp_kernels == "x" and chunks > 1:
             return self._field_forward_chunked(o, d, pk, save, chunks)
         feat = ops.hashgrid_fwd(f.grid, f.table, scene=self.scene, rays=(o, d), samples=samples, n=pk.n, layout=1)

@@ -514,7 +514,7 @@ def test_chunked_two_stream_forward_equals_single_launch(amd, spec, full_table_c
     ops, engine = amd
     p = field.init_params(spec, seed=5)
     p["hash"] = full_table_cache(7, 0.5)
-    R = 32768                                                    # x 128 samples = 4 M samples -> 4 chunks
+    R = 65536                                                    # x 128 samples = 8 M samples -> 8 chunks
     gen = torch.Generator().manual_seed(3)
     ang = torch.rand(R, generator=gen) * 2 * math.pi
     o = torch.stack([4 * torch.cos(ang), 4 * torch.sin(ang), torch.rand(R, generator=gen) - 0.5], -1)

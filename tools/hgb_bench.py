@@ -4,7 +4,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from robust_e_nerf_amd import _lib, ops, engine
 dev = "cuda:0"
-R, S = 131072, 128
+R, S = int(os.environ.get("RAYS", 131072)), 128
 grid, n_table = ops.make_grid_desc()
 g = torch.Generator().manual_seed(0)
 ang = torch.rand(R, generator=g) * 2 * math.pi
