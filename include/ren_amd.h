@@ -222,6 +222,31 @@ int ren_event_loss_bwd(const float *intensity_start, const float *intensity_end,
                        const uint8_t *valid, int64_t B, int32_t err_fn, float scale,
                        const float *loss_sum, float *g_start, float *g_end, void *stream);
 
+/* ---- event batch glue ---------------------------------------------------------------------------
+ * ren_event_prepare: ContrastThreshold.forward and RefractoryPeriod.forward
+ * (models/event_generation_params.py:72-84,196-203), the supervision timestamps of
+ * RobustENeRF.training_step (models/robust_e_nerf.py:319-357) and both loss targets
+ * (loss_metric/loss.py:39-42,63-66) for B events in one launch:
+ *   ev = num_pos C_p - num_neg C_n (float32);  start = start_ts + tau (float64);
+ *   ts_diff = (end - start) u_ts_diff;  ts_start = lerp(start, max(end - ts_diff, start), u_diff_start);
+ *   ts_end = min(ts_start + ts_diff, end);  target_diff = float(ts_diff ev / (end - start));
+ *   ts_grad = lerp(ts_start, ts_end, u_grad), target_grad = float(ev / (end - start))   [optional, NULL to skip];
+ *   dts_* = d ts_* / d tau  [optional: only when the refractory period is trained].
+ * ren_event_param_grad: d(loss term)/d(raw C_p/C_n ratio) and the direct d(loss term)/d(tau) through the loss
+ * target with the rendered prediction held fixed -- the closed form of what the reference obtains by autograd
+ * through event_generation_params.py:51-84 and loss.py:32-74 with the scaling of robust_e_nerf.py:470-486.
+ * kind 0: pred = log I_end - log I_start against target_diff; kind 1: pred = d log I / dt against target_grad.
+ * param_weight_power k: the 1/C^k normalisation (0: none).  Accumulates (+=) into ct_grad[1] (float32) and
+ * tau_grad[1] (float64) on the device; either may be NULL. */
+int ren_event_prepare(const int64_t *start_ts, const int64_t *end_ts, const int64_t *num_pos, const int64_t *num_neg,
+                      const double *u_ts_diff, const double *u_diff_start, const double *u_grad, int64_t B, float c_p,
+                      float c_n, double tau, double *ts_start, double *ts_end, float *target_diff, double *ts_grad,
+                      float *target_grad, double *dts_start, double *dts_end, double *dts_grad, void *stream);
+int ren_event_param_grad(int32_t kind, int32_t err_fn, int32_t param_weight_power, const float *pred,
+                         const uint8_t *valid, const int64_t *start_ts, const int64_t *end_ts, const int64_t *num_pos,
+                         const int64_t *num_neg, const double *u_ts_diff, int64_t B, float c_p, float c_n,
+                         float raw_ratio, double tau, float weight, float *ct_grad, double *tau_grad, void *stream);
+
 /* ---- optimiser ----------------------------------------------------------------------------------
  * torch.optim.Adam step as configured by RobustENeRF.configure_optimizers
  * (models/robust_e_nerf.py:782-813): L2-style weight decay (grad += wd*p), bias correction.

@@ -57,6 +57,9 @@ SIGNATURES = {
     "ren_mlp_fwd_save": (c_int, [P, c_int32, c_int32, P, POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, P, P, P, P, P]),
     "ren_mlp_bwd_saved": (c_int, [P, c_int32, c_int32, P, P, P, POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, P, P, P,
                                   P, P, P, P, P]),
+    "ren_event_prepare": (c_int, [P, P, P, P, P, P, P, c_int64, c_float, c_float, c_double, P, P, P, P, P, P, P, P, P]),
+    "ren_event_param_grad": (c_int, [c_int32, c_int32, c_int32, P, P, P, P, P, P, P, c_int64, c_float, c_float, c_float,
+                                     c_double, c_float, P, P, P]),
     "ren_mlp_fwd_x": (c_int, [P, c_int32, c_int32, P, POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, c_int32, P, P, P, P, P]),
     "ren_mlp_bwd_x_workspace_floats": (c_int64, [c_int32]),
     "ren_mlp_bwd_x": (c_int, [P, c_int32, c_int32, P, P, P, POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, P, P, P, P, P,

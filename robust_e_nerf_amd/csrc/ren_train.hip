@@ -164,7 +164,161 @@ __global__ void binarize_kernel(const float *__restrict__ occs, int64_t cells, f
     binary[i] = (uint8_t)(occs[i] > thr);
 }
 
+// ---------------------------------------------------------------------------------- event batch glue
+// a2-a4 of SURVEY 8(a) in ONE launch instead of ~15 float64 torch kernels (at the reference's 2^20-sample
+// budget the step is launch-bound on this glue): event correction (event_generation_params.py:72-84,196-203),
+// supervision timestamps (robust_e_nerf.py:319-357) and both loss targets (loss.py:39-42,63-66), plus the
+// derivative of every supervision timestamp w.r.t. the refractory period (chain rule of the same lines).
+struct PrepArgs {
+    const int64_t *start_ts, *end_ts, *num_pos, *num_neg;
+    const double *u_ts_diff, *u_diff_start, *u_grad;
+    int64_t B;
+    float c_p, c_n;
+    double tau;
+    double *ts_start, *ts_end, *ts_grad, *dts_start, *dts_end, *dts_grad;
+    float *target_diff, *target_grad;
+};
+
+__device__ __forceinline__ double lerp64(double a, double b, double w) {      // torch.lerp's two-sided formula
+    const double diff = b - a;
+    return fabs(w) < 0.5 ? a + w * diff : b - diff * (1.0 - w);
+}
+
+__global__ __launch_bounds__(256) void event_prepare_kernel(PrepArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.B) return;
+    const float ev = __fsub_rn(__fmul_rn((float)a.num_pos[i], a.c_p), __fmul_rn((float)a.num_neg[i], a.c_n));
+    const double end = (double)a.end_ts[i];
+    const double start = (double)a.start_ts[i] + a.tau;
+    const double u1 = a.u_ts_diff[i], u2 = a.u_diff_start[i];
+    const double span = end - start;
+    const double ts_diff = span * u1;
+    const bool late = end - ts_diff > start;                       // max(end - ts_diff, start)
+    const double hi = late ? end - ts_diff : start;
+    const double d_start = lerp64(start, hi, u2);
+    const bool inside = d_start + ts_diff < end;                   // min(d_start + ts_diff, end)
+    const double d_end = inside ? d_start + ts_diff : end;
+    const double rate = (double)ev / span;
+    a.ts_start[i] = d_start;
+    a.ts_end[i] = d_end;
+    a.target_diff[i] = (float)(ts_diff * rate);
+    if (a.target_grad) a.target_grad[i] = (float)rate;
+    // d/d tau: start' = 1, ts_diff' = -u1, hi' = late ? u1 : 1
+    const double g_start = (1.0 - u2) + u2 * (late ? u1 : 1.0);
+    const double g_end = inside ? g_start - u1 : 0.0;
+    if (a.dts_start) { a.dts_start[i] = g_start; a.dts_end[i] = g_end; }
+    if (a.ts_grad) {
+        const double u3 = a.u_grad[i];
+        a.ts_grad[i] = lerp64(d_start, d_end, u3);
+        if (a.dts_grad) a.dts_grad[i] = (1.0 - u3) * g_start + u3 * g_end;
+    }
+}
+
+// d(loss term)/d(raw contrast-threshold ratio) and the DIRECT d(loss term)/d(tau) through the loss target, with
+// the rendered prediction held fixed (event_generation_params.py:51-84,196-203, loss.py:32-74,
+// robust_e_nerf.py:470-486): closed form of what the reference gets from autograd, one workgroup.
+//   L = w pw(C) mean_valid e(pred - target),  C = (C_p + C_n)/2,  C_p = softplus(raw) C_n,  pw = C^-k
+struct ParamGradArgs {
+    const float *pred;
+    const uint8_t *valid;
+    const int64_t *start_ts, *end_ts, *num_pos, *num_neg;
+    const double *u_ts_diff;
+    int64_t B;
+    int kind, fn, pw_k;                                            // kind 0: diff target, 1: rate target
+    float c_p, c_n, raw, weight;
+    double tau;
+    float *ct_grad;                                                // += dL/d raw   (NULL: skip)
+    double *tau_grad;                                              // += dL/d tau   (NULL: skip)
+};
+
+__global__ __launch_bounds__(1024) void event_param_grad_kernel(ParamGradArgs a) {
+    __shared__ double red[4][16];
+    double s_e = 0.0, s_c = 0.0, s_t = 0.0, cnt = 0.0;
+    for (int64_t i = threadIdx.x; i < a.B; i += 1024) {
+        if (a.valid && !a.valid[i]) continue;
+        const float np = (float)a.num_pos[i], nn = (float)a.num_neg[i];
+        const float ev = __fsub_rn(__fmul_rn(np, a.c_p), __fmul_rn(nn, a.c_n));
+        const double span = (double)a.end_ts[i] - ((double)a.start_ts[i] + a.tau);
+        const double rate = (double)ev / span;
+        double tgt, t_c, t_t;                                      // target and its derivatives w.r.t. C_p, tau
+        if (a.kind == 0) {
+            const double u1 = a.u_ts_diff[i], ts_diff = span * u1;
+            tgt = ts_diff * rate;
+            t_c = ts_diff * (double)np / span;
+            t_t = -u1 * rate + ts_diff * (double)ev / (span * span);
+        } else {
+            tgt = rate;
+            t_c = (double)np / span;
+            t_t = (double)ev / (span * span);
+        }
+        const float tf = (float)tgt, p = a.pred[i], d = p - tf;
+        const float sg = (float)((d > 0.f) - (d < 0.f));
+        float e, e_t;                                              // error and d error / d target
+        if (a.fn == 0) { e = fabsf(d); e_t = -sg; }
+        else if (a.fn == 1) { e = d * d; e_t = -2.f * d; }
+        else {
+            const float at = fabsf(tf), den = fmaxf(at, 2.220446049250313e-16f);
+            e = fabsf(d) / den;
+            e_t = -sg / den - (at > 2.220446049250313e-16f ? fabsf(d) * (float)((tf > 0.f) - (tf < 0.f)) / (den * den) : 0.f);
+        }
+        s_e += (double)e; s_c += (double)e_t * t_c; s_t += (double)e_t * t_t; cnt += 1.0;
+    }
+    double v[4] = {s_e, s_c, s_t, cnt};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_xor(v[k], off, 64);
+        if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int k = 0; k < 4; ++k)
+            for (int w = 0; w < 16; ++w) t[k] += red[k][w];
+        const double C = ((double)a.c_p + (double)a.c_n) * 0.5;
+        const double pw = a.pw_k == 0 ? 1.0 : (a.pw_k == 1 ? 1.0 / C : 1.0 / (C * C));
+        const double dpw = a.pw_k == 0 ? 0.0 : (a.pw_k == 1 ? -0.5 / (C * C) : -1.0 / (C * C * C));   // d pw / d C_p
+        const double mean_e = t[0] / t[3], mean_c = t[1] / t[3], mean_t = t[2] / t[3];
+        const double g_cp = (double)a.weight * (dpw * mean_e + pw * mean_c);
+        const double sig = 1.0 / (1.0 + exp(-(double)a.raw));     // d softplus(raw) / d raw
+        if (a.ct_grad) a.ct_grad[0] += (float)(g_cp * sig * (double)a.c_n);
+        if (a.tau_grad) a.tau_grad[0] += (double)a.weight * pw * mean_t;
+    }
+}
+
 }  // namespace
+
+extern "C" int ren_event_prepare(const int64_t *start_ts, const int64_t *end_ts, const int64_t *num_pos,
+                                 const int64_t *num_neg, const double *u_ts_diff, const double *u_diff_start,
+                                 const double *u_grad, int64_t B, float c_p, float c_n, double tau, double *ts_start,
+                                 double *ts_end, float *target_diff, double *ts_grad, float *target_grad,
+                                 double *dts_start, double *dts_end, double *dts_grad, void *stream) {
+    if (!start_ts || !end_ts || !num_pos || !num_neg || !u_ts_diff || !u_diff_start || !ts_start || !ts_end ||
+        !target_diff || B < 0)
+        return REN_ERR_BAD_ARG;
+    if ((ts_grad && !u_grad) || (dts_grad && !ts_grad) || ((dts_start == nullptr) != (dts_end == nullptr)))
+        return REN_ERR_BAD_ARG;
+    if (B == 0) return REN_OK;
+    PrepArgs a{start_ts, end_ts, num_pos, num_neg, u_ts_diff, u_diff_start, u_grad, B, c_p, c_n, tau,
+               ts_start, ts_end, ts_grad, dts_start, dts_end, dts_grad, target_diff, target_grad};
+    hipLaunchKernelGGL(event_prepare_kernel, dim3(ren_blocks(B, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    REN_CHECK_LAUNCH();
+}
+
+extern "C" int ren_event_param_grad(int32_t kind, int32_t err_fn, int32_t param_weight_power, const float *pred,
+                                    const uint8_t *valid, const int64_t *start_ts, const int64_t *end_ts,
+                                    const int64_t *num_pos, const int64_t *num_neg, const double *u_ts_diff, int64_t B,
+                                    float c_p, float c_n, float raw_ratio, double tau, float weight, float *ct_grad,
+                                    double *tau_grad, void *stream) {
+    if (kind < 0 || kind > 1 || err_fn < 0 || err_fn > 2 || param_weight_power < 0 || param_weight_power > 2)
+        return REN_ERR_BAD_ARG;
+    if (!pred || !start_ts || !end_ts || !num_pos || !num_neg || (kind == 0 && !u_ts_diff) || B < 0) return REN_ERR_BAD_ARG;
+    if (B == 0 || (!ct_grad && !tau_grad)) return REN_OK;
+    ParamGradArgs a{pred, valid, start_ts, end_ts, num_pos, num_neg, u_ts_diff, B, kind, err_fn, param_weight_power,
+                    c_p, c_n, raw_ratio, weight, tau, ct_grad, tau_grad};
+    hipLaunchKernelGGL(event_param_grad_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
+    REN_CHECK_LAUNCH();
+}
 
 extern "C" int ren_event_loss_fwd(const float *i_start, const float *i_end, const float *target,
                                   const uint8_t *valid, int64_t B, int32_t err_fn, float *loss_sum,

@@ -392,7 +392,7 @@ class Trainer:
         # host side of the step -- its gradient is assembled from per-ray forward-mode tangents dI/dt.
         self.tau_raw = traw.clone().requires_grad_(False)
         self.tau_max = tmax.to(torch.float64)
-        self.tau_grad = torch.zeros((), dtype=torch.float64)
+        self._tau_grad_dev = torch.zeros(1, dtype=torch.float64, device=dev)   # d loss / d tau, accumulated on the device
         self._tau_opt = None
         # small-parameter block: [bkgd_raw (C) | pad] with its own Adam state (group "others", lr default)
         self.small = torch.zeros(4, device=dev, dtype=torch.float32)
@@ -412,24 +412,13 @@ class Trainer:
         # normalisation only, i.e. O(B) elementwise work on already rendered predictions.
         self.ct = torch.zeros(4, device=dev, dtype=torch.float32)
         self.ct[0] = p2n_raw.detach().reshape(-1)[0].to(dev, torch.float32)
+        self.ct_raw = float(p2n_raw.detach().reshape(-1)[0])
         self.ct_grad, self.ct_m, self.ct_v = torch.zeros_like(self.ct), torch.zeros_like(self.ct), torch.zeros_like(self.ct)
 
-    def _tau_chain(self, batch, which):
-        """d(supervision timestamp)/d(tau) per event, float64, for which in {"start", "end", "grad"}
-        (robust_e_nerf.py:319-357 differentiated w.r.t. the refractory period).  Every timestamp depends
-        on tau through its own event only, so the gradient of the sum w.r.t. a per-event copy of tau is the
-        per-event derivative."""
-        end = batch["end_ts"].to(torch.float64)
-        tau_v = torch.full_like(end, self.tau).requires_grad_()
-        start = batch["start_ts"].to(torch.float64) + tau_v
-        ts_diff = (end - start) * batch["u_ts_diff"]
-        d_start = torch.lerp(start, torch.max(end - ts_diff, start), batch["u_diff_start"])
-        d_end = torch.min(d_start + ts_diff, end)
-        out = {"start": d_start, "end": d_end}
-        if which == "grad":
-            out["grad"] = torch.lerp(d_start, d_end, batch["u_grad"])
-        (gv,) = torch.autograd.grad(out[which].sum(), tau_v)
-        return gv
+    @property
+    def tau_grad(self) -> torch.Tensor:
+        """d loss / d tau accumulated so far (float64 scalar, host copy)"""
+        return self._tau_grad_dev.cpu().reshape(())
 
     def _refresh_tau(self):
         if self.t.train_refractory_period:
@@ -440,50 +429,26 @@ class Trainer:
 
     def _refresh_contrast_threshold(self):
         if self.t.train_contrast_threshold:
-            ratio = float(torch.nn.functional.softplus(self.ct[0]))      # 4-byte host read per step
+            raw = self.ct[0]
+            self.ct_raw, ratio = torch.stack([raw, torch.nn.functional.softplus(raw)]).tolist()   # one 8-byte host read per step
             self.c_p = ratio * self.c_n
             self.mean_c = (self.c_p + self.c_n) / 2
 
-    def _contrast_threshold_grad(self, batch, pred, kind: str, valid=None):
-        """d(loss term)/d(raw ratio) and the DIRECT d(loss term)/d(tau) (through the event rate target),
-        with the rendered prediction held fixed (event_generation_params.py:51-84,196-203, loss.py:32-74,
-        robust_e_nerf.py:470-486), by autograd on (B,) device tensors."""
+    def _param_grad(self, batch, pred, kind: str, valid=None):
+        """d(loss term)/d(raw ratio) and the DIRECT d(loss term)/d(tau) (through the event-rate target), with the
+        rendered prediction held fixed: `ren_event_param_grad` (closed form of the reference's autograd through
+        event_generation_params.py:51-84,196-203, loss.py:32-74, robust_e_nerf.py:470-486)."""
         t = self.t
-        dev = pred.device
-        raw = self.ct[0].detach().clone().requires_grad_()
-        tau = torch.tensor(self.tau, dtype=torch.float64, device=dev, requires_grad=True)
-        c_p = torch.nn.functional.softplus(raw) * self.c_n
-        mean_c = (c_p + self.c_n) / 2
-        ev = batch["num_pos"] * c_p - batch["num_neg"] * self.c_n
-        start = batch["start_ts"].to(torch.float64) + tau
-        rate = ev / (batch["end_ts"] - start)
-        if kind == "diff":
-            ts_diff = (batch["end_ts"] - start) * batch["u_ts_diff"]
-            target, err, w, pwk = (ts_diff * rate).to(torch.float32), t.err_diff, t.w_diff, t.pw_diff
-        else:
-            target, err, w, pwk = rate.to(torch.float32), t.err_grad, t.w_grad, t.pw_grad
-        d = pred.detach() - target
-        e = {"l1": d.abs(), "mse": d * d, "mape": d.abs() / target.abs().clamp(min=2.220446049250313e-16)}[err]
-        if valid is not None:
-            e = e[valid.bool()]
-        pw = {None: 1.0, "mean_contrast_reciprocal": 1 / mean_c, "mean_contrast_reciprocal_sq": 1 / mean_c ** 2}[pwk]
-        g_raw, g_tau = torch.autograd.grad(w * pw * e.mean(), [raw, tau], allow_unused=True)
-        if t.train_contrast_threshold and g_raw is not None:
-            self.ct_grad[0] += g_raw.to(torch.float32)
-        if t.train_refractory_period and g_tau is not None:
-            self.tau_grad = self.tau_grad + g_tau.detach().cpu()
+        err, w, pwk = (t.err_diff, t.w_diff, t.pw_diff) if kind == "diff" else (t.err_grad, t.w_grad, t.pw_grad)
+        ops.event_param_grad(kind, err, pwk, pred.contiguous(), valid, batch, self.c_p, self.c_n, self.ct_raw, self.tau, w,
+                             ct_grad=self.ct_grad if t.train_contrast_threshold else None,
+                             tau_grad=self._tau_grad_dev if t.train_refractory_period else None)
 
-    # ---- a2-a4: event correction + supervision timestamps (float64 elementwise, negligible) -------
+    # ---- a2-a4: event correction + supervision timestamps: one launch (ren_event_prepare) ---------------------
     def _prepare(self, batch):
-        ev_diff = batch["num_pos"] * self.c_p - batch["num_neg"] * self.c_n   # :72-84 (float32)
-        start = batch["start_ts"].to(torch.float64) + self.tau            # :196-203 (float64)
-        end = batch["end_ts"]
-        ts_diff = (end - start) * batch["u_ts_diff"]                      # robust_e_nerf.py:322-336
-        d_start = torch.lerp(start, torch.max(end - ts_diff, start), batch["u_diff_start"])
-        d_end = torch.min(d_start + ts_diff, end.to(torch.float64))
-        target_grad = ev_diff / (end - start)                             # loss.py:39-42 (float64)
-        target = (ts_diff * target_grad).to(torch.float32)                # loss.py:63-66
-        return d_start.contiguous(), d_end.contiguous(), target.contiguous()
+        B = batch["position"].shape[0]
+        p = ops.event_prepare(batch, self.c_p, self.c_n, self.tau)
+        return p["ts"][:B], p["ts"][B:], p["target_diff"]
 
     def forward_backward(self, batch, jitter_start=None, jitter_end=None):
         """Loss + gradients (no optimiser step).  Returns (loss tensor (device scalar), aux)."""
@@ -491,8 +456,8 @@ class Trainer:
         B = batch["position"].shape[0]
         self._refresh_contrast_threshold()
         self._refresh_tau()
-        d_start, d_end, target = self._prepare(batch)
-        ts_all = torch.cat([d_start, d_end])
+        prep = ops.event_prepare(batch, self.c_p, self.c_n, self.tau, with_dtau=t.train_refractory_period)
+        ts_all, target = prep["ts"], prep["target_diff"]
         px = torch.cat([batch["position"], batch["position"]]).contiguous()
         jitter = None
         if jitter_start is not None:
@@ -522,13 +487,12 @@ class Trainer:
         g_s, g_e = ops.event_loss_bwd(i_s, i_e, target, valid, t.err_diff, scale, loss_sum)
         g_colors = torch.cat([g_s, g_e])[:, None].contiguous()
         if t.train_contrast_threshold or t.train_refractory_period:
-            self._contrast_threshold_grad(batch, i_e.log() - i_s.log(), "diff", valid)
+            self._param_grad(batch, i_e.log() - i_s.log(), "diff", valid)
         if t.train_refractory_period:
             # through the poses: sum_i dL/dI_i * dI_i/dt_i * dt_i/dtau  (start and end renders)
             idot = colords[:, 0].double()
-            g_tau = (g_s.double() * idot[:B] * self._tau_chain(batch, "start")).sum() \
-                + (g_e.double() * idot[B:] * self._tau_chain(batch, "end")).sum()
-            self.tau_grad = self.tau_grad + g_tau.detach().cpu()
+            self._tau_grad_dev += (g_s.double() * idot[:B] * prep["dts_start"]).sum() \
+                + (g_e.double() * idot[B:] * prep["dts_end"]).sum()
         d_bkgd = r.backward(ctx, g_colors)
         if d_bkgd is not None:
             self.small_grad[: f.C] += d_bkgd * torch.sigmoid(self.small[: f.C])     # d softplus
@@ -545,11 +509,8 @@ class Trainer:
         B = batch["position"].shape[0]
         self._refresh_contrast_threshold()
         self._refresh_tau()
-        d_start, d_end, _ = self._prepare(batch)
-        ts_g = torch.lerp(d_start, d_end, batch["u_grad"]).contiguous()
-        ev_diff = batch["num_pos"] * self.c_p - batch["num_neg"] * self.c_n
-        start = batch["start_ts"].to(torch.float64) + self.tau
-        target = (ev_diff / (batch["end_ts"] - start)).to(torch.float32).contiguous()      # loss.py:39-42
+        prep = ops.event_prepare(batch, self.c_p, self.c_n, self.tau, with_grad_ts=True, with_dtau=t.train_refractory_period)
+        ts_g, target = prep["ts_grad"], prep["target_grad"]                                 # loss.py:39-42
         ddd = None
         if t.train_refractory_period:                                  # tau moves ts_g: second-order tangent
             pos, rot, dpos, drot, ddrot = jvp.trajectory_jvp2(ts_g, self.tab_ts, self.tab_pos, self.tab_quat)
@@ -570,13 +531,12 @@ class Trainer:
         loss = loss_sum[0] / loss_sum[1] * scale
         g_i, g_id = jvp.grad_loss_bwd(inten, intend, target, valid, t.err_grad, scale, loss_sum)
         if t.train_contrast_threshold or t.train_refractory_period:
-            self._contrast_threshold_grad(batch, intend / inten, "grad", valid)
+            self._param_grad(batch, intend / inten, "grad", valid)
         if t.train_refractory_period:
             # d L/d tau through the pose: dL/dI * dI/dt + dL/dI' * d2I/dt2, times d ts_g/d tau  (per event)
             _, _, colorsdd = jvp.render_forward2(r, o, d, od, dd, ddd, ctx["pk"], bkgd)
-            dts = self._tau_chain(batch, "grad")
             per_ev = g_i.double() * intend.double() + g_id.double() * colorsdd[:, 0].double()
-            self.tau_grad = self.tau_grad + (per_ev * dts.to(per_ev.device)).sum().cpu()
+            self._tau_grad_dev += (per_ev * prep["dts_grad"]).sum()
         d_bkgd = jvp.render_backward(r, ctx, g_i[:, None].contiguous(), g_id[:, None].contiguous())
         if d_bkgd is not None:
             self.small_grad[: f.C] += d_bkgd * torch.sigmoid(self.small[: f.C])
@@ -604,18 +564,16 @@ class Trainer:
             if self._tau_opt is None:
                 self.tau_raw.requires_grad_(True)
                 self._tau_opt = torch.optim.Adam([self.tau_raw], lr=float(self.tau_max) * self.t.relative_lr_refractory_period)
-            g = self.tau_grad
             if self.world_size > 1:
                 import torch.distributed as dist
-                gd = g.to(f.flat.device)
-                dist.all_reduce(gd, group=self.pg)
-                g = gd.cpu()
+                dist.all_reduce(self._tau_grad_dev, group=self.pg)
+            g = self.tau_grad                                                # the one host read of this group
             sg = torch.sigmoid(self.tau_raw.detach() / self.tau_max)
             self.tau_raw.grad = (g * gs * sg * (1 - sg)).to(torch.float64).reshape(self.tau_raw.shape)
             for grp in self._tau_opt.param_groups:
                 grp["lr"] = float(self.tau_max) * self.t.relative_lr_refractory_period * self.lr_scale
             self._tau_opt.step()
-            self.tau_grad = torch.zeros((), dtype=torch.float64)
+            self._tau_grad_dev.zero_()
         if self.t.train_contrast_threshold:
             if self.world_size > 1:
                 from . import parallel

@@ -414,6 +414,42 @@ def column_sum(x: torch.Tensor):
 ERR_FN = {"l1": 0, "mse": 1, "mape": 2}
 
 
+PARAM_WEIGHT_POWER = {None: 0, "mean_contrast_reciprocal": 1, "mean_contrast_reciprocal_sq": 2}
+
+
+def event_prepare(batch, c_p: float, c_n: float, tau: float, *, with_grad_ts: bool = False, with_dtau: bool = False):
+    """a2-a4 in one launch -> dict(ts (2B,) f64 [start | end], target_diff f32, ts_grad, target_grad, dts_start,
+    dts_end, dts_grad) -- the optional entries are None unless asked for."""
+    st, en = batch["start_ts"], batch["end_ts"]
+    B, dev = st.shape[0], st.device
+    ts = torch.empty(2 * B, device=dev, dtype=torch.float64)
+    target = torch.empty(B, device=dev, dtype=torch.float32)
+    ts_g = torch.empty(B, device=dev, dtype=torch.float64) if with_grad_ts else None
+    target_g = torch.empty(B, device=dev, dtype=torch.float32) if with_grad_ts else None
+    dts = torch.empty(3 if with_grad_ts else 2, B, device=dev, dtype=torch.float64) if with_dtau else None
+    check(_lib.load().ren_event_prepare(
+        _ptr(st, torch.int64), _ptr(en, torch.int64), _ptr(batch["num_pos"], torch.int64), _ptr(batch["num_neg"], torch.int64),
+        _ptr(batch["u_ts_diff"], torch.float64), _ptr(batch["u_diff_start"], torch.float64),
+        _ptr(batch["u_grad"], torch.float64) if with_grad_ts else None, B, _f(c_p), _f(c_n), ctypes.c_double(float(tau)),
+        _ptr(ts), _ptr(ts[B:]) if B else None, _ptr(target), _ptr(ts_g), _ptr(target_g),
+        _ptr(dts[0]) if with_dtau else None, _ptr(dts[1]) if with_dtau else None,
+        _ptr(dts[2]) if (with_dtau and with_grad_ts) else None, _stream()), "ren_event_prepare")
+    return dict(ts=ts, target_diff=target, ts_grad=ts_g, target_grad=target_g,
+                dts_start=dts[0] if with_dtau else None, dts_end=dts[1] if with_dtau else None,
+                dts_grad=dts[2] if (with_dtau and with_grad_ts) else None)
+
+
+def event_param_grad(kind: str, err_fn: str, param_weight, pred, valid, batch, c_p: float, c_n: float, raw_ratio: float,
+                     tau: float, weight: float, ct_grad=None, tau_grad=None):
+    """closed-form d(loss term)/d(raw ratio) += ct_grad[0], direct d(loss term)/d(tau) += tau_grad[0] (f64)"""
+    check(_lib.load().ren_event_param_grad(
+        {"diff": 0, "grad": 1}[kind], ERR_FN[err_fn], PARAM_WEIGHT_POWER[param_weight], _ptr(pred, torch.float32), _ptr(valid),
+        _ptr(batch["start_ts"], torch.int64), _ptr(batch["end_ts"], torch.int64), _ptr(batch["num_pos"], torch.int64),
+        _ptr(batch["num_neg"], torch.int64), _ptr(batch["u_ts_diff"], torch.float64), pred.shape[0], _f(c_p), _f(c_n),
+        _f(raw_ratio), ctypes.c_double(float(tau)), _f(weight), _ptr(ct_grad, torch.float32), _ptr(tau_grad, torch.float64),
+        _stream()), "ren_event_param_grad")
+
+
 def event_loss_fwd(i_start, i_end, target, valid, err_fn: str):
     if err_fn not in ERR_FN:
         raise NotImplementedError(err_fn)

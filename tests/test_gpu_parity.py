@@ -416,6 +416,85 @@ def test_event_loss(amd, fn):
     assert rel_err(gs.cpu(), i_s.grad) < 1e-5 and rel_err(ge.cpu(), i_e.grad) < 1e-5
 
 
+def _event_glue_batch(B, seed):
+    g = torch.Generator().manual_seed(seed)
+    end = torch.randint(50_000_000, 1_900_000_000, (B,), generator=g)
+    pol = torch.rand(B, generator=g) < 0.5
+    b = dict(start_ts=end - torch.randint(200_000, 20_000_000, (B,), generator=g), end_ts=end,
+             num_pos=pol.long() * torch.randint(1, 3, (B,), generator=g), num_neg=(~pol).long(),
+             u_ts_diff=torch.rand(B, generator=g, dtype=torch.float64), u_diff_start=torch.rand(B, generator=g, dtype=torch.float64),
+             u_grad=torch.rand(B, generator=g, dtype=torch.float64))
+    b["u_ts_diff"][: B // 3] = 1.0                                   # the reference's Dirac(1) sampler
+    return b
+
+
+def test_event_prepare_vs_torch_formulas(amd):
+    """ren_event_prepare (a2-a4 + d ts/d tau) vs the float64 torch restatement of robust_e_nerf.py:319-357 with
+    autograd for the tau derivatives."""
+    ops, _ = amd
+    B, c_p, c_n, tau0 = 4099, 0.31, 0.25, 37_000.0
+    b = _event_glue_batch(B, 0)
+    tau = torch.tensor(tau0, dtype=torch.float64, requires_grad=True)
+    ev = b["num_pos"] * c_p - b["num_neg"] * c_n
+    start = b["start_ts"].double() + tau
+    ts_diff = (b["end_ts"] - start) * b["u_ts_diff"]
+    d_start = torch.lerp(start, torch.max(b["end_ts"] - ts_diff, start), b["u_diff_start"])
+    d_end = torch.min(d_start + ts_diff, b["end_ts"].double())
+    ts_g = torch.lerp(d_start, d_end, b["u_grad"])
+    rate = ev / (b["end_ts"] - start)
+    out = ops.event_prepare({k: dev(v) for k, v in b.items()}, c_p, c_n, tau0, with_grad_ts=True, with_dtau=True)
+    assert rel_err(out["ts"][:B].cpu() - b["start_ts"], (d_start - b["start_ts"]).detach()) < 1e-12
+    assert rel_err(out["ts"][B:].cpu() - b["start_ts"], (d_end - b["start_ts"]).detach()) < 1e-12
+    assert rel_err(out["ts_grad"].cpu() - b["start_ts"], (ts_g - b["start_ts"]).detach()) < 1e-12
+    assert rel_err(out["target_diff"].cpu(), (ts_diff * rate).float().detach()) < 1e-6
+    assert rel_err(out["target_grad"].cpu(), rate.float().detach()) < 1e-6
+    for key, y in (("dts_start", d_start), ("dts_end", d_end), ("dts_grad", ts_g)):
+        # per-event derivative: every timestamp depends on tau through its own event only
+        tv = torch.full((B,), tau0, dtype=torch.float64, requires_grad=True)
+        st = b["start_ts"].double() + tv
+        td = (b["end_ts"] - st) * b["u_ts_diff"]
+        ds = torch.lerp(st, torch.max(b["end_ts"] - td, st), b["u_diff_start"])
+        de = torch.min(ds + td, b["end_ts"].double())
+        yy = {"dts_start": ds, "dts_end": de, "dts_grad": torch.lerp(ds, de, b["u_grad"])}[key]
+        (gv,) = torch.autograd.grad(yy.sum(), tv)
+        assert rel_err(out[key].cpu(), gv) < 1e-12, key
+
+
+@pytest.mark.parametrize("kind", ["diff", "grad"])
+@pytest.mark.parametrize("err", ["l1", "mse", "mape"])
+@pytest.mark.parametrize("pwk", [None, "mean_contrast_reciprocal", "mean_contrast_reciprocal_sq"])
+def test_event_param_grad_vs_autograd(amd, kind, err, pwk):
+    """ren_event_param_grad (closed form) vs autograd through the reference's formulas with the prediction fixed."""
+    ops, _ = amd
+    B, c_n, tau0, raw0, w = 3001, 0.25, 21_000.0, 0.43, 0.7
+    b = _event_glue_batch(B, 1)
+    g = torch.Generator().manual_seed(2)
+    valid = (torch.rand(B, generator=g) < 0.8).to(torch.uint8)
+    raw = torch.tensor(raw0, requires_grad=True)
+    tau = torch.tensor(tau0, dtype=torch.float64, requires_grad=True)
+    c_p = torch.nn.functional.softplus(raw) * c_n
+    mean_c = (c_p + c_n) / 2
+    ev = b["num_pos"] * c_p - b["num_neg"] * c_n
+    start = b["start_ts"].double() + tau
+    rate = ev / (b["end_ts"] - start)
+    target = ((b["end_ts"] - start) * b["u_ts_diff"] * rate if kind == "diff" else rate).to(torch.float32)
+    pred = (target.detach() * (1 + 0.3 * torch.randn(B, generator=g))).float()
+    d = pred - target
+    e = {"l1": d.abs(), "mse": d * d, "mape": d.abs() / target.abs().clamp(min=2.220446049250313e-16)}[err][valid.bool()]
+    pw = {None: 1.0, "mean_contrast_reciprocal": 1 / mean_c, "mean_contrast_reciprocal_sq": 1 / mean_c ** 2}[pwk]
+    g_raw, g_tau = torch.autograd.grad(w * pw * e.mean(), [raw, tau])
+    ct_grad = torch.zeros(4, device=DEV)
+    tau_grad = torch.zeros(1, device=DEV, dtype=torch.float64)
+    ops.event_param_grad(kind, err, pwk, dev(pred), dev(valid), {k: dev(v) for k, v in b.items()}, float(c_p.detach()), c_n, raw0, tau0, w,
+                         ct_grad=ct_grad, tau_grad=tau_grad)
+    assert rel_err(ct_grad[:1].cpu(), g_raw) < 2e-5
+    if kind == "grad":
+        assert rel_err(tau_grad.cpu(), g_tau) < 2e-5
+    else:                                                            # tau cancels in ts_diff * rate: both are round-off
+        scale = float((w * pw * e.mean()).detach()) / 1e6
+        assert abs(float(tau_grad)) < 1e-6 * scale and abs(float(g_tau)) < 1e-6 * scale
+
+
 def test_adam_matches_torch(amd):
     ops, _ = amd
     n = 100_003
