@@ -90,14 +90,18 @@ int ren_ray_aabb_intersect(const float *rays_o, const float *rays_d, int64_t n_r
  *                               mode 1 -> comb shifted by u*delta.
  * binary: uint8/bool grid (res[0]*res[1]*res[2]), x-major.  roi host[6], res host[3].
  * Pass 1 (t_starts==NULL): writes counts[n_rays].  Pass 2: offsets[n_rays] (int64,
- * exclusive cumsum of counts) given, writes ray_indices/t_starts/t_ends. */
+ * exclusive cumsum of counts) given, writes ray_indices/t_starts/t_ends.
+ * interval_cache (optional, mode 0): float[n_rays * cache_cap * 2].  Pass 1 keeps the first cache_cap
+ * intervals of every ray in it; pass 2 (same cache, and counts given as well) copies them instead of marching
+ * again and re-marches only the rays with more than cache_cap samples.  Same output either way. */
 int ren_ray_march(const float *rays_o, const float *rays_d, const float *t_min,
                   const float *t_max, const float *jitter, int64_t n_rays,
                   const float *roi_host, const int32_t *res_host, const uint8_t *binary,
                   int32_t contraction_type, float step_size, float cone_angle,
                   int32_t mode, int32_t n_uniform,
                   const int64_t *offsets, int32_t *counts,
-                  int32_t *ray_indices, float *t_starts, float *t_ends, void *stream);
+                  int32_t *ray_indices, float *t_starts, float *t_ends, float *interval_cache,
+                  int32_t cache_cap, void *stream);
 /* exclusive cumsum of counts[n] (int32) -> offsets[n] (int64), total[1] (int64) */
 int ren_exclusive_scan(const int32_t *counts, int64_t n, int64_t *offsets, int64_t *total,
                        int64_t *scratch1024 /* int64[1024] device scratch, may be NULL (slow path) */, void *stream);

@@ -45,6 +45,7 @@ class RenderCfg:
                                        # "f32": exact f32-MFMA kernels (csrc/ren_mlp.hip)
     save_activations: bool = True      # training forward stores the hidden activations (768 B/sample) instead of
                                        # recomputing them in the backward (128 f32 MFMAs + 192 softplus per 32 samples)
+    march_cache: int = 512             # intervals per ray kept between the two marching passes (0: march twice)
     fwd_chunks: int = 16               # > 1: hash encoding and MLP of alternate sample chunks on two HIP streams
     mlp_bf16: bool = False             # BASELINE configs[2]: bf16 MLP (rounded linear inputs/weights, fp32 accumulate), fp32 composite
 
@@ -125,10 +126,13 @@ class Renderer:
         jit = jitter if training else None
         args = (o, d, t_min, t_max, jit, c.aabb, c.occ_res, self.binary, c.contraction_type,
                 c.render_step_size, c.cone_angle, mode, c.n_uniform)
-        counts = ops.ray_march_count(*args)
+        # occupancy-grid marching is a ~1 000-step dependent chain per ray: the count pass keeps the first
+        # march_cache intervals of every ray, the write pass copies them (re-marching only longer rays)
+        cache = torch.empty(o.shape[0], c.march_cache, 2, device=o.device) if (mode == 0 and c.march_cache > 0) else None
+        counts = ops.ray_march_count(*args, cache=cache)
         offsets, total = ops.exclusive_scan(counts)
         n0 = int(total.item())                      # host sync, as in the reference (H4: next round)
-        ri, ts, te = ops.ray_march_write(*args, offsets, n0)
+        ri, ts, te = ops.ray_march_write(*args, offsets, n0, counts=counts, cache=cache)
         if mode == 1 or n0 == 0:
             return Packed(ri, ts, te, offsets, counts, n0, n0)
         # sigma_fn pre-pass (external/utils.py:68-81) + render_visibility

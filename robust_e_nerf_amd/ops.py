@@ -142,19 +142,21 @@ def exclusive_scan(counts: torch.Tensor):
     return offsets, total
 
 
-def ray_march_count(o, d, t_min, t_max, jitter, roi, res, binary, ct, step, cone, mode, n_uniform):
+def ray_march_count(o, d, t_min, t_max, jitter, roi, res, binary, ct, step, cone, mode, n_uniform, cache=None):
+    """cache: optional float32 (n_rays, cap, 2) interval cache filled here and consumed by ray_march_write"""
     n = o.shape[0]
     counts = torch.empty(n, device=o.device, dtype=torch.int32)
     roi_c = (ctypes.c_float * 6)(*[float(v) for v in roi])
     res_c = (ctypes.c_int32 * 3)(*[int(v) for v in res])
     check(_lib.load().ren_ray_march(_ptr(o), _ptr(d), _ptr(t_min), _ptr(t_max), _ptr(jitter), n, roi_c, res_c,
                                     _ptr(binary, (torch.uint8, torch.bool)), ct, _f(step), _f(cone), mode, n_uniform,
-                                    None, _ptr(counts), None, None, None, _stream()), "ren_ray_march(count)")
+                                    None, _ptr(counts), None, None, None, _ptr(cache, torch.float32),
+                                    0 if cache is None else cache.shape[1], _stream()), "ren_ray_march(count)")
     return counts
 
 
 def ray_march_write(o, d, t_min, t_max, jitter, roi, res, binary, ct, step, cone, mode, n_uniform,
-                    offsets, n_total: int, out=None):
+                    offsets, n_total: int, out=None, counts=None, cache=None):
     n = o.shape[0]
     if out is None:
         ri = torch.empty(n_total, device=o.device, dtype=torch.int32)
@@ -168,7 +170,9 @@ def ray_march_write(o, d, t_min, t_max, jitter, roi, res, binary, ct, step, cone
     res_c = (ctypes.c_int32 * 3)(*[int(v) for v in res])
     check(_lib.load().ren_ray_march(_ptr(o), _ptr(d), _ptr(t_min), _ptr(t_max), _ptr(jitter), n, roi_c, res_c,
                                     _ptr(binary, (torch.uint8, torch.bool)), ct, _f(step), _f(cone), mode, n_uniform,
-                                    _ptr(offsets, torch.int64), None, _ptr(ri), _ptr(ts), _ptr(te), _stream()),
+                                    _ptr(offsets, torch.int64), _ptr(counts, torch.int32), _ptr(ri), _ptr(ts), _ptr(te),
+                                    _ptr(cache, torch.float32) if counts is not None else None,
+                                    0 if (cache is None or counts is None) else cache.shape[1], _stream()),
           "ren_ray_march(write)")
     return ri, ts, te
 

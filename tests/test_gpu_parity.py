@@ -103,6 +103,13 @@ def test_ray_marching_bit_exact(amd, ct, res, cone, near, far):
     ri, ts, te = ops.ray_march_write(*args, offsets, int(total))
     assert torch.equal(ri.cpu(), ri_o) and torch.equal(ts.cpu(), ts_o) and torch.equal(te.cpu(), te_o)
     assert int(total) > 1000
+    # interval cache between the two passes (march once): identical streams, also when most rays overflow it
+    for cap in (7, 1024):
+        cache = torch.empty(R, cap, 2, device=DEV)
+        counts_c = ops.ray_march_count(*args, cache=cache)
+        assert torch.equal(counts_c, counts)
+        ri_c, ts_c, te_c = ops.ray_march_write(*args, offsets, int(total), counts=counts_c, cache=cache)
+        assert torch.equal(ri_c, ri) and torch.equal(ts_c, ts) and torch.equal(te_c, te), cap
     # pack_info round trip
     offs2, cnt2 = ops.pack_info(ri, R)
     assert torch.equal(cnt2.cpu(), counts_o)
