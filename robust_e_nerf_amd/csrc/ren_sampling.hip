@@ -306,43 +306,64 @@ __global__ __launch_bounds__(1024) void exclusive_scan_kernel(const int32_t *__r
     if (tid == 1023 && total) total[0] = part[1023];
 }
 
-__global__ void visibility_kernel(const int64_t *__restrict__ offsets, const int32_t *__restrict__ counts,
+// One wavefront per ray (a thread per ray walked ~200 samples as a dependent chain of loads and expf: 0.15 ms
+// for any ray count).  The 64 alphas of a chunk are formed in parallel; the transmittance is still multiplied up
+// in sample order (readlane loop), so every T -- and with it every keep decision -- has the sequential rounding.
+__global__ __launch_bounds__(256) void visibility_kernel(const int64_t *__restrict__ offsets, const int32_t *__restrict__ counts,
                                   int64_t n_rays, const float *__restrict__ sigmas,
                                   const float *__restrict__ t_starts, const float *__restrict__ t_ends,
                                   float eps, float alpha_thre, uint8_t *__restrict__ keep,
                                   int32_t *__restrict__ kept_counts) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
     if (i >= n_rays) return;
-    float T = 1.f;
+    const int64_t b = offsets[i];
+    const int cnt = counts[i];
+    float T = 1.f;                                                 // wave-uniform
     int kept = 0;
-    const int64_t b = offsets[i], e = b + counts[i];
-    for (int64_t j = b; j < e; ++j) {
-        float alpha = 1.f - expf(-sigmas[j] * (t_ends[j] - t_starts[j]));
-        bool k = T >= eps;
+    for (int c0 = 0; c0 < cnt; c0 += 64) {
+        const bool valid = c0 + lane < cnt;
+        const int64_t j = b + c0 + lane;
+        float alpha = 0.f;
+        if (valid) alpha = 1.f - expf(-sigmas[j] * (t_ends[j] - t_starts[j]));
+        const float om = 1.f - alpha;                              // exactly 1 on the padding lanes
+        float t_here = 0.f;
+#pragma unroll
+        for (int l = 0; l < 64; ++l) {
+            if (lane == l) t_here = T;
+            T = T * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, om), l));
+        }
+        bool k = valid && t_here >= eps;
         if (alpha_thre > 0.f) k = k && (alpha >= alpha_thre);
-        keep[j] = (uint8_t)k;
-        kept += k;
-        T = T * (1.f - alpha);
+        if (valid) keep[j] = (uint8_t)k;
+        kept += __popcll(__ballot(k));
     }
-    kept_counts[i] = kept;
+    if (lane == 0) kept_counts[i] = kept;
 }
 
-__global__ void compact_kernel(const int64_t *__restrict__ offsets, const int32_t *__restrict__ counts,
+__global__ __launch_bounds__(256) void compact_kernel(const int64_t *__restrict__ offsets, const int32_t *__restrict__ counts,
                                const int64_t *__restrict__ new_offsets, int64_t n_rays,
                                const uint8_t *__restrict__ keep, const float *__restrict__ t_starts,
                                const float *__restrict__ t_ends, int32_t *__restrict__ out_ri,
                                float *__restrict__ out_ts, float *__restrict__ out_te) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
     if (i >= n_rays) return;
-    const int64_t b = offsets[i], e = b + counts[i];
+    const int64_t b = offsets[i];
+    const int cnt = counts[i];
     int64_t w = new_offsets[i];
-    for (int64_t j = b; j < e; ++j) {
-        if (keep[j]) {
-            out_ri[w] = (int32_t)i;
-            out_ts[w] = t_starts[j];
-            out_te[w] = t_ends[j];
-            ++w;
+    for (int c0 = 0; c0 < cnt; c0 += 64) {
+        const bool valid = c0 + lane < cnt;
+        const int64_t j = b + c0 + lane;
+        const bool k = valid && keep[j];
+        const unsigned long long m = __ballot(k);
+        if (k) {
+            const int64_t at = w + __popcll(m & ((1ull << lane) - 1ull));
+            out_ri[at] = (int32_t)i;
+            out_ts[at] = t_starts[j];
+            out_te[at] = t_ends[j];
         }
+        w += __popcll(m);
     }
 }
 
@@ -452,7 +473,7 @@ extern "C" int ren_visibility(const int64_t *offsets, const int32_t *counts, int
     if (!offsets || !counts || !sigmas || !t_starts || !t_ends || !keep || !kept_counts || n_rays < 0)
         return REN_ERR_BAD_ARG;
     if (n_rays == 0) return REN_OK;
-    hipLaunchKernelGGL(visibility_kernel, dim3(ren_blocks(n_rays, 64)), dim3(64), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(visibility_kernel, dim3(ren_blocks(n_rays * 64, 256)), dim3(256), 0, (hipStream_t)stream,
                        offsets, counts, n_rays, sigmas, t_starts, t_ends, early_stop_eps, alpha_thre, keep,
                        kept_counts);
     REN_CHECK_LAUNCH();
@@ -467,7 +488,7 @@ extern "C" int ren_compact_samples(const int64_t *offsets, const int32_t *counts
         !out_t_starts || !out_t_ends || n_rays < 0)
         return REN_ERR_BAD_ARG;
     if (n_rays == 0) return REN_OK;
-    hipLaunchKernelGGL(compact_kernel, dim3(ren_blocks(n_rays, 64)), dim3(64), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(compact_kernel, dim3(ren_blocks(n_rays * 64, 256)), dim3(256), 0, (hipStream_t)stream,
                        offsets, counts, new_offsets, n_rays, keep, t_starts, t_ends, out_ray_indices,
                        out_t_starts, out_t_ends);
     REN_CHECK_LAUNCH();
