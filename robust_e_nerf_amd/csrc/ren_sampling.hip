@@ -7,6 +7,7 @@
 // bit.  One thread per ray: rays are independent, the 2 MiB (128^3) / 16 MiB (256^3) occupancy
 // grid is L2 / Infinity-Cache resident, and the march is latency- not bandwidth-bound.
 #include "ren_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -181,6 +182,98 @@ __global__ void ray_march_kernel(const float *__restrict__ o, const float *__res
         }
     }
     if (!WRITE) counts[i] = j;
+}
+
+// Speculative marching, SPEC lanes per ray.  The march is a dependent chain (position -> occupancy byte -> next
+// position) of ~1 000 steps per ray, i.e. ~0.45 ms of pure load latency however few rays there are.  Lane l of a
+// ray's group assumes the next l cells are all occupied, forms ITS state with the same float operations in the
+// same order the sequential loop would use (l "advance one interval" transitions from the group's state), and all
+// lanes test their cell at once.  The leading run of occupied cells is emitted, the first empty (or out-of-range)
+// lane decides how the group continues, exactly as the sequential loop does at that step.  In contracted space an
+// empty cell advances the state like an occupied one, so all SPEC lanes always count.  Output is bit-identical to
+// ray_march_kernel (same tests); dense rays need 1/SPEC of the load round trips.
+constexpr int SPEC = 8;
+
+template <bool WRITE>
+__global__ __launch_bounds__(256) void ray_march_spec_kernel(
+    const float *__restrict__ o, const float *__restrict__ d, const float *__restrict__ t_min,
+    const float *__restrict__ t_max, const float *__restrict__ jitter, int64_t n_rays, MarchArgs a,
+    const uint8_t *__restrict__ binary, const int64_t *__restrict__ offsets, int32_t *__restrict__ counts,
+    int32_t *__restrict__ ray_indices, float *__restrict__ t_starts, float *__restrict__ t_ends,
+    float2 *__restrict__ cache, int cache_cap) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / SPEC;
+    const int l = threadIdx.x % SPEC, lane = threadIdx.x & 63, g0 = lane - l;   // g0: first lane of the group
+    bool done = i >= n_rays;
+    if (!done && WRITE && cache && counts[i] <= cache_cap) done = true;          // copied by cached_write_kernel
+    float ro[3] = {0.f, 0.f, 0.f}, rd[3] = {1.f, 1.f, 1.f};
+    float near = 0.f, far = 0.f;
+    int64_t base = 0;
+    if (!done) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { ro[k] = o[3 * i + k]; rd[k] = d[3 * i + k]; }
+        near = t_min[i]; far = t_max[i];
+        if (WRITE) base = offsets[i];
+        if (jitter) near = near + jitter[i] * a.step_size;
+    }
+    const float inv_dir[3] = {1.f / rd[0], 1.f / rd[1], 1.f / rd[2]};
+    const float dt_min = a.step_size, dt_max = 1e10f;
+    float t0 = near;
+    float t1 = t0 + calc_dt(t0, a.cone_angle, dt_min, dt_max);
+    float t_mid = (t0 + t1) * 0.5f;
+    int j = 0;
+    const bool is_aabb = a.type == REN_CT_AABB;
+    if (!(t_mid < far)) done = true;
+    while (__any(!done)) {
+        float a0 = t0, a1 = t1, am = t_mid;                      // this lane's state: l intervals further on
+#pragma unroll
+        for (int k = 0; k < SPEC - 1; ++k)
+            if (k < l) { a0 = a1; a1 = a0 + calc_dt(a0, a.cone_angle, dt_min, dt_max); am = (a0 + a1) * 0.5f; }
+        const bool in = !done && am < far;
+        bool occ = false;
+        if (in) {
+            const float p[3] = {ro[0] + am * rd[0], ro[1] + am * rd[1], ro[2] + am * rd[2]};
+            occ = grid_occupied_at(p, a, binary);
+        }
+        const unsigned in_bits = (unsigned)(__ballot(in) >> g0) & ((1u << SPEC) - 1u);
+        const unsigned occ_bits = (unsigned)(__ballot(occ) >> g0) & ((1u << SPEC) - 1u);
+        // lanes [0, f) are steps the sequential loop takes with the state this lane assumed
+        const int n_in = __builtin_ctz(~in_bits | (1u << SPEC));                 // leading lanes still inside [near, far)
+        const int f = is_aabb ? __builtin_ctz(~occ_bits | (1u << SPEC)) : n_in;  // aabb: stop at the first empty cell
+        const bool emit = !done && l < f && occ;
+        if (emit) {
+            const int at = j + __popc(occ_bits & ((1u << l) - 1u));
+            if (WRITE) {
+                t_starts[base + at] = a0;
+                t_ends[base + at] = a1;
+                ray_indices[base + at] = (int32_t)i;
+            } else if (cache && at < cache_cap) {
+                cache[i * cache_cap + at] = make_float2(a0, a1);
+            }
+        }
+        const int src = g0 + (f < SPEC ? f : SPEC - 1);
+        const float b0 = __shfl(a0, src, 64), b1 = __shfl(a1, src, 64), bm = __shfl(am, src, 64);
+        if (!done) {
+            j += __popc(occ_bits & ((1u << f) - 1u));
+            if (f == SPEC) {                                     // whole group consumed: one more transition
+                t0 = b1;
+                t1 = t0 + calc_dt(t0, a.cone_angle, dt_min, dt_max);
+                t_mid = (t0 + t1) * 0.5f;
+            } else if (f >= n_in) {                              // lane f is past the far end: the loop ends
+                done = true;
+            } else {                                             // aabb only: lane f sits in an empty cell
+                float tm = bm;
+                const float p[3] = {ro[0] + tm * rd[0], ro[1] + tm * rd[1], ro[2] + tm * rd[2]};
+                const float t_target = tm + distance_to_next_voxel(p, rd, inv_dir, a);
+                do { tm += dt_min; } while (tm < t_target);
+                const float dt = calc_dt(tm, a.cone_angle, dt_min, dt_max);
+                t0 = tm - dt * 0.5f;
+                t1 = tm + dt * 0.5f;
+                t_mid = tm;
+            }
+            if (!(t_mid < far)) done = true;
+        }
+    }
+    if (!WRITE && l == 0 && i < n_rays) counts[i] = j;
 }
 
 // Write pass from the interval cache of the count pass: 8 lanes per ray copy its (t0, t1) pairs into the packed
@@ -433,6 +526,11 @@ extern "C" int ren_ray_march(const float *rays_o, const float *rays_d, const flo
     a.type = contraction_type; a.step_size = step_size; a.cone_angle = cone_angle;
     a.mode = mode; a.n_uniform = n_uniform;
     dim3 grid(ren_blocks(n_rays, 64)), block(64);   // short blocks: ray lengths vary a lot
+    const char *env_seq = getenv("REN_MARCH_SEQUENTIAL");                      // tuning/verification knob
+    // speculation spends SPEC lanes per ray to cut load round trips: it wins while the launch is latency-bound
+    // (measured: 2x at 15 k rays, 3x slower at 131 k rays where the sequential kernel already fills the chip)
+    const bool spec = mode == 0 && n_rays <= 24576 && !(env_seq && env_seq[0] == '1');
+    const dim3 sgrid(ren_blocks(n_rays * SPEC, 256));
     if (write && mode == 1)
         hipLaunchKernelGGL(uniform_write_kernel, dim3(ren_blocks(n_rays * n_uniform, 256)), dim3(256), 0,
                            (hipStream_t)stream, t_min, t_max, jitter, n_rays, n_uniform, offsets, ray_indices,
@@ -441,10 +539,19 @@ extern "C" int ren_ray_march(const float *rays_o, const float *rays_d, const flo
         if (cache)
             hipLaunchKernelGGL(cached_write_kernel, dim3(ren_blocks(n_rays * 8, 256)), dim3(256), 0, (hipStream_t)stream,
                                cache, cache_cap, n_rays, offsets, counts, ray_indices, t_starts, t_ends);
-        hipLaunchKernelGGL(ray_march_kernel<true>, grid, block, 0, (hipStream_t)stream, rays_o, rays_d,
+        if (spec)
+            hipLaunchKernelGGL(ray_march_spec_kernel<true>, sgrid, dim3(256), 0, (hipStream_t)stream, rays_o, rays_d,
+                               t_min, t_max, jitter, n_rays, a, binary, offsets, counts, ray_indices,
+                               t_starts, t_ends, cache, cache_cap);
+        else
+            hipLaunchKernelGGL(ray_march_kernel<true>, grid, block, 0, (hipStream_t)stream, rays_o, rays_d,
+                               t_min, t_max, jitter, n_rays, a, binary, offsets, counts, ray_indices,
+                               t_starts, t_ends, cache, cache_cap);
+    } else if (spec)
+        hipLaunchKernelGGL(ray_march_spec_kernel<false>, sgrid, dim3(256), 0, (hipStream_t)stream, rays_o, rays_d,
                            t_min, t_max, jitter, n_rays, a, binary, offsets, counts, ray_indices,
                            t_starts, t_ends, cache, cache_cap);
-    } else
+    else
         hipLaunchKernelGGL(ray_march_kernel<false>, grid, block, 0, (hipStream_t)stream, rays_o, rays_d,
                            t_min, t_max, jitter, n_rays, a, binary, offsets, counts, ray_indices,
                            t_starts, t_ends, cache, cache_cap);
