@@ -118,6 +118,11 @@ int ren_compact_samples(const int64_t *offsets, const int32_t *counts, const int
                         int64_t n_rays, const uint8_t *keep, const float *t_starts,
                         const float *t_ends, int32_t *out_ray_indices, float *out_t_starts,
                         float *out_t_ends, void *stream);
+/* Fragment-layout features (32 floats per sample, see ren_hashgrid_fwd layout 1) of the kept samples, moved to
+ * their compacted positions (same offsets/counts/new_offsets/keep as ren_compact_samples).  feat_out must hold
+ * ceil(n_kept/32) blocks; the caller zeroes its last block (padding lanes). */
+int ren_compact_features(const int64_t *offsets, const int32_t *counts, const int64_t *new_offsets, int64_t n_rays,
+                         const uint8_t *keep, const float *feat_in, float *feat_out, void *stream);
 /* (offsets, counts) from sorted ray_indices[n] (nerfacc unpack_info inverse) */
 int ren_pack_info(const int32_t *ray_indices, int64_t n, int64_t n_rays, int64_t *offsets,
                   int32_t *counts, void *stream);

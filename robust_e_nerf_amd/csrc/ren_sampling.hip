@@ -460,6 +460,38 @@ __global__ __launch_bounds__(256) void compact_kernel(const int64_t *__restrict_
     }
 }
 
+// Per-sample feature vectors (fragment layout, 32 floats per sample) of the samples that survive the visibility
+// test, moved to their compacted positions: the density pre-pass already encoded every marched sample, so the
+// differentiable pass need not gather the hash table again for the survivors.
+__global__ __launch_bounds__(256) void compact_features_kernel(const int64_t *__restrict__ offsets, const int32_t *__restrict__ counts,
+                                        const int64_t *__restrict__ new_offsets, int64_t n_rays,
+                                        const uint8_t *__restrict__ keep, const float *__restrict__ feat_in,
+                                        float *__restrict__ feat_out) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (i >= n_rays) return;
+    const int64_t b = offsets[i];
+    const int cnt = counts[i];
+    int64_t w = new_offsets[i];
+    for (int c0 = 0; c0 < cnt; c0 += 64) {
+        const bool valid = c0 + lane < cnt;
+        const int64_t j = b + c0 + lane;
+        const bool k = valid && keep[j];
+        const unsigned long long m = __ballot(k);
+        if (k) {
+            const int64_t at = w + __popcll(m & ((1ull << lane) - 1ull));
+            const float *src = feat_in + (j >> 5) * 1024 + (j & 31);
+            float *dst = feat_out + (at >> 5) * 1024 + (at & 31);
+            float v[32];
+#pragma unroll
+            for (int q = 0; q < 32; ++q) v[q] = src[q * 32];
+#pragma unroll
+            for (int q = 0; q < 32; ++q) dst[q * 32] = v[q];
+        }
+        w += __popcll(m);
+    }
+}
+
 __global__ void zero_i32_kernel(int32_t *p, int64_t n) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = 0;
@@ -598,6 +630,16 @@ extern "C" int ren_compact_samples(const int64_t *offsets, const int32_t *counts
     hipLaunchKernelGGL(compact_kernel, dim3(ren_blocks(n_rays * 64, 256)), dim3(256), 0, (hipStream_t)stream,
                        offsets, counts, new_offsets, n_rays, keep, t_starts, t_ends, out_ray_indices,
                        out_t_starts, out_t_ends);
+    REN_CHECK_LAUNCH();
+}
+
+extern "C" int ren_compact_features(const int64_t *offsets, const int32_t *counts, const int64_t *new_offsets,
+                                    int64_t n_rays, const uint8_t *keep, const float *feat_in, float *feat_out,
+                                    void *stream) {
+    if (!offsets || !counts || !new_offsets || !keep || !feat_in || !feat_out || n_rays < 0) return REN_ERR_BAD_ARG;
+    if (n_rays == 0) return REN_OK;
+    hipLaunchKernelGGL(compact_features_kernel, dim3(ren_blocks(n_rays * 64, 256)), dim3(256), 0, (hipStream_t)stream,
+                       offsets, counts, new_offsets, n_rays, keep, feat_in, feat_out);
     REN_CHECK_LAUNCH();
 }
 

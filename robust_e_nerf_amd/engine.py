@@ -94,6 +94,7 @@ class Packed:
     counts: torch.Tensor
     n: int
     n_marched: int = 0
+    feat: Optional[torch.Tensor] = None         # hash features of these samples, when the density pre-pass made them
 
 
 class Renderer:
@@ -111,9 +112,10 @@ class Renderer:
                                device=dev, dtype=torch.float32)
         self._bin_ws = None
         self._fwd_streams = None
+        self._reuse_prepass_feat = True             # the differentiable pass reuses the pre-pass hash features
 
     # ---- sampling (K1-K3): ray/AABB, two-pass march, no-grad density pre-pass + visibility --------
-    def sample(self, o, d, jitter: Optional[torch.Tensor], training: bool) -> Packed:
+    def sample(self, o, d, jitter: Optional[torch.Tensor], training: bool, keep_feat: bool = False) -> Packed:
         c = self.cfg
         scene_aabb = c.aabb if c.contraction_type == ops.AABB else None           # nerf.py:248-251
         if scene_aabb is not None:
@@ -136,12 +138,19 @@ class Renderer:
         if mode == 1 or n0 == 0:
             return Packed(ri, ts, te, offsets, counts, n0, n0)
         # sigma_fn pre-pass (external/utils.py:68-81) + render_visibility
-        sigma = self._density_stream(o, d, (ri, ts, te), n0)
+        keep_feat = keep_feat and self._reuse_prepass_feat and c.mlp_kernels == "x"
+        sigma = self._density_stream(o, d, (ri, ts, te), n0, keep_feat)
+        feat0 = None
+        if keep_feat:
+            sigma, feat0 = sigma
         keep, kept = ops.visibility(offsets, counts, sigma, ts, te, c.early_stop_eps, c.alpha_thre)
         new_offsets, total2 = ops.exclusive_scan(kept)
         n1 = int(total2.item())
         ri2, ts2, te2 = ops.compact_samples(offsets, counts, new_offsets, keep, ts, te, n1)
-        return Packed(ri2, ts2, te2, new_offsets, kept, n1, n0)
+        feat1 = None
+        if feat0 is not None and n1 > 0:                     # the pre-pass already encoded every survivor
+            feat1 = feat0 if n1 == n0 else ops.compact_features(offsets, counts, new_offsets, keep, feat0, n1)
+        return Packed(ri2, ts2, te2, new_offsets, kept, n1, n0, feat1)
 
     # ---- field evaluation over a packed sample stream (overridden by vanilla.VanillaRenderer) ----------
     def _mlp_params(self):
@@ -150,13 +159,13 @@ class Renderer:
         m = self.field.mlp
         return m.to(torch.bfloat16).to(torch.float32) if self.cfg.mlp_bf16 else m
 
-    def _density_stream(self, o, d, samples, n):
+    def _density_stream(self, o, d, samples, n, return_feat: bool = False):
         feat = ops.hashgrid_fwd(self.field.grid, self.field.table, scene=self.scene, rays=(o, d),
                                 samples=samples, n=n, layout=1)
         if self.cfg.mlp_kernels == "x":
             _, sigma, _, _ = ops.mlp_fwd_x(self.field.mlp, self.field.C, self._xmode(), feat, self.scene, rays=(o, d),
                                            samples=samples, n=n, density_only=True)
-            return sigma
+            return (sigma, feat) if return_feat else sigma
         _, sigma, _ = ops.mlp_fwd(self._mlp_params(), self.field.C, feat, self.scene, rays=(o, d),
                                   samples=samples, n=n, density_only=True, bf16=self.cfg.mlp_bf16)
         return sigma
@@ -168,9 +177,10 @@ class Renderer:
         f = self.field
         samples = (pk.ray_indices, pk.t_starts, pk.t_ends)
         chunks = min(self.cfg.fwd_chunks, pk.n >> 20) if pk.n >= (1 << 23) else 1   # pays from ~8 M samples, >= 1 M per chunk
-        if self.cfg.mlp_kernels == "x" and chunks > 1:
+        if self.cfg.mlp_kernels == "x" and chunks > 1 and pk.feat is None:
             return self._field_forward_chunked(o, d, pk, save, chunks)
-        feat = ops.hashgrid_fwd(f.grid, f.table, scene=self.scene, rays=(o, d), samples=samples, n=pk.n, layout=1)
+        feat = pk.feat if pk.feat is not None else \
+            ops.hashgrid_fwd(f.grid, f.table, scene=self.scene, rays=(o, d), samples=samples, n=pk.n, layout=1)
         if self.cfg.mlp_kernels == "x":
             rgb, sigma, base, acts = ops.mlp_fwd_x(f.mlp, f.C, self._xmode(), feat, self.scene, rays=(o, d), samples=samples,
                                                    n=pk.n, save=save)
@@ -258,7 +268,7 @@ class Renderer:
     def forward(self, o, d, jitter=None, bkgd: Optional[torch.Tensor] = None, training: bool = True,
                 save: bool = True):
         f = self.field
-        pk = self.sample(o, d, jitter, training)
+        pk = self.sample(o, d, jitter, training, keep_feat=True)
         n_rays = o.shape[0]
         if pk.n == 0:
             colors = torch.zeros(n_rays, f.C, device=o.device)

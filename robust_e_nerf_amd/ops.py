@@ -200,6 +200,18 @@ def compact_samples(offsets, counts, new_offsets, keep, ts, te, n_new: int):
     return ri2, ts2, te2
 
 
+def compact_features(offsets, counts, new_offsets, keep, feat, n_new: int):
+    """fragment-layout features of the kept samples at their compacted positions (padding lanes zero)"""
+    out = torch.empty(n_blocks32(n_new) * FRAG_FLOATS_PER_BLOCK, device=feat.device, dtype=torch.float32)
+    if n_new == 0:
+        return out
+    out[-FRAG_FLOATS_PER_BLOCK:].zero_()
+    check(_lib.load().ren_compact_features(_ptr(offsets, torch.int64), _ptr(counts, torch.int32), _ptr(new_offsets, torch.int64),
+                                           counts.shape[0], _ptr(keep), _ptr(feat, torch.float32), _ptr(out), _stream()),
+          "ren_compact_features")
+    return out
+
+
 def pack_info(ray_indices: torch.Tensor, n_rays: int):
     n = ray_indices.shape[0]
     offsets = torch.empty(n_rays, device=ray_indices.device, dtype=torch.int64)
@@ -511,7 +523,7 @@ def occgrid_binarize(occs, occ_thre: float, binary, scratch):
 # disabled (zero overhead) otherwise.
 _PROFILE = None
 _TIMED = ("ray_aabb_intersect", "ray_march_count", "ray_march_write", "exclusive_scan", "visibility",
-          "compact_samples", "hashgrid_fwd", "hashgrid_bwd", "hashgrid_bwd_binned", "mlp_fwd", "mlp_bwd", "mlp_fwd_save",
+          "compact_samples", "compact_features", "hashgrid_fwd", "hashgrid_bwd", "hashgrid_bwd_binned", "mlp_fwd", "mlp_bwd", "mlp_fwd_save",
           "mlp_bwd_saved", "mlp_fwd_x", "mlp_bwd_x", "composite_fwd",
           "composite_bwd", "column_sum", "event_loss_fwd", "event_loss_bwd", "adam_step", "trajectory", "raygen")
 

@@ -103,6 +103,7 @@ class VanillaRenderer(Renderer):
 
     def __init__(self, fld: VanillaField, cfg: RenderCfg, n_splits: int = 256):
         super().__init__(fld, cfg)
+        self._reuse_prepass_feat = False            # frequency encoding: nothing worth carrying over
         self.n_splits = n_splits
         self._dw_ws = None
         # HIP-event timing per kernel family when ops.profile_start() is active (bench.py)
@@ -167,7 +168,7 @@ class VanillaRenderer(Renderer):
         return B.rgb4[:n, :C].contiguous(), sigma
 
     # ---- Renderer hooks ---------------------------------------------------------------------------------
-    def _density_stream(self, o, d, samples, n):
+    def _density_stream(self, o, d, samples, n, return_feat: bool = False):
         B = _Buffers(n, o.device, self.field.C, full=False, backward=False)
         self._encode(B, False, rays=(o, d), samples=samples)
         return self._trunk(B)

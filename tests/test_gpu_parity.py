@@ -602,6 +602,38 @@ def test_rays_without_samples_render_background(amd, spec, full_table_cache):
     assert torch.equal(img_a, img_b) and torch.equal(op_a, op_b)
 
 
+def test_prepass_feature_reuse_equals_reencoding(amd, spec, full_table_cache):
+    """Occupancy-grid sampling: the differentiable pass takes the hash features of the surviving samples from the
+    density pre-pass (ren_compact_features) instead of encoding them again -- identical render and gradients."""
+    from oracle import field
+    ops, engine = amd
+    p = field.init_params(spec, seed=5)
+    p["hash"] = full_table_cache(7, 0.5)
+    R = 4099
+    o, d = make_rays(R, seed=11)
+    o, d = dev(o), dev(d)
+    jit = dev(torch.rand(R, generator=torch.Generator().manual_seed(4)))
+    g_col = dev(torch.randn(R, 1, generator=torch.Generator().manual_seed(6)))
+    for early_stop in (1e-4, 0.5):                                  # nothing culled / many samples culled
+        out = []
+        for reuse in (True, False):
+            fld = engine.NGPField(DEV)
+            fld.load(p)
+            r = engine.Renderer(fld, engine.RenderCfg(sampler="occgrid", early_stop_eps=early_stop))
+            r.binary.copy_(dev(ball_binary(128, 1.1).to(torch.uint8)).view(-1))
+            r._reuse_prepass_feat = reuse
+            colors, opac, depth, ctx = r.forward(o, d, jit, None, True)
+            assert (ctx["pk"].feat is not None) == reuse
+            r.backward(ctx, g_col)
+            torch.cuda.synchronize()
+            out.append((colors.clone(), ctx["pk"].n, ctx["pk"].n_marched, ctx["feat"][: ctx["pk"].n // 32 * 1024].clone(),
+                        fld.g_mlp.clone(), fld.g_table.clone()))
+        a, b = out
+        assert a[1] == b[1] and a[2] == b[2] and (a[1] < a[2]) == (early_stop == 0.5)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[3], b[3])
+        assert rel_err(a[4], b[4]) < 1e-5 and rel_err(a[5], b[5]) < 1e-5
+
+
 def test_chunked_two_stream_forward_equals_single_launch(amd, spec, full_table_cache):
     """RenderCfg.fwd_chunks: hash encoding / MLP of alternate sample chunks on two HIP streams (with the MLP kernel
     in its one-workgroup-per-CU mode) give bit-identical renders and gradients that agree to summation order."""
