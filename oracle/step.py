@@ -78,11 +78,13 @@ def render_rays(o, d, p: Dict[str, torch.Tensor], spec, cfg: SceneCfg, *,
     return colors, opac, depth, ts.shape[0], (ri, ts, te)
 
 
-def render_pixels(Kinv, px, pos, R, p, spec, cfg: SceneCfg, **kw):
-    """robust_e_nerf.py:849-885 (monochrome): intensity, opacity, depth*cos, n, is_valid."""
+def render_pixels(Kinv, px, pos, R, p, spec, cfg: SceneCfg, channel_idx=None, **kw):
+    """robust_e_nerf.py:849-885: intensity, opacity, depth*cos, n, is_valid.  channel_idx (Bayer sensor): the
+    colour channel each event's pixel sees, `bayering` (:887-890) applied to the (B, 3) render."""
     o, d = trajectory.pixel_params_to_ray(Kinv, px, pos, R)
     colors, opac, depth, n, packed = render_rays(o, d, p, spec, cfg, **kw)
-    intensity = colors.squeeze(-1) + cfg.min_modeled_intensity
+    intensity = colors + cfg.min_modeled_intensity                      # :867
+    intensity = intensity.squeeze(-1) if channel_idx is None else intensity.gather(1, channel_idx.long()[:, None])[:, 0]
     is_valid = torch.ones_like(opac, dtype=torch.bool) if cfg.bkgd_is_param else opac > 0
     depth = depth * (d * R[..., 2]).sum(-1)
     return intensity, opac, depth, n, is_valid, packed
@@ -98,6 +100,7 @@ class EventBatch:
     u_ts_diff: torch.Tensor         # (B,) f64
     u_diff_start: torch.Tensor      # (B,) f64
     u_grad: torch.Tensor            # (B,) f64
+    channel_idx: Optional[torch.Tensor] = None   # (B,) colour channel per event (Bayer sensor), else monochrome
 
 
 def training_forward(batch: EventBatch, p, spec, cfg: SceneCfg, *, Kinv, tab_ts, tab_pos, tab_quat,
@@ -124,7 +127,7 @@ def training_forward(batch: EventBatch, p, spec, cfg: SceneCfg, *, Kinv, tab_ts,
         if not ts_g.requires_grad:
             ts_g = ts_g.detach().requires_grad_()               # robust_e_nerf.py:355
         pos, R = trajectory.linear_trajectory(ts_g, tab_ts, tab_pos, tab_quat)
-        out["grad"] = render_pixels(Kinv, batch.position, pos, R, p, spec, cfg,
+        out["grad"] = render_pixels(Kinv, batch.position, pos, R, p, spec, cfg, channel_idx=batch.channel_idx,
                                     binary=binary, jitter=jitter_grad, bkgd=bkgd, training=True)
         log_g = out["grad"][0].log()
         (dlog,) = torch.autograd.grad(log_g, ts_g, torch.ones_like(log_g), create_graph=True)   # utils/autograd.py:4-34
@@ -132,7 +135,7 @@ def training_forward(batch: EventBatch, p, spec, cfg: SceneCfg, *, Kinv, tab_ts,
     for name, ts, jit in (("start", tsd["diff_start_ts"], jitter_start),
                           ("end", tsd["diff_end_ts"], jitter_end)):
         pos, R = trajectory.linear_trajectory(ts, tab_ts, tab_pos, tab_quat)
-        out[name] = render_pixels(Kinv, batch.position, pos, R, p, spec, cfg,
+        out[name] = render_pixels(Kinv, batch.position, pos, R, p, spec, cfg, channel_idx=batch.channel_idx,
                                   binary=binary, jitter=jit, bkgd=bkgd, training=True)
     log_s, log_e = out["start"][0].log(), out["end"][0].log()
     pred = log_e - log_s

@@ -448,6 +448,27 @@ class Trainer:
             self.c_p = ratio * self.c_n
             self.mean_c = (self.c_p + self.c_n) / 2
 
+    # ---- Bayer sensor: every event sees one colour channel of the (., 3) render (`bayering`, robust_e_nerf.py:887-890)
+    def _channel_index(self, batch, repeat: int):
+        if self.r.field.C == 1:
+            return None
+        if "channel_idx" not in batch:
+            raise ValueError("radiance_dim 3 (Bayer sensor) needs batch['channel_idx'] (data.colorize_events)")
+        ch = batch["channel_idx"].to(torch.int64)
+        return (torch.cat([ch] * repeat) if repeat > 1 else ch)[:, None]
+
+    @staticmethod
+    def _bayer(x, ch):
+        """(R, C) -> (R,): the event's channel (monochrome: the only one)"""
+        return x[:, 0] if ch is None else x.gather(1, ch)[:, 0]
+
+    @staticmethod
+    def _unbayer(g, ch, C):
+        """(R,) gradient -> (R, C) with zeros in the channels the event does not see"""
+        if ch is None:
+            return g[:, None].contiguous()
+        return torch.zeros(g.shape[0], C, device=g.device, dtype=g.dtype).scatter_(1, ch, g[:, None])
+
     def _param_grad(self, batch, pred, kind: str, valid=None):
         """d(loss term)/d(raw ratio) and the DIRECT d(loss term)/d(tau) (through the event-rate target), with the
         rendered prediction held fixed: `ren_event_param_grad` (closed form of the reference's autograd through
@@ -488,7 +509,8 @@ class Trainer:
             pos, rot = ops.trajectory(ts_all, self.tab_ts, self.tab_pos, self.tab_quat)
             o, d = ops.raygen(self.Kinv, px, pos, rot)
             colors, opac, depth, ctx = r.forward(o, d, jitter, bkgd, training=True, save=True)
-        inten = colors[:, 0] + r.cfg.min_modeled_intensity               # robust_e_nerf.py:867 (monochrome)
+        ch = self._channel_index(batch, 2)
+        inten = self._bayer(colors, ch) + r.cfg.min_modeled_intensity    # robust_e_nerf.py:867, 425-431
         i_s, i_e = inten[:B].contiguous(), inten[B:].contiguous()
         valid = None
         if not t.bkgd_is_param:                                           # :868-871, 442-443
@@ -499,12 +521,12 @@ class Trainer:
         scale = pw * t.w_diff
         loss = loss_sum[0] / loss_sum[1] * scale
         g_s, g_e = ops.event_loss_bwd(i_s, i_e, target, valid, t.err_diff, scale, loss_sum)
-        g_colors = torch.cat([g_s, g_e])[:, None].contiguous()
+        g_colors = self._unbayer(torch.cat([g_s, g_e]), ch, f.C)
         if t.train_contrast_threshold or t.train_refractory_period:
             self._param_grad(batch, i_e.log() - i_s.log(), "diff", valid)
         if t.train_refractory_period:
             # through the poses: sum_i dL/dI_i * dI_i/dt_i * dt_i/dtau  (start and end renders)
-            idot = colords[:, 0].double()
+            idot = self._bayer(colords, ch).double()
             self._tau_grad_dev += (g_s.double() * idot[:B] * prep["dts_start"]).sum() \
                 + (g_e.double() * idot[B:] * prep["dts_end"]).sum()
         d_bkgd = r.backward(ctx, g_colors)
@@ -535,8 +557,9 @@ class Trainer:
         bkgd = torch.nn.functional.softplus(self.small[: f.C]) if t.bkgd_is_param else None
         jit = None if jitter_grad is None else jitter_grad.to(torch.float32).contiguous()
         colors, colords, opac, ctx = jvp.render_forward(r, o, d, od, dd, jit, bkgd, training=True)
-        inten = (colors[:, 0] + r.cfg.min_modeled_intensity).contiguous()
-        intend = colords[:, 0].contiguous()                                   # d I/dt ; d log I/dt = Id / I
+        ch = self._channel_index(batch, 1)
+        inten = (self._bayer(colors, ch) + r.cfg.min_modeled_intensity).contiguous()         # robust_e_nerf.py:390-393
+        intend = self._bayer(colords, ch).contiguous()                        # d I/dt ; d log I/dt = Id / I
         valid = None if t.bkgd_is_param else (opac > 0).to(torch.uint8).contiguous()
         loss_sum = jvp.grad_loss_fwd(inten, intend, target, valid, t.err_grad)
         inv_c = 1.0 / self.mean_c
@@ -549,9 +572,9 @@ class Trainer:
         if t.train_refractory_period:
             # d L/d tau through the pose: dL/dI * dI/dt + dL/dI' * d2I/dt2, times d ts_g/d tau  (per event)
             _, _, colorsdd = jvp.render_forward2(r, o, d, od, dd, ddd, ctx["pk"], bkgd)
-            per_ev = g_i.double() * intend.double() + g_id.double() * colorsdd[:, 0].double()
+            per_ev = g_i.double() * intend.double() + g_id.double() * self._bayer(colorsdd, ch).double()
             self._tau_grad_dev += (per_ev * prep["dts_grad"]).sum()
-        d_bkgd = jvp.render_backward(r, ctx, g_i[:, None].contiguous(), g_id[:, None].contiguous())
+        d_bkgd = jvp.render_backward(r, ctx, self._unbayer(g_i, ch, f.C), self._unbayer(g_id, ch, f.C))
         if d_bkgd is not None:
             self.small_grad[: f.C] += d_bkgd * torch.sigmoid(self.small[: f.C])
         aux = dict(intensity=inten, dlog_dt=intend / inten, n=ctx["pk"].n, rays=B)

@@ -130,9 +130,10 @@ def main():
         fld.load({k: v for name, o, i in vanilla.layer_shapes(1) for k, v in zip((name + ".weight", name + ".bias"), lin(o, i))})
         renderer = vanilla.VanillaRenderer(fld, rcfg)
     else:
-        fld = engine.NGPField(dev, 1, ncfg.get("ngp", {}).get("pos_encoding"))
+        C = 3 if "channel_idx" in events else 1             # Bayer sensor -> radiance_dim 3 (robust_e_nerf.py:230-233)
+        fld = engine.NGPField(dev, C, ncfg.get("ngp", {}).get("pos_encoding"))
         p = {"hash": (torch.rand(fld.n_table, generator=gen) * 2 - 1) * 1e-4}          # tcnn grid init U(+-1e-4)
-        for k, (o, i) in {"base.w0": (64, 32), "base.wo": (16, 64), "head.w0": (64, 31), "head.w1": (64, 64), "head.wo": (1, 64)}.items():
+        for k, (o, i) in {"base.w0": (64, 32), "base.wo": (16, 64), "head.w0": (64, 31), "head.w1": (64, 64), "head.wo": (C, 64)}.items():
             p[k], p[k.replace(".w", ".b")] = lin(o, i)
         fld.load(p)
         renderer = engine.Renderer(fld, rcfg)
@@ -150,7 +151,7 @@ def main():
         else torch.tensor(-1e30, dtype=torch.float64)
     tr = engine.Trainer(renderer, tcfg, Kinv=Kinv, tab_ts=tab_ts, tab_pos=tab_pos, tab_quat=tab_quat,
                         p2n_raw=torch.tensor(softplus_inv(pos_ct / neg_ct)), neg_ct=torch.tensor(neg_ct),
-                        tau_raw=tau_raw, tau_max=tau_max, bkgd_raw=torch.tensor([softplus_inv(1.0)]),
+                        tau_raw=tau_raw, tau_max=tau_max, bkgd_raw=torch.tensor([softplus_inv(1.0)] * fld.C),
                         world_size=world, process_group=None)
     if args.resume:
         rsd = torch.load(args.resume, map_location="cpu")["state_dict"]
