@@ -580,7 +580,7 @@ class Trainer:
         aux = dict(intensity=inten, dlog_dt=intend / inten, n=ctx["pk"].n, rays=B)
         return loss, aux
 
-    def optimizer_step(self):
+    def optimizer_step(self, accumulate_grad_batches: int = 1):
         """Adam on [hash table | MLPs] (lr default, L2 decay 1e-6: robust_e_nerf.py:786-813) and on the
         background scalar (no decay).  Under data parallelism gradients are summed over ranks (RCCL
         all-reduce of the single flat buffer) and scaled by 1/world inside the Adam kernel."""
@@ -589,7 +589,7 @@ class Trainer:
             from . import parallel
             parallel.allreduce_sum_([f.grad, self.small_grad], group=self.pg, world_size=self.world_size)
         self.step_count += 1
-        gs = 1.0 / self.world_size
+        gs = 1.0 / (self.world_size * accumulate_grad_batches)            # mean over ranks and accumulated micro-batches
         lr = self.t.lr * self.lr_scale
         ops.adam_step(f.flat, f.grad, self.m, self.v, lr=lr, betas=self.t.betas, eps=self.t.eps,
                       weight_decay=self.t.weight_decay, step=self.step_count, grad_scale=gs, zero_grad=True)
@@ -633,13 +633,20 @@ class Trainer:
         """MultiStepLR stepped per epoch (robust_e_nerf.py:818-832, synthetic.yaml:113-128)."""
         self.lr_scale = gamma ** sum(1 for m in milestones if epoch >= m)
 
-    def step(self, batch, jitter_start=None, jitter_end=None, global_step: Optional[int] = None, jitter_grad=None):
-        if global_step is not None:
+    def step(self, batch, jitter_start=None, jitter_end=None, global_step: Optional[int] = None, jitter_grad=None,
+             batch_index: Optional[int] = None, accumulate_grad_batches: int = 1):
+        """One training batch.  With gradient accumulation (PL `accumulate_grad_batches`): the occupancy grid is
+        refreshed on the first micro-batch only (robust_e_nerf.py:375-379), gradients add up over the micro-batches
+        and the optimiser steps on the last one with their mean."""
+        k = max(1, accumulate_grad_batches)
+        bi = 0 if batch_index is None else batch_index
+        if global_step is not None and bi % k == 0:
             self.r.update_occ_grid(global_step, self.tab_pos)
         loss, aux = self.forward_backward(batch, jitter_start, jitter_end)
         if self.t.w_grad > 0:
             lg, aux_g = self.grad_loss_forward_backward(batch, jitter_grad)
             loss = loss + lg
             aux = dict(aux, grad=aux_g)
-        self.optimizer_step()
+        if (bi + 1) % k == 0:
+            self.optimizer_step(k)
         return loss, aux

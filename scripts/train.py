@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--max-epochs", type=int)
     ap.add_argument("--limit-train-batches", type=int)
     ap.add_argument("--resume")
+    ap.add_argument("--accumulate-grad-batches", type=int, help="overrides trainer.accumulate_grad_batches")
     args = ap.parse_args()
     cfg = yaml.safe_load(open(args.config))
     rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("LOCAL_RANK", 0), ("WORLD_SIZE", 1)))
@@ -167,20 +168,27 @@ def main():
     max_epochs = args.max_epochs or int(tcf["max_epochs"])
     per_epoch = args.limit_train_batches or int(tcf["limit_train_batches"])
     log_every = int(tcf.get("log_every_n_steps", 100))
+    accum = int(args.accumulate_grad_batches or tcf.get("accumulate_grad_batches", 1) or 1)
+    # a new batch size takes effect two batches later (one batch is already pre-fetched, robust_e_nerf.py:925-931)
+    from collections import deque
+    pending = deque([batch_size])
     jgen = torch.Generator(device=dev).manual_seed(seed + 17 + rank)
     os.makedirs(args.out, exist_ok=True)
     step, t0, rays = 0, time.perf_counter(), 0
     for epoch in range(max_epochs):
         tr.set_epoch(epoch, tuple(sched["milestones"]), float(sched["gamma"]))
-        for _ in range(per_epoch):
+        for bi in range(per_epoch):
             batch = batcher.next()
             B = batch["position"].shape[0]
             j = torch.rand(3, B, device=dev, generator=jgen)
-            loss, aux = tr.step(batch, j[0], j[1], global_step=step, jitter_grad=j[2])
+            loss, aux = tr.step(batch, j[0], j[1], global_step=step, jitter_grad=j[2], batch_index=bi,
+                                accumulate_grad_batches=accum)
             rays += (3 if tcfg.w_grad > 0 else 2) * B
-            batcher.set_batch_size(tr.update_train_batch_size(aux, budget))      # robust_e_nerf.py:907-950
-            step += 1
-            if rank == 0 and step % log_every == 0:
+            if accum == 1 or bi % accum == accum - 2:                            # robust_e_nerf.py:907-950
+                pending.append(tr.update_train_batch_size(aux, budget))
+            batcher.set_batch_size(pending.popleft() if len(pending) > 1 else pending[0])
+            step += (bi + 1) % accum == 0                                        # global_step counts optimiser steps
+            if rank == 0 and (bi + 1) % accum == 0 and step % log_every == 0:
                 torch.cuda.synchronize()
                 dt = time.perf_counter() - t0
                 print(f"epoch {epoch} step {step}  loss {float(loss):.5f}  batch {B}  samples/ray {aux['n'] / max(aux['rays'], 1):.1f}"

@@ -1070,3 +1070,8 @@ def test_train_cli_smoke_and_checkpoint_keys(tmp_path):
     out2 = subprocess.run(cmd + ["--resume", os.path.join(tmp_path, "last.ckpt"), "--max-epochs", "1", "--limit-train-batches", "8"],
                           capture_output=True, text=True, timeout=600)
     assert out2.returncode == 0, out2.stderr[-2000:]
+    # gradient accumulation: 8 micro-batches = 4 optimiser steps (global_step counts optimiser steps)
+    out3 = subprocess.run(cmd + ["--max-epochs", "1", "--limit-train-batches", "8", "--accumulate-grad-batches", "2"],
+                          capture_output=True, text=True, timeout=600)
+    assert out3.returncode == 0, out3.stderr[-2000:]
+    assert torch.load(os.path.join(tmp_path, "last.ckpt"), map_location="cpu")["global_step"] == 4
