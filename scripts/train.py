@@ -53,6 +53,35 @@ def load_field_state_dict(fld, arch, sd):
         fld.load({ours: sd[theirs] for ours, theirs in NGP_KEYS.items()})
 
 
+SUPPORTED = {  # what the fused kernels implement = what every shipped configs/train/*.yaml selects
+    "ngp": {"dir_encoding": {"degree": 4},
+            "mlp_base": {"hidden_activation": "softplus", "density_activation": "shifted_trunc_exp", "n_neurons": 64,
+                         "n_hidden_layers": 1, "geo_feat_dim": 15, "weight_norm": False},
+            "mlp_head": {"hidden_activation": "softplus", "radiance_activation": "softplus", "n_neurons": 64,
+                         "n_hidden_layers": 2, "weight_norm": False}},
+    "mlp": {"net_depth": 8, "net_width": 256, "skip_layer": 4, "net_depth_condition": 1, "net_width_condition": 128,
+            "hidden_activation": "softplus", "density_activation": "shifted_trunc_exp", "radiance_activation": "softplus",
+            "pos_encoder_max_deg": 10, "view_encoder_max_deg": 4, "weight_norm": False},
+}
+
+
+def check_supported(ncfg, arch):
+    """Fail loudly on hyper-parameters the HIP kernels do not implement (no silent fallback)."""
+    def walk(want, got, path):
+        for k, v in want.items():
+            if k not in got:
+                continue                                        # absent key = the reference default = supported value
+            if isinstance(v, dict):
+                walk(v, got[k] or {}, path + [k])
+            elif got[k] != v:
+                raise NotImplementedError(f"model.nerf.{'.'.join(path + [k])} = {got[k]!r}: the MI355X kernels implement {v!r} only")
+    walk(SUPPORTED[arch], ncfg.get(arch) or {}, [arch])
+    pe = (ncfg.get("ngp") or {}).get("pos_encoding") or {}
+    if arch == "ngp" and (pe.get("otype", "HashGrid") != "HashGrid" or pe.get("interpolation", "Linear") != "Linear"
+                          or pe.get("n_features_per_level", 2) != 2 or pe.get("n_levels", 16) != 16):
+        raise NotImplementedError(f"model.nerf.ngp.pos_encoding {pe}: HashGrid, Linear interpolation, 16 levels x 2 features only")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", required=True)
@@ -120,6 +149,7 @@ def main():
                             min_modeled_intensity=float(mcfg["min_modeled_intensity"]), occ_thre=float(og["occ_thre"]),
                             ema_decay=float(og["ema_decay"]), warmup_steps=int(og["warmup_steps"]), occ_n=int(og["n"]))
     arch = ncfg.get("arch", "ngp")
+    check_supported(ncfg, arch)
     gen = torch.Generator().manual_seed(seed)
 
     def lin(o, i):                                           # nn.Linear default init (hidden_init=None, ngp.py:179-185)
