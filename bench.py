@@ -161,11 +161,16 @@ def main():
         raise SystemExit("for --gpus N > 1 launch with torch.distributed.run --nproc-per-node N")
     import torch.distributed as dist
     pg = None
+    # REN_BENCH_DIST=gloo:shared-gpu runs the N-rank code path on ONE device over gloo (a self-test of the launch
+    # contract on a 1-GPU box; numbers mean nothing).  Normal runs: one rank per GPU over RCCL.
+    selftest = os.environ.get("REN_BENCH_DIST", "") == "gloo:shared-gpu"
+    if selftest:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl")
+        dist.init_process_group(backend="gloo" if selftest else "nccl")
     dev = f"cuda:{local_rank}"
     torch.cuda.set_device(local_rank)
 

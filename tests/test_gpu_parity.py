@@ -1075,3 +1075,20 @@ def test_train_cli_smoke_and_checkpoint_keys(tmp_path):
                           capture_output=True, text=True, timeout=600)
     assert out3.returncode == 0, out3.stderr[-2000:]
     assert torch.load(os.path.join(tmp_path, "last.ckpt"), map_location="cpu")["global_step"] == 4
+
+
+def test_bench_n_rank_contract_selftest():
+    """bench.py's N-rank launch contract (torch.distributed.run, per-rank seeds, gradient all-reduce, barrier,
+    max-over-ranks time, one JSON line from rank 0) on ONE device over gloo -- the 8-GPU run itself is the driver's."""
+    import json, os, subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, REN_BENCH_DIST="gloo:shared-gpu")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", "29517", os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "2",
+                          "--warmup", "1", "--events", "2048"], capture_output=True, text=True, timeout=600, env=env, cwd=repo)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["config"]["parallelism"] == "dp2"
+    assert d["value"] > 0 and "cpu_baseline" not in d and "roofline" in d
