@@ -542,6 +542,9 @@ class Trainer:
         with the event rate C/dt.  Accumulates gradients; returns (weighted loss term, aux)."""
         from . import jvp
         r, t, f = self.r, self.t, self.r.field
+        if not isinstance(f, NGPField):
+            raise NotImplementedError("the log-intensity-gradient loss (forward-mode d/dt render) is built for arch ngp only; "
+                                      "set loss.weight.log_intensity_grad to 0 for arch mlp")
         B = batch["position"].shape[0]
         self._refresh_contrast_threshold()
         self._refresh_tau()

@@ -13,7 +13,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import ops
-from .engine import Renderer
+from .engine import NGPField, Renderer
 
 
 def pixel_grid(height: int, width: int, device) -> torch.Tensor:
@@ -38,10 +38,14 @@ def render_pixels(r: Renderer, Kinv: torch.Tensor, px: torch.Tensor, pos: torch.
 
 @torch.no_grad()
 def render_image(r: Renderer, Kinv: torch.Tensor, cam_pos: torch.Tensor, cam_rot: torch.Tensor, height: int,
-                 width: int, bkgd: Optional[torch.Tensor] = None, chunk: int = 1 << 20):
+                 width: int, bkgd: Optional[torch.Tensor] = None, chunk: Optional[int] = None):
     """evaluation_step: (H, W) predicted intensity, opacity, depth for one pose.  ``chunk`` is the reference's
     ``test_chunk_size`` (16 384 there, to fit a 2080 Ti); with 288 GB a 640x480 image is one chunk, which is 4x
-    faster than 19 chunks (2.6 vs 10.3 ms, tools/render_bench.py).  The result does not depend on it."""
+    faster than 19 chunks (2.6 vs 10.3 ms, tools/render_bench.py).  The result does not depend on it.  Default: one
+    chunk for arch ngp (~200 B/sample of temporaries), the reference's 16 384 rays for arch mlp (its 8 x 256 hidden
+    activations are ~10 KB/sample: a whole 640x480 image at ~600 samples per ray would not fit)."""
+    if chunk is None:
+        chunk = (1 << 20) if isinstance(r.field, NGPField) else 16384
     dev = Kinv.device
     px = pixel_grid(height, width, dev).reshape(-1, 2)
     n = px.shape[0]

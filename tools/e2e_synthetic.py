@@ -114,9 +114,17 @@ def evaluate(ckpt, Kinv_d, cfg, png=None):
     sys.path.insert(0, os.path.join(REPO, "scripts"))
     import train as cli
     sd = torch.load(ckpt, map_location="cpu")["state_dict"]
-    fld = engine.NGPField(DEV, 1)
-    cli.load_field_state_dict(fld, "ngp", sd)
-    r = engine.Renderer(fld, engine.RenderCfg(aabb=AABB, sampler="occgrid", render_step_size=3 * math.sqrt(3) / 1024))
+    arch = cfg["model"]["nerf"].get("arch", "ngp")
+    rcfg = engine.RenderCfg(aabb=AABB, sampler="occgrid", render_step_size=3 * math.sqrt(3) / 1024)
+    if arch == "mlp":
+        from robust_e_nerf_amd import vanilla
+        fld = vanilla.VanillaField(DEV, 1)
+        cli.load_field_state_dict(fld, "mlp", sd)
+        r = vanilla.VanillaRenderer(fld, rcfg)
+    else:
+        fld = engine.NGPField(DEV, 1)
+        cli.load_field_state_dict(fld, "ngp", sd)
+        r = engine.Renderer(fld, rcfg)
     r.binary.copy_(sd["nerf.occ_grid._binary"].reshape(-1).to(torch.uint8).to(DEV))
     bk = torch.nn.functional.softplus(sd["nerf.parametrizations.render_bkgd.original"].to(DEV))
     scores, tiles = [], []
@@ -138,6 +146,8 @@ def main():
     ap.add_argument("--out", default="gpurun_out/e2e")
     ap.add_argument("--epochs", type=int, default=6)
     ap.add_argument("--steps-per-epoch", type=int, default=500)
+    ap.add_argument("--arch", default="ngp", choices=["ngp", "mlp"])
+    ap.add_argument("--budget", type=int, default=1 << 20, help="train_eff_ray_sample_batch_size")
     args = ap.parse_args()
     data_dir = os.path.join(args.out, "dataset")
     t0 = time.perf_counter()
@@ -146,7 +156,10 @@ def main():
     print(f"simulated {n_events} events in {t_sim:.1f} s", flush=True)
     import yaml
     cfg = yaml.safe_load(open(os.path.join(REPO, "configs", "synthetic_smoke.yaml")))
-    cfg["data"].update(dataset_directory=data_dir, train_init_eff_batch_size=65536, train_eff_ray_sample_batch_size=1 << 20)
+    cfg["data"].update(dataset_directory=data_dir, train_init_eff_batch_size=65536 if args.arch == "ngp" else 2048, train_eff_ray_sample_batch_size=args.budget)
+    cfg["model"]["nerf"]["arch"] = args.arch
+    if args.arch == "mlp":
+        cfg["loss"]["weight"]["log_intensity_grad"] = 0.0          # l_grad is built for arch ngp only
     cfg["trainer"].update(max_epochs=args.epochs, limit_train_batches=args.steps_per_epoch, log_every_n_steps=100)
     cfg["lr_scheduler"]["multi_step_lr"]["milestones"] = [max(1, args.epochs // 2), max(2, 3 * args.epochs // 4), max(3, 9 * args.epochs // 10)]
     cfg_path = os.path.join(args.out, "train.yaml")
