@@ -174,8 +174,7 @@ def main():
     dev = f"cuda:{local_rank}"
     torch.cuda.set_device(local_rank)
 
-    from oracle import hashgrid                      # only for the portable seeded table generator
-    from robust_e_nerf_amd import engine, ops
+    from robust_e_nerf_amd import engine, ops          # the oracle is imported by the cpu_baseline leg only
 
     scene = synthetic_scene()
     tab_ts, tab_pos, tab_quat, Kinv = scene
@@ -193,7 +192,7 @@ def main():
     p["head.w0"], p["head.b0"] = lin(64, 31)
     p["head.w1"], p["head.b1"] = lin(64, 64)
     p["head.wo"], p["head.bo"] = lin(1, 64)
-    p["hash"] = hashgrid.init_table(hashgrid.make_spec(), 0, 0.1, "mix32")
+    p["hash"] = (torch.rand(ops.make_grid_desc()[1], generator=gen) * 2 - 1) * 0.1
 
     aabb = (-1.5, -1.5, -1.5, 1.5, 1.5, 1.5)
     cfg = engine.RenderCfg(aabb=aabb, sampler=args.sampler, n_uniform=args.samples, mlp_bf16=args.mlp_bf16,

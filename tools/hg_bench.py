@@ -3,11 +3,10 @@ import os, sys, time, math
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from robust_e_nerf_amd import ops, engine
-from oracle import hashgrid
 dev = "cuda:0"
 R, S = 131072, 128
 grid, n_table = ops.make_grid_desc()
-table = hashgrid.init_table(hashgrid.make_spec(), 0, 0.1, "mix32").to(dev)
+table = ((torch.rand(ops.make_grid_desc()[1], generator=torch.Generator().manual_seed(0)) * 2 - 1) * 0.1).to(dev)
 g = torch.Generator().manual_seed(0)
 ang = torch.rand(R, generator=g) * 2 * math.pi
 o = torch.stack([4 * torch.cos(ang), 4 * torch.sin(ang), torch.rand(R, generator=g) - 0.5], -1)
