@@ -443,7 +443,13 @@ int ren_freq_encode(const ren_scene_desc *scene, const float *x_world, const flo
                     const float *t_ends, int64_t n, float *enc, int32_t ld_enc, float *cat, int32_t ld_cat,
                     int32_t cat_col, float *view, int32_t ld_view, int32_t view_col, uint8_t *selector,
                     void *stream);
-/* Y[:, :n_out] = act(X[:, :n_in] W^T + b)  (nn.Linear + activation, mlp.py:99-113), n_out <= 256 */
+/* Y[:, :n_out] = act(X[:, :n_in] W^T + b)  (nn.Linear + activation, mlp.py:99-113), n_out <= 256
+ * Matrix-core path: OR one of these into `act` (ren_dense_fwd) / `prev_act` (ren_dense_bwd_data):
+ * REN_DENSE_F32 exact v_mfma_f32_32x32x2_f32; REN_DENSE_BF16X6 split-bf16, six bf16 MFMAs per k-step at fp32
+ * accuracy (2.7x fewer matrix-pipe cycles, co-issues with the VALU); REN_DENSE_BF16 plain bf16 operands. */
+#define REN_DENSE_F32 0x000
+#define REN_DENSE_BF16X6 0x600
+#define REN_DENSE_BF16 0x100
 int ren_dense_fwd(const float *X, int32_t ldx, const float *W, const float *bias, int32_t n_out, int32_t n_in,
                   int32_t act, const uint8_t *selector, float *Y, int32_t ldy, int64_t n, void *stream);
 /* dX[:, :n_store] (+)= dZ[:, :n_out] W[:, :n_store], then multiplied by prev_act'(Yprev) -> the dZ of the

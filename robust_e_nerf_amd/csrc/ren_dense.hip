@@ -63,6 +63,64 @@ __device__ __forceinline__ void store_chunk(float *buf, const float (&pre)[NT * 
     }
 }
 
+// bias / activation (forward) or accumulate + previous layer's activation derivative (backward-data), row-major
+// float4 stores; shared by the f32 and the split-bf16 kernels (same accumulator layout)
+template <int NT, bool BWD>
+__device__ __forceinline__ void dense_epilogue(const DenseArgs &a, f32x16 (&acc)[NT], bool active, int64_t row, int hi) {
+    if (!active || row >= ((a.n + 31) & ~(int64_t)31)) return;
+    const bool live = row < a.n;
+    const bool selv = (!BWD && a.act == ACT_TRUNC_EXP_SEL && live) ? a.sel[row] != 0 : false;
+    // epilogue in two halves of NT/2 tiles: all loads of a half (saved activations / accumulate target) are
+    // issued as float4 before any arithmetic, so their latencies overlap instead of queueing per element
+    constexpr int HT = NT > 1 ? NT / 2 : 1;
+#pragma unroll
+    for (int half = 0; half < NT / HT; ++half) {
+        float4 yp4[HT][4], yo4[HT][4];
+        if (BWD) {
+#pragma unroll
+            for (int u = 0; u < HT; ++u)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int o0 = a.out0 + (half * HT + u) * 32 + 8 * q + 4 * hi;
+                    const bool in = o0 + 3 < a.n_out;                 // n_out is a multiple of 4 on this path (host check)
+                    yp4[u][q] = (in && a.act == ACT_SOFTPLUS100) ? *reinterpret_cast<const float4 *>(a.Yprev + row * a.ldyp + o0)
+                                                                : make_float4(0.f, 0.f, 0.f, 0.f);
+                    yo4[u][q] = (in && a.accumulate) ? *reinterpret_cast<const float4 *>(a.Y + row * a.ldy + o0)
+                                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+        }
+#pragma unroll
+        for (int u = 0; u < HT; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int t = half * HT + u;
+                const int o0 = a.out0 + t * 32 + 8 * q + 4 * hi;
+                if (o0 >= a.n_out) continue;
+                float v[4];
+                const float yp[4] = {yp4[u][q].x, yp4[u][q].y, yp4[u][q].z, yp4[u][q].w};
+                const float yo[4] = {yo4[u][q].x, yo4[u][q].y, yo4[u][q].z, yo4[u][q].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float z = acc[t][4 * q + j];
+                    if (!BWD) {
+                        if (a.act == ACT_SOFTPLUS100) z = softplus100(z);
+                        else if (a.act == ACT_SOFTPLUS1) z = softplus1(z);
+                        else if (a.act == ACT_TRUNC_EXP_SEL) z = selv ? __expf(z - 1.f) : 0.f;      // ngp.py:45-65
+                    } else {
+                        z += yo[j];
+                        if (a.act == ACT_SOFTPLUS100) z *= dsoftplus_from_out(yp[j], 100.f);
+                    }
+                    v[j] = live ? z : 0.f;
+                }
+                float *yptr = a.Y + row * a.ldy + o0;
+                if (o0 + 3 < a.n_out) *reinterpret_cast<float4 *>(yptr) = make_float4(v[0], v[1], v[2], v[3]);
+                else
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (o0 + j < a.n_out) yptr[j] = v[j];
+            }
+    }
+}
+
 template <int NT, bool BWD>
 __global__ __launch_bounds__(256, 2) void dense_kernel(DenseArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];        // 2 x [NT*32][33]
@@ -125,58 +183,131 @@ __global__ __launch_bounds__(256, 2) void dense_kernel(DenseArgs a) {
         }
         __syncthreads();
     }
-    if (!active || row >= ((a.n + 31) & ~(int64_t)31)) return;
-    const bool live = row < a.n;
-    const bool selv = (!BWD && a.act == ACT_TRUNC_EXP_SEL && live) ? a.sel[row] != 0 : false;
-    // epilogue in two halves of NT/2 tiles: all loads of a half (saved activations / accumulate target) are
-    // issued as float4 before any arithmetic, so their latencies overlap instead of queueing per element
-    constexpr int HT = NT > 1 ? NT / 2 : 1;
+    dense_epilogue<NT, BWD>(a, acc, active, row, hi);
+}
+
+// ---- the same layer on the bf16 matrix cores ------------------------------------------------------------------
+// MODE 6: every fp32 operand split into three bf16 pieces, six v_mfma_f32_32x32x16_bf16 per 16-wide k-step
+// reproduce the fp32 product to fp32 round-off (see ren_mlp_x.hip) -- 192 matrix-pipe cycles per k-step against
+// 512 for eight f32 MFMAs, and unlike those they co-issue with the VALU.  MODE 1: plain bf16 operands.
+// The weight chunk W[:, k0:k0+32] is split ONCE per workgroup while it is staged in LDS ([piece][row][40] bf16:
+// one ds_read_b128 per A operand, conflict-free for 16-byte reads at an 80-byte row stride); the 8 k-values a lane
+// feeds per k-step are contiguous in the row-major activations (two float4 loads) and are split in registers.
+constexpr int XST = 40;                                  // LDS row stride in bf16 (32 k + 8 pad)
+
+template <int NT, bool BWD, int NP>
+__device__ __forceinline__ void load_chunk_x(const DenseArgs &a, int c, float (&pre)[NT * 4]) {
+    const int k0 = c * KC;
 #pragma unroll
-    for (int half = 0; half < NT / HT; ++half) {
-        float4 yp4[HT][4], yo4[HT][4];
-        if (BWD) {
+    for (int j = 0; j < NT * 2; ++j) {                   // thread -> (row, column pair) of the [NT*32][32] chunk
+        const int e = threadIdx.x + 256 * j;
+        float v0 = 0.f, v1 = 0.f;
+        if (!BWD) {
+            const int row = a.out0 + (e >> 4), col = k0 + 2 * (e & 15);
+            if (row < a.w_rows) {
+                const float *w = a.W + (int64_t)row * a.w_cols + col;
+                if (col < a.w_cols) v0 = w[0];
+                if (col + 1 < a.w_cols) v1 = w[1];
+            }
+        } else {                                         // W^T: out row = W column, k = W row; coalesced along W columns
+            const int row = a.out0 + e % (NT * 32), col = k0 + 2 * (e / (NT * 32));
+            if (row < a.w_cols) {
+                if (col < a.w_rows) v0 = a.W[(int64_t)col * a.w_cols + row];
+                if (col + 1 < a.w_rows) v1 = a.W[(int64_t)(col + 1) * a.w_cols + row];
+            }
+        }
+        pre[2 * j] = v0; pre[2 * j + 1] = v1;
+    }
+}
+
+template <int NT, bool BWD, int NP>
+__device__ __forceinline__ void store_chunk_x(__bf16 *buf, const float (&pre)[NT * 4]) {
 #pragma unroll
-            for (int u = 0; u < HT; ++u)
+    for (int j = 0; j < NT * 2; ++j) {
+        const int e = threadIdx.x + 256 * j;
+        const int row = BWD ? e % (NT * 32) : e >> 4, cp = BWD ? e / (NT * 32) : e & 15;
+        __bf16 s0[3], s1[3];
+        split<NP>(pre[2 * j], s0);
+        split<NP>(pre[2 * j + 1], s1);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int o0 = a.out0 + (half * HT + u) * 32 + 8 * q + 4 * hi;
-                    const bool in = o0 + 3 < a.n_out;                 // n_out is a multiple of 4 on this path (host check)
-                    yp4[u][q] = (in && a.act == ACT_SOFTPLUS100) ? *reinterpret_cast<const float4 *>(a.Yprev + row * a.ldyp + o0)
-                                                                : make_float4(0.f, 0.f, 0.f, 0.f);
-                    yo4[u][q] = (in && a.accumulate) ? *reinterpret_cast<const float4 *>(a.Y + row * a.ldy + o0)
-                                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int p = 0; p < NP; ++p) {
+            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+            bf16x2 v; v[0] = s0[p]; v[1] = s1[p];
+            *reinterpret_cast<bf16x2 *>(buf + ((p * NT * 32 + row) * XST + 2 * cp)) = v;
+        }
+    }
+}
+
+template <int NT, bool BWD, int MODE>
+__global__ __launch_bounds__(256, 2) void dense_x_kernel(DenseArgs a) {
+    using PR = Pairs<MODE>;
+    constexpr int NP = PR::NT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_x[];   // 2 x [NP][NT*32][XST] bf16
+    __bf16 *lds = reinterpret_cast<__bf16 *>(smem_x);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hi = lane >> 5, sl = lane & 31;
+    const int64_t n_blk = (a.n + 31) >> 5;
+    const int64_t blk = (int64_t)blockIdx.x * 4 + wave;
+    const bool active = blk < n_blk;
+    const int64_t row = blk * 32 + sl;
+    const int n_chunks = (a.red + KC - 1) / KC;
+    constexpr int BUF = NP * NT * 32 * XST;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const int o = a.out0 + t * 32 + rowc(g) + 4 * hi;
+            float bv = 0.f;
+            if (!BWD && a.bias) { bv = a.bias[min(o, a.w_rows - 1)]; bv = o < a.w_rows ? bv : 0.f; }
+            acc[t][g] = bv;
+        }
+    {
+        float pre[NT * 4];
+        load_chunk_x<NT, BWD, NP>(a, 0, pre);
+        store_chunk_x<NT, BWD, NP>(lds, pre);
+    }
+    __syncthreads();
+    float4 xv[4];                                        // this lane's 2 x 8 k-values of the chunk: k0 + 16 s + 8 hi + j
+    auto load_x = [&](int c, float4 (&dst)[4]) {
+        if (active) {
+            const float4 *xp = reinterpret_cast<const float4 *>(a.X + row * a.ldx + c * KC + 8 * hi);
+            dst[0] = xp[0]; dst[1] = xp[1]; dst[2] = xp[4]; dst[3] = xp[5];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dst[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    load_x(0, xv);
+    for (int c = 0; c < n_chunks; ++c) {
+        float pre[NT * 4];
+        float4 xn[4];
+        const bool more = c + 1 < n_chunks;
+        if (more) { load_chunk_x<NT, BWD, NP>(a, c + 1, pre); load_x(c + 1, xn); }
+        const __bf16 *buf = lds + (c & 1) * BUF;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const float xs[8] = {xv[2 * s].x, xv[2 * s].y, xv[2 * s].z, xv[2 * s].w,
+                                 xv[2 * s + 1].x, xv[2 * s + 1].y, xv[2 * s + 1].z, xv[2 * s + 1].w};
+            bf16x8 b[3];
+            split8<NP>(xs, b);
+#pragma unroll
+            for (int k = 0; k < PR::N; ++k)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {           // consecutive MFMAs hit different accumulators
+                    const bf16x8 w = *reinterpret_cast<const bf16x8 *>(buf + ((PR::W[k] * NT * 32 + t * 32 + sl) * XST + 16 * s + 8 * hi));
+                    acc[t] = MFMAB(w, b[PR::A[k]], acc[t]);
                 }
         }
+        if (more) {
+            store_chunk_x<NT, BWD, NP>(lds + ((c + 1) & 1) * BUF, pre);
 #pragma unroll
-        for (int u = 0; u < HT; ++u)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int t = half * HT + u;
-                const int o0 = a.out0 + t * 32 + 8 * q + 4 * hi;
-                if (o0 >= a.n_out) continue;
-                float v[4];
-                const float yp[4] = {yp4[u][q].x, yp4[u][q].y, yp4[u][q].z, yp4[u][q].w};
-                const float yo[4] = {yo4[u][q].x, yo4[u][q].y, yo4[u][q].z, yo4[u][q].w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float z = acc[t][4 * q + j];
-                    if (!BWD) {
-                        if (a.act == ACT_SOFTPLUS100) z = softplus100(z);
-                        else if (a.act == ACT_SOFTPLUS1) z = softplus1(z);
-                        else if (a.act == ACT_TRUNC_EXP_SEL) z = selv ? __expf(z - 1.f) : 0.f;      // ngp.py:45-65
-                    } else {
-                        z += yo[j];
-                        if (a.act == ACT_SOFTPLUS100) z *= dsoftplus_from_out(yp[j], 100.f);
-                    }
-                    v[j] = live ? z : 0.f;
-                }
-                float *yptr = a.Y + row * a.ldy + o0;
-                if (o0 + 3 < a.n_out) *reinterpret_cast<float4 *>(yptr) = make_float4(v[0], v[1], v[2], v[3]);
-                else
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) if (o0 + j < a.n_out) yptr[j] = v[j];
-            }
+            for (int j = 0; j < 4; ++j) xv[j] = xn[j];
+        }
+        __syncthreads();
     }
+    dense_epilogue<NT, BWD>(a, acc, active, row, hi);
 }
 
 // ---- weight / bias gradient:  dW[N][K] += dZ^T X,  db[N] += sum dZ ------------------------------------
@@ -366,28 +497,34 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const float *__restrict_
 }
 
 template <bool BWD>
-int launch_dense(DenseArgs a, int tiles, hipStream_t st) {
+int launch_dense(DenseArgs a, int tiles, int mode, hipStream_t st) {
     if (tiles == 8) {                                   // two launches of 4 tiles: see DenseArgs::out0
         a.out0 = 0;
-        int rc = launch_dense<BWD>(a, 4, st);
+        int rc = launch_dense<BWD>(a, 4, mode, st);
         if (rc != REN_OK) return rc;
         a.out0 = 128;
-        return launch_dense<BWD>(a, 4, st);
+        return launch_dense<BWD>(a, 4, mode, st);
     }
     const int64_t n_blk = (a.n + 31) / 32;
     const dim3 grd((unsigned)((n_blk + 3) / 4)), blk(256);
+#define REN_DENSE_LAUNCH(KERNEL, LDS)                                                                        \
+    do {                                                                                                     \
+        const size_t lds = (LDS);                                                                            \
+        (void)hipFuncSetAttribute((const void *)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(KERNEL, grd, blk, lds, st, a);                                                    \
+    } while (0)
 #define REN_DENSE_CASE(NT)                                                                                   \
-    case NT: {                                                                                               \
-        const size_t lds = 2 * (size_t)NT * 32 * 33 * 4;                                                     \
-        (void)hipFuncSetAttribute((const void *)dense_kernel<NT, BWD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((dense_kernel<NT, BWD>), grd, blk, lds, st, a);                                   \
-        break;                                                                                               \
-    }
+    case NT:                                                                                                 \
+        if (mode == 6) REN_DENSE_LAUNCH((dense_x_kernel<NT, BWD, 6>), 2 * (size_t)3 * NT * 32 * XST * 2);     \
+        else if (mode == 1) REN_DENSE_LAUNCH((dense_x_kernel<NT, BWD, 1>), 2 * (size_t)1 * NT * 32 * XST * 2); \
+        else REN_DENSE_LAUNCH((dense_kernel<NT, BWD>), 2 * (size_t)NT * 32 * 33 * 4);                          \
+        break;
     switch (tiles) {
         REN_DENSE_CASE(1) REN_DENSE_CASE(2) REN_DENSE_CASE(4)
         default: return REN_ERR_UNSUPPORTED;
     }
 #undef REN_DENSE_CASE
+#undef REN_DENSE_LAUNCH
     REN_CHECK_LAUNCH();
 }
 
@@ -417,6 +554,9 @@ extern "C" int ren_freq_encode(const ren_scene_desc *scene, const float *x_world
 extern "C" int ren_dense_fwd(const float *X, int32_t ldx, const float *W, const float *bias, int32_t n_out,
                              int32_t n_in, int32_t act, const uint8_t *selector, float *Y, int32_t ldy, int64_t n,
                              void *stream) {
+    const int mode = (act >> 8) & 0xff;                                      // REN_DENSE_F32 / _BF16X6 / _BF16
+    act &= 0xff;
+    if (mode != 0 && mode != 1 && mode != 6) return REN_ERR_BAD_ARG;
     if (!X || !W || !Y || n < 0 || n_out < 1 || n_in < 1 || (ldx & 3) || (ldy & 3)) return REN_ERR_BAD_ARG;
     if (ldx < ((n_in + KC - 1) / KC) * KC) return REN_ERR_BAD_ARG;           // X rows are read in whole 32-wide chunks
     if (act < ACT_NONE || act > ACT_TRUNC_EXP_SEL || (act == ACT_TRUNC_EXP_SEL && !selector)) return REN_ERR_BAD_ARG;
@@ -426,12 +566,15 @@ extern "C" int ren_dense_fwd(const float *X, int32_t ldx, const float *W, const 
     DenseArgs a = {};
     a.X = X; a.ldx = ldx; a.W = W; a.w_rows = n_out; a.w_cols = n_in; a.red = n_in; a.n_out = n_out; a.bias = bias;
     a.act = act; a.sel = selector; a.Y = Y; a.ldy = ldy; a.n = n;
-    return launch_dense<false>(a, tiles, (hipStream_t)stream);
+    return launch_dense<false>(a, tiles, mode, (hipStream_t)stream);
 }
 
 extern "C" int ren_dense_bwd_data(const float *dZ, int32_t ldz, const float *W, int32_t n_out, int32_t n_in,
                                   int32_t n_store, int32_t prev_act, const float *Yprev, int32_t ldyp,
                                   int32_t accumulate, float *dX, int32_t ldx, int64_t n, void *stream) {
+    const int mode = (prev_act >> 8) & 0xff;
+    prev_act &= 0xff;
+    if (mode != 0 && mode != 1 && mode != 6) return REN_ERR_BAD_ARG;
     if (!dZ || !W || !dX || n < 0 || n_out < 1 || n_in < 1 || n_store < 1 || n_store > n_in || (ldz & 3) || (ldx & 3) ||
         (n_store & 3) || (Yprev && (ldyp & 3)))
         return REN_ERR_BAD_ARG;
@@ -444,7 +587,7 @@ extern "C" int ren_dense_bwd_data(const float *dZ, int32_t ldz, const float *W, 
     DenseArgs a = {};
     a.X = dZ; a.ldx = ldz; a.W = W; a.w_rows = n_out; a.w_cols = n_in; a.red = n_out; a.n_out = n_store;
     a.act = prev_act; a.Yprev = Yprev; a.ldyp = ldyp; a.accumulate = accumulate; a.Y = dX; a.ldy = ldx; a.n = n;
-    return launch_dense<true>(a, tiles, (hipStream_t)stream);
+    return launch_dense<true>(a, tiles, mode, (hipStream_t)stream);
 }
 
 extern "C" int64_t ren_dense_bwd_weight_workspace_floats(int32_t n_out, int32_t n_in, int32_t n_splits) {

@@ -170,6 +170,41 @@ __device__ __forceinline__ void sample_geom(const SampleSrc &s, const ren_scene_
     sel = ux > 0.f && ux < 1.f && uy > 0.f && uy < 1.f && uz > 0.f && uz < 1.f;   // ngp.py:238
 }
 
+// ---- split-bf16 arithmetic shared by ren_mlp_x.hip and ren_dense.hip ------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define MFMAB(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+// ---- split / pack ---------------------------------------------------------------------------------------------
+template <int NT>
+__device__ __forceinline__ void split(float v, __bf16 (&t)[3]) {
+    t[0] = (__bf16)v;
+    if (NT > 1) {
+        const float r = v - (float)t[0];
+        t[1] = (__bf16)r;
+        if (NT > 2) t[2] = (__bf16)(r - (float)t[1]);
+    }
+}
+
+// 8 fp32 values -> NT bf16x8 operands
+template <int NT>
+__device__ __forceinline__ void split8(const float *v, bf16x8 (&out)[3]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        __bf16 t[3];
+        split<NT>(v[j], t);
+#pragma unroll
+        for (int k = 0; k < NT; ++k) out[k][j] = t[k];
+    }
+}
+
+// (weight term, activation term) pairs, smallest products first
+template <int MODE> struct Pairs;
+template <> struct Pairs<1> { static constexpr int N = 1, NT = 1; static constexpr int W[1] = {0}, A[1] = {0}; };
+template <> struct Pairs<6> {
+    static constexpr int N = 6, NT = 3;
+    static constexpr int W[6] = {2, 0, 1, 1, 0, 0}, A[6] = {0, 2, 1, 0, 1, 0};
+};
+
 // grad[j] += sum_w slab[w * len + j], deterministic (fixed summation tree, no atomics).  16 parameters x 16
 // slab groups per workgroup: with one thread per parameter walking all ~1 024 slabs the kernel was a 0.1 ms
 // latency chain, five of them per training step.

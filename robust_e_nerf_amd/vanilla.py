@@ -113,17 +113,24 @@ class VanillaRenderer(Renderer):
         self._encode = ops._wrap("freq_encode", self._encode)
 
     # ---- kernels ------------------------------------------------------------------------------------
+    def _dense_mode(self) -> int:
+        """matrix-core path of ren_dense_fwd / ren_dense_bwd_data: 0 exact f32 MFMA, 6 split-bf16 at fp32 accuracy,
+        1 plain bf16 operands (RenderCfg.mlp_kernels / mlp_bf16, as for arch ngp)"""
+        if self.cfg.mlp_bf16:
+            return 1
+        return 6 if self.cfg.mlp_kernels == "x" else 0
+
     def _fwd(self, X, ldx, name, act, Y, ldy, n, sel=None):
         f = self.field
         o, i = f.w[name].shape
-        check(_lib.load().ren_dense_fwd(_ptr(X), ldx, _ptr(f.w[name]), _ptr(f.b[name]), o, i, act,
+        check(_lib.load().ren_dense_fwd(_ptr(X), ldx, _ptr(f.w[name]), _ptr(f.b[name]), o, i, act | (self._dense_mode() << 8),
                                         _ptr(sel, torch.uint8) if sel is not None else None, _ptr(Y), ldy, n, _stream()),
               "ren_dense_fwd")
 
     def _bwd_data(self, dZ, ldz, name, n_store, prev_act, Yprev, ldyp, accumulate, dX, ldx, n):
         f = self.field
         o, i = f.w[name].shape
-        check(_lib.load().ren_dense_bwd_data(_ptr(dZ), ldz, _ptr(f.w[name]), o, i, n_store, prev_act,
+        check(_lib.load().ren_dense_bwd_data(_ptr(dZ), ldz, _ptr(f.w[name]), o, i, n_store, prev_act | (self._dense_mode() << 8),
                                              _ptr(Yprev) if Yprev is not None else None, ldyp, int(accumulate),
                                              _ptr(dX), ldx, n, _stream()), "ren_dense_bwd_data")
 

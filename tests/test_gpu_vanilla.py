@@ -103,3 +103,34 @@ def test_vanilla_training_steps(amd):
         tr.optimizer_step()
         losses.append(float(loss))
     assert losses[-1] < losses[0], losses
+
+
+def test_dense_matrix_core_modes(amd):
+    """ren_dense_fwd / ren_dense_bwd_data on the bf16 matrix cores: split-bf16 (REN_DENSE_BF16X6) equals the exact
+    f32-MFMA path to fp32 round-off; plain bf16 (REN_DENSE_BF16) equals a float64 product of bf16-rounded operands."""
+    import ctypes
+    from robust_e_nerf_amd import _lib
+    ops, engine, vanilla = amd
+    P, st = ops._ptr, ops._stream
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(0)
+    n, n_in, n_out = 1000, 283, 256
+    ldx, ldy = 288, 256
+    X = torch.zeros(1024, ldx)
+    X[:n, :n_in] = torch.randn(n, n_in, generator=gen)
+    W = torch.randn(n_out, n_in, generator=gen) / math.sqrt(n_in)
+    b = torch.randn(n_out, generator=gen)
+    Xd, Wd, bd = X.to(DEV), W.to(DEV).contiguous(), b.to(DEV)
+    outs = {}
+    for mode in (0, 6, 1):
+        Y = torch.zeros(1024, ldy, device=DEV)
+        assert lib.ren_dense_fwd(P(Xd), ldx, P(Wd), P(bd), n_out, n_in, 1 | (mode << 8), None, P(Y), ldy, n, st()) == 0
+        dX = torch.zeros(1024, ldx, device=DEV)
+        assert lib.ren_dense_bwd_data(P(Y), ldy, P(Wd), n_out, n_in, 256, 0 | (mode << 8), None, 0, 0, P(dX), ldx, n, st()) == 0
+        outs[mode] = (Y[:n].cpu(), dX[:n, :256].cpu())
+    assert rel_err(outs[6][0], outs[0][0]) < 2e-6 and rel_err(outs[6][1], outs[0][1]) < 2e-6
+    r16 = lambda v: v.to(torch.bfloat16).double()
+    z = r16(X[:n, :n_in]) @ r16(W).T + b.double()
+    y_ref = torch.where(z * 100 > 20, z, torch.log1p(torch.exp(z * 100)) / 100)
+    assert rel_err(outs[1][0], y_ref) < 1e-5
+    assert rel_err(outs[1][1], (r16(outs[1][0]) @ r16(W))[:, :256]) < 1e-5
