@@ -25,6 +25,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+MFMA_BF16_PEAK_TFLOPS = 2500.0              # dense bf16 (MI355X_MICROARCH.md; not the 2:1-sparsity figure)
 MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak (= f32 vector peak)
 # algorithmic bytes per differentiable sample (DESIGN.md "Roofline"):
 BYTES = {"hashgrid_fwd": 1024 + 12, "hashgrid_bwd": 2048 + 12, "hashgrid_bwd_binned": 2048 + 12}
@@ -280,10 +281,18 @@ def main():
         else:
             # dense_* families: one launch per layer, so price the whole family per step
             per = (ms / args.steps) if dom.startswith("dense") else (ms / c)
-            achieved = FLOPS[dom] * samples_per_launch / (per * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": pmc_traffic(dom, args),
-                    "algorithmic_flops_per_sample": FLOPS[dom], "avg_launch_ms": ms / c}
+            # matrix-core peak of the path that ran: exact f32 MFMA, or bf16 MFMA with 6 (split-bf16, fp32 accuracy)
+            # or 1 (plain bf16) hardware multiply-adds per algorithmic one
+            if dom == "dense_bwd_weight" or (args.mlp_kernels == "f32" and not args.mlp_bf16):   # dW kernel: f32 MFMA
+                peak, terms, pipe = MFMA_F32_PEAK_TFLOPS, 1, "v_mfma_f32_32x32x2_f32"
+            else:
+                peak, terms, pipe = MFMA_BF16_PEAK_TFLOPS, (1 if args.mlp_bf16 else 6), "v_mfma_f32_32x32x16_bf16"
+            algorithmic = FLOPS[dom] * samples_per_launch / (per * 1e-3) / 1e12
+            achieved = algorithmic * terms
+            roof = {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": peak,
+                    "unit": "TFLOP/s", "frac": achieved / peak, "traffic": pmc_traffic(dom, args),
+                    "algorithmic_flops_per_sample": FLOPS[dom], "avg_launch_ms": ms / c, "matrix_pipe": pipe,
+                    "hardware_multiply_adds_per_algorithmic": terms, "algorithmic_tflops": algorithmic}
         out = {
             "metric": "train_rays_per_sec", "value": rays / dt, "unit": "rays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
