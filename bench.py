@@ -270,7 +270,8 @@ def main():
     if rank == 0:
         kern = {k: {"launches": c, "avg_ms": ms / max(c, 1)} for k, (c, ms) in prof.items()}
         dom = max(list(BYTES) + list(FLOPS), key=lambda k: prof.get(k, (0, 0.0))[1])
-        c, ms = prof[dom]
+        c, ms = prof.get(dom, (1, 1e-9))                 # degenerate runs (no sample at all) launch none of them
+        c, ms = max(c, 1), max(ms, 1e-9)
         # this rank's samples per launch of the dominant kernel (chunked calls: one launch per chunk)
         samples_per_launch = n_main / (args.steps if dom.startswith("dense") else max(c, 1))
         if dom in BYTES:
