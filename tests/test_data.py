@@ -98,3 +98,35 @@ def test_batcher_shapes_ranges_and_rank_seeding():
     assert float(b0["u_ts_diff"].min()) == 1.0 and (b0["start_ts"] < b0["end_ts"]).all()
     big = data.trunc_normal(0.0, 1.0, 200000, 0.5, 0.25, torch.float64, torch.Generator().manual_seed(0), "cpu")
     assert abs(float(big.mean()) - 0.5) < 5e-3 and 0.19 < float(big.std()) < 0.23      # truncated at 2 sigma
+
+
+def test_cli_rejects_unsupported_hyperparameters():
+    """scripts/train.py:check_supported -- every shipped reference config shape passes; alternatives the kernels do not
+    implement raise NotImplementedError instead of silently training something else."""
+    import copy, importlib.util, os
+    import pytest
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("train_cli", os.path.join(repo, "scripts", "train.py"))
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    import yaml
+    ncfg = yaml.safe_load(open(os.path.join(repo, "configs", "synthetic_smoke.yaml")))["model"]["nerf"]
+    ncfg["ngp"] = {"pos_encoding": {"otype": "HashGrid", "n_levels": 16, "n_features_per_level": 2, "interpolation": "Linear"},
+                   "dir_encoding": {"degree": 4},
+                   "mlp_base": {"hidden_activation": "softplus", "density_activation": "shifted_trunc_exp", "n_neurons": 64,
+                                "n_hidden_layers": 1, "geo_feat_dim": 15, "weight_norm": False},
+                   "mlp_head": {"hidden_activation": "softplus", "radiance_activation": "softplus", "n_neurons": 64,
+                                "n_hidden_layers": 2, "weight_norm": False}}
+    cli.check_supported(ncfg, "ngp")
+    for path, bad in ((("mlp_head", "radiance_activation"), "sigmoid"), (("mlp_base", "hidden_activation"), "relu"),
+                      (("mlp_base", "weight_norm"), True), (("pos_encoding", "interpolation"), "Smoothstep"),
+                      (("pos_encoding", "otype"), "DenseGrid")):
+        c = copy.deepcopy(ncfg)
+        c["ngp"][path[0]][path[1]] = bad
+        with pytest.raises(NotImplementedError):
+            cli.check_supported(c, "ngp")
+    ncfg["mlp"] = {"net_depth": 8, "net_width": 256, "skip_layer": 4, "hidden_activation": "softplus"}
+    cli.check_supported(ncfg, "mlp")
+    ncfg["mlp"]["net_width"] = 128
+    with pytest.raises(NotImplementedError):
+        cli.check_supported(ncfg, "mlp")
