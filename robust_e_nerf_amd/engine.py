@@ -542,9 +542,9 @@ class Trainer:
         with the event rate C/dt.  Accumulates gradients; returns (weighted loss term, aux)."""
         from . import jvp
         r, t, f = self.r, self.t, self.r.field
-        if not isinstance(f, NGPField):
-            raise NotImplementedError("the log-intensity-gradient loss (forward-mode d/dt render) is built for arch ngp only; "
-                                      "set loss.weight.log_intensity_grad to 0 for arch mlp")
+        if t.train_refractory_period and not isinstance(f, NGPField):
+            raise NotImplementedError("a trainable refractory period with the log-intensity-gradient loss needs the second-order "
+                                      "tangent render, which is built for arch ngp only")
         B = batch["position"].shape[0]
         self._refresh_contrast_threshold()
         self._refresh_tau()

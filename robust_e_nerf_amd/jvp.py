@@ -88,19 +88,24 @@ def render_forward(r, o, d, od, dd, jitter, bkgd, training: bool = True):
     if n == 0:
         colors = torch.zeros(R, f.C, device=dev) + (bkgd if bkgd is not None else 0.0)
         return colors, torch.zeros(R, f.C, device=dev), torch.zeros(R, device=dev), dict(pk=pk, empty=True, bkgd=bkgd)
-    nb = ops.n_blocks32(n)
-    feat = torch.empty(nb * 1024, device=dev)
-    featd = torch.empty(nb * 1024, device=dev)
     ri, ts, te = pk.ray_indices, pk.t_starts, pk.t_ends
-    check(lib.ren_hashgrid_fwd_jvp(ctypes.byref(f.grid), _ptr(f.table), ctypes.byref(r.scene), _ptr(o), _ptr(d),
-                                   _ptr(od), _ptr(dd), _ptr(ri), _ptr(ts), _ptr(te), n, _ptr(feat), _ptr(featd),
-                                   _stream()), "ren_hashgrid_fwd_jvp")
-    rgb, rgbd = torch.empty(n, f.C, device=dev), torch.empty(n, f.C, device=dev)
-    sigma, sigmad = torch.empty(n, device=dev), torch.empty(n, device=dev)
-    base, based = torch.empty(nb * 512, device=dev), torch.empty(nb * 512, device=dev)
-    check(lib.ren_mlp_fwd_jvp(_ptr(f.mlp), f.C, _ptr(feat), _ptr(featd), ctypes.byref(r.scene), _ptr(o), _ptr(d),
-                              _ptr(dd), _ptr(ri), _ptr(ts), _ptr(te), n, _ptr(rgb), _ptr(rgbd), _ptr(sigma),
-                              _ptr(sigmad), _ptr(base), _ptr(based), _stream()), "ren_mlp_fwd_jvp")
+    if hasattr(r, "_field_forward_jvp"):                   # arch mlp: dense layers, value + tangent (vanilla.py)
+        rgb, rgbd, sigma, sigmad, fctx = r._field_forward_jvp(o, d, od, dd, pk)
+        feat = featd = base = based = None
+    else:
+        fctx = None
+        nb = ops.n_blocks32(n)
+        feat = torch.empty(nb * 1024, device=dev)
+        featd = torch.empty(nb * 1024, device=dev)
+        check(lib.ren_hashgrid_fwd_jvp(ctypes.byref(f.grid), _ptr(f.table), ctypes.byref(r.scene), _ptr(o), _ptr(d),
+                                       _ptr(od), _ptr(dd), _ptr(ri), _ptr(ts), _ptr(te), n, _ptr(feat), _ptr(featd),
+                                       _stream()), "ren_hashgrid_fwd_jvp")
+        rgb, rgbd = torch.empty(n, f.C, device=dev), torch.empty(n, f.C, device=dev)
+        sigma, sigmad = torch.empty(n, device=dev), torch.empty(n, device=dev)
+        base, based = torch.empty(nb * 512, device=dev), torch.empty(nb * 512, device=dev)
+        check(lib.ren_mlp_fwd_jvp(_ptr(f.mlp), f.C, _ptr(feat), _ptr(featd), ctypes.byref(r.scene), _ptr(o), _ptr(d),
+                                  _ptr(dd), _ptr(ri), _ptr(ts), _ptr(te), n, _ptr(rgb), _ptr(rgbd), _ptr(sigma),
+                                  _ptr(sigmad), _ptr(base), _ptr(based), _stream()), "ren_mlp_fwd_jvp")
     colors, colords = torch.empty(R, f.C, device=dev), torch.empty(R, f.C, device=dev)
     opac, opacd = torch.empty(R, device=dev), torch.empty(R, device=dev)
     w, T, eds = (torch.empty(n, device=dev) for _ in range(3))
@@ -110,7 +115,7 @@ def render_forward(r, o, d, od, dd, jitter, bkgd, training: bool = True):
           "ren_composite_fwd_jvp")
     ctx = dict(pk=pk, o=o, d=d, od=od, dd=dd, feat=feat, featd=featd, rgb=rgb, rgbd=rgbd, sigma=sigma,
                sigmad=sigmad, base=base, based=based, w=w, T=T, eds=eds, opac=opac, opacd=opacd, bkgd=bkgd,
-               empty=False)
+               empty=False, fctx=fctx)
     return colors, colords, opac, ctx
 
 
@@ -133,6 +138,9 @@ def render_backward(r, ctx, g_colors, g_colords):
                                     _ptr(ctx["opacd"]), _ptr(g_colors.contiguous()), _ptr(g_colords.contiguous()),
                                     _ptr(d_sig), _ptr(d_sigd), _ptr(d_rgb), _ptr(d_rgbd), _ptr(d_bk), _stream()),
           "ren_composite_bwd_jvp")
+    if ctx.get("fctx") is not None:                        # arch mlp
+        r._field_backward_jvp(ctx["fctx"], pk, ctx["rgb"], ctx["sigma"], d_rgb, d_rgbd, d_sig, d_sigd)
+        return ops.column_sum(d_bk) if d_bk is not None else None
     scratch = torch.empty(nb * 5120, device=dev)
     dfeat, dfeatd = torch.empty(nb * 1024, device=dev), torch.empty(nb * 1024, device=dev)
     ws = torch.empty(int(lib.ren_mlp_bwd_jvp_workspace_floats(f.C)), device=dev)

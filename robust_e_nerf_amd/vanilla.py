@@ -218,6 +218,134 @@ class VanillaRenderer(Renderer):
                 self._bwd_data(dh[cur], WIDTH, name, WIDTH, ACT_SOFTPLUS100, X, ldx, False, dh[1 - cur], WIDTH, n)
                 cur = 1 - cur
 
+    # ---- forward-mode tangent (d/dt) through the field and its reverse pass: the log-intensity-gradient loss -----
+    # Same construction as the NGP path (csrc/ren_mlp_jvp.hip): per layer z = W a + b, zd = W ad; y = sp(z),
+    # yd = s zd with s = sp'(z) recovered from the output; backward of (dy, dyd): dz = dy s + dyd zd s', dzd = dyd s,
+    # dW += dz^T a + dzd^T ad, da = dz W, dad = dzd W.  Every GEMM is a ren_dense_* launch (value and tangent share the
+    # weights: the tangent stream is a second launch without bias); the activation algebra is elementwise torch on
+    # the same row-major buffers.
+    def _lin(self, X, ldx, name, Y, ldy, n):
+        """Y = X W^T (no bias, no activation): the tangent stream of a layer"""
+        f = self.field
+        o, i = f.w[name].shape
+        check(_lib.load().ren_dense_fwd(_ptr(X), ldx, _ptr(f.w[name]), None, o, i, ACT_NONE | (self._dense_mode() << 8), None,
+                                        _ptr(Y), ldy, n, _stream()), "ren_dense_fwd")
+
+    def _bwd_weight_nobias(self, dZ, ldz, X, ldx, name, n):
+        """dW += dZ^T X only (the tangent stream has no bias)"""
+        f = self.field
+        keep = f.gb[name].clone()
+        self._bwd_weight(dZ, ldz, X, ldx, name, n)
+        f.gb[name].copy_(keep)
+
+    def _encode_tangent(self, B, o, d, od, dd, pk):
+        """d/dt of the position and view encodings for the packed samples -> (encd (n_pad, 64), viewd (n_pad, 32))"""
+        import math
+        c = self.cfg
+        ri = pk.ray_indices.long()
+        tm = ((pk.t_starts + pk.t_ends) * 0.5)[:, None]
+        x, xd = o[ri] + tm * d[ri], od[ri] + tm * dd[ri]
+        _, ud = torch.func.jvp(lambda v: contract_points(v, c.aabb, c.contraction_type), (x,), (xd,))
+        u = contract_points(x, c.aabb, c.contraction_type)
+
+        def sin_enc_d(p, pd, deg):                                   # layout of csrc/ren_dense.hip:sin_enc
+            sc = 2.0 ** torch.arange(deg, device=p.device, dtype=torch.float32)
+            pb = (p[:, None, :] * sc[None, :, None]).reshape(p.shape[0], -1)          # (n, 3 deg): k-major, then axis
+            pbd = (pd[:, None, :] * sc[None, :, None]).reshape(p.shape[0], -1)
+            return torch.cat([pd, torch.cos(pb) * pbd, torch.cos(pb + 0.5 * math.pi) * pbd], 1)
+        encd = torch.zeros(B.n_pad, 64, device=x.device)
+        encd[: B.n, :63] = sin_enc_d(2 * math.pi * (u - 0.5), 2 * math.pi * ud, 10)
+        viewd = torch.zeros(B.n_pad, 32, device=x.device)
+        viewd[: B.n, :27] = sin_enc_d(d[ri] * math.pi, dd[ri] * math.pi, 4)
+        return encd, viewd
+
+    def _field_forward_jvp(self, o, d, od, dd, pk):
+        n, C, dev = pk.n, self.field.C, o.device
+        B = _Buffers(n, dev, C, full=True, backward=False)
+        self._encode(B, True, rays=(o, d), samples=(pk.ray_indices, pk.t_starts, pk.t_ends))
+        rgb, sigma = self._field_eval(B, True)
+        z = lambda ld: torch.empty(B.n_pad, ld, device=dev, dtype=torch.float32)
+        encd, viewd = self._encode_tangent(B, o, d, od, dd, pk)
+        catd = torch.zeros(B.n_pad, 320, device=dev)
+        catd[:, 256:320] = encd
+        T = dict(encd=encd, catd=catd, zd={}, yd={})
+        Xd, ldx = encd, 64
+        for i in range(DEPTH):
+            Y, ldy = B.out_of(i)
+            zd = z(WIDTH)
+            self._lin(Xd, ldx, f"mlp.base.hidden_layers.{i}", zd, WIDTH, n)
+            s = 1.0 - torch.exp(-100.0 * Y[:, :WIDTH])
+            yd = (catd[:, :WIDTH] if i == SKIP else z(WIDTH))
+            torch.mul(zd, s, out=yd)
+            T["zd"][i], T["yd"][i] = zd, yd
+            Xd, ldx = (catd, 320) if i == SKIP else (yd, WIDTH)
+        h7d = T["yd"][DEPTH - 1]
+        s4d = z(4)
+        self._lin(h7d, WIDTH, "mlp.sigma_layer.output_layer", s4d, 4, n)
+        dphi = torch.clamp(sigma, max=3269017.3724721107)            # trunc_exp: d/dz clamps at e^15 (ngp.py:45-65)
+        sigmad = dphi * s4d[:n, 0]
+        rind = torch.zeros(B.n_pad, 288, device=dev)
+        rind[:, 256:288] = viewd
+        self._lin(h7d, WIDTH, "mlp.bottleneck_layer.output_layer", rind, 288, n)
+        zrd = z(WIDTH_COND)
+        self._lin(rind, 288, "mlp.rgb_layer.hidden_layers.0", zrd, WIDTH_COND, n)
+        rd = zrd * (1.0 - torch.exp(-100.0 * B.r))
+        zod = z(4)
+        self._lin(rd, WIDTH_COND, "mlp.rgb_layer.output_layer", zod, 4, n)
+        rgbd = (zod[:n, :C] * (1.0 - torch.exp(-rgb))).contiguous()
+        T.update(rind=rind, zrd=zrd, rd=rd, zod=zod[:n, :C].contiguous(), zsd=s4d[:n, 0].contiguous(), buffers=B)
+        return rgb, rgbd, sigma, sigmad.contiguous(), T
+
+    def _field_backward_jvp(self, T, pk, rgb, sigma, d_rgb, d_rgbd, d_sig, d_sigd):
+        B, n, C = T["buffers"], pk.n, self.field.C
+        dev = rgb.device
+        z = lambda ld: torch.zeros(B.n_pad, ld, device=dev, dtype=torch.float32)
+
+        def act_bwd(gy, gyd, Y, Zd, beta):                           # -> (gz, gzd) of y = softplus_beta(z), yd = s zd
+            s = 1.0 - torch.exp(-beta * Y)
+            return gy * s + gyd * Zd * (beta * s * (1.0 - s)), gyd * s
+
+        # output heads
+        gz_o, gzd_o = act_bwd(d_rgb, d_rgbd, rgb, T["zod"], 1.0)
+        dz_rgb, dzd_rgb = z(32), z(32)
+        dz_rgb[:n, :C], dzd_rgb[:n, :C] = gz_o, gzd_o
+        dphi = torch.clamp(sigma, max=3269017.3724721107)
+        d2phi = torch.where(sigma < 3269017.3724721107, sigma, torch.zeros_like(sigma))
+        dz_sig, dzd_sig = z(32), z(32)
+        dz_sig[:n, 0] = d_sig * dphi + d_sigd * T["zsd"] * d2phi
+        dzd_sig[:n, 0] = d_sigd * dphi
+        h7, h7d = B.h[DEPTH - 1], T["yd"][DEPTH - 1]
+
+        def lin_bwd(gz, gzd, ldz, name, X, ldx, Xd, ldxd, n_store):  # dW (+ db from the value stream), -> (gX, gXd)
+            self._bwd_weight(gz, ldz, X, ldx, name, n)
+            self._bwd_weight_nobias(gzd, ldz, Xd, ldxd, name, n)
+            gx, gxd = z(n_store), z(n_store)
+            self._bwd_data(gz, ldz, name, n_store, ACT_NONE, None, 0, False, gx, n_store, n)
+            self._bwd_data(gzd, ldz, name, n_store, ACT_NONE, None, 0, False, gxd, n_store, n)
+            return gx, gxd
+
+        gr, grd = lin_bwd(dz_rgb, dzd_rgb, 32, "mlp.rgb_layer.output_layer", B.r, WIDTH_COND, T["rd"], WIDTH_COND, WIDTH_COND)
+        gzr, gzrd = act_bwd(gr, grd, B.r, T["zrd"], 100.0)
+        gb, gbd = lin_bwd(gzr, gzrd, WIDTH_COND, "mlp.rgb_layer.hidden_layers.0", B.rin, 288, T["rind"], 288, WIDTH)
+        g7, g7d = lin_bwd(gb, gbd, WIDTH, "mlp.bottleneck_layer.output_layer", h7, WIDTH, h7d, WIDTH, WIDTH)
+        gs, gsd = lin_bwd(dz_sig, dzd_sig, 32, "mlp.sigma_layer.output_layer", h7, WIDTH, h7d, WIDTH, WIDTH)
+        gy, gyd = g7 + gs, g7d + gsd
+        for i in range(DEPTH - 1, -1, -1):
+            name = f"mlp.base.hidden_layers.{i}"
+            Y, _ = B.out_of(i)
+            gz, gzd = act_bwd(gy, gyd, Y[:, :WIDTH], T["zd"][i], 100.0)
+            gz, gzd = gz.contiguous(), gzd.contiguous()
+            if i == 0:
+                X, ldx, Xd, ldxd = B.enc, 64, T["encd"], 64
+            else:
+                (X, ldx) = B.out_of(i - 1)
+                Xd, ldxd = (T["catd"], 320) if i - 1 == SKIP else (T["yd"][i - 1], WIDTH)
+            if i > 0:
+                gy, gyd = lin_bwd(gz, gzd, WIDTH, name, X, ldx, Xd, ldxd, WIDTH)
+            else:
+                self._bwd_weight(gz, WIDTH, X, ldx, name, n)
+                self._bwd_weight_nobias(gzd, WIDTH, Xd, ldxd, name, n)
+
     def query_density(self, x_world: torch.Tensor) -> torch.Tensor:
         """VanillaNeRFRadianceField.query_density (mlp.py:343-347) for arbitrary world points."""
         n = x_world.shape[0]

@@ -134,3 +134,49 @@ def test_dense_matrix_core_modes(amd):
     y_ref = torch.where(z * 100 > 20, z, torch.log1p(torch.exp(z * 100)) / 100)
     assert rel_err(outs[1][0], y_ref) < 1e-5
     assert rel_err(outs[1][1], (r16(outs[1][0]) @ r16(W))[:, :256]) < 1e-5
+
+
+@pytest.mark.parametrize("ct", ["aabb", "sphere"])
+def test_vanilla_field_tangent_and_its_backward_vs_float64_autograd(amd, ct):
+    """arch mlp under the log-intensity-gradient loss: d/dt of (rgb, sigma) along moving rays (forward mode through the
+    dense layers) and the parameter gradient of a functional of values AND tangents, against float64 autograd
+    (jvp by double backward, then backward again) through the oracle field."""
+    from oracle import vanilla as ovan
+    ops, engine, vanilla = amd
+    g = load_golden(f"field_mlp_{ct}")
+    r, p = _field(vanilla, engine, g)
+    gen = torch.Generator().manual_seed(11)
+    R = 300
+    o = (torch.rand(R, 3, generator=gen) - 0.5) * 1.0
+    d = torch.randn(R, 3, generator=gen); d = d / d.norm(dim=-1, keepdim=True)
+    od, dd = torch.randn(R, 3, generator=gen) * 0.3, torch.randn(R, 3, generator=gen) * 0.3
+    tm = torch.rand(R, generator=gen) * 1.2
+    pk = engine.Packed(ray_indices=torch.arange(R, dtype=torch.int32, device=DEV), t_starts=(tm - 0.01).to(DEV),
+                       t_ends=(tm + 0.01).to(DEV), offsets=torch.arange(R, device=DEV), counts=torch.ones(R, dtype=torch.int32, device=DEV),
+                       n=R)
+    dev = lambda v: v.to(DEV).contiguous()
+    rgb, rgbd, sigma, sigmad, T = r._field_forward_jvp(dev(o), dev(d), dev(od), dev(dd), pk)
+    w = [torch.randn(R, 1, generator=gen), torch.randn(R, 1, generator=gen), torch.randn(R, generator=gen), torch.randn(R, generator=gen)]
+    r.field.grad.zero_()
+    r._field_backward_jvp(T, pk, rgb, sigma, dev(w[0]), dev(w[1]), dev(w[2]), dev(w[3]))
+    torch.cuda.synchronize()
+    # float64 reference
+    p64 = {k: v.double().requires_grad_() for k, v in p.items()}
+    aabb = torch.tensor([float(v) for v in g["aabb"]], dtype=torch.float64)
+    tm64 = ((tm - 0.01).float() + (tm + 0.01).float()).double()[:, None] * 0.5
+    x0, xd = o.double() + tm64 * d.double(), od.double() + tm64 * dd.double()
+
+    def f(tt):
+        rgb_, sig_ = ovan.forward(p64, x0 + tt * xd, d.double() + tt * dd.double(), aabb, int(g["contraction_type"]))
+        return rgb_, sig_[:, 0]
+    (rgb_o, sig_o), (rgbd_o, sigd_o) = torch.autograd.functional.jvp(f, torch.zeros((), dtype=torch.float64),
+                                                                   torch.ones((), dtype=torch.float64), create_graph=True)
+    assert rel_err(rgb.cpu(), rgb_o.detach()) < 2e-5 and rel_err(sigma.cpu(), sig_o.detach()) < 2e-5
+    # float32 through the 2^9 x 2 pi frequency band: the tangent carries that amplification of the position round-off
+    assert rel_err(rgbd.cpu(), rgbd_o.detach()) < 5e-4, "d rgb / dt"
+    assert rel_err(sigmad.cpu(), sigd_o.detach()) < 5e-4, "d sigma / dt"
+    L = (w[0].double() * rgb_o).sum() + (w[1].double() * rgbd_o).sum() + (w[2].double() * sig_o).sum() + (w[3].double() * sigd_o).sum()
+    grads = torch.autograd.grad(L, list(p64.values()))
+    ref = dict(zip(p64.keys(), grads))
+    for k, v in r.field.state_dict(grad=True).items():
+        assert rel_err(v.cpu(), ref[k]) < 3e-3, k

@@ -158,8 +158,6 @@ def main():
     cfg = yaml.safe_load(open(os.path.join(REPO, "configs", "synthetic_smoke.yaml")))
     cfg["data"].update(dataset_directory=data_dir, train_init_eff_batch_size=65536 if args.arch == "ngp" else 2048, train_eff_ray_sample_batch_size=args.budget)
     cfg["model"]["nerf"]["arch"] = args.arch
-    if args.arch == "mlp":
-        cfg["loss"]["weight"]["log_intensity_grad"] = 0.0          # l_grad is built for arch ngp only
     cfg["trainer"].update(max_epochs=args.epochs, limit_train_batches=args.steps_per_epoch, log_every_n_steps=100)
     cfg["lr_scheduler"]["multi_step_lr"]["milestones"] = [max(1, args.epochs // 2), max(2, 3 * args.epochs // 4), max(3, 9 * args.epochs // 10)]
     cfg_path = os.path.join(args.out, "train.yaml")
