@@ -458,6 +458,14 @@ int ren_dense_bwd_data(const float *dZ, int32_t ldz, const float *W, int32_t n_o
                        int32_t prev_act, const float *Yprev, int32_t ldyp, int32_t accumulate, float *dX,
                        int32_t ldx, int64_t n, void *stream);
 /* grad_w[n_out][n_in] += dZ^T X, grad_b[n_out] += column sums of dZ (slab-reduced, deterministic) */
+/* Activation algebra of the tangent stream of a dense layer (log-intensity-gradient loss with arch mlp): y = softplus_beta(z),
+ * yd = s zd with s = 1 - exp(-beta y) taken from the output.  fwd: Yd = s Zd.  bwd: gz = gy s + gyd zd beta s (1 - s),
+ * gzd = gyd s.  Row-major buffers; Y (and Yd in fwd) may be column ranges of wider buffers (ld), the others are dense
+ * [rows][width]; width and every ld are multiples of 4. */
+int ren_act_jvp_fwd(const float *Y, int32_t ldy, const float *Zd, int32_t ldz, float beta, float *Yd, int32_t ldyd,
+                    int64_t rows, int32_t width, void *stream);
+int ren_act_jvp_bwd(const float *gy, const float *gyd, const float *Y, int32_t ldy, const float *Zd, float beta, float *gz,
+                    float *gzd, int64_t rows, int32_t width, void *stream);
 int64_t ren_dense_bwd_weight_workspace_floats(int32_t n_out, int32_t n_in, int32_t n_splits);
 int ren_dense_bwd_weight(const float *dZ, int32_t ldz, const float *X, int32_t ldx, int32_t n_out, int32_t n_in,
                          int64_t n, int32_t n_splits, float *grad_w, float *grad_b, float *workspace,

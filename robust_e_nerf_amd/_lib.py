@@ -58,6 +58,8 @@ SIGNATURES = {
     "ren_mlp_fwd_save": (c_int, [P, c_int32, c_int32, P, POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, P, P, P, P, P]),
     "ren_mlp_bwd_saved": (c_int, [P, c_int32, c_int32, P, P, P, POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, P, P, P,
                                   P, P, P, P, P]),
+    "ren_act_jvp_fwd": (c_int, [P, c_int32, P, c_int32, c_float, P, c_int32, c_int64, c_int32, P]),
+    "ren_act_jvp_bwd": (c_int, [P, P, P, c_int32, P, c_float, P, P, c_int64, c_int32, P]),
     "ren_event_prepare": (c_int, [P, P, P, P, P, P, P, c_int64, c_float, c_float, c_double, P, P, P, P, P, P, P, P, P]),
     "ren_event_param_grad": (c_int, [c_int32, c_int32, c_int32, P, P, P, P, P, P, P, c_int64, c_float, c_float, c_float,
                                      c_double, c_float, P, P, P]),

@@ -496,6 +496,48 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const float *__restrict_
     for (int j = 1; j < 8; ++j) { zr[j] = make_float4(0.f, 0.f, 0.f, 0.f); zs[j] = make_float4(0.f, 0.f, 0.f, 0.f); }
 }
 
+// ---- activation algebra of the tangent stream (log-intensity-gradient loss, arch mlp) ---------------------------
+// forward:  yd = s zd,  s = softplus_beta'(z) = 1 - exp(-beta y) recovered from the output y
+// backward: gz = gy s + gyd zd s',  gzd = gyd s,  s' = beta s (1 - s)
+// Row-major [rows][ld] buffers (the value outputs may be column ranges of a wider buffer), float4 per thread.
+__global__ __launch_bounds__(256) void act_jvp_fwd_kernel(const float *__restrict__ Y, int ldy, const float *__restrict__ Zd,
+                                                          int ldz, float beta, float *__restrict__ Yd, int ldyd,
+                                                          int64_t rows, int width4) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= rows * width4) return;
+    const int64_t r = e / width4;
+    const int c = (int)(e - r * width4) * 4;
+    const float4 y = *reinterpret_cast<const float4 *>(Y + r * ldy + c), zd = *reinterpret_cast<const float4 *>(Zd + r * ldz + c);
+    float4 o;
+    o.x = zd.x * dsoftplus_from_out(y.x, beta); o.y = zd.y * dsoftplus_from_out(y.y, beta);
+    o.z = zd.z * dsoftplus_from_out(y.z, beta); o.w = zd.w * dsoftplus_from_out(y.w, beta);
+    *reinterpret_cast<float4 *>(Yd + r * ldyd + c) = o;
+}
+
+__global__ __launch_bounds__(256) void act_jvp_bwd_kernel(const float *__restrict__ Gy, const float *__restrict__ Gyd,
+                                                          const float *__restrict__ Y, int ldy, const float *__restrict__ Zd,
+                                                          float beta, float *__restrict__ Gz, float *__restrict__ Gzd,
+                                                          int64_t rows, int width4) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= rows * width4) return;
+    const int64_t r = e / width4;
+    const int c = (int)(e - r * width4) * 4, w = width4 * 4;
+    const float4 y4 = *reinterpret_cast<const float4 *>(Y + r * ldy + c);
+    const float4 gy4 = *reinterpret_cast<const float4 *>(Gy + r * w + c), gd4 = *reinterpret_cast<const float4 *>(Gyd + r * w + c);
+    const float4 zd4 = *reinterpret_cast<const float4 *>(Zd + r * w + c);
+    const float y[4] = {y4.x, y4.y, y4.z, y4.w}, gy[4] = {gy4.x, gy4.y, gy4.z, gy4.w}, gd[4] = {gd4.x, gd4.y, gd4.z, gd4.w},
+                zd[4] = {zd4.x, zd4.y, zd4.z, zd4.w};
+    float gz[4], gzd[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float sj = dsoftplus_from_out(y[j], beta);
+        gz[j] = gy[j] * sj + gd[j] * zd[j] * (beta * sj * (1.f - sj));
+        gzd[j] = gd[j] * sj;
+    }
+    *reinterpret_cast<float4 *>(Gz + r * w + c) = make_float4(gz[0], gz[1], gz[2], gz[3]);
+    *reinterpret_cast<float4 *>(Gzd + r * w + c) = make_float4(gzd[0], gzd[1], gzd[2], gzd[3]);
+}
+
 template <bool BWD>
 int launch_dense(DenseArgs a, int tiles, int mode, hipStream_t st) {
     if (tiles == 8) {                                   // two launches of 4 tiles: see DenseArgs::out0
@@ -588,6 +630,27 @@ extern "C" int ren_dense_bwd_data(const float *dZ, int32_t ldz, const float *W, 
     a.X = dZ; a.ldx = ldz; a.W = W; a.w_rows = n_out; a.w_cols = n_in; a.red = n_out; a.n_out = n_store;
     a.act = prev_act; a.Yprev = Yprev; a.ldyp = ldyp; a.accumulate = accumulate; a.Y = dX; a.ldy = ldx; a.n = n;
     return launch_dense<true>(a, tiles, mode, (hipStream_t)stream);
+}
+
+extern "C" int ren_act_jvp_fwd(const float *Y, int32_t ldy, const float *Zd, int32_t ldz, float beta, float *Yd, int32_t ldyd,
+                               int64_t rows, int32_t width, void *stream) {
+    if (!Y || !Zd || !Yd || rows < 0 || width < 4 || (width & 3) || (ldy & 3) || (ldz & 3) || (ldyd & 3) || ldy < width ||
+        ldz < width || ldyd < width)
+        return REN_ERR_BAD_ARG;
+    if (rows == 0) return REN_OK;
+    hipLaunchKernelGGL(act_jvp_fwd_kernel, dim3(ren_blocks(rows * (width / 4), 256)), dim3(256), 0, (hipStream_t)stream, Y, ldy,
+                       Zd, ldz, beta, Yd, ldyd, rows, width / 4);
+    REN_CHECK_LAUNCH();
+}
+
+extern "C" int ren_act_jvp_bwd(const float *gy, const float *gyd, const float *Y, int32_t ldy, const float *Zd, float beta,
+                               float *gz, float *gzd, int64_t rows, int32_t width, void *stream) {
+    if (!gy || !gyd || !Y || !Zd || !gz || !gzd || rows < 0 || width < 4 || (width & 3) || (ldy & 3) || ldy < width)
+        return REN_ERR_BAD_ARG;
+    if (rows == 0) return REN_OK;
+    hipLaunchKernelGGL(act_jvp_bwd_kernel, dim3(ren_blocks(rows * (width / 4), 256)), dim3(256), 0, (hipStream_t)stream, gy, gyd,
+                       Y, ldy, Zd, beta, gz, gzd, rows, width / 4);
+    REN_CHECK_LAUNCH();
 }
 
 extern "C" int64_t ren_dense_bwd_weight_workspace_floats(int32_t n_out, int32_t n_in, int32_t n_splits) {

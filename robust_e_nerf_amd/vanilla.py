@@ -231,6 +231,16 @@ class VanillaRenderer(Renderer):
         check(_lib.load().ren_dense_fwd(_ptr(X), ldx, _ptr(f.w[name]), None, o, i, ACT_NONE | (self._dense_mode() << 8), None,
                                         _ptr(Y), ldy, n, _stream()), "ren_dense_fwd")
 
+    def _act_fwd(self, Y, ldy, Zd, beta, Yd, ldyd, width, rows):
+        check(_lib.load().ren_act_jvp_fwd(_ptr(Y), ldy, _ptr(Zd), width, ctypes.c_float(beta), _ptr(Yd), ldyd, rows, width,
+                                          _stream()), "ren_act_jvp_fwd")
+
+    def _act_bwd(self, gy, gyd, Y, ldy, Zd, beta, width, rows):
+        gz, gzd = torch.empty_like(gy), torch.empty_like(gyd)
+        check(_lib.load().ren_act_jvp_bwd(_ptr(gy), _ptr(gyd), _ptr(Y), ldy, _ptr(Zd), ctypes.c_float(beta), _ptr(gz), _ptr(gzd),
+                                          rows, width, _stream()), "ren_act_jvp_bwd")
+        return gz, gzd
+
     def _bwd_weight_nobias(self, dZ, ldz, X, ldx, name, n):
         """dW += dZ^T X only (the tangent stream has no bias)"""
         f = self.field
@@ -274,9 +284,8 @@ class VanillaRenderer(Renderer):
             Y, ldy = B.out_of(i)
             zd = z(WIDTH)
             self._lin(Xd, ldx, f"mlp.base.hidden_layers.{i}", zd, WIDTH, n)
-            s = 1.0 - torch.exp(-100.0 * Y[:, :WIDTH])
-            yd = (catd[:, :WIDTH] if i == SKIP else z(WIDTH))
-            torch.mul(zd, s, out=yd)
+            yd, ldyd = (catd, 320) if i == SKIP else (z(WIDTH), WIDTH)
+            self._act_fwd(Y, ldy, zd, 100.0, yd, ldyd, WIDTH, B.n_pad)
             T["zd"][i], T["yd"][i] = zd, yd
             Xd, ldx = (catd, 320) if i == SKIP else (yd, WIDTH)
         h7d = T["yd"][DEPTH - 1]
@@ -289,7 +298,8 @@ class VanillaRenderer(Renderer):
         self._lin(h7d, WIDTH, "mlp.bottleneck_layer.output_layer", rind, 288, n)
         zrd = z(WIDTH_COND)
         self._lin(rind, 288, "mlp.rgb_layer.hidden_layers.0", zrd, WIDTH_COND, n)
-        rd = zrd * (1.0 - torch.exp(-100.0 * B.r))
+        rd = z(WIDTH_COND)
+        self._act_fwd(B.r, WIDTH_COND, zrd, 100.0, rd, WIDTH_COND, WIDTH_COND, B.n_pad)
         zod = z(4)
         self._lin(rd, WIDTH_COND, "mlp.rgb_layer.output_layer", zod, 4, n)
         rgbd = (zod[:n, :C] * (1.0 - torch.exp(-rgb))).contiguous()
@@ -325,16 +335,15 @@ class VanillaRenderer(Renderer):
             return gx, gxd
 
         gr, grd = lin_bwd(dz_rgb, dzd_rgb, 32, "mlp.rgb_layer.output_layer", B.r, WIDTH_COND, T["rd"], WIDTH_COND, WIDTH_COND)
-        gzr, gzrd = act_bwd(gr, grd, B.r, T["zrd"], 100.0)
+        gzr, gzrd = self._act_bwd(gr, grd, B.r, WIDTH_COND, T["zrd"], 100.0, WIDTH_COND, B.n_pad)
         gb, gbd = lin_bwd(gzr, gzrd, WIDTH_COND, "mlp.rgb_layer.hidden_layers.0", B.rin, 288, T["rind"], 288, WIDTH)
         g7, g7d = lin_bwd(gb, gbd, WIDTH, "mlp.bottleneck_layer.output_layer", h7, WIDTH, h7d, WIDTH, WIDTH)
         gs, gsd = lin_bwd(dz_sig, dzd_sig, 32, "mlp.sigma_layer.output_layer", h7, WIDTH, h7d, WIDTH, WIDTH)
         gy, gyd = g7 + gs, g7d + gsd
         for i in range(DEPTH - 1, -1, -1):
             name = f"mlp.base.hidden_layers.{i}"
-            Y, _ = B.out_of(i)
-            gz, gzd = act_bwd(gy, gyd, Y[:, :WIDTH], T["zd"][i], 100.0)
-            gz, gzd = gz.contiguous(), gzd.contiguous()
+            Y, ldy = B.out_of(i)
+            gz, gzd = self._act_bwd(gy, gyd, Y, ldy, T["zd"][i], 100.0, WIDTH, B.n_pad)
             if i == 0:
                 X, ldx, Xd, ldxd = B.enc, 64, T["encd"], 64
             else:
