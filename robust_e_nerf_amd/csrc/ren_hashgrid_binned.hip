@@ -318,6 +318,7 @@ __global__ __launch_bounds__(SC_THREADS) void bin_scatter_kernel(GridDev g, BinT
     __shared__ uint32_t st_key[SC_ENTRIES];
     __shared__ float2 st_v[SC_ENTRIES];
     __shared__ float wave_max[SC_THREADS / 64];
+    __shared__ int any_overflow;
     const int group = blockIdx.x % LEVEL_GROUPS;
     const int64_t chunk = blockIdx.x / LEVEL_GROUPS;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -328,6 +329,7 @@ __global__ __launch_bounds__(SC_THREADS) void bin_scatter_kernel(GridDev g, BinT
 #pragma unroll 1
     for (int lvl = group; lvl < g.n_levels; lvl += LEVEL_GROUPS) {
         if (tid < MAX_BINS_PER_LEVEL) hist[tid] = 0;
+        if (tid == 0) any_overflow = 0;
         lds_barrier();                                           // also: previous level's append is done
         const uint32_t res = g.res[lvl], size = g.size[lvl];
         const bool hashed = g.hashed[lvl] != 0;
@@ -403,6 +405,7 @@ __global__ __launch_bounds__(SC_THREADS) void bin_scatter_kernel(GridDev g, BinT
                 base = ws.bin_start[gb] + at;
             }
             fit[tid] = room;                                           // entries of this run that fit the region
+            if (room < cnt) any_overflow = 1;
             gdelta[tid] = base - (inc - cnt);
         }
         lds_barrier();
@@ -417,6 +420,15 @@ __global__ __launch_bounds__(SC_THREADS) void bin_scatter_kernel(GridDev g, BinT
         }
         lds_barrier();
         const uint32_t total = loc[MAX_BINS_PER_LEVEL];
+        if (!any_overflow) {                                       // the usual case: every run fits its region
+            for (uint32_t q = tid; q < total; q += SC_THREADS) {
+                const uint32_t idx = st_key[q];
+                const uint64_t gp = gdelta[idx >> BIN_SHIFT] + q;
+                ws.out_idx[gp] = (uint16_t)(idx & (BIN_ENTRIES - 1));
+                ws.out_v[gp] = st_v[q];
+            }
+            continue;
+        }
         for (uint32_t q = tid; q < total; q += SC_THREADS) {
             const uint32_t idx = st_key[q], b = idx >> BIN_SHIFT;
             const float2 v = st_v[q];
