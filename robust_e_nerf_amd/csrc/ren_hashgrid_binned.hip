@@ -357,10 +357,17 @@ __global__ __launch_bounds__(SC_THREADS) void bin_scatter_kernel(GridDev g, BinT
         bool head;
         const bool have = run_tail(!hashed, valid, cell_key(p), lane, head);
         if (!hashed) run_merge(head, lane, v0, v1);
+        // upper bound of |update| in this level (scale of the fixed-point sums): interpolation weights are <= 1 and a
+        // merged run adds at most 8 lanes, so 8 max|d feature| bounds every update (3 of the 38 bits); with tangents
+        // the updates carry the scale * |ud| terms as well, so take them as they are
         float vmax = 0.f;
-        if (have) {
+        if (TAN) {
+            if (have) {
 #pragma unroll
-            for (int c = 0; c < 8; ++c) vmax = fmaxf(vmax, fmaxf(fabsf(v0[c]), fabsf(v1[c])));
+                for (int c = 0; c < 8; ++c) vmax = fmaxf(vmax, fmaxf(fabsf(v0[c]), fabsf(v1[c])));
+            }
+        } else if (valid) {
+            vmax = fmaxf(fabsf(d0), fabsf(d1)) * (hashed ? 1.f : 8.f);
         }
         {
             uint32_t idx[8];
