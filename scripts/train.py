@@ -225,7 +225,8 @@ def main():
                 torch.cuda.synchronize()
                 dt = time.perf_counter() - t0
                 print(f"epoch {epoch} step {step}  loss {float(loss):.5f}  batch {B}  samples/ray {aux['n'] / max(aux['rays'], 1):.1f}"
-                      f"  {rays * world / dt / 1e6:.2f} M rays/s", flush=True)
+                      f"  {rays * world / dt / 1e6:.2f} M rays/s  mem {torch.cuda.memory_allocated() / 2**30:.1f}/"
+                      f"{torch.cuda.memory_reserved() / 2**30:.1f} GiB", flush=True)
                 t0, rays = time.perf_counter(), 0
         if rank == 0:
             sd = field_state_dict(fld, arch)
