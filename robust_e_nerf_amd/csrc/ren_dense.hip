@@ -410,6 +410,126 @@ __global__ __launch_bounds__(512, 1) void dense_dw_kernel(DwArgs a) {
     }
 }
 
+// ---- weight gradient on the bf16 matrix cores -------------------------------------------------------------------
+// dW = dZ^T X with the SAMPLES as the reduction: both MFMA operands need 8 consecutive samples per lane, i.e. the
+// transposes of the row-major [sample][feature] tiles.  The stage loader does the transposition while it splits:
+// thread (sample s = tid & 31, feature group tid >> 5) loads 16 consecutive features of its sample row and writes
+// them as bf16 pieces to [piece][feature][sample] (lanes of a wave vary s: consecutive 2-byte addresses, conflict
+// free), so both operands are read back as one ds_read_b128.  Two pieces / three MFMAs per product pair (as the
+// weight gradients of ren_mlp_x.hip: a sum over ~1e6 samples is noisier than 2^-16 per product), i.e. 48 bf16 MFMAs
+// (1 536 matrix-pipe cycles) per wave and 32-sample stage against 128 f32 MFMAs (8 192).  The bias gradient is an
+// fp32 side sum of the loader's own values.
+constexpr int DWX_ST = 40;                               // [feature][32 samples + 8 pad] bf16: 80-byte rows
+constexpr int DWX_NP = 2;
+
+__global__ __launch_bounds__(512, 1) void dense_dw_x_kernel(DwArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_dw[];    // ZT | XT: [NP][256][DWX_ST] bf16 each
+    __bf16 *ZT = reinterpret_cast<__bf16 *>(smem_dw), *XT = ZT + DWX_NP * 256 * DWX_ST;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hi = lane >> 5, sl = lane & 31;
+    const int ls = threadIdx.x & 31, fg = threadIdx.x >> 5;                   // loader: sample row, 16-feature group
+    const int n_splits = gridDim.x;
+    const int64_t n_blk = (a.n + 31) >> 5;
+    const int k_tiles = (a.K + 31) >> 5, n_tiles = (a.N + 31) >> 5;
+    const bool has_tile = wave < n_tiles;
+    float *sw = a.slab_w + (int64_t)blockIdx.x * a.N * a.K, *sb = a.slab_b + (int64_t)blockIdx.x * a.N;
+    for (int kg = 0; kg * 8 < k_tiles; ++kg) {
+        const int kt = min(8, k_tiles - kg * 8);
+        f32x16 acc[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[t][g] = 0.f;
+        float bsum[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) bsum[q] = 0.f;
+        float4 pz[4], px[4];
+        auto fetch = [&](int64_t blk) {
+            const int64_t row = blk * 32 + ls;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = fg * 16 + 4 * j;
+                pz[j] = (row < a.n && c < a.ldz && c < ((a.N + 3) & ~3))
+                            ? *reinterpret_cast<const float4 *>(a.dZ + row * a.ldz + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const int cx = kg * 256 + c;
+                px[j] = (row < a.n && cx < a.ldx && c < kt * 32)
+                            ? *reinterpret_cast<const float4 *>(a.X + row * a.ldx + cx) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        auto stash = [&]() {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float z[4] = {pz[j].x, pz[j].y, pz[j].z, pz[j].w}, x[4] = {px[j].x, px[j].y, px[j].z, px[j].w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int f = fg * 16 + 4 * j + q;
+                    __bf16 tz[3], tx[3];
+                    split<DWX_NP>(z[q], tz);
+                    split<DWX_NP>(x[q], tx);
+#pragma unroll
+                    for (int p = 0; p < DWX_NP; ++p) {
+                        ZT[(p * 256 + f) * DWX_ST + ls] = tz[p];
+                        XT[(p * 256 + f) * DWX_ST + ls] = tx[p];
+                    }
+                    bsum[4 * j + q] += z[q];
+                }
+            }
+        };
+        int64_t blk = blockIdx.x;
+        if (blk < n_blk) fetch(blk);
+        for (; blk < n_blk; blk += n_splits) {
+            __syncthreads();                                       // previous stage's readers are done
+            stash();
+            __syncthreads();
+            const int64_t nxt = blk + n_splits;
+            if (nxt < n_blk) fetch(nxt);
+            if (has_tile) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    bf16x8 az[DWX_NP];
+#pragma unroll
+                    for (int p = 0; p < DWX_NP; ++p)
+                        az[p] = *reinterpret_cast<const bf16x8 *>(ZT + (p * 256 + wave * 32 + sl) * DWX_ST + 16 * ks + 8 * hi);
+#pragma unroll
+                    for (int t = 0; t < 8; ++t)
+                        if (t < kt) {                              // wave-uniform
+                            bf16x8 bx[DWX_NP];
+#pragma unroll
+                            for (int p = 0; p < DWX_NP; ++p)
+                                bx[p] = *reinterpret_cast<const bf16x8 *>(XT + (p * 256 + t * 32 + sl) * DWX_ST + 16 * ks + 8 * hi);
+                            acc[t] = MFMAB(az[1], bx[0], acc[t]);
+                            acc[t] = MFMAB(az[0], bx[1], acc[t]);
+                            acc[t] = MFMAB(az[0], bx[0], acc[t]);
+                        }
+                }
+            }
+        }
+        if (has_tile) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int k = (kg * 8 + t) * 32 + sl;
+                if (t >= kt || k >= a.K) continue;
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int o = wave * 32 + rowc(g) + 4 * hi;
+                    if (o < a.N) sw[(int64_t)o * a.K + k] = acc[t][g];
+                }
+            }
+        }
+        if (kg == 0) {                                             // bias: sum over the 32 sample lanes of the loader
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                float v = bsum[q];
+#pragma unroll
+                for (int off = 1; off < 32; off <<= 1) v += __shfl_xor(v, off, 64);
+                const int neuron = fg * 16 + q;
+                if (ls == 0 && neuron < a.N) sb[neuron] = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ---- frequency encodings (SinusoidalEncoder, mlp.py:208-243) ---------------------------------------------------
 struct EncArgs {
     SampleSrc src;
@@ -661,6 +781,8 @@ extern "C" int64_t ren_dense_bwd_weight_workspace_floats(int32_t n_out, int32_t 
 extern "C" int ren_dense_bwd_weight(const float *dZ, int32_t ldz, const float *X, int32_t ldx, int32_t n_out,
                                     int32_t n_in, int64_t n, int32_t n_splits, float *grad_w, float *grad_b,
                                     float *workspace, void *stream) {
+    const int mode = (n_splits >> 16) & 0xff;                                  // REN_DENSE_* >> 8 in bits 16..23
+    n_splits &= 0xffff;
     if (!dZ || !X || !grad_w || !grad_b || !workspace || n < 0 || n_out < 1 || n_in < 1 || n_splits < 1)
         return REN_ERR_BAD_ARG;
     if (ldx < ((n_in + 31) / 32) * 32 || ldz < n_out || (ldx & 3) || (ldz & 3) || n_out > 256) return REN_ERR_BAD_ARG;
@@ -669,9 +791,15 @@ extern "C" int ren_dense_bwd_weight(const float *dZ, int32_t ldz, const float *X
     a.dZ = dZ; a.ldz = ldz; a.N = n_out; a.X = X; a.ldx = ldx; a.K = n_in; a.n = n;
     a.slab_w = workspace; a.slab_b = workspace + (int64_t)n_splits * n_out * n_in;
     hipStream_t st = (hipStream_t)stream;
-    const size_t lds = 2 * 2 * 32 * 256 * sizeof(float);                       // 128 KiB: one workgroup per CU
-    (void)hipFuncSetAttribute((const void *)dense_dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(dense_dw_kernel, dim3(n_splits), dim3(512), lds, st, a);
+    if (mode != 0) {                                                           // bf16 matrix cores (split, 2 pieces)
+        const size_t lds = 2 * (size_t)DWX_NP * 256 * DWX_ST * 2;              // 80 KiB
+        (void)hipFuncSetAttribute((const void *)dense_dw_x_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(dense_dw_x_kernel, dim3(n_splits), dim3(512), lds, st, a);
+    } else {
+        const size_t lds = 2 * 2 * 32 * 256 * sizeof(float);                   // 128 KiB: one workgroup per CU
+        (void)hipFuncSetAttribute((const void *)dense_dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(dense_dw_kernel, dim3(n_splits), dim3(512), lds, st, a);
+    }
     const int len_w = n_out * n_in;
     launch_reduce_slabs(a.slab_w, n_splits, len_w, grad_w, st);
     launch_reduce_slabs(a.slab_b, n_splits, n_out, grad_b, st);

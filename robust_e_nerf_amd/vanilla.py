@@ -142,7 +142,7 @@ class VanillaRenderer(Renderer):
         if self._dw_ws is None or self._dw_ws.numel() < need:
             self._dw_ws = None
             self._dw_ws = torch.empty(need, device=dZ.device, dtype=torch.float32)
-        check(lib.ren_dense_bwd_weight(_ptr(dZ), ldz, _ptr(X), ldx, o, i, n, splits, _ptr(f.gw[name]), _ptr(f.gb[name]),
+        check(lib.ren_dense_bwd_weight(_ptr(dZ), ldz, _ptr(X), ldx, o, i, n, splits | (self._dense_mode() << 16), _ptr(f.gw[name]), _ptr(f.gb[name]),
                                        _ptr(self._dw_ws), _stream()), "ren_dense_bwd_weight")
 
     def _encode(self, B: _Buffers, full: bool, *, rays=None, samples=None, x_world=None, dirs=None):

@@ -134,6 +134,19 @@ def test_dense_matrix_core_modes(amd):
     y_ref = torch.where(z * 100 > 20, z, torch.log1p(torch.exp(z * 100)) / 100)
     assert rel_err(outs[1][0], y_ref) < 1e-5
     assert rel_err(outs[1][1], (r16(outs[1][0]) @ r16(W))[:, :256]) < 1e-5
+    # weight / bias gradient: bf16 matrix cores (two pieces, three MFMAs per product pair) vs the exact f32 kernel
+    dZ = torch.zeros(1024, ldy)
+    dZ[:n] = torch.randn(n, n_out, generator=gen)
+    dZd = dZ.to(DEV)
+    grads = {}
+    for mode in (0, 6):
+        gw, gb = torch.zeros(n_out, n_in, device=DEV), torch.zeros(n_out, device=DEV)
+        ws = torch.empty(int(lib.ren_dense_bwd_weight_workspace_floats(n_out, n_in, 32)), device=DEV)
+        assert lib.ren_dense_bwd_weight(P(dZd), ldy, P(Xd), ldx, n_out, n_in, n, 32 | (mode << 16), P(gw), P(gb), P(ws), st()) == 0
+        grads[mode] = (gw.cpu(), gb.cpu())
+    ref_w, ref_b = dZ[:n].double().T @ X[:n, :n_in].double(), dZ[:n].double().sum(0)
+    assert rel_err(grads[0][0], ref_w) < 1e-5 and rel_err(grads[0][1], ref_b) < 1e-5
+    assert rel_err(grads[6][0], ref_w) < 3e-5 and rel_err(grads[6][1], ref_b) < 1e-5
 
 
 @pytest.mark.parametrize("ct", ["aabb", "sphere"])
