@@ -23,6 +23,7 @@ struct DenseArgs {
     const float *X; int ldx;                           // [n_pad][ldx]: B operand rows (inputs, or dZ for backward-data)
     const float *W; int w_rows, w_cols;                // torch nn.Linear weight [w_rows][w_cols]
     int red;                                           // reduction length: w_cols (forward) / w_rows (backward)
+    int groups;                                        // output groups of 128 interleaved over blockIdx.x (1 or 2)
     int out0;                                          // first output feature of this launch (wide layers run as two
                                                        // 128-output launches: 64 accumulator registers, two waves/SIMD)
     int n_out;                                         // outputs stored (absolute bound)
@@ -123,11 +124,15 @@ __device__ __forceinline__ void dense_epilogue(const DenseArgs &a, f32x16 (&acc)
 
 template <int NT, bool BWD>
 __global__ __launch_bounds__(256, 2) void dense_kernel(DenseArgs a) {
+    // wide layers: the two 128-output halves of one 128-sample block are neighbouring workgroups, so the second
+    // one finds the activation rows in L2 instead of re-reading them from HBM a whole pass later
+    const int grp = a.groups > 1 ? (int)(blockIdx.x % a.groups) : 0;
+    a.out0 += grp * 128;
     extern __shared__ __attribute__((aligned(16))) float lds[];        // 2 x [NT*32][33]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int hi = lane >> 5, sl = lane & 31;
     const int64_t n_blk = (a.n + 31) >> 5;
-    const int64_t blk = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t blk = (int64_t)(blockIdx.x / (a.groups > 1 ? a.groups : 1)) * 4 + wave;
     const bool active = blk < n_blk;
     const int64_t row = blk * 32 + sl;
     const int n_chunks = (a.red + KC - 1) / KC;
@@ -240,6 +245,10 @@ __device__ __forceinline__ void store_chunk_x(__bf16 *buf, const float (&pre)[NT
 
 template <int NT, bool BWD, int MODE>
 __global__ __launch_bounds__(256, 2) void dense_x_kernel(DenseArgs a) {
+    // wide layers: the two 128-output halves of one 128-sample block are neighbouring workgroups, so the second
+    // one finds the activation rows in L2 instead of re-reading them from HBM a whole pass later
+    const int grp = a.groups > 1 ? (int)(blockIdx.x % a.groups) : 0;
+    a.out0 += grp * 128;
     using PR = Pairs<MODE>;
     constexpr int NP = PR::NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_x[];   // 2 x [NP][NT*32][XST] bf16
@@ -247,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void dense_x_kernel(DenseArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int hi = lane >> 5, sl = lane & 31;
     const int64_t n_blk = (a.n + 31) >> 5;
-    const int64_t blk = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t blk = (int64_t)(blockIdx.x / (a.groups > 1 ? a.groups : 1)) * 4 + wave;
     const bool active = blk < n_blk;
     const int64_t row = blk * 32 + sl;
     const int n_chunks = (a.red + KC - 1) / KC;
@@ -660,15 +669,14 @@ __global__ __launch_bounds__(256) void act_jvp_bwd_kernel(const float *__restric
 
 template <bool BWD>
 int launch_dense(DenseArgs a, int tiles, int mode, hipStream_t st) {
-    if (tiles == 8) {                                   // two launches of 4 tiles: see DenseArgs::out0
+    a.groups = 1;
+    if (tiles == 8) {                                   // 256 outputs = two interleaved groups of 4 tiles (DenseArgs::out0)
+        a.groups = 2;
         a.out0 = 0;
-        int rc = launch_dense<BWD>(a, 4, mode, st);
-        if (rc != REN_OK) return rc;
-        a.out0 = 128;
-        return launch_dense<BWD>(a, 4, mode, st);
+        tiles = 4;
     }
     const int64_t n_blk = (a.n + 31) / 32;
-    const dim3 grd((unsigned)((n_blk + 3) / 4)), blk(256);
+    const dim3 grd((unsigned)((n_blk + 3) / 4 * a.groups)), blk(256);
 #define REN_DENSE_LAUNCH(KERNEL, LDS)                                                                        \
     do {                                                                                                     \
         const size_t lds = (LDS);                                                                            \
