@@ -84,7 +84,7 @@ struct FwdJArgs {
 };
 
 template <int C>
-__global__ __launch_bounds__(256, 1) void mlp_fwd_jvp_kernel(FwdJArgs a) {
+__global__ __launch_bounds__(256, 2) void mlp_fwd_jvp_kernel(FwdJArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds_base[];
     fill_base(lds_base, a.params, L_W1, L_W2, L_B1, L_B2);
     fill_head(lds_base, a.params, C, L_WH1, L_WH2, L_WH3, L_BH1, L_BH2, L_BH3);
@@ -236,6 +236,7 @@ __device__ __forceinline__ void dw_64x32(f32x16 (&acc)[2], const float *Tz, cons
 }
 
 constexpr int GRID_J = 256;                       // persistent workgroups of the jvp backward kernels
+constexpr int GRID_J1 = 512;                      // head1 fits 256 registers: two workgroups per CU hide its waits
 constexpr int LEN_H2 = 64 * 64 + 64;              // head.w1 | head.b1  (+ 65 C for head.wo | head.bo)
 constexpr int LEN_H1 = 64 * 31 + 64;              // head.w0 | head.b0
 __host__ __device__ constexpr int len_h2(int C) { return LEN_H2 + 65 * C; }
@@ -439,7 +440,7 @@ struct BwdJ1Args {
     float *d_base, *d_based, *slab;
 };
 
-__global__ __launch_bounds__(256, 1) void mlp_bwd_jvp_head1_kernel(BwdJ1Args a) {
+__global__ __launch_bounds__(256, 2) void mlp_bwd_jvp_head1_kernel(BwdJ1Args a) {
     extern __shared__ __attribute__((aligned(16))) float lds_base[];
     fill_head(lds_base, a.params, 1, LH_WH1, LH_WH2, LH_WH3, LH_BH1, LH_BH2, LH_BH3);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -702,7 +703,7 @@ extern "C" int ren_mlp_fwd_jvp(const float *mlp_params, int32_t C, const float *
 
 extern "C" int64_t ren_mlp_bwd_jvp_workspace_floats(int32_t C) {
     if (C != 1 && C != 3) return -1;
-    return (int64_t)GRID_J * 4 * (len_h2(C) + LEN_H1 + P_BASE_N);
+    return (int64_t)GRID_J * 4 * (len_h2(C) + P_BASE_N) + (int64_t)GRID_J1 * 4 * LEN_H1;
 }
 
 extern "C" int ren_mlp_bwd_jvp(const float *mlp_params, int32_t C, const float *feat, const float *featd,
@@ -726,7 +727,7 @@ extern "C" int ren_mlp_bwd_jvp(const float *mlp_params, int32_t C, const float *
     const int64_t n_blk = (n + 31) / 32;
     // scratch (floats): dz1 | dz1d (2048 per block each) | d_base | d_based (512 per block each)
     float *dz1 = scratch, *dz1d = dz1 + n_blk * 2048, *d_base = dz1d + n_blk * 2048, *d_based = d_base + n_blk * 512;
-    float *slab2 = workspace, *slab1 = slab2 + (int64_t)GRID_J * 4 * len_h2(C), *slabb = slab1 + (int64_t)GRID_J * 4 * LEN_H1;
+    float *slab2 = workspace, *slab1 = slab2 + (int64_t)GRID_J * 4 * len_h2(C), *slabb = slab1 + (int64_t)GRID_J1 * 4 * LEN_H1;
     const RaySrc src{rays_o, rays_d, rays_dd, ray_indices, t_starts, t_ends};
     const ren_scene_dev sc = ren_make_scene(scene);
     BwdJ2Args a2;
@@ -738,13 +739,13 @@ extern "C" int ren_mlp_bwd_jvp(const float *mlp_params, int32_t C, const float *
     a1.params = mlp_params; a1.base_out = base_out; a1.base_outd = base_outd; a1.dz1 = dz1; a1.dz1d = dz1d;
     a1.src = src; a1.sc = sc; a1.n = n; a1.d_sigma = d_sigma; a1.d_sigmad = d_sigmad; a1.d_base = d_base;
     a1.d_based = d_based; a1.slab = slab1;
-    hipLaunchKernelGGL(mlp_bwd_jvp_head1_kernel, dim3(GRID_J), dim3(256), J1_LDS, st, a1);
+    hipLaunchKernelGGL(mlp_bwd_jvp_head1_kernel, dim3(GRID_J1), dim3(256), J1_LDS, st, a1);
     BwdJBArgs ab;
     ab.params = mlp_params; ab.feat = feat; ab.featd = featd; ab.d_base = d_base; ab.d_based = d_based; ab.n = n;
     ab.dfeat = dfeat; ab.dfeatd = dfeatd; ab.slab = slabb;
     hipLaunchKernelGGL(mlp_bwd_jvp_base_kernel, dim3(GRID_J), dim3(256), JB_LDS, st, ab);
     launch_reduce_slabs(slab2, GRID_J * 4, len_h2(C), grad_mlp_params + P_HW1, st);
-    launch_reduce_slabs(slab1, GRID_J * 4, LEN_H1, grad_mlp_params + P_HW0, st);
+    launch_reduce_slabs(slab1, GRID_J1 * 4, LEN_H1, grad_mlp_params + P_HW0, st);
     launch_reduce_slabs(slabb, GRID_J * 4, P_BASE_N, grad_mlp_params, st);
     REN_CHECK_LAUNCH();
 }
