@@ -21,6 +21,13 @@
 //   4. accumulate  stream a bin part (coalesced), 64-bit fixed-point ds_add_u64 into LDS, flush.
 // HBM traffic: 10 B written + 10 B read per update = 2.56 KB/sample (vs 2 KB of atomic RMW it
 // replaces) but all of it streaming; global atomic requests drop from 128 to ~0.1 per sample.
+//
+// Pair records (hashed levels, round 2): corners (x, y, z) and (x+1, y, z) of a cell hash to indices that differ
+// only in their low bits (x ^ (x+1) = 2^(k+1) - 1), so they fall into the same 8 192-entry bin except with
+// probability 2^-13, and their updates are (1 - fx) A and fx A with ONE shared A = wy wz dfeat.  A hashed level
+// therefore stages 4 records {u32 idx0 | idx1 << 13, float2 A, float fx} = 16 B per sample instead of 8 x 10 B:
+// 8 B per update, half as many ranking atomics and LDS placements in the scatter, and one 16-byte store / load
+// per record.  Dense levels keep the single-update records (their run merge sums different fx).
 #include <cstdlib>
 #include "ren_hashgrid_common.h"
 
@@ -33,12 +40,14 @@ constexpr int MAX_BINS = REN_MAX_LEVELS * MAX_BINS_PER_LEVEL;
 #ifndef REN_SC_THREADS
 #define REN_SC_THREADS 512
 #endif
-#ifndef REN_LEVEL_GROUPS
-#define REN_LEVEL_GROUPS 1
+#ifndef REN_SC_WAVES
+#define REN_SC_WAVES 6
+#endif
+#ifndef REN_SC_WAVES_PAIR
+#define REN_SC_WAVES_PAIR 8
 #endif
 constexpr int SC_THREADS = REN_SC_THREADS;           // scatter workgroup: one sample per thread
 constexpr int SC_ENTRIES = SC_THREADS * 8;           // staged updates per level pass = 48 KiB
-constexpr int LEVEL_GROUPS = REN_LEVEL_GROUPS;      // a scatter workgroup walks lvl = group, group + LEVEL_GROUPS, ...
 constexpr int CNT_THREADS = 256, CNT_SAMPLES = 1024; // count workgroup: 4 samples per thread, all levels
 // Updates per accumulate workgroup ("part").  A part follows n (a fixed 2 M-entry part is a ~1 ms single-workgroup
 // tail when the whole call is only a few million updates: occupancy-grid sampling, ~10 samples per ray), and it is
@@ -68,22 +77,26 @@ struct BinTab {
     // `cnt_stride` (rays of a batch are i.i.d., so blocks are exchangeable) and the offsets kernel scales the
     // sampled count back up with a 25 % + 4096 margin; the same overflow fallback keeps it exact.
     uint32_t cap[REN_MAX_LEVELS];
+    uint32_t pair[REN_MAX_LEVELS];                   // 1: the level's bins hold 16-byte pair records (cap counts records)
     int cnt_stride;
     int halve;                                       // test hook (REN_HGB_HALVE_REGIONS=1): force the overflow path
 };
 
 struct Part {
     uint32_t gbin, single;
-    uint64_t begin, end;
+    uint64_t begin, end;                             // entries, relative to the bin's region
 };
 
+// Staging pool: bin b owns 16-byte slots [bin_start[b], bin_start[b+1]).  Single-update regions hold
+// float2 v[bin_cap] followed by u16 idx[bin_cap]; pair regions hold float4 records[bin_cap].
 struct Workspace {
     uint32_t *counts, *level_max, *cursors, *n_parts;     // level_max: float bits of max |update|, [level][slot] one line each
-    uint64_t *bin_start;
+    uint32_t *bin_cap;                                    // entries the region can take
+    uint64_t *bin_start;                                  // first 16-byte slot of the region
     Part *parts;
-    uint16_t *out_idx;
-    float2 *out_v;
+    char *pool;
 };
+constexpr int PAIR_BIN_SHIFT = 26;                        // pair record code: idx0 | idx1 << 13 | bin << 26 (bin: LDS staging only)
 
 // optional tangent inputs (log-intensity-gradient loss): update = w * dfeat + wdot * dfeatd
 struct TanSrc {
@@ -246,22 +259,27 @@ __global__ __launch_bounds__(CNT_THREADS) void bin_count_kernel(GridDev g, BinTa
 }
 
 // ---- 2. offsets: exclusive scan of the region sizes (count for dense bins, capacity for hashed bins) ------
-__global__ __launch_bounds__(MAX_BINS) void bin_offsets_kernel(int n_bins, BinTab bt, uint64_t capacity,
+__global__ __launch_bounds__(MAX_BINS) void bin_offsets_kernel(int n_bins, BinTab bt, uint64_t capacity_slots,
                                                                const uint32_t *__restrict__ counts,
                                                                uint32_t *__restrict__ cursors,
+                                                               uint32_t *__restrict__ bin_cap,
                                                                uint64_t *__restrict__ bin_start) {
     __shared__ uint64_t s_cnt[MAX_BINS];
     const int t = threadIdx.x;
-    uint64_t c = 0;
+    uint64_t c = 0, slots = 0;
+    bool pair = false;
     if (t < n_bins) {
         int lvl = 0;
         while (lvl + 1 < REN_MAX_LEVELS && t >= bt.bin_base[lvl + 1]) ++lvl;
+        pair = bt.pair[lvl] != 0;
         c = bt.cap[lvl] ? bt.cap[lvl] : counts[t];
         if (!bt.cap[lvl] && bt.cnt_stride > 1) c = c * bt.cnt_stride + c * bt.cnt_stride / 4 + 4096;
         if (bt.halve) c = c / 2;
+        c &= ~(uint64_t)7;                                         // idx[] of a single-update region stays 16-byte aligned
+        slots = pair ? c : (c * 10 + 15) / 16;
         cursors[t] = 0;
     }
-    s_cnt[t] = c;
+    s_cnt[t] = slots;
     __syncthreads();
     for (int off = 1; off < MAX_BINS; off <<= 1) {
         const uint64_t a = t >= off ? s_cnt[t - off] : 0;
@@ -270,23 +288,26 @@ __global__ __launch_bounds__(MAX_BINS) void bin_offsets_kernel(int n_bins, BinTa
         __syncthreads();
     }
     // regions never leave the workspace: whatever does not fit takes the overflow path of the scatter
-    if (t < n_bins) bin_start[t] = s_cnt[t] - c < capacity ? s_cnt[t] - c : capacity;
-    if (t == n_bins - 1) bin_start[n_bins] = s_cnt[t] < capacity ? s_cnt[t] : capacity;
+    if (t < n_bins) {
+        const uint64_t start = s_cnt[t] - slots;
+        uint64_t room = start < capacity_slots ? capacity_slots - start : 0;
+        if (room > slots) room = slots;
+        if (room < slots) c = (pair ? room : room * 16 / 10) & ~(uint64_t)7;
+        bin_start[t] = start < capacity_slots ? start : capacity_slots;
+        bin_cap[t] = (uint32_t)c;
+    }
+    if (t == n_bins - 1) bin_start[n_bins] = s_cnt[t] < capacity_slots ? s_cnt[t] : capacity_slots;
 }
 
 // ---- 3b. work partition of the accumulate pass, from the ACTUAL fill of every bin region ---------------------
 __global__ __launch_bounds__(MAX_BINS) void bin_partition_kernel(int n_bins, uint64_t PART_ENTRIES,
                                                                  const uint32_t *__restrict__ cursors,
-                                                                 const uint64_t *__restrict__ bin_start,
+                                                                 const uint32_t *__restrict__ bin_cap,
                                                                  Part *__restrict__ parts, uint32_t *__restrict__ n_parts) {
     __shared__ uint32_t s_np[MAX_BINS];
     const int t = threadIdx.x;
-    uint64_t c = 0, start = 0;
-    if (t < n_bins) {
-        start = bin_start[t];
-        const uint64_t room = bin_start[t + 1] - start;
-        c = cursors[t] < room ? cursors[t] : room;                   // overflowing updates went to the table directly
-    }
+    uint64_t c = 0;
+    if (t < n_bins) c = cursors[t] < bin_cap[t] ? cursors[t] : bin_cap[t];   // overflowing updates went to the table directly
     const uint32_t np = (uint32_t)((c + PART_ENTRIES - 1) / PART_ENTRIES);
     s_np[t] = np;
     __syncthreads();
@@ -301,33 +322,48 @@ __global__ __launch_bounds__(MAX_BINS) void bin_partition_kernel(int n_bins, uin
     for (uint32_t k = 0; k < np; ++k) {
         Part p;
         p.gbin = t; p.single = np == 1;
-        p.begin = start + (uint64_t)k * PART_ENTRIES;
-        p.end = k + 1 == np ? start + c : p.begin + PART_ENTRIES;
+        p.begin = (uint64_t)k * PART_ENTRIES;
+        p.end = k + 1 == np ? c : p.begin + PART_ENTRIES;
         parts[pbase + k] = p;
     }
 }
 
 // ---- 3. scatter (counting sort by bin inside the workgroup, coalesced append) ----------------------------
-// One sample per thread; the workgroup walks the levels {group, group + 4, ...} and runs one
+// One sample per thread; the workgroup walks the levels and runs one
 // rank -> offsets -> LDS placement -> coalesced append pass per level over the same staging area.
-template <bool TAN>
-__global__ __launch_bounds__(SC_THREADS) void bin_scatter_kernel(GridDev g, BinTab bt, SampleArgs a, Workspace ws,
-                                                                 float *__restrict__ grad_table) {
+__device__ __forceinline__ void table_atomic(float *grad_table, uint32_t offset, uint32_t idx, float a, float b) {
+    float *gt = grad_table + 2 * ((size_t)offset + idx);
+    atomicAdd(gt, a);
+    atomicAdd(gt + 1, b);
+}
+
+// KIND 0: every level with single-update records (the tangent variant), 1: the pair-record (hashed) levels only,
+// 2: the single-update (dense) levels only.  Two launches instead of one let the hashed-level kernel run with a
+// 32 KiB staging area and 64 registers: four workgroups per CU.
+template <bool TAN, int KIND>
+__global__ __launch_bounds__(SC_THREADS, KIND == 1 ? REN_SC_WAVES_PAIR : REN_SC_WAVES) void bin_scatter_kernel(
+    GridDev g, BinTab bt, SampleArgs a, Workspace ws, float *__restrict__ grad_table) {
     __shared__ uint32_t hist[MAX_BINS_PER_LEVEL], loc[MAX_BINS_PER_LEVEL + 1], fit[MAX_BINS_PER_LEVEL];
-    __shared__ uint64_t gdelta[MAX_BINS_PER_LEVEL];               // global position - staging position, per bin
-    __shared__ uint32_t st_key[SC_ENTRIES];
-    __shared__ float2 st_v[SC_ENTRIES];
+    // per bin: where staging position q of this pass goes in HBM (pointer - local offset of the bin's run):
+    // gp0 = float2 v[] (single updates) or float4 records[] (pairs), gp1 = u16 idx[] (single updates)
+    __shared__ char *gp0[MAX_BINS_PER_LEVEL], *gp1[MAX_BINS_PER_LEVEL];
+    __shared__ __attribute__((aligned(16))) unsigned char stage[KIND == 1 ? SC_THREADS * 4 * 16 : SC_ENTRIES * 12];   // float4[]  |  key u32[] + v float2[]
     __shared__ float wave_max[SC_THREADS / 64];
     __shared__ int any_overflow;
-    const int group = blockIdx.x % LEVEL_GROUPS;
-    const int64_t chunk = blockIdx.x / LEVEL_GROUPS;
+    uint32_t *st_key = reinterpret_cast<uint32_t *>(stage);
+    float2 *st_v = reinterpret_cast<float2 *>(stage + SC_ENTRIES * 4);
+    float4 *st_p = reinterpret_cast<float4 *>(stage);
+    const int64_t chunk = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63;
     const int64_t i = chunk * SC_THREADS + tid;
     const bool inb = i < a.n;
     float u[3] = {0.f, 0.f, 0.f}, ud[3] = {0.f, 0.f, 0.f};
     if (inb) unit_pos<TAN>(a, i, u, ud);
+    constexpr bool pairs = KIND == 1;
 #pragma unroll 1
-    for (int lvl = group; lvl < g.n_levels; lvl += LEVEL_GROUPS) {
+    for (int lvl = 0; lvl < g.n_levels; ++lvl) {
+        if (KIND == 1 && !bt.pair[lvl]) continue;
+        if (KIND == 2 && bt.pair[lvl]) continue;
         if (tid < MAX_BINS_PER_LEVEL) hist[tid] = 0;
         if (tid == 0) any_overflow = 0;
         lds_barrier();                                           // also: previous level's append is done
@@ -339,39 +375,64 @@ __global__ __launch_bounds__(SC_THREADS) void bin_scatter_kernel(GridDev g, BinT
         const LevelPos p = level_pos(u[0], u[1], u[2], scale);
         const float wx1 = p.w[0], wy1 = p.w[1], wz1 = p.w[2], wx0 = 1.f - wx1, wy0 = 1.f - wy1, wz0 = 1.f - wz1;
         if (!valid) { d0 = 0.f; d1 = 0.f; e0 = 0.f; e1 = 0.f; }
-        const float wxy[4] = {wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};
-        uint32_t key[8];                                           // rank << 19 | table index in level
-        float v0[8], v1[8];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const float wz = (c & 4) ? wz1 : wz0;
-            const float w = wxy[c & 3] * wz;
-            v0[c] = w * d0; v1[c] = w * d1;
-            if (TAN) {                                             // + d w / dt * d(feature tangent)
-                const float wx = (c & 1) ? wx1 : wx0, wy = (c & 2) ? wy1 : wy0;
-                const float bx = (c & 1) ? ud[0] : -ud[0], by = (c & 2) ? ud[1] : -ud[1], bz = (c & 4) ? ud[2] : -ud[2];
-                const float wdc = scale * (bx * wy * wz + wx * by * wz + wxy[c & 3] * bz);
-                v0[c] += wdc * e0; v1[c] += wdc * e1;
-            }
-        }
-        bool head;
-        const bool have = run_tail(!hashed, valid, cell_key(p), lane, head);
-        if (!hashed) run_merge(head, lane, v0, v1);
-        // upper bound of |update| in this level (scale of the fixed-point sums): interpolation weights are <= 1 and a
-        // merged run adds at most 8 lanes, so 8 max|d feature| bounds every update (3 of the 38 bits); with tangents
-        // the updates carry the scale * |ud| terms as well, so take them as they are
+        uint32_t key[8];                                           // singles: rank << 19 | table index in level
+        float v0[8], v1[8];                                        // pairs:   key[j] = record code, key[4 + j] = rank
+        bool have;
         float vmax = 0.f;
-        if (TAN) {
-            if (have) {
+        uint32_t idx[8];
+        corner_indices8(p.c[0], p.c[1], p.c[2], res, size, hashed, idx);
+        if (pairs) {
+            // ---- pair records: (x, x+1) corners share A = wy wz dfeat, their weights are 1 - fx and fx
+            const bool same = ((idx[0] ^ idx[1]) >> BIN_SHIFT) == 0;   // idx0 ^ idx1 is the same for the four pairs
 #pragma unroll
-                for (int c = 0; c < 8; ++c) vmax = fmaxf(vmax, fmaxf(fabsf(v0[c]), fabsf(v1[c])));
+            for (int j = 0; j < 4; ++j) {
+                const float wyz = ((j & 1) ? wy1 : wy0) * ((j & 2) ? wz1 : wz0);
+                v0[j] = wyz * d0; v1[j] = wyz * d1;
             }
-        } else if (valid) {
-            vmax = fmaxf(fabsf(d0), fabsf(d1)) * (hashed ? 1.f : 8.f);
-        }
-        {
-            uint32_t idx[8];
-            corner_indices8(p.c[0], p.c[1], p.c[2], res, size, hashed, idx);
+            if (valid && !same) {                                  // x + 1 carries past bit 12: once in 8 192 cells
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    table_atomic(grad_table, g.offset[lvl], idx[2 * j], wx0 * v0[j], wx0 * v1[j]);
+                    table_atomic(grad_table, g.offset[lvl], idx[2 * j + 1], wx1 * v0[j], wx1 * v1[j]);
+                }
+            }
+            have = valid && same;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t bin = idx[2 * j] >> BIN_SHIFT;
+                key[4 + j] = have ? atomicAdd(&hist[bin], 1u) : 0u;
+                key[j] = (idx[2 * j] & (BIN_ENTRIES - 1)) | ((idx[2 * j + 1] & (BIN_ENTRIES - 1)) << BIN_SHIFT) |
+                         (bin << PAIR_BIN_SHIFT);
+            }
+            if (valid) vmax = fmaxf(fabsf(d0), fabsf(d1));
+        } else {
+            const float wxy[4] = {wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float wz = (c & 4) ? wz1 : wz0;
+                const float w = wxy[c & 3] * wz;
+                v0[c] = w * d0; v1[c] = w * d1;
+                if (TAN) {                                             // + d w / dt * d(feature tangent)
+                    const float wx = (c & 1) ? wx1 : wx0, wy = (c & 2) ? wy1 : wy0;
+                    const float bx = (c & 1) ? ud[0] : -ud[0], by = (c & 2) ? ud[1] : -ud[1], bz = (c & 4) ? ud[2] : -ud[2];
+                    const float wdc = scale * (bx * wy * wz + wx * by * wz + wxy[c & 3] * bz);
+                    v0[c] += wdc * e0; v1[c] += wdc * e1;
+                }
+            }
+            bool head;
+            have = run_tail(!hashed, valid, cell_key(p), lane, head);
+            if (!hashed) run_merge(head, lane, v0, v1);
+            // upper bound of |update| in this level (scale of the fixed-point sums): interpolation weights are <= 1 and a
+            // merged run adds at most 8 lanes, so 8 max|d feature| bounds every update (3 of the 38 bits); with tangents
+            // the updates carry the scale * |ud| terms as well, so take them as they are
+            if (TAN) {
+                if (have) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) vmax = fmaxf(vmax, fmaxf(fabsf(v0[c]), fabsf(v1[c])));
+                }
+            } else if (valid) {
+                vmax = fmaxf(fabsf(d0), fabsf(d1)) * (hashed ? 1.f : 8.f);
+            }
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 const uint32_t rank = bin_rank(!hashed, have, idx[c] >> BIN_SHIFT, lane, hist);
@@ -402,51 +463,64 @@ __global__ __launch_bounds__(SC_THREADS) void bin_scatter_kernel(GridDev g, BinT
             }
             loc[tid] = inc - cnt;
             if (tid == MAX_BINS_PER_LEVEL - 1) loc[MAX_BINS_PER_LEVEL] = inc;
-            uint64_t base = 0;
             uint32_t room = cnt;
+            char *q0 = nullptr, *q1 = nullptr;
             if (tid < nb && cnt) {
                 const int gb = bt.bin_base[lvl] + tid;
                 const uint32_t at = atomicAdd(&ws.cursors[gb], cnt);         // reserve the run in the bin's region
-                const uint64_t cap = ws.bin_start[gb + 1] - ws.bin_start[gb];
-                room = at >= cap ? 0u : (uint32_t)(cap - at < cnt ? cap - at : cnt);
-                base = ws.bin_start[gb] + at;
+                const uint32_t cap = ws.bin_cap[gb];
+                room = at >= cap ? 0u : (cap - at < cnt ? cap - at : cnt);
+                char *base = ws.pool + ws.bin_start[gb] * 16;
+                const int64_t first = (int64_t)at - (int64_t)(inc - cnt);    // region entry of staging position 0
+                if (pairs) q0 = base + first * 16;
+                else { q0 = base + first * 8; q1 = base + (int64_t)cap * 8 + first * 2; }
             }
             fit[tid] = room;                                           // entries of this run that fit the region
             if (room < cnt) any_overflow = 1;
-            gdelta[tid] = base - (inc - cnt);
+            gp0[tid] = q0; gp1[tid] = q1;
         }
         lds_barrier();
         if (have) {
+            if (pairs) {
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const uint32_t idx = key[c] & 0x7FFFFu;
-                const uint32_t pos = loc[idx >> BIN_SHIFT] + (key[c] >> 19);
-                st_key[pos] = idx;
-                st_v[pos] = make_float2(v0[c], v1[c]);
+                for (int j = 0; j < 4; ++j)
+                    st_p[loc[key[j] >> PAIR_BIN_SHIFT] + key[4 + j]] = make_float4(__uint_as_float(key[j]), v0[j], v1[j], wx1);
+            } else {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const uint32_t ix = key[c] & 0x7FFFFu;
+                    const uint32_t pos = loc[ix >> BIN_SHIFT] + (key[c] >> 19);
+                    st_key[pos] = ix;
+                    st_v[pos] = make_float2(v0[c], v1[c]);
+                }
             }
         }
         lds_barrier();
         const uint32_t total = loc[MAX_BINS_PER_LEVEL];
-        if (!any_overflow) {                                       // the usual case: every run fits its region
+        const bool ovf = any_overflow != 0;
+        if (pairs) {
             for (uint32_t q = tid; q < total; q += SC_THREADS) {
-                const uint32_t idx = st_key[q];
-                const uint64_t gp = gdelta[idx >> BIN_SHIFT] + q;
-                ws.out_idx[gp] = (uint16_t)(idx & (BIN_ENTRIES - 1));
-                ws.out_v[gp] = st_v[q];
+                const float4 r = st_p[q];
+                const uint32_t code = __float_as_uint(r.x), b = code >> PAIR_BIN_SHIFT;
+                if (!ovf || q - loc[b] < fit[b]) {
+                    reinterpret_cast<float4 *>(gp0[b])[q] = r;
+                } else {                                               // region full (capacity-sized hashed bins only)
+                    const uint32_t i0 = (b << BIN_SHIFT) | (code & (BIN_ENTRIES - 1));
+                    const uint32_t i1 = (b << BIN_SHIFT) | ((code >> BIN_SHIFT) & (BIN_ENTRIES - 1));
+                    table_atomic(grad_table, g.offset[lvl], i0, (1.f - r.w) * r.y, (1.f - r.w) * r.z);
+                    table_atomic(grad_table, g.offset[lvl], i1, r.w * r.y, r.w * r.z);
+                }
             }
             continue;
         }
         for (uint32_t q = tid; q < total; q += SC_THREADS) {
-            const uint32_t idx = st_key[q], b = idx >> BIN_SHIFT;
+            const uint32_t ix = st_key[q], b = ix >> BIN_SHIFT;
             const float2 v = st_v[q];
-            if (q - loc[b] < fit[b]) {
-                const uint64_t gp = gdelta[b] + q;
-                ws.out_idx[gp] = (uint16_t)(idx & (BIN_ENTRIES - 1));
-                ws.out_v[gp] = v;
-            } else {                                                   // region full (capacity-sized hashed bins only)
-                float *gt = grad_table + 2 * ((size_t)g.offset[lvl] + idx);
-                atomicAdd(gt, v.x);
-                atomicAdd(gt + 1, v.y);
+            if (!ovf || q - loc[b] < fit[b]) {
+                reinterpret_cast<uint16_t *>(gp1[b])[q] = (uint16_t)(ix & (BIN_ENTRIES - 1));
+                reinterpret_cast<float2 *>(gp0[b])[q] = v;
+            } else {
+                table_atomic(grad_table, g.offset[lvl], ix, v.x, v.y);
             }
         }
     }
@@ -475,23 +549,47 @@ __global__ __launch_bounds__(1024) void bin_accumulate_kernel(GridDev g, BinTab 
     for (int k = 0; k < LMAX_SLOTS; ++k) lmax = max(lmax, ws.level_max[(lvl * LMAX_SLOTS + k) * LMAX_STRIDE]);
     (void)frexpf(__uint_as_float(lmax), &ex);                     // level max < 2^ex
     const double scale = ldexp(1.0, 38 - ex), inv_scale = ldexp(1.0, ex - 38);
+    const char *base = ws.pool + ws.bin_start[part.gbin] * 16;
     __syncthreads();
     uint64_t e = part.begin + threadIdx.x;
-    for (; e + 3 * 1024 < part.end; e += 4 * 1024) {               // 4 independent loads in flight per lane
-        uint32_t ix[4]; float2 v[4];
+    if (bt.pair[lvl]) {
+        const float4 *rec = reinterpret_cast<const float4 *>(base);
+        auto add = [&](const float4 &r) {
+            const uint32_t code = __float_as_uint(r.x);
+            const uint32_t i0 = code & (BIN_ENTRIES - 1), i1 = (code >> BIN_SHIFT) & (BIN_ENTRIES - 1);
+            const float f0 = 1.f - r.w;
+            atomicAdd(&acc0[i0], (unsigned long long)to_fixed(f0 * r.y, scale));      // ds_add_u64
+            atomicAdd(&acc1[i0], (unsigned long long)to_fixed(f0 * r.z, scale));
+            atomicAdd(&acc0[i1], (unsigned long long)to_fixed(r.w * r.y, scale));
+            atomicAdd(&acc1[i1], (unsigned long long)to_fixed(r.w * r.z, scale));
+        };
+        for (; e + 3 * 1024 < part.end; e += 4 * 1024) {           // 4 independent 16-byte loads in flight per lane
+            float4 r[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { ix[u] = ws.out_idx[e + u * 1024]; v[u] = ws.out_v[e + u * 1024]; }
+            for (int u = 0; u < 4; ++u) r[u] = rec[e + u * 1024];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            atomicAdd(&acc0[ix[u]], (unsigned long long)to_fixed(v[u].x, scale));    // ds_add_u64
-            atomicAdd(&acc1[ix[u]], (unsigned long long)to_fixed(v[u].y, scale));
+            for (int u = 0; u < 4; ++u) add(r[u]);
         }
-    }
-    for (; e < part.end; e += 1024) {
-        const uint32_t idx = ws.out_idx[e];
-        const float2 v = ws.out_v[e];
-        atomicAdd(&acc0[idx], (unsigned long long)to_fixed(v.x, scale));
-        atomicAdd(&acc1[idx], (unsigned long long)to_fixed(v.y, scale));
+        for (; e < part.end; e += 1024) add(rec[e]);
+    } else {
+        const float2 *out_v = reinterpret_cast<const float2 *>(base);
+        const uint16_t *out_idx = reinterpret_cast<const uint16_t *>(base + (size_t)ws.bin_cap[part.gbin] * 8);
+        for (; e + 3 * 1024 < part.end; e += 4 * 1024) {           // 4 independent loads in flight per lane
+            uint32_t ix[4]; float2 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { ix[u] = out_idx[e + u * 1024]; v[u] = out_v[e + u * 1024]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                atomicAdd(&acc0[ix[u]], (unsigned long long)to_fixed(v[u].x, scale));    // ds_add_u64
+                atomicAdd(&acc1[ix[u]], (unsigned long long)to_fixed(v[u].y, scale));
+            }
+        }
+        for (; e < part.end; e += 1024) {
+            const uint32_t idx = out_idx[e];
+            const float2 v = out_v[e];
+            atomicAdd(&acc0[idx], (unsigned long long)to_fixed(v.x, scale));
+            atomicAdd(&acc1[idx], (unsigned long long)to_fixed(v.y, scale));
+        }
     }
     __syncthreads();
     const uint32_t first = ((uint32_t)part.gbin - bt.bin_base[lvl]) << BIN_SHIFT;   // first entry of the bin in its level
@@ -514,24 +612,26 @@ __global__ __launch_bounds__(1024) void bin_accumulate_kernel(GridDev g, BinTab 
 
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-struct Layout { size_t counts, level_max, cursors, n_parts, bin_start, parts, out_idx, out_v, total, entries; int64_t max_parts; };
+struct Layout { size_t counts, level_max, cursors, n_parts, bin_cap, bin_start, parts, pool, total, slots; int64_t entries, max_parts; };
 
 Layout make_layout(int64_t n) {
     Layout L;
-    // at most 128 n updates (16 levels x 8 corners) + capacity slack: 2 % of the hashed and 25 % of the dense
-    // levels, 4096 per bin, one stride of count blocks; the offsets kernel clamps the regions to this total
+    // at most 128 n single updates of 10 B (16 levels x 8 corners; pair records are 16 B for two) + capacity
+    // slack: 2 % of the hashed and 25 % of the dense levels, 4096 per bin, one stride of count blocks; the
+    // offsets kernel clamps the regions to this total
     const size_t E = (size_t)n * 140 + (size_t)MAX_BINS * 4096 + 16 * 8 * 16 * CNT_SAMPLES;
-    L.entries = E;
+    L.entries = (int64_t)E;
+    L.slots = (E * 10 + 15) / 16 + MAX_BINS;
     L.max_parts = (int64_t)(E / PART_ENTRIES_MIN) + MAX_BINS + 1;   // room for the smallest part size
     size_t o = 0;
     L.counts = o; o += MAX_BINS * 4;                       // counts | level_max are cleared by one memset
     L.level_max = o; o = align256(o + LMAX_WORDS * 4);
     L.cursors = o; o = align256(o + MAX_BINS * 4);
     L.n_parts = o; o = align256(o + 4);
+    L.bin_cap = o; o = align256(o + MAX_BINS * 4);
     L.bin_start = o; o = align256(o + (MAX_BINS + 1) * 8);
     L.parts = o; o = align256(o + (size_t)L.max_parts * sizeof(Part));
-    L.out_idx = o; o = align256(o + E * 2);
-    L.out_v = o; o = align256(o + E * 8);
+    L.pool = o; o = align256(o + L.slots * 16);
     L.total = o;
     return L;
 }
@@ -568,11 +668,15 @@ static int binned_impl(const ren_grid_desc *grid, float *grad_table, const float
     bt.bin_base[REN_MAX_LEVELS] = nb;
     for (int l = g.n_levels; l < REN_MAX_LEVELS; ++l) bt.bin_base[l] = nb;
     int64_t hashed_cap = 0;
+    const char *no_pairs = getenv("REN_HGB_NO_PAIRS");             // verification knob: single-update records everywhere
+    const bool use_pairs = !tan.dfeatd && !(no_pairs && no_pairs[0] == '1');
     for (int l = 0; l < REN_MAX_LEVELS; ++l) {
         bt.cap[l] = 0;
+        bt.pair[l] = 0;
         if (l < g.n_levels && g.hashed[l]) {
             const int64_t bins = (g.size[l] + BIN_ENTRIES - 1) >> BIN_SHIFT;
-            const int64_t mean = (8 * n + bins - 1) / bins;
+            bt.pair[l] = use_pairs ? 1 : 0;                       // 4 pair records instead of 8 updates per sample
+            const int64_t mean = ((use_pairs ? 4 : 8) * n + bins - 1) / bins;
             bt.cap[l] = (uint32_t)(mean + mean / 50 + 4096);
             if ((int64_t)bt.cap[l] > hashed_cap) hashed_cap = bt.cap[l];
         }
@@ -586,9 +690,9 @@ static int binned_impl(const ren_grid_desc *grid, float *grad_table, const float
     Workspace ws;
     ws.counts = (uint32_t *)(w + L.counts); ws.level_max = (uint32_t *)(w + L.level_max);
     ws.cursors = (uint32_t *)(w + L.cursors);
-    ws.n_parts = (uint32_t *)(w + L.n_parts); ws.bin_start = (uint64_t *)(w + L.bin_start);
-    ws.parts = (Part *)(w + L.parts); ws.out_idx = (uint16_t *)(w + L.out_idx);
-    ws.out_v = (float2 *)(w + L.out_v);
+    ws.n_parts = (uint32_t *)(w + L.n_parts); ws.bin_cap = (uint32_t *)(w + L.bin_cap);
+    ws.bin_start = (uint64_t *)(w + L.bin_start);
+    ws.parts = (Part *)(w + L.parts); ws.pool = w + L.pool;
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(ws.counts, 0, (MAX_BINS + LMAX_WORDS) * 4, st) != hipSuccess) return REN_ERR_LAUNCH;
     SampleArgs a;
@@ -599,14 +703,19 @@ static int binned_impl(const ren_grid_desc *grid, float *grad_table, const float
     const int64_t cnt_blocks = (n + CNT_SAMPLES - 1) / CNT_SAMPLES;
     bt.cnt_stride = cnt_blocks >= 4096 ? 16 : cnt_blocks >= 2048 ? 8 : cnt_blocks >= 1024 ? 4 : 1;   // >= 256 sampled blocks or exact
     const dim3 cgrd((unsigned)((cnt_blocks + bt.cnt_stride - 1) / bt.cnt_stride)), cblk(CNT_THREADS);
-    const dim3 sgrd((unsigned)((n + SC_THREADS - 1) / SC_THREADS * LEVEL_GROUPS)), sblk(SC_THREADS);
+    const dim3 sgrd((unsigned)((n + SC_THREADS - 1) / SC_THREADS)), sblk(SC_THREADS);
     if (tan.dfeatd) hipLaunchKernelGGL(bin_count_kernel<true>, cgrd, cblk, 0, st, g, bt, a, ws.counts);
     else            hipLaunchKernelGGL(bin_count_kernel<false>, cgrd, cblk, 0, st, g, bt, a, ws.counts);
-    hipLaunchKernelGGL(bin_offsets_kernel, dim3(1), dim3(MAX_BINS), 0, st, nb, bt, (uint64_t)L.entries, ws.counts,
-                       ws.cursors, ws.bin_start);
-    if (tan.dfeatd) hipLaunchKernelGGL(bin_scatter_kernel<true>, sgrd, sblk, 0, st, g, bt, a, ws, grad_table);
-    else            hipLaunchKernelGGL(bin_scatter_kernel<false>, sgrd, sblk, 0, st, g, bt, a, ws, grad_table);
-    hipLaunchKernelGGL(bin_partition_kernel, dim3(1), dim3(MAX_BINS), 0, st, nb, (uint64_t)part_entries, ws.cursors, ws.bin_start, ws.parts,
+    hipLaunchKernelGGL(bin_offsets_kernel, dim3(1), dim3(MAX_BINS), 0, st, nb, bt, (uint64_t)L.slots, ws.counts,
+                       ws.cursors, ws.bin_cap, ws.bin_start);
+    bool any_pair = false, any_single = false;
+    for (int l = 0; l < g.n_levels; ++l) { any_pair |= bt.pair[l] != 0; any_single |= bt.pair[l] == 0; }
+    if (tan.dfeatd) hipLaunchKernelGGL((bin_scatter_kernel<true, 0>), sgrd, sblk, 0, st, g, bt, a, ws, grad_table);
+    else {
+        if (any_pair)   hipLaunchKernelGGL((bin_scatter_kernel<false, 1>), sgrd, sblk, 0, st, g, bt, a, ws, grad_table);
+        if (any_single) hipLaunchKernelGGL((bin_scatter_kernel<false, 2>), sgrd, sblk, 0, st, g, bt, a, ws, grad_table);
+    }
+    hipLaunchKernelGGL(bin_partition_kernel, dim3(1), dim3(MAX_BINS), 0, st, nb, (uint64_t)part_entries, ws.cursors, ws.bin_cap, ws.parts,
                        ws.n_parts);
     const size_t acc_lds = 2 * BIN_ENTRIES * sizeof(unsigned long long);
     (void)hipFuncSetAttribute((const void *)bin_accumulate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)acc_lds);
