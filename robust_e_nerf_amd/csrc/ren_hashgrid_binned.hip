@@ -7,27 +7,27 @@
 // samples of one training step = 105 ms, 88 % of the step.  11 of the 16 levels are spatial hashes
 // whose updates have no locality at all, so nothing short of a sort can aggregate them on chip.
 //
-// What: the updates are sorted by 8 192-entry table bin (2 features x int64 = 128 KiB = one LDS) in two steps:
-//   1. scatter   one sample per thread, the workgroup (512 samples) walks the levels: per level rank its
-//                records by bin (LDS counters), place them in an LDS staging area and write the sorted block
-//                -- one "slab" per (level, workgroup) -- to HBM with one contiguous, fully coalesced 32-40 KiB
-//                store, plus a 256-byte directory (start | count per bin)
-//   2. accumulate  one workgroup per bin(-part) walks the directory column of its bin, gathers the bin's run
-//                out of every slab (~0.5 KiB pieces), adds them with 64-bit fixed-point ds_add_u64 into LDS and
-//                adds the finished 128 KiB slice to the gradient table with plain coalesced read-modify-writes.
-// Round 1 appended every run to a per-bin region instead (reserved with a returning global atomic per run):
-// 64 concurrent ~0.5 KiB append streams per workgroup cost 3.84 ms where the contiguous slab costs 2.70 ms
-// (n = 16.8 M, hashed levels), the gather on the read side costs nothing (2.65 vs 2.58 ms), and the slab needs no
-// count pass, no capacity estimate, no overflow path and no cursor atomics: memset + 2 scatter launches + 1
-// accumulate launch.
+// What: a counting sort of the updates by 8 192-entry table bin (2 features x int64 = 128 KiB = one
+// LDS), then one workgroup per bin(-part) accumulates its updates with LDS atomics and adds the
+// finished 128 KiB slice to the gradient table with plain coalesced read-modify-writes:
+//   1. count    per (level, bin) number of updates; one thread walks all levels of its samples, the
+//               histogram stays in LDS and reaches the global counters once per 1 024 samples
+//   2. offsets  exclusive scan of the ~770 bin counts + work partition  (one workgroup)
+//   3. scatter  one sample per thread, the workgroup walks the levels: per level rank the 512 x 8
+//               corner updates by bin (LDS counters), place them in an LDS staging area, and append the
+//               runs to the bins' regions of an HBM staging buffer {u16 local index | float2 value}
+//               with fully coalesced stores (288 GB of HBM is what makes a 10 B x 128 x n buffer
+//               -- 21.5 GB at n = 16.8 M -- a reasonable thing to do)
+//   4. accumulate  stream a bin part (coalesced), 64-bit fixed-point ds_add_u64 into LDS, flush.
+// HBM traffic: 10 B written + 10 B read per update = 2.56 KB/sample (vs 2 KB of atomic RMW it
+// replaces) but all of it streaming; global atomic requests drop from 128 to ~0.1 per sample.
 //
-// Pair records (hashed levels): corners (x, y, z) and (x+1, y, z) of a cell hash to indices that differ only in
-// their low bits (x ^ (x+1) = 2^(k+1) - 1), so they fall into the same bin except with probability 2^-13 (those
-// go to the table with global atomics), and their updates are (1 - fx) A and fx A with ONE shared A = wy wz dfeat.
-// A hashed level therefore stages 4 records {u32 idx0 | idx1 << 13, float2 A, float fx} = 16 B per sample instead
-// of 8 x 10 B: 8 B per update, half as many ranking atomics and LDS placements, one 16-byte store / load per
-// record.  Dense levels keep single-update records {u16 idx, float2 v} (their run merge sums different fx).
-// HBM traffic at config B: 64 B x 11 hashed levels + ~19 B x 5 dense levels per sample, written once and read once.
+// Pair records (hashed levels, round 2): corners (x, y, z) and (x+1, y, z) of a cell hash to indices that differ
+// only in their low bits (x ^ (x+1) = 2^(k+1) - 1), so they fall into the same 8 192-entry bin except with
+// probability 2^-13, and their updates are (1 - fx) A and fx A with ONE shared A = wy wz dfeat.  A hashed level
+// therefore stages 4 records {u32 idx0 | idx1 << 13, float2 A, float fx} = 16 B per sample instead of 8 x 10 B:
+// 8 B per update, half as many ranking atomics and LDS placements in the scatter, and one 16-byte store / load
+// per record.  Dense levels keep the single-update records (their run merge sums different fx).
 #include <cstdlib>
 #include "ren_hashgrid_common.h"
 
@@ -36,6 +36,7 @@ namespace {
 constexpr int BIN_SHIFT = 13;
 constexpr int BIN_ENTRIES = 1 << BIN_SHIFT;          // 8 192 table entries (x2 features x int64 = 128 KiB LDS)
 constexpr int MAX_BINS_PER_LEVEL = 64;
+constexpr int MAX_BINS = REN_MAX_LEVELS * MAX_BINS_PER_LEVEL;
 #ifndef REN_SC_THREADS
 #define REN_SC_THREADS 512
 #endif
@@ -46,15 +47,22 @@ constexpr int MAX_BINS_PER_LEVEL = 64;
 #define REN_SC_WAVES_PAIR 8
 #endif
 constexpr int SC_THREADS = REN_SC_THREADS;           // scatter workgroup: one sample per thread
-constexpr int SC_ENTRIES = SC_THREADS * 8;           // single-update records per level pass (48 KiB staged)
-constexpr int SC_PAIRS = SC_THREADS * 4;             // pair records per level pass (32 KiB staged)
-// one slab per (level, scatter workgroup): float4 rec[SC_PAIRS]  |  float2 v[SC_ENTRIES] + u16 idx[SC_ENTRIES]
-constexpr size_t SLAB_BYTES = (size_t)SC_ENTRIES * 10;
-static_assert(SLAB_BYTES >= (size_t)SC_PAIRS * 16 && SLAB_BYTES % 256 == 0, "slab layout");
-// records per accumulate part of a dense bin (hashed bins are always ONE part: a bin cut in two flushes both
-// halves with 16 384 float atomics -- memory-side, ~18 G/s chip-wide -- instead of one coalesced read-modify-write)
-constexpr int64_t PART_RECORDS = 1 << 20;
-constexpr int MAX_PARTS_PER_BIN = 256;
+constexpr int SC_ENTRIES = SC_THREADS * 8;           // staged updates per level pass = 48 KiB
+constexpr int CNT_THREADS = 256, CNT_SAMPLES = 1024; // count workgroup: 4 samples per thread, all levels
+// Updates per accumulate workgroup ("part").  A part follows n (a fixed 2 M-entry part is a ~1 ms single-workgroup
+// tail when the whole call is only a few million updates: occupancy-grid sampling, ~10 samples per ray), and it is
+// the capacity of a hashed bin whenever there are hashed levels, so that every hashed bin is ONE part: a bin cut
+// in two flushes both halves with 16 384 float atomics (memory-side, ~18 G/s chip-wide) instead of one coalesced
+// read-modify-write.  <= 2^23 updates of magnitude < 2^38 cannot overflow the 64-bit fixed-point sums.
+constexpr int64_t PART_ENTRIES_MIN = 1 << 16, PART_ENTRIES_MAX = 1 << 23;
+inline int64_t part_entries_for(int64_t n, int64_t hashed_cap) {
+    int64_t p = hashed_cap;
+    if (p == 0) {                                    // dense levels only: ~1 024 parts
+        p = PART_ENTRIES_MIN;
+        while (p < (1 << 21) && p * 1024 < n * 128) p <<= 1;
+    }
+    return p < PART_ENTRIES_MIN ? PART_ENTRIES_MIN : (p > PART_ENTRIES_MAX ? PART_ENTRIES_MAX : p);
+}
 // max |update| per level is published with atomicMax: spread over LMAX_SLOTS cache lines per level and
 // only raised when the value actually grows, so the workgroups do not queue on one memory channel.
 constexpr int LMAX_SLOTS = 8, LMAX_STRIDE = 32;      // u32 words between slots (128 B)
@@ -62,18 +70,33 @@ constexpr int LMAX_WORDS = REN_MAX_LEVELS * LMAX_SLOTS * LMAX_STRIDE;
 
 struct BinTab {
     int bin_base[REN_MAX_LEVELS + 1];                // first global bin of each level
-    uint32_t pair[REN_MAX_LEVELS];                   // 1: the level is staged as 16-byte pair records
-    int first_part[REN_MAX_LEVELS + 1];              // accumulate grid: parts of level l are [first_part[l], first_part[l+1])
-    int parts_per_bin[REN_MAX_LEVELS];               // a bin's slabs are split into this many ranges of scatter workgroups
+    // Hashed levels are NOT counted: the hash spreads the 8 n updates of a level evenly over its bins (binomial,
+    // sigma/mean ~ 7e-4 at config B), so every bin of a hashed level gets a region of `cap` entries (mean + 2 %
+    // + 4096); an update that would not fit falls back to a global atomic (never seen, kept for correctness).
+    // cap = 0: dense level, regions sized by the count pass.  The count pass looks at one sample block in
+    // `cnt_stride` (rays of a batch are i.i.d., so blocks are exchangeable) and the offsets kernel scales the
+    // sampled count back up with a 25 % + 4096 margin; the same overflow fallback keeps it exact.
+    uint32_t cap[REN_MAX_LEVELS];
+    uint32_t pair[REN_MAX_LEVELS];                   // 1: the level's bins hold 16-byte pair records (cap counts records)
+    int cnt_stride;
+    int halve;                                       // test hook (REN_HGB_HALVE_REGIONS=1): force the overflow path
 };
 
-struct Workspace {
-    uint32_t *level_max;                             // float bits of max |update|, [level][slot] one line each
-    uint32_t *dir;                                   // [level][scatter workgroup][64 bins]: start | count << 16
-    char *slabs;                                     // [level][scatter workgroup] SLAB_BYTES each
-    int64_t n_wg;                                    // scatter workgroups = ceil(n / SC_THREADS)
+struct Part {
+    uint32_t gbin, single;
+    uint64_t begin, end;                             // entries, relative to the bin's region
 };
-constexpr int PAIR_BIN_SHIFT = 26;                   // pair record code: idx0 | idx1 << 13 | bin << 26 (bin: LDS staging only)
+
+// Staging pool: bin b owns 16-byte slots [bin_start[b], bin_start[b+1]).  Single-update regions hold
+// float2 v[bin_cap] followed by u16 idx[bin_cap]; pair regions hold float4 records[bin_cap].
+struct Workspace {
+    uint32_t *counts, *level_max, *cursors, *n_parts;     // level_max: float bits of max |update|, [level][slot] one line each
+    uint32_t *bin_cap;                                    // entries the region can take
+    uint64_t *bin_start;                                  // first 16-byte slot of the region
+    Part *parts;
+    char *pool;
+};
+constexpr int PAIR_BIN_SHIFT = 26;                        // pair record code: idx0 | idx1 << 13 | bin << 26 (bin: LDS staging only)
 
 // optional tangent inputs (log-intensity-gradient loss): update = w * dfeat + wdot * dfeatd
 struct TanSrc {
@@ -195,7 +218,119 @@ __device__ __forceinline__ uint32_t bin_rank(bool dense, bool emit, uint32_t bin
     return rank;
 }
 
-// ---- 1. scatter (counting sort by bin inside the workgroup, one contiguous slab per level) --------------------
+// ---- 1. count ------------------------------------------------------------------------------------
+// One thread walks all levels of its 4 samples; the per-(level, bin) histogram lives in LDS and reaches
+// the global counters once per workgroup (the counters are memory-side atomics, ~18 G/s chip-wide).
+template <bool TAN>
+__global__ __launch_bounds__(CNT_THREADS) void bin_count_kernel(GridDev g, BinTab bt, SampleArgs a,
+                                                                uint32_t *__restrict__ counts) {
+    __shared__ uint32_t hist[MAX_BINS];
+    for (int t = threadIdx.x; t < MAX_BINS; t += CNT_THREADS) hist[t] = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+#pragma unroll 1
+    for (int k = 0; k < CNT_SAMPLES / CNT_THREADS; ++k) {
+        const int64_t i = (int64_t)blockIdx.x * bt.cnt_stride * CNT_SAMPLES + k * CNT_THREADS + threadIdx.x;
+        const bool inb = i < a.n;
+        float u[3] = {0.f, 0.f, 0.f}, ud[3];
+        if (inb) unit_pos<TAN>(a, i, u, ud);
+#pragma unroll 1
+        for (int lvl = 0; lvl < g.n_levels; ++lvl) {
+            if (bt.cap[lvl]) continue;                               // hashed level: capacity-sized regions, no count
+            float d0, d1, e0, e1;
+            const bool have = inb && load_dfeat<TAN>(a, g.n_levels, lvl, i, d0, d1, e0, e1);
+            const LevelPos p = level_pos(u[0], u[1], u[2], g.scale[lvl]);
+            const uint32_t res = g.res[lvl], size = g.size[lvl];
+            const bool hashed = g.hashed[lvl] != 0;
+            bool head;
+            const bool emit = run_tail(!hashed, have, cell_key(p), lane, head);
+            uint32_t idx[8];
+            corner_indices8(p.c[0], p.c[1], p.c[2], res, size, hashed, idx);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) (void)bin_rank(!hashed, emit, idx[c] >> BIN_SHIFT, lane, hist + lvl * MAX_BINS_PER_LEVEL);
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < MAX_BINS; t += CNT_THREADS) {
+        const int lvl = t / MAX_BINS_PER_LEVEL, bin = t % MAX_BINS_PER_LEVEL;
+        if (lvl < g.n_levels && bin < bt.bin_base[lvl + 1] - bt.bin_base[lvl] && hist[t])
+            atomicAdd(&counts[bt.bin_base[lvl] + bin], hist[t]);
+    }
+}
+
+// ---- 2. offsets: exclusive scan of the region sizes (count for dense bins, capacity for hashed bins) ------
+__global__ __launch_bounds__(MAX_BINS) void bin_offsets_kernel(int n_bins, BinTab bt, uint64_t capacity_slots,
+                                                               const uint32_t *__restrict__ counts,
+                                                               uint32_t *__restrict__ cursors,
+                                                               uint32_t *__restrict__ bin_cap,
+                                                               uint64_t *__restrict__ bin_start) {
+    __shared__ uint64_t s_cnt[MAX_BINS];
+    const int t = threadIdx.x;
+    uint64_t c = 0, slots = 0;
+    bool pair = false;
+    if (t < n_bins) {
+        int lvl = 0;
+        while (lvl + 1 < REN_MAX_LEVELS && t >= bt.bin_base[lvl + 1]) ++lvl;
+        pair = bt.pair[lvl] != 0;
+        c = bt.cap[lvl] ? bt.cap[lvl] : counts[t];
+        if (!bt.cap[lvl] && bt.cnt_stride > 1) c = c * bt.cnt_stride + c * bt.cnt_stride / 4 + 4096;
+        if (bt.halve) c = c / 2;
+        c &= ~(uint64_t)7;                                         // idx[] of a single-update region stays 16-byte aligned
+        slots = pair ? c : (c * 10 + 15) / 16;
+        cursors[t] = 0;
+    }
+    s_cnt[t] = slots;
+    __syncthreads();
+    for (int off = 1; off < MAX_BINS; off <<= 1) {
+        const uint64_t a = t >= off ? s_cnt[t - off] : 0;
+        __syncthreads();
+        s_cnt[t] += a;
+        __syncthreads();
+    }
+    // regions never leave the workspace: whatever does not fit takes the overflow path of the scatter
+    if (t < n_bins) {
+        const uint64_t start = s_cnt[t] - slots;
+        uint64_t room = start < capacity_slots ? capacity_slots - start : 0;
+        if (room > slots) room = slots;
+        if (room < slots) c = (pair ? room : room * 16 / 10) & ~(uint64_t)7;
+        bin_start[t] = start < capacity_slots ? start : capacity_slots;
+        bin_cap[t] = (uint32_t)c;
+    }
+    if (t == n_bins - 1) bin_start[n_bins] = s_cnt[t] < capacity_slots ? s_cnt[t] : capacity_slots;
+}
+
+// ---- 3b. work partition of the accumulate pass, from the ACTUAL fill of every bin region ---------------------
+__global__ __launch_bounds__(MAX_BINS) void bin_partition_kernel(int n_bins, uint64_t PART_ENTRIES,
+                                                                 const uint32_t *__restrict__ cursors,
+                                                                 const uint32_t *__restrict__ bin_cap,
+                                                                 Part *__restrict__ parts, uint32_t *__restrict__ n_parts) {
+    __shared__ uint32_t s_np[MAX_BINS];
+    const int t = threadIdx.x;
+    uint64_t c = 0;
+    if (t < n_bins) c = cursors[t] < bin_cap[t] ? cursors[t] : bin_cap[t];   // overflowing updates went to the table directly
+    const uint32_t np = (uint32_t)((c + PART_ENTRIES - 1) / PART_ENTRIES);
+    s_np[t] = np;
+    __syncthreads();
+    for (int off = 1; off < MAX_BINS; off <<= 1) {
+        const uint32_t b = t >= off ? s_np[t - off] : 0;
+        __syncthreads();
+        s_np[t] += b;
+        __syncthreads();
+    }
+    if (t == n_bins - 1) n_parts[0] = s_np[t];
+    const uint32_t pbase = s_np[t] - np;
+    for (uint32_t k = 0; k < np; ++k) {
+        Part p;
+        p.gbin = t; p.single = np == 1;
+        p.begin = (uint64_t)k * PART_ENTRIES;
+        p.end = k + 1 == np ? c : p.begin + PART_ENTRIES;
+        parts[pbase + k] = p;
+    }
+}
+
+// ---- 3. scatter (counting sort by bin inside the workgroup, coalesced append) ----------------------------
+// One sample per thread; the workgroup walks the levels and runs one
+// rank -> offsets -> LDS placement -> coalesced append pass per level over the same staging area.
 __device__ __forceinline__ void table_atomic(float *grad_table, uint32_t offset, uint32_t idx, float a, float b) {
     float *gt = grad_table + 2 * ((size_t)offset + idx);
     atomicAdd(gt, a);
@@ -208,9 +343,13 @@ __device__ __forceinline__ void table_atomic(float *grad_table, uint32_t offset,
 template <bool TAN, int KIND>
 __global__ __launch_bounds__(SC_THREADS, KIND == 1 ? REN_SC_WAVES_PAIR : REN_SC_WAVES) void bin_scatter_kernel(
     GridDev g, BinTab bt, SampleArgs a, Workspace ws, float *__restrict__ grad_table) {
-    __shared__ uint32_t hist[MAX_BINS_PER_LEVEL], loc[MAX_BINS_PER_LEVEL + 1];
-    __shared__ __attribute__((aligned(16))) unsigned char stage[KIND == 1 ? SC_PAIRS * 16 : SC_ENTRIES * 12];   // float4[]  |  key u32[] + v float2[]
+    __shared__ uint32_t hist[MAX_BINS_PER_LEVEL], loc[MAX_BINS_PER_LEVEL + 1], fit[MAX_BINS_PER_LEVEL];
+    // per bin: where staging position q of this pass goes in HBM (pointer - local offset of the bin's run):
+    // gp0 = float2 v[] (single updates) or float4 records[] (pairs), gp1 = u16 idx[] (single updates)
+    __shared__ char *gp0[MAX_BINS_PER_LEVEL], *gp1[MAX_BINS_PER_LEVEL];
+    __shared__ __attribute__((aligned(16))) unsigned char stage[KIND == 1 ? SC_THREADS * 4 * 16 : SC_ENTRIES * 12];   // float4[]  |  key u32[] + v float2[]
     __shared__ float wave_max[SC_THREADS / 64];
+    __shared__ int any_overflow;
     uint32_t *st_key = reinterpret_cast<uint32_t *>(stage);
     float2 *st_v = reinterpret_cast<float2 *>(stage + SC_ENTRIES * 4);
     float4 *st_p = reinterpret_cast<float4 *>(stage);
@@ -226,11 +365,8 @@ __global__ __launch_bounds__(SC_THREADS, KIND == 1 ? REN_SC_WAVES_PAIR : REN_SC_
         if (KIND == 1 && !bt.pair[lvl]) continue;
         if (KIND == 2 && bt.pair[lvl]) continue;
         if (tid < MAX_BINS_PER_LEVEL) hist[tid] = 0;
-        // level maximum seen so far: loaded here, needed after the ranking (the read may be stale: that only costs an atomic)
-        uint32_t *lmax_slot = ws.level_max + (lvl * LMAX_SLOTS + (int)(chunk % LMAX_SLOTS)) * LMAX_STRIDE;
-        uint32_t lmax_seen = 0;
-        if (tid == SC_THREADS - 1) lmax_seen = __builtin_nontemporal_load(lmax_slot);
-        lds_barrier();                                           // also: the previous level's slab has left the staging area
+        if (tid == 0) any_overflow = 0;
+        lds_barrier();                                           // also: previous level's append is done
         const uint32_t res = g.res[lvl], size = g.size[lvl];
         const bool hashed = g.hashed[lvl] != 0;
         const float scale = g.scale[lvl];
@@ -312,10 +448,12 @@ __global__ __launch_bounds__(SC_THREADS, KIND == 1 ? REN_SC_WAVES_PAIR : REN_SC_
             float m = 0.f;
 #pragma unroll
             for (int w = 0; w < SC_THREADS / 64; ++w) m = fmaxf(m, wave_max[w]);
-            // non-negative floats order like uints
-            if (__float_as_uint(m) > lmax_seen) atomicMax(lmax_slot, __float_as_uint(m));
+            uint32_t *slot = ws.level_max + (lvl * LMAX_SLOTS + (int)(chunk % LMAX_SLOTS)) * LMAX_STRIDE;
+            // non-negative floats order like uints; the plain read may be stale (that only costs an atomic)
+            if (__float_as_uint(m) > __builtin_nontemporal_load(slot)) atomicMax(slot, __float_as_uint(m));
         }
         if (tid < MAX_BINS_PER_LEVEL) {
+            const int nb = bt.bin_base[lvl + 1] - bt.bin_base[lvl];
             const uint32_t cnt = hist[tid];
             uint32_t inc = cnt;                                    // inclusive wave scan over the 64 bins -> local offsets
 #pragma unroll
@@ -325,7 +463,21 @@ __global__ __launch_bounds__(SC_THREADS, KIND == 1 ? REN_SC_WAVES_PAIR : REN_SC_
             }
             loc[tid] = inc - cnt;
             if (tid == MAX_BINS_PER_LEVEL - 1) loc[MAX_BINS_PER_LEVEL] = inc;
-            ws.dir[((int64_t)lvl * ws.n_wg + chunk) * MAX_BINS_PER_LEVEL + tid] = (inc - cnt) | (cnt << 16);   // start < 2^16... see static_assert
+            uint32_t room = cnt;
+            char *q0 = nullptr, *q1 = nullptr;
+            if (tid < nb && cnt) {
+                const int gb = bt.bin_base[lvl] + tid;
+                const uint32_t at = atomicAdd(&ws.cursors[gb], cnt);         // reserve the run in the bin's region
+                const uint32_t cap = ws.bin_cap[gb];
+                room = at >= cap ? 0u : (cap - at < cnt ? cap - at : cnt);
+                char *base = ws.pool + ws.bin_start[gb] * 16;
+                const int64_t first = (int64_t)at - (int64_t)(inc - cnt);    // region entry of staging position 0
+                if (pairs) q0 = base + first * 16;
+                else { q0 = base + first * 8; q1 = base + (int64_t)cap * 8 + first * 2; }
+            }
+            fit[tid] = room;                                           // entries of this run that fit the region
+            if (room < cnt) any_overflow = 1;
+            gp0[tid] = q0; gp1[tid] = q1;
         }
         lds_barrier();
         if (have) {
@@ -345,135 +497,109 @@ __global__ __launch_bounds__(SC_THREADS, KIND == 1 ? REN_SC_WAVES_PAIR : REN_SC_
         }
         lds_barrier();
         const uint32_t total = loc[MAX_BINS_PER_LEVEL];
-        char *slab = ws.slabs + ((int64_t)lvl * ws.n_wg + chunk) * SLAB_BYTES;
+        const bool ovf = any_overflow != 0;
         if (pairs) {
-            float4 *out = reinterpret_cast<float4 *>(slab);
-            for (uint32_t q = tid; q < total; q += SC_THREADS) out[q] = st_p[q];
-        } else {
-            float2 *out_v = reinterpret_cast<float2 *>(slab);
-            uint16_t *out_i = reinterpret_cast<uint16_t *>(slab + (size_t)SC_ENTRIES * 8);
             for (uint32_t q = tid; q < total; q += SC_THREADS) {
-                out_v[q] = st_v[q];
-                out_i[q] = (uint16_t)(st_key[q] & (BIN_ENTRIES - 1));
+                const float4 r = st_p[q];
+                const uint32_t code = __float_as_uint(r.x), b = code >> PAIR_BIN_SHIFT;
+                if (!ovf || q - loc[b] < fit[b]) {
+                    reinterpret_cast<float4 *>(gp0[b])[q] = r;
+                } else {                                               // region full (capacity-sized hashed bins only)
+                    const uint32_t i0 = (b << BIN_SHIFT) | (code & (BIN_ENTRIES - 1));
+                    const uint32_t i1 = (b << BIN_SHIFT) | ((code >> BIN_SHIFT) & (BIN_ENTRIES - 1));
+                    table_atomic(grad_table, g.offset[lvl], i0, (1.f - r.w) * r.y, (1.f - r.w) * r.z);
+                    table_atomic(grad_table, g.offset[lvl], i1, r.w * r.y, r.w * r.z);
+                }
+            }
+            continue;
+        }
+        for (uint32_t q = tid; q < total; q += SC_THREADS) {
+            const uint32_t ix = st_key[q], b = ix >> BIN_SHIFT;
+            const float2 v = st_v[q];
+            if (!ovf || q - loc[b] < fit[b]) {
+                reinterpret_cast<uint16_t *>(gp1[b])[q] = (uint16_t)(ix & (BIN_ENTRIES - 1));
+                reinterpret_cast<float2 *>(gp0[b])[q] = v;
+            } else {
+                table_atomic(grad_table, g.offset[lvl], ix, v.x, v.y);
             }
         }
     }
 }
-static_assert(SC_ENTRIES <= 65535, "directory entries pack start and count in 16 bits each");
 
-// ---- 2. accumulate one bin part in LDS, flush to the gradient table -------------------------------------------
+// ---- 4. accumulate one bin part in LDS, flush to the gradient table -------------------------------------------
 // LDS float atomics are lane-serialised on gfx950 (ds_add_f32: 0.37 lanes/clk/CU measured), integer
 // ones are 3x faster, so the sums are formed in 64-bit fixed point: q = round(v * 2^k) with
-// 2^k * max|v| ~ 2^38, i.e. a quantum of 4e-12 of the level's largest update; 2^25 updates per part
+// 2^k * max|v| ~ 2^38, i.e. a quantum of 4e-12 of the level's largest update; 2^21 updates per part
 // cannot overflow, and the result is MORE accurate than an fp32 running sum.
 __device__ __forceinline__ long long to_fixed(float v, double scale) {
     return __double2ll_rn((double)v * scale);
 }
 
-constexpr int ACC_THREADS = 1024, ACC_TILE = 1024;    // directory entries staged per round (one per thread)
-
-__global__ __launch_bounds__(ACC_THREADS) void bin_accumulate_kernel(GridDev g, BinTab bt, Workspace ws,
-                                                                     float *__restrict__ grad_table) {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long acc[];   // acc0[8192] | acc1[8192] | dir tile
+__global__ __launch_bounds__(1024) void bin_accumulate_kernel(GridDev g, BinTab bt, Workspace ws,
+                                                              float *__restrict__ grad_table) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long acc[];   // acc0[8192] | acc1[8192]
+    if (blockIdx.x >= ws.n_parts[0]) return;
+    const Part part = ws.parts[blockIdx.x];
     unsigned long long *acc0 = acc, *acc1 = acc + BIN_ENTRIES;
-    uint32_t *tile = reinterpret_cast<uint32_t *>(acc + 2 * BIN_ENTRIES);
-    const int tid = threadIdx.x;
+    for (int e = threadIdx.x; e < 2 * BIN_ENTRIES; e += 1024) acc[e] = 0ull;
     int lvl = 0;
-    while (lvl + 1 < g.n_levels && (int)blockIdx.x >= bt.first_part[lvl + 1]) ++lvl;
-    const int ppb = bt.parts_per_bin[lvl];
-    const int rel = (int)blockIdx.x - bt.first_part[lvl];
-    const int bin = rel / ppb, part = rel - bin * ppb;
-    const int64_t w0 = ws.n_wg * part / ppb, w1 = ws.n_wg * (part + 1) / ppb;
-    for (int e = tid; e < 2 * BIN_ENTRIES; e += ACC_THREADS) acc[e] = 0ull;
+    while (lvl + 1 < g.n_levels && (int)part.gbin >= bt.bin_base[lvl + 1]) ++lvl;
     int ex;
     uint32_t lmax = 0;
     for (int k = 0; k < LMAX_SLOTS; ++k) lmax = max(lmax, ws.level_max[(lvl * LMAX_SLOTS + k) * LMAX_STRIDE]);
     (void)frexpf(__uint_as_float(lmax), &ex);                     // level max < 2^ex
     const double scale = ldexp(1.0, 38 - ex), inv_scale = ldexp(1.0, ex - 38);
-    const uint32_t *dir = ws.dir + (int64_t)lvl * ws.n_wg * MAX_BINS_PER_LEVEL + bin;
-    const char *slabs = ws.slabs + (int64_t)lvl * ws.n_wg * SLAB_BYTES;
-    const bool pairs = bt.pair[lvl] != 0;
-    auto add_pair = [&](const float4 &r) {
-        const uint32_t code = __float_as_uint(r.x);
-        const uint32_t i0 = code & (BIN_ENTRIES - 1), i1 = (code >> BIN_SHIFT) & (BIN_ENTRIES - 1);
-        const float f0 = 1.f - r.w;
-        atomicAdd(&acc0[i0], (unsigned long long)to_fixed(f0 * r.y, scale));      // ds_add_u64
-        atomicAdd(&acc1[i0], (unsigned long long)to_fixed(f0 * r.z, scale));
-        atomicAdd(&acc0[i1], (unsigned long long)to_fixed(r.w * r.y, scale));
-        atomicAdd(&acc1[i1], (unsigned long long)to_fixed(r.w * r.z, scale));
-    };
-    uint32_t next = w0 + tid < w1 ? dir[(w0 + tid) * MAX_BINS_PER_LEVEL] : 0u;     // directory column, one tile ahead
-    for (int64_t t0 = w0; t0 < w1; t0 += ACC_TILE) {
-        __syncthreads();                                          // zeroing / previous tile done
-        tile[tid] = next;
-        const int64_t tn = t0 + ACC_TILE + tid;
-        next = tn < w1 ? dir[tn * MAX_BINS_PER_LEVEL] : 0u;
-        __syncthreads();
-        const int n_tile = (int)(w1 - t0 < ACC_TILE ? w1 - t0 : ACC_TILE);
-        if (pairs) {
-            // half a wave per slab (a hashed bin holds ~32 +- 6 of a slab's 2 048 records), four slabs in flight
-            const int hw = tid >> 5, hl = tid & 31;
-            for (int j = hw; j < n_tile; j += 4 * (ACC_THREADS / 32)) {
-                uint32_t st[4], cn[4];
-                const float4 *rec[4];
-                float4 r[4][2];
+    const char *base = ws.pool + ws.bin_start[part.gbin] * 16;
+    __syncthreads();
+    uint64_t e = part.begin + threadIdx.x;
+    if (bt.pair[lvl]) {
+        const float4 *rec = reinterpret_cast<const float4 *>(base);
+        auto add = [&](const float4 &r) {
+            const uint32_t code = __float_as_uint(r.x);
+            const uint32_t i0 = code & (BIN_ENTRIES - 1), i1 = (code >> BIN_SHIFT) & (BIN_ENTRIES - 1);
+            const float f0 = 1.f - r.w;
+            atomicAdd(&acc0[i0], (unsigned long long)to_fixed(f0 * r.y, scale));      // ds_add_u64
+            atomicAdd(&acc1[i0], (unsigned long long)to_fixed(f0 * r.z, scale));
+            atomicAdd(&acc0[i1], (unsigned long long)to_fixed(r.w * r.y, scale));
+            atomicAdd(&acc1[i1], (unsigned long long)to_fixed(r.w * r.z, scale));
+        };
+        for (; e + 3 * 1024 < part.end; e += 4 * 1024) {           // 4 independent 16-byte loads in flight per lane
+            float4 r[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int ju = j + u * (ACC_THREADS / 32);
-                    const uint32_t d = ju < n_tile ? tile[ju] : 0u;
-                    st[u] = d & 0xFFFFu; cn[u] = d >> 16;
-                    rec[u] = reinterpret_cast<const float4 *>(slabs + (t0 + ju) * SLAB_BYTES) + st[u];
+            for (int u = 0; u < 4; ++u) r[u] = rec[e + u * 1024];
 #pragma unroll
-                    for (int k = 0; k < 2; ++k)
-                        if (hl + 32 * k < cn[u]) r[u][k] = rec[u][hl + 32 * k];
-                }
+            for (int u = 0; u < 4; ++u) add(r[u]);
+        }
+        for (; e < part.end; e += 1024) add(rec[e]);
+    } else {
+        const float2 *out_v = reinterpret_cast<const float2 *>(base);
+        const uint16_t *out_idx = reinterpret_cast<const uint16_t *>(base + (size_t)ws.bin_cap[part.gbin] * 8);
+        for (; e + 3 * 1024 < part.end; e += 4 * 1024) {           // 4 independent loads in flight per lane
+            uint32_t ix[4]; float2 v[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 4; ++u) { ix[u] = out_idx[e + u * 1024]; v[u] = out_v[e + u * 1024]; }
 #pragma unroll
-                    for (int k = 0; k < 2; ++k)
-                        if (hl + 32 * k < cn[u]) add_pair(r[u][k]);
-                    for (uint32_t q = hl + 64; q < cn[u]; q += 32) add_pair(rec[u][q]);    // crowded bin (clustered samples)
-                }
+            for (int u = 0; u < 4; ++u) {
+                atomicAdd(&acc0[ix[u]], (unsigned long long)to_fixed(v[u].x, scale));    // ds_add_u64
+                atomicAdd(&acc1[ix[u]], (unsigned long long)to_fixed(v[u].y, scale));
             }
-        } else {
-            // a wave per slab: dense bins hold anything from nothing to the whole slab
-            const int wv = tid >> 6, ln = tid & 63;
-            for (int j = wv; j < n_tile; j += ACC_THREADS / 64) {
-                const uint32_t d = tile[j];
-                const uint32_t st = d & 0xFFFFu, cn = d >> 16;
-                if (cn == 0) continue;
-                const char *slab = slabs + (t0 + j) * SLAB_BYTES;
-                const float2 *pv = reinterpret_cast<const float2 *>(slab) + st;
-                const uint16_t *pi = reinterpret_cast<const uint16_t *>(slab + (size_t)SC_ENTRIES * 8) + st;
-                uint32_t q = ln;
-                for (; q + 3 * 64 < cn; q += 4 * 64) {             // 4 independent loads in flight per lane
-                    uint32_t ix[4]; float2 v[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) { ix[u] = pi[q + u * 64]; v[u] = pv[q + u * 64]; }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        atomicAdd(&acc0[ix[u]], (unsigned long long)to_fixed(v[u].x, scale));
-                        atomicAdd(&acc1[ix[u]], (unsigned long long)to_fixed(v[u].y, scale));
-                    }
-                }
-                for (; q < cn; q += 64) {
-                    const uint32_t ix = pi[q];
-                    const float2 v = pv[q];
-                    atomicAdd(&acc0[ix], (unsigned long long)to_fixed(v.x, scale));
-                    atomicAdd(&acc1[ix], (unsigned long long)to_fixed(v.y, scale));
-                }
-            }
+        }
+        for (; e < part.end; e += 1024) {
+            const uint32_t idx = out_idx[e];
+            const float2 v = out_v[e];
+            atomicAdd(&acc0[idx], (unsigned long long)to_fixed(v.x, scale));
+            atomicAdd(&acc1[idx], (unsigned long long)to_fixed(v.y, scale));
         }
     }
     __syncthreads();
-    const uint32_t first = (uint32_t)bin << BIN_SHIFT;             // first entry of the bin in its level
+    const uint32_t first = ((uint32_t)part.gbin - bt.bin_base[lvl]) << BIN_SHIFT;   // first entry of the bin in its level
     const uint32_t lim = g.size[lvl] > first ? g.size[lvl] - first : 0;
     float2 *gt = reinterpret_cast<float2 *>(grad_table) + g.offset[lvl] + first;
-    for (uint32_t k = tid; k < BIN_ENTRIES && k < lim; k += ACC_THREADS) {
+    for (uint32_t k = threadIdx.x; k < BIN_ENTRIES && k < lim; k += 1024) {
         const long long qa = (long long)acc0[k], qb = (long long)acc1[k];
         if (qa == 0 && qb == 0) continue;
         const float a = (float)((double)qa * inv_scale), b = (float)((double)qb * inv_scale);
-        if (ppb == 1) {                                            // exclusive owner: plain coalesced RMW
+        if (part.single) {                                         // exclusive owner: plain coalesced RMW
             float2 v = gt[k];
             v.x += a; v.y += b;
             gt[k] = v;
@@ -486,15 +612,26 @@ __global__ __launch_bounds__(ACC_THREADS) void bin_accumulate_kernel(GridDev g, 
 
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-struct Layout { size_t level_max, dir, slabs, total; int64_t n_wg; };
+struct Layout { size_t counts, level_max, cursors, n_parts, bin_cap, bin_start, parts, pool, total, slots; int64_t entries, max_parts; };
 
 Layout make_layout(int64_t n) {
     Layout L;
-    L.n_wg = (n + SC_THREADS - 1) / SC_THREADS;
+    // at most 128 n single updates of 10 B (16 levels x 8 corners; pair records are 16 B for two) + capacity
+    // slack: 2 % of the hashed and 25 % of the dense levels, 4096 per bin, one stride of count blocks; the
+    // offsets kernel clamps the regions to this total
+    const size_t E = (size_t)n * 140 + (size_t)MAX_BINS * 4096 + 16 * 8 * 16 * CNT_SAMPLES;
+    L.entries = (int64_t)E;
+    L.slots = (E * 10 + 15) / 16 + MAX_BINS;
+    L.max_parts = (int64_t)(E / PART_ENTRIES_MIN) + MAX_BINS + 1;   // room for the smallest part size
     size_t o = 0;
+    L.counts = o; o += MAX_BINS * 4;                       // counts | level_max are cleared by one memset
     L.level_max = o; o = align256(o + LMAX_WORDS * 4);
-    L.dir = o; o = align256(o + (size_t)REN_MAX_LEVELS * L.n_wg * MAX_BINS_PER_LEVEL * 4);
-    L.slabs = o; o = align256(o + (size_t)REN_MAX_LEVELS * L.n_wg * SLAB_BYTES);
+    L.cursors = o; o = align256(o + MAX_BINS * 4);
+    L.n_parts = o; o = align256(o + 4);
+    L.bin_cap = o; o = align256(o + MAX_BINS * 4);
+    L.bin_start = o; o = align256(o + (MAX_BINS + 1) * 8);
+    L.parts = o; o = align256(o + (size_t)L.max_parts * sizeof(Part));
+    L.pool = o; o = align256(o + L.slots * 16);
     L.total = o;
     return L;
 }
@@ -518,60 +655,72 @@ static int binned_impl(const ren_grid_desc *grid, float *grad_table, const float
     const bool from_rays = x_unit == nullptr;
     if (from_rays && (!scene || !rays_o || !rays_d || !ray_indices || !t_starts || !t_ends)) return REN_ERR_BAD_ARG;
     if (layout == 1 && g.n_levels != REN_MAX_LEVELS) return REN_ERR_UNSUPPORTED;
-    if (n >= ((int64_t)1 << 28)) return REN_ERR_UNSUPPORTED;      // 2^25 updates per accumulate part keep the fixed-point sums exact
+    if (n >= ((int64_t)1 << 28)) return REN_ERR_UNSUPPORTED;      // 8 n updates per level must fit uint32
     BinTab bt;
-    const char *no_pairs = getenv("REN_HGB_NO_PAIRS");             // verification knob: single-update records everywhere
-    const bool use_pairs = !tan.dfeatd && !(no_pairs && no_pairs[0] == '1');
-    int nb = 0, np = 0;
-    bool any_pair = false, any_single = false;
+    int nb = 0;
     for (int l = 0; l < REN_MAX_LEVELS; ++l) {
         bt.bin_base[l] = nb;
-        bt.first_part[l] = np;
-        bt.pair[l] = 0;
-        bt.parts_per_bin[l] = 1;
         if (l < g.n_levels) {
             if (g.size[l] > (uint32_t)(MAX_BINS_PER_LEVEL << BIN_SHIFT)) return REN_ERR_UNSUPPORTED;
-            const int bins = (int)((g.size[l] + BIN_ENTRIES - 1) >> BIN_SHIFT);
-            if (g.hashed[l]) {
-                bt.pair[l] = use_pairs ? 1 : 0;                   // 4 pair records instead of 8 updates per sample
-            } else {
-                // dense level: split every bin's slabs into ranges of about PART_RECORDS updates (upper bound 8 n / bins)
-                int64_t ppb = (8 * n / bins + PART_RECORDS - 1) / PART_RECORDS;
-                const int64_t n_wg = (n + SC_THREADS - 1) / SC_THREADS;
-                if (ppb > n_wg) ppb = n_wg;
-                bt.parts_per_bin[l] = (int)(ppb < 1 ? 1 : (ppb > MAX_PARTS_PER_BIN ? MAX_PARTS_PER_BIN : ppb));
-            }
-            (bt.pair[l] ? any_pair : any_single) = true;
-            nb += bins;
-            np += bins * bt.parts_per_bin[l];
+            nb += (int)((g.size[l] + BIN_ENTRIES - 1) >> BIN_SHIFT);
         }
     }
     bt.bin_base[REN_MAX_LEVELS] = nb;
-    bt.first_part[REN_MAX_LEVELS] = np;
+    for (int l = g.n_levels; l < REN_MAX_LEVELS; ++l) bt.bin_base[l] = nb;
+    int64_t hashed_cap = 0;
+    const char *no_pairs = getenv("REN_HGB_NO_PAIRS");             // verification knob: single-update records everywhere
+    const bool use_pairs = !tan.dfeatd && !(no_pairs && no_pairs[0] == '1');
+    for (int l = 0; l < REN_MAX_LEVELS; ++l) {
+        bt.cap[l] = 0;
+        bt.pair[l] = 0;
+        if (l < g.n_levels && g.hashed[l]) {
+            const int64_t bins = (g.size[l] + BIN_ENTRIES - 1) >> BIN_SHIFT;
+            bt.pair[l] = use_pairs ? 1 : 0;                       // 4 pair records instead of 8 updates per sample
+            const int64_t mean = ((use_pairs ? 4 : 8) * n + bins - 1) / bins;
+            bt.cap[l] = (uint32_t)(mean + mean / 50 + 4096);
+            if ((int64_t)bt.cap[l] > hashed_cap) hashed_cap = bt.cap[l];
+        }
+    }
+    const int64_t part_entries = part_entries_for(n, hashed_cap);
     if (n == 0) return REN_OK;
     ren_scene_dev sc = {};
     if (scene) sc = ren_make_scene(scene);
     const Layout L = make_layout(n);
     char *w = (char *)workspace;
     Workspace ws;
-    ws.level_max = (uint32_t *)(w + L.level_max);
-    ws.dir = (uint32_t *)(w + L.dir);
-    ws.slabs = w + L.slabs;
-    ws.n_wg = L.n_wg;
+    ws.counts = (uint32_t *)(w + L.counts); ws.level_max = (uint32_t *)(w + L.level_max);
+    ws.cursors = (uint32_t *)(w + L.cursors);
+    ws.n_parts = (uint32_t *)(w + L.n_parts); ws.bin_cap = (uint32_t *)(w + L.bin_cap);
+    ws.bin_start = (uint64_t *)(w + L.bin_start);
+    ws.parts = (Part *)(w + L.parts); ws.pool = w + L.pool;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(ws.level_max, 0, LMAX_WORDS * 4, st) != hipSuccess) return REN_ERR_LAUNCH;
+    if (hipMemsetAsync(ws.counts, 0, (MAX_BINS + LMAX_WORDS) * 4, st) != hipSuccess) return REN_ERR_LAUNCH;
     SampleArgs a;
     a.layout = layout; a.dfeat = dfeat; a.x_unit = x_unit; a.sc = sc; a.rays_o = rays_o; a.rays_d = rays_d;
     a.ray_indices = ray_indices; a.t_starts = t_starts; a.t_ends = t_ends; a.n = n; a.tan = tan;
-    const dim3 sgrd((unsigned)L.n_wg), sblk(SC_THREADS);
+    const char *halve = getenv("REN_HGB_HALVE_REGIONS");
+    bt.halve = halve && halve[0] == '1';
+    const int64_t cnt_blocks = (n + CNT_SAMPLES - 1) / CNT_SAMPLES;
+    bt.cnt_stride = cnt_blocks >= 4096 ? 16 : cnt_blocks >= 2048 ? 8 : cnt_blocks >= 1024 ? 4 : 1;   // >= 256 sampled blocks or exact
+    const dim3 cgrd((unsigned)((cnt_blocks + bt.cnt_stride - 1) / bt.cnt_stride)), cblk(CNT_THREADS);
+    const dim3 sgrd((unsigned)((n + SC_THREADS - 1) / SC_THREADS)), sblk(SC_THREADS);
+    if (tan.dfeatd) hipLaunchKernelGGL(bin_count_kernel<true>, cgrd, cblk, 0, st, g, bt, a, ws.counts);
+    else            hipLaunchKernelGGL(bin_count_kernel<false>, cgrd, cblk, 0, st, g, bt, a, ws.counts);
+    hipLaunchKernelGGL(bin_offsets_kernel, dim3(1), dim3(MAX_BINS), 0, st, nb, bt, (uint64_t)L.slots, ws.counts,
+                       ws.cursors, ws.bin_cap, ws.bin_start);
+    bool any_pair = false, any_single = false;
+    for (int l = 0; l < g.n_levels; ++l) { any_pair |= bt.pair[l] != 0; any_single |= bt.pair[l] == 0; }
     if (tan.dfeatd) hipLaunchKernelGGL((bin_scatter_kernel<true, 0>), sgrd, sblk, 0, st, g, bt, a, ws, grad_table);
     else {
         if (any_pair)   hipLaunchKernelGGL((bin_scatter_kernel<false, 1>), sgrd, sblk, 0, st, g, bt, a, ws, grad_table);
         if (any_single) hipLaunchKernelGGL((bin_scatter_kernel<false, 2>), sgrd, sblk, 0, st, g, bt, a, ws, grad_table);
     }
-    const size_t acc_lds = 2 * BIN_ENTRIES * sizeof(unsigned long long) + ACC_TILE * 4;
+    hipLaunchKernelGGL(bin_partition_kernel, dim3(1), dim3(MAX_BINS), 0, st, nb, (uint64_t)part_entries, ws.cursors, ws.bin_cap, ws.parts,
+                       ws.n_parts);
+    const size_t acc_lds = 2 * BIN_ENTRIES * sizeof(unsigned long long);
     (void)hipFuncSetAttribute((const void *)bin_accumulate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)acc_lds);
-    hipLaunchKernelGGL(bin_accumulate_kernel, dim3((unsigned)np), dim3(ACC_THREADS), acc_lds, st, g, bt, ws, grad_table);
+    const int64_t acc_grid = (int64_t)(L.entries / part_entries) + nb + 1;
+    hipLaunchKernelGGL(bin_accumulate_kernel, dim3((unsigned)acc_grid), dim3(1024), acc_lds, st, g, bt, ws, grad_table);
     REN_CHECK_LAUNCH();
 }
 
