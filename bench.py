@@ -144,6 +144,9 @@ def main():
                     help="> 1: hash encoding and MLP forward of alternate sample chunks on two HIP streams")
     ap.add_argument("--mlp-kernels", default="x", choices=["x", "f32"],
                     help="x = split-bf16 matrix-core MLP kernels at fp32 accuracy (default), f32 = exact f32-MFMA kernels")
+    ap.add_argument("--save-activations", type=int, default=-1, choices=[-1, 0, 1],
+                    help="1: the training forward stores the hidden MLP activations (768 B/sample), 0: the backward recomputes "
+                         "them, -1 (default): recompute with the x kernels, save with the exact-f32 kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
@@ -197,7 +200,8 @@ def main():
 
     aabb = (-1.5, -1.5, -1.5, 1.5, 1.5, 1.5)
     cfg = engine.RenderCfg(aabb=aabb, sampler=args.sampler, n_uniform=args.samples, mlp_bf16=args.mlp_bf16,
-                           mlp_kernels=args.mlp_kernels, fwd_chunks=args.fwd_chunks)
+                           mlp_kernels=args.mlp_kernels, fwd_chunks=args.fwd_chunks,
+                           save_activations=None if args.save_activations < 0 else bool(args.save_activations))
     if args.arch == "mlp":
         from robust_e_nerf_amd import vanilla
         fld = vanilla.VanillaField(dev, 1)

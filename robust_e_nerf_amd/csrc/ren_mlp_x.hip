@@ -420,23 +420,43 @@ struct BwdXHArgs {
     float *d_base, *slab;
 };
 
-template <int C, int MODE>
+// RECOMP: the hidden activations p, q are recomputed from the saved base outputs with the forward's own MFMA
+// sequence (bit-identical to what the forward would have stored) instead of being loaded: 512 B/sample less HBM
+// traffic each way (the forward then writes 64 B/sample instead of 832).
+template <int MODE, bool RECOMP> struct HeadLds {
+    static constexpr int NT = Pairs<MODE>::NT;
+    static constexpr int F_WH2T = 0, F_WH1T = 2 * 4 * NT * 512, F_WH1 = F_WH1T + 1 * 4 * NT * 512;    // bf16 elements
+    static constexpr int F_WH2 = F_WH1 + (RECOMP ? 2 * 2 * NT * 512 : 0), F_END = F_WH2 + (RECOMP ? 2 * 4 * NT * 512 : 0);
+    static constexpr int T_W3 = 0, T_BH1 = 256, T_BH2 = 320, T_END = 384;                          // f32 tail
+    static constexpr int TAIL_BYTES = T_END * 4;
+};
+
+template <int C, int MODE, bool RECOMP>
 __global__ __launch_bounds__(256, 1) void mlp_bwd_head_x_kernel(BwdXHArgs a) {
     using PR = Pairs<MODE>;
+    using HL = HeadLds<MODE, RECOMP>;
     constexpr int NT = PR::NT, NP = MODE == 1 ? 1 : 2;
-    constexpr int F_WH2T = 0, F_WH1T = 2 * 4 * NT * 512, F_END = F_WH1T + 1 * 4 * NT * 512;
+    constexpr int F_WH2T = HL::F_WH2T, F_WH1T = HL::F_WH1T, F_END = HL::F_END;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __bf16 *frag = reinterpret_cast<__bf16 *>(smem);
-    float *w3 = reinterpret_cast<float *>(smem + F_END * 2);                       // [C][64] (+ pad)
+    float *w3 = reinterpret_cast<float *>(smem + F_END * 2);                       // [C][64] (+ pad), then bh1[64] bh2[64]
     fill_frags_t<NT, 3>(frag + F_WH2T, a.params, 2, 4);                            // head.w1^T : rows = p index
     fill_frags_t<NT, 2>(frag + F_WH1T, a.params, 1, 4);                            // head.w0^T : rows = v index
+    if (RECOMP) {
+        fill_frags<NT, 2>(frag + HL::F_WH1, a.params, 2, 2);                       // forward fragments of head.w0, head.w1
+        fill_frags<NT, 3>(frag + HL::F_WH2, a.params, 2, 4);
+        for (int i = threadIdx.x; i < 64; i += blockDim.x) {
+            w3[HL::T_BH1 + i] = a.params[P_HB0 + i];
+            w3[HL::T_BH2 + i] = a.params[P_HB1 + i];
+        }
+    }
     for (int i = threadIdx.x; i < 64 * C; i += blockDim.x) {
         const float w = a.params[P_HWO + i];
         w3[i] = MODE == 1 ? (float)(__bf16)w : w;
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int hi = lane >> 5, sl = lane & 31;
-    __bf16 *Tz = reinterpret_cast<__bf16 *>(smem + F_END * 2 + 256 * 4) + wave * (3 * NP * 32 * ST);
+    __bf16 *Tz = reinterpret_cast<__bf16 *>(smem + F_END * 2 + HL::TAIL_BYTES) + wave * (3 * NP * 32 * ST);
     __bf16 *Ta = Tz + NP * 32 * ST, *Ta2 = Ta + NP * 32 * ST;
     __syncthreads();
     const int64_t n_blk = (a.n + 31) >> 5;
@@ -479,7 +499,36 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_head_x_kernel(BwdXHArgs a) {
             for (int g = 0; g < 8; ++g) o[g] = bo[g * 64];
         }
         float p[2][16], q[2][16];
-        {
+        bf16x8 bp[4][3];                                           // RECOMP: split p, reused by the weight-gradient staging
+        if (RECOMP) {
+            bf16x8 bv[2][3];
+            split8<NT>(o, bv[0]);
+            split8<NT>(shs, bv[1]);
+            f32x16 pa[2], qa[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) pa[t][g] = W3[HL::T_BH1 + 32 * t + rowc(g) + 4 * hi];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) mma2<MODE>(pa[0], pa[1], fr + HL::F_WH1, 2, c, bv[c], lane);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                for (int g = 0; g < 16; ++g) p[t][g] = softplus100(pa[t][g]);
+                split8<NT>(p[t], bp[2 * t]);
+                split8<NT>(p[t] + 8, bp[2 * t + 1]);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) qa[t][g] = W3[HL::T_BH2 + 32 * t + rowc(g) + 4 * hi];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) mma2<MODE>(qa[0], qa[1], fr + HL::F_WH2, 4, c, bp[c], lane);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) q[t][g] = softplus100(qa[t][g]);
+        } else {
             const float *ac = a.acts + blk * ACT_SAVE_FLOATS_X + lane;
 #pragma unroll
             for (int t = 0; t < 2; ++t)
@@ -509,8 +558,13 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_head_x_kernel(BwdXHArgs a) {
                 acc_bh2[t][g] += dz2[t][g];
             }
         // ---- dW(head.w1)[ot][it] += dz2(ot) . p(it)^T ;  d p = W1^T dz2   (dz2 is split once for both)
-        stage_tile<NP>(Ta, p[0], hi, sl);
-        stage_tile<NP>(Ta2, p[1], hi, sl);
+        if (RECOMP) {
+            stage_pieces<NP>(Ta, bp[0], bp[1], hi, sl);
+            stage_pieces<NP>(Ta2, bp[2], bp[3], hi, sl);
+        } else {
+            stage_tile<NP>(Ta, p[0], hi, sl);
+            stage_tile<NP>(Ta2, p[1], hi, sl);
+        }
         f32x16 dp[2];
 #pragma unroll
         for (int g = 0; g < 16; ++g) { dp[0][g] = 0.f; dp[1][g] = 0.f; }
@@ -609,18 +663,31 @@ struct BwdXBArgs {
     float *dfeat, *slab;
 };
 
-template <int MODE>
+template <int MODE, bool RECOMP> struct BaseLds {
+    static constexpr int NT = Pairs<MODE>::NT;
+    static constexpr int F_W2T = 0, F_W1T = 2 * 1 * NT * 512, F_W1 = F_W1T + 1 * 4 * NT * 512;
+    static constexpr int F_END = F_W1 + (RECOMP ? 2 * 2 * NT * 512 : 0);
+    static constexpr int TAIL_BYTES = RECOMP ? 64 * 4 : 0;                                           // b1[64]
+};
+
+template <int MODE, bool RECOMP>
 __global__ __launch_bounds__(256, 2) void mlp_bwd_base_x_kernel(BwdXBArgs a) {
     using PR = Pairs<MODE>;
+    using BL = BaseLds<MODE, RECOMP>;
     constexpr int NT = PR::NT, NP = MODE == 1 ? 1 : 2;
-    constexpr int F_W2T = 0, F_W1T = 2 * 1 * NT * 512, F_END = F_W1T + 1 * 4 * NT * 512;
+    constexpr int F_W2T = BL::F_W2T, F_W1T = BL::F_W1T, F_END = BL::F_END;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __bf16 *frag = reinterpret_cast<__bf16 *>(smem);
+    float *b1 = reinterpret_cast<float *>(smem + F_END * 2);
     fill_frags_t<NT, 1>(frag + F_W2T, a.params, 2, 1);                             // base.wo^T : rows = h index, 1 chunk (16 outs)
     fill_frags_t<NT, 0>(frag + F_W1T, a.params, 1, 4);                             // base.w0^T : rows = feature index
+    if (RECOMP) {
+        fill_frags<NT, 0>(frag + BL::F_W1, a.params, 2, 2);                        // forward fragments of base.w0
+        for (int i = threadIdx.x; i < 64; i += blockDim.x) b1[i] = a.params[P_BB0 + i];
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int hi = lane >> 5, sl = lane & 31;
-    __bf16 *Tz = reinterpret_cast<__bf16 *>(smem + F_END * 2) + wave * (2 * NP * 32 * ST);
+    __bf16 *Tz = reinterpret_cast<__bf16 *>(smem + F_END * 2 + BL::TAIL_BYTES) + wave * (2 * NP * 32 * ST);
     __bf16 *Ta = Tz + NP * 32 * ST;
     for (int k = lane; k < 2 * NP * 32 * ST; k += 64) Tz[k] = (__bf16)0.f;          // dO rows 16..31 stay zero
     __syncthreads();
@@ -646,11 +713,30 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_base_x_kernel(BwdXBArgs a) {
             const float *db = a.d_base + blk * (8 * 64) + lane;
 #pragma unroll
             for (int g = 0; g < 8; ++g) dob[g] = db[g * 64];
-            const float *ac = a.acts + blk * ACT_SAVE_FLOATS_X + lane;
+            if (!RECOMP) {
+                const float *ac = a.acts + blk * ACT_SAVE_FLOATS_X + lane;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) h[t][g] = ac[(t * 16 + g) * 64];
+            }
+        }
+        bf16x8 bx[2][3];                                           // RECOMP: split x, reused by the weight-gradient staging
+        if (RECOMP) {
+            const float *B1 = b1 + zo;
+            split8<NT>(x, bx[0]);
+            split8<NT>(x + 8, bx[1]);
+            f32x16 ha[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int g = 0; g < 16; ++g) h[t][g] = ac[(t * 16 + g) * 64];
+                for (int g = 0; g < 16; ++g) ha[t][g] = B1[32 * t + rowc(g) + 4 * hi];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) mma2<MODE>(ha[0], ha[1], fr + BL::F_W1, 2, c, bx[c], lane);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) h[t][g] = softplus100(ha[t][g]);
         }
         // ---- dW(base.wo)[it] += dO . h(it)^T   (dO: 16 real rows of a 32-row tile)
 #pragma unroll
@@ -678,8 +764,15 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_base_x_kernel(BwdXBArgs a) {
                 acc_b1[t][g] += dz0[t][g];
             }
         // ---- dW(base.w0)[ot] += dz0(ot) . x^T   (x row = feature index 2 s + hi)
+        if (RECOMP) {
 #pragma unroll
-        for (int s = 0; s < 16; ++s) stage_one<NP>(Ta, 2 * s + hi, x[s], sl);
+            for (int k = 0; k < NP; ++k)
+#pragma unroll
+                for (int s = 0; s < 16; ++s) Ta[(k * 32 + 2 * s + hi) * ST + sl] = bx[s >> 3][k][s & 7];
+        } else {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) stage_one<NP>(Ta, 2 * s + hi, x[s], sl);
+        }
         // ---- d x = W0^T dz0 -> hash-feature gradient, fragment layout (dz0 is split once for both uses)
         f32x16 dxv, dxv2;
 #pragma unroll
@@ -737,21 +830,23 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_base_x_kernel(BwdXBArgs a) {
     }
 }
 
-template <int MODE>
+template <int MODE, bool RECOMP>
 int launch_bwd_x(const BwdXHArgs &h, const BwdXBArgs &b, int C, float *grad, hipStream_t st) {
-    constexpr int NT = Pairs<MODE>::NT, NP = MODE == 1 ? 1 : 2;
+    constexpr int NP = MODE == 1 ? 1 : 2;
+    using HL = HeadLds<MODE, RECOMP>;
+    using BL = BaseLds<MODE, RECOMP>;
     const size_t tile = (size_t)NP * 32 * ST * 2;
-    const size_t lds_h = (size_t)(2 * 4 + 4) * NT * 512 * 2 + 256 * 4 + 4 * 3 * tile;
-    const size_t lds_b = (size_t)(2 * 1 + 4) * NT * 512 * 2 + 4 * 2 * tile;
+    const size_t lds_h = (size_t)HL::F_END * 2 + HL::TAIL_BYTES + 4 * 3 * tile;
+    const size_t lds_b = (size_t)BL::F_END * 2 + BL::TAIL_BYTES + 4 * 2 * tile;
     if (C == 1) {
-        (void)hipFuncSetAttribute((const void *)mlp_bwd_head_x_kernel<1, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h);
-        hipLaunchKernelGGL((mlp_bwd_head_x_kernel<1, MODE>), dim3(GRID_XH), dim3(256), lds_h, st, h);
+        (void)hipFuncSetAttribute((const void *)mlp_bwd_head_x_kernel<1, MODE, RECOMP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h);
+        hipLaunchKernelGGL((mlp_bwd_head_x_kernel<1, MODE, RECOMP>), dim3(GRID_XH), dim3(256), lds_h, st, h);
     } else {
-        (void)hipFuncSetAttribute((const void *)mlp_bwd_head_x_kernel<3, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h);
-        hipLaunchKernelGGL((mlp_bwd_head_x_kernel<3, MODE>), dim3(GRID_XH), dim3(256), lds_h, st, h);
+        (void)hipFuncSetAttribute((const void *)mlp_bwd_head_x_kernel<3, MODE, RECOMP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h);
+        hipLaunchKernelGGL((mlp_bwd_head_x_kernel<3, MODE, RECOMP>), dim3(GRID_XH), dim3(256), lds_h, st, h);
     }
-    (void)hipFuncSetAttribute((const void *)mlp_bwd_base_x_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
-    hipLaunchKernelGGL((mlp_bwd_base_x_kernel<MODE>), dim3(GRID_XB), dim3(256), lds_b, st, b);
+    (void)hipFuncSetAttribute((const void *)mlp_bwd_base_x_kernel<MODE, RECOMP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
+    hipLaunchKernelGGL((mlp_bwd_base_x_kernel<MODE, RECOMP>), dim3(GRID_XB), dim3(256), lds_b, st, b);
     const int head_len = p_total(C) - P_BASE_N;
     launch_reduce_slabs(h.slab, GRID_XH * 4, head_len, grad + P_BASE_N, st);
     launch_reduce_slabs(b.slab, GRID_XB * 4, P_BASE_N, grad, st);
@@ -771,7 +866,8 @@ extern "C" int ren_mlp_bwd_x(const float *mlp_params, int32_t C, int32_t mode, c
                              const float *t_starts, const float *t_ends, int64_t n, const float *rgb,
                              const float *d_rgb, const float *d_sigma, float *d_base, float *dfeat,
                              float *grad_mlp_params, float *workspace, void *stream) {
-    if (!mlp_params || !feat || !base_out || !act_save || !scene || !rgb || !d_rgb || !d_sigma || !d_base || !dfeat ||
+    // act_save == nullptr: the hidden activations are recomputed from feat / base_out (the forward need not save them)
+    if (!mlp_params || !feat || !base_out || !scene || !rgb || !d_rgb || !d_sigma || !d_base || !dfeat ||
         !grad_mlp_params || !workspace || n < 0)
         return REN_ERR_BAD_ARG;
     if (C != 1 && C != 3) return REN_ERR_UNSUPPORTED;
@@ -787,6 +883,9 @@ extern "C" int ren_mlp_bwd_x(const float *mlp_params, int32_t C, int32_t mode, c
     BwdXBArgs b;
     b.params = mlp_params; b.feat = feat; b.d_base = d_base; b.acts = act_save; b.n = n; b.dfeat = dfeat;
     b.slab = workspace + (int64_t)GRID_XH * 4 * head_len;
-    return mode == 6 ? launch_bwd_x<6>(h, b, C, grad_mlp_params, (hipStream_t)stream)
-                     : launch_bwd_x<1>(h, b, C, grad_mlp_params, (hipStream_t)stream);
+    if (act_save)
+        return mode == 6 ? launch_bwd_x<6, false>(h, b, C, grad_mlp_params, (hipStream_t)stream)
+                         : launch_bwd_x<1, false>(h, b, C, grad_mlp_params, (hipStream_t)stream);
+    return mode == 6 ? launch_bwd_x<6, true>(h, b, C, grad_mlp_params, (hipStream_t)stream)
+                     : launch_bwd_x<1, true>(h, b, C, grad_mlp_params, (hipStream_t)stream);
 }

@@ -43,8 +43,10 @@ class RenderCfg:
     binned_scatter: bool = True        # LDS-binned hash-grid backward (False: per-update global atomics)
     mlp_kernels: str = "x"             # "x": split-bf16 matrix-core kernels at fp32 accuracy (csrc/ren_mlp_x.hip);
                                        # "f32": exact f32-MFMA kernels (csrc/ren_mlp.hip)
-    save_activations: bool = True      # training forward stores the hidden activations (768 B/sample) instead of
-                                       # recomputing them in the backward (128 f32 MFMAs + 192 softplus per 32 samples)
+    save_activations: Optional[bool] = None   # training forward stores the hidden activations (768 B/sample) instead of
+                                       # recomputing them in the backward.  Off since round 2: on the bf16 matrix cores the
+                                       # recompute (96 MFMAs + 96 softplus per 32 samples) is cheaper than 13 GB of HBM traffic;
+                                       # None = auto: recompute with the "x" kernels, save with the exact-f32 kernels
     march_cache: int = 512             # intervals per ray kept between the two marching passes (0: march twice)
     fwd_chunks: int = 16               # > 1: hash encoding and MLP of alternate sample chunks on two HIP streams
     mlp_bf16: bool = False             # BASELINE configs[2]: bf16 MLP (rounded linear inputs/weights, fp32 accumulate), fp32 composite
@@ -170,6 +172,10 @@ class Renderer:
                                   samples=samples, n=n, density_only=True, bf16=self.cfg.mlp_bf16)
         return sigma
 
+    def _save_acts(self) -> bool:
+        c = self.cfg
+        return (c.mlp_kernels != "x") if c.save_activations is None else bool(c.save_activations)
+
     def _xmode(self) -> int:
         return 1 if self.cfg.mlp_bf16 else 6
 
@@ -183,10 +189,10 @@ class Renderer:
             ops.hashgrid_fwd(f.grid, f.table, scene=self.scene, rays=(o, d), samples=samples, n=pk.n, layout=1)
         if self.cfg.mlp_kernels == "x":
             rgb, sigma, base, acts = ops.mlp_fwd_x(f.mlp, f.C, self._xmode(), feat, self.scene, rays=(o, d), samples=samples,
-                                                   n=pk.n, save=save)
+                                                   n=pk.n, save=save, save_acts=self._save_acts())
             return rgb, sigma, dict(feat=feat, base=base, acts=acts, xmode=self._xmode() if save else None)
         mp = self._mlp_params()
-        if save and self.cfg.save_activations:
+        if save and self._save_acts():
             rgb, sigma, base, acts = ops.mlp_fwd_save(mp, f.C, feat, self.scene, rays=(o, d), samples=samples, n=pk.n,
                                                       bf16=self.cfg.mlp_bf16)
             return rgb, sigma, dict(feat=feat, base=base, mlp_params=mp, acts=acts)
@@ -207,7 +213,7 @@ class Renderer:
         sigma = torch.empty(n, device=dev)
         rgb = torch.empty(n, f.C, device=dev)
         base = torch.empty(nblk * ops.BASE_FLOATS_PER_BLOCK, device=dev) if save else None
-        acts = torch.empty(nblk * lib_acts, device=dev) if save else None
+        acts = torch.empty(nblk * lib_acts, device=dev) if (save and self._save_acts()) else None
         if self._fwd_streams is None:
             self._fwd_streams = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
         main = torch.cuda.current_stream()
@@ -229,7 +235,7 @@ class Renderer:
                 s_mlp.wait_event(ev)
                 out = (rgb[lo:hi], sigma[lo:hi],
                        base[b0 * ops.BASE_FLOATS_PER_BLOCK: b1 * ops.BASE_FLOATS_PER_BLOCK] if save else None,
-                       acts[b0 * lib_acts: b1 * lib_acts] if save else None)
+                       acts[b0 * lib_acts: b1 * lib_acts] if acts is not None else None)
                 ops.mlp_fwd_x(f.mlp, f.C, self._xmode(), fk, self.scene, rays=(o, d), samples=smp, n=hi - lo, save=save,
                               out=out, share_cu=True)
         main.wait_stream(s_enc)

@@ -322,9 +322,10 @@ def mlp_bwd_saved(mlp_params, C: int, feat, base_out, acts, scene: SceneDesc, *,
 
 
 def mlp_fwd_x(mlp_params, C: int, mode: int, feat, scene: SceneDesc, *, rays=None, samples=None, x_world=None, dirs=None,
-              n: int, density_only: bool = False, save: bool = False, out=None, share_cu: bool = False):
+              n: int, density_only: bool = False, save: bool = False, out=None, share_cu: bool = False, save_acts: bool = True):
     """Split-bf16 matrix-core kernels (csrc/ren_mlp_x.hip).  mode 6: fp32 accuracy; mode 1: plain bf16 operands.
-    -> rgb, sigma, base, acts (base/acts None unless save); out: preallocated (rgb, sigma, base, acts) views"""
+    -> rgb, sigma, base, acts (base/acts None unless save; acts None with save_acts=False: mlp_bwd_x then recomputes
+    the hidden activations); out: preallocated (rgb, sigma, base, acts) views"""
     dev = feat.device
     o, d = rays if rays is not None else (None, None)
     ri, ts, te = samples if samples is not None else (None, None, None)
@@ -335,7 +336,7 @@ def mlp_fwd_x(mlp_params, C: int, mode: int, feat, scene: SceneDesc, *, rays=Non
         sigma = torch.empty(n, device=dev, dtype=torch.float32)
         rgb = None if density_only else torch.empty(n, C, device=dev, dtype=torch.float32)
         base = torch.empty(n_blocks32(n) * BASE_FLOATS_PER_BLOCK, device=dev, dtype=torch.float32) if save else None
-        acts = torch.empty(int(lib.ren_mlp_act_save_floats(n)), device=dev, dtype=torch.float32) if save else None
+        acts = torch.empty(int(lib.ren_mlp_act_save_floats(n)), device=dev, dtype=torch.float32) if (save and save_acts) else None
     check(lib.ren_mlp_fwd_x(_ptr(mlp_params, torch.float32), C, mode, _ptr(feat, torch.float32), ctypes.byref(scene),
                             _ptr(x_world), _ptr(dirs), _ptr(o), _ptr(d), _ptr(ri), _ptr(ts), _ptr(te), n,
                             (1 if density_only else 0) | (2 if share_cu else 0), _ptr(rgb), _ptr(sigma), _ptr(base),

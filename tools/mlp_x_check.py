@@ -73,3 +73,12 @@ for mode in (6, 1):
         sl_ = slice(off, off + math.prod(shape))
         print(f"      {k:8s} %.2e" % rel(b[2][sl_], b0[2][sl_]), end="")
     print()
+    # recompute variant (act_save = NULL): must equal the saved-activation backward bit for bit
+    b2 = bwd_outs()
+    fr = lambda: lib.ren_mlp_bwd_x(P(params), C, mode, P(feat), P(r[2]), None, ctypes.byref(scene), P(x), P(d), None, None,
+                                   None, None, None, n, P(r[0]), P(d_rgb), P(d_sig), P(b2[0]), P(b2[1]), P(b2[2]), P(ws), st)
+    assert fr() == 0
+    t2 = timeit(fr)
+    b2[2].zero_(); fr(); torch.cuda.synchronize()
+    print(f"   recompute (no act load) {t2:6.2f} ms   vs saved: d_base %.2e dfeat %.2e gparams %.2e" %
+          tuple(rel(a, c) for a, c in zip(b2, b)))
