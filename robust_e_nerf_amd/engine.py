@@ -628,6 +628,40 @@ class Trainer:
                           betas=self.t.betas, eps=self.t.eps, weight_decay=0.0, step=self.step_count, grad_scale=gs,
                           zero_grad=True)
 
+    # ---- optimiser state for checkpoints (what ModelCheckpoint keeps under "optimizer_states": scripts/run.py:66-68) ----
+    def optimizer_state_dict(self) -> Dict[str, object]:
+        cpu = lambda t: t.detach().cpu().clone()
+        sd = dict(step_count=self.step_count, exp_avg=cpu(self.m), exp_avg_sq=cpu(self.v), small_exp_avg=cpu(self.sm),
+                  small_exp_avg_sq=cpu(self.sv), ct_exp_avg=cpu(self.ct_m), ct_exp_avg_sq=cpu(self.ct_v))
+        if self._tau_opt is not None:
+            sd["tau_adam"] = self._tau_opt.state_dict()
+        return sd
+
+    def load_optimizer_state_dict(self, sd: Dict[str, object]):
+        self.step_count = int(sd["step_count"])
+        for dst, key in ((self.m, "exp_avg"), (self.v, "exp_avg_sq"), (self.sm, "small_exp_avg"),
+                         (self.sv, "small_exp_avg_sq"), (self.ct_m, "ct_exp_avg"), (self.ct_v, "ct_exp_avg_sq")):
+            dst.copy_(sd[key].to(dst.device, dst.dtype))
+        if "tau_adam" in sd:
+            self.tau_raw.requires_grad_(True)
+            self._tau_opt = torch.optim.Adam([self.tau_raw], lr=float(self.tau_max) * self.t.relative_lr_refractory_period)
+            self._tau_opt.load_state_dict(sd["tau_adam"])
+
+    def load_event_params(self, p2n_raw: Optional[torch.Tensor] = None, tau_raw: Optional[torch.Tensor] = None):
+        """restore the learned contrast-threshold ratio / refractory period (checkpoint resume)"""
+        if p2n_raw is not None:
+            self.ct[0] = p2n_raw.detach().reshape(-1)[0].to(self.ct.device, torch.float32)
+            self.ct_raw = float(self.ct[0])
+            ratio = float(torch.nn.functional.softplus(self.ct[0]))
+            self.c_p = ratio * self.c_n
+            self.mean_c = (self.c_p + self.c_n) / 2
+        if tau_raw is not None:
+            with torch.no_grad():
+                self.tau_raw.copy_(tau_raw.detach().to(torch.float64).reshape(self.tau_raw.shape))
+            lim = torch.tensor(1e-4, dtype=torch.float64).logit().abs()
+            tr_ = self.tau_max * (self.tau_raw.detach() / self.tau_max).clamp(-lim, lim)
+            self.tau = float(self.tau_max * torch.sigmoid(tr_ / self.tau_max))
+
     def update_train_batch_size(self, aux, eff_ray_sample_batch_size: int = 1 << 20) -> int:
         """Dynamic batch size (robust_e_nerf.py:907-950): keep rays x samples per render near the budget.
         mean_S = mean over this step's renders of n/R, averaged over ranks (C2); budget = eff // num_gpus

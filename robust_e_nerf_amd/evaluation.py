@@ -26,10 +26,11 @@ def pixel_grid(height: int, width: int, device) -> torch.Tensor:
 def render_pixels(r: Renderer, Kinv: torch.Tensor, px: torch.Tensor, pos: torch.Tensor, rot: torch.Tensor,
                   bkgd: Optional[torch.Tensor] = None, training: bool = False, jitter=None):
     """robust_e_nerf.py:849-885 for (N,2) pixels with per-pixel poses (N,3), (N,3,3):
-    -> intensity (N,) [monochrome], opacity, depth (z-depth), samples used, is_valid."""
+    -> intensity (N,) [monochrome] or (N, 3) [Bayer sensor, radiance_dim 3], opacity, depth (z-depth), samples used,
+    is_valid."""
     o, d = ops.raygen(Kinv, px.contiguous(), pos.contiguous(), rot.contiguous())
     colors, opac, depth, ctx = r.forward(o, d, jitter, bkgd, training=training, save=False)
-    intensity = colors[:, 0] + r.cfg.min_modeled_intensity
+    intensity = (colors[:, 0] if colors.shape[1] == 1 else colors) + r.cfg.min_modeled_intensity
     is_valid = torch.ones_like(opac, dtype=torch.bool) if bkgd is not None else opac > 0
     depth = depth / (opac + r.cfg.opacity_eps)                         # nerf.py:279-282
     depth = depth * (d * rot[:, :, 2]).sum(-1)                        # ray distance -> z depth (:873-884)
@@ -39,7 +40,7 @@ def render_pixels(r: Renderer, Kinv: torch.Tensor, px: torch.Tensor, pos: torch.
 @torch.no_grad()
 def render_image(r: Renderer, Kinv: torch.Tensor, cam_pos: torch.Tensor, cam_rot: torch.Tensor, height: int,
                  width: int, bkgd: Optional[torch.Tensor] = None, chunk: Optional[int] = None):
-    """evaluation_step: (H, W) predicted intensity, opacity, depth for one pose.  ``chunk`` is the reference's
+    """evaluation_step: (H, W) predicted intensity ((3, H, W) for radiance_dim 3), opacity, depth for one pose.  ``chunk`` is the reference's
     ``test_chunk_size`` (16 384 there, to fit a 2080 Ti); with 288 GB a 640x480 image is one chunk, which is 4x
     faster than 19 chunks (2.6 vs 10.3 ms, tools/render_bench.py).  The result does not depend on it.  Default: one
     chunk for arch ngp (~200 B/sample of temporaries), the reference's 16 384 rays for arch mlp (its 8 x 256 hidden
@@ -49,7 +50,8 @@ def render_image(r: Renderer, Kinv: torch.Tensor, cam_pos: torch.Tensor, cam_rot
     dev = Kinv.device
     px = pixel_grid(height, width, dev).reshape(-1, 2)
     n = px.shape[0]
-    out_i = torch.empty(n, device=dev)
+    C = r.field.C
+    out_i = torch.empty((n,) if C == 1 else (n, C), device=dev)
     out_o = torch.empty(n, device=dev)
     out_d = torch.empty(n, device=dev)
     for s in range(0, n, chunk):                                       # external/utils.py:99-105
@@ -58,12 +60,16 @@ def render_image(r: Renderer, Kinv: torch.Tensor, cam_pos: torch.Tensor, cam_rot
         rot = cam_rot.reshape(1, 3, 3).expand(e - s, 3, 3).contiguous()
         i, o, d, _, _ = render_pixels(r, Kinv, px[s:e], pos, rot, bkgd)
         out_i[s:e], out_o[s:e], out_d[s:e] = i, o, d
-    return out_i.view(height, width), out_o.view(height, width), out_d.view(height, width)
+    img = out_i.view(height, width) if C == 1 else out_i.view(height, width, C).permute(2, 0, 1).contiguous()
+    return img, out_o.view(height, width), out_d.view(height, width)
 
 
 def affine_align_log(pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
     """Least-squares a, b with a*log(pred)+b ~= log(target), float64 (robust_e_nerf.py:634-677);
-    returns the aligned prediction exp(a*log(pred)+b) in target's dtype."""
+    returns the aligned prediction exp(a*log(pred)+b) in target's dtype.  (3, H, W) images are aligned per channel,
+    as the reference does for Bayer sensors (:651-667)."""
+    if pred.dim() == 3 and pred.shape[0] == 3 and target.shape == pred.shape:
+        return torch.stack([affine_align_log(pred[c], target[c]) for c in range(3)])
     lp = pred.reshape(-1).log().to(torch.float64)
     A = torch.stack([lp, torch.ones_like(lp)], dim=1)
     sol = torch.linalg.lstsq(A.cpu(), target.reshape(-1, 1).log().to(torch.float64).cpu()).solution

@@ -30,6 +30,9 @@ NGP_KEYS = {"hash": "mlp_base.0.params", "base.w0": "mlp_base.1.hidden_layers.0.
             "head.b1": "mlp_head.hidden_layers.1.bias", "head.wo": "mlp_head.output_layer.weight",
             "head.bo": "mlp_head.output_layer.bias"}
 PREFIX = "nerf.radiance_field."                       # RobustENeRF.nerf (models/nerf.py) . radiance_field
+OCC = "nerf.occupancy_grid."                          # NeRF.occupancy_grid = nerfacc.OccupancyGrid (models/nerf.py:98-102)
+CT_KEY = "contrast_threshold.parametrizations.p2n_contrast_threshold_ratio.original"
+TAU_KEY = "refractory_period.parametrizations._refractory_period.original"
 
 
 def softplus_inv(y):
@@ -91,6 +94,8 @@ def main():
     ap.add_argument("--max-epochs", type=int)
     ap.add_argument("--limit-train-batches", type=int)
     ap.add_argument("--resume")
+    ap.add_argument("--mlp-bf16", action="store_true",
+                    help="bf16 MLP operands, fp32 accumulate / composite (same as float32_matmul_precision: medium)")
     ap.add_argument("--accumulate-grad-batches", type=int, help="overrides trainer.accumulate_grad_batches")
     args = ap.parse_args()
     cfg = yaml.safe_load(open(args.config))
@@ -125,8 +130,11 @@ def main():
         pos_ct, neg_ct = float(calib["pos_contrast_threshold"]), float(calib["neg_contrast_threshold"])
         tau_max = data.load_max_refractory_period(root).to(torch.float64)
         tau0 = float(calib["refractory_period"])
-        if not (0 <= tau0 < float(tau_max)):               # event_generation_params.py:123-139
-            tau0 = 0.5 * float(tau_max)
+        if not (0 <= tau0 < float(tau_max)):               # event_generation_params.py:89,113-130
+            import warnings
+            warnings.warn(f"Calibrated refractory period ({tau0}) is not in [0, max. refractory period = {float(tau_max)}): "
+                          f"redefining it to 0.999 of the max. refractory period")
+            tau0 = 0.999 * float(tau_max)
     budget = int(dcfg["train_eff_ray_sample_batch_size"])
     batch_size = max(1, int(dcfg["train_init_eff_batch_size"]) // world)
     batcher = data.EventBatcher(events, batch_size, dev, seed=seed, rank=rank,
@@ -142,12 +150,17 @@ def main():
         ext = max(aabb[3 + k] - aabb[k] for k in range(3))
         step_size = ext * math.sqrt(3) / 1024
     og = ncfg["occ_grid"]
+    # float32_matmul_precision (scripts/run.py:34-35, torch.set_float32_matmul_precision): "highest" = fp32 products,
+    # "medium" = bf16 operands with fp32 accumulation = the bf16 matrix-core mode of the fused MLPs (BASELINE configs[2]);
+    # "high" (TF32) has no MI355X counterpart and runs at fp32 accuracy
+    mlp_bf16 = args.mlp_bf16 or cfg.get("float32_matmul_precision", "highest") == "medium"
     rcfg = engine.RenderCfg(aabb=tuple(float(v) for v in aabb), contraction_type=ct, occ_res=(int(og["resolution"]),) * 3,
                             near_plane=ncfg.get("near_plane"), far_plane=ncfg.get("far_plane"),
                             render_step_size=float(step_size), cone_angle=float(ncfg["cone_angle"]),
                             early_stop_eps=float(ncfg["early_stop_eps"]), alpha_thre=float(ncfg["alpha_thre"]),
                             min_modeled_intensity=float(mcfg["min_modeled_intensity"]), occ_thre=float(og["occ_thre"]),
-                            ema_decay=float(og["ema_decay"]), warmup_steps=int(og["warmup_steps"]), occ_n=int(og["n"]))
+                            ema_decay=float(og["ema_decay"]), warmup_steps=int(og["warmup_steps"]), occ_n=int(og["n"]),
+                            mlp_bf16=mlp_bf16)
     arch = ncfg.get("arch", "ngp")
     check_supported(ncfg, arch)
     if arch == "mlp" and float(cfg["loss"]["weight"]["log_intensity_grad"]) > 0 and not mcfg["refractory_period"]["freeze"]:
@@ -158,13 +171,13 @@ def main():
     def lin(o, i):                                           # nn.Linear default init (hidden_init=None, ngp.py:179-185)
         b = 1 / math.sqrt(i)
         return (torch.rand(o, i, generator=gen) * 2 - 1) * b, (torch.rand(o, generator=gen) * 2 - 1) * b
+    C = 3 if "channel_idx" in events else 1                 # Bayer sensor -> radiance_dim 3 (robust_e_nerf.py:230-233)
     if arch == "mlp":
         from robust_e_nerf_amd import vanilla
-        fld = vanilla.VanillaField(dev, 1)
-        fld.load({k: v for name, o, i in vanilla.layer_shapes(1) for k, v in zip((name + ".weight", name + ".bias"), lin(o, i))})
+        fld = vanilla.VanillaField(dev, C)
+        fld.load({k: v for name, o, i in vanilla.layer_shapes(C) for k, v in zip((name + ".weight", name + ".bias"), lin(o, i))})
         renderer = vanilla.VanillaRenderer(fld, rcfg)
     else:
-        C = 3 if "channel_idx" in events else 1             # Bayer sensor -> radiance_dim 3 (robust_e_nerf.py:230-233)
         fld = engine.NGPField(dev, C, ncfg.get("ngp", {}).get("pos_encoding"))
         p = {"hash": (torch.rand(fld.n_table, generator=gen) * 2 - 1) * 1e-4}          # tcnn grid init U(+-1e-4)
         for k, (o, i) in {"base.w0": (64, 32), "base.wo": (16, 64), "head.w0": (64, 31), "head.w1": (64, 64), "head.wo": (C, 64)}.items():
@@ -177,6 +190,9 @@ def main():
         pw_diff=lcfg["param_weight"].get("log_intensity_diff"), err_grad=lcfg["error_fn"]["log_intensity_grad"],
         w_grad=float(lcfg["weight"]["log_intensity_grad"]), pw_grad=lcfg["param_weight"].get("log_intensity_grad"),
         lr=float(ocfg["lr"]["default"]), weight_decay=float(lcfg["weight"]["nerf_mlp_weight_decay"]),
+        # render_bkgd is a parameter only when alpha_over_white_bg (robust_e_nerf.py:154-159); otherwise no background is
+        # composited and the loss is masked with is_valid = opacity > 0 (:868-871): mocap-*, office-maze
+        bkgd_is_param=bool(dcfg.get("alpha_over_white_bg", True)),
         train_contrast_threshold=not mcfg["contrast_threshold"]["freeze"],
         lr_contrast_threshold=float(ocfg["lr"]["contrast_threshold"]),
         train_refractory_period=not mcfg["refractory_period"]["freeze"],
@@ -187,14 +203,24 @@ def main():
                         p2n_raw=torch.tensor(softplus_inv(pos_ct / neg_ct)), neg_ct=torch.tensor(neg_ct),
                         tau_raw=tau_raw, tau_max=tau_max, bkgd_raw=torch.tensor([softplus_inv(1.0)] * fld.C),
                         world_size=world, process_group=None)
+    start_epoch, start_step = 0, 0
     if args.resume:
-        rsd = torch.load(args.resume, map_location="cpu")["state_dict"]
+        ck = torch.load(args.resume, map_location="cpu", weights_only=False)
+        rsd = ck["state_dict"]
         load_field_state_dict(fld, arch, rsd)
-        if "nerf.parametrizations.render_bkgd.original" in rsd:
+        if tcfg.bkgd_is_param:
             tr.small[: fld.C] = rsd["nerf.parametrizations.render_bkgd.original"].to(dev, torch.float32).reshape(-1)
-        if "nerf.occ_grid._binary" in rsd:
-            renderer.occs.copy_(rsd["nerf.occ_grid.occs"].to(dev).reshape(-1))
-            renderer.binary.copy_(rsd["nerf.occ_grid._binary"].reshape(-1).to(torch.uint8).to(dev))
+        if OCC + "_binary" not in rsd or OCC + "occs" not in rsd:
+            raise KeyError(f"{args.resume}: no occupancy grid ({OCC}occs / {OCC}_binary) in the checkpoint")
+        renderer.occs.copy_(rsd[OCC + "occs"].to(dev).reshape(-1))
+        renderer.binary.copy_(rsd[OCC + "_binary"].reshape(-1).to(torch.uint8).to(dev))
+        tr.load_event_params(rsd.get(CT_KEY), rsd.get(TAU_KEY))
+        if "optimizer_state" in ck:                          # absent in a reference (PL) checkpoint: fresh moments then
+            tr.load_optimizer_state_dict(ck["optimizer_state"])
+            start_epoch, start_step = int(ck["epoch"]) + 1, int(ck["global_step"])
+            if "batch_size" in ck:
+                batch_size = int(ck["batch_size"])
+                batcher.set_batch_size(batch_size)
 
     # ---- fit loop ---------------------------------------------------------------------------------------------
     tcf, sched = cfg["trainer"], cfg["lr_scheduler"]["multi_step_lr"]
@@ -207,8 +233,8 @@ def main():
     pending = deque([batch_size])
     jgen = torch.Generator(device=dev).manual_seed(seed + 17 + rank)
     os.makedirs(args.out, exist_ok=True)
-    step, t0, rays = 0, time.perf_counter(), 0
-    for epoch in range(max_epochs):
+    step, t0, rays = start_step, time.perf_counter(), 0
+    for epoch in range(start_epoch, max_epochs):
         tr.set_epoch(epoch, tuple(sched["milestones"]), float(sched["gamma"]))
         for bi in range(per_epoch):
             batch = batcher.next()
@@ -230,13 +256,18 @@ def main():
                 t0, rays = time.perf_counter(), 0
         if rank == 0:
             sd = field_state_dict(fld, arch)
-            sd["contrast_threshold.parametrizations.p2n_contrast_threshold_ratio.original"] = tr.ct[:1].detach().cpu().clone()
-            sd["refractory_period.parametrizations._refractory_period.original"] = tr.tau_raw.detach().clone()
+            sd[CT_KEY] = tr.ct[:1].detach().cpu().clone()
+            sd[TAU_KEY] = tr.tau_raw.detach().clone()
             if tcfg.bkgd_is_param:                      # models/nerf.py:81-88 (softplus-parametrised parameter)
                 sd["nerf.parametrizations.render_bkgd.original"] = tr.small[: fld.C].detach().cpu().clone()
-            sd["nerf.occ_grid.occs"] = renderer.occs.detach().cpu().clone()
-            sd["nerf.occ_grid._binary"] = renderer.binary.detach().cpu().bool().view(*rcfg.occ_res)
-            torch.save({"state_dict": sd, "epoch": epoch, "global_step": step}, os.path.join(args.out, "last.ckpt"))
+            # nerfacc.OccupancyGrid persistent buffers (models/nerf.py:98-102; nerfacc 0.3.x registers _roi_aabb, _binary,
+            # resolution, occs -- grid_coords / grid_indices are non-persistent)
+            sd[OCC + "_roi_aabb"] = torch.tensor(rcfg.aabb, dtype=torch.float32)
+            sd[OCC + "_binary"] = renderer.binary.detach().cpu().bool().view(*rcfg.occ_res)
+            sd[OCC + "resolution"] = torch.tensor(rcfg.occ_res, dtype=torch.int32)
+            sd[OCC + "occs"] = renderer.occs.detach().cpu().clone()
+            torch.save({"state_dict": sd, "epoch": epoch, "global_step": step, "optimizer_state": tr.optimizer_state_dict(),
+                        "batch_size": batcher.batch_size}, os.path.join(args.out, "last.ckpt"))
     if world > 1:
         dist.destroy_process_group()
 

@@ -651,20 +651,28 @@ def test_chunked_two_stream_forward_equals_single_launch(amd, spec, full_table_c
     jit = dev(torch.rand(R, generator=gen))
     g_col = dev(torch.randn(R, 1, generator=gen))
     out = []
-    for chunks in (1, 16):
+    # (chunks, save_activations): the backward that recomputes the hidden activations (default) must give the
+    # gradients of the one that loads them -- the recompute repeats the forward's MFMA sequence bit for bit
+    for chunks, save in ((1, True), (16, True), (1, None), (16, None)):
         fld = engine.NGPField(DEV)
         fld.load(p)
-        r = engine.Renderer(fld, engine.RenderCfg(sampler="uniform", n_uniform=128, fwd_chunks=chunks))
+        r = engine.Renderer(fld, engine.RenderCfg(sampler="uniform", n_uniform=128, fwd_chunks=chunks,
+                                                   save_activations=save))
         colors, opac, depth, ctx = r.forward(o, d, jit, None, True)
         assert ctx["pk"].n >> 20 >= 2
+        assert (ctx["acts"] is not None) == bool(save)
         r.backward(ctx, g_col)
         torch.cuda.synchronize()
-        out.append((colors.clone(), opac.clone(), ctx["sigma"].clone(), ctx["feat"].clone(), ctx["acts"].clone(),
+        out.append((colors.clone(), opac.clone(), ctx["sigma"].clone(), ctx["feat"].clone(), ctx["base"].clone(),
                     fld.g_mlp.clone(), fld.g_table.clone()))
-    a, b = out
-    for k in range(5):
-        assert torch.equal(a[k], b[k]), k
-    assert rel_err(b[5], a[5]) < 1e-5 and rel_err(b[6], a[6]) < 1e-5
+        if save:
+            out[-1] = out[-1] + (ctx["acts"].clone(),)
+    a = out[0]
+    assert torch.equal(out[1][7], a[7])
+    for b in out[1:]:
+        for k in range(5):
+            assert torch.equal(a[k], b[k]), k
+        assert rel_err(b[5], a[5]) < 1e-5 and rel_err(b[6], a[6]) < 1e-5
 
 
 # ------------------------------------------------------------------------------------------ whole training step
