@@ -1068,21 +1068,44 @@ def test_train_cli_smoke_and_checkpoint_keys(tmp_path):
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "M rays/s" in out.stdout
-    ck = torch.load(os.path.join(tmp_path, "last.ckpt"), map_location="cpu")
+    ck = torch.load(os.path.join(tmp_path, "last.ckpt"), map_location="cpu", weights_only=False)
     sd = ck["state_dict"]
-    for k in ("nerf.radiance_field.mlp_base.0.params", "nerf.radiance_field.mlp_base.1.hidden_layers.0.weight",
-              "nerf.radiance_field.mlp_head.output_layer.bias", "nerf.occ_grid.occs", "nerf.occ_grid._binary",
-              "contrast_threshold.parametrizations.p2n_contrast_threshold_ratio.original"):
-        assert k in sd, k
+    # the reference's state-dict keys for arch ngp with alpha_over_white_bg (robust_e_nerf.py:176-196,
+    # nerf.py:81-142, ngp.py:152-205; nerfacc.OccupancyGrid persistent buffers) -- exactly these, nothing else
+    ref_keys = {"contrast_threshold.parametrizations.p2n_contrast_threshold_ratio.original",
+                "refractory_period.parametrizations._refractory_period.original",
+                "nerf.parametrizations.render_bkgd.original",
+                "nerf.occupancy_grid._roi_aabb", "nerf.occupancy_grid._binary", "nerf.occupancy_grid.resolution",
+                "nerf.occupancy_grid.occs", "nerf.radiance_field.mlp_base.0.params"} | {
+        "nerf.radiance_field." + k for k in (
+            "mlp_base.1.hidden_layers.0.weight", "mlp_base.1.hidden_layers.0.bias", "mlp_base.1.output_layer.weight",
+            "mlp_base.1.output_layer.bias", "mlp_head.hidden_layers.0.weight", "mlp_head.hidden_layers.0.bias",
+            "mlp_head.hidden_layers.1.weight", "mlp_head.hidden_layers.1.bias", "mlp_head.output_layer.weight",
+            "mlp_head.output_layer.bias")}
+    assert set(sd) == ref_keys, set(sd) ^ ref_keys
+    assert sd["nerf.occupancy_grid._binary"].shape == (128, 128, 128) and sd["nerf.occupancy_grid._binary"].dtype == torch.bool
     assert sd["nerf.radiance_field.mlp_base.0.params"].numel() == 12_599_920 and ck["global_step"] == 48
-    out2 = subprocess.run(cmd + ["--resume", os.path.join(tmp_path, "last.ckpt"), "--max-epochs", "1", "--limit-train-batches", "8"],
-                          capture_output=True, text=True, timeout=600)
+    assert ck["optimizer_state"]["step_count"] == 48 and float(ck["optimizer_state"]["exp_avg_sq"].abs().sum()) > 0
+    ct_learned = float(sd["contrast_threshold.parametrizations.p2n_contrast_threshold_ratio.original"])
+    # resume: continues at the next epoch with the Adam moments, step counters and the learned C_p ratio
+    out2 = subprocess.run(cmd + ["--resume", os.path.join(tmp_path, "last.ckpt"), "--max-epochs", str(ck["epoch"] + 2),
+                                 "--limit-train-batches", "8"], capture_output=True, text=True, timeout=600)
     assert out2.returncode == 0, out2.stderr[-2000:]
+    ck2 = torch.load(os.path.join(tmp_path, "last.ckpt"), map_location="cpu", weights_only=False)
+    assert ck2["epoch"] == ck["epoch"] + 1 and ck2["global_step"] == 56 and ck2["optimizer_state"]["step_count"] == 56
+    ct2 = float(ck2["state_dict"]["contrast_threshold.parametrizations.p2n_contrast_threshold_ratio.original"])
+    assert abs(ct2 - ct_learned) < 0.5 * abs(ct_learned - 0.5413) + 0.05      # moved on from the learned value, not from the initial one
+    # a checkpoint without the occupancy grid is refused
+    bad = dict(ck2, state_dict={k: v for k, v in ck2["state_dict"].items() if "occupancy_grid" not in k})
+    torch.save(bad, os.path.join(tmp_path, "bad.ckpt"))
+    out_bad = subprocess.run(cmd + ["--resume", os.path.join(tmp_path, "bad.ckpt"), "--max-epochs", "9", "--limit-train-batches", "1"],
+                             capture_output=True, text=True, timeout=600)
+    assert out_bad.returncode != 0 and "occupancy grid" in out_bad.stderr
     # gradient accumulation: 8 micro-batches = 4 optimiser steps (global_step counts optimiser steps)
     out3 = subprocess.run(cmd + ["--max-epochs", "1", "--limit-train-batches", "8", "--accumulate-grad-batches", "2"],
                           capture_output=True, text=True, timeout=600)
     assert out3.returncode == 0, out3.stderr[-2000:]
-    assert torch.load(os.path.join(tmp_path, "last.ckpt"), map_location="cpu")["global_step"] == 4
+    assert torch.load(os.path.join(tmp_path, "last.ckpt"), map_location="cpu", weights_only=False)["global_step"] == 4
 
 
 def test_bench_n_rank_contract_selftest():
