@@ -39,10 +39,14 @@ def softplus_inv(y):
     return float(y + math.log(-math.expm1(-y)))
 
 
-def field_state_dict(fld, arch):
+def field_state_dict(fld, arch, aabb):
+    """parameters + persistent buffers of the reference's radiance field module (ngp.py:152, mlp.py:217-219,269)"""
+    buf = {PREFIX + "aabb": torch.tensor(aabb, dtype=torch.float32)}
     if arch == "mlp":
-        return {PREFIX + k: v.detach().cpu().clone() for k, v in fld.state_dict().items()}
-    sd = {PREFIX + NGP_KEYS["hash"]: fld.table.detach().cpu().clone()}
+        buf[PREFIX + "posi_encoder.scales"] = torch.tensor([2 ** i for i in range(10)])
+        buf[PREFIX + "view_encoder.scales"] = torch.tensor([2 ** i for i in range(4)])
+        return dict(buf, **{PREFIX + k: v.detach().cpu().clone() for k, v in fld.state_dict().items()})
+    sd = dict(buf, **{PREFIX + NGP_KEYS["hash"]: fld.table.detach().cpu().clone()})
     for k, v in fld.mlp_views().items():
         sd[PREFIX + NGP_KEYS[k]] = v.detach().cpu().clone()
     return sd
@@ -218,6 +222,9 @@ def main():
         if "optimizer_state" in ck:                          # absent in a reference (PL) checkpoint: fresh moments then
             tr.load_optimizer_state_dict(ck["optimizer_state"])
             start_epoch, start_step = int(ck["epoch"]) + 1, int(ck["global_step"])
+            if rank == 0:
+                print(f"resumed {args.resume}: epoch {start_epoch}, global_step {start_step}, raw C_p/C_n ratio "
+                      f"{float(tr.ct[0]):.4f}, tau {tr.tau:.6g}", flush=True)
             if "batch_size" in ck:
                 batch_size = int(ck["batch_size"])
                 batcher.set_batch_size(batch_size)
@@ -255,7 +262,7 @@ def main():
                       f"{torch.cuda.memory_reserved() / 2**30:.1f} GiB", flush=True)
                 t0, rays = time.perf_counter(), 0
         if rank == 0:
-            sd = field_state_dict(fld, arch)
+            sd = field_state_dict(fld, arch, rcfg.aabb)
             sd[CT_KEY] = tr.ct[:1].detach().cpu().clone()
             sd[TAU_KEY] = tr.tau_raw.detach().clone()
             if tcfg.bkgd_is_param:                      # models/nerf.py:81-88 (softplus-parametrised parameter)
