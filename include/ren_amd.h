@@ -327,6 +327,22 @@ int ren_mlp_bwd_jvp(const float *mlp_params, int32_t radiance_dim, const float *
                     const float *d_rgb, const float *d_rgbd, const float *d_sigma, const float *d_sigmad,
                     float *scratch, float *dfeat, float *dfeatd, float *grad_mlp_params, float *workspace,
                     void *stream);
+/* The same two calls on the bf16 matrix cores (csrc/ren_mlp_jvp_x.hip; default tangent path since ABI v15).
+ * mode 6: split-bf16 products at fp32 accuracy; mode 1: plain bf16 operands with fp32 accumulation for value AND tangent
+ * of every nn.Linear (BASELINE configs[2]: bf16 MLP + fp32 composite with the log-intensity-gradient loss of
+ * robust_e_nerf/models/robust_e_nerf.py:383-409 switched on).  Buffers, scratch and layouts as for the calls above. */
+int ren_mlp_fwd_jvp_x(const float *mlp_params, int32_t radiance_dim, int32_t mode, const float *feat, const float *featd,
+                      const ren_scene_desc *scene, const float *rays_o, const float *rays_d, const float *rays_dd,
+                      const int32_t *ray_indices, const float *t_starts, const float *t_ends, int64_t n,
+                      float *rgb, float *rgbd, float *sigma, float *sigmad, float *base_out, float *base_outd,
+                      void *stream);
+int64_t ren_mlp_bwd_jvp_x_workspace_floats(int32_t radiance_dim);
+int ren_mlp_bwd_jvp_x(const float *mlp_params, int32_t radiance_dim, int32_t mode, const float *feat, const float *featd,
+                      const float *base_out, const float *base_outd, const ren_scene_desc *scene,
+                      const float *rays_o, const float *rays_d, const float *rays_dd, const int32_t *ray_indices,
+                      const float *t_starts, const float *t_ends, int64_t n, const float *rgb, const float *d_rgb,
+                      const float *d_rgbd, const float *d_sigma, const float *d_sigmad, float *scratch, float *dfeat,
+                      float *dfeatd, float *grad_mlp_params, float *workspace, void *stream);
 /* compositing with tangent: colors/colords [n_rays,C], opacities/opacds [n_rays]; saves weights, trans,
  * eds (exclusive prefix of sigmad*dt) [n] for the reverse pass */
 int ren_composite_fwd_jvp(const int64_t *offsets, const int32_t *counts, int64_t n_rays, const float *t_starts,

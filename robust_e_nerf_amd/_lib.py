@@ -86,6 +86,10 @@ SIGNATURES = {
     "ren_mlp_bwd_jvp_workspace_floats": (c_int64, [c_int32]),
     "ren_mlp_bwd_jvp": (c_int, [P, c_int32, P, P, P, P, POINTER(SceneDesc), P, P, P, P, P, P, c_int64, P, P, P, P, P,
                                 P, P, P, P, P, P]),
+    "ren_mlp_fwd_jvp_x": (c_int, [P, c_int32, c_int32, P, P, POINTER(SceneDesc), P, P, P, P, P, P, c_int64, P, P, P, P, P, P, P]),
+    "ren_mlp_bwd_jvp_x_workspace_floats": (c_int64, [c_int32]),
+    "ren_mlp_bwd_jvp_x": (c_int, [P, c_int32, c_int32, P, P, P, P, POINTER(SceneDesc), P, P, P, P, P, P, c_int64, P, P, P, P, P,
+                                  P, P, P, P, P, P]),
     "ren_composite_fwd_jvp": (c_int, [P, P, c_int64, P, P, P, P, P, P, c_int32, P, P, P, P, P, P, P, P, P]),
     "ren_composite_bwd_jvp": (c_int, [P, P, c_int64, P, P, P, P, P, P, c_int32, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "ren_trajectory_jvp2": (c_int, [P, c_int64, P, P, P, c_int64, P, P, P, P, P, P]),

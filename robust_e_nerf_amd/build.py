@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(CSRC, "libren_amd.so")
 SOURCES = ["ren_api.hip", "ren_pose.hip", "ren_sampling.hip", "ren_composite.hip", "ren_train.hip",
-           "ren_hashgrid.hip", "ren_hashgrid_binned.hip", "ren_mlp.hip", "ren_jvp.hip", "ren_mlp_jvp.hip", "ren_jvp2.hip", "ren_dense.hip", "ren_mlp_x.hip"]
+           "ren_hashgrid.hip", "ren_hashgrid_binned.hip", "ren_mlp.hip", "ren_jvp.hip", "ren_mlp_jvp.hip", "ren_jvp2.hip", "ren_dense.hip", "ren_mlp_x.hip", "ren_mlp_jvp_x.hip"]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
           "-Wno-unused-result"]
 # the sampler must match the sequential oracle bit for bit: no FMA contraction there
@@ -23,7 +23,7 @@ def _stale(target, deps):
 
 def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = os.environ.get("HIPCC", "hipcc")
-    headers = [os.path.join(CSRC, "ren_common.h"), os.path.join(CSRC, "ren_hashgrid_common.h"), os.path.join(CSRC, "ren_mlp_common.h"),
+    headers = [os.path.join(CSRC, "ren_common.h"), os.path.join(CSRC, "ren_hashgrid_common.h"), os.path.join(CSRC, "ren_mlp_common.h"), os.path.join(CSRC, "ren_mlp_xfrag.h"), os.path.join(CSRC, "ren_mlp_jvp_common.h"),
                os.path.join(HERE, "..", "include", "ren_amd.h")]
     objs = []
     for src in SOURCES:

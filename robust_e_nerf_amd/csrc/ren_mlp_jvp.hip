@@ -11,56 +11,9 @@
 //   head2: output layer + head layer 1 (64->64) -> (dz1, dz1d)      [recomputes head layers 0 and 1]
 //   head1: head layer 0 ([base_out|SH] -> 64) + density -> (d base_out, d base_outd)
 //   base : base MLP -> (d feat, d featd)                             [recomputes the hidden layer]
-#include "ren_mlp_common.h"
+#include "ren_mlp_jvp_common.h"
 
 namespace {
-
-__device__ __forceinline__ float d2softplus_from_s(float s, float beta) { return beta * (1.f - s) * s; }
-
-// SH degree 4 and its directional derivative along dd; component 2j+hi -> out[j]
-__device__ __forceinline__ void sh4_jvp_select(float x, float y, float z, float xd, float yd, float zd, int hi,
-                                               float *out, float *outd) {
-    const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
-    const float A = 0.48860251190291987f, Bc = 1.0925484305920792f, C6 = 0.94617469575755997f,
-                E = 0.54627421529603959f, F = 0.59004358992664352f, G = 2.8906114426405538f,
-                H = 0.45704579946446572f, K = 0.3731763325901154f, M = 1.4453057213202769f;
-    float s[16], t[16];
-    s[0] = 0.28209479177387814f;                 t[0] = 0.f;
-    s[1] = -A * y;                               t[1] = -A * yd;
-    s[2] = A * z;                                t[2] = A * zd;
-    s[3] = -A * x;                               t[3] = -A * xd;
-    s[4] = Bc * xy;                              t[4] = Bc * (xd * y + x * yd);
-    s[5] = -Bc * yz;                             t[5] = -Bc * (yd * z + y * zd);
-    s[6] = C6 * z2 - 0.31539156525251999f;       t[6] = 2.f * C6 * z * zd;
-    s[7] = -Bc * xz;                             t[7] = -Bc * (xd * z + x * zd);
-    s[8] = E * x2 - E * y2;                      t[8] = 2.f * E * (x * xd - y * yd);
-    s[9] = F * y * (-3.f * x2 + y2);             t[9] = F * (yd * (-3.f * x2 + y2) + y * (-6.f * x * xd + 2.f * y * yd));
-    s[10] = G * xy * z;                          t[10] = G * (xd * yz + x * yd * z + xy * zd);
-    s[11] = H * y * (1.f - 5.f * z2);            t[11] = H * (yd * (1.f - 5.f * z2) - 10.f * y * z * zd);
-    s[12] = K * z * (5.f * z2 - 3.f);            t[12] = K * zd * (15.f * z2 - 3.f);
-    s[13] = H * x * (1.f - 5.f * z2);            t[13] = H * (xd * (1.f - 5.f * z2) - 10.f * x * z * zd);
-    s[14] = M * z * (x2 - y2);                   t[14] = M * (zd * (x2 - y2) + z * (2.f * x * xd - 2.f * y * yd));
-    s[15] = F * x * (-x2 + 3.f * y2);            t[15] = F * (xd * (-x2 + 3.f * y2) + x * (-2.f * x * xd + 6.f * y * yd));
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { out[j] = hi ? s[2 * j + 1] : s[2 * j]; outd[j] = hi ? t[2 * j + 1] : t[2 * j]; }
-}
-
-struct RaySrc {                                   // packed sample stream with ray tangents
-    const float *rays_o, *rays_d, *rays_dd;
-    const int32_t *ray_indices;
-    const float *t_starts, *t_ends;
-};
-
-__device__ __forceinline__ void geom_jvp(const RaySrc &s, const ren_scene_dev &sc, int64_t i, bool &sel, float *d,
-                                         float *dd) {
-    float x, y, z; int ray;
-    ren_sample_pos(s.rays_o, s.rays_d, s.ray_indices, s.t_starts, s.t_ends, i, x, y, z, ray);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { d[k] = s.rays_d[3 * (int64_t)ray + k]; dd[k] = s.rays_dd[3 * (int64_t)ray + k]; }
-    float ux, uy, uz;
-    ren_contract(sc, x, y, z, ux, uy, uz);
-    sel = ux > 0.f && ux < 1.f && uy > 0.f && uy < 1.f && uz > 0.f && uz < 1.f;
-}
 
 // activation with tangent, in place: z -> y = sp100(z), zd -> yd = s zd; optionally keeps zd (pre-activation tangent)
 __device__ __forceinline__ void act_jvp(f32x16 (&y)[2], f32x16 (&yd)[2]) {

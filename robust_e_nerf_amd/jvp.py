@@ -69,7 +69,7 @@ def render_forward2(r, o, d, od, dd, ddd, pk, bkgd):
                                     _ptr(featd), _ptr(featdd), _stream()), "ren_hashgrid_fwd_jvp2")
     rgb, rgbd, rgbdd = (torch.empty(n, f.C, device=dev) for _ in range(3))
     sg, sgd, sgdd = (torch.empty(n, device=dev) for _ in range(3))
-    check(lib.ren_mlp_fwd_jvp2(_ptr(f.mlp), f.C, _ptr(feat), _ptr(featd), _ptr(featdd), ctypes.byref(r.scene),
+    check(lib.ren_mlp_fwd_jvp2(_ptr(r._mlp_params()), f.C, _ptr(feat), _ptr(featd), _ptr(featdd), ctypes.byref(r.scene),
                                _ptr(o), _ptr(d), _ptr(od), _ptr(dd), _ptr(ddd), _ptr(ri), _ptr(ts), _ptr(te), n,
                                _ptr(rgb), _ptr(rgbd), _ptr(rgbdd), _ptr(sg), _ptr(sgd), _ptr(sgdd), _stream()),
           "ren_mlp_fwd_jvp2")
@@ -103,9 +103,14 @@ def render_forward(r, o, d, od, dd, jitter, bkgd, training: bool = True):
         rgb, rgbd = torch.empty(n, f.C, device=dev), torch.empty(n, f.C, device=dev)
         sigma, sigmad = torch.empty(n, device=dev), torch.empty(n, device=dev)
         base, based = torch.empty(nb * 512, device=dev), torch.empty(nb * 512, device=dev)
-        check(lib.ren_mlp_fwd_jvp(_ptr(f.mlp), f.C, _ptr(feat), _ptr(featd), ctypes.byref(r.scene), _ptr(o), _ptr(d),
-                                  _ptr(dd), _ptr(ri), _ptr(ts), _ptr(te), n, _ptr(rgb), _ptr(rgbd), _ptr(sigma),
-                                  _ptr(sigmad), _ptr(base), _ptr(based), _stream()), "ren_mlp_fwd_jvp")
+        if r.cfg.mlp_kernels == "x":                        # bf16 matrix cores: mode 6 (fp32 accuracy) / 1 (bf16 operands)
+            check(lib.ren_mlp_fwd_jvp_x(_ptr(f.mlp), f.C, r._xmode(), _ptr(feat), _ptr(featd), ctypes.byref(r.scene), _ptr(o),
+                                        _ptr(d), _ptr(dd), _ptr(ri), _ptr(ts), _ptr(te), n, _ptr(rgb), _ptr(rgbd), _ptr(sigma),
+                                        _ptr(sigmad), _ptr(base), _ptr(based), _stream()), "ren_mlp_fwd_jvp_x")
+        else:
+            check(lib.ren_mlp_fwd_jvp(_ptr(r._mlp_params()), f.C, _ptr(feat), _ptr(featd), ctypes.byref(r.scene), _ptr(o), _ptr(d),
+                                      _ptr(dd), _ptr(ri), _ptr(ts), _ptr(te), n, _ptr(rgb), _ptr(rgbd), _ptr(sigma),
+                                      _ptr(sigmad), _ptr(base), _ptr(based), _stream()), "ren_mlp_fwd_jvp")
     colors, colords = torch.empty(R, f.C, device=dev), torch.empty(R, f.C, device=dev)
     opac, opacd = torch.empty(R, device=dev), torch.empty(R, device=dev)
     w, T, eds = (torch.empty(n, device=dev) for _ in range(3))
@@ -143,12 +148,20 @@ def render_backward(r, ctx, g_colors, g_colords):
         return ops.column_sum(d_bk) if d_bk is not None else None
     scratch = torch.empty(nb * 5120, device=dev)
     dfeat, dfeatd = torch.empty(nb * 1024, device=dev), torch.empty(nb * 1024, device=dev)
-    ws = torch.empty(int(lib.ren_mlp_bwd_jvp_workspace_floats(f.C)), device=dev)
-    check(lib.ren_mlp_bwd_jvp(_ptr(f.mlp), f.C, _ptr(ctx["feat"]), _ptr(ctx["featd"]), _ptr(ctx["base"]),
-                              _ptr(ctx["based"]), ctypes.byref(r.scene), _ptr(ctx["o"]), _ptr(ctx["d"]),
-                              _ptr(ctx["dd"]), _ptr(ri), _ptr(ts), _ptr(te), n, _ptr(ctx["rgb"]), _ptr(d_rgb),
-                              _ptr(d_rgbd), _ptr(d_sig), _ptr(d_sigd), _ptr(scratch), _ptr(dfeat), _ptr(dfeatd),
-                              _ptr(f.g_mlp), _ptr(ws), _stream()), "ren_mlp_bwd_jvp")
+    if r.cfg.mlp_kernels == "x":
+        ws = torch.empty(int(lib.ren_mlp_bwd_jvp_x_workspace_floats(f.C)), device=dev)
+        check(lib.ren_mlp_bwd_jvp_x(_ptr(f.mlp), f.C, r._xmode(), _ptr(ctx["feat"]), _ptr(ctx["featd"]), _ptr(ctx["base"]),
+                                    _ptr(ctx["based"]), ctypes.byref(r.scene), _ptr(ctx["o"]), _ptr(ctx["d"]),
+                                    _ptr(ctx["dd"]), _ptr(ri), _ptr(ts), _ptr(te), n, _ptr(ctx["rgb"]), _ptr(d_rgb),
+                                    _ptr(d_rgbd), _ptr(d_sig), _ptr(d_sigd), _ptr(scratch), _ptr(dfeat), _ptr(dfeatd),
+                                    _ptr(f.g_mlp), _ptr(ws), _stream()), "ren_mlp_bwd_jvp_x")
+    else:
+        ws = torch.empty(int(lib.ren_mlp_bwd_jvp_workspace_floats(f.C)), device=dev)
+        check(lib.ren_mlp_bwd_jvp(_ptr(f.mlp), f.C, _ptr(ctx["feat"]), _ptr(ctx["featd"]), _ptr(ctx["base"]),
+                                  _ptr(ctx["based"]), ctypes.byref(r.scene), _ptr(ctx["o"]), _ptr(ctx["d"]),
+                                  _ptr(ctx["dd"]), _ptr(ri), _ptr(ts), _ptr(te), n, _ptr(ctx["rgb"]), _ptr(d_rgb),
+                                  _ptr(d_rgbd), _ptr(d_sig), _ptr(d_sigd), _ptr(scratch), _ptr(dfeat), _ptr(dfeatd),
+                                  _ptr(f.g_mlp), _ptr(ws), _stream()), "ren_mlp_bwd_jvp")
     if r.cfg.binned_scatter:
         need = ops.hashgrid_bwd_binned_workspace_bytes(n)
         if r._bin_ws is None or r._bin_ws.numel() < need:

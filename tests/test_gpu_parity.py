@@ -676,9 +676,10 @@ def test_chunked_two_stream_forward_equals_single_launch(amd, spec, full_table_c
 
 
 # ------------------------------------------------------------------------------------------ whole training step
-def _trainer_from_golden(engine, g, table, sampler="occgrid"):
+def _trainer_from_golden(engine, g, table, sampler="occgrid", **render_kw):
     occ_res = int(g["occ_res"])
-    cfg = engine.RenderCfg(occ_res=(occ_res,) * 3, render_step_size=float(g["render_step_size"]), sampler=sampler)
+    cfg = engine.RenderCfg(occ_res=(occ_res,) * 3, render_step_size=float(g["render_step_size"]), sampler=sampler,
+                           **render_kw)
     fld = engine.NGPField(DEV)
     fld.load(field_params_from(g, table))
     r = engine.Renderer(fld, cfg)
@@ -970,14 +971,16 @@ def test_pose_tangent_vs_oracle_autograd(amd):
         assert rel_err(od[:, k].cpu(), go) < 1e-4 and rel_err(dd[:, k].cpu(), gd) < 1e-3
 
 
-def test_grad_loss_step_vs_reference_golden(amd, full_table_cache):
+@pytest.mark.parametrize("kernels", ["x", "f32"])
+def test_grad_loss_step_vs_reference_golden(amd, full_table_cache, kernels):
     """Forward-mode d(log I)/dt + reverse pass vs the reference's autograd.gradient(create_graph=True)
     training_step (l_diff + l_grad).  The golden run has C_p and tau trainable; their values enter here as
-    the (frozen) constants of that step, and the field / background gradients are compared."""
+    the (frozen) constants of that step, and the field / background gradients are compared.  kernels: the tangent
+    MLP kernels on the bf16 matrix cores at fp32 accuracy (csrc/ren_mlp_jvp_x.hip, default) / the exact-f32 MFMA ones."""
     ops, engine = amd
     g = load_golden("training_step_grad")
     table = full_table_cache(g["table_seed"], g["table_scale"])
-    tr, batch = _trainer_from_golden(engine, g, table)
+    tr, batch = _trainer_from_golden(engine, g, table, mlp_kernels=kernels)
     tr.t.w_grad, tr.t.err_grad, tr.t.pw_grad = float(g["w_grad"]), "mape", None
     tr.t.train_contrast_threshold = True
     batch["u_grad"] = dev(g["u_grad"])
@@ -997,6 +1000,124 @@ def test_grad_loss_step_vs_reference_golden(amd, full_table_cache):
     assert rel_err(tr.ct_grad[:1].cpu(), g["g_p2n_raw"]) < 1e-3, "d loss / d (C_p/C_n ratio parameter)"
     tr.optimizer_step()                                     # three Adam groups incl. the lr-0.1 ratio group
     assert float(tr.ct_grad.abs().max()) == 0.0 and float(tr.ct[0]) != float(g["p2n_raw"].reshape(-1)[0])
+
+
+def test_tangent_mlp_matrix_core_kernels_vs_f32_kernels(amd, spec, full_table_cache):
+    """ren_mlp_fwd_jvp_x / ren_mlp_bwd_jvp_x (mode 6: fp32 accuracy, mode 1: bf16 operands) vs the exact-f32 MFMA tangent
+    kernels on 200 k samples of a random stream: every output, both feature gradients and the parameter gradient."""
+    import ctypes
+    from robust_e_nerf_amd import _lib
+    from oracle import field
+    ops, engine = amd
+    lib = _lib.load()
+    P = ops._ptr
+    R, S = 2048, 100
+    o, d = make_rays(R, seed=11)
+    gen = torch.Generator().manual_seed(12)
+    od, dd = torch.randn(R, 3, generator=gen) * 0.3, torch.randn(R, 3, generator=gen) * 0.3
+    n = R * S
+    ri = dev(torch.arange(R, dtype=torch.int32).repeat_interleave(S))
+    tsv = torch.rand(n, generator=gen) * 3 + 2.5
+    ts, te = dev(tsv), dev(tsv + 0.01)
+    nb = ops.n_blocks32(n)
+    feat, featd = dev(torch.randn(nb * 1024, generator=gen) * 0.3), dev(torch.randn(nb * 1024, generator=gen) * 0.3)
+    p = field.init_params(spec, seed=9)
+    fld = engine.NGPField(DEV)
+    p["hash"] = full_table_cache(7, 0.5)
+    fld.load(p)
+    scene = ops.make_scene_desc([-1.5] * 3 + [1.5] * 3, 0)
+    o_, d_, dd_ = dev(o), dev(d), dev(dd)
+    st = ops._stream()
+    g_rgb, g_rgbd = dev(torch.randn(n, 1, generator=gen)), dev(torch.randn(n, 1, generator=gen))
+    g_sig, g_sigd = dev(torch.randn(n, generator=gen)), dev(torch.randn(n, generator=gen))
+
+    def run(mode):
+        rgb, rgbd = torch.empty(n, 1, device=DEV), torch.empty(n, 1, device=DEV)
+        sig, sigd = torch.empty(n, device=DEV), torch.empty(n, device=DEV)
+        base, based = torch.empty(nb * 512, device=DEV), torch.empty(nb * 512, device=DEV)
+        if mode == 0:
+            rc = lib.ren_mlp_fwd_jvp(P(fld.mlp), 1, P(feat), P(featd), ctypes.byref(scene), P(o_), P(d_), P(dd_), P(ri), P(ts),
+                                     P(te), n, P(rgb), P(rgbd), P(sig), P(sigd), P(base), P(based), st)
+        else:
+            rc = lib.ren_mlp_fwd_jvp_x(P(fld.mlp), 1, mode, P(feat), P(featd), ctypes.byref(scene), P(o_), P(d_), P(dd_), P(ri),
+                                       P(ts), P(te), n, P(rgb), P(rgbd), P(sig), P(sigd), P(base), P(based), st)
+        assert rc == 0
+        scratch = torch.empty(nb * 5120, device=DEV)
+        dfeat, dfeatd = torch.empty(nb * 1024, device=DEV), torch.empty(nb * 1024, device=DEV)
+        gp = torch.zeros_like(fld.mlp)
+        if mode == 0:
+            ws = torch.empty(int(lib.ren_mlp_bwd_jvp_workspace_floats(1)), device=DEV)
+            rc = lib.ren_mlp_bwd_jvp(P(fld.mlp), 1, P(feat), P(featd), P(base), P(based), ctypes.byref(scene), P(o_), P(d_),
+                                     P(dd_), P(ri), P(ts), P(te), n, P(rgb), P(g_rgb), P(g_rgbd), P(g_sig), P(g_sigd),
+                                     P(scratch), P(dfeat), P(dfeatd), P(gp), P(ws), st)
+        else:
+            ws = torch.empty(int(lib.ren_mlp_bwd_jvp_x_workspace_floats(1)), device=DEV)
+            rc = lib.ren_mlp_bwd_jvp_x(P(fld.mlp), 1, mode, P(feat), P(featd), P(base), P(based), ctypes.byref(scene), P(o_),
+                                       P(d_), P(dd_), P(ri), P(ts), P(te), n, P(rgb), P(g_rgb), P(g_rgbd), P(g_sig),
+                                       P(g_sigd), P(scratch), P(dfeat), P(dfeatd), P(gp), P(ws), st)
+        assert rc == 0
+        torch.cuda.synchronize()
+        return dict(rgb=rgb, rgbd=rgbd, sig=sig, sigd=sigd, base=base, based=based, dfeat=dfeat, dfeatd=dfeatd, gp=gp)
+
+    ref, x6, x1 = run(0), run(6), run(1)
+    for k in ref:
+        e6, e1 = rel_err(x6[k].cpu(), ref[k].cpu()), rel_err(x1[k].cpu(), ref[k].cpu())
+        print(f"{k:7s} mode 6 {e6:.2e}   mode 1 (bf16 operands) {e1:.2e}")
+        assert e6 < (5e-5 if k == "gp" else 5e-6), (k, e6)       # fp32 round-off (the parameter gradient sums 200 k terms)
+        assert e1 < 5e-2, (k, e1)                                 # bf16 operands: 2^-9 per operand
+
+
+def test_config_c3_bf16_lgrad_step_vs_oracle(amd, spec, full_table_cache):
+    """BASELINE configs[2]: C_p + tau optimised, l_grad on, bf16 MLP with fp32 composite.  One whole step (three
+    renders, tangent render on the bf16 matrix cores in mode 1) vs the oracle with its bf16_linear() emulation
+    (bf16-rounded linear inputs / weights, fp32 accumulation, straight-through backward).  The kernel also rounds the
+    TANGENT operands of every layer to bf16 (the emulation keeps them fp32), so the tolerance on d(log I)/dt terms is
+    the bf16 operand precision (2^-9), stated below; loss and intensities are compared tighter."""
+    from oracle import field, step as ostep
+    ops, engine = amd
+    g = load_golden("training_step_grad")
+    table = full_table_cache(g["table_seed"], g["table_scale"])
+    tr, batch = _trainer_from_golden(engine, g, table, mlp_bf16=True)
+    w_grad = float(g["w_grad"])
+    tr.t.w_grad, tr.t.err_grad, tr.t.pw_grad = w_grad, "mape", None
+    tr.t.train_contrast_threshold = True
+    tr.t.train_refractory_period = True
+    batch["u_grad"] = dev(g["u_grad"])
+    jit = t(g["jitters"])
+    loss_d, aux = tr.forward_backward(batch, dev(jit[1]), dev(jit[2]))
+    loss_g, aux_g = tr.grad_loss_forward_backward(batch, dev(jit[0]))
+    occ_res = int(g["occ_res"])
+    binary = t(np.unpackbits(g["binary"])[: occ_res ** 3].astype(bool)).view(occ_res, occ_res, occ_res)
+    cfg = ostep.SceneCfg(occ_res=(occ_res,) * 3, render_step_size=float(g["render_step_size"]))
+    ob = ostep.EventBatch(t(g["position"]), t(g["start_ts"]), t(g["end_ts"]), t(g["num_pos"]), t(g["num_neg"]),
+                          t(g["u_ts_diff"]), t(g["u_diff_start"]), t(g["u_grad"]))
+    po = {k: v.clone().requires_grad_() for k, v in field_params_from(g, table).items()}
+    tau_raw = t(g["tau_raw"]).clone().requires_grad_()
+    p2n = t(g["p2n_raw"]).clone().requires_grad_()
+    with field.bf16_linear():
+        loss_o, aux_o = ostep.training_forward(
+            ob, po, spec, cfg, Kinv=t(g["Kinv"]), tab_ts=t(g["tab_ts"]), tab_pos=t(g["tab_pos"]),
+            tab_quat=t(g["tab_quat"]), p2n_raw=p2n, neg_ct=t(g["neg_ct"]), tau_raw=tau_raw, tau_max=t(g["tau_max"]),
+            bkgd_raw=t(g["bkgd_raw"]), binary=binary, jitter_start=jit[1], jitter_end=jit[2], jitter_grad=jit[0],
+            loss_cfg=dict(w_grad=w_grad, err_grad="mape", pw_grad=None))
+        loss_o.backward()
+    loss = float(loss_d) + float(loss_g)
+    e_loss = abs(loss - float(loss_o)) / abs(float(loss_o))
+    e_int = rel_err(aux["intensity_start"].cpu(), aux_o["intensity_start"].detach())
+    e_dlog = rel_err(aux_g["dlog_dt"].cpu().double(), aux_o["pred_log_grad"].detach().double())
+    f = tr.r.field
+    e_gw = max(rel_err(v.cpu(), po[k].grad) for k, v in f.mlp_views(grad=True).items())
+    nz = po["hash"].grad.reshape(-1).abs().topk(4096).indices
+    e_gt = rel_err(f.g_table.cpu()[nz], po["hash"].grad.reshape(-1)[nz])
+    sg = torch.sigmoid(tr.tau_raw.detach() / tr.tau_max)
+    e_tau = rel_err(tr.tau_grad * sg * (1 - sg), tau_raw.grad)
+    e_ct = rel_err(tr.ct_grad[:1].cpu(), p2n.grad.reshape(-1)[:1])
+    print(f"configs[2] step vs bf16 emulation: loss {e_loss:.2e} intensity {e_int:.2e} dlogI/dt {e_dlog:.2e} "
+          f"MLP grads {e_gw:.2e} table grad {e_gt:.2e} d/dtau {e_tau:.2e} d/dC_p {e_ct:.2e}; "
+          f"loss vs the fp32 reference step {abs(loss - float(g['loss'])) / abs(float(g['loss'])):.2e}")
+    assert e_int < 1e-3 and e_loss < 1e-2 and e_dlog < 5e-2
+    assert e_gw < 5e-2 and e_gt < 5e-2 and e_tau < 5e-2 and e_ct < 2e-2
+    tr.optimizer_step()
 
 
 def test_refractory_period_gradient_full_step_vs_reference_golden(amd, full_table_cache):
