@@ -100,13 +100,32 @@ def install_stubs():
                 raise RuntimeError("not training")
             if step % n == 0:
                 cells = self.occs.numel()
-                assert step < warmup_steps, "golden generator only exercises the warm-up policy"
-                idx = torch.arange(cells)
-                jit = torch.rand(cells, 3)
-                self.updates.append(dict(indices=idx, jitter=jit))
-                self.occs, b = occgrid.update(self.occs, tuple(self.resolution), self._roi_aabb,
-                                              self.contraction_type.value, idx, jit, occ_eval_fn,
-                                              occ_thre, ema_decay)
+                if step < warmup_steps:
+                    idx = torch.arange(cells)
+                else:
+                    # nerfacc 0.3.x OccupancyGrid._sample_uniform_and_occupied_cells(cells // 4) (restated: SURVEY App. A.1)
+                    k = cells // 4
+                    uni = torch.randint(cells, (k,))
+                    occ_idx = torch.nonzero(self._binary.flatten())[:, 0]
+                    if k < len(occ_idx):
+                        occ_idx = occ_idx[torch.randint(len(occ_idx), (k,))]
+                    idx = torch.cat([uni, occ_idx])
+                jit = torch.rand(idx.shape[0], 3).half().float()   # fp16-representable: fixtures store it in 2 bytes
+                drawn = []
+                orig_randint = torch.randint
+
+                def logging_randint(*a, **kw):          # the reference's occ_eval_fn draws one camera per point (nerf.py:177-181)
+                    out = orig_randint(*a, **kw)
+                    drawn.append(out.clone())
+                    return out
+                torch.randint = logging_randint
+                try:
+                    self.occs, b = occgrid.update(self.occs, tuple(self.resolution), self._roi_aabb,
+                                                  self.contraction_type.value, idx, jit, occ_eval_fn,
+                                                  occ_thre, ema_decay)
+                finally:
+                    torch.randint = orig_randint
+                self.updates.append(dict(indices=idx, jitter=jit, cam_ids=drawn[0] if drawn else None, step=step))
                 self._binary = b
 
     def ray_marching(rays_o, rays_d, t_min=None, t_max=None, scene_aabb=None, grid=None,
@@ -398,12 +417,23 @@ def gen_trajectory(trajectories, nerf_mod):
     return ts_tab, pos, quat, K
 
 
-def gen_training_step(mods, with_grad_loss: bool):
-    """The reference's real RobustENeRF.training_step over the oracle-backed stubs."""
+E_AABB = [0.5, -2.1, 0.6, 2.0, -0.6, 1.6]                  # configs/train/mocap-desk2.yaml:38-39
+
+
+def gen_training_step(mods, with_grad_loss: bool, config_e: bool = False):
+    """The reference's real RobustENeRF.training_step over the oracle-backed stubs.
+
+    config_e: the settings of configs/train/mocap-desk2.yaml (BASELINE configs[4]): sphere contraction (=> scene_aabb=None,
+    rays march near -> far, nerf.py:248-251), cone angle 0.004, near / far planes, no background parameter
+    (alpha_over_white_bg false => is_valid = opacity > 0), l_grad on, C_p and tau trainable, and an occupancy-grid update
+    inside the step (global_step 16) with the cone-angle step sizes of nerf.py:175-193."""
     rmod, nerf_mod, trajectories, egp, loss_mod, nerfacc = mods
     JITTER_LOG.clear()
-    torch.manual_seed(50 + int(with_grad_loss))
+    torch.manual_seed(50 + int(with_grad_loss) + 7 * int(config_e))
     ts_tab, pos, quat = orbit_poses()
+    if config_e:                                            # orbit inside the room, around the centre of the AABB
+        centre = np.array([1.25, -1.35, 1.1], np.float32)
+        pos = (pos * np.array([0.22, 0.22, 0.3], np.float32) + centre).astype(np.float32)
     K = np.array([[480.0, 0, 172.5], [0, 480.0, 129.5], [0, 0, 1]], np.float32)
     tmp = tempfile.mkdtemp()
     np.savez(os.path.join(tmp, "camera_calibration.npz"), intrinsics=K,
@@ -423,14 +453,18 @@ def gen_training_step(mods, with_grad_loss: bool):
         contrast_threshold=dict(freeze=not with_grad_loss), refractory_period=dict(freeze=not with_grad_loss))
     m.has_bayer_filter = False
     m.register_buffer("train_intrinsics_inv", torch.linalg.inv(torch.from_numpy(K)), persistent=False)
-    m.render_bkgd = "parameter"
+    m.render_bkgd = None if config_e else "parameter"      # robust_e_nerf.py:154-159
     m.contrast_threshold = egp.ContrastThreshold(tmp)
     m.refractory_period = egp.RefractoryPeriod(tmp)
     occ_cfg = EasyDict(resolution=occ_res, occ_thre=1e-2, ema_decay=0.95, warmup_steps=256, n=16)
-    step = 3 ** 0.5 * 3.0 / 1024
-    m.nerf = nerf_mod.NeRF([-1.5] * 3 + [1.5] * 3, nerfacc.ContractionType.AABB, occ_cfg, None, None, step,
-                           "parameter", 0.0, 1e-4, 0.0, 16384, "ngp", EasyDict(NGP_CFG), 3, 1)
-    m.nerf.occupancy_grid._binary = ball_binary(occ_res)
+    step = 3 ** 0.5 * (1.5 if config_e else 3.0) / 1024      # "auto": robust_e_nerf.py:220-226
+    if config_e:
+        m.nerf = nerf_mod.NeRF(E_AABB, nerfacc.ContractionType.UN_BOUNDED_SPHERE, occ_cfg, 0.05, 3.0, step,
+                               None, 0.004, 1e-4, 0.0, 16384, "ngp", EasyDict(NGP_CFG), 3, 1)
+    else:
+        m.nerf = nerf_mod.NeRF([-1.5] * 3 + [1.5] * 3, nerfacc.ContractionType.AABB, occ_cfg, None, None, step,
+                               "parameter", 0.0, 1e-4, 0.0, 16384, "ngp", EasyDict(NGP_CFG), 3, 1)
+        m.nerf.occupancy_grid._binary = ball_binary(occ_res)
     cam = EasyDict(camera_poses=EasyDict(
         T_wc_position=torch.from_numpy(pos), T_wc_orientation=torch.from_numpy(quat),
         T_wc_timestamp=torch.from_numpy(ts_tab)))
@@ -440,7 +474,7 @@ def gen_training_step(mods, with_grad_loss: bool):
     ns = types.SimpleNamespace
     m.trainer = ns(accumulate_grad_batches=1,
                    datamodule=ns(train_dataset=ns(batch_size=B), train_normalized_sampler=ns(datasets=[])))
-    m.global_step = 1                                      # not a multiple of n=16: no grid refresh
+    m.global_step = 16 if config_e else 1                  # 1: not a multiple of n=16, no grid refresh
     logged = {}
     m.log = lambda k, v, **kw: logged.__setitem__(k, float(v))
     m.all_gather = lambda t: t.unsqueeze(0)
@@ -475,7 +509,14 @@ def gen_training_step(mods, with_grad_loss: bool):
         extra = dict(
             g_p2n_raw=named["contrast_threshold.parametrizations.p2n_contrast_threshold_ratio.original"].grad,
             g_tau_raw=named["refractory_period.parametrizations._refractory_period.original"].grad)
-    save("training_step_grad" if with_grad_loss else "training_step_diff",
+    if config_e:
+        up = m.nerf.occupancy_grid.updates[0]
+        assert len(m.nerf.occupancy_grid.updates) == 1 and up["cam_ids"] is not None
+        extra.update(aabb=np.array(E_AABB, np.float32), near_plane=0.05, far_plane=3.0, cone_angle=0.004,
+                     occ_step=up["step"], occ_jitter=up["jitter"].numpy().astype(np.float16),
+                     occ_cam_ids=up["cam_ids"].reshape(-1).numpy().astype(np.uint8),
+                     occ_occs_after=m.nerf.occupancy_grid.occs)
+    save("training_step_e" if config_e else "training_step_grad" if with_grad_loss else "training_step_diff",
          table_seed=TABLE_SEED, table_scale=TABLE_SCALE, occ_res=occ_res,
          binary=np.packbits(m.nerf.occupancy_grid._binary.numpy().reshape(-1)),
          tab_ts=ts_tab, tab_pos=pos, tab_quat=quat, Kinv=m.train_intrinsics_inv,
@@ -486,10 +527,10 @@ def gen_training_step(mods, with_grad_loss: bool):
          neg_ct=m.contrast_threshold.neg_contrast_threshold,
          tau_raw=named["refractory_period.parametrizations._refractory_period.original"],
          tau_max=m.refractory_period.max_refractory_period,
-         bkgd_raw=named["nerf.parametrizations.render_bkgd.original"],
+         bkgd_raw=named.get("nerf.parametrizations.render_bkgd.original", torch.zeros(1)),
          loss=loss, w_grad=w_grad,
          logged_keys=np.array(sorted(logged)), logged_vals=np.array([logged[k] for k in sorted(logged)]),
-         g_bkgd_raw=named["nerf.parametrizations.render_bkgd.original"].grad,
+         g_bkgd_raw=named["nerf.parametrizations.render_bkgd.original"].grad if not config_e else torch.zeros(1),
          g_table_sum=gt.double().sum(), g_table_abs=gt.double().abs().sum(), g_table_idx=pick,
          g_table_val=gt[pick], **field_params_np(rf), **grads, **extra)
 
@@ -549,6 +590,7 @@ def main():
     mods = (rmod, nerf_mod, trajectories, egp, loss_mod, nerfacc)
     gen_training_step(mods, with_grad_loss=False)
     gen_training_step(mods, with_grad_loss=True)
+    gen_training_step(mods, with_grad_loss=True, config_e=True)
 
 
 if __name__ == "__main__":

@@ -1122,6 +1122,63 @@ def test_config_c3_bf16_lgrad_step_vs_oracle(amd, spec, full_table_cache):
     tr.optimizer_step()
 
 
+def test_config_e_step_vs_reference_golden(amd, full_table_cache):
+    """BASELINE configs[4] settings (configs/train/mocap-desk2.yaml:38-51): the reference's real training_step with
+    sphere contraction (scene_aabb=None: rays march near -> far, nerf.py:248-251), cone angle 0.004, near / far planes,
+    no background parameter (is_valid = opacity > 0, robust_e_nerf.py:868-871), l_grad, C_p and tau trainable, and
+    the occupancy refresh inside that step with the cone-angle step sizes of nerf.py:175-193 -- vs the HIP path
+    (~610 samples per ray; exercises the sphere branches of the marcher, encoder, MLP and all tangent kernels)."""
+    ops, engine = amd
+    g = load_golden("training_step_e")
+    table = full_table_cache(g["table_seed"], g["table_scale"])
+    occ_res = int(g["occ_res"])
+    cells = occ_res ** 3
+    cfg = engine.RenderCfg(aabb=tuple(float(v) for v in g["aabb"]), contraction_type=ops.UN_BOUNDED_SPHERE,
+                           occ_res=(occ_res,) * 3, near_plane=float(g["near_plane"]), far_plane=float(g["far_plane"]),
+                           render_step_size=float(g["render_step_size"]), cone_angle=float(g["cone_angle"]))
+    fld = engine.NGPField(DEV)
+    fld.load(field_params_from(g, table))
+    r = engine.Renderer(fld, cfg)
+    tcfg = engine.TrainCfg(bkgd_is_param=False, w_grad=float(g["w_grad"]), err_grad="mape", pw_grad=None,
+                           train_contrast_threshold=True, train_refractory_period=True)
+    tr = engine.Trainer(r, tcfg, Kinv=t(g["Kinv"]), tab_ts=t(g["tab_ts"]), tab_pos=t(g["tab_pos"]),
+                        tab_quat=t(g["tab_quat"]), p2n_raw=t(g["p2n_raw"]), neg_ct=t(g["neg_ct"]),
+                        tau_raw=t(g["tau_raw"]), tau_max=t(g["tau_max"]), bkgd_raw=torch.zeros(1))
+    # ---- occupancy refresh (warm-up policy: every cell; one random camera per cell inside the contraction sphere)
+    idx = torch.arange(cells)
+    jit = t(g["occ_jitter"]).float()
+    _, valid = ops.occgrid_cell_points(dev(idx), dev(jit), cfg.aabb, cfg.occ_res, cfg.contraction_type)
+    cam = torch.zeros(cells, dtype=torch.int64)
+    cam[valid.cpu().bool()] = t(g["occ_cam_ids"]).long()
+    assert r.update_occ_grid(int(g["occ_step"]), cam_positions=dev(g["tab_pos"]), indices=dev(idx), jitter=dev(jit),
+                             cam_ids=dev(cam))
+    assert rel_err(r.occs.cpu(), g["occ_occs_after"]) < 1e-4
+    gold_bin = torch.from_numpy(np.unpackbits(g["binary"])[:cells].astype(np.uint8))
+    assert float((r.binary.cpu() != gold_bin).float().mean()) < 1e-3          # cells at the threshold may flip
+    r.binary.copy_(dev(gold_bin))
+    # ---- the step
+    batch = dict(position=dev(g["position"]), start_ts=dev(g["start_ts"]), end_ts=dev(g["end_ts"]),
+                 num_pos=dev(g["num_pos"]), num_neg=dev(g["num_neg"]), u_ts_diff=dev(g["u_ts_diff"]),
+                 u_diff_start=dev(g["u_diff_start"]), u_grad=dev(g["u_grad"]))
+    jit = t(g["jitters"])
+    loss_d, aux = tr.forward_backward(batch, dev(jit[1]), dev(jit[2]))
+    loss_g, aux_g = tr.grad_loss_forward_backward(batch, dev(jit[0]))
+    loss = float(loss_d) + float(loss_g)
+    assert abs(loss - float(g["loss"])) < 1e-4 * abs(float(g["loss"])), (loss, float(g["loss"]))
+    logged = dict(zip(g["logged_keys"].tolist(), g["logged_vals"].tolist()))
+    assert abs((aux["n"] + aux_g["n"]) / (aux["rays"] + aux_g["rays"]) - logged["train/mean_num_samples_per_ray"]) < 1e-2
+    assert abs(float(loss_g) / float(g["w_grad"]) - logged["train/log_intensity_grad"]) < 1e-3 * logged["train/log_intensity_grad"]
+    f = tr.r.field
+    for k, v in f.mlp_views(grad=True).items():
+        assert rel_err(v.cpu(), g["g." + k]) < 3e-3, k
+    idx = t(g["g_table_idx"])
+    assert rel_err(f.g_table.cpu()[idx], g["g_table_val"]) < 3e-3
+    assert rel_err(tr.ct_grad[:1].cpu(), g["g_p2n_raw"]) < 1e-3
+    sg = torch.sigmoid(tr.tau_raw.detach() / tr.tau_max)
+    assert rel_err(tr.tau_grad * sg * (1 - sg), torch.as_tensor(g["g_tau_raw"]).double()) < 5e-3
+    tr.optimizer_step()
+
+
 def test_refractory_period_gradient_full_step_vs_reference_golden(amd, full_table_cache):
     """d(l_diff + l_grad)/d(tau) vs the REFERENCE's own training_step (C_p and tau trainable, golden
     `g_tau_raw`).  The l_grad part needs d2I/dt2 per ray: second-order forward tangent (csrc/ren_jvp2.hip)

@@ -77,13 +77,19 @@ def test_field_forward_backward(ct, full_table_cache):
     assert abs(float(table.grad.double().abs().sum()) - float(g["g_table_abs"])) < 1e-4 * float(g["g_table_abs"])
 
 
-def _run_training_step(g, table, with_grad):
+def _run_training_step(g, table, with_grad, config_e=False):
     p = field_params_from(g, table)
     for v in p.values():
         v.requires_grad_()
     occ_res = int(g["occ_res"])
     binary = t(np.unpackbits(g["binary"])[: occ_res ** 3].astype(bool)).view(occ_res, occ_res, occ_res)
     cfg = step.SceneCfg(occ_res=(occ_res,) * 3, render_step_size=float(g["render_step_size"]), sampler="occgrid")
+    if config_e:                                             # configs/train/mocap-desk2.yaml:38-51
+        from oracle import field as ofield
+        cfg = step.SceneCfg(aabb=tuple(float(v) for v in g["aabb"]), contraction_type=ofield.UN_BOUNDED_SPHERE,
+                            occ_res=(occ_res,) * 3, near_plane=float(g["near_plane"]), far_plane=float(g["far_plane"]),
+                            render_step_size=float(g["render_step_size"]), cone_angle=float(g["cone_angle"]),
+                            bkgd_is_param=False, sampler="occgrid")
     batch = step.EventBatch(t(g["position"]), t(g["start_ts"]), t(g["end_ts"]), t(g["num_pos"]), t(g["num_neg"]),
                             t(g["u_ts_diff"]), t(g["u_diff_start"]), t(g["u_grad"]))
     bkgd_raw = t(g["bkgd_raw"]).requires_grad_()
@@ -131,6 +137,44 @@ def test_training_step_grad(full_table_cache):
     for k in FIELD_KEYS:
         assert rel_err(p[k].grad, g["g." + k]) < 5e-4, k
     assert rel_err(bkgd_raw.grad, g["g_bkgd_raw"]) < 1e-4
+    assert rel_err(p["hash"].grad[t(g["g_table_idx"])], g["g_table_val"]) < 5e-4
+    assert rel_err(aux["leaves"]["p2n_raw"].grad, g["g_p2n_raw"]) < 1e-4
+    assert rel_err(aux["leaves"]["tau_raw"].grad, g["g_tau_raw"]) < 1e-3
+
+
+def test_training_step_config_e(full_table_cache):
+    """The reference's real training_step at the settings of configs/train/mocap-desk2.yaml (BASELINE configs[4]):
+    sphere contraction with scene_aabb=None (rays march near -> far), cone angle, no background parameter (is_valid =
+    opacity > 0), l_grad, C_p / tau trainable -- and the occupancy refresh inside that step with the cone-angle step
+    sizes of nerf.py:175-193 (warm-up policy, one random camera per cell)."""
+    from oracle import field as ofield, occgrid
+    g = load_golden("training_step_e")
+    table = full_table_cache(g["table_seed"], g["table_scale"]).clone()
+    # ---- occupancy refresh that ran inside the reference step
+    occ_res = int(g["occ_res"])
+    p0 = field_params_from(g, table)
+    aabb = t(g["aabb"])
+    cells = occ_res ** 3
+    cam_ids, tab_pos = t(g["occ_cam_ids"]).long(), t(g["tab_pos"])
+    step_size = float(g["render_step_size"])
+
+    def occ_eval_fn(x):
+        dens = ofield.query_density(x, p0, SPEC, aabb, ofield.UN_BOUNDED_SPHERE)
+        return occgrid.occ_eval(x, lambda _: dens, step_size, float(g["cone_angle"]), tab_pos, cam_ids,
+                                float(g["near_plane"]), float(g["far_plane"]))
+    occs, binary = occgrid.update(torch.zeros(cells), (occ_res,) * 3, aabb, ofield.UN_BOUNDED_SPHERE, torch.arange(cells),
+                                  t(g["occ_jitter"]).float(), occ_eval_fn, 1e-2, 0.95)
+    assert rel_err(occs, g["occ_occs_after"]) < 1e-5
+    gold_bin = np.unpackbits(g["binary"])[:cells].astype(bool)
+    assert (binary.reshape(-1).numpy() != gold_bin).mean() < 1e-4
+    # ---- the step itself
+    loss, aux, p, bkgd_raw = _run_training_step(g, table, True, config_e=True)
+    assert rel_err(loss, g["loss"]) < 1e-5
+    logged = dict(zip(g["logged_keys"].tolist(), g["logged_vals"].tolist()))
+    assert abs(aux["n_start"] + aux["n_end"] + aux["grad"][3] - 3 * 96 * logged["train/mean_num_samples_per_ray"]) < 1.0
+    loss.backward()
+    for k in FIELD_KEYS:
+        assert rel_err(p[k].grad, g["g." + k]) < 5e-4, k
     assert rel_err(p["hash"].grad[t(g["g_table_idx"])], g["g_table_val"]) < 5e-4
     assert rel_err(aux["leaves"]["p2n_raw"].grad, g["g_p2n_raw"]) < 1e-4
     assert rel_err(aux["leaves"]["tau_raw"].grad, g["g_tau_raw"]) < 1e-3
