@@ -71,9 +71,21 @@ def synthetic_scene(n_poses=2001, seed=0):
     return ts, pos.astype(np.float32), quat, np.linalg.inv(K).astype(np.float32)
 
 
-def synthetic_events(B, t_end_ns, seed):
+E_AABB = (0.5, -2.1, 0.6, 2.0, -0.6, 1.6)          # configs/train/mocap-desk2.yaml:38-39
+
+
+def synthetic_scene_e(n_poses=2001):
+    """BASELINE configs[4] / SURVEY 8(d) config E: a hand-held orbit inside the mocap room (AABB above), 640x480, f = 500."""
+    ts, pos, quat, _ = synthetic_scene(n_poses)
+    centre = np.array([1.25, -1.35, 1.1], np.float32)
+    pos = (pos * np.array([0.22, 0.22, 0.3], np.float32) + centre).astype(np.float32)
+    K = np.array([[500.0, 0, 319.5], [0, 500.0, 239.5], [0, 0, 1]], np.float32)
+    return ts, pos, quat, np.linalg.inv(K).astype(np.float32)
+
+
+def synthetic_events(B, t_end_ns, seed, width=346, height=260):
     g = np.random.default_rng(seed)
-    px = np.stack([g.integers(0, 346, B), g.integers(0, 260, B)], -1).astype(np.float32)
+    px = np.stack([g.integers(0, width, B), g.integers(0, height, B)], -1).astype(np.float32)
     end = g.integers(20_000_000, t_end_ns, B).astype(np.int64)
     delta = np.exp(g.uniform(np.log(2e5), np.log(2e7), B)).astype(np.int64)
     pol = g.random(B) < 0.5
@@ -133,6 +145,10 @@ def main():
                     help="events per step per GPU (2 rays each): 32768 = the 65536-ray batch of BASELINE configs[1]")
     ap.add_argument("--samples", type=int, default=128, help="samples per ray (uniform sampler)")
     ap.add_argument("--sampler", default="uniform", choices=["uniform", "occgrid"])
+    ap.add_argument("--workload", default="b", choices=["b", "e"],
+                    help="b: BASELINE configs[1] (default).  e: the settings of configs[4] / configs/train/mocap-desk2.yaml on "
+                         "synthetic events: sphere contraction (rays march near -> far), 256^3 occupancy grid, cone angle 0.004, "
+                         "near 0.05 / far 3.0, l_diff + l_grad, C_p and tau trainable, no background parameter, 640x480 camera")
     ap.add_argument("--arch", default="ngp", choices=["ngp", "mlp"],
                     help="ngp = hash grid (BASELINE configs[1], default); mlp = frequency encoding + 8x256 MLP "
                          "(10.4 KB of saved activations per sample: use --events 8192 or less)")
@@ -180,7 +196,11 @@ def main():
 
     from robust_e_nerf_amd import engine, ops          # the oracle is imported by the cpu_baseline leg only
 
-    scene = synthetic_scene()
+    if args.workload == "e":
+        args.sampler = "occgrid"
+        if args.loss_grad == 0.0:
+            args.loss_grad = 1e-3
+    scene = synthetic_scene_e() if args.workload == "e" else synthetic_scene()
     tab_ts, tab_pos, tab_quat, Kinv = scene
     T = torch.from_numpy
     # field parameters: torch nn.Linear default init, hash table U(+-0.1) ("trained-like": random
@@ -202,6 +222,13 @@ def main():
     cfg = engine.RenderCfg(aabb=aabb, sampler=args.sampler, n_uniform=args.samples, mlp_bf16=args.mlp_bf16,
                            mlp_kernels=args.mlp_kernels, fwd_chunks=args.fwd_chunks,
                            save_activations=None if args.save_activations < 0 else bool(args.save_activations))
+    if args.workload == "e":
+        aabb = E_AABB
+        cfg = engine.RenderCfg(aabb=aabb, contraction_type=ops.UN_BOUNDED_SPHERE, occ_res=(256,) * 3, near_plane=0.05,
+                               far_plane=3.0, render_step_size=math.sqrt(3) * 1.5 / 1024, cone_angle=0.004,
+                               sampler="occgrid", mlp_bf16=args.mlp_bf16, mlp_kernels=args.mlp_kernels,
+                               fwd_chunks=args.fwd_chunks,
+                               save_activations=None if args.save_activations < 0 else bool(args.save_activations))
     if args.arch == "mlp":
         from robust_e_nerf_amd import vanilla
         fld = vanilla.VanillaField(dev, 1)
@@ -212,9 +239,17 @@ def main():
         fld = engine.NGPField(dev)
         fld.load(p)
         r = engine.Renderer(fld, cfg)
-    if args.sampler == "occgrid":
+    if args.workload == "e":
+        # occupied: a ball of 40 % of the contraction sphere's radius around the room centre (objects on the desk)
+        g3 = np.stack(np.meshgrid(*[np.arange(256)] * 3, indexing="ij"), -1)
+        r.binary.copy_(T((np.linalg.norm((g3 + 0.5) / 256 - 0.5, axis=-1) < 0.1).astype(np.uint8).reshape(-1)).to(dev))
+    elif args.sampler == "occgrid":
         r.binary.copy_(T(ball_binary(128, 0.42, aabb)).to(dev))
-    tr = engine.Trainer(r, engine.TrainCfg(w_grad=args.loss_grad), Kinv=T(Kinv), tab_ts=T(tab_ts), tab_pos=T(tab_pos), tab_quat=T(tab_quat),
+    tcfg = engine.TrainCfg(w_grad=args.loss_grad)
+    if args.workload == "e":
+        tcfg = engine.TrainCfg(w_grad=args.loss_grad, bkgd_is_param=False, train_contrast_threshold=True,
+                               train_refractory_period=True)
+    tr = engine.Trainer(r, tcfg, Kinv=T(Kinv), tab_ts=T(tab_ts), tab_pos=T(tab_pos), tab_quat=T(tab_quat),
                         p2n_raw=torch.tensor(0.5413), neg_ct=torch.tensor(0.25),
                         tau_raw=torch.tensor(0.0, dtype=torch.float64), tau_max=torch.tensor(1e5),
                         bkgd_raw=torch.tensor([0.5413]), world_size=world, process_group=pg)
@@ -223,7 +258,8 @@ def main():
     n_batches = 4                                    # pre-staged in HBM; per-rank seeds (datamodule.py:85-89)
     batches = []
     for b in range(n_batches):
-        ev = synthetic_events(B, int(tab_ts[-1]), seed=1 + 1000 * rank + b)
+        ev = synthetic_events(B, int(tab_ts[-1]), seed=1 + 1000 * rank + b,
+                              **(dict(width=640, height=480) if args.workload == "e" else {}))
         batches.append({k: T(v).to(dev).contiguous() for k, v in ev.items()})
     jgen = torch.Generator(device=dev).manual_seed(3 + rank)
 
@@ -305,7 +341,9 @@ def main():
             "dtype": "bf16-operand/f32-accumulate MLP, f32 elsewhere" if args.mlp_bf16 else "f32", "data": "synthetic",
             "mlp_samples_per_sec": n_samples / dt, "mean_samples_per_ray": n_samples / rays,
             "loss": float(loss),
-            "config": {"workload": "BASELINE configs[1]: synthetic ficus-like event stream, "
+            "config": {"workload": ("BASELINE configs[4] settings (mocap-desk2.yaml: sphere contraction, 256^3 grid, cone 0.004, "
+                                    "near/far, C_p + tau trainable) on synthetic events, " if args.workload == "e" else
+                                    "BASELINE configs[1]: synthetic ficus-like event stream, ") +
                                    f"{B} events/step/GPU = {2 * B} rays x {args.samples} samples, arch {args.arch}, fp32, "
                                    f"{'l_diff + l_grad (3 renders)' if args.loss_grad > 0 else 'l_diff (2 renders)'}, fwd+bwd+Adam; sampler={args.sampler}",
                        "events_per_step_per_gpu": B, "rays_per_step_per_gpu": 2 * B, "sampler": args.sampler,
