@@ -169,12 +169,21 @@ def load_calibration(root: str) -> Dict[str, object]:
 
 
 # ------------------------------------------------------------------------------------------- batcher
-def trunc_normal(low, high, size, mean, std, dtype, generator, device):
-    """samplers.py:33-80 (inverse-CDF truncated normal)."""
+def trunc_normal_from_uniform(u01: torch.Tensor, low, high, mean, std) -> torch.Tensor:
+    """samplers.py:33-84 (inverse-CDF truncated normal) applied to given U[0,1) samples (what its torch.rand draws)."""
     cdf = lambda v: (1.0 + math.erf(v / math.sqrt(2.0))) / 2.0
     lo, up = cdf((low - mean) / std), cdf((high - mean) / std)
-    u = 2 * (up - lo) * torch.rand(size, dtype=dtype, generator=generator, device=device) + (2 * lo - 1)
+    u = 2 * (up - lo) * u01 + (2 * lo - 1)
     return (u.erfinv_() * (std * math.sqrt(2.0)) + mean).clamp_(low, high)
+
+
+def uniform_from_uniform(u01: torch.Tensor, low, high) -> torch.Tensor:
+    """samplers.py:6-23 (UniformSampler)"""
+    return (high - low) * u01 + low
+
+
+def trunc_normal(low, high, size, mean, std, dtype, generator, device):
+    return trunc_normal_from_uniform(torch.rand(size, dtype=dtype, generator=generator, device=device), low, high, mean, std)
 
 
 class EventBatcher:

@@ -662,15 +662,21 @@ class Trainer:
             tr_ = self.tau_max * (self.tau_raw.detach() / self.tau_max).clamp(-lim, lim)
             self.tau = float(self.tau_max * torch.sigmoid(tr_ / self.tau_max))
 
-    def update_train_batch_size(self, aux, eff_ray_sample_batch_size: int = 1 << 20) -> int:
+    def update_train_batch_size(self, aux, eff_ray_sample_batch_size: int = 1 << 20, accumulate_grad_batches: int = 1,
+                                batch_index: int = 0) -> Optional[int]:
         """Dynamic batch size (robust_e_nerf.py:907-950): keep rays x samples per render near the budget.
-        mean_S = mean over this step's renders of n/R, averaged over ranks (C2); budget = eff // num_gpus
-        (:63-66).  Returns the new per-rank event batch size."""
+        mean_S = mean over this step's renders (start, end [, grad]) of n/R, averaged over ranks (C2); budget = eff //
+        num_gpus (:63-66).  Returns the new per-rank event batch size, or None when the gradient-accumulation rule of the
+        reference skips the update for this micro-batch."""
         from . import parallel
-        mean_s = parallel.allgather_mean(aux["n"] / max(aux["rays"], 1), self.pg) if self.world_size > 1 \
-            else aux["n"] / max(aux["rays"], 1)
+        # start / end renders are one batched pass of 2B rays: (n_s / B + n_e / B) / 2 = n / 2B, twice
+        means = [aux["n"] / max(aux["rays"], 1)] * 2
+        if aux.get("grad") is not None:
+            means.append(aux["grad"]["n"] / max(aux["grad"]["rays"], 1))
+        gather = (lambda m: parallel.allgather_mean(m, self.pg)) if self.world_size > 1 else None
         budget = parallel.per_rank_budget(eff_ray_sample_batch_size, self.world_size)
-        return int(budget / max(mean_s, 1e-9))
+        mean, new = parallel.new_train_batch_size(budget, means, gather, accumulate_grad_batches, batch_index)
+        return None if new is None else max(1, new)
 
     def set_epoch(self, epoch: int, milestones=(20, 30, 36), gamma: float = 0.33):
         """MultiStepLR stepped per epoch (robust_e_nerf.py:818-832, synthetic.yaml:113-128)."""

@@ -63,3 +63,18 @@ def allgather_mean(value: float, group=None) -> float:
     t = torch.tensor([float(value)], device=dev, dtype=torch.float64)
     dist.all_reduce(t, group=group)
     return float(t) / dist.get_world_size(group)
+
+
+def new_train_batch_size(budget_per_rank: int, render_means, gather_mean=None, accumulate_grad_batches: int = 1,
+                         batch_index: int = 0):
+    """RobustENeRF.update_train_batch_size (robust_e_nerf.py:907-950): mean over this step's renders of their mean
+    number of samples per ray (grad / start / end, each its own n / R), mean over ranks (`gather_mean`), and -- unless
+    gradient accumulation is on and this is not its second-to-last micro-batch -- budget // mean as the new per-rank
+    event batch size.  -> (mean over renders and ranks, new batch size or None)."""
+    means = [float(m) for m in render_means]
+    mean = sum(means) / len(means)
+    if gather_mean is not None:
+        mean = float(gather_mean(mean))
+    if accumulate_grad_batches > 1 and batch_index % accumulate_grad_batches != accumulate_grad_batches - 2:
+        return mean, None
+    return mean, int(budget_per_rank / mean)

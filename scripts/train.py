@@ -250,8 +250,9 @@ def main():
             loss, aux = tr.step(batch, j[0], j[1], global_step=step, jitter_grad=j[2], batch_index=bi,
                                 accumulate_grad_batches=accum)
             rays += (3 if tcfg.w_grad > 0 else 2) * B
-            if accum == 1 or bi % accum == accum - 2:                            # robust_e_nerf.py:907-950
-                pending.append(tr.update_train_batch_size(aux, budget))
+            nb = tr.update_train_batch_size(aux, budget, accum, bi)              # robust_e_nerf.py:907-950
+            if nb is not None:
+                pending.append(nb)
             batcher.set_batch_size(pending.popleft() if len(pending) > 1 else pending[0])
             step += (bi + 1) % accum == 0                                        # global_step counts optimiser steps
             if rank == 0 and (bi + 1) % accum == 0 and step % log_every == 0:

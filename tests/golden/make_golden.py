@@ -569,6 +569,94 @@ def gen_events(egp, loss_mod):
          pred_diff=pred_diff, pred_grad=pred_grad, ts_diff=ts_diff, valid=valid, **out)
 
 
+def gen_dataset(datasets_mod, samplers_mod):
+    """f1: the reference's own `Event` interval construction, maximum refractory period, Bayer colourisation
+    (data/datasets.py:133-329) on a small raw stream with repeated timestamps, and its three normalized samplers
+    (data/samplers.py) together with the uniforms their generator produced."""
+    g = np.random.default_rng(70)
+    W, H, N = 24, 18, 3000
+    pos = np.stack([g.integers(0, W, N), g.integers(0, H, N)], -1).astype(np.uint16)
+    ts = np.sort(g.integers(0, 400, N)).astype(np.int64) * 1000      # many equal timestamps, also at the same pixel
+    pol = g.random(N) < 0.5
+    tmp = tempfile.mkdtemp()
+    np.savez(os.path.join(tmp, "raw_events.npz"), position=pos, timestamp=ts, polarity=pol)
+    np.savez(os.path.join(tmp, "camera_calibration.npz"), img_height=np.uint16(H), img_width=np.uint16(W),
+             bayer_pattern="RGGB", intrinsics=np.eye(3, dtype=np.float32), distortion_model="",
+             distortion_params=np.zeros(4, np.float32))
+    Ev = datasets_mod.Event
+    calib = Ev.load_camera_calibration(tmp)
+    q = Ev.queue_raw_events(tmp, calib)
+    tau_max = Ev.extract_max_refractory_period(Ev.load_raw_events(tmp), calib)
+    q = Ev.colorize_events(q, calib)
+    out = dict(raw_position=pos, raw_timestamp=ts, raw_polarity=pol, width=W, height=H, bayer_pattern="RGGB",
+               position=q.position, start_ts=q.start_ts, end_ts=q.end_ts, num_pos=q.num_pos, num_neg=q.num_neg,
+               channel_idx=q.channel_idx, max_refractory_period=tau_max)
+    # samplers: float64, the generator's uniforms next to what the sampler made of them
+    n = 512
+    gen = lambda: torch.Generator().manual_seed(71)
+    out["u01"] = torch.rand(n, dtype=torch.float64, generator=gen())
+    out["uniform_0_1"] = next(iter(samplers_mod.UniformSampler(0.0, 1.0, n, torch.float64, gen())))
+    out["uniform_m2_3"] = next(iter(samplers_mod.UniformSampler(-2.0, 3.0, n, torch.float64, gen())))
+    out["trunc_normal_05_025"] = next(iter(samplers_mod.TruncatedNormalSampler(0.0, 1.0, n, 0.5, 0.25, torch.float64, gen())))
+    out["trunc_normal_02_01"] = next(iter(samplers_mod.TruncatedNormalSampler(0.0, 1.0, n, 0.2, 0.1, torch.float64, gen())))
+    out["dirac_1"] = next(iter(samplers_mod.DiracDeltaSampler(1.0, n, torch.float64)))
+    save("dataset", **out)
+
+
+def gen_batch_size(rmod):
+    """a19: the reference's RobustENeRF.update_train_batch_size (robust_e_nerf.py:907-950) for a table of cases:
+    (ray-sample budget, mean samples per ray of the grad / start / end renders, accumulate_grad_batches, batch index)
+    -> returned mean, new per-device batch size (unchanged when the accumulation rule skips the update)."""
+    ns = types.SimpleNamespace
+    cases, res = [], []
+    g = np.random.default_rng(80)
+    for k in range(24):
+        budget = int(2 ** g.integers(14, 21)) // int(g.choice([1, 2, 8]))
+        with_grad = bool(k % 2)
+        ms = g.uniform(3.0, 700.0, 3)
+        accum = int(g.choice([1, 1, 2, 4]))
+        bi = int(g.integers(0, 8))
+        m = rmod.RobustENeRF.__new__(rmod.RobustENeRF)
+        torch.nn.Module.__init__(m)
+        m.train_ray_sample_batch_size = budget
+        ds = ns(batch_size=-1)
+        samp = [ns(size=-1), ns(size=-1)]
+        m.trainer = ns(accumulate_grad_batches=accum, datamodule=ns(train_dataset=ds, train_normalized_sampler=ns(datasets=samp)))
+        m.all_gather = lambda t: torch.stack([t, t * 1.5])          # two ranks: the other one saw 1.5x the samples
+        bg = EasyDict(mean_num_samples_per_ray=float(ms[0])) if with_grad else None
+        bd = EasyDict(start_mean_num_samples_per_ray=float(ms[1]), end_mean_num_samples_per_ray=float(ms[2]))
+        mean = m.update_train_batch_size(bg, bd, bi)
+        assert samp[0].size == ds.batch_size
+        cases.append([budget, float(with_grad), ms[0], ms[1], ms[2], accum, bi])
+        res.append([float(mean), ds.batch_size])
+    save("batch_size", cases=np.array(cases, np.float64), result=np.array(res, np.float64))
+
+
+def gen_occgrid_post_warmup(nerf_mod, nerfacc):
+    """a21 past warm-up: NeRF.update_occ_grid (nerf.py:170-204) at step 272 > warmup_steps = 256: the reference's
+    occ_eval_fn over the cells nerfacc's OccupancyGrid samples then (1/4 uniform + up to 1/4 of the occupied ones;
+    policy restated from nerfacc 0.3.x -- parity unpinned)."""
+    torch.manual_seed(90)
+    occ_res = 32
+    occ_cfg = EasyDict(resolution=occ_res, occ_thre=1e-2, ema_decay=0.95, warmup_steps=256, n=16)
+    step = 3 ** 0.5 * 3.0 / 1024
+    nerf = nerf_mod.NeRF([-1.5] * 3 + [1.5] * 3, nerfacc.ContractionType.AABB, occ_cfg, None, None, step,
+                         "parameter", 0.0, 1e-4, 0.0, 16384, "ngp", EasyDict(NGP_CFG), 3, 1)
+    nerf.train()
+    grid = nerf.occupancy_grid
+    grid._binary = ball_binary(occ_res, 0.9)
+    grid.occs = torch.rand(occ_res ** 3) * 3e-3 * grid._binary.flatten().float()
+    occs_before = grid.occs.clone()
+    _, pos, _ = orbit_poses()
+    nerf.update_occ_grid(272, torch.from_numpy(pos))
+    up = grid.updates[0]
+    save("occgrid_post_warmup", table_seed=TABLE_SEED, table_scale=TABLE_SCALE, occ_res=occ_res, step=272,
+         render_step_size=step, occs_before=occs_before, binary_before=np.packbits(ball_binary(occ_res, 0.9).numpy().reshape(-1)),
+         indices=up["indices"].numpy().astype(np.int32), jitter=up["jitter"].numpy().astype(np.float16),
+         occs_after=grid.occs, binary_after=np.packbits(grid._binary.numpy().reshape(-1)),
+         **field_params_np(nerf.radiance_field))
+
+
 def main():
     assert os.path.isdir(REF), "golden vectors can only be regenerated where /root/reference exists"
     install_stubs()
@@ -591,6 +679,10 @@ def main():
     gen_training_step(mods, with_grad_loss=False)
     gen_training_step(mods, with_grad_loss=True)
     gen_training_step(mods, with_grad_loss=True, config_e=True)
+    from robust_e_nerf.data import datasets as datasets_mod, samplers as samplers_mod
+    gen_dataset(datasets_mod, samplers_mod)
+    gen_batch_size(rmod)
+    gen_occgrid_post_warmup(nerf_mod, nerfacc)
 
 
 if __name__ == "__main__":

@@ -141,3 +141,51 @@ def test_scripts_and_tools_compile():
     assert len(files) > 10
     for f in files:
         compile(open(f).read(), f, "exec")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Fixtures generated by the REFERENCE's own code (tests/golden/make_golden.py: gen_dataset, gen_batch_size)
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_event_intervals_refractory_and_bayer_vs_reference_fixture():
+    """data/datasets.py:133-329 run by make_golden.py on a 3 000-event stream: interval construction (`queue_raw_events`),
+    `extract_max_refractory_period` and `colorize_events` -- every integer identical."""
+    g = np.load(os.path.join(GOLD, "dataset.npz"))
+    ev = data.queue_raw_events(g["raw_position"], g["raw_timestamp"], g["raw_polarity"], int(g["width"]))
+    for k in ("position", "start_ts", "end_ts", "num_pos", "num_neg"):
+        assert ev[k].dtype == torch.int64 and np.array_equal(ev[k].numpy(), g[k]), k
+    assert float(data.max_refractory_period(g["raw_position"], g["raw_timestamp"], int(g["width"]))) == float(g["max_refractory_period"])
+    col = data.colorize_events(ev, str(g["bayer_pattern"]))
+    assert col["channel_idx"].dtype == torch.uint8 and np.array_equal(col["channel_idx"].numpy(), g["channel_idx"])
+
+
+def test_normalized_samplers_vs_reference_fixture():
+    """data/samplers.py: the three samplers as transforms of the uniforms their generator drew (float64, exact)."""
+    g = np.load(os.path.join(GOLD, "dataset.npz"))
+    u = torch.from_numpy(g["u01"])
+    assert u.dtype == torch.float64
+    assert torch.equal(data.uniform_from_uniform(u.clone(), 0.0, 1.0), torch.from_numpy(g["uniform_0_1"]))
+    assert torch.equal(data.uniform_from_uniform(u.clone(), -2.0, 3.0), torch.from_numpy(g["uniform_m2_3"]))
+    assert torch.equal(data.trunc_normal_from_uniform(u.clone(), 0.0, 1.0, 0.5, 0.25), torch.from_numpy(g["trunc_normal_05_025"]))
+    assert torch.equal(data.trunc_normal_from_uniform(u.clone(), 0.0, 1.0, 0.2, 0.1), torch.from_numpy(g["trunc_normal_02_01"]))
+    assert float(np.abs(g["dirac_1"] - 1.0).max()) == 0.0
+
+
+def test_update_train_batch_size_vs_reference_fixture():
+    """a19: RobustENeRF.update_train_batch_size (robust_e_nerf.py:907-950) run by make_golden.py on 24 cases (with and
+    without the grad render, 2 ranks, accumulate_grad_batches 1 / 2 / 4): mean over renders and ranks, new batch size,
+    and the micro-batches on which the reference leaves the batch size alone."""
+    from robust_e_nerf_amd import parallel
+    g = np.load(os.path.join(GOLD, "batch_size.npz"))
+    skipped = 0
+    for (budget, with_grad, mg, ms, me, accum, bi), (mean_ref, new_ref) in zip(g["cases"], g["result"]):
+        means = ([mg] if with_grad else []) + [ms, me]
+        mean, new = parallel.new_train_batch_size(int(budget), means, lambda m: (m + 1.5 * m) / 2, int(accum), int(bi))
+        assert abs(mean - mean_ref) <= 1e-6 * mean_ref                  # the reference reduces in float32
+        if new_ref < 0:
+            assert new is None
+            skipped += 1
+        else:
+            assert new is not None and abs(new - int(new_ref)) <= 1     # int(budget / mean) at float32 vs float64 mean
+    assert 0 < skipped < len(g["cases"])

@@ -559,6 +559,75 @@ def test_occgrid_update(amd, spec, full_table_cache):
     assert not r.update_occ_grid(3)                       # only every n-th step
 
 
+def test_occgrid_update_past_warmup_vs_reference_fixture(amd, full_table_cache):
+    """a21 past warm-up: the reference's NeRF.update_occ_grid (nerf.py:170-204) at step 272 > warmup_steps over the
+    cells nerfacc's policy samples then (fixture: indices, in-cell jitter) -> EMA-max occupancies and binarisation;
+    then the engine's own draw of that policy: 1/4 of the cells uniformly + up to 1/4 among the occupied ones."""
+    ops, engine = amd
+    g = load_golden("occgrid_post_warmup")
+    table = full_table_cache(g["table_seed"], g["table_scale"])
+    occ_res = int(g["occ_res"])
+    cells = occ_res ** 3
+    cfg = engine.RenderCfg(occ_res=(occ_res,) * 3, render_step_size=float(g["render_step_size"]))
+    fld = engine.NGPField(DEV)
+    fld.load(field_params_from(g, table))
+    r = engine.Renderer(fld, cfg)
+    r.occs.copy_(dev(g["occs_before"]))
+    r.binary.copy_(dev(np.unpackbits(g["binary_before"])[:cells].astype(np.uint8)))
+    assert not r.update_occ_grid(int(g["step"]) + 1)
+    assert r.update_occ_grid(int(g["step"]), indices=dev(g["indices"].astype(np.int64)), jitter=dev(g["jitter"].astype(np.float32)))
+    assert rel_err(r.occs.cpu(), g["occs_after"]) < 1e-4
+    gold = torch.from_numpy(np.unpackbits(g["binary_after"])[:cells].astype(np.uint8))
+    assert float((r.binary.cpu() != gold).float().mean()) < 1e-3
+    # the engine's own sampling past warm-up
+    n_occ = int(r.binary.sum())
+    seen = {}
+    orig = ops.occgrid_cell_points
+    ops.occgrid_cell_points = lambda idx, *a, **k: (seen.__setitem__("idx", idx.clone()), orig(idx, *a, **k))[1]
+    try:
+        gen = torch.Generator(device=DEV).manual_seed(5)
+        occ_before = r.binary.clone()
+        assert r.update_occ_grid(int(g["step"]) + 16, generator=gen)
+    finally:
+        ops.occgrid_cell_points = orig
+    idx = seen["idx"].cpu()
+    assert idx.numel() == cells // 4 + min(cells // 4, n_occ) and int(idx.min()) >= 0 and int(idx.max()) < cells
+    assert bool(occ_before.cpu()[idx[cells // 4:]].all())            # the second part comes from the occupied cells
+
+
+def test_event_batcher_on_device(amd):
+    """f1 on the device: EventBatcher batches are random rows of the HBM-resident table (utils/datasets.py:20-34) joined
+    with the three normalized samplers (data/samplers.py; transforms pinned by the reference fixture), per-rank streams."""
+    from robust_e_nerf_amd import data
+    g = load_golden("dataset")
+    ev = data.queue_raw_events(g["raw_position"], g["raw_timestamp"], g["raw_polarity"], int(g["width"]))
+    ev = data.colorize_events(ev, str(g["bayer_pattern"]))
+    n = len(ev["position"])
+    b = data.EventBatcher(ev, 4096, DEV, seed=3, rank=0)
+    batch = b.next()
+    assert all(v.is_cuda and v.shape[0] == 4096 for v in batch.values())
+    assert batch["position"].dtype == torch.float32 and batch["start_ts"].dtype == torch.int64
+    assert batch["channel_idx"].dtype == torch.uint8 and batch["u_diff_start"].dtype == torch.float64
+    # every row of the batch is a row of the table
+    key = lambda d: (d["position"][:, 0].long() * 64 + d["position"][:, 1].long()) * 10 ** 7 + d["end_ts"].long() // 1000 * 4 \
+        + d["num_pos"].long() * 2 + d["channel_idx"].long() % 2
+    assert bool(torch.isin(key({k: v.cpu() for k, v in batch.items()}), key(ev)).all())
+    assert bool((batch["start_ts"] < batch["end_ts"]).all()) and bool((batch["num_pos"] + batch["num_neg"] == 1).all())
+    assert bool((batch["u_ts_diff"] == 1).all())
+    u2, u3 = batch["u_diff_start"], batch["u_grad"]
+    assert 0 <= float(u2.min()) and float(u2.max()) < 1 and abs(float(u2.mean()) - 0.5) < 0.03
+    assert 0 <= float(u3.min()) and float(u3.max()) <= 1 and abs(float(u3.mean()) - 0.5) < 0.02 and abs(float(u3.std()) - 0.24) < 0.02
+    # the device-side transform equals the reference sampler on the reference's own uniforms
+    u = dev(g["u01"])
+    assert torch.equal(data.trunc_normal_from_uniform(u.clone(), 0.0, 1.0, 0.5, 0.25).cpu(), t(g["trunc_normal_05_025"]))
+    # per-rank streams differ, same rank + seed repeats; the dynamic batch size takes effect on the next batch
+    b1, b0 = data.EventBatcher(ev, 4096, DEV, seed=3, rank=1), data.EventBatcher(ev, 4096, DEV, seed=3, rank=0)
+    assert torch.equal(b0.next()["end_ts"], batch["end_ts"]) and not torch.equal(b1.next()["end_ts"], batch["end_ts"])
+    b.set_batch_size(100)
+    assert b.next()["position"].shape[0] == 100
+    assert n > 0
+
+
 def test_rays_without_samples_render_background(amd, spec, full_table_cache):
     """A ray chunk that meets no occupied cell (image rows above the object) renders the background, opacity 0,
     and back-propagates nothing but d(bkgd) -- both samplers, training and inference."""
