@@ -277,6 +277,12 @@ int ren_occgrid_cell_points(const int64_t *indices, const float *jitter, int64_t
 int ren_occgrid_ema(float *occs, const int64_t *indices, const uint8_t *valid, const float *sigma,
                     const float *step_sizes, float step_size, int64_t m, float ema_decay,
                     void *stream);
+/* The same for cell samples that may hold duplicates (past warm-up nerfacc draws cells with replacement; its indexed
+ * assignment keeps an arbitrary candidate): deterministic, a cell takes the largest of its new occupancies, decayed once.
+ * scratch_cells: one float per grid cell (contents irrelevant). */
+int ren_occgrid_ema_unique(float *occs, const int64_t *indices, const uint8_t *valid, const float *sigma,
+                           const float *step_sizes, float step_size, int64_t m, float ema_decay, float *scratch_cells,
+                           void *stream);
 /* binary = occs > min(mean(occs), occ_thre);  scratch[2] device floats. */
 int ren_occgrid_binarize(const float *occs, int64_t cells, float occ_thre, uint8_t *binary,
                          float *scratch, void *stream);

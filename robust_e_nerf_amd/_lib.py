@@ -75,6 +75,7 @@ SIGNATURES = {
                               c_float, c_int32, P]),
     "ren_occgrid_cell_points": (c_int, [P, P, c_int64, POINTER(c_float), POINTER(c_int32), c_int32, P, P, P]),
     "ren_occgrid_ema": (c_int, [P, P, P, P, P, c_float, c_int64, c_float, P]),
+    "ren_occgrid_ema_unique": (c_int, [P, P, P, P, P, c_float, c_int64, c_float, P, P]),
     "ren_occgrid_binarize": (c_int, [P, c_int64, c_float, P, P, P]),
     "ren_column_sum": (c_int, [P, c_int64, c_int32, P, P, P]),
     "ren_trajectory_jvp": (c_int, [P, c_int64, P, P, P, c_int64, P, P, P, P, P]),

