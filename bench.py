@@ -338,7 +338,13 @@ def main():
             "metric": "train_rays_per_sec", "value": rays / dt, "unit": "rays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16-operand/f32-accumulate MLP, f32 elsewhere" if args.mlp_bf16 else "f32", "data": "synthetic",
+            # fp32 storage and accumulation everywhere.  MLP products on the bf16 matrix cores: 6-term split (fp32 round-off)
+            # for outputs and data gradients, 3-term / two-piece split (2^-16 per product, measured <= 4e-5 on the summed
+            # gradient: test_matrix_core_mlp_kernels_vs_exact_f32_kernels_at_config_b_size) for the weight gradients;
+            # --mlp-kernels f32 runs every product on the exact-f32 MFMA
+            "dtype": ("bf16-operand/f32-accumulate MLP, f32 elsewhere" if args.mlp_bf16 else
+                      "f32" if args.mlp_kernels == "f32" else "f32 (MLP weight-gradient products: bf16x2 split, 2^-16)"),
+            "data": "synthetic",
             "mlp_samples_per_sec": n_samples / dt, "mean_samples_per_ray": n_samples / rays,
             "loss": float(loss),
             "config": {"workload": ("BASELINE configs[4] settings (mocap-desk2.yaml: sphere contraction, 256^3 grid, cone 0.004, "
