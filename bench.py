@@ -160,6 +160,13 @@ def main():
                     help="> 1: hash encoding and MLP forward of alternate sample chunks on two HIP streams")
     ap.add_argument("--mlp-kernels", default="x", choices=["x", "f32"],
                     help="x = split-bf16 matrix-core MLP kernels at fp32 accuracy (default), f32 = exact f32-MFMA kernels")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --events per GPU whatever N (default).  strong: the reference's semantics (a fixed GLOBAL budget, "
+                         "train_eff_ray_sample_batch_size // num_gpus, robust_e_nerf.py:63-66): --events is the global batch, "
+                         "every rank takes events // N")
+    ap.add_argument("--no-dp-overlap", action="store_true",
+                    help="N > 1: one all-reduce of the packed gradient buffer after the backward pass instead of reducing the "
+                         "fine levels' slice beside the coarse levels' scatter")
     ap.add_argument("--save-activations", type=int, default=-1, choices=[-1, 0, 1],
                     help="1: the training forward stores the hidden MLP activations (768 B/sample), 0: the backward recomputes "
                          "them, -1 (default): recompute with the x kernels, save with the exact-f32 kernels")
@@ -222,13 +229,15 @@ def main():
     cfg = engine.RenderCfg(aabb=aabb, sampler=args.sampler, n_uniform=args.samples, mlp_bf16=args.mlp_bf16,
                            mlp_kernels=args.mlp_kernels, fwd_chunks=args.fwd_chunks,
                            save_activations=None if args.save_activations < 0 else bool(args.save_activations))
+    cfg.dp_overlap = not args.no_dp_overlap
     if args.workload == "e":
         aabb = E_AABB
         cfg = engine.RenderCfg(aabb=aabb, contraction_type=ops.UN_BOUNDED_SPHERE, occ_res=(256,) * 3, near_plane=0.05,
                                far_plane=3.0, render_step_size=math.sqrt(3) * 1.5 / 1024, cone_angle=0.004,
                                sampler="occgrid", mlp_bf16=args.mlp_bf16, mlp_kernels=args.mlp_kernels,
                                fwd_chunks=args.fwd_chunks,
-                               save_activations=None if args.save_activations < 0 else bool(args.save_activations))
+                               save_activations=None if args.save_activations < 0 else bool(args.save_activations),
+                               dp_overlap=not args.no_dp_overlap)
     if args.arch == "mlp":
         from robust_e_nerf_amd import vanilla
         fld = vanilla.VanillaField(dev, 1)
@@ -254,7 +263,7 @@ def main():
                         tau_raw=torch.tensor(0.0, dtype=torch.float64), tau_max=torch.tensor(1e5),
                         bkgd_raw=torch.tensor([0.5413]), world_size=world, process_group=pg)
 
-    B = args.events
+    B = args.events if args.scaling == "weak" else max(1, args.events // world)
     n_batches = 4                                    # pre-staged in HBM; per-rank seeds (datamodule.py:85-89)
     batches = []
     for b in range(n_batches):
@@ -337,7 +346,7 @@ def main():
         out = {
             "metric": "train_rays_per_sec", "value": rays / dt, "unit": "rays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             # fp32 storage and accumulation everywhere.  MLP products on the bf16 matrix cores: 6-term split (fp32 round-off)
             # for outputs and data gradients, 3-term / two-piece split (2^-16 per product, measured <= 4e-5 on the summed
             # gradient: test_matrix_core_mlp_kernels_vs_exact_f32_kernels_at_config_b_size) for the weight gradients;
@@ -353,7 +362,8 @@ def main():
                                    f"{B} events/step/GPU = {2 * B} rays x {args.samples} samples, arch {args.arch}, fp32, "
                                    f"{'l_diff + l_grad (3 renders)' if args.loss_grad > 0 else 'l_diff (2 renders)'}, fwd+bwd+Adam; sampler={args.sampler}",
                        "events_per_step_per_gpu": B, "rays_per_step_per_gpu": 2 * B, "sampler": args.sampler,
-                       "samples_per_ray": args.samples, "parallelism": f"dp{world}"},
+                       "samples_per_ray": args.samples, "parallelism": f"dp{world}",
+                       "collectives_per_step": getattr(tr, "last_collectives", 0)},
             "roofline": roof,
             "kernels": kern,
         }

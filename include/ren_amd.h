@@ -317,6 +317,15 @@ int ren_hashgrid_bwd_binned_jvp(const ren_grid_desc *grid, float *grad_table, co
                                 const float *rays_dd, const int32_t *ray_indices, const float *t_starts,
                                 const float *t_ends, int64_t n, const float *dfeat, const float *dfeatd,
                                 void *workspace, void *stream);
+/* Either of the two binned calls restricted to the levels whose bit is set in level_mask (rays_do / rays_dd / dfeatd all
+ * NULL: value-only call; all given: the tangent call).  Data-parallel training (replaces DDP's bucketed
+ * all-reduce of scripts/run.py:81-93) runs the fine levels first and all-reduces their slice of the table gradient while
+ * the coarse levels are scattered. */
+int ren_hashgrid_bwd_binned_levels(const ren_grid_desc *grid, float *grad_table, const float *x_unit,
+                                   const ren_scene_desc *scene, const float *rays_o, const float *rays_d,
+                                   const int32_t *ray_indices, const float *t_starts, const float *t_ends, int64_t n,
+                                   int32_t layout, const float *dfeat, const float *rays_do, const float *rays_dd,
+                                   const float *dfeatd, uint32_t level_mask, void *workspace, void *stream);
 /* fused MLPs with tangent: rgb, rgbd [n,C]; sigma, sigmad [n]; base_out, base_outd (ceil(n/32)*512 floats) */
 int ren_mlp_fwd_jvp(const float *mlp_params, int32_t radiance_dim, const float *feat, const float *featd,
                     const ren_scene_desc *scene, const float *rays_o, const float *rays_d, const float *rays_dd,

@@ -83,6 +83,8 @@ SIGNATURES = {
     "ren_hashgrid_fwd_jvp": (c_int, [POINTER(GridDesc), P, POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, P, P, P]),
     "ren_hashgrid_bwd_jvp": (c_int, [POINTER(GridDesc), P, POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, P, P, P]),
     "ren_hashgrid_bwd_binned_jvp": (c_int, [POINTER(GridDesc), P, POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, P, P, P, P]),
+    "ren_hashgrid_bwd_binned_levels": (c_int, [POINTER(GridDesc), P, P, POINTER(SceneDesc), P, P, P, P, P, c_int64, c_int32, P,
+                                               P, P, P, c_uint32, P, P]),
     "ren_mlp_fwd_jvp": (c_int, [P, c_int32, P, P, POINTER(SceneDesc), P, P, P, P, P, P, c_int64, P, P, P, P, P, P, P]),
     "ren_mlp_bwd_jvp_workspace_floats": (c_int64, [c_int32]),
     "ren_mlp_bwd_jvp": (c_int, [P, c_int32, P, P, P, P, POINTER(SceneDesc), P, P, P, P, P, P, c_int64, P, P, P, P, P,

@@ -78,6 +78,7 @@ struct BinTab {
     // sampled count back up with a 25 % + 4096 margin; the same overflow fallback keeps it exact.
     uint32_t cap[REN_MAX_LEVELS];
     uint32_t pair[REN_MAX_LEVELS];                   // 1: the level's bins hold 16-byte pair records (cap counts records)
+    uint32_t skip[REN_MAX_LEVELS];                   // 1: level not part of this call (level_mask of the *_levels entry points)
     int cnt_stride;
     int halve;                                       // test hook (REN_HGB_HALVE_REGIONS=1): force the overflow path
 };
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(CNT_THREADS) void bin_count_kernel(GridDev g, BinTa
         if (inb) unit_pos<TAN>(a, i, u, ud);
 #pragma unroll 1
         for (int lvl = 0; lvl < g.n_levels; ++lvl) {
-            if (bt.cap[lvl]) continue;                               // hashed level: capacity-sized regions, no count
+            if (bt.cap[lvl] || bt.skip[lvl]) continue;               // hashed level: capacity-sized regions, no count
             float d0, d1, e0, e1;
             const bool have = inb && load_dfeat<TAN>(a, g.n_levels, lvl, i, d0, d1, e0, e1);
             const LevelPos p = level_pos(u[0], u[1], u[2], g.scale[lvl]);
@@ -272,8 +273,8 @@ __global__ __launch_bounds__(MAX_BINS) void bin_offsets_kernel(int n_bins, BinTa
         int lvl = 0;
         while (lvl + 1 < REN_MAX_LEVELS && t >= bt.bin_base[lvl + 1]) ++lvl;
         pair = bt.pair[lvl] != 0;
-        c = bt.cap[lvl] ? bt.cap[lvl] : counts[t];
-        if (!bt.cap[lvl] && bt.cnt_stride > 1) c = c * bt.cnt_stride + c * bt.cnt_stride / 4 + 4096;
+        c = bt.skip[lvl] ? 0 : bt.cap[lvl] ? bt.cap[lvl] : counts[t];
+        if (!bt.skip[lvl] && !bt.cap[lvl] && bt.cnt_stride > 1) c = c * bt.cnt_stride + c * bt.cnt_stride / 4 + 4096;
         if (bt.halve) c = c / 2;
         c &= ~(uint64_t)7;                                         // idx[] of a single-update region stays 16-byte aligned
         slots = pair ? c : (c * 10 + 15) / 16;
@@ -362,6 +363,7 @@ __global__ __launch_bounds__(SC_THREADS, KIND == 1 ? REN_SC_WAVES_PAIR : REN_SC_
     constexpr bool pairs = KIND == 1;
 #pragma unroll 1
     for (int lvl = 0; lvl < g.n_levels; ++lvl) {
+        if (bt.skip[lvl]) continue;
         if (KIND == 1 && !bt.pair[lvl]) continue;
         if (KIND == 2 && bt.pair[lvl]) continue;
         if (tid < MAX_BINS_PER_LEVEL) hist[tid] = 0;
@@ -647,7 +649,7 @@ static int binned_impl(const ren_grid_desc *grid, float *grad_table, const float
                        const ren_scene_desc *scene, const float *rays_o, const float *rays_d,
                        const int32_t *ray_indices, const float *t_starts, const float *t_ends,
                        int64_t n, int32_t layout, const float *dfeat, void *workspace,
-                       void *stream, TanSrc tan) {
+                       void *stream, TanSrc tan, uint32_t level_mask = 0xFFFFFFFFu) {
     GridDev g;
     int rc = make_grid(grid, g);
     if (rc) return rc;
@@ -673,6 +675,7 @@ static int binned_impl(const ren_grid_desc *grid, float *grad_table, const float
     for (int l = 0; l < REN_MAX_LEVELS; ++l) {
         bt.cap[l] = 0;
         bt.pair[l] = 0;
+        bt.skip[l] = l < g.n_levels && !((level_mask >> l) & 1u);
         if (l < g.n_levels && g.hashed[l]) {
             const int64_t bins = (g.size[l] + BIN_ENTRIES - 1) >> BIN_SHIFT;
             bt.pair[l] = use_pairs ? 1 : 0;                       // 4 pair records instead of 8 updates per sample
@@ -709,7 +712,9 @@ static int binned_impl(const ren_grid_desc *grid, float *grad_table, const float
     hipLaunchKernelGGL(bin_offsets_kernel, dim3(1), dim3(MAX_BINS), 0, st, nb, bt, (uint64_t)L.slots, ws.counts,
                        ws.cursors, ws.bin_cap, ws.bin_start);
     bool any_pair = false, any_single = false;
-    for (int l = 0; l < g.n_levels; ++l) { any_pair |= bt.pair[l] != 0; any_single |= bt.pair[l] == 0; }
+    for (int l = 0; l < g.n_levels; ++l)
+        if (!bt.skip[l]) { any_pair |= bt.pair[l] != 0; any_single |= bt.pair[l] == 0; }
+    if (!any_pair && !any_single) return REN_OK;
     if (tan.dfeatd) hipLaunchKernelGGL((bin_scatter_kernel<true, 0>), sgrd, sblk, 0, st, g, bt, a, ws, grad_table);
     else {
         if (any_pair)   hipLaunchKernelGGL((bin_scatter_kernel<false, 1>), sgrd, sblk, 0, st, g, bt, a, ws, grad_table);
@@ -741,4 +746,17 @@ extern "C" int ren_hashgrid_bwd_binned_jvp(const ren_grid_desc *grid, float *gra
     if (!rays_do || !rays_dd || !dfeatd) return REN_ERR_BAD_ARG;
     return binned_impl(grid, grad_table, nullptr, scene, rays_o, rays_d, ray_indices, t_starts, t_ends, n, 1, dfeat,
                        workspace, stream, TanSrc{rays_do, rays_dd, dfeatd});
+}
+
+// The same for a subset of the levels (bit l of level_mask): data-parallel training splits the call in two so that the
+// all-reduce of the first group's slice of the table gradient runs beside the second group's scatter (engine.py).
+extern "C" int ren_hashgrid_bwd_binned_levels(const ren_grid_desc *grid, float *grad_table, const float *x_unit,
+                                              const ren_scene_desc *scene, const float *rays_o, const float *rays_d,
+                                              const int32_t *ray_indices, const float *t_starts, const float *t_ends,
+                                              int64_t n, int32_t layout, const float *dfeat, const float *rays_do,
+                                              const float *rays_dd, const float *dfeatd, uint32_t level_mask,
+                                              void *workspace, void *stream) {
+    if ((rays_do || rays_dd || dfeatd) && (!rays_do || !rays_dd || !dfeatd || layout != 1 || x_unit)) return REN_ERR_BAD_ARG;
+    return binned_impl(grid, grad_table, x_unit, scene, rays_o, rays_d, ray_indices, t_starts, t_ends, n, layout, dfeat,
+                       workspace, stream, TanSrc{rays_do, rays_dd, dfeatd}, level_mask);
 }

@@ -40,6 +40,7 @@ class RenderCfg:
     ema_decay: float = 0.95
     warmup_steps: int = 256
     occ_n: int = 16
+    occ_seed: int = 20230                # seed of the grid-refresh stream (the same on every rank)
     binned_scatter: bool = True        # LDS-binned hash-grid backward (False: per-update global atomics)
     mlp_kernels: str = "x"             # "x": split-bf16 matrix-core kernels at fp32 accuracy (csrc/ren_mlp_x.hip);
                                        # "f32": exact f32-MFMA kernels (csrc/ren_mlp.hip)
@@ -49,6 +50,8 @@ class RenderCfg:
                                        # None = auto: recompute with the "x" kernels, save with the exact-f32 kernels
     march_cache: int = 512             # intervals per ray kept between the two marching passes (0: march twice)
     fwd_chunks: int = 16               # > 1: hash encoding and MLP of alternate sample chunks on two HIP streams
+    dp_overlap: bool = True            # data parallel: all-reduce the fine levels' table gradient beside the coarse levels' scatter
+    dp_split_level: int = 8            # levels >= this one go first (8 x 4 MiB of the 50 MB buffer)
     mlp_bf16: bool = False             # BASELINE configs[2]: bf16 MLP (rounded linear inputs/weights, fp32 accumulate), fp32 composite
 
 
@@ -70,7 +73,11 @@ class NGPField:
         self.n_params = n
         n_pad = (n + 3) // 4 * 4
         self.flat = torch.zeros(n_pad, device=device, dtype=torch.float32)
-        self.grad = torch.zeros(n_pad, device=device, dtype=torch.float32)
+        # gradient buffer with the data-parallel tail: [table | MLP | pad | aux] is ONE all-reduce (parallel.GradSync)
+        from .parallel import AUX_FLOATS
+        self.grad_all = torch.zeros(n_pad + AUX_FLOATS, device=device, dtype=torch.float32)
+        self.grad = self.grad_all[:n_pad]
+        self.aux = self.grad_all[n_pad:]
         self.table = self.flat[: self.n_table]
         self.mlp = self.flat[self.n_table: n]
         self.g_table = self.grad[: self.n_table]
@@ -114,6 +121,8 @@ class Renderer:
                                device=dev, dtype=torch.float32)
         self._bin_ws = None
         self._occ_scratch = None
+        self._occ_gen = None
+        self.grad_sync = None                       # parallel.GradSync of the Trainer under data parallelism
         self._fwd_streams = None
         self._reuse_prepass_feat = True             # the differentiable pass reuses the pre-pass hash features
 
@@ -243,7 +252,7 @@ class Renderer:
         main.wait_stream(s_mlp)
         return rgb, sigma, dict(feat=feat, base=base, acts=acts, xmode=self._xmode() if save else None)
 
-    def _field_backward(self, ctx, d_rgb, d_sig):
+    def _field_backward(self, ctx, d_rgb, d_sig, final: bool = False):
         f, pk = self.field, ctx["pk"]
         samples = (pk.ray_indices, pk.t_starts, pk.t_ends)
         mp = ctx.get("mlp_params")                      # absent when the forward ran on the (fp32) tangent kernels
@@ -265,8 +274,16 @@ class Renderer:
             if self._bin_ws is None or self._bin_ws.numel() < need:
                 self._bin_ws = None                                   # release before growing
                 self._bin_ws = torch.empty(need, device=dfeat.device, dtype=torch.uint8)
-            ops.hashgrid_bwd_binned(f.grid, f.g_table, dfeat, self._bin_ws, scene=self.scene,
-                                    rays=(ctx["o"], ctx["d"]), samples=samples, n=pk.n, layout=1)
+            kw = dict(scene=self.scene, rays=(ctx["o"], ctx["d"]), samples=samples, n=pk.n, layout=1)
+            if final and self.grad_sync is not None and self.cfg.dp_overlap:
+                # last backward of the step under data parallelism: fine levels first, their slice of the table gradient
+                # is all-reduced while the coarse levels are scattered
+                lo_mask = (1 << self.cfg.dp_split_level) - 1
+                ops.hashgrid_bwd_binned(f.grid, f.g_table, dfeat, self._bin_ws, level_mask=0xFFFF & ~lo_mask, **kw)
+                self.grad_sync.early(f.grad_all, 2 * int(f.grid.offset[self.cfg.dp_split_level]), f.n_table)
+                ops.hashgrid_bwd_binned(f.grid, f.g_table, dfeat, self._bin_ws, level_mask=lo_mask, **kw)
+            else:
+                ops.hashgrid_bwd_binned(f.grid, f.g_table, dfeat, self._bin_ws, **kw)
         else:
             ops.hashgrid_bwd(f.grid, f.g_table, dfeat, scene=self.scene, rays=(ctx["o"], ctx["d"]), samples=samples,
                              n=pk.n, layout=1)
@@ -290,7 +307,8 @@ class Renderer:
         return colors, opac, depth, ctx
 
     # ---- backward: accumulates into field.grad, returns d(bkgd) -------------------------------------
-    def backward(self, ctx, g_colors, g_opac=None, g_depth=None):
+    def backward(self, ctx, g_colors, g_opac=None, g_depth=None, final: bool = False):
+        """final: this is the last backward pass of the step (its gradients are complete when it returns)"""
         f = self.field
         if ctx["empty"]:
             return g_colors.sum(0) if ctx.get("bkgd") is not None else None
@@ -298,7 +316,7 @@ class Renderer:
         d_sig, d_rgb, d_bk = ops.composite_bwd(pk.offsets, pk.counts, pk.t_starts, pk.t_ends, ctx["sigma"],
                                                ctx["rgb"], f.C, ctx["bkgd"], ctx["w"], ctx["T"], ctx["opac"],
                                                g_colors, g_opac, g_depth, want_bkgd=ctx["bkgd"] is not None)
-        self._field_backward(ctx, d_rgb, d_sig)
+        self._field_backward(ctx, d_rgb, d_sig, final=final)
         return ops.column_sum(d_bk) if d_bk is not None else None
 
     # ---- density query (occ_eval_fn / query_density) ----------------------------------------------------
@@ -322,6 +340,13 @@ class Renderer:
             return False
         dev = self.occs.device
         cells = self.occs.numel()
+        if generator is None:
+            # every rank owns the SAME stream for the grid refresh (cell sample, in-cell jitter, camera choice), consumed
+            # by nothing else: the replicated occupancy grids stay bit-identical without DDP's per-forward buffer
+            # broadcast (scripts/run.py:81-93, models/nerf.py:98-102; collective C4 of SURVEY 2.3)
+            if self._occ_gen is None:
+                self._occ_gen = torch.Generator(device=dev).manual_seed(self.cfg.occ_seed)
+            generator = self._occ_gen
         if indices is None:
             if step < c.warmup_steps:
                 indices = torch.arange(cells, device=dev)
@@ -430,6 +455,12 @@ class Trainer:
         self.step_count = 0
         self.world_size = world_size
         self.pg = process_group
+        self.sync = None
+        if world_size > 1:
+            from . import parallel
+            self.sync = parallel.GradSync(process_group, world_size)
+            renderer.grad_sync = self.sync
+        self._mean_s_dev = None                                  # samples / ray of this step, summed over ranks (device)
         self.lr_scale = 1.0
         # trainable C_p / C_n ratio (softplus-parametrised scalar, its own Adam group with lr 0.1:
         # robust_e_nerf.py:800-803).  Its loss dependence is through the per-event targets and the 1/C^k
@@ -495,8 +526,11 @@ class Trainer:
         p = ops.event_prepare(batch, self.c_p, self.c_n, self.tau)
         return p["ts"][:B], p["ts"][B:], p["target_diff"]
 
-    def forward_backward(self, batch, jitter_start=None, jitter_end=None):
-        """Loss + gradients (no optimiser step).  Returns (loss tensor (device scalar), aux)."""
+    def forward_backward(self, batch, jitter_start=None, jitter_end=None, final: Optional[bool] = None):
+        """Loss + gradients (no optimiser step).  Returns (loss tensor (device scalar), aux).  final: this is the step's last
+        backward pass (default: yes unless the log-intensity-gradient term follows)."""
+        if final is None:
+            final = not (self.t.w_grad > 0)
         r, t, f = self.r, self.t, self.r.field
         B = batch["position"].shape[0]
         self._refresh_contrast_threshold()
@@ -539,7 +573,7 @@ class Trainer:
             idot = self._bayer(colords, ch).double()
             self._tau_grad_dev += (g_s.double() * idot[:B] * prep["dts_start"]).sum() \
                 + (g_e.double() * idot[B:] * prep["dts_end"]).sum()
-        d_bkgd = r.backward(ctx, g_colors)
+        d_bkgd = r.backward(ctx, g_colors, final=final)
         if d_bkgd is not None:
             self.small_grad[: f.C] += d_bkgd * torch.sigmoid(self.small[: f.C])     # d softplus
         aux = dict(intensity_start=i_s, intensity_end=i_e, n=ctx["pk"].n, n_marched=ctx["pk"].n_marched,
@@ -587,20 +621,35 @@ class Trainer:
             _, _, colorsdd = jvp.render_forward2(r, o, d, od, dd, ddd, ctx["pk"], bkgd)
             per_ev = g_i.double() * intend.double() + g_id.double() * self._bayer(colorsdd, ch).double()
             self._tau_grad_dev += (per_ev * prep["dts_grad"]).sum()
-        d_bkgd = jvp.render_backward(r, ctx, self._unbayer(g_i, ch, f.C), self._unbayer(g_id, ch, f.C))
+        d_bkgd = jvp.render_backward(r, ctx, self._unbayer(g_i, ch, f.C), self._unbayer(g_id, ch, f.C), final=True)
         if d_bkgd is not None:
             self.small_grad[: f.C] += d_bkgd * torch.sigmoid(self.small[: f.C])
         aux = dict(intensity=inten, dlog_dt=intend / inten, n=ctx["pk"].n, rays=B)
         return loss, aux
 
-    def optimizer_step(self, accumulate_grad_batches: int = 1):
+    def optimizer_step(self, accumulate_grad_batches: int = 1, mean_samples_per_ray: Optional[float] = None):
         """Adam on [hash table | MLPs] (lr default, L2 decay 1e-6: robust_e_nerf.py:786-813) and on the
         background scalar (no decay).  Under data parallelism gradients are summed over ranks (RCCL
         all-reduce of the single flat buffer) and scaled by 1/world inside the Adam kernel."""
         f = self.r.field
         if self.world_size > 1:
-            from . import parallel
-            parallel.allreduce_sum_([f.grad, self.small_grad], group=self.pg, world_size=self.world_size)
+            # ONE collective for everything a step sums over the ranks (plus the early slice when dp_overlap is on):
+            # [table | MLP | pad | aux = small-parameter grads, C_p ratio grad, d loss / d tau as two floats, samples per ray]
+            from . import parallel as P_
+            aux = f.aux
+            aux[P_.AUX_SMALL: P_.AUX_SMALL + 4] = self.small_grad
+            aux[P_.AUX_CT] = self.ct_grad[0]
+            hi = self._tau_grad_dev.to(torch.float32)
+            aux[P_.AUX_TAU_HI] = hi[0]
+            aux[P_.AUX_TAU_LO] = (self._tau_grad_dev - hi.double()).to(torch.float32)[0]
+            aux[P_.AUX_MEAN_S] = float(mean_samples_per_ray) if mean_samples_per_ray is not None else 0.0
+            self.sync.finish(f.grad_all)
+            self.small_grad.copy_(aux[P_.AUX_SMALL: P_.AUX_SMALL + 4])
+            self.ct_grad[0] = aux[P_.AUX_CT]
+            self._tau_grad_dev[0] = aux[P_.AUX_TAU_HI].double() + aux[P_.AUX_TAU_LO].double()
+            self._mean_s_dev = aux[P_.AUX_MEAN_S].clone()
+            aux.zero_()
+            self.last_collectives = self.sync.reset_count()
         self.step_count += 1
         gs = 1.0 / (self.world_size * accumulate_grad_batches)            # mean over ranks and accumulated micro-batches
         lr = self.t.lr * self.lr_scale
@@ -614,9 +663,6 @@ class Trainer:
             if self._tau_opt is None:
                 self.tau_raw.requires_grad_(True)
                 self._tau_opt = torch.optim.Adam([self.tau_raw], lr=float(self.tau_max) * self.t.relative_lr_refractory_period)
-            if self.world_size > 1:
-                import torch.distributed as dist
-                dist.all_reduce(self._tau_grad_dev, group=self.pg)
             g = self.tau_grad                                                # the one host read of this group
             sg = torch.sigmoid(self.tau_raw.detach() / self.tau_max)
             self.tau_raw.grad = (g * gs * sg * (1 - sg)).to(torch.float64).reshape(self.tau_raw.shape)
@@ -625,9 +671,6 @@ class Trainer:
             self._tau_opt.step()
             self._tau_grad_dev.zero_()
         if self.t.train_contrast_threshold:
-            if self.world_size > 1:
-                from . import parallel
-                parallel.allreduce_sum_([self.ct_grad], group=self.pg, world_size=self.world_size)
             ops.adam_step(self.ct, self.ct_grad, self.ct_m, self.ct_v, lr=self.t.lr_contrast_threshold * self.lr_scale,
                           betas=self.t.betas, eps=self.t.eps, weight_decay=0.0, step=self.step_count, grad_scale=gs,
                           zero_grad=True)
@@ -673,14 +716,26 @@ class Trainer:
         num_gpus (:63-66).  Returns the new per-rank event batch size, or None when the gradient-accumulation rule of the
         reference skips the update for this micro-batch."""
         from . import parallel
+        means = self._render_means(aux)
+        gather = None
+        if self.world_size > 1:
+            if self._mean_s_dev is not None and aux.get("_mean_s_synced"):
+                summed = float(self._mean_s_dev)                 # rode along in the gradient all-reduce: one host read
+                gather = lambda m: summed / self.world_size
+            else:                                                # no optimiser step on this micro-batch (gradient accumulation)
+                gather = lambda m: parallel.allgather_mean(m, self.pg)
+        budget = parallel.per_rank_budget(eff_ray_sample_batch_size, self.world_size)
+        mean, new = parallel.new_train_batch_size(budget, means, gather, accumulate_grad_batches, batch_index)
+        return None if new is None else max(1, new)
+
+    @staticmethod
+    def _render_means(aux):
+        """mean samples per ray of every render of the step (start, end [, grad]), robust_e_nerf.py:909-913"""
         # start / end renders are one batched pass of 2B rays: (n_s / B + n_e / B) / 2 = n / 2B, twice
         means = [aux["n"] / max(aux["rays"], 1)] * 2
         if aux.get("grad") is not None:
             means.append(aux["grad"]["n"] / max(aux["grad"]["rays"], 1))
-        gather = (lambda m: parallel.allgather_mean(m, self.pg)) if self.world_size > 1 else None
-        budget = parallel.per_rank_budget(eff_ray_sample_batch_size, self.world_size)
-        mean, new = parallel.new_train_batch_size(budget, means, gather, accumulate_grad_batches, batch_index)
-        return None if new is None else max(1, new)
+        return means
 
     def set_epoch(self, epoch: int, milestones=(20, 30, 36), gamma: float = 0.33):
         """MultiStepLR stepped per epoch (robust_e_nerf.py:818-832, synthetic.yaml:113-128)."""
@@ -701,5 +756,7 @@ class Trainer:
             loss = loss + lg
             aux = dict(aux, grad=aux_g)
         if (bi + 1) % k == 0:
-            self.optimizer_step(k)
+            means = self._render_means(aux)
+            self.optimizer_step(k, mean_samples_per_ray=sum(means) / len(means))
+            aux["_mean_s_synced"] = self.world_size > 1
         return loss, aux

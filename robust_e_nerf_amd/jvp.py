@@ -124,8 +124,8 @@ def render_forward(r, o, d, od, dd, jitter, bkgd, training: bool = True):
     return colors, colords, opac, ctx
 
 
-def render_backward(r, ctx, g_colors, g_colords):
-    """Accumulates into r.field.grad; returns d(bkgd) (C,) or None."""
+def render_backward(r, ctx, g_colors, g_colords, final: bool = False):
+    """Accumulates into r.field.grad; returns d(bkgd) (C,) or None.  final: last backward pass of the step."""
     f, lib = r.field, _lib.load()
     if ctx["empty"]:
         return g_colors.sum(0) if ctx.get("bkgd") is not None else None
@@ -167,10 +167,15 @@ def render_backward(r, ctx, g_colors, g_colords):
         if r._bin_ws is None or r._bin_ws.numel() < need:
             r._bin_ws = None
             r._bin_ws = torch.empty(need, device=dev, dtype=torch.uint8)
-        check(lib.ren_hashgrid_bwd_binned_jvp(ctypes.byref(f.grid), _ptr(f.g_table), ctypes.byref(r.scene),
-                                              _ptr(ctx["o"]), _ptr(ctx["d"]), _ptr(ctx["od"]), _ptr(ctx["dd"]),
-                                              _ptr(ri), _ptr(ts), _ptr(te), n, _ptr(dfeat), _ptr(dfeatd),
-                                              _ptr(r._bin_ws), _stream()), "ren_hashgrid_bwd_binned_jvp")
+        kw = dict(scene=r.scene, rays=(ctx["o"], ctx["d"]), samples=(ri, ts, te), n=n, layout=1,
+                  tangent=(ctx["od"], ctx["dd"], dfeatd))
+        if final and r.grad_sync is not None and r.cfg.dp_overlap:   # see Renderer._field_backward
+            lo_mask = (1 << r.cfg.dp_split_level) - 1
+            ops.hashgrid_bwd_binned(f.grid, f.g_table, dfeat, r._bin_ws, level_mask=0xFFFF & ~lo_mask, **kw)
+            r.grad_sync.early(f.grad_all, 2 * int(f.grid.offset[r.cfg.dp_split_level]), f.n_table)
+            ops.hashgrid_bwd_binned(f.grid, f.g_table, dfeat, r._bin_ws, level_mask=lo_mask, **kw)
+        else:
+            ops.hashgrid_bwd_binned(f.grid, f.g_table, dfeat, r._bin_ws, **kw)
     else:
         check(lib.ren_hashgrid_bwd_jvp(ctypes.byref(f.grid), _ptr(f.g_table), ctypes.byref(r.scene), _ptr(ctx["o"]),
                                        _ptr(ctx["d"]), _ptr(ctx["od"]), _ptr(ctx["dd"]), _ptr(ri), _ptr(ts),

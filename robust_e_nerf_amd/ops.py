@@ -253,13 +253,21 @@ def hashgrid_bwd_binned_workspace_bytes(n: int) -> int:
 
 
 def hashgrid_bwd_binned(grid: GridDesc, grad_table, dfeat, workspace, *, x_unit=None, scene=None, rays=None,
-                        samples=None, n: int, layout: int):
+                        samples=None, n: int, layout: int, level_mask: Optional[int] = None, tangent=None):
     """LDS-binned (atomic-free) variant of hashgrid_bwd; workspace: uint8 tensor of
-    hashgrid_bwd_binned_workspace_bytes(n) bytes."""
+    hashgrid_bwd_binned_workspace_bytes(n) bytes.  level_mask: only the levels whose bit is set; tangent: (rays_do,
+    rays_dd, dfeatd) of the log-intensity-gradient render."""
     if workspace.numel() * workspace.element_size() < hashgrid_bwd_binned_workspace_bytes(n):
         raise ValueError("hashgrid_bwd_binned: workspace too small")
     o, d = rays if rays is not None else (None, None)
     ri, ts, te = samples if samples is not None else (None, None, None)
+    if level_mask is not None or tangent is not None:
+        do, dd, dfd = tangent if tangent is not None else (None, None, None)
+        check(_lib.load().ren_hashgrid_bwd_binned_levels(
+            ctypes.byref(grid), _ptr(grad_table, torch.float32), _ptr(x_unit), ctypes.byref(scene) if scene is not None else None,
+            _ptr(o), _ptr(d), _ptr(ri), _ptr(ts), _ptr(te), n, layout, _ptr(dfeat, torch.float32), _ptr(do), _ptr(dd), _ptr(dfd),
+            0xFFFFFFFF if level_mask is None else int(level_mask), _ptr(workspace), _stream()), "ren_hashgrid_bwd_binned_levels")
+        return
     check(_lib.load().ren_hashgrid_bwd_binned(ctypes.byref(grid), _ptr(grad_table, torch.float32), _ptr(x_unit),
                                               ctypes.byref(scene) if scene is not None else None,
                                               _ptr(o), _ptr(d), _ptr(ri), _ptr(ts), _ptr(te), n, layout,

@@ -39,6 +39,50 @@ def allreduce_sum_(buffers: Iterable[torch.Tensor], group=None, world_size: Opti
         dist.all_reduce(b, op=dist.ReduceOp.SUM, group=group)
 
 
+# tail of the packed gradient buffer [table | MLP | pad | AUX]: everything else a step has to sum over the ranks
+AUX_FLOATS = 16
+AUX_SMALL, AUX_CT, AUX_TAU_HI, AUX_TAU_LO, AUX_MEAN_S = 0, 4, 5, 6, 7     # small-parameter grads [0:4], C_p ratio, tau (two floats), samples / ray
+
+
+class GradSync:
+    """Gradient exchange of one step: the packed buffer [table | MLP | pad | aux] in ONE all-reduce (SUM), or -- with
+    `early(...)` calls from the backward pass -- the slices that are final early in their own asynchronous all-reduce,
+    running on RCCL's stream beside the rest of the backward; `finish()` reduces what is left and waits for all of it.
+    Replaces DDP's bucketed all-reduce (scripts/run.py:81-93)."""
+
+    def __init__(self, group=None, world_size: Optional[int] = None):
+        self.group = group
+        self.world = world_size if world_size is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
+        self.pending = []
+        self.done = []                                           # (start, stop) element ranges already launched
+        self.collectives = 0                                     # launched in the current step (tests / DESIGN numbers)
+
+    def early(self, buf: torch.Tensor, start: int, stop: int):
+        if self.world <= 1 or stop <= start:
+            return
+        self.pending.append(dist.all_reduce(buf[start:stop], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self.done.append((start, stop))
+        self.collectives += 1
+
+    def finish(self, buf: torch.Tensor):
+        """all-reduce every element range of `buf` not launched by early(), wait for everything"""
+        if self.world <= 1:
+            return
+        pos = 0
+        for a, b in sorted(self.done) + [(buf.numel(), buf.numel())]:
+            if a > pos:
+                self.pending.append(dist.all_reduce(buf[pos:a], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                self.collectives += 1
+            pos = max(pos, b)
+        for w in self.pending:
+            w.wait()
+        self.pending, self.done = [], []
+
+    def reset_count(self) -> int:
+        c, self.collectives = self.collectives, 0
+        return c
+
+
 def rank_seed(base_seed: int, rank: int) -> int:
     """Per-rank data seed (data/datamodule.py:85-89: process_seed = initial_seed + rank)."""
     return base_seed + rank

@@ -49,7 +49,10 @@ class VanillaField:
         self.n_params = n
         n_pad = (n + 3) // 4 * 4
         self.flat = torch.zeros(n_pad, device=device, dtype=torch.float32)
-        self.grad = torch.zeros(n_pad, device=device, dtype=torch.float32)
+        from .parallel import AUX_FLOATS                         # [parameters | pad | aux]: one all-reduce (parallel.GradSync)
+        self.grad_all = torch.zeros(n_pad + AUX_FLOATS, device=device, dtype=torch.float32)
+        self.grad = self.grad_all[:n_pad]
+        self.aux = self.grad_all[n_pad:]
         self.w, self.b, self.gw, self.gb = {}, {}, {}, {}
         off = 0
         for name, o, i in self.layers:
@@ -186,7 +189,7 @@ class VanillaRenderer(Renderer):
         rgb, sigma = self._field_eval(B, True)
         return rgb, sigma, dict(buffers=B if save else None)
 
-    def _field_backward(self, ctx, d_rgb, d_sig):
+    def _field_backward(self, ctx, d_rgb, d_sig, final: bool = False):
         B, n, C = ctx["buffers"], ctx["pk"].n, self.field.C
         dev = d_rgb.device
         z = lambda ld: torch.empty(B.n_pad, ld, device=dev, dtype=torch.float32)

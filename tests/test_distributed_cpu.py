@@ -80,6 +80,24 @@ def _worker(rank, port, out_dir):
     mean_s = parallel.allgather_mean(10.0 * (rank + 1))
     assert abs(mean_s - 15.0) < 1e-12
     assert parallel.rank_seed(7, rank) == 7 + rank and parallel.per_rank_budget(1 << 20, WORLD) == 1 << 19
+    # ---- the packed buffer [table | MLP | pad | aux]: one collective; with an early slice three, same sums
+    n_tab, n_pad = 1000, 1040
+    buf = torch.arange(n_pad + parallel.AUX_FLOATS, dtype=torch.float32) * (rank + 1)
+    buf[n_pad + parallel.AUX_TAU_HI] = 1e8 * (rank + 1)
+    buf[n_pad + parallel.AUX_TAU_LO] = 0.25
+    want = torch.arange(n_pad + parallel.AUX_FLOATS, dtype=torch.float32) * 3
+    want[n_pad + parallel.AUX_TAU_HI], want[n_pad + parallel.AUX_TAU_LO] = 3e8, 0.5
+    sync = parallel.GradSync(None, WORLD)
+    b1 = buf.clone()
+    sync.finish(b1)
+    assert sync.reset_count() == 1 and torch.equal(b1, want)
+    b2 = buf.clone()
+    sync.early(b2, 400, n_tab)                              # the fine levels' slice, launched from the backward pass
+    sync.finish(b2)
+    assert sync.reset_count() == 3 and torch.equal(b2, want)
+    # d loss / d tau travels as (hi, lo) float pair: the sum keeps what a float32 alone would lose
+    tau = float(b2[n_pad + parallel.AUX_TAU_HI].double() + b2[n_pad + parallel.AUX_TAU_LO].double())
+    assert tau == 3e8 + 0.5
     if rank == 0:
         torch.save({"grad_sum": grad, "loss0": loss}, os.path.join(out_dir, "r0.pt"))
     dist.barrier()

@@ -698,6 +698,43 @@ def test_event_batcher_on_device(amd):
     assert n > 0
 
 
+def test_replicated_occupancy_grids_stay_identical_and_level_split_backward(amd, spec, full_table_cache):
+    """Data-parallel readiness on one device.  (1) Two replicas ("ranks") refresh their occupancy grids past warm-up from
+    the renderer-owned stream: bit-identical grids whatever else each rank draws from the default generator (replaces
+    DDP's buffer broadcast, collective C4).  (2) The binned hash-grid backward in two level groups (what the overlap of
+    the gradient all-reduce uses) adds up to the single call."""
+    from oracle import field
+    ops, engine = amd
+    p = field.init_params(spec, seed=5)
+    p["hash"] = full_table_cache(7, 0.5)
+    grids = []
+    for rank in range(2):
+        fld = engine.NGPField(DEV)
+        fld.load(p)
+        r = engine.Renderer(fld, engine.RenderCfg(occ_res=(32,) * 3, warmup_steps=16))
+        torch.manual_seed(100 + rank)
+        for step in range(0, 80, 16):                            # one warm-up refresh, four sampled ones
+            torch.rand(1000 * (rank + 1) + step, device=DEV)      # rank-dependent use of the default stream
+            assert r.update_occ_grid(step)
+        grids.append((r.occs.clone(), r.binary.clone()))
+    assert torch.equal(grids[0][0], grids[1][0]) and torch.equal(grids[0][1], grids[1][1])
+    assert 0 < int(grids[0][1].sum()) < 32 ** 3
+    # ---- level groups
+    grid, n_table = ops.make_grid_desc()
+    n = 200_000
+    gen = torch.Generator(device=DEV).manual_seed(1)
+    x = torch.rand(n, 3, device=DEV, generator=gen)
+    gout = torch.randn(n, 32, device=DEV, generator=gen)
+    ws = torch.empty(ops.hashgrid_bwd_binned_workspace_bytes(n), device=DEV, dtype=torch.uint8)
+    full, split = torch.zeros(n_table, device=DEV), torch.zeros(n_table, device=DEV)
+    ops.hashgrid_bwd_binned(grid, full, gout, ws, x_unit=x, n=n, layout=0)
+    ops.hashgrid_bwd_binned(grid, split, gout, ws, x_unit=x, n=n, layout=0, level_mask=0xFF00)
+    lo = 2 * int(grid.offset[8])
+    assert float(split[:lo].abs().max()) == 0.0 and float(split[lo:].abs().max()) > 0.0
+    ops.hashgrid_bwd_binned(grid, split, gout, ws, x_unit=x, n=n, layout=0, level_mask=0x00FF)
+    assert rel_err(split, full) < 1e-5
+
+
 def test_rays_without_samples_render_background(amd, spec, full_table_cache):
     """A ray chunk that meets no occupied cell (image rows above the object) renders the background, opacity 0,
     and back-propagates nothing but d(bkgd) -- both samplers, training and inference."""
