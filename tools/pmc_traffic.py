@@ -14,7 +14,7 @@ import json, sqlite3, sys
 
 GROUPS = {  # C-ABI call -> (kernel-name fragment, launches of that kernel per call)
     "hashgrid_fwd": [("hashgrid_fwd_kernel", 1)],
-    "hashgrid_bwd_binned": [("bin_count_kernel", 1), ("bin_offsets_kernel", 1), ("bin_scatter_kernel", 1),
+    "hashgrid_bwd_binned": [("bin_count_kernel", 1), ("bin_offsets_kernel", 1), ("bin_scatter_kernel", 1),   # both scatter launches
                             ("bin_partition_kernel", 1), ("bin_accumulate_kernel", 1)],
     "mlp_fwd": [("mlp_fwd_kernel", 1)],
     "mlp_bwd": [("mlp_bwd_head_kernel", 1), ("mlp_bwd_base_kernel", 1), ("reduce_slabs_kernel", 2)],

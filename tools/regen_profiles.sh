@@ -1,23 +1,33 @@
 # Regenerates everything under profiles/ on a GPU box (run from the repo root through gpurun); results land in
-# gpurun_out/r01b/ and are copied into profiles/ by hand afterwards.
+# gpurun_out/$RND/ and profiles/ (the bench reads profiles/${RND}_pmc_traffic.json for roofline.traffic).
+#   gpurun --timeout 1700 -- 'bash tools/regen_profiles.sh r02'
 set -x
+RND=${1:-r02}
 R=$PWD
-O=$R/gpurun_out/r01b
+O=$R/gpurun_out/$RND
 mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
-# HBM traffic first: bench.py reads profiles/r01_pmc_traffic.json for roofline.traffic
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_FETCH_SIZE -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --fwd-chunks 1 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_WRITE_SIZE -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --fwd-chunks 1 > /dev/null 2>&1
+B="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --fwd-chunks 1"
+# HBM traffic first: bench.py reads profiles/${RND}_pmc_traffic.json for roofline.traffic
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_FETCH_SIZE -o pmc -- $B > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_WRITE_SIZE -o pmc -- $B > /dev/null 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $O/pmc_mfma -o pmc -- $B > /dev/null 2>&1
 cd $R
-python tools/pmc_traffic.py $O/pmc_FETCH_SIZE/pmc_results.db $O/pmc_WRITE_SIZE/pmc_results.db profiles/r01_pmc_traffic.json > /dev/null
-cp profiles/r01_pmc_traffic.json $O/
-python bench.py > $O/r01_bench.json 2> $O/bench.err
-python bench.py --no-cpu-baseline --events 65536 > $O/r01_bench_2x.json 2>>$O/bench.err
-python bench.py --no-cpu-baseline --sampler occgrid > $O/r01_bench_occgrid.json 2>>$O/bench.err
-python bench.py --no-cpu-baseline --arch mlp --events 4096 > $O/r01_bench_arch_mlp.json 2>>$O/bench.err
-python bench.py --no-cpu-baseline --loss-grad 1 > $O/r01_bench_lossgrad.json 2>>$O/bench.err
-python bench.py --no-cpu-baseline --mlp-bf16 > $O/r01_bench_bf16.json 2>>$O/bench.err
-python bench.py --no-cpu-baseline --mlp-kernels f32 > $O/r01_bench_f32mfma.json 2>>$O/bench.err
+python tools/pmc_traffic.py $O/pmc_FETCH_SIZE/pmc_results.db $O/pmc_WRITE_SIZE/pmc_results.db profiles/${RND}_pmc_traffic.json > /dev/null
+python tools/pmc_mfma.py $O/pmc_mfma/pmc_results.db profiles/${RND}_pmc_mfma.json > /dev/null
+python bench.py > profiles/${RND}_bench.json 2> $O/bench.err
+python bench.py --no-cpu-baseline --events 65536 > profiles/${RND}_bench_2x.json 2>>$O/bench.err
+python bench.py --no-cpu-baseline --sampler occgrid > profiles/${RND}_bench_occgrid.json 2>>$O/bench.err
+python bench.py --no-cpu-baseline --loss-grad 1e-3 > profiles/${RND}_bench_lossgrad.json 2>>$O/bench.err
+python bench.py --no-cpu-baseline --loss-grad 1e-3 --mlp-bf16 > profiles/${RND}_bench_lossgrad_bf16.json 2>>$O/bench.err
+python bench.py --no-cpu-baseline --mlp-bf16 > profiles/${RND}_bench_bf16.json 2>>$O/bench.err
+python bench.py --no-cpu-baseline --mlp-kernels f32 > profiles/${RND}_bench_f32mfma.json 2>>$O/bench.err
+python bench.py --no-cpu-baseline --save-activations 1 > profiles/${RND}_bench_saved_activations.json 2>>$O/bench.err
+python bench.py --no-cpu-baseline --workload e --events 8192 > profiles/${RND}_bench_config_e.json 2>>$O/bench.err
+python bench.py --no-cpu-baseline --arch mlp --events 4096 > profiles/${RND}_bench_arch_mlp.json 2>>$O/bench.err
+python tools/render_bench.py --config-e > profiles/${RND}_render_config_e.txt 2>>$O/bench.err
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o x -- python $R/bench.py --no-cpu-baseline > /dev/null 2>&1
-cd $R; ls $O $O/prof
+cd $R
+python tools/summarize_profile.py $(find $O/prof -name '*kernel_stats.csv' | head -1) profiles/${RND}_bench_kernel_stats.csv "rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline (13 steps of BASELINE configs[1])"
+ls profiles | grep $RND
