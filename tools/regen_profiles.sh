@@ -30,4 +30,4 @@ cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o x -- python $R/bench.py --no-cpu-baseline > /dev/null 2>&1
 cd $R
 python tools/summarize_profile.py $(find $O/prof -name '*kernel_stats.csv' | head -1) profiles/${RND}_bench_kernel_stats.csv "rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline (13 steps of BASELINE configs[1])"
-ls profiles | grep $RND
+cp profiles/${RND}_* $O/; ls $O
