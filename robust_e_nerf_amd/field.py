@@ -91,6 +91,35 @@ class _FieldFn(torch.autograd.Function):
         return (None, None, g_table, None, None, *outs)
 
 
+class _TruncExp(torch.autograd.Function):
+    """exp with the gradient clamp of the reference (external/ngp.py:45-65): backward g exp(min(x, 15)), written with
+    differentiable ops so that create_graph=True works."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return torch.exp(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return g * torch.exp(x.clamp(max=15.0))
+
+
+def sh4(d: torch.Tensor) -> torch.Tensor:
+    """real spherical harmonics of degree 4 (16 components, tcnn sign convention: external/sh_encoder.py:56-93) in
+    differentiable torch ops; the same polynomials as csrc/ren_mlp_common.h:sh4_select"""
+    x, y, z = d.unbind(-1)
+    xy, xz, yz, x2, y2, z2 = x * y, x * z, y * z, x * x, y * y, z * z
+    return torch.stack([
+        torch.full_like(x, 0.28209479177387814), -0.48860251190291987 * y, 0.48860251190291987 * z, -0.48860251190291987 * x,
+        1.0925484305920792 * xy, -1.0925484305920792 * yz, 0.94617469575755997 * z2 - 0.31539156525251999,
+        -1.0925484305920792 * xz, 0.54627421529603959 * x2 - 0.54627421529603959 * y2,
+        0.59004358992664352 * y * (-3.0 * x2 + y2), 2.8906114426405538 * xy * z, 0.45704579946446572 * y * (1.0 - 5.0 * z2),
+        0.3731763325901154 * z * (5.0 * z2 - 3.0), 0.45704579946446572 * x * (1.0 - 5.0 * z2),
+        1.4453057213202769 * z * (x2 - y2), 0.59004358992664352 * x * (-x2 + 3.0 * y2)], -1)
+
+
 class NGPradianceField(torch.nn.Module):
     """Instant-NGP radiance field with the reference's interface (external/ngp.py:109-280)."""
 
@@ -154,10 +183,32 @@ class NGPradianceField(torch.nn.Module):
             sigma = _FieldFn.apply(x.reshape(-1, 3), None, self.encoding.params, self, True, *self._mlp_tensors())
         return sigma.view(*shp, 1)
 
+    def _forward_twice_differentiable(self, x, d):
+        """The same field composed op by op -- contraction, HIP hash-grid encoding (tcnn_api, twice differentiable), the two
+        tiny MLPs and the SH encoder in torch, as the reference does itself for this very reason (ngp.py:5-19) -- for the
+        log-intensity-gradient loss, whose autograd.gradient(..., create_graph=True) w.r.t. the ray timestamps needs
+        d(rgb, sigma)/d(position, direction) and their second derivatives (robust_e_nerf.py:383-409)."""
+        F = torch.nn.functional
+        xu = contract_points(x, self.aabb.tolist(), self.contraction_type.value)
+        sel = ((xu > 0.0) & (xu < 1.0)).all(dim=-1, keepdim=True)
+        feat = self.encoding(xu)
+        sp = lambda v: F.softplus(v, beta=100)
+        b, h = self.mlp_base[1], self.mlp_head
+        o = F.linear(sp(F.linear(feat, b.hidden_layers[0].weight, b.hidden_layers[0].bias)), b.output_layer.weight, b.output_layer.bias)
+        sigma = _TruncExp.apply(o[:, :1] - 1.0) * sel
+        hin = torch.cat([sh4(d), o[:, 1:]], dim=-1)                                     # ngp.py:256-260
+        p = sp(F.linear(hin, h.hidden_layers[0].weight, h.hidden_layers[0].bias))
+        q = sp(F.linear(p, h.hidden_layers[1].weight, h.hidden_layers[1].bias))
+        rgb = F.softplus(F.linear(q, h.output_layer.weight, h.output_layer.bias), beta=1)
+        return rgb, sigma
+
     def forward(self, positions: torch.Tensor, directions: torch.Tensor = None):
         assert directions is not None and positions.shape == directions.shape, \
             f"{positions.shape} v.s. {None if directions is None else directions.shape}"
         shp = positions.shape[:-1]
+        if torch.is_grad_enabled() and (positions.requires_grad or directions.requires_grad):
+            rgb, sigma = self._forward_twice_differentiable(positions.reshape(-1, 3), directions.reshape(-1, 3))
+            return rgb.view(*shp, self.radiance_dim), sigma.view(*shp, 1)
         rgb, sigma = _FieldFn.apply(positions.reshape(-1, 3), directions.reshape(-1, 3), self.encoding.params, self,
                                     False, *self._mlp_tensors())
         return rgb.view(*shp, self.radiance_dim), sigma.view(*shp, 1)

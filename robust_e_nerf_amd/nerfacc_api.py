@@ -140,14 +140,39 @@ class _RenderWeightFromDensity(torch.autograd.Function):
         ts, te, sg = (t.reshape(-1).contiguous().float() for t in (t_starts, t_ends, sigmas))
         _, opac, _, w, T = ops.composite_fwd(offsets, counts, ts, te, sg, None, 1, None, save=True)
         ctx.save_for_backward(ts, te, sg, offsets, counts, w, T)
+        ctx.sigmas_in = sigmas                                   # with its graph, for the differentiable backward
         return w[:, None]
 
     @staticmethod
     def backward(ctx, g_w):
         ts, te, sg, offsets, counts, w, T = ctx.saved_tensors
+        if torch.is_grad_enabled() and (ctx.sigmas_in.requires_grad or g_w.requires_grad):
+            # create_graph=True (the log-intensity-gradient loss differentiates this backward again,
+            # utils/autograd.py:4-34): the same derivative written with differentiable torch scans
+            return None, None, _weights_backward_torch(ts, te, ctx.sigmas_in, offsets, counts, g_w), None, None
         d_sig, _, _ = ops.composite_bwd(offsets, counts, ts, te, sg, None, 1, None, w, T, None, None,
                                         g_weights=g_w.reshape(-1).contiguous().float())
         return None, None, d_sig[:, None], None, None
+
+
+def _weights_backward_torch(ts, te, sigmas, offsets, counts, g_w):
+    """d(sum g_i w_i)/d sigma_k = dt_k (g_k T_k exp(-s_k) - sum_{i>k in the ray} g_i w_i), s = sigma dt, from float64
+    cumulative sums over the packed stream (differentiable to any order w.r.t. sigmas and g_w)."""
+    n = ts.shape[0]
+    dt = (te - ts).double()
+    s = sigmas.reshape(-1).double() * dt
+    g = g_w.reshape(-1).double()
+    ray = torch.repeat_interleave(torch.arange(counts.shape[0], device=ts.device), counts.long(), output_size=n)
+    first = offsets.long()[ray]                                   # first sample of this sample's ray
+    cs = torch.cumsum(s, 0)
+    excl = cs - s                                                 # sum_{j < k, whole stream}
+    T = torch.exp(-(excl - excl[first]))                          # transmittance in front of sample k
+    w = T * (1.0 - torch.exp(-s))
+    gw = g * w
+    cg = torch.cumsum(gw, 0)
+    last = first + counts.long()[ray] - 1
+    suffix = cg[last] - cg                                        # sum_{i > k in the ray} g_i w_i
+    return ((g * T * torch.exp(-s) - suffix) * dt).to(sigmas.dtype).reshape(sigmas.shape)
 
 
 def render_weight_from_density(t_starts, t_ends, sigmas, *, packed_info=None, ray_indices=None, n_rays=None):

@@ -1099,6 +1099,65 @@ def test_opwise_seam_matches_fused_engine_and_reference(amd, full_table_cache):
     assert rel_err(bk_raw.grad.cpu(), g["g_bkgd_raw"]) < 1e-3
 
 
+def test_opwise_seam_grad_loss_matches_reference(amd, full_table_cache):
+    """The log-intensity-gradient loss THROUGH the op-by-op seam and plain autograd, as the reference computes it
+    (autograd.gradient(log I, ts, create_graph=True), utils/autograd.py:4-34, robust_e_nerf.py:383-409): twice-
+    differentiable HIP hash-grid encoding (tcnn_api), nerfacc-shaped weights with a differentiable backward, torch MLPs /
+    SH -- against the reference's own training_step golden (l_diff + l_grad): loss, d log I / dt, every field gradient."""
+    ops, engine = amd
+    from robust_e_nerf_amd import jvp, nerfacc_api, render_glue
+    g = load_golden("training_step_grad")
+    table = full_table_cache(g["table_seed"], g["table_scale"])
+    rf = _seam_field(amd, g, table)
+    rf.train()
+    occ_res = int(g["occ_res"])
+    grid = nerfacc_api.OccupancyGrid([-1.5] * 3 + [1.5] * 3, occ_res).to(DEV)
+    grid._binary = dev(np.unpackbits(g["binary"])[: occ_res ** 3].astype(bool)).view(occ_res, occ_res, occ_res)
+    tr, batch = _trainer_from_golden(engine, g, table)
+    batch["u_grad"] = dev(g["u_grad"])
+    w_grad = float(g["w_grad"])
+    prep = ops.event_prepare(batch, tr.c_p, tr.c_n, tr.tau, with_grad_ts=True)
+    B = batch["position"].shape[0]
+    jit = t(g["jitters"])
+    bk_raw = dev(g["bkgd_raw"]).clone().requires_grad_()
+    bkgd = torch.nn.functional.softplus(bk_raw)
+    kw = dict(scene_aabb=torch.tensor([-1.5] * 3 + [1.5] * 3, device=DEV), render_step_size=float(g["render_step_size"]),
+              render_bkgd=bkgd)
+    # ---- l_grad render: rays as functions of a per-ray time offset s (the pose tangents come from the HIP trajectory
+    # kernel; the reference differentiates its torch LinearTrajectory instead), d log I / dt = d log I / ds at s = 0
+    pos, rot, dpos, drot = jvp.trajectory_jvp(prep["ts_grad"], tr.tab_ts, tr.tab_pos, tr.tab_quat)
+    o0, d0, od, dd = jvp.raygen_jvp(tr.Kinv, batch["position"].contiguous(), pos, rot, dpos, drot)
+    s = torch.zeros(B, 1, device=DEV, requires_grad=True)
+    colors_g, opac_g, _, n_g = render_glue.render_image(rf, grid, o0 + od * s, d0 + dd * s, jitter=dev(jit[0]).float(), **kw)
+    log_i = (colors_g[:, 0] + 1e-3).log()
+    (dlog,) = torch.autograd.grad(log_i, s, torch.ones_like(log_i), create_graph=True)
+    dlog = dlog[:, 0]
+    target_g = prep["target_grad"]
+    loss_g = ((dlog - target_g).abs() / target_g.abs().clamp_min(2.220446049250313e-16)).mean() * w_grad   # MAPE (modules.py:77-102)
+    # ---- l_diff renders (no position gradient: the fused field function)
+    pos2, rot2 = ops.trajectory(prep["ts"], tr.tab_ts, tr.tab_pos, tr.tab_quat)
+    o, d = ops.raygen(tr.Kinv, torch.cat([batch["position"], batch["position"]]).contiguous(), pos2, rot2)
+    colors, _, _, _ = render_glue.render_image(rf, grid, o, d, jitter=torch.cat([dev(jit[1]), dev(jit[2])]).float(), **kw)
+    inten = colors[:, 0] + 1e-3
+    loss_d = ((inten[B:].log() - inten[:B].log() - prep["target_diff"]) ** 2).mean() / tr.mean_c ** 2
+    loss = loss_d + loss_g
+    assert rel_err(loss.detach().cpu(), g["loss"]) < 1e-4, (float(loss), float(g["loss"]))
+    logged = dict(zip(g["logged_keys"].tolist(), g["logged_vals"].tolist()))
+    assert abs(float(loss_g) / w_grad - logged["train/log_intensity_grad"]) < 1e-3 * logged["train/log_intensity_grad"]
+    loss.backward()
+    names = {"base.w0": "mlp_base.1.hidden_layers.0.weight", "base.b0": "mlp_base.1.hidden_layers.0.bias",
+             "base.wo": "mlp_base.1.output_layer.weight", "base.bo": "mlp_base.1.output_layer.bias",
+             "head.w0": "mlp_head.hidden_layers.0.weight", "head.b0": "mlp_head.hidden_layers.0.bias",
+             "head.w1": "mlp_head.hidden_layers.1.weight", "head.b1": "mlp_head.hidden_layers.1.bias",
+             "head.wo": "mlp_head.output_layer.weight", "head.bo": "mlp_head.output_layer.bias"}
+    params = dict(rf.named_parameters())
+    for k, nm in names.items():
+        e = rel_err(params[nm].grad.cpu(), g["g." + k])
+        assert e < 3e-3, (k, e)
+    assert rel_err(params["mlp_base.0.params"].grad.cpu()[t(g["g_table_idx"])], g["g_table_val"]) < 3e-3
+    assert rel_err(bk_raw.grad.cpu(), g["g_bkgd_raw"]) < 2e-3
+
+
 def test_eval_render_psnr_vs_oracle(amd, spec, full_table_cache):
     """evaluation_step-shaped chunked render of a 40x30 view; PSNR of HIP vs the CPU oracle render."""
     from oracle import step as ostep, trajectory as otraj
