@@ -53,11 +53,16 @@ def pmc_traffic(call, args):
     return c["hbm_bytes_per_launch"] if (same and c) else None
 
 
-def synthetic_scene(n_poses=2001, seed=0):
+def synthetic_scene(n_poses=2001, seed=0, hard=False):
     """radius-4 orbit with slow z oscillation looking at the origin, 1 ms pose spacing,
-    346x260 camera, K = [[480,0,172.5],[0,480,129.5],[0,0,1]]."""
+    346x260 camera, K = [[480,0,172.5],[0,480,129.5],[0,0,1]].  hard (BASELINE configs[2], "non-uniform motion"): the
+    same path traversed at non-uniform speed -- the path parameter is a smooth monotone warp of time (speed varies by
+    a factor of ~4 along the orbit) while the pose samples stay 1 ms apart."""
     k = np.arange(n_poses)
-    ang = 2 * np.pi * k / (n_poses - 1) * 1.5
+    u = k / (n_poses - 1)
+    if hard:
+        u = u + 0.6 / (2 * np.pi * 3) * np.sin(2 * np.pi * 3 * u)      # du/dt = 1 + 0.6 cos(6 pi t) > 0
+    ang = 2 * np.pi * u * 1.5
     pos = np.stack([4 * np.cos(ang), 4 * np.sin(ang), 0.6 * np.sin(3 * ang)], -1)
     fwd = -pos / np.linalg.norm(pos, axis=-1, keepdims=True)
     right = np.cross(fwd, np.array([0.0, 0.0, 1.0]))
@@ -163,10 +168,15 @@ def main():
                     help="> 1: hash encoding and MLP forward of alternate sample chunks on two HIP streams")
     ap.add_argument("--mlp-kernels", default="x", choices=["x", "f32"],
                     help="x = split-bf16 matrix-core MLP kernels at fp32 accuracy (default), f32 = exact f32-MFMA kernels")
+    ap.add_argument("--hard", action="store_true",
+                    help="BASELINE configs[2] 'lego hard' shape: non-uniform camera speed, C_p and tau trainable and mis-initialised "
+                         "(ratio 1.0, tau 0.999 tau_max), l_grad on (1e-3 unless --loss-grad is given); combine with --mlp-bf16")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --events per GPU whatever N (default).  strong: the reference's semantics (a fixed GLOBAL budget, "
                          "train_eff_ray_sample_batch_size // num_gpus, robust_e_nerf.py:63-66): --events is the global batch, "
                          "every rank takes events // N")
+    ap.add_argument("--dp-compress", default=None, choices=["bf16"],
+                    help="N > 1: parameter gradients cross the links as bfloat16 (the aux scalars stay fp32)")
     ap.add_argument("--no-dp-overlap", action="store_true",
                     help="N > 1: one all-reduce of the packed gradient buffer after the backward pass instead of reducing the "
                          "fine levels' slice beside the coarse levels' scatter")
@@ -210,7 +220,9 @@ def main():
         args.sampler = "occgrid"
         if args.loss_grad == 0.0:
             args.loss_grad = 1e-3
-    scene = synthetic_scene_e() if args.workload == "e" else synthetic_scene()
+    if args.hard and args.loss_grad == 0.0:
+        args.loss_grad = 1e-3
+    scene = synthetic_scene_e() if args.workload == "e" else synthetic_scene(hard=args.hard)
     tab_ts, tab_pos, tab_quat, Kinv = scene
     T = torch.from_numpy
     # field parameters: torch nn.Linear default init, hash table U(+-0.1) ("trained-like": random
@@ -233,6 +245,7 @@ def main():
                            mlp_kernels=args.mlp_kernels, fwd_chunks=args.fwd_chunks,
                            save_activations=None if args.save_activations < 0 else bool(args.save_activations))
     cfg.dp_overlap = not args.no_dp_overlap
+    cfg.dp_compress = args.dp_compress
     if args.workload == "e":
         aabb = E_AABB
         cfg = engine.RenderCfg(aabb=aabb, contraction_type=ops.UN_BOUNDED_SPHERE, occ_res=(256,) * 3, near_plane=0.05,
@@ -240,7 +253,7 @@ def main():
                                sampler="occgrid", mlp_bf16=args.mlp_bf16, mlp_kernels=args.mlp_kernels,
                                fwd_chunks=args.fwd_chunks,
                                save_activations=None if args.save_activations < 0 else bool(args.save_activations),
-                               dp_overlap=not args.no_dp_overlap)
+                               dp_overlap=not args.no_dp_overlap, dp_compress=args.dp_compress)
     if args.arch == "mlp":
         from robust_e_nerf_amd import vanilla
         fld = vanilla.VanillaField(dev, 1)
@@ -261,9 +274,13 @@ def main():
     if args.workload == "e":
         tcfg = engine.TrainCfg(w_grad=args.loss_grad, bkgd_is_param=False, train_contrast_threshold=True,
                                train_refractory_period=True)
+    p2n0, tau0 = torch.tensor(0.5413), torch.tensor(0.0, dtype=torch.float64)
+    if args.hard:                                    # ratio initialised at 1.0, tau at 0.999 tau_max (README.md:103)
+        tcfg = engine.TrainCfg(w_grad=args.loss_grad, train_contrast_threshold=True, train_refractory_period=True)
+        p2n0 = torch.tensor(math.log(math.expm1(1.0)))
+        tau0 = torch.tensor(1e5 * float(torch.logit(torch.tensor(0.999, dtype=torch.float64))), dtype=torch.float64)
     tr = engine.Trainer(r, tcfg, Kinv=T(Kinv), tab_ts=T(tab_ts), tab_pos=T(tab_pos), tab_quat=T(tab_quat),
-                        p2n_raw=torch.tensor(0.5413), neg_ct=torch.tensor(0.25),
-                        tau_raw=torch.tensor(0.0, dtype=torch.float64), tau_max=torch.tensor(1e5),
+                        p2n_raw=p2n0, neg_ct=torch.tensor(0.25), tau_raw=tau0, tau_max=torch.tensor(1e5),
                         bkgd_raw=torch.tensor([0.5413]), world_size=world, process_group=pg)
 
     B = args.events if args.scaling == "weak" else max(1, args.events // world)
@@ -361,6 +378,8 @@ def main():
             "loss": float(loss),
             "config": {"workload": ("BASELINE configs[4] settings (mocap-desk2.yaml: sphere contraction, 256^3 grid, cone 0.004, "
                                     "near/far, C_p + tau trainable) on synthetic events, " if args.workload == "e" else
+                                    "BASELINE configs[2] shape (non-uniform motion, C_p + tau trainable, l_grad" +
+                                    (", bf16 MLP + fp32 composite" if args.mlp_bf16 else "") + "): synthetic event stream, " if args.hard else
                                     "BASELINE configs[1]: synthetic ficus-like event stream, ") +
                                    f"{B} events/step/GPU = {2 * B} rays x {args.samples} samples, arch {args.arch}, fp32, "
                                    f"{'l_diff + l_grad (3 renders)' if args.loss_grad > 0 else 'l_diff (2 renders)'}, fwd+bwd+Adam; sampler={args.sampler}",

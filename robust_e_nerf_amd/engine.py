@@ -52,6 +52,7 @@ class RenderCfg:
     fwd_chunks: int = 16               # > 1: hash encoding and MLP of alternate sample chunks on two HIP streams
     dp_overlap: bool = True            # data parallel: all-reduce the fine levels' table gradient beside the coarse levels' scatter
     dp_split_level: int = 8            # levels >= this one go first (8 x 4 MiB of the 50 MB buffer)
+    dp_compress: Optional[str] = None  # "bf16": parameter gradients cross the links as bfloat16 (strong scaling), aux block stays fp32
     mlp_bf16: bool = False             # BASELINE configs[2]: bf16 MLP (rounded linear inputs/weights, fp32 accumulate), fp32 composite
 
 
@@ -458,7 +459,7 @@ class Trainer:
         self.sync = None
         if world_size > 1:
             from . import parallel
-            self.sync = parallel.GradSync(process_group, world_size)
+            self.sync = parallel.GradSync(process_group, world_size, compress=renderer.cfg.dp_compress)
             renderer.grad_sync = self.sync
         self._mean_s_dev = None                                  # samples / ray of this step, summed over ranks (device)
         self.lr_scale = 1.0

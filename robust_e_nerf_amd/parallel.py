@@ -50,32 +50,51 @@ class GradSync:
     running on RCCL's stream beside the rest of the backward; `finish()` reduces what is left and waits for all of it.
     Replaces DDP's bucketed all-reduce (scripts/run.py:81-93)."""
 
-    def __init__(self, group=None, world_size: Optional[int] = None):
+    def __init__(self, group=None, world_size: Optional[int] = None, compress: Optional[str] = None, n_exact_tail: int = AUX_FLOATS):
+        """compress="bf16": the parameter gradients travel as bfloat16 (half the bytes per link: SURVEY 8(e), for strong
+        scaling where the all-reduce is a visible fraction of the step); the last `n_exact_tail` floats (the aux block:
+        tau as a float pair, counters) always travel as float32."""
+        if compress not in (None, "bf16"):
+            raise NotImplementedError(f"gradient compression {compress!r}")
         self.group = group
         self.world = world_size if world_size is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
+        self.compress, self.n_exact_tail = compress, n_exact_tail
         self.pending = []
         self.done = []                                           # (start, stop) element ranges already launched
         self.collectives = 0                                     # launched in the current step (tests / DESIGN numbers)
 
+    def _launch(self, view: torch.Tensor, exact: bool):
+        if self.compress == "bf16" and not exact:
+            half = view.to(torch.bfloat16)
+            work = dist.all_reduce(half, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self.pending.append((work, view, half))
+        else:
+            self.pending.append((dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True), None, None))
+        self.collectives += 1
+
     def early(self, buf: torch.Tensor, start: int, stop: int):
         if self.world <= 1 or stop <= start:
             return
-        self.pending.append(dist.all_reduce(buf[start:stop], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        assert stop <= buf.numel() - self.n_exact_tail
+        self._launch(buf[start:stop], exact=False)
         self.done.append((start, stop))
-        self.collectives += 1
 
     def finish(self, buf: torch.Tensor):
         """all-reduce every element range of `buf` not launched by early(), wait for everything"""
         if self.world <= 1:
             return
+        n_cmp = buf.numel() - (self.n_exact_tail if self.compress else 0)      # [0, n_cmp) may be compressed
         pos = 0
-        for a, b in sorted(self.done) + [(buf.numel(), buf.numel())]:
+        for a, b in sorted(self.done) + [(n_cmp, n_cmp)]:
             if a > pos:
-                self.pending.append(dist.all_reduce(buf[pos:a], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-                self.collectives += 1
+                self._launch(buf[pos:a], exact=False)
             pos = max(pos, b)
-        for w in self.pending:
-            w.wait()
+        if n_cmp < buf.numel():
+            self._launch(buf[n_cmp:], exact=True)
+        for work, view, half in self.pending:
+            work.wait()
+            if half is not None:
+                view.copy_(half)
         self.pending, self.done = [], []
 
     def reset_count(self) -> int:

@@ -81,3 +81,13 @@ def test_level_table_matches_oracle():
     assert tuple(g.res) == spec.resolutions and tuple(g.size) == spec.sizes
     assert tuple(g.offset) == spec.offsets and tuple(bool(h) for h in g.hashed) == spec.hashed
     assert all(abs(a - b) < 1e-6 for a, b in zip(g.scale, spec.scales))
+
+
+def test_lightning_adapter_is_import_guarded():
+    """robust_e_nerf_amd.lightning imports without pytorch_lightning and says so when asked for a module"""
+    import importlib.util
+    import pytest as _pytest
+    from robust_e_nerf_amd import lightning
+    if importlib.util.find_spec("pytorch_lightning") is None:
+        with _pytest.raises(ImportError, match="scripts/train.py"):
+            lightning.make_module(None)

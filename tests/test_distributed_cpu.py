@@ -98,6 +98,14 @@ def _worker(rank, port, out_dir):
     # d loss / d tau travels as (hi, lo) float pair: the sum keeps what a float32 alone would lose
     tau = float(b2[n_pad + parallel.AUX_TAU_HI].double() + b2[n_pad + parallel.AUX_TAU_LO].double())
     assert tau == 3e8 + 0.5
+    # bf16-compressed parameter gradients: the sum agrees to bf16 precision, the aux tail (tau pair, counters) stays exact
+    csync = parallel.GradSync(None, WORLD, compress="bf16")
+    b3 = buf.clone()
+    csync.early(b3, 400, n_tab)
+    csync.finish(b3)
+    assert csync.reset_count() == 4                          # early slice, the two remaining ranges, the fp32 aux block
+    assert torch.equal(b3[n_pad:], want[n_pad:])
+    assert float(((b3[:n_pad] - want[:n_pad]).abs() / want[:n_pad].clamp_min(1.0)).max()) < 2 ** -7
     if rank == 0:
         torch.save({"grad_sum": grad, "loss0": loss}, os.path.join(out_dir, "r0.pt"))
     dist.barrier()
