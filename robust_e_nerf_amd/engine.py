@@ -481,7 +481,7 @@ class Trainer:
             lim = torch.tensor(1e-4, dtype=torch.float64).logit().abs()
             with torch.no_grad():                                         # clamp_refractory_period (:170-185)
                 self.tau_raw.copy_(self.tau_max * (self.tau_raw / self.tau_max).clamp(-lim, lim))
-            self.tau = float(self.tau_max * torch.sigmoid(self.tau_raw / self.tau_max))
+            self.tau = float(self.tau_max * torch.sigmoid(self.tau_raw.detach() / self.tau_max))
 
     def _refresh_contrast_threshold(self):
         if self.t.train_contrast_threshold:
