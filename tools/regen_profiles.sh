@@ -24,6 +24,8 @@ python bench.py --no-cpu-baseline --mlp-bf16 > profiles/${RND}_bench_bf16.json 2
 python bench.py --no-cpu-baseline --mlp-kernels f32 > profiles/${RND}_bench_f32mfma.json 2>>$O/bench.err
 python bench.py --no-cpu-baseline --save-activations 1 > profiles/${RND}_bench_saved_activations.json 2>>$O/bench.err
 python bench.py --no-cpu-baseline --workload e --events 8192 > profiles/${RND}_bench_config_e.json 2>>$O/bench.err
+python bench.py --no-cpu-baseline --hard --loss-grad 1e-3 --mlp-bf16 > profiles/${RND}_bench_hard_bf16.json 2>>$O/bench.err
+python bench.py --no-cpu-baseline --hard --loss-grad 1e-3 > profiles/${RND}_bench_hard.json 2>>$O/bench.err
 python bench.py --no-cpu-baseline --arch mlp --events 4096 > profiles/${RND}_bench_arch_mlp.json 2>>$O/bench.err
 python tools/render_bench.py --config-e > profiles/${RND}_render_config_e.txt 2>>$O/bench.err
 cd /tmp
