@@ -243,9 +243,12 @@ __device__ __forceinline__ void store_chunk_x(__bf16 *buf, const float (&pre)[NT
     }
 }
 
-template <int NT, bool BWD, int MODE>
+// NB = 32-sample blocks per wave: every weight fragment read from LDS feeds NB MFMAs (one per block).  With NB = 1 the
+// kernel is LDS-bound (one 1 KB ds_read_b128 per 32-cycle MFMA and SIMD = the whole 128 B/clk of the CU in bf16 mode)
+// and the weight staging (global load + split + LDS store by every workgroup) is amortised over 128 samples only.
+template <int NT, bool BWD, int MODE, int NB>
 __global__ __launch_bounds__(256, 2) void dense_x_kernel(DenseArgs a) {
-    // wide layers: the two 128-output halves of one 128-sample block are neighbouring workgroups, so the second
+    // wide layers: the two 128-output halves of one sample block are neighbouring workgroups, so the second
     // one finds the activation rows in L2 instead of re-reading them from HBM a whole pass later
     const int grp = a.groups > 1 ? (int)(blockIdx.x % a.groups) : 0;
     a.out0 += grp * 128;
@@ -256,13 +259,15 @@ __global__ __launch_bounds__(256, 2) void dense_x_kernel(DenseArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int hi = lane >> 5, sl = lane & 31;
     const int64_t n_blk = (a.n + 31) >> 5;
-    const int64_t blk = (int64_t)(blockIdx.x / (a.groups > 1 ? a.groups : 1)) * 4 + wave;
-    const bool active = blk < n_blk;
-    const int64_t row = blk * 32 + sl;
+    const int64_t blk0 = ((int64_t)(blockIdx.x / (a.groups > 1 ? a.groups : 1)) * 4 + wave) * NB;
+    bool active[NB];
+    int64_t row[NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) { active[u] = blk0 + u < n_blk; row[u] = (blk0 + u) * 32 + sl; }
     const int n_chunks = (a.red + KC - 1) / KC;
     constexpr int BUF = NP * NT * 32 * XST;
 
-    f32x16 acc[NT];
+    f32x16 acc[NB][NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -270,7 +275,8 @@ __global__ __launch_bounds__(256, 2) void dense_x_kernel(DenseArgs a) {
             const int o = a.out0 + t * 32 + rowc(g) + 4 * hi;
             float bv = 0.f;
             if (!BWD && a.bias) { bv = a.bias[min(o, a.w_rows - 1)]; bv = o < a.w_rows ? bv : 0.f; }
-            acc[t][g] = bv;
+#pragma unroll
+            for (int u = 0; u < NB; ++u) acc[u][t][g] = bv;
         }
     {
         float pre[NT * 4];
@@ -278,45 +284,57 @@ __global__ __launch_bounds__(256, 2) void dense_x_kernel(DenseArgs a) {
         store_chunk_x<NT, BWD, NP>(lds, pre);
     }
     __syncthreads();
-    float4 xv[4];                                        // this lane's 2 x 8 k-values of the chunk: k0 + 16 s + 8 hi + j
-    auto load_x = [&](int c, float4 (&dst)[4]) {
-        if (active) {
-            const float4 *xp = reinterpret_cast<const float4 *>(a.X + row * a.ldx + c * KC + 8 * hi);
-            dst[0] = xp[0]; dst[1] = xp[1]; dst[2] = xp[4]; dst[3] = xp[5];
-        } else {
+    // k-steps of 16 are software-pipelined across chunk boundaries: the 8 k-values a lane feeds in step q = 2 c + s are
+    // X[row][16 q + 8 hi ..+8] (two float4), fetched one step ahead -- 16 registers in flight per block instead of a
+    // whole chunk for each of this and the next one
+    const int n_steps = 2 * n_chunks;
+    float4 xc[NB][2];
+    auto load_x = [&](int q, float4 (&dst)[NB][2]) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) dst[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int u = 0; u < NB; ++u) {
+            if (active[u]) {
+                const float4 *xp = reinterpret_cast<const float4 *>(a.X + row[u] * a.ldx + 16 * q + 8 * hi);
+                dst[u][0] = xp[0]; dst[u][1] = xp[1];
+            } else {
+                dst[u][0] = make_float4(0.f, 0.f, 0.f, 0.f); dst[u][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
     };
-    load_x(0, xv);
+    load_x(0, xc);
     for (int c = 0; c < n_chunks; ++c) {
         float pre[NT * 4];
-        float4 xn[4];
         const bool more = c + 1 < n_chunks;
-        if (more) { load_chunk_x<NT, BWD, NP>(a, c + 1, pre); load_x(c + 1, xn); }
+        if (more) load_chunk_x<NT, BWD, NP>(a, c + 1, pre);
         const __bf16 *buf = lds + (c & 1) * BUF;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            const float xs[8] = {xv[2 * s].x, xv[2 * s].y, xv[2 * s].z, xv[2 * s].w,
-                                 xv[2 * s + 1].x, xv[2 * s + 1].y, xv[2 * s + 1].z, xv[2 * s + 1].w};
-            bf16x8 b[3];
-            split8<NP>(xs, b);
+            float4 xn[NB][2];
+            const int q = 2 * c + s;
+            if (q + 1 < n_steps) load_x(q + 1, xn);
+            bf16x8 b[NB][3];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const float xs[8] = {xc[u][0].x, xc[u][0].y, xc[u][0].z, xc[u][0].w, xc[u][1].x, xc[u][1].y, xc[u][1].z, xc[u][1].w};
+                split8<NP>(xs, b[u]);
+            }
 #pragma unroll
             for (int k = 0; k < PR::N; ++k)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {           // consecutive MFMAs hit different accumulators
                     const bf16x8 w = *reinterpret_cast<const bf16x8 *>(buf + ((PR::W[k] * NT * 32 + t * 32 + sl) * XST + 16 * s + 8 * hi));
-                    acc[t] = MFMAB(w, b[PR::A[k]], acc[t]);
-                }
-        }
-        if (more) {
-            store_chunk_x<NT, BWD, NP>(lds + ((c + 1) & 1) * BUF, pre);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) xv[j] = xn[j];
+                    for (int u = 0; u < NB; ++u) acc[u][t] = MFMAB(w, b[u][PR::A[k]], acc[u][t]);
+                }
+            if (q + 1 < n_steps) {
+#pragma unroll
+                for (int u = 0; u < NB; ++u) { xc[u][0] = xn[u][0]; xc[u][1] = xn[u][1]; }
+            }
         }
+        if (more) store_chunk_x<NT, BWD, NP>(lds + ((c + 1) & 1) * BUF, pre);
         __syncthreads();
     }
-    dense_epilogue<NT, BWD>(a, acc, active, row, hi);
+#pragma unroll
+    for (int u = 0; u < NB; ++u) dense_epilogue<NT, BWD>(a, acc[u], active[u], row[u], hi);
 }
 
 // ---- weight / bias gradient:  dW[N][K] += dZ^T X,  db[N] += sum dZ ------------------------------------
@@ -669,6 +687,7 @@ __global__ __launch_bounds__(256) void act_jvp_bwd_kernel(const float *__restric
 
 template <bool BWD>
 int launch_dense(DenseArgs a, int tiles, int mode, hipStream_t st) {
+    static const int nb_env = [] { const char *e = getenv("REN_DENSE_NB"); return e ? atoi(e) : 2; }();
     a.groups = 1;
     if (tiles == 8) {                                   // 256 outputs = two interleaved groups of 4 tiles (DenseArgs::out0)
         a.groups = 2;
@@ -676,17 +695,23 @@ int launch_dense(DenseArgs a, int tiles, int mode, hipStream_t st) {
         tiles = 4;
     }
     const int64_t n_blk = (a.n + 31) / 32;
-    const dim3 grd((unsigned)((n_blk + 3) / 4 * a.groups)), blk(256);
+    const int nb = (mode != 0 && nb_env == 2 && n_blk > 4 * 2048) ? 2 : 1;     // small launches: more workgroups instead
+    const dim3 grd((unsigned)((n_blk + 4 * nb - 1) / (4 * nb) * a.groups)), blk(256);
 #define REN_DENSE_LAUNCH(KERNEL, LDS)                                                                        \
     do {                                                                                                     \
         const size_t lds = (LDS);                                                                            \
         (void)hipFuncSetAttribute((const void *)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(KERNEL, grd, blk, lds, st, a);                                                    \
     } while (0)
+#define REN_DENSE_X(NT, MODE, NP)                                                                            \
+    do {                                                                                                     \
+        if (nb == 2) REN_DENSE_LAUNCH((dense_x_kernel<NT, BWD, MODE, 2>), 2 * (size_t)NP * NT * 32 * XST * 2); \
+        else REN_DENSE_LAUNCH((dense_x_kernel<NT, BWD, MODE, 1>), 2 * (size_t)NP * NT * 32 * XST * 2);        \
+    } while (0)
 #define REN_DENSE_CASE(NT)                                                                                   \
     case NT:                                                                                                 \
-        if (mode == 6) REN_DENSE_LAUNCH((dense_x_kernel<NT, BWD, 6>), 2 * (size_t)3 * NT * 32 * XST * 2);     \
-        else if (mode == 1) REN_DENSE_LAUNCH((dense_x_kernel<NT, BWD, 1>), 2 * (size_t)1 * NT * 32 * XST * 2); \
+        if (mode == 6) REN_DENSE_X(NT, 6, 3);                                                                \
+        else if (mode == 1) REN_DENSE_X(NT, 1, 1);                                                           \
         else REN_DENSE_LAUNCH((dense_kernel<NT, BWD>), 2 * (size_t)NT * 32 * 33 * 4);                          \
         break;
     switch (tiles) {
@@ -694,6 +719,7 @@ int launch_dense(DenseArgs a, int tiles, int mode, hipStream_t st) {
         default: return REN_ERR_UNSUPPORTED;
     }
 #undef REN_DENSE_CASE
+#undef REN_DENSE_X
 #undef REN_DENSE_LAUNCH
     REN_CHECK_LAUNCH();
 }
