@@ -200,36 +200,43 @@ __global__ __launch_bounds__(256, 2) void dense_kernel(DenseArgs a) {
 // feeds per k-step are contiguous in the row-major activations (two float4 loads) and are split in registers.
 constexpr int XST = 40;                                  // LDS row stride in bf16 (32 k + 8 pad)
 
-template <int NT, bool BWD, int NP>
-__device__ __forceinline__ void load_chunk_x(const DenseArgs &a, int c, float (&pre)[NT * 4]) {
+template <int NT, bool BWD, int NP, int NTH = 256>
+__device__ __forceinline__ void load_chunk_x(const DenseArgs &a, int c, float (&pre)[NT * 1024 / NTH], int j0 = 0,
+                                             int j1 = NT * 512 / NTH) {
     const int k0 = c * KC;
+    // 32-bit element offsets from the (wave-uniform) weight pointer: one address register per load instead of a
+    // 64-bit pair -- sixteen hoisted pairs were what spilled inside the backward-data loop
 #pragma unroll
-    for (int j = 0; j < NT * 2; ++j) {                   // thread -> (row, column pair) of the [NT*32][32] chunk
-        const int e = threadIdx.x + 256 * j;
+    for (int j = 0; j < NT * 512 / NTH; ++j) {           // thread -> (row, column pair) of the [NT*32][32] chunk
+        if (j < j0 || j >= j1) continue;
+        const int e = threadIdx.x + NTH * j;
         float v0 = 0.f, v1 = 0.f;
         if (!BWD) {
             const int row = a.out0 + (e >> 4), col = k0 + 2 * (e & 15);
             if (row < a.w_rows) {
-                const float *w = a.W + (int64_t)row * a.w_cols + col;
-                if (col < a.w_cols) v0 = w[0];
-                if (col + 1 < a.w_cols) v1 = w[1];
+                const uint32_t o = (uint32_t)(row * a.w_cols + col);
+                if (col < a.w_cols) v0 = a.W[o];
+                if (col + 1 < a.w_cols) v1 = a.W[o + 1];
             }
         } else {                                         // W^T: out row = W column, k = W row; coalesced along W columns
             const int row = a.out0 + e % (NT * 32), col = k0 + 2 * (e / (NT * 32));
             if (row < a.w_cols) {
-                if (col < a.w_rows) v0 = a.W[(int64_t)col * a.w_cols + row];
-                if (col + 1 < a.w_rows) v1 = a.W[(int64_t)(col + 1) * a.w_cols + row];
+                const uint32_t o = (uint32_t)(col * a.w_cols + row);
+                if (col < a.w_rows) v0 = a.W[o];
+                if (col + 1 < a.w_rows) v1 = a.W[o + (uint32_t)a.w_cols];
             }
         }
         pre[2 * j] = v0; pre[2 * j + 1] = v1;
     }
 }
 
-template <int NT, bool BWD, int NP>
-__device__ __forceinline__ void store_chunk_x(__bf16 *buf, const float (&pre)[NT * 4]) {
+template <int NT, bool BWD, int NP, int NTH = 256>
+__device__ __forceinline__ void store_chunk_x(__bf16 *buf, const float (&pre)[NT * 1024 / NTH], int j0 = 0,
+                                              int j1 = NT * 512 / NTH) {
 #pragma unroll
-    for (int j = 0; j < NT * 2; ++j) {
-        const int e = threadIdx.x + 256 * j;
+    for (int j = 0; j < NT * 512 / NTH; ++j) {
+        if (j < j0 || j >= j1) continue;
+        const int e = threadIdx.x + NTH * j;
         const int row = BWD ? e % (NT * 32) : e >> 4, cp = BWD ? e / (NT * 32) : e & 15;
         __bf16 s0[3], s1[3];
         split<NP>(pre[2 * j], s0);
@@ -304,10 +311,10 @@ __global__ __launch_bounds__(256, 2) void dense_x_kernel(DenseArgs a) {
     for (int c = 0; c < n_chunks; ++c) {
         float pre[NT * 4];
         const bool more = c + 1 < n_chunks;
-        if (more) load_chunk_x<NT, BWD, NP>(a, c + 1, pre);
         const __bf16 *buf = lds + (c & 1) * BUF;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
+            if (more && s == 0) load_chunk_x<NT, BWD, NP>(a, c + 1, pre);
             float4 xn[NB][2];
             const int q = 2 * c + s;
             if (q + 1 < n_steps) load_x(q + 1, xn);
@@ -329,12 +336,162 @@ __global__ __launch_bounds__(256, 2) void dense_x_kernel(DenseArgs a) {
 #pragma unroll
                 for (int u = 0; u < NB; ++u) { xc[u][0] = xn[u][0]; xc[u][1] = xn[u][1]; }
             }
+            if (more && s == 1) store_chunk_x<NT, BWD, NP>(lds + ((c + 1) & 1) * BUF, pre);
         }
-        if (more) store_chunk_x<NT, BWD, NP>(lds + ((c + 1) & 1) * BUF, pre);
         __syncthreads();
     }
 #pragma unroll
     for (int u = 0; u < NB; ++u) dense_epilogue<NT, BWD>(a, acc[u], active[u], row[u], hi);
+}
+
+// ---- wide layers (128 / 256 outputs): activation tiles staged through LDS ---------------------------------------------
+// One workgroup of 8 waves per CU; a wave owns NB blocks of 32 samples and NT x NB = 8 accumulator tiles (NT = 8: all
+// 256 outputs of a block, so the activation rows are read ONCE and every split of an activation operand feeds 48 MFMAs;
+// NT = 4: two blocks share each weight fragment).  What the row-major "lane = sample" loads of dense_x_kernel cost
+// (PMC at 1 M x 256 x 256, mode 6: MFMA 32 %, VALU 34 %, TA 54 % busy, waves waiting 35-40 % of their cycles): a wave
+// load touched 32 rows x 2 x 16 B, half of every 128-B line, one k-step ahead of its use.  Here a load instruction
+// covers 8 rows x 128 B (whole lines), a chunk ahead, and the tile is turned into the MFMA B layout through a
+// wave-private LDS tile (row stride 36 words: conflict-free for 16-byte accesses both ways); the epilogue goes back
+// through the same tile so that the stores (and the backward's saved-activation loads) are whole lines as well.
+constexpr int TST = 36;
+
+template <int NT, int NB, bool BWD, int MODE, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void dense_t_kernel(DenseArgs a) {
+    using PR = Pairs<MODE>;
+    constexpr int NP = PR::NT;
+    constexpr int WBUF = NP * NT * 32 * XST;             // bf16 elements of one weight chunk buffer
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_t[];
+    __bf16 *wl = reinterpret_cast<__bf16 *>(smem_t);     // 2 x [NP][NT*32][XST]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *xt = reinterpret_cast<float *>(smem_t + 2 * WBUF * 2) + wave * NB * 32 * TST;   // this wave's NB tiles
+    const int hi = lane >> 5, sl = lane & 31;
+    const int rl = lane >> 3, cl = 4 * (lane & 7);       // whole-line access: lane -> (row within 8, column group)
+    const int64_t n_blk = (a.n + 31) >> 5;
+    const int64_t blk0 = ((int64_t)blockIdx.x * NW + wave) * NB;
+    bool active[NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) active[u] = blk0 + u < n_blk;
+    const int n_chunks = (a.red + KC - 1) / KC;
+
+    f32x16 acc[NB][NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const int o = a.out0 + t * 32 + rowc(g) + 4 * hi;
+            float bv = 0.f;
+            if (!BWD && a.bias) { bv = a.bias[min(o, a.w_rows - 1)]; bv = o < a.w_rows ? bv : 0.f; }
+#pragma unroll
+            for (int u = 0; u < NB; ++u) acc[u][t][g] = bv;
+        }
+    float4 xn[NB][4];
+    auto load_x = [&](int c) {
+#pragma unroll
+        for (int u = 0; u < NB; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                xn[u][i] = active[u] ? *reinterpret_cast<const float4 *>(a.X + ((blk0 + u) * 32 + 8 * i + rl) * a.ldx + c * KC + cl)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto store_x = [&]() {
+#pragma unroll
+        for (int u = 0; u < NB; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<float4 *>(xt + (u * 32 + 8 * i + rl) * TST + cl) = xn[u][i];
+    };
+    {
+        float pre[NT * 16 / NW];
+        load_chunk_x<NT, BWD, NP, 64 * NW>(a, 0, pre);
+        load_x(0);
+        store_chunk_x<NT, BWD, NP, 64 * NW>(wl, pre);
+        store_x();
+    }
+    __syncthreads();
+    for (int c = 0; c < n_chunks; ++c) {
+        float pre[NT * 16 / NW];
+        const bool more = c + 1 < n_chunks;
+        if (more) load_x(c + 1);
+        const __bf16 *buf = wl + (c & 1) * WBUF;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if (more && s == 0) load_chunk_x<NT, BWD, NP, 64 * NW>(a, c + 1, pre);
+            bf16x8 b[NB][3];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const float4 x0 = *reinterpret_cast<const float4 *>(xt + (u * 32 + sl) * TST + 16 * s + 8 * hi);
+                const float4 x1 = *reinterpret_cast<const float4 *>(xt + (u * 32 + sl) * TST + 16 * s + 8 * hi + 4);
+                const float xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                split8<NP>(xs, b[u]);
+            }
+#pragma unroll
+            for (int k = 0; k < PR::N; ++k)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const bf16x8 w = *reinterpret_cast<const bf16x8 *>(buf + ((PR::W[k] * NT * 32 + t * 32 + sl) * XST + 16 * s + 8 * hi));
+#pragma unroll
+                    for (int u = 0; u < NB; ++u) acc[u][t] = MFMAB(w, b[u][PR::A[k]], acc[u][t]);
+                }
+            if (more && s == 1) store_chunk_x<NT, BWD, NP, 64 * NW>(wl + ((c + 1) & 1) * WBUF, pre);
+        }
+        if (more) store_x();                             // wave-private tile: LDS operations of one wave stay in order
+        __syncthreads();
+    }
+    // epilogue through the wave's tile: accumulators -> [sample][neuron] -> whole-line rows
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        if (!active[u]) continue;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            float *T = xt + u * 32 * TST;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<float4 *>(T + sl * TST + 8 * q + 4 * hi) =
+                    make_float4(acc[u][t][4 * q], acc[u][t][4 * q + 1], acc[u][t][4 * q + 2], acc[u][t][4 * q + 3]);
+            const int o0 = a.out0 + t * 32 + cl;
+            if (o0 >= a.n_out) continue;                 // (per lane; the LDS write above is unconditional)
+            const bool whole = o0 + 3 < a.n_out;
+            float4 yp4[4], yo4[4];
+            if (BWD) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int64_t row = (blk0 + u) * 32 + 8 * i + rl;
+                    yp4[i] = (whole && a.act == ACT_SOFTPLUS100) ? *reinterpret_cast<const float4 *>(a.Yprev + row * a.ldyp + o0)
+                                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+                    yo4[i] = (whole && a.accumulate) ? *reinterpret_cast<const float4 *>(a.Y + row * a.ldy + o0)
+                                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int64_t row = (blk0 + u) * 32 + 8 * i + rl;
+                const bool live = row < a.n;
+                const float4 z4 = *reinterpret_cast<const float4 *>(T + (8 * i + rl) * TST + cl);
+                const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
+                const float yp[4] = {yp4[i].x, yp4[i].y, yp4[i].z, yp4[i].w};
+                const float yo[4] = {yo4[i].x, yo4[i].y, yo4[i].z, yo4[i].w};
+                const bool selv = (!BWD && a.act == ACT_TRUNC_EXP_SEL && live) ? a.sel[row] != 0 : false;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float z = zz[j];
+                    if (!BWD) {
+                        if (a.act == ACT_SOFTPLUS100) z = softplus100(z);
+                        else if (a.act == ACT_SOFTPLUS1) z = softplus1(z);
+                        else if (a.act == ACT_TRUNC_EXP_SEL) z = selv ? __expf(z - 1.f) : 0.f;
+                    } else {
+                        z += yo[j];
+                        if (a.act == ACT_SOFTPLUS100) z *= dsoftplus_from_out(yp[j], 100.f);
+                    }
+                    v[j] = live ? z : 0.f;
+                }
+                float *yptr = a.Y + row * a.ldy + o0;
+                if (whole) *reinterpret_cast<float4 *>(yptr) = make_float4(v[0], v[1], v[2], v[3]);
+                else
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (o0 + j < a.n_out) yptr[j] = v[j];
+            }
+        }
+    }
 }
 
 // ---- weight / bias gradient:  dW[N][K] += dZ^T X,  db[N] += sum dZ ------------------------------------
@@ -687,8 +844,32 @@ __global__ __launch_bounds__(256) void act_jvp_bwd_kernel(const float *__restric
 
 template <bool BWD>
 int launch_dense(DenseArgs a, int tiles, int mode, hipStream_t st) {
-    static const int nb_env = [] { const char *e = getenv("REN_DENSE_NB"); return e ? atoi(e) : 2; }();
+    // kernel variant per (matrix-core mode, direction): 1 = dense_x_kernel, one block per wave; 2 = two blocks per wave;
+    // 3 = dense_t_kernel (wide layers only).  Defaults from tools/dense_bench.py / bench.py --arch mlp on MI355X.
+    static const int sel6 = [] { const char *e = getenv(BWD ? "REN_DENSE_BWD6" : "REN_DENSE_FWD6"); return e ? atoi(e) : (BWD ? 1 : 2); }();
+    static const int sel1 = [] { const char *e = getenv(BWD ? "REN_DENSE_BWD1" : "REN_DENSE_FWD1"); return e ? atoi(e) : 3; }();
+    const int sel = mode == 6 ? sel6 : sel1;
+    const int nb_env = sel == 1 ? 1 : 2;
+    const int use_t = sel == 3;
     a.groups = 1;
+    if (use_t && mode != 0 && tiles >= 4 && (a.n + 31) / 32 > 2048) {      // LDS-staged activation tiles, 8 waves per workgroup
+        a.out0 = 0;
+        const int64_t nblk = (a.n + 31) / 32;
+        constexpr int nw = 8;
+        const int nbw = 8 / tiles;                        // NT x NB = 8 accumulator tiles per wave
+        const dim3 grd((unsigned)((nblk + nw * nbw - 1) / (nw * nbw))), blk(64 * nw);
+#define REN_DENSE_T(NT, NB, MODE, NP, NW)                                                                    \
+        do {                                                                                                 \
+            const size_t lds = 2 * (size_t)NP * NT * 32 * XST * 2 + (size_t)NW * NB * 32 * TST * 4;              \
+            (void)hipFuncSetAttribute((const void *)dense_t_kernel<NT, NB, BWD, MODE, NW>,                    \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
+            hipLaunchKernelGGL((dense_t_kernel<NT, NB, BWD, MODE, NW>), grd, blk, lds, st, a);                \
+        } while (0)
+        if (tiles == 8) { if (mode == 6) REN_DENSE_T(8, 1, 6, 3, 8); else REN_DENSE_T(8, 1, 1, 1, 8); }
+        else { if (mode == 6) REN_DENSE_T(4, 2, 6, 3, 8); else REN_DENSE_T(4, 2, 1, 1, 8); }
+#undef REN_DENSE_T
+        REN_CHECK_LAUNCH();
+    }
     if (tiles == 8) {                                   // 256 outputs = two interleaved groups of 4 tiles (DenseArgs::out0)
         a.groups = 2;
         a.out0 = 0;

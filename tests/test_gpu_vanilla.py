@@ -149,6 +149,55 @@ def test_dense_matrix_core_modes(amd):
     assert rel_err(grads[6][0], ref_w) < 3e-5 and rel_err(grads[6][1], ref_b) < 1e-5
 
 
+@pytest.mark.parametrize("n_out,n_in", [(256, 256), (128, 283), (256, 319)])
+def test_dense_wide_layer_variants_at_training_size(amd, n_out, n_in):
+    """The large-launch variants of the wide layers (two sample blocks per wave sharing the weight fragments, and the
+    8-wave kernel that stages activation tiles through LDS) only run above 65 536 / 262 144 samples: forward (bias +
+    softplus100) and backward-data (accumulate + previous layer's activation derivative) at a ragged 300 001 samples,
+    split-bf16 == exact f32 MFMA to fp32 round-off, plain bf16 == float64 product of bf16-rounded operands."""
+    from robust_e_nerf_amd import _lib
+    ops, engine, vanilla = amd
+    P, st = ops._ptr, ops._stream
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(1)
+    n = 300001
+    n_pad = (n + 31) // 32 * 32
+    ldx = (n_in + 31) // 32 * 32
+    X = torch.zeros(n_pad, ldx)
+    X[:n, :n_in] = torch.randn(n, n_in, generator=gen)
+    W = torch.randn(n_out, n_in, generator=gen) / math.sqrt(n_in)
+    b = torch.randn(n_out, generator=gen) * 0.1
+    Yp = torch.rand(n_pad, 256, generator=gen) * 0.05                  # the previous layer's saved outputs
+    acc0 = torch.randn(n_pad, 256, generator=gen)
+    Xd, Wd, bd, Ypd = X.to(DEV), W.to(DEV).contiguous(), b.to(DEV), Yp.to(DEV)
+    outs = {}
+    for mode in (0, 6, 1):
+        Y = torch.full((n_pad, n_out), float("nan"), device=DEV)
+        assert lib.ren_dense_fwd(P(Xd), ldx, P(Wd), P(bd), n_out, n_in, 1 | (mode << 8), None, P(Y), n_out, n, st()) == 0
+        dX = acc0.to(DEV).clone()
+        assert lib.ren_dense_bwd_data(P(Y), n_out, P(Wd), n_out, n_in, 256, 1 | (mode << 8), P(Ypd), 256, 1, P(dX), 256, n, st()) == 0
+        assert not torch.isnan(Y[:n]).any()
+        outs[mode] = (Y[:n].cpu(), dX[:n].cpu())
+    assert rel_err(outs[6][0], outs[0][0]) < 2e-6 and rel_err(outs[6][1], outs[0][1]) < 2e-6
+    m = slice(n - 4097, n)                                             # float64 check on the ragged tail
+    z = X[m, :n_in].double() @ W.double().T + b.double()
+    y_ref = torch.where(z * 100 > 20, z, torch.log1p(torch.exp(z * 100)) / 100)
+    assert rel_err(outs[6][0][m], y_ref) < 2e-6
+    k = min(n_in, 256)
+    dx_ref = acc0[m].double()
+    dx_ref[:, :k] += (outs[6][0][m].double() @ W.double())[:, :k]
+    dx_ref *= 1.0 - torch.exp(-100.0 * Yp[m].double())
+    assert rel_err(outs[6][1][m], dx_ref) < 2e-6
+    r16 = lambda v: v.to(torch.bfloat16).double()
+    z = r16(X[m, :n_in]) @ r16(W).T + b.double()
+    y16 = torch.where(z * 100 > 20, z, torch.log1p(torch.exp(z * 100)) / 100)
+    assert rel_err(outs[1][0][m], y16) < 1e-5
+    dx16 = acc0[m].double()
+    dx16[:, :k] += (r16(outs[1][0][m]) @ r16(W))[:, :k]
+    dx16 *= 1.0 - torch.exp(-100.0 * Yp[m].double())
+    assert rel_err(outs[1][1][m], dx16) < 1e-5
+
+
 @pytest.mark.parametrize("ct", ["aabb", "sphere"])
 def test_vanilla_field_tangent_and_its_backward_vs_float64_autograd(amd, ct):
     """arch mlp under the log-intensity-gradient loss: d/dt of (rgb, sigma) along moving rays (forward mode through the
