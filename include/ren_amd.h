@@ -488,7 +488,8 @@ int ren_dense_fwd(const float *X, int32_t ldx, const float *W, const float *bias
 int ren_dense_bwd_data(const float *dZ, int32_t ldz, const float *W, int32_t n_out, int32_t n_in, int32_t n_store,
                        int32_t prev_act, const float *Yprev, int32_t ldyp, int32_t accumulate, float *dX,
                        int32_t ldx, int64_t n, void *stream);
-/* grad_w[n_out][n_in] += dZ^T X, grad_b[n_out] += column sums of dZ (slab-reduced, deterministic) */
+/* grad_w[n_out][n_in] += dZ^T X, grad_b[n_out] += column sums of dZ (slab-reduced, deterministic); grad_b may be NULL
+ * (tangent stream of a layer: no bias) */
 /* Activation algebra of the tangent stream of a dense layer (log-intensity-gradient loss with arch mlp): y = softplus_beta(z),
  * yd = s zd with s = 1 - exp(-beta y) taken from the output.  fwd: Yd = s Zd.  bwd: gz = gy s + gyd zd beta s (1 - s),
  * gzd = gyd s.  Row-major buffers; Y (and Yd in fwd) may be column ranges of wider buffers (ld), the others are dense
@@ -507,6 +508,29 @@ int ren_dense_bwd_weight(const float *dZ, int32_t ldz, const float *X, int32_t l
  * g_sigma * d sigma/d raw; padding zeroed */
 int ren_vanilla_heads_bwd(const float *g_rgb, const float *rgb, const float *g_sigma, const float *sigma,
                           int64_t n, int32_t C, float *dz_rgb, float *dz_sigma, void *stream);
+/* Tangent streams of the vanilla field (robust_e_nerf/external/mlp.py:208-243,333-358 under
+ * utils/autograd.py:4-34 for the log-intensity-gradient loss, models/robust_e_nerf.py:383-409; the second order serves
+ * d loss / d tau, see ren_trajectory_jvp2).  ren_freq_encode_jvp: `order`-th time derivative (1 or 2) of ren_freq_encode's
+ * position / view features for a packed sample stream whose rays carry o, d and their time derivatives do, dd, ddd
+ * (o'' = 0 inside a pose segment); same destinations and layout as ren_freq_encode, rows n..n_pad written as zeros. */
+int ren_freq_encode_jvp(const ren_scene_desc *scene, const float *rays_o, const float *rays_d, const float *rays_do,
+                        const float *rays_dd, const float *rays_ddd, const int32_t *ray_indices, const float *t_starts,
+                        const float *t_ends, int64_t n, int32_t order, float *enc, int32_t ld_enc, float *cat, int32_t ld_cat,
+                        int32_t cat_col, float *view, int32_t ld_view, int32_t view_col, void *stream);
+/* y = softplus_beta(z) with first and second time derivatives: Yd = s Zd, Ydd = beta s (1 - s) Zd^2 + s Zdd */
+int ren_act_jvp2_fwd(const float *Y, int32_t ldy, const float *Zd, const float *Zdd, int32_t ldz, float beta, float *Yd,
+                     int32_t ldyd, float *Ydd, int32_t ldydd, int64_t rows, int32_t width, void *stream);
+/* Output heads of the tangent streams: rgb = softplus_1(zo), sigma = selector exp(zs - 1) (clamped derivative, ngp.py:45-65).
+ * zod / zodd / zsd / zsdd: [n_pad][4] pre-activation tangents (ren_dense_fwd without bias / activation); the second-order
+ * arguments (zodd, zsdd, rgbdd, sigmadd) may all be NULL.  rgb* are (n, C), sigma* (n). */
+int ren_vanilla_heads_jvp(const float *rgb, const float *sigma, const float *zod, const float *zodd, const float *zsd,
+                          const float *zsdd, int64_t n, int32_t C, float *rgbd, float *rgbdd, float *sigmad, float *sigmadd,
+                          void *stream);
+/* reverse pass of (rgb, rgbd, sigma, sigmad) -> pre-activation gradients of the value and the tangent stream, each
+ * [n_pad][32] zero-padded (as ren_vanilla_heads_bwd) */
+int ren_vanilla_heads_bwd_jvp(const float *g_rgb, const float *g_rgbd, const float *g_sigma, const float *g_sigmad,
+                              const float *rgb, const float *sigma, const float *zod, const float *zsd, int64_t n, int32_t C,
+                              float *dz_rgb, float *dzd_rgb, float *dz_sigma, float *dzd_sigma, void *stream);
 
 /* ---- utilities ------------------------------------------------------------------------------------- */
 /* out[c] = sum_r in[r*C + c]   (C <= 4); scratch512: 512 floats of device scratch (two-stage, deterministic) */

@@ -842,6 +842,86 @@ __global__ __launch_bounds__(256) void act_jvp_bwd_kernel(const float *__restric
     *reinterpret_cast<float4 *>(Gzd + r * w + c) = make_float4(gzd[0], gzd[1], gzd[2], gzd[3]);
 }
 
+// second-order forward:  yd = s zd,  ydd = s' zd^2 + s zdd  (y = softplus_beta(z); trainable tau under the
+// log-intensity-gradient loss, arch mlp: value, d/dt and d2/dt2 streams through the same dense layers)
+__global__ __launch_bounds__(256) void act_jvp2_fwd_kernel(const float *__restrict__ Y, int ldy, const float *__restrict__ Zd,
+                                                           const float *__restrict__ Zdd, int ldz, float beta,
+                                                           float *__restrict__ Yd, int ldyd, float *__restrict__ Ydd, int ldydd,
+                                                           int64_t rows, int width4) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= rows * width4) return;
+    const int64_t r = e / width4;
+    const int c = (int)(e - r * width4) * 4;
+    const float4 y4 = *reinterpret_cast<const float4 *>(Y + r * ldy + c);
+    const float4 zd4 = *reinterpret_cast<const float4 *>(Zd + r * ldz + c), ze4 = *reinterpret_cast<const float4 *>(Zdd + r * ldz + c);
+    const float y[4] = {y4.x, y4.y, y4.z, y4.w}, zd[4] = {zd4.x, zd4.y, zd4.z, zd4.w}, ze[4] = {ze4.x, ze4.y, ze4.z, ze4.w};
+    float od[4], oe[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float sj = dsoftplus_from_out(y[j], beta);
+        od[j] = sj * zd[j];
+        oe[j] = beta * sj * (1.f - sj) * zd[j] * zd[j] + sj * ze[j];
+    }
+    *reinterpret_cast<float4 *>(Yd + r * ldyd + c) = make_float4(od[0], od[1], od[2], od[3]);
+    *reinterpret_cast<float4 *>(Ydd + r * ldydd + c) = make_float4(oe[0], oe[1], oe[2], oe[3]);
+}
+
+// ---- output heads of the tangent streams ------------------------------------------------------------------------------
+// rgb = softplus_1(zo):  rgbd = s zod,  rgbdd = s (1 - s) zod^2 + s zodd,  s = 1 - exp(-rgb)
+// sigma = sel exp(zs - 1) with the reference's clamped derivative (ngp.py:45-65): phi' = min(sigma, e^15),
+// phi'' = sigma below the clamp, 0 above:  sigmad = phi' zsd,  sigmadd = phi'' zsd^2 + phi' zsdd
+__global__ __launch_bounds__(256) void heads_jvp_kernel(const float *__restrict__ rgb, const float *__restrict__ sigma,
+                                                        const float *__restrict__ zod, const float *__restrict__ zodd,
+                                                        const float *__restrict__ zsd, const float *__restrict__ zsdd,
+                                                        int64_t n, int C, float *__restrict__ rgbd, float *__restrict__ rgbdd,
+                                                        float *__restrict__ sigmad, float *__restrict__ sigmadd) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float E15 = 3269017.3724721107f;
+    const float sg = sigma[i], p1 = fminf(sg, E15), p2 = sg < E15 ? sg : 0.f;
+    const float d = zsd[4 * i];
+    sigmad[i] = p1 * d;
+    if (sigmadd) sigmadd[i] = p2 * d * d + p1 * zsdd[4 * i];
+    for (int c = 0; c < C; ++c) {
+        const float s = dsoftplus_from_out(rgb[i * C + c], 1.f), zd = zod[4 * i + c];
+        rgbd[i * C + c] = s * zd;
+        if (rgbdd) rgbdd[i * C + c] = s * (1.f - s) * zd * zd + s * zodd[4 * i + c];
+    }
+}
+
+// reverse pass of (rgb, rgbd, sigma, sigmad): pre-activation gradients of the value and the tangent stream, written as
+// zero-padded [n_pad][32] rows (the B operands of the output layers' weight / data gradient launches)
+__global__ __launch_bounds__(256) void heads_bwd_jvp_kernel(const float *__restrict__ g_rgb, const float *__restrict__ g_rgbd,
+                                                            const float *__restrict__ g_sigma, const float *__restrict__ g_sigmad,
+                                                            const float *__restrict__ rgb, const float *__restrict__ sigma,
+                                                            const float *__restrict__ zod, const float *__restrict__ zsd,
+                                                            int64_t n, int64_t n_pad, int C, float *__restrict__ dz_rgb,
+                                                            float *__restrict__ dzd_rgb, float *__restrict__ dz_sigma,
+                                                            float *__restrict__ dzd_sigma) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pad) return;
+    float r[4] = {0.f, 0.f, 0.f, 0.f}, rd[4] = {0.f, 0.f, 0.f, 0.f}, s0 = 0.f, sd0 = 0.f;
+    if (i < n) {
+        for (int c = 0; c < C; ++c) {
+            const float s = dsoftplus_from_out(rgb[i * C + c], 1.f);
+            r[c] = g_rgb[i * C + c] * s + g_rgbd[i * C + c] * zod[4 * i + c] * s * (1.f - s);
+            rd[c] = g_rgbd[i * C + c] * s;
+        }
+        const float E15 = 3269017.3724721107f;
+        const float sg = sigma[i], p1 = fminf(sg, E15), p2 = sg < E15 ? sg : 0.f;
+        s0 = g_sigma[i] * p1 + g_sigmad[i] * zsd[4 * i] * p2;
+        sd0 = g_sigmad[i] * p1;
+    }
+    float4 *o[4] = {reinterpret_cast<float4 *>(dz_rgb + i * 32), reinterpret_cast<float4 *>(dzd_rgb + i * 32),
+                    reinterpret_cast<float4 *>(dz_sigma + i * 32), reinterpret_cast<float4 *>(dzd_sigma + i * 32)};
+    o[0][0] = make_float4(r[0], r[1], r[2], r[3]);
+    o[1][0] = make_float4(rd[0], rd[1], rd[2], rd[3]);
+    o[2][0] = make_float4(s0, 0.f, 0.f, 0.f);
+    o[3][0] = make_float4(sd0, 0.f, 0.f, 0.f);
+    for (int q = 0; q < 4; ++q)
+        for (int j = 1; j < 8; ++j) o[q][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 template <bool BWD>
 int launch_dense(DenseArgs a, int tiles, int mode, hipStream_t st) {
     // kernel variant per (matrix-core mode, direction): 1 = dense_x_kernel, one block per wave; 2 = two blocks per wave;
@@ -998,7 +1078,7 @@ extern "C" int ren_dense_bwd_weight(const float *dZ, int32_t ldz, const float *X
                                     float *workspace, void *stream) {
     const int mode = (n_splits >> 16) & 0xff;                                  // REN_DENSE_* >> 8 in bits 16..23
     n_splits &= 0xffff;
-    if (!dZ || !X || !grad_w || !grad_b || !workspace || n < 0 || n_out < 1 || n_in < 1 || n_splits < 1)
+    if (!dZ || !X || !grad_w || !workspace || n < 0 || n_out < 1 || n_in < 1 || n_splits < 1)
         return REN_ERR_BAD_ARG;
     if (ldx < ((n_in + 31) / 32) * 32 || ldz < n_out || (ldx & 3) || (ldz & 3) || n_out > 256) return REN_ERR_BAD_ARG;
     if (n == 0) return REN_OK;
@@ -1017,7 +1097,7 @@ extern "C" int ren_dense_bwd_weight(const float *dZ, int32_t ldz, const float *X
     }
     const int len_w = n_out * n_in;
     launch_reduce_slabs(a.slab_w, n_splits, len_w, grad_w, st);
-    launch_reduce_slabs(a.slab_b, n_splits, n_out, grad_b, st);
+    if (grad_b) launch_reduce_slabs(a.slab_b, n_splits, n_out, grad_b, st);    // NULL: a tangent stream (no bias)
     REN_CHECK_LAUNCH();
 }
 
@@ -1029,5 +1109,43 @@ extern "C" int ren_vanilla_heads_bwd(const float *g_rgb, const float *rgb, const
     const int64_t n_pad = (n + 31) / 32 * 32;
     hipLaunchKernelGGL(heads_bwd_kernel, dim3(ren_blocks(n_pad, 256)), dim3(256), 0, (hipStream_t)stream, g_rgb, rgb,
                        g_sigma, sigma, n, n_pad, C, dz_rgb, dz_sigma);
+    REN_CHECK_LAUNCH();
+}
+
+extern "C" int ren_act_jvp2_fwd(const float *Y, int32_t ldy, const float *Zd, const float *Zdd, int32_t ldz, float beta,
+                                float *Yd, int32_t ldyd, float *Ydd, int32_t ldydd, int64_t rows, int32_t width, void *stream) {
+    if (!Y || !Zd || !Zdd || !Yd || !Ydd || rows < 0 || width < 4 || (width & 3) || (ldy & 3) || (ldz & 3) || (ldyd & 3) ||
+        (ldydd & 3) || ldy < width || ldz < width || ldyd < width || ldydd < width)
+        return REN_ERR_BAD_ARG;
+    if (rows == 0) return REN_OK;
+    hipLaunchKernelGGL(act_jvp2_fwd_kernel, dim3(ren_blocks(rows * (width / 4), 256)), dim3(256), 0, (hipStream_t)stream, Y, ldy,
+                       Zd, Zdd, ldz, beta, Yd, ldyd, Ydd, ldydd, rows, width / 4);
+    REN_CHECK_LAUNCH();
+}
+
+extern "C" int ren_vanilla_heads_jvp(const float *rgb, const float *sigma, const float *zod, const float *zodd,
+                                     const float *zsd, const float *zsdd, int64_t n, int32_t C, float *rgbd, float *rgbdd,
+                                     float *sigmad, float *sigmadd, void *stream) {
+    if (!rgb || !sigma || !zod || !zsd || !rgbd || !sigmad || n < 0) return REN_ERR_BAD_ARG;
+    if ((rgbdd || sigmadd) && (!rgbdd || !sigmadd || !zodd || !zsdd)) return REN_ERR_BAD_ARG;
+    if (C != 1 && C != 3) return REN_ERR_UNSUPPORTED;
+    if (n == 0) return REN_OK;
+    hipLaunchKernelGGL(heads_jvp_kernel, dim3(ren_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, rgb, sigma, zod, zodd,
+                       zsd, zsdd, n, C, rgbd, rgbdd, sigmad, sigmadd);
+    REN_CHECK_LAUNCH();
+}
+
+extern "C" int ren_vanilla_heads_bwd_jvp(const float *g_rgb, const float *g_rgbd, const float *g_sigma, const float *g_sigmad,
+                                         const float *rgb, const float *sigma, const float *zod, const float *zsd, int64_t n,
+                                         int32_t C, float *dz_rgb, float *dzd_rgb, float *dz_sigma, float *dzd_sigma,
+                                         void *stream) {
+    if (!g_rgb || !g_rgbd || !g_sigma || !g_sigmad || !rgb || !sigma || !zod || !zsd || !dz_rgb || !dzd_rgb || !dz_sigma ||
+        !dzd_sigma || n < 0)
+        return REN_ERR_BAD_ARG;
+    if (C != 1 && C != 3) return REN_ERR_UNSUPPORTED;
+    if (n == 0) return REN_OK;
+    const int64_t n_pad = (n + 31) / 32 * 32;
+    hipLaunchKernelGGL(heads_bwd_jvp_kernel, dim3(ren_blocks(n_pad, 256)), dim3(256), 0, (hipStream_t)stream, g_rgb, g_rgbd,
+                       g_sigma, g_sigmad, rgb, sigma, zod, zsd, n, n_pad, C, dz_rgb, dzd_rgb, dz_sigma, dzd_sigma);
     REN_CHECK_LAUNCH();
 }

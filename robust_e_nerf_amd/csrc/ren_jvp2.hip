@@ -457,6 +457,79 @@ __global__ __launch_bounds__(256) void composite_fwd_jvp2_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------------ arch mlp: d/dt, d2/dt2
+// of the frequency encodings (SinusoidalEncoder, robust_e_nerf/external/mlp.py:208-243,333-352) of a packed sample
+// stream: the position encoding of u(t) (contracted sample midpoint) and the view encoding of d(t).  Same feature
+// order as freq_encode_kernel (csrc/ren_dense.hip): [x, sin(2^k x) (k-major, then axis), sin(2^k x + pi/2)].
+// `order` picks the Taylor coefficient written (1: first, 2: second derivative); rows n..n_pad are zero.
+template <int deg>
+__device__ __forceinline__ void sin_enc_t2(const T2 *x, int order, float *out) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) out[j] = order == 1 ? x[j].d : x[j].e;
+#pragma unroll
+    for (int k = 0; k < deg; ++k) {
+        const float sc = (float)(1 << k);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float xb = x[j].v * sc, xd = x[j].d * sc, xe = x[j].e * sc;
+            const float sn = sinf(xb), cs = sinf(xb + 1.5707963267948966f);
+            out[3 + 3 * k + j] = order == 1 ? cs * xd : cs * xe - sn * xd * xd;
+            out[3 + 3 * deg + 3 * k + j] = order == 1 ? -sn * xd : -sn * xe - cs * xd * xd;
+        }
+    }
+}
+
+struct EncT2Args {
+    Ray2 ray;
+    ren_scene_dev sc;
+    int64_t n, n_pad;
+    int order;
+    float *enc; int ld_enc;
+    float *cat; int ld_cat, cat_col;
+    float *view; int ld_view, view_col;
+};
+
+__global__ __launch_bounds__(256) void freq_encode_jvp_kernel(EncT2Args a) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_pad) return;
+    float e[64], v[32];
+#pragma unroll
+    for (int j = 0; j < 64; ++j) e[j] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) v[j] = 0.f;
+    if (i < a.n) {
+        T2 u[3]; int ray;
+        unit_pos2(a.ray, a.sc, i, u, ray);
+        const float TWO_PI = 6.283185307179586f, PI = 3.141592653589793f;
+        T2 p[3], c[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            p[k] = TWO_PI * (u[k] + (-0.5f));
+            const int64_t j = 3 * (int64_t)ray + k;
+            c[k] = t2(PI * a.ray.d[j], PI * a.ray.dd[j], PI * a.ray.ddd[j]);
+        }
+        sin_enc_t2<10>(p, a.order, e);
+        e[63] = 0.f;
+        if (a.view) sin_enc_t2<4>(c, a.order, v);
+    }
+    float4 *o1 = reinterpret_cast<float4 *>(a.enc + i * a.ld_enc);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) o1[j] = make_float4(e[4 * j], e[4 * j + 1], e[4 * j + 2], e[4 * j + 3]);
+    if (a.cat) {
+        float4 *o2 = reinterpret_cast<float4 *>(a.cat + i * a.ld_cat + a.cat_col);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) o2[j] = make_float4(e[4 * j], e[4 * j + 1], e[4 * j + 2], e[4 * j + 3]);
+    }
+    if (a.view) {
+#pragma unroll
+        for (int j = 27; j < 32; ++j) v[j] = 0.f;
+        float4 *o3 = reinterpret_cast<float4 *>(a.view + i * a.ld_view + a.view_col);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o3[j] = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+    }
+}
+
+
 }  // namespace
 
 extern "C" int ren_trajectory_jvp2(const double *ts, int64_t B, const int64_t *tab_ts, const float *tab_pos,
@@ -548,5 +621,26 @@ extern "C" int ren_composite_fwd_jvp2(const int64_t *offsets, const int32_t *cou
         hipLaunchKernelGGL(composite_fwd_jvp2_kernel<3>, grid, block, 0, (hipStream_t)stream, offsets, counts, n_rays,
                            t_starts, t_ends, sigmas, sigmads, sigmadds, rgbs, rgbds, rgbdds, bkgd, colors, colords,
                            colorsdd);
+    REN_CHECK_LAUNCH();
+}
+
+extern "C" int ren_freq_encode_jvp(const ren_scene_desc *scene, const float *rays_o, const float *rays_d,
+                                   const float *rays_do, const float *rays_dd, const float *rays_ddd,
+                                   const int32_t *ray_indices, const float *t_starts, const float *t_ends, int64_t n,
+                                   int32_t order, float *enc, int32_t ld_enc, float *cat, int32_t ld_cat, int32_t cat_col,
+                                   float *view, int32_t ld_view, int32_t view_col, void *stream) {
+    if (!scene || !rays_o || !rays_d || !rays_do || !rays_dd || !rays_ddd || !ray_indices || !t_starts || !t_ends || !enc ||
+        n < 0 || (order != 1 && order != 2) || ld_enc < 64 || (ld_enc & 3))
+        return REN_ERR_BAD_ARG;
+    if (cat && (ld_cat < cat_col + 64 || (ld_cat & 3) || (cat_col & 3))) return REN_ERR_BAD_ARG;
+    if (view && (ld_view < view_col + 32 || (ld_view & 3) || (view_col & 3))) return REN_ERR_BAD_ARG;
+    if (n == 0) return REN_OK;
+    EncT2Args a;
+    a.ray = Ray2{rays_o, rays_d, rays_do, rays_dd, rays_ddd, ray_indices, t_starts, t_ends};
+    a.sc = ren_make_scene(scene);
+    a.n = n; a.n_pad = (n + 31) / 32 * 32; a.order = order;
+    a.enc = enc; a.ld_enc = ld_enc; a.cat = cat; a.ld_cat = ld_cat; a.cat_col = cat_col;
+    a.view = view; a.ld_view = ld_view; a.view_col = view_col;
+    hipLaunchKernelGGL(freq_encode_jvp_kernel, dim3(ren_blocks(a.n_pad, 256)), dim3(256), 0, (hipStream_t)stream, a);
     REN_CHECK_LAUNCH();
 }

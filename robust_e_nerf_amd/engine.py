@@ -587,9 +587,6 @@ class Trainer:
         with the event rate C/dt.  Accumulates gradients; returns (weighted loss term, aux)."""
         from . import jvp
         r, t, f = self.r, self.t, self.r.field
-        if t.train_refractory_period and not isinstance(f, NGPField):
-            raise NotImplementedError("a trainable refractory period with the log-intensity-gradient loss needs the second-order "
-                                      "tangent render, which is built for arch ngp only")
         B = batch["position"].shape[0]
         self._refresh_contrast_threshold()
         self._refresh_tau()

@@ -61,9 +61,16 @@ def render_forward2(r, o, d, od, dd, ddd, pk, bkgd):
     if n == 0:
         z = torch.zeros(R, f.C, device=dev)
         return z + (bkgd if bkgd is not None else 0.0), z.clone(), z.clone()
+    ri, ts, te = pk.ray_indices, pk.t_starts, pk.t_ends
+    if hasattr(r, "_field_forward_jvp"):                   # arch mlp: value, d/dt, d2/dt2 streams through the dense layers
+        rgb, rgbd, rgbdd, sg, sgd, sgdd = r._field_forward_jvp(o, d, od, dd, pk, ddd=ddd)
+        colors, colords, colorsdd = (torch.empty(R, f.C, device=dev) for _ in range(3))
+        check(lib.ren_composite_fwd_jvp2(_ptr(pk.offsets), _ptr(pk.counts), R, _ptr(ts), _ptr(te), _ptr(sg), _ptr(sgd),
+                                         _ptr(sgdd), _ptr(rgb), _ptr(rgbd), _ptr(rgbdd), f.C, _ptr(bkgd), _ptr(colors),
+                                         _ptr(colords), _ptr(colorsdd), _stream()), "ren_composite_fwd_jvp2")
+        return colors, colords, colorsdd
     nb = ops.n_blocks32(n)
     feat, featd, featdd = (torch.empty(nb * 1024, device=dev) for _ in range(3))
-    ri, ts, te = pk.ray_indices, pk.t_starts, pk.t_ends
     check(lib.ren_hashgrid_fwd_jvp2(ctypes.byref(f.grid), _ptr(f.table), ctypes.byref(r.scene), _ptr(o), _ptr(d),
                                     _ptr(od), _ptr(dd), _ptr(ddd), _ptr(ri), _ptr(ts), _ptr(te), n, _ptr(feat),
                                     _ptr(featd), _ptr(featdd), _stream()), "ren_hashgrid_fwd_jvp2")
@@ -121,6 +128,8 @@ def render_forward(r, o, d, od, dd, jitter, bkgd, training: bool = True):
     ctx = dict(pk=pk, o=o, d=d, od=od, dd=dd, feat=feat, featd=featd, rgb=rgb, rgbd=rgbd, sigma=sigma,
                sigmad=sigmad, base=base, based=based, w=w, T=T, eds=eds, opac=opac, opacd=opacd, bkgd=bkgd,
                empty=False, fctx=fctx)
+    if fctx is not None:
+        ctx["buffers"] = fctx["buffers"]                    # the value-only reverse pass (Renderer.backward) of arch mlp
     return colors, colords, opac, ctx
 
 

@@ -18,7 +18,7 @@ import torch
 
 from . import _lib, ops
 from ._lib import check
-from .engine import RenderCfg, Renderer, contract_points
+from .engine import RenderCfg, Renderer
 from .ops import _ptr, _stream
 
 POS_DIM, VIEW_DIM = 63, 27                      # SinusoidalEncoder(3, 0, 10) / (3, 0, 4), mlp.py:208-243
@@ -225,8 +225,9 @@ class VanillaRenderer(Renderer):
     # Same construction as the NGP path (csrc/ren_mlp_jvp.hip): per layer z = W a + b, zd = W ad; y = sp(z),
     # yd = s zd with s = sp'(z) recovered from the output; backward of (dy, dyd): dz = dy s + dyd zd s', dzd = dyd s,
     # dW += dz^T a + dzd^T ad, da = dz W, dad = dzd W.  Every GEMM is a ren_dense_* launch (value and tangent share the
-    # weights: the tangent stream is a second launch without bias); the activation algebra is elementwise torch on
-    # the same row-major buffers.
+    # weights: the tangent stream is a second launch without bias); the encodings' time derivatives, the activation
+    # algebra and the output heads are HIP kernels on the same row-major buffers (ren_freq_encode_jvp, ren_act_jvp*,
+    # ren_vanilla_heads_jvp / _bwd_jvp).
     def _lin(self, X, ldx, name, Y, ldy, n):
         """Y = X W^T (no bias, no activation): the tangent stream of a layer"""
         f = self.field
@@ -246,103 +247,117 @@ class VanillaRenderer(Renderer):
 
     def _bwd_weight_nobias(self, dZ, ldz, X, ldx, name, n):
         """dW += dZ^T X only (the tangent stream has no bias)"""
-        f = self.field
-        keep = f.gb[name].clone()
-        self._bwd_weight(dZ, ldz, X, ldx, name, n)
-        f.gb[name].copy_(keep)
+        f, lib = self.field, _lib.load()
+        o, i = f.w[name].shape
+        splits = max(1, min(self.n_splits, (n + 31) // 32))
+        need = int(lib.ren_dense_bwd_weight_workspace_floats(o, i, splits))
+        if self._dw_ws is None or self._dw_ws.numel() < need:
+            self._dw_ws = None
+            self._dw_ws = torch.empty(need, device=dZ.device, dtype=torch.float32)
+        check(lib.ren_dense_bwd_weight(_ptr(dZ), ldz, _ptr(X), ldx, o, i, n, splits | (self._dense_mode() << 16), _ptr(f.gw[name]), None,
+                                       _ptr(self._dw_ws), _stream()), "ren_dense_bwd_weight")
 
-    def _encode_tangent(self, B, o, d, od, dd, pk):
-        """d/dt of the position and view encodings for the packed samples -> (encd (n_pad, 64), viewd (n_pad, 32))"""
-        import math
-        c = self.cfg
-        ri = pk.ray_indices.long()
-        tm = ((pk.t_starts + pk.t_ends) * 0.5)[:, None]
-        x, xd = o[ri] + tm * d[ri], od[ri] + tm * dd[ri]
-        _, ud = torch.func.jvp(lambda v: contract_points(v, c.aabb, c.contraction_type), (x,), (xd,))
-        u = contract_points(x, c.aabb, c.contraction_type)
+    def _encode_tangent(self, B, o, d, od, dd, ddd, pk, order, enc, cat, view):
+        """`order`-th time derivative of the position / view encodings of the packed samples (csrc/ren_jvp2.hip):
+        enc (n_pad, 64), copy at cat[:, 256:320], view features at view[:, 256:288]"""
+        if ddd is None:
+            ddd = torch.zeros_like(dd)
+        check(_lib.load().ren_freq_encode_jvp(ctypes.byref(self.scene), _ptr(o), _ptr(d), _ptr(od), _ptr(dd), _ptr(ddd),
+                                              _ptr(pk.ray_indices, torch.int32), _ptr(pk.t_starts), _ptr(pk.t_ends), B.n, order,
+                                              _ptr(enc), 64, _ptr(cat), 320, 256, _ptr(view), 288, 256, _stream()),
+              "ren_freq_encode_jvp")
 
-        def sin_enc_d(p, pd, deg):                                   # layout of csrc/ren_dense.hip:sin_enc
-            sc = 2.0 ** torch.arange(deg, device=p.device, dtype=torch.float32)
-            pb = (p[:, None, :] * sc[None, :, None]).reshape(p.shape[0], -1)          # (n, 3 deg): k-major, then axis
-            pbd = (pd[:, None, :] * sc[None, :, None]).reshape(p.shape[0], -1)
-            return torch.cat([pd, torch.cos(pb) * pbd, torch.cos(pb + 0.5 * math.pi) * pbd], 1)
-        encd = torch.zeros(B.n_pad, 64, device=x.device)
-        encd[: B.n, :63] = sin_enc_d(2 * math.pi * (u - 0.5), 2 * math.pi * ud, 10)
-        viewd = torch.zeros(B.n_pad, 32, device=x.device)
-        viewd[: B.n, :27] = sin_enc_d(d[ri] * math.pi, dd[ri] * math.pi, 4)
-        return encd, viewd
-
-    def _field_forward_jvp(self, o, d, od, dd, pk):
+    def _field_forward_jvp(self, o, d, od, dd, pk, ddd=None):
+        """value + d/dt (+ d2/dt2 when the rays carry `ddd`: second-order tangent, forward only -- d loss / d tau of the
+        log-intensity-gradient loss, engine.Trainer.grad_loss_forward_backward) of (rgb, sigma) for the packed samples.
+        -> rgb, rgbd, sigma, sigmad, T           (first order; T = what _field_backward_jvp needs)
+        -> rgb, rgbd, rgbdd, sigma, sigmad, sigmadd   (second order)"""
         n, C, dev = pk.n, self.field.C, o.device
+        second = ddd is not None
+        lib = _lib.load()
         B = _Buffers(n, dev, C, full=True, backward=False)
         self._encode(B, True, rays=(o, d), samples=(pk.ray_indices, pk.t_starts, pk.t_ends))
         rgb, sigma = self._field_eval(B, True)
         z = lambda ld: torch.empty(B.n_pad, ld, device=dev, dtype=torch.float32)
-        encd, viewd = self._encode_tangent(B, o, d, od, dd, pk)
-        catd = torch.zeros(B.n_pad, 320, device=dev)
-        catd[:, 256:320] = encd
+        encd, catd, rind = z(64), z(320), z(288)
+        self._encode_tangent(B, o, d, od, dd, ddd, pk, 1, encd, catd, rind)
+        if second:
+            encdd, catdd, rindd = z(64), z(320), z(288)
+            self._encode_tangent(B, o, d, od, dd, ddd, pk, 2, encdd, catdd, rindd)
         T = dict(encd=encd, catd=catd, zd={}, yd={})
         Xd, ldx = encd, 64
+        if second:
+            Xdd = encdd
         for i in range(DEPTH):
+            name = f"mlp.base.hidden_layers.{i}"
             Y, ldy = B.out_of(i)
             zd = z(WIDTH)
-            self._lin(Xd, ldx, f"mlp.base.hidden_layers.{i}", zd, WIDTH, n)
+            self._lin(Xd, ldx, name, zd, WIDTH, n)
             yd, ldyd = (catd, 320) if i == SKIP else (z(WIDTH), WIDTH)
-            self._act_fwd(Y, ldy, zd, 100.0, yd, ldyd, WIDTH, B.n_pad)
+            if second:
+                zdd = z(WIDTH)
+                self._lin(Xdd, ldx, name, zdd, WIDTH, n)
+                ydd = catdd if i == SKIP else z(WIDTH)
+                check(lib.ren_act_jvp2_fwd(_ptr(Y), ldy, _ptr(zd), _ptr(zdd), WIDTH, ctypes.c_float(100.0), _ptr(yd), ldyd,
+                                           _ptr(ydd), ldyd, B.n_pad, WIDTH, _stream()), "ren_act_jvp2_fwd")
+                Xdd = ydd
+            else:
+                self._act_fwd(Y, ldy, zd, 100.0, yd, ldyd, WIDTH, B.n_pad)
             T["zd"][i], T["yd"][i] = zd, yd
-            Xd, ldx = (catd, 320) if i == SKIP else (yd, WIDTH)
+            Xd, ldx = yd, ldyd
         h7d = T["yd"][DEPTH - 1]
         s4d = z(4)
         self._lin(h7d, WIDTH, "mlp.sigma_layer.output_layer", s4d, 4, n)
-        dphi = torch.clamp(sigma, max=3269017.3724721107)            # trunc_exp: d/dz clamps at e^15 (ngp.py:45-65)
-        sigmad = dphi * s4d[:n, 0]
-        rind = torch.zeros(B.n_pad, 288, device=dev)
-        rind[:, 256:288] = viewd
         self._lin(h7d, WIDTH, "mlp.bottleneck_layer.output_layer", rind, 288, n)
-        zrd = z(WIDTH_COND)
+        zrd, rd, zod = z(WIDTH_COND), z(WIDTH_COND), z(4)
         self._lin(rind, 288, "mlp.rgb_layer.hidden_layers.0", zrd, WIDTH_COND, n)
-        rd = z(WIDTH_COND)
-        self._act_fwd(B.r, WIDTH_COND, zrd, 100.0, rd, WIDTH_COND, WIDTH_COND, B.n_pad)
-        zod = z(4)
+        s4dd = zodd = rgbdd = sigmadd = None
+        if second:
+            h7dd = Xdd
+            s4dd, zrdd, rdd, zodd = z(4), z(WIDTH_COND), z(WIDTH_COND), z(4)
+            self._lin(h7dd, WIDTH, "mlp.sigma_layer.output_layer", s4dd, 4, n)
+            self._lin(h7dd, WIDTH, "mlp.bottleneck_layer.output_layer", rindd, 288, n)
+            self._lin(rindd, 288, "mlp.rgb_layer.hidden_layers.0", zrdd, WIDTH_COND, n)
+            check(lib.ren_act_jvp2_fwd(_ptr(B.r), WIDTH_COND, _ptr(zrd), _ptr(zrdd), WIDTH_COND, ctypes.c_float(100.0), _ptr(rd),
+                                       WIDTH_COND, _ptr(rdd), WIDTH_COND, B.n_pad, WIDTH_COND, _stream()), "ren_act_jvp2_fwd")
+            self._lin(rdd, WIDTH_COND, "mlp.rgb_layer.output_layer", zodd, 4, n)
+            rgbdd, sigmadd = torch.empty(n, C, device=dev), torch.empty(n, device=dev)
+        else:
+            self._act_fwd(B.r, WIDTH_COND, zrd, 100.0, rd, WIDTH_COND, WIDTH_COND, B.n_pad)
         self._lin(rd, WIDTH_COND, "mlp.rgb_layer.output_layer", zod, 4, n)
-        rgbd = (zod[:n, :C] * (1.0 - torch.exp(-rgb))).contiguous()
-        T.update(rind=rind, zrd=zrd, rd=rd, zod=zod[:n, :C].contiguous(), zsd=s4d[:n, 0].contiguous(), buffers=B)
-        return rgb, rgbd, sigma, sigmad.contiguous(), T
+        rgbd, sigmad = torch.empty(n, C, device=dev), torch.empty(n, device=dev)
+        check(lib.ren_vanilla_heads_jvp(_ptr(rgb), _ptr(sigma), _ptr(zod), _ptr(zodd), _ptr(s4d), _ptr(s4dd), n, C, _ptr(rgbd),
+                                        _ptr(rgbdd), _ptr(sigmad), _ptr(sigmadd), _stream()), "ren_vanilla_heads_jvp")
+        if second:
+            return rgb, rgbd, rgbdd, sigma, sigmad, sigmadd
+        T.update(rind=rind, zrd=zrd, rd=rd, zod=zod, zsd=s4d, buffers=B)
+        return rgb, rgbd, sigma, sigmad, T
 
     def _field_backward_jvp(self, T, pk, rgb, sigma, d_rgb, d_rgbd, d_sig, d_sigd):
         B, n, C = T["buffers"], pk.n, self.field.C
         dev = rgb.device
-        z = lambda ld: torch.zeros(B.n_pad, ld, device=dev, dtype=torch.float32)
-
-        def act_bwd(gy, gyd, Y, Zd, beta):                           # -> (gz, gzd) of y = softplus_beta(z), yd = s zd
-            s = 1.0 - torch.exp(-beta * Y)
-            return gy * s + gyd * Zd * (beta * s * (1.0 - s)), gyd * s
-
-        # output heads
-        gz_o, gzd_o = act_bwd(d_rgb, d_rgbd, rgb, T["zod"], 1.0)
-        dz_rgb, dzd_rgb = z(32), z(32)
-        dz_rgb[:n, :C], dzd_rgb[:n, :C] = gz_o, gzd_o
-        dphi = torch.clamp(sigma, max=3269017.3724721107)
-        d2phi = torch.where(sigma < 3269017.3724721107, sigma, torch.zeros_like(sigma))
-        dz_sig, dzd_sig = z(32), z(32)
-        dz_sig[:n, 0] = d_sig * dphi + d_sigd * T["zsd"] * d2phi
-        dzd_sig[:n, 0] = d_sigd * dphi
+        z = lambda ld: torch.empty(B.n_pad, ld, device=dev, dtype=torch.float32)
+        dz_rgb, dzd_rgb, dz_sig, dzd_sig = z(32), z(32), z(32), z(32)
+        check(_lib.load().ren_vanilla_heads_bwd_jvp(_ptr(d_rgb.contiguous()), _ptr(d_rgbd.contiguous()), _ptr(d_sig.contiguous()),
+                                                    _ptr(d_sigd.contiguous()), _ptr(rgb), _ptr(sigma), _ptr(T["zod"]), _ptr(T["zsd"]),
+                                                    n, C, _ptr(dz_rgb), _ptr(dzd_rgb), _ptr(dz_sig), _ptr(dzd_sig), _stream()),
+              "ren_vanilla_heads_bwd_jvp")
         h7, h7d = B.h[DEPTH - 1], T["yd"][DEPTH - 1]
 
-        def lin_bwd(gz, gzd, ldz, name, X, ldx, Xd, ldxd, n_store):  # dW (+ db from the value stream), -> (gX, gXd)
+        def lin_bwd(gz, gzd, ldz, name, X, ldx, Xd, ldxd, n_store, into=None):
+            """dW (+ db from the value stream) and -> (gX, gXd); `into`: accumulate onto an existing pair"""
             self._bwd_weight(gz, ldz, X, ldx, name, n)
             self._bwd_weight_nobias(gzd, ldz, Xd, ldxd, name, n)
-            gx, gxd = z(n_store), z(n_store)
-            self._bwd_data(gz, ldz, name, n_store, ACT_NONE, None, 0, False, gx, n_store, n)
-            self._bwd_data(gzd, ldz, name, n_store, ACT_NONE, None, 0, False, gxd, n_store, n)
+            gx, gxd = into if into is not None else (z(n_store), z(n_store))
+            self._bwd_data(gz, ldz, name, n_store, ACT_NONE, None, 0, into is not None, gx, n_store, n)
+            self._bwd_data(gzd, ldz, name, n_store, ACT_NONE, None, 0, into is not None, gxd, n_store, n)
             return gx, gxd
 
         gr, grd = lin_bwd(dz_rgb, dzd_rgb, 32, "mlp.rgb_layer.output_layer", B.r, WIDTH_COND, T["rd"], WIDTH_COND, WIDTH_COND)
         gzr, gzrd = self._act_bwd(gr, grd, B.r, WIDTH_COND, T["zrd"], 100.0, WIDTH_COND, B.n_pad)
         gb, gbd = lin_bwd(gzr, gzrd, WIDTH_COND, "mlp.rgb_layer.hidden_layers.0", B.rin, 288, T["rind"], 288, WIDTH)
-        g7, g7d = lin_bwd(gb, gbd, WIDTH, "mlp.bottleneck_layer.output_layer", h7, WIDTH, h7d, WIDTH, WIDTH)
-        gs, gsd = lin_bwd(dz_sig, dzd_sig, 32, "mlp.sigma_layer.output_layer", h7, WIDTH, h7d, WIDTH, WIDTH)
-        gy, gyd = g7 + gs, g7d + gsd
+        gy, gyd = lin_bwd(gb, gbd, WIDTH, "mlp.bottleneck_layer.output_layer", h7, WIDTH, h7d, WIDTH, WIDTH)
+        lin_bwd(dz_sig, dzd_sig, 32, "mlp.sigma_layer.output_layer", h7, WIDTH, h7d, WIDTH, WIDTH, into=(gy, gyd))
         for i in range(DEPTH - 1, -1, -1):
             name = f"mlp.base.hidden_layers.{i}"
             Y, ldy = B.out_of(i)

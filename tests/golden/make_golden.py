@@ -420,8 +420,16 @@ def gen_trajectory(trajectories, nerf_mod):
 E_AABB = [0.5, -2.1, 0.6, 2.0, -0.6, 1.6]                  # configs/train/mocap-desk2.yaml:38-39
 
 
-def gen_training_step(mods, with_grad_loss: bool, config_e: bool = False):
+MLP_CFG = dict(net_depth=8, net_width=256, skip_layer=4, net_depth_condition=1, net_width_condition=128,
+               hidden_activation="softplus", density_activation="shifted_trunc_exp", radiance_activation="softplus",
+               pos_encoder_max_deg=10, view_encoder_max_deg=4, weight_norm=False)      # configs/train/synthetic.yaml:85-96
+
+
+def gen_training_step(mods, with_grad_loss: bool, config_e: bool = False, arch_mlp: bool = False):
     """The reference's real RobustENeRF.training_step over the oracle-backed stubs.
+
+    arch_mlp: `arch: mlp` (VanillaNeRFRadianceField, parameters regenerated from a seed as in gen_field_mlp) with l_diff +
+    l_grad and C_p, tau trainable: the third-order autograd graph of d l_grad / d tau through the vanilla field.
 
     config_e: the settings of configs/train/mocap-desk2.yaml (BASELINE configs[4]): sphere contraction (=> scene_aabb=None,
     rays march near -> far, nerf.py:248-251), cone angle 0.004, near / far planes, no background parameter
@@ -429,7 +437,7 @@ def gen_training_step(mods, with_grad_loss: bool, config_e: bool = False):
     inside the step (global_step 16) with the cone-angle step sizes of nerf.py:175-193."""
     rmod, nerf_mod, trajectories, egp, loss_mod, nerfacc = mods
     JITTER_LOG.clear()
-    torch.manual_seed(50 + int(with_grad_loss) + 7 * int(config_e))
+    torch.manual_seed(50 + int(with_grad_loss) + 7 * int(config_e) + 13 * int(arch_mlp))
     ts_tab, pos, quat = orbit_poses()
     if config_e:                                            # orbit inside the room, around the centre of the AABB
         centre = np.array([1.25, -1.35, 1.1], np.float32)
@@ -461,6 +469,13 @@ def gen_training_step(mods, with_grad_loss: bool, config_e: bool = False):
     if config_e:
         m.nerf = nerf_mod.NeRF(E_AABB, nerfacc.ContractionType.UN_BOUNDED_SPHERE, occ_cfg, 0.05, 3.0, step,
                                None, 0.004, 1e-4, 0.0, 16384, "ngp", EasyDict(NGP_CFG), 3, 1)
+    elif arch_mlp:
+        from oracle import vanilla
+        m.nerf = nerf_mod.NeRF([-1.5] * 3 + [1.5] * 3, nerfacc.ContractionType.AABB, occ_cfg, None, None, step,
+                               "parameter", 0.0, 1e-4, 0.0, 16384, "mlp", EasyDict(MLP_CFG), 3, 1)
+        m.nerf.occupancy_grid._binary = ball_binary(occ_res)
+        sd = m.nerf.radiance_field.state_dict()
+        m.nerf.radiance_field.load_state_dict({**sd, **vanilla.init_params(23, C=1, gain=1.6)})
     else:
         m.nerf = nerf_mod.NeRF([-1.5] * 3 + [1.5] * 3, nerfacc.ContractionType.AABB, occ_cfg, None, None, step,
                                "parameter", 0.0, 1e-4, 0.0, 16384, "ngp", EasyDict(NGP_CFG), 3, 1)
@@ -494,6 +509,27 @@ def gen_training_step(mods, with_grad_loss: bool, config_e: bool = False):
     loss.backward()
     named = dict(m.named_parameters())
     rf = m.nerf.radiance_field
+    if arch_mlp:
+        grads = {}
+        for k, v in rf.named_parameters():
+            g = v.grad.reshape(-1)
+            pick = torch.linspace(0, g.numel() - 1, min(64, g.numel())).long()
+            grads["gi." + k], grads["gv." + k], grads["gs." + k] = pick, g[pick], g.double().abs().sum()
+        save("training_step_mlp", param_seed=23, param_gain=1.6, occ_res=occ_res,
+             binary=np.packbits(m.nerf.occupancy_grid._binary.numpy().reshape(-1)),
+             tab_ts=ts_tab, tab_pos=pos, tab_quat=quat, Kinv=m.train_intrinsics_inv,
+             position=px, start_ts=start, end_ts=end, num_pos=npos, num_neg=nneg,
+             u_ts_diff=u1, u_diff_start=u2, u_grad=u3, jitters=torch.stack(JITTER_LOG), render_step_size=step,
+             p2n_raw=named["contrast_threshold.parametrizations.p2n_contrast_threshold_ratio.original"],
+             neg_ct=m.contrast_threshold.neg_contrast_threshold,
+             tau_raw=named["refractory_period.parametrizations._refractory_period.original"],
+             tau_max=m.refractory_period.max_refractory_period,
+             bkgd_raw=named["nerf.parametrizations.render_bkgd.original"], loss=loss, w_grad=w_grad,
+             logged_keys=np.array(sorted(logged)), logged_vals=np.array([logged[k] for k in sorted(logged)]),
+             g_bkgd_raw=named["nerf.parametrizations.render_bkgd.original"].grad,
+             g_p2n_raw=named["contrast_threshold.parametrizations.p2n_contrast_threshold_ratio.original"].grad,
+             g_tau_raw=named["refractory_period.parametrizations._refractory_period.original"].grad, **grads)
+        return
     gmap = {"base.w0": "mlp_base.1.hidden_layers.0.weight", "base.b0": "mlp_base.1.hidden_layers.0.bias",
             "base.wo": "mlp_base.1.output_layer.weight", "base.bo": "mlp_base.1.output_layer.bias",
             "head.w0": "mlp_head.hidden_layers.0.weight", "head.b0": "mlp_head.hidden_layers.0.bias",
@@ -679,6 +715,7 @@ def main():
     gen_training_step(mods, with_grad_loss=False)
     gen_training_step(mods, with_grad_loss=True)
     gen_training_step(mods, with_grad_loss=True, config_e=True)
+    gen_training_step(mods, with_grad_loss=True, arch_mlp=True)
     from robust_e_nerf.data import datasets as datasets_mod, samplers as samplers_mod
     gen_dataset(datasets_mod, samplers_mod)
     gen_batch_size(rmod)

@@ -242,3 +242,82 @@ def test_vanilla_field_tangent_and_its_backward_vs_float64_autograd(amd, ct):
     ref = dict(zip(p64.keys(), grads))
     for k, v in r.field.state_dict(grad=True).items():
         assert rel_err(v.cpu(), ref[k]) < 3e-3, k
+
+
+@pytest.mark.parametrize("ct", ["aabb", "sphere"])
+def test_vanilla_field_second_order_tangent_vs_float64(amd, ct):
+    """value, d/dt and d2/dt2 of (rgb, sigma) along x(t) = x0 + t xd + t^2/2 xdd, dir(t) likewise (the forward-only
+    second-order stream behind d l_grad / d tau) vs nested float64 Jacobian-vector products through the oracle field."""
+    from oracle import vanilla as ovan
+    ops, engine, vanilla = amd
+    g = load_golden(f"field_mlp_{ct}")
+    r, p = _field(vanilla, engine, g)
+    gen = torch.Generator().manual_seed(13)
+    R = 257
+    o = (torch.rand(R, 3, generator=gen) - 0.5) * 1.0
+    d = torch.randn(R, 3, generator=gen); d = d / d.norm(dim=-1, keepdim=True)
+    od, dd, ddd = (torch.randn(R, 3, generator=gen) * 0.3 for _ in range(3))
+    tm = torch.rand(R, generator=gen) * 1.2
+    pk = engine.Packed(ray_indices=torch.arange(R, dtype=torch.int32, device=DEV), t_starts=(tm - 0.01).to(DEV),
+                       t_ends=(tm + 0.01).to(DEV), offsets=torch.arange(R, device=DEV), counts=torch.ones(R, dtype=torch.int32, device=DEV),
+                       n=R)
+    dev = lambda v: v.to(DEV).contiguous()
+    rgb, rgbd, rgbdd, sigma, sigmad, sigmadd = r._field_forward_jvp(dev(o), dev(d), dev(od), dev(dd), pk, ddd=dev(ddd))
+    rgb1, rgbd1, sigma1, sigmad1, _ = r._field_forward_jvp(dev(o), dev(d), dev(od), dev(dd), pk)
+    assert torch.equal(rgbd, rgbd1) and torch.equal(sigmad, sigmad1) and torch.equal(rgb, rgb1)   # same first-order stream
+    p64 = {k: v.double() for k, v in p.items()}
+    aabb = torch.tensor([float(v) for v in g["aabb"]], dtype=torch.float64)
+    tm64 = ((tm - 0.01).float() + (tm + 0.01).float()).double()[:, None] * 0.5
+    x0, xd, xdd = o.double() + tm64 * d.double(), od.double() + tm64 * dd.double(), tm64 * ddd.double()   # o'' = 0
+
+    def f(tt):
+        rgb_, sig_ = ovan.forward(p64, x0 + tt * xd + 0.5 * tt * tt * xdd, d.double() + tt * dd.double() + 0.5 * tt * tt * ddd.double(),
+                                  aabb, int(g["contraction_type"]))
+        return torch.cat([rgb_, sig_], 1)
+    zero, one = torch.zeros((), dtype=torch.float64), torch.ones((), dtype=torch.float64)
+    first = lambda tt: torch.autograd.functional.jvp(f, tt, one, create_graph=True)[1]    # (double-backward trick, nested)
+    d1, d2 = torch.autograd.functional.jvp(first, zero, one)
+    assert rel_err(rgbd.cpu(), d1[:, :1]) < 5e-4 and rel_err(sigmad.cpu(), d1[:, 1]) < 5e-4
+    # second derivatives carry the square of the 2^9 x 2 pi frequency band's amplification of float32 round-off
+    assert rel_err(rgbdd.cpu(), d2[:, :1]) < 5e-3, "d2 rgb / dt2"
+    assert rel_err(sigmadd.cpu(), d2[:, 1]) < 5e-3, "d2 sigma / dt2"
+
+
+def test_vanilla_grad_loss_step_with_trainable_tau_vs_reference_golden(amd):
+    """`arch: mlp`, l_diff + l_grad, C_p and tau trainable: loss, field / background / C_p gradients and d loss / d tau
+    (which needs the second-order tangent through the vanilla field) vs the REFERENCE's own training_step
+    (tests/golden/training_step_mlp.npz: its third-order autograd graph)."""
+    from oracle import vanilla as ovan
+    ops, engine, vanilla = amd
+    g = load_golden("training_step_mlp")
+    occ_res = int(g["occ_res"])
+    cfg = engine.RenderCfg(occ_res=(occ_res,) * 3, render_step_size=float(g["render_step_size"]), sampler="occgrid")
+    fld = vanilla.VanillaField(DEV, 1)
+    fld.load(ovan.init_params(int(g["param_seed"]), 1, float(g["param_gain"])))
+    r = vanilla.VanillaRenderer(fld, cfg)
+    r.binary.copy_(torch.from_numpy(np.unpackbits(g["binary"])[: occ_res ** 3].astype(np.uint8)).to(DEV))
+    tr = engine.Trainer(r, engine.TrainCfg(), Kinv=t(g["Kinv"]), tab_ts=t(g["tab_ts"]), tab_pos=t(g["tab_pos"]),
+                        tab_quat=t(g["tab_quat"]), p2n_raw=t(g["p2n_raw"]), neg_ct=t(g["neg_ct"]),
+                        tau_raw=t(g["tau_raw"]), tau_max=t(g["tau_max"]), bkgd_raw=t(g["bkgd_raw"]))
+    dv = lambda v: torch.as_tensor(v).to(DEV)
+    batch = {k: dv(g[k]) for k in ("position", "start_ts", "end_ts", "num_pos", "num_neg", "u_ts_diff", "u_diff_start", "u_grad")}
+    tr.t.w_grad, tr.t.err_grad, tr.t.pw_grad = float(g["w_grad"]), "mape", None
+    tr.t.train_contrast_threshold = tr.t.train_refractory_period = True
+    jit = t(g["jitters"])
+    loss_d, _ = tr.forward_backward(batch, dv(jit[1]), dv(jit[2]))
+    loss_g, _ = tr.grad_loss_forward_backward(batch, dv(jit[0]))
+    loss = float(loss_d) + float(loss_g)
+    assert abs(loss - float(g["loss"])) < 1e-4 * abs(float(g["loss"])), (loss, float(g["loss"]))
+    for k, v in fld.state_dict(grad=True).items():
+        got = v.reshape(-1).cpu()
+        assert rel_err(got[t(g["gi." + k]).long()], g["gv." + k]) < 5e-3, k
+        assert abs(float(got.double().abs().sum()) - float(g["gs." + k])) < 5e-3 * float(g["gs." + k]), k
+    assert rel_err(tr.small_grad[:1].cpu(), g["g_bkgd_raw"]) < 2e-3
+    assert rel_err(tr.ct_grad[:1].cpu(), g["g_p2n_raw"]) < 1e-3, "d loss / d (C_p/C_n ratio parameter)"
+    sg = torch.sigmoid(tr.tau_raw.detach() / tr.tau_max)
+    got = tr.tau_grad * sg * (1 - sg)
+    ref = torch.as_tensor(g["g_tau_raw"]).double()
+    print("d loss/d tau_raw: got", float(got), "ref", float(ref))
+    assert rel_err(got, ref) < 1e-2, (float(got), float(ref))
+    tr.optimizer_step()
+    assert float(tr.tau_grad) == 0.0
