@@ -45,10 +45,18 @@ def render_rays(o, d, p: Dict[str, torch.Tensor], spec, cfg: SceneCfg, *,
     def positions(ts, te, ri):
         return o[ri] + d[ri] * (ts + te) / 2.0             # external/utils.py:68-72
 
+    arch_mlp = "mlp.base.hidden_layers.0.weight" in p       # `arch: mlp` parameters (oracle/vanilla.py; nerf.py:143-160)
+
     def sigma_fn(ts, te, ri):
+        if arch_mlp:
+            from . import vanilla
+            return vanilla.forward(p, positions(ts, te, ri), None, aabb, cfg.contraction_type, density_only=True)
         return field.query_density(positions(ts, te, ri), p, spec, aabb, cfg.contraction_type)
 
     def rgb_sigma_fn(ts, te, ri):
+        if arch_mlp:
+            from . import vanilla
+            return vanilla.forward(p, positions(ts, te, ri), d[ri], aabb, cfg.contraction_type)
         return field.field_forward(positions(ts, te, ri), d[ri], p, spec, aabb, cfg.contraction_type)
 
     scene_aabb = aabb if cfg.contraction_type == field.AABB else None   # nerf.py:248-251

@@ -77,8 +77,8 @@ def test_field_forward_backward(ct, full_table_cache):
     assert abs(float(table.grad.double().abs().sum()) - float(g["g_table_abs"])) < 1e-4 * float(g["g_table_abs"])
 
 
-def _run_training_step(g, table, with_grad, config_e=False):
-    p = field_params_from(g, table)
+def _run_training_step(g, table, with_grad, config_e=False, params=None):
+    p = params if params is not None else field_params_from(g, table)
     for v in p.values():
         v.requires_grad_()
     occ_res = int(g["occ_res"])
@@ -138,6 +138,24 @@ def test_training_step_grad(full_table_cache):
         assert rel_err(p[k].grad, g["g." + k]) < 5e-4, k
     assert rel_err(bkgd_raw.grad, g["g_bkgd_raw"]) < 1e-4
     assert rel_err(p["hash"].grad[t(g["g_table_idx"])], g["g_table_val"]) < 5e-4
+    assert rel_err(aux["leaves"]["p2n_raw"].grad, g["g_p2n_raw"]) < 1e-4
+    assert rel_err(aux["leaves"]["tau_raw"].grad, g["g_tau_raw"]) < 1e-3
+
+
+def test_training_step_arch_mlp():
+    """The reference's training_step with `arch: mlp` (VanillaNeRFRadianceField), l_diff + l_grad, C_p and tau trainable,
+    through the oracle's restatement of the vanilla field: loss, all 24 parameter gradients, C_p and tau gradients."""
+    from oracle import vanilla
+    g = load_golden("training_step_mlp")
+    params = vanilla.init_params(int(g["param_seed"]), 1, float(g["param_gain"]))
+    loss, aux, p, bkgd_raw = _run_training_step(g, None, True, params=params)
+    assert rel_err(loss, g["loss"]) < 1e-5
+    loss.backward()
+    for k, v in p.items():
+        got = v.grad.reshape(-1)
+        assert rel_err(got[t(g["gi." + k]).long()], g["gv." + k]) < 5e-4, k
+        assert abs(float(got.double().abs().sum()) - float(g["gs." + k])) < 5e-4 * float(g["gs." + k]), k
+    assert rel_err(bkgd_raw.grad, g["g_bkgd_raw"]) < 1e-4
     assert rel_err(aux["leaves"]["p2n_raw"].grad, g["g_p2n_raw"]) < 1e-4
     assert rel_err(aux["leaves"]["tau_raw"].grad, g["g_tau_raw"]) < 1e-3
 
