@@ -206,11 +206,20 @@ def main():
     selftest = os.environ.get("REN_BENCH_DIST", "") == "gloo:shared-gpu"
     if selftest:
         local_rank = 0
-    if world > 1:
+    # REN_BENCH_DIST=nccl:single-rank: ONE rank with an RCCL process group whose trainer takes the data-parallel code path
+    # (early fine-level slice, packed aux block, asynchronous all-reduces on RCCL's stream); a smoke test of the RCCL
+    # calls on a 1-GPU box -- the reductions are identities, the Adam scale is that of two ranks.
+    rccl_single = os.environ.get("REN_BENCH_DIST", "") == "nccl:single-rank"
+    dp_world = 2 if rccl_single else world
+    if world > 1 or rccl_single:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29519")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="gloo" if selftest else "nccl")
+        if rccl_single:
+            dist.init_process_group(backend="nccl", rank=0, world_size=1)
+        else:
+            dist.init_process_group(backend="gloo" if selftest else "nccl")
     dev = f"cuda:{local_rank}"
     torch.cuda.set_device(local_rank)
 
@@ -281,7 +290,7 @@ def main():
         tau0 = torch.tensor(1e5 * float(torch.logit(torch.tensor(0.999, dtype=torch.float64))), dtype=torch.float64)
     tr = engine.Trainer(r, tcfg, Kinv=T(Kinv), tab_ts=T(tab_ts), tab_pos=T(tab_pos), tab_quat=T(tab_quat),
                         p2n_raw=p2n0, neg_ct=torch.tensor(0.25), tau_raw=tau0, tau_max=torch.tensor(1e5),
-                        bkgd_raw=torch.tensor([0.5413]), world_size=world, process_group=pg)
+                        bkgd_raw=torch.tensor([0.5413]), world_size=dp_world, process_group=pg)
 
     B = args.events if args.scaling == "weak" else max(1, args.events // world)
     n_batches = 4                                    # pre-staged in HBM; per-rank seeds (datamodule.py:85-89)
@@ -392,7 +401,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, scene, {k: v.clone() for k, v in p.items()}, 0)
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or rccl_single:
         dist.destroy_process_group()
 
 

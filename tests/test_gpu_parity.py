@@ -1545,3 +1545,17 @@ def test_bench_n_rank_contract_selftest():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["config"]["parallelism"] == "dp2"
     assert d["value"] > 0 and "cpu_baseline" not in d and "roofline" in d
+
+
+def test_bench_data_parallel_step_over_rccl_single_rank():
+    """The data-parallel step (level-split backward, early slice, packed aux, asynchronous all-reduces) with the collectives
+    going through RCCL itself: one rank, so every reduction is an identity -- this checks the RCCL calls and stream
+    ordering on real hardware, which the gloo tests cannot (the multi-GPU run is the driver's)."""
+    import json, os, subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, REN_BENCH_DIST="nccl:single-rank", MASTER_ADDR="127.0.0.1", MASTER_PORT="29521")
+    out = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--steps", "3", "--warmup", "1", "--events", "4096",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env, cwd=repo)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["config"]["collectives_per_step"] == 3 and d["value"] > 0 and d["loss"] == d["loss"]
