@@ -145,6 +145,11 @@ def cpu_baseline(args, scene, params_cpu, table_seed):
 
 
 def main():
+    # stdout carries exactly ONE line, the JSON result: native libraries that write to file descriptor 1 (RCCL prints a version
+    # banner there when its process group goes away) are sent to stderr for the life of the process
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -318,6 +323,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if tr.sync is not None:
+        # RCCL sets up its channels / buffers lazily on the first collectives of each size class: do that here, not in the
+        # driver's (possibly short) warm-up, with the step's own call pattern on the real gradient buffer (all zeros)
+        f_ = r.field
+        for _ in range(2):
+            tr.sync.early(f_.grad_all, f_.grad_all.numel() // 3, 2 * (f_.grad_all.numel() // 3))
+            tr.sync.finish(f_.grad_all)
+        tr.sync.reset_count()
+        torch.cuda.synchronize()
     log("setup done")
     for i in range(args.warmup):
         one_step(i)
@@ -400,7 +414,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, scene, {k: v.clone() for k, v in p.items()}, 0)
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1 or rccl_single:
         dist.destroy_process_group()
 
