@@ -640,7 +640,9 @@ class Trainer:
             hi = self._tau_grad_dev.to(torch.float32)
             aux[P_.AUX_TAU_HI] = hi[0]
             aux[P_.AUX_TAU_LO] = (self._tau_grad_dev - hi.double()).to(torch.float32)[0]
-            aux[P_.AUX_MEAN_S] = float(mean_samples_per_ray) if mean_samples_per_ray is not None else 0.0
+            # (fill_, not `aux[i] = python scalar`: that is a host-to-device copy which drains the whole queue on ROCm --
+            # tools/sync_probe.py -- and cost the data-parallel step its launch lead)
+            aux.narrow(0, P_.AUX_MEAN_S, 1).fill_(float(mean_samples_per_ray) if mean_samples_per_ray is not None else 0.0)
             self.sync.finish(f.grad_all)
             self.small_grad.copy_(aux[P_.AUX_SMALL: P_.AUX_SMALL + 4])
             self.ct_grad[0] = aux[P_.AUX_CT]
