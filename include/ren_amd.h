@@ -453,6 +453,15 @@ int ren_mlp_fwd_jvp2(const float *mlp_params, int32_t C, const float *feat, cons
                      const int32_t *ray_indices, const float *t_starts, const float *t_ends, int64_t n,
                      float *rgb, float *rgbd, float *rgbdd, float *sigma, float *sigmad, float *sigmadd,
                      void *stream);
+/* ren_mlp_fwd_jvp2 on the bf16 matrix cores (csrc/ren_jvp2.hip: mlp_fwd_jvp2_x_kernel); mode 6: split-bf16 at fp32
+ * accuracy, mode 1: plain bf16 operands -- the second-order render of a step follows the precision mode of its other
+ * MLP kernels (RenderCfg.mlp_kernels = "x") */
+int ren_mlp_fwd_jvp2_x(const float *mlp_params, int32_t C, int32_t mode, const float *feat, const float *featd,
+                       const float *featdd, const ren_scene_desc *scene, const float *rays_o, const float *rays_d,
+                       const float *rays_do, const float *rays_dd, const float *rays_ddd,
+                       const int32_t *ray_indices, const float *t_starts, const float *t_ends, int64_t n,
+                       float *rgb, float *rgbd, float *rgbdd, float *sigma, float *sigmad, float *sigmadd,
+                       void *stream);
 int ren_composite_fwd_jvp2(const int64_t *offsets, const int32_t *counts, int64_t n_rays, const float *t_starts,
                            const float *t_ends, const float *sigmas, const float *sigmads, const float *sigmadds,
                            const float *rgbs, const float *rgbds, const float *rgbdds, int32_t C,

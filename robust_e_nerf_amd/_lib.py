@@ -99,6 +99,8 @@ SIGNATURES = {
     "ren_raygen_jvp2": (c_int, [P, P, P, P, P, P, P, c_int64, P, P, P, P, P, P]),
     "ren_hashgrid_fwd_jvp2": (c_int, [POINTER(GridDesc), P, POINTER(SceneDesc), P, P, P, P, P, P, P, P, c_int64, P, P, P, P]),
     "ren_mlp_fwd_jvp2": (c_int, [P, c_int32, P, P, P, POINTER(SceneDesc), P, P, P, P, P, P, P, P, c_int64, P, P, P, P, P, P, P]),
+    "ren_mlp_fwd_jvp2_x": (c_int, [P, c_int32, c_int32, P, P, P, POINTER(SceneDesc), P, P, P, P, P, P, P, P, c_int64, P, P, P, P, P, P,
+                                   P]),
     "ren_composite_fwd_jvp2": (c_int, [P, P, c_int64, P, P, P, P, P, P, P, P, c_int32, P, P, P, P, P]),
     "ren_freq_encode": (c_int, [POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, P, c_int32, P, c_int32, c_int32, P,
                                 c_int32, c_int32, P, P]),

@@ -11,7 +11,7 @@ SOURCES = ["ren_api.hip", "ren_pose.hip", "ren_sampling.hip", "ren_composite.hip
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
           "-Wno-unused-result"]
 # the sampler must match the sequential oracle bit for bit: no FMA contraction there
-PER_FILE = {"ren_sampling.hip": ["-ffp-contract=off"]}
+PER_FILE = {"ren_sampling.hip": ["-ffp-contract=off"], "ren_jvp2.hip": ["-fno-slp-vectorize"]}
 
 
 def _stale(target, deps):

@@ -6,7 +6,7 @@
 // gets it as a third-order autograd graph).  Everything is pointwise in t, sample placement is held
 // fixed (external/vol_rendering.py:36-37) and cell/contraction branch boundaries are not differentiated,
 // exactly like autograd.  Second-order truncated Taylor arithmetic (T2) carries (v, v', v'').
-#include "ren_mlp_common.h"
+#include "ren_mlp_xfrag.h"
 #include "ren_hashgrid_common.h"
 
 namespace {
@@ -395,6 +395,218 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_jvp2_kernel(Fwd2Args a) {
     }
 }
 
+// ---- the same forward on the bf16 matrix cores (MODE 6: split-bf16 at fp32 accuracy, MODE 1: plain bf16 operands) ----------
+// Value, first and second tangent share every weight-fragment read (one ds_read_b128, three MFMAs with independent
+// accumulators); activations are split into bf16 pieces one 8-wide k-chunk at a time, so only one chunk of operand
+// pieces of the three streams is live.  Fragment layouts and the LDS image are those of csrc/ren_mlp_jvp_x.hip.
+template <int NT> struct XL2 {
+    static constexpr int F_W1 = 0;                              // 2 tiles x 2 chunks
+    static constexpr int F_W2 = F_W1 + 2 * 2 * NT * 512;        // 1 x 4
+    static constexpr int F_WH1 = F_W2 + 1 * 4 * NT * 512;       // 2 x 2
+    static constexpr int F_WH2 = F_WH1 + 2 * 2 * NT * 512;      // 2 x 4
+    static constexpr int F_END = F_WH2 + 2 * 4 * NT * 512;      // bf16 elements
+    static constexpr int BYTES_F = F_END * 2;
+    static constexpr int T_B1 = 0, T_B2 = 64, T_BH1 = 96, T_BH2 = 160, T_WH3 = 224, T_BH3 = 416, T_END = 420;
+    static constexpr size_t BYTES = (size_t)BYTES_F + T_END * 4;
+};
+
+template <int MODE, int TILES>
+__device__ __forceinline__ void mma_j3(f32x16 *a, f32x16 *d, f32x16 *e, const __bf16 *frag, int chunks, int c,
+                                       const bf16x8 (&b)[3], const bf16x8 (&bd)[3], const bf16x8 (&be)[3], int lane) {
+    using PR = Pairs<MODE>;
+#pragma unroll
+    for (int k = 0; k < PR::N; ++k)
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) {
+            const bf16x8 w = ldfrag<PR::NT>(frag, t, chunks, c, PR::W[k], lane);
+            a[t] = MFMAB(w, b[PR::A[k]], a[t]);
+            d[t] = MFMAB(w, bd[PR::A[k]], d[t]);
+            e[t] = MFMAB(w, be[PR::A[k]], e[t]);
+        }
+}
+
+// k-chunk c (8 inputs per lane) of an activated 64-wide layer held as two accumulator tiles -> bf16 operand pieces
+template <int NT>
+__device__ __forceinline__ void chunk_pieces(const f32x16 (&y)[2], int c, bf16x8 (&b)[3]) {
+    float v[8];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) v[g] = y[c >> 1][8 * (c & 1) + g];
+    split8<NT>(v, b);
+}
+
+template <int C, int MODE>
+__global__ __launch_bounds__(256, 2) void mlp_fwd_jvp2_x_kernel(Fwd2Args a) {
+    using PR = Pairs<MODE>;
+    constexpr int NT = PR::NT;
+    using L = XL2<NT>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
+    __bf16 *frag = reinterpret_cast<__bf16 *>(smem2);
+    float *tail = reinterpret_cast<float *>(smem2 + L::BYTES_F);
+    fill_frags<NT, 0>(frag + L::F_W1, a.params, 2, 2);
+    fill_frags<NT, 1>(frag + L::F_W2, a.params, 1, 4);
+    fill_frags<NT, 2>(frag + L::F_WH1, a.params, 2, 2);
+    fill_frags<NT, 3>(frag + L::F_WH2, a.params, 2, 4);
+    for (int i = threadIdx.x; i < 64; i += blockDim.x) {
+        tail[L::T_B1 + i] = a.params[P_BB0 + i];
+        tail[L::T_BH1 + i] = a.params[P_HB0 + i];
+        tail[L::T_BH2 + i] = a.params[P_HB1 + i];
+        if (i < 32) tail[L::T_B2 + i] = i < 16 ? a.params[P_BBO + i] : 0.f;
+    }
+    for (int i = threadIdx.x; i < 64 * C; i += blockDim.x) tail[L::T_WH3 + i] = a.params[P_HWO + i];
+    if (threadIdx.x < C) tail[L::T_BH3 + threadIdx.x] = a.params[P_HWO + 64 * C + threadIdx.x];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hi = lane >> 5, sl = lane & 31;
+    const int64_t n_blk = (a.n + 31) >> 5;
+    for (int64_t blk = (int64_t)blockIdx.x * 4 + wave; blk < n_blk; blk += (int64_t)gridDim.x * 4) {
+        int zo = 0;                                             // keep the (loop-invariant) LDS reads inside the loop
+        asm volatile("" : "+v"(zo));
+        const __bf16 *fr = frag + zo;
+        const float *tl = tail + zo;
+        const int64_t i = blk * 32 + sl;
+        const bool live = i < a.n;
+        // ---- base layer 0 on the hash features and their two tangents
+        f32x16 h[2], hd[2], he[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) { h[t][g] = tl[L::T_B1 + 32 * t + rowc(g) + 4 * hi]; hd[t][g] = 0.f; he[t][g] = 0.f; }
+        {
+            const int64_t fo = blk * (16 * 64) + lane;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                float x[8], xd[8], xe[8];
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    x[s] = a.feat[fo + (8 * c + s) * 64]; xd[s] = a.featd[fo + (8 * c + s) * 64]; xe[s] = a.featdd[fo + (8 * c + s) * 64];
+                }
+                bf16x8 b[3], bd[3], be[3];
+                split8<NT>(x, b); split8<NT>(xd, bd); split8<NT>(xe, be);
+                mma_j3<MODE, 2>(h, hd, he, fr + L::F_W1, 2, c, b, bd, be, lane);
+            }
+        }
+        // Compiler barrier before every activation of this kernel: without it hipcc (ROCm 7.2) interleaves the activation's
+        // VALU code with the tail of the MFMA group and the FIRST launch of the mode-6 kernel in a process returns wrong
+        // second tangents (the stream whose MFMA issues last) for one or two half-blocks of 16 samples -- reproducible in
+        // nine of ten fresh processes, never on a repeat launch, gone with the barrier (tools/jvp2_first_launch.py,
+        // test_second_order_mlp_forward_matrix_core_kernel_vs_f32_kernel).
+        asm volatile("" ::: "memory");
+        act2(h, hd, he);
+        // ---- base output: 64 -> 16 (rows 16..31 of the tile are zero)
+        f32x16 o, od, oe;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) { o[g] = tl[L::T_B2 + rowc(g) + 4 * hi]; od[g] = 0.f; oe[g] = 0.f; }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            bf16x8 b[3], bd[3], be[3];
+            chunk_pieces<NT>(h, c, b); chunk_pieces<NT>(hd, c, bd); chunk_pieces<NT>(he, c, be);
+            mma_j3<MODE, 1>(&o, &od, &oe, fr + L::F_W2, 4, c, b, bd, be, lane);
+        }
+        bool sel = false;
+        T2 dir[3] = {t2(0.f), t2(0.f), t2(1.f)};
+        if (live) {
+            T2 u[3]; int ray;
+            unit_pos2(a.ray, a.sc, i, u, ray);
+            sel = u[0].v > 0.f && u[0].v < 1.f && u[1].v > 0.f && u[1].v < 1.f && u[2].v > 0.f && u[2].v < 1.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int64_t j = 3 * (int64_t)ray + k;
+                dir[k] = t2(a.ray.d[j], a.ray.dd[j], a.ray.ddd[j]);
+            }
+        }
+        if (live && hi == 0) {
+            // trunc_exp (ngp.py:45-65): value exp(x), derivative exp(min(x, 15))
+            const float xr = o[0] - 1.f, ec = __expf(fminf(xr, 15.f));
+            a.sigma[i] = sel ? __expf(xr) : 0.f;
+            a.sigmad[i] = sel ? ec * od[0] : 0.f;
+            a.sigmadd[i] = sel ? ec * (oe[0] + (xr < 15.f ? od[0] * od[0] : 0.f)) : 0.f;
+        }
+        // ---- head layer 0: [base_out(16) | SH(16)] -> 64
+        f32x16 p[2], pd[2], pe[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) { p[t][g] = tl[L::T_BH1 + 32 * t + rowc(g) + 4 * hi]; pd[t][g] = 0.f; pe[t][g] = 0.f; }
+        {
+            T2 shs[8];
+            sh4_t2_select(dir[0], dir[1], dir[2], hi, shs);
+            float v[8], vd[8], ve[8];
+            bf16x8 b[3], bd[3], be[3];
+#pragma unroll
+            for (int g = 0; g < 8; ++g) { v[g] = o[g]; vd[g] = od[g]; ve[g] = oe[g]; }
+            split8<NT>(v, b); split8<NT>(vd, bd); split8<NT>(ve, be);
+            mma_j3<MODE, 2>(p, pd, pe, fr + L::F_WH1, 2, 0, b, bd, be, lane);
+#pragma unroll
+            for (int g = 0; g < 8; ++g) { v[g] = shs[g].v; vd[g] = shs[g].d; ve[g] = shs[g].e; }
+            split8<NT>(v, b); split8<NT>(vd, bd); split8<NT>(ve, be);
+            mma_j3<MODE, 2>(p, pd, pe, fr + L::F_WH1, 2, 1, b, bd, be, lane);
+        }
+        asm volatile("" ::: "memory");
+        act2(p, pd, pe);
+        // ---- head layer 1: 64 -> 64
+        f32x16 q[2], qd[2], qe[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) { q[t][g] = tl[L::T_BH2 + 32 * t + rowc(g) + 4 * hi]; qd[t][g] = 0.f; qe[t][g] = 0.f; }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            bf16x8 b[3], bd[3], be[3];
+            chunk_pieces<NT>(p, c, b); chunk_pieces<NT>(pd, c, bd); chunk_pieces<NT>(pe, c, be);
+            mma_j3<MODE, 2>(q, qd, qe, fr + L::F_WH2, 4, c, b, bd, be, lane);
+        }
+        asm volatile("" ::: "memory");
+        act2(q, qd, qe);
+        // ---- head output: 64 -> C on the VALU in fp32 (MODE 1: bf16-rounded operands, as every other layer)
+        float acc[C], accd[C], acce[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) { acc[c] = 0.f; accd[c] = 0.f; acce[c] = 0.f; }
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const float qa = MODE == 1 ? (float)(__bf16)q[r][g] : q[r][g];
+                const float qb = MODE == 1 ? (float)(__bf16)qd[r][g] : qd[r][g];
+                const float qc = MODE == 1 ? (float)(__bf16)qe[r][g] : qe[r][g];
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    float w3 = tl[L::T_WH3 + c * 64 + 32 * r + rowc(g) + 4 * hi];
+                    if (MODE == 1) w3 = (float)(__bf16)w3;
+                    acc[c] += qa * w3; accd[c] += qb * w3; acce[c] += qc * w3;
+                }
+            }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float z3 = acc[c] + __shfl_xor(acc[c], 32, 64) + tl[L::T_BH3 + c];
+            const float z3d = accd[c] + __shfl_xor(accd[c], 32, 64);
+            const float z3e = acce[c] + __shfl_xor(acce[c], 32, 64);
+            if (hi == 0 && live) {
+                const float y = softplus1(z3), s = dsoftplus_from_out(y, 1.f);
+                a.rgb[i * C + c] = y;
+                a.rgbd[i * C + c] = s * z3d;
+                a.rgbdd[i * C + c] = s * z3e + (1.f - s) * s * z3d * z3d;
+            }
+        }
+    }
+}
+
+template <int MODE>
+int launch_fwd_jvp2_x(const Fwd2Args &a, int C, hipStream_t st) {
+    using L = XL2<Pairs<MODE>::NT>;
+    const int64_t n_blk = (a.n + 31) / 32;
+    int64_t blocks = (n_blk + 3) / 4;
+    if (blocks > 512) blocks = 512;                             // two persistent workgroups per CU
+#define REN_J2X(CC)                                                                                          \
+    do {                                                                                                     \
+        (void)hipFuncSetAttribute((const void *)mlp_fwd_jvp2_x_kernel<CC, MODE>,                              \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::BYTES);                \
+        hipLaunchKernelGGL((mlp_fwd_jvp2_x_kernel<CC, MODE>), dim3((int)blocks), dim3(256), L::BYTES, st, a); \
+    } while (0)
+    if (C == 1) REN_J2X(1); else REN_J2X(3);
+#undef REN_J2X
+    REN_CHECK_LAUNCH();
+}
+
 // ------------------------------------------------------------------------------------------------ compositing
 __device__ __forceinline__ float wave_incl_scan2(float v, int lane) {
 #pragma unroll
@@ -600,6 +812,27 @@ extern "C" int ren_mlp_fwd_jvp2(const float *mlp_params, int32_t C, const float 
     if (C == 1) hipLaunchKernelGGL(mlp_fwd_jvp2_kernel<1>, dim3((int)blocks), dim3(256), lds, (hipStream_t)stream, a);
     else        hipLaunchKernelGGL(mlp_fwd_jvp2_kernel<3>, dim3((int)blocks), dim3(256), lds, (hipStream_t)stream, a);
     REN_CHECK_LAUNCH();
+}
+
+extern "C" int ren_mlp_fwd_jvp2_x(const float *mlp_params, int32_t C, int32_t mode, const float *feat, const float *featd,
+                                  const float *featdd, const ren_scene_desc *scene, const float *rays_o, const float *rays_d,
+                                  const float *rays_do, const float *rays_dd, const float *rays_ddd,
+                                  const int32_t *ray_indices, const float *t_starts, const float *t_ends, int64_t n,
+                                  float *rgb, float *rgbd, float *rgbdd, float *sigma, float *sigmad, float *sigmadd,
+                                  void *stream) {
+    if (!mlp_params || !feat || !featd || !featdd || !scene || !rays_o || !rays_d || !rays_do || !rays_dd ||
+        !rays_ddd || !ray_indices || !t_starts || !t_ends || !rgb || !rgbd || !rgbdd || !sigma || !sigmad ||
+        !sigmadd || n < 0)
+        return REN_ERR_BAD_ARG;
+    if (C != 1 && C != 3) return REN_ERR_UNSUPPORTED;
+    if (mode != 1 && mode != 6) return REN_ERR_UNSUPPORTED;
+    if (n == 0) return REN_OK;
+    Fwd2Args a;
+    a.params = mlp_params; a.feat = feat; a.featd = featd; a.featdd = featdd;
+    a.ray = Ray2{rays_o, rays_d, rays_do, rays_dd, rays_ddd, ray_indices, t_starts, t_ends};
+    a.sc = ren_make_scene(scene);
+    a.n = n; a.rgb = rgb; a.rgbd = rgbd; a.rgbdd = rgbdd; a.sigma = sigma; a.sigmad = sigmad; a.sigmadd = sigmadd;
+    return mode == 6 ? launch_fwd_jvp2_x<6>(a, C, (hipStream_t)stream) : launch_fwd_jvp2_x<1>(a, C, (hipStream_t)stream);
 }
 
 extern "C" int ren_composite_fwd_jvp2(const int64_t *offsets, const int32_t *counts, int64_t n_rays,

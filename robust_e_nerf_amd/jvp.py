@@ -76,10 +76,16 @@ def render_forward2(r, o, d, od, dd, ddd, pk, bkgd):
                                     _ptr(featd), _ptr(featdd), _stream()), "ren_hashgrid_fwd_jvp2")
     rgb, rgbd, rgbdd = (torch.empty(n, f.C, device=dev) for _ in range(3))
     sg, sgd, sgdd = (torch.empty(n, device=dev) for _ in range(3))
-    check(lib.ren_mlp_fwd_jvp2(_ptr(r._mlp_params()), f.C, _ptr(feat), _ptr(featd), _ptr(featdd), ctypes.byref(r.scene),
-                               _ptr(o), _ptr(d), _ptr(od), _ptr(dd), _ptr(ddd), _ptr(ri), _ptr(ts), _ptr(te), n,
-                               _ptr(rgb), _ptr(rgbd), _ptr(rgbdd), _ptr(sg), _ptr(sgd), _ptr(sgdd), _stream()),
-          "ren_mlp_fwd_jvp2")
+    if r.cfg.mlp_kernels == "x":                            # bf16 matrix cores, in the step's precision mode
+        check(lib.ren_mlp_fwd_jvp2_x(_ptr(f.mlp), f.C, r._xmode(), _ptr(feat), _ptr(featd), _ptr(featdd), ctypes.byref(r.scene),
+                                     _ptr(o), _ptr(d), _ptr(od), _ptr(dd), _ptr(ddd), _ptr(ri), _ptr(ts), _ptr(te), n,
+                                     _ptr(rgb), _ptr(rgbd), _ptr(rgbdd), _ptr(sg), _ptr(sgd), _ptr(sgdd), _stream()),
+              "ren_mlp_fwd_jvp2_x")
+    else:
+        check(lib.ren_mlp_fwd_jvp2(_ptr(r._mlp_params()), f.C, _ptr(feat), _ptr(featd), _ptr(featdd), ctypes.byref(r.scene),
+                                   _ptr(o), _ptr(d), _ptr(od), _ptr(dd), _ptr(ddd), _ptr(ri), _ptr(ts), _ptr(te), n,
+                                   _ptr(rgb), _ptr(rgbd), _ptr(rgbdd), _ptr(sg), _ptr(sgd), _ptr(sgdd), _stream()),
+              "ren_mlp_fwd_jvp2")
     colors, colords, colorsdd = (torch.empty(R, f.C, device=dev) for _ in range(3))
     check(lib.ren_composite_fwd_jvp2(_ptr(pk.offsets), _ptr(pk.counts), R, _ptr(ts), _ptr(te), _ptr(sg), _ptr(sgd),
                                      _ptr(sgdd), _ptr(rgb), _ptr(rgbd), _ptr(rgbdd), f.C, _ptr(bkgd), _ptr(colors),
@@ -130,6 +136,10 @@ def render_forward(r, o, d, od, dd, jitter, bkgd, training: bool = True):
                empty=False, fctx=fctx)
     if fctx is not None:
         ctx["buffers"] = fctx["buffers"]                    # the value-only reverse pass (Renderer.backward) of arch mlp
+    elif r.cfg.mlp_kernels == "x":
+        # Renderer.backward on this context (l_diff with a trainable tau: the tangent is only needed forward) runs the
+        # bf16-matrix-core backward in the forward's mode, recomputing the hidden activations from feat / base
+        ctx["xmode"], ctx["acts"] = r._xmode(), None
     return colors, colords, opac, ctx
 
 

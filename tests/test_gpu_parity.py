@@ -1598,3 +1598,75 @@ def test_prefetched_step_front_gives_the_same_steps(amd, full_table_cache):
     tr.t.train_contrast_threshold = False
     tr.r.cfg.sampler = "occgrid"
     assert not tr.prefetch(*steps[3])
+
+
+def test_second_order_mlp_forward_matrix_core_kernel_vs_f32_kernel(amd, spec, full_table_cache):
+    """ren_mlp_fwd_jvp2_x (value, d/dt, d2/dt2 through the fused MLPs on the bf16 matrix cores) vs the exact-f32 MFMA
+    ren_mlp_fwd_jvp2 on 100 k samples of a random stream: mode 6 to fp32 round-off, mode 1 (bf16 operands) to 3e-2."""
+    import ctypes
+    from robust_e_nerf_amd import _lib
+    from oracle import field
+    ops, engine = amd
+    lib = _lib.load()
+    P = ops._ptr
+    R, S = 1024, 100
+    o, d = make_rays(R, seed=21)
+    gen = torch.Generator().manual_seed(22)
+    od, dd, ddd = (torch.randn(R, 3, generator=gen) * 0.3 for _ in range(3))
+    n = R * S
+    ri = dev(torch.arange(R, dtype=torch.int32).repeat_interleave(S))
+    tsv = torch.rand(n, generator=gen) * 3 + 2.5
+    ts, te = dev(tsv), dev(tsv + 0.01)
+    nb = ops.n_blocks32(n)
+    feat, featd, featdd = (dev(torch.randn(nb * 1024, generator=gen) * 0.3) for _ in range(3))
+    p = field.init_params(spec, seed=9)
+    fld = engine.NGPField(DEV)
+    p["hash"] = full_table_cache(7, 0.5)
+    fld.load(p)
+    scene = ops.make_scene_desc([-1.5] * 3 + [1.5] * 3, 0)
+    rays = [dev(v) for v in (o, d, od, dd, ddd)]
+    st = ops._stream()
+
+    def run(mode):
+        outs = [torch.empty(n, 1, device=DEV) for _ in range(3)] + [torch.empty(n, device=DEV) for _ in range(3)]
+        args = [P(feat), P(featd), P(featdd), ctypes.byref(scene)] + [P(v) for v in rays] + [P(ri), P(ts), P(te), n] + [P(v) for v in outs] + [st]
+        rc = lib.ren_mlp_fwd_jvp2(P(fld.mlp), 1, *args) if mode == 0 else lib.ren_mlp_fwd_jvp2_x(P(fld.mlp), 1, mode, *args)
+        assert rc == 0
+        torch.cuda.synchronize()
+        return [v.cpu() for v in outs]
+    ref, x6, x1 = run(0), run(6), run(1)
+    # float64 ground truth on the first 4096 samples: nested Jacobian-vector products through the oracle MLPs along
+    # enc(t) = feat + t featd + t^2/2 featdd, dir(t) = d + t dd + t^2/2 ddd
+    m = 4096
+    unfrag = lambda v: v.cpu().view(nb, 16, 2, 32).permute(0, 3, 1, 2).reshape(nb * 32, 32)[:m].double()
+    e0, e1, e2 = unfrag(feat), unfrag(featd), unfrag(featdd)
+    rid = ri.cpu().long()[:m]
+    d0, d1, d2 = d.double()[rid], dd.double()[rid], ddd.double()[rid]
+    p64 = {k: v.double() for k, v in p.items() if k != "hash"}
+
+    def fn(tt):
+        enc = e0 + tt * e1 + 0.5 * tt * tt * e2
+        h = field.softplus(field.linear(enc, p64["base.w0"], p64["base.b0"]), 100.0)
+        raw = field.linear(h, p64["base.wo"], p64["base.bo"])
+        rgb_ = field.query_rgb(d0 + tt * d1 + 0.5 * tt * tt * d2, raw[:, 1:], p64)
+        return torch.cat([rgb_, field.shifted_trunc_exp(raw[:, :1])], 1)
+    zero, one = torch.zeros((), dtype=torch.float64), torch.ones((), dtype=torch.float64)
+    first = lambda tt: torch.autograd.functional.jvp(fn, tt, one, create_graph=True)[1]
+    v0 = fn(zero)
+    v1, v2 = torch.autograd.functional.jvp(first, zero, one)
+    truth = [v0[:, :1], v1[:, :1], v2[:, :1], v0[:, 1], v1[:, 1], v2[:, 1]]
+    for name, a, b, tr_ in zip(("rgb", "rgbd", "rgbdd", "sigma", "sigmad", "sigmadd"), ref, x6, truth):
+        sel_ = (ref[3][:m] > 0).double() if name.startswith("sigma") else 1.0           # sigma is zero outside the box
+        assert rel_err(a[:m], tr_ * sel_) < 1e-5 and rel_err(b[:m], tr_ * sel_) < 1e-5, name
+    for name, a, b, c in zip(("rgb", "rgbd", "rgbdd", "sigma", "sigmad", "sigmadd"), ref, x6, x1):
+        assert rel_err(b, a) < 2e-5, name
+        assert rel_err(c, a) < 3e-2, name
+    # the first launch of a kernel in a process must give what every later launch gives (a scheduling problem of the
+    # compiler showed up exactly there, see csrc/ren_jvp2.hip): fresh process, each mode twice
+    import os, subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for order in ("6,6", "1,1"):
+        out = subprocess.run([sys.executable, os.path.join(repo, "tools", "jvp2_first_launch.py"), order], capture_output=True,
+                             text=True, timeout=300, cwd=repo)
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert "differing elements per output [0, 0, 0, 0, 0, 0]" in out.stdout, out.stdout

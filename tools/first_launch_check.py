@@ -1,0 +1,45 @@
+"""First launch vs repeat launch of the fused MLP kernels in a fresh process (see the note in csrc/ren_jvp2.hip): two
+identical l_diff + l_grad steps (trainable C_p / tau, so the second-order render runs too) from the same parameters
+must give the same loss and gradients.   python tools/first_launch_check.py [--mlp-bf16]"""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+import bench
+from robust_e_nerf_amd import engine
+
+bf16 = "--mlp-bf16" in sys.argv
+dev = "cuda:0"
+tab_ts, tab_pos, tab_quat, Kinv = bench.synthetic_scene(hard=True)
+T = torch.from_numpy
+gen = torch.Generator().manual_seed(0)
+fld = engine.NGPField(dev)
+fld.table.copy_((torch.rand(fld.n_table, generator=gen) * 0.2 - 0.1).to(dev))
+fld.mlp.copy_((torch.rand(fld.mlp.numel(), generator=gen) * 0.4 - 0.2).to(dev))
+r = engine.Renderer(fld, engine.RenderCfg(sampler="uniform", n_uniform=64, mlp_bf16=bf16))
+tcfg = engine.TrainCfg(w_grad=1e-3, train_contrast_threshold=True, train_refractory_period=True)
+tr = engine.Trainer(r, tcfg, Kinv=T(Kinv), tab_ts=T(tab_ts), tab_pos=T(tab_pos), tab_quat=T(tab_quat),
+                    p2n_raw=torch.tensor(0.5413), neg_ct=torch.tensor(0.25), tau_raw=torch.tensor(0.0, dtype=torch.float64),
+                    tau_max=torch.tensor(1e5), bkgd_raw=torch.tensor([0.5413]))
+B = 8192
+ev = bench.synthetic_events(B, int(tab_ts[-1]), seed=1)
+batch = {k: T(v).to(dev).contiguous() for k, v in ev.items()}
+j = [torch.rand(B, device=dev, generator=torch.Generator(device=dev).manual_seed(3 + k)) for k in range(3)]
+res = []
+for rep in range(3):
+    fld.grad_all.zero_(); tr.small_grad.zero_(); tr.ct_grad.zero_(); tr._tau_grad_dev.zero_()
+    l0, _ = tr.forward_backward(batch, j[0], j[1])
+    l1, _ = tr.grad_loss_forward_backward(batch, j[2])
+    torch.cuda.synchronize()
+    res.append((float(l0), float(l1), fld.g_mlp.clone(), fld.g_table.clone(), float(tr.tau_grad)))
+ok = True
+for rep in (1, 2):
+    a, b = res[0], res[rep]
+    dm = float((a[2] - b[2]).abs().max() / a[2].abs().max())
+    dt = float((a[3] - b[3]).abs().max() / a[3].abs().max())
+    print(f"launch 1 vs {rep + 1}: loss {a[0] - b[0]:+.3e} {a[1] - b[1]:+.3e}  |d MLP grad| {dm:.2e}  |d table grad| {dt:.2e}  "
+          f"d tau grad {abs(a[4] - b[4]) / max(abs(a[4]), 1e-300):.2e}")
+    # (the loss reduction and the few direct table atomics of the binned scatter are not order-deterministic: ~1 ulp / ~1e-6)
+    ok = ok and abs(a[0] - b[0]) <= 1e-6 * abs(a[0]) and abs(a[1] - b[1]) <= 1e-6 * abs(a[1]) and dm < 1e-6 and dt < 1e-5 \
+        and abs(a[4] - b[4]) <= 1e-6 * abs(a[4])
+print("first launch OK" if ok else "FIRST LAUNCH DIFFERS")
+sys.exit(0 if ok else 1)

@@ -1,0 +1,40 @@
+import ctypes, sys, os, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+from robust_e_nerf_amd import _lib, ops, engine
+from oracle import field, hashgrid
+DEV = "cuda:0"
+order = [int(v) for v in sys.argv[1].split(",")]
+lib = _lib.load(); P = ops._ptr
+R, S = 1024, 100
+gen = torch.Generator().manual_seed(22)
+o = torch.randn(R, 3, generator=gen); d = torch.randn(R, 3, generator=gen); d = d / d.norm(dim=-1, keepdim=True)
+od, dd, ddd = (torch.randn(R, 3, generator=gen) * 0.3 for _ in range(3))
+n = R * S
+dev = lambda v: v.to(DEV).contiguous()
+ri = dev(torch.arange(R, dtype=torch.int32).repeat_interleave(S))
+tsv = torch.rand(n, generator=gen) * 3 + 2.5
+ts, te = dev(tsv), dev(tsv + 0.01)
+nb = ops.n_blocks32(n)
+feat, featd, featdd = (dev(torch.randn(nb * 1024, generator=gen) * 0.3) for _ in range(3))
+mlp = dev(torch.randn(9425 + 3, generator=gen) * 0.2)
+scene = ops.make_scene_desc([-1.5] * 3 + [1.5] * 3, 0)
+rays = [dev(v) for v in (o, d, od, dd, ddd)]
+st = ops._stream()
+torch.cuda.synchronize()
+def run(mode):
+    outs = [torch.zeros(n, 1, device=DEV) for _ in range(3)] + [torch.zeros(n, device=DEV) for _ in range(3)]
+    torch.cuda.synchronize()
+    args = [P(feat), P(featd), P(featdd), ctypes.byref(scene)] + [P(v) for v in rays] + [P(ri), P(ts), P(te), n] + [P(v) for v in outs] + [st]
+    rc = lib.ren_mlp_fwd_jvp2(P(mlp), 1, *args) if mode == 0 else lib.ren_mlp_fwd_jvp2_x(P(mlp), 1, mode, *args)
+    assert rc == 0
+    torch.cuda.synchronize()
+    return [v.cpu() for v in outs]
+res = {}
+for m in order:
+    r = run(m)
+    if m in res:
+        bad = [int(((r[k] - res[m][k]).abs().reshape(-1) > 1e-6 * float(res[m][k].abs().max())).sum()) for k in range(6)]
+        print("mode", m, "repeat vs first launch: differing elements per output", bad)
+    else:
+        res[m] = r
