@@ -41,5 +41,24 @@ for rep in (1, 2):
     # (the loss reduction and the few direct table atomics of the binned scatter are not order-deterministic: ~1 ulp / ~1e-6)
     ok = ok and abs(a[0] - b[0]) <= 1e-6 * abs(a[0]) and abs(a[1] - b[1]) <= 1e-6 * abs(a[1]) and dm < 1e-6 and dt < 1e-5 \
         and abs(a[4] - b[4]) <= 1e-6 * abs(a[4])
+# the plain l_diff step (frozen C_p / tau): ren_mlp_fwd_x / ren_mlp_bwd_x
+fld2 = engine.NGPField(dev)
+fld2.table.copy_(fld.table); fld2.mlp.copy_(fld.mlp)
+r2 = engine.Renderer(fld2, engine.RenderCfg(sampler="uniform", n_uniform=64, mlp_bf16=bf16))
+tr2 = engine.Trainer(r2, engine.TrainCfg(), Kinv=T(Kinv), tab_ts=T(tab_ts), tab_pos=T(tab_pos), tab_quat=T(tab_quat),
+                     p2n_raw=torch.tensor(0.5413), neg_ct=torch.tensor(0.25), tau_raw=torch.tensor(0.0, dtype=torch.float64),
+                     tau_max=torch.tensor(1e5), bkgd_raw=torch.tensor([0.5413]))
+res = []
+for rep in range(3):
+    fld2.grad_all.zero_(); tr2.small_grad.zero_()
+    l0, aux = tr2.forward_backward(batch, j[0], j[1])
+    torch.cuda.synchronize()
+    res.append((float(l0), fld2.g_mlp.clone(), aux["intensity_start"].clone(), aux["intensity_end"].clone()))
+for rep in (1, 2):
+    a, b = res[0], res[rep]
+    dm = float((a[1] - b[1]).abs().max() / a[1].abs().max())
+    same_i = torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+    print(f"plain step, launch 1 vs {rep + 1}: loss {a[0] - b[0]:+.3e}  |d MLP grad| {dm:.2e}  rendered intensities identical: {same_i}")
+    ok = ok and abs(a[0] - b[0]) <= 1e-6 * abs(a[0]) and dm < 1e-6 and same_i
 print("first launch OK" if ok else "FIRST LAUNCH DIFFERS")
 sys.exit(0 if ok else 1)
