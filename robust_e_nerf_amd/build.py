@@ -25,16 +25,22 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = os.environ.get("HIPCC", "hipcc")
     headers = [os.path.join(CSRC, "ren_common.h"), os.path.join(CSRC, "ren_hashgrid_common.h"), os.path.join(CSRC, "ren_mlp_common.h"), os.path.join(CSRC, "ren_mlp_xfrag.h"), os.path.join(CSRC, "ren_mlp_jvp_common.h"),
                os.path.join(HERE, "..", "include", "ren_amd.h")]
-    objs = []
+    objs, jobs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
         if force or _stale(o, [s] + headers):
-            cmd = [hipcc] + COMMON + PER_FILE.get(src, []) + ["-c", s, "-o", o]
+            jobs.append([hipcc] + COMMON + PER_FILE.get(src, []) + ["-c", s, "-o", o])
+        objs.append(o)
+    if jobs:                                             # translation units are independent: compile them side by side
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(cmd):
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
-        objs.append(o)
+        with ThreadPoolExecutor(max_workers=min(len(jobs), max(1, (os.cpu_count() or 2) // 2), 8)) as pool:
+            list(pool.map(run, jobs))
     if force or _stale(OUT, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", OUT]
         if verbose:
