@@ -120,7 +120,7 @@ class Renderer:
         self._scratch = torch.zeros(4, device=dev, dtype=torch.float32)
         self._ws = torch.empty(max(ops.mlp_bwd_workspace_floats(fld.C), ops.mlp_bwd_x_workspace_floats(fld.C)),
                                device=dev, dtype=torch.float32)
-        self._bin_ws = None
+        self._bin_ws, self._bin_ws_small = None, 0
         self._occ_scratch = None
         self._occ_gen = None
         self.grad_sync = None                       # parallel.GradSync of the Trainer under data parallelism
@@ -192,6 +192,25 @@ class Renderer:
         _, sigma, _ = ops.mlp_fwd(self._mlp_params(), self.field.C, feat, self.scene, rays=(o, d),
                                   samples=samples, n=n, density_only=True, bf16=self.cfg.mlp_bf16)
         return sigma
+
+    def _binned_workspace(self, n: int, device) -> torch.Tensor:
+        """staging pool of the binned hash-grid backward (~1.4 KB per sample): grown on demand, and given back when a pass
+        needs less than a quarter of it for 32 passes in a row -- the first steps of a run, before the occupancy grid has
+        pruned and the batch size has adapted, can march 50 M samples (an 80 GB pool that would otherwise stay)"""
+        need = ops.hashgrid_bwd_binned_workspace_bytes(n)
+        ws = self._bin_ws
+        if ws is not None and ws.numel() >= need:
+            self._bin_ws_small = self._bin_ws_small + 1 if ws.numel() > 4 * need else 0
+            if self._bin_ws_small < 32:
+                return ws
+        shrink = ws is not None and ws.numel() >= need
+        del ws
+        self._bin_ws = None                                           # release before (re)allocating
+        self._bin_ws_small = 0
+        if shrink:
+            torch.cuda.empty_cache()                                  # rare: hand the big block back to the driver as well
+        self._bin_ws = torch.empty(need + need // 4, device=device, dtype=torch.uint8)
+        return self._bin_ws
 
     def _save_acts(self) -> bool:
         c = self.cfg
@@ -281,10 +300,7 @@ class Renderer:
                                 d_sigma=d_sig, grad_mlp_params=f.g_mlp, workspace=self._ws,
                                 bf16=self.cfg.mlp_bf16 and mp is not None)
         if self.cfg.binned_scatter:
-            need = ops.hashgrid_bwd_binned_workspace_bytes(pk.n)
-            if self._bin_ws is None or self._bin_ws.numel() < need:
-                self._bin_ws = None                                   # release before growing
-                self._bin_ws = torch.empty(need, device=dfeat.device, dtype=torch.uint8)
+            self._binned_workspace(pk.n, dfeat.device)
             kw = dict(scene=self.scene, rays=(ctx["o"], ctx["d"]), samples=samples, n=pk.n, layout=1)
             if final and self.grad_sync is not None and self.cfg.dp_overlap:
                 # last backward of the step under data parallelism: fine levels first, their slice of the table gradient

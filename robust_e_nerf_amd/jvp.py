@@ -182,10 +182,7 @@ def render_backward(r, ctx, g_colors, g_colords, final: bool = False):
                                   _ptr(d_rgbd), _ptr(d_sig), _ptr(d_sigd), _ptr(scratch), _ptr(dfeat), _ptr(dfeatd),
                                   _ptr(f.g_mlp), _ptr(ws), _stream()), "ren_mlp_bwd_jvp")
     if r.cfg.binned_scatter:
-        need = ops.hashgrid_bwd_binned_workspace_bytes(n)
-        if r._bin_ws is None or r._bin_ws.numel() < need:
-            r._bin_ws = None
-            r._bin_ws = torch.empty(need, device=dev, dtype=torch.uint8)
+        r._binned_workspace(n, dev)
         kw = dict(scene=r.scene, rays=(ctx["o"], ctx["d"]), samples=(ri, ts, te), n=n, layout=1,
                   tangent=(ctx["od"], ctx["dd"], dfeatd))
         if final and r.grad_sync is not None and r.cfg.dp_overlap:   # see Renderer._field_backward

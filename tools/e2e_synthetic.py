@@ -125,7 +125,7 @@ def evaluate(ckpt, Kinv_d, cfg, png=None):
         fld = engine.NGPField(DEV, 1)
         cli.load_field_state_dict(fld, "ngp", sd)
         r = engine.Renderer(fld, rcfg)
-    r.binary.copy_(sd["nerf.occ_grid._binary"].reshape(-1).to(torch.uint8).to(DEV))
+    r.binary.copy_(sd[cli.OCC + "_binary"].reshape(-1).to(torch.uint8).to(DEV))
     bk = torch.nn.functional.softplus(sd["nerf.parametrizations.render_bkgd.original"].to(DEV))
     scores, tiles = [], []
     for pos, rot in novel_views():
