@@ -73,8 +73,8 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(
         if (i < n) reinterpret_cast<float2 *>(feat)[i * g.n_levels + lvl] = make_float2(f0, f1);
     } else {
         const int64_t b = ((i >> 5) * REN_MAX_LEVELS + lvl) * 64 + (i & 31);
-        feat[b] = f0;
-        feat[b + 32] = f1;
+        __builtin_nontemporal_store(f0, feat + b);           // streamed once: keep the level's table slice in L2 instead
+        __builtin_nontemporal_store(f1, feat + b + 32);
     }
 }
 

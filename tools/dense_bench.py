@@ -60,7 +60,7 @@ def main():
         t_b = timeit(bwd)
         refb = (dZ[:m, :o].double() @ W.double())[:, :i4] * (1.0 - torch.exp(-100.0 * Yp[:m].double()))
         err_b = float((dX[:m].double() - refb).abs().max() / refb.abs().max())
-        splits = 256
+        splits = int(os.environ.get("DW_SPLITS", 256))
         ws = torch.empty(int(lib.ren_dense_bwd_weight_workspace_floats(o, i, splits)), device=dev)
         gW, gb = torch.zeros(o, i, device=dev), torch.zeros(o, device=dev)
         dw = lambda: check(lib.ren_dense_bwd_weight(_ptr(dZ), ldo, _ptr(X), ldx, o, i, n, splits | (a.mode << 16), _ptr(gW), _ptr(gb),
