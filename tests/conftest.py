@@ -50,5 +50,14 @@ def field_params_from(g, table):
 
 
 def rel_err(a, b):
+    """max |a - b| / max |b|: error relative to the tensor's scale"""
     a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
     return float((a.detach() - b.detach()).abs().max() / b.detach().abs().max().clamp(min=1e-30))
+
+
+def elem_err(a, b, floor=1e-3):
+    """max over elements of |a - b| / max(|b|, floor * max |b|): element-wise relative error, with elements below
+    `floor` of the tensor's scale judged against that floor (an fp32 result has no relative accuracy at its zeros)"""
+    a, b = torch.as_tensor(a).double().detach(), torch.as_tensor(b).double().detach()
+    den = b.abs().clamp(min=floor * float(b.abs().max().clamp(min=1e-30)))
+    return float(((a - b).abs() / den).max())
