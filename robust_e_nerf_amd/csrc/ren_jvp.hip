@@ -147,8 +147,8 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_jvp_kernel(
         }
     }
     const int64_t b = ((i >> 5) * REN_MAX_LEVELS + lvl) * 64 + (i & 31);
-    feat[b] = f0; feat[b + 32] = f1;
-    featd[b] = g0; featd[b + 32] = g1;
+    __builtin_nontemporal_store(f0, feat + b); __builtin_nontemporal_store(f1, feat + b + 32);      // streamed once (see hashgrid_fwd_kernel)
+    __builtin_nontemporal_store(g0, featd + b); __builtin_nontemporal_store(g1, featd + b + 32);
 }
 
 // d table += w_c * dfeat + wdot_c * dfeatd  (per-update atomics, lane pair per feature)
