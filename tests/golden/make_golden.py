@@ -673,6 +673,10 @@ def gen_occgrid_post_warmup(nerf_mod, nerfacc):
     occ_eval_fn over the cells nerfacc's OccupancyGrid samples then (1/4 uniform + up to 1/4 of the occupied ones;
     policy restated from nerfacc 0.3.x -- parity unpinned)."""
     torch.manual_seed(90)
+    # the sample holds duplicate cells (drawn with replacement); the indexed assignment that applies the update keeps an
+    # arbitrary candidate for them when it runs multi-threaded: one thread, so that this fixture regenerates bit for bit
+    n_threads = torch.get_num_threads()
+    torch.set_num_threads(1)
     occ_res = 32
     occ_cfg = EasyDict(resolution=occ_res, occ_thre=1e-2, ema_decay=0.95, warmup_steps=256, n=16)
     step = 3 ** 0.5 * 3.0 / 1024
@@ -691,6 +695,7 @@ def gen_occgrid_post_warmup(nerf_mod, nerfacc):
          indices=up["indices"].numpy().astype(np.int32), jitter=up["jitter"].numpy().astype(np.float16),
          occs_after=grid.occs, binary_after=np.packbits(grid._binary.numpy().reshape(-1)),
          **field_params_np(nerf.radiance_field))
+    torch.set_num_threads(n_threads)
 
 
 def main():
