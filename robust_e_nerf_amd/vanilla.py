@@ -178,10 +178,23 @@ class VanillaRenderer(Renderer):
         return B.rgb4[:n, :C].contiguous(), sigma
 
     # ---- Renderer hooks ---------------------------------------------------------------------------------
-    def _density_stream(self, o, d, samples, n, return_feat: bool = False):
-        B = _Buffers(n, o.device, self.field.C, full=False, backward=False)
-        self._encode(B, False, rays=(o, d), samples=samples)
-        return self._trunk(B)
+    def _density_stream(self, o, d, samples, n, return_feat: bool = False, chunk: int = 1 << 21):
+        """no-grad density of the marched samples (the sampler's sigma_fn pre-pass), in chunks of whole 32-sample blocks: the
+        trunk keeps ~8.7 KB of activations per sample, and a first step through an empty occupancy grid can march 60 M of
+        them (the rendered-sample budget of the dynamic batch size does not bound the marched count)"""
+        if n <= chunk:
+            B = _Buffers(n, o.device, self.field.C, full=False, backward=False)
+            self._encode(B, False, rays=(o, d), samples=samples)
+            return self._trunk(B)
+        ri, ts, te = samples
+        out = torch.empty(n, device=o.device, dtype=torch.float32)
+        for s0 in range(0, n, chunk):
+            e0 = min(s0 + chunk, n)
+            B = _Buffers(e0 - s0, o.device, self.field.C, full=False, backward=False)
+            self._encode(B, False, rays=(o, d), samples=(ri[s0:e0], ts[s0:e0], te[s0:e0]))
+            out[s0:e0] = self._trunk(B)
+            del B
+        return out
 
     def _field_forward(self, o, d, pk, save):
         B = _Buffers(pk.n, o.device, self.field.C, full=True, backward=False)
@@ -376,9 +389,15 @@ class VanillaRenderer(Renderer):
     def query_density(self, x_world: torch.Tensor) -> torch.Tensor:
         """VanillaNeRFRadianceField.query_density (mlp.py:343-347) for arbitrary world points."""
         n = x_world.shape[0]
-        B = _Buffers(n, x_world.device, self.field.C, full=False, backward=False)
-        self._encode(B, False, x_world=x_world.contiguous())
-        return self._trunk(B)
+        chunk = 1 << 21                                    # an occupancy refresh queries up to 256^3 cells: 8.7 KB of
+        out = torch.empty(n, device=x_world.device, dtype=torch.float32)     # trunk activations per point, so in pieces
+        for s0 in range(0, n, chunk):
+            xs = x_world[s0: s0 + chunk].contiguous()
+            B = _Buffers(xs.shape[0], x_world.device, self.field.C, full=False, backward=False)
+            self._encode(B, False, x_world=xs)
+            out[s0: s0 + chunk] = self._trunk(B)
+            del B
+        return out
 
     def query(self, x_world: torch.Tensor, dirs: torch.Tensor):
         """field(x, d) -> (rgb (n, C), sigma (n,), buffers) for free-standing points (mlp.py:349-358)."""

@@ -167,9 +167,6 @@ def main():
                             mlp_bf16=mlp_bf16)
     arch = ncfg.get("arch", "ngp")
     check_supported(ncfg, arch)
-    if arch == "mlp" and float(cfg["loss"]["weight"]["log_intensity_grad"]) > 0 and not mcfg["refractory_period"]["freeze"]:
-        raise NotImplementedError("arch mlp: the log-intensity-gradient loss with a trainable refractory period needs the "
-                                  "second-order tangent render, which is built for arch ngp only")
     gen = torch.Generator().manual_seed(seed)
 
     def lin(o, i):                                           # nn.Linear default init (hidden_init=None, ngp.py:179-185)
