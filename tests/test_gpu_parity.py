@@ -1706,3 +1706,11 @@ def test_train_cli_with_tum_vie_settings(tmp_path, arch):
     assert "nerf.parametrizations.render_bkgd.original" not in sd                  # alpha_over_white_bg: false
     assert float(sd["refractory_period.parametrizations._refractory_period.original"]) != 0.0   # tau moved off its start
     assert tuple(sd["nerf.occupancy_grid._binary"].shape) == (256, 256, 256)
+    # resume with the learned tau and its float64 Adam state
+    out2 = subprocess.run([sys.executable, os.path.join(repo, "scripts", "train.py"), "--config", path, "--synthetic", "100000", "--out",
+                           str(tmp_path), "--resume", os.path.join(tmp_path, "last.ckpt"), "--max-epochs", "3",
+                           "--limit-train-batches", "4"], capture_output=True, text=True, timeout=900)
+    assert out2.returncode == 0, out2.stderr[-2000:]
+    assert "resumed" in out2.stdout
+    ck2 = torch.load(os.path.join(tmp_path, "last.ckpt"), map_location="cpu", weights_only=False)
+    assert ck2["epoch"] == 2 and "tau_adam" in ck2["optimizer_state"]
