@@ -191,8 +191,8 @@ __global__ void ray_march_kernel(const float *__restrict__ o, const float *__res
 // lanes test their cell at once.  The leading run of occupied cells is emitted, the first empty (or out-of-range)
 // lane decides how the group continues, exactly as the sequential loop does at that step.  In contracted space an
 // empty cell advances the state like an occupied one, so all SPEC lanes always count.  Output is bit-identical to
-// ray_march_kernel (same tests); dense rays need 1/SPEC of the load round trips.
-constexpr int SPEC = 8;
+// ray_march_kernel (same tests); dense rays need 1/SPEC of the load round trips (SPEC 8 -> 16: 96 -> 77 us for 16 k rays at configs[4] settings).
+constexpr int SPEC = 16;
 
 template <bool WRITE>
 __global__ __launch_bounds__(256) void ray_march_spec_kernel(
