@@ -2,7 +2,6 @@ import ctypes, sys, os, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 from robust_e_nerf_amd import _lib, ops, engine
-from oracle import field, hashgrid
 DEV = "cuda:0"
 order = [int(v) for v in sys.argv[1].split(",")]
 lib = _lib.load(); P = ops._ptr
