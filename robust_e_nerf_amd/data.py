@@ -37,10 +37,34 @@ def _by_pixel(position: np.ndarray, width: int):
     return order, same
 
 
-def queue_raw_events(position: np.ndarray, timestamp: np.ndarray, polarity: np.ndarray, width: int) -> Dict[str, torch.Tensor]:
+def _queue_raw_events_device(position, timestamp, polarity, width: int, device) -> Dict[str, torch.Tensor]:
+    """queue_raw_events with the stable by-pixel sort and the scatter back to stream order on the GPU (torch ops on device
+    tensors: 20 M events in well under a second instead of 15 s of numpy; the result comes back on the host)"""
+    pos = torch.as_tensor(np.ascontiguousarray(np.asarray(position).astype(np.int64))).to(device)
+    ts = torch.as_tensor(np.ascontiguousarray(np.asarray(timestamp).astype(np.int64))).to(device)
+    pol = torch.as_tensor(np.ascontiguousarray(np.asarray(polarity).astype(np.int64))).to(device)
+    pix = pos[:, 1] * int(width) + pos[:, 0]
+    ps, order = torch.sort(pix, stable=True)
+    ts_sorted = ts[order]
+    first = torch.ones(1, dtype=torch.bool, device=device)
+    valid_sorted = ~torch.cat([first, (ps[1:] != ps[:-1]) | (ts_sorted[1:] == ts_sorted[:-1])])
+    prev_ts = torch.cat([ts_sorted[:1], ts_sorted[:-1]])
+    start = torch.empty_like(ts)
+    valid = torch.empty_like(valid_sorted)
+    start[order] = prev_ts
+    valid[order] = valid_sorted
+    keep = torch.nonzero(valid)[:, 0]
+    return {"position": pos[keep].cpu(), "start_ts": start[keep].cpu(), "end_ts": ts[keep].cpu(), "num_pos": pol[keep].cpu(),
+            "num_neg": (1 - pol[keep]).cpu()}
+
+
+def queue_raw_events(position: np.ndarray, timestamp: np.ndarray, polarity: np.ndarray, width: int,
+                     device=None) -> Dict[str, torch.Tensor]:
     """datasets.py:190-284: every event with a predecessor at its pixel at an EARLIER time becomes the
     interval (start_ts = predecessor's time, end_ts = its own, num_pos/num_neg = its own polarity).
-    Events are kept in stream order."""
+    Events are kept in stream order.  device: run the sort / scatter there (same result)."""
+    if device is not None and torch.device(device).type == "cuda":
+        return _queue_raw_events_device(position, timestamp, polarity, width, device)
     position = np.asarray(position).astype(np.int64)
     timestamp = np.asarray(timestamp).astype(np.int64)
     pol = np.asarray(polarity).astype(np.int64)
@@ -126,15 +150,15 @@ def undistort_events(events: Dict[str, torch.Tensor], calib) -> Dict[str, torch.
     return events
 
 
-def load_events(root: str, permutation_seed: Optional[int] = None, use_cache: bool = True) -> Dict[str, torch.Tensor]:
-    """``Event.__init__`` (datasets.py:36-62): cached ``events.pt`` if present, else build and cache."""
+def load_events(root: str, permutation_seed: Optional[int] = None, use_cache: bool = True, device=None) -> Dict[str, torch.Tensor]:
+    """``Event.__init__`` (datasets.py:36-62): cached ``events.pt`` if present, else build (on `device` if given) and cache."""
     cache = os.path.join(root, TF_EVENTS)
     if use_cache and os.path.isfile(cache):
         events = dict(torch.load(cache))
     else:
         calib = np.load(os.path.join(root, CAMERA_CALIBRATION))
         raw = np.load(os.path.join(root, RAW_EVENTS))
-        events = queue_raw_events(raw["position"], raw["timestamp"], raw["polarity"], int(calib["img_width"]))
+        events = queue_raw_events(raw["position"], raw["timestamp"], raw["polarity"], int(calib["img_width"]), device=device)
         events = colorize_events(events, str(calib["bayer_pattern"]) if "bayer_pattern" in calib.files else "")
         events = undistort_events(events, calib)
         if use_cache:

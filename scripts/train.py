@@ -127,7 +127,7 @@ def main():
         pos_ct, neg_ct, tau0, tau_max = 0.25, 0.25, 0.0, torch.tensor(1e5, dtype=torch.float64)
     else:
         root = args.dataset_dir or dcfg["dataset_directory"]
-        events = data.load_events(root, dcfg.get("train_dataset_perm_seed"))
+        events = data.load_events(root, dcfg.get("train_dataset_perm_seed"), device=dev)
         tab_ts, tab_pos, tab_quat = data.load_camera_poses(root)
         calib = data.load_calibration(root)
         Kinv = calib["Kinv"]

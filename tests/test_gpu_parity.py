@@ -1714,3 +1714,24 @@ def test_train_cli_with_tum_vie_settings(tmp_path, arch):
     assert "resumed" in out2.stdout
     ck2 = torch.load(os.path.join(tmp_path, "last.ckpt"), map_location="cpu", weights_only=False)
     assert ck2["epoch"] == 2 and "tau_adam" in ck2["optimizer_state"]
+
+
+def test_event_interval_construction_on_device_equals_host():
+    """data.queue_raw_events (datasets.py:190-284) with the by-pixel sort on the GPU: identical intervals, in the same
+    stream order, as the numpy path (which tests/test_data.py pins to the reference's own Event class) -- incl. equal
+    timestamps at a pixel and pixels with a single event."""
+    import time
+    from robust_e_nerf_amd import data
+    g = np.random.default_rng(5)
+    N = 3_000_000
+    pos = np.stack([g.integers(0, 346, N), g.integers(0, 260, N)], 1).astype(np.uint16)
+    ts = np.sort(g.integers(0, 40_000_000, N)).astype(np.int64)          # dense in time: repeated timestamps occur
+    pol = g.random(N) < 0.5
+    host = data.queue_raw_events(pos, ts, pol, 346)
+    t0 = time.perf_counter()
+    devr = data.queue_raw_events(pos, ts, pol, 346, device=DEV)
+    dt = time.perf_counter() - t0
+    assert set(host) == set(devr) and host["end_ts"].shape[0] > N // 2
+    for k in host:
+        assert torch.equal(host[k], devr[k]), k
+    print(f"{N} events on the device: {dt:.2f} s")
