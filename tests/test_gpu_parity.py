@@ -1516,6 +1516,15 @@ def test_train_cli_smoke_and_checkpoint_keys(tmp_path):
     assert sd["nerf.radiance_field.mlp_base.0.params"].numel() == 12_599_920 and ck["global_step"] == 48
     assert ck["optimizer_state"]["step_count"] == 48 and float(ck["optimizer_state"]["exp_avg_sq"].abs().sum()) > 0
     ct_learned = float(sd["contrast_threshold.parametrizations.p2n_contrast_threshold_ratio.original"])
+    # scripts/render.py: views along the trajectory from that checkpoint (the inference side of evaluation_step)
+    rd = os.path.join(tmp_path, "renders")
+    out_r = subprocess.run([sys.executable, os.path.join(repo, "scripts", "render.py"), "--config",
+                            os.path.join(repo, "configs", "synthetic_smoke.yaml"), "--ckpt", os.path.join(tmp_path, "last.ckpt"),
+                            "--synthetic", "--every", "500", "--out", rd], capture_output=True, text=True, timeout=600)
+    assert out_r.returncode == 0, out_r.stderr[-2000:]
+    views = np.load(os.path.join(rd, "views.npz"))
+    assert views["intensity"].shape == (5, 260, 346) and np.isfinite(views["intensity"]).all() and views["intensity"].min() > 0
+    assert views["opacity"].min() >= 0 and views["opacity"].max() <= 1 + 1e-5 and os.path.isfile(os.path.join(rd, "1000.png"))
     # resume: continues at the next epoch with the Adam moments, step counters and the learned C_p ratio
     out2 = subprocess.run(cmd + ["--resume", os.path.join(tmp_path, "last.ckpt"), "--max-epochs", str(ck["epoch"] + 2),
                                  "--limit-train-batches", "8"], capture_output=True, text=True, timeout=600)
