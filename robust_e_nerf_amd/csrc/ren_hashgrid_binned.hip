@@ -219,6 +219,38 @@ __device__ __forceinline__ uint32_t bin_rank(bool dense, bool emit, uint32_t bin
     return rank;
 }
 
+// The eight corners of a dense cell at once.  bin_rank costs one LDS round trip per corner (the leader's atomic has to
+// come back before the next corner can start): ~1 000 cycles of latency per wave and level, which is what the dense
+// levels' scatter was made of.  When every emitting lane of the wave has the same bin for corner c (all corners of
+// levels 0-2, most waves of levels 3-4), the leader issues the eight counter bumps back to back and the wave waits once.
+__device__ __forceinline__ void bin_rank8_dense(bool emit, const uint32_t (&bin)[8], int lane, uint32_t *hist, uint32_t (&rank)[8]) {
+    const uint64_t m = __ballot(emit);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) rank[c] = 0;
+    if (!m) return;
+    const int leader = __ffsll((unsigned long long)m) - 1;
+    uint32_t lb[8];
+    bool mixed = false;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        lb[c] = __shfl(bin[c], leader, 64);
+        mixed |= emit && bin[c] != lb[c];
+    }
+    if (__ballot(mixed)) {                                         // wave-uniform branch
+#pragma unroll
+        for (int c = 0; c < 8; ++c) rank[c] = bin_rank(true, emit, bin[c], lane, hist);
+        return;
+    }
+    const uint32_t cnt = (uint32_t)__popcll(m), pre = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    uint32_t base[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (lane == leader) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) base[c] = atomicAdd(&hist[lb[c]], cnt);   // same bin twice: ordered, distinct bases
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) rank[c] = __shfl(base[c], leader, 64) + pre;
+}
+
 // ---- 1. count ------------------------------------------------------------------------------------
 // One thread walks all levels of its 4 samples; the per-(level, bin) histogram lives in LDS and reaches
 // the global counters once per workgroup (the counters are memory-side atomics, ~18 G/s chip-wide).
@@ -435,10 +467,19 @@ __global__ __launch_bounds__(SC_THREADS, KIND == 1 ? REN_SC_WAVES_PAIR : REN_SC_
             } else if (valid) {
                 vmax = fmaxf(fabsf(d0), fabsf(d1)) * (hashed ? 1.f : 8.f);
             }
+            if (!hashed) {
+                uint32_t bins[8], rk[8];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const uint32_t rank = bin_rank(!hashed, have, idx[c] >> BIN_SHIFT, lane, hist);
-                key[c] = (rank << 19) | idx[c];                    // idx < 2^19, rank < 4096
+                for (int c = 0; c < 8; ++c) bins[c] = idx[c] >> BIN_SHIFT;
+                bin_rank8_dense(have, bins, lane, hist, rk);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) key[c] = (rk[c] << 19) | idx[c];
+            } else {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const uint32_t rank = bin_rank(false, have, idx[c] >> BIN_SHIFT, lane, hist);
+                    key[c] = (rank << 19) | idx[c];                // idx < 2^19, rank < 4096
+                }
             }
         }
         // max |update| of the level: scales the 64-bit fixed-point accumulation of the next kernel
