@@ -161,9 +161,9 @@ __device__ __forceinline__ uint64_t cell_key(const LevelPos &p) {
     return ((uint64_t)p.c[2] << 42) ^ ((uint64_t)p.c[1] << 21) ^ (uint64_t)p.c[0];
 }
 
-// Runs are confined to aligned groups of RUN_LANES = 8 lanes so the merge is three DPP row shifts (no LDS).
+// Runs are confined to aligned groups of RUN_LANES = 16 lanes (one DPP row) so the merge is four DPP row shifts (no LDS).
 // emit = this lane is the LAST lane of a run of valid lanes with equal cell (always true for hashed levels)
-constexpr int RUN_LANES = 8;
+constexpr int RUN_LANES = 16;
 
 template <int OFF>
 __device__ __forceinline__ float dpp_shr(float v) {               // value of lane - OFF in the 16-lane row, else 0
@@ -198,6 +198,7 @@ __device__ __forceinline__ void run_merge(bool head, int lane, float (&v0)[8], f
     run_merge_step<1>(f, v0, v1);
     run_merge_step<2>(f, v0, v1);
     run_merge_step<4>(f, v0, v1);
+    run_merge_step<8>(f, v0, v1);
 }
 
 // LDS counter bump with one atomic per distinct bin in the wave (dense levels: the lanes of a wave
@@ -457,7 +458,7 @@ __global__ __launch_bounds__(SC_THREADS, KIND == 1 ? REN_SC_WAVES_PAIR : REN_SC_
             have = run_tail(!hashed, valid, cell_key(p), lane, head);
             if (!hashed) run_merge(head, lane, v0, v1);
             // upper bound of |update| in this level (scale of the fixed-point sums): interpolation weights are <= 1 and a
-            // merged run adds at most 8 lanes, so 8 max|d feature| bounds every update (3 of the 38 bits); with tangents
+            // merged run adds at most RUN_LANES lanes, so RUN_LANES max|d feature| bounds every update (4 of the 38 bits); with tangents
             // the updates carry the scale * |ud| terms as well, so take them as they are
             if (TAN) {
                 if (have) {
@@ -465,7 +466,7 @@ __global__ __launch_bounds__(SC_THREADS, KIND == 1 ? REN_SC_WAVES_PAIR : REN_SC_
                     for (int c = 0; c < 8; ++c) vmax = fmaxf(vmax, fmaxf(fabsf(v0[c]), fabsf(v1[c])));
                 }
             } else if (valid) {
-                vmax = fmaxf(fabsf(d0), fabsf(d1)) * (hashed ? 1.f : 8.f);
+                vmax = fmaxf(fabsf(d0), fabsf(d1)) * (hashed ? 1.f : (float)RUN_LANES);
             }
             if (!hashed) {
                 uint32_t bins[8], rk[8];
