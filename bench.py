@@ -5,8 +5,10 @@ hash grid -> fused MLPs -> compositing -> event loss -> backward -> (all-reduce)
     python bench.py --gpus N --steps K --warmup W
 
 N > 1 is launched by the driver through torch.distributed.run (one process per GPU, RCCL).
-Workload = BASELINE.json configs[1]: synthetic 'ficus'-like event stream, 65 536 events per step
-(two renders = 131 072 rays), 128 samples per ray, fp32, default synthetic.yaml NGP model.
+Workload = BASELINE.json configs[1] as SURVEY.md 8 defines config B: synthetic 'ficus'-like event stream, R = 65 536
+rays PER RENDER x 128 samples, i.e. 65 536 events per step whose two renders (start / end timestamps) run as one
+131 072-ray pass (n = 16 777 216 samples per kernel launch), fp32, default synthetic.yaml NGP model.
+`--events 32768` is the other reading (65 536 rays per STEP, n = 8 388 608 per launch; profiles/rNN_bench_half.json).
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant
 kernel (HIP-event timed inside the timed region) and `cpu_baseline` (the CPU oracle on a bounded
 sample of the same workload, rank 0, N = 1 only).
@@ -154,8 +156,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--events", type=int, default=32768,
-                    help="events per step per GPU (2 rays each): 32768 = the 65536-ray batch of BASELINE configs[1]")
+    ap.add_argument("--events", type=int, default=65536,
+                    help="events per step per GPU (2 rays each): 65536 = R 65536 rays per render of BASELINE configs[1] "
+                         "(SURVEY 8 config B); 32768 = 65536 rays per step")
     ap.add_argument("--samples", type=int, default=128, help="samples per ray (uniform sampler)")
     ap.add_argument("--sampler", default="uniform", choices=["uniform", "occgrid"])
     ap.add_argument("--workload", default="b", choices=["b", "e"],
@@ -407,12 +410,10 @@ def main():
             "metric": "train_rays_per_sec", "value": rays / dt, "unit": "rays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            # fp32 storage and accumulation everywhere.  MLP products on the bf16 matrix cores: 6-term split (fp32 round-off)
-            # for outputs and data gradients, 3-term / two-piece split (2^-16 per product, measured <= 4e-5 on the summed
-            # gradient: test_matrix_core_mlp_kernels_vs_exact_f32_kernels_at_config_b_size) for the weight gradients;
-            # --mlp-kernels f32 runs every product on the exact-f32 MFMA
-            "dtype": ("bf16-operand/f32-accumulate MLP, f32 elsewhere" if args.mlp_bf16 else
-                      "f32" if args.mlp_kernels == "f32" else "f32 (MLP weight-gradient products: bf16x2 split, 2^-16)"),
+            # fp32 storage, products and accumulation everywhere.  The default MLP kernels form every product -- outputs, data
+            # gradients AND weight gradients -- as the six-term split on the bf16 matrix cores, i.e. to fp32 round-off
+            # (test_matrix_core_mlp_kernels_vs_exact_f32_kernels_at_config_b_size); --mlp-kernels f32 runs them on the f32 MFMA
+            "dtype": "bf16-operand/f32-accumulate MLP, f32 elsewhere" if args.mlp_bf16 else "f32",
             "data": "synthetic",
             "mlp_samples_per_sec": n_samples / dt, "mean_samples_per_ray": n_samples / rays,
             "loss": float(loss),
@@ -421,7 +422,7 @@ def main():
                                     "BASELINE configs[2] shape (non-uniform motion, C_p + tau trainable, l_grad" +
                                     (", bf16 MLP + fp32 composite" if args.mlp_bf16 else "") + "): synthetic event stream, " if args.hard else
                                     "BASELINE configs[1]: synthetic ficus-like event stream, ") +
-                                   f"{B} events/step/GPU = {2 * B} rays x {args.samples} samples, arch {args.arch}, fp32, "
+                                   f"{B} events/step/GPU = 2 renders x {B} rays x {args.samples} samples, arch {args.arch}, fp32, "
                                    f"{'l_diff + l_grad (3 renders)' if args.loss_grad > 0 else 'l_diff (2 renders)'}, fwd+bwd+Adam; sampler={args.sampler}",
                        "events_per_step_per_gpu": B, "rays_per_step_per_gpu": 2 * B, "sampler": args.sampler,
                        "samples_per_ray": args.samples, "parallelism": f"dp{world}",

@@ -11,7 +11,10 @@ SOURCES = ["ren_api.hip", "ren_pose.hip", "ren_sampling.hip", "ren_composite.hip
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
           "-Wno-unused-result"]
 # the sampler must match the sequential oracle bit for bit: no FMA contraction there
-PER_FILE = {"ren_sampling.hip": ["-ffp-contract=off"], "ren_jvp2.hip": ["-fno-slp-vectorize"]}
+# the one-wave-per-SIMD MLP backward kernels: MFMA results in VGPRs (the chain's VALU work reads them directly) instead of
+# the AGPR form + one v_accvgpr_read per result register that hipcc picks for kernels with a 512-register budget
+PER_FILE = {"ren_sampling.hip": ["-ffp-contract=off"], "ren_jvp2.hip": ["-fno-slp-vectorize"],
+            "ren_mlp_x.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _stale(target, deps):

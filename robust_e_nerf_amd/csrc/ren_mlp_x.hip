@@ -55,7 +55,7 @@ __global__ __launch_bounds__(64 * FWD_X_WAVES, 2) void mlp_fwd_x_kernel(FwdXArgs
     __bf16 *frag = reinterpret_cast<__bf16 *>(smem);
     float *tail = reinterpret_cast<float *>(smem + L::BYTES_F);
     fill_frags<NT, 0>(frag + L::F_W1, a.params, 2, 2);
-    fill_frags<NT, 1>(frag + L::F_W2, a.params, 1, 4);
+    fill_frags<NT, 1, true>(frag + L::F_W2, a.params, 1, 4);           // odd chunks negated: o - o2 below
     if (!DENSITY_ONLY) {
         fill_frags<NT, 2>(frag + L::F_WH1, a.params, 2, 2);
         fill_frags<NT, 3>(frag + L::F_WH2, a.params, 2, 4);
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(64 * FWD_X_WAVES, 2) void mlp_fwd_x_kernel(FwdXArgs
         mma1x2<MODE>(o, o2, fr + L::F_W2, 4, 0, 1, bh[0], bh[1], lane);
         mma1x2<MODE>(o, o2, fr + L::F_W2, 4, 2, 3, bh[2], bh[3], lane);
 #pragma unroll
-        for (int g = 0; g < 16; ++g) o[g] += o2[g];
+        for (int g = 0; g < 16; ++g) o[g] -= o2[g];                // o2 ran on the negated odd chunks (fill_frags NEG_ODD)
         bool sel = false;
         float dx = 0.f, dy = 0.f, dz = 1.f;
         if (live) sample_geom(a.src, a.sc, i, sel, dx, dy, dz);
@@ -253,16 +253,23 @@ extern "C" int ren_mlp_fwd_x(const float *mlp_params, int32_t C, int32_t mode, c
 }
 
 // ================================================================================================ backward
-// Saved-activation backward (the forward stored h, p, q), two persistent kernels as in ren_mlp.hip.
-// Data gradients (W^T dZ chains) use the same 6-term products as the forward.  Weight gradients are sums
-// over all samples of dz . act products: they use two pieces per operand and three terms (2^-16 per product,
-// far below the fp32 round-off of a 16.8 M-term fp32 sum), which halves the LDS transpose traffic:
-// each lane writes its sample's 16 tile values as bf16 pieces into T[piece][neuron][sample] and reads them
-// back along the sample axis as MFMA operands (k = sample).
+// Two persistent kernels (head, base), one wave per SIMD with the whole register file.  Data gradients (W^T dZ
+// chains) and weight gradients use the same term pairs as the forward: six bf16 products per fp32 product in MODE 6
+// (every product of the default path is formed to fp32 round-off), one in MODE 1.  The weight-gradient operands
+// (k = sample) come from the chain's own split operands by a transposition on the matrix cores (transpose_tile,
+// ren_mlp_xfrag.h): nothing is staged through the LDS, which holds the weight fragments only.
 namespace {
 
-constexpr int GRID_XH = 256, GRID_XB = 512;               // persistent workgroups of 4 waves: head one per CU (477
-                                                          // registers), base two per CU (fits 256 with 5 spills: 1.13 -> 0.99 ms)
+#ifndef REN_BASE_WAVES
+#define REN_BASE_WAVES 2                                  // waves per SIMD of the base kernel
+#endif
+#ifdef REN_NO_PHASE_FENCE
+#define REN_PHASE_FENCE() do { } while (0)
+#else
+#define REN_PHASE_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+
+constexpr int GRID_XH = 256, GRID_XB = 256 * REN_BASE_WAVES;   // persistent workgroups of 4 waves: head one per CU, base REN_BASE_WAVES
 
 struct BwdXHArgs {
     const float *params, *base_out, *acts;
@@ -288,13 +295,13 @@ template <int C, int MODE, bool RECOMP>
 __global__ __launch_bounds__(256, 1) void mlp_bwd_head_x_kernel(BwdXHArgs a) {
     using PR = Pairs<MODE>;
     using HL = HeadLds<MODE, RECOMP>;
-    constexpr int NT = PR::NT, NP = MODE == 1 ? 1 : 2;
+    constexpr int NT = PR::NT;
     constexpr int F_WH2T = HL::F_WH2T, F_WH1T = HL::F_WH1T, F_END = HL::F_END;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __bf16 *frag = reinterpret_cast<__bf16 *>(smem);
     float *w3 = reinterpret_cast<float *>(smem + F_END * 2);                       // [C][64] (+ pad), then bh1[64] bh2[64]
-    fill_frags_t<NT, 3>(frag + F_WH2T, a.params, 2, 4);                            // head.w1^T : rows = p index
-    fill_frags_t<NT, 2>(frag + F_WH1T, a.params, 1, 4);                            // head.w0^T : rows = v index
+    fill_frags_t<NT, 3, true>(frag + F_WH2T, a.params, 2, 4);                      // head.w1^T : rows = p index (odd chunks negated)
+    fill_frags_t<NT, 2, true>(frag + F_WH1T, a.params, 1, 4);                      // head.w0^T : rows = v index (odd chunks negated)
     if (RECOMP) {
         fill_frags<NT, 2>(frag + HL::F_WH1, a.params, 2, 2);                       // forward fragments of head.w0, head.w1
         fill_frags<NT, 3>(frag + HL::F_WH2, a.params, 2, 4);
@@ -309,19 +316,22 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_head_x_kernel(BwdXHArgs a) {
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int hi = lane >> 5, sl = lane & 31;
-    __bf16 *Tz = reinterpret_cast<__bf16 *>(smem + F_END * 2 + HL::TAIL_BYTES) + wave * (3 * NP * 32 * ST);
-    __bf16 *Ta = Tz + NP * 32 * ST, *Ta2 = Ta + NP * 32 * ST;
+    const bf16x8 sel0 = make_sel<0>(lane), sel1 = make_sel<1>(lane), sel_sh = make_sel<3>(lane);
     __syncthreads();
     const int64_t n_blk = (a.n + 31) >> 5;
 
-    // bias gradients = sums of dz over samples: kept per lane (= per sample slot) and reduced over the 32 lanes of
-    // a half once at the end, like the output-layer weights
+    // weight gradients: 32 x 32 tiles accumulated over the whole persistent loop.  head.b0's gradient rides in
+    // column v = 0 of acc_wh1 (that input slot carries no weight: the V operand holds 1 there); the other bias /
+    // output-layer sums are kept per lane (= per sample slot) and reduced over the 32 lanes of a half at the end
+    // the per-lane sums of head.b1 (and of the output layer for C == 1) are kept in lane-private LDS slots ([value / 4][lane]
+    // float4: one b128 read-modify-write per four values), which leaves their registers to the chain -- the C == 1
+    // kernel does not spill; C == 3 (Bayer sensors) keeps its 96 output-layer sums in registers
+    constexpr bool W3_LDS = C == 1;                            // slots 0..7: head.wo (C == 1), 8..15: head.b1
+    float4 *accl = reinterpret_cast<float4 *>(smem + F_END * 2 + HL::TAIL_BYTES) + wave * (16 * 64) + lane;
     f32x16 acc_wh2[2][2], acc_wh1[2];
-    float acc_w3[C][32], acc_bh2[2][16], acc_bh1[2][16], acc_bh3[C];
+    float acc_w3[W3_LDS ? 1 : C][32], acc_bh3[C];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int g = 0; g < 16; ++g) { acc_bh2[t][g] = 0.f; acc_bh1[t][g] = 0.f; }
+    for (int v = 0; v < 16; ++v) accl[v * 64] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
         acc_wh2[0][0][g] = 0.f; acc_wh2[0][1][g] = 0.f; acc_wh2[1][0][g] = 0.f; acc_wh2[1][1][g] = 0.f;
@@ -330,33 +340,81 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_head_x_kernel(BwdXHArgs a) {
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         acc_bh3[c] = 0.f;
+        if (!W3_LDS) {
 #pragma unroll
-        for (int k = 0; k < 32; ++k) acc_w3[c][k] = 0.f;
+            for (int k = 0; k < 32; ++k) acc_w3[c][k] = 0.f;
+        }
     }
 
-    for (int64_t blk = (int64_t)blockIdx.x * 4 + wave; blk < n_blk; blk += (int64_t)gridDim.x * 4) {
+    // One wave per SIMD hides no latency by itself: the block's global inputs are fetched one iteration ahead (the ray
+    // index of the packed stream two ahead, because the ray origin / direction loads depend on it).  Out-of-range
+    // blocks read clamped addresses and are never used.
+    const int64_t stride = (int64_t)gridDim.x * 4, blk0 = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t i_last = a.n - 1;
+    const bool packed = a.src.ray_indices != nullptr;
+    struct Staged { float pos[3], dir[3], tm, o[8], rgb[C], d_rgb[C], d_sigma; };
+    auto load_ray = [&](int64_t blk) -> int {
+        const int64_t i = min(blk * 32 + sl, i_last);
+        return packed ? a.src.ray_indices[i] : 0;
+    };
+    auto load_inputs = [&](int64_t blk, int ray, Staged &st) {
+        const int64_t i = min(blk * 32 + sl, i_last), b = min(blk, n_blk - 1);
+        if (packed) {
+            st.tm = (a.src.t_starts[i] + a.src.t_ends[i]) * 0.5f;
+            const float *ro = a.src.rays_o + 3 * (int64_t)ray, *rd = a.src.rays_d + 3 * (int64_t)ray;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { st.pos[k] = ro[k]; st.dir[k] = rd[k]; }
+        } else {
+            st.tm = 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { st.pos[k] = a.src.x_world[3 * i + k]; st.dir[k] = a.src.dirs ? a.src.dirs[3 * i + k] : (k == 2 ? 1.f : 0.f); }
+        }
+        const float *bo = a.base_out + b * (8 * 64) + lane;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) st.o[g] = bo[g * 64];
+#pragma unroll
+        for (int c = 0; c < C; ++c) { st.rgb[c] = a.rgb[i * C + c]; st.d_rgb[c] = a.d_rgb[i * C + c]; }
+        st.d_sigma = a.d_sigma[i];
+    };
+    Staged nxt;
+    int ray_nn = 0;
+    if (blk0 < n_blk) {
+        load_inputs(blk0, load_ray(blk0), nxt);
+        ray_nn = load_ray(blk0 + stride);
+    }
+
+    for (int64_t blk = blk0; blk < n_blk; blk += stride) {
         int zo = 0;
         asm volatile("" : "+v"(zo));
         const __bf16 *fr = frag + zo;
         const float *W3 = w3 + zo;
         const int64_t i = blk * 32 + sl;
         const bool live = i < a.n;
+        const Staged cur = nxt;
+        load_inputs(blk + stride, ray_nn, nxt);
+        ray_nn = load_ray(blk + 2 * stride);
         bool sel = false;
         float dx = 0.f, dy = 0.f, dz = 1.f;
-        if (live) sample_geom(a.src, a.sc, i, sel, dx, dy, dz);
+        if (live) {
+            // position (contracted -> selector, ngp.py:238) and view direction, as sample_geom()
+            float ux, uy, uz;
+            ren_contract(a.sc, cur.pos[0] + cur.dir[0] * cur.tm, cur.pos[1] + cur.dir[1] * cur.tm, cur.pos[2] + cur.dir[2] * cur.tm,
+                         ux, uy, uz);
+            sel = ux > 0.f && ux < 1.f && uy > 0.f && uy < 1.f && uz > 0.f && uz < 1.f;
+            dx = cur.dir[0]; dy = cur.dir[1]; dz = cur.dir[2];
+        }
         float shs[8], o[8];
         sh4_select(dx, dy, dz, hi, shs);
-        {
-            const float *bo = a.base_out + blk * (8 * 64) + lane;
 #pragma unroll
-            for (int g = 0; g < 8; ++g) o[g] = bo[g * 64];
-        }
+        for (int g = 0; g < 8; ++g) o[g] = cur.o[g];
+        const float o_sigma = o[0];                                // raw density (lanes hi = 0)
+        if (hi == 0) o[0] = 1.f;                                   // v = 0: weight 0 in the chain, the ones row of V^T
+        bf16x8 bv[2][3];                                           // V = [base_out | SH]: chain operand and source of V^T
+        split8<NT>(o, bv[0]);
+        split8<NT>(shs, bv[1]);
         float p[2][16], q[2][16];
-        bf16x8 bp[4][3];                                           // RECOMP: split p, reused by the weight-gradient staging
+        bf16x8 bp[4][3];                                           // split p: chain operand and source of p^T
         if (RECOMP) {
-            bf16x8 bv[2][3];
-            split8<NT>(o, bv[0]);
-            split8<NT>(shs, bv[1]);
             f32x16 pa[2], qa[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t)
@@ -384,91 +442,114 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_head_x_kernel(BwdXHArgs a) {
         } else {
             const float *ac = a.acts + blk * ACT_SAVE_FLOATS_X + lane;
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < 2; ++t) {
 #pragma unroll
                 for (int g = 0; g < 16; ++g) { p[t][g] = ac[((2 + t) * 16 + g) * 64]; q[t][g] = ac[((4 + t) * 16 + g) * 64]; }
+                split8<NT>(p[t], bp[2 * t]);
+                split8<NT>(p[t] + 8, bp[2 * t + 1]);
+            }
         }
+        REN_PHASE_FENCE();
+        // ---- p^T (k = sample operands of dW(head.w1))
+        bf16x8 pT[2][2][3];
+        transpose_tile<NT>(bp[0], bp[1], sel0, sel1, pT[0]);
+        transpose_tile<NT>(bp[2], bp[3], sel0, sel1, pT[1]);
+        REN_PHASE_FENCE();
         // ---- output layer: dz3, dW3, dq -> dz2 (fp32 VALU)
         float dz3[C];
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            dz3[c] = live ? a.d_rgb[i * C + c] * dsoftplus_from_out(a.rgb[i * C + c], 1.f) : 0.f;
+            dz3[c] = live ? cur.d_rgb[c] * dsoftplus_from_out(cur.rgb[c], 1.f) : 0.f;
             if (hi == 0) acc_bh3[c] += dz3[c];
         }
         float dz2[2][16];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const float qv = MODE == 1 ? (float)(__bf16)q[t][g] : q[t][g];
-                float dq = 0.f;
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 ab = accl[(8 + t * 4 + g4) * 64];
+                float4 aw = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (W3_LDS) aw = accl[(t * 4 + g4) * 64];
+                float w[4] = {aw.x, aw.y, aw.z, aw.w}, b[4] = {ab.x, ab.y, ab.z, ab.w};
 #pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    acc_w3[c][t * 16 + g] += dz3[c] * qv;
-                    dq += dz3[c] * W3[c * 64 + 32 * t + rowc(g) + 4 * hi];
+                for (int gi = 0; gi < 4; ++gi) {
+                    const int g = 4 * g4 + gi;
+                    const float qv = MODE == 1 ? (float)(__bf16)q[t][g] : q[t][g];
+                    float dq = 0.f;
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        if (W3_LDS) w[gi] += dz3[c] * qv;
+                        else acc_w3[c][t * 16 + g] += dz3[c] * qv;
+                        dq += dz3[c] * W3[c * 64 + 32 * t + rowc(g) + 4 * hi];
+                    }
+                    dz2[t][g] = dq * dsoftplus_from_out(q[t][g], 100.f);
+                    b[gi] += dz2[t][g];
                 }
-                dz2[t][g] = dq * dsoftplus_from_out(q[t][g], 100.f);
-                acc_bh2[t][g] += dz2[t][g];
+                if (W3_LDS) accl[(t * 4 + g4) * 64] = make_float4(w[0], w[1], w[2], w[3]);
+                accl[(8 + t * 4 + g4) * 64] = make_float4(b[0], b[1], b[2], b[3]);
             }
+        REN_PHASE_FENCE();
         // ---- dW(head.w1)[ot][it] += dz2(ot) . p(it)^T ;  d p = W1^T dz2   (dz2 is split once for both)
-        if (RECOMP) {
-            stage_pieces<NP>(Ta, bp[0], bp[1], hi, sl);
-            stage_pieces<NP>(Ta2, bp[2], bp[3], hi, sl);
-        } else {
-            stage_tile<NP>(Ta, p[0], hi, sl);
-            stage_tile<NP>(Ta2, p[1], hi, sl);
-        }
-        f32x16 dp[2];
+        f32x16 dp[2], dpn[2];                                      // even chunks | negated odd chunks
 #pragma unroll
-        for (int g = 0; g < 16; ++g) { dp[0][g] = 0.f; dp[1][g] = 0.f; }
+        for (int g = 0; g < 16; ++g) { dp[0][g] = 0.f; dp[1][g] = 0.f; dpn[0][g] = 0.f; dpn[1][g] = 0.f; }
         {
             bf16x8 bz[4][3];
 #pragma unroll
             for (int t = 0; t < 2; ++t) { split8<NT>(dz2[t], bz[2 * t]); split8<NT>(dz2[t] + 8, bz[2 * t + 1]); }
+            // the block's dW contributions are formed in FRESH accumulators and added to the persistent ones on the VALU
+            // (round to nearest) -- see dw_block() -- after the d p chain has been issued, so the adds do not wait
+            f32x16 tw[2][2];
 #pragma unroll
             for (int ot = 0; ot < 2; ++ot) {
-                stage_pieces<NP>(Tz, bz[2 * ot], bz[2 * ot + 1], hi, sl);
-                dw_tile<NP>(acc_wh2[ot][0], Tz, Ta, hi, sl);
-                dw_tile<NP>(acc_wh2[ot][1], Tz, Ta2, hi, sl);
-            }
 #pragma unroll
-            for (int c = 0; c < 4; ++c) mma2<MODE>(dp[0], dp[1], fr + F_WH2T, 4, c, bz[c], lane);
+                for (int g = 0; g < 16; ++g) { tw[ot][0][g] = 0.f; tw[ot][1][g] = 0.f; }
+                bf16x8 zT[2][3];
+                transpose_tile<NT>(bz[2 * ot], bz[2 * ot + 1], sel0, sel1, zT);
+                dw_acc2<MODE>(tw[ot][0], tw[ot][1], zT, pT[0], pT[1]);
+            }
+            mma2_pn<MODE>(dp[0], dp[1], dpn[0], dpn[1], fr + F_WH2T, 4, 0, 1, bz[0], bz[1], lane);
+            mma2_pn<MODE>(dp[0], dp[1], dpn[0], dpn[1], fr + F_WH2T, 4, 2, 3, bz[2], bz[3], lane);
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) { acc_wh2[ot][0][g] += tw[ot][0][g]; acc_wh2[ot][1][g] += tw[ot][1][g]; }
         }
+        REN_PHASE_FENCE();
         float dz1[2][16];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                dz1[t][g] = dp[t][g] * dsoftplus_from_out(p[t][g], 100.f);
-                acc_bh1[t][g] += dz1[t][g];
-            }
-        // ---- dW(head.w0)[ot] += dz1(ot) . V^T, V = [base_out(16) | SH(16)] in v order
-#pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            stage_one<NP>(Ta, rowc(g) + 4 * hi, o[g], sl);
-            stage_one<NP>(Ta, 16 + 2 * g + hi, shs[g], sl);
-        }
-        // ---- d V = W0^T dz1 (rows 0..15 = d base_out); row 0 takes the density gradient
+            for (int g = 0; g < 16; ++g) dz1[t][g] = (dp[t][g] - dpn[t][g]) * dsoftplus_from_out(p[t][g], 100.f);
+        // ---- dW(head.w0)[ot] += dz1(ot) . V^T (column v = 0: the bias gradient) ;  d V = W0^T dz1
         f32x16 dv, dv2;
 #pragma unroll
         for (int g = 0; g < 16; ++g) { dv[g] = 0.f; dv2[g] = 0.f; }
         {
+            bf16x8 vT[2][3];
+            transpose_tile<NT>(bv[0], bv[1], sel0, sel_sh, vT);
             bf16x8 bz[4][3];
 #pragma unroll
             for (int t = 0; t < 2; ++t) { split8<NT>(dz1[t], bz[2 * t]); split8<NT>(dz1[t] + 8, bz[2 * t + 1]); }
+            f32x16 tw[2];
 #pragma unroll
             for (int ot = 0; ot < 2; ++ot) {
-                stage_pieces<NP>(Tz, bz[2 * ot], bz[2 * ot + 1], hi, sl);
-                dw_tile<NP>(acc_wh1[ot], Tz, Ta, hi, sl);
+#pragma unroll
+                for (int g = 0; g < 16; ++g) tw[ot][g] = 0.f;
+                bf16x8 zT[2][3];
+                transpose_tile<NT>(bz[2 * ot], bz[2 * ot + 1], sel0, sel1, zT);
+                dw_acc<MODE>(tw[ot], zT, vT);
             }
             mma1x2<MODE>(dv, dv2, fr + F_WH1T, 4, 0, 1, bz[0], bz[1], lane);
             mma1x2<MODE>(dv, dv2, fr + F_WH1T, 4, 2, 3, bz[2], bz[3], lane);
 #pragma unroll
-            for (int g = 0; g < 16; ++g) dv[g] += dv2[g];
+            for (int g = 0; g < 16; ++g) { acc_wh1[0][g] += tw[0][g]; acc_wh1[1][g] += tw[1][g]; }
+#pragma unroll
+            for (int g = 0; g < 16; ++g) dv[g] -= dv2[g];
         }
-        if (hi == 0) {
-            const float ds = live ? a.d_sigma[i] : 0.f;
-            dv[0] = sel ? ds * __expf(fminf(o[0] - 1.f, 15.f)) : 0.f;              // ngp.py:54-58,247-250
+        if (hi == 0) {                                             // rows 0..15 = d base_out; row 0 takes the density gradient
+            const float ds = live ? cur.d_sigma : 0.f;
+            dv[0] = sel ? ds * __expf(fminf(o_sigma - 1.f, 15.f)) : 0.f;           // ngp.py:54-58,247-250
         }
         {
             float *db = a.d_base + blk * (8 * 64) + lane;
@@ -487,20 +568,21 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_head_x_kernel(BwdXHArgs a) {
             slab[O + P_HW1 + out * 64 + sl] = acc_wh2[ob][0][g];
             slab[O + P_HW1 + out * 64 + 32 + sl] = acc_wh2[ob][1][g];
             if (sl != 0) slab[O + P_HW0 + out * 31 + (sl < 16 ? 15 + sl : sl - 16)] = acc_wh1[ob][g];
+            else slab[O + P_HB0 + out] = acc_wh1[ob][g];
         }
 #pragma unroll
         for (int g = 0; g < 16; ++g) {                              // bias: sum over the 32 sample lanes of this half
-            float b2 = acc_bh2[ob][g], b1 = acc_bh1[ob][g];
+            float b2 = reinterpret_cast<const float *>(accl + (8 + ob * 4 + (g >> 2)) * 64)[g & 3];
 #pragma unroll
-            for (int off = 1; off < 32; off <<= 1) { b2 += __shfl_xor(b2, off, 64); b1 += __shfl_xor(b1, off, 64); }
-            if (sl == 0) { slab[O + P_HB1 + 32 * ob + rowc(g) + 4 * hi] = b2; slab[O + P_HB0 + 32 * ob + rowc(g) + 4 * hi] = b1; }
+            for (int off = 1; off < 32; off <<= 1) b2 += __shfl_xor(b2, off, 64);
+            if (sl == 0) slab[O + P_HB1 + 32 * ob + rowc(g) + 4 * hi] = b2;
         }
     }
 #pragma unroll
     for (int c = 0; c < C; ++c) {
 #pragma unroll
         for (int k = 0; k < 32; ++k) {
-            float v = acc_w3[c][k];
+            float v = W3_LDS ? reinterpret_cast<const float *>(accl + (k >> 2) * 64)[k & 3] : acc_w3[c][k];
 #pragma unroll
             for (int off = 1; off < 32; off <<= 1) v += __shfl_xor(v, off, 64);
             if (sl == 0) slab[O + P_HWO + c * 64 + 32 * (k >> 4) + rowc(k & 15) + 4 * hi] = v;
@@ -518,43 +600,50 @@ struct BwdXBArgs {
 
 template <int MODE, bool RECOMP> struct BaseLds {
     static constexpr int NT = Pairs<MODE>::NT;
-    static constexpr int F_W2T = 0, F_W1T = 2 * 1 * NT * 512, F_W1 = F_W1T + 1 * 4 * NT * 512;
+    // base.wo^T is stored twice, as it is and negated (F_W2TN): d h = Wo^T dO is a single 16-wide k-chunk, so there is no
+    // second chunk to pair it with; instead every other block of a wave computes -d h from the negated fragments (the sign
+    // is folded into the activation derivative), and the accumulate's rounding bias alternates in sign from block to
+    // block: it cancels in the sums over samples that base.b0 / base.w0 are
+    static constexpr int F_W2T = 0, F_W2TN = 2 * 1 * NT * 512, F_W1T = 2 * F_W2TN, F_W1 = F_W1T + 1 * 4 * NT * 512;
     static constexpr int F_END = F_W1 + (RECOMP ? 2 * 2 * NT * 512 : 0);
     static constexpr int TAIL_BYTES = RECOMP ? 64 * 4 : 0;                                           // b1[64]
 };
 
 template <int MODE, bool RECOMP>
-__global__ __launch_bounds__(256, 2) void mlp_bwd_base_x_kernel(BwdXBArgs a) {
+__global__ __launch_bounds__(256, REN_BASE_WAVES) void mlp_bwd_base_x_kernel(BwdXBArgs a) {
     using PR = Pairs<MODE>;
     using BL = BaseLds<MODE, RECOMP>;
-    constexpr int NT = PR::NT, NP = MODE == 1 ? 1 : 2;
+    constexpr int NT = PR::NT;
     constexpr int F_W2T = BL::F_W2T, F_W1T = BL::F_W1T, F_END = BL::F_END;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __bf16 *frag = reinterpret_cast<__bf16 *>(smem);
     float *b1 = reinterpret_cast<float *>(smem + F_END * 2);
     fill_frags_t<NT, 1>(frag + F_W2T, a.params, 2, 1);                             // base.wo^T : rows = h index, 1 chunk (16 outs)
-    fill_frags_t<NT, 0>(frag + F_W1T, a.params, 1, 4);                             // base.w0^T : rows = feature index
+    fill_frags_t<NT, 1>(frag + BL::F_W2TN, a.params, 2, 1);
+    __syncthreads();
+    for (int e = threadIdx.x; e < BL::F_W2TN; e += blockDim.x) frag[BL::F_W2TN + e] = -frag[BL::F_W2TN + e];
+    fill_frags_t<NT, 0, true>(frag + F_W1T, a.params, 1, 4);                       // base.w0^T : rows = feature index (odd chunks negated)
     if (RECOMP) {
         fill_frags<NT, 0>(frag + BL::F_W1, a.params, 2, 2);                        // forward fragments of base.w0
         for (int i = threadIdx.x; i < 64; i += blockDim.x) b1[i] = a.params[P_BB0 + i];
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int hi = lane >> 5, sl = lane & 31;
-    __bf16 *Tz = reinterpret_cast<__bf16 *>(smem + F_END * 2 + BL::TAIL_BYTES) + wave * (2 * NP * 32 * ST);
-    __bf16 *Ta = Tz + NP * 32 * ST;
-    for (int k = lane; k < 2 * NP * 32 * ST; k += 64) Tz[k] = (__bf16)0.f;          // dO rows 16..31 stay zero
+    const bf16x8 sel0 = make_sel<0>(lane), sel1 = make_sel<1>(lane), sel_x0 = make_sel<2>(lane), sel_x1 = make_sel<3>(lane);
     __syncthreads();
     const int64_t n_blk = (a.n + 31) >> 5;
+    // base.b0's 32 per-lane sums live in lane-private LDS slots ([value / 4][lane] float4), as in the head kernel
+    // (slots 0..7: base.b0, 8..9: base.bo)
+    float4 *accl = reinterpret_cast<float4 *>(smem + F_END * 2 + BL::TAIL_BYTES) + wave * (10 * 64) + lane;
     f32x16 acc_w2[2], acc_w1[2];
-    float acc_b2[8], acc_b1[2][16];
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
         acc_w2[0][g] = 0.f; acc_w2[1][g] = 0.f; acc_w1[0][g] = 0.f; acc_w1[1][g] = 0.f;
-        acc_b1[0][g] = 0.f; acc_b1[1][g] = 0.f;
-        if (g < 8) acc_b2[g] = 0.f;
+        if (g < 10) accl[g * 64] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 
-    for (int64_t blk = (int64_t)blockIdx.x * 4 + wave; blk < n_blk; blk += (int64_t)gridDim.x * 4) {
+    bool flip = false;
+    for (int64_t blk = (int64_t)blockIdx.x * 4 + wave; blk < n_blk; blk += (int64_t)gridDim.x * 4, flip = !flip) {
         int zo = 0;
         asm volatile("" : "+v"(zo));
         const __bf16 *fr = frag + zo;
@@ -574,11 +663,11 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_base_x_kernel(BwdXBArgs a) {
                     for (int g = 0; g < 16; ++g) h[t][g] = ac[(t * 16 + g) * 64];
             }
         }
-        bf16x8 bx[2][3];                                           // RECOMP: split x, reused by the weight-gradient staging
+        bf16x8 bx[2][3];                                           // split x: chain operand (RECOMP) and source of x^T
+        split8<NT>(x, bx[0]);
+        split8<NT>(x + 8, bx[1]);
         if (RECOMP) {
             const float *B1 = b1 + zo;
-            split8<NT>(x, bx[0]);
-            split8<NT>(x + 8, bx[1]);
             f32x16 ha[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t)
@@ -591,62 +680,73 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_base_x_kernel(BwdXBArgs a) {
 #pragma unroll
                 for (int g = 0; g < 16; ++g) h[t][g] = softplus100(ha[t][g]);
         }
-        // ---- dW(base.wo)[it] += dO . h(it)^T   (dO: 16 real rows of a 32-row tile)
+        // ---- dW(base.wo)[it] += dO . h(it)^T   (dO: 16 real rows = ONE chain operand; rows 16..31 of the tile stay zero)
+        bf16x8 bo[3];
+        split8<NT>(dob, bo);
 #pragma unroll
-        for (int g = 0; g < 8; ++g) { stage_one<NP>(Tz, rowc(g) + 4 * hi, dob[g], sl); acc_b2[g] += dob[g]; }
+        for (int g4 = 0; g4 < 2; ++g4) {
+            const float4 ab = accl[(8 + g4) * 64];
+            accl[(8 + g4) * 64] = make_float4(ab.x + dob[4 * g4], ab.y + dob[4 * g4 + 1], ab.z + dob[4 * g4 + 2], ab.w + dob[4 * g4 + 3]);
+        }
+        {
+            bf16x8 oT[2][3];
+            transpose_half<NT>(bo, sel0, oT);
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            stage_tile<NP>(Ta, h[it], hi, sl);
-            dw_tile<NP>(acc_w2[it], Tz, Ta, hi, sl);
+            for (int it = 0; it < 2; ++it) {
+                bf16x8 bh[2][3], hT[2][3];
+                split8<NT>(h[it], bh[0]);
+                split8<NT>(h[it] + 8, bh[1]);
+                transpose_tile<NT>(bh[0], bh[1], sel0, sel1, hT);
+                dw_block<MODE>(acc_w2[it], oT, hT);
+            }
         }
         // ---- d h = Wo^T dO (one k-chunk: slot j -> base_out neuron rowc(j) + 4 hi) ; dz0 = d h * softplus'(h)
         f32x16 dh[2];
 #pragma unroll
         for (int g = 0; g < 16; ++g) { dh[0][g] = 0.f; dh[1][g] = 0.f; }
-        {
-            bf16x8 bo[3];
-            split8<NT>(dob, bo);
-            mma2<MODE>(dh[0], dh[1], fr + F_W2T, 1, 0, bo, lane);
-        }
+        mma2<MODE>(dh[0], dh[1], fr + (flip ? BL::F_W2TN : F_W2T), 1, 0, bo, lane);      // flip: -d h
+        const float sgn = flip ? -1.f : 1.f;
         float dz0[2][16];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                dz0[t][g] = dh[t][g] * dsoftplus_from_out(h[t][g], 100.f);
-                acc_b1[t][g] += dz0[t][g];
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 ab = accl[(t * 4 + g4) * 64];
+                float b[4] = {ab.x, ab.y, ab.z, ab.w};
+#pragma unroll
+                for (int gi = 0; gi < 4; ++gi) {
+                    const int g = 4 * g4 + gi;
+                    // softplus'(beta = 100) through the output, times the block's sign: sgn (1 - exp(-100 h))
+                    dz0[t][g] = dh[t][g] * fmaf(-sgn, __builtin_amdgcn_exp2f(h[t][g] * -144.26950408889634f), sgn);
+                    b[gi] += dz0[t][g];
+                }
+                accl[(t * 4 + g4) * 64] = make_float4(b[0], b[1], b[2], b[3]);
             }
-        // ---- dW(base.w0)[ot] += dz0(ot) . x^T   (x row = feature index 2 s + hi)
-        if (RECOMP) {
-#pragma unroll
-            for (int k = 0; k < NP; ++k)
-#pragma unroll
-                for (int s = 0; s < 16; ++s) Ta[(k * 32 + 2 * s + hi) * ST + sl] = bx[s >> 3][k][s & 7];
-        } else {
-#pragma unroll
-            for (int s = 0; s < 16; ++s) stage_one<NP>(Ta, 2 * s + hi, x[s], sl);
-        }
-        // ---- d x = W0^T dz0 -> hash-feature gradient, fragment layout (dz0 is split once for both uses)
+        // ---- dW(base.w0)[ot] += dz0(ot) . x^T ;  d x = W0^T dz0 -> hash-feature gradient, fragment layout
         f32x16 dxv, dxv2;
 #pragma unroll
         for (int g = 0; g < 16; ++g) { dxv[g] = 0.f; dxv2[g] = 0.f; }
         {
+            bf16x8 xT[2][3];
+            transpose_tile<NT>(bx[0], bx[1], sel_x0, sel_x1, xT);
             bf16x8 bz[4][3];
 #pragma unroll
             for (int t = 0; t < 2; ++t) { split8<NT>(dz0[t], bz[2 * t]); split8<NT>(dz0[t] + 8, bz[2 * t + 1]); }
+            f32x16 tw[2];
 #pragma unroll
             for (int ot = 0; ot < 2; ++ot) {
-                // Tz rows 16..31 are overwritten here; the dO staging of the next block rewrites rows 0..15 only,
-                // so the zero rows are restored below
-                stage_pieces<NP>(Tz, bz[2 * ot], bz[2 * ot + 1], hi, sl);
-                dw_tile<NP>(acc_w1[ot], Tz, Ta, hi, sl);
-            }
 #pragma unroll
-            for (int g = 8; g < 16; ++g) stage_one<NP>(Tz, rowc(g) + 4 * hi, 0.f, sl);
+                for (int g = 0; g < 16; ++g) tw[ot][g] = 0.f;
+                bf16x8 zT[2][3];
+                transpose_tile<NT>(bz[2 * ot], bz[2 * ot + 1], sel0, sel1, zT);
+                dw_acc<MODE>(tw[ot], zT, xT);
+            }
             mma1x2<MODE>(dxv, dxv2, fr + F_W1T, 4, 0, 1, bz[0], bz[1], lane);
             mma1x2<MODE>(dxv, dxv2, fr + F_W1T, 4, 2, 3, bz[2], bz[3], lane);
 #pragma unroll
-            for (int g = 0; g < 16; ++g) dxv[g] += dxv2[g];
+            for (int g = 0; g < 16; ++g) { acc_w1[0][g] += tw[0][g]; acc_w1[1][g] += tw[1][g]; }
+#pragma unroll
+            for (int g = 0; g < 16; ++g) dxv[g] -= dxv2[g];
         }
         {
             float *df = a.dfeat + blk * (16 * 64) + sl;
@@ -670,7 +770,8 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_base_x_kernel(BwdXBArgs a) {
     }
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
-        float b2 = g < 8 ? acc_b2[g] : 0.f, b10 = acc_b1[0][g], b11 = acc_b1[1][g];
+        float b2 = g < 8 ? reinterpret_cast<const float *>(accl + (8 + (g >> 2)) * 64)[g & 3] : 0.f, b10 = reinterpret_cast<const float *>(accl + (g >> 2) * 64)[g & 3],
+              b11 = reinterpret_cast<const float *>(accl + (4 + (g >> 2)) * 64)[g & 3];
 #pragma unroll
         for (int off = 1; off < 32; off <<= 1) {
             b2 += __shfl_xor(b2, off, 64); b10 += __shfl_xor(b10, off, 64); b11 += __shfl_xor(b11, off, 64);
@@ -685,12 +786,10 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_base_x_kernel(BwdXBArgs a) {
 
 template <int MODE, bool RECOMP>
 int launch_bwd_x(const BwdXHArgs &h, const BwdXBArgs &b, int C, float *grad, hipStream_t st) {
-    constexpr int NP = MODE == 1 ? 1 : 2;
     using HL = HeadLds<MODE, RECOMP>;
     using BL = BaseLds<MODE, RECOMP>;
-    const size_t tile = (size_t)NP * 32 * ST * 2;
-    const size_t lds_h = (size_t)HL::F_END * 2 + HL::TAIL_BYTES + 4 * 3 * tile;
-    const size_t lds_b = (size_t)BL::F_END * 2 + BL::TAIL_BYTES + 4 * 2 * tile;
+    const size_t lds_h = (size_t)HL::F_END * 2 + HL::TAIL_BYTES + 4 * 16 * 64 * sizeof(float4);
+    const size_t lds_b = (size_t)BL::F_END * 2 + BL::TAIL_BYTES + 4 * 10 * 64 * sizeof(float4);
     if (C == 1) {
         (void)hipFuncSetAttribute((const void *)mlp_bwd_head_x_kernel<1, MODE, RECOMP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h);
         hipLaunchKernelGGL((mlp_bwd_head_x_kernel<1, MODE, RECOMP>), dim3(GRID_XH), dim3(256), lds_h, st, h);

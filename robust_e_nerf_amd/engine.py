@@ -282,6 +282,19 @@ class Renderer:
         main.wait_stream(s_mlp)
         return rgb, sigma, dict(feat=feat, base=base, acts=acts, xmode=self._xmode() if save else None)
 
+    # ---- data parallelism: the slice of the packed gradient buffer that is reduced beside the rest of the backward ----
+    def dp_early_slice(self) -> Optional[Tuple[int, int]]:
+        """element range [start, stop) of field.grad_all whose all-reduce starts inside the step's LAST backward pass (the
+        fine hash levels), or None.  A function of the configuration only, so every rank issues the same collectives."""
+        if self.grad_sync is None or not self.cfg.dp_overlap or not self.cfg.binned_scatter:
+            return None
+        f = self.field
+        return 2 * int(f.grid.offset[self.cfg.dp_split_level]), f.n_table
+
+    def dp_early(self):
+        a, b = self.dp_early_slice()
+        self.grad_sync.early(self.field.grad_all, a, b)
+
     def _field_backward(self, ctx, d_rgb, d_sig, final: bool = False):
         f, pk = self.field, ctx["pk"]
         samples = (pk.ray_indices, pk.t_starts, pk.t_ends)
@@ -302,12 +315,12 @@ class Renderer:
         if self.cfg.binned_scatter:
             self._binned_workspace(pk.n, dfeat.device)
             kw = dict(scene=self.scene, rays=(ctx["o"], ctx["d"]), samples=samples, n=pk.n, layout=1)
-            if final and self.grad_sync is not None and self.cfg.dp_overlap:
+            if final and self.dp_early_slice() is not None:
                 # last backward of the step under data parallelism: fine levels first, their slice of the table gradient
                 # is all-reduced while the coarse levels are scattered
                 lo_mask = (1 << self.cfg.dp_split_level) - 1
                 ops.hashgrid_bwd_binned(f.grid, f.g_table, dfeat, self._bin_ws, level_mask=0xFFFF & ~lo_mask, **kw)
-                self.grad_sync.early(f.grad_all, 2 * int(f.grid.offset[self.cfg.dp_split_level]), f.n_table)
+                self.dp_early()
                 ops.hashgrid_bwd_binned(f.grid, f.g_table, dfeat, self._bin_ws, level_mask=lo_mask, **kw)
             else:
                 ops.hashgrid_bwd_binned(f.grid, f.g_table, dfeat, self._bin_ws, **kw)
@@ -338,6 +351,10 @@ class Renderer:
         """final: this is the last backward pass of the step (its gradients are complete when it returns)"""
         f = self.field
         if ctx["empty"]:
+            # a rank without a single sample must still issue the collectives its peers issue (the slice is final here:
+            # this pass adds nothing to it) -- otherwise the ranks' all-reduce sequences differ and RCCL hangs
+            if final and self.dp_early_slice() is not None:
+                self.dp_early()
             return g_colors.sum(0) if ctx.get("bkgd") is not None else None
         pk = ctx["pk"]
         d_sig, d_rgb, d_bk = ops.composite_bwd(pk.offsets, pk.counts, pk.t_starts, pk.t_ends, ctx["sigma"],
@@ -675,7 +692,7 @@ class Trainer:
                    opacity=opac, rays=2 * B)
         return loss, aux
 
-    def grad_loss_forward_backward(self, batch, jitter_grad=None):
+    def grad_loss_forward_backward(self, batch, jitter_grad=None, final: bool = True):
         """Log-intensity-GRADIENT loss term (robust_e_nerf.py:340-357,383-409; loss.py:43-57): a third
         render at grad.ts = lerp(diff.start, diff.end, u_grad) carrying d/dt in forward mode, compared
         with the event rate C/dt.  Accumulates gradients; returns (weighted loss term, aux)."""
@@ -713,7 +730,7 @@ class Trainer:
             _, _, colorsdd = jvp.render_forward2(r, o, d, od, dd, ddd, ctx["pk"], bkgd)
             per_ev = g_i.double() * intend.double() + g_id.double() * self._bayer(colorsdd, ch).double()
             self._tau_grad_dev += (per_ev * prep["dts_grad"]).sum()
-        d_bkgd = jvp.render_backward(r, ctx, self._unbayer(g_i, ch, f.C), self._unbayer(g_id, ch, f.C), final=True)
+        d_bkgd = jvp.render_backward(r, ctx, self._unbayer(g_i, ch, f.C), self._unbayer(g_id, ch, f.C), final=final)
         if d_bkgd is not None:
             self.small_grad[: f.C] += d_bkgd * torch.sigmoid(self.small[: f.C])
         aux = dict(intensity=inten, dlog_dt=intend / inten, n=ctx["pk"].n, rays=B)
@@ -844,9 +861,13 @@ class Trainer:
         bi = 0 if batch_index is None else batch_index
         if global_step is not None and bi % k == 0:
             self.r.update_occ_grid(global_step, self.tab_pos)
-        loss, aux = self.forward_backward(batch, jitter_start, jitter_end)
+        # only the LAST backward pass of the LAST micro-batch may start the early all-reduce of the fine levels' slice:
+        # an earlier pass would reduce it once per micro-batch (the rank-summed slice of micro-batch 1 would be summed
+        # over the ranks again with micro-batch 2 on top) and the next scatter would write into a slice in flight
+        last = (bi + 1) % k == 0
+        loss, aux = self.forward_backward(batch, jitter_start, jitter_end, final=last and not (self.t.w_grad > 0))
         if self.t.w_grad > 0:
-            lg, aux_g = self.grad_loss_forward_backward(batch, jitter_grad)
+            lg, aux_g = self.grad_loss_forward_backward(batch, jitter_grad, final=last)
             loss = loss + lg
             aux = dict(aux, grad=aux_g)
         if (bi + 1) % k == 0:

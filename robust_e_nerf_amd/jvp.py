@@ -147,6 +147,8 @@ def render_backward(r, ctx, g_colors, g_colords, final: bool = False):
     """Accumulates into r.field.grad; returns d(bkgd) (C,) or None.  final: last backward pass of the step."""
     f, lib = r.field, _lib.load()
     if ctx["empty"]:
+        if final and r.dp_early_slice() is not None:         # same collective sequence on every rank (Renderer.backward)
+            r.dp_early()
         return g_colors.sum(0) if ctx.get("bkgd") is not None else None
     pk = ctx["pk"]
     n, R, dev = pk.n, ctx["o"].shape[0], ctx["o"].device
@@ -185,10 +187,10 @@ def render_backward(r, ctx, g_colors, g_colords, final: bool = False):
         r._binned_workspace(n, dev)
         kw = dict(scene=r.scene, rays=(ctx["o"], ctx["d"]), samples=(ri, ts, te), n=n, layout=1,
                   tangent=(ctx["od"], ctx["dd"], dfeatd))
-        if final and r.grad_sync is not None and r.cfg.dp_overlap:   # see Renderer._field_backward
+        if final and r.dp_early_slice() is not None:          # see Renderer._field_backward
             lo_mask = (1 << r.cfg.dp_split_level) - 1
             ops.hashgrid_bwd_binned(f.grid, f.g_table, dfeat, r._bin_ws, level_mask=0xFFFF & ~lo_mask, **kw)
-            r.grad_sync.early(f.grad_all, 2 * int(f.grid.offset[r.cfg.dp_split_level]), f.n_table)
+            r.dp_early()
             ops.hashgrid_bwd_binned(f.grid, f.g_table, dfeat, r._bin_ws, level_mask=lo_mask, **kw)
         else:
             ops.hashgrid_bwd_binned(f.grid, f.g_table, dfeat, r._bin_ws, **kw)

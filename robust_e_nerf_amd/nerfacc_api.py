@@ -35,11 +35,14 @@ class OccupancyGrid(torch.nn.Module):
         if isinstance(resolution, int):
             resolution = [resolution] * 3
         assert len(resolution) == 3
-        self.resolution = [int(r) for r in resolution]
+        self._res = [int(r) for r in resolution]
         self.contraction_type = contraction_type
-        self.num_cells = self.resolution[0] * self.resolution[1] * self.resolution[2]
+        self.num_cells = self._res[0] * self._res[1] * self._res[2]
         self.register_buffer("_roi_aabb", torch.as_tensor(roi_aabb, dtype=torch.float32).flatten())
-        self.register_buffer("_binary", torch.zeros(self.resolution, dtype=torch.bool))
+        # nerfacc 0.3.1 keeps the resolution as a persistent int32 buffer: the key `nerf.occupancy_grid.resolution` of a
+        # reference checkpoint must load with strict=True
+        self.register_buffer("resolution", torch.tensor(self._res, dtype=torch.int32))
+        self.register_buffer("_binary", torch.zeros(self._res, dtype=torch.bool))
         self.register_buffer("occs", torch.zeros(self.num_cells, dtype=torch.float32))
         self.register_buffer("_scratch", torch.zeros(4, dtype=torch.float32), persistent=False)
 
@@ -68,13 +71,13 @@ class OccupancyGrid(torch.nn.Module):
         if jitter is None:
             jitter = torch.rand(indices.shape[0], 3, device=dev)
         roi = self._roi_aabb.tolist()
-        x, valid = ops.occgrid_cell_points(indices.contiguous(), jitter.contiguous(), roi, self.resolution,
+        x, valid = ops.occgrid_cell_points(indices.contiguous(), jitter.contiguous(), roi, self._res,
                                            self.contraction_type.value)
         occ = occ_eval_fn(x).reshape(-1).to(torch.float32).contiguous()
         ops.occgrid_ema(self.occs, indices.contiguous(), valid, occ, None, 1.0, ema_decay)
         binary_u8 = torch.empty(self.num_cells, device=dev, dtype=torch.uint8)
         ops.occgrid_binarize(self.occs, occ_thre, binary_u8, self._scratch)
-        self._binary = binary_u8.view(self.resolution).bool()
+        self._binary = binary_u8.view(self._res).bool()
 
     def every_n_step(self, step: int, occ_eval_fn: Callable, occ_thre: float = 1e-2, ema_decay: float = 0.95,
                      warmup_steps: int = 256, n: int = 16):
@@ -112,7 +115,7 @@ def ray_marching(rays_o, rays_d, t_min=None, t_max=None, scene_aabb=None, grid: 
     if stratified and jitter is None:
         jitter = torch.rand(n_rays, device=rays_o.device)
     if grid is not None:
-        roi, res, binary, ct = grid._roi_aabb.tolist(), grid.resolution, grid._binary.contiguous().view(-1), \
+        roi, res, binary, ct = grid._roi_aabb.tolist(), grid._res, grid._binary.contiguous().view(-1), \
             grid.contraction_type.value
     else:
         roi, res, ct = [-1e10] * 3 + [1e10] * 3, [1, 1, 1], 0

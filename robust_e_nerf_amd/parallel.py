@@ -76,6 +76,9 @@ class GradSync:
         if self.world <= 1 or stop <= start:
             return
         assert stop <= buf.numel() - self.n_exact_tail
+        # a range is reduced ONCE per optimiser step: a second launch would sum the already rank-summed values again
+        assert all(stop <= a or b <= start for a, b in self.done), \
+            f"gradient range [{start}, {stop}) was already all-reduced in this step: {self.done}"
         self._launch(buf[start:stop], exact=False)
         self.done.append((start, stop))
 

@@ -115,6 +115,9 @@ class VanillaRenderer(Renderer):
         self._bwd_weight = ops._wrap("dense_bwd_weight", self._bwd_weight)
         self._encode = ops._wrap("freq_encode", self._encode)
 
+    def dp_early_slice(self):
+        return None                                 # no hash table: the 2.4 MB of dense weights go in the one packed all-reduce
+
     # ---- kernels ------------------------------------------------------------------------------------
     def _dense_mode(self) -> int:
         """matrix-core path of ren_dense_fwd / ren_dense_bwd_data: 0 exact f32 MFMA, 6 split-bf16 at fp32 accuracy,
