@@ -379,6 +379,38 @@ def main():
         n_samples = float(ns)
     rays = (3 if args.loss_grad > 0 else 2) * B * args.steps * world
 
+    # N > 1, default (weak) run: the reference's own semantics as a second measurement in the same JSON line -- a fixed
+    # GLOBAL batch (train_eff_ray_sample_batch_size // num_gpus, robust_e_nerf.py:63-66): every rank takes events // N.
+    # One driver run per N then yields both curves.
+    strong = None
+    if world > 1 and args.scaling == "weak" and not rccl_single:
+        B_weak = B
+        B = max(1, args.events // world)
+        batches = []
+        for b in range(n_batches):
+            ev = synthetic_events(B, int(tab_ts[-1]), seed=1 + 1000 * rank + b,
+                                  **(dict(width=640, height=480) if args.workload == "e" else {}))
+            batches.append({k: T(v).to(dev).contiguous() for k, v in ev.items()})
+        staged.clear()
+        for i in range(args.warmup):
+            one_step(i)
+        barrier()
+        t0s = time.perf_counter()
+        ns_s = 0
+        for i in range(args.steps):
+            _, aux_s = one_step(i)
+            ns_s += aux_s["n"]
+        barrier()
+        dts = torch.tensor([time.perf_counter() - t0s, float(ns_s)], device=dev, dtype=torch.float64)
+        tmax = dts[:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(dts[1:])
+        rays_s = (3 if args.loss_grad > 0 else 2) * B * args.steps * world
+        strong = {"scaling": "strong", "events_per_step_global": B * world, "events_per_step_per_gpu": B,
+                  "value": rays_s / float(tmax), "unit": "rays/s", "ms_per_step": float(tmax) / args.steps * 1e3,
+                  "mlp_samples_per_sec": float(dts[1]) / float(tmax), "steps": args.steps, "warmup": args.warmup}
+        B = B_weak
+
     if rank == 0:
         kern = {k: {"launches": c, "avg_ms": ms / max(c, 1)} for k, (c, ms) in prof.items()}
         dom = max(list(BYTES) + list(FLOPS), key=lambda k: prof.get(k, (0, 0.0))[1])
@@ -430,6 +462,8 @@ def main():
             "roofline": roof,
             "kernels": kern,
         }
+        if strong is not None:
+            out["strong_scaling"] = strong
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, scene, {k: v.clone() for k, v in p.items()}, 0)
         os.write(json_fd, (json.dumps(out) + "\n").encode())

@@ -39,7 +39,8 @@ def render_pixels(r: Renderer, Kinv: torch.Tensor, px: torch.Tensor, pos: torch.
 
 @torch.no_grad()
 def render_image(r: Renderer, Kinv: torch.Tensor, cam_pos: torch.Tensor, cam_rot: torch.Tensor, height: int,
-                 width: int, bkgd: Optional[torch.Tensor] = None, chunk: Optional[int] = None):
+                 width: int, bkgd: Optional[torch.Tensor] = None, chunk: Optional[int] = None,
+                 rows: Optional[Tuple[int, int]] = None):
     """evaluation_step: (H, W) predicted intensity ((3, H, W) for radiance_dim 3), opacity, depth for one pose.  ``chunk`` is the reference's
     ``test_chunk_size`` (16 384 there, to fit a 2080 Ti); with 288 GB a 640x480 image is one chunk, which is 4x
     faster than 19 chunks (2.6 vs 10.3 ms, tools/render_bench.py).  The result does not depend on it.  Default: one
@@ -48,7 +49,11 @@ def render_image(r: Renderer, Kinv: torch.Tensor, cam_pos: torch.Tensor, cam_rot
     if chunk is None:
         chunk = (1 << 20) if isinstance(r.field, NGPField) else 16384
     dev = Kinv.device
-    px = pixel_grid(height, width, dev).reshape(-1, 2)
+    px = pixel_grid(height, width, dev)
+    if rows is not None:                                               # a band of image rows (render_image_sharded)
+        px = px[rows[0]: rows[1]]
+        height = rows[1] - rows[0]
+    px = px.reshape(-1, 2)
     n = px.shape[0]
     C = r.field.C
     out_i = torch.empty((n,) if C == 1 else (n, C), device=dev)
@@ -62,6 +67,60 @@ def render_image(r: Renderer, Kinv: torch.Tensor, cam_pos: torch.Tensor, cam_rot
         out_i[s:e], out_o[s:e], out_d[s:e] = i, o, d
     img = out_i.view(height, width) if C == 1 else out_i.view(height, width, C).permute(2, 0, 1).contiguous()
     return img, out_o.view(height, width), out_d.view(height, width)
+
+
+# ---- data-parallel evaluation: collective C3 of SURVEY 2.3 (`self.all_gather(outputs)`, robust_e_nerf.py:591) ------------
+def view_shard(n_views: int, rank: int, world: int):
+    """indices of the evaluation views this rank renders: torch's DistributedSampler(shuffle=False) as Lightning's DDP
+    installs it on the reference's val / test loaders (scripts/run.py:81-93) -- the index list is padded to a multiple of
+    the world size by wrapping around, rank r takes r, r + world, ..."""
+    if n_views == 0:
+        return []
+    per = -(-n_views // world)
+    idx = list(range(n_views))
+    while len(idx) < per * world:                                      # DistributedSampler: repeat from the start
+        idx += idx[: per * world - len(idx)]
+    return idx[rank: per * world: world]
+
+
+def gather_views(local: torch.Tensor, n_views: int, rank: int, world: int, group=None) -> torch.Tensor:
+    """`local`: (len(view_shard(...)), ...) outputs of this rank's views -> (n_views, ...) on every rank, in view order
+    (all_gather of equal-sized blocks; the wrap-around duplicates are dropped)."""
+    if world == 1:
+        return local
+    import torch.distributed as dist
+    blocks = [torch.empty_like(local) for _ in range(world)]
+    dist.all_gather(blocks, local.contiguous(), group=group)
+    out = torch.empty((n_views,) + tuple(local.shape[1:]), device=local.device, dtype=local.dtype)
+    seen = set()
+    for r_ in range(world):
+        for j, v in enumerate(view_shard(n_views, r_, world)):
+            if v not in seen:
+                out[v] = blocks[r_][j]
+                seen.add(v)
+    return out
+
+
+@torch.no_grad()
+def render_image_sharded(r: Renderer, Kinv, cam_pos, cam_rot, height: int, width: int, bkgd=None, *, rank: int, world: int,
+                         group=None, chunk: Optional[int] = None):
+    """ONE image rendered by all ranks (BASELINE configs[4]: a 640x480 novel view on 8 GPUs): rank r renders a band of
+    ceil(H / world) rows, the bands are all-gathered (3 x H x W floats over xGMI).  Same result as render_image."""
+    if world == 1:
+        return render_image(r, Kinv, cam_pos, cam_rot, height, width, bkgd, chunk)
+    import torch.distributed as dist
+    per = -(-height // world)
+    lo, hi = min(rank * per, height), min((rank + 1) * per, height)
+    C = r.field.C
+    band = torch.zeros(C + 2, per, width, device=Kinv.device)          # intensity (C) | opacity | depth
+    if hi > lo:
+        img, opac, depth = render_image(r, Kinv, cam_pos, cam_rot, height, width, bkgd, chunk, rows=(lo, hi))
+        band[:C, : hi - lo] = img if C > 1 else img[None]
+        band[C, : hi - lo], band[C + 1, : hi - lo] = opac, depth
+    bands = [torch.empty_like(band) for _ in range(world)]
+    dist.all_gather(bands, band, group=group)
+    full = torch.cat(bands, dim=1)[:, :height]
+    return (full[0] if C == 1 else full[:C].contiguous()), full[C], full[C + 1]
 
 
 def affine_align_log(pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:

@@ -106,6 +106,13 @@ def _worker(rank, port, out_dir):
     assert csync.reset_count() == 4                          # early slice, the two remaining ranges, the fp32 aux block
     assert torch.equal(b3[n_pad:], want[n_pad:])
     assert float(((b3[:n_pad] - want[:n_pad]).abs() / want[:n_pad].clamp_min(1.0)).max()) < 2 ** -7
+    # ---- evaluation: views sharded like DistributedSampler(shuffle=False), outputs all-gathered (C3, robust_e_nerf.py:591)
+    from robust_e_nerf_amd import evaluation
+    for n_views in (1, 4, 5):
+        mine = evaluation.view_shard(n_views, rank, WORLD)
+        local = torch.stack([torch.full((2, 3), float(v)) for v in mine])
+        allv = evaluation.gather_views(local, n_views, rank, WORLD)
+        assert allv.shape == (n_views, 2, 3) and torch.equal(allv[:, 0, 0], torch.arange(n_views, dtype=torch.float32))
     if rank == 0:
         torch.save({"grad_sum": grad, "loss0": loss}, os.path.join(out_dir, "r0.pt"))
     dist.barrier()
@@ -130,6 +137,16 @@ def test_two_rank_gradient_allreduce_matches_full_batch(tmp_path):
     # Adam normalises each coordinate by sqrt(v): compare only coordinates with a non-negligible gradient
     m = full.abs() > 1e-3 * full.abs().max()
     assert float((a - b)[m].abs().max()) < 1e-4 * 0.01 * 10
+
+
+def test_view_shard_is_distributed_sampler_without_shuffle():
+    from torch.utils.data.distributed import DistributedSampler
+    from robust_e_nerf_amd import evaluation
+    for n in (1, 2, 5, 8, 9):
+        for w in (1, 2, 3, 8):
+            for r in range(w):
+                ref = list(DistributedSampler(list(range(n)), num_replicas=w, rank=r, shuffle=False))
+                assert evaluation.view_shard(n, r, w) == ref, (n, w, r)
 
 
 def test_shard_bounds_cover_everything():

@@ -1611,6 +1611,9 @@ def test_bench_n_rank_contract_selftest():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["config"]["parallelism"] == "dp2"
     assert d["value"] > 0 and "cpu_baseline" not in d and "roofline" in d
+    # the same line carries the reference's strong-scaling semantics (global batch // N per rank, robust_e_nerf.py:63-66)
+    st = d["strong_scaling"]
+    assert st["events_per_step_per_gpu"] == 1024 and st["events_per_step_global"] == 2048 and st["value"] > 0
 
 
 def test_bench_data_parallel_step_over_rccl_single_rank():
