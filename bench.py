@@ -176,7 +176,7 @@ def main():
                     help="run the next step's batch / ray / sample-count front on a side stream (Trainer.prefetch): the host no "
                          "longer waits for the previous step at the sample-count read; measured 12.03 vs 12.04 ms/step, i.e. nothing "
                          "-- the step's 0.35 ms of GPU idle is inter-kernel dispatch latency, not this wait")
-    ap.add_argument("--fwd-chunks", type=int, default=16,
+    ap.add_argument("--fwd-chunks", type=int, default=4,
                     help="> 1: hash encoding and MLP forward of alternate sample chunks on two HIP streams")
     ap.add_argument("--mlp-kernels", default="x", choices=["x", "f32"],
                     help="x = split-bf16 matrix-core MLP kernels at fp32 accuracy (default), f32 = exact f32-MFMA kernels")
@@ -322,7 +322,7 @@ def main():
 
     def draw(i):
         with torch.cuda.stream(tr.side_stream if can_prefetch else torch.cuda.current_stream()):
-            return batches[i % n_batches], torch.rand(B, device=dev, generator=jgen), torch.rand(B, device=dev, generator=jgen)
+            return batches[i % n_batches], torch.rand(2 * B, device=dev, generator=jgen), None     # both renders' jitters
 
     def one_step(i):
         b, j0, j1 = staged.pop(i) if i in staged else draw(i)

@@ -76,6 +76,11 @@ int ren_trajectory_fwd(const double *ts, int64_t B, const int64_t *tab_ts, const
 /* Kinv[9] device, px[B,2], pos[B,3], rot[B,9] -> rays_o[B,3], rays_d[B,3] */
 int ren_raygen_fwd(const float *Kinv, const float *px, const float *pos, const float *rot,
                    int64_t B, float *rays_o, float *rays_d, void *stream);
+/* both in one launch: rays_o/rays_d[R,3] of the poses at ts[R] through pixels px[i % px_rows] (px[px_rows,2]; the start
+ * and end renders of a training step share the events' pixels: R = 2B, px_rows = B).  Same arithmetic as the two calls. */
+int ren_pose_rays_fwd(const double *ts, int64_t R, const float *px, int64_t px_rows, const float *Kinv,
+                      const int64_t *tab_ts, const float *tab_pos, const float *tab_quat, int64_t C,
+                      float *rays_o, float *rays_d, void *stream);
 
 /* ---- sampling ---------------------------------------------------------------------
  * nerfacc.ray_marching as called at robust_e_nerf/external/utils.py:106-119. */
@@ -230,6 +235,20 @@ int ren_event_loss_fwd(const float *intensity_start, const float *intensity_end,
 int ren_event_loss_bwd(const float *intensity_start, const float *intensity_end, const float *target,
                        const uint8_t *valid, int64_t B, int32_t err_fn, float scale,
                        const float *loss_sum, float *g_start, float *g_end, void *stream);
+
+/* The same loss straight from the render outputs of the batched start / end pass (colors[2B, C], opacities[2B]; rows
+ * [0, B) = start render): the intensity epilogue of RobustENeRF.render_pixels (models/robust_e_nerf.py:865-871: +
+ * min_modeled_intensity, is_valid = opacity > 0 of either render when use_validity), `bayering` (:887-890: channel_idx[B]
+ * uint8 or NULL), the log difference (:432-435) and the masked mean in ONE forward and ONE backward launch.
+ * bwd writes g_colors[2B, C] (zeros in the channels an event does not see), and optionally intensity[2B], pred[B] (=
+ * log I_end - log I_start), valid[B] and loss[1] = scale * loss_sum[0] / loss_sum[1] -- all on the device. */
+int ren_event_diff_loss_fwd(const float *colors, const float *opacities, const uint8_t *channel_idx, int32_t C,
+                            float min_intensity, const float *target, int32_t use_validity, int64_t B, int32_t err_fn,
+                            float *loss_sum, void *stream);
+int ren_event_diff_loss_bwd(const float *colors, const float *opacities, const uint8_t *channel_idx, int32_t C,
+                            float min_intensity, const float *target, int32_t use_validity, int64_t B, int32_t err_fn,
+                            float scale, const float *loss_sum, float *g_colors, float *intensity, float *pred,
+                            uint8_t *valid, float *loss, void *stream);
 
 /* ---- event batch glue ---------------------------------------------------------------------------
  * ren_event_prepare: ContrastThreshold.forward and RefractoryPeriod.forward
@@ -544,6 +563,11 @@ int ren_vanilla_heads_bwd_jvp(const float *g_rgb, const float *g_rgbd, const flo
 /* ---- utilities ------------------------------------------------------------------------------------- */
 /* out[c] = sum_r in[r*C + c]   (C <= 4); scratch512: 512 floats of device scratch (two-stage, deterministic) */
 int ren_column_sum(const float *in, int64_t rows, int32_t C, float *out, float *scratch512, void *stream);
+/* NeRF.render_bkgd as a softplus-parametrised parameter (models/nerf.py:81-88): bkgd[C] = softplus(raw[C]); and its gradient
+ * from the per-ray d_bkgd of ren_composite_bwd: grad_raw[c] += sigmoid(raw[c]) * sum_r d_bkgd_per_ray[r, c] */
+int ren_bkgd_param_fwd(const float *raw, int32_t C, float *bkgd, void *stream);
+int ren_bkgd_param_grad(const float *d_bkgd_per_ray, int64_t rows, int32_t C, const float *raw, float *grad_raw,
+                        float *scratch512, void *stream);
 
 #ifdef __cplusplus
 }

@@ -37,6 +37,7 @@ SIGNATURES = {
     "ren_build_info": (c_char_p, []),
     "ren_trajectory_fwd": (c_int, [P, c_int64, P, P, P, c_int64, P, P, P]),
     "ren_raygen_fwd": (c_int, [P, P, P, P, c_int64, P, P, P]),
+    "ren_pose_rays_fwd": (c_int, [P, c_int64, P, c_int64, P, P, P, P, c_int64, P, P, P]),
     "ren_ray_aabb_intersect": (c_int, [P, P, c_int64, POINTER(c_float), c_float, c_float, P, P, P]),
     "ren_ray_march": (c_int, [P, P, P, P, P, c_int64, POINTER(c_float), POINTER(c_int32), P, c_int32,
                               c_float, c_float, c_int32, c_int32, P, P, P, P, P, P, c_int32, P]),
@@ -71,6 +72,10 @@ SIGNATURES = {
     "ren_composite_bwd": (c_int, [P, P, c_int64, P, P, P, P, c_int32, P, P, P, P, P, P, P, P, P, P, P, P]),
     "ren_event_loss_fwd": (c_int, [P, P, P, P, c_int64, c_int32, P, P]),
     "ren_event_loss_bwd": (c_int, [P, P, P, P, c_int64, c_int32, c_float, P, P, P, P]),
+    "ren_event_diff_loss_fwd": (c_int, [P, P, P, c_int32, c_float, P, c_int32, c_int64, c_int32, P, P]),
+    "ren_event_diff_loss_bwd": (c_int, [P, P, P, c_int32, c_float, P, c_int32, c_int64, c_int32, c_float, P, P, P, P, P, P, P]),
+    "ren_bkgd_param_fwd": (c_int, [P, c_int32, P, P]),
+    "ren_bkgd_param_grad": (c_int, [P, c_int64, c_int32, P, P, P, P]),
     "ren_adam_step": (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int64,
                               c_float, c_int32, P]),
     "ren_occgrid_cell_points": (c_int, [P, P, c_int64, POINTER(c_float), POINTER(c_int32), c_int32, P, P, P]),

@@ -163,7 +163,39 @@ __global__ void column_sum_final_kernel(const float *__restrict__ part, int n_pa
     if (lane == 0) out[c] = s;
 }
 
+// the same final stage with the epilogue of the background parameter: bkgd = softplus(raw) (models/nerf.py:81-88), so
+// d loss / d raw[c] += sigmoid(raw[c]) * sum_r d_bkgd_per_ray[r, c]
+__global__ void bkgd_grad_final_kernel(const float *__restrict__ part, int n_part, int C, const float *__restrict__ raw,
+                                       float *__restrict__ grad) {
+    const int c = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int k = lane; k < n_part; k += 64) s += part[k * 4 + c];
+    s = ren_wave_sum(s);
+    if (lane == 0) grad[c] += s / (1.f + expf(-raw[c]));
+}
+
+__global__ void softplus1_kernel(const float *__restrict__ raw, int n, float *__restrict__ out) {
+    const int i = threadIdx.x;
+    if (i < n) out[i] = raw[i] > 20.f ? raw[i] : log1pf(expf(raw[i]));          // torch softplus(beta 1, threshold 20)
+}
+
 }  // namespace
+
+extern "C" int ren_bkgd_param_fwd(const float *raw, int32_t C, float *bkgd, void *stream) {
+    if (!raw || !bkgd || C < 1 || C > 4) return REN_ERR_BAD_ARG;
+    hipLaunchKernelGGL(softplus1_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, raw, C, bkgd);
+    REN_CHECK_LAUNCH();
+}
+
+extern "C" int ren_bkgd_param_grad(const float *d_bkgd_per_ray, int64_t rows, int32_t C, const float *raw, float *grad_raw,
+                                   float *scratch512, void *stream) {
+    if (!d_bkgd_per_ray || !raw || !grad_raw || !scratch512 || rows < 0 || C < 1 || C > 4) return REN_ERR_BAD_ARG;
+    const int n_part = rows >= 128 * 256 ? 128 : (int)((rows + 255) / 256 > 0 ? (rows + 255) / 256 : 1);
+    hipLaunchKernelGGL(column_sum_partial_kernel, dim3(n_part), dim3(256), 0, (hipStream_t)stream, d_bkgd_per_ray, rows, C, scratch512);
+    hipLaunchKernelGGL(bkgd_grad_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch512, n_part, C, raw, grad_raw);
+    REN_CHECK_LAUNCH();
+}
 
 extern "C" int ren_composite_fwd(const int64_t *offsets, const int32_t *counts, int64_t n_rays,
                                  const float *t_starts, const float *t_ends, const float *sigmas,

@@ -59,6 +59,62 @@ __global__ void event_loss_bwd_kernel(const float *__restrict__ i_start, const f
     g_start[i] = -g / is;
 }
 
+// ---- the same loss straight from the render outputs: one forward and one backward launch per step replace the
+// intensity epilogue (+ min_modeled_intensity, Bayer channel gather), the validity mask, the two loss kernels, the
+// gradient concatenation / channel scatter and the scalar loss arithmetic that used to be ~12 torch launches
+struct DiffLossArgs {
+    const float *colors, *opac, *target;     // (2B, C): rows [0, B) start render, [B, 2B) end render
+    const uint8_t *channel;                  // (B) Bayer channel of the event, NULL: channel 0
+    int64_t B;
+    int C, fn, use_validity;
+    float min_intensity;
+};
+
+__device__ __forceinline__ bool diff_loss_event(const DiffLossArgs &a, int64_t i, float &is, float &ie, int &ch) {
+    ch = a.channel ? (int)a.channel[i] : 0;
+    is = a.colors[i * a.C + ch] + a.min_intensity;                 // robust_e_nerf.py:867, 425-431
+    ie = a.colors[(a.B + i) * a.C + ch] + a.min_intensity;
+    return !a.use_validity || a.opac[i] > 0.f || a.opac[a.B + i] > 0.f;   // :868-871, 442-443
+}
+
+__global__ __launch_bounds__(256) void diff_loss_fwd_kernel(DiffLossArgs a, float *__restrict__ loss_sum) {
+    __shared__ float ps[4], pc[4];
+    float s = 0.f, c = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.B; i += (int64_t)gridDim.x * blockDim.x) {
+        float is, ie; int ch;
+        if (!diff_loss_event(a, i, is, ie, ch)) continue;
+        s += err_fn_val(a.fn, logf(ie) - logf(is), a.target[i]);
+        c += 1.f;
+    }
+    s = ren_wave_sum(s);
+    c = ren_wave_sum(c);
+    if ((threadIdx.x & 63) == 0) { ps[threadIdx.x >> 6] = s; pc[threadIdx.x >> 6] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(loss_sum, ps[0] + ps[1] + ps[2] + ps[3]);
+        atomicAdd(loss_sum + 1, pc[0] + pc[1] + pc[2] + pc[3]);
+    }
+}
+
+__global__ void diff_loss_bwd_kernel(DiffLossArgs a, float scale, const float *__restrict__ loss_sum,
+                                     float *__restrict__ g_colors, float *__restrict__ inten, float *__restrict__ pred_out,
+                                     uint8_t *__restrict__ valid_out, float *__restrict__ loss_out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && loss_out) loss_out[0] = loss_sum[0] / loss_sum[1] * scale;   // an empty mask gives NaN like the reference
+    if (i >= a.B) return;
+    float is, ie; int ch;
+    const bool ok = diff_loss_event(a, i, is, ie, ch);
+    const float pred = logf(ie) - logf(is);
+    const float g = ok ? scale / loss_sum[1] * err_fn_grad(a.fn, pred, a.target[i]) : 0.f;
+    for (int c = 0; c < a.C; ++c) {                                  // zeros in the channels the event does not see
+        g_colors[i * a.C + c] = c == ch ? -g / is : 0.f;
+        g_colors[(a.B + i) * a.C + c] = c == ch ? g / ie : 0.f;
+    }
+    if (inten) { inten[i] = is; inten[a.B + i] = ie; }
+    if (pred_out) pred_out[i] = pred;
+    if (valid_out) valid_out[i] = ok ? 1 : 0;
+}
+
 // ---------------------------------------------------------------------------------- Adam
 // torch.optim.Adam (single-tensor formulation): g += wd*p; m,v EMA; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
 __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, float *__restrict__ g,
@@ -367,6 +423,33 @@ extern "C" int ren_event_loss_bwd(const float *i_start, const float *i_end, cons
     if (B == 0) return REN_OK;
     hipLaunchKernelGGL(event_loss_bwd_kernel, dim3(ren_blocks(B, 256)), dim3(256), 0, (hipStream_t)stream,
                        i_start, i_end, target, valid, B, err_fn, scale, loss_sum, g_start, g_end);
+    REN_CHECK_LAUNCH();
+}
+
+extern "C" int ren_event_diff_loss_fwd(const float *colors, const float *opacities, const uint8_t *channel_idx, int32_t C,
+                                       float min_intensity, const float *target, int32_t use_validity, int64_t B,
+                                       int32_t err_fn, float *loss_sum, void *stream) {
+    if (!colors || !target || !loss_sum || B < 0 || err_fn < 0 || err_fn > 2 || (C != 1 && C != 3)) return REN_ERR_BAD_ARG;
+    if (use_validity && !opacities) return REN_ERR_BAD_ARG;
+    if (hipMemsetAsync(loss_sum, 0, 2 * sizeof(float), (hipStream_t)stream) != hipSuccess) return REN_ERR_LAUNCH;
+    if (B == 0) return REN_OK;
+    int blocks = ren_blocks(B, 256);
+    if (blocks > 1024) blocks = 1024;
+    const DiffLossArgs a{colors, opacities, target, channel_idx, B, C, err_fn, use_validity, min_intensity};
+    hipLaunchKernelGGL(diff_loss_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, loss_sum);
+    REN_CHECK_LAUNCH();
+}
+
+extern "C" int ren_event_diff_loss_bwd(const float *colors, const float *opacities, const uint8_t *channel_idx, int32_t C,
+                                       float min_intensity, const float *target, int32_t use_validity, int64_t B,
+                                       int32_t err_fn, float scale, const float *loss_sum, float *g_colors,
+                                       float *intensity, float *pred, uint8_t *valid, float *loss, void *stream) {
+    if (!colors || !target || !loss_sum || !g_colors || B < 0 || err_fn < 0 || err_fn > 2 || (C != 1 && C != 3))
+        return REN_ERR_BAD_ARG;
+    if (use_validity && !opacities) return REN_ERR_BAD_ARG;
+    const DiffLossArgs a{colors, opacities, target, channel_idx, B, C, err_fn, use_validity, min_intensity};
+    hipLaunchKernelGGL(diff_loss_bwd_kernel, dim3(ren_blocks(B > 0 ? B : 1, 256)), dim3(256), 0, (hipStream_t)stream, a, scale,
+                       loss_sum, g_colors, intensity, pred, valid, loss);
     REN_CHECK_LAUNCH();
 }
 

@@ -49,7 +49,7 @@ class RenderCfg:
                                        # recompute (96 MFMAs + 96 softplus per 32 samples) is cheaper than 13 GB of HBM traffic;
                                        # None = auto: recompute with the "x" kernels, save with the exact-f32 kernels
     march_cache: int = 512             # intervals per ray kept between the two marching passes (0: march twice)
-    fwd_chunks: int = 16               # > 1: hash encoding and MLP of alternate sample chunks on two HIP streams
+    fwd_chunks: int = 4                # > 1: hash encoding and MLP of alternate sample chunks on two HIP streams
     dp_overlap: bool = True            # data parallel: all-reduce the fine levels' table gradient beside the coarse levels' scatter
     dp_split_level: int = 8            # levels >= this one go first (8 x 4 MiB of the 50 MB buffer)
     dp_compress: Optional[str] = None  # "bf16": parameter gradients cross the links as bfloat16 (strong scaling), aux block stays fp32
@@ -347,20 +347,26 @@ class Renderer:
         return colors, opac, depth, ctx
 
     # ---- backward: accumulates into field.grad, returns d(bkgd) -------------------------------------
-    def backward(self, ctx, g_colors, g_opac=None, g_depth=None, final: bool = False):
-        """final: this is the last backward pass of the step (its gradients are complete when it returns)"""
+    def backward(self, ctx, g_colors, g_opac=None, g_depth=None, final: bool = False, per_ray_bkgd: bool = False):
+        """final: this is the last backward pass of the step (its gradients are complete when it returns).
+        per_ray_bkgd: return the (R, C) per-ray background gradient instead of its column sums (Trainer folds the sum
+        into ren_bkgd_param_grad)"""
         f = self.field
         if ctx["empty"]:
             # a rank without a single sample must still issue the collectives its peers issue (the slice is final here:
             # this pass adds nothing to it) -- otherwise the ranks' all-reduce sequences differ and RCCL hangs
             if final and self.dp_early_slice() is not None:
                 self.dp_early()
-            return g_colors.sum(0) if ctx.get("bkgd") is not None else None
+            if ctx.get("bkgd") is None:
+                return None
+            return g_colors if per_ray_bkgd else g_colors.sum(0)
         pk = ctx["pk"]
         d_sig, d_rgb, d_bk = ops.composite_bwd(pk.offsets, pk.counts, pk.t_starts, pk.t_ends, ctx["sigma"],
                                                ctx["rgb"], f.C, ctx["bkgd"], ctx["w"], ctx["T"], ctx["opac"],
                                                g_colors, g_opac, g_depth, want_bkgd=ctx["bkgd"] is not None)
         self._field_backward(ctx, d_rgb, d_sig, final=final)
+        if per_ray_bkgd:
+            return d_bk
         return ops.column_sum(d_bk) if d_bk is not None else None
 
     # ---- density query (occ_eval_fn / query_density) ----------------------------------------------------
@@ -578,14 +584,18 @@ class Trainer:
         self._refresh_contrast_threshold()
         self._refresh_tau()
         prep = ops.event_prepare(batch, self.c_p, self.c_n, self.tau, with_dtau=t.train_refractory_period)
-        px = torch.cat([batch["position"], batch["position"]]).contiguous()
         jitter = None
         if jitter_start is not None:
-            jitter = torch.cat([jitter_start, jitter_end]).to(torch.float32).contiguous()
-        front = dict(prep=prep, px=px, jitter=jitter)
+            # jitter_end None: jitter_start already holds the 2B uniforms of both renders (start rays first)
+            jitter = jitter_start if jitter_end is None else torch.cat([jitter_start, jitter_end])
+            jitter = jitter.to(torch.float32).contiguous()
+        front = dict(prep=prep, jitter=jitter)
         if not t.train_refractory_period:
-            pos, rot = ops.trajectory(prep["ts"], self.tab_ts, self.tab_pos, self.tab_quat)
-            front["o"], front["d"] = ops.raygen(self.Kinv, px, pos, rot)
+            # poses + rays of both renders in one launch; the 2B timestamps share the B event pixels
+            front["o"], front["d"] = ops.pose_rays(prep["ts"], batch["position"].contiguous(), self.Kinv, self.tab_ts,
+                                                   self.tab_pos, self.tab_quat)
+        else:
+            front["px"] = torch.cat([batch["position"], batch["position"]]).contiguous()
         return front
 
     @property
@@ -652,9 +662,9 @@ class Trainer:
         front = self._take_prefetched(batch, jitter_start, jitter_end)
         if front is None:
             front = self._front(batch, jitter_start, jitter_end)
-        prep, px, jitter = front["prep"], front["px"], front["jitter"]
+        prep, px, jitter = front["prep"], front.get("px"), front["jitter"]
         ts_all, target = prep["ts"], prep["target_diff"]
-        bkgd = torch.nn.functional.softplus(self.small[: f.C]) if t.bkgd_is_param else None   # nerf.py:81-88
+        bkgd = ops.bkgd_param_fwd(self.small, f.C) if t.bkgd_is_param else None              # nerf.py:81-88
         colords = None
         if t.train_refractory_period:
             # d loss/d tau needs dI/dt of both renders: carry the tangent forward (value path unchanged)
@@ -665,29 +675,29 @@ class Trainer:
         else:
             o, d = front["o"], front["d"]
             colors, opac, depth, ctx = r.forward(o, d, jitter, bkgd, training=True, save=True, begun=front.get("begun"))
-        ch = self._channel_index(batch, 2)
-        inten = self._bayer(colors, ch) + r.cfg.min_modeled_intensity    # robust_e_nerf.py:867, 425-431
-        i_s, i_e = inten[:B].contiguous(), inten[B:].contiguous()
-        valid = None
-        if not t.bkgd_is_param:                                           # :868-871, 442-443
-            valid = ((opac[:B] > 0) | (opac[B:] > 0)).to(torch.uint8).contiguous()
-        loss_sum = ops.event_loss_fwd(i_s, i_e, target, valid, t.err_diff)
+        # a16 + a18: intensity epilogue, validity, Bayer channel, loss and its gradient: two launches (ren_event_diff_loss_*)
+        if f.C > 1 and "channel_idx" not in batch:
+            raise ValueError("radiance_dim 3 (Bayer sensor) needs batch['channel_idx'] (data.colorize_events)")
+        chan = batch["channel_idx"].to(torch.uint8).contiguous() if f.C > 1 else None
         inv_c = 1.0 / self.mean_c                                         # robust_e_nerf.py:470-486
         pw = {None: 1.0, "mean_contrast_reciprocal": inv_c, "mean_contrast_reciprocal_sq": inv_c ** 2}[t.pw_diff]
         scale = pw * t.w_diff
-        loss = loss_sum[0] / loss_sum[1] * scale
-        g_s, g_e = ops.event_loss_bwd(i_s, i_e, target, valid, t.err_diff, scale, loss_sum)
-        g_colors = self._unbayer(torch.cat([g_s, g_e]), ch, f.C)
-        if t.train_contrast_threshold or t.train_refractory_period:
-            self._param_grad(batch, i_e.log() - i_s.log(), "diff", valid)
+        need_param = t.train_contrast_threshold or t.train_refractory_period
+        L = ops.event_diff_loss(colors, opac, chan, target, t.err_diff, scale, r.cfg.min_modeled_intensity,
+                                use_validity=not t.bkgd_is_param, want_pred=need_param)
+        loss, g_colors, inten = L["loss"], L["g_colors"], L["intensity"]
+        i_s, i_e = inten[:B], inten[B:]
+        if need_param:
+            self._param_grad(batch, L["pred"], "diff", L["valid"])
         if t.train_refractory_period:
             # through the poses: sum_i dL/dI_i * dI_i/dt_i * dt_i/dtau  (start and end renders)
+            ch = self._channel_index(batch, 2)
             idot = self._bayer(colords, ch).double()
-            self._tau_grad_dev += (g_s.double() * idot[:B] * prep["dts_start"]).sum() \
-                + (g_e.double() * idot[B:] * prep["dts_end"]).sum()
-        d_bkgd = r.backward(ctx, g_colors, final=final)
-        if d_bkgd is not None:
-            self.small_grad[: f.C] += d_bkgd * torch.sigmoid(self.small[: f.C])     # d softplus
+            g_ev = self._bayer(g_colors, ch).double()
+            self._tau_grad_dev += (g_ev[:B] * idot[:B] * prep["dts_start"]).sum() + (g_ev[B:] * idot[B:] * prep["dts_end"]).sum()
+        d_bk = r.backward(ctx, g_colors, final=final, per_ray_bkgd=True)
+        if d_bk is not None:
+            ops.bkgd_param_grad(d_bk, self.small, self.small_grad)       # += sigmoid(raw) * column sums (d softplus)
         aux = dict(intensity_start=i_s, intensity_end=i_e, n=ctx["pk"].n, n_marched=ctx["pk"].n_marched,
                    opacity=opac, rays=2 * B)
         return loss, aux

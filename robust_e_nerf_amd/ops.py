@@ -120,6 +120,17 @@ def raygen(Kinv, px, pos, rot):
     return o, d
 
 
+def pose_rays(ts, px, Kinv, tab_ts, tab_pos, tab_quat):
+    """trajectory() + raygen() in one launch; px (B, 2) is reused cyclically when ts has a multiple of B entries"""
+    R = ts.shape[0]
+    o = torch.empty(R, 3, device=ts.device, dtype=torch.float32)
+    d = torch.empty(R, 3, device=ts.device, dtype=torch.float32)
+    check(_lib.load().ren_pose_rays_fwd(_ptr(ts, torch.float64), R, _ptr(px, torch.float32), px.shape[0], _ptr(Kinv, torch.float32),
+                                        _ptr(tab_ts, torch.int64), _ptr(tab_pos, torch.float32), _ptr(tab_quat, torch.float32),
+                                        tab_ts.shape[0], _ptr(o), _ptr(d), _stream()), "ren_pose_rays_fwd")
+    return o, d
+
+
 # ------------------------------------------------------------------------------- sampling
 def ray_aabb_intersect(o, d, aabb: Sequence[float], near: Optional[float] = None, far: Optional[float] = None):
     n = o.shape[0]
@@ -492,6 +503,45 @@ def event_loss_bwd(i_start, i_end, target, valid, err_fn: str, scale: float, los
                                          ERR_FN[err_fn], _f(scale), _ptr(loss_sum), _ptr(g_s), _ptr(g_e), _stream()),
           "ren_event_loss_bwd")
     return g_s, g_e
+
+
+def event_diff_loss(colors, opac, channel_idx, target, err_fn: str, scale: float, min_intensity: float, use_validity: bool,
+                    want_pred: bool = False):
+    """Loss + its gradient straight from the batched start / end render: colors (2B, C), opac (2B,) ->
+    dict(loss (device scalar), loss_sum, g_colors (2B, C), intensity (2B,), pred (B,) | None, valid (B,) uint8 | None).
+    Two launches (ren_event_diff_loss_fwd / _bwd) instead of the intensity epilogue, mask, loss, scatter and scalar glue."""
+    if err_fn not in ERR_FN:
+        raise NotImplementedError(err_fn)
+    dev = colors.device
+    B, C = colors.shape[0] // 2, colors.shape[1]
+    lib = _lib.load()
+    loss_sum = torch.empty(2, device=dev, dtype=torch.float32)
+    args = (_ptr(colors, torch.float32), _ptr(opac, torch.float32), _ptr(channel_idx, torch.uint8), C, _f(min_intensity),
+            _ptr(target, torch.float32), 1 if use_validity else 0, B, ERR_FN[err_fn])
+    check(lib.ren_event_diff_loss_fwd(*args, _ptr(loss_sum), _stream()), "ren_event_diff_loss_fwd")
+    g_colors = torch.empty_like(colors)
+    inten = torch.empty(2 * B, device=dev, dtype=torch.float32)
+    pred = torch.empty(B, device=dev, dtype=torch.float32) if want_pred else None
+    valid = torch.empty(B, device=dev, dtype=torch.uint8) if use_validity else None
+    loss = torch.empty((), device=dev, dtype=torch.float32)
+    check(lib.ren_event_diff_loss_bwd(*args, _f(scale), _ptr(loss_sum), _ptr(g_colors), _ptr(inten), _ptr(pred), _ptr(valid),
+                                      _ptr(loss), _stream()), "ren_event_diff_loss_bwd")
+    return dict(loss=loss, loss_sum=loss_sum, g_colors=g_colors, intensity=inten, pred=pred, valid=valid)
+
+
+def bkgd_param_fwd(raw: torch.Tensor, C: int) -> torch.Tensor:
+    """softplus of the background parameter (models/nerf.py:81-88), one tiny launch"""
+    out = torch.empty(C, device=raw.device, dtype=torch.float32)
+    check(_lib.load().ren_bkgd_param_fwd(_ptr(raw, torch.float32), C, _ptr(out), _stream()), "ren_bkgd_param_fwd")
+    return out
+
+
+def bkgd_param_grad(d_bkgd_per_ray: torch.Tensor, raw: torch.Tensor, grad_raw: torch.Tensor):
+    """grad_raw[:C] += sigmoid(raw[:C]) * column sums of the per-ray background gradient"""
+    rows, C = d_bkgd_per_ray.shape
+    scratch = torch.empty(512, device=raw.device, dtype=torch.float32)
+    check(_lib.load().ren_bkgd_param_grad(_ptr(d_bkgd_per_ray, torch.float32), rows, C, _ptr(raw, torch.float32),
+                                          _ptr(grad_raw, torch.float32), _ptr(scratch), _stream()), "ren_bkgd_param_grad")
 
 
 def adam_step(p, g, m, v, *, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, step: int, grad_scale=1.0,

@@ -1359,6 +1359,75 @@ def test_tangent_mlp_matrix_core_kernels_vs_f32_kernels(amd, spec, full_table_ca
         assert e1 < 5e-2, (k, e1)                                 # bf16 operands: 2^-9 per operand
 
 
+def test_bf16_mode_tangent_arithmetic_is_pinned(amd, spec, full_table_cache):
+    """BASELINE configs[2] "bf16 MLP with fp32 composite", the arithmetic of the l_grad (tangent) render: in bf16 mode EVERY
+    operand of an nn.Linear product is rounded to bfloat16 -- the value inputs, the weights AND the tangent inputs (what
+    `float32_matmul_precision: medium` does to every matmul of the reference, the ones autograd adds included) -- with
+    fp32 accumulation, bias, activations and activation derivatives.  ren_mlp_fwd_jvp_x(mode 1) against a float64
+    forward-mode emulation of exactly that (rounding op whose JVP rounds the tangent): values and time derivatives agree
+    to 2e-3 (a pre-activation that differs in its last fp32 ulp can round to the neighbouring bf16 value), i.e. the 6 %
+    between this mode and the oracle's straight-through emulation in test_config_c3_bf16_lgrad_step_vs_oracle is the
+    rounding of the tangent operands, not an error."""
+    import ctypes
+    import torch.autograd.forward_ad as fwAD
+    from robust_e_nerf_amd import _lib, tcnn_api
+    from oracle import field
+    ops, engine = amd
+    lib = _lib.load()
+    P = ops._ptr
+    R, S = 512, 64
+    o, d = make_rays(R, seed=21)
+    gen = torch.Generator().manual_seed(22)
+    dd = torch.randn(R, 3, generator=gen) * 0.3
+    n = R * S
+    ri = torch.arange(R, dtype=torch.int32).repeat_interleave(S)
+    tsv = torch.rand(n, generator=gen) * 3 + 2.5
+    nb = ops.n_blocks32(n)
+    feat, featd = torch.randn(nb * 1024, generator=gen) * 0.3, torch.randn(nb * 1024, generator=gen) * 0.3
+    p = field.init_params(spec, seed=9)
+    fld = engine.NGPField(DEV)
+    p["hash"] = full_table_cache(7, 0.5)
+    fld.load(p)
+    scene = ops.make_scene_desc([-1.5] * 3 + [1.5] * 3, 0)
+    rgb, rgbd = torch.empty(n, 1, device=DEV), torch.empty(n, 1, device=DEV)
+    sig, sigd = torch.empty(n, device=DEV), torch.empty(n, device=DEV)
+    base, based = torch.empty(nb * 512, device=DEV), torch.empty(nb * 512, device=DEV)
+    assert lib.ren_mlp_fwd_jvp_x(P(fld.mlp), 1, 1, P(dev(feat)), P(dev(featd)), ctypes.byref(scene), P(dev(o)), P(dev(d)), P(dev(dd)),
+                                 P(dev(ri)), P(dev(tsv)), P(dev(tsv + 0.01)), n, P(rgb), P(rgbd), P(sig), P(sigd), P(base), P(based),
+                                 ops._stream()) == 0
+    torch.cuda.synchronize()
+
+    class BF(torch.autograd.Function):                     # round to bf16; forward mode: the tangent is rounded too
+        @staticmethod
+        def forward(ctx, x):
+            return x.to(torch.bfloat16).to(x.dtype)
+
+        @staticmethod
+        def jvp(ctx, t):
+            return t.to(torch.bfloat16).to(t.dtype)
+
+    def lin(x, w, b):
+        return BF.apply(x) @ BF.apply(w.double()).T + b.double()
+
+    rows, rowsd = tcnn_api._to_rows(feat, n).double(), tcnn_api._to_rows(featd, n).double()
+    dirs, dirsd = d[ri.long()].double(), dd[ri.long()].double()
+    xs = (o[ri.long()] + d[ri.long()] * (tsv + 0.005)[:, None])
+    sel = ((xs > -1.5) & (xs < 1.5)).all(-1).double()
+    with fwAD.dual_level():
+        e, dv_ = fwAD.make_dual(rows, rowsd), fwAD.make_dual(dirs, dirsd)
+        h = field.softplus(lin(e, p["base.w0"], p["base.b0"]), 100.0)
+        raw = lin(h, p["base.wo"], p["base.bo"])
+        sigma = torch.exp(raw[:, 0] - 1) * sel
+        hin = torch.cat([field.sh_encode(dv_, 4), raw[:, 1:]], dim=-1)
+        q = field.softplus(lin(field.softplus(lin(hin, p["head.w0"], p["head.b0"]), 100.0), p["head.w1"], p["head.b1"]), 100.0)
+        out = field.softplus(lin(q, p["head.wo"], p["head.bo"]), 1.0)
+        (rgb_e, rgbd_e), (sig_e, sigd_e) = fwAD.unpack_dual(out), fwAD.unpack_dual(sigma)
+    for name, got, want in (("rgb", rgb, rgb_e), ("d rgb/dt", rgbd, rgbd_e), ("sigma", sig, sig_e), ("d sigma/dt", sigd, sigd_e)):
+        err = rel_err(got.cpu().reshape(-1), want.reshape(-1))
+        print(f"bf16 mode, kernel vs forward-mode emulation with rounded tangent operands: {name:10s} {err:.2e}")
+        assert err < 2e-3, (name, err)
+
+
 def test_config_c3_bf16_lgrad_step_vs_oracle(amd, spec, full_table_cache):
     """BASELINE configs[2]: C_p + tau optimised, l_grad on, bf16 MLP with fp32 composite.  One whole step (three
     renders, tangent render on the bf16 matrix cores in mode 1) vs the oracle with its bf16_linear() emulation
