@@ -45,9 +45,12 @@ constexpr int ACT_SAVE_FLOATS_X = 3 * 2 * 16 * 64;            // same layout as 
 // 8 waves share one 63 KB fragment image, two workgroups per CU: four waves per SIMD, so one wave's split /
 // softplus VALU work runs under another's bf16 MFMAs (which, unlike the f32 MFMA, do co-issue with the VALU)
 constexpr int FWD_X_WAVES = 8;
+#ifndef REN_FWD_WAVES
+#define REN_FWD_WAVES 4                                   // waves per SIMD the register allocation must allow (2 workgroups per CU)
+#endif
 
 template <int C, int MODE, bool DENSITY_ONLY>
-__global__ __launch_bounds__(64 * FWD_X_WAVES, 2) void mlp_fwd_x_kernel(FwdXArgs a) {
+__global__ __launch_bounds__(64 * FWD_X_WAVES, REN_FWD_WAVES) void mlp_fwd_x_kernel(FwdXArgs a) {
     using PR = Pairs<MODE>;
     constexpr int NT = PR::NT;
     using L = XL<NT>;
