@@ -35,6 +35,8 @@ P = c_void_p
 SIGNATURES = {
     "ren_abi_version": (c_int, []),
     "ren_build_info": (c_char_p, []),
+    "ren_set_knob": (c_int, [c_int32, c_int32]),
+    "ren_get_knob": (c_int, [c_int32]),
     "ren_trajectory_fwd": (c_int, [P, c_int64, P, P, P, c_int64, P, P, P]),
     "ren_raygen_fwd": (c_int, [P, P, P, P, c_int64, P, P, P]),
     "ren_pose_rays_fwd": (c_int, [P, c_int64, P, c_int64, P, P, P, P, c_int64, P, P, P]),

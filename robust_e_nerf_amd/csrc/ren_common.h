@@ -27,6 +27,27 @@
 
 static inline int ren_blocks(int64_t n, int threads) { return (int)((n + threads - 1) / threads); }
 
+// Verification / tuning knobs (include/ren_amd.h: ren_set_knob).  One process-wide atomic per knob, initialised ONCE from
+// the environment variable of the same purpose: no getenv on the launch path (it is not thread-safe against setenv, and
+// the data-parallel step launches from two streams).  None of them changes results.
+#include <atomic>
+#include <cstdlib>
+inline std::atomic<int> *ren_knob_store() {
+    static std::atomic<int> knobs[REN_KNOB_COUNT];
+    static const bool init = [] {
+        const char *names[REN_KNOB_COUNT] = {"REN_HGB_NO_PAIRS", "REN_HGB_HALVE_REGIONS", "REN_MARCH_SEQUENTIAL", "REN_HG_VARIANT"};
+        const int defaults[REN_KNOB_COUNT] = {0, 0, 0, 2};
+        for (int k = 0; k < REN_KNOB_COUNT; ++k) {
+            const char *e = getenv(names[k]);
+            knobs[k].store(e ? atoi(e) : defaults[k], std::memory_order_relaxed);
+        }
+        return true;
+    }();
+    (void)init;
+    return knobs;
+}
+static inline int ren_knob(int k) { return ren_knob_store()[k].load(std::memory_order_relaxed); }
+
 struct ren_scene_dev {
     float lo[3], inv_ext[3];   // (x - lo) * inv_ext is NOT used where parity needs the division
     float hi[3];

@@ -135,12 +135,9 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_kernel(
     }
 }
 
-// Tuning knob (REN_HG_VARIANT environment variable, read per call): bit 0 = XCD-affine level
+// Tuning knob (REN_KNOB_HG_VARIANT): bit 0 = XCD-affine level
 // mapping, bit 1 = lane-pair feature split in the backward kernel.
-int hg_variant() {
-    const char *e = getenv("REN_HG_VARIANT");
-    return e ? atoi(e) : 2;
-}
+int hg_variant() { return ren_knob(REN_KNOB_HG_VARIANT); }
 
 }  // namespace
 

@@ -712,8 +712,7 @@ static int binned_impl(const ren_grid_desc *grid, float *grad_table, const float
     bt.bin_base[REN_MAX_LEVELS] = nb;
     for (int l = g.n_levels; l < REN_MAX_LEVELS; ++l) bt.bin_base[l] = nb;
     int64_t hashed_cap = 0;
-    const char *no_pairs = getenv("REN_HGB_NO_PAIRS");             // verification knob: single-update records everywhere
-    const bool use_pairs = !tan.dfeatd && !(no_pairs && no_pairs[0] == '1');
+    const bool use_pairs = !tan.dfeatd && ren_knob(REN_KNOB_HGB_NO_PAIRS) != 1;   // verification knob: single-update records everywhere
     for (int l = 0; l < REN_MAX_LEVELS; ++l) {
         bt.cap[l] = 0;
         bt.pair[l] = 0;
@@ -743,8 +742,7 @@ static int binned_impl(const ren_grid_desc *grid, float *grad_table, const float
     SampleArgs a;
     a.layout = layout; a.dfeat = dfeat; a.x_unit = x_unit; a.sc = sc; a.rays_o = rays_o; a.rays_d = rays_d;
     a.ray_indices = ray_indices; a.t_starts = t_starts; a.t_ends = t_ends; a.n = n; a.tan = tan;
-    const char *halve = getenv("REN_HGB_HALVE_REGIONS");
-    bt.halve = halve && halve[0] == '1';
+    bt.halve = ren_knob(REN_KNOB_HGB_HALVE_REGIONS) == 1;
     const int64_t cnt_blocks = (n + CNT_SAMPLES - 1) / CNT_SAMPLES;
     bt.cnt_stride = cnt_blocks >= 4096 ? 16 : cnt_blocks >= 2048 ? 8 : cnt_blocks >= 1024 ? 4 : 1;   // >= 256 sampled blocks or exact
     const dim3 cgrd((unsigned)((cnt_blocks + bt.cnt_stride - 1) / bt.cnt_stride)), cblk(CNT_THREADS);

@@ -558,10 +558,10 @@ extern "C" int ren_ray_march(const float *rays_o, const float *rays_d, const flo
     a.type = contraction_type; a.step_size = step_size; a.cone_angle = cone_angle;
     a.mode = mode; a.n_uniform = n_uniform;
     dim3 grid(ren_blocks(n_rays, 64)), block(64);   // short blocks: ray lengths vary a lot
-    const char *env_seq = getenv("REN_MARCH_SEQUENTIAL");                      // tuning/verification knob
+    const bool force_seq = ren_knob(REN_KNOB_MARCH_SEQUENTIAL) == 1;           // tuning/verification knob
     // speculation spends SPEC lanes per ray to cut load round trips: it wins while the launch is latency-bound
     // (measured: 2x at 15 k rays, 3x slower at 131 k rays where the sequential kernel already fills the chip)
-    const bool spec = mode == 0 && n_rays <= 24576 && !(env_seq && env_seq[0] == '1');
+    const bool spec = mode == 0 && n_rays <= 24576 && !force_seq;
     const dim3 sgrid(ren_blocks(n_rays * SPEC, 256));
     if (write && mode == 1)
         hipLaunchKernelGGL(uniform_write_kernel, dim3(ren_blocks(n_rays * n_uniform, 256)), dim3(256), 0,

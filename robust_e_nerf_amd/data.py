@@ -192,6 +192,119 @@ def load_calibration(root: str) -> Dict[str, object]:
     return out
 
 
+# ------------------------------------------------------------------------------------------- posed images
+# The reference's validation / test data: `PosedImage` (robust_e_nerf/data/datasets.py:376-690) -- NeRF-synthetic style
+# `views/transforms_{stage}.json` (in the dataset directory or one level above it) with OpenGL camera-to-world matrices,
+# images as Gray / BGR / BGRA files, optional `renderer_params.npz` of synthetic renders.
+T_COPENGL_CCOMMON = np.array([[1.0, 0.0, 0.0], [0.0, -1.0, 0.0], [0.0, 0.0, -1.0]])   # datasets.py:380-382
+POSED_IMG_FOLDER, RENDERER_PARAMS = "views", "renderer_params.npz"
+
+
+def _views_dir(root: str) -> Optional[str]:
+    for p in (os.path.join(root, POSED_IMG_FOLDER), os.path.join(root, "..", POSED_IMG_FOLDER)):     # :424-433
+        if os.path.isdir(p):
+            return p
+    return None
+
+
+def has_posed_images(root: str, stage: str) -> bool:
+    d = _views_dir(root)
+    return d is not None and os.path.isfile(os.path.join(d, f"transforms_{stage}.json"))
+
+
+def _read_image(path: str) -> np.ndarray:
+    """(H, W) or (H, W, 3 | 4) in RGB(A) channel order, integer dtype as stored (8 / 16 bit) or float (.npy)"""
+    if path.endswith(".npy"):
+        return np.load(path)
+    from PIL import Image
+    im = Image.open(path)
+    if im.mode in ("I;16", "I;16B", "I"):
+        return np.asarray(im).astype(np.uint16)
+    if im.mode == "P":
+        im = im.convert("RGBA" if "transparency" in im.info else "RGB")
+    return np.asarray(im)
+
+
+def load_posed_images(root: str, stage: str, alpha_over_white_bg: bool = False, permutation_seed: Optional[int] = None):
+    """PosedImage(root, stage, permutation_seed, alpha_over_white_bg) (datasets.py:400-431) ->
+    dict(sample_id [N str], img (N, H, W) | (N, 3, H, W) float32 normalized intensity, T_wc_position (N, 3),
+    T_wc_orientation (N, 3, 3) in the common camera convention, intrinsics (3, 3), min / max_normalized_pixel_value)."""
+    import glob
+    import json
+    d = _views_dir(root)
+    if d is None:
+        raise FileNotFoundError(f"no '{POSED_IMG_FOLDER}' folder in {root} or above it")
+    tf = json.load(open(os.path.join(d, f"transforms_{stage}.json")))
+    rp_path = os.path.join(root, RENDERER_PARAMS)
+    rp = np.load(rp_path) if os.path.isfile(rp_path) else None                   # synthetic renders only (:449-459)
+    calib = np.load(os.path.join(root, CAMERA_CALIBRATION))
+    ids, imgs, pos, rot = [], [], [], []
+    for fr in tf["frames"]:                                                      # :461-504
+        ids.append(os.path.basename(fr["file_path"]))
+        imgs.append(_read_image(sorted(glob.glob(os.path.join(d, fr["file_path"] + ".*")))[0]))
+        T = np.array(fr["transform_matrix"], dtype=np.float64)
+        pos.append(T[:3, 3])
+        rot.append(T[:3, :3])
+    img = np.stack(imgs)
+    H, W = img.shape[1:3]
+    if "camera_angle_x" in tf:                                                   # :514-524
+        f = (W / 2) / math.tan(tf["camera_angle_x"] / 2)
+        K = np.array([[f, 0, W / 2 - 0.5], [0, f, H / 2 - 0.5], [0, 0, 1]])
+    else:
+        K = np.array(tf["intrinsics"], dtype=np.float64)
+    # ---- transform_img (:532-666)
+    quantized = np.issubdtype(img.dtype, np.unsignedinteger)
+    synthetic = rp is not None
+    channels = 1 if img.ndim == 3 else img.shape[3]
+    bayer = str(calib["bayer_pattern"]) if "bayer_pattern" in calib.files else ""
+    if not (quantized or np.issubdtype(img.dtype, np.floating)) or (img < 0).any():
+        raise ValueError("images must be unsigned integers or non-negative floats (datasets.py:580-583)")
+    if channels not in (1, 3, 4) or (channels == 4 and not synthetic) or (not synthetic and not quantized):
+        raise ValueError("unsupported image format (datasets.py:584-594)")
+    levels = None
+    if quantized:
+        levels = 2 ** int(tf["bit_depth"]) if "bit_depth" in tf else int(np.iinfo(img.dtype).max) + 1
+    space = str(rp["interm_color_space"]) if synthetic else None
+    if synthetic and ((quantized and space != "display") or (not quantized and space != "linear")):
+        raise ValueError("quantized synthetic renders must be in display, float ones in linear colour space (datasets.py:585-589)")
+    img = img.astype(np.float64)
+    if alpha_over_white_bg:                                                      # :599-616 (needs the alpha channel)
+        if space == "display":                                                   # straight alpha
+            alpha = img[..., 3:4] / (levels - 1)
+            img = alpha * img[..., :3] + (1 - alpha) * (levels - 1)
+        elif space == "linear":                                                  # premultiplied alpha
+            img = img[..., :3] + (1 - img[..., 3:4])
+    elif channels == 4:
+        img = img[..., :3]
+    img = img.astype(np.float32)
+    if bayer != "":                                                              # colour sensor: (N, 3, H, W) RGB (:623-629)
+        img = img.transpose(0, 3, 1, 2)
+    elif channels == 3:                                                          # cv2.COLOR_BGR2GRAY weights (:632-637)
+        img = (0.299 * img[..., 0] + 0.587 * img[..., 1] + 0.114 * img[..., 2]).astype(np.float32)
+    elif channels == 4:
+        # as the reference: its grey conversion tests the channel count of the LOADED image (4), so composited / stripped
+        # BGRA renders of a monochrome sensor stay (N, H, W, 3) in OpenCV's BGR order (:543-548,632)
+        img = np.ascontiguousarray(img[..., ::-1])
+    if quantized:                                                                # ADC bin centres (:639-657)
+        lo = 0.5 / levels
+        img = img / levels + lo
+        hi = 1 - lo
+    else:
+        lo = float(rp["log_eps"])
+        img = img + lo
+        hi = float(img.max())
+    out = dict(sample_id=ids, img=torch.from_numpy(np.ascontiguousarray(img, dtype=np.float32)),
+               T_wc_position=torch.from_numpy(np.stack(pos).astype(np.float32)),
+               T_wc_orientation=torch.from_numpy((np.stack(rot) @ T_COPENGL_CCOMMON).astype(np.float32)),   # :668-688
+               intrinsics=torch.from_numpy(K.astype(np.float32)), min_normalized_pixel_value=lo, max_normalized_pixel_value=hi)
+    if permutation_seed is not None:                                             # :420-431 (tensor_ops.randperm_manual_seed)
+        perm = torch.randperm(len(ids), generator=torch.Generator().manual_seed(permutation_seed))
+        out["sample_id"] = [ids[i] for i in perm.tolist()]
+        for k in ("img", "T_wc_position", "T_wc_orientation"):
+            out[k] = out[k][perm]
+    return out
+
+
 # ------------------------------------------------------------------------------------------- batcher
 def trunc_normal_from_uniform(u01: torch.Tensor, low, high, mean, std) -> torch.Tensor:
     """samplers.py:33-84 (inverse-CDF truncated normal) applied to given U[0,1) samples (what its torch.rand draws)."""

@@ -626,12 +626,21 @@ class Trainer:
             ev = torch.cuda.Event()
             ev.record(side)
         front["begun"] = st
-        self._prefetched = ((id(batch), id(jitter_start), id(jitter_end)), front, ev, (batch, jitter_start, jitter_end))
+        self._prefetched = (self._prefetch_key(batch, jitter_start, jitter_end), front, ev, (batch, jitter_start, jitter_end))
         return True
+
+    @staticmethod
+    def _prefetch_key(batch, jitter_start, jitter_end):
+        """identity AND in-place version of every tensor the prefetched front was computed from: a batch or jitter tensor
+        mutated between prefetch() and forward_backward() (same object ids, new contents) must not reuse the stale front"""
+        ver = lambda t: (id(t), t._version) if isinstance(t, torch.Tensor) else (id(t), 0)
+        return (id(batch), tuple(sorted((k, ver(v)) for k, v in batch.items())), ver(jitter_start), ver(jitter_end))
 
     def _take_prefetched(self, batch, jitter_start, jitter_end):
         pf, self._prefetched = self._prefetched, None
-        if pf is None or pf[0] != (id(batch), id(jitter_start), id(jitter_end)):
+        t = self.t
+        if pf is None or pf[0] != self._prefetch_key(batch, jitter_start, jitter_end) or t.train_contrast_threshold or \
+                t.train_refractory_period or self.r.cfg.sampler != "uniform":       # the guards of prefetch(), re-checked
             return None
         _, front, ev, _ = pf
         ev.synchronize()                                               # host: waits for the side stream's few small kernels only

@@ -143,3 +143,29 @@ def psnr(pred: torch.Tensor, target: torch.Tensor, data_range: float) -> float:
 
 def l1(pred: torch.Tensor, target: torch.Tensor) -> float:
     return float((pred.double() - target.double()).abs().mean())
+
+
+@torch.no_grad()
+def evaluate_posed_images(r: Renderer, posed: dict, bkgd: Optional[torch.Tensor] = None, rank: int = 0, world: int = 1,
+                          group=None, chunk: Optional[int] = None, limit: Optional[int] = None):
+    """validation / test epoch of the reference (models/robust_e_nerf.py:519-696) over data.load_posed_images(...): every
+    view is rendered at its pose (views sharded over the ranks like DDP's DistributedSampler, metrics all-gathered: C3),
+    aligned to the target by the affine fit in log space (:634-677) and scored with L1 / PSNR over the target's pixel-value
+    range (loss_metric/metric.py:60-72).  -> dict(l1, psnr: means over the views; per_view: (V, 2) tensor)"""
+    dev = r.field.flat.device
+    n = len(posed["sample_id"]) if limit is None else min(limit, len(posed["sample_id"]))
+    Kinv = torch.linalg.inv(posed["intrinsics"].double()).float().contiguous().to(dev).contiguous()
+    H, W = posed["img"].shape[-2:]
+    rng = posed["max_normalized_pixel_value"] - posed["min_normalized_pixel_value"]
+    mine = view_shard(n, rank, world)
+    local = torch.zeros(len(mine), 2, device=dev)
+    for j, v in enumerate(mine):
+        tgt = posed["img"][v].to(dev)
+        img, _, _ = render_image(r, Kinv, posed["T_wc_position"][v].to(dev), posed["T_wc_orientation"][v].to(dev).contiguous(),
+                                 H, W, bkgd, chunk)
+        if img.shape != tgt.shape:
+            raise ValueError(f"view {posed['sample_id'][v]}: prediction {tuple(img.shape)} vs target {tuple(tgt.shape)}")
+        al = affine_align_log(img.clamp_min(1e-12), tgt)
+        local[j, 0], local[j, 1] = l1(al, tgt), psnr(al, tgt, rng)
+    per_view = gather_views(local, n, rank, world, group)
+    return dict(l1=float(per_view[:, 0].mean()), psnr=float(per_view[:, 1].mean()), per_view=per_view.cpu(), n_views=n)

@@ -19,6 +19,24 @@ BASE_FLOATS_PER_BLOCK = 8 * 64           # saved base-MLP outputs, per 32 sample
 _DT = {torch.float32: 4, torch.float64: 8, torch.int32: 4, torch.int64: 8, torch.uint8: 1, torch.bool: 1}
 
 
+KNOBS = {"hgb_no_pairs": 0, "hgb_halve_regions": 1, "march_sequential": 2, "hg_variant": 3}     # include/ren_amd.h REN_KNOB_*
+
+
+class knob:
+    """`with ops.knob("hgb_halve_regions", 1): ...` -- set a verification / tuning knob of the library for a block"""
+
+    def __init__(self, name: str, value: int):
+        self.k, self.v = KNOBS[name], int(value)
+
+    def __enter__(self):
+        lib = _lib.load()
+        self.old = lib.ren_get_knob(self.k)
+        check(lib.ren_set_knob(self.k, self.v), "ren_set_knob")
+
+    def __exit__(self, *a):
+        _lib.load().ren_set_knob(self.k, self.old)
+
+
 def _ptr(t: Optional[torch.Tensor], dtype=None):
     if t is None:
         return None

@@ -37,6 +37,10 @@ def main():
     ap.add_argument("--width", type=int)
     ap.add_argument("--gain", type=float, default=1.0, help="multiplies the intensity before the 8-bit PNG is written")
     ap.add_argument("--gt-dir", help="<index>.npy ground-truth intensity images: aligned PSNR is reported")
+    ap.add_argument("--stage", choices=["val", "test"],
+                    help="evaluate on the dataset's posed images (views/transforms_<stage>.json, the reference's PosedImage "
+                         "layout) instead of rendering along the trajectory: aligned L1 / PSNR per view and their means, as "
+                         "the reference's validation / test epochs (robust_e_nerf.py:519-696)")
     ap.add_argument("--chunk", type=int, help="rays per render call (default: whole image for arch ngp, 16 384 for arch mlp)")
     args = ap.parse_args()
 
@@ -89,6 +93,18 @@ def main():
 
     os.makedirs(args.out, exist_ok=True)
     from PIL import Image
+    if args.stage:
+        if args.synthetic:
+            raise SystemExit("--stage needs a dataset directory with a views/ folder")
+        posed = data.load_posed_images(root, args.stage, bool(dcfg.get("alpha_over_white_bg", False)),
+                                       dcfg.get(f"{args.stage}_dataset_perm_seed"))
+        m = evaluation.evaluate_posed_images(r, posed, bkgd, chunk=args.chunk)
+        for sid, (l1v, ps) in zip(posed["sample_id"], m["per_view"].tolist()):
+            print(f"{args.stage} view {sid}: l1 {l1v:.5f}  psnr {ps:.2f} dB")
+        np.savez(os.path.join(args.out, f"{args.stage}_metrics.npz"), sample_id=np.array(posed["sample_id"]),
+                 l1_psnr=m["per_view"].numpy())
+        print(f"{args.stage}: {m['n_views']} views, mean l1 {m['l1']:.5f}, mean PSNR {m['psnr']:.2f} dB", flush=True)
+        return
     Kinv_d = Kinv.to(dev, torch.float32)
     idx = list(range(0, tab_ts.shape[0], max(1, args.every)))
     pos_all, rot_all = ops.trajectory(tab_ts[idx].to(dev, torch.float64), tab_ts.to(dev), tab_pos.to(dev), tab_quat.to(dev))

@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--mlp-bf16", action="store_true",
                     help="bf16 MLP operands, fp32 accumulate / composite (same as float32_matmul_precision: medium)")
     ap.add_argument("--accumulate-grad-batches", type=int, help="overrides trainer.accumulate_grad_batches")
+    ap.add_argument("--no-validation", action="store_true", help="skip the validation epochs over views/transforms_val.json")
+    ap.add_argument("--limit-val-batches", type=int, help="validate on the first N views only")
     args = ap.parse_args()
     cfg = yaml.safe_load(open(args.config))
     rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("LOCAL_RANK", 0), ("WORLD_SIZE", 1)))
@@ -205,6 +207,7 @@ def main():
                         tau_raw=tau_raw, tau_max=tau_max, bkgd_raw=torch.tensor([softplus_inv(1.0)] * fld.C),
                         world_size=world, process_group=None)
     start_epoch, start_step = 0, 0
+    resume_rng = None
     if args.resume:
         ck = torch.load(args.resume, map_location="cpu", weights_only=False)
         rsd = ck["state_dict"]
@@ -225,6 +228,7 @@ def main():
             if "batch_size" in ck:
                 batch_size = int(ck["batch_size"])
                 batcher.set_batch_size(batch_size)
+            resume_rng = ck.get("rng_state")
 
     # ---- fit loop ---------------------------------------------------------------------------------------------
     tcf, sched = cfg["trainer"], cfg["lr_scheduler"]["multi_step_lr"]
@@ -236,7 +240,26 @@ def main():
     from collections import deque
     pending = deque([batch_size])
     jgen = torch.Generator(device=dev).manual_seed(seed + 17 + rank)
+    if resume_rng is not None:
+        # continue the random streams (event indices / normalized samplers, ray jitters, occupancy-grid refresh) where the
+        # checkpointed run left them: a resumed run then equals the uninterrupted one instead of replaying epoch 0's draws.
+        # The streams of ranks > 0 differ by their seed only: those ranks re-seed with the resumed epoch folded in.
+        if rank == 0:
+            batcher.gen.set_state(resume_rng["batcher"])
+            jgen.set_state(resume_rng["jitter"])
+        else:
+            batcher.gen.manual_seed(seed + rank + 7919 * start_epoch)
+            jgen.manual_seed(seed + 17 + rank + 7919 * start_epoch)
+        if resume_rng.get("occ") is not None:                   # identical on every rank by construction
+            renderer._occ_gen = torch.Generator(device=dev)
+            renderer._occ_gen.set_state(resume_rng["occ"])
     os.makedirs(args.out, exist_ok=True)
+    val_views, val_every = None, int(tcf.get("check_val_every_n_epoch", 1) or 1)
+    if not args.synthetic and not args.no_validation and data.has_posed_images(root, "val"):
+        val_views = data.load_posed_images(root, "val", bool(dcfg.get("alpha_over_white_bg", False)),
+                                           dcfg.get("val_dataset_perm_seed"))
+        if rank == 0:
+            print(f"validation: {len(val_views['sample_id'])} posed views every {val_every} epoch(s)", flush=True)
     step, t0, rays = start_step, time.perf_counter(), 0
     for epoch in range(start_epoch, max_epochs):
         tr.set_epoch(epoch, tuple(sched["milestones"]), float(sched["gamma"]))
@@ -259,6 +282,14 @@ def main():
                       f"  {rays * world / dt / 1e6:.2f} M rays/s  mem {torch.cuda.memory_allocated() / 2**30:.1f}/"
                       f"{torch.cuda.memory_reserved() / 2**30:.1f} GiB", flush=True)
                 t0, rays = time.perf_counter(), 0
+        # ---- validation epoch (trainer.check_val_every_n_epoch, synthetic.yaml:152-154; robust_e_nerf.py:519-571):
+        # the dataset's posed validation views, rendered by all ranks, aligned and scored as the reference does
+        if val_views is not None and (epoch + 1) % val_every == 0:
+            from robust_e_nerf_amd import evaluation
+            bk = torch.nn.functional.softplus(tr.small[: fld.C]) if tcfg.bkgd_is_param else None
+            vm = evaluation.evaluate_posed_images(renderer, val_views, bk, rank, world, limit=args.limit_val_batches)
+            if rank == 0:
+                print(f"epoch {epoch} validation over {vm['n_views']} views: val/l1 {vm['l1']:.5f}  val/psnr {vm['psnr']:.3f} dB", flush=True)
         if rank == 0:
             sd = field_state_dict(fld, arch, rcfg.aabb)
             sd[CT_KEY] = tr.ct[:1].detach().cpu().clone()
@@ -271,8 +302,10 @@ def main():
             sd[OCC + "_binary"] = renderer.binary.detach().cpu().bool().view(*rcfg.occ_res)
             sd[OCC + "resolution"] = torch.tensor(rcfg.occ_res, dtype=torch.int32)
             sd[OCC + "occs"] = renderer.occs.detach().cpu().clone()
+            rng = {"batcher": batcher.gen.get_state(), "jitter": jgen.get_state(),
+                   "occ": renderer._occ_gen.get_state() if renderer._occ_gen is not None else None}
             torch.save({"state_dict": sd, "epoch": epoch, "global_step": step, "optimizer_state": tr.optimizer_state_dict(),
-                        "batch_size": batcher.batch_size}, os.path.join(args.out, "last.ckpt"))
+                        "batch_size": batcher.batch_size, "rng_state": rng}, os.path.join(args.out, "last.ckpt"))
     if world > 1:
         dist.destroy_process_group()
 

@@ -698,6 +698,76 @@ def gen_occgrid_post_warmup(nerf_mod, nerfacc):
     torch.set_num_threads(n_threads)
 
 
+def _install_cv2_stub():
+    """cv2 is absent from this image: the three calls `PosedImage` makes (imread IMREAD_UNCHANGED, cvtColor BGR2RGB /
+    BGR2GRAY on float32) over PIL / numpy -- OpenCV's documented BGR channel order and its BT.601 grey weights."""
+    from PIL import Image
+    cv2 = sys.modules["cv2"]
+    cv2.IMREAD_UNCHANGED, cv2.COLOR_BGR2RGB, cv2.COLOR_BGR2GRAY = -1, 4, 6
+
+    def imread(path, flags=None):
+        im = Image.open(path)
+        a = np.asarray(im).astype(np.uint16) if im.mode.startswith("I") else np.asarray(im)
+        if a.ndim == 3:
+            a = a[..., [2, 1, 0] + ([3] if a.shape[2] == 4 else [])]          # RGB(A) -> BGR(A)
+        return np.ascontiguousarray(a)
+
+    def cvtColor(img, code):
+        if code == cv2.COLOR_BGR2RGB:
+            return np.ascontiguousarray(img[..., ::-1])
+        assert code == cv2.COLOR_BGR2GRAY
+        return (np.float32(0.114) * img[..., 0] + np.float32(0.587) * img[..., 1] + np.float32(0.299) * img[..., 2]).astype(np.float32)
+    cv2.imread, cv2.cvtColor = imread, cvtColor
+
+
+def gen_posed_images(datasets_mod):
+    """f2: the reference's own `PosedImage` (data/datasets.py:376-690) on three tiny datasets written here: quantized
+    synthetic BGRA display renders composited over white, a 12-bit grey real capture with explicit intrinsics, and a
+    colour (Bayer) sensor.  The fixture keeps the input files' contents and the loader's outputs."""
+    import json
+    from PIL import Image
+    _install_cv2_stub()
+    g = np.random.default_rng(77)
+    out = {}
+
+    def pose(k):
+        a = 0.3 * k
+        R = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1.0]])
+        T = np.eye(4)
+        T[:3, :3], T[:3, 3] = R, [4 * np.cos(a), 4 * np.sin(a), 0.5 * k]
+        return T.tolist()
+    cases = {
+        "rgba": dict(img=g.integers(0, 256, (3, 6, 8, 4), dtype=np.uint8), stage="val", alpha=True, bayer="", seed=3,
+                     tf=dict(camera_angle_x=0.69), rp=dict(interm_color_space="display", log_eps=1e-3)),
+        "gray12": dict(img=g.integers(0, 4096, (2, 5, 7), dtype=np.uint16), stage="test", alpha=False, bayer="", seed=None,
+                       tf=dict(intrinsics=[[300.0, 0, 3.2], [0, 301.0, 2.1], [0, 0, 1]], bit_depth=12), rp=None),
+        "bayer": dict(img=g.integers(0, 256, (2, 4, 6, 3), dtype=np.uint8), stage="val", alpha=False, bayer="RGGB", seed=None,
+                      tf=dict(camera_angle_x=0.8), rp=None),
+    }
+    for name, c in cases.items():
+        root = tempfile.mkdtemp()
+        os.makedirs(os.path.join(root, "views", c["stage"]))
+        frames = []
+        for k, im in enumerate(c["img"]):
+            Image.fromarray(im).save(os.path.join(root, "views", c["stage"], f"r_{k}.png"))
+            frames.append(dict(file_path=f"./{c['stage']}/r_{k}", transform_matrix=pose(k)))
+        tf = dict(c["tf"], frames=frames)
+        json.dump(tf, open(os.path.join(root, "views", f"transforms_{c['stage']}.json"), "w"))
+        np.savez(os.path.join(root, "camera_calibration.npz"), bayer_pattern=np.array(c["bayer"]))
+        if c["rp"] is not None:
+            np.savez(os.path.join(root, "renderer_params.npz"), **{k: np.array(v) for k, v in c["rp"].items()})
+        ds = datasets_mod.PosedImage(root, c["stage"], c["seed"], alpha_over_white_bg=c["alpha"])
+        pi = ds.posed_imgs
+        out.update({f"{name}.in_img": c["img"], f"{name}.transforms": np.array(json.dumps(tf)), f"{name}.stage": np.array(c["stage"]),
+                    f"{name}.alpha": np.array(c["alpha"]), f"{name}.bayer": np.array(c["bayer"]),
+                    f"{name}.seed": np.array(-1 if c["seed"] is None else c["seed"]),
+                    f"{name}.rp": np.array(json.dumps(c["rp"])),
+                    f"{name}.img": pi.img, f"{name}.T_wc_position": pi.T_wc_position, f"{name}.T_wc_orientation": pi.T_wc_orientation,
+                    f"{name}.intrinsics": pi.intrinsics, f"{name}.sample_id": pi.sample_id,
+                    f"{name}.min": np.array(ds.min_normalized_pixel_value), f"{name}.max": np.array(ds.max_normalized_pixel_value)})
+    save("posed_images", **out)
+
+
 def main():
     assert os.path.isdir(REF), "golden vectors can only be regenerated where /root/reference exists"
     install_stubs()
@@ -725,6 +795,7 @@ def main():
     gen_dataset(datasets_mod, samplers_mod)
     gen_batch_size(rmod)
     gen_occgrid_post_warmup(nerf_mod, nerfacc)
+    gen_posed_images(datasets_mod)
 
 
 if __name__ == "__main__":

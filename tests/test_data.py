@@ -216,3 +216,38 @@ def test_reference_train_yamls_are_accepted_by_the_cli_schema():
             assert all(k in cfg[sec] for k in keys), (f, sec)
         assert set(ncfg["occ_grid"]) >= {"resolution", "occ_thre", "ema_decay", "warmup_steps", "n"}
         assert "multi_step_lr" in cfg["lr_scheduler"] and "freeze" in cfg["model"]["contrast_threshold"]
+
+
+def test_posed_image_loader_vs_reference_fixture(tmp_path):
+    """f2: data.load_posed_images against the reference's own `PosedImage` (data/datasets.py:376-690; fixture
+    posed_images.npz written by tests/golden/make_golden.py::gen_posed_images): the dataset files are rebuilt from the
+    fixture's inputs, the loader must return the reference's normalized images, poses (OpenGL -> common convention),
+    intrinsics, sample ids, permutation and pixel-value bounds."""
+    import json
+    from PIL import Image
+    from robust_e_nerf_amd import data
+    g = dict(np.load(os.path.join(GOLD, "posed_images.npz")))
+    for name in ("rgba", "gray12", "bayer"):
+        root = tmp_path / name
+        stage = str(g[f"{name}.stage"])
+        os.makedirs(root / "views" / stage)
+        for k, im in enumerate(g[f"{name}.in_img"]):
+            Image.fromarray(im).save(str(root / "views" / stage / f"r_{k}.png"))
+        (root / "views" / f"transforms_{stage}.json").write_text(str(g[f"{name}.transforms"]))
+        np.savez(str(root / "camera_calibration.npz"), bayer_pattern=np.array(str(g[f"{name}.bayer"])))
+        rp = json.loads(str(g[f"{name}.rp"]))
+        if rp is not None:
+            np.savez(str(root / "renderer_params.npz"), **{k: np.array(v) for k, v in rp.items()})
+        assert data.has_posed_images(str(root), stage) and not data.has_posed_images(str(root), "train")
+        seed = int(g[f"{name}.seed"])
+        got = data.load_posed_images(str(root), stage, alpha_over_white_bg=bool(g[f"{name}.alpha"]),
+                                     permutation_seed=None if seed < 0 else seed)
+        assert got["img"].shape == g[f"{name}.img"].shape, name
+        assert np.allclose(got["img"].numpy(), g[f"{name}.img"], rtol=2e-6, atol=1e-7), name
+        assert np.allclose(got["T_wc_position"].numpy(), g[f"{name}.T_wc_position"], atol=1e-6)
+        assert np.allclose(got["T_wc_orientation"].numpy(), g[f"{name}.T_wc_orientation"], atol=1e-6)
+        assert np.allclose(got["intrinsics"].numpy(), g[f"{name}.intrinsics"], rtol=1e-6)
+        ref_ids = ["".join(map(chr, row)).rstrip() for row in g[f"{name}.sample_id"]]
+        assert got["sample_id"] == ref_ids, (got["sample_id"], ref_ids)
+        assert abs(got["min_normalized_pixel_value"] - float(g[f"{name}.min"])) < 1e-9
+        assert abs(got["max_normalized_pixel_value"] - float(g[f"{name}.max"])) < 1e-6

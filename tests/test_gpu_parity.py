@@ -104,13 +104,10 @@ def test_ray_marching_bit_exact(amd, ct, res, cone, near, far):
     assert torch.equal(ri.cpu(), ri_o) and torch.equal(ts.cpu(), ts_o) and torch.equal(te.cpu(), te_o)
     assert int(total) > 1000
     # the speculative kernel (8 lanes per ray, used for <= 24 576 rays) against the sequential one
-    os.environ["REN_MARCH_SEQUENTIAL"] = "1"
-    try:
+    with ops.knob("march_sequential", 1):
         counts_s = ops.ray_march_count(*args)
         ri_s, ts_s, te_s = ops.ray_march_write(*args, offsets, int(total))
         torch.cuda.synchronize()
-    finally:
-        del os.environ["REN_MARCH_SEQUENTIAL"]
     assert torch.equal(counts_s, counts) and torch.equal(ri_s, ri) and torch.equal(ts_s, ts) and torch.equal(te_s, te)
     # interval cache between the two passes (march once): identical streams, also when most rays overflow it
     for cap in (7, 1024):
@@ -214,13 +211,10 @@ def test_hashgrid_fwd_bwd(amd, spec, full_table_cache):
         assert rel_err(gt3.cpu() - 1.0, tab.grad) < 1e-5, layout
     # bin regions of hashed levels are capacity-sized, not counted: with the regions halved about half of the
     # updates must take the overflow path (global atomics) and the result is still the same
-    os.environ["REN_HGB_HALVE_REGIONS"] = "1"
-    try:
+    with ops.knob("hgb_halve_regions", 1):
         gt4 = torch.zeros_like(td)
         ops.hashgrid_bwd_binned(grid, gt4, dev(gout), ws, x_unit=dev(x), n=n, layout=0)
         torch.cuda.synchronize()
-    finally:
-        del os.environ["REN_HGB_HALVE_REGIONS"]
     assert rel_err(gt4.cpu(), tab.grad) < 1e-5
 
 
@@ -238,14 +232,11 @@ def test_hashgrid_bwd_binned_sampled_count_vs_atomics(amd):
     gt = torch.zeros(n_table, device=DEV)
     ops.hashgrid_bwd(grid, gt, gout, x_unit=x, n=n, layout=0)
     ws = torch.empty(ops.hashgrid_bwd_binned_workspace_bytes(n), device=DEV, dtype=torch.uint8)
-    for halve in ("0", "1"):
-        os.environ["REN_HGB_HALVE_REGIONS"] = halve
-        try:
+    for halve in (0, 1):
+        with ops.knob("hgb_halve_regions", halve):
             gb = torch.zeros(n_table, device=DEV)
             ops.hashgrid_bwd_binned(grid, gb, gout, ws, x_unit=x, n=n, layout=0)
             torch.cuda.synchronize()
-        finally:
-            del os.environ["REN_HGB_HALVE_REGIONS"]
         assert rel_err(gb, gt) < 1e-4, halve          # fp32 sums of up to ~2 M terms per entry, in different orders
 
 
@@ -1846,6 +1837,41 @@ def test_train_cli_with_tum_vie_settings(tmp_path, arch):
     assert "resumed" in out2.stdout
     ck2 = torch.load(os.path.join(tmp_path, "last.ckpt"), map_location="cpu", weights_only=False)
     assert ck2["epoch"] == 2 and "tau_adam" in ck2["optimizer_state"]
+
+
+def test_train_cli_validation_epoch_and_posed_image_evaluation(tmp_path):
+    """f2 + f4: a dataset in the reference's layout (raw_events.npz, camera_poses.npz, camera_calibration.npz AND
+    views/transforms_val.json with 16-bit images, data/datasets.py:376-690) through scripts/train.py: the validation epoch
+    runs at trainer.check_val_every_n_epoch (synthetic.yaml:152-154) and prints the affine-aligned L1 / PSNR of
+    robust_e_nerf.py:519-696; scripts/render.py --stage val evaluates a checkpoint on the same views."""
+    import os, subprocess, sys, yaml
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(repo, "tools"))
+    import e2e_synthetic as e2e
+    ddir = os.path.join(tmp_path, "dataset")
+    n_events, _ = e2e.simulate(ddir, n_poses=61, val_views=3)
+    assert n_events > 1000 and os.path.isfile(os.path.join(ddir, "views", "transforms_val.json"))
+    cfg = yaml.safe_load(open(os.path.join(repo, "configs", "synthetic_smoke.yaml")))
+    cfg["data"]["dataset_directory"] = ddir
+    cfg["trainer"].update(max_epochs=2, limit_train_batches=40, check_val_every_n_epoch=1)
+    path = os.path.join(tmp_path, "cfg.yaml")
+    yaml.safe_dump(cfg, open(path, "w"))
+    out = subprocess.run([sys.executable, os.path.join(repo, "scripts", "train.py"), "--config", path, "--out", str(tmp_path)],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    vals = [l for l in out.stdout.splitlines() if "val/psnr" in l]
+    assert len(vals) == 2 and "over 3 views" in vals[0], out.stdout[-1500:]
+    ps = [float(l.split("val/psnr")[1].split()[0]) for l in vals]
+    assert all(math.isfinite(p) and p > 5.0 for p in ps), ps
+    rv = subprocess.run([sys.executable, os.path.join(repo, "scripts", "render.py"), "--config", path, "--ckpt",
+                         os.path.join(tmp_path, "last.ckpt"), "--out", os.path.join(tmp_path, "val"), "--stage", "val"],
+                        capture_output=True, text=True, timeout=600)
+    assert rv.returncode == 0, rv.stderr[-2000:]
+    line = [l for l in rv.stdout.splitlines() if l.startswith("val:")][0]
+    assert abs(float(line.split("mean PSNR")[1].split()[0]) - ps[-1]) < 0.05, (line, ps)   # same checkpoint, same views
+    # the checkpoint carries the random streams: resuming continues them (ADVICE r2)
+    ck = torch.load(os.path.join(tmp_path, "last.ckpt"), map_location="cpu", weights_only=False)
+    assert set(ck["rng_state"]) == {"batcher", "jitter", "occ"}
 
 
 def test_event_interval_construction_on_device_equals_host():

@@ -60,8 +60,29 @@ def rotmats(quat_xyzw):
     return torch.from_numpy(Rotation.from_quat(quat_xyzw).as_matrix().astype(np.float32))
 
 
-def simulate(out_dir):
-    tab_ts, tab_pos, tab_quat, Kinv = bench.synthetic_scene()
+def write_val_views(out_dir, Kinv, n=6, bit_depth=16):
+    """the novel views as the reference's posed-image layout (data/datasets.py:376-690): views/transforms_val.json with
+    OpenGL camera-to-world matrices and explicit intrinsics, images as 16-bit grey PNGs (a real-capture style dataset:
+    quantized, no renderer_params.npz)"""
+    import json
+    from PIL import Image
+    os.makedirs(os.path.join(out_dir, "views", "val"), exist_ok=True)
+    Kinv_d = torch.from_numpy(Kinv).to(DEV) if not torch.is_tensor(Kinv) else Kinv
+    frames, levels = [], 2 ** bit_depth
+    for j, (pos, rot) in enumerate(novel_views(n)):
+        img = render_scene(Kinv_d, pos, rot)                                 # linear intensity in (0, 1)
+        q = (img * levels).floor().clamp(0, levels - 1).to(torch.int32).cpu().numpy().astype(np.uint16)
+        Image.fromarray(q).save(os.path.join(out_dir, "views", "val", f"r_{j}.png"))
+        T = np.eye(4)
+        T[:3, :3] = rot.cpu().numpy().astype(np.float64) @ np.diag([1.0, -1.0, -1.0])      # common -> OpenGL camera frame
+        T[:3, 3] = pos.cpu().numpy()
+        frames.append(dict(file_path=f"./val/r_{j}", transform_matrix=T.tolist()))
+    K = np.linalg.inv(Kinv_d.cpu().numpy().astype(np.float64))
+    json.dump(dict(intrinsics=K.tolist(), frames=frames), open(os.path.join(out_dir, "views", "transforms_val.json"), "w"))
+
+
+def simulate(out_dir, n_poses=2001, val_views=6):
+    tab_ts, tab_pos, tab_quat, Kinv = bench.synthetic_scene(n_poses)
     Kinv_d, rot = torch.from_numpy(Kinv).to(DEV), rotmats(tab_quat).to(DEV)
     pos = torch.from_numpy(tab_pos).to(DEV)
     eps = 1e-3
@@ -94,6 +115,8 @@ def simulate(out_dir):
     np.savez(os.path.join(out_dir, "camera_calibration.npz"), intrinsics=np.linalg.inv(Kinv.astype(np.float64)),
              img_width=W, img_height=H, distortion_params=np.zeros(4), distortion_model="plumb_bob", bayer_pattern="",
              pos_contrast_threshold=CT, neg_contrast_threshold=CT, refractory_period=0.0)
+    if val_views:
+        write_val_views(out_dir, Kinv_d, val_views)
     return len(t), Kinv_d
 
 
@@ -176,10 +199,18 @@ def main():
     if log.returncode:
         raise SystemExit("training failed")
     scores = evaluate(os.path.join(args.out, "run", "last.ckpt"), Kinv_d, cfg, png=os.path.join(args.out, "e2e_novel_views.png"))
+    # the same views through the reference's dataset layout: views/transforms_val.json (16-bit PNGs) -> scripts/render.py --stage val
+    rv = subprocess.run([sys.executable, os.path.join(REPO, "scripts", "render.py"), "--config", cfg_path, "--ckpt",
+                         os.path.join(args.out, "run", "last.ckpt"), "--out", os.path.join(args.out, "val_render"), "--stage", "val"],
+                        capture_output=True, text=True)
+    val_line = [l for l in rv.stdout.splitlines() if l.startswith("val:")]
+    val_epochs = [l for l in log.stdout.splitlines() if "val/psnr" in l]
     res = {"what": "tools/e2e_synthetic.py: simulated events of an analytic scene -> scripts/train.py -> novel-view PSNR "
                    "after affine log alignment (left/right halves of e2e_novel_views.png: analytic scene / prediction)",
            "mean_psnr_db_after_1_step": float(np.mean(scores0)), "events": n_events, "simulate_s": t_sim, "train_s": t_train, "epochs": args.epochs,
            "steps": args.epochs * args.steps_per_epoch, "novel_view_psnr_db": scores, "mean_psnr_db": float(np.mean(scores)),
+           "posed_image_validation (scripts/render.py --stage val)": val_line[0] if val_line else rv.stderr[-500:],
+           "validation_epochs (scripts/train.py)": val_epochs,
            "train_log_tail": log.stdout.strip().splitlines()[-6:]}
     json.dump(res, open(os.path.join(args.out, "e2e_result.json"), "w"), indent=1)
     print(json.dumps(res, indent=1))

@@ -22,15 +22,14 @@ for k, n in enumerate(sizes):
     ref = torch.zeros(n_table, device=dev)
     ops.hashgrid_bwd(grid, ref, gout, x_unit=x, n=n, layout=0)
     ws = torch.empty(ops.hashgrid_bwd_binned_workspace_bytes(n), device=dev, dtype=torch.uint8)
-    for halve in ("0", "1"):
-        os.environ["REN_HGB_HALVE_REGIONS"] = halve
-        out = torch.zeros(n_table, device=dev)
-        ops.hashgrid_bwd_binned(grid, out, gout, ws, x_unit=x, n=n, layout=0)
-        torch.cuda.synchronize()
+    for halve in (0, 1):
+        with ops.knob("hgb_halve_regions", halve):
+            out = torch.zeros(n_table, device=dev)
+            ops.hashgrid_bwd_binned(grid, out, gout, ws, x_unit=x, n=n, layout=0)
+            torch.cuda.synchronize()
         err = float((out - ref).abs().max() / ref.abs().max().clamp(min=1e-30))
         worst = max(worst, err)
         flag = "" if err < 2e-4 else "   <-- MISMATCH"
         print(f"n={n:8d} mode={mode} halve={halve} rel err {err:.2e}{flag}", flush=True)
-os.environ.pop("REN_HGB_HALVE_REGIONS", None)
 print("worst", worst)
 assert worst < 2e-4

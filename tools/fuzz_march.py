@@ -3,7 +3,7 @@ random occupancy grids of several densities and resolutions, all contraction typ
 import math, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from robust_e_nerf_amd import ops
+from robust_e_nerf_amd import _lib, ops
 dev = "cuda:0"
 g = torch.Generator().manual_seed(0)
 aabb = (-1.5, -1.5, -1.5, 1.5, 1.5, 1.5)
@@ -29,7 +29,7 @@ for trial in range(48):
     args = (o, d, tmin, tmax, jit, aabb, (res,) * 3, binary, ct, step, cone, 0, 0)
     out = {}
     for seq in ("1", "0"):
-        os.environ["REN_MARCH_SEQUENTIAL"] = seq
+        _lib.load().ren_set_knob(ops.KNOBS["march_sequential"], int(seq))
         counts = ops.ray_march_count(*args)
         offsets, total = ops.exclusive_scan(counts)
         n = int(total)
@@ -40,7 +40,7 @@ for trial in range(48):
         torch.cuda.synchronize()
         same_c = torch.equal(counts_c, counts) and torch.equal(ri_c, ri) and torch.equal(ts_c, ts) and torch.equal(te_c, te)
         out[seq] = (counts, ri, ts, te, same_c)
-    os.environ.pop("REN_MARCH_SEQUENTIAL")
+    _lib.load().ren_set_knob(ops.KNOBS["march_sequential"], 0)
     a, b = out["1"], out["0"]
     ok = all(torch.equal(a[k], b[k]) for k in range(4)) and a[4] and b[4]
     bad += not ok

@@ -2,7 +2,7 @@
 import os, sys, time, math
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from robust_e_nerf_amd import ops, engine
+from robust_e_nerf_amd import _lib, ops, engine
 dev = "cuda:0"
 R, S = 131072, 128
 grid, n_table = ops.make_grid_desc()
@@ -30,7 +30,7 @@ def timeit(fn, reps=3):
     torch.cuda.synchronize()
     return (time.perf_counter() - t) / reps * 1e3
 for v in os.environ.get("VARIANTS", "0,1,2,3").split(","):
-    os.environ["REN_HG_VARIANT"] = v
+    _lib.load().ren_set_knob(ops.KNOBS["hg_variant"], int(v))
     tf = timeit(lambda: ops.hashgrid_fwd(grid, table, scene=scene, rays=(o, d), samples=samples, n=n, layout=1))
     tb = timeit(lambda: ops.hashgrid_bwd(grid, gt, dfeat, scene=scene, rays=(o, d), samples=samples, n=n, layout=1))
     print(f"variant {v}: fwd {tf:.2f} ms ({1036*n/tf/1e6:.0f} GB/s alg)  bwd {tb:.2f} ms ({2060*n/tb/1e6:.0f} GB/s alg)", flush=True)
@@ -38,7 +38,7 @@ for v in os.environ.get("VARIANTS", "0,1,2,3").split(","):
 ws = torch.empty(ops.hashgrid_bwd_binned_workspace_bytes(n), device=dev, dtype=torch.uint8)
 tb = timeit(lambda: ops.hashgrid_bwd_binned(grid, gt, dfeat, ws, scene=scene, rays=(o, d), samples=samples, n=n, layout=1))
 print(f"binned: bwd {tb:.2f} ms ({2060*n/tb/1e6:.0f} GB/s alg)", flush=True)
-gt.zero_(); os.environ["REN_HG_VARIANT"] = "2"
+gt.zero_(); _lib.load().ren_set_knob(ops.KNOBS["hg_variant"], 2)
 ops.hashgrid_bwd(grid, gt, dfeat, scene=scene, rays=(o, d), samples=samples, n=n, layout=1)
 ga = gt.clone(); gt.zero_()
 ops.hashgrid_bwd_binned(grid, gt, dfeat, ws, scene=scene, rays=(o, d), samples=samples, n=n, layout=1)
