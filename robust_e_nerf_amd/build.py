@@ -14,7 +14,7 @@ COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-at
 # the one-wave-per-SIMD MLP backward kernels: MFMA results in VGPRs (the chain's VALU work reads them directly) instead of
 # the AGPR form + one v_accvgpr_read per result register that hipcc picks for kernels with a 512-register budget
 PER_FILE = {"ren_sampling.hip": ["-ffp-contract=off"], "ren_jvp2.hip": ["-fno-slp-vectorize"],
-            "ren_mlp_x.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+            "ren_mlp_x.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], "ren_mlp_jvp_x.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _stale(target, deps):

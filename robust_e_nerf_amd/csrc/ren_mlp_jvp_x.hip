@@ -251,7 +251,7 @@ struct BwdJX2Args {
 };
 
 template <int MODE> struct H2Lds {
-    static constexpr int NT = Pairs<MODE>::NT, NP = MODE == 1 ? 1 : 2;
+    static constexpr int NT = Pairs<MODE>::NT, NP = MODE == 1 ? 1 : 3;
     static constexpr int F_WH1 = 0, F_WH2 = F_WH1 + 2 * 2 * NT * 512, F_WH2T = F_WH2 + 2 * 4 * NT * 512;
     static constexpr int F_END = F_WH2T + 2 * 4 * NT * 512;
     static constexpr int T_W3 = 0, T_BH1 = 256, T_BH2 = 320, T_END = 384;
@@ -475,7 +475,7 @@ struct BwdJX1Args {
 };
 
 template <int MODE> struct H1Lds {
-    static constexpr int NT = Pairs<MODE>::NT, NP = MODE == 1 ? 1 : 2;
+    static constexpr int NT = Pairs<MODE>::NT, NP = MODE == 1 ? 1 : 3;
     static constexpr int F_WH1T = 0, F_END = 1 * 4 * NT * 512;
     static constexpr size_t TILE = (size_t)NP * 32 * ST * 2;
     static constexpr size_t BYTES = (size_t)F_END * 2 + 4 * 2 * TILE;
@@ -599,7 +599,7 @@ struct BwdJXBArgs {
 };
 
 template <int MODE> struct BJLds {
-    static constexpr int NT = Pairs<MODE>::NT, NP = MODE == 1 ? 1 : 2;
+    static constexpr int NT = Pairs<MODE>::NT, NP = MODE == 1 ? 1 : 3;
     static constexpr int F_W1 = 0, F_W2T = F_W1 + 2 * 2 * NT * 512, F_W1T = F_W2T + 2 * 1 * NT * 512;
     static constexpr int F_END = F_W1T + 1 * 4 * NT * 512;
     static constexpr size_t TILE = (size_t)NP * 32 * ST * 2;

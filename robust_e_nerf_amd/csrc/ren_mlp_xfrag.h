@@ -102,7 +102,8 @@ __device__ __forceinline__ void mma1x2(f32x16 &acca, f32x16 &accb, const __bf16 
     }
 }
 
-// ---- weight-gradient staging (backward kernels) --------------------------------------------------------------
+// ---- weight-gradient staging through LDS (the tangent kernels of ren_mlp_jvp_x.hip; the value kernels of ren_mlp_x.hip
+// transpose on the matrix cores instead, see below) ---------------------------------------------------------------
 constexpr int ST = 40;                                   // staging row stride in bf16 (32 samples + pad, 80 B)
 template <int NP> struct StageBytes { static constexpr int TILE = NP * 32 * ST * 2; };   // one 32-neuron tile
 
@@ -149,7 +150,10 @@ __device__ __forceinline__ void dw_tile(f32x16 &acc, const __bf16 *Tz, const __b
             az[k] = *reinterpret_cast<const bf16x8 *>(Tz + (k * 32 + sl) * ST + 16 * c + 8 * hi);
             ba[k] = *reinterpret_cast<const bf16x8 *>(Ta + (k * 32 + sl) * ST + 16 * c + 8 * hi);
         }
-        if (NP == 2) { acc = MFMAB(az[1], ba[0], acc); acc = MFMAB(az[0], ba[1], acc); }
+        if (NP == 3) {                                    // six terms, smallest first: fp32 round-off per product
+            acc = MFMAB(az[2], ba[0], acc); acc = MFMAB(az[0], ba[2], acc); acc = MFMAB(az[1], ba[1], acc);
+        }
+        if (NP >= 2) { acc = MFMAB(az[1], ba[0], acc); acc = MFMAB(az[0], ba[1], acc); }
         acc = MFMAB(az[0], ba[0], acc);
     }
 }
