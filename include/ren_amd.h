@@ -538,7 +538,8 @@ int ren_act_jvp_bwd(const float *gy, const float *gyd, const float *Y, int32_t l
                     float *gzd, int64_t rows, int32_t width, void *stream);
 int64_t ren_dense_bwd_weight_workspace_floats(int32_t n_out, int32_t n_in, int32_t n_splits);
 /* Matrix-core path of ren_dense_bwd_weight: OR (REN_DENSE_BF16X6 or REN_DENSE_BF16) << 8 into n_splits (bits 16..23) for
- * bf16 MFMAs on operands split into two bf16 pieces (three MFMAs per product pair); default: exact f32 MFMA. */
+ * bf16 MFMAs: REN_DENSE_BF16X6 = operands split into three bf16 pieces, six MFMAs per product pair (fp32 round-off);
+ * REN_DENSE_BF16 = plain bf16 operands (one MFMA); default: exact f32 MFMA. */
 int ren_dense_bwd_weight(const float *dZ, int32_t ldz, const float *X, int32_t ldx, int32_t n_out, int32_t n_in,
                          int64_t n, int32_t n_splits, float *grad_w, float *grad_b, float *workspace,
                          void *stream);

@@ -599,13 +599,13 @@ __global__ __launch_bounds__(512, 1) void dense_dw_kernel(DwArgs a) {
 // transposes of the row-major [sample][feature] tiles.  The stage loader does the transposition while it splits:
 // thread (sample s = tid & 31, feature group tid >> 5) loads 16 consecutive features of its sample row and writes
 // them as bf16 pieces to [piece][feature][sample] (lanes of a wave vary s: consecutive 2-byte addresses, conflict
-// free), so both operands are read back as one ds_read_b128.  Two pieces / three MFMAs per product pair (as the
-// weight gradients of ren_mlp_x.hip: a sum over ~1e6 samples is noisier than 2^-16 per product), i.e. 48 bf16 MFMAs
-// (1 536 matrix-pipe cycles) per wave and 32-sample stage against 128 f32 MFMAs (8 192).  The bias gradient is an
+// free), so both operands are read back as one ds_read_b128.  fp32 modes: three pieces / six MFMAs per product pair
+// (fp32 round-off per product, as everywhere else), i.e. 96 bf16 MFMAs (3 072 matrix-pipe cycles) per wave and 32-sample
+// stage against 128 f32 MFMAs (8 192); bf16 mode: one piece, one MFMA.  The bias gradient is an
 // fp32 side sum of the loader's own values.
 constexpr int DWX_ST = 40;                               // [feature][32 samples + 8 pad] bf16: 80-byte rows
-constexpr int DWX_NP = 2;
-
+// DWX_NP pieces per operand: 3 (six product terms: fp32 round-off, the fp32 modes) or 1 (plain bf16 operands, `mlp_bf16`)
+template <int DWX_NP>
 __global__ __launch_bounds__(512, 1) void dense_dw_x_kernel(DwArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_dw[];    // ZT | XT: [NP][256][DWX_ST] bf16 each
     __bf16 *ZT = reinterpret_cast<__bf16 *>(smem_dw), *XT = ZT + DWX_NP * 256 * DWX_ST;
@@ -681,8 +681,15 @@ __global__ __launch_bounds__(512, 1) void dense_dw_x_kernel(DwArgs a) {
 #pragma unroll
                             for (int p = 0; p < DWX_NP; ++p)
                                 bx[p] = *reinterpret_cast<const bf16x8 *>(XT + (p * 256 + t * 32 + sl) * DWX_ST + 16 * ks + 8 * hi);
-                            acc[t] = MFMAB(az[1], bx[0], acc[t]);
-                            acc[t] = MFMAB(az[0], bx[1], acc[t]);
+                            if (DWX_NP == 3) {
+                                acc[t] = MFMAB(az[2], bx[0], acc[t]);
+                                acc[t] = MFMAB(az[0], bx[2], acc[t]);
+                                acc[t] = MFMAB(az[1], bx[1], acc[t]);
+                            }
+                            if (DWX_NP >= 2) {
+                                acc[t] = MFMAB(az[1], bx[0], acc[t]);
+                                acc[t] = MFMAB(az[0], bx[1], acc[t]);
+                            }
                             acc[t] = MFMAB(az[0], bx[0], acc[t]);
                         }
                 }
@@ -1086,10 +1093,14 @@ extern "C" int ren_dense_bwd_weight(const float *dZ, int32_t ldz, const float *X
     a.dZ = dZ; a.ldz = ldz; a.N = n_out; a.X = X; a.ldx = ldx; a.K = n_in; a.n = n;
     a.slab_w = workspace; a.slab_b = workspace + (int64_t)n_splits * n_out * n_in;
     hipStream_t st = (hipStream_t)stream;
-    if (mode != 0) {                                                           // bf16 matrix cores (split, 2 pieces)
-        const size_t lds = 2 * (size_t)DWX_NP * 256 * DWX_ST * 2;              // 80 KiB
-        (void)hipFuncSetAttribute((const void *)dense_dw_x_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(dense_dw_x_kernel, dim3(n_splits), dim3(512), lds, st, a);
+    if (mode == 1) {                                                           // bf16 matrix cores, plain bf16 operands
+        const size_t lds = 2 * (size_t)1 * 256 * DWX_ST * 2;                   // 40 KiB
+        (void)hipFuncSetAttribute((const void *)dense_dw_x_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(dense_dw_x_kernel<1>, dim3(n_splits), dim3(512), lds, st, a);
+    } else if (mode != 0) {                                                    // bf16 matrix cores, three pieces / six terms
+        const size_t lds = 2 * (size_t)3 * 256 * DWX_ST * 2;                   // 120 KiB
+        (void)hipFuncSetAttribute((const void *)dense_dw_x_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(dense_dw_x_kernel<3>, dim3(n_splits), dim3(512), lds, st, a);
     } else {
         const size_t lds = 2 * 2 * 32 * 256 * sizeof(float);                   // 128 KiB: one workgroup per CU
         (void)hipFuncSetAttribute((const void *)dense_dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
