@@ -38,7 +38,7 @@ VANILLA_MACS = 593152            # 63-256x4-(+63)-256x3, sigm
 FLOPS = {"mlp_fwd": 2 * MLP_MACS, "mlp_bwd": 4 * MLP_MACS, "mlp_fwd_save": 2 * MLP_MACS, "mlp_bwd_saved": 4 * MLP_MACS,
          "mlp_fwd_x": 2 * MLP_MACS, "mlp_bwd_x": 4 * MLP_MACS, "dense_fwd": 2 * VANILLA_MACS,
          "dense_bwd_data": 2 * VANILLA_MACS, "dense_bwd_weight": 2 * VANILLA_MACS}
-PMC_TRAFFIC = os.path.join(REPO, "profiles", "r02_pmc_traffic.json")
+PMC_TRAFFIC = os.path.join(REPO, "profiles", "r03_pmc_traffic.json")
 
 
 def pmc_traffic(call, args):

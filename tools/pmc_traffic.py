@@ -40,7 +40,7 @@ def main():
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) around "
                      "`python bench.py --steps 2 --warmup 1 --no-cpu-baseline --fwd-chunks 1`",
            "corrections": "bytes = 1024 x counter; FETCH_SIZE doubled (gfx950, MI355X_MICROARCH.md HBM section)",
-           "workload": {"events": 32768, "samples": 128, "sampler": "uniform", "loss_grad": 0.0}, "calls": {}}
+           "workload": {"events": 65536, "samples": 128, "sampler": "uniform", "loss_grad": 0.0}, "calls": {}}
     for call, parts in GROUPS.items():
         f = w = 0.0
         for frag, mult in parts:

@@ -1,8 +1,8 @@
 # Regenerates everything under profiles/ on a GPU box (run from the repo root through gpurun); results land in
 # gpurun_out/$RND/ and profiles/ (the bench reads profiles/${RND}_pmc_traffic.json for roofline.traffic).
-#   gpurun --timeout 1700 -- 'bash tools/regen_profiles.sh r02'
+#   gpurun --timeout 1700 -- 'bash tools/regen_profiles.sh r03'
 set -x
-RND=${1:-r02}
+RND=${1:-r03}
 R=$PWD
 O=$R/gpurun_out/$RND
 mkdir -p $O
@@ -16,16 +16,16 @@ cd $R
 python tools/pmc_traffic.py $O/pmc_FETCH_SIZE/pmc_results.db $O/pmc_WRITE_SIZE/pmc_results.db profiles/${RND}_pmc_traffic.json > /dev/null
 python tools/pmc_mfma.py $O/pmc_mfma/pmc_results.db profiles/${RND}_pmc_mfma.json > /dev/null
 python bench.py > profiles/${RND}_bench.json 2> $O/bench.err
-python bench.py --no-cpu-baseline --events 65536 > profiles/${RND}_bench_2x.json 2>>$O/bench.err
+python bench.py --no-cpu-baseline --events 32768 > profiles/${RND}_bench_half.json 2>>$O/bench.err
 python bench.py --no-cpu-baseline --sampler occgrid > profiles/${RND}_bench_occgrid.json 2>>$O/bench.err
-python bench.py --no-cpu-baseline --loss-grad 1e-3 > profiles/${RND}_bench_lossgrad.json 2>>$O/bench.err
-python bench.py --no-cpu-baseline --loss-grad 1e-3 --mlp-bf16 > profiles/${RND}_bench_lossgrad_bf16.json 2>>$O/bench.err
+python bench.py --no-cpu-baseline --events 32768 --loss-grad 1e-3 > profiles/${RND}_bench_lossgrad.json 2>>$O/bench.err
+python bench.py --no-cpu-baseline --events 32768 --loss-grad 1e-3 --mlp-bf16 > profiles/${RND}_bench_lossgrad_bf16.json 2>>$O/bench.err
 python bench.py --no-cpu-baseline --mlp-bf16 > profiles/${RND}_bench_bf16.json 2>>$O/bench.err
 python bench.py --no-cpu-baseline --mlp-kernels f32 > profiles/${RND}_bench_f32mfma.json 2>>$O/bench.err
 python bench.py --no-cpu-baseline --save-activations 1 > profiles/${RND}_bench_saved_activations.json 2>>$O/bench.err
 python bench.py --no-cpu-baseline --workload e --events 8192 > profiles/${RND}_bench_config_e.json 2>>$O/bench.err
-python bench.py --no-cpu-baseline --hard --loss-grad 1e-3 --mlp-bf16 > profiles/${RND}_bench_hard_bf16.json 2>>$O/bench.err
-python bench.py --no-cpu-baseline --hard --loss-grad 1e-3 > profiles/${RND}_bench_hard.json 2>>$O/bench.err
+python bench.py --no-cpu-baseline --events 32768 --hard --loss-grad 1e-3 --mlp-bf16 > profiles/${RND}_bench_hard_bf16.json 2>>$O/bench.err
+python bench.py --no-cpu-baseline --events 32768 --hard --loss-grad 1e-3 > profiles/${RND}_bench_hard.json 2>>$O/bench.err
 python bench.py --no-cpu-baseline --arch mlp --events 4096 > profiles/${RND}_bench_arch_mlp.json 2>>$O/bench.err
 python bench.py --no-cpu-baseline --arch mlp --events 4096 --mlp-bf16 > profiles/${RND}_bench_arch_mlp_bf16.json 2>>$O/bench.err
 REN_BENCH_DIST=nccl:single-rank python bench.py --no-cpu-baseline > profiles/${RND}_bench_dp_rccl_single_rank.json 2>>$O/bench.err
@@ -33,5 +33,5 @@ python tools/render_bench.py --config-e > profiles/${RND}_render_config_e.txt 2>
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o x -- python $R/bench.py --no-cpu-baseline > /dev/null 2>&1
 cd $R
-python tools/summarize_profile.py $(find $O/prof -name '*kernel_stats.csv' | head -1) profiles/${RND}_bench_kernel_stats.csv "rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline (13 steps of BASELINE configs[1])"
+python tools/summarize_profile.py $(find $O/prof -name '*kernel_stats.csv' | head -1) profiles/${RND}_bench_kernel_stats.csv "rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline (13 steps of BASELINE configs[1], R = 65 536 rays per render)"
 cp profiles/${RND}_* $O/; ls $O
