@@ -75,17 +75,85 @@ class VanillaField:
         return out
 
 
-class _Buffers:
-    """Activation buffers for n samples: row-major [n_pad][ld], zero padding columns."""
+class Trunk:
+    """The eight hidden layers as fused launches (csrc/ren_trunk.hip; include/ren_amd.h `ren_trunk_*`): forward with the
+    activations saved in the kernels' fragment layout, backward (data), weight gradient.  mode 1 = bf16 operands / bf16
+    saved copies, 6 = three-piece split (fp32 round-off) / fp32 saved copies."""
 
-    def __init__(self, n: int, dev, C: int, full: bool, backward: bool):
+    def __init__(self, fld: VanillaField, mode: int, n_splits: int = 256):
+        self.field, self.mode, self.n_splits = fld, mode, n_splits
+        lib = _lib.load()
+        self.image = torch.empty(int(lib.ren_trunk_image_bytes(mode)), device=fld.flat.device, dtype=torch.uint8)
+        self._ws = None
+        self._version = None
+
+    def prep(self):
+        """rebuild the weight image from the current parameters (once per optimiser step / checkpoint load)"""
+        check(_lib.load().ren_trunk_prep(_ptr(self.field.flat), self.mode, _ptr(self.image, torch.uint8), _stream()), "ren_trunk_prep")
+
+    def new_saved(self, n: int) -> torch.Tensor:
+        return torch.empty(int(_lib.load().ren_trunk_saved_bytes(self.mode, n)), device=self.field.flat.device, dtype=torch.uint8)
+
+    def forward(self, enc, n, saved, h7):
+        check(_lib.load().ren_trunk_fwd(_ptr(enc), enc.shape[1], _ptr(self.field.flat), _ptr(self.image, torch.uint8), self.mode, n,
+                                        _ptr(saved, torch.uint8) if saved is not None else None,
+                                        _ptr(h7) if h7 is not None else None, h7.shape[1] if h7 is not None else 0, _stream()),
+              "ren_trunk_fwd")
+
+    def backward(self, dz7, n, saved, dz):
+        check(_lib.load().ren_trunk_bwd(_ptr(dz7), dz7.shape[1], _ptr(self.image, torch.uint8), self.mode, n,
+                                        _ptr(saved, torch.uint8), _ptr(dz, torch.uint8), _stream()), "ren_trunk_bwd")
+
+    def backward_weight(self, dz, saved, enc, n):
+        lib = _lib.load()
+        splits = max(1, min(self.n_splits, (n + 31) // 32))
+        need = int(lib.ren_trunk_bwd_weight_workspace_floats(splits))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, device=enc.device, dtype=torch.float32)
+        check(lib.ren_trunk_bwd_weight(_ptr(dz, torch.uint8), _ptr(saved, torch.uint8), _ptr(enc), enc.shape[1], self.mode, n, splits,
+                                       _ptr(self.field.grad), _ptr(self._ws), _stream()), "ren_trunk_bwd_weight")
+
+    def decode(self, saved: torch.Tensor, n: int) -> List[torch.Tensor]:
+        """fragment layout -> eight row-major (n, 256) float32 tensors (tests / tools only)"""
+        n_blk = (n + 31) // 32
+        dev = saved.device
+        lane = torch.arange(64, device=dev)
+        sl, hi = lane & 31, lane >> 5
+        if self.mode == 1:
+            v = saved.view(torch.bfloat16).view(8, n_blk, 16, 64, 8).float()
+            c, j = torch.arange(16, device=dev), torch.arange(8, device=dev)
+            feat = ((c >> 1) * 32 + 16 * (c & 1))[:, None, None] + (8 * (j >> 2) + (j & 3))[None, None, :] + 4 * hi[None, :, None]
+            samp = sl[None, :, None].expand(16, 64, 8)
+        else:
+            v = saved.view(torch.float32).view(8, n_blk, 32, 64, 4)
+            tq, j = torch.arange(32, device=dev), torch.arange(4, device=dev)
+            feat = (8 * tq)[:, None, None] + 4 * hi[None, :, None] + j[None, None, :]
+            samp = sl[None, :, None].expand(32, 64, 4)
+        out = torch.empty(8, n_blk, 32, 256, device=dev)
+        out[:, :, samp.reshape(-1), feat.reshape(-1)] = v.reshape(8, n_blk, -1)
+        return [out[l].reshape(n_blk * 32, 256)[:n] for l in range(8)]
+
+
+class _Buffers:
+    """Activation buffers for n samples: row-major [n_pad][ld], zero padding columns.  `trunk` (a Trunk): the hidden layers
+    run fused -- only the encoding, the last layer's row-major copy for the heads and (save=True) the fragment-layout
+    activations exist; otherwise one row-major buffer per layer (the dense-layer launches and the tangent stream)."""
+
+    def __init__(self, n: int, dev, C: int, full: bool, backward: bool, trunk: Optional[Trunk] = None, save: bool = False):
         self.n, self.n_pad = n, (n + 31) // 32 * 32
         # no pre-zeroing: every kernel writes all rows < n_pad of its output columns and the encoder writes the
         # zero padding columns; rows >= n only ever feed their own (discarded) output rows
         z = lambda ld: torch.empty(self.n_pad, ld, device=dev, dtype=torch.float32)
         self.enc = z(64)
-        self.cat = z(320)                                   # [h4 (256) | enc (63) | 0]
-        self.h = {i: (None if i == SKIP else z(WIDTH)) for i in range(DEPTH)}
+        self.trunk = trunk
+        if trunk is None:
+            self.cat = z(320)                               # [h4 (256) | enc (63) | 0]
+            self.h = {i: (None if i == SKIP else z(WIDTH)) for i in range(DEPTH)}
+        else:
+            self.cat = None
+            self.h = {DEPTH - 1: z(WIDTH)}
+            self.saved = trunk.new_saved(n) if save else None
         self.sel = torch.zeros(self.n_pad, device=dev, dtype=torch.uint8)
         self.s4 = z(4)
         if full:
@@ -109,11 +177,16 @@ class VanillaRenderer(Renderer):
         self._reuse_prepass_feat = False            # frequency encoding: nothing worth carrying over
         self.n_splits = n_splits
         self._dw_ws = None
+        self._trunks = {}
+        self.fused_trunk = True                     # csrc/ren_trunk.hip for the eight hidden layers (matrix-core modes)
         # HIP-event timing per kernel family when ops.profile_start() is active (bench.py)
         self._fwd = ops._wrap("dense_fwd", self._fwd)
         self._bwd_data = ops._wrap("dense_bwd_data", self._bwd_data)
         self._bwd_weight = ops._wrap("dense_bwd_weight", self._bwd_weight)
         self._encode = ops._wrap("freq_encode", self._encode)
+        self._trunk_fwd = ops._wrap("trunk_fwd", self._trunk_fwd)
+        self._trunk_bwd = ops._wrap("trunk_bwd", self._trunk_bwd)
+        self._trunk_dw = ops._wrap("trunk_bwd_weight", self._trunk_dw)
 
     def dp_early_slice(self):
         return None                                 # no hash table: the 2.4 MB of dense weights go in the one packed all-reduce
@@ -125,6 +198,28 @@ class VanillaRenderer(Renderer):
         if self.cfg.mlp_bf16:
             return 1
         return 6 if self.cfg.mlp_kernels == "x" else 0
+
+    def _fused(self) -> Optional[Trunk]:
+        """the fused-trunk object of the current matrix-core mode with a weight image of the CURRENT parameters, or None
+        (exact-f32 mode / fused_trunk off).  Called once per field evaluation: the image is 9 us to rebuild, which is cheaper
+        than tracking every place the flat parameter buffer can change (Adam, load, tests)."""
+        mode = self._dense_mode()
+        if not self.fused_trunk or mode == 0:
+            return None
+        tr = self._trunks.get(mode)
+        if tr is None:
+            tr = self._trunks[mode] = Trunk(self.field, mode, self.n_splits)
+        tr.prep()
+        return tr
+
+    def _trunk_fwd(self, tr, B):
+        tr.forward(B.enc, B.n, B.saved, B.h[DEPTH - 1])
+
+    def _trunk_bwd(self, tr, dz7, B, dz):
+        tr.backward(dz7, B.n, B.saved, dz)
+
+    def _trunk_dw(self, tr, dz, B):
+        tr.backward_weight(dz, B.saved, B.enc, B.n)
 
     def _fwd(self, X, ldx, name, act, Y, ldy, n, sel=None):
         f = self.field
@@ -156,17 +251,21 @@ class VanillaRenderer(Renderer):
         o, d = rays if rays is not None else (None, None)
         ri, ts, te = samples if samples is not None else (None, None, None)
         check(_lib.load().ren_freq_encode(ctypes.byref(self.scene), _ptr(x_world), _ptr(dirs), _ptr(o), _ptr(d),
-                                          _ptr(ri, torch.int32), _ptr(ts), _ptr(te), n, _ptr(B.enc), 64, _ptr(B.cat), 320,
+                                          _ptr(ri, torch.int32), _ptr(ts), _ptr(te), n, _ptr(B.enc), 64,
+                                          _ptr(B.cat) if B.cat is not None else None, 320,
                                           256, _ptr(B.rin) if full else None, 288, 256, _ptr(B.sel, torch.uint8), _stream()),
               "ren_freq_encode")
 
     def _trunk(self, B: _Buffers):
         n = B.n
-        X, ldx = B.enc, 64
-        for i in range(DEPTH):                                             # mlp.py:99-113
-            Y, ldy = B.out_of(i)
-            self._fwd(X, ldx, f"mlp.base.hidden_layers.{i}", ACT_SOFTPLUS100, Y, ldy, n)
-            X, ldx = Y, ldy
+        if B.trunk is not None:
+            self._trunk_fwd(B.trunk, B)
+        else:
+            X, ldx = B.enc, 64
+            for i in range(DEPTH):                                         # mlp.py:99-113
+                Y, ldy = B.out_of(i)
+                self._fwd(X, ldx, f"mlp.base.hidden_layers.{i}", ACT_SOFTPLUS100, Y, ldy, n)
+                X, ldx = Y, ldy
         self._fwd(B.h[DEPTH - 1], WIDTH, "mlp.sigma_layer.output_layer", ACT_TRUNC_EXP_SEL, B.s4, 4, n, sel=B.sel)
         return B.s4[:n, 0].contiguous()
 
@@ -185,22 +284,23 @@ class VanillaRenderer(Renderer):
         """no-grad density of the marched samples (the sampler's sigma_fn pre-pass), in chunks of whole 32-sample blocks: the
         trunk keeps ~8.7 KB of activations per sample, and a first step through an empty occupancy grid can march 60 M of
         them (the rendered-sample budget of the dynamic batch size does not bound the marched count)"""
+        tr = self._fused()
         if n <= chunk:
-            B = _Buffers(n, o.device, self.field.C, full=False, backward=False)
+            B = _Buffers(n, o.device, self.field.C, full=False, backward=False, trunk=tr)
             self._encode(B, False, rays=(o, d), samples=samples)
             return self._trunk(B)
         ri, ts, te = samples
         out = torch.empty(n, device=o.device, dtype=torch.float32)
         for s0 in range(0, n, chunk):
             e0 = min(s0 + chunk, n)
-            B = _Buffers(e0 - s0, o.device, self.field.C, full=False, backward=False)
+            B = _Buffers(e0 - s0, o.device, self.field.C, full=False, backward=False, trunk=tr)
             self._encode(B, False, rays=(o, d), samples=(ri[s0:e0], ts[s0:e0], te[s0:e0]))
             out[s0:e0] = self._trunk(B)
             del B
         return out
 
     def _field_forward(self, o, d, pk, save):
-        B = _Buffers(pk.n, o.device, self.field.C, full=True, backward=False)
+        B = _Buffers(pk.n, o.device, self.field.C, full=True, backward=False, trunk=self._fused(), save=save)
         self._encode(B, True, rays=(o, d), samples=(pk.ray_indices, pk.t_starts, pk.t_ends))
         rgb, sigma = self._field_eval(B, True)
         return rgb, sigma, dict(buffers=B if save else None)
@@ -225,6 +325,11 @@ class VanillaRenderer(Renderer):
         # sigma layer joins at h7; its data gradient is accumulated, then the trunk activation derivative applied
         self._bwd_weight(dz_sig, 32, h7, WIDTH, "mlp.sigma_layer.output_layer", n)
         self._bwd_data(dz_sig, 32, "mlp.sigma_layer.output_layer", WIDTH, ACT_SOFTPLUS100, h7, WIDTH, True, dh[0], WIDTH, n)
+        if B.trunk is not None:                             # dh[0] = d loss / d (pre-activation of layer 7), row-major
+            dz = B.trunk.new_saved(n)
+            self._trunk_bwd(B.trunk, dh[0], B, dz)
+            self._trunk_dw(B.trunk, dz, B)
+            return
         cur = 0
         for i in range(DEPTH - 1, -1, -1):
             name = f"mlp.base.hidden_layers.{i}"
@@ -393,10 +498,11 @@ class VanillaRenderer(Renderer):
         """VanillaNeRFRadianceField.query_density (mlp.py:343-347) for arbitrary world points."""
         n = x_world.shape[0]
         chunk = 1 << 21                                    # an occupancy refresh queries up to 256^3 cells: 8.7 KB of
+        tr = self._fused()
         out = torch.empty(n, device=x_world.device, dtype=torch.float32)     # trunk activations per point, so in pieces
         for s0 in range(0, n, chunk):
             xs = x_world[s0: s0 + chunk].contiguous()
-            B = _Buffers(xs.shape[0], x_world.device, self.field.C, full=False, backward=False)
+            B = _Buffers(xs.shape[0], x_world.device, self.field.C, full=False, backward=False, trunk=tr)
             self._encode(B, False, x_world=xs)
             out[s0: s0 + chunk] = self._trunk(B)
             del B
@@ -405,7 +511,7 @@ class VanillaRenderer(Renderer):
     def query(self, x_world: torch.Tensor, dirs: torch.Tensor):
         """field(x, d) -> (rgb (n, C), sigma (n,), buffers) for free-standing points (mlp.py:349-358)."""
         n = x_world.shape[0]
-        B = _Buffers(n, x_world.device, self.field.C, full=True, backward=False)
+        B = _Buffers(n, x_world.device, self.field.C, full=True, backward=False, trunk=self._fused(), save=True)
         self._encode(B, True, x_world=x_world.contiguous(), dirs=dirs.contiguous())
         rgb, sigma = self._field_eval(B, True)
         return rgb, sigma, B
