@@ -93,6 +93,9 @@ __global__ __launch_bounds__(256) void trunk_prep_kernel(const float *__restrict
 }
 
 __device__ __forceinline__ void glds16(const void *g, void *l) {
+#ifdef TRUNK_NO_GLDS                                       // timing experiment: no weight stream (results are garbage)
+    return;
+#endif
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
                                      (__attribute__((address_space(3))) void *)l, 16, 0, 0);
 }
@@ -130,25 +133,41 @@ __device__ __forceinline__ void store_tile(void *base, int64_t blk, int t, int l
 }
 
 // ---- forward ---------------------------------------------------------------------------------------------------------
-template <int MODE>
+// The layer body exists in three compile-time shapes (first layer: encoding chunks only; hidden; skip layer: hidden +
+// encoding chunks) and with / without the saved copy: a run-time `if` around a group of MFMAs makes the compiler copy
+// whole accumulator tuples between AGPRs at the join (a first version spent 30 % of its VALU issue on such copies).
+template <bool B> struct BoolC { static constexpr bool value = B; };
+// scheduling fence between the MFMA stages and between the epilogue tiles: without it the scheduler interleaves them
+// across the whole unrolled layer and spills ~150 VGPRs
+#define TRUNK_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+template <int MODE, bool SAVE>
 __global__ __launch_bounds__(256, 1) void trunk_fwd_kernel(TrunkArgs a) {
     using C = TC<MODE>;
     using PR = Pairs<MODE>;
     constexpr int NP = C::NP, NB = C::NB, NTS = C::NTS, NTG = 8 / NTS;
     constexpr int STAGE = NTS * 20 * NP * 1024;          // bytes of the largest stage (layer 5)
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_tf[];
-    float *bias = reinterpret_cast<float *>(smem_tf + 2 * STAGE);            // [8][256]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+    float *bias = reinterpret_cast<float *>(smem_all);   // [8][256], FIRST: its reads fold into 16-bit ds offsets of one base
+    unsigned char *smem_tf = smem_all + 8192;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int hi = lane >> 5, sl = lane & 31;
+    const uint32_t lane16 = lane * 16;
     for (int i = threadIdx.x; i < 2048; i += 256) bias[i] = a.P[t_boff(i >> 8) + (i & 255)];
     const int64_t n_blk = (a.n + 31) >> 5, n_grp = (n_blk + 4 * NB - 1) / (4 * NB);
-    const size_t lstride = (size_t)n_blk * 32 * 256;     // elements per saved layer
+    const size_t lstride = (size_t)n_grp * 4 * NB * 32 * 256;                // elements per saved layer (whole groups)
 
     auto issue = [&](int l, int tg, int buf) {           // stage (layer l, tile group tg) -> LDS buffer buf
         const int nch = t_nch(l), pieces = NTS * nch * NP;
-        const unsigned char *src = reinterpret_cast<const unsigned char *>(a.img) + (size_t)(t_coff(l) * 8 + tg * NTS * nch) * NP * 1024;
-        unsigned char *dst = smem_tf + buf * STAGE;
-        for (int i = wave; i < pieces; i += 4) glds16(src + i * 1024 + lane * 16, dst + i * 1024);
+        // uniform (scalar) piece offset + one 32-bit lane offset; the empty asm keeps the compiler from precomputing a
+        // 64-bit vector address per piece and stage in the kernel prologue (it spilled ~180 registers doing so)
+        uint32_t off = (uint32_t)(t_coff(l) * 8 + tg * NTS * nch) * NP * 1024 + wave * 1024;
+        unsigned char *dst = smem_tf + buf * STAGE + wave * 1024;
+        for (int i = wave; i < pieces; i += 4) {
+            asm volatile("" : "+s"(off));
+            glds16(reinterpret_cast<const unsigned char *>(a.img) + off + lane16, dst);
+            off += 4096; dst += 4096;
+        }
     };
     int buf = 0;
     if ((int64_t)blockIdx.x < n_grp) issue(0, 0, 0);
@@ -156,114 +175,102 @@ __global__ __launch_bounds__(256, 1) void trunk_fwd_kernel(TrunkArgs a) {
         const int64_t blk0 = (grp * 4 + wave) * NB;
         const bool more_grp = grp + gridDim.x < n_grp;
         bf16x8 x[NB][NP][16];
+        // encoding operands (layers 0 and 5); rows of blocks past the end are clamped (their results are never stored
+        // row-major, and the fragment-layout buffers are whole groups)
+        auto load_enc = [&](bf16x8 (&e)[NB][NP][4]) {
 #pragma unroll
-        for (int u = 0; u < NB; ++u)
+            for (int u = 0; u < NB; ++u) {
+                const int64_t blk = blk0 + u < n_blk ? blk0 + u : n_blk - 1;
+                const float *xp = a.enc + (blk * 32 + sl) * a.ld_enc + 8 * hi;
 #pragma unroll
-            for (int p = 0; p < NP; ++p)
+                for (int c = 0; c < 4; ++c) {
+                    const float4 v0 = *reinterpret_cast<const float4 *>(xp + 16 * c), v1 = *reinterpret_cast<const float4 *>(xp + 16 * c + 4);
+                    const float xs[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                    bf16x8 o[3];
+                    split8<NP>(xs, o);
 #pragma unroll
-                for (int c = 0; c < 16; ++c)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) x[u][p][c][j] = (__bf16)0.f;
-        for (int l = 0; l < 8; ++l) {
-            const int nch = t_nch(l);
-            const bool has_h = l > 0, has_e = l == 0 || l == T_SKIP;
-            const int ce = l == 0 ? 0 : 16;              // first encoding chunk within the stage
-            bf16x8 e[NB][NP][4];
-            if (has_e) {
-#pragma unroll
-                for (int u = 0; u < NB; ++u) {
-                    const bool act = blk0 + u < n_blk;
-                    const float *xp = a.enc + ((blk0 + u) * 32 + sl) * a.ld_enc + 8 * hi;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
-                        if (act) { v0 = *reinterpret_cast<const float4 *>(xp + 16 * c); v1 = *reinterpret_cast<const float4 *>(xp + 16 * c + 4); }
-                        const float xs[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-                        bf16x8 o[3];
-                        split8<NP>(xs, o);
-#pragma unroll
-                        for (int p = 0; p < NP; ++p) e[u][p][c] = o[p];
-                    }
+                    for (int p = 0; p < NP; ++p) e[u][p][c] = o[p];
                 }
             }
+        };
+        auto layer = [&](auto has_h_c, auto has_e_c, auto last_c, const int l) {
+            constexpr bool HAS_H = decltype(has_h_c)::value, HAS_E = decltype(has_e_c)::value, LAST = decltype(last_c)::value;
+            constexpr int nch = (HAS_H ? 16 : 0) + (HAS_E ? 4 : 0), ce = HAS_H ? 16 : 0;
+            bf16x8 e[NB][NP][4];
+            if (HAS_E) load_enc(e);
             f32x16 acc[NB][8];
 #pragma unroll
             for (int tg = 0; tg < NTG; ++tg) {
                 __syncthreads();                         // stage (l, tg) has landed (the fence drains this wave's LDS-DMA)
                 if (tg + 1 < NTG) issue(l, tg + 1, buf ^ 1);
-                else if (l + 1 < 8) issue(l + 1, 0, buf ^ 1);
+                else if (!LAST) issue(l + 1, 0, buf ^ 1);
                 else if (more_grp) issue(0, 0, buf ^ 1);
-                const unsigned char *st = smem_tf + buf * STAGE;
+                const unsigned char *st = smem_tf + buf * STAGE + lane * 16;
 #pragma unroll
                 for (int tt = 0; tt < NTS; ++tt) {
                     const int t = tg * NTS + tt;
-                    f32x16 part;                         // odd chunks when a stage has a single accumulator (fp32 mode)
+                    f32x16 part;                         // odd product terms when a stage has a single accumulator (fp32 mode)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float4 b4 = *reinterpret_cast<const float4 *>(bias + l * 256 + t * 32 + 8 * q + 4 * hi);
+                    for (int g = 0; g < 16; ++g) {
+                        part[g] = 0.f;
 #pragma unroll
-                        for (int u = 0; u < NB; ++u) { acc[u][t][4 * q] = b4.x; acc[u][t][4 * q + 1] = b4.y; acc[u][t][4 * q + 2] = b4.z; acc[u][t][4 * q + 3] = b4.w; }
+                        for (int u = 0; u < NB; ++u) acc[u][t][g] = 0.f;
                     }
+                    const unsigned char *wt = st + tt * nch * NP * 1024;
+                    int m = 0;
 #pragma unroll
-                    for (int g = 0; g < 16; ++g) part[g] = 0.f;
-                    const unsigned char *wt = st + (size_t)tt * nch * NP * 1024 + lane * 16;
-                    if (has_h) {
+                    for (int c = 0; c < nch; ++c) {
+                        bf16x8 w[NP];
 #pragma unroll
-                        for (int c = 0; c < 16; ++c) {
-                            bf16x8 w[NP];
+                        for (int p = 0; p < NP; ++p) w[p] = *reinterpret_cast<const bf16x8 *>(wt + (c * NP + p) * 1024);
 #pragma unroll
-                            for (int p = 0; p < NP; ++p) w[p] = *reinterpret_cast<const bf16x8 *>(wt + (c * NP + p) * 1024);
+                        for (int k = 0; k < PR::N; ++k)
 #pragma unroll
-                            for (int k = 0; k < PR::N; ++k)
-#pragma unroll
-                                for (int u = 0; u < NB; ++u) {
-                                    if (NB * NTS == 1 && (c & 1)) part = MFMAB(w[PR::W[k]], x[u][PR::A[k]][c], part);
-                                    else acc[u][t] = MFMAB(w[PR::W[k]], x[u][PR::A[k]][c], acc[u][t]);
-                                }
-                        }
-                    }
-                    if (has_e) {
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            bf16x8 w[NP];
-#pragma unroll
-                            for (int p = 0; p < NP; ++p) w[p] = *reinterpret_cast<const bf16x8 *>(wt + ((size_t)(ce + c) * NP + p) * 1024);
-#pragma unroll
-                            for (int k = 0; k < PR::N; ++k)
-#pragma unroll
-                                for (int u = 0; u < NB; ++u) {
-                                    if (NB * NTS == 1 && (c & 1)) part = MFMAB(w[PR::W[k]], e[u][PR::A[k]][c], part);
-                                    else acc[u][t] = MFMAB(w[PR::W[k]], e[u][PR::A[k]][c], acc[u][t]);
-                                }
-                        }
+                            for (int u = 0; u < NB; ++u, ++m) {
+                                const bf16x8 &xv = (HAS_H && c < 16) ? x[u][PR::A[k]][c & 15] : e[u][PR::A[k]][(c - ce) & 3];
+                                if (NB * NTS == 1 && (m & 1)) part = MFMAB(w[PR::W[k]], xv, part);
+                                else acc[u][t] = MFMAB(w[PR::W[k]], xv, acc[u][t]);
+                            }
                     }
                     if (NB * NTS == 1) acc[0][t] += part;
                 }
                 buf ^= 1;
+                TRUNK_FENCE();
             }
-            // activation; the accumulators become the next layer's operands and the saved copy
-            void *sv = a.acts ? reinterpret_cast<void *>(reinterpret_cast<typename C::ST *>(a.acts) + (size_t)l * lstride) : nullptr;
+            // bias + activation; the accumulators become the next layer's operands and the saved copy
+            typename C::ST *sv = reinterpret_cast<typename C::ST *>(a.acts) + (size_t)l * lstride;
 #pragma unroll
             for (int u = 0; u < NB; ++u) {
-                const bool act = blk0 + u < n_blk;
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
                     float y[16];
 #pragma unroll
-                    for (int g = 0; g < 16; ++g) y[g] = softplus100(acc[u][t][g]);
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 b4 = *reinterpret_cast<const float4 *>(bias + l * 256 + t * 32 + 8 * q + 4 * hi);
+                        y[4 * q] = softplus100(acc[u][t][4 * q] + b4.x);
+                        y[4 * q + 1] = softplus100(acc[u][t][4 * q + 1] + b4.y);
+                        y[4 * q + 2] = softplus100(acc[u][t][4 * q + 2] + b4.z);
+                        y[4 * q + 3] = softplus100(acc[u][t][4 * q + 3] + b4.w);
+                    }
                     bf16x8 lo[3], hi8[3];
                     pack_tile<MODE>(y, lo, hi8);
 #pragma unroll
                     for (int p = 0; p < NP; ++p) { x[u][p][2 * t] = lo[p]; x[u][p][2 * t + 1] = hi8[p]; }
-                    if (sv && act) store_tile<MODE>(sv, blk0 + u, t, lane, y, lo[0], hi8[0]);
-                    if (l == 7 && a.h7 && act) {
+                    if (SAVE) store_tile<MODE>(sv, blk0 + u, t, lane, y, lo[0], hi8[0]);
+                    if (LAST && a.h7 && blk0 + u < n_blk) {
                         float *hp = a.h7 + ((blk0 + u) * 32 + sl) * a.ld_h7 + t * 32 + 4 * hi;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) *reinterpret_cast<float4 *>(hp + 8 * q) = make_float4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
                     }
+                    TRUNK_FENCE();
                 }
             }
-        }
+        };
+        layer(BoolC<false>(), BoolC<true>(), BoolC<false>(), 0);
+        for (int l = 1; l < T_SKIP; ++l) layer(BoolC<true>(), BoolC<false>(), BoolC<false>(), l);
+        layer(BoolC<true>(), BoolC<true>(), BoolC<false>(), T_SKIP);
+        layer(BoolC<true>(), BoolC<false>(), BoolC<false>(), 6);
+        layer(BoolC<true>(), BoolC<false>(), BoolC<true>(), 7);
     }
 }
 
@@ -280,14 +287,19 @@ __global__ __launch_bounds__(256, 1) void trunk_bwd_kernel(TrunkArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_tb[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int hi = lane >> 5, sl = lane & 31;
+    const uint32_t lane16 = lane * 16;
     const int64_t n_blk = (a.n + 31) >> 5, n_grp = (n_blk + 4 * NB - 1) / (4 * NB);
-    const size_t lstride = (size_t)n_blk * 32 * 256;
+    const size_t lstride = (size_t)n_grp * 4 * NB * 32 * 256;                // whole groups: stores need no bounds
 
     auto issue = [&](int l, int tg, int buf) {           // stage (layer l in 1..7, input-tile group tg)
         const int pieces = NTS * 16 * NP;
-        const unsigned char *src = reinterpret_cast<const unsigned char *>(a.img) + (size_t)((l - 1) * 128 + tg * NTS * 16) * NP * 1024;
-        unsigned char *dst = smem_tb + buf * STAGE;
-        for (int i = wave; i < pieces; i += 4) glds16(src + i * 1024 + lane * 16, dst + i * 1024);
+        uint32_t off = (uint32_t)((l - 1) * 128 + tg * NTS * 16) * NP * 1024 + wave * 1024;       // see trunk_fwd_kernel
+        unsigned char *dst = smem_tb + buf * STAGE + wave * 1024;
+        for (int i = wave; i < pieces; i += 4) {
+            asm volatile("" : "+s"(off));
+            glds16(reinterpret_cast<const unsigned char *>(a.img) + off + lane16, dst);
+            off += 4096; dst += 4096;
+        }
     };
     int buf = 0;
     if ((int64_t)blockIdx.x < n_grp) issue(7, 0, 0);
@@ -298,21 +310,21 @@ __global__ __launch_bounds__(256, 1) void trunk_bwd_kernel(TrunkArgs a) {
         // dz7 (row-major, written by the heads' backward) -> chain operands + fragment-layout copy for trunk_dw
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
-            const bool act = blk0 + u < n_blk;
-            const float *zp = a.dz7 + ((blk0 + u) * 32 + sl) * a.ld_dz7 + 4 * hi;
+            const int64_t blkc = blk0 + u < n_blk ? blk0 + u : n_blk - 1;            // past the end: any valid rows (never used)
+            const float *zp = a.dz7 + (blkc * 32 + sl) * a.ld_dz7 + 4 * hi;
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
                 float y[16];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float4 v = act ? *reinterpret_cast<const float4 *>(zp + t * 32 + 8 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float4 v = *reinterpret_cast<const float4 *>(zp + t * 32 + 8 * q);
                     y[4 * q] = v.x; y[4 * q + 1] = v.y; y[4 * q + 2] = v.z; y[4 * q + 3] = v.w;
                 }
                 bf16x8 lo[3], hi8[3];
                 pack_tile<MODE>(y, lo, hi8);
 #pragma unroll
                 for (int p = 0; p < NP; ++p) { x[u][p][2 * t] = lo[p]; x[u][p][2 * t + 1] = hi8[p]; }
-                if (act) store_tile<MODE>(reinterpret_cast<ST *>(a.dz) + 7 * lstride, blk0 + u, t, lane, y, lo[0], hi8[0]);
+                store_tile<MODE>(reinterpret_cast<ST *>(a.dz) + 7 * lstride, blk0 + u, t, lane, y, lo[0], hi8[0]);
             }
         }
         for (int l = 7; l >= 1; --l) {
@@ -320,8 +332,7 @@ __global__ __launch_bounds__(256, 1) void trunk_bwd_kernel(TrunkArgs a) {
             uint4 hpre[PD][HV];
             auto load_h = [&](int i, uint4 (&dst)[HV]) {                                           // i = u * 8 + t
                 const int u = i >> 3, t = i & 7;
-                const bool act = blk0 + u < n_blk;
-                const int64_t blk = act ? blk0 + u : 0;
+                const int64_t blk = blk0 + u;
                 const uint4 *p = MODE == 1 ? reinterpret_cast<const uint4 *>(hs + ((blk * 16 + 2 * t) * 64 + lane) * 8)
                                            : reinterpret_cast<const uint4 *>(hs + ((blk * 8 + t) * 4 * 64 + lane) * 4);
 #pragma unroll
@@ -371,7 +382,6 @@ __global__ __launch_bounds__(256, 1) void trunk_bwd_kernel(TrunkArgs a) {
 #pragma unroll
             for (int i = 0; i < NB * 8; ++i) {
                 const int u = i >> 3, t = i & 7;
-                const bool act = blk0 + u < n_blk;
                 float h[16];
                 if (MODE == 1) {
 #pragma unroll
@@ -395,7 +405,7 @@ __global__ __launch_bounds__(256, 1) void trunk_bwd_kernel(TrunkArgs a) {
                 pack_tile<MODE>(y, lo, hi8);
 #pragma unroll
                 for (int p = 0; p < NP; ++p) { x[u][p][2 * t] = lo[p]; x[u][p][2 * t + 1] = hi8[p]; }
-                if (act) store_tile<MODE>(sv, blk0 + u, t, lane, y, lo[0], hi8[0]);
+                store_tile<MODE>(sv, blk0 + u, t, lane, y, lo[0], hi8[0]);
             }
         }
     }
@@ -564,7 +574,8 @@ extern "C" int64_t ren_trunk_image_bytes(int32_t mode) {
 
 extern "C" int64_t ren_trunk_saved_bytes(int32_t mode, int64_t n) {
     if ((mode != 1 && mode != 6) || n < 0) return -1;
-    return 8 * ((n + 31) / 32) * 32 * 256 * (mode == 1 ? 2 : 4);
+    const int64_t per_grp = 4 * (mode == 1 ? TC<1>::NB : TC<6>::NB), n_grp = ((n + 31) / 32 + per_grp - 1) / per_grp;
+    return 8 * n_grp * per_grp * 32 * 256 * (mode == 1 ? 2 : 4);                // whole workgroup passes of 32-sample blocks
 }
 
 extern "C" int ren_trunk_prep(const float *trunk_params, int32_t mode, void *image, void *stream) {
@@ -591,13 +602,13 @@ extern "C" int ren_trunk_fwd(const float *enc, int32_t ld_enc, const float *trun
     a.enc = enc; a.ld_enc = ld_enc; a.P = trunk_params; a.img = reinterpret_cast<const __bf16 *>(image);
     a.acts = saved; a.h7 = h7; a.ld_h7 = ld_h7; a.n = n;
     hipStream_t st = (hipStream_t)stream;
-    if (mode == 1) {
-        (void)hipFuncSetAttribute((const void *)trunk_fwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_lds<1>());
-        hipLaunchKernelGGL(trunk_fwd_kernel<1>, dim3(trunk_grid(n, TC<1>::NB)), dim3(256), fwd_lds<1>(), st, a);
-    } else {
-        (void)hipFuncSetAttribute((const void *)trunk_fwd_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_lds<6>());
-        hipLaunchKernelGGL(trunk_fwd_kernel<6>, dim3(trunk_grid(n, TC<6>::NB)), dim3(256), fwd_lds<6>(), st, a);
-    }
+#define REN_TRUNK_FWD(MODE, SAVE)                                                                                              \
+    do {                                                                                                                        \
+        (void)hipFuncSetAttribute((const void *)trunk_fwd_kernel<MODE, SAVE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_lds<MODE>()); \
+        hipLaunchKernelGGL((trunk_fwd_kernel<MODE, SAVE>), dim3(trunk_grid(n, TC<MODE>::NB)), dim3(256), fwd_lds<MODE>(), st, a); \
+    } while (0)
+    if (mode == 1) { if (saved) REN_TRUNK_FWD(1, true); else REN_TRUNK_FWD(1, false); }
+    else { if (saved) REN_TRUNK_FWD(6, true); else REN_TRUNK_FWD(6, false); }
     REN_CHECK_LAUNCH();
 }
 
@@ -630,7 +641,7 @@ extern "C" int ren_trunk_bwd_weight(const void *dz, const void *saved, const flo
         return REN_ERR_BAD_ARG;
     if (n == 0) return REN_OK;
     hipStream_t st = (hipStream_t)stream;
-    const size_t esz = mode == 1 ? 2 : 4, lbytes = (size_t)((n + 31) / 32) * 32 * 256 * esz;
+    const size_t lbytes = (size_t)ren_trunk_saved_bytes(mode, n) / 8;
     for (int l = 7; l >= 0; --l) {
         TrunkDwArgs a;
         a.dz = reinterpret_cast<const unsigned char *>(dz) + l * lbytes;

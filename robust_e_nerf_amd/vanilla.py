@@ -116,7 +116,7 @@ class Trunk:
 
     def decode(self, saved: torch.Tensor, n: int) -> List[torch.Tensor]:
         """fragment layout -> eight row-major (n, 256) float32 tensors (tests / tools only)"""
-        n_blk = (n + 31) // 32
+        n_blk = saved.numel() // (8 * 32 * 256 * (2 if self.mode == 1 else 4))       # whole workgroup passes
         dev = saved.device
         lane = torch.arange(64, device=dev)
         sl, hi = lane & 31, lane >> 5

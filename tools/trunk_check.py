@@ -18,7 +18,16 @@ def main():
     ap.add_argument("--mode", type=int, default=6)
     ap.add_argument("--time", action="store_true")
     ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--lib", default=None, help="single-file build of csrc/ren_trunk.hip to take the ren_trunk_* entry points from")
     a = ap.parse_args()
+    if a.lib:
+        import ctypes
+        var, lib = ctypes.CDLL(os.path.abspath(a.lib)), _lib.load()
+        for name, (res, args) in _lib.SIGNATURES.items():
+            if name.startswith("ren_trunk_"):
+                fn = getattr(var, name)
+                fn.restype, fn.argtypes = res, args
+                setattr(lib, name, fn)
     dev = "cuda:0"
     torch.manual_seed(0)
     fld = vanilla.VanillaField(dev)
