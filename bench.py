@@ -35,12 +35,13 @@ BYTES = {"hashgrid_fwd": 1024 + 12, "hashgrid_bwd": 2048 + 12, "hashgrid_bwd_bin
 # base 32-64-16 + head 31-64-64-1 forward; backward = data + weight gradients = 2 x forward (no recompute counted)
 MLP_MACS = 32 * 64 + 64 * 16 + 31 * 64 + 64 * 64 + 64
 VANILLA_MACS = 593152            # 63-256x4-(+63)-256x3, sigma, bottleneck, 283-128-1
-TRUNK_MACS = 63 * 256 + 6 * 65536 + 319 * 256
 FLOPS = {"mlp_fwd": 2 * MLP_MACS, "mlp_bwd": 4 * MLP_MACS, "mlp_fwd_save": 2 * MLP_MACS, "mlp_bwd_saved": 4 * MLP_MACS,
          "mlp_fwd_x": 2 * MLP_MACS, "mlp_bwd_x": 4 * MLP_MACS, "dense_fwd": 2 * VANILLA_MACS,
          "dense_bwd_data": 2 * VANILLA_MACS, "dense_bwd_weight": 2 * VANILLA_MACS,
-         # arch mlp, fused trunk (csrc/ren_trunk.hip): 63-256, 5 x 256-256, 319-256, 256-256; backward-data has no layer 0
-         "trunk_fwd": 2 * TRUNK_MACS, "trunk_bwd": 2 * 7 * 65536, "trunk_bwd_weight": 2 * TRUNK_MACS}
+         # arch mlp, fused field (csrc/ren_vfield.hip): all twelve layers; backward-data has no first layer and only the
+         # bottleneck columns of the colour hidden layer
+         "vfield_fwd": 2 * VANILLA_MACS, "vfield_bwd": 2 * (VANILLA_MACS - 63 * 256 - 63 * 256 - 27 * 128),
+         "vfield_bwd_weight": 2 * VANILLA_MACS}
 PMC_TRAFFIC = os.path.join(REPO, "profiles", "r03_pmc_traffic.json")
 
 

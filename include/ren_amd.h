@@ -548,27 +548,30 @@ int ren_dense_bwd_weight(const float *dZ, int32_t ldz, const float *X, int32_t l
 int ren_vanilla_heads_bwd(const float *g_rgb, const float *rgb, const float *g_sigma, const float *sigma,
                           int64_t n, int32_t C, float *dz_rgb, float *dz_sigma, void *stream);
 
-/* ---- arch mlp: the 8 x 256 trunk as three launches per pass (csrc/ren_trunk.hip) ------------------------------------------
- * Replaces the eight `hidden_layers` Linear + Softplus(beta = 100) of MLP.forward with the skip concatenation after layer 4
- * (robust_e_nerf/external/mlp.py:26-113) and their autograd: activations stay in registers from layer to layer.
- * `trunk_params`: the first eight (weight, bias) pairs of the field's parameter block (torch layout, 63 / 256 / 319 input
- * columns).  `mode`: REN_DENSE_BF16 (1: bf16 operands, saved copies in bf16) or REN_DENSE_BF16X6 (6: three-piece split, fp32
- * round-off, saved copies in fp32).  `image` (ren_trunk_image_bytes) is the MFMA-fragment form of the weights: rebuild it
- * with ren_trunk_prep whenever the parameters change.  `saved` / `dz` (ren_trunk_saved_bytes each) hold the eight layers'
- * activations / pre-activation gradients in the kernels' fragment layout (documented in ren_trunk.hip); enc is the
- * [n_pad][ld_enc >= 64] output of ren_freq_encode, h7 (optional) a row-major fp32 copy of the last layer for the heads,
- * dz7 the row-major [n_pad][ld] gradient w.r.t. layer 7's pre-activation (rows >= n zero).  ren_trunk_bwd_weight ADDS
- * dW_l = dz_l^T x_{l-1}, db_l = sum dz_l to `trunk_grads` (same layout as trunk_params), slab-reduced (deterministic). */
-int64_t ren_trunk_image_bytes(int32_t mode);
-int64_t ren_trunk_saved_bytes(int32_t mode, int64_t n);
-int ren_trunk_prep(const float *trunk_params, int32_t mode, void *image, void *stream);
-int ren_trunk_fwd(const float *enc, int32_t ld_enc, const float *trunk_params, const void *image, int32_t mode, int64_t n,
-                  void *saved, float *h7, int32_t ld_h7, void *stream);
-int ren_trunk_bwd(const float *dz7, int32_t ld_dz7, const void *image, int32_t mode, int64_t n, const void *saved, void *dz,
-                  void *stream);
-int64_t ren_trunk_bwd_weight_workspace_floats(int32_t n_splits);
-int ren_trunk_bwd_weight(const void *dz, const void *saved, const float *enc, int32_t ld_enc, int32_t mode, int64_t n,
-                         int32_t n_splits, float *trunk_grads, float *workspace, void *stream);
+/* ---- arch mlp: the whole field as one launch per pass (csrc/ren_vfield.hip) ------------------------------------------------
+ * Replaces NerfMLP.forward / query_density (robust_e_nerf/external/mlp.py:126-205: eight hidden Linear + Softplus(beta = 100)
+ * with the skip concatenation after layer 4, sigma layer, bottleneck, 283 -> 128 -> C colour head) and its autograd:
+ * activations stay in registers from layer to layer.  `params`: the field's parameter block (reference state-dict order,
+ * torch layout).  `mode`: REN_DENSE_BF16 (1: bf16 operands, saved copies in bf16) or REN_DENSE_BF16X6 (6: three-piece split,
+ * fp32 round-off, saved copies in fp32).  `image` (ren_vanilla_image_bytes) is the MFMA-fragment form of the weights: rebuild
+ * it with ren_vanilla_prep whenever the parameters change.  `saved` / `dz` (ren_vanilla_saved_bytes each) hold the layers'
+ * activations / pre-activation gradients in the kernels' fragment layout (documented in ren_vfield.hip).
+ * fwd: enc [n_pad][ld_enc >= 64], view [n_pad][ld_view >= 32], selector [n_pad] are the outputs of ren_freq_encode (rows
+ * n .. n_pad zero); sigma [n_pad]; rgb4 [n_pad][4] (columns >= C zero) or NULL for the density only (then view may be NULL
+ * and saved must be).  bwd: dz_rgb / dz_sigma [n_pad][32] as written by ren_vanilla_heads_bwd.  ren_vanilla_bwd_weight ADDS
+ * dW_l = dz_l^T x_{l-1}, db_l = sum dz_l of all twelve layers to `grads` (layout of params), slab-reduced (deterministic). */
+int64_t ren_vanilla_image_bytes(int32_t mode);
+int64_t ren_vanilla_saved_bytes(int32_t mode, int64_t n);
+int ren_vanilla_prep(const float *params, int32_t C, int32_t mode, void *image, void *stream);
+int ren_vanilla_fwd(const float *enc, int32_t ld_enc, const float *view, int32_t ld_view, const uint8_t *selector,
+                    const float *params, int32_t C, const void *image, int32_t mode, int64_t n, void *saved, float *sigma,
+                    float *rgb4, void *stream);
+int ren_vanilla_bwd(const float *dz_rgb, const float *dz_sigma, const void *image, int32_t mode, int64_t n, const void *saved,
+                    void *dz, void *stream);
+int64_t ren_vanilla_bwd_weight_workspace_floats(int32_t n_splits);
+int ren_vanilla_bwd_weight(const void *dz, const void *saved, const float *enc, int32_t ld_enc, const float *view,
+                           int32_t ld_view, const float *dz_rgb, const float *dz_sigma, int32_t C, int32_t mode, int64_t n,
+                           int32_t n_splits, float *grads, float *workspace, void *stream);
 /* Tangent streams of the vanilla field (robust_e_nerf/external/mlp.py:208-243,333-358 under
  * utils/autograd.py:4-34 for the log-intensity-gradient loss, models/robust_e_nerf.py:383-409; the second order serves
  * d loss / d tau, see ren_trajectory_jvp2).  ren_freq_encode_jvp: `order`-th time derivative (1 or 2) of ren_freq_encode's

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(CSRC, "libren_amd.so")
 SOURCES = ["ren_api.hip", "ren_pose.hip", "ren_sampling.hip", "ren_composite.hip", "ren_train.hip",
-           "ren_hashgrid.hip", "ren_hashgrid_binned.hip", "ren_mlp.hip", "ren_jvp.hip", "ren_mlp_jvp.hip", "ren_jvp2.hip", "ren_dense.hip", "ren_trunk.hip", "ren_mlp_x.hip", "ren_mlp_jvp_x.hip"]
+           "ren_hashgrid.hip", "ren_hashgrid_binned.hip", "ren_mlp.hip", "ren_jvp.hip", "ren_mlp_jvp.hip", "ren_jvp2.hip", "ren_dense.hip", "ren_vfield.hip", "ren_mlp_x.hip", "ren_mlp_jvp_x.hip"]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
           "-Wno-unused-result"]
 # the sampler must match the sequential oracle bit for bit: no FMA contraction there

@@ -749,7 +749,15 @@ __device__ __forceinline__ void sin_enc(const float *x, float *out) {           
 
 __global__ __launch_bounds__(256) void freq_encode_kernel(EncArgs a) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.n) return;
+    if (i >= a.n) {                                      // rows up to the next multiple of 32: zeros (finite inputs for the
+        if (i < ((a.n + 31) & ~(int64_t)31)) {           // padded rows of the last 32-sample block, csrc/ren_vfield.hip)
+            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int j = 0; j < 16; ++j) reinterpret_cast<float4 *>(a.enc + i * a.ld_enc)[j] = z4;
+            if (a.cat) for (int j = 0; j < 16; ++j) reinterpret_cast<float4 *>(a.cat + i * a.ld_cat + a.cat_col)[j] = z4;
+            if (a.view) for (int j = 0; j < 8; ++j) reinterpret_cast<float4 *>(a.view + i * a.ld_view + a.view_col)[j] = z4;
+        }
+        return;
+    }
     float x, y, z, dx = 0.f, dy = 0.f, dz = 1.f;
     if (a.src.ray_indices) {
         int ray;
@@ -1011,7 +1019,7 @@ extern "C" int ren_freq_encode(const ren_scene_desc *scene, const float *x_world
     a.sc = ren_make_scene(scene);
     a.n = n; a.enc = enc; a.ld_enc = ld_enc; a.cat = cat; a.ld_cat = ld_cat; a.cat_col = cat_col;
     a.view = view; a.ld_view = ld_view; a.view_col = view_col; a.sel = selector;
-    hipLaunchKernelGGL(freq_encode_kernel, dim3(ren_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(freq_encode_kernel, dim3(ren_blocks((n + 31) & ~(int64_t)31, 256)), dim3(256), 0, (hipStream_t)stream, a);
     REN_CHECK_LAUNCH();
 }
 

@@ -1,0 +1,805 @@
+// `arch: mlp`: the whole vanilla-NeRF field (robust_e_nerf/external/mlp.py:26-205: MLP / NerfMLP -- eight Linear +
+// Softplus(beta = 100) hidden layers with the input encoding concatenated again after layer 4, the sigma layer, the
+// bottleneck layer, the 283 -> 128 -> C colour head) as ONE launch forward and ONE launch backward (data), plus the weight
+// gradients, instead of 12 + 11 + 12 dense-layer launches with a 2 KB-per-sample HBM round trip between each of them
+// (ren_dense.hip, which stays for the exact-f32 mode and the forward-mode tangent stream):
+//
+//   vfield_fwd  a wave keeps its 32-sample blocks in registers through all layers: the outputs of a layer are its
+//               accumulator tiles (lane = sample), and the accumulator layout IS the next layer's B-operand layout (a
+//               k-slot permutation the weight image is pre-permuted for, as in ren_mlp_x.hip), so activations never leave
+//               the register file except as the copy saved for the backward pass;
+//   vfield_bwd  the same chain backwards over W^T, from (d loss / d rgb pre-activation, d loss / d sigma pre-activation)
+//               to the first layer: dz_{l-1} = (W_l^T dz_l) * act'(h_{l-1});
+//   vfield_dw   dW_l = dz_l^T x_{l-1}, db_l = sum dz_l from the saved copies (samples are the reduction: the
+//               transposition goes through LDS as in dense_dw_x_kernel), slab-reduced: deterministic, no atomics.
+//
+// Weights: `vfield_prep` turns the fp32 parameter block into bf16 MFMA A-fragment images (1 KB = one 32 x 16 fragment,
+// lane-linear), once per field evaluation (9 us); the kernels stream them through a double-buffered LDS stage with
+// `global_load_lds` (1 KB per wave instruction, no staging registers) while the matrix cores work on the previous stage.
+// All four waves of the workgroup (one per SIMD: the accumulators and operands of a wave fill the 512-register file)
+// share a stage.  One weight fragment read from LDS feeds two MFMAs (bf16 mode: two sample blocks per wave; fp32 mode:
+// the six product terms of the three-piece split use three fragments), so LDS bandwidth stays at half of its peak.
+//
+// Saved activations / pre-activation gradients ("fragment layout": per slot and 32-sample block, lane-linear 1 KB pieces =
+// exactly the registers of a wave; slots 0-7 = hidden layers, 8 = bottleneck output, 9 = colour-head hidden layer (128)):
+//   bf16 mode (MODE 1)  [blk][c 16][lane 64][8 bf16]   feature kmap(c, lane >> 5, j), sample blk * 32 + (lane & 31)
+//   fp32 mode (MODE 6)  [blk][t 8][q 4][lane 64][4 f32] feature 32 t + 8 q + 4 (lane >> 5) + j
+// bf16 mode stores what the next layer's matrix product sees anyway (bf16-rounded activations: the weight gradient is
+// unchanged by the rounding; the activation derivative is taken from the rounded value).
+#include "ren_mlp_common.h"
+
+namespace {
+
+// ---- the network ---------------------------------------------------------------------------------------------------------
+// forward layers: 0-7 hidden, 8 sigma, 9 bottleneck, 10 colour hidden, 11 colour output
+constexpr int NL = 12, L_SKIP = 5, L_SIGMA = 8, L_BOTT = 9, L_RGBH = 10, L_RGBO = 11;
+__host__ __device__ constexpr int l_in(int l) {          // torch in_features
+    return l == 0 ? 63 : l == L_SKIP ? 319 : l == L_RGBH ? 283 : l == L_RGBO ? 128 : 256;
+}
+__host__ __device__ constexpr int l_out(int l, int C) { return l == L_SIGMA ? 1 : l == L_RGBH ? 128 : l == L_RGBO ? C : 256; }
+__host__ __device__ constexpr int l_nh(int l) { return l == 0 ? 0 : l == L_RGBO ? 8 : 16; }       // k-chunks from the chain
+__host__ __device__ constexpr int l_ne(int l) { return l == 0 || l == L_SKIP ? 4 : l == L_RGBH ? 2 : 0; }   // encoding chunks
+__host__ __device__ constexpr int l_nch(int l) { return l_nh(l) + l_ne(l); }
+__host__ __device__ constexpr int l_nt(int l) { return l == L_SIGMA || l == L_RGBO ? 1 : l == L_RGBH ? 4 : 8; }   // output tiles
+// parameter block (floats), reference state-dict order: hidden 0-7, sigma, bottleneck, colour hidden, colour output
+__host__ __device__ constexpr int l_woff(int l, int C) {
+    int o = 0;
+    for (int i = 0; i < l; ++i) o += l_out(i, C) * l_in(i) + l_out(i, C);
+    return o;
+}
+__host__ __device__ constexpr int l_boff(int l, int C) { return l_woff(l, C) + l_out(l, C) * l_in(l); }
+// forward image: fragment (= 1 KB x NP) offset of layer l: [tile][chunk] fragments per layer
+__host__ __device__ constexpr int f_off(int l) {
+    int o = 0;
+    for (int i = 0; i < l; ++i) o += l_nt(i) * l_nch(i);
+    return o;
+}
+constexpr int F_FRAGS = f_off(NL);
+// backward (W^T) image, steps 11, 10, 9, 7 .. 1 (sigma is the extra chunk of step 9):
+//   11: 4 input tiles x 1 chunk (k = the C outputs, natural order)      10: 8 tiles (the 256 bottleneck inputs) x 8 chunks
+//    9: 8 tiles x (16 chunks + 1 chunk whose k-slot 0 is the sigma layer)   7..1: 8 tiles x 16 chunks
+__host__ __device__ constexpr int b_nt(int l) { return l == L_RGBO ? 4 : 8; }
+__host__ __device__ constexpr int b_nch(int l) { return l == L_RGBO ? 1 : l == L_RGBH ? 8 : l == L_BOTT ? 17 : 16; }
+__host__ __device__ constexpr int b_off(int l) {         // order in the image: 1..7, 9, 10, 11
+    int o = 0;
+    for (int i = 1; i < l; ++i)
+        if (i != L_SIGMA) o += b_nt(i) * b_nch(i);
+    return o;
+}
+constexpr int B_FRAGS = b_off(NL);
+// register identity of the chain: accumulator register g of output tile t' (neuron 32 t' + rowc(g) + 4 hi) is k-slot
+// j = g & 7 of chunk c = 2 t' + (g >> 3)
+__host__ __device__ constexpr int kmap(int c, int hi, int j) { return (c >> 1) * 32 + 16 * (c & 1) + 8 * (j >> 2) + 4 * hi + (j & 3); }
+constexpr int N_SLOTS = 10;                              // saved / dz slots (see the header)
+
+template <int MODE> struct TC;
+template <> struct TC<1> { static constexpr int NP = 1, NB = 2, NTS = 2; typedef __bf16 ST; };
+template <> struct TC<6> { static constexpr int NP = 3, NB = 1, NTS = 1; typedef float ST; };
+
+// ---- weight images -------------------------------------------------------------------------------------------------
+template <int NP>
+__global__ __launch_bounds__(256) void vfield_prep_kernel(const float *__restrict__ P, int C, __bf16 *__restrict__ fimg,
+                                                          __bf16 *__restrict__ bimg) {
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    const int lane = id & 63, sl = lane & 31, hi = lane >> 5;
+    int fr = id >> 6;
+    float v[8];
+    __bf16 *dst;
+    if (fr < F_FRAGS) {
+        int l = 0;
+        while (l < NL - 1 && fr >= f_off(l + 1)) ++l;
+        const int nch = l_nch(l), r = fr - f_off(l), t = r / nch, c = r % nch, kin = l_in(l), nh = l_nh(l);
+        const int row = t * 32 + sl;
+        const float *W = P + l_woff(l, C) + row * kin;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int col = c < nh ? kmap(c, hi, j) : 16 * nh + 16 * (c - nh) + 8 * hi + j;
+            v[j] = (row < l_out(l, C) && col < kin) ? W[col] : 0.f;
+        }
+        dst = fimg + ((size_t)fr * NP * 64 + lane) * 8;
+    } else {
+        fr -= F_FRAGS;
+        if (fr >= B_FRAGS) return;
+        int l = 1;
+        for (int i = 2; i < NL; ++i)
+            if (i != L_SIGMA && fr >= b_off(i)) l = i;
+        const int nch = b_nch(l), r = fr - b_off(l), t = r / nch, c = r % nch, kin = l_in(l);
+        const int i = t * 32 + sl;                       // input index = row of W^T
+        const float *W = P + l_woff(l, C) + i;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float w = 0.f;
+            if (l == L_RGBO) {                           // k = output o, natural order
+                const int o = 8 * hi + j;
+                if (o < C) w = W[o * kin];
+            } else if (l == L_BOTT && c == 16) {         // sigma layer: k-slot 0
+                if (hi == 0 && j == 0) w = P[l_woff(L_SIGMA, C) + i];
+            } else {
+                w = W[kmap(c, hi, j) * kin];
+            }
+            v[j] = w;
+        }
+        dst = bimg + ((size_t)fr * NP * 64 + lane) * 8;
+    }
+    bf16x8 o[3];
+    split8<NP>(v, o);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) *reinterpret_cast<bf16x8 *>(dst + p * 512) = o[p];
+}
+
+__device__ __forceinline__ void glds16(const void *g, void *l) {
+#ifdef TRUNK_NO_GLDS                                       // timing experiment: no weight stream (results are garbage)
+    return;
+#endif
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)l, 16, 0, 0);
+}
+
+struct FieldArgs {
+    const float *enc; int ld_enc;                        // [n_pad][>= 64] position encoding (63 features + zero)
+    const float *view; int ld_view;                      // [n_pad][>= 32] direction encoding (27 features + zero)
+    const uint8_t *sel;                                  // [n_pad] inside-the-box selector of the sigma activation
+    const float *P; int C;                               // parameter block (biases)
+    const __bf16 *img;                                   // forward / backward weight image
+    void *acts;                                          // saved activations (N_SLOTS slots)
+    float *sigma, *rgb4;                                 // forward outputs: [n_pad], [n_pad][4]
+    const float *dz_rgb, *dz_sig;                        // backward inputs: [n_pad][32] (columns < C / column 0)
+    void *dz;                                            // backward: pre-activation gradients (N_SLOTS slots)
+    int64_t n;
+};
+
+// values of one accumulator tile -> the two k-chunks it is in the next layer, and the saved copy
+template <int MODE>
+__device__ __forceinline__ void pack_tile(const float (&y)[16], bf16x8 (&lo)[3], bf16x8 (&hi8)[3]) {
+    constexpr int NP = TC<MODE>::NP;
+    split8<NP>(y, lo);
+    split8<NP>(y + 8, hi8);
+}
+template <int MODE>
+__device__ __forceinline__ void store_tile(void *base, int64_t blk, int t, int lane, const float (&y)[16], const bf16x8 &lo,
+                                           const bf16x8 &hi8) {
+    if (MODE == 1) {
+        __bf16 *p = reinterpret_cast<__bf16 *>(base) + (((blk * 16 + 2 * t) * 64) + lane) * 8;
+        *reinterpret_cast<bf16x8 *>(p) = lo;
+        *reinterpret_cast<bf16x8 *>(p + 512) = hi8;
+    } else {
+        float *p = reinterpret_cast<float *>(base) + (((blk * 8 + t) * 4) * 64 + lane) * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<float4 *>(p + q * 256) = make_float4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
+    }
+}
+
+// A layer shape is a compile-time type: a run-time `if` around a group of MFMAs makes the compiler copy whole accumulator
+// tuples between AGPRs at the join (a first version spent 30 % of its VALU issue on such copies).
+constexpr int A_SP100 = 0, A_NONE = 1, A_SIGMA = 2, A_RGB = 3;
+template <int NH_, int NE_, int NT_, int ACT_> struct Shape { static constexpr int NH = NH_, NE = NE_, NT = NT_, ACT = ACT_; };
+// scheduling fence between the MFMA stages and between the epilogue tiles
+#define TRUNK_FENCE() __builtin_amdgcn_sched_barrier(0)
+// LDS: bias table first (its reads fold into 16-bit ds offsets of one base register), then the two stage buffers
+constexpr int LB_HID = 0, LB_BOTT = 2048, LB_RGBH = 2304, LB_SIGMA = 2432, LB_RGBO = 2436, LB_FLOATS = 2560;
+__host__ __device__ constexpr int lb_off(int l) {
+    return l < 8 ? LB_HID + 256 * l : l == L_SIGMA ? LB_SIGMA : l == L_BOTT ? LB_BOTT : l == L_RGBH ? LB_RGBH : LB_RGBO;
+}
+
+// ---- forward ---------------------------------------------------------------------------------------------------------
+// FULL: all twelve layers (rgb and sigma); otherwise the hidden layers and sigma only (the sampler's density pre-pass,
+// occupancy-grid queries).  SAVE: keep the activations for the backward pass.
+template <int MODE, bool SAVE, bool FULL>
+__global__ __launch_bounds__(256, 1) void vfield_fwd_kernel(FieldArgs a) {
+    using C = TC<MODE>;
+    using PR = Pairs<MODE>;
+    typedef typename C::ST ST;
+    constexpr int NP = C::NP, NB = C::NB, NTS = C::NTS;
+    constexpr int STAGE = NTS * 20 * NP * 1024;          // bytes of the largest stage (layer 5)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+    float *bias = reinterpret_cast<float *>(smem_all);
+    unsigned char *smem_tf = smem_all + LB_FLOATS * 4;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int hi = lane >> 5, sl = lane & 31;
+    const uint32_t lane16 = lane * 16;
+    for (int i = threadIdx.x; i < LB_FLOATS; i += 256) {
+        float b = 0.f;
+        if (i < 2048) b = a.P[l_boff(i >> 8, a.C) + (i & 255)];
+        else if (i < LB_RGBH) b = a.P[l_boff(L_BOTT, a.C) + i - LB_BOTT];
+        else if (i < LB_SIGMA) b = a.P[l_boff(L_RGBH, a.C) + i - LB_RGBH];
+        else if (i == LB_SIGMA) b = a.P[l_boff(L_SIGMA, a.C)];
+        else if (i >= LB_RGBO && i < LB_RGBO + a.C) b = a.P[l_boff(L_RGBO, a.C) + i - LB_RGBO];
+        bias[i] = b;
+    }
+    const int64_t n_blk = (a.n + 31) >> 5, n_grp = (n_blk + 4 * NB - 1) / (4 * NB);
+    const size_t sstride = (size_t)n_grp * 4 * NB * 32 * 256;                // elements per slot (whole groups)
+
+    auto issue = [&](int l, int tg, int buf) {           // stage (layer l, tile group tg) -> LDS buffer buf
+        const int nch = l_nch(l), nts = min(NTS, l_nt(l) - tg * NTS), pieces = nts * nch * NP;
+        // uniform (scalar) piece offset + one 32-bit lane offset; the empty asm keeps the compiler from precomputing a
+        // 64-bit vector address per piece and stage in the kernel prologue (it spilled ~180 registers doing so)
+        uint32_t off = (uint32_t)(f_off(l) + tg * NTS * nch) * NP * 1024 + wave * 1024;
+        unsigned char *dst = smem_tf + buf * STAGE + wave * 1024;
+        for (int i = wave; i < pieces; i += 4) {
+            asm volatile("" : "+s"(off));
+            glds16(reinterpret_cast<const unsigned char *>(a.img) + off + lane16, dst);
+            off += 4096; dst += 4096;
+        }
+    };
+    int buf = 0;
+    if ((int64_t)blockIdx.x < n_grp) issue(0, 0, 0);
+    for (int64_t grp = blockIdx.x; grp < n_grp; grp += gridDim.x) {
+        const int64_t blk0 = (grp * 4 + wave) * NB;
+        const bool more_grp = grp + gridDim.x < n_grp;
+        bf16x8 x[NB][NP][16];
+        // encoding operands; rows of blocks past the end are clamped to the last block (their results are never stored
+        // row-major, and the fragment-layout buffers are whole groups)
+        auto load_rows = [&](const float *src, int ld, int nchunks, bf16x8 (&e)[NB][NP][4]) {
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const int64_t blk = blk0 + u < n_blk ? blk0 + u : n_blk - 1;
+                const float *xp = src + (blk * 32 + sl) * ld + 8 * hi;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (c >= nchunks) continue;
+                    const float4 v0 = *reinterpret_cast<const float4 *>(xp + 16 * c), v1 = *reinterpret_cast<const float4 *>(xp + 16 * c + 4);
+                    const float xs[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                    bf16x8 o[3];
+                    split8<NP>(xs, o);
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) e[u][p][c] = o[p];
+                }
+            }
+        };
+        // l: this layer, ln: the layer whose first stage follows (-1: none)
+        auto layer = [&](auto shape, const int l, const int ln, const int slot) {
+            using S = decltype(shape);
+            constexpr int NH = S::NH, NE = S::NE, NT = S::NT, ACT = S::ACT, nch = NH + NE;
+            constexpr int NTG = (NT + NTS - 1) / NTS;
+            bf16x8 e[NB][NP][4];
+            if (NE == 4) load_rows(a.enc, a.ld_enc, 4, e);
+            if (NE == 2) load_rows(a.view, a.ld_view, 2, e);
+            f32x16 acc[NB][NT];
+#pragma unroll
+            for (int tg = 0; tg < NTG; ++tg) {
+                __syncthreads();                         // stage (l, tg) has landed (the fence drains this wave's LDS-DMA)
+                if (tg + 1 < NTG) issue(l, tg + 1, buf ^ 1);
+                else if (ln >= 0) issue(ln, 0, buf ^ 1);
+                const unsigned char *st = smem_tf + buf * STAGE + lane16;
+#pragma unroll
+                for (int tt = 0; tt < NTS; ++tt) {
+                    const int t = tg * NTS + tt;
+                    if (t >= NT) continue;
+                    f32x16 part;                         // odd product terms when a stage has a single accumulator (fp32 mode)
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) {
+                        part[g] = 0.f;
+#pragma unroll
+                        for (int u = 0; u < NB; ++u) acc[u][t][g] = 0.f;
+                    }
+                    const unsigned char *wt = st + tt * nch * NP * 1024;
+                    int m = 0;
+#pragma unroll
+                    for (int c = 0; c < nch; ++c) {
+                        bf16x8 w[NP];
+#pragma unroll
+                        for (int p = 0; p < NP; ++p) w[p] = *reinterpret_cast<const bf16x8 *>(wt + (c * NP + p) * 1024);
+#pragma unroll
+                        for (int k = 0; k < PR::N; ++k)
+#pragma unroll
+                            for (int u = 0; u < NB; ++u, ++m) {
+                                const bf16x8 &xv = c < NH ? x[u][PR::A[k]][c & 15] : e[u][PR::A[k]][(c - NH) & 3];
+                                if (NB * NTS == 1 && (m & 1)) part = MFMAB(w[PR::W[k]], xv, part);
+                                else acc[u][t] = MFMAB(w[PR::W[k]], xv, acc[u][t]);
+                            }
+                    }
+                    if (NB * NTS == 1) acc[0][t] += part;
+                }
+                buf ^= 1;
+                TRUNK_FENCE();
+            }
+            const float *bl = bias + lb_off(l);
+            if (ACT == A_SIGMA) {                        // row 0 of the tile: lanes hi == 0, register 0 (ngp.py:45-65 trunc_exp)
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const int64_t row = (blk0 + u) * 32 + sl;
+                    if (hi == 0 && row < a.n) a.sigma[row] = a.sel[row] ? __expf(acc[u][0][0] + bl[0] - 1.f) : 0.f;
+                }
+                return;
+            }
+            if (ACT == A_RGB) {                          // rows 0 .. C-1: lanes hi == 0, registers 0 .. 3
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const int64_t row = (blk0 + u) * 32 + sl;
+                    if (hi == 0 && row < a.n) {
+                        float r[4];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) r[c] = c < a.C ? softplus1(acc[u][0][c] + bl[c]) : 0.f;
+                        *reinterpret_cast<float4 *>(a.rgb4 + row * 4) = make_float4(r[0], r[1], r[2], r[3]);
+                    }
+                }
+                return;
+            }
+            // bias + activation; the accumulators become the next layer's operands and the saved copy
+            ST *sv = reinterpret_cast<ST *>(a.acts) + (size_t)slot * sstride;
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    float y[16];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 b4 = *reinterpret_cast<const float4 *>(bl + t * 32 + 8 * q + 4 * hi);
+                        const float z[4] = {acc[u][t][4 * q] + b4.x, acc[u][t][4 * q + 1] + b4.y, acc[u][t][4 * q + 2] + b4.z, acc[u][t][4 * q + 3] + b4.w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) y[4 * q + j] = ACT == A_SP100 ? softplus100(z[j]) : z[j];
+                    }
+                    bf16x8 lo[3], hi8[3];
+                    pack_tile<MODE>(y, lo, hi8);
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) { x[u][p][2 * t] = lo[p]; x[u][p][2 * t + 1] = hi8[p]; }
+                    if (SAVE) store_tile<MODE>(sv, blk0 + u, t, lane, y, lo[0], hi8[0]);
+                    TRUNK_FENCE();
+                }
+            }
+        };
+        layer(Shape<0, 4, 8, A_SP100>(), 0, 1, 0);
+        for (int l = 1; l < L_SKIP; ++l) layer(Shape<16, 0, 8, A_SP100>(), l, l + 1, l);
+        layer(Shape<16, 4, 8, A_SP100>(), L_SKIP, 6, L_SKIP);
+        layer(Shape<16, 0, 8, A_SP100>(), 6, 7, 6);
+        layer(Shape<16, 0, 8, A_SP100>(), 7, L_SIGMA, 7);
+        layer(Shape<16, 0, 1, A_SIGMA>(), L_SIGMA, FULL ? L_BOTT : (more_grp ? 0 : -1), -1);
+        if (FULL) {
+            layer(Shape<16, 0, 8, A_NONE>(), L_BOTT, L_RGBH, 8);
+            layer(Shape<16, 2, 4, A_SP100>(), L_RGBH, L_RGBO, 9);
+            layer(Shape<8, 0, 1, A_RGB>(), L_RGBO, more_grp ? 0 : -1, -1);
+        }
+    }
+}
+
+// ---- backward (data) ---------------------------------------------------------------------------------------------------
+// steps: 11 (dz_rgb -> dz of the colour hidden layer), 10 (-> d bottleneck), 9 (+ sigma -> dz7), 7 .. 1
+template <int NH_, int NE_, int NT_, bool DERIV_> struct BShape { static constexpr int NH = NH_, NE = NE_, NT = NT_; static constexpr bool DERIV = DERIV_; };
+
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void vfield_bwd_kernel(FieldArgs a) {
+    using C = TC<MODE>;
+    using PR = Pairs<MODE>;
+    typedef typename C::ST ST;
+    constexpr int NP = C::NP, NB = C::NB, NTS = C::NTS;
+    constexpr int STAGE = NTS * 17 * NP * 1024;
+    constexpr int HV = MODE == 1 ? 2 : 4;                // 16-byte loads per lane and tile of a saved layer
+    constexpr int PD = 4;                                // saved-activation tiles in flight
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_tb[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int hi = lane >> 5, sl = lane & 31;
+    const uint32_t lane16 = lane * 16;
+    const int64_t n_blk = (a.n + 31) >> 5, n_grp = (n_blk + 4 * NB - 1) / (4 * NB);
+    const size_t sstride = (size_t)n_grp * 4 * NB * 32 * 256;                // whole groups: stores need no bounds
+
+    auto issue = [&](int l, int tg, int buf) {           // stage (step l, input-tile group tg)
+        const int nch = b_nch(l), nts = min(NTS, b_nt(l) - tg * NTS), pieces = nts * nch * NP;
+        uint32_t off = (uint32_t)(b_off(l) + tg * NTS * nch) * NP * 1024 + wave * 1024;       // see vfield_fwd_kernel
+        unsigned char *dst = smem_tb + buf * STAGE + wave * 1024;
+        for (int i = wave; i < pieces; i += 4) {
+            asm volatile("" : "+s"(off));
+            glds16(reinterpret_cast<const unsigned char *>(a.img) + off + lane16, dst);
+            off += 4096; dst += 4096;
+        }
+    };
+    int buf = 0;
+    if ((int64_t)blockIdx.x < n_grp) issue(L_RGBO, 0, 0);
+    for (int64_t grp = blockIdx.x; grp < n_grp; grp += gridDim.x) {
+        const int64_t blk0 = (grp * 4 + wave) * NB;
+        const bool more_grp = grp + gridDim.x < n_grp;
+        bf16x8 x[NB][NP][16];
+        // one extra operand chunk from a row-major [n_pad][32] gradient buffer: columns 8 hi .. 8 hi + 7 (step 11: dz_rgb),
+        // or k-slot 0 only (step 9: dz_sigma, column 0)
+        auto load_extra = [&](const float *src, bool slot0, bf16x8 (&e)[NB][NP]) {
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const int64_t blk = blk0 + u < n_blk ? blk0 + u : n_blk - 1;
+                const float *xp = src + (blk * 32 + sl) * 32 + 8 * hi;
+                float xs[8];
+                if (slot0) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) xs[j] = 0.f;
+                    xs[0] = hi == 0 ? xp[0] : 0.f;
+                } else {
+                    const float4 v0 = *reinterpret_cast<const float4 *>(xp), v1 = *reinterpret_cast<const float4 *>(xp + 4);
+                    xs[0] = v0.x; xs[1] = v0.y; xs[2] = v0.z; xs[3] = v0.w; xs[4] = v1.x; xs[5] = v1.y; xs[6] = v1.z; xs[7] = v1.w;
+                }
+                bf16x8 o[3];
+                split8<NP>(xs, o);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) e[u][p] = o[p];
+            }
+        };
+        // step l; ln: the step whose first stage follows (-1 none); hslot: saved activation whose derivative multiplies the
+        // result (DERIV); dslot: where the result (a pre-activation gradient) is stored
+        auto step = [&](auto shape, const int l, const int ln, const int hslot, const int dslot, const float *extra) {
+            using S = decltype(shape);
+            constexpr int NH = S::NH, NE = S::NE, NT = S::NT, nch = NH + NE;
+            constexpr bool DERIV = S::DERIV;
+            constexpr int NTG = (NT + NTS - 1) / NTS;
+            const ST *hs = reinterpret_cast<const ST *>(a.acts) + (size_t)(DERIV ? hslot : 0) * sstride;
+            uint4 hpre[PD][HV];
+            auto load_h = [&](int i, uint4 (&dst)[HV]) {                                           // i = u * NT + t
+                const int u = i / NT, t = i % NT;
+                const int64_t blk = blk0 + u;
+                const uint4 *p = MODE == 1 ? reinterpret_cast<const uint4 *>(hs + ((blk * 16 + 2 * t) * 64 + lane) * 8)
+                                           : reinterpret_cast<const uint4 *>(hs + ((blk * 8 + t) * 4 * 64 + lane) * 4);
+#pragma unroll
+                for (int q = 0; q < HV; ++q) dst[q] = p[q * 64];
+            };
+            bf16x8 e[NB][NP];
+            if (NE) load_extra(extra, l == L_BOTT, e);
+            f32x16 acc[NB][NT];
+#pragma unroll
+            for (int tg = 0; tg < NTG; ++tg) {
+                __syncthreads();
+                if (tg + 1 < NTG) issue(l, tg + 1, buf ^ 1);
+                else if (ln >= 0) issue(ln, 0, buf ^ 1);
+                if (DERIV && tg == NTG - 1) {
+#pragma unroll
+                    for (int i = 0; i < PD; ++i) load_h(i, hpre[i]);
+                }
+                const unsigned char *st = smem_tb + buf * STAGE + lane16;
+#pragma unroll
+                for (int tt = 0; tt < NTS; ++tt) {
+                    const int t = tg * NTS + tt;
+                    if (t >= NT) continue;
+                    f32x16 part;
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) {
+                        part[g] = 0.f;
+#pragma unroll
+                        for (int u = 0; u < NB; ++u) acc[u][t][g] = 0.f;
+                    }
+                    const unsigned char *wt = st + tt * nch * NP * 1024;
+                    int m = 0;
+#pragma unroll
+                    for (int c = 0; c < nch; ++c) {
+                        bf16x8 w[NP];
+#pragma unroll
+                        for (int p = 0; p < NP; ++p) w[p] = *reinterpret_cast<const bf16x8 *>(wt + (c * NP + p) * 1024);
+#pragma unroll
+                        for (int k = 0; k < PR::N; ++k)
+#pragma unroll
+                            for (int u = 0; u < NB; ++u, ++m) {
+                                const bf16x8 &xv = c < NH ? x[u][PR::A[k]][c & 15] : e[u][PR::A[k]];
+                                if (NB * NTS == 1 && (m & 1)) part = MFMAB(w[PR::W[k]], xv, part);
+                                else acc[u][t] = MFMAB(w[PR::W[k]], xv, acc[u][t]);
+                            }
+                    }
+                    if (NB * NTS == 1) acc[0][t] += part;
+                }
+                buf ^= 1;
+                TRUNK_FENCE();
+            }
+            ST *sv = reinterpret_cast<ST *>(a.dz) + (size_t)dslot * sstride;
+#pragma unroll
+            for (int i = 0; i < NB * NT; ++i) {
+                const int u = i / NT, t = i % NT;
+                float y[16];
+                if (DERIV) {
+                    float h[16];
+                    if (MODE == 1) {
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const bf16x8 hv = *reinterpret_cast<const bf16x8 *>(&hpre[i % PD][q]);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) h[8 * q + j] = (float)hv[j];
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float4 hv = *reinterpret_cast<const float4 *>(&hpre[i % PD][q]);
+                            h[4 * q] = hv.x; h[4 * q + 1] = hv.y; h[4 * q + 2] = hv.z; h[4 * q + 3] = hv.w;
+                        }
+                    }
+                    if (i + PD < NB * NT) load_h(i + PD, hpre[i % PD]);
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) y[g] = acc[u][t][g] * dsoftplus_from_out(h[g], 100.f);
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) y[g] = acc[u][t][g];
+                }
+                bf16x8 lo[3], hi8[3];
+                pack_tile<MODE>(y, lo, hi8);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) { x[u][p][2 * t] = lo[p]; x[u][p][2 * t + 1] = hi8[p]; }
+                store_tile<MODE>(sv, blk0 + u, t, lane, y, lo[0], hi8[0]);
+                TRUNK_FENCE();
+            }
+        };
+        step(BShape<0, 1, 4, true>(), L_RGBO, L_RGBH, 9, 9, a.dz_rgb);
+        step(BShape<8, 0, 8, false>(), L_RGBH, L_BOTT, 0, 8, nullptr);
+        step(BShape<16, 1, 8, true>(), L_BOTT, 7, 7, 7, a.dz_sig);
+        for (int l = 7; l >= 1; --l) step(BShape<16, 0, 8, true>(), l, l > 1 ? l - 1 : (more_grp ? L_RGBO : -1), l - 1, l - 1, nullptr);
+    }
+}
+
+// ---- weight / bias gradient of one layer from the fragment-layout copies -------------------------------------------------------
+// as dense_dw_x_kernel (ren_dense.hip): one workgroup of 8 waves per sample split, per 32-sample stage the block's dz and
+// inputs go to LDS transposed, [feature][sample] bf16 pieces; wave w owns the output rows 32 w .. against up to 8 input
+// tiles per K group.  Narrow layers (sigma: 1 output, colour output: C) take dz from the row-major [n_pad][32] buffers.
+constexpr int TDW_ST = 40;
+struct FieldDwArgs {
+    const void *dz; int nz;                              // fragment slot with nz (256 / 128) features, or ..
+    const float *dz_rows;                                // .. row-major [n_pad][32] (nz = 32)
+    const void *x; int nx;                               // K group 0: fragment slot with nx features (0: none)
+    const float *x_rows; int ld_rows, n_rows;            // last K group: row-major encoding columns (n_rows 64 / 32; 0: none)
+    int N, K;                                            // torch out / in features
+    int64_t n;
+    float *slab_w, *slab_b;                              // [n_splits][N][K], [n_splits][N]
+};
+
+template <int MODE>
+__global__ __launch_bounds__(512, 1) void vfield_dw_kernel(FieldDwArgs a) {
+    typedef typename TC<MODE>::ST ST;
+    constexpr int NP = TC<MODE>::NP;
+    constexpr int NV = MODE == 1 ? 2 : 4;                // 16-byte pieces per thread and operand per stage (256 features)
+    constexpr int FPP = MODE == 1 ? 8 : 4;               // features per piece and lane
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_td[];
+    __bf16 *ZT = reinterpret_cast<__bf16 *>(smem_td), *XT = ZT + NP * 256 * TDW_ST;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hi = lane >> 5, sl = lane & 31;
+    const int n_splits = gridDim.x;
+    const int64_t n_blk = (a.n + 31) >> 5;
+    const int k_groups = (a.nx ? 1 : 0) + (a.n_rows ? 1 : 0);
+    const bool has_tile = wave * 32 < a.N;
+    float *sw = a.slab_w + (int64_t)blockIdx.x * a.N * a.K, *sb = a.slab_b + (int64_t)blockIdx.x * a.N;
+    for (int kg = 0; kg < k_groups; ++kg) {
+        const bool x_rows = kg == k_groups - 1 && a.n_rows;       // this K group: the row-major encoding
+        const int kt = x_rows ? a.n_rows / 32 : a.nx / 32, k0 = (kg == 1) ? a.nx : 0;
+        f32x16 acc[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[t][g] = 0.f;
+        float bsum[NV * FPP];
+#pragma unroll
+        for (int q = 0; q < NV * FPP; ++q) bsum[q] = 0.f;
+        uint4 pz[NV], px[NV];
+        float4 pe, pzr;
+        auto fetch = [&](int64_t blk) {
+            const uint4 *zb = reinterpret_cast<const uint4 *>(reinterpret_cast<const ST *>(a.dz) + blk * 32 * 256);
+            const uint4 *xb = reinterpret_cast<const uint4 *>(reinterpret_cast<const ST *>(a.x) + blk * 32 * 256);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int piece = wave * NV + v;
+                if (!a.dz_rows && piece * FPP * 2 < a.nz) pz[v] = zb[piece * 64 + lane];
+                if (!x_rows && piece * FPP * 2 < a.nx) px[v] = xb[piece * 64 + lane];
+            }
+            const int s = threadIdx.x & 31, f0 = 4 * (threadIdx.x >> 5);
+            if (x_rows && f0 < a.n_rows) pe = *reinterpret_cast<const float4 *>(a.x_rows + (blk * 32 + s) * a.ld_rows + f0);
+            if (a.dz_rows && f0 < 32) pzr = *reinterpret_cast<const float4 *>(a.dz_rows + (blk * 32 + s) * 32 + f0);
+        };
+        auto put = [&](__bf16 *T, int f, int s, float v) {
+            __bf16 sp[3];
+            split<NP>(v, sp);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) T[(p * 256 + f) * TDW_ST + s] = sp[p];
+        };
+        auto stash = [&](int64_t blk) {
+            const bool live = blk * 32 + sl < a.n;       // samples past the end contribute nothing
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int piece = wave * NV + v;
+                const bool zin = !a.dz_rows && piece * FPP * 2 < a.nz, xin = !x_rows && piece * FPP * 2 < a.nx;
+                if (MODE == 1) {                         // piece = chunk c: features kmap(c, hi, j)
+                    const bf16x8 z8 = *reinterpret_cast<const bf16x8 *>(&pz[v]), x8 = *reinterpret_cast<const bf16x8 *>(&px[v]);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int f = kmap(piece, hi, j);
+                        if (zin) { ZT[f * TDW_ST + sl] = live ? z8[j] : (__bf16)0.f; bsum[8 * v + j] += live ? (float)z8[j] : 0.f; }
+                        if (xin) XT[f * TDW_ST + sl] = live ? x8[j] : (__bf16)0.f;
+                    }
+                } else {                                 // piece = (t, q): features 32 t + 8 q + 4 hi + j
+                    const float4 z4 = *reinterpret_cast<const float4 *>(&pz[v]), x4 = *reinterpret_cast<const float4 *>(&px[v]);
+                    const float z[4] = {z4.x, z4.y, z4.z, z4.w}, xx[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int f = 8 * piece + 4 * hi + j;
+                        if (zin) { put(ZT, f, sl, live ? z[j] : 0.f); bsum[4 * v + j] += live ? z[j] : 0.f; }
+                        if (xin) put(XT, f, sl, live ? xx[j] : 0.f);
+                    }
+                }
+            }
+            const int s = threadIdx.x & 31, f0 = 4 * (threadIdx.x >> 5);
+            const bool lives = blk * 32 + s < a.n;
+            if (x_rows && f0 < a.n_rows) {               // thread -> (sample tid & 31, features 4 (tid >> 5) ..)
+                const float ev[4] = {pe.x, pe.y, pe.z, pe.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) put(XT, f0 + j, s, lives ? ev[j] : 0.f);
+            }
+            if (a.dz_rows && f0 < 32) {
+                const float zv[4] = {pzr.x, pzr.y, pzr.z, pzr.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { put(ZT, f0 + j, s, lives ? zv[j] : 0.f); bsum[j] += lives ? zv[j] : 0.f; }
+            }
+        };
+        int64_t blk = blockIdx.x;
+        if (blk < n_blk) fetch(blk);
+        for (; blk < n_blk; blk += n_splits) {
+            __syncthreads();
+            stash(blk);
+            __syncthreads();
+            const int64_t nxt = blk + n_splits;
+            if (nxt < n_blk) fetch(nxt);
+            if (has_tile) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    bf16x8 az[NP];
+#pragma unroll
+                    for (int p = 0; p < NP; ++p)
+                        az[p] = *reinterpret_cast<const bf16x8 *>(ZT + (p * 256 + wave * 32 + sl) * TDW_ST + 16 * ks + 8 * hi);
+#pragma unroll
+                    for (int t = 0; t < 8; ++t)
+                        if (t < kt) {
+                            bf16x8 bx[NP];
+#pragma unroll
+                            for (int p = 0; p < NP; ++p)
+                                bx[p] = *reinterpret_cast<const bf16x8 *>(XT + (p * 256 + t * 32 + sl) * TDW_ST + 16 * ks + 8 * hi);
+                            if (NP == 3) {
+                                acc[t] = MFMAB(az[2], bx[0], acc[t]);
+                                acc[t] = MFMAB(az[0], bx[2], acc[t]);
+                                acc[t] = MFMAB(az[1], bx[1], acc[t]);
+                                acc[t] = MFMAB(az[1], bx[0], acc[t]);
+                                acc[t] = MFMAB(az[0], bx[1], acc[t]);
+                            }
+                            acc[t] = MFMAB(az[0], bx[0], acc[t]);
+                        }
+                }
+            }
+        }
+        if (has_tile) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int k = k0 + t * 32 + sl;
+                if (t >= kt || k >= a.K) continue;
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int o = wave * 32 + rowc(g) + 4 * hi;
+                    if (o < a.N) sw[(int64_t)o * a.K + k] = acc[t][g];
+                }
+            }
+        }
+        if (kg == 0) {                                   // bias gradient: sum over the 32 sample lanes
+            if (a.dz_rows) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float s = bsum[j];
+#pragma unroll
+                    for (int off = 1; off < 32; off <<= 1) s += __shfl_xor(s, off, 64);
+                    const int f = 4 * (threadIdx.x >> 5) + j;
+                    if ((threadIdx.x & 31) == 0 && f < a.N) sb[f] = s;
+                }
+            } else {
+#pragma unroll
+                for (int v = 0; v < NV; ++v)
+#pragma unroll
+                    for (int j = 0; j < FPP; ++j) {
+                        float s = bsum[FPP * v + j];
+#pragma unroll
+                        for (int off = 1; off < 32; off <<= 1) s += __shfl_xor(s, off, 64);
+                        const int piece = wave * NV + v;
+                        const int f = MODE == 1 ? kmap(piece, hi, j) : 8 * piece + 4 * hi + j;
+                        if (sl == 0 && f < a.N) sb[f] = s;
+                    }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int MODE> size_t fwd_lds() { return LB_FLOATS * 4 + 2 * (size_t)TC<MODE>::NTS * 20 * TC<MODE>::NP * 1024; }
+template <int MODE> size_t bwd_lds() { return 2 * (size_t)TC<MODE>::NTS * 17 * TC<MODE>::NP * 1024; }
+
+}  // namespace
+
+static inline int vfield_np(int mode) { return mode == 1 ? 1 : 3; }
+static inline bool vfield_ok(int mode, int C) { return (mode == 1 || mode == 6) && C >= 1 && C <= 4; }
+
+extern "C" int64_t ren_vanilla_image_bytes(int32_t mode) {
+    if (mode != 1 && mode != 6) return -1;
+    return (int64_t)(F_FRAGS + B_FRAGS) * vfield_np(mode) * 1024;
+}
+
+extern "C" int64_t ren_vanilla_saved_bytes(int32_t mode, int64_t n) {
+    if ((mode != 1 && mode != 6) || n < 0) return -1;
+    const int64_t per_grp = 4 * (mode == 1 ? TC<1>::NB : TC<6>::NB), n_grp = ((n + 31) / 32 + per_grp - 1) / per_grp;
+    return N_SLOTS * n_grp * per_grp * 32 * 256 * (mode == 1 ? 2 : 4);          // whole workgroup passes of 32-sample blocks
+}
+
+extern "C" int ren_vanilla_prep(const float *params, int32_t C, int32_t mode, void *image, void *stream) {
+    if (!params || !image || !vfield_ok(mode, C)) return REN_ERR_BAD_ARG;
+    const int np = vfield_np(mode);
+    __bf16 *f = reinterpret_cast<__bf16 *>(image), *b = f + (size_t)F_FRAGS * np * 512;
+    const int blocks = ((F_FRAGS + B_FRAGS) * 64 + 255) / 256;
+    if (mode == 1) hipLaunchKernelGGL(vfield_prep_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, C, f, b);
+    else hipLaunchKernelGGL(vfield_prep_kernel<3>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, C, f, b);
+    REN_CHECK_LAUNCH();
+}
+
+static int vfield_grid(int64_t n, int nb) {
+    const int64_t n_grp = ((n + 31) / 32 + 4 * nb - 1) / (4 * nb);
+    return (int)(n_grp < 256 ? n_grp : 256);
+}
+
+extern "C" int ren_vanilla_fwd(const float *enc, int32_t ld_enc, const float *view, int32_t ld_view, const uint8_t *selector,
+                               const float *params, int32_t C, const void *image, int32_t mode, int64_t n, void *saved,
+                               float *sigma, float *rgb4, void *stream) {
+    if (!enc || !selector || !params || !image || !sigma || !vfield_ok(mode, C) || n < 0 || ld_enc < 64 || (ld_enc & 3)) return REN_ERR_BAD_ARG;
+    if (rgb4 && (!view || ld_view < 32 || (ld_view & 3))) return REN_ERR_BAD_ARG;
+    if (saved && !rgb4) return REN_ERR_BAD_ARG;                                 // the backward pass needs the whole field
+    if (n == 0) return REN_OK;
+    FieldArgs a = {};
+    a.enc = enc; a.ld_enc = ld_enc; a.view = view; a.ld_view = ld_view; a.sel = selector; a.P = params; a.C = C;
+    a.img = reinterpret_cast<const __bf16 *>(image); a.acts = saved; a.sigma = sigma; a.rgb4 = rgb4; a.n = n;
+    hipStream_t st = (hipStream_t)stream;
+#define REN_VFIELD_FWD(MODE, SAVE, FULL)                                                                                        \
+    do {                                                                                                                        \
+        (void)hipFuncSetAttribute((const void *)vfield_fwd_kernel<MODE, SAVE, FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_lds<MODE>()); \
+        hipLaunchKernelGGL((vfield_fwd_kernel<MODE, SAVE, FULL>), dim3(vfield_grid(n, TC<MODE>::NB)), dim3(256), fwd_lds<MODE>(), st, a); \
+    } while (0)
+    if (mode == 1) { if (saved) REN_VFIELD_FWD(1, true, true); else if (rgb4) REN_VFIELD_FWD(1, false, true); else REN_VFIELD_FWD(1, false, false); }
+    else { if (saved) REN_VFIELD_FWD(6, true, true); else if (rgb4) REN_VFIELD_FWD(6, false, true); else REN_VFIELD_FWD(6, false, false); }
+    REN_CHECK_LAUNCH();
+}
+
+extern "C" int ren_vanilla_bwd(const float *dz_rgb, const float *dz_sigma, const void *image, int32_t mode, int64_t n,
+                               const void *saved, void *dz, void *stream) {
+    if (!dz_rgb || !dz_sigma || !image || !saved || !dz || (mode != 1 && mode != 6) || n < 0) return REN_ERR_BAD_ARG;
+    if (n == 0) return REN_OK;
+    FieldArgs a = {};
+    a.img = reinterpret_cast<const __bf16 *>(image) + (size_t)F_FRAGS * vfield_np(mode) * 512;
+    a.acts = const_cast<void *>(saved); a.dz_rgb = dz_rgb; a.dz_sig = dz_sigma; a.dz = dz; a.n = n;
+    hipStream_t st = (hipStream_t)stream;
+    if (mode == 1) {
+        (void)hipFuncSetAttribute((const void *)vfield_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds<1>());
+        hipLaunchKernelGGL(vfield_bwd_kernel<1>, dim3(vfield_grid(n, TC<1>::NB)), dim3(256), bwd_lds<1>(), st, a);
+    } else {
+        (void)hipFuncSetAttribute((const void *)vfield_bwd_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds<6>());
+        hipLaunchKernelGGL(vfield_bwd_kernel<6>, dim3(vfield_grid(n, TC<6>::NB)), dim3(256), bwd_lds<6>(), st, a);
+    }
+    REN_CHECK_LAUNCH();
+}
+
+extern "C" int64_t ren_vanilla_bwd_weight_workspace_floats(int32_t n_splits) {
+    if (n_splits < 1) return -1;
+    return (int64_t)n_splits * (256 * 319 + 256);
+}
+
+extern "C" int ren_vanilla_bwd_weight(const void *dz, const void *saved, const float *enc, int32_t ld_enc, const float *view,
+                                      int32_t ld_view, const float *dz_rgb, const float *dz_sigma, int32_t C, int32_t mode,
+                                      int64_t n, int32_t n_splits, float *grads, float *workspace, void *stream) {
+    if (!dz || !saved || !enc || !view || !dz_rgb || !dz_sigma || !grads || !workspace || !vfield_ok(mode, C) || n < 0 || n_splits < 1 ||
+        ld_enc < 64 || (ld_enc & 3) || ld_view < 32 || (ld_view & 3))
+        return REN_ERR_BAD_ARG;
+    if (n == 0) return REN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t sbytes = (size_t)ren_vanilla_saved_bytes(mode, n) / N_SLOTS;
+    auto slot = [&](const void *base, int s) { return reinterpret_cast<const unsigned char *>(base) + s * sbytes; };
+    for (int l = NL - 1; l >= 0; --l) {
+        FieldDwArgs a = {};
+        a.N = l_out(l, C); a.K = l_in(l); a.n = n;
+        if (l == L_RGBO) { a.dz_rows = dz_rgb; a.nz = 32; a.x = slot(saved, 9); a.nx = 128; }
+        else if (l == L_RGBH) { a.dz = slot(dz, 9); a.nz = 128; a.x = slot(saved, 8); a.nx = 256; a.x_rows = view; a.ld_rows = ld_view; a.n_rows = 32; }
+        else if (l == L_BOTT) { a.dz = slot(dz, 8); a.nz = 256; a.x = slot(saved, 7); a.nx = 256; }
+        else if (l == L_SIGMA) { a.dz_rows = dz_sigma; a.nz = 32; a.x = slot(saved, 7); a.nx = 256; }
+        else {
+            a.dz = slot(dz, l); a.nz = 256;
+            if (l > 0) { a.x = slot(saved, l - 1); a.nx = 256; }
+            if (l == 0 || l == L_SKIP) { a.x_rows = enc; a.ld_rows = ld_enc; a.n_rows = 64; }
+        }
+        a.slab_w = workspace; a.slab_b = workspace + (int64_t)n_splits * a.N * a.K;
+        const size_t lds = 2 * (size_t)vfield_np(mode) * 256 * TDW_ST * 2;
+        if (mode == 1) {
+            (void)hipFuncSetAttribute((const void *)vfield_dw_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(vfield_dw_kernel<1>, dim3(n_splits), dim3(512), lds, st, a);
+        } else {
+            (void)hipFuncSetAttribute((const void *)vfield_dw_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(vfield_dw_kernel<6>, dim3(n_splits), dim3(512), lds, st, a);
+        }
+        launch_reduce_slabs(a.slab_w, n_splits, a.N * a.K, grads + l_woff(l, C), st);
+        launch_reduce_slabs(a.slab_b, n_splits, a.N, grads + l_boff(l, C), st);
+    }
+    REN_CHECK_LAUNCH();
+}

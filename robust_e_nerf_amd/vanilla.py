@@ -75,86 +75,91 @@ class VanillaField:
         return out
 
 
-class Trunk:
-    """The eight hidden layers as fused launches (csrc/ren_trunk.hip; include/ren_amd.h `ren_trunk_*`): forward with the
-    activations saved in the kernels' fragment layout, backward (data), weight gradient.  mode 1 = bf16 operands / bf16
+class FusedField:
+    """The whole field as fused launches (csrc/ren_vfield.hip; include/ren_amd.h `ren_vanilla_*`): forward with the
+    activations saved in the kernels' fragment layout, backward (data), weight gradients.  mode 1 = bf16 operands / bf16
     saved copies, 6 = three-piece split (fp32 round-off) / fp32 saved copies."""
 
     def __init__(self, fld: VanillaField, mode: int, n_splits: int = 256):
         self.field, self.mode, self.n_splits = fld, mode, n_splits
-        lib = _lib.load()
-        self.image = torch.empty(int(lib.ren_trunk_image_bytes(mode)), device=fld.flat.device, dtype=torch.uint8)
+        self.image = torch.empty(int(_lib.load().ren_vanilla_image_bytes(mode)), device=fld.flat.device, dtype=torch.uint8)
         self._ws = None
-        self._version = None
 
     def prep(self):
-        """rebuild the weight image from the current parameters (once per optimiser step / checkpoint load)"""
-        check(_lib.load().ren_trunk_prep(_ptr(self.field.flat), self.mode, _ptr(self.image, torch.uint8), _stream()), "ren_trunk_prep")
+        """rebuild the weight image from the current parameters"""
+        check(_lib.load().ren_vanilla_prep(_ptr(self.field.flat), self.field.C, self.mode, _ptr(self.image, torch.uint8), _stream()),
+              "ren_vanilla_prep")
 
     def new_saved(self, n: int) -> torch.Tensor:
-        return torch.empty(int(_lib.load().ren_trunk_saved_bytes(self.mode, n)), device=self.field.flat.device, dtype=torch.uint8)
+        return torch.empty(int(_lib.load().ren_vanilla_saved_bytes(self.mode, n)), device=self.field.flat.device, dtype=torch.uint8)
 
-    def forward(self, enc, n, saved, h7):
-        check(_lib.load().ren_trunk_fwd(_ptr(enc), enc.shape[1], _ptr(self.field.flat), _ptr(self.image, torch.uint8), self.mode, n,
-                                        _ptr(saved, torch.uint8) if saved is not None else None,
-                                        _ptr(h7) if h7 is not None else None, h7.shape[1] if h7 is not None else 0, _stream()),
-              "ren_trunk_fwd")
+    def forward(self, B, full: bool):
+        """B: _Buffers (enc / view / sel filled by the encoder) -> B.sigma, B.rgb4 (full), B.saved (when allocated)"""
+        check(_lib.load().ren_vanilla_fwd(_ptr(B.enc), 64, _ptr(B.view) if full else None, 32, _ptr(B.sel, torch.uint8),
+                                          _ptr(self.field.flat), self.field.C, _ptr(self.image, torch.uint8), self.mode, B.n,
+                                          _ptr(B.saved, torch.uint8) if (full and B.saved is not None) else None, _ptr(B.sigma),
+                                          _ptr(B.rgb4) if full else None, _stream()), "ren_vanilla_fwd")
 
-    def backward(self, dz7, n, saved, dz):
-        check(_lib.load().ren_trunk_bwd(_ptr(dz7), dz7.shape[1], _ptr(self.image, torch.uint8), self.mode, n,
-                                        _ptr(saved, torch.uint8), _ptr(dz, torch.uint8), _stream()), "ren_trunk_bwd")
+    def backward(self, dz_rgb, dz_sig, B, dz):
+        check(_lib.load().ren_vanilla_bwd(_ptr(dz_rgb), _ptr(dz_sig), _ptr(self.image, torch.uint8), self.mode, B.n,
+                                          _ptr(B.saved, torch.uint8), _ptr(dz, torch.uint8), _stream()), "ren_vanilla_bwd")
 
-    def backward_weight(self, dz, saved, enc, n):
-        lib = _lib.load()
+    def backward_weight(self, dz_rgb, dz_sig, B, dz):
+        lib, n = _lib.load(), B.n
         splits = max(1, min(self.n_splits, (n + 31) // 32))
-        need = int(lib.ren_trunk_bwd_weight_workspace_floats(splits))
+        need = int(lib.ren_vanilla_bwd_weight_workspace_floats(splits))
         if self._ws is None or self._ws.numel() < need:
             self._ws = None
-            self._ws = torch.empty(need, device=enc.device, dtype=torch.float32)
-        check(lib.ren_trunk_bwd_weight(_ptr(dz, torch.uint8), _ptr(saved, torch.uint8), _ptr(enc), enc.shape[1], self.mode, n, splits,
-                                       _ptr(self.field.grad), _ptr(self._ws), _stream()), "ren_trunk_bwd_weight")
+            self._ws = torch.empty(need, device=B.enc.device, dtype=torch.float32)
+        check(lib.ren_vanilla_bwd_weight(_ptr(dz, torch.uint8), _ptr(B.saved, torch.uint8), _ptr(B.enc), 64, _ptr(B.view), 32,
+                                         _ptr(dz_rgb), _ptr(dz_sig), self.field.C, self.mode, n, splits, _ptr(self.field.grad),
+                                         _ptr(self._ws), _stream()), "ren_vanilla_bwd_weight")
 
     def decode(self, saved: torch.Tensor, n: int) -> List[torch.Tensor]:
-        """fragment layout -> eight row-major (n, 256) float32 tensors (tests / tools only)"""
-        n_blk = saved.numel() // (8 * 32 * 256 * (2 if self.mode == 1 else 4))       # whole workgroup passes
+        """fragment layout -> ten row-major (n, 256) float32 tensors: slots 0-7 hidden layers, 8 bottleneck, 9 colour hidden
+        layer (first 128 columns) (tests / tools only)"""
+        S = 10
+        n_blk = saved.numel() // (S * 32 * 256 * (2 if self.mode == 1 else 4))       # whole workgroup passes
         dev = saved.device
         lane = torch.arange(64, device=dev)
         sl, hi = lane & 31, lane >> 5
         if self.mode == 1:
-            v = saved.view(torch.bfloat16).view(8, n_blk, 16, 64, 8).float()
+            v = saved.view(torch.bfloat16).view(S, n_blk, 16, 64, 8).float()
             c, j = torch.arange(16, device=dev), torch.arange(8, device=dev)
             feat = ((c >> 1) * 32 + 16 * (c & 1))[:, None, None] + (8 * (j >> 2) + (j & 3))[None, None, :] + 4 * hi[None, :, None]
             samp = sl[None, :, None].expand(16, 64, 8)
         else:
-            v = saved.view(torch.float32).view(8, n_blk, 32, 64, 4)
+            v = saved.view(torch.float32).view(S, n_blk, 32, 64, 4)
             tq, j = torch.arange(32, device=dev), torch.arange(4, device=dev)
             feat = (8 * tq)[:, None, None] + 4 * hi[None, :, None] + j[None, None, :]
             samp = sl[None, :, None].expand(32, 64, 4)
-        out = torch.empty(8, n_blk, 32, 256, device=dev)
-        out[:, :, samp.reshape(-1), feat.reshape(-1)] = v.reshape(8, n_blk, -1)
-        return [out[l].reshape(n_blk * 32, 256)[:n] for l in range(8)]
+        out = torch.empty(S, n_blk, 32, 256, device=dev)
+        out[:, :, samp.reshape(-1), feat.reshape(-1)] = v.reshape(S, n_blk, -1)
+        return [out[l].reshape(n_blk * 32, 256)[:n] for l in range(S)]
 
 
 class _Buffers:
-    """Activation buffers for n samples: row-major [n_pad][ld], zero padding columns.  `trunk` (a Trunk): the hidden layers
-    run fused -- only the encoding, the last layer's row-major copy for the heads and (save=True) the fragment-layout
-    activations exist; otherwise one row-major buffer per layer (the dense-layer launches and the tangent stream)."""
+    """Activation buffers for n samples: row-major [n_pad][ld], zero padding columns.  `fused` (a FusedField): the field runs
+    as one launch -- only the encodings, the outputs and (save=True) the fragment-layout activations exist; otherwise one
+    row-major buffer per layer (the dense-layer launches: exact-f32 mode, tangent stream)."""
 
-    def __init__(self, n: int, dev, C: int, full: bool, backward: bool, trunk: Optional[Trunk] = None, save: bool = False):
+    def __init__(self, n: int, dev, C: int, full: bool, backward: bool, fused: Optional[FusedField] = None, save: bool = False):
         self.n, self.n_pad = n, (n + 31) // 32 * 32
         # no pre-zeroing: every kernel writes all rows < n_pad of its output columns and the encoder writes the
         # zero padding columns; rows >= n only ever feed their own (discarded) output rows
         z = lambda ld: torch.empty(self.n_pad, ld, device=dev, dtype=torch.float32)
         self.enc = z(64)
-        self.trunk = trunk
-        if trunk is None:
-            self.cat = z(320)                               # [h4 (256) | enc (63) | 0]
-            self.h = {i: (None if i == SKIP else z(WIDTH)) for i in range(DEPTH)}
-        else:
-            self.cat = None
-            self.h = {DEPTH - 1: z(WIDTH)}
-            self.saved = trunk.new_saved(n) if save else None
+        self.fused = fused
         self.sel = torch.zeros(self.n_pad, device=dev, dtype=torch.uint8)
+        if fused is not None:
+            self.cat = None
+            self.sigma = torch.empty(self.n_pad, device=dev, dtype=torch.float32)
+            self.saved = fused.new_saved(n) if save else None
+            if full:
+                self.view, self.rgb4 = z(32), z(4)
+            return
+        self.cat = z(320)                                   # [h4 (256) | enc (63) | 0]
+        self.h = {i: (None if i == SKIP else z(WIDTH)) for i in range(DEPTH)}
         self.s4 = z(4)
         if full:
             self.rin = z(288)                               # [bottleneck (256) | view enc (27) | 0]
@@ -177,16 +182,16 @@ class VanillaRenderer(Renderer):
         self._reuse_prepass_feat = False            # frequency encoding: nothing worth carrying over
         self.n_splits = n_splits
         self._dw_ws = None
-        self._trunks = {}
-        self.fused_trunk = True                     # csrc/ren_trunk.hip for the eight hidden layers (matrix-core modes)
+        self._fused_fields = {}
+        self.fused_field = True                     # csrc/ren_vfield.hip: the field as one launch per pass (matrix-core modes)
         # HIP-event timing per kernel family when ops.profile_start() is active (bench.py)
         self._fwd = ops._wrap("dense_fwd", self._fwd)
         self._bwd_data = ops._wrap("dense_bwd_data", self._bwd_data)
         self._bwd_weight = ops._wrap("dense_bwd_weight", self._bwd_weight)
         self._encode = ops._wrap("freq_encode", self._encode)
-        self._trunk_fwd = ops._wrap("trunk_fwd", self._trunk_fwd)
-        self._trunk_bwd = ops._wrap("trunk_bwd", self._trunk_bwd)
-        self._trunk_dw = ops._wrap("trunk_bwd_weight", self._trunk_dw)
+        self._fused_fwd = ops._wrap("vfield_fwd", self._fused_fwd)
+        self._fused_bwd = ops._wrap("vfield_bwd", self._fused_bwd)
+        self._fused_dw = ops._wrap("vfield_bwd_weight", self._fused_dw)
 
     def dp_early_slice(self):
         return None                                 # no hash table: the 2.4 MB of dense weights go in the one packed all-reduce
@@ -199,27 +204,27 @@ class VanillaRenderer(Renderer):
             return 1
         return 6 if self.cfg.mlp_kernels == "x" else 0
 
-    def _fused(self) -> Optional[Trunk]:
-        """the fused-trunk object of the current matrix-core mode with a weight image of the CURRENT parameters, or None
-        (exact-f32 mode / fused_trunk off).  Called once per field evaluation: the image is 9 us to rebuild, which is cheaper
+    def _fused(self) -> Optional[FusedField]:
+        """the fused-field object of the current matrix-core mode with a weight image of the CURRENT parameters, or None
+        (exact-f32 mode / fused_field off).  Called once per field evaluation: the image is 9 us to rebuild, which is cheaper
         than tracking every place the flat parameter buffer can change (Adam, load, tests)."""
         mode = self._dense_mode()
-        if not self.fused_trunk or mode == 0:
+        if not self.fused_field or mode == 0:
             return None
-        tr = self._trunks.get(mode)
-        if tr is None:
-            tr = self._trunks[mode] = Trunk(self.field, mode, self.n_splits)
-        tr.prep()
-        return tr
+        ff = self._fused_fields.get(mode)
+        if ff is None:
+            ff = self._fused_fields[mode] = FusedField(self.field, mode, self.n_splits)
+        ff.prep()
+        return ff
 
-    def _trunk_fwd(self, tr, B):
-        tr.forward(B.enc, B.n, B.saved, B.h[DEPTH - 1])
+    def _fused_fwd(self, B, full):
+        B.fused.forward(B, full)
 
-    def _trunk_bwd(self, tr, dz7, B, dz):
-        tr.backward(dz7, B.n, B.saved, dz)
+    def _fused_bwd(self, dz_rgb, dz_sig, B, dz):
+        B.fused.backward(dz_rgb, dz_sig, B, dz)
 
-    def _trunk_dw(self, tr, dz, B):
-        tr.backward_weight(dz, B.saved, B.enc, B.n)
+    def _fused_dw(self, dz_rgb, dz_sig, B, dz):
+        B.fused.backward_weight(dz_rgb, dz_sig, B, dz)
 
     def _fwd(self, X, ldx, name, act, Y, ldy, n, sel=None):
         f = self.field
@@ -252,24 +257,29 @@ class VanillaRenderer(Renderer):
         ri, ts, te = samples if samples is not None else (None, None, None)
         check(_lib.load().ren_freq_encode(ctypes.byref(self.scene), _ptr(x_world), _ptr(dirs), _ptr(o), _ptr(d),
                                           _ptr(ri, torch.int32), _ptr(ts), _ptr(te), n, _ptr(B.enc), 64,
-                                          _ptr(B.cat) if B.cat is not None else None, 320,
-                                          256, _ptr(B.rin) if full else None, 288, 256, _ptr(B.sel, torch.uint8), _stream()),
+                                          _ptr(B.cat) if B.cat is not None else None, 320, 256,
+                                          (_ptr(B.view) if B.fused is not None else _ptr(B.rin)) if full else None,
+                                          32 if B.fused is not None else 288, 0 if B.fused is not None else 256,
+                                          _ptr(B.sel, torch.uint8), _stream()),
               "ren_freq_encode")
 
     def _trunk(self, B: _Buffers):
         n = B.n
-        if B.trunk is not None:
-            self._trunk_fwd(B.trunk, B)
-        else:
-            X, ldx = B.enc, 64
-            for i in range(DEPTH):                                         # mlp.py:99-113
-                Y, ldy = B.out_of(i)
-                self._fwd(X, ldx, f"mlp.base.hidden_layers.{i}", ACT_SOFTPLUS100, Y, ldy, n)
-                X, ldx = Y, ldy
+        if B.fused is not None:
+            self._fused_fwd(B, False)
+            return B.sigma[:n]
+        X, ldx = B.enc, 64
+        for i in range(DEPTH):                                             # mlp.py:99-113
+            Y, ldy = B.out_of(i)
+            self._fwd(X, ldx, f"mlp.base.hidden_layers.{i}", ACT_SOFTPLUS100, Y, ldy, n)
+            X, ldx = Y, ldy
         self._fwd(B.h[DEPTH - 1], WIDTH, "mlp.sigma_layer.output_layer", ACT_TRUNC_EXP_SEL, B.s4, 4, n, sel=B.sel)
         return B.s4[:n, 0].contiguous()
 
     def _field_eval(self, B: _Buffers, full: bool):
+        if B.fused is not None and full:
+            self._fused_fwd(B, True)
+            return B.rgb4[:B.n, :self.field.C].contiguous(), B.sigma[:B.n]
         sigma = self._trunk(B)
         if not full:
             return None, sigma
@@ -286,21 +296,21 @@ class VanillaRenderer(Renderer):
         them (the rendered-sample budget of the dynamic batch size does not bound the marched count)"""
         tr = self._fused()
         if n <= chunk:
-            B = _Buffers(n, o.device, self.field.C, full=False, backward=False, trunk=tr)
+            B = _Buffers(n, o.device, self.field.C, full=False, backward=False, fused=tr)
             self._encode(B, False, rays=(o, d), samples=samples)
             return self._trunk(B)
         ri, ts, te = samples
         out = torch.empty(n, device=o.device, dtype=torch.float32)
         for s0 in range(0, n, chunk):
             e0 = min(s0 + chunk, n)
-            B = _Buffers(e0 - s0, o.device, self.field.C, full=False, backward=False, trunk=tr)
+            B = _Buffers(e0 - s0, o.device, self.field.C, full=False, backward=False, fused=tr)
             self._encode(B, False, rays=(o, d), samples=(ri[s0:e0], ts[s0:e0], te[s0:e0]))
             out[s0:e0] = self._trunk(B)
             del B
         return out
 
     def _field_forward(self, o, d, pk, save):
-        B = _Buffers(pk.n, o.device, self.field.C, full=True, backward=False, trunk=self._fused(), save=save)
+        B = _Buffers(pk.n, o.device, self.field.C, full=True, backward=False, fused=self._fused(), save=save)
         self._encode(B, True, rays=(o, d), samples=(pk.ray_indices, pk.t_starts, pk.t_ends))
         rgb, sigma = self._field_eval(B, True)
         return rgb, sigma, dict(buffers=B if save else None)
@@ -309,10 +319,16 @@ class VanillaRenderer(Renderer):
         B, n, C = ctx["buffers"], ctx["pk"].n, self.field.C
         dev = d_rgb.device
         z = lambda ld: torch.empty(B.n_pad, ld, device=dev, dtype=torch.float32)
-        dz_rgb, dz_sig, dr, db, dh = z(32), z(32), z(WIDTH_COND), z(WIDTH), [z(WIDTH), z(WIDTH)]
+        dz_rgb, dz_sig = z(32), z(32)
         check(_lib.load().ren_vanilla_heads_bwd(_ptr(d_rgb.contiguous()), _ptr(ctx["rgb"]), _ptr(d_sig.contiguous()),
                                                 _ptr(ctx["sigma"]), n, C, _ptr(dz_rgb), _ptr(dz_sig), _stream()),
               "ren_vanilla_heads_bwd")
+        if B.fused is not None:
+            dz = B.fused.new_saved(n)
+            self._fused_bwd(dz_rgb, dz_sig, B, dz)
+            self._fused_dw(dz_rgb, dz_sig, B, dz)
+            return
+        dr, db, dh = z(WIDTH_COND), z(WIDTH), [z(WIDTH), z(WIDTH)]
         h7 = B.h[DEPTH - 1]
         # colour head: 128 -> C, [bottleneck | view] -> 128, bottleneck 256 -> 256 (no activation)
         self._bwd_weight(dz_rgb, 32, B.r, WIDTH_COND, "mlp.rgb_layer.output_layer", n)
@@ -325,11 +341,6 @@ class VanillaRenderer(Renderer):
         # sigma layer joins at h7; its data gradient is accumulated, then the trunk activation derivative applied
         self._bwd_weight(dz_sig, 32, h7, WIDTH, "mlp.sigma_layer.output_layer", n)
         self._bwd_data(dz_sig, 32, "mlp.sigma_layer.output_layer", WIDTH, ACT_SOFTPLUS100, h7, WIDTH, True, dh[0], WIDTH, n)
-        if B.trunk is not None:                             # dh[0] = d loss / d (pre-activation of layer 7), row-major
-            dz = B.trunk.new_saved(n)
-            self._trunk_bwd(B.trunk, dh[0], B, dz)
-            self._trunk_dw(B.trunk, dz, B)
-            return
         cur = 0
         for i in range(DEPTH - 1, -1, -1):
             name = f"mlp.base.hidden_layers.{i}"
@@ -502,7 +513,7 @@ class VanillaRenderer(Renderer):
         out = torch.empty(n, device=x_world.device, dtype=torch.float32)     # trunk activations per point, so in pieces
         for s0 in range(0, n, chunk):
             xs = x_world[s0: s0 + chunk].contiguous()
-            B = _Buffers(xs.shape[0], x_world.device, self.field.C, full=False, backward=False, trunk=tr)
+            B = _Buffers(xs.shape[0], x_world.device, self.field.C, full=False, backward=False, fused=tr)
             self._encode(B, False, x_world=xs)
             out[s0: s0 + chunk] = self._trunk(B)
             del B
@@ -511,7 +522,7 @@ class VanillaRenderer(Renderer):
     def query(self, x_world: torch.Tensor, dirs: torch.Tensor):
         """field(x, d) -> (rgb (n, C), sigma (n,), buffers) for free-standing points (mlp.py:349-358)."""
         n = x_world.shape[0]
-        B = _Buffers(n, x_world.device, self.field.C, full=True, backward=False, trunk=self._fused(), save=True)
+        B = _Buffers(n, x_world.device, self.field.C, full=True, backward=False, fused=self._fused(), save=True)
         self._encode(B, True, x_world=x_world.contiguous(), dirs=dirs.contiguous())
         rgb, sigma = self._field_eval(B, True)
         return rgb, sigma, B
