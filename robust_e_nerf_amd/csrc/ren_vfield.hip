@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256, 1) void vfield_fwd_kernel(FieldArgs a) {
     unsigned char *smem_tf = smem_all + LB_FLOATS * 4;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int hi = lane >> 5, sl = lane & 31;
-    const uint32_t lane16 = lane * 16;
+    const uint32_t lane16_k = lane * 16;
     for (int i = threadIdx.x; i < LB_FLOATS; i += 256) {
         float b = 0.f;
         if (i < 2048) b = a.P[l_boff(i >> 8, a.C) + (i & 255)];
@@ -217,19 +217,19 @@ __global__ __launch_bounds__(256, 1) void vfield_fwd_kernel(FieldArgs a) {
         unsigned char *dst = smem_tf + buf * STAGE + wave * 1024;
         for (int i = wave; i < pieces; i += 4) {
             asm volatile("" : "+s"(off));
-            glds16(reinterpret_cast<const unsigned char *>(a.img) + off + lane16, dst);
+            glds16(reinterpret_cast<const unsigned char *>(a.img) + off + lane16_k, dst);
             off += 4096; dst += 4096;
         }
     };
     int buf = 0;
     if ((int64_t)blockIdx.x < n_grp) issue(0, 0, 0);
     for (int64_t grp = blockIdx.x; grp < n_grp; grp += gridDim.x) {
-        const int64_t blk0 = (grp * 4 + wave) * NB;
+        const int64_t blk0_g = (grp * 4 + wave) * NB;
         const bool more_grp = grp + gridDim.x < n_grp;
         bf16x8 x[NB][NP][16];
         // encoding operands; rows of blocks past the end are clamped to the last block (their results are never stored
         // row-major, and the fragment-layout buffers are whole groups)
-        auto load_rows = [&](const float *src, int ld, int nchunks, bf16x8 (&e)[NB][NP][4]) {
+        auto load_rows = [&](const float *src, int ld, int nchunks, bf16x8 (&e)[NB][NP][4], int64_t blk0, int sl, int hi) {
 #pragma unroll
             for (int u = 0; u < NB; ++u) {
                 const int64_t blk = blk0 + u < n_blk ? blk0 + u : n_blk - 1;
@@ -251,9 +251,15 @@ __global__ __launch_bounds__(256, 1) void vfield_fwd_kernel(FieldArgs a) {
             using S = decltype(shape);
             constexpr int NH = S::NH, NE = S::NE, NT = S::NT, ACT = S::ACT, nch = NH + NE;
             constexpr int NTG = (NT + NTS - 1) / NTS;
+            // opaque per-layer copies of the lane offset and block index: everything addressed through them is computed
+            // inside the layer instead of once per kernel / group for all six layer shapes (which spilled ~300 registers)
+            uint32_t lane16 = lane16_k;
+            int64_t blk0 = blk0_g;
+            asm volatile("" : "+v"(lane16), "+s"(blk0));
+            const int lane = lane16 >> 4, hi = lane >> 5, sl = lane & 31;
             bf16x8 e[NB][NP][4];
-            if (NE == 4) load_rows(a.enc, a.ld_enc, 4, e);
-            if (NE == 2) load_rows(a.view, a.ld_view, 2, e);
+            if (NE == 4) load_rows(a.enc, a.ld_enc, 4, e, blk0, sl, hi);
+            if (NE == 2) load_rows(a.view, a.ld_view, 2, e, blk0, sl, hi);
             f32x16 acc[NB][NT];
 #pragma unroll
             for (int tg = 0; tg < NTG; ++tg) {
@@ -368,7 +374,7 @@ __global__ __launch_bounds__(256, 1) void vfield_bwd_kernel(FieldArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_tb[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int hi = lane >> 5, sl = lane & 31;
-    const uint32_t lane16 = lane * 16;
+    const uint32_t lane16_k = lane * 16;
     const int64_t n_blk = (a.n + 31) >> 5, n_grp = (n_blk + 4 * NB - 1) / (4 * NB);
     const size_t sstride = (size_t)n_grp * 4 * NB * 32 * 256;                // whole groups: stores need no bounds
 
@@ -378,19 +384,19 @@ __global__ __launch_bounds__(256, 1) void vfield_bwd_kernel(FieldArgs a) {
         unsigned char *dst = smem_tb + buf * STAGE + wave * 1024;
         for (int i = wave; i < pieces; i += 4) {
             asm volatile("" : "+s"(off));
-            glds16(reinterpret_cast<const unsigned char *>(a.img) + off + lane16, dst);
+            glds16(reinterpret_cast<const unsigned char *>(a.img) + off + lane16_k, dst);
             off += 4096; dst += 4096;
         }
     };
     int buf = 0;
     if ((int64_t)blockIdx.x < n_grp) issue(L_RGBO, 0, 0);
     for (int64_t grp = blockIdx.x; grp < n_grp; grp += gridDim.x) {
-        const int64_t blk0 = (grp * 4 + wave) * NB;
+        const int64_t blk0_g = (grp * 4 + wave) * NB;
         const bool more_grp = grp + gridDim.x < n_grp;
         bf16x8 x[NB][NP][16];
         // one extra operand chunk from a row-major [n_pad][32] gradient buffer: columns 8 hi .. 8 hi + 7 (step 11: dz_rgb),
         // or k-slot 0 only (step 9: dz_sigma, column 0)
-        auto load_extra = [&](const float *src, bool slot0, bf16x8 (&e)[NB][NP]) {
+        auto load_extra = [&](const float *src, bool slot0, bf16x8 (&e)[NB][NP], int64_t blk0, int sl, int hi) {
 #pragma unroll
             for (int u = 0; u < NB; ++u) {
                 const int64_t blk = blk0 + u < n_blk ? blk0 + u : n_blk - 1;
@@ -417,6 +423,10 @@ __global__ __launch_bounds__(256, 1) void vfield_bwd_kernel(FieldArgs a) {
             constexpr int NH = S::NH, NE = S::NE, NT = S::NT, nch = NH + NE;
             constexpr bool DERIV = S::DERIV;
             constexpr int NTG = (NT + NTS - 1) / NTS;
+            uint32_t lane16 = lane16_k;                  // opaque per-step copies: see vfield_fwd_kernel
+            int64_t blk0 = blk0_g;
+            asm volatile("" : "+v"(lane16), "+s"(blk0));
+            const int lane = lane16 >> 4, hi = lane >> 5, sl = lane & 31;
             const ST *hs = reinterpret_cast<const ST *>(a.acts) + (size_t)(DERIV ? hslot : 0) * sstride;
             uint4 hpre[PD][HV];
             auto load_h = [&](int i, uint4 (&dst)[HV]) {                                           // i = u * NT + t
@@ -428,7 +438,7 @@ __global__ __launch_bounds__(256, 1) void vfield_bwd_kernel(FieldArgs a) {
                 for (int q = 0; q < HV; ++q) dst[q] = p[q * 64];
             };
             bf16x8 e[NB][NP];
-            if (NE) load_extra(extra, l == L_BOTT, e);
+            if (NE) load_extra(extra, l == L_BOTT, e, blk0, sl, hi);
             f32x16 acc[NB][NT];
 #pragma unroll
             for (int tg = 0; tg < NTG; ++tg) {

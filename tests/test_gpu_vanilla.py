@@ -2,6 +2,7 @@
 VanillaNeRFRadianceField (golden) and vs the CPU oracle; end-to-end training step through the shared
 sampling / compositing / loss path."""
 import math
+import os
 import types
 
 import numpy as np
@@ -321,3 +322,82 @@ def test_vanilla_grad_loss_step_with_trainable_tau_vs_reference_golden(amd):
     assert rel_err(got, ref) < 1e-2, (float(got), float(ref))
     tr.optimizer_step()
     assert float(tr.tau_grad) == 0.0
+
+
+def _vfield_tool():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("vfield_check", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                               "tools", "vfield_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("mode,C,n", [(6, 1, 4133), (6, 3, 1000), (1, 1, 4133)])
+def test_fused_field_kernels_vs_float64_model(amd, mode, C, n):
+    """csrc/ren_vfield.hip (the whole field as one launch per pass) against a float64 torch model of the twelve layers
+    (mlp.py:26-205): outputs, every saved activation, every pre-activation gradient and every weight / bias gradient.
+    fp32 mode (three-piece split): fp32 round-off; bf16 mode: bf16 operand rounding.  n is not a multiple of the 32-sample
+    block nor of a workgroup pass: the padded rows must not leak into the weight gradients."""
+    ops, engine, vanilla = amd
+    ref = _vfield_tool().reference
+    torch.manual_seed(1)
+    fld = vanilla.VanillaField(DEV, C)
+    for name, o, i in fld.layers:
+        k = 1.0 / i ** 0.5
+        fld.w[name].uniform_(-k, k)
+        fld.b[name].uniform_(-k, k)
+    ff = vanilla.FusedField(fld, mode)
+    ff.prep()
+    B = vanilla._Buffers(n, DEV, C, full=True, backward=False, fused=ff, save=True)
+    B.enc.zero_(); B.view.zero_()                                    # rows n .. n_pad: zero, as the encoder leaves them
+    B.enc[:n, :63] = torch.rand(n, 63, device=DEV) * 2 - 1
+    B.view[:n, :27] = torch.rand(n, 27, device=DEV) * 2 - 1
+    B.sel[:n] = (torch.rand(n, device=DEV) < 0.8).to(torch.uint8)
+    ff.forward(B, True)
+    R = ref(fld, B.enc, B.view, B.sel, n)
+    rel = lambda got, want: float((got.double() - want.detach()).abs().max() / want.detach().abs().max())
+    t_out, t_dz, t_dw = (2e-6, 6e-6, 1.5e-5) if mode == 6 else (3e-3, 6e-2, 4e-2)
+    assert rel(B.sigma[:n], R["sigma"]) < t_out and rel(B.rgb4[:n, :C], R["rgb"]) < t_out
+    assert C == 4 or float(B.rgb4[:n, C:].abs().max()) == 0.0
+    acts = ff.decode(B.saved, n)
+    for l in range(8):
+        assert rel(acts[l], R["hs"][l]) < max(t_out, 8e-3 if mode == 1 else 0), l        # bf16 storage: 2^-8 relative
+    only = vanilla._Buffers(n, DEV, C, full=False, backward=False, fused=ff)
+    only.enc.copy_(B.enc); only.sel.copy_(B.sel)
+    ff.forward(only, False)
+    assert torch.equal(only.sigma[:n], B.sigma[:n]), "density-only launch"
+    dz_rgb, dz_sig = torch.zeros(B.n_pad, 32, device=DEV), torch.zeros(B.n_pad, 32, device=DEV)
+    dz_rgb[:n, :C] = torch.randn(n, C, device=DEV)
+    dz_sig[:n, 0] = torch.randn(n, device=DEV)
+    ((R["zo"] * dz_rgb[:n, :C].double()).sum() + (R["zsig"][:, 0] * dz_sig[:n, 0].double()).sum()).backward()
+    dz = ff.new_saved(n)
+    ff.backward(dz_rgb, dz_sig, B, dz)
+    dzr = ff.decode(dz, n)
+    for l in range(8):
+        assert rel(dzr[l], R["zs"][l].grad) < t_dz, ("dz", l)
+    assert rel(dzr[8], R["bott"].grad) < t_dz and rel(dzr[9][:, :128], R["zr"].grad) < t_dz
+    fld.grad.zero_()
+    ff.backward_weight(dz_rgb, dz_sig, B, dz)
+    for i, k in enumerate(R["names"]):
+        assert rel(fld.gw[k], R["W"][i].grad) < t_dw, ("dW", k)
+        assert rel(fld.gb[k], R["B"][i].grad) < t_dw, ("db", k)
+
+
+def test_fused_field_equals_dense_layer_path(amd):
+    """VanillaRenderer with the fused field (default) and with one dense-layer launch per Linear (fused_field = False: the
+    path the exact-f32 mode and the tangent stream keep) agree to fp32 round-off, outputs and parameter gradients."""
+    ops, engine, vanilla = amd
+    g = load_golden("field_mlp_aabb")
+    res = {}
+    for fused in (True, False):
+        r, _ = _field(vanilla, engine, g)
+        r.fused_field = fused
+        x, d = t(g["x"]).to(DEV).contiguous(), t(g["d"]).to(DEV).contiguous()
+        rgb, sigma, B = r.query(x, d)
+        assert (B.fused is not None) == fused
+        ctx = dict(buffers=B, pk=types.SimpleNamespace(n=x.shape[0]), rgb=rgb, sigma=sigma)
+        r._field_backward(ctx, t(g["g_rgb"]).to(DEV).contiguous(), t(g["g_sigma"])[:, 0].to(DEV).contiguous())
+        res[fused] = (rgb.clone(), sigma.clone(), r.field.grad.clone(), r.query_density(x).clone())
+    for a, b, tol in zip(res[True], res[False], (2e-6, 2e-6, 2e-5, 2e-6)):
+        assert rel_err(a, b) < tol, (rel_err(a, b), tol)
