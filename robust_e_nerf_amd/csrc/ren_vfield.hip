@@ -172,6 +172,7 @@ __device__ __forceinline__ void store_tile(void *base, int64_t blk, int t, int l
 // A layer shape is a compile-time type: a run-time `if` around a group of MFMAs makes the compiler copy whole accumulator
 // tuples between AGPRs at the join (a first version spent 30 % of its VALU issue on such copies).
 constexpr int A_SP100 = 0, A_NONE = 1, A_SIGMA = 2, A_RGB = 3;
+template <int I> struct IntC { static constexpr int value = I; };
 template <int NH_, int NE_, int NT_, int ACT_> struct Shape { static constexpr int NH = NH_, NE = NE_, NT = NT_, ACT = ACT_; };
 // scheduling fence between the MFMA stages and between the epilogue tiles
 #define TRUNK_FENCE() __builtin_amdgcn_sched_barrier(0)
@@ -531,108 +532,122 @@ __global__ __launch_bounds__(256, 1) void vfield_bwd_kernel(FieldArgs a) {
 // tiles per K group.  Narrow layers (sigma: 1 output, colour output: C) take dz from the row-major [n_pad][32] buffers.
 constexpr int TDW_ST = 40;
 struct FieldDwArgs {
-    const void *dz; int nz;                              // fragment slot with nz (256 / 128) features, or ..
-    const float *dz_rows;                                // .. row-major [n_pad][32] (nz = 32)
-    const void *x; int nx;                               // K group 0: fragment slot with nx features (0: none)
-    const float *x_rows; int ld_rows, n_rows;            // last K group: row-major encoding columns (n_rows 64 / 32; 0: none)
+    const void *dz;                                      // fragment slot (256-feature stride; nz valid features), or ..
+    const float *dz_rows;                                // .. row-major [n_pad][32]
+    const void *x; int nx;                               // fragment slot with nx valid features
+    const float *x_rows; int ld_rows, n_rows;            // row-major encoding columns (n_rows 64 / 32)
     int N, K;                                            // torch out / in features
     int64_t n;
     float *slab_w, *slab_b;                              // [n_splits][N][K], [n_splits][N]
 };
 
-template <int MODE>
+// ZROWS: dz from the row-major buffer (narrow layers); XFRAG / XROWS: the input has a fragment-slot part / a row-major
+// encoding part (both: [slot | encoding], the skip layer and the colour hidden layer).  All compile-time: the loads of a stage
+// are unconditional straight-line code, so the compiler counts them (`s_waitcnt vmcnt(N)`) and two stages stay in flight --
+// with a run-time `if` around them every use waited for vmcnt(0), i.e. for the stage issued last (3.3 TB/s, latency-bound).
+template <int MODE, bool ZROWS, bool XFRAG, bool XROWS>
 __global__ __launch_bounds__(512, 1) void vfield_dw_kernel(FieldDwArgs a) {
     typedef typename TC<MODE>::ST ST;
     constexpr int NP = TC<MODE>::NP;
     constexpr int NV = MODE == 1 ? 2 : 4;                // 16-byte pieces per thread and operand per stage (256 features)
     constexpr int FPP = MODE == 1 ? 8 : 4;               // features per piece and lane
+    constexpr bool ONEPASS = MODE == 1 || !(XFRAG && XROWS);      // fp32 mode: [slot | encoding] inputs in two passes (registers)
+    constexpr int NACC = (XFRAG && XROWS && ONEPASS) ? 10 : 8;
+    constexpr int XROWS_T = NACC == 10 ? 320 : 256;      // feature rows of the transposed input tile
+    using PRD = Pairs<MODE>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_td[];
     __bf16 *ZT = reinterpret_cast<__bf16 *>(smem_td), *XT = ZT + NP * 256 * TDW_ST;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int hi = lane >> 5, sl = lane & 31;
+    const int wave_k = threadIdx.x >> 6;
     const int n_splits = gridDim.x;
     const int64_t n_blk = (a.n + 31) >> 5;
-    const int k_groups = (a.nx ? 1 : 0) + (a.n_rows ? 1 : 0);
-    const bool has_tile = wave * 32 < a.N;
+    const bool has_tile = wave_k * 32 < a.N;
     float *sw = a.slab_w + (int64_t)blockIdx.x * a.N * a.K, *sb = a.slab_b + (int64_t)blockIdx.x * a.N;
-    for (int kg = 0; kg < k_groups; ++kg) {
-        const bool x_rows = kg == k_groups - 1 && a.n_rows;       // this K group: the row-major encoding
-        const int kt = x_rows ? a.n_rows / 32 : a.nx / 32, k0 = (kg == 1) ? a.nx : 0;
-        f32x16 acc[8];
+    constexpr int PASSES = ONEPASS ? 1 : 2;
+    for (int pass = 0; pass < PASSES; ++pass) {
+        const bool use_frag = XFRAG && (ONEPASS || pass == 0), use_rows = XROWS && (ONEPASS || pass == PASSES - 1);
+        const int kt_frag = use_frag ? a.nx / 32 : 0, kt = kt_frag + (use_rows ? a.n_rows / 32 : 0);
+        const int k0 = (!ONEPASS && pass == 1) ? a.nx : 0;                 // first input column of this pass
+        const int rows_at = ONEPASS ? (XFRAG ? 256 : 0) : 0;               // XT row of the encoding part
+        f32x16 acc[NACC];
 #pragma unroll
-        for (int t = 0; t < 8; ++t)
+        for (int t = 0; t < NACC; ++t)
 #pragma unroll
             for (int g = 0; g < 16; ++g) acc[t][g] = 0.f;
-        float bsum[NV * FPP];
+        float bsum[ZROWS ? 4 : NV * FPP];
 #pragma unroll
-        for (int q = 0; q < NV * FPP; ++q) bsum[q] = 0.f;
-        uint4 pz[NV], px[NV];
-        float4 pe, pzr;
-        auto fetch = [&](int64_t blk) {
+        for (int q = 0; q < (ZROWS ? 4 : NV * FPP); ++q) bsum[q] = 0.f;
+        struct Stage { uint4 pz[NV], px[NV]; float4 pe, pzr; };
+        Stage sq[2];                                     // two stages in flight
+        // `tid`: an opaque copy of threadIdx.x (see `stage`): the ~40 LDS / global addresses derived from it are computed per
+        // stage instead of once per kernel (where they spilled)
+        auto fetch = [&](int tid, int64_t blk, Stage &q) {
+            const int lane = tid & 63, wave = tid >> 6;
             const uint4 *zb = reinterpret_cast<const uint4 *>(reinterpret_cast<const ST *>(a.dz) + blk * 32 * 256);
             const uint4 *xb = reinterpret_cast<const uint4 *>(reinterpret_cast<const ST *>(a.x) + blk * 32 * 256);
 #pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                const int piece = wave * NV + v;
-                if (!a.dz_rows && piece * FPP * 2 < a.nz) pz[v] = zb[piece * 64 + lane];
-                if (!x_rows && piece * FPP * 2 < a.nx) px[v] = xb[piece * 64 + lane];
+            for (int v = 0; v < NV; ++v) {               // (slots have the full 256-feature stride: pieces past nz / nx are
+                const int piece = wave * NV + v;         //  valid memory whose values land in unused rows)
+                if (!ZROWS) q.pz[v] = zb[piece * 64 + lane];
+                if (XFRAG) q.px[v] = xb[piece * 64 + lane];
             }
-            const int s = threadIdx.x & 31, f0 = 4 * (threadIdx.x >> 5);
-            if (x_rows && f0 < a.n_rows) pe = *reinterpret_cast<const float4 *>(a.x_rows + (blk * 32 + s) * a.ld_rows + f0);
-            if (a.dz_rows && f0 < 32) pzr = *reinterpret_cast<const float4 *>(a.dz_rows + (blk * 32 + s) * 32 + f0);
+            const int s = tid & 31, f0 = 4 * (tid >> 5);
+            if (XROWS) q.pe = *reinterpret_cast<const float4 *>(a.x_rows + (blk * 32 + s) * a.ld_rows + (f0 & (a.n_rows - 1)));
+            if (ZROWS) q.pzr = *reinterpret_cast<const float4 *>(a.dz_rows + (blk * 32 + s) * 32 + (f0 & 31));
         };
-        auto put = [&](__bf16 *T, int f, int s, float v) {
+        auto put = [&](__bf16 *T, int rows, int f, int s, float v) {
             __bf16 sp[3];
             split<NP>(v, sp);
 #pragma unroll
-            for (int p = 0; p < NP; ++p) T[(p * 256 + f) * TDW_ST + s] = sp[p];
+            for (int p = 0; p < NP; ++p) T[(p * rows + f) * TDW_ST + s] = sp[p];
         };
-        auto stash = [&](int64_t blk) {
+        auto stash = [&](int tid, int64_t blk, const Stage &q) {
+            const int lane = tid & 63, wave = tid >> 6, hi = lane >> 5, sl = lane & 31;
             const bool live = blk * 32 + sl < a.n;       // samples past the end contribute nothing
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 const int piece = wave * NV + v;
-                const bool zin = !a.dz_rows && piece * FPP * 2 < a.nz, xin = !x_rows && piece * FPP * 2 < a.nx;
                 if (MODE == 1) {                         // piece = chunk c: features kmap(c, hi, j)
-                    const bf16x8 z8 = *reinterpret_cast<const bf16x8 *>(&pz[v]), x8 = *reinterpret_cast<const bf16x8 *>(&px[v]);
+                    const bf16x8 z8 = *reinterpret_cast<const bf16x8 *>(&q.pz[v]), x8 = *reinterpret_cast<const bf16x8 *>(&q.px[v]);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const int f = kmap(piece, hi, j);
-                        if (zin) { ZT[f * TDW_ST + sl] = live ? z8[j] : (__bf16)0.f; bsum[8 * v + j] += live ? (float)z8[j] : 0.f; }
-                        if (xin) XT[f * TDW_ST + sl] = live ? x8[j] : (__bf16)0.f;
+                        if (!ZROWS) { ZT[f * TDW_ST + sl] = live ? z8[j] : (__bf16)0.f; bsum[8 * v + j] += live ? (float)z8[j] : 0.f; }
+                        if (use_frag) XT[f * TDW_ST + sl] = live ? x8[j] : (__bf16)0.f;
                     }
                 } else {                                 // piece = (t, q): features 32 t + 8 q + 4 hi + j
-                    const float4 z4 = *reinterpret_cast<const float4 *>(&pz[v]), x4 = *reinterpret_cast<const float4 *>(&px[v]);
+                    const float4 z4 = *reinterpret_cast<const float4 *>(&q.pz[v]), x4 = *reinterpret_cast<const float4 *>(&q.px[v]);
                     const float z[4] = {z4.x, z4.y, z4.z, z4.w}, xx[4] = {x4.x, x4.y, x4.z, x4.w};
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int f = 8 * piece + 4 * hi + j;
-                        if (zin) { put(ZT, f, sl, live ? z[j] : 0.f); bsum[4 * v + j] += live ? z[j] : 0.f; }
-                        if (xin) put(XT, f, sl, live ? xx[j] : 0.f);
+                        if (!ZROWS) { put(ZT, 256, f, sl, live ? z[j] : 0.f); bsum[4 * v + j] += live ? z[j] : 0.f; }
+                        if (use_frag) put(XT, XROWS_T, f, sl, live ? xx[j] : 0.f);
                     }
                 }
             }
-            const int s = threadIdx.x & 31, f0 = 4 * (threadIdx.x >> 5);
+            const int s = tid & 31, f0 = 4 * (tid >> 5);
             const bool lives = blk * 32 + s < a.n;
-            if (x_rows && f0 < a.n_rows) {               // thread -> (sample tid & 31, features 4 (tid >> 5) ..)
-                const float ev[4] = {pe.x, pe.y, pe.z, pe.w};
+            if (use_rows && f0 < a.n_rows) {             // thread -> (sample tid & 31, features 4 (tid >> 5) ..)
+                const float ev[4] = {q.pe.x, q.pe.y, q.pe.z, q.pe.w};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) put(XT, f0 + j, s, lives ? ev[j] : 0.f);
+                for (int j = 0; j < 4; ++j) put(XT, XROWS_T, rows_at + f0 + j, s, lives ? ev[j] : 0.f);
             }
-            if (a.dz_rows && f0 < 32) {
-                const float zv[4] = {pzr.x, pzr.y, pzr.z, pzr.w};
+            if (ZROWS && f0 < 32) {
+                const float zv[4] = {q.pzr.x, q.pzr.y, q.pzr.z, q.pzr.w};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { put(ZT, f0 + j, s, lives ? zv[j] : 0.f); bsum[j] += lives ? zv[j] : 0.f; }
+                for (int j = 0; j < 4; ++j) { put(ZT, 256, f0 + j, s, lives ? zv[j] : 0.f); bsum[j] += lives ? zv[j] : 0.f; }
             }
         };
-        int64_t blk = blockIdx.x;
-        if (blk < n_blk) fetch(blk);
-        for (; blk < n_blk; blk += n_splits) {
+        auto stage = [&](auto slot_c, int64_t blk) {
+            constexpr int SL = decltype(slot_c)::value;
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));
             __syncthreads();
-            stash(blk);
+            stash(tid, blk, sq[SL]);
             __syncthreads();
-            const int64_t nxt = blk + n_splits;
-            if (nxt < n_blk) fetch(nxt);
+            const int64_t nxt = blk + 2 * (int64_t)n_splits;
+            fetch(tid, nxt < n_blk ? nxt : n_blk - 1, sq[SL]);         // unconditional (past the end: the last block, unused)
+            const int lane = tid & 63, wave = tid >> 6, hi = lane >> 5, sl = lane & 31;
             if (has_tile) {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
@@ -641,45 +656,56 @@ __global__ __launch_bounds__(512, 1) void vfield_dw_kernel(FieldDwArgs a) {
                     for (int p = 0; p < NP; ++p)
                         az[p] = *reinterpret_cast<const bf16x8 *>(ZT + (p * 256 + wave * 32 + sl) * TDW_ST + 16 * ks + 8 * hi);
 #pragma unroll
-                    for (int t = 0; t < 8; ++t)
-                        if (t < kt) {
-                            bf16x8 bx[NP];
+                    for (int t = 0; t < NACC; t += 2)    // two input tiles at a time: consecutive MFMAs alternate accumulators
+                        if (NACC == 10 || t < kt) {
+                            bf16x8 bx[2][NP];
 #pragma unroll
-                            for (int p = 0; p < NP; ++p)
-                                bx[p] = *reinterpret_cast<const bf16x8 *>(XT + (p * 256 + t * 32 + sl) * TDW_ST + 16 * ks + 8 * hi);
-                            if (NP == 3) {
-                                acc[t] = MFMAB(az[2], bx[0], acc[t]);
-                                acc[t] = MFMAB(az[0], bx[2], acc[t]);
-                                acc[t] = MFMAB(az[1], bx[1], acc[t]);
-                                acc[t] = MFMAB(az[1], bx[0], acc[t]);
-                                acc[t] = MFMAB(az[0], bx[1], acc[t]);
+                            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                                for (int p = 0; p < NP; ++p)
+                                    bx[tt][p] = *reinterpret_cast<const bf16x8 *>(XT + (p * XROWS_T + (t + tt) * 32 + sl) * TDW_ST + 16 * ks + 8 * hi);
+#pragma unroll
+                            for (int k = 0; k < PRD::N; ++k) {
+                                acc[t] = MFMAB(az[PRD::W[k]], bx[0][PRD::A[k]], acc[t]);
+                                acc[t + 1] = MFMAB(az[PRD::W[k]], bx[1][PRD::A[k]], acc[t + 1]);       // (odd tile counts: never stored)
                             }
-                            acc[t] = MFMAB(az[0], bx[0], acc[t]);
                         }
                 }
             }
+        };
+        {
+            const int64_t b0 = blockIdx.x;
+            fetch(threadIdx.x, b0 < n_blk ? b0 : n_blk - 1, sq[0]);
+            fetch(threadIdx.x, b0 + n_splits < n_blk ? b0 + n_splits : n_blk - 1, sq[1]);
+            for (int64_t blk = b0; blk < n_blk; blk += 2 * (int64_t)n_splits) {
+                stage(IntC<0>(), blk);
+                if (blk + n_splits < n_blk) stage(IntC<1>(), blk + n_splits);
+            }
         }
+        const int lane = threadIdx.x & 63, hi = lane >> 5, sl = lane & 31;
         if (has_tile) {
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const int k = k0 + t * 32 + sl;
-                if (t >= kt || k >= a.K) continue;
+            for (int t = 0; t < NACC; ++t) {
+                // XT tile t -> input column: the fragment part first, the encoding part after it
+                const int k = NACC == 10 ? t * 32 + sl : k0 + t * 32 + sl;
+                const bool valid = NACC == 10 ? (t < 8 || (t - 8) < a.n_rows / 32) : t < kt;
+                if (!valid || k >= a.K) continue;
 #pragma unroll
                 for (int g = 0; g < 16; ++g) {
-                    const int o = wave * 32 + rowc(g) + 4 * hi;
+                    const int o = wave_k * 32 + rowc(g) + 4 * hi;
                     if (o < a.N) sw[(int64_t)o * a.K + k] = acc[t][g];
                 }
             }
         }
-        if (kg == 0) {                                   // bias gradient: sum over the 32 sample lanes
-            if (a.dz_rows) {
+        if (pass == 0) {                                 // bias gradient: sum over the 32 sample lanes
+            if (ZROWS) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float s = bsum[j];
 #pragma unroll
                     for (int off = 1; off < 32; off <<= 1) s += __shfl_xor(s, off, 64);
                     const int f = 4 * (threadIdx.x >> 5) + j;
-                    if ((threadIdx.x & 31) == 0 && f < a.N) sb[f] = s;
+                    if ((threadIdx.x & 31) == 0 && f < a.N && f < 32) sb[f] = s;
                 }
             } else {
 #pragma unroll
@@ -689,7 +715,7 @@ __global__ __launch_bounds__(512, 1) void vfield_dw_kernel(FieldDwArgs a) {
                         float s = bsum[FPP * v + j];
 #pragma unroll
                         for (int off = 1; off < 32; off <<= 1) s += __shfl_xor(s, off, 64);
-                        const int piece = wave * NV + v;
+                        const int piece = wave_k * NV + v;
                         const int f = MODE == 1 ? kmap(piece, hi, j) : 8 * piece + 4 * hi + j;
                         if (sl == 0 && f < a.N) sb[f] = s;
                     }
@@ -790,24 +816,31 @@ extern "C" int ren_vanilla_bwd_weight(const void *dz, const void *saved, const f
     for (int l = NL - 1; l >= 0; --l) {
         FieldDwArgs a = {};
         a.N = l_out(l, C); a.K = l_in(l); a.n = n;
-        if (l == L_RGBO) { a.dz_rows = dz_rgb; a.nz = 32; a.x = slot(saved, 9); a.nx = 128; }
-        else if (l == L_RGBH) { a.dz = slot(dz, 9); a.nz = 128; a.x = slot(saved, 8); a.nx = 256; a.x_rows = view; a.ld_rows = ld_view; a.n_rows = 32; }
-        else if (l == L_BOTT) { a.dz = slot(dz, 8); a.nz = 256; a.x = slot(saved, 7); a.nx = 256; }
-        else if (l == L_SIGMA) { a.dz_rows = dz_sigma; a.nz = 32; a.x = slot(saved, 7); a.nx = 256; }
+        if (l == L_RGBO) { a.dz_rows = dz_rgb; a.x = slot(saved, 9); a.nx = 128; }
+        else if (l == L_RGBH) { a.dz = slot(dz, 9); a.x = slot(saved, 8); a.nx = 256; a.x_rows = view; a.ld_rows = ld_view; a.n_rows = 32; }
+        else if (l == L_BOTT) { a.dz = slot(dz, 8); a.x = slot(saved, 7); a.nx = 256; }
+        else if (l == L_SIGMA) { a.dz_rows = dz_sigma; a.x = slot(saved, 7); a.nx = 256; }
         else {
-            a.dz = slot(dz, l); a.nz = 256;
+            a.dz = slot(dz, l);
             if (l > 0) { a.x = slot(saved, l - 1); a.nx = 256; }
             if (l == 0 || l == L_SKIP) { a.x_rows = enc; a.ld_rows = ld_enc; a.n_rows = 64; }
         }
         a.slab_w = workspace; a.slab_b = workspace + (int64_t)n_splits * a.N * a.K;
-        const size_t lds = 2 * (size_t)vfield_np(mode) * 256 * TDW_ST * 2;
-        if (mode == 1) {
-            (void)hipFuncSetAttribute((const void *)vfield_dw_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(vfield_dw_kernel<1>, dim3(n_splits), dim3(512), lds, st, a);
-        } else {
-            (void)hipFuncSetAttribute((const void *)vfield_dw_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(vfield_dw_kernel<6>, dim3(n_splits), dim3(512), lds, st, a);
-        }
+        const bool zrows = a.dz_rows != nullptr, xfrag = a.x != nullptr, xrows = a.x_rows != nullptr;
+#define REN_VFIELD_DW(MODE, ZR, XF, XR)                                                                                         \
+    do {                                                                                                                        \
+        const size_t lds = (size_t)vfield_np(MODE) * (256 + ((XF) && (XR) && MODE == 1 ? 320 : 256)) * TDW_ST * 2;             \
+        (void)hipFuncSetAttribute((const void *)vfield_dw_kernel<MODE, ZR, XF, XR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((vfield_dw_kernel<MODE, ZR, XF, XR>), dim3(n_splits), dim3(512), lds, st, a);                         \
+    } while (0)
+#define REN_VFIELD_DW_MODE(MODE)                                                                                                \
+    do {                                                                                                                        \
+        if (zrows) REN_VFIELD_DW(MODE, true, true, false);                                                                      \
+        else if (xfrag && xrows) REN_VFIELD_DW(MODE, false, true, true);                                                        \
+        else if (xfrag) REN_VFIELD_DW(MODE, false, true, false);                                                                \
+        else REN_VFIELD_DW(MODE, false, false, true);                                                                           \
+    } while (0)
+        if (mode == 1) REN_VFIELD_DW_MODE(1); else REN_VFIELD_DW_MODE(6);
         launch_reduce_slabs(a.slab_w, n_splits, a.N * a.K, grads + l_woff(l, C), st);
         launch_reduce_slabs(a.slab_b, n_splits, a.N, grads + l_boff(l, C), st);
     }
