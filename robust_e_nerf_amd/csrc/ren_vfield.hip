@@ -88,7 +88,9 @@ __global__ __launch_bounds__(256) void vfield_prep_kernel(const float *__restric
     if (fr < F_FRAGS) {
         int l = 0;
         while (l < NL - 1 && fr >= f_off(l + 1)) ++l;
-        const int nch = l_nch(l), r = fr - f_off(l), t = r / nch, c = r % nch, kin = l_in(l), nh = l_nh(l);
+        const int nch = l_nch(l), r = fr - f_off(l), kin = l_in(l), nh = l_nh(l);
+        // bf16 mode: [tile][chunk] (a stage = tiles); fp32 mode: [chunk][tile] (a stage = two chunks of all tiles)
+        const int t = NP == 3 ? r % l_nt(l) : r / nch, c = NP == 3 ? r / l_nt(l) : r % nch;
         const int row = t * 32 + sl;
         const float *W = P + l_woff(l, C) + row * kin;
 #pragma unroll
@@ -103,7 +105,8 @@ __global__ __launch_bounds__(256) void vfield_prep_kernel(const float *__restric
         int l = 1;
         for (int i = 2; i < NL; ++i)
             if (i != L_SIGMA && fr >= b_off(i)) l = i;
-        const int nch = b_nch(l), r = fr - b_off(l), t = r / nch, c = r % nch, kin = l_in(l);
+        const int nch = b_nch(l), r = fr - b_off(l), kin = l_in(l);
+        const int t = NP == 3 ? r % b_nt(l) : r / nch, c = NP == 3 ? r / b_nt(l) : r % nch;
         const int i = t * 32 + sl;                       // input index = row of W^T
         const float *W = P + l_woff(l, C) + i;
 #pragma unroll
@@ -169,6 +172,26 @@ __device__ __forceinline__ void store_tile(void *base, int64_t blk, int t, int l
     }
 }
 
+// fp32 mode: the third (smallest) bf16 piece of the chain operands lives in AGPRs by construction and is copied to VGPRs
+// next to the one MFMA per chunk that uses it.  Three pieces x 16 chunks x 4 registers = 192 operand registers do not fit
+// beside the weight fragments and epilogue temporaries in the 256 architectural VGPRs; left to itself the compiler spilled
+// them to scratch and reloaded them for every output tile.
+__device__ __forceinline__ void agpr_put(uint32_t (&dst)[4], const bf16x8 &v) {
+    const uint4 u = *reinterpret_cast<const uint4 *>(&v);
+    asm("v_accvgpr_write_b32 %0, %1" : "=a"(dst[0]) : "v"(u.x));
+    asm("v_accvgpr_write_b32 %0, %1" : "=a"(dst[1]) : "v"(u.y));
+    asm("v_accvgpr_write_b32 %0, %1" : "=a"(dst[2]) : "v"(u.z));
+    asm("v_accvgpr_write_b32 %0, %1" : "=a"(dst[3]) : "v"(u.w));
+}
+__device__ __forceinline__ bf16x8 agpr_get(const uint32_t (&src)[4]) {
+    uint4 u;
+    asm("v_accvgpr_read_b32 %0, %1" : "=v"(u.x) : "a"(src[0]));
+    asm("v_accvgpr_read_b32 %0, %1" : "=v"(u.y) : "a"(src[1]));
+    asm("v_accvgpr_read_b32 %0, %1" : "=v"(u.z) : "a"(src[2]));
+    asm("v_accvgpr_read_b32 %0, %1" : "=v"(u.w) : "a"(src[3]));
+    return *reinterpret_cast<const bf16x8 *>(&u);
+}
+
 // A layer shape is a compile-time type: a run-time `if` around a group of MFMAs makes the compiler copy whole accumulator
 // tuples between AGPRs at the join (a first version spent 30 % of its VALU issue on such copies).
 constexpr int A_SP100 = 0, A_NONE = 1, A_SIGMA = 2, A_RGB = 3;
@@ -190,7 +213,7 @@ __global__ __launch_bounds__(256, 1) void vfield_fwd_kernel(FieldArgs a) {
     using C = TC<MODE>;
     using PR = Pairs<MODE>;
     typedef typename C::ST ST;
-    constexpr int NP = C::NP, NB = C::NB, NTS = C::NTS;
+    constexpr int NP = C::NP, NB = C::NB, NTS = C::NTS, XP = NP == 3 ? 2 : NP;
     constexpr int STAGE = NTS * 20 * NP * 1024;          // bytes of the largest stage (layer 5)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
     float *bias = reinterpret_cast<float *>(smem_all);
@@ -227,7 +250,8 @@ __global__ __launch_bounds__(256, 1) void vfield_fwd_kernel(FieldArgs a) {
     for (int64_t grp = blockIdx.x; grp < n_grp; grp += gridDim.x) {
         const int64_t blk0_g = (grp * 4 + wave) * NB;
         const bool more_grp = grp + gridDim.x < n_grp;
-        bf16x8 x[NB][NP][16];
+        bf16x8 x[NB][XP][16];
+        uint32_t x2a[NB][16][4];                         // fp32 mode: piece 2 (AGPRs)
         // encoding operands; rows of blocks past the end are clamped to the last block (their results are never stored
         // row-major, and the fragment-layout buffers are whole groups)
         auto load_rows = [&](const float *src, int ld, int nchunks, bf16x8 (&e)[NB][NP][4], int64_t blk0, int sl, int hi) {
@@ -290,7 +314,8 @@ __global__ __launch_bounds__(256, 1) void vfield_fwd_kernel(FieldArgs a) {
                         for (int k = 0; k < PR::N; ++k)
 #pragma unroll
                             for (int u = 0; u < NB; ++u, ++m) {
-                                const bf16x8 &xv = c < NH ? x[u][PR::A[k]][c & 15] : e[u][PR::A[k]][(c - NH) & 3];
+                                const bf16x8 xv = c < NH ? ((NP == 3 && PR::A[k] == 2) ? agpr_get(x2a[u][c & 15]) : x[u][PR::A[k] % XP][c & 15])
+                                                         : e[u][PR::A[k]][(c - NH) & 3];
                                 if (NB * NTS == 1 && (m & 1)) part = MFMAB(w[PR::W[k]], xv, part);
                                 else acc[u][t] = MFMAB(w[PR::W[k]], xv, acc[u][t]);
                             }
@@ -339,7 +364,8 @@ __global__ __launch_bounds__(256, 1) void vfield_fwd_kernel(FieldArgs a) {
                     bf16x8 lo[3], hi8[3];
                     pack_tile<MODE>(y, lo, hi8);
 #pragma unroll
-                    for (int p = 0; p < NP; ++p) { x[u][p][2 * t] = lo[p]; x[u][p][2 * t + 1] = hi8[p]; }
+                    for (int p = 0; p < XP; ++p) { x[u][p][2 * t] = lo[p]; x[u][p][2 * t + 1] = hi8[p]; }
+                    if (NP == 3) { agpr_put(x2a[u][2 * t], lo[2]); agpr_put(x2a[u][2 * t + 1], hi8[2]); }
                     if (SAVE) store_tile<MODE>(sv, blk0 + u, t, lane, y, lo[0], hi8[0]);
                     TRUNK_FENCE();
                 }
@@ -368,7 +394,7 @@ __global__ __launch_bounds__(256, 1) void vfield_bwd_kernel(FieldArgs a) {
     using C = TC<MODE>;
     using PR = Pairs<MODE>;
     typedef typename C::ST ST;
-    constexpr int NP = C::NP, NB = C::NB, NTS = C::NTS;
+    constexpr int NP = C::NP, NB = C::NB, NTS = C::NTS, XP = NP == 3 ? 2 : NP;
     constexpr int STAGE = NTS * 17 * NP * 1024;
     constexpr int HV = MODE == 1 ? 2 : 4;                // 16-byte loads per lane and tile of a saved layer
     constexpr int PD = 4;                                // saved-activation tiles in flight
@@ -394,7 +420,8 @@ __global__ __launch_bounds__(256, 1) void vfield_bwd_kernel(FieldArgs a) {
     for (int64_t grp = blockIdx.x; grp < n_grp; grp += gridDim.x) {
         const int64_t blk0_g = (grp * 4 + wave) * NB;
         const bool more_grp = grp + gridDim.x < n_grp;
-        bf16x8 x[NB][NP][16];
+        bf16x8 x[NB][XP][16];
+        uint32_t x2a[NB][16][4];                         // fp32 mode: piece 2 (AGPRs)
         // one extra operand chunk from a row-major [n_pad][32] gradient buffer: columns 8 hi .. 8 hi + 7 (step 11: dz_rgb),
         // or k-slot 0 only (step 9: dz_sigma, column 0)
         auto load_extra = [&](const float *src, bool slot0, bf16x8 (&e)[NB][NP], int64_t blk0, int sl, int hi) {
@@ -473,7 +500,8 @@ __global__ __launch_bounds__(256, 1) void vfield_bwd_kernel(FieldArgs a) {
                         for (int k = 0; k < PR::N; ++k)
 #pragma unroll
                             for (int u = 0; u < NB; ++u, ++m) {
-                                const bf16x8 &xv = c < NH ? x[u][PR::A[k]][c & 15] : e[u][PR::A[k]];
+                                const bf16x8 xv = c < NH ? ((NP == 3 && PR::A[k] == 2) ? agpr_get(x2a[u][c & 15]) : x[u][PR::A[k] % XP][c & 15])
+                                                         : e[u][PR::A[k]];
                                 if (NB * NTS == 1 && (m & 1)) part = MFMAB(w[PR::W[k]], xv, part);
                                 else acc[u][t] = MFMAB(w[PR::W[k]], xv, acc[u][t]);
                             }
@@ -514,8 +542,288 @@ __global__ __launch_bounds__(256, 1) void vfield_bwd_kernel(FieldArgs a) {
                 bf16x8 lo[3], hi8[3];
                 pack_tile<MODE>(y, lo, hi8);
 #pragma unroll
-                for (int p = 0; p < NP; ++p) { x[u][p][2 * t] = lo[p]; x[u][p][2 * t + 1] = hi8[p]; }
+                for (int p = 0; p < XP; ++p) { x[u][p][2 * t] = lo[p]; x[u][p][2 * t + 1] = hi8[p]; }
+                if (NP == 3) { agpr_put(x2a[u][2 * t], lo[2]); agpr_put(x2a[u][2 * t + 1], hi8[2]); }
                 store_tile<MODE>(sv, blk0 + u, t, lane, y, lo[0], hi8[0]);
+                TRUNK_FENCE();
+            }
+        };
+        step(BShape<0, 1, 4, true>(), L_RGBO, L_RGBH, 9, 9, a.dz_rgb);
+        step(BShape<8, 0, 8, false>(), L_RGBH, L_BOTT, 0, 8, nullptr);
+        step(BShape<16, 1, 8, true>(), L_BOTT, 7, 7, 7, a.dz_sig);
+        for (int l = 7; l >= 1; --l) step(BShape<16, 0, 8, true>(), l, l > 1 ? l - 1 : (more_grp ? L_RGBO : -1), l - 1, l - 1, nullptr);
+    }
+}
+
+// ---- fp32 mode (three-piece split): reduction-outer variants -------------------------------------------------------------------
+// Three bf16 pieces of 256 activations are 192 operand registers per 32-sample block: beside the weight fragments and the
+// epilogue they do not fit in the 256 architectural VGPRs (the tile-outer kernels above, instantiated for this mode, spilled
+// 250-350 registers to scratch and reloaded the operands for every output tile).  Here the loops are turned around: the
+// previous layer's activated outputs stay as fp32 in 128 registers (`yprev`, in the accumulator layout), a k-chunk of them
+// is split into its three pieces right before use -- each chunk is used exactly once per layer, so the split costs what it
+// cost as part of the epilogue -- and feeds the MFMAs of ALL output tiles, whose 128 accumulators fill the AGPRs.  The
+// weight image of this mode is chunk-major ([chunk][tile][piece]) and a stage is two chunks of all tiles (<= 48 KB).
+template <bool SAVE, bool FULL>
+__global__ __launch_bounds__(256, 1) void vfield_fwd6_kernel(FieldArgs a) {
+    using PR = Pairs<6>;
+    constexpr int NP = 3;
+    constexpr int STAGE = 2 * 8 * NP * 1024;             // two chunks x eight tiles
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+    float *bias = reinterpret_cast<float *>(smem_all);
+    unsigned char *smem_tf = smem_all + LB_FLOATS * 4;
+    const int lane_k = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane16_k = lane_k * 16;
+    for (int i = threadIdx.x; i < LB_FLOATS; i += 256) {
+        float b = 0.f;
+        if (i < 2048) b = a.P[l_boff(i >> 8, a.C) + (i & 255)];
+        else if (i < LB_RGBH) b = a.P[l_boff(L_BOTT, a.C) + i - LB_BOTT];
+        else if (i < LB_SIGMA) b = a.P[l_boff(L_RGBH, a.C) + i - LB_RGBH];
+        else if (i == LB_SIGMA) b = a.P[l_boff(L_SIGMA, a.C)];
+        else if (i >= LB_RGBO && i < LB_RGBO + a.C) b = a.P[l_boff(L_RGBO, a.C) + i - LB_RGBO];
+        bias[i] = b;
+    }
+    const int64_t n_blk = (a.n + 31) >> 5, n_grp = (n_blk + 3) / 4;
+    const size_t sstride = (size_t)n_grp * 4 * 32 * 256;
+
+    auto issue = [&](int l, int cg, int buf) {           // stage (layer l, chunks 2 cg, 2 cg + 1) -> LDS buffer buf
+        const int nt = l_nt(l), pieces = min(2, l_nch(l) - 2 * cg) * nt * NP;
+        uint32_t off = (uint32_t)(f_off(l) + 2 * cg * nt) * NP * 1024 + wave * 1024;
+        unsigned char *dst = smem_tf + buf * STAGE + wave * 1024;
+        for (int i = wave; i < pieces; i += 4) {
+            asm volatile("" : "+s"(off));
+            glds16(reinterpret_cast<const unsigned char *>(a.img) + off + lane16_k, dst);
+            off += 4096; dst += 4096;
+        }
+    };
+    int buf = 0;
+    if ((int64_t)blockIdx.x < n_grp) issue(0, 0, 0);
+    for (int64_t grp = blockIdx.x; grp < n_grp; grp += gridDim.x) {
+        const int64_t blk_g = grp * 4 + wave;
+        const bool more_grp = grp + gridDim.x < n_grp;
+        f32x16 yprev[8];                                 // activated outputs of the previous layer (accumulator layout)
+        auto layer = [&](auto shape, const int l, const int ln, const int slot) {
+            using S = decltype(shape);
+            constexpr int NH = S::NH, NE = S::NE, NT = S::NT, ACT = S::ACT, nch = NH + NE, NCG = (nch + 1) / 2;
+            uint32_t lane16 = lane16_k;
+            int64_t blk = blk_g;
+            asm volatile("" : "+v"(lane16), "+s"(blk));
+            const int lane = lane16 >> 4, hi = lane >> 5, sl = lane & 31;
+            float ef[NE ? NE : 1][8];                    // encoding chunks of this block (fp32; split at use)
+            if (NE) {
+                const int64_t bc = blk < n_blk ? blk : n_blk - 1;
+                const float *xp = (NE == 4 ? a.enc + (bc * 32 + sl) * a.ld_enc : a.view + (bc * 32 + sl) * a.ld_view) + 8 * hi;
+#pragma unroll
+                for (int c = 0; c < NE; ++c) {
+                    const float4 v0 = *reinterpret_cast<const float4 *>(xp + 16 * c), v1 = *reinterpret_cast<const float4 *>(xp + 16 * c + 4);
+                    ef[c][0] = v0.x; ef[c][1] = v0.y; ef[c][2] = v0.z; ef[c][3] = v0.w; ef[c][4] = v1.x; ef[c][5] = v1.y; ef[c][6] = v1.z; ef[c][7] = v1.w;
+                }
+            }
+            f32x16 acc[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) acc[t][g] = 0.f;
+#pragma unroll
+            for (int cg = 0; cg < NCG; ++cg) {
+                __syncthreads();
+                if (cg + 1 < NCG) issue(l, cg + 1, buf ^ 1);
+                else if (ln >= 0) issue(ln, 0, buf ^ 1);
+                const unsigned char *st = smem_tf + buf * STAGE + lane16;
+#pragma unroll
+                for (int ci = 0; ci < 2; ++ci) {
+                    const int c = 2 * cg + ci;
+                    if (c >= nch) continue;
+                    float xs[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) xs[j] = c < NH ? yprev[(c >> 1) & 7][8 * (c & 1) + j] : ef[(c - NH) % (NE ? NE : 1)][j];
+                    bf16x8 xp[3];
+                    split8<3>(xs, xp);
+#pragma unroll
+                    for (int t0 = 0; t0 < NT; t0 += 2) { // two tiles at a time: consecutive MFMAs alternate accumulators
+                        bf16x8 w[2][NP];
+#pragma unroll
+                        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                            for (int p = 0; p < NP; ++p)
+                                if (t0 + tt < NT) w[tt][p] = *reinterpret_cast<const bf16x8 *>(st + ((ci * NT + t0 + tt) * NP + p) * 1024);
+#pragma unroll
+                        for (int k = 0; k < PR::N; ++k) {
+                            acc[t0] = MFMAB(w[0][PR::W[k]], xp[PR::A[k]], acc[t0]);
+                            if (t0 + 1 < NT) acc[t0 + 1] = MFMAB(w[1][PR::W[k]], xp[PR::A[k]], acc[t0 + 1]);
+                        }
+                    }
+                }
+                buf ^= 1;
+                TRUNK_FENCE();
+            }
+            const float *bl = bias + lb_off(l);
+            if (ACT == A_SIGMA) {
+                const int64_t row = blk * 32 + sl;
+                if (hi == 0 && row < a.n) a.sigma[row] = a.sel[row] ? __expf(acc[0][0] + bl[0] - 1.f) : 0.f;
+                return;
+            }
+            if (ACT == A_RGB) {
+                const int64_t row = blk * 32 + sl;
+                if (hi == 0 && row < a.n) {
+                    float r[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) r[c] = c < a.C ? softplus1(acc[0][c] + bl[c]) : 0.f;
+                    *reinterpret_cast<float4 *>(a.rgb4 + row * 4) = make_float4(r[0], r[1], r[2], r[3]);
+                }
+                return;
+            }
+            float *sv = reinterpret_cast<float *>(a.acts) + (size_t)slot * sstride;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                float y[16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 b4 = *reinterpret_cast<const float4 *>(bl + t * 32 + 8 * q + 4 * hi);
+                    const float z[4] = {acc[t][4 * q] + b4.x, acc[t][4 * q + 1] + b4.y, acc[t][4 * q + 2] + b4.z, acc[t][4 * q + 3] + b4.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) y[4 * q + j] = ACT == A_SP100 ? softplus100(z[j]) : z[j];
+                }
+#pragma unroll
+                for (int g = 0; g < 16; ++g) yprev[t][g] = y[g];
+                if (SAVE) {
+                    float *p = sv + (((blk * 8 + t) * 4) * 64 + lane) * 4;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) *reinterpret_cast<float4 *>(p + q * 256) = make_float4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
+                }
+                TRUNK_FENCE();
+            }
+        };
+        layer(Shape<0, 4, 8, A_SP100>(), 0, 1, 0);
+        for (int l = 1; l < L_SKIP; ++l) layer(Shape<16, 0, 8, A_SP100>(), l, l + 1, l);
+        layer(Shape<16, 4, 8, A_SP100>(), L_SKIP, 6, L_SKIP);
+        layer(Shape<16, 0, 8, A_SP100>(), 6, 7, 6);
+        layer(Shape<16, 0, 8, A_SP100>(), 7, L_SIGMA, 7);
+        layer(Shape<16, 0, 1, A_SIGMA>(), L_SIGMA, FULL ? L_BOTT : (more_grp ? 0 : -1), -1);
+        if (FULL) {
+            layer(Shape<16, 0, 8, A_NONE>(), L_BOTT, L_RGBH, 8);
+            layer(Shape<16, 2, 4, A_SP100>(), L_RGBH, L_RGBO, 9);
+            layer(Shape<8, 0, 1, A_RGB>(), L_RGBO, more_grp ? 0 : -1, -1);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void vfield_bwd6_kernel(FieldArgs a) {
+    using PR = Pairs<6>;
+    constexpr int NP = 3;
+    constexpr int STAGE = 2 * 8 * NP * 1024;
+    constexpr int PD = 2;                                // saved-activation tiles in flight (16 registers each)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_tb[];
+    const int lane_k = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane16_k = lane_k * 16;
+    const int64_t n_blk = (a.n + 31) >> 5, n_grp = (n_blk + 3) / 4;
+    const size_t sstride = (size_t)n_grp * 4 * 32 * 256;
+
+    auto issue = [&](int l, int cg, int buf) {
+        const int nt = b_nt(l), pieces = min(2, b_nch(l) - 2 * cg) * nt * NP;
+        uint32_t off = (uint32_t)(b_off(l) + 2 * cg * nt) * NP * 1024 + wave * 1024;
+        unsigned char *dst = smem_tb + buf * STAGE + wave * 1024;
+        for (int i = wave; i < pieces; i += 4) {
+            asm volatile("" : "+s"(off));
+            glds16(reinterpret_cast<const unsigned char *>(a.img) + off + lane16_k, dst);
+            off += 4096; dst += 4096;
+        }
+    };
+    int buf = 0;
+    if ((int64_t)blockIdx.x < n_grp) issue(L_RGBO, 0, 0);
+    for (int64_t grp = blockIdx.x; grp < n_grp; grp += gridDim.x) {
+        const int64_t blk_g = grp * 4 + wave;
+        const bool more_grp = grp + gridDim.x < n_grp;
+        f32x16 yprev[8];                                 // pre-activation gradient of the layer above (accumulator layout)
+        auto step = [&](auto shape, const int l, const int ln, const int hslot, const int dslot, const float *extra) {
+            using S = decltype(shape);
+            constexpr int NH = S::NH, NE = S::NE, NT = S::NT, nch = NH + NE, NCG = (nch + 1) / 2;
+            constexpr bool DERIV = S::DERIV;
+            uint32_t lane16 = lane16_k;
+            int64_t blk = blk_g;
+            asm volatile("" : "+v"(lane16), "+s"(blk));
+            const int lane = lane16 >> 4, hi = lane >> 5, sl = lane & 31;
+            const float *hs = reinterpret_cast<const float *>(a.acts) + (size_t)(DERIV ? hslot : 0) * sstride;
+            float ef[8];                                 // the extra operand chunk (dz_rgb columns / dz_sigma in k-slot 0)
+            if (NE) {
+                const int64_t bc = blk < n_blk ? blk : n_blk - 1;
+                const float *xp = extra + (bc * 32 + sl) * 32 + 8 * hi;
+                if (l == L_BOTT) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) ef[j] = 0.f;
+                    ef[0] = hi == 0 ? xp[0] : 0.f;
+                } else {
+                    const float4 v0 = *reinterpret_cast<const float4 *>(xp), v1 = *reinterpret_cast<const float4 *>(xp + 4);
+                    ef[0] = v0.x; ef[1] = v0.y; ef[2] = v0.z; ef[3] = v0.w; ef[4] = v1.x; ef[5] = v1.y; ef[6] = v1.z; ef[7] = v1.w;
+                }
+            }
+            float4 hpre[PD][4];
+            auto load_h = [&](int t, float4 (&dst)[4]) {
+                const float4 *p = reinterpret_cast<const float4 *>(hs + ((blk * 8 + t) * 4 * 64 + lane) * 4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dst[q] = p[q * 64];
+            };
+            f32x16 acc[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) acc[t][g] = 0.f;
+#pragma unroll
+            for (int cg = 0; cg < NCG; ++cg) {
+                __syncthreads();
+                if (cg + 1 < NCG) issue(l, cg + 1, buf ^ 1);
+                else if (ln >= 0) issue(ln, 0, buf ^ 1);
+                if (DERIV && cg == NCG - 1) {
+#pragma unroll
+                    for (int i = 0; i < PD; ++i) load_h(i, hpre[i]);
+                }
+                const unsigned char *st = smem_tb + buf * STAGE + lane16;
+#pragma unroll
+                for (int ci = 0; ci < 2; ++ci) {
+                    const int c = 2 * cg + ci;
+                    if (c >= nch) continue;
+                    float xs[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) xs[j] = c < NH ? yprev[(c >> 1) & 7][8 * (c & 1) + j] : ef[j];
+                    bf16x8 xp[3];
+                    split8<3>(xs, xp);
+#pragma unroll
+                    for (int t0 = 0; t0 < NT; t0 += 2) {
+                        bf16x8 w[2][NP];
+#pragma unroll
+                        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                            for (int p = 0; p < NP; ++p)
+                                if (t0 + tt < NT) w[tt][p] = *reinterpret_cast<const bf16x8 *>(st + ((ci * NT + t0 + tt) * NP + p) * 1024);
+#pragma unroll
+                        for (int k = 0; k < PR::N; ++k) {
+                            acc[t0] = MFMAB(w[0][PR::W[k]], xp[PR::A[k]], acc[t0]);
+                            if (t0 + 1 < NT) acc[t0 + 1] = MFMAB(w[1][PR::W[k]], xp[PR::A[k]], acc[t0 + 1]);
+                        }
+                    }
+                }
+                buf ^= 1;
+                TRUNK_FENCE();
+            }
+            float *sv = reinterpret_cast<float *>(a.dz) + (size_t)dslot * sstride;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                float y[16];
+                if (DERIV) {
+                    float h[16];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { h[4 * q] = hpre[t % PD][q].x; h[4 * q + 1] = hpre[t % PD][q].y; h[4 * q + 2] = hpre[t % PD][q].z; h[4 * q + 3] = hpre[t % PD][q].w; }
+                    if (t + PD < NT) load_h(t + PD, hpre[t % PD]);
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) y[g] = acc[t][g] * dsoftplus_from_out(h[g], 100.f);
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) y[g] = acc[t][g];
+                }
+#pragma unroll
+                for (int g = 0; g < 16; ++g) yprev[t][g] = y[g];
+                float *p = sv + (((blk * 8 + t) * 4) * 64 + lane) * 4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) *reinterpret_cast<float4 *>(p + q * 256) = make_float4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
                 TRUNK_FENCE();
             }
         };
@@ -726,6 +1034,8 @@ __global__ __launch_bounds__(512, 1) void vfield_dw_kernel(FieldDwArgs a) {
 }
 
 template <int MODE> size_t fwd_lds() { return LB_FLOATS * 4 + 2 * (size_t)TC<MODE>::NTS * 20 * TC<MODE>::NP * 1024; }
+static size_t fwd6_lds() { return LB_FLOATS * 4 + 2 * (size_t)2 * 8 * 3 * 1024; }
+static size_t bwd6_lds() { return 2 * (size_t)2 * 8 * 3 * 1024; }
 template <int MODE> size_t bwd_lds() { return 2 * (size_t)TC<MODE>::NTS * 17 * TC<MODE>::NP * 1024; }
 
 }  // namespace
@@ -776,7 +1086,14 @@ extern "C" int ren_vanilla_fwd(const float *enc, int32_t ld_enc, const float *vi
         hipLaunchKernelGGL((vfield_fwd_kernel<MODE, SAVE, FULL>), dim3(vfield_grid(n, TC<MODE>::NB)), dim3(256), fwd_lds<MODE>(), st, a); \
     } while (0)
     if (mode == 1) { if (saved) REN_VFIELD_FWD(1, true, true); else if (rgb4) REN_VFIELD_FWD(1, false, true); else REN_VFIELD_FWD(1, false, false); }
-    else { if (saved) REN_VFIELD_FWD(6, true, true); else if (rgb4) REN_VFIELD_FWD(6, false, true); else REN_VFIELD_FWD(6, false, false); }
+    else {
+#define REN_VFIELD_FWD6(SAVE, FULL)                                                                                             \
+    do {                                                                                                                        \
+        (void)hipFuncSetAttribute((const void *)vfield_fwd6_kernel<SAVE, FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd6_lds()); \
+        hipLaunchKernelGGL((vfield_fwd6_kernel<SAVE, FULL>), dim3(vfield_grid(n, 1)), dim3(256), fwd6_lds(), st, a);            \
+    } while (0)
+        if (saved) REN_VFIELD_FWD6(true, true); else if (rgb4) REN_VFIELD_FWD6(false, true); else REN_VFIELD_FWD6(false, false);
+    }
     REN_CHECK_LAUNCH();
 }
 
@@ -792,8 +1109,8 @@ extern "C" int ren_vanilla_bwd(const float *dz_rgb, const float *dz_sigma, const
         (void)hipFuncSetAttribute((const void *)vfield_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds<1>());
         hipLaunchKernelGGL(vfield_bwd_kernel<1>, dim3(vfield_grid(n, TC<1>::NB)), dim3(256), bwd_lds<1>(), st, a);
     } else {
-        (void)hipFuncSetAttribute((const void *)vfield_bwd_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds<6>());
-        hipLaunchKernelGGL(vfield_bwd_kernel<6>, dim3(vfield_grid(n, TC<6>::NB)), dim3(256), bwd_lds<6>(), st, a);
+        (void)hipFuncSetAttribute((const void *)vfield_bwd6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd6_lds());
+        hipLaunchKernelGGL(vfield_bwd6_kernel, dim3(vfield_grid(n, 1)), dim3(256), bwd6_lds(), st, a);
     }
     REN_CHECK_LAUNCH();
 }
