@@ -835,201 +835,252 @@ __global__ __launch_bounds__(256, 1) void vfield_bwd6_kernel(FieldArgs a) {
 }
 
 // ---- weight / bias gradient of one layer from the fragment-layout copies -------------------------------------------------------
-// as dense_dw_x_kernel (ren_dense.hip): one workgroup of 8 waves per sample split, per 32-sample stage the block's dz and
-// inputs go to LDS transposed, [feature][sample] bf16 pieces; wave w owns the output rows 32 w .. against up to 8 input
-// tiles per K group.  Narrow layers (sigma: 1 output, colour output: C) take dz from the row-major [n_pad][32] buffers.
-constexpr int TDW_ST = 40;
+// dW = dz^T x with the SAMPLES as the reduction: both MFMA operands need, per lane = feature, eight consecutive samples --
+// the transposes of the saved [sample][feature] data.  A wave transposes the 32 x 32 tile it loaded on the matrix cores:
+// the saved fragment (lane = sample, k-slots = 16 features) is exactly an A operand, so T = X . Sel with a 0/1 selection
+// matrix Sel as B operand is the tile with lane = feature and the 32 samples in the accumulator registers (two MFMAs per tile
+// and piece, exact: every product is a bf16 value times 1), which packs into the two k-chunk operands of the gradient
+// product.  The operands go to LDS as ready-made 1 KB fragments (one ds_write_b128 per lane; a first version scattered 2-byte
+// LDS writes to transpose, which cost more than the gradient MFMAs of a stage).  One workgroup of 8 waves per sample split,
+// wave w owns the output rows 32 w .. against up to 10 input tiles; partial sums go to per-split slabs.
+// Narrow layers (sigma: 1 output, colour output: C) take dz from the row-major [n_pad][32] buffers; the first layer, the skip
+// layer and the colour hidden layer take (part of) their input from the row-major encodings.
 struct FieldDwArgs {
-    const void *dz;                                      // fragment slot (256-feature stride; nz valid features), or ..
+    const void *dz;                                      // fragment slot (256-feature stride), or ..
     const float *dz_rows;                                // .. row-major [n_pad][32]
     const void *x; int nx;                               // fragment slot with nx valid features
     const float *x_rows; int ld_rows, n_rows;            // row-major encoding columns (n_rows 64 / 32)
     int N, K;                                            // torch out / in features
+    int k_base, skip_bias;                               // first input column of this launch; 1: weights only (second launch of a layer)
     int64_t n;
     float *slab_w, *slab_b;                              // [n_splits][N][K], [n_splits][N]
 };
 
-// ZROWS: dz from the row-major buffer (narrow layers); XFRAG / XROWS: the input has a fragment-slot part / a row-major
-// encoding part (both: [slot | encoding], the skip layer and the colour hidden layer).  All compile-time: the loads of a stage
-// are unconditional straight-line code, so the compiler counts them (`s_waitcnt vmcnt(N)`) and two stages stay in flight --
-// with a run-time `if` around them every use waited for vmcnt(0), i.e. for the stage issued last (3.3 TB/s, latency-bound).
+// ZROWS / XFRAG / XROWS compile-time: the loads of a stage are unconditional straight-line code, so the compiler counts them
+// (`s_waitcnt vmcnt(N)`) and a whole stage stays in flight behind the one being worked on -- with a run-time `if` around them
+// every use waited for vmcnt(0), i.e. for the loads issued last (3.3 TB/s, latency-bound).
 template <int MODE, bool ZROWS, bool XFRAG, bool XROWS>
 __global__ __launch_bounds__(512, 1) void vfield_dw_kernel(FieldDwArgs a) {
     typedef typename TC<MODE>::ST ST;
     constexpr int NP = TC<MODE>::NP;
-    constexpr int NV = MODE == 1 ? 2 : 4;                // 16-byte pieces per thread and operand per stage (256 features)
-    constexpr int FPP = MODE == 1 ? 8 : 4;               // features per piece and lane
-    constexpr bool ONEPASS = MODE == 1 || !(XFRAG && XROWS);      // fp32 mode: [slot | encoding] inputs in two passes (registers)
-    constexpr int NACC = (XFRAG && XROWS && ONEPASS) ? 10 : 8;
-    constexpr int XROWS_T = NACC == 10 ? 320 : 256;      // feature rows of the transposed input tile
+    constexpr int NV = MODE == 1 ? 2 : 4;                // 16-byte pieces per lane of one 32-feature tile
+    constexpr int NXT = XFRAG && XROWS ? 10 : 8;         // input tiles held in LDS: the slot's, then the encoding's
+    constexpr int XR0 = XFRAG ? 8 : 0;                   // first encoding tile
+    constexpr bool DB = MODE == 1;                       // bf16 mode: double-buffered operand fragments (36 KB each)
+    constexpr int ZBYTES = 8 * 2 * NP * 1024, BUFBYTES = ZBYTES + NXT * 2 * NP * 1024;
     using PRD = Pairs<MODE>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_td[];
-    __bf16 *ZT = reinterpret_cast<__bf16 *>(smem_td), *XT = ZT + NP * 256 * TDW_ST;
     const int wave_k = threadIdx.x >> 6;
     const int n_splits = gridDim.x;
     const int64_t n_blk = (a.n + 31) >> 5;
     const bool has_tile = wave_k * 32 < a.N;
     float *sw = a.slab_w + (int64_t)blockIdx.x * a.N * a.K, *sb = a.slab_b + (int64_t)blockIdx.x * a.N;
-    constexpr int PASSES = ONEPASS ? 1 : 2;
-    for (int pass = 0; pass < PASSES; ++pass) {
-        const bool use_frag = XFRAG && (ONEPASS || pass == 0), use_rows = XROWS && (ONEPASS || pass == PASSES - 1);
-        const int kt_frag = use_frag ? a.nx / 32 : 0, kt = kt_frag + (use_rows ? a.n_rows / 32 : 0);
-        const int k0 = (!ONEPASS && pass == 1) ? a.nx : 0;                 // first input column of this pass
-        const int rows_at = ONEPASS ? (XFRAG ? 256 : 0) : 0;               // XT row of the encoding part
-        f32x16 acc[NACC];
+    const int kt_frag = XFRAG ? a.nx / 32 : 0, kt_rows = XROWS ? a.n_rows / 32 : 0;
+
+    f32x16 acc[NXT];
 #pragma unroll
-        for (int t = 0; t < NACC; ++t)
+    for (int t = 0; t < NXT; ++t)
 #pragma unroll
-            for (int g = 0; g < 16; ++g) acc[t][g] = 0.f;
-        float bsum[ZROWS ? 4 : NV * FPP];
+        for (int g = 0; g < 16; ++g) acc[t][g] = 0.f;
+    float bsum = 0.f;                                    // lane = feature (transposed layout): one partial per lane
+    float bs4[4] = {0.f, 0.f, 0.f, 0.f};                 // ZROWS: lane = sample, columns 0 .. 3
+    struct Stage { uint4 pz[NV], px[NV]; float4 rz[4], rx[4]; };
+    Stage sq[DB ? 2 : 1];
+    // `tid`: an opaque copy of threadIdx.x (see `stage`): the addresses derived from it are computed per stage instead of once
+    // per kernel (where they spilled)
+    auto fetch = [&](int tid, int64_t blk, Stage &q) {
+        const int lane = tid & 63, wave = tid >> 6, hi = lane >> 5, sl = lane & 31;
+        const uint4 *zb = reinterpret_cast<const uint4 *>(reinterpret_cast<const ST *>(a.dz) + blk * 32 * 256);
+        const uint4 *xb = reinterpret_cast<const uint4 *>(reinterpret_cast<const ST *>(a.x) + blk * 32 * 256);
 #pragma unroll
-        for (int q = 0; q < (ZROWS ? 4 : NV * FPP); ++q) bsum[q] = 0.f;
-        struct Stage { uint4 pz[NV], px[NV]; float4 pe, pzr; };
-        Stage sq[2];                                     // two stages in flight
-        // `tid`: an opaque copy of threadIdx.x (see `stage`): the ~40 LDS / global addresses derived from it are computed per
-        // stage instead of once per kernel (where they spilled)
-        auto fetch = [&](int tid, int64_t blk, Stage &q) {
-            const int lane = tid & 63, wave = tid >> 6;
-            const uint4 *zb = reinterpret_cast<const uint4 *>(reinterpret_cast<const ST *>(a.dz) + blk * 32 * 256);
-            const uint4 *xb = reinterpret_cast<const uint4 *>(reinterpret_cast<const ST *>(a.x) + blk * 32 * 256);
+        for (int v = 0; v < NV; ++v) {                   // wave w: tile w of dz and of the slot part of x
+            if (!ZROWS) q.pz[v] = zb[(wave * NV + v) * 64 + lane];
+            if (XFRAG) q.px[v] = xb[(wave * NV + v) * 64 + lane];
+        }
+        // row-major sources: lane = sample, 2 x 8 consecutive columns per 16-column chunk of the wave's 32-column tile
+        if (XROWS) {
+            const float *p = a.x_rows + (blk * 32 + sl) * a.ld_rows + ((wave * 32) & (a.n_rows - 1)) + 8 * hi;
+            q.rx[0] = *reinterpret_cast<const float4 *>(p); q.rx[1] = *reinterpret_cast<const float4 *>(p + 4);
+            q.rx[2] = *reinterpret_cast<const float4 *>(p + 16); q.rx[3] = *reinterpret_cast<const float4 *>(p + 20);
+        }
+        if (ZROWS) {
+            const float *p = a.dz_rows + (blk * 32 + sl) * 32 + 8 * hi;
+            q.rz[0] = *reinterpret_cast<const float4 *>(p); q.rz[1] = *reinterpret_cast<const float4 *>(p + 4);
+            q.rz[2] = *reinterpret_cast<const float4 *>(p + 16); q.rz[3] = *reinterpret_cast<const float4 *>(p + 20);
+        }
+    };
+    // the 32 x 32 tile whose two 16-feature chunks are `c0`, `c1` (lane = sample; kmap order: KM, natural order: !KM),
+    // transposed, as the two k-chunk operands (k = samples) at dst[ks][piece]
+    auto transpose_store = [&](const float (&c0)[8], const float (&c1)[8], bool km, int lane, unsigned char *dst, float *colsum) {
+        const int hi = lane >> 5, sl = lane & 31;
+        bf16x8 sel[2];
 #pragma unroll
-            for (int v = 0; v < NV; ++v) {               // (slots have the full 256-feature stride: pieces past nz / nx are
-                const int piece = wave * NV + v;         //  valid memory whose values land in unused rows)
-                if (!ZROWS) q.pz[v] = zb[piece * 64 + lane];
-                if (XFRAG) q.px[v] = xb[piece * 64 + lane];
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int f = km ? 16 * u + 8 * (j >> 2) + 4 * hi + (j & 3) : 16 * u + 8 * hi + j;
+                sel[u][j] = sl == f ? (__bf16)1.f : (__bf16)0.f;
             }
-            const int s = tid & 31, f0 = 4 * (tid >> 5);
-            if (XROWS) q.pe = *reinterpret_cast<const float4 *>(a.x_rows + (blk * 32 + s) * a.ld_rows + (f0 & (a.n_rows - 1)));
-            if (ZROWS) q.pzr = *reinterpret_cast<const float4 *>(a.dz_rows + (blk * 32 + s) * 32 + (f0 & 31));
-        };
-        auto put = [&](__bf16 *T, int rows, int f, int s, float v) {
-            __bf16 sp[3];
-            split<NP>(v, sp);
+        bf16x8 p0[3], p1[3];
+        split8<NP>(c0, p0);
+        split8<NP>(c1, p1);
+        float cs = 0.f;
 #pragma unroll
-            for (int p = 0; p < NP; ++p) T[(p * rows + f) * TDW_ST + s] = sp[p];
-        };
-        auto stash = [&](int tid, int64_t blk, const Stage &q) {
-            const int lane = tid & 63, wave = tid >> 6, hi = lane >> 5, sl = lane & 31;
-            const bool live = blk * 32 + sl < a.n;       // samples past the end contribute nothing
+        for (int p = 0; p < NP; ++p) {
+            f32x16 T;
 #pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                const int piece = wave * NV + v;
-                if (MODE == 1) {                         // piece = chunk c: features kmap(c, hi, j)
-                    const bf16x8 z8 = *reinterpret_cast<const bf16x8 *>(&q.pz[v]), x8 = *reinterpret_cast<const bf16x8 *>(&q.px[v]);
+            for (int g = 0; g < 16; ++g) T[g] = 0.f;
+            T = MFMAB(p0[p], sel[0], T);
+            T = MFMAB(p1[p], sel[1], T);
+            bf16x8 o0, o1;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int f = kmap(piece, hi, j);
-                        if (!ZROWS) { ZT[f * TDW_ST + sl] = live ? z8[j] : (__bf16)0.f; bsum[8 * v + j] += live ? (float)z8[j] : 0.f; }
-                        if (use_frag) XT[f * TDW_ST + sl] = live ? x8[j] : (__bf16)0.f;
-                    }
-                } else {                                 // piece = (t, q): features 32 t + 8 q + 4 hi + j
-                    const float4 z4 = *reinterpret_cast<const float4 *>(&q.pz[v]), x4 = *reinterpret_cast<const float4 *>(&q.px[v]);
-                    const float z[4] = {z4.x, z4.y, z4.z, z4.w}, xx[4] = {x4.x, x4.y, x4.z, x4.w};
+            for (int j = 0; j < 8; ++j) { o0[j] = (__bf16)T[j]; o1[j] = (__bf16)T[8 + j]; cs += T[j] + T[8 + j]; }
+            *reinterpret_cast<bf16x8 *>(dst + (0 * NP + p) * 1024 + lane * 16) = o0;
+            *reinterpret_cast<bf16x8 *>(dst + (1 * NP + p) * 1024 + lane * 16) = o1;
+        }
+        if (colsum) *colsum += cs;
+    };
+    auto stash = [&](int tid, int64_t blk, const Stage &q, unsigned char *buf) {
+        const int lane = tid & 63, wave = tid >> 6, hi = lane >> 5, sl = lane & 31;
+        const bool live = blk * 32 + sl < a.n;           // lane = sample here: samples past the end contribute nothing
+        unsigned char *zf = buf, *xf = buf + ZBYTES;
+        auto unpack = [&](const uint4 (&pp)[NV], float (&c0)[8], float (&c1)[8]) {
+            if (MODE == 1) {                             // the two 1 KB pieces are the tile's chunks
+                const bf16x8 a0 = *reinterpret_cast<const bf16x8 *>(&pp[0]), a1 = *reinterpret_cast<const bf16x8 *>(&pp[NV > 1 ? 1 : 0]);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int f = 8 * piece + 4 * hi + j;
-                        if (!ZROWS) { put(ZT, 256, f, sl, live ? z[j] : 0.f); bsum[4 * v + j] += live ? z[j] : 0.f; }
-                        if (use_frag) put(XT, XROWS_T, f, sl, live ? xx[j] : 0.f);
-                    }
+                for (int j = 0; j < 8; ++j) { c0[j] = live ? (float)a0[j] : 0.f; c1[j] = live ? (float)a1[j] : 0.f; }
+            } else {                                     // pieces q = 0 .. 3: chunk u = q >> 1, k-slots 4 (q & 1) ..
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    const float4 v = *reinterpret_cast<const float4 *>(&pp[qq % NV]);
+                    float *c = qq < 2 ? c0 : c1;
+                    c[4 * (qq & 1)] = live ? v.x : 0.f; c[4 * (qq & 1) + 1] = live ? v.y : 0.f;
+                    c[4 * (qq & 1) + 2] = live ? v.z : 0.f; c[4 * (qq & 1) + 3] = live ? v.w : 0.f;
                 }
             }
-            const int s = tid & 31, f0 = 4 * (tid >> 5);
-            const bool lives = blk * 32 + s < a.n;
-            if (use_rows && f0 < a.n_rows) {             // thread -> (sample tid & 31, features 4 (tid >> 5) ..)
-                const float ev[4] = {q.pe.x, q.pe.y, q.pe.z, q.pe.w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) put(XT, XROWS_T, rows_at + f0 + j, s, lives ? ev[j] : 0.f);
-            }
-            if (ZROWS && f0 < 32) {
-                const float zv[4] = {q.pzr.x, q.pzr.y, q.pzr.z, q.pzr.w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { put(ZT, 256, f0 + j, s, lives ? zv[j] : 0.f); bsum[j] += lives ? zv[j] : 0.f; }
-            }
         };
-        auto stage = [&](auto slot_c, int64_t blk) {
-            constexpr int SL = decltype(slot_c)::value;
+        auto unrows = [&](const float4 (&r)[4], float (&c0)[8], float (&c1)[8]) {
+            c0[0] = r[0].x; c0[1] = r[0].y; c0[2] = r[0].z; c0[3] = r[0].w; c0[4] = r[1].x; c0[5] = r[1].y; c0[6] = r[1].z; c0[7] = r[1].w;
+            c1[0] = r[2].x; c1[1] = r[2].y; c1[2] = r[2].z; c1[3] = r[2].w; c1[4] = r[3].x; c1[5] = r[3].y; c1[6] = r[3].z; c1[7] = r[3].w;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { c0[j] = live ? c0[j] : 0.f; c1[j] = live ? c1[j] : 0.f; }
+        };
+        float c0[8], c1[8];
+        if (!ZROWS) {
+            unpack(q.pz, c0, c1);
+            transpose_store(c0, c1, true, lane, zf + wave * 2 * NP * 1024, &bsum);
+        } else if (wave == 0) {
+            unrows(q.rz, c0, c1);
+            transpose_store(c0, c1, false, lane, zf, nullptr);
+            if (hi == 0) {                               // bias of a narrow layer: fp32 sums of the rows' own values (columns 0 .. 3)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bs4[j] += c0[j];
+            }
+        }
+        if (XFRAG) {
+            unpack(q.px, c0, c1);
+            transpose_store(c0, c1, true, lane, xf + wave * 2 * NP * 1024, nullptr);
+        }
+        if (XROWS && wave < kt_rows) {
+            unrows(q.rx, c0, c1);
+            transpose_store(c0, c1, false, lane, xf + (XR0 + wave) * 2 * NP * 1024, nullptr);
+        }
+    };
+    auto products = [&](int tid, const unsigned char *buf) {
+        const int lane = tid & 63, wave = tid >> 6;
+        const unsigned char *zf = buf + lane * 16, *xf = buf + ZBYTES + lane * 16;
+        if (has_tile) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 az[NP];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) az[p] = *reinterpret_cast<const bf16x8 *>(zf + ((wave * 2 + ks) * NP + p) * 1024);
+#pragma unroll
+                for (int t = 0; t < NXT; t += 2)         // two input tiles at a time: consecutive MFMAs alternate accumulators
+                    if (t >= XR0 ? t - XR0 < kt_rows : t < kt_frag) {
+                        bf16x8 bx[2][NP];
+#pragma unroll
+                        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                            for (int p = 0; p < NP; ++p)
+                                bx[tt][p] = *reinterpret_cast<const bf16x8 *>(xf + (((t + tt) * 2 + ks) * NP + p) * 1024);
+#pragma unroll
+                        for (int k = 0; k < PRD::N; ++k) {
+                            acc[t] = MFMAB(az[PRD::W[k]], bx[0][PRD::A[k]], acc[t]);
+                            acc[t + 1] = MFMAB(az[PRD::W[k]], bx[1][PRD::A[k]], acc[t + 1]);       // (odd tile counts: never stored)
+                        }
+                    }
+            }
+        }
+    };
+    const int64_t b0 = blockIdx.x;
+    if (DB) {
+        // stage i+1 is transposed into the other buffer while the products of stage i are read from this one: one barrier a stage
+        fetch(threadIdx.x, b0 < n_blk ? b0 : n_blk - 1, sq[0]);
+        if (b0 < n_blk) {
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));
+            stash(tid, b0, sq[0], smem_td);
+            fetch(tid, b0 + n_splits < n_blk ? b0 + n_splits : n_blk - 1, sq[0]);
+        }
+        __syncthreads();
+        int cur = 0;
+        for (int64_t blk = b0; blk < n_blk; blk += n_splits) {
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));
+            const int64_t nxt = blk + n_splits;
+            if (nxt < n_blk) {
+                stash(tid, nxt, sq[0], smem_td + (cur ^ 1) * BUFBYTES);
+                fetch(tid, nxt + n_splits < n_blk ? nxt + n_splits : n_blk - 1, sq[0]);
+            }
+            products(tid, smem_td + cur * BUFBYTES);
+            __syncthreads();
+            cur ^= 1;
+        }
+    } else {
+        fetch(threadIdx.x, b0 < n_blk ? b0 : n_blk - 1, sq[0]);
+        for (int64_t blk = b0; blk < n_blk; blk += n_splits) {
             int tid = threadIdx.x;
             asm volatile("" : "+v"(tid));
             __syncthreads();
-            stash(tid, blk, sq[SL]);
+            stash(tid, blk, sq[0], smem_td);
             __syncthreads();
-            const int64_t nxt = blk + 2 * (int64_t)n_splits;
-            fetch(tid, nxt < n_blk ? nxt : n_blk - 1, sq[SL]);         // unconditional (past the end: the last block, unused)
-            const int lane = tid & 63, wave = tid >> 6, hi = lane >> 5, sl = lane & 31;
-            if (has_tile) {
+            fetch(tid, blk + n_splits < n_blk ? blk + n_splits : n_blk - 1, sq[0]);
+            products(tid, smem_td);
+        }
+    }
+    const int lane = threadIdx.x & 63, hi = lane >> 5, sl = lane & 31;
+    if (has_tile) {
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    bf16x8 az[NP];
+        for (int t = 0; t < NXT; ++t) {
+            // tile t -> input column: the slot part first, the encoding part after it
+            const int k = a.k_base + (t >= XR0 ? kt_frag * 32 + (t - XR0) * 32 + sl : t * 32 + sl);
+            const bool valid = t >= XR0 ? t - XR0 < kt_rows : t < kt_frag;
+            if (!valid || k >= a.K) continue;
 #pragma unroll
-                    for (int p = 0; p < NP; ++p)
-                        az[p] = *reinterpret_cast<const bf16x8 *>(ZT + (p * 256 + wave * 32 + sl) * TDW_ST + 16 * ks + 8 * hi);
-#pragma unroll
-                    for (int t = 0; t < NACC; t += 2)    // two input tiles at a time: consecutive MFMAs alternate accumulators
-                        if (NACC == 10 || t < kt) {
-                            bf16x8 bx[2][NP];
-#pragma unroll
-                            for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-                                for (int p = 0; p < NP; ++p)
-                                    bx[tt][p] = *reinterpret_cast<const bf16x8 *>(XT + (p * XROWS_T + (t + tt) * 32 + sl) * TDW_ST + 16 * ks + 8 * hi);
-#pragma unroll
-                            for (int k = 0; k < PRD::N; ++k) {
-                                acc[t] = MFMAB(az[PRD::W[k]], bx[0][PRD::A[k]], acc[t]);
-                                acc[t + 1] = MFMAB(az[PRD::W[k]], bx[1][PRD::A[k]], acc[t + 1]);       // (odd tile counts: never stored)
-                            }
-                        }
-                }
-            }
-        };
-        {
-            const int64_t b0 = blockIdx.x;
-            fetch(threadIdx.x, b0 < n_blk ? b0 : n_blk - 1, sq[0]);
-            fetch(threadIdx.x, b0 + n_splits < n_blk ? b0 + n_splits : n_blk - 1, sq[1]);
-            for (int64_t blk = b0; blk < n_blk; blk += 2 * (int64_t)n_splits) {
-                stage(IntC<0>(), blk);
-                if (blk + n_splits < n_blk) stage(IntC<1>(), blk + n_splits);
+            for (int g = 0; g < 16; ++g) {
+                const int o = wave_k * 32 + rowc(g) + 4 * hi;
+                if (o < a.N) sw[(int64_t)o * a.K + k] = acc[t][g];
             }
         }
-        const int lane = threadIdx.x & 63, hi = lane >> 5, sl = lane & 31;
-        if (has_tile) {
+    }
+    // bias gradient: lane (feature sl of the wave's dz tile, hi) summed 16 of the 32 samples of every stage
+    if (ZROWS) {
+        if (wave_k == 0) {
 #pragma unroll
-            for (int t = 0; t < NACC; ++t) {
-                // XT tile t -> input column: the fragment part first, the encoding part after it
-                const int k = NACC == 10 ? t * 32 + sl : k0 + t * 32 + sl;
-                const bool valid = NACC == 10 ? (t < 8 || (t - 8) < a.n_rows / 32) : t < kt;
-                if (!valid || k >= a.K) continue;
+            for (int j = 0; j < 4; ++j) {
+                float v = bs4[j];
 #pragma unroll
-                for (int g = 0; g < 16; ++g) {
-                    const int o = wave_k * 32 + rowc(g) + 4 * hi;
-                    if (o < a.N) sw[(int64_t)o * a.K + k] = acc[t][g];
-                }
+                for (int off = 1; off < 32; off <<= 1) v += __shfl_xor(v, off, 64);
+                if (lane == 0 && j < a.N) sb[j] = v;
             }
         }
-        if (pass == 0) {                                 // bias gradient: sum over the 32 sample lanes
-            if (ZROWS) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float s = bsum[j];
-#pragma unroll
-                    for (int off = 1; off < 32; off <<= 1) s += __shfl_xor(s, off, 64);
-                    const int f = 4 * (threadIdx.x >> 5) + j;
-                    if ((threadIdx.x & 31) == 0 && f < a.N && f < 32) sb[f] = s;
-                }
-            } else {
-#pragma unroll
-                for (int v = 0; v < NV; ++v)
-#pragma unroll
-                    for (int j = 0; j < FPP; ++j) {
-                        float s = bsum[FPP * v + j];
-#pragma unroll
-                        for (int off = 1; off < 32; off <<= 1) s += __shfl_xor(s, off, 64);
-                        const int piece = wave_k * NV + v;
-                        const int f = MODE == 1 ? kmap(piece, hi, j) : 8 * piece + 4 * hi + j;
-                        if (sl == 0 && f < a.N) sb[f] = s;
-                    }
-            }
+    } else {
+        bsum += __shfl_xor(bsum, 32, 64);
+        if (hi == 0 && !a.skip_bias) {
+            const int f = wave_k * 32 + sl;
+            if (f < a.N) sb[f] = bsum;
         }
-        __syncthreads();
     }
 }
 
@@ -1146,14 +1197,19 @@ extern "C" int ren_vanilla_bwd_weight(const void *dz, const void *saved, const f
         const bool zrows = a.dz_rows != nullptr, xfrag = a.x != nullptr, xrows = a.x_rows != nullptr;
 #define REN_VFIELD_DW(MODE, ZR, XF, XR)                                                                                         \
     do {                                                                                                                        \
-        const size_t lds = (size_t)vfield_np(MODE) * (256 + ((XF) && (XR) && MODE == 1 ? 320 : 256)) * TDW_ST * 2;             \
+        const size_t lds = (size_t)(MODE == 1 ? 2 : 1) * (8 + ((XF) && (XR) ? 10 : 8)) * 2 * vfield_np(MODE) * 1024;                 \
         (void)hipFuncSetAttribute((const void *)vfield_dw_kernel<MODE, ZR, XF, XR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((vfield_dw_kernel<MODE, ZR, XF, XR>), dim3(n_splits), dim3(512), lds, st, a);                         \
     } while (0)
 #define REN_VFIELD_DW_MODE(MODE)                                                                                                \
     do {                                                                                                                        \
         if (zrows) REN_VFIELD_DW(MODE, true, true, false);                                                                      \
-        else if (xfrag && xrows) REN_VFIELD_DW(MODE, false, true, true);                                                        \
+        else if (xfrag && xrows && MODE == 1) REN_VFIELD_DW(MODE, false, true, true);                                           \
+        else if (xfrag && xrows) {             /* fp32 mode: 10 input tiles of accumulators do not fit: two launches */            \
+            REN_VFIELD_DW(MODE, false, true, false);                                                                            \
+            a.k_base = a.nx; a.skip_bias = 1;                                                                                   \
+            REN_VFIELD_DW(MODE, false, false, true);                                                                            \
+        }                                                                                                                       \
         else if (xfrag) REN_VFIELD_DW(MODE, false, true, false);                                                                \
         else REN_VFIELD_DW(MODE, false, false, true);                                                                           \
     } while (0)
