@@ -48,13 +48,17 @@ PMC_TRAFFIC = os.path.join(REPO, "profiles", "r03_pmc_traffic.json")
 def pmc_traffic(call, args):
     """HBM bytes per launch of `call` from the committed rocprofv3 PMC passes (tools/pmc_traffic.py), or None
     when they were taken on a different workload."""
+    path = PMC_TRAFFIC
+    if args.arch == "mlp":
+        path = PMC_TRAFFIC.replace(".json", "_arch_mlp_bf16.json" if args.mlp_bf16 else "_arch_mlp.json")
     try:
-        t = json.load(open(PMC_TRAFFIC))
+        t = json.load(open(path))
     except OSError:
         return None
     w = t.get("workload", {})
     same = (w.get("events") == args.events and w.get("samples") == args.samples and
-            w.get("sampler") == args.sampler and float(w.get("loss_grad", 0.0)) == float(args.loss_grad))
+            w.get("sampler") == args.sampler and float(w.get("loss_grad", 0.0)) == float(args.loss_grad) and
+            w.get("arch", "ngp") == args.arch and bool(w.get("mlp_bf16", False)) == (bool(args.mlp_bf16) if args.arch == "mlp" else False))
     c = t.get("calls", {}).get(call)
     return c["hbm_bytes_per_launch"] if (same and c) else None
 

@@ -23,6 +23,13 @@ GROUPS = {  # C-ABI call -> (kernel-name fragment, launches of that kernel per c
     "mlp_fwd_save": [("mlp_fwd_kernel", 1)],
     "mlp_bwd_saved": [("mlp_bwd_head_kernel", 1), ("mlp_bwd_base_kernel", 1), ("reduce_slabs_kernel", 2)],
 }
+# arch mlp (csrc/ren_vfield.hip): calls that launch several template instantiations -- all bytes of the matching kernels
+# divided by the number of calls (= launches of the reference kernel, one per call)
+CALLS = {
+    "vfield_fwd": (["vfield_fwd"], "vfield_fwd"),
+    "vfield_bwd": (["vfield_bwd"], "vfield_bwd"),
+    "vfield_bwd_weight": (["vfield_dw_kernel", "reduce_slabs_kernel"], "vfield_bwd"),
+}
 
 
 def per_kernel(db):
@@ -32,11 +39,15 @@ def per_kernel(db):
     q = f"""select s.kernel_name, count(*), sum(p.value) from {T('pmc_event')} p
             join {T('kernel_dispatch')} k on p.event_id=k.event_id
             join {T('info_kernel_symbol')} s on k.kernel_id=s.id group by s.kernel_name"""
-    return {name: tot / cnt for name, cnt, tot in cur.execute(q)}
+    rows = list(cur.execute(q))
+    per_kernel.totals = {name: (cnt, tot) for name, cnt, tot in rows}
+    return {name: tot / cnt for name, cnt, tot in rows}
 
 
 def main():
-    fetch, write, dst = per_kernel(sys.argv[1]), per_kernel(sys.argv[2]), sys.argv[3]
+    fetch = per_kernel(sys.argv[1]); ftot = per_kernel.totals
+    write = per_kernel(sys.argv[2]); wtot = per_kernel.totals
+    dst = sys.argv[3]
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) around "
                      "`python bench.py --steps 2 --warmup 1 --no-cpu-baseline --fwd-chunks 1`",
            "corrections": "bytes = 1024 x counter; FETCH_SIZE doubled (gfx950, MI355X_MICROARCH.md HBM section)",
@@ -47,6 +58,17 @@ def main():
             f += mult * sum(v for k, v in fetch.items() if frag in k) * 2 * 1024
             w += mult * sum(v for k, v in write.items() if frag in k) * 1024
         out["calls"][call] = {"fetch_bytes_per_launch": f, "write_bytes_per_launch": w, "hbm_bytes_per_launch": f + w}
+    if len(sys.argv) > 4:                                    # workload of an arch-mlp pass: '{"events": 4096, "arch": "mlp", ...}'
+        out["workload"] = json.loads(sys.argv[4])
+        out["source"] = out["source"].replace("--fwd-chunks 1", "--arch mlp --events 4096 [--mlp-bf16]")
+    for call, (frags, ref) in CALLS.items():
+        n_calls = sum(c for k, (c, _) in ftot.items() if ref in k)
+        if not n_calls:
+            continue
+        f = sum(t for k, (_, t) in ftot.items() if any(fr in k for fr in frags)) * 2 * 1024 / n_calls
+        w = sum(t for k, (_, t) in wtot.items() if any(fr in k for fr in frags)) * 1024 / n_calls
+        out["calls"][call] = {"fetch_bytes_per_launch": f, "write_bytes_per_launch": w, "hbm_bytes_per_launch": f + w}
+    out["calls"] = {k: v for k, v in out["calls"].items() if v["hbm_bytes_per_launch"] > 0}
     json.dump(out, open(dst, "w"), indent=1)
     print(json.dumps(out["calls"], indent=1))
 
