@@ -867,6 +867,7 @@ __global__ __launch_bounds__(512, 1) void vfield_dw_kernel(FieldDwArgs a) {
     constexpr int NXT = XFRAG && XROWS ? 10 : 8;         // input tiles held in LDS: the slot's, then the encoding's
     constexpr int XR0 = XFRAG ? 8 : 0;                   // first encoding tile
     constexpr bool DB = MODE == 1;                       // bf16 mode: double-buffered operand fragments (36 KB each)
+    constexpr int RD = (DB && ZROWS) ? 4 : 1;           // stages of loads in flight: narrow layers do little per stage (wide ones: 2 measured slower)
     constexpr int ZBYTES = 8 * 2 * NP * 1024, BUFBYTES = ZBYTES + NXT * 2 * NP * 1024;
     using PRD = Pairs<MODE>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_td[];
@@ -876,6 +877,7 @@ __global__ __launch_bounds__(512, 1) void vfield_dw_kernel(FieldDwArgs a) {
     const bool has_tile = wave_k * 32 < a.N;
     float *sw = a.slab_w + (int64_t)blockIdx.x * a.N * a.K, *sb = a.slab_b + (int64_t)blockIdx.x * a.N;
     const int kt_frag = XFRAG ? a.nx / 32 : 0, kt_rows = XROWS ? a.n_rows / 32 : 0;
+    const int nzt = a.N >= 256 ? 8 : a.N > 64 ? 4 : 8, nxt_ = kt_frag == 4 ? 4 : 8;     // valid 32-feature tiles of the dz / x slots
 
     f32x16 acc[NXT];
 #pragma unroll
@@ -885,7 +887,7 @@ __global__ __launch_bounds__(512, 1) void vfield_dw_kernel(FieldDwArgs a) {
     float bsum = 0.f;                                    // lane = feature (transposed layout): one partial per lane
     float bs4[4] = {0.f, 0.f, 0.f, 0.f};                 // ZROWS: lane = sample, columns 0 .. 3
     struct Stage { uint4 pz[NV], px[NV]; float4 rz[4], rx[4]; };
-    Stage sq[DB ? 2 : 1];
+    Stage sq[RD];
     // `tid`: an opaque copy of threadIdx.x (see `stage`): the addresses derived from it are computed per stage instead of once
     // per kernel (where they spilled)
     auto fetch = [&](int tid, int64_t blk, Stage &q) {
@@ -894,8 +896,9 @@ __global__ __launch_bounds__(512, 1) void vfield_dw_kernel(FieldDwArgs a) {
         const uint4 *xb = reinterpret_cast<const uint4 *>(reinterpret_cast<const ST *>(a.x) + blk * 32 * 256);
 #pragma unroll
         for (int v = 0; v < NV; ++v) {                   // wave w: tile w of dz and of the slot part of x
-            if (!ZROWS) q.pz[v] = zb[(wave * NV + v) * 64 + lane];
-            if (XFRAG) q.px[v] = xb[(wave * NV + v) * 64 + lane];
+            // (128-feature slots: the upper waves re-read the lower tiles -- cache hits instead of HBM reads of unused pieces)
+            if (!ZROWS) q.pz[v] = zb[((wave & (nzt - 1)) * NV + v) * 64 + lane];
+            if (XFRAG) q.px[v] = xb[((wave & (nxt_ - 1)) * NV + v) * 64 + lane];
         }
         // row-major sources: lane = sample, 2 x 8 consecutive columns per 16-column chunk of the wave's 32-column tile
         if (XROWS) {
@@ -1015,27 +1018,32 @@ __global__ __launch_bounds__(512, 1) void vfield_dw_kernel(FieldDwArgs a) {
     };
     const int64_t b0 = blockIdx.x;
     if (DB) {
-        // stage i+1 is transposed into the other buffer while the products of stage i are read from this one: one barrier a stage
-        fetch(threadIdx.x, b0 < n_blk ? b0 : n_blk - 1, sq[0]);
-        if (b0 < n_blk) {
+        // Stage i+1 is transposed into the other LDS buffer while the products of stage i are read from this one: one barrier
+        // a stage.  RD stages of loads are in flight (narrow layers do so little per stage that one stage of lead time is
+        // shorter than the HBM latency).  Everything in the loop is unconditional -- blocks past the end are clamped loads
+        // whose samples count as not live -- so that the compiler's load counters stay exact (counted vmcnt waits).
+        const int64_t S = n_splits, n_it = b0 < n_blk ? (n_blk - b0 + S - 1) / S : 0, n_it_pad = (n_it + RD - 1) / RD * RD;
+        auto clampb = [&](int64_t blk) { return blk < n_blk ? blk : n_blk - 1; };
+#pragma unroll
+        for (int k = 0; k < RD; ++k) fetch(threadIdx.x, clampb(b0 + k * S), sq[k]);
+        if (n_it) {
             int tid = threadIdx.x;
             asm volatile("" : "+v"(tid));
             stash(tid, b0, sq[0], smem_td);
-            fetch(tid, b0 + n_splits < n_blk ? b0 + n_splits : n_blk - 1, sq[0]);
+            fetch(tid, clampb(b0 + RD * S), sq[0]);
         }
         __syncthreads();
-        int cur = 0;
-        for (int64_t blk = b0; blk < n_blk; blk += n_splits) {
-            int tid = threadIdx.x;
-            asm volatile("" : "+v"(tid));
-            const int64_t nxt = blk + n_splits;
-            if (nxt < n_blk) {
-                stash(tid, nxt, sq[0], smem_td + (cur ^ 1) * BUFBYTES);
-                fetch(tid, nxt + n_splits < n_blk ? nxt + n_splits : n_blk - 1, sq[0]);
+        for (int64_t i = 0; i < n_it_pad; i += RD) {
+#pragma unroll
+            for (int k = 0; k < RD; ++k) {
+                int tid = threadIdx.x;
+                asm volatile("" : "+v"(tid));
+                const int64_t ii = i + k, nxt = b0 + (ii + 1) * S;               // (nominal: may be past the end)
+                stash(tid, nxt, sq[(k + 1) % RD], smem_td + ((ii + 1) & 1) * BUFBYTES);
+                fetch(tid, clampb(nxt + RD * S), sq[(k + 1) % RD]);
+                products(tid, smem_td + (ii & 1) * BUFBYTES);
+                __syncthreads();
             }
-            products(tid, smem_td + cur * BUFBYTES);
-            __syncthreads();
-            cur ^= 1;
         }
     } else {
         fetch(threadIdx.x, b0 < n_blk ? b0 : n_blk - 1, sq[0]);
