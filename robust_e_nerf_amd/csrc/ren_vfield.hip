@@ -555,6 +555,207 @@ __global__ __launch_bounds__(256, 1) void vfield_bwd_kernel(FieldArgs a) {
     }
 }
 
+// ---- bf16 mode forward, software-pipelined --------------------------------------------------------------------------------
+// In vfield_fwd_kernel<1> the matrix cores idle while a wave runs the activation epilogue (per output: accumulator read, bias,
+// two quarter-rate transcendentals, pack: ~1.5x the MFMA time of a layer, and with one wave per SIMD nothing else to issue).
+// Here the epilogue of tile group g is issued between the MFMAs of group g + 1 -- in eight slices of eight values, one
+// every second k-chunk -- and the last group of a layer between the first MFMAs of the NEXT layer, whose k-chunks 0 .. 11
+// do not depend on it.  The outputs of a layer's finished groups wait in a second operand set `xn` until the layer ends.
+// The saved copies of a slice group are stored at the START of the following stage (from the operand registers they sit in
+// anyway): a store issued inside a stage is still in flight at the stage's closing barrier, whose fence waits for it
+// (+0.3 ms per pass when the slices issued them; one burst per layer instead spilled 136 registers).
+template <int NH_, int NE_, int NT_, int ACT_, int PACT_, int PNT_, int S0_ = -1> struct Shape1 {
+    static constexpr int NH = NH_, NE = NE_, NT = NT_, ACT = ACT_, PACT = PACT_, PNT = PNT_;     // P*: the pending tile group's layer
+    static constexpr int S0 = S0_;                       // >= 0: first of four operand chunks whose saved copy this layer's first stage stores as well
+};
+
+template <bool SAVE, bool FULL>
+__global__ __launch_bounds__(256, 1) void vfield_fwd1_kernel(FieldArgs a) {
+    constexpr int NB = 2, NTS = 2;
+    constexpr int STAGE = NTS * 20 * 1024;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+    float *bias = reinterpret_cast<float *>(smem_all);
+    unsigned char *smem_tf = smem_all + LB_FLOATS * 4;
+    const int lane_k = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane16_k = lane_k * 16;
+    for (int i = threadIdx.x; i < LB_FLOATS; i += 256) {
+        float b = 0.f;
+        if (i < 2048) b = a.P[l_boff(i >> 8, a.C) + (i & 255)];
+        else if (i < LB_RGBH) b = a.P[l_boff(L_BOTT, a.C) + i - LB_BOTT];
+        else if (i < LB_SIGMA) b = a.P[l_boff(L_RGBH, a.C) + i - LB_RGBH];
+        else if (i == LB_SIGMA) b = a.P[l_boff(L_SIGMA, a.C)];
+        else if (i >= LB_RGBO && i < LB_RGBO + a.C) b = a.P[l_boff(L_RGBO, a.C) + i - LB_RGBO];
+        bias[i] = b;
+    }
+    const int64_t n_blk = (a.n + 31) >> 5, n_grp = (n_blk + 4 * NB - 1) / (4 * NB);
+    const size_t sstride = (size_t)n_grp * 4 * NB * 32 * 256;
+
+    auto issue = [&](int l, int tg, int buf) {
+        const int nch = l_nch(l), nts = min(NTS, l_nt(l) - tg * NTS), pieces = nts * nch;
+        uint32_t off = (uint32_t)(f_off(l) + tg * NTS * nch) * 1024 + wave * 1024;
+        unsigned char *dst = smem_tf + buf * STAGE + wave * 1024;
+        for (int i = wave; i < pieces; i += 4) {
+            asm volatile("" : "+s"(off));
+            glds16(reinterpret_cast<const unsigned char *>(a.img) + off + lane16_k, dst);
+            off += 4096; dst += 4096;
+        }
+    };
+    int buf = 0;
+    if ((int64_t)blockIdx.x < n_grp) issue(0, 0, 0);
+    for (int64_t grp = blockIdx.x; grp < n_grp; grp += gridDim.x) {
+        const int64_t blk0_g = (grp * 4 + wave) * NB;
+        const bool more_grp = grp + gridDim.x < n_grp;
+        bf16x8 x[NB][16], xn[NB][12];
+        f32x16 pend[NB][2];                              // the previous layer's last tile group, epilogue not yet run
+        // l: this layer, ln: the layer whose first stage follows (-1: none), slot: its saved slot; pl / pslot: the layer the
+        // pending group belongs to
+        auto layer = [&](auto shape, const int l, const int ln, const int slot, const int pl, const int pslot) {
+            using S = decltype(shape);
+            constexpr int NH = S::NH, NE = S::NE, NT = S::NT, ACT = S::ACT, PACT = S::PACT, PNT = S::PNT, nch = NH + NE;
+            constexpr int NTG = (NT + NTS - 1) / NTS;
+            constexpr int PC0 = PACT >= 0 ? 2 * PNT - 4 : 0;             // k-chunks the pending group will become
+            uint32_t lane16 = lane16_k;
+            int64_t blk0 = blk0_g;
+            asm volatile("" : "+v"(lane16), "+s"(blk0));
+            const int lane = lane16 >> 4, hi = lane >> 5, sl = lane & 31;
+            if (PACT >= 0) {
+#pragma unroll
+                for (int u = 0; u < NB; ++u)
+#pragma unroll
+                    for (int c = 0; c < PC0; ++c) x[u][c] = xn[u][c];
+            }
+            bf16x8 e[NB][4];
+            if (NE) {
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const int64_t blk = blk0 + u < n_blk ? blk0 + u : n_blk - 1;
+                    const float *xp = (NE == 4 ? a.enc + (blk * 32 + sl) * a.ld_enc : a.view + (blk * 32 + sl) * a.ld_view) + 8 * hi;
+#pragma unroll
+                    for (int c = 0; c < NE; ++c) {
+                        const float4 v0 = *reinterpret_cast<const float4 *>(xp + 16 * c), v1 = *reinterpret_cast<const float4 *>(xp + 16 * c + 4);
+                        const float xs[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                        bf16x8 o[3];
+                        split8<1>(xs, o);
+                        e[u][c] = o[0];
+                    }
+                }
+            }
+            // eight values of one tile (half h of its 16 registers) -> one k-chunk of the next layer (+ the saved copy)
+            auto slice = [&](auto act_c, const f32x16 &tile, const int t, const int h, const float *bl, const int u, bf16x8 &dst,
+                             const int sslot) {
+                constexpr int A = decltype(act_c)::value;
+                const float4 b0 = *reinterpret_cast<const float4 *>(bl + t * 32 + 16 * h + 4 * hi);
+                const float4 b1 = *reinterpret_cast<const float4 *>(bl + t * 32 + 16 * h + 8 + 4 * hi);
+                const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+                bf16x8 p;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float v = tile[8 * h + j] + bb[j];
+                    p[j] = (__bf16)(A == A_SP100 ? softplus100(v) : v);
+                }
+                dst = p;
+                (void)sslot; (void)u;
+            };
+            // saved copy of four operand chunks c0 .. c0 + 3 (both blocks) of slot sslot, from x or xn
+            auto late_store = [&](const bool from_x, const int c0, const int sslot) {
+                if (!SAVE) return;
+                __bf16 *sv = reinterpret_cast<__bf16 *>(a.acts) + (size_t)sslot * sstride;
+#pragma unroll
+                for (int u = 0; u < NB; ++u)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        *reinterpret_cast<bf16x8 *>(sv + (((blk0 + u) * 16 + c0 + k) * 64 + lane) * 8) = from_x ? x[u][(c0 + k) & 15] : xn[u][(c0 + k) % 12];
+            };
+            f32x16 acc[NB][NT];
+#pragma unroll
+            for (int tg = 0; tg < NTG; ++tg) {
+                __syncthreads();
+                if (tg + 1 < NTG) issue(l, tg + 1, buf ^ 1);
+                else if (ln >= 0) issue(ln, 0, buf ^ 1);
+                const unsigned char *st = smem_tf + buf * STAGE + lane16;
+                // saved copies of what the previous stage's slices produced
+                if (tg == 0 && PACT >= 0) late_store(true, 2 * PNT - 8, pslot);
+                if (tg == 0 && S::S0 >= 0) late_store(true, S::S0, pslot);
+                if (tg == 1 && PACT >= 0) late_store(true, PC0, pslot);
+                if (tg >= 2) late_store(false, 4 * (tg - 2), slot);
+#pragma unroll
+                for (int tt = 0; tt < NTS; ++tt)
+                    if (tg * NTS + tt < NT) {
+#pragma unroll
+                        for (int g = 0; g < 16; ++g)
+#pragma unroll
+                            for (int u = 0; u < NB; ++u) acc[u][tg * NTS + tt][g] = 0.f;
+                    }
+                // the eight slices of the group whose epilogue runs inside this stage, spread over its first LIM k-chunks
+                const bool HAS = tg == 0 ? PACT >= 0 : true;
+                const int LIM = tg == 0 ? (PC0 < nch ? PC0 : nch) : nch;
+#pragma unroll
+                for (int c = 0; c < nch; ++c) {
+#pragma unroll
+                    for (int tt = 0; tt < NTS; ++tt) {
+                        const int t = tg * NTS + tt;
+                        if (t >= NT) continue;
+                        const bf16x8 w = *reinterpret_cast<const bf16x8 *>(st + (tt * nch + c) * 1024);
+#pragma unroll
+                        for (int u = 0; u < NB; ++u) acc[u][t] = MFMAB(w, c < NH ? x[u][c & 15] : e[u][(c - NH) & 3], acc[u][t]);
+                    }
+                    if (HAS && c < LIM) {
+#pragma unroll
+                        for (int s = c * 8 / (LIM > 0 ? LIM : 1); s < (c + 1) * 8 / (LIM > 0 ? LIM : 1); ++s) {
+                            const int u = s >> 2, tt = (s >> 1) & 1, h = s & 1;
+                            if (tg == 0) {
+                                const int t = PNT - 2 + tt;
+                                slice(IntC<(PACT >= 0 ? PACT : 0)>(), pend[u][tt], t, h, bias + lb_off(pl), u, x[u][(2 * t + h) & 15], pslot);
+                            } else {
+                                const int t = 2 * (tg - 1) + tt;
+                                slice(IntC<ACT>(), acc[u][t < NT ? t : 0], t, h, bias + lb_off(l), u, xn[u][(2 * t + h) % 12], slot);
+                            }
+                        }
+                    }
+                }
+                buf ^= 1;
+                TRUNK_FENCE();
+            }
+            const float *bl = bias + lb_off(l);
+            if (ACT == A_RGB && PACT >= 0) late_store(true, PC0, pslot);              // last layer: nothing follows
+            if (ACT == A_SIGMA) {
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const int64_t row = (blk0 + u) * 32 + sl;
+                    if (hi == 0 && row < a.n) a.sigma[row] = a.sel[row] ? __expf(acc[u][0][0] + bl[0] - 1.f) : 0.f;
+                }
+            } else if (ACT == A_RGB) {
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const int64_t row = (blk0 + u) * 32 + sl;
+                    if (hi == 0 && row < a.n) {
+                        float r[4];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) r[c] = c < a.C ? softplus1(acc[u][0][c] + bl[c]) : 0.f;
+                        *reinterpret_cast<float4 *>(a.rgb4 + row * 4) = make_float4(r[0], r[1], r[2], r[3]);
+                    }
+                }
+            } else {                                     // the last tile group stays pending
+#pragma unroll
+                for (int u = 0; u < NB; ++u)
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) pend[u][tt] = acc[u][NT >= 2 ? NT - 2 + tt : 0];
+            }
+        };
+        layer(Shape1<0, 4, 8, A_SP100, -1, 8>(), 0, 1, 0, 0, 0);
+        for (int l = 1; l < L_SKIP; ++l) layer(Shape1<16, 0, 8, A_SP100, A_SP100, 8>(), l, l + 1, l, l - 1, l - 1);
+        layer(Shape1<16, 4, 8, A_SP100, A_SP100, 8>(), L_SKIP, 6, L_SKIP, 4, 4);
+        layer(Shape1<16, 0, 8, A_SP100, A_SP100, 8>(), 6, 7, 6, 5, 5);
+        layer(Shape1<16, 0, 8, A_SP100, A_SP100, 8>(), 7, L_SIGMA, 7, 6, 6);
+        layer(Shape1<16, 0, 1, A_SIGMA, A_SP100, 8>(), L_SIGMA, FULL ? L_BOTT : (more_grp ? 0 : -1), -1, 7, 7);
+        if (FULL) {
+            layer(Shape1<16, 0, 8, A_NONE, -1, 8, 12>(), L_BOTT, L_RGBH, 8, 7, 7);      // (+ the copy of layer 7's last group, finished inside the sigma stage)
+            layer(Shape1<16, 2, 4, A_SP100, A_NONE, 8>(), L_RGBH, L_RGBO, 9, L_BOTT, 8);
+            layer(Shape1<8, 0, 1, A_RGB, A_SP100, 4>(), L_RGBO, more_grp ? 0 : -1, -1, L_RGBH, 9);
+        }
+    }
+}
+
 // ---- fp32 mode (three-piece split): reduction-outer variants -------------------------------------------------------------------
 // Three bf16 pieces of 256 activations are 192 operand registers per 32-sample block: beside the weight fragments and the
 // epilogue they do not fit in the 256 architectural VGPRs (the tile-outer kernels above, instantiated for this mode, spilled
@@ -1144,7 +1345,15 @@ extern "C" int ren_vanilla_fwd(const float *enc, int32_t ld_enc, const float *vi
         (void)hipFuncSetAttribute((const void *)vfield_fwd_kernel<MODE, SAVE, FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_lds<MODE>()); \
         hipLaunchKernelGGL((vfield_fwd_kernel<MODE, SAVE, FULL>), dim3(vfield_grid(n, TC<MODE>::NB)), dim3(256), fwd_lds<MODE>(), st, a); \
     } while (0)
-    if (mode == 1) { if (saved) REN_VFIELD_FWD(1, true, true); else if (rgb4) REN_VFIELD_FWD(1, false, true); else REN_VFIELD_FWD(1, false, false); }
+    if (mode == 1) {
+#define REN_VFIELD_FWD1(SAVE, FULL)                                                                                             \
+    do {                                                                                                                        \
+        (void)hipFuncSetAttribute((const void *)vfield_fwd1_kernel<SAVE, FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_lds<1>()); \
+        hipLaunchKernelGGL((vfield_fwd1_kernel<SAVE, FULL>), dim3(vfield_grid(n, 2)), dim3(256), fwd_lds<1>(), st, a);          \
+    } while (0)
+        if (ren_knob(REN_KNOB_VFIELD_PLAIN)) { if (saved) REN_VFIELD_FWD(1, true, true); else if (rgb4) REN_VFIELD_FWD(1, false, true); else REN_VFIELD_FWD(1, false, false); }
+        else if (saved) REN_VFIELD_FWD1(true, true); else if (rgb4) REN_VFIELD_FWD1(false, true); else REN_VFIELD_FWD1(false, false);
+    }
     else {
 #define REN_VFIELD_FWD6(SAVE, FULL)                                                                                             \
     do {                                                                                                                        \

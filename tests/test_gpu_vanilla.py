@@ -367,6 +367,14 @@ def test_fused_field_kernels_vs_float64_model(amd, mode, C, n):
     only.enc.copy_(B.enc); only.sel.copy_(B.sel)
     ff.forward(only, False)
     assert torch.equal(only.sigma[:n], B.sigma[:n]), "density-only launch"
+    if mode == 1:                                  # the software-pipelined forward (default) == the plain one, bit for bit
+        P = vanilla._Buffers(n, DEV, C, full=True, backward=False, fused=ff, save=True)
+        P.enc.copy_(B.enc); P.view.copy_(B.view); P.sel.copy_(B.sel)
+        with ops.knob("vfield_plain", 1):
+            ff.forward(P, True)
+        assert torch.equal(P.sigma[:n], B.sigma[:n]) and torch.equal(P.rgb4[:n], B.rgb4[:n])
+        for i, (got, want) in enumerate(zip(ff.decode(P.saved, n), acts)):      # (slot 9 holds 128 features)
+            assert torch.equal(got[:, :128 if i == 9 else 256], want[:, :128 if i == 9 else 256]), ("saved activations: pipelined vs plain forward", i)
     dz_rgb, dz_sig = torch.zeros(B.n_pad, 32, device=DEV), torch.zeros(B.n_pad, 32, device=DEV)
     dz_rgb[:n, :C] = torch.randn(n, C, device=DEV)
     dz_sig[:n, 0] = torch.randn(n, device=DEV)
