@@ -355,23 +355,24 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_head_x_kernel(BwdXHArgs a) {
     const int64_t stride = (int64_t)gridDim.x * 4, blk0 = (int64_t)blockIdx.x * 4 + wave;
     const int64_t i_last = a.n - 1;
     const bool packed = a.src.ray_indices != nullptr;
-    struct Staged { float pos[3], dir[3], tm, o[8], rgb[C], d_rgb[C], d_sigma; };
+    // Branch-free: a run-time `if (packed)` around the loads made the compiler wait for them inside the prefetch (counters
+    // are merged conservatively at the join, and `tm` was formed right there): a whole memory latency exposed per block
+    // at one wave per SIMD.  Sources are selected by pointer instead, all arithmetic on the loaded values happens at use.
+    struct Staged { float pos[3], dir[3], ts, te, o[8], rgb[C], d_rgb[C], d_sigma; };
+    const float *p_pos = packed ? a.src.rays_o : a.src.x_world;
+    const float *p_dir = packed ? a.src.rays_d : (a.src.dirs ? a.src.dirs : a.d_sigma);       // (no dirs: any readable floats)
+    const float *p_ts = packed ? a.src.t_starts : a.d_sigma, *p_te = packed ? a.src.t_ends : a.d_sigma;
+    const bool has_dir = packed || a.src.dirs != nullptr, dir3 = has_dir;
     auto load_ray = [&](int64_t blk) -> int {
         const int64_t i = min(blk * 32 + sl, i_last);
-        return packed ? a.src.ray_indices[i] : 0;
+        return a.src.ray_indices ? a.src.ray_indices[i] : 0;
     };
     auto load_inputs = [&](int64_t blk, int ray, Staged &st) {
         const int64_t i = min(blk * 32 + sl, i_last), b = min(blk, n_blk - 1);
-        if (packed) {
-            st.tm = (a.src.t_starts[i] + a.src.t_ends[i]) * 0.5f;
-            const float *ro = a.src.rays_o + 3 * (int64_t)ray, *rd = a.src.rays_d + 3 * (int64_t)ray;
+        const int64_t ip = packed ? 3 * (int64_t)ray : 3 * i, id = dir3 ? ip : 0;
+        st.ts = p_ts[i]; st.te = p_te[i];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { st.pos[k] = ro[k]; st.dir[k] = rd[k]; }
-        } else {
-            st.tm = 0.f;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) { st.pos[k] = a.src.x_world[3 * i + k]; st.dir[k] = a.src.dirs ? a.src.dirs[3 * i + k] : (k == 2 ? 1.f : 0.f); }
-        }
+        for (int k = 0; k < 3; ++k) { st.pos[k] = p_pos[ip + k]; st.dir[k] = p_dir[id + k]; }
         const float *bo = a.base_out + b * (8 * 64) + lane;
 #pragma unroll
         for (int g = 0; g < 8; ++g) st.o[g] = bo[g * 64];
@@ -401,10 +402,11 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_head_x_kernel(BwdXHArgs a) {
         if (live) {
             // position (contracted -> selector, ngp.py:238) and view direction, as sample_geom()
             float ux, uy, uz;
-            ren_contract(a.sc, cur.pos[0] + cur.dir[0] * cur.tm, cur.pos[1] + cur.dir[1] * cur.tm, cur.pos[2] + cur.dir[2] * cur.tm,
-                         ux, uy, uz);
+            const float tm = packed ? (cur.ts + cur.te) * 0.5f : 0.f;
+            const float cdx = has_dir ? cur.dir[0] : 0.f, cdy = has_dir ? cur.dir[1] : 0.f, cdz = has_dir ? cur.dir[2] : 1.f;
+            ren_contract(a.sc, cur.pos[0] + cdx * tm, cur.pos[1] + cdy * tm, cur.pos[2] + cdz * tm, ux, uy, uz);
             sel = ux > 0.f && ux < 1.f && uy > 0.f && uy < 1.f && uz > 0.f && uz < 1.f;
-            dx = cur.dir[0]; dy = cur.dir[1]; dz = cur.dir[2];
+            dx = cdx; dy = cdy; dz = cdz;
         }
         float shs[8], o[8];
         sh4_select(dx, dy, dz, hi, shs);
