@@ -272,7 +272,10 @@ namespace {
 #define REN_PHASE_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
 
-constexpr int GRID_XH = 256, GRID_XB = 256 * REN_BASE_WAVES;   // persistent workgroups of 4 waves: head one per CU, base REN_BASE_WAVES
+#ifndef REN_GRID_CUS
+#define REN_GRID_CUS 256                                  // CUs the persistent backward kernels occupy
+#endif
+constexpr int GRID_XH = REN_GRID_CUS, GRID_XB = REN_GRID_CUS * REN_BASE_WAVES;   // persistent workgroups of 4 waves: head one per CU, base REN_BASE_WAVES
 
 struct BwdXHArgs {
     const float *params, *base_out, *acts;
