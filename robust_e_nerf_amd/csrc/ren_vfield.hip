@@ -1067,9 +1067,8 @@ __global__ __launch_bounds__(512, 1) void vfield_dw_kernel(FieldDwArgs a) {
     constexpr int NV = MODE == 1 ? 2 : 4;                // 16-byte pieces per lane of one 32-feature tile
     constexpr int NXT = XFRAG && XROWS ? 10 : 8;         // input tiles held in LDS: the slot's, then the encoding's
     constexpr int XR0 = XFRAG ? 8 : 0;                   // first encoding tile
-    constexpr bool DB = MODE == 1;                       // bf16 mode: double-buffered operand fragments (36 KB each)
-    constexpr int RD = (DB && ZROWS) ? 4 : 1;           // stages of loads in flight: narrow layers do little per stage (wide ones: 2 measured slower)
-    constexpr int ZBYTES = 8 * 2 * NP * 1024, BUFBYTES = ZBYTES + NXT * 2 * NP * 1024;
+    constexpr int RD = ZROWS ? (MODE == 1 ? 3 : 2) : 1;           // stages of loads in flight: narrow layers do little per stage (wide ones: 2 measured slower)
+    constexpr int BUFBYTES = NXT * 2 * NP * 1024;        // one LDS buffer: the input operand fragments (dz fragments stay in registers)
     using PRD = Pairs<MODE>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_td[];
     const int wave_k = threadIdx.x >> 6;
@@ -1089,6 +1088,7 @@ __global__ __launch_bounds__(512, 1) void vfield_dw_kernel(FieldDwArgs a) {
     float bs4[4] = {0.f, 0.f, 0.f, 0.f};                 // ZROWS: lane = sample, columns 0 .. 3
     struct Stage { uint4 pz[NV], px[NV]; float4 rz[4], rx[4]; };
     Stage sq[RD];
+    bf16x8 azr[2][3];                                    // this wave's dz tile, transposed: [k-chunk][piece]
     // `tid`: an opaque copy of threadIdx.x (see `stage`): the addresses derived from it are computed per stage instead of once
     // per kernel (where they spilled)
     auto fetch = [&](int tid, int64_t blk, Stage &q) {
@@ -1115,7 +1115,8 @@ __global__ __launch_bounds__(512, 1) void vfield_dw_kernel(FieldDwArgs a) {
     };
     // the 32 x 32 tile whose two 16-feature chunks are `c0`, `c1` (lane = sample; kmap order: KM, natural order: !KM),
     // transposed, as the two k-chunk operands (k = samples) at dst[ks][piece]
-    auto transpose_store = [&](const float (&c0)[8], const float (&c1)[8], bool km, int lane, unsigned char *dst, float *colsum) {
+    auto transpose_store = [&](const float (&c0)[8], const float (&c1)[8], bool km, int lane, unsigned char *dst, float *colsum,
+                               bf16x8 (*regs)[3]) {
         const int hi = lane >> 5, sl = lane & 31;
         bf16x8 sel[2];
 #pragma unroll
@@ -1139,15 +1140,18 @@ __global__ __launch_bounds__(512, 1) void vfield_dw_kernel(FieldDwArgs a) {
             bf16x8 o0, o1;
 #pragma unroll
             for (int j = 0; j < 8; ++j) { o0[j] = (__bf16)T[j]; o1[j] = (__bf16)T[8 + j]; cs += T[j] + T[8 + j]; }
-            *reinterpret_cast<bf16x8 *>(dst + (0 * NP + p) * 1024 + lane * 16) = o0;
-            *reinterpret_cast<bf16x8 *>(dst + (1 * NP + p) * 1024 + lane * 16) = o1;
+            if (regs) { regs[0][p] = o0; regs[1][p] = o1; }
+            else {
+                *reinterpret_cast<bf16x8 *>(dst + (0 * NP + p) * 1024 + lane * 16) = o0;
+                *reinterpret_cast<bf16x8 *>(dst + (1 * NP + p) * 1024 + lane * 16) = o1;
+            }
         }
         if (colsum) *colsum += cs;
     };
     auto stash = [&](int tid, int64_t blk, const Stage &q, unsigned char *buf) {
         const int lane = tid & 63, wave = tid >> 6, hi = lane >> 5, sl = lane & 31;
         const bool live = blk * 32 + sl < a.n;           // lane = sample here: samples past the end contribute nothing
-        unsigned char *zf = buf, *xf = buf + ZBYTES;
+        unsigned char *xf = buf;
         auto unpack = [&](const uint4 (&pp)[NV], float (&c0)[8], float (&c1)[8]) {
             if (MODE == 1) {                             // the two 1 KB pieces are the tile's chunks
                 const bf16x8 a0 = *reinterpret_cast<const bf16x8 *>(&pp[0]), a1 = *reinterpret_cast<const bf16x8 *>(&pp[NV > 1 ? 1 : 0]);
@@ -1172,10 +1176,10 @@ __global__ __launch_bounds__(512, 1) void vfield_dw_kernel(FieldDwArgs a) {
         float c0[8], c1[8];
         if (!ZROWS) {
             unpack(q.pz, c0, c1);
-            transpose_store(c0, c1, true, lane, zf + wave * 2 * NP * 1024, &bsum);
+            transpose_store(c0, c1, true, lane, nullptr, &bsum, azr);      // wave w's dz tile is used by wave w only
         } else if (wave == 0) {
             unrows(q.rz, c0, c1);
-            transpose_store(c0, c1, false, lane, zf, nullptr);
+            transpose_store(c0, c1, false, lane, nullptr, nullptr, azr);
             if (hi == 0) {                               // bias of a narrow layer: fp32 sums of the rows' own values (columns 0 .. 3)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) bs4[j] += c0[j];
@@ -1183,22 +1187,23 @@ __global__ __launch_bounds__(512, 1) void vfield_dw_kernel(FieldDwArgs a) {
         }
         if (XFRAG) {
             unpack(q.px, c0, c1);
-            transpose_store(c0, c1, true, lane, xf + wave * 2 * NP * 1024, nullptr);
+            transpose_store(c0, c1, true, lane, xf + wave * 2 * NP * 1024, nullptr, nullptr);
         }
         if (XROWS && wave < kt_rows) {
             unrows(q.rx, c0, c1);
-            transpose_store(c0, c1, false, lane, xf + (XR0 + wave) * 2 * NP * 1024, nullptr);
+            transpose_store(c0, c1, false, lane, xf + (XR0 + wave) * 2 * NP * 1024, nullptr, nullptr);
         }
     };
     auto products = [&](int tid, const unsigned char *buf) {
         const int lane = tid & 63, wave = tid >> 6;
-        const unsigned char *zf = buf + lane * 16, *xf = buf + ZBYTES + lane * 16;
+        const unsigned char *xf = buf + lane * 16;
+        (void)wave;
         if (has_tile) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 bf16x8 az[NP];
 #pragma unroll
-                for (int p = 0; p < NP; ++p) az[p] = *reinterpret_cast<const bf16x8 *>(zf + ((wave * 2 + ks) * NP + p) * 1024);
+                for (int p = 0; p < NP; ++p) az[p] = azr[ks][p];
 #pragma unroll
                 for (int t = 0; t < NXT; t += 2)         // two input tiles at a time: consecutive MFMAs alternate accumulators
                     if (t >= XR0 ? t - XR0 < kt_rows : t < kt_frag) {
@@ -1218,16 +1223,17 @@ __global__ __launch_bounds__(512, 1) void vfield_dw_kernel(FieldDwArgs a) {
         }
     };
     const int64_t b0 = blockIdx.x;
-    if (DB) {
-        // Stage i+1 is transposed into the other LDS buffer while the products of stage i are read from this one: one barrier
-        // a stage.  RD stages of loads are in flight (narrow layers do so little per stage that one stage of lead time is
-        // shorter than the HBM latency).  Everything in the loop is unconditional -- blocks past the end are clamped loads
-        // whose samples count as not live -- so that the compiler's load counters stay exact (counted vmcnt waits).
+    {
+        // products of stage i (this wave's dz fragments in registers, the input fragments from LDS buffer i & 1), then stage
+        // i + 1 is transposed into the other buffer: one barrier a stage.  RD stages of loads are in flight (narrow layers do
+        // so little per stage that one stage of lead time is shorter than the HBM latency).  Everything in the loop is
+        // unconditional -- blocks past the end are clamped loads whose samples count as not live -- so that the compiler's
+        // load counters stay exact (counted vmcnt waits).
         const int64_t S = n_splits, n_it = b0 < n_blk ? (n_blk - b0 + S - 1) / S : 0, n_it_pad = (n_it + RD - 1) / RD * RD;
         auto clampb = [&](int64_t blk) { return blk < n_blk ? blk : n_blk - 1; };
 #pragma unroll
         for (int k = 0; k < RD; ++k) fetch(threadIdx.x, clampb(b0 + k * S), sq[k]);
-        if (n_it) {
+        {
             int tid = threadIdx.x;
             asm volatile("" : "+v"(tid));
             stash(tid, b0, sq[0], smem_td);
@@ -1240,22 +1246,11 @@ __global__ __launch_bounds__(512, 1) void vfield_dw_kernel(FieldDwArgs a) {
                 int tid = threadIdx.x;
                 asm volatile("" : "+v"(tid));
                 const int64_t ii = i + k, nxt = b0 + (ii + 1) * S;               // (nominal: may be past the end)
+                products(tid, smem_td + (ii & 1) * BUFBYTES);
                 stash(tid, nxt, sq[(k + 1) % RD], smem_td + ((ii + 1) & 1) * BUFBYTES);
                 fetch(tid, clampb(nxt + RD * S), sq[(k + 1) % RD]);
-                products(tid, smem_td + (ii & 1) * BUFBYTES);
                 __syncthreads();
             }
-        }
-    } else {
-        fetch(threadIdx.x, b0 < n_blk ? b0 : n_blk - 1, sq[0]);
-        for (int64_t blk = b0; blk < n_blk; blk += n_splits) {
-            int tid = threadIdx.x;
-            asm volatile("" : "+v"(tid));
-            __syncthreads();
-            stash(tid, blk, sq[0], smem_td);
-            __syncthreads();
-            fetch(tid, blk + n_splits < n_blk ? blk + n_splits : n_blk - 1, sq[0]);
-            products(tid, smem_td);
         }
     }
     const int lane = threadIdx.x & 63, hi = lane >> 5, sl = lane & 31;
@@ -1414,7 +1409,7 @@ extern "C" int ren_vanilla_bwd_weight(const void *dz, const void *saved, const f
         const bool zrows = a.dz_rows != nullptr, xfrag = a.x != nullptr, xrows = a.x_rows != nullptr;
 #define REN_VFIELD_DW(MODE, ZR, XF, XR)                                                                                         \
     do {                                                                                                                        \
-        const size_t lds = (size_t)(MODE == 1 ? 2 : 1) * (8 + ((XF) && (XR) ? 10 : 8)) * 2 * vfield_np(MODE) * 1024;                 \
+        const size_t lds = (size_t)2 * ((XF) && (XR) ? 10 : 8) * 2 * vfield_np(MODE) * 1024;                                  \
         (void)hipFuncSetAttribute((const void *)vfield_dw_kernel<MODE, ZR, XF, XR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((vfield_dw_kernel<MODE, ZR, XF, XR>), dim3(n_splits), dim3(512), lds, st, a);                         \
     } while (0)
