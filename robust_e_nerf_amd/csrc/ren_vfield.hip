@@ -10,8 +10,12 @@
 //               the register file except as the copy saved for the backward pass;
 //   vfield_bwd  the same chain backwards over W^T, from (d loss / d rgb pre-activation, d loss / d sigma pre-activation)
 //               to the first layer: dz_{l-1} = (W_l^T dz_l) * act'(h_{l-1});
-//   vfield_dw   dW_l = dz_l^T x_{l-1}, db_l = sum dz_l from the saved copies (samples are the reduction: the
-//               transposition goes through LDS as in dense_dw_x_kernel), slab-reduced: deterministic, no atomics.
+//   vfield_dw   dW_l = dz_l^T x_{l-1}, db_l = sum dz_l from the saved copies (samples are the reduction: the tiles are
+//               transposed on the matrix cores), slab-reduced: deterministic, no atomics.
+//
+// Kernels in this file: vfield_fwd1 / vfield_bwd<1> (bf16 mode; vfield_fwd<1> is the forward without the software-pipelined
+// epilogue, kept behind REN_KNOB_VFIELD_PLAIN as its bit-exact reference), vfield_fwd6 / vfield_bwd6 (fp32 mode,
+// reduction-outer), vfield_dw<1 | 6> (both modes), vfield_prep.
 //
 // Weights: `vfield_prep` turns the fp32 parameter block into bf16 MFMA A-fragment images (1 KB = one 32 x 16 fragment,
 // lane-linear), once per field evaluation (9 us); the kernels stream them through a double-buffered LDS stage with
@@ -19,6 +23,8 @@
 // All four waves of the workgroup (one per SIMD: the accumulators and operands of a wave fill the 512-register file)
 // share a stage.  One weight fragment read from LDS feeds two MFMAs (bf16 mode: two sample blocks per wave; fp32 mode:
 // the six product terms of the three-piece split use three fragments), so LDS bandwidth stays at half of its peak.
+// bf16 mode: a stage is two output tiles of all k-chunks ([tile][chunk] image); fp32 mode: two k-chunks of all output
+// tiles ([chunk][tile] image), see the reduction-outer kernels below.
 //
 // Saved activations / pre-activation gradients ("fragment layout": per slot and 32-sample block, lane-linear 1 KB pieces =
 // exactly the registers of a wave; slots 0-7 = hidden layers, 8 = bottleneck output, 9 = colour-head hidden layer (128)):
@@ -205,7 +211,7 @@ __host__ __device__ constexpr int lb_off(int l) {
     return l < 8 ? LB_HID + 256 * l : l == L_SIGMA ? LB_SIGMA : l == L_BOTT ? LB_BOTT : l == L_RGBH ? LB_RGBH : LB_RGBO;
 }
 
-// ---- forward ---------------------------------------------------------------------------------------------------------
+// ---- forward (tile-outer; instantiated for bf16 mode only: the plain reference of vfield_fwd1_kernel) ---------------------
 // FULL: all twelve layers (rgb and sigma); otherwise the hidden layers and sigma only (the sampler's density pre-pass,
 // occupancy-grid queries).  SAVE: keep the activations for the backward pass.
 template <int MODE, bool SAVE, bool FULL>
