@@ -446,6 +446,10 @@ def main():
                     "unit": "TFLOP/s", "frac": achieved / peak, "traffic": pmc_traffic(dom, args),
                     "algorithmic_flops_per_sample": FLOPS[dom], "avg_launch_ms": ms / c, "matrix_pipe": pipe,
                     "hardware_multiply_adds_per_algorithmic": terms, "algorithmic_tflops": algorithmic}
+            if roof["traffic"]:
+                # the fused arch-mlp kernels move their saved copies through HBM: how close the same call is to the HBM peak
+                roof["hbm_traffic_gbs"] = roof["traffic"] / (per * 1e-3) / 1e9
+                roof["hbm_traffic_frac_of_peak"] = roof["hbm_traffic_gbs"] / HBM_PEAK_GBS
         out = {
             "metric": "train_rays_per_sec", "value": rays / dt, "unit": "rays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
