@@ -330,7 +330,7 @@ def main():
 
     def draw(i):
         with torch.cuda.stream(tr.side_stream if can_prefetch else torch.cuda.current_stream()):
-            return batches[i % n_batches], torch.rand(2 * B, device=dev, generator=jgen), None     # both renders' jitters
+            return batches[i % n_batches], ops.uniform(2 * B, 1234 + rank, i, device=dev), None   # both renders' jitters (library Philox stream)
 
     def one_step(i):
         b, j0, j1 = staged.pop(i) if i in staged else draw(i)
@@ -339,7 +339,7 @@ def main():
             staged[i + 1] = draw(i + 1)
             tr.prefetch(*staged[i + 1])
         if args.loss_grad > 0:
-            j2 = torch.rand(B, device=dev, generator=jgen)
+            j2 = ops.uniform(B, 4321 + rank, i, device=dev)
             lg, aux_g = tr.grad_loss_forward_backward(batches[i % n_batches], j2)
             loss = loss + lg
             aux = dict(aux, n=aux["n"] + aux_g["n"], rays=aux["rays"] + aux_g["rays"], n_main=aux["n"])

@@ -119,6 +119,9 @@ int ren_ray_march(const float *rays_o, const float *rays_d, const float *t_min,
                   int32_t *ray_indices, float *t_starts, float *t_ends, float *interval_cache,
                   int32_t cache_cap, void *stream);
 /* exclusive cumsum of counts[n] (int32) -> offsets[n] (int64), total[1] (int64) */
+/* out[n] = iid U[0, 1) floats (24 bits), Philox4x32-10 keyed by `seed` at stream position `offset` (e.g. the step number): the
+ * per-ray jitter of stratified sampling without a framework RNG launch (models/nerf.py:209-215 draws it with torch.rand). */
+int ren_uniform(uint64_t seed, uint64_t offset, int64_t n, float *out, void *stream);
 int ren_exclusive_scan(const int32_t *counts, int64_t n, int64_t *offsets, int64_t *total,
                        int64_t *scratch1024 /* int64[1024] device scratch, may be NULL (slow path) */, void *stream);
 /* nerfacc.render_visibility inside ray_marching (sigma_fn branch): per ray

@@ -44,6 +44,7 @@ SIGNATURES = {
     "ren_ray_march": (c_int, [P, P, P, P, P, c_int64, POINTER(c_float), POINTER(c_int32), P, c_int32,
                               c_float, c_float, c_int32, c_int32, P, P, P, P, P, P, c_int32, P]),
     "ren_compact_features": (c_int, [P, P, P, c_int64, P, P, P, P]),
+    "ren_uniform": (c_int, [ctypes.c_uint64, ctypes.c_uint64, c_int64, P, P]),
     "ren_exclusive_scan": (c_int, [P, c_int64, P, P, P, P]),
     "ren_visibility": (c_int, [P, P, c_int64, P, P, P, c_float, c_float, P, P, P]),
     "ren_compact_samples": (c_int, [P, P, P, c_int64, P, P, P, P, P, P, P]),

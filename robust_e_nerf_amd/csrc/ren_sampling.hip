@@ -590,6 +590,32 @@ extern "C" int ren_ray_march(const float *rays_o, const float *rays_d, const flo
     REN_CHECK_LAUNCH();
 }
 
+// ---- uniform random numbers for the stratified-sampling jitter (models/nerf.py passes torch.rand; any iid U[0,1) stream is
+// the same sampler): Philox4x32-10, counter = (index of the group of four, offset), key = seed
+__global__ __launch_bounds__(256) void philox_uniform_kernel(uint64_t seed, uint64_t offset, int64_t n, float *__restrict__ out) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (4 * g >= n) return;
+    uint32_t c[4] = {(uint32_t)g, (uint32_t)((uint64_t)g >> 32), (uint32_t)offset, (uint32_t)(offset >> 32)};
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+        c[1] = (uint32_t)p1; c[3] = (uint32_t)p0; c[0] = n0; c[2] = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (4 * g + j < n) out[4 * g + j] = (float)(c[j] >> 8) * 5.9604644775390625e-8f;       // 24 bits: [0, 1)
+}
+
+extern "C" int ren_uniform(uint64_t seed, uint64_t offset, int64_t n, float *out, void *stream) {
+    if (!out || n < 0) return REN_ERR_BAD_ARG;
+    if (n == 0) return REN_OK;
+    hipLaunchKernelGGL(philox_uniform_kernel, dim3(ren_blocks((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, seed, offset, n, out);
+    REN_CHECK_LAUNCH();
+}
+
 extern "C" int ren_exclusive_scan(const int32_t *counts, int64_t n, int64_t *offsets, int64_t *total,
                                   int64_t *scratch1024, void *stream) {
     if (!counts || !offsets || n < 0) return REN_ERR_BAD_ARG;

@@ -161,6 +161,14 @@ def ray_aabb_intersect(o, d, aabb: Sequence[float], near: Optional[float] = None
     return tmin, tmax
 
 
+def uniform(n: int, seed: int, offset: int = 0, device="cuda:0", out=None):
+    """n iid U[0, 1) floats from the library's Philox stream (seed, offset): jitter without a torch RNG launch"""
+    if out is None:
+        out = torch.empty(n, device=device, dtype=torch.float32)
+    check(_lib.load().ren_uniform(int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), n, _ptr(out), _stream()), "ren_uniform")
+    return out
+
+
 def exclusive_scan(counts: torch.Tensor):
     n = counts.shape[0]
     offsets = torch.empty(n, device=counts.device, dtype=torch.int64)

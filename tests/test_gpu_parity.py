@@ -1893,3 +1893,26 @@ def test_event_interval_construction_on_device_equals_host():
     for k in host:
         assert torch.equal(host[k], devr[k]), k
     print(f"{N} events on the device: {dt:.2f} s")
+
+
+def test_library_uniform_stream_is_philox4x32_10(amd):
+    """ren_uniform (the per-ray stratified-sampling jitter of the bench, instead of a torch RNG launch) against a numpy
+    restatement of Philox4x32-10 (counter = (group index, offset), key = seed; 24-bit mantissa floats): bit-exact, and
+    the stream looks uniform."""
+    from robust_e_nerf_amd import ops as _ops
+    n, seed, off = 10007, 0x1234_5678_9ABC_DEF1, 42
+    got = _ops.uniform(n, seed, off).cpu().numpy()
+    g = np.arange((n + 3) // 4, dtype=np.uint64)
+    c = [(g & 0xFFFFFFFF).astype(np.uint64), (g >> 32).astype(np.uint64),
+         np.full_like(g, off & 0xFFFFFFFF), np.full_like(g, off >> 32)]
+    k0, k1 = seed & 0xFFFFFFFF, seed >> 32
+    for _ in range(10):
+        p0, p1 = np.uint64(0xD2511F53) * c[0], np.uint64(0xCD9E8D57) * c[2]
+        n0 = ((p1 >> 32) ^ c[1] ^ np.uint64(k0)) & 0xFFFFFFFF
+        n2 = ((p0 >> 32) ^ c[3] ^ np.uint64(k1)) & 0xFFFFFFFF
+        c = [n0, p1 & 0xFFFFFFFF, n2, p0 & 0xFFFFFFFF]
+        k0, k1 = (k0 + 0x9E3779B9) & 0xFFFFFFFF, (k1 + 0xBB67AE85) & 0xFFFFFFFF
+    want = (np.stack(c, 1).reshape(-1)[:n] >> 8).astype(np.float32) * np.float32(2.0 ** -24)
+    assert np.array_equal(got, want)
+    assert got.min() >= 0.0 and got.max() < 1.0 and abs(got.mean() - 0.5) < 0.01 and abs(got.var() - 1 / 12) < 0.005
+    assert not np.array_equal(got, _ops.uniform(n, seed, off + 1).cpu().numpy())
