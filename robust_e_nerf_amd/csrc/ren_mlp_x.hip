@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_head_x_kernel(BwdXHArgs a) {
     // at one wave per SIMD.  Sources are selected by pointer instead, all arithmetic on the loaded values happens at use.
     struct Staged { float pos[3], dir[3], ts, te, o[8], rgb[C], d_rgb[C], d_sigma; };
     const float *p_pos = packed ? a.src.rays_o : a.src.x_world;
-    const float *p_dir = packed ? a.src.rays_d : (a.src.dirs ? a.src.dirs : a.d_sigma);       // (no dirs: any readable floats)
+    const float *p_dir = packed ? a.src.rays_d : (a.src.dirs ? a.src.dirs : a.src.x_world);   // (no dirs: any three readable floats)
     const float *p_ts = packed ? a.src.t_starts : a.d_sigma, *p_te = packed ? a.src.t_ends : a.d_sigma;
     const bool has_dir = packed || a.src.dirs != nullptr, dir3 = has_dir;
     auto load_ray = [&](int64_t blk) -> int {

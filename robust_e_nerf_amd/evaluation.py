@@ -44,10 +44,13 @@ def render_image(r: Renderer, Kinv: torch.Tensor, cam_pos: torch.Tensor, cam_rot
     """evaluation_step: (H, W) predicted intensity ((3, H, W) for radiance_dim 3), opacity, depth for one pose.  ``chunk`` is the reference's
     ``test_chunk_size`` (16 384 there, to fit a 2080 Ti); with 288 GB a 640x480 image is one chunk, which is 4x
     faster than 19 chunks (2.6 vs 10.3 ms, tools/render_bench.py).  The result does not depend on it.  Default: one
-    chunk for arch ngp (~200 B/sample of temporaries), the reference's 16 384 rays for arch mlp (its 8 x 256 hidden
-    activations are ~10 KB/sample: a whole 640x480 image at ~600 samples per ray would not fit)."""
+    chunk for arch ngp (~200 B/sample of temporaries), 65 536 rays for arch mlp on the fused field, the reference's 16 384
+    rays for arch mlp on the per-layer kernels (8 x 256 hidden activations are ~10 KB/sample)."""
     if chunk is None:
-        chunk = (1 << 20) if isinstance(r.field, NGPField) else 16384
+        if isinstance(r.field, NGPField):
+            chunk = 1 << 20
+        else:       # arch mlp: the fused field keeps nothing per sample in inference (~0.5 KB of encodings / outputs)
+            chunk = 65536 if getattr(r, "fused_field", False) and r._dense_mode() != 0 else 16384
     dev = Kinv.device
     px = pixel_grid(height, width, dev)
     if rows is not None:                                               # a band of image rows (render_image_sharded)
