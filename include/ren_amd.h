@@ -563,7 +563,10 @@ int ren_vanilla_heads_bwd(const float *g_rgb, const float *rgb, const float *g_s
  * fwd: enc [n_pad][ld_enc >= 64], view [n_pad][ld_view >= 32], selector [n_pad] are the outputs of ren_freq_encode (rows
  * n .. n_pad zero); sigma [n_pad]; rgb4 [n_pad][4] (columns >= C zero) or NULL for the density only (then view may be NULL
  * and saved must be).  bwd: dz_rgb / dz_sigma [n_pad][32] as written by ren_vanilla_heads_bwd.  ren_vanilla_bwd_weight ADDS
- * dW_l = dz_l^T x_{l-1}, db_l = sum dz_l of all twelve layers to `grads` (layout of params), slab-reduced (deterministic). */
+ * dW_l = dz_l^T x_{l-1}, db_l = sum dz_l of all twelve layers to `grads` (layout of params), slab-reduced (deterministic).
+ * Backward over a sample RANGE of a larger forward pass (bounds the memory of `dz`): row pointers (dz_rgb, dz_sigma, enc, view)
+ * and `saved` advanced to the first sample of the range -- a multiple of 256 samples; saved + first_sample * 256 * element
+ * size -- n = samples in the range, saved_slot_bytes = ren_vanilla_saved_bytes(mode, n_forward) / 10 (0: the pass itself). */
 int64_t ren_vanilla_image_bytes(int32_t mode);
 int64_t ren_vanilla_saved_bytes(int32_t mode, int64_t n);
 int ren_vanilla_prep(const float *params, int32_t C, int32_t mode, void *image, void *stream);
@@ -571,11 +574,11 @@ int ren_vanilla_fwd(const float *enc, int32_t ld_enc, const float *view, int32_t
                     const float *params, int32_t C, const void *image, int32_t mode, int64_t n, void *saved, float *sigma,
                     float *rgb4, void *stream);
 int ren_vanilla_bwd(const float *dz_rgb, const float *dz_sigma, const void *image, int32_t mode, int64_t n, const void *saved,
-                    void *dz, void *stream);
+                    int64_t saved_slot_bytes, void *dz, void *stream);
 int64_t ren_vanilla_bwd_weight_workspace_floats(int32_t n_splits);
-int ren_vanilla_bwd_weight(const void *dz, const void *saved, const float *enc, int32_t ld_enc, const float *view,
-                           int32_t ld_view, const float *dz_rgb, const float *dz_sigma, int32_t C, int32_t mode, int64_t n,
-                           int32_t n_splits, float *grads, float *workspace, void *stream);
+int ren_vanilla_bwd_weight(const void *dz, const void *saved, int64_t saved_slot_bytes, const float *enc, int32_t ld_enc,
+                           const float *view, int32_t ld_view, const float *dz_rgb, const float *dz_sigma, int32_t C,
+                           int32_t mode, int64_t n, int32_t n_splits, float *grads, float *workspace, void *stream);
 /* Tangent streams of the vanilla field (robust_e_nerf/external/mlp.py:208-243,333-358 under
  * utils/autograd.py:4-34 for the log-intensity-gradient loss, models/robust_e_nerf.py:383-409; the second order serves
  * d loss / d tau, see ren_trajectory_jvp2).  ren_freq_encode_jvp: `order`-th time derivative (1 or 2) of ren_freq_encode's

@@ -154,6 +154,8 @@ struct FieldArgs {
     float *sigma, *rgb4;                                 // forward outputs: [n_pad], [n_pad][4]
     const float *dz_rgb, *dz_sig;                        // backward inputs: [n_pad][32] (columns < C / column 0)
     void *dz;                                            // backward: pre-activation gradients (N_SLOTS slots)
+    int64_t acts_sstride;                                // backward: elements per slot of `acts` (0: as for n samples) -- the
+                                                         // backward of a sample RANGE of a larger forward pass
     int64_t n;
 };
 
@@ -461,7 +463,7 @@ __global__ __launch_bounds__(256, 1) void vfield_bwd_kernel(FieldArgs a) {
             int64_t blk0 = blk0_g;
             asm volatile("" : "+v"(lane16), "+s"(blk0));
             const int lane = lane16 >> 4, hi = lane >> 5, sl = lane & 31;
-            const ST *hs = reinterpret_cast<const ST *>(a.acts) + (size_t)(DERIV ? hslot : 0) * sstride;
+            const ST *hs = reinterpret_cast<const ST *>(a.acts) + (size_t)(DERIV ? hslot : 0) * (a.acts_sstride ? (size_t)a.acts_sstride : sstride);
             uint4 hpre[PD][HV];
             auto load_h = [&](int i, uint4 (&dst)[HV]) {                                           // i = u * NT + t
                 const int u = i / NT, t = i % NT;
@@ -949,7 +951,7 @@ __global__ __launch_bounds__(256, 1) void vfield_bwd6_kernel(FieldArgs a) {
             int64_t blk = blk_g;
             asm volatile("" : "+v"(lane16), "+s"(blk));
             const int lane = lane16 >> 4, hi = lane >> 5, sl = lane & 31;
-            const float *hs = reinterpret_cast<const float *>(a.acts) + (size_t)(DERIV ? hslot : 0) * sstride;
+            const float *hs = reinterpret_cast<const float *>(a.acts) + (size_t)(DERIV ? hslot : 0) * (a.acts_sstride ? (size_t)a.acts_sstride : sstride);
             float ef[8];                                 // the extra operand chunk (dz_rgb columns / dz_sigma in k-slot 0)
             if (NE) {
                 const int64_t bc = blk < n_blk ? blk : n_blk - 1;
@@ -1367,12 +1369,13 @@ extern "C" int ren_vanilla_fwd(const float *enc, int32_t ld_enc, const float *vi
 }
 
 extern "C" int ren_vanilla_bwd(const float *dz_rgb, const float *dz_sigma, const void *image, int32_t mode, int64_t n,
-                               const void *saved, void *dz, void *stream) {
-    if (!dz_rgb || !dz_sigma || !image || !saved || !dz || (mode != 1 && mode != 6) || n < 0) return REN_ERR_BAD_ARG;
+                               const void *saved, int64_t saved_slot_bytes, void *dz, void *stream) {
+    if (!dz_rgb || !dz_sigma || !image || !saved || !dz || (mode != 1 && mode != 6) || n < 0 || saved_slot_bytes < 0) return REN_ERR_BAD_ARG;
     if (n == 0) return REN_OK;
     FieldArgs a = {};
     a.img = reinterpret_cast<const __bf16 *>(image) + (size_t)F_FRAGS * vfield_np(mode) * 512;
     a.acts = const_cast<void *>(saved); a.dz_rgb = dz_rgb; a.dz_sig = dz_sigma; a.dz = dz; a.n = n;
+    a.acts_sstride = saved_slot_bytes / (mode == 1 ? 2 : 4);
     hipStream_t st = (hipStream_t)stream;
     if (mode == 1) {
         (void)hipFuncSetAttribute((const void *)vfield_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds<1>());
@@ -1389,16 +1392,19 @@ extern "C" int64_t ren_vanilla_bwd_weight_workspace_floats(int32_t n_splits) {
     return (int64_t)n_splits * (256 * 319 + 256);
 }
 
-extern "C" int ren_vanilla_bwd_weight(const void *dz, const void *saved, const float *enc, int32_t ld_enc, const float *view,
-                                      int32_t ld_view, const float *dz_rgb, const float *dz_sigma, int32_t C, int32_t mode,
-                                      int64_t n, int32_t n_splits, float *grads, float *workspace, void *stream) {
+extern "C" int ren_vanilla_bwd_weight(const void *dz, const void *saved, int64_t saved_slot_bytes, const float *enc, int32_t ld_enc,
+                                      const float *view, int32_t ld_view, const float *dz_rgb, const float *dz_sigma, int32_t C,
+                                      int32_t mode, int64_t n, int32_t n_splits, float *grads, float *workspace, void *stream) {
     if (!dz || !saved || !enc || !view || !dz_rgb || !dz_sigma || !grads || !workspace || !vfield_ok(mode, C) || n < 0 || n_splits < 1 ||
         ld_enc < 64 || (ld_enc & 3) || ld_view < 32 || (ld_view & 3))
         return REN_ERR_BAD_ARG;
     if (n == 0) return REN_OK;
     hipStream_t st = (hipStream_t)stream;
-    const size_t sbytes = (size_t)ren_vanilla_saved_bytes(mode, n) / N_SLOTS;
-    auto slot = [&](const void *base, int s) { return reinterpret_cast<const unsigned char *>(base) + s * sbytes; };
+    const size_t sbytes = (size_t)ren_vanilla_saved_bytes(mode, n) / N_SLOTS;       // dz: n samples; saved: possibly a range of more
+    const size_t sbytes_saved = saved_slot_bytes > 0 ? (size_t)saved_slot_bytes : sbytes;
+    auto slot = [&](const void *base, int s) {
+        return reinterpret_cast<const unsigned char *>(base) + s * (base == saved ? sbytes_saved : sbytes);
+    };
     for (int l = NL - 1; l >= 0; --l) {
         FieldDwArgs a = {};
         a.N = l_out(l, C); a.K = l_in(l); a.n = n;

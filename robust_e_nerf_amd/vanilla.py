@@ -100,20 +100,31 @@ class FusedField:
                                           _ptr(B.saved, torch.uint8) if (full and B.saved is not None) else None, _ptr(B.sigma),
                                           _ptr(B.rgb4) if full else None, _stream()), "ren_vanilla_fwd")
 
-    def backward(self, dz_rgb, dz_sig, B, dz):
-        check(_lib.load().ren_vanilla_bwd(_ptr(dz_rgb), _ptr(dz_sig), _ptr(self.image, torch.uint8), self.mode, B.n,
-                                          _ptr(B.saved, torch.uint8), _ptr(dz, torch.uint8), _stream()), "ren_vanilla_bwd")
+    def _range(self, B, s0: int, m: Optional[int]):
+        """(samples in the range, byte offset of its first block inside a slot of B.saved, slot stride of B.saved)"""
+        m = B.n - s0 if m is None else m
+        esz = 2 if self.mode == 1 else 4
+        if s0 % 256:
+            raise ValueError("a backward sample range starts at a multiple of 256 samples")
+        return m, s0 * 256 * esz, B.saved.numel() // 10
 
-    def backward_weight(self, dz_rgb, dz_sig, B, dz):
-        lib, n = _lib.load(), B.n
-        splits = max(1, min(self.n_splits, (n + 31) // 32))
+    def backward(self, dz_rgb, dz_sig, B, dz, s0: int = 0, m: Optional[int] = None):
+        """backward (data) of the samples s0 .. s0 + m of the pass saved in B (default: all); dz: new_saved(m)"""
+        m, off, stride = self._range(B, s0, m)
+        check(_lib.load().ren_vanilla_bwd(_ptr(dz_rgb[s0:]), _ptr(dz_sig[s0:]), _ptr(self.image, torch.uint8), self.mode, m,
+                                          B.saved.data_ptr() + off, stride, _ptr(dz, torch.uint8), _stream()), "ren_vanilla_bwd")
+
+    def backward_weight(self, dz_rgb, dz_sig, B, dz, s0: int = 0, m: Optional[int] = None):
+        lib = _lib.load()
+        m, off, stride = self._range(B, s0, m)
+        splits = max(1, min(self.n_splits, (m + 31) // 32))
         need = int(lib.ren_vanilla_bwd_weight_workspace_floats(splits))
         if self._ws is None or self._ws.numel() < need:
             self._ws = None
             self._ws = torch.empty(need, device=B.enc.device, dtype=torch.float32)
-        check(lib.ren_vanilla_bwd_weight(_ptr(dz, torch.uint8), _ptr(B.saved, torch.uint8), _ptr(B.enc), 64, _ptr(B.view), 32,
-                                         _ptr(dz_rgb), _ptr(dz_sig), self.field.C, self.mode, n, splits, _ptr(self.field.grad),
-                                         _ptr(self._ws), _stream()), "ren_vanilla_bwd_weight")
+        check(lib.ren_vanilla_bwd_weight(_ptr(dz, torch.uint8), B.saved.data_ptr() + off, stride, _ptr(B.enc[s0:]), 64,
+                                         _ptr(B.view[s0:]), 32, _ptr(dz_rgb[s0:]), _ptr(dz_sig[s0:]), self.field.C, self.mode, m,
+                                         splits, _ptr(self.field.grad), _ptr(self._ws), _stream()), "ren_vanilla_bwd_weight")
 
     def decode(self, saved: torch.Tensor, n: int) -> List[torch.Tensor]:
         """fragment layout -> ten row-major (n, 256) float32 tensors: slots 0-7 hidden layers, 8 bottleneck, 9 colour hidden
@@ -184,6 +195,7 @@ class VanillaRenderer(Renderer):
         self._dw_ws = None
         self._fused_fields = {}
         self.fused_field = True                     # csrc/ren_vfield.hip: the field as one launch per pass (matrix-core modes)
+        self.bwd_chunk = 1 << 21                    # samples per backward range of the fused field (multiple of 256)
         # HIP-event timing per kernel family when ops.profile_start() is active (bench.py)
         self._fwd = ops._wrap("dense_fwd", self._fwd)
         self._bwd_data = ops._wrap("dense_bwd_data", self._bwd_data)
@@ -220,11 +232,11 @@ class VanillaRenderer(Renderer):
     def _fused_fwd(self, B, full):
         B.fused.forward(B, full)
 
-    def _fused_bwd(self, dz_rgb, dz_sig, B, dz):
-        B.fused.backward(dz_rgb, dz_sig, B, dz)
+    def _fused_bwd(self, dz_rgb, dz_sig, B, dz, s0=0, m=None):
+        B.fused.backward(dz_rgb, dz_sig, B, dz, s0, m)
 
-    def _fused_dw(self, dz_rgb, dz_sig, B, dz):
-        B.fused.backward_weight(dz_rgb, dz_sig, B, dz)
+    def _fused_dw(self, dz_rgb, dz_sig, B, dz, s0=0, m=None):
+        B.fused.backward_weight(dz_rgb, dz_sig, B, dz, s0, m)
 
     def _fwd(self, X, ldx, name, act, Y, ldy, n, sel=None):
         f = self.field
@@ -324,9 +336,14 @@ class VanillaRenderer(Renderer):
                                                 _ptr(ctx["sigma"]), n, C, _ptr(dz_rgb), _ptr(dz_sig), _stream()),
               "ren_vanilla_heads_bwd")
         if B.fused is not None:
-            dz = B.fused.new_saved(n)
-            self._fused_bwd(dz_rgb, dz_sig, B, dz)
-            self._fused_dw(dz_rgb, dz_sig, B, dz)
+            # in ranges of bwd_chunk samples: the pre-activation gradients (as large as the saved activations) only ever
+            # exist for one range
+            for s0 in range(0, n, self.bwd_chunk):
+                m = min(self.bwd_chunk, n - s0)
+                dz = B.fused.new_saved(m)
+                self._fused_bwd(dz_rgb, dz_sig, B, dz, s0, m)
+                self._fused_dw(dz_rgb, dz_sig, B, dz, s0, m)
+                del dz
             return
         dr, db, dh = z(WIDTH_COND), z(WIDTH), [z(WIDTH), z(WIDTH)]
         h7 = B.h[DEPTH - 1]

@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_abi_version_and_build_info(lib):
-    assert lib.ren_abi_version() == 19
+    assert lib.ren_abi_version() == 20
     assert b"gfx950" in lib.ren_build_info()
 
 

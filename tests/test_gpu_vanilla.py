@@ -390,6 +390,15 @@ def test_fused_field_kernels_vs_float64_model(amd, mode, C, n):
     for i, k in enumerate(R["names"]):
         assert rel(fld.gw[k], R["W"][i].grad) < t_dw, ("dW", k)
         assert rel(fld.gb[k], R["B"][i].grad) < t_dw, ("db", k)
+    # the same backward in sample ranges (what VanillaRenderer does to bound the memory of dz): same gradients
+    whole = fld.grad.clone()
+    fld.grad.zero_()
+    for s0 in range(0, n, 1024):
+        m = min(1024, n - s0)
+        dzc = ff.new_saved(m)
+        ff.backward(dz_rgb, dz_sig, B, dzc, s0, m)
+        ff.backward_weight(dz_rgb, dz_sig, B, dzc, s0, m)
+    assert rel_err(fld.grad, whole) < (2e-6 if mode == 6 else 2e-3), rel_err(fld.grad, whole)
 
 
 def test_fused_field_equals_dense_layer_path(amd):
