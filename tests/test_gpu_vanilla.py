@@ -418,3 +418,53 @@ def test_fused_field_equals_dense_layer_path(amd):
         res[fused] = (rgb.clone(), sigma.clone(), r.field.grad.clone(), r.query_density(x).clone())
     for a, b, tol in zip(res[True], res[False], (2e-6, 2e-6, 2e-5, 2e-6)):
         assert rel_err(a, b) < tol, (rel_err(a, b), tol)
+
+
+@pytest.mark.parametrize("mode", [6, 1])
+def test_fused_field_properties_at_bench_size(amd, mode):
+    """Size-independent properties of the fused field at the bench's sample count (n = 2^20 + 37: ragged last block and
+    workgroup pass): a sample's outputs do not depend on which other samples share the launch (prefix of the pass ==
+    a pass over the prefix, bit for bit), repeated launches are bit-identical, and the backward is exactly linear under a
+    power-of-two scaling of the incoming gradients (every intermediate scales exactly): grads(4 g) == 4 grads(g)."""
+    ops, engine, vanilla = amd
+    torch.manual_seed(3)
+    C, n = 1, (1 << 20) + 37
+    fld = vanilla.VanillaField(DEV, C)
+    for name, o, i in fld.layers:
+        k = 1.0 / i ** 0.5
+        fld.w[name].uniform_(-k, k)
+        fld.b[name].uniform_(-k, k)
+    ff = vanilla.FusedField(fld, mode)
+    ff.prep()
+
+    def buffers(m, save):
+        B = vanilla._Buffers(m, DEV, C, full=True, backward=False, fused=ff, save=save)
+        B.enc.zero_(); B.view.zero_()
+        return B
+    B = buffers(n, True)
+    B.enc[:n, :63] = torch.rand(n, 63, device=DEV) * 2 - 1
+    B.view[:n, :27] = torch.rand(n, 27, device=DEV) * 2 - 1
+    B.sel[:n] = 1
+    ff.forward(B, True)
+    sigma, rgb = B.sigma[:n].clone(), B.rgb4[:n].clone()
+    assert bool(torch.isfinite(sigma).all()) and bool(torch.isfinite(rgb).all())
+    ff.forward(B, True)
+    assert torch.equal(B.sigma[:n], sigma) and torch.equal(B.rgb4[:n], rgb), "repeat launch"
+    m = 300_001
+    P = buffers(m, False)
+    P.enc[:m].copy_(B.enc[:m]); P.view[:m].copy_(B.view[:m]); P.sel[:m] = 1
+    ff.forward(P, True)
+    assert torch.equal(P.sigma[:m], sigma[:m]) and torch.equal(P.rgb4[:m], rgb[:m]), "prefix of the pass"
+    dz_rgb, dz_sig = torch.zeros(B.n_pad, 32, device=DEV), torch.zeros(B.n_pad, 32, device=DEV)
+    dz_rgb[:n, :C] = torch.randn(n, C, device=DEV)
+    dz_sig[:n, 0] = torch.randn(n, device=DEV)
+    grads = []
+    for scale in (1.0, 4.0):
+        fld.grad.zero_()
+        dz = ff.new_saved(n)
+        ff.backward(dz_rgb * scale, dz_sig * scale, B, dz)
+        ff.backward_weight(dz_rgb * scale, dz_sig * scale, B, dz)
+        grads.append(fld.grad.clone())
+        del dz
+    assert bool(torch.isfinite(grads[0]).all()) and float(grads[0].abs().max()) > 0
+    assert torch.equal(grads[1], 4.0 * grads[0]), float((grads[1] - 4.0 * grads[0]).abs().max())
