@@ -48,7 +48,7 @@ constexpr int MAX_BINS = REN_MAX_LEVELS * MAX_BINS_PER_LEVEL;
 #endif
 constexpr int SC_THREADS = REN_SC_THREADS;           // scatter workgroup: one sample per thread
 constexpr int SC_ENTRIES = SC_THREADS * 8;           // staged updates per level pass = 48 KiB
-constexpr int CNT_THREADS = 256, CNT_SAMPLES = 1024; // count workgroup: 4 samples per thread, all levels
+constexpr int CNT_THREADS = 1024, CNT_SAMPLES = 1024; // count workgroup: one sample per thread, all levels (4 per thread: a 4x longer latency chain, 72 us however small the batch)
 // Updates per accumulate workgroup ("part").  A part follows n (a fixed 2 M-entry part is a ~1 ms single-workgroup
 // tail when the whole call is only a few million updates: occupancy-grid sampling, ~10 samples per ray), and it is
 // the capacity of a hashed bin whenever there are hashed levels, so that every hashed bin is ONE part: a bin cut
