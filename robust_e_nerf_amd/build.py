@@ -1,13 +1,23 @@
-"""Build the C-ABI HIP library in-tree: robust_e_nerf_amd/csrc/libren_amd.so (gfx950 only)."""
+"""Build the C-ABI HIP library in-tree: robust_e_nerf_amd/csrc/libren_amd.so (gfx950 only).
+
+Staleness is keyed on CONTENT, not mtimes: every object carries a stamp = sha256(source + the
+headers it can include + its flags + the compiler version), the library a stamp over its objects'
+stamps.  Objects live in csrc/_obj/ (git- and gpurun-ignored: only the .so and its stamp travel
+to the GPU box).  `python -m robust_e_nerf_amd.build --check` exits non-zero when the shipped .so
+does not correspond to the sources next to it."""
+import hashlib
 import os
 import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
 OUT = os.path.join(CSRC, "libren_amd.so")
+STAMP = OUT + ".stamp"
 SOURCES = ["ren_api.hip", "ren_pose.hip", "ren_sampling.hip", "ren_composite.hip", "ren_train.hip",
-           "ren_hashgrid.hip", "ren_hashgrid_binned.hip", "ren_mlp.hip", "ren_jvp.hip", "ren_mlp_jvp.hip", "ren_jvp2.hip", "ren_dense.hip", "ren_vfield.hip", "ren_mlp_x.hip", "ren_mlp_jvp_x.hip"]
+           "ren_hashgrid.hip", "ren_hashgrid_binned.hip", "ren_mlp.hip", "ren_jvp.hip", "ren_mlp_jvp.hip",
+           "ren_jvp2.hip", "ren_dense.hip", "ren_vfield.hip", "ren_mlp_x.hip", "ren_mlp_jvp_x.hip"]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
           "-Wno-unused-result"]
 # the sampler must match the sequential oracle bit for bit: no FMA contraction there
@@ -17,40 +27,95 @@ PER_FILE = {"ren_sampling.hip": ["-ffp-contract=off"], "ren_jvp2.hip": ["-fno-sl
             "ren_mlp_x.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], "ren_mlp_jvp_x.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
-def _stale(target, deps):
-    if not os.path.exists(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+def _headers():
+    hs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
+    return hs + [os.path.join(HERE, "..", "include", "ren_amd.h")]
+
+
+_compiler_id = None
+
+
+def _compiler(hipcc):
+    global _compiler_id
+    if _compiler_id is None:
+        try:
+            _compiler_id = subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout.strip()
+        except OSError:
+            _compiler_id = "no-hipcc"
+    return _compiler_id
+
+
+def _digest(paths, extra):
+    h = hashlib.sha256()
+    for p in paths:
+        with open(p, "rb") as f:
+            h.update(hashlib.sha256(f.read()).digest())
+    h.update("\0".join(extra).encode())
+    return h.hexdigest()
+
+
+def source_stamps(hipcc="hipcc", with_compiler=True):
+    """{source: stamp} for the current tree and the library stamp derived from them."""
+    hs = _headers()
+    comp = [_compiler(hipcc)] if with_compiler else []
+    per = {s: _digest([os.path.join(CSRC, s)] + hs, COMMON + PER_FILE.get(s, []) + comp) for s in SOURCES}
+    lib = hashlib.sha256("".join(per[s] for s in SOURCES).encode()).hexdigest()
+    return per, lib
+
+
+def _read(path):
+    try:
+        with open(path) as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
+def is_current(hipcc="hipcc") -> bool:
+    """True when csrc/libren_amd.so was produced from the sources, headers and flags in this tree."""
+    return os.path.exists(OUT) and _read(STAMP) == source_stamps(hipcc, with_compiler=False)[1]
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = os.environ.get("HIPCC", "hipcc")
-    headers = [os.path.join(CSRC, "ren_common.h"), os.path.join(CSRC, "ren_hashgrid_common.h"), os.path.join(CSRC, "ren_mlp_common.h"), os.path.join(CSRC, "ren_mlp_xfrag.h"), os.path.join(CSRC, "ren_mlp_jvp_common.h"),
-               os.path.join(HERE, "..", "include", "ren_amd.h")]
+    os.makedirs(OBJ, exist_ok=True)
+    per, _ = source_stamps(hipcc)
+    _, lib_stamp = source_stamps(hipcc, with_compiler=False)      # the shipped stamp must be checkable without hipcc
     objs, jobs = [], []
     for src in SOURCES:
-        s = os.path.join(CSRC, src)
-        o = os.path.join(CSRC, src.replace(".hip", ".o"))
-        if force or _stale(o, [s] + headers):
-            jobs.append([hipcc] + COMMON + PER_FILE.get(src, []) + ["-c", s, "-o", o])
+        o = os.path.join(OBJ, src.replace(".hip", ".o"))
+        if force or not os.path.exists(o) or _read(o + ".stamp") != per[src]:
+            jobs.append((src, o, [hipcc] + COMMON + PER_FILE.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", o]))
         objs.append(o)
     if jobs:                                             # translation units are independent: compile them side by side
         from concurrent.futures import ThreadPoolExecutor
 
-        def run(cmd):
+        def run(job):
+            src, o, cmd = job
             if verbose:
                 print(" ".join(cmd), flush=True)
+            if os.path.exists(o + ".stamp"):
+                os.remove(o + ".stamp")
             subprocess.check_call(cmd)
+            with open(o + ".stamp", "w") as f:
+                f.write(per[src])
         with ThreadPoolExecutor(max_workers=min(len(jobs), max(1, (os.cpu_count() or 2) // 2), 8)) as pool:
             list(pool.map(run, jobs))
-    if force or _stale(OUT, objs):
+    if force or jobs or not os.path.exists(OUT) or _read(STAMP) != lib_stamp:
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", OUT]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+        with open(STAMP, "w") as f:
+            f.write(lib_stamp)
+    if verbose:
+        print(f"libren_amd.so: {len(jobs)} of {len(SOURCES)} translation units compiled, stamp {lib_stamp[:16]}")
     return OUT
 
 
 if __name__ == "__main__":
+    if "--check" in sys.argv:
+        ok = is_current()
+        print("libren_amd.so is", "current" if ok else "STALE (or missing)")
+        sys.exit(0 if ok else 1)
     print(build(force="--force" in sys.argv, verbose=True))

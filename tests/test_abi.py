@@ -33,6 +33,23 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     assert sorted(_lib.SIGNATURES) == declared, "ctypes table and header disagree"
 
 
+def test_shipped_library_corresponds_to_the_sources(lib, tmp_path):
+    """build.py keys staleness on a content hash of sources + headers + flags: the .so that travels to the GPU box must
+    carry the stamp of the tree it travels with, and touching a source must invalidate it"""
+    from robust_e_nerf_amd import build
+    assert build.is_current(), "csrc/libren_amd.so is stale: run python -m robust_e_nerf_amd.build"
+    per, lib_stamp = build.source_stamps(with_compiler=False)
+    assert set(per) == set(build.SOURCES) and len(set(per.values())) == len(per)
+    src = os.path.join(build.CSRC, "ren_api.hip")
+    body = open(src).read()
+    try:
+        open(src, "w").write(body + "\n// touched\n")
+        assert not build.is_current()
+    finally:
+        open(src, "w").write(body)
+    assert build.is_current()
+
+
 def test_abi_version_and_build_info(lib):
     assert lib.ren_abi_version() == 20
     assert b"gfx950" in lib.ren_build_info()

@@ -1108,7 +1108,8 @@ def _seam_field(amd, g, table):
 def test_opwise_seam_matches_fused_engine_and_reference(amd, full_table_cache):
     """nerfacc-/tcnn-shaped ops + reference-shaped glue (autograd) == fused engine == reference golden."""
     ops, engine = amd
-    from robust_e_nerf_amd import nerfacc_api, render_glue
+    from robust_e_nerf_amd import nerfacc_api
+    import opwise_render as render_glue
     g = load_golden("training_step_diff")
     table = full_table_cache(g["table_seed"], g["table_scale"])
     rf = _seam_field(amd, g, table)
@@ -1153,7 +1154,8 @@ def test_opwise_seam_grad_loss_matches_reference(amd, full_table_cache):
     differentiable HIP hash-grid encoding (tcnn_api), nerfacc-shaped weights with a differentiable backward, torch MLPs /
     SH -- against the reference's own training_step golden (l_diff + l_grad): loss, d log I / dt, every field gradient."""
     ops, engine = amd
-    from robust_e_nerf_amd import jvp, nerfacc_api, render_glue
+    from robust_e_nerf_amd import jvp, nerfacc_api
+    import opwise_render as render_glue
     g = load_golden("training_step_grad")
     table = full_table_cache(g["table_seed"], g["table_scale"])
     rf = _seam_field(amd, g, table)
