@@ -212,16 +212,54 @@ def has_posed_images(root: str, stage: str) -> bool:
     return d is not None and os.path.isfile(os.path.join(d, f"transforms_{stage}.json"))
 
 
+def _png_header(path: str):
+    """(bit depth, colour type) of a PNG's IHDR, None for other files"""
+    with open(path, "rb") as f:
+        head = f.read(26)
+    if len(head) < 26 or head[:8] != b"\x89PNG\r\n\x1a\n":
+        return None
+    return head[24], head[25]
+
+
 def _read_image(path: str) -> np.ndarray:
-    """(H, W) or (H, W, 3 | 4) in RGB(A) channel order, integer dtype as stored (8 / 16 bit) or float (.npy)"""
+    """(H, W) or (H, W, 3 | 4) in RGB(A) channel order, dtype AS STORED (uint8 / uint16 / float32): what the reference's
+    `cv2.imread(path, cv2.IMREAD_UNCHANGED)` (datasets.py:470-480) returns, up to OpenCV's BGR(A) order which the caller's
+    channel arithmetic accounts for.  Decoders: numpy for .npy, OpenCV when importable (EXR float renders, 16-bit colour
+    PNGs), else imageio, else Pillow for what Pillow decodes losslessly; anything else raises instead of being
+    silently down-converted (Pillow turns 16-bit RGB(A) PNGs into 8 bit, which would change the inferred number of
+    quantisation levels and with it the pixel-value range of the PSNR)."""
     if path.endswith(".npy"):
         return np.load(path)
+    ext = os.path.splitext(path)[1].lower()
+    png = _png_header(path) if ext == ".png" else None
+    needs_full_decoder = ext in (".exr", ".hdr", ".tif", ".tiff") or (png is not None and png[0] == 16 and png[1] in (2, 4, 6))
+    try:
+        import cv2
+        if ext == ".exr":
+            os.environ.setdefault("OPENCV_IO_ENABLE_OPENEXR", "1")
+        a = cv2.imread(path, cv2.IMREAD_UNCHANGED)
+        if a is None:
+            raise ValueError(f"OpenCV cannot decode {path}")
+        if a.ndim == 3:                                                       # BGR(A) -> RGB(A)
+            a = a[..., [2, 1, 0] + ([3] if a.shape[2] == 4 else [])]
+        return np.ascontiguousarray(a)
+    except ImportError:
+        pass
+    if needs_full_decoder:
+        try:
+            import imageio.v3 as iio
+            return np.asarray(iio.imread(path))
+        except ImportError as e:
+            raise ValueError(f"{path}: float / 16-bit multi-channel images need OpenCV or imageio (Pillow would down-convert "
+                             "them); install one of them or store the views as .npy") from e
     from PIL import Image
     im = Image.open(path)
     if im.mode in ("I;16", "I;16B", "I"):
         return np.asarray(im).astype(np.uint16)
     if im.mode == "P":
         im = im.convert("RGBA" if "transparency" in im.info else "RGB")
+    if im.mode not in ("L", "RGB", "RGBA"):
+        raise ValueError(f"{path}: image mode {im.mode} is not supported (datasets.py:580-594)")
     return np.asarray(im)
 
 
@@ -303,6 +341,54 @@ def load_posed_images(root: str, stage: str, alpha_over_white_bg: bool = False, 
         for k in ("img", "T_wc_position", "T_wc_orientation"):
             out[k] = out[k][perm]
     return out
+
+
+def eval_transforms_stage(stage: str, eval_target) -> str:
+    """which `transforms_{...}.json` a val / test epoch reads (datamodule.py:105-117): the training views for
+    eval_target [event_view], the stage's own views for [novel_view]"""
+    tgt = set(eval_target if eval_target is not None else ["novel_view"])
+    if tgt == {"event_view"}:
+        return "train"
+    if tgt == {"novel_view"}:
+        return stage
+    raise NotImplementedError(f"eval_target {sorted(tgt)} (datamodule.py:116-117)")
+
+
+def trim_views(posed: dict, n: int) -> dict:
+    """TrimDataset(dataset, 0, n) (datamodule.py:132-134) on a load_posed_images(...) dict"""
+    out = dict(posed)
+    out["sample_id"] = posed["sample_id"][:n]
+    for k in ("img", "T_wc_position", "T_wc_orientation"):
+        out[k] = posed[k][:n]
+    return out
+
+
+def load_eval_views(root: str, stage: str, dcfg: dict, eval_target=None) -> dict:
+    """DataModule._build_dataset("val" | "test") (data/datamodule.py:100-134) from the YAML's `data:` section: the posed
+    images of `eval_target`'s transforms file, permuted with `eval_dataset_perm_seed`, composited per
+    `alpha_over_white_bg`, then the FIRST `{stage}_dataset_ratio` x `{stage}_eff_batch_size` views (int ratio) or that
+    fraction of them (float ratio)."""
+    if stage not in ("val", "test"):
+        raise ValueError(stage)
+    posed = load_posed_images(root, eval_transforms_stage(stage, eval_target), alpha_over_white_bg_of(dcfg),
+                              dcfg.get("eval_dataset_perm_seed"))
+    ratio = dcfg.get(f"{stage}_dataset_ratio", 1.0)
+    total = len(posed["sample_id"])
+    if isinstance(ratio, bool) or not isinstance(ratio, (int, float)) or (isinstance(ratio, float) and not 0.0 < ratio <= 1.0):
+        raise ValueError(f"{stage}_dataset_ratio must be an int or a float in (0, 1] (datamodule.py:29-33)")
+    n = ratio * int(dcfg.get(f"{stage}_eff_batch_size", 1)) if isinstance(ratio, int) else int(ratio * total)
+    if n > total:
+        raise ValueError(f"{stage}_dataset_ratio x {stage}_eff_batch_size = {n} views, the dataset has {total} (datamodule.py:129)")
+    return trim_views(posed, n)
+
+
+def alpha_over_white_bg_of(dcfg: dict) -> bool:
+    """`data.alpha_over_white_bg`, read in ONE place and REQUIRED (the reference's DataModule / model constructors take it
+    without a default, scripts/run.py:38-44): the trainer's background parameter (robust_e_nerf.py:154-159) and the
+    evaluation images' compositing (datasets.py:599-616) must agree"""
+    if "alpha_over_white_bg" not in dcfg or dcfg["alpha_over_white_bg"] is None:
+        raise KeyError("data.alpha_over_white_bg is missing from the config (every reference YAML sets it)")
+    return bool(dcfg["alpha_over_white_bg"])
 
 
 # ------------------------------------------------------------------------------------------- batcher

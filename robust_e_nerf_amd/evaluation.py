@@ -127,15 +127,47 @@ def render_image_sharded(r: Renderer, Kinv, cam_pos, cam_rot, height: int, width
 
 
 def affine_align_log(pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
-    """Least-squares a, b with a*log(pred)+b ~= log(target), float64 (robust_e_nerf.py:634-677);
-    returns the aligned prediction exp(a*log(pred)+b) in target's dtype.  (3, H, W) images are aligned per channel,
-    as the reference does for Bayer sensors (:651-667)."""
-    if pred.dim() == 3 and pred.shape[0] == 3 and target.shape == pred.shape:
-        return torch.stack([affine_align_log(pred[c], target[c]) for c in range(3)])
-    lp = pred.reshape(-1).log().to(torch.float64)
-    A = torch.stack([lp, torch.ones_like(lp)], dim=1)
-    sol = torch.linalg.lstsq(A.cpu(), target.reshape(-1, 1).log().to(torch.float64).cpu()).solution
-    return (A.cpu() @ sol).reshape(pred.shape).exp().to(target.dtype).to(target.device)
+    """Least-squares a, b with a*log(pred)+b ~= log(target), float64, for ONE image (or per channel of a (3, H, W) one);
+    returns exp(a*log(pred)+b) in target's dtype.  The reference's epoch metric uses one fit over all views:
+    ``align_and_score``; this per-image form is for displaying a single novel view (scripts/render.py)."""
+    a, b = solve_affine(log_fit_sums(pred[None], target[None]))
+    return apply_affine(pred, a, b).to(target.dtype)
+
+
+def _channel_view(x: torch.Tensor) -> torch.Tensor:
+    """(V, H, W) or (V, N) -> (V, 1, pixels);  (V, 3, H, W) -> (V, 3, pixels)"""
+    return x.reshape(x.shape[0], x.shape[1], -1) if x.dim() == 4 else x.reshape(x.shape[0], 1, -1)
+
+
+def log_fit_sums(pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """Per-channel sums of the normal equations of  a*log(pred) + b ~= log(target)  over the given views, float64:
+    (C, 5) = [sum x^2, sum x, count, sum x*y, sum y] with x = log pred, y = log target.  Additive over views and ranks,
+    which is what lets every rank contribute its shard of the reference's single fit over the gathered views
+    (robust_e_nerf.py:640-670) with a 5C-double all-reduce instead of gathering the images."""
+    x = _channel_view(pred).log().to(torch.float64)
+    y = _channel_view(target).log().to(torch.float64)
+    cnt = torch.full(x.shape[1:2], float(x.shape[0] * x.shape[2]), dtype=torch.float64, device=x.device)
+    return torch.stack([(x * x).sum((0, 2)), x.sum((0, 2)), cnt, (x * y).sum((0, 2)), y.sum((0, 2))], dim=1)
+
+
+def solve_affine(sums: torch.Tensor):
+    """(C, 5) sums -> scale a (C,), offset b (C,) of the least-squares fit (the solution ``torch.linalg.lstsq`` returns at
+    robust_e_nerf.py:666-669), solved in centred form for conditioning."""
+    sxx, sx, n, sxy, sy = sums.unbind(1)
+    mx, my = sx / n, sy / n
+    a = (sxy - n * mx * my) / (sxx - n * mx * mx)
+    return a, my - a * mx
+
+
+def apply_affine(pred: torch.Tensor, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """exp(a log(pred) + b), per channel; float64 product rounded to float32 before the exp as the reference (:670-683)"""
+    if a.numel() == 1:                                                 # monochrome (H, W)
+        shape = (1,) * pred.dim()
+    else:                                                              # (3, H, W) of a Bayer sensor
+        assert pred.dim() == 3 and pred.shape[0] == a.numel()
+        shape = (-1, 1, 1)
+    lp = pred.log().to(torch.float64) * a.to(pred.device).view(shape) + b.to(pred.device).view(shape)
+    return lp.to(torch.float32).exp()
 
 
 def psnr(pred: torch.Tensor, target: torch.Tensor, data_range: float) -> float:
@@ -148,27 +180,59 @@ def l1(pred: torch.Tensor, target: torch.Tensor) -> float:
     return float((pred.double() - target.double()).abs().mean())
 
 
+def align_and_score(pred: torch.Tensor, target: torch.Tensor, data_range: float, sums: Optional[torch.Tensor] = None):
+    """evaluation_epoch_end's metric part (robust_e_nerf.py:634-696): `pred`, `target` (V, H, W) or (V, 3, H, W).
+    ONE scale / offset per channel fitted over all views (``sums``: the fit's sums when the views of other ranks take part
+    in it, default: these views only), then L1 and PSNR of every aligned view.  -> (V, 2) float64 [l1, psnr], (a, b)"""
+    a, b = solve_affine(log_fit_sums(pred, target) if sums is None else sums)
+    out = torch.zeros(pred.shape[0], 2, dtype=torch.float64)
+    for v in range(pred.shape[0]):
+        al = apply_affine(pred[v], a, b)
+        out[v, 0], out[v, 1] = l1(al, target[v]), psnr(al, target[v], data_range)
+    return out, (a, b)
+
+
 @torch.no_grad()
 def evaluate_posed_images(r: Renderer, posed: dict, bkgd: Optional[torch.Tensor] = None, rank: int = 0, world: int = 1,
                           group=None, chunk: Optional[int] = None, limit: Optional[int] = None):
     """validation / test epoch of the reference (models/robust_e_nerf.py:519-696) over data.load_posed_images(...): every
-    view is rendered at its pose (views sharded over the ranks like DDP's DistributedSampler, metrics all-gathered: C3),
-    aligned to the target by the affine fit in log space (:634-677) and scored with L1 / PSNR over the target's pixel-value
-    range (loss_metric/metric.py:60-72).  -> dict(l1, psnr: means over the views; per_view: (V, 2) tensor)"""
+    view is rendered at its pose (views sharded over the ranks like DDP's DistributedSampler), ALL views are aligned to
+    their targets by ONE affine fit in log space per channel (:634-677: the reference flattens batch x H x W before its
+    lstsq) -- each rank adds the normal-equation sums of its views, a 5C-double all-reduce replaces the image gather (C3)
+    -- and every view is then scored with L1 / PSNR over the target's pixel-value range (loss_metric/metric.py:60-72).
+    The wrap-around duplicates DistributedSampler pads with are left out of the fit and of the means.
+    -> dict(l1, psnr: means over the views; per_view: (V, 2) tensor; scale, offset: the fit)"""
     dev = r.field.flat.device
     n = len(posed["sample_id"]) if limit is None else min(limit, len(posed["sample_id"]))
     Kinv = torch.linalg.inv(posed["intrinsics"].double()).float().contiguous().to(dev).contiguous()
     H, W = posed["img"].shape[-2:]
     rng = posed["max_normalized_pixel_value"] - posed["min_normalized_pixel_value"]
     mine = view_shard(n, rank, world)
-    local = torch.zeros(len(mine), 2, device=dev)
-    for j, v in enumerate(mine):
+    fresh = [j * world + rank < n for j in range(len(mine))]          # False: a padded repeat of some other rank's view
+    C = 1 if posed["img"].dim() == 3 else posed["img"].shape[1]
+    preds, tgts = [], []
+    for v in mine:
         tgt = posed["img"][v].to(dev)
         img, _, _ = render_image(r, Kinv, posed["T_wc_position"][v].to(dev), posed["T_wc_orientation"][v].to(dev).contiguous(),
                                  H, W, bkgd, chunk)
         if img.shape != tgt.shape:
             raise ValueError(f"view {posed['sample_id'][v]}: prediction {tuple(img.shape)} vs target {tuple(tgt.shape)}")
-        al = affine_align_log(img.clamp_min(1e-12), tgt)
-        local[j, 0], local[j, 1] = l1(al, tgt), psnr(al, tgt, rng)
+        preds.append(img.clamp_min(1e-12))
+        tgts.append(tgt)
+    sums = torch.zeros(C, 5, dtype=torch.float64, device=dev)
+    own = [j for j, f in enumerate(fresh) if f]
+    if own:
+        sums += log_fit_sums(torch.stack([preds[j] for j in own]), torch.stack([tgts[j] for j in own]))
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(sums, group=group)
+    local = torch.zeros(len(mine), 2, device=dev)
+    a = b = None
+    if mine:
+        sc, (a, b) = align_and_score(torch.stack(preds), torch.stack(tgts), rng, sums)
+        local.copy_(sc)
+    else:
+        a, b = solve_affine(sums)
     per_view = gather_views(local, n, rank, world, group)
-    return dict(l1=float(per_view[:, 0].mean()), psnr=float(per_view[:, 1].mean()), per_view=per_view.cpu(), n_views=n)
+    return dict(l1=float(per_view[:, 0].mean()), psnr=float(per_view[:, 1].mean()), per_view=per_view.cpu(), n_views=n,
+                scale=a.cpu(), offset=b.cpu())

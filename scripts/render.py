@@ -96,8 +96,7 @@ def main():
     if args.stage:
         if args.synthetic:
             raise SystemExit("--stage needs a dataset directory with a views/ folder")
-        posed = data.load_posed_images(root, args.stage, bool(dcfg.get("alpha_over_white_bg", False)),
-                                       dcfg.get(f"{args.stage}_dataset_perm_seed"))
+        posed = data.load_eval_views(root, args.stage, dcfg, cfg.get("eval_target"))      # datamodule.py:100-134
         m = evaluation.evaluate_posed_images(r, posed, bkgd, chunk=args.chunk)
         for sid, (l1v, ps) in zip(posed["sample_id"], m["per_view"].tolist()):
             print(f"{args.stage} view {sid}: l1 {l1v:.5f}  psnr {ps:.2f} dB")

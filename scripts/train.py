@@ -195,7 +195,7 @@ def main():
         lr=float(ocfg["lr"]["default"]), weight_decay=float(lcfg["weight"]["nerf_mlp_weight_decay"]),
         # render_bkgd is a parameter only when alpha_over_white_bg (robust_e_nerf.py:154-159); otherwise no background is
         # composited and the loss is masked with is_valid = opacity > 0 (:868-871): mocap-*, office-maze
-        bkgd_is_param=bool(dcfg.get("alpha_over_white_bg", True)),
+        bkgd_is_param=data.alpha_over_white_bg_of(dcfg),
         train_contrast_threshold=not mcfg["contrast_threshold"]["freeze"],
         lr_contrast_threshold=float(ocfg["lr"]["contrast_threshold"]),
         train_refractory_period=not mcfg["refractory_period"]["freeze"],
@@ -241,23 +241,32 @@ def main():
     pending = deque([batch_size])
     jgen = torch.Generator(device=dev).manual_seed(seed + 17 + rank)
     if resume_rng is not None:
-        # continue the random streams (event indices / normalized samplers, ray jitters, occupancy-grid refresh) where the
-        # checkpointed run left them: a resumed run then equals the uninterrupted one instead of replaying epoch 0's draws.
-        # The streams of ranks > 0 differ by their seed only: those ranks re-seed with the resumed epoch folded in.
-        if rank == 0:
-            batcher.gen.set_state(resume_rng["batcher"])
-            jgen.set_state(resume_rng["jitter"])
+        # continue the random streams (event indices / normalized samplers, ray jitters, occupancy-grid refresh) and the
+        # in-flight batch-size queue where the checkpointed run left them: a resumed run then equals the uninterrupted one
+        # instead of replaying epoch 0's draws.  Every rank's generator states are in the checkpoint (gathered to rank 0 when
+        # it was written); a checkpoint written by a different world size re-seeds the ranks it has no state for.
+        per_rank = resume_rng.get("per_rank")
+        if per_rank is None:                                    # round-3 checkpoints: rank 0's states only
+            per_rank = [{"batcher": resume_rng["batcher"], "jitter": resume_rng["jitter"]}]
+        if rank < len(per_rank):
+            batcher.gen.set_state(per_rank[rank]["batcher"])
+            jgen.set_state(per_rank[rank]["jitter"])
         else:
             batcher.gen.manual_seed(seed + rank + 7919 * start_epoch)
             jgen.manual_seed(seed + 17 + rank + 7919 * start_epoch)
+            print(f"rank {rank}: no random-stream state in {args.resume} (written by {len(per_rank)} rank(s)): re-seeded",
+                  flush=True)
         if resume_rng.get("occ") is not None:                   # identical on every rank by construction
             renderer._occ_gen = torch.Generator(device=dev)
             renderer._occ_gen.set_state(resume_rng["occ"])
+        if resume_rng.get("pending"):
+            pending = deque(int(b) for b in resume_rng["pending"])
     os.makedirs(args.out, exist_ok=True)
     val_views, val_every = None, int(tcf.get("check_val_every_n_epoch", 1) or 1)
-    if not args.synthetic and not args.no_validation and data.has_posed_images(root, "val"):
-        val_views = data.load_posed_images(root, "val", bool(dcfg.get("alpha_over_white_bg", False)),
-                                           dcfg.get("val_dataset_perm_seed"))
+    if not args.synthetic and not args.no_validation and \
+            data.has_posed_images(root, data.eval_transforms_stage("val", cfg.get("eval_target"))):
+        # datamodule.py:100-134: eval_target's views, eval_dataset_perm_seed, first val_dataset_ratio (x val_eff_batch_size)
+        val_views = data.load_eval_views(root, "val", dcfg, cfg.get("eval_target"))
         if rank == 0:
             print(f"validation: {len(val_views['sample_id'])} posed views every {val_every} epoch(s)", flush=True)
     step, t0, rays = start_step, time.perf_counter(), 0
@@ -290,6 +299,11 @@ def main():
             vm = evaluation.evaluate_posed_images(renderer, val_views, bk, rank, world, limit=args.limit_val_batches)
             if rank == 0:
                 print(f"epoch {epoch} validation over {vm['n_views']} views: val/l1 {vm['l1']:.5f}  val/psnr {vm['psnr']:.3f} dB", flush=True)
+        mine_rng = {"batcher": batcher.gen.get_state().cpu(), "jitter": jgen.get_state().cpu()}
+        rank_rng = [mine_rng]
+        if world > 1:                                           # every rank's generator states travel to rank 0's file
+            rank_rng = [None] * world
+            dist.all_gather_object(rank_rng, mine_rng)
         if rank == 0:
             sd = field_state_dict(fld, arch, rcfg.aabb)
             sd[CT_KEY] = tr.ct[:1].detach().cpu().clone()
@@ -302,7 +316,7 @@ def main():
             sd[OCC + "_binary"] = renderer.binary.detach().cpu().bool().view(*rcfg.occ_res)
             sd[OCC + "resolution"] = torch.tensor(rcfg.occ_res, dtype=torch.int32)
             sd[OCC + "occs"] = renderer.occs.detach().cpu().clone()
-            rng = {"batcher": batcher.gen.get_state(), "jitter": jgen.get_state(),
+            rng = {"per_rank": rank_rng, "pending": list(pending),
                    "occ": renderer._occ_gen.get_state() if renderer._occ_gen is not None else None}
             torch.save({"state_dict": sd, "epoch": epoch, "global_step": step, "optimizer_state": tr.optimizer_state_dict(),
                         "batch_size": batcher.batch_size, "rng_state": rng}, os.path.join(args.out, "last.ckpt"))

@@ -768,6 +768,92 @@ def gen_posed_images(datasets_mod):
     save("posed_images", **out)
 
 
+def gen_eval_epoch(rmod):
+    """The reference's own ``RobustENeRF.evaluation_epoch_end`` (models/robust_e_nerf.py:590-707) run on given
+    prediction / target images: ONE affine fit in log space per channel over ALL views, then per-view L1 / PSNR
+    (loss_metric/metric.py:60-72; torchmetrics' psnr restated as 10 log10(range^2 / mse) per sample) averaged over
+    the views.  Monochrome (5 views) and Bayer-sensor (3 views x 3 channels) cases; the views have different gains so
+    that a per-view fit would score differently."""
+    import torchmetrics.functional as tmf
+    from robust_e_nerf.loss_metric import metric as metric_mod
+
+    def psnr(preds, target, data_range, reduction="elementwise_mean", dim=None):
+        mse = ((preds - target) ** 2).mean(dim=dim)
+        return (10.0 * torch.log10(torch.as_tensor(data_range, dtype=preds.dtype) ** 2 / mse)).mean()
+    tmf.psnr = psnr
+    tmf.ssim = lambda preds, target, data_range, reduction: torch.full((), float("nan"))
+    m = metric_mod.Metric.__new__(metric_mod.Metric)
+    torch.nn.Module.__init__(m)
+    object.__setattr__(m, "lpips", lambda in0, in1: torch.zeros(1))
+    g = torch.Generator().manual_seed(11)
+    out = {}
+    for name, V, shape, bayer in (("mono", 5, (24, 32), False), ("bayer", 3, (3, 16, 20), True)):
+        lo, hi = 0.5 / 256, 1 - 0.5 / 256
+        target = (torch.rand((V,) + shape, generator=g) * (hi - lo) + lo).float()
+        gain = torch.linspace(0.6, 1.7, V).view((V,) + (1,) * len(shape))
+        pred = (target.log() * gain * 0.8 + 0.3 + 0.05 * torch.randn((V,) + shape, generator=g)).exp().float()
+        logged = {}
+        stub = types.SimpleNamespace(
+            all_gather=lambda o: o, unicode_code_pt_tensor_to_str=rmod.RobustENeRF.unicode_code_pt_tensor_to_str,
+            trainer=types.SimpleNamespace(log_dir=None, is_global_zero=True), has_bayer_filter=bayer, metric=m,
+            device=torch.device("cpu"), current_epoch=0, logger=None, eval_save_pred_intensity_img=False,
+            log=lambda k, v, **kw: logged.__setitem__(k, float(v)))
+        sid = torch.tensor([[ord(c) for c in f"r_{v}".ljust(16)] for v in range(V)])
+        outputs = [dict(sample_id=sid[v:v + 1], pred_intensity_img=pred[v:v + 1], target_intensity_img=target[v:v + 1])
+                   for v in range(V)]
+        stage = EasyDict(name="val", min_normalized_pixel_value=lo, max_normalized_pixel_value=hi)
+        rmod.RobustENeRF.evaluation_epoch_end(stub, outputs, stage)
+        out.update({f"{name}.pred": pred, f"{name}.target": target, f"{name}.min": np.array(lo), f"{name}.max": np.array(hi),
+                    f"{name}.l1": np.array(logged["val/l1"]), f"{name}.psnr": np.array(logged["val/psnr"])})
+        print(f"eval_epoch {name}: l1 {logged['val/l1']:.6f} psnr {logged['val/psnr']:.4f}")
+    save("eval_epoch", **out)
+
+
+def gen_eval_dataset(datasets_mod):
+    """The reference's own `DataModule._build_dataset("val" | "test")` (data/datamodule.py:100-134) on a tiny dataset with
+    train / val / test transforms: which views, in which order, a validation / test epoch sees for the YAML's
+    eval_target, eval_dataset_perm_seed and {val,test}_dataset_ratio x {val,test}_eff_batch_size."""
+    import json
+    from PIL import Image
+    from robust_e_nerf.data import datamodule as dm_mod
+    _install_cv2_stub()
+    g = np.random.default_rng(5)
+    root = tempfile.mkdtemp()
+    counts = dict(train=7, val=6, test=5)
+    tfs, imgs = {}, {}
+    for stage, n in counts.items():
+        os.makedirs(os.path.join(root, "views", stage))
+        imgs[stage] = g.integers(0, 256, (n, 4, 6), dtype=np.uint8)
+        frames = []
+        for k in range(n):
+            Image.fromarray(imgs[stage][k]).save(os.path.join(root, "views", stage, f"{stage[0]}_{k}.png"))
+            T = np.eye(4)
+            T[:3, 3] = [k, 0.5 * k, 2.0]
+            frames.append(dict(file_path=f"./{stage}/{stage[0]}_{k}", transform_matrix=T.tolist()))
+        tfs[stage] = dict(camera_angle_x=0.7, frames=frames)
+        json.dump(tfs[stage], open(os.path.join(root, "views", f"transforms_{stage}.json"), "w"))
+    np.savez(os.path.join(root, "camera_calibration.npz"), bayer_pattern=np.array(""))
+    dm_mod.DataModule.save_hyperparameters = lambda self, *a: setattr(self, "hparams", EasyDict(train_init_eff_batch_size=4))
+    cases = [dict(stage="val", eval_target=["novel_view"], seed=2, ratio=1.0, eff=1),
+             dict(stage="val", eval_target=["novel_view"], seed=3, ratio=2, eff=2),
+             dict(stage="test", eval_target=["novel_view"], seed=None, ratio=0.5, eff=1),
+             dict(stage="val", eval_target=["event_view"], seed=3, ratio=0.75, eff=1)]
+    out = {"n_cases": np.array(len(cases)), "transforms": np.array(json.dumps(tfs))}
+    for stage in counts:
+        out[f"img.{stage}"] = imgs[stage]
+    for i, c in enumerate(cases):
+        dm = dm_mod.DataModule(0, c["eval_target"], 1, None, root, 1.0, c["ratio"] if c["stage"] == "val" else 1.0,
+                               c["ratio"] if c["stage"] == "test" else 1.0, None, c["seed"], False, 4, 1024,
+                               c["eff"], c["eff"], 0)
+        ds = dm._build_dataset(c["stage"])
+        ids = ["".join(map(chr, ds[k]["sample_id"])).rstrip() for k in range(len(ds))]
+        out[f"case{i}"] = np.array(json.dumps(c))
+        out[f"case{i}.ids"] = np.array(ids)
+        out[f"case{i}.img0"] = ds[0]["img"]
+        print(f"eval_dataset case {i}: {c} -> {ids}")
+    save("eval_dataset", **out)
+
+
 def main():
     assert os.path.isdir(REF), "golden vectors can only be regenerated where /root/reference exists"
     install_stubs()
@@ -779,6 +865,11 @@ def main():
     from robust_e_nerf.models import robust_e_nerf as rmod
     from robust_e_nerf.models import trajectories
 
+    if sys.argv[1:] == ["eval_epoch"]:                 # regenerate one fixture only
+        return gen_eval_epoch(rmod)
+    if sys.argv[1:] == ["eval_dataset"]:
+        from robust_e_nerf.data import datasets as datasets_mod
+        return gen_eval_dataset(datasets_mod)
     gen_sh(sh_encoder)
     gen_rendering(vol_rendering)
     gen_trajectory(trajectories, nerf_mod)
@@ -796,6 +887,8 @@ def main():
     gen_batch_size(rmod)
     gen_occgrid_post_warmup(nerf_mod, nerfacc)
     gen_posed_images(datasets_mod)
+    gen_eval_epoch(rmod)
+    gen_eval_dataset(datasets_mod)
 
 
 if __name__ == "__main__":

@@ -4,6 +4,7 @@ import collections
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from robust_e_nerf_amd import data
@@ -251,3 +252,96 @@ def test_posed_image_loader_vs_reference_fixture(tmp_path):
         assert got["sample_id"] == ref_ids, (got["sample_id"], ref_ids)
         assert abs(got["min_normalized_pixel_value"] - float(g[f"{name}.min"])) < 1e-9
         assert abs(got["max_normalized_pixel_value"] - float(g[f"{name}.max"])) < 1e-6
+
+
+def test_epoch_metric_is_one_affine_fit_over_all_views_vs_reference_fixture():
+    """f2 / ADVICE r3: evaluation.align_and_score against the reference's own `evaluation_epoch_end`
+    (models/robust_e_nerf.py:590-707; fixture eval_epoch.npz from tests/golden/make_golden.py::gen_eval_epoch): ONE
+    scale / offset per channel over the flattened batch x H x W, then the mean of the per-view L1 / PSNR.  The fit is
+    additive over view shards (what the ranks all-reduce), and a per-view fit scores measurably differently."""
+    from robust_e_nerf_amd import evaluation
+    g = dict(np.load(os.path.join(GOLD, "eval_epoch.npz")))
+    for name in ("mono", "bayer"):
+        pred, tgt = torch.from_numpy(g[f"{name}.pred"]), torch.from_numpy(g[f"{name}.target"])
+        rng = float(g[f"{name}.max"]) - float(g[f"{name}.min"])
+        pv, (a, b) = evaluation.align_and_score(pred, tgt, rng)
+        assert abs(float(pv[:, 0].mean()) - float(g[f"{name}.l1"])) < 1e-6 * float(g[f"{name}.l1"]) + 1e-8, name
+        assert abs(float(pv[:, 1].mean()) - float(g[f"{name}.psnr"])) < 1e-4, name
+        # the reference's lstsq on the same data (float64) gives the same scale / offset
+        C = 1 if pred.dim() == 3 else 3
+        x = pred.reshape(pred.shape[0], C, -1).transpose(0, 1).reshape(C, -1).log().double()
+        y = tgt.reshape(tgt.shape[0], C, -1).transpose(0, 1).reshape(C, -1).log().double()
+        sol = torch.linalg.lstsq(torch.stack([x, torch.ones_like(x)], -1), y[..., None]).solution[..., 0]
+        assert torch.allclose(a, sol[:, 0], rtol=1e-10) and torch.allclose(b, sol[:, 1], rtol=1e-9, atol=1e-12)
+        # shards add up: sums of views [0, 2) + sums of views [2, V) == sums of all views
+        s = evaluation.log_fit_sums(pred[:2], tgt[:2]) + evaluation.log_fit_sums(pred[2:], tgt[2:])
+        assert torch.allclose(s, evaluation.log_fit_sums(pred, tgt), rtol=1e-12)
+        pv2, _ = evaluation.align_and_score(pred[2:], tgt[2:], rng, sums=s)
+        assert torch.equal(pv2, pv[2:])
+        # what the per-view fit of round 3 would have reported: systematically better than the reference's number
+        per_view = torch.stack([evaluation.align_and_score(pred[v:v + 1], tgt[v:v + 1], rng)[0][0] for v in range(len(pred))])
+        assert float(per_view[:, 1].mean()) > float(g[f"{name}.psnr"]) + 0.5
+
+
+def test_eval_views_vs_reference_datamodule_fixture(tmp_path):
+    """f1/f2, ADVICE r3: data.load_eval_views against the reference's own `DataModule._build_dataset` (data/datamodule.py:
+    100-134; fixture eval_dataset.npz from make_golden.py::gen_eval_dataset): eval_target picks the transforms file,
+    eval_dataset_perm_seed permutes, {val,test}_dataset_ratio (x {val,test}_eff_batch_size for ints) trims."""
+    import json
+    from PIL import Image
+    from robust_e_nerf_amd import data
+    g = dict(np.load(os.path.join(GOLD, "eval_dataset.npz")))
+    root = tmp_path / "ds"
+    tfs = json.loads(str(g["transforms"]))
+    for stage, tf in tfs.items():
+        os.makedirs(root / "views" / stage)
+        for k, im in enumerate(g[f"img.{stage}"]):
+            Image.fromarray(im).save(str(root / "views" / stage / f"{stage[0]}_{k}.png"))
+        (root / "views" / f"transforms_{stage}.json").write_text(json.dumps(tf))
+    np.savez(str(root / "camera_calibration.npz"), bayer_pattern=np.array(""))
+    for i in range(int(g["n_cases"])):
+        c = json.loads(str(g[f"case{i}"]))
+        dcfg = {"alpha_over_white_bg": False, "eval_dataset_perm_seed": c["seed"], f"{c['stage']}_dataset_ratio": c["ratio"],
+                f"{c['stage']}_eff_batch_size": c["eff"]}
+        got = data.load_eval_views(str(root), c["stage"], dcfg, c["eval_target"])
+        assert got["sample_id"] == list(g[f"case{i}.ids"]), (c, got["sample_id"])
+        assert len(got["img"]) == len(got["sample_id"]) == len(got["T_wc_position"])
+        assert np.allclose(got["img"][0].numpy(), g[f"case{i}.img0"], rtol=2e-6)
+    with pytest.raises(KeyError):
+        data.load_eval_views(str(root), "val", {}, ["novel_view"])                  # alpha_over_white_bg is required
+    with pytest.raises(NotImplementedError):
+        data.load_eval_views(str(root), "val", {"alpha_over_white_bg": False}, ["novel_view", "event_view"])
+    with pytest.raises(ValueError):                                                   # datamodule.py:129
+        data.load_eval_views(str(root), "val", {"alpha_over_white_bg": False, "val_dataset_ratio": 4, "val_eff_batch_size": 2},
+                             ["novel_view"])
+
+
+def test_image_reader_refuses_what_it_would_silently_downconvert(tmp_path):
+    """a 16-bit RGB PNG decoded by Pillow comes back as 8 bit (wrong quantisation levels -> wrong pixel-value
+    range -> wrong PSNR).  Without OpenCV / imageio the reader must raise; 8-bit colour and 16-bit grey stay lossless."""
+    import importlib.util
+    import struct
+    import zlib
+    from PIL import Image
+    from robust_e_nerf_amd import data
+    H, W = 3, 4
+    px = np.arange(H * W * 3, dtype=np.uint16).reshape(H, W, 3) * 1000
+    raw = b"".join(b"\x00" + px[y].astype(">u2").tobytes() for y in range(H))
+    chunk = lambda t, d: struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", W, H, 16, 2, 0, 0, 0)) + \
+        chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b"")
+    p16 = tmp_path / "rgb16.png"
+    p16.write_bytes(png)
+    assert data._png_header(str(p16)) == (16, 2)
+    if importlib.util.find_spec("cv2") is None and importlib.util.find_spec("imageio") is None:
+        with pytest.raises(ValueError, match="OpenCV or imageio"):
+            data._read_image(str(p16))
+    else:
+        assert np.array_equal(data._read_image(str(p16)), px)
+    g16 = (np.arange(H * W, dtype=np.uint16).reshape(H, W) * 4000)
+    Image.fromarray(g16).save(str(tmp_path / "g16.png"))
+    got = data._read_image(str(tmp_path / "g16.png"))
+    assert got.dtype == np.uint16 and np.array_equal(got, g16)
+    c8 = (np.arange(H * W * 4, dtype=np.uint8).reshape(H, W, 4))
+    Image.fromarray(c8).save(str(tmp_path / "c8.png"))
+    assert np.array_equal(data._read_image(str(tmp_path / "c8.png")), c8)

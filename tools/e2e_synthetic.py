@@ -150,13 +150,15 @@ def evaluate(ckpt, Kinv_d, cfg, png=None):
         r = engine.Renderer(fld, rcfg)
     r.binary.copy_(sd[cli.OCC + "_binary"].reshape(-1).to(torch.uint8).to(DEV))
     bk = torch.nn.functional.softplus(sd["nerf.parametrizations.render_bkgd.original"].to(DEV))
-    scores, tiles = [], []
+    gts, preds = [], []
     for pos, rot in novel_views():
-        gt = render_scene(Kinv_d, pos, rot) + 1e-3
-        pred, _, _ = evaluation.render_image(r, Kinv_d, pos, rot, H, W, bkgd=bk)
-        al = evaluation.affine_align_log(pred, gt)
-        scores.append(evaluation.psnr(al, gt, 1.0))
-        tiles.append(torch.cat([gt, al], 1))
+        gts.append(render_scene(Kinv_d, pos, rot) + 1e-3)
+        preds.append(evaluation.render_image(r, Kinv_d, pos, rot, H, W, bkgd=bk)[0])
+    # the reference's epoch metric: ONE affine fit in log space over all views, then per-view PSNR (robust_e_nerf.py:634-696)
+    gts, preds = torch.stack(gts), torch.stack(preds)
+    per_view, (a, b) = evaluation.align_and_score(preds, gts, 1.0)
+    scores = per_view[:, 1].tolist()
+    tiles = [torch.cat([gts[v], evaluation.apply_affine(preds[v], a, b)], 1) for v in range(len(gts))]
     if png:                                                        # rows: views; left = analytic scene, right = prediction
         from PIL import Image
         img = (torch.cat(tiles[:3], 0).clamp(0, 1) * 255).round().byte().cpu().numpy()
