@@ -1054,6 +1054,9 @@ __global__ __launch_bounds__(256, 1) void vfield_bwd6_kernel(FieldArgs a) {
 // wave w owns the output rows 32 w .. against up to 10 input tiles; partial sums go to per-split slabs.
 // Narrow layers (sigma: 1 output, colour output: C) take dz from the row-major [n_pad][32] buffers; the first layer, the skip
 // layer and the colour hidden layer take (part of) their input from the row-major encodings.
+#ifndef DW_FLIP
+#define DW_FLIP 4                                       // stages between sign changes of the dW accumulators (see vfield_dw_kernel)
+#endif
 struct FieldDwArgs {
     const void *dz;                                      // fragment slot (256-feature stride), or ..
     const float *dz_rows;                                // .. row-major [n_pad][32]
@@ -1123,8 +1126,10 @@ __global__ __launch_bounds__(512, 1) void vfield_dw_kernel(FieldDwArgs a) {
     };
     // the 32 x 32 tile whose two 16-feature chunks are `c0`, `c1` (lane = sample; kmap order: KM, natural order: !KM),
     // transposed, as the two k-chunk operands (k = samples) at dst[ks][piece]
+    // `sgn` (+-1): the selection matrix carries the sign, so the transposed tile comes out negated for free (dz tiles of the
+    // stages that accumulate into the negated accumulator, see the stage loop)
     auto transpose_store = [&](const float (&c0)[8], const float (&c1)[8], bool km, int lane, unsigned char *dst, float *colsum,
-                               bf16x8 (*regs)[3]) {
+                               bf16x8 (*regs)[3], float sgn) {
         const int hi = lane >> 5, sl = lane & 31;
         bf16x8 sel[2];
 #pragma unroll
@@ -1132,7 +1137,7 @@ __global__ __launch_bounds__(512, 1) void vfield_dw_kernel(FieldDwArgs a) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int f = km ? 16 * u + 8 * (j >> 2) + 4 * hi + (j & 3) : 16 * u + 8 * hi + j;
-                sel[u][j] = sl == f ? (__bf16)1.f : (__bf16)0.f;
+                sel[u][j] = (__bf16)(sl == f ? sgn : 0.f);
             }
         bf16x8 p0[3], p1[3];
         split8<NP>(c0, p0);
@@ -1154,9 +1159,9 @@ __global__ __launch_bounds__(512, 1) void vfield_dw_kernel(FieldDwArgs a) {
                 *reinterpret_cast<bf16x8 *>(dst + (1 * NP + p) * 1024 + lane * 16) = o1;
             }
         }
-        if (colsum) *colsum += cs;
+        if (colsum) *colsum += sgn * cs;
     };
-    auto stash = [&](int tid, int64_t blk, const Stage &q, unsigned char *buf) {
+    auto stash = [&](int tid, int64_t blk, const Stage &q, unsigned char *buf, float zsgn) {
         const int lane = tid & 63, wave = tid >> 6, hi = lane >> 5, sl = lane & 31;
         const bool live = blk * 32 + sl < a.n;           // lane = sample here: samples past the end contribute nothing
         unsigned char *xf = buf;
@@ -1184,10 +1189,10 @@ __global__ __launch_bounds__(512, 1) void vfield_dw_kernel(FieldDwArgs a) {
         float c0[8], c1[8];
         if (!ZROWS) {
             unpack(q.pz, c0, c1);
-            transpose_store(c0, c1, true, lane, nullptr, &bsum, azr);      // wave w's dz tile is used by wave w only
+            transpose_store(c0, c1, true, lane, nullptr, &bsum, azr, zsgn);      // wave w's dz tile is used by wave w only
         } else if (wave == 0) {
             unrows(q.rz, c0, c1);
-            transpose_store(c0, c1, false, lane, nullptr, nullptr, azr);
+            transpose_store(c0, c1, false, lane, nullptr, nullptr, azr, zsgn);
             if (hi == 0) {                               // bias of a narrow layer: fp32 sums of the rows' own values (columns 0 .. 3)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) bs4[j] += c0[j];
@@ -1195,11 +1200,11 @@ __global__ __launch_bounds__(512, 1) void vfield_dw_kernel(FieldDwArgs a) {
         }
         if (XFRAG) {
             unpack(q.px, c0, c1);
-            transpose_store(c0, c1, true, lane, xf + wave * 2 * NP * 1024, nullptr, nullptr);
+            transpose_store(c0, c1, true, lane, xf + wave * 2 * NP * 1024, nullptr, nullptr, 1.f);
         }
         if (XROWS && wave < kt_rows) {
             unrows(q.rx, c0, c1);
-            transpose_store(c0, c1, false, lane, xf + (XR0 + wave) * 2 * NP * 1024, nullptr, nullptr);
+            transpose_store(c0, c1, false, lane, xf + (XR0 + wave) * 2 * NP * 1024, nullptr, nullptr, 1.f);
         }
     };
     auto products = [&](int tid, const unsigned char *buf) {
@@ -1231,20 +1236,26 @@ __global__ __launch_bounds__(512, 1) void vfield_dw_kernel(FieldDwArgs a) {
         }
     };
     const int64_t b0 = blockIdx.x;
+    float fsgn = 1.f;                                    // sign the accumulators carry at the end
     {
         // products of stage i (this wave's dz fragments in registers, the input fragments from LDS buffer i & 1), then stage
         // i + 1 is transposed into the other buffer: one barrier a stage.  RD stages of loads are in flight (narrow layers do
         // so little per stage that one stage of lead time is shorter than the HBM latency).  Everything in the loop is
         // unconditional -- blocks past the end are clamped loads whose samples count as not live -- so that the compiler's
         // load counters stay exact (counted vmcnt waits).
+        // Rounding bias of the MFMA accumulate (toward -inf whatever the sign, tools/mlp_bias_probe.py; it grows like the
+        // number of accumulations: 4e-5 of max |dW| at n = 1 M against 4e-6 at 10 k): every DW_FLIP stages the accumulators
+        // AND the dz operand change sign, so the running sum is held alternately as +S and -S and the bias of one period
+        // cancels the next one's -- the cure of ren_mlp_x.hip without a second accumulator set.
         const int64_t S = n_splits, n_it = b0 < n_blk ? (n_blk - b0 + S - 1) / S : 0, n_it_pad = (n_it + RD - 1) / RD * RD;
         auto clampb = [&](int64_t blk) { return blk < n_blk ? blk : n_blk - 1; };
+        auto sgn_of = [](int64_t stage) { return ((stage / DW_FLIP) & 1) ? -1.f : 1.f; };
 #pragma unroll
         for (int k = 0; k < RD; ++k) fetch(threadIdx.x, clampb(b0 + k * S), sq[k]);
         {
             int tid = threadIdx.x;
             asm volatile("" : "+v"(tid));
-            stash(tid, b0, sq[0], smem_td);
+            stash(tid, b0, sq[0], smem_td, 1.f);
             fetch(tid, clampb(b0 + RD * S), sq[0]);
         }
         __syncthreads();
@@ -1254,12 +1265,19 @@ __global__ __launch_bounds__(512, 1) void vfield_dw_kernel(FieldDwArgs a) {
                 int tid = threadIdx.x;
                 asm volatile("" : "+v"(tid));
                 const int64_t ii = i + k, nxt = b0 + (ii + 1) * S;               // (nominal: may be past the end)
+                if (ii > 0 && ii % DW_FLIP == 0) {       // wave-uniform
+#pragma unroll
+                    for (int t = 0; t < NXT; ++t)
+#pragma unroll
+                        for (int g = 0; g < 16; ++g) acc[t][g] = -acc[t][g];
+                }
                 products(tid, smem_td + (ii & 1) * BUFBYTES);
-                stash(tid, nxt, sq[(k + 1) % RD], smem_td + ((ii + 1) & 1) * BUFBYTES);
+                stash(tid, nxt, sq[(k + 1) % RD], smem_td + ((ii + 1) & 1) * BUFBYTES, sgn_of(ii + 1));
                 fetch(tid, clampb(nxt + RD * S), sq[(k + 1) % RD]);
                 __syncthreads();
             }
         }
+        if (n_it_pad > 0) fsgn = sgn_of(n_it_pad - 1);
     }
     const int lane = threadIdx.x & 63, hi = lane >> 5, sl = lane & 31;
     if (has_tile) {
@@ -1272,7 +1290,7 @@ __global__ __launch_bounds__(512, 1) void vfield_dw_kernel(FieldDwArgs a) {
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
                 const int o = wave_k * 32 + rowc(g) + 4 * hi;
-                if (o < a.N) sw[(int64_t)o * a.K + k] = acc[t][g];
+                if (o < a.N) sw[(int64_t)o * a.K + k] = fsgn * acc[t][g];
             }
         }
     }

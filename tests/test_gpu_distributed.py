@@ -31,10 +31,9 @@ def _free_port():
     return p
 
 
-def _make_trainer(world, sampler="occgrid", w_grad=1e-3, dp_overlap=True):
+def _make_trainer(world, sampler="occgrid", w_grad=1e-3, dp_overlap=True, dev="cuda:0"):
     import bench
     from robust_e_nerf_amd import engine
-    dev = "cuda:0"
     ts, pos, quat, Kinv = bench.synthetic_scene(201)
     T = torch.from_numpy
     gen = torch.Generator(device=dev).manual_seed(0)
@@ -50,9 +49,8 @@ def _make_trainer(world, sampler="occgrid", w_grad=1e-3, dp_overlap=True):
     return tr, int(ts[-1])
 
 
-def _events(B, t_end, seed):
+def _events(B, t_end, seed, dev="cuda:0"):
     import bench
-    dev = "cuda:0"
     ev = bench.synthetic_events(B, t_end, seed=seed)
     b = {k: torch.from_numpy(v).to(dev).contiguous() for k, v in ev.items()}
     g = torch.Generator().manual_seed(seed)
@@ -63,31 +61,37 @@ def _shard(b, jit, lo, hi):
     return {k: v[lo:hi].contiguous() for k, v in b.items()}, jit[:, lo:hi].contiguous()
 
 
-def _worker(rank, port, out_dir):
+def _worker(rank, port, out_dir, backend="gloo", one_gpu_per_rank=False):
+    """backend gloo + both ranks on cuda:0 (this file), or backend nccl (= RCCL) + one GPU per rank
+    (tests/test_gpu_rccl_multirank.py, needs >= 2 GPUs): the same checks either way"""
     sys.path.insert(0, REPO)
     sys.path.insert(0, os.path.join(REPO, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD),
                       HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
     from robust_e_nerf_amd import parallel
-    torch.cuda.set_device(0)
-    parallel.init_from_env(backend="gloo")
-    res = {}
+    dev = f"cuda:{rank}" if one_gpu_per_rank else "cuda:0"
+    torch.cuda.set_device(dev)
+    parallel.init_from_env(backend=backend)
+    assert dist.get_world_size() == WORLD and dist.get_backend() == backend
+    res = {"backend": dist.get_backend(), "world": dist.get_world_size(), "device": dev}
+    import functools
+    mk, evs = functools.partial(_make_trainer, dev=dev), functools.partial(_events, dev=dev)   # this rank's device
     # ---- 1. gradient accumulation under data parallelism: 2 ranks x 2 micro-batches, ONE optimiser step
-    tr, t_end = _make_trainer(WORLD)
+    tr, t_end = mk(WORLD)
     B = 256                                                   # events per rank and micro-batch
     for bi in range(2):
-        b, jit = _events(2 * B, t_end, seed=10 + bi)
+        b, jit = evs(2 * B, t_end, seed=10 + bi)
         sb, sj = _shard(b, jit, rank * B, (rank + 1) * B)
         tr.step(sb, sj[0], sj[1], global_step=0, jitter_grad=sj[2], batch_index=bi, accumulate_grad_batches=2)
     res["collectives"] = tr.last_collectives
     res["m_accum"] = tr.m.clone()
     res["ct_m"] = tr.ct_m.clone()
     # ---- 2. a rank without samples (empty occupancy grid on rank 1 only) still matches its peer's collectives
-    tr2, _ = _make_trainer(WORLD, w_grad=0.0)
+    tr2, _ = mk(WORLD, w_grad=0.0)
     if rank == 1:
         tr2.r.binary.zero_()
-    b, jit = _events(2 * B, t_end, seed=20)
+    b, jit = evs(2 * B, t_end, seed=20)
     sb, sj = _shard(b, jit, rank * B, (rank + 1) * B)
     loss, aux = tr2.step(sb, sj[0], sj[1])
     res["empty_n"] = aux["n"]
@@ -95,10 +99,10 @@ def _worker(rank, port, out_dir):
     res["empty_m_nonzero"] = int((tr2.m != 0).sum())
     del tr2
     # ---- 3. K steps: occupancy refresh inside, dynamic batch size; replicas must stay identical
-    tr3, _ = _make_trainer(WORLD)
+    tr3, _ = mk(WORLD)
     Bk, sizes = 256, []
     for k, gs in enumerate((15, 16, 17, 32, 33)):              # refreshes at 16 and 32
-        b, jit = _events(2 * Bk, t_end, seed=30 + k)
+        b, jit = evs(2 * Bk, t_end, seed=30 + k)
         sb, sj = _shard(b, jit, rank * Bk, (rank + 1) * Bk)
         loss, aux = tr3.step(sb, sj[0], sj[1], global_step=gs, jitter_grad=sj[2])
         new = tr3.update_train_batch_size(aux, eff_ray_sample_batch_size=1 << 14)
@@ -109,7 +113,7 @@ def _worker(rank, port, out_dir):
     mine = [tr3.r.field.flat, tr3.m, tr3.v, tr3.small, tr3.ct, tr3.r.binary.float(), tr3.r.occs]
     same = []
     for t in mine:
-        tc = t.detach().cpu()
+        tc = t.detach().clone() if backend == "nccl" else t.detach().cpu()
         both = [torch.empty_like(tc) for _ in range(WORLD)]
         dist.all_gather(both, tc)
         same.append(bool(torch.equal(both[0], both[1])))
@@ -117,7 +121,7 @@ def _worker(rank, port, out_dir):
     res["binary_cells"] = int(tr3.r.binary.sum())
     # ---- 4. one evaluation image rendered by both ranks (row bands + all-gather, C3) == the single-rank render
     from robust_e_nerf_amd import evaluation, ops
-    ts_q = torch.tensor([7.3e6], dtype=torch.float64, device="cuda:0")
+    ts_q = torch.tensor([7.3e6], dtype=torch.float64, device=dev)
     pos, rot = ops.trajectory(ts_q, tr3.tab_ts, tr3.tab_pos, tr3.tab_quat)
     bk = torch.nn.functional.softplus(tr3.small[:1])
     full = evaluation.render_image(tr3.r, tr3.Kinv, pos[0], rot[0], 50, 64, bk)
@@ -137,7 +141,10 @@ def _worker(rank, port, out_dir):
 def test_two_ranks_through_the_hip_path_on_one_gpu(tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(port, str(tmp_path)), nprocs=WORLD, join=True)
-    got = torch.load(os.path.join(tmp_path, "r0.pt"))
+    check_two_rank_results(torch.load(os.path.join(tmp_path, "r0.pt")))
+
+
+def check_two_rank_results(got):
     # 1. one rank, the same four micro-batches, accumulate 4: the mean gradient (Adam's first moment after step 1) must agree
     tr, t_end = _make_trainer(1)
     B, bi = 256, 0

@@ -976,6 +976,46 @@ def test_config_a_step_vs_oracle(amd, spec, full_table_cache):
     assert rel_err(loss.cpu(), loss_o) < 1e-4
 
 
+def test_config_b_loss_vs_oracle(amd, spec, full_table_cache):
+    """BASELINE configs[1] at its own size (65 536 rays x 128 samples = 8 388 608 samples in ONE pass on
+    the GPU, fp32): rendered log-intensity of EVERY ray and the loss vs the CPU oracle <= 1e-4 (the BASELINE wording "loss
+    match vs CPU <= 1e-4").  The oracle runs the same batch in four event chunks (4 GB instead of 16 GB of host memory); with a
+    background parameter every ray is valid, so the batch loss is the mean of the equal-sized chunks' losses."""
+    from oracle import step as ostep
+    ops, engine = amd
+    g = load_golden("training_step_diff")
+    table = full_table_cache(g["table_seed"], g["table_scale"])
+    B, S, CH = 32768, 128, 4                                # 2 renders x 32 768 events = 65 536 rays
+    nb = _config_batch(B, 41, int(g["tab_ts"][-1]))
+    tr, _ = _trainer_from_golden(engine, g, table, sampler="uniform")
+    tr.r.cfg.n_uniform = S
+    batch = {k: dev(v) for k, v in nb.items()}
+    gen = torch.Generator().manual_seed(42)
+    j0, j1 = torch.rand(B, generator=gen), torch.rand(B, generator=gen)
+    loss, aux = tr.forward_backward(batch, dev(j0), dev(j1))
+    assert aux["n"] == 2 * B * S == 8388608
+    p = field_params_from(g, table)
+    cfg = ostep.SceneCfg(sampler="uniform", n_uniform=S, render_step_size=float(g["render_step_size"]))
+    keys = ("position", "start_ts", "end_ts", "num_pos", "num_neg", "u_ts_diff", "u_diff_start")
+    losses, worst = [], 0.0
+    li_s, li_e = aux["intensity_start"].cpu().log(), aux["intensity_end"].cpu().log()
+    for c in range(CH):
+        sl = slice(c * B // CH, (c + 1) * B // CH)
+        ob = ostep.EventBatch(*(t(nb[k][sl]) for k in keys), t(np.zeros(B // CH)))
+        with torch.no_grad():
+            loss_o, aux_o = ostep.training_forward(
+                ob, p, spec, cfg, Kinv=t(g["Kinv"]), tab_ts=t(g["tab_ts"]), tab_pos=t(g["tab_pos"]),
+                tab_quat=t(g["tab_quat"]), p2n_raw=t(g["p2n_raw"]), neg_ct=t(g["neg_ct"]), tau_raw=t(g["tau_raw"]),
+                tau_max=t(g["tau_max"]), bkgd_raw=t(g["bkgd_raw"]), binary=None, jitter_start=j0[sl], jitter_end=j1[sl])
+        assert aux_o["n_start"] + aux_o["n_end"] == 2 * (B // CH) * S
+        worst = max(worst, rel_err(li_s[sl], aux_o["intensity_start"].log()), rel_err(li_e[sl], aux_o["intensity_end"].log()))
+        losses.append(float(loss_o))
+    loss_o = sum(losses) / CH
+    err = abs(float(loss) - loss_o) / abs(loss_o)
+    print(f"config B (n = {aux['n']}): log-intensity max rel err {worst:.2e}, loss {float(loss):.7f} vs oracle {loss_o:.7f} ({err:.2e})")
+    assert worst < 1e-4 and err < 1e-4
+
+
 def test_bayer_sensor_step_vs_oracle(amd, spec, full_table_cache):
     """radiance_dim 3 with per-event colour channels (`bayering`, robust_e_nerf.py:230-233,390-393,425-431,887-890):
     l_diff + l_grad loss and gradients of the whole step vs the CPU oracle."""
@@ -1237,6 +1277,54 @@ def test_eval_render_psnr_vs_oracle(amd, spec, full_table_cache):
     assert rel_err(depth.cpu().reshape(-1), d_o) < 1e-3
     aligned = evaluation.affine_align_log(img.cpu().reshape(-1) * 1.7, i_o)      # affine ambiguity removed
     assert evaluation.psnr(aligned, i_o, data_range=float(i_o.max() - i_o.min())) > 60.0
+
+
+def test_config_e_eval_render_vs_oracle(amd, spec, full_table_cache):
+    """BASELINE configs[4]'s inference leg (evaluation_step, models/robust_e_nerf.py:533-571) at the settings of
+    configs/train/mocap-desk2.yaml:38-54 -- sphere contraction (rays march near -> far, no scene AABB), near 0.05 / far 3.0,
+    cone angle 0.004, 256^3 occupancy grid, no background parameter -- a 640 x 480 novel view = 307 200 rays in the
+    reference's 19 chunks of 16 384 rays: the whole image on the HIP path, bit-identical to the one-chunk render, and a
+    random 8 192-pixel subset against the CPU oracle at PSNR > 70 dB."""
+    import bench
+    from oracle import field as ofield, step as ostep, trajectory as otraj
+    from robust_e_nerf_amd import evaluation
+    ops, engine = amd
+    g = load_golden("training_step_e")
+    table = full_table_cache(g["table_seed"], g["table_scale"])
+    H, W, RES = 480, 640, 256
+    dt = math.sqrt(3) * 1.5 / 1024                                      # "auto" step of the 1.5 m room AABB (robust_e_nerf.py:220-226)
+    cfg = engine.RenderCfg(aabb=bench.E_AABB, contraction_type=ops.UN_BOUNDED_SPHERE, occ_res=(RES,) * 3, near_plane=0.05,
+                           far_plane=3.0, render_step_size=dt, cone_angle=0.004, sampler="occgrid")
+    fld = engine.NGPField(DEV)
+    fld.load(field_params_from(g, table))
+    r = engine.Renderer(fld, cfg)
+    g3 = np.stack(np.meshgrid(*[np.arange(RES)] * 3, indexing="ij"), -1)
+    binary = np.linalg.norm((g3 + 0.5) / RES - 0.5, axis=-1) < 0.1       # objects on the desk: a ball in contracted space
+    r.binary.copy_(dev(binary.astype(np.uint8).reshape(-1)))
+    ts, pos, quat, Kinv = bench.synthetic_scene_e(2001)
+    cam_pos, cam_R = t(pos[300]), otraj.unitquat_to_rotmat(t(quat[300])[None])[0]
+    Kinv = t(Kinv)
+    img, opac, depth = evaluation.render_image(r, dev(Kinv), dev(cam_pos), dev(cam_R), H, W, bkgd=None, chunk=16384)
+    img1, opac1, depth1 = evaluation.render_image(r, dev(Kinv), dev(cam_pos), dev(cam_R), H, W, bkgd=None, chunk=1 << 20)
+    assert torch.equal(img, img1) and torch.equal(opac, opac1) and torch.equal(depth, depth1), "the chunk size changed the image"
+    hit = float((opac > 0).float().mean())
+    assert 0.05 < hit < 0.95 and bool(torch.isfinite(img).all()), hit    # the view sees the occupied ball and empty space
+    # CPU oracle on a random subset of the pixels (rays are independent)
+    sel = torch.randperm(H * W, generator=torch.Generator().manual_seed(5))[:8192]
+    px = evaluation.pixel_grid(H, W, "cpu").reshape(-1, 2)[sel]
+    ocfg = ostep.SceneCfg(aabb=bench.E_AABB, contraction_type=ofield.UN_BOUNDED_SPHERE, occ_res=(RES,) * 3, near_plane=0.05,
+                          far_plane=3.0, render_step_size=dt, cone_angle=0.004, bkgd_is_param=False)
+    with torch.no_grad():
+        i_o, o_o, d_o, n_o, valid_o, _ = ostep.render_pixels(
+            Kinv, px, cam_pos[None].expand(len(sel), 3), cam_R[None].expand(len(sel), 3, 3), field_params_from(g, table),
+            spec, ocfg, binary=t(binary), jitter=None, bkgd=None, training=False)
+    i_h, o_h, d_h = img.cpu().reshape(-1)[sel], opac.cpu().reshape(-1)[sel], depth.cpu().reshape(-1)[sel]
+    ps = evaluation.psnr(i_h, i_o, data_range=float(i_o.max() - i_o.min()))
+    print(f"config E 640x480 render: {hit:.2f} of the rays hit, {n_o} oracle samples on 8192 rays, PSNR vs oracle {ps:.1f} dB")
+    assert ps > 70.0, f"PSNR vs oracle render {ps:.1f} dB"
+    assert rel_err(i_h, i_o) < 1e-4 and rel_err(o_h, o_o) < 1e-4
+    assert torch.equal(o_h > 0, valid_o)                                # is_valid = opacity > 0 (robust_e_nerf.py:868-871)
+    assert rel_err(d_h, d_o) < 1e-3
 
 
 # ------------------------------------------------------------------------------------------ log-intensity-gradient loss

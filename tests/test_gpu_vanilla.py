@@ -401,6 +401,60 @@ def test_fused_field_kernels_vs_float64_model(amd, mode, C, n):
     assert rel_err(fld.grad, whole) < (2e-6 if mode == 6 else 2e-3), rel_err(fld.grad, whole)
 
 
+def test_fused_field_weight_gradient_vs_float64_at_training_size(amd):
+    """the fp32-mode weight gradient of the fused field at the sample counts training runs it on (n = 2^21 + 5:
+    the e2e run's backward ranges are 2 M samples).  The MFMA accumulate rounds toward -inf whatever the sign, so a plain
+    accumulator drifts like the number of accumulations (4e-6 of max |dW| at n = 10 k, 4e-5 at 1 M); vfield_dw flips the
+    sign of accumulator and operand every few stages so that the drift cancels.  Against a float64 model of the twelve
+    layers (evaluated in sample chunks, gradients summed in float64): every dW and db <= 1e-5 of its largest entry."""
+    ops, engine, vanilla = amd
+    ref = _vfield_tool().reference
+    torch.manual_seed(7)
+    C, n, mode = 1, (1 << 21) + 5, 6
+    fld = vanilla.VanillaField(DEV, C)
+    for name, o, i in fld.layers:
+        k = 1.0 / i ** 0.5
+        fld.w[name].uniform_(-k, k)
+        fld.b[name].uniform_(-k, k)
+    ff = vanilla.FusedField(fld, mode)
+    ff.prep()
+    B = vanilla._Buffers(n, DEV, C, full=True, backward=False, fused=ff, save=True)
+    B.enc.zero_(); B.view.zero_()
+    B.enc[:n, :63] = torch.rand(n, 63, device=DEV) * 2 - 1
+    B.view[:n, :27] = torch.rand(n, 27, device=DEV) * 2 - 1
+    B.sel[:n] = (torch.rand(n, device=DEV) < 0.8).to(torch.uint8)
+    ff.forward(B, True)
+    dz_rgb, dz_sig = torch.zeros(B.n_pad, 32, device=DEV), torch.zeros(B.n_pad, 32, device=DEV)
+    # upstream gradients with a non-zero mean, as d loss / d (rgb, sigma pre-activations) have in training: a drift shows
+    # in sums whose terms do not cancel
+    dz_rgb[:n, :C] = torch.randn(n, C, device=DEV) + 0.5
+    dz_sig[:n, 0] = torch.randn(n, device=DEV) - 0.25
+    dz = ff.new_saved(n)
+    ff.backward(dz_rgb, dz_sig, B, dz)
+    fld.grad.zero_()
+    ff.backward_weight(dz_rgb, dz_sig, B, dz)
+    del dz
+    gw64, gb64, names = None, None, None
+    CH = 1 << 18
+    for s0 in range(0, n, CH):
+        m = min(CH, n - s0)
+        R = ref(fld, B.enc[s0:], B.view[s0:], B.sel[s0:], m)
+        ((R["zo"] * dz_rgb[s0:s0 + m, :C].double()).sum() + (R["zsig"][:, 0] * dz_sig[s0:s0 + m, 0].double()).sum()).backward()
+        gw = [w.grad.clone() for w in R["W"]]
+        gb = [b.grad.clone() for b in R["B"]]
+        gw64 = gw if gw64 is None else [a + b for a, b in zip(gw64, gw)]
+        gb64 = gb if gb64 is None else [a + b for a, b in zip(gb64, gb)]
+        names = R["names"]
+        del R
+    worst = 0.0
+    for i, k in enumerate(names):
+        ew = float((fld.gw[k].double() - gw64[i]).abs().max() / gw64[i].abs().max())
+        eb = float((fld.gb[k].double() - gb64[i]).abs().max() / gb64[i].abs().max())
+        worst = max(worst, ew, eb)
+        assert ew < 1e-5 and eb < 1e-5, (k, ew, eb)
+    print(f"fused field, fp32 mode, n = {n}: worst dW / db error vs float64 {worst:.2e} of the tensor's largest entry")
+
+
 def test_fused_field_equals_dense_layer_path(amd):
     """VanillaRenderer with the fused field (default) and with one dense-layer launch per Linear (fused_field = False: the
     path the exact-f32 mode and the tangent stream keep) agree to fp32 round-off, outputs and parameter gradients."""

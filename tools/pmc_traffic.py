@@ -10,7 +10,9 @@ Calibration on this workload (known byte counts): adam_kernel on the 49 MB table
 writes p,m,v,g(zeroed): 2 x FETCH = 98 MB/launch avg (expected 98), WRITE = 98.5 MB (expected 98);
 mlp_fwd reads the 2.15 GB feature stream: 2 x FETCH = 2.32 GB; bin_scatter writes 10 B x entries: 18.2 GB.
 """
-import json, sqlite3, sys
+import json, os, sqlite3, sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 GROUPS = {  # C-ABI call -> (kernel-name fragment, launches of that kernel per call)
     "hashgrid_fwd": [("hashgrid_fwd_kernel", 1)],
@@ -69,6 +71,8 @@ def main():
         w = sum(t for k, (_, t) in wtot.items() if any(fr in k for fr in frags)) * 1024 / n_calls
         out["calls"][call] = {"fetch_bytes_per_launch": f, "write_bytes_per_launch": w, "hbm_bytes_per_launch": f + w}
     out["calls"] = {k: v for k, v in out["calls"].items() if v["hbm_bytes_per_launch"] > 0}
+    from robust_e_nerf_amd import build                       # bench.py reports these numbers only for the kernels they measured
+    out["kernels_digest"] = build.source_stamps(with_compiler=False)[1]
     json.dump(out, open(dst, "w"), indent=1)
     print(json.dumps(out["calls"], indent=1))
 

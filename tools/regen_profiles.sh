@@ -1,8 +1,8 @@
 # Regenerates everything under profiles/ on a GPU box (run from the repo root through gpurun); results land in
 # gpurun_out/$RND/ and profiles/ (the bench reads profiles/${RND}_pmc_traffic.json for roofline.traffic).
-#   gpurun --timeout 1700 -- 'bash tools/regen_profiles.sh r03'
+#   gpurun --timeout 1700 -- 'bash tools/regen_profiles.sh r04'
 set -x
-RND=${1:-r03}
+RND=${1:-r04}
 R=$PWD
 O=$R/gpurun_out/$RND
 mkdir -p $O
