@@ -26,14 +26,23 @@ class _TruncExp(torch.autograd.Function):
     """exp with backward g*exp(clamp(x, max=15)) -- ngp.py:45-61."""
 
     @staticmethod
-    def forward(ctx, x):
-        ctx.save_for_backward(x)
+    def forward(x):
         return torch.exp(x)
+
+    @staticmethod
+    def setup_context(ctx, inputs, output):
+        ctx.save_for_backward(inputs[0])
+        ctx.save_for_forward(inputs[0])
 
     @staticmethod
     def backward(ctx, g):
         (x,) = ctx.saved_tensors
         return g * torch.exp(torch.clamp(x, max=15))
+
+    @staticmethod
+    def jvp(ctx, xd):                                       # forward mode (training_forward(tangent="forward")): same clamp
+        (x,) = ctx.saved_tensors
+        return xd * torch.exp(torch.clamp(x, max=15))
 
 
 def shifted_trunc_exp(x, shift=1.0):                       # ngp.py:64-65
@@ -45,24 +54,51 @@ def softplus(x, beta: float, threshold: float = 20.0):     # nerf.py:17-29 (torc
 
 
 # ----------------------------------------------------------------------------- bf16 MLP mode
-class _BRound(torch.autograd.Function):
-    """Round to bfloat16 (nearest even) and back, straight-through gradient."""
+def _bround(x):
+    return x.to(torch.bfloat16).to(x.dtype)
+
+
+class _RoundedMatMul(torch.autograd.Function):
+    """a @ b with BOTH operands rounded to bfloat16 (nearest even) and fp32 accumulation -- and the same for every matrix
+    product differentiation adds, in either mode and to any order: the tangent product of forward mode is
+    round(da) @ round(b), the products of the backward pass are round(g) @ round(b)^T and round(a)^T @ round(g).  This is what
+    `float32_matmul_precision: medium` (BASELINE configs[2]) does to the matmuls of the reference's nn.Linear layers, the
+    ones autograd adds included, and what mode 1 of the HIP MLP kernels does."""
 
     @staticmethod
-    def forward(ctx, x):
-        return x.to(torch.bfloat16).to(x.dtype)
+    def forward(a, b):
+        return _bround(a) @ _bround(b)
+
+    @staticmethod
+    def setup_context(ctx, inputs, output):
+        ctx.save_for_backward(*inputs)
+        ctx.save_for_forward(*inputs)
 
     @staticmethod
     def backward(ctx, g):
-        return g
+        a, b = ctx.saved_tensors
+        return _RoundedMatMul.apply(g, b.transpose(-1, -2)), _RoundedMatMul.apply(a.transpose(-1, -2), g)
+
+    @staticmethod
+    def jvp(ctx, ad, bd):
+        a, b = ctx.saved_tensors
+        out = None
+        if ad is not None:
+            out = _RoundedMatMul.apply(ad, b)
+        if bd is not None:
+            t = _RoundedMatMul.apply(a, bd)
+            out = t if out is None else out + t
+        return out
 
 
 BF16_LINEAR = False          # BASELINE configs[2] "bf16 MLP with fp32 composite": see bf16_linear()
 
 
 class bf16_linear:
-    """Context manager: every nn.Linear of the field sees bf16-rounded inputs and weights, fp32 accumulation,
-    fp32 bias / activations; the backward pass is the exact derivative (straight-through rounding)."""
+    """Context manager: every matrix product of the field's nn.Linear layers -- forward, tangent and backward -- sees
+    bf16-rounded operands (`_RoundedMatMul`); fp32 accumulation, bias, activations and activation derivatives.  With it
+    `step.training_forward` takes d log I / dt in FORWARD mode, as the HIP path does (the rounding sits on the tangent
+    operands of every layer; reverse mode would put it on the cotangents: same mathematics, other round-off)."""
 
     def __enter__(self):
         global BF16_LINEAR
@@ -75,7 +111,7 @@ class bf16_linear:
 
 def linear(x, w, b):
     if BF16_LINEAR:
-        x, w = _BRound.apply(x), _BRound.apply(w)
+        return _RoundedMatMul.apply(x, w.T) + b
     return x @ w.T + b
 
 

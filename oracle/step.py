@@ -113,12 +113,21 @@ class EventBatch:
 
 def training_forward(batch: EventBatch, p, spec, cfg: SceneCfg, *, Kinv, tab_ts, tab_pos, tab_quat,
                      p2n_raw, neg_ct, tau_raw, tau_max, bkgd_raw, binary,
-                     jitter_start, jitter_end, loss_cfg: Optional[dict] = None, jitter_grad=None):
+                     jitter_start, jitter_end, loss_cfg: Optional[dict] = None, jitter_grad=None,
+                     tangent: Optional[str] = None):
     """training_step: log-intensity-difference loss (two renders) and, when loss_cfg["w_grad"] > 0,
     the log-intensity-gradient loss (a third render differentiated w.r.t. its timestamp with
     create_graph=True, robust_e_nerf.py:383-409).
 
+    tangent: how d log I / dt of the third render is taken -- "reverse" = `torch.autograd.grad(..., create_graph=True)` as
+    the reference (utils/autograd.py:4-34), "forward" = forward-mode AD of the same graph (what the HIP path computes with
+    its tangent kernels; identical mathematics, and in fp32 identical to round-off -- tests/test_oracle_golden.py).  Default:
+    reverse, except inside `field.bf16_linear()` where the placement of the bf16 roundings depends on the mode and the
+    emulation follows the kernels.
+
     Returns (loss, aux) where aux holds every intermediate the parity tests compare."""
+    if tangent is None:
+        tangent = "forward" if field.BF16_LINEAR else "reverse"
     lc = dict(err_diff="mse", w_diff=1.0, pw_diff="mean_contrast_reciprocal_sq")
     lc.update(loss_cfg or {})
     w_grad = lc.get("w_grad", 0.0)
@@ -134,11 +143,22 @@ def training_forward(batch: EventBatch, p, spec, cfg: SceneCfg, *, Kinv, tab_ts,
         ts_g = tsd["grad_ts"]
         if not ts_g.requires_grad:
             ts_g = ts_g.detach().requires_grad_()               # robust_e_nerf.py:355
-        pos, R = trajectory.linear_trajectory(ts_g, tab_ts, tab_pos, tab_quat)
-        out["grad"] = render_pixels(Kinv, batch.position, pos, R, p, spec, cfg, channel_idx=batch.channel_idx,
+        if tangent == "forward":
+            import torch.autograd.forward_ad as fwAD
+            with fwAD.dual_level():
+                pos, R = trajectory.linear_trajectory(fwAD.make_dual(ts_g, torch.ones_like(ts_g)), tab_ts, tab_pos, tab_quat)
+                res = render_pixels(Kinv, batch.position, pos, R, p, spec, cfg, channel_idx=batch.channel_idx,
                                     binary=binary, jitter=jitter_grad, bkgd=bkgd, training=True)
-        log_g = out["grad"][0].log()
-        (dlog,) = torch.autograd.grad(log_g, ts_g, torch.ones_like(log_g), create_graph=True)   # utils/autograd.py:4-34
+                dual = fwAD.unpack_dual(res[0].log())
+                dlog = dual.tangent if dual.tangent is not None else torch.zeros_like(dual.primal)
+                out["grad"] = tuple(fwAD.unpack_dual(v).primal if torch.is_tensor(v) else v for v in res[:5]) + (res[5],)
+            dlog = dlog.to(ts_g.dtype)
+        else:
+            pos, R = trajectory.linear_trajectory(ts_g, tab_ts, tab_pos, tab_quat)
+            out["grad"] = render_pixels(Kinv, batch.position, pos, R, p, spec, cfg, channel_idx=batch.channel_idx,
+                                        binary=binary, jitter=jitter_grad, bkgd=bkgd, training=True)
+            log_g = out["grad"][0].log()
+            (dlog,) = torch.autograd.grad(log_g, ts_g, torch.ones_like(log_g), create_graph=True)   # utils/autograd.py:4-34
         grad_kw = dict(pred_log_grad=dlog, grad_valid=out["grad"][4])
     for name, ts, jit in (("start", tsd["diff_start_ts"], jitter_start),
                           ("end", tsd["diff_end_ts"], jitter_end)):

@@ -997,8 +997,10 @@ def test_config_b_loss_vs_oracle(amd, spec, full_table_cache):
     p = field_params_from(g, table)
     cfg = ostep.SceneCfg(sampler="uniform", n_uniform=S, render_step_size=float(g["render_step_size"]))
     keys = ("position", "start_ts", "end_ts", "num_pos", "num_neg", "u_ts_diff", "u_diff_start")
-    losses, worst = [], 0.0
+    from oracle import trajectory as otraj
+    losses, worst, n_edge = [], 0.0, 0
     li_s, li_e = aux["intensity_start"].cpu().log(), aux["intensity_end"].cpu().log()
+    lo3, ext3 = torch.tensor(cfg.aabb[:3]), torch.tensor(cfg.aabb[3:]) - torch.tensor(cfg.aabb[:3])
     for c in range(CH):
         sl = slice(c * B // CH, (c + 1) * B // CH)
         ob = ostep.EventBatch(*(t(nb[k][sl]) for k in keys), t(np.zeros(B // CH)))
@@ -1008,12 +1010,30 @@ def test_config_b_loss_vs_oracle(amd, spec, full_table_cache):
                 tab_quat=t(g["tab_quat"]), p2n_raw=t(g["p2n_raw"]), neg_ct=t(g["neg_ct"]), tau_raw=t(g["tau_raw"]),
                 tau_max=t(g["tau_max"]), bkgd_raw=t(g["bkgd_raw"]), binary=None, jitter_start=j0[sl], jitter_end=j1[sl])
         assert aux_o["n_start"] + aux_o["n_end"] == 2 * (B // CH) * S
-        worst = max(worst, rel_err(li_s[sl], aux_o["intensity_start"].log()), rel_err(li_e[sl], aux_o["intensity_end"].log()))
         losses.append(float(loss_o))
+        for nm, li in (("start", li_s), ("end", li_e)):
+            lo = aux_o["intensity_" + nm].log()
+            err = (li[sl] - lo).abs() / lo.abs().max()
+            # The field multiplies the density by selector = all(0 < x_unit < 1) (ngp.py:238): a STEP at the faces of the
+            # AABB.  The fixed-S comb puts a sample midpoint within float32 round-off of the exit face when the ray's
+            # jitter is within ~2e-5 of 1/2 (a few rays in 65 536), and whether that sample counts is then decided by the
+            # last ulp of the ray -- the reference semantics are discontinuous there, so those rays are identified (in
+            # the oracle's own samples) and left out of the 1e-4 bound; they must be rare and still close.
+            ts_ = aux_o["ts"]["diff_" + nm + "_ts"]
+            pos_, R_ = otraj.linear_trajectory(ts_, t(g["tab_ts"]), t(g["tab_pos"]), t(g["tab_quat"]))
+            o_, d_ = otraj.pixel_params_to_ray(t(g["Kinv"]), ob.position, pos_, R_)
+            ri, tsx, tex = aux_o["packed_" + nm]
+            u = (o_[ri.long()] + d_[ri.long()] * (tsx + tex).reshape(-1, 1) / 2 - lo3) / ext3
+            face = torch.minimum(u.abs(), (1 - u).abs()).min(dim=1).values
+            edge = torch.zeros(B // CH, dtype=torch.bool).index_put_((ri.long()[face < 1e-6],), torch.tensor(True))
+            n_edge += int(edge.sum())
+            worst = max(worst, float(err[~edge].max()))
+            assert float(err[edge].max() if edge.any() else 0.0) < 2e-2
     loss_o = sum(losses) / CH
     err = abs(float(loss) - loss_o) / abs(loss_o)
-    print(f"config B (n = {aux['n']}): log-intensity max rel err {worst:.2e}, loss {float(loss):.7f} vs oracle {loss_o:.7f} ({err:.2e})")
-    assert worst < 1e-4 and err < 1e-4
+    print(f"config B (n = {aux['n']}): log-intensity max rel err {worst:.2e} ({n_edge} rays with a sample on an AABB face set aside), "
+          f"loss {float(loss):.7f} vs oracle {loss_o:.7f} ({err:.2e})")
+    assert worst < 1e-4 and err < 1e-4 and n_edge <= 2 * B * 1e-3
 
 
 def test_bayer_sensor_step_vs_oracle(amd, spec, full_table_cache):
@@ -1511,57 +1531,76 @@ def test_bf16_mode_tangent_arithmetic_is_pinned(amd, spec, full_table_cache):
 
 def test_config_c3_bf16_lgrad_step_vs_oracle(amd, spec, full_table_cache):
     """BASELINE configs[2]: C_p + tau optimised, l_grad on, bf16 MLP with fp32 composite.  One whole step (three
-    renders, tangent render on the bf16 matrix cores in mode 1) vs the oracle with its bf16_linear() emulation
-    (bf16-rounded linear inputs / weights, fp32 accumulation, straight-through backward).  The kernel also rounds the
-    TANGENT operands of every layer to bf16 (the emulation keeps them fp32), so the tolerance on d(log I)/dt terms is
-    the bf16 operand precision (2^-9), stated below; loss and intensities are compared tighter."""
+    renders, tangent render on the bf16 matrix cores in mode 1) vs the oracle inside `field.bf16_linear()`: EVERY matrix
+    product of the nn.Linear layers -- forward, tangent, backward, of every order -- with bf16-rounded operands and fp32
+    accumulation (`oracle.field._RoundedMatMul`), d log I / dt in forward mode as the kernels take it.
+
+    What bounds the agreement of d log I / dt is NOT the bf16 arithmetic: the time derivative of a trilinear hash-grid
+    feature is piecewise constant, so a sample within one float32 ulp of a cell face of a fine level (cells of 2.4e-4 at
+    level 15) takes the neighbouring cell's gradient when the ray differs in its last bit -- and the HIP pose kernel and
+    the oracle's torch ops do differ there (d: 2e-7, dd: 5e-6).  A few rays in a hundred then deviate by per cents of the
+    largest |d log I / dt| IN FP32 TOO.  So the same step is run in fp32 (HIP fp32 vs fp32 oracle) and the bf16-mode error
+    distribution over the rays is held to that one: median and 90th percentile within 4x + 2e-4 of the fp32 pair's, the
+    worst ray within 2x.  Gradients: MLP 1e-2 (fp32 pair: 3e-3 against the reference golden), table 3e-3, d/d tau 5e-3
+    (second time derivative: forward-over-forward in the kernels, reverse-over-forward in the oracle), d/d C_p 1e-4.
+    Round 3 compared against a straight-through emulation (fp32 tangent / backward operands): d log I / dt 6e-2 max, MLP 2e-2."""
+    import contextlib
     from oracle import field, step as ostep
     ops, engine = amd
     g = load_golden("training_step_grad")
     table = full_table_cache(g["table_seed"], g["table_scale"])
-    tr, batch = _trainer_from_golden(engine, g, table, mlp_bf16=True)
     w_grad = float(g["w_grad"])
-    tr.t.w_grad, tr.t.err_grad, tr.t.pw_grad = w_grad, "mape", None
-    tr.t.train_contrast_threshold = True
-    tr.t.train_refractory_period = True
-    batch["u_grad"] = dev(g["u_grad"])
-    jit = t(g["jitters"])
-    loss_d, aux = tr.forward_backward(batch, dev(jit[1]), dev(jit[2]))
-    loss_g, aux_g = tr.grad_loss_forward_backward(batch, dev(jit[0]))
     occ_res = int(g["occ_res"])
     binary = t(np.unpackbits(g["binary"])[: occ_res ** 3].astype(bool)).view(occ_res, occ_res, occ_res)
     cfg = ostep.SceneCfg(occ_res=(occ_res,) * 3, render_step_size=float(g["render_step_size"]))
     ob = ostep.EventBatch(t(g["position"]), t(g["start_ts"]), t(g["end_ts"]), t(g["num_pos"]), t(g["num_neg"]),
                           t(g["u_ts_diff"]), t(g["u_diff_start"]), t(g["u_grad"]))
-    po = {k: v.detach().clone().requires_grad_() for k, v in field_params_from(g, table).items()}
-    tau_raw = t(g["tau_raw"]).clone().requires_grad_()
-    p2n = t(g["p2n_raw"]).clone().requires_grad_()
-    with field.bf16_linear():
-        loss_o, aux_o = ostep.training_forward(
-            ob, po, spec, cfg, Kinv=t(g["Kinv"]), tab_ts=t(g["tab_ts"]), tab_pos=t(g["tab_pos"]),
-            tab_quat=t(g["tab_quat"]), p2n_raw=p2n, neg_ct=t(g["neg_ct"]), tau_raw=tau_raw, tau_max=t(g["tau_max"]),
-            bkgd_raw=t(g["bkgd_raw"]), binary=binary, jitter_start=jit[1], jitter_end=jit[2], jitter_grad=jit[0],
-            loss_cfg=dict(w_grad=w_grad, err_grad="mape", pw_grad=None))
-        loss_o.backward()
-    loss = float(loss_d) + float(loss_g)
-    e_loss = abs(loss - float(loss_o)) / abs(float(loss_o))
-    e_int = rel_err(aux["intensity_start"].cpu(), aux_o["intensity_start"].detach())
-    e_dlog = rel_err(aux_g["dlog_dt"].cpu().double(), aux_o["pred_log_grad"].detach().double())
-    f = tr.r.field
-    e_gw = max(rel_err(v.cpu(), po[k].grad) for k, v in f.mlp_views(grad=True).items())
-    nz = po["hash"].grad.reshape(-1).abs().topk(4096).indices
-    e_gt = rel_err(f.g_table.cpu()[nz], po["hash"].grad.reshape(-1)[nz])
-    sg = torch.sigmoid(tr.tau_raw.detach() / tr.tau_max)
-    e_tau = rel_err(tr.tau_grad * sg * (1 - sg), tau_raw.grad)
-    e_ct = rel_err(tr.ct_grad[:1].cpu(), p2n.grad.reshape(-1)[:1])
-    print(f"configs[2] step vs bf16 emulation: loss {e_loss:.2e} intensity {e_int:.2e} dlogI/dt {e_dlog:.2e} "
-          f"MLP grads {e_gw:.2e} table grad {e_gt:.2e} d/dtau {e_tau:.2e} d/dC_p {e_ct:.2e}; "
-          f"loss vs the fp32 reference step {abs(loss - float(g['loss'])) / abs(float(g['loss'])):.2e}")
-    # measured: loss 6e-7, intensity 2e-6, d log I/dt 5.8e-2 (tangent operands rounded to bf16), MLP grads 2e-2,
-    # table grad 2.6e-3, d/d tau 2.6e-3, d/d C_p 3e-7
-    assert e_int < 1e-4 and e_loss < 1e-4 and e_dlog < 0.1
-    assert e_gw < 5e-2 and e_gt < 1e-2 and e_tau < 1e-2 and e_ct < 1e-4
-    tr.optimizer_step()
+    jit = t(g["jitters"])
+    stats = {}
+    for bf in (False, True):
+        tr, batch = _trainer_from_golden(engine, g, table, mlp_bf16=bf)
+        tr.t.w_grad, tr.t.err_grad, tr.t.pw_grad = w_grad, "mape", None
+        tr.t.train_contrast_threshold = True
+        tr.t.train_refractory_period = True
+        batch["u_grad"] = dev(g["u_grad"])
+        loss_d, aux = tr.forward_backward(batch, dev(jit[1]), dev(jit[2]))
+        loss_g, aux_g = tr.grad_loss_forward_backward(batch, dev(jit[0]))
+        po = {k: v.detach().clone().requires_grad_() for k, v in field_params_from(g, table).items()}
+        tau_raw = t(g["tau_raw"]).clone().requires_grad_()
+        p2n = t(g["p2n_raw"]).clone().requires_grad_()
+        with (field.bf16_linear() if bf else contextlib.nullcontext()):
+            loss_o, aux_o = ostep.training_forward(
+                ob, po, spec, cfg, Kinv=t(g["Kinv"]), tab_ts=t(g["tab_ts"]), tab_pos=t(g["tab_pos"]),
+                tab_quat=t(g["tab_quat"]), p2n_raw=p2n, neg_ct=t(g["neg_ct"]), tau_raw=tau_raw, tau_max=t(g["tau_max"]),
+                bkgd_raw=t(g["bkgd_raw"]), binary=binary, jitter_start=jit[1], jitter_end=jit[2], jitter_grad=jit[0],
+                loss_cfg=dict(w_grad=w_grad, err_grad="mape", pw_grad=None), tangent="forward")
+            loss_o.backward()
+        loss = float(loss_d) + float(loss_g)
+        f = tr.r.field
+        ref_dlog = aux_o["pred_log_grad"].detach().double()
+        e_ray = (aux_g["dlog_dt"].cpu().double() - ref_dlog).abs() / ref_dlog.abs().max()
+        nz = po["hash"].grad.reshape(-1).abs().topk(4096).indices
+        sg = torch.sigmoid(tr.tau_raw.detach() / tr.tau_max)
+        stats[bf] = dict(
+            loss=abs(loss - float(loss_o)) / abs(float(loss_o)),
+            inten=rel_err(aux["intensity_start"].cpu(), aux_o["intensity_start"].detach()),
+            dlog=[float(v) for v in torch.quantile(e_ray, torch.tensor([0.5, 0.9, 1.0], dtype=torch.float64))],
+            gw=max(rel_err(v.cpu(), po[k].grad) for k, v in f.mlp_views(grad=True).items()),
+            gt=rel_err(f.g_table.cpu()[nz], po["hash"].grad.reshape(-1)[nz]),
+            tau=rel_err(tr.tau_grad * sg * (1 - sg), tau_raw.grad),
+            ct=rel_err(tr.ct_grad[:1].cpu(), p2n.grad.reshape(-1)[:1]),
+            vs_ref=abs(loss - float(g["loss"])) / abs(float(g["loss"])))
+        print(("configs[2] bf16 step vs bf16 emulation: " if bf else "the same step in fp32 vs the fp32 oracle:   ") +
+              "  ".join(f"{k} {v:.2e}" if not isinstance(v, list) else f"{k} (median / 90 % / max over rays) " + " / ".join(f"{x:.1e}" for x in v)
+                        for k, v in stats[bf].items()))
+        if bf:
+            tr.optimizer_step()
+    a, b = stats[True], stats[False]
+    assert a["inten"] < 1e-4 and a["loss"] < 1e-4 and b["inten"] < 1e-4 and b["loss"] < 1e-4
+    assert a["dlog"][0] < 4 * b["dlog"][0] + 2e-4 and a["dlog"][1] < 4 * b["dlog"][1] + 2e-4 and a["dlog"][2] < 2 * b["dlog"][2] + 2e-3
+    assert a["dlog"][0] < 5e-4 and a["dlog"][1] < 1e-2
+    assert a["gw"] < 1e-2 and a["gt"] < 3e-3 and a["tau"] < 5e-3 and a["ct"] < 1e-4
+    assert b["gw"] < 5e-3 and b["gt"] < 3e-3 and b["tau"] < 5e-3 and b["ct"] < 1e-4
 
 
 def test_config_e_step_vs_reference_golden(amd, full_table_cache):
@@ -1961,7 +2000,10 @@ def test_train_cli_validation_epoch_and_posed_image_evaluation(tmp_path):
     assert abs(float(line.split("mean PSNR")[1].split()[0]) - ps[-1]) < 0.05, (line, ps)   # same checkpoint, same views
     # the checkpoint carries the random streams: resuming continues them
     ck = torch.load(os.path.join(tmp_path, "last.ckpt"), map_location="cpu", weights_only=False)
-    assert set(ck["rng_state"]) == {"batcher", "jitter", "occ"}
+    # ... every rank's generator states and the in-flight batch-size queue included
+    assert set(ck["rng_state"]) == {"per_rank", "pending", "occ"}
+    assert len(ck["rng_state"]["per_rank"]) == 1 and set(ck["rng_state"]["per_rank"][0]) == {"batcher", "jitter"}
+    assert len(ck["rng_state"]["pending"]) >= 1
 
 
 def test_event_interval_construction_on_device_equals_host():

@@ -77,7 +77,7 @@ def test_field_forward_backward(ct, full_table_cache):
     assert abs(float(table.grad.double().abs().sum()) - float(g["g_table_abs"])) < 1e-4 * float(g["g_table_abs"])
 
 
-def _run_training_step(g, table, with_grad, config_e=False, params=None):
+def _run_training_step(g, table, with_grad, config_e=False, params=None, tangent=None):
     p = params if params is not None else field_params_from(g, table)
     for v in p.values():
         v.requires_grad_()
@@ -105,7 +105,7 @@ def _run_training_step(g, table, with_grad, config_e=False, params=None):
         batch, p, SPEC, cfg, Kinv=t(g["Kinv"]), tab_ts=t(g["tab_ts"]), tab_pos=t(g["tab_pos"]),
         tab_quat=t(g["tab_quat"]), neg_ct=t(g["neg_ct"]),
         tau_max=t(g["tau_max"]), bkgd_raw=bkgd_raw, binary=binary,
-        jitter_start=jit[-2], jitter_end=jit[-1], jitter_grad=jit[0] if with_grad else None, loss_cfg=lc, **kw)
+        jitter_start=jit[-2], jitter_end=jit[-1], jitter_grad=jit[0] if with_grad else None, loss_cfg=lc, tangent=tangent, **kw)
     aux["leaves"] = kw
     return loss, aux, p, bkgd_raw
 
@@ -140,6 +140,36 @@ def test_training_step_grad(full_table_cache):
     assert rel_err(p["hash"].grad[t(g["g_table_idx"])], g["g_table_val"]) < 5e-4
     assert rel_err(aux["leaves"]["p2n_raw"].grad, g["g_p2n_raw"]) < 1e-4
     assert rel_err(aux["leaves"]["tau_raw"].grad, g["g_tau_raw"]) < 1e-3
+
+
+def test_training_step_grad_forward_mode(full_table_cache):
+    """d log I / dt taken in FORWARD mode (step.training_forward(tangent="forward"): what the HIP path computes, and what
+    the bf16 emulation of BASELINE configs[2] uses) reproduces the reference's reverse-mode `autograd.gradient` step:
+    the same golden loss and gradients, incl. d loss / d tau through the second derivative."""
+    from oracle import field as ofield
+    g = load_golden("training_step_grad")
+    table = full_table_cache(g["table_seed"], g["table_scale"]).clone()
+    loss, aux, p, bkgd_raw = _run_training_step(g, table, True, tangent="forward")
+    assert rel_err(loss, g["loss"]) < 1e-5
+    loss.backward()
+    for k in FIELD_KEYS:
+        assert rel_err(p[k].grad, g["g." + k]) < 5e-4, k
+    assert rel_err(p["hash"].grad[t(g["g_table_idx"])], g["g_table_val"]) < 5e-4
+    assert rel_err(aux["leaves"]["p2n_raw"].grad, g["g_p2n_raw"]) < 1e-4
+    assert rel_err(aux["leaves"]["tau_raw"].grad, g["g_tau_raw"]) < 1e-3
+    # the rounded matrix product of the bf16 emulation: operands rounded in the forward, tangent AND backward products
+    a, b = torch.randn(7, 5, dtype=torch.float64, requires_grad=True), torch.randn(5, 3, dtype=torch.float64, requires_grad=True)
+    R = lambda x: x.to(torch.bfloat16).to(x.dtype)
+    y = ofield._RoundedMatMul.apply(a, b)
+    assert torch.equal(y, R(a) @ R(b))
+    gy = torch.randn(7, 3, dtype=torch.float64)
+    ga, gb = torch.autograd.grad(y, (a, b), gy)
+    assert torch.equal(ga, R(gy) @ R(b).T) and torch.equal(gb, R(a).T @ R(gy))
+    import torch.autograd.forward_ad as fwAD
+    da = torch.randn(7, 5, dtype=torch.float64)
+    with fwAD.dual_level():
+        yd = fwAD.unpack_dual(ofield._RoundedMatMul.apply(fwAD.make_dual(a.detach(), da), b.detach())).tangent
+    assert torch.equal(yd, R(da) @ R(b.detach()))
 
 
 def test_training_step_arch_mlp():

@@ -20,8 +20,16 @@ gt = torch.zeros(n_table, device=dev)
 P = ops._ptr
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 ref = None
-for path in (sys.argv[1:] or [_lib.LIB_PATH]):
+# REN_AB="hgb_scatter=1,2": time the default library once per value of that knob (A/B of kernel generations inside one build)
+ab = os.environ.get("REN_AB")
+variants = [(p_, None) for p_ in (sys.argv[1:] or [_lib.LIB_PATH])]
+if ab:
+    kname, vals = ab.split("=")
+    variants = [(_lib.LIB_PATH, (ops.KNOBS[kname], int(v))) for v in vals.split(",")]
+for path, kv in variants:
     lib = ctypes.CDLL(os.path.abspath(path))
+    if kv is not None:
+        lib.ren_set_knob(kv[0], kv[1])
     for name in ("ren_hashgrid_bwd_binned", "ren_hashgrid_bwd_binned_workspace_bytes"):
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = _lib.SIGNATURES[name]
@@ -41,5 +49,5 @@ for path in (sys.argv[1:] or [_lib.LIB_PATH]):
         ref = gt.clone()
     else:
         msg = "  max|diff| vs first %.2e (max %.2e)" % (float((gt - ref).abs().max()), float(ref.abs().max()))
-    print(f"{os.path.basename(path):24s} {e0.elapsed_time(e1) / 3:7.2f} ms{msg}", flush=True)
+    print(f"{os.path.basename(path):24s} {'' if kv is None else 'knob=%d ' % kv[1]}{e0.elapsed_time(e1) / 3:7.2f} ms{msg}", flush=True)
     del ws
