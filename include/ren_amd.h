@@ -69,11 +69,9 @@ int ren_abi_version(void);                       /* bumps when a signature chang
  *   REN_KNOB_HGB_HALVE_REGIONS 1: halve the bin regions so the overflow path (global atomics) runs
  *   REN_KNOB_MARCH_SEQUENTIAL  1: sequential occupancy marcher instead of the speculative one
  *   REN_KNOB_HG_VARIANT        atomic hash-grid backward: bit 0 XCD-affine level mapping, bit 1 lane-pair atomics (default 2)
- *   REN_KNOB_VFIELD_PLAIN      1: arch mlp, bf16 mode: the forward / backward kernels without the software-pipelined epilogue
- *   REN_KNOB_HGB_SCATTER       binned hash-grid backward, scatter kernels: 2 (default) = count-then-place workgroups (one cursor
- *                              reservation per workgroup for all levels), 1 = the per-level rank / reserve / place passes */
+ *   REN_KNOB_VFIELD_PLAIN      1: arch mlp, bf16 mode: the forward / backward kernels without the software-pipelined epilogue */
 enum { REN_KNOB_HGB_NO_PAIRS = 0, REN_KNOB_HGB_HALVE_REGIONS = 1, REN_KNOB_MARCH_SEQUENTIAL = 2, REN_KNOB_HG_VARIANT = 3,
-       REN_KNOB_VFIELD_PLAIN = 4, REN_KNOB_HGB_SCATTER = 5, REN_KNOB_COUNT = 6 };
+       REN_KNOB_VFIELD_PLAIN = 4, REN_KNOB_COUNT = 5 };
 int ren_set_knob(int32_t knob, int32_t value);    /* REN_OK or REN_ERR_BAD_ARG */
 int ren_get_knob(int32_t knob);
 const char *ren_build_info(void);                /* "gfx950 ..."                        */

@@ -570,337 +570,6 @@ __global__ __launch_bounds__(SC_THREADS, KIND == 1 ? REN_SC_WAVES_PAIR : REN_SC_
     }
 }
 
-// ---- 3'. scatter, count-then-place (round 4; REN_KNOB_HGB_SCATTER = 2, the default) ---------------------------------------
-// The per-level pass above is a dependency chain -- histogram -> barrier -> 64 threads reserve the bins' runs with global
-// (memory-side, ~2 us) cursor atomics while 448 wait -> barrier -> placement -> barrier -> append -- run once per level: four
-// barriers and one exposed atomic round trip per level and 512 samples; 2.56 TB/s of appends at 38 % VALU (round 3).  Here a
-// workgroup first COUNTS the records of all its levels (hashing only: positions are in registers, nothing is loaded), then
-// reserves every (level, bin) run with ONE round of cursor atomics (704 of them in flight together), and only then walks the
-// levels: rank (LDS counter) -> place -> barrier -> append, with the next level's feature gradients, hashes and ranks formed
-// between the append's stores and the barrier that frees the staging area.  Two LDS-only barriers per level, no global
-// round trip inside the level loop.  The records, the regions and the accumulate pass are unchanged.
-constexpr int SC2_MAX_LEVELS = REN_MAX_LEVELS;
-
-struct LevelList { int n; int lvl[REN_MAX_LEVELS]; };
-
-// reserve the runs of `n_lv` levels x 64 bins: cnt[k][b] records each.  loc = staging offset of the run inside its level
-// (levels are staged one at a time), dst = first 16-byte slot (pairs) / first entry (singles) of the run in the pool.
-// A wave takes one level per round: its 64 lanes are the level's bins, so the prefix is a wave scan.
-template <int THREADS, bool PAIRS>
-__device__ __forceinline__ void reserve_runs(const BinTab &bt, const Workspace &ws, const LevelList &ll, uint32_t (*cnt)[MAX_BINS_PER_LEVEL],
-                                             uint16_t (*loc)[MAX_BINS_PER_LEVEL + 1], uint16_t (*fit)[MAX_BINS_PER_LEVEL],
-                                             uint64_t (*dst)[MAX_BINS_PER_LEVEL], int *any_overflow) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int k = wave; k < ll.n; k += THREADS / 64) {
-        const int lvl = ll.lvl[k];
-        const int nb = bt.bin_base[lvl + 1] - bt.bin_base[lvl];
-        const uint32_t c = cnt[k][lane];
-        uint32_t inc = c;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t t = __shfl_up(inc, off, 64);
-            if (lane >= off) inc += t;
-        }
-        uint32_t room = c;
-        uint64_t d = 0;
-        if (lane < nb && c) {
-            const int gb = bt.bin_base[lvl] + lane;
-            const uint32_t at = atomicAdd(&ws.cursors[gb], c);         // reserve the run in the bin's region
-            const uint32_t cap = ws.bin_cap[gb];
-            room = at >= cap ? 0u : (cap - at < c ? cap - at : c);
-            d = ws.bin_start[gb] + at;                                 // absolute 16-byte slot of the run's first record
-        }
-        loc[k][lane] = (uint16_t)(inc - c);
-        if (lane == 63) loc[k][64] = (uint16_t)inc;
-        fit[k][lane] = (uint16_t)room;
-        dst[k][lane] = d;
-        cnt[k][lane] = 0;                                              // becomes the rank counter of the placement phase
-        const uint64_t ov = __ballot(room < c);
-        if (lane == 0) any_overflow[k] = ov != 0;
-    }
-}
-
-template <int THREADS>
-__global__ __launch_bounds__(THREADS, THREADS == 1024 ? 2 : 6) void bin_scatter_pairs2_kernel(
-    GridDev g, BinTab bt, LevelList ll, SampleArgs a, Workspace ws, float *__restrict__ grad_table) {
-    __shared__ uint32_t cnt[SC2_MAX_LEVELS][MAX_BINS_PER_LEVEL];      // phase 1: records per (level, bin); phase 2: rank counters
-    __shared__ uint16_t loc[SC2_MAX_LEVELS][MAX_BINS_PER_LEVEL + 1], fit[SC2_MAX_LEVELS][MAX_BINS_PER_LEVEL];
-    __shared__ uint64_t dst[SC2_MAX_LEVELS][MAX_BINS_PER_LEVEL];
-    __shared__ int any_overflow[SC2_MAX_LEVELS];
-    __shared__ uint32_t lmax_s[SC2_MAX_LEVELS];
-    __shared__ __attribute__((aligned(16))) float4 st_p[THREADS * 4];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int64_t chunk = blockIdx.x, i = chunk * THREADS + tid;
-    const bool inb = i < a.n;
-    float u[3] = {0.f, 0.f, 0.f}, ud[3];
-    if (inb) unit_pos<false>(a, i, u, ud);
-    for (int e = tid; e < SC2_MAX_LEVELS * MAX_BINS_PER_LEVEL; e += THREADS) (&cnt[0][0])[e] = 0;
-    if (tid < SC2_MAX_LEVELS) lmax_s[tid] = 0;
-    lds_barrier();
-    // ---- phase 1: count.  Every in-range sample stages its four pair records (zero gradients included: they add zeros),
-    // except when x + 1 carries past bit 12 of the hash (once in 8 192 cells: those go to the table directly, in phase 2)
-#pragma unroll 1
-    for (int k = 0; k < ll.n; ++k) {
-        const int lvl = ll.lvl[k];
-        const LevelPos p = level_pos(u[0], u[1], u[2], g.scale[lvl]);
-        const uint32_t m = g.size[lvl] - 1u;
-        const uint32_t hy0 = p.c[1] * 2654435761u, hy1 = hy0 + 2654435761u, hz0 = p.c[2] * 805459861u, hz1 = hz0 + 805459861u;
-        const bool same = (((p.c[0] ^ (p.c[0] + 1u)) & m) >> BIN_SHIFT) == 0;
-        if (inb && same) {
-            atomicAdd(&cnt[k][((p.c[0] ^ hy0 ^ hz0) & m) >> BIN_SHIFT], 1u);
-            atomicAdd(&cnt[k][((p.c[0] ^ hy1 ^ hz0) & m) >> BIN_SHIFT], 1u);
-            atomicAdd(&cnt[k][((p.c[0] ^ hy0 ^ hz1) & m) >> BIN_SHIFT], 1u);
-            atomicAdd(&cnt[k][((p.c[0] ^ hy1 ^ hz1) & m) >> BIN_SHIFT], 1u);
-        }
-    }
-    lds_barrier();
-    reserve_runs<THREADS, true>(bt, ws, ll, cnt, loc, fit, dst, any_overflow);
-    lds_barrier();
-    // ---- phase 2: per level rank -> place -> append
-    uint32_t code[4], rank[4];
-    float v0[4], v1[4], fx = 0.f;
-    bool have = false;
-    float d0 = 0.f, d1 = 0.f, e0, e1;
-    if (ll.n > 0 && inb) (void)load_dfeat<false>(a, g.n_levels, ll.lvl[0], i, d0, d1, e0, e1);
-    auto form = [&](int k, float dd0, float dd1) {                     // records + ranks of level list entry k
-        const int lvl = ll.lvl[k];
-        const LevelPos p = level_pos(u[0], u[1], u[2], g.scale[lvl]);
-        uint32_t idx[8];
-        corner_indices8(p.c[0], p.c[1], p.c[2], g.res[lvl], g.size[lvl], true, idx);
-        const bool same = ((idx[0] ^ idx[1]) >> BIN_SHIFT) == 0;
-        const float wy1 = p.w[1], wz1 = p.w[2], wy0 = 1.f - wy1, wz0 = 1.f - wz1;
-        fx = p.w[0];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float wyz = ((j & 1) ? wy1 : wy0) * ((j & 2) ? wz1 : wz0);
-            v0[j] = wyz * dd0; v1[j] = wyz * dd1;
-        }
-        if (inb && !same && (dd0 != 0.f || dd1 != 0.f)) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                table_atomic(grad_table, g.offset[lvl], idx[2 * j], (1.f - fx) * v0[j], (1.f - fx) * v1[j]);
-                table_atomic(grad_table, g.offset[lvl], idx[2 * j + 1], fx * v0[j], fx * v1[j]);
-            }
-        }
-        have = inb && same;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t bin = idx[2 * j] >> BIN_SHIFT;
-            rank[j] = have ? atomicAdd(&cnt[k][bin], 1u) : 0u;
-            code[j] = (idx[2 * j] & (BIN_ENTRIES - 1)) | ((idx[2 * j + 1] & (BIN_ENTRIES - 1)) << BIN_SHIFT) | (bin << PAIR_BIN_SHIFT);
-        }
-        // max |update| of the level (scale of the accumulate pass's fixed-point sums): one LDS atomic per wave
-        float vmax = inb ? fmaxf(fabsf(dd0), fabsf(dd1)) : 0.f;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
-        if (lane == 0 && vmax > 0.f) atomicMax(&lmax_s[k], __float_as_uint(vmax));
-    };
-    if (ll.n > 0) form(0, d0, d1);
-#pragma unroll 1
-    for (int k = 0; k < ll.n; ++k) {
-        const int lvl = ll.lvl[k];
-        const bool more = k + 1 < ll.n;
-        if (more && inb) (void)load_dfeat<false>(a, g.n_levels, ll.lvl[k + 1], i, d0, d1, e0, e1);   // in flight over the append
-        if (have) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                st_p[loc[k][code[j] >> PAIR_BIN_SHIFT] + rank[j]] = make_float4(__uint_as_float(code[j]), v0[j], v1[j], fx);
-        }
-        lds_barrier();
-        const uint32_t total = loc[k][MAX_BINS_PER_LEVEL];
-        const bool ovf = any_overflow[k] != 0;
-        float4 *pool = reinterpret_cast<float4 *>(ws.pool);
-        for (uint32_t q = tid; q < total; q += THREADS) {
-            const float4 r = st_p[q];
-            const uint32_t c = __float_as_uint(r.x), b = c >> PAIR_BIN_SHIFT, off = q - loc[k][b];
-            if (!ovf || off < fit[k][b]) {
-                pool[dst[k][b] + off] = r;
-            } else {                                                   // region full (capacity-sized hashed bins only)
-                const uint32_t i0 = (b << BIN_SHIFT) | (c & (BIN_ENTRIES - 1));
-                const uint32_t i1 = (b << BIN_SHIFT) | ((c >> BIN_SHIFT) & (BIN_ENTRIES - 1));
-                table_atomic(grad_table, g.offset[lvl], i0, (1.f - r.w) * r.y, (1.f - r.w) * r.z);
-                table_atomic(grad_table, g.offset[lvl], i1, r.w * r.y, r.w * r.z);
-            }
-        }
-        if (more) form(k + 1, inb ? d0 : 0.f, inb ? d1 : 0.f);
-        lds_barrier();                                                 // the staging area is free again
-    }
-    if (tid < ll.n && lmax_s[tid]) {
-        uint32_t *slot = ws.level_max + (ll.lvl[tid] * LMAX_SLOTS + (int)(chunk % LMAX_SLOTS)) * LMAX_STRIDE;
-        if (lmax_s[tid] > __builtin_nontemporal_load(slot)) atomicMax(slot, lmax_s[tid]);
-    }
-}
-
-// count-only twin of bin_rank8_dense: the leader adds the number of emitting lanes to the corners' bins
-__device__ __forceinline__ void bin_count8_dense(bool emit, const uint32_t (&bin)[8], int lane, uint32_t *hist) {
-    const uint64_t m = __ballot(emit);
-    if (!m) return;
-    const int leader = __ffsll((unsigned long long)m) - 1;
-    uint32_t lb[8];
-    bool mixed = false;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        lb[c] = __shfl(bin[c], leader, 64);
-        mixed |= emit && bin[c] != lb[c];
-    }
-    if (__ballot(mixed)) {                                         // wave-uniform branch
-#pragma unroll
-        for (int c = 0; c < 8; ++c)
-            if (emit) atomicAdd(&hist[bin[c]], 1u);
-        return;
-    }
-    if (lane == leader) {
-        const uint32_t cnt = (uint32_t)__popcll(m);
-#pragma unroll
-        for (int c = 0; c < 8; ++c) atomicAdd(&hist[lb[c]], cnt);
-    }
-}
-
-// Dense (non-hashed) levels, count-then-place: after the run merge a workgroup has only ~2 500 single-update records for ALL
-// five dense levels (x 6.7 fewer than samples x corners at level 0 ... x 1.5 at level 4), yet the per-level pass above spends as
-// long on a dense level as on a hashed one (0.4 ms per level at n = 16.8 M: the chain, not the bytes).  Here the levels are
-// counted first, reserved together, and then placed into ONE staging area and appended in ONE pass (in batches of levels
-// whose records fit the staging area, for sample streams whose consecutive samples do not share cells): four barriers per
-// workgroup instead of twenty.
-constexpr int SC2_DENSE_MAX = 8;
-
-template <int THREADS>
-__global__ __launch_bounds__(THREADS, 6) void bin_scatter_dense2_kernel(
-    GridDev g, BinTab bt, LevelList ll, SampleArgs a, Workspace ws, float *__restrict__ grad_table) {
-    constexpr int ENTRIES = THREADS * 8;
-    __shared__ uint32_t cnt[SC2_DENSE_MAX][MAX_BINS_PER_LEVEL];
-    __shared__ uint16_t loc[SC2_DENSE_MAX][MAX_BINS_PER_LEVEL + 1], fit[SC2_DENSE_MAX][MAX_BINS_PER_LEVEL];
-    __shared__ uint64_t dst_v[SC2_DENSE_MAX][MAX_BINS_PER_LEVEL], dst_i[SC2_DENSE_MAX][MAX_BINS_PER_LEVEL];   // byte offsets in the pool
-    __shared__ int any_overflow[SC2_DENSE_MAX];
-    __shared__ uint32_t lmax_s[SC2_DENSE_MAX], sbase[SC2_DENSE_MAX];
-    __shared__ __attribute__((aligned(16))) unsigned char stage[ENTRIES * 12];     // key u32[] | v float2[]
-    uint32_t *st_key = reinterpret_cast<uint32_t *>(stage);
-    float2 *st_v = reinterpret_cast<float2 *>(stage + ENTRIES * 4);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int64_t chunk = blockIdx.x, i = chunk * THREADS + tid;
-    const bool inb = i < a.n;
-    float u[3] = {0.f, 0.f, 0.f}, ud[3];
-    if (inb) unit_pos<false>(a, i, u, ud);
-    for (int e = tid; e < SC2_DENSE_MAX * MAX_BINS_PER_LEVEL; e += THREADS) (&cnt[0][0])[e] = 0;
-    if (tid < SC2_DENSE_MAX) lmax_s[tid] = 0;
-    lds_barrier();
-    // ---- phase 1: count the run tails
-#pragma unroll 1
-    for (int k = 0; k < ll.n; ++k) {
-        const int lvl = ll.lvl[k];
-        float d0, d1, e0, e1;
-        const bool valid = inb && load_dfeat<false>(a, g.n_levels, lvl, i, d0, d1, e0, e1);
-        const LevelPos p = level_pos(u[0], u[1], u[2], g.scale[lvl]);
-        uint32_t idx[8], bins[8];
-        corner_indices8(p.c[0], p.c[1], p.c[2], g.res[lvl], g.size[lvl], false, idx);
-#pragma unroll
-        for (int c = 0; c < 8; ++c) bins[c] = idx[c] >> BIN_SHIFT;
-        bool head;
-        const bool emit = run_tail(true, valid, cell_key(p), lane, head);
-        bin_count8_dense(emit, bins, lane, cnt[k]);
-    }
-    lds_barrier();
-    {   // reserve (as reserve_runs, plus the region capacities the append of single-update records needs)
-        const int wave = tid >> 6;
-        for (int k = wave; k < ll.n; k += THREADS / 64) {
-            const int lvl = ll.lvl[k];
-            const int nb = bt.bin_base[lvl + 1] - bt.bin_base[lvl];
-            const uint32_t c = cnt[k][lane];
-            uint32_t inc = c;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t t = __shfl_up(inc, off, 64);
-                if (lane >= off) inc += t;
-            }
-            uint32_t room = c;
-            uint64_t dv = 0, di = 0;
-            if (lane < nb && c) {
-                const int gb = bt.bin_base[lvl] + lane;
-                const uint32_t at = atomicAdd(&ws.cursors[gb], c);
-                const uint32_t cap = ws.bin_cap[gb];
-                room = at >= cap ? 0u : (cap - at < c ? cap - at : c);
-                dv = ws.bin_start[gb] * 16 + (uint64_t)at * 8;         // float2 v[cap] at the region's start, u16 idx[cap] behind it
-                di = ws.bin_start[gb] * 16 + (uint64_t)cap * 8 + (uint64_t)at * 2;
-            }
-            loc[k][lane] = (uint16_t)(inc - c);
-            if (lane == 63) loc[k][64] = (uint16_t)inc;
-            fit[k][lane] = (uint16_t)room;
-            dst_v[k][lane] = dv;
-            dst_i[k][lane] = di;
-            cnt[k][lane] = 0;
-            const uint64_t ov = __ballot(room < c);
-            if (lane == 0) any_overflow[k] = ov != 0;
-        }
-    }
-    lds_barrier();
-    // ---- phase 2: batches of levels whose records fit the staging area together
-    int k0 = 0;
-#pragma unroll 1
-    while (k0 < ll.n) {
-        int k1 = k0;
-        uint32_t sum = 0;
-        while (k1 < ll.n && (k1 == k0 || sum + loc[k1][MAX_BINS_PER_LEVEL] <= (uint32_t)ENTRIES)) sum += loc[k1++][MAX_BINS_PER_LEVEL];
-        uint32_t sb = 0;
-#pragma unroll 1
-        for (int k = k0; k < k1; ++k) {
-            const int lvl = ll.lvl[k];
-            float d0 = 0.f, d1 = 0.f, e0, e1;
-            const bool valid = inb && load_dfeat<false>(a, g.n_levels, lvl, i, d0, d1, e0, e1);
-            if (!valid) { d0 = 0.f; d1 = 0.f; }
-            const LevelPos p = level_pos(u[0], u[1], u[2], g.scale[lvl]);
-            const float wx1 = p.w[0], wy1 = p.w[1], wz1 = p.w[2], wx0 = 1.f - wx1, wy0 = 1.f - wy1, wz0 = 1.f - wz1;
-            const float wxy[4] = {wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};
-            float v0[8], v1[8];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const float w = wxy[c & 3] * ((c & 4) ? wz1 : wz0);
-                v0[c] = w * d0; v1[c] = w * d1;
-            }
-            uint32_t idx[8], bins[8], rk[8];
-            corner_indices8(p.c[0], p.c[1], p.c[2], g.res[lvl], g.size[lvl], false, idx);
-            bool head;
-            const bool emit = run_tail(true, valid, cell_key(p), lane, head);
-            run_merge(head, lane, v0, v1);
-#pragma unroll
-            for (int c = 0; c < 8; ++c) bins[c] = idx[c] >> BIN_SHIFT;
-            bin_rank8_dense(emit, bins, lane, cnt[k], rk);
-            if (emit) {
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const uint32_t pos = sb + loc[k][bins[c]] + rk[c];
-                    st_key[pos] = idx[c] | ((uint32_t)k << 19);        // dense level sizes are < 2^19
-                    st_v[pos] = make_float2(v0[c], v1[c]);
-                }
-            }
-            // a merged run adds at most RUN_LANES lanes with weights <= 1
-            float vmax = valid ? fmaxf(fabsf(d0), fabsf(d1)) * (float)RUN_LANES : 0.f;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
-            if (lane == 0 && vmax > 0.f) atomicMax(&lmax_s[k], __float_as_uint(vmax));
-            if (tid == 0) sbase[k] = sb;
-            sb += loc[k][MAX_BINS_PER_LEVEL];
-        }
-        lds_barrier();
-        for (uint32_t q = tid; q < sum; q += THREADS) {
-            const uint32_t key = st_key[q], k = key >> 19, ix = key & 0x7FFFFu, b = ix >> BIN_SHIFT;
-            const float2 v = st_v[q];
-            const uint32_t off = q - sbase[k] - loc[k][b];
-            if (!any_overflow[k] || off < fit[k][b]) {
-                reinterpret_cast<float2 *>(ws.pool + dst_v[k][b])[off] = v;
-                reinterpret_cast<uint16_t *>(ws.pool + dst_i[k][b])[off] = (uint16_t)(ix & (BIN_ENTRIES - 1));
-            } else {
-                table_atomic(grad_table, g.offset[ll.lvl[k]], ix, v.x, v.y);
-            }
-        }
-        lds_barrier();
-        k0 = k1;
-    }
-    if (tid < ll.n && lmax_s[tid]) {
-        uint32_t *slot = ws.level_max + (ll.lvl[tid] * LMAX_SLOTS + (int)(chunk % LMAX_SLOTS)) * LMAX_STRIDE;
-        if (lmax_s[tid] > __builtin_nontemporal_load(slot)) atomicMax(slot, lmax_s[tid]);
-    }
-}
-
 // ---- 4. accumulate one bin part in LDS, flush to the gradient table -------------------------------------------
 // LDS float atomics are lane-serialised on gfx950 (ds_add_f32: 0.37 lanes/clk/CU measured), integer
 // ones are 3x faster, so the sums are formed in 64-bit fixed point: q = round(v * 2^k) with
@@ -1088,21 +757,8 @@ static int binned_impl(const ren_grid_desc *grid, float *grad_table, const float
     if (!any_pair && !any_single) return REN_OK;
     if (tan.dfeatd) hipLaunchKernelGGL((bin_scatter_kernel<true, 0>), sgrd, sblk, 0, st, g, bt, a, ws, grad_table);
     else {
-        LevelList lp, ls;
-        lp.n = ls.n = 0;
-        for (int l = 0; l < g.n_levels; ++l)
-            if (!bt.skip[l]) { if (bt.pair[l]) lp.lvl[lp.n++] = l; else ls.lvl[ls.n++] = l; }
-        const bool v2 = ren_knob(REN_KNOB_HGB_SCATTER) != 1;
-        if (any_pair && v2)
-            hipLaunchKernelGGL((bin_scatter_pairs2_kernel<SC_THREADS>), sgrd, sblk, 0, st, g, bt, lp, a, ws, grad_table);
-        else if (any_pair)
-            hipLaunchKernelGGL((bin_scatter_kernel<false, 1>), sgrd, sblk, 0, st, g, bt, a, ws, grad_table);
-        bool dense_only = ls.n <= SC2_DENSE_MAX;
-        for (int k = 0; k < ls.n; ++k) dense_only &= !g.hashed[ls.lvl[k]];
-        if (any_single && v2 && dense_only)
-            hipLaunchKernelGGL((bin_scatter_dense2_kernel<SC_THREADS>), sgrd, sblk, 0, st, g, bt, ls, a, ws, grad_table);
-        else if (any_single)
-            hipLaunchKernelGGL((bin_scatter_kernel<false, 2>), sgrd, sblk, 0, st, g, bt, a, ws, grad_table);
+        if (any_pair)   hipLaunchKernelGGL((bin_scatter_kernel<false, 1>), sgrd, sblk, 0, st, g, bt, a, ws, grad_table);
+        if (any_single) hipLaunchKernelGGL((bin_scatter_kernel<false, 2>), sgrd, sblk, 0, st, g, bt, a, ws, grad_table);
     }
     hipLaunchKernelGGL(bin_partition_kernel, dim3(1), dim3(MAX_BINS), 0, st, nb, (uint64_t)part_entries, ws.cursors, ws.bin_cap, ws.parts,
                        ws.n_parts);

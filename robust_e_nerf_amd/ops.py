@@ -19,7 +19,7 @@ BASE_FLOATS_PER_BLOCK = 8 * 64           # saved base-MLP outputs, per 32 sample
 _DT = {torch.float32: 4, torch.float64: 8, torch.int32: 4, torch.int64: 8, torch.uint8: 1, torch.bool: 1}
 
 
-KNOBS = {"hgb_no_pairs": 0, "hgb_halve_regions": 1, "march_sequential": 2, "hg_variant": 3, "vfield_plain": 4, "hgb_scatter": 5}     # include/ren_amd.h REN_KNOB_*
+KNOBS = {"hgb_no_pairs": 0, "hgb_halve_regions": 1, "march_sequential": 2, "hg_variant": 3, "vfield_plain": 4}     # include/ren_amd.h REN_KNOB_*
 
 
 class knob:
