@@ -69,9 +69,12 @@ int ren_abi_version(void);                       /* bumps when a signature chang
  *   REN_KNOB_HGB_HALVE_REGIONS 1: halve the bin regions so the overflow path (global atomics) runs
  *   REN_KNOB_MARCH_SEQUENTIAL  1: sequential occupancy marcher instead of the speculative one
  *   REN_KNOB_HG_VARIANT        atomic hash-grid backward: bit 0 XCD-affine level mapping, bit 1 lane-pair atomics (default 2)
- *   REN_KNOB_VFIELD_PLAIN      1: arch mlp, bf16 mode: the forward / backward kernels without the software-pipelined epilogue */
+ *   REN_KNOB_VFIELD_PLAIN      1: arch mlp, bf16 mode: the forward / backward kernels without the software-pipelined epilogue
+ *   REN_KNOB_HGB_SUBREGION     binned scatter, which of a pair bin's 8 sub-regions a workgroup appends to: 1 (default) = the one
+ *                              of the XCD it runs on, 0 = (workgroup index / 8) % 8, i.e. every sub-region written from all XCDs
+ *                              (the A/B of the per-XCD layout: same code, same cursors, only the line sharing differs) */
 enum { REN_KNOB_HGB_NO_PAIRS = 0, REN_KNOB_HGB_HALVE_REGIONS = 1, REN_KNOB_MARCH_SEQUENTIAL = 2, REN_KNOB_HG_VARIANT = 3,
-       REN_KNOB_VFIELD_PLAIN = 4, REN_KNOB_COUNT = 5 };
+       REN_KNOB_VFIELD_PLAIN = 4, REN_KNOB_HGB_SUBREGION = 5, REN_KNOB_COUNT = 6 };
 int ren_set_knob(int32_t knob, int32_t value);    /* REN_OK or REN_ERR_BAD_ARG */
 int ren_get_knob(int32_t knob);
 const char *ren_build_info(void);                /* "gfx950 ..."                        */
@@ -403,6 +406,17 @@ int ren_composite_bwd_jvp(const int64_t *offsets, const int32_t *counts, int64_t
                           const float *trans, const float *eds, const float *opacities, const float *opacds,
                           const float *g_colors, const float *g_colords, float *d_sigmas, float *d_sigmads,
                           float *d_rgbs, float *d_rgbds, float *d_bkgd_per_ray, void *stream);
+/* Epilogue of the tangent (l_grad) render in one launch (robust_e_nerf.py:390-398,865-871, `bayering` :887-890):
+ * intensity = colors[:, channel] + min_modeled_intensity, intensity_dot = colords[:, channel], valid = opacity > 0 (NULL:
+ * a background parameter makes every ray valid), dlog_dt = intensity_dot / intensity (NULL: not wanted).  C = 1: channel_idx
+ * may be NULL. */
+int ren_rate_epilogue(const float *colors, const float *colords, const float *opacities, const uint8_t *channel_idx,
+                      int32_t C, int64_t n, float min_modeled_intensity, float *intensity, float *intensity_dot,
+                      uint8_t *valid, float *dlog_dt, void *stream);
+/* d loss / d tau through the poses (robust_e_nerf.py:340-357: tau moves every supervision timestamp):
+ * tau_grad[0] += sum_i (g_a[i] x_a[i] + g_b[i] x_b[i]) dts[i], float64, one launch (g_b, x_b may both be NULL). */
+int ren_tau_pose_grad(const float *g_a, const float *x_a, const float *g_b, const float *x_b, const double *dts,
+                      int64_t n, double *tau_grad, void *stream);
 /* Loss.log_intensity_grad (loss_metric/loss.py:43-57): pred = intensity_dot / intensity vs target;
  * same loss_sum / scale conventions as ren_event_loss_fwd/bwd */
 int ren_grad_loss_fwd(const float *intensity, const float *intensity_dot, const float *target,

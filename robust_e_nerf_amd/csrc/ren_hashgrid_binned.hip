@@ -55,6 +55,18 @@ constexpr int CNT_THREADS = 1024, CNT_SAMPLES = 1024; // count workgroup: one sa
 // in two flushes both halves with 16 384 float atomics (memory-side, ~18 G/s chip-wide) instead of one coalesced
 // read-modify-write.  <= 2^23 updates of magnitude < 2^38 cannot overflow the 64-bit fixed-point sums.
 constexpr int64_t PART_ENTRIES_MIN = 1 << 16, PART_ENTRIES_MAX = 1 << 23;
+// Pair-record (hashed) bins are split into N_SUB sub-regions, one per XCD: a workgroup appends to the sub-region of the XCD
+// it runs on (its own cursor).  Runs are unaligned 512-byte pieces, so the 128-byte line at every run boundary is shared by
+// two runs; with ONE cursor per bin the two halves of such a line usually come from workgroups on different XCDs, i.e. from
+// two mutually incoherent L2s, each of which writes its part back as a masked partial line (tools/append_bench.hip: 4.1 TB/s
+// against 7.2 TB/s for line-aligned runs).  With a sub-region per XCD both halves pass through the same L2, which merges them.
+// Correctness does not depend on the id being an XCD: any value in [0, N_SUB) partitions the appends.
+constexpr int N_SUB = 8;
+__device__ __forceinline__ int xcd_id() {
+    unsigned x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    return (int)(x & (N_SUB - 1));
+}
 inline int64_t part_entries_for(int64_t n, int64_t hashed_cap) {
     int64_t p = hashed_cap;
     if (p == 0) {                                    // dense levels only: ~1 024 parts
@@ -79,6 +91,7 @@ struct BinTab {
     uint32_t cap[REN_MAX_LEVELS];
     uint32_t pair[REN_MAX_LEVELS];                   // 1: the level's bins hold 16-byte pair records (cap counts records)
     uint32_t skip[REN_MAX_LEVELS];                   // 1: level not part of this call (level_mask of the *_levels entry points)
+    int sub_by_xcd;                                  // pair bins: sub-region = XCD of the workgroup (REN_KNOB_HGB_SUBREGION)
     int cnt_stride;
     int halve;                                       // test hook (REN_HGB_HALVE_REGIONS=1): force the overflow path
 };
@@ -157,9 +170,6 @@ __device__ __forceinline__ bool load_dfeat(const SampleArgs &a, int n_levels, in
 // updates of a run of lanes hit identical table entries.  Merging such runs in registers (segmented
 // wave scan) before anything touches LDS removes the same-address serialisation of the LDS atomics
 // and shrinks the staging traffic (x6.7 fewer updates at level 0 ... x1.5 at level 4).
-__device__ __forceinline__ uint64_t cell_key(const LevelPos &p) {
-    return ((uint64_t)p.c[2] << 42) ^ ((uint64_t)p.c[1] << 21) ^ (uint64_t)p.c[0];
-}
 
 // Runs are confined to aligned groups of RUN_LANES = 16 lanes (one DPP row) so the merge is four DPP row shifts (no LDS).
 // emit = this lane is the LAST lane of a run of valid lanes with equal cell (always true for hashed levels)
@@ -172,13 +182,17 @@ __device__ __forceinline__ float dpp_shr(float v) {               // value of la
 template <int OFF>
 __device__ __forceinline__ int dpp_shr_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x110 | OFF, 0xf, 0xf, true); }
 
-__device__ __forceinline__ bool run_tail(bool dense, bool have, uint64_t key, int lane, bool &head) {
+// `key`: index of the cell's first corner.  Equal keys mean equal index sets for all 8 corners (the other seven are the
+// first plus per-level constants, also after the wrap of positions outside the unit cube), which is all a merge needs; a
+// lane without an update takes a key no other lane has, so ONE neighbour exchange each way decides head and tail
+// (round 3 shuffled a 64-bit cell key and the `have` flag separately: six LDS permutes per level instead of two).
+__device__ __forceinline__ bool run_tail(bool dense, bool have, uint32_t key, int lane, bool &head) {
     if (!dense) { head = true; return have; }
-    const uint64_t kp = __shfl_up(key, 1, 64), kn = __shfl_down(key, 1, 64);
-    const int hp = __shfl_up((int)have, 1, 64), hn = __shfl_down((int)have, 1, 64);
+    const uint32_t k = have ? key : 0x80000000u | (uint32_t)lane;        // table indices are < 2^19
+    const uint32_t kp = __shfl_up(k, 1, 64), kn = __shfl_down(k, 1, 64);
     const int sub = lane & (RUN_LANES - 1);
-    head = !(sub > 0 && hp && have && kp == key);
-    return have && (sub == RUN_LANES - 1 || !(hn && kn == key));
+    head = !(sub > 0 && have && kp == k);
+    return have && (sub == RUN_LANES - 1 || kn != k);
 }
 
 // segmented inclusive scan: after it the tail lane of every run holds the run's sums
@@ -277,9 +291,9 @@ __global__ __launch_bounds__(CNT_THREADS) void bin_count_kernel(GridDev g, BinTa
             const uint32_t res = g.res[lvl], size = g.size[lvl];
             const bool hashed = g.hashed[lvl] != 0;
             bool head;
-            const bool emit = run_tail(!hashed, have, cell_key(p), lane, head);
             uint32_t idx[8];
             corner_indices8(p.c[0], p.c[1], p.c[2], res, size, hashed, idx);
+            const bool emit = run_tail(!hashed, have, idx[0], lane, head);
 #pragma unroll
             for (int c = 0; c < 8; ++c) (void)bin_rank(!hashed, emit, idx[c] >> BIN_SHIFT, lane, hist + lvl * MAX_BINS_PER_LEVEL);
         }
@@ -310,8 +324,9 @@ __global__ __launch_bounds__(MAX_BINS) void bin_offsets_kernel(int n_bins, BinTa
         if (!bt.skip[lvl] && !bt.cap[lvl] && bt.cnt_stride > 1) c = c * bt.cnt_stride + c * bt.cnt_stride / 4 + 4096;
         if (bt.halve) c = c / 2;
         c &= ~(uint64_t)7;                                         // idx[] of a single-update region stays 16-byte aligned
-        slots = pair ? c : (c * 10 + 15) / 16;
-        cursors[t] = 0;
+        if (pair) c = (c / N_SUB) & ~(uint64_t)7;                  // entries per sub-region (one per XCD)
+        slots = pair ? c * N_SUB : (c * 10 + 15) / 16;
+        for (int x = 0; x < N_SUB; ++x) cursors[t * N_SUB + x] = 0;
     }
     s_cnt[t] = slots;
     __syncthreads();
@@ -326,7 +341,7 @@ __global__ __launch_bounds__(MAX_BINS) void bin_offsets_kernel(int n_bins, BinTa
         const uint64_t start = s_cnt[t] - slots;
         uint64_t room = start < capacity_slots ? capacity_slots - start : 0;
         if (room > slots) room = slots;
-        if (room < slots) c = (pair ? room : room * 16 / 10) & ~(uint64_t)7;
+        if (room < slots) c = (pair ? room / N_SUB : room * 16 / 10) & ~(uint64_t)7;
         bin_start[t] = start < capacity_slots ? start : capacity_slots;
         bin_cap[t] = (uint32_t)c;
     }
@@ -334,15 +349,23 @@ __global__ __launch_bounds__(MAX_BINS) void bin_offsets_kernel(int n_bins, BinTa
 }
 
 // ---- 3b. work partition of the accumulate pass, from the ACTUAL fill of every bin region ---------------------
-__global__ __launch_bounds__(MAX_BINS) void bin_partition_kernel(int n_bins, uint64_t PART_ENTRIES,
+__global__ __launch_bounds__(MAX_BINS) void bin_partition_kernel(int n_bins, uint64_t PART_ENTRIES, BinTab bt,
                                                                  const uint32_t *__restrict__ cursors,
                                                                  const uint32_t *__restrict__ bin_cap,
                                                                  Part *__restrict__ parts, uint32_t *__restrict__ n_parts) {
     __shared__ uint32_t s_np[MAX_BINS];
     const int t = threadIdx.x;
     uint64_t c = 0;
-    if (t < n_bins) c = cursors[t] < bin_cap[t] ? cursors[t] : bin_cap[t];   // overflowing updates went to the table directly
-    const uint32_t np = (uint32_t)((c + PART_ENTRIES - 1) / PART_ENTRIES);
+    bool pair = false;
+    if (t < n_bins) {
+        int lvl = 0;
+        while (lvl + 1 < REN_MAX_LEVELS && t >= bt.bin_base[lvl + 1]) ++lvl;
+        pair = bt.pair[lvl] != 0;
+        // overflowing updates went to the table directly
+        for (int x = 0; x < (pair ? N_SUB : 1); ++x) c += cursors[t * N_SUB + x] < bin_cap[t] ? cursors[t * N_SUB + x] : bin_cap[t];
+    }
+    // a pair bin is ONE part (the part size is the capacity of a hashed bin): it walks its N_SUB sub-regions itself
+    const uint32_t np = pair ? (c ? 1u : 0u) : (uint32_t)((c + PART_ENTRIES - 1) / PART_ENTRIES);
     s_np[t] = np;
     __syncthreads();
     for (int off = 1; off < MAX_BINS; off <<= 1) {
@@ -355,7 +378,7 @@ __global__ __launch_bounds__(MAX_BINS) void bin_partition_kernel(int n_bins, uin
     const uint32_t pbase = s_np[t] - np;
     for (uint32_t k = 0; k < np; ++k) {
         Part p;
-        p.gbin = t; p.single = np == 1;
+        p.gbin = t; p.single = np == 1;                         // (pair bins: begin / end unused)
         p.begin = (uint64_t)k * PART_ENTRIES;
         p.end = k + 1 == np ? c : p.begin + PART_ENTRIES;
         parts[pbase + k] = p;
@@ -394,6 +417,8 @@ __global__ __launch_bounds__(SC_THREADS, KIND == 1 ? REN_SC_WAVES_PAIR : REN_SC_
     float u[3] = {0.f, 0.f, 0.f}, ud[3] = {0.f, 0.f, 0.f};
     if (inb) unit_pos<TAN>(a, i, u, ud);
     constexpr bool pairs = KIND == 1;
+    // which sub-region of a pair bin this workgroup appends to
+    const int sub = !pairs ? 0 : bt.sub_by_xcd ? xcd_id() : (int)((chunk >> 3) & (N_SUB - 1));
 #pragma unroll 1
     for (int lvl = 0; lvl < g.n_levels; ++lvl) {
         if (bt.skip[lvl]) continue;
@@ -455,7 +480,7 @@ __global__ __launch_bounds__(SC_THREADS, KIND == 1 ? REN_SC_WAVES_PAIR : REN_SC_
                 }
             }
             bool head;
-            have = run_tail(!hashed, valid, cell_key(p), lane, head);
+            have = run_tail(!hashed, valid, idx[0], lane, head);
             if (!hashed) run_merge(head, lane, v0, v1);
             // upper bound of |update| in this level (scale of the fixed-point sums): interpolation weights are <= 1 and a
             // merged run adds at most RUN_LANES lanes, so RUN_LANES max|d feature| bounds every update (4 of the 38 bits); with tangents
@@ -511,10 +536,10 @@ __global__ __launch_bounds__(SC_THREADS, KIND == 1 ? REN_SC_WAVES_PAIR : REN_SC_
             char *q0 = nullptr, *q1 = nullptr;
             if (tid < nb && cnt) {
                 const int gb = bt.bin_base[lvl] + tid;
-                const uint32_t at = atomicAdd(&ws.cursors[gb], cnt);         // reserve the run in the bin's region
+                const uint32_t at = atomicAdd(&ws.cursors[gb * N_SUB + sub], cnt);   // reserve the run in the bin's (sub-)region
                 const uint32_t cap = ws.bin_cap[gb];
                 room = at >= cap ? 0u : (cap - at < cnt ? cap - at : cnt);
-                char *base = ws.pool + ws.bin_start[gb] * 16;
+                char *base = ws.pool + (ws.bin_start[gb] + (pairs ? (uint64_t)sub * cap : 0)) * 16;
                 const int64_t first = (int64_t)at - (int64_t)(inc - cnt);    // region entry of staging position 0
                 if (pairs) q0 = base + first * 16;
                 else { q0 = base + first * 8; q1 = base + (int64_t)cap * 8 + first * 2; }
@@ -607,14 +632,21 @@ __global__ __launch_bounds__(1024) void bin_accumulate_kernel(GridDev g, BinTab 
             atomicAdd(&acc0[i1], (unsigned long long)to_fixed(r.w * r.y, scale));
             atomicAdd(&acc1[i1], (unsigned long long)to_fixed(r.w * r.z, scale));
         };
-        for (; e + 3 * 1024 < part.end; e += 4 * 1024) {           // 4 independent 16-byte loads in flight per lane
-            float4 r[4];
+        const uint32_t cap = ws.bin_cap[part.gbin];
+        for (int x = 0; x < N_SUB; ++x) {                          // one sub-region per XCD of the scatter
+            const float4 *rx = rec + (size_t)x * cap;
+            const uint32_t fill = ws.cursors[part.gbin * N_SUB + x];
+            const uint64_t end = fill < cap ? fill : cap;
+            uint64_t q = threadIdx.x;
+            for (; q + 3 * 1024 < end; q += 4 * 1024) {            // 4 independent 16-byte loads in flight per lane
+                float4 r[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) r[u] = rec[e + u * 1024];
+                for (int u = 0; u < 4; ++u) r[u] = rx[q + u * 1024];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) add(r[u]);
+                for (int u = 0; u < 4; ++u) add(r[u]);
+            }
+            for (; q < end; q += 1024) add(rx[q]);
         }
-        for (; e < part.end; e += 1024) add(rec[e]);
     } else {
         const float2 *out_v = reinterpret_cast<const float2 *>(base);
         const uint16_t *out_idx = reinterpret_cast<const uint16_t *>(base + (size_t)ws.bin_cap[part.gbin] * 8);
@@ -670,7 +702,7 @@ Layout make_layout(int64_t n) {
     size_t o = 0;
     L.counts = o; o += MAX_BINS * 4;                       // counts | level_max are cleared by one memset
     L.level_max = o; o = align256(o + LMAX_WORDS * 4);
-    L.cursors = o; o = align256(o + MAX_BINS * 4);
+    L.cursors = o; o = align256(o + MAX_BINS * 4 * N_SUB);
     L.n_parts = o; o = align256(o + 4);
     L.bin_cap = o; o = align256(o + MAX_BINS * 4);
     L.bin_start = o; o = align256(o + (MAX_BINS + 1) * 8);
@@ -721,7 +753,10 @@ static int binned_impl(const ren_grid_desc *grid, float *grad_table, const float
             const int64_t bins = (g.size[l] + BIN_ENTRIES - 1) >> BIN_SHIFT;
             bt.pair[l] = use_pairs ? 1 : 0;                       // 4 pair records instead of 8 updates per sample
             const int64_t mean = ((use_pairs ? 4 : 8) * n + bins - 1) / bins;
-            bt.cap[l] = (uint32_t)(mean + mean / 50 + 4096);
+            // pair bins: N_SUB sub-regions (one per XCD) of mean / N_SUB + 0.25 % + 1 024 records each (workgroups are dealt
+            // to the XCDs round robin, so the sub-regions fill evenly; what does not fit goes to the table with atomics)
+            bt.cap[l] = use_pairs ? (uint32_t)(N_SUB * (((mean / N_SUB + mean / 400 + 1024) + 7) & ~(int64_t)7))
+                                  : (uint32_t)(mean + mean / 50 + 4096);
             if ((int64_t)bt.cap[l] > hashed_cap) hashed_cap = bt.cap[l];
         }
     }
@@ -743,6 +778,7 @@ static int binned_impl(const ren_grid_desc *grid, float *grad_table, const float
     a.layout = layout; a.dfeat = dfeat; a.x_unit = x_unit; a.sc = sc; a.rays_o = rays_o; a.rays_d = rays_d;
     a.ray_indices = ray_indices; a.t_starts = t_starts; a.t_ends = t_ends; a.n = n; a.tan = tan;
     bt.halve = ren_knob(REN_KNOB_HGB_HALVE_REGIONS) == 1;
+    bt.sub_by_xcd = ren_knob(REN_KNOB_HGB_SUBREGION) != 0;
     const int64_t cnt_blocks = (n + CNT_SAMPLES - 1) / CNT_SAMPLES;
     bt.cnt_stride = cnt_blocks >= 4096 ? 16 : cnt_blocks >= 2048 ? 8 : cnt_blocks >= 1024 ? 4 : 1;   // >= 256 sampled blocks or exact
     const dim3 cgrd((unsigned)((cnt_blocks + bt.cnt_stride - 1) / bt.cnt_stride)), cblk(CNT_THREADS);
@@ -760,7 +796,7 @@ static int binned_impl(const ren_grid_desc *grid, float *grad_table, const float
         if (any_pair)   hipLaunchKernelGGL((bin_scatter_kernel<false, 1>), sgrd, sblk, 0, st, g, bt, a, ws, grad_table);
         if (any_single) hipLaunchKernelGGL((bin_scatter_kernel<false, 2>), sgrd, sblk, 0, st, g, bt, a, ws, grad_table);
     }
-    hipLaunchKernelGGL(bin_partition_kernel, dim3(1), dim3(MAX_BINS), 0, st, nb, (uint64_t)part_entries, ws.cursors, ws.bin_cap, ws.parts,
+    hipLaunchKernelGGL(bin_partition_kernel, dim3(1), dim3(MAX_BINS), 0, st, nb, (uint64_t)part_entries, bt, ws.cursors, ws.bin_cap, ws.parts,
                        ws.n_parts);
     const size_t acc_lds = 2 * BIN_ENTRIES * sizeof(unsigned long long);
     (void)hipFuncSetAttribute((const void *)bin_accumulate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)acc_lds);

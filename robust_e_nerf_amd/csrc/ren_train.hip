@@ -367,7 +367,70 @@ __global__ __launch_bounds__(1024) void event_param_grad_kernel(ParamGradArgs a)
     }
 }
 
+
+// ---- epilogue of the tangent (l_grad) render: intensity, its time derivative, validity and d log I / dt of the event's
+// colour channel in one launch (robust_e_nerf.py:390-398,865-871): I = c + min_modeled_intensity, I' = c',
+// valid = opacity > 0 (no background parameter), d log I / dt = I' / I.
+__global__ void rate_epilogue_kernel(const float *__restrict__ colors, const float *__restrict__ colords,
+                                     const float *__restrict__ opac, const uint8_t *__restrict__ chan, int C, int64_t n,
+                                     float min_i, float *__restrict__ inten, float *__restrict__ intend,
+                                     uint8_t *__restrict__ valid, float *__restrict__ dlog) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c = chan ? chan[i] : 0;
+    const float v = colors[i * C + c] + min_i, vd = colords[i * C + c];
+    inten[i] = v;
+    intend[i] = vd;
+    if (valid) valid[i] = opac[i] > 0.f;
+    if (dlog) dlog[i] = vd / v;
+}
+
+// ---- d loss / d tau through the poses: sum_i (g_a[i] x_a[i] + g_b[i] x_b[i]) dts[i] in float64, added to out[0]
+// (robust_e_nerf.py:340-357: every supervision timestamp moves with tau; g = d loss / d (intensity | its time derivative),
+// x = the next time derivative of the intensity).  One workgroup: B is a batch of events.
+__global__ __launch_bounds__(1024) void tau_pose_grad_kernel(const float *__restrict__ g_a, const float *__restrict__ x_a,
+                                                             const float *__restrict__ g_b, const float *__restrict__ x_b,
+                                                             const double *__restrict__ dts, int64_t n, double *__restrict__ out) {
+    __shared__ double red[16];
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        double v = (double)g_a[i] * (double)x_a[i];
+        if (g_b) v += (double)g_b[i] * (double)x_b[i];
+        s += v * dts[i];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < 16; ++w) t += red[w];
+        out[0] += t;
+    }
+}
+
 }  // namespace
+
+extern "C" int ren_rate_epilogue(const float *colors, const float *colords, const float *opacities, const uint8_t *channel_idx,
+                                 int32_t C, int64_t n, float min_modeled_intensity, float *intensity, float *intensity_dot,
+                                 uint8_t *valid, float *dlog_dt, void *stream) {
+    if (!colors || !colords || !intensity || !intensity_dot || n < 0 || C < 1 || C > 4 || (C > 1 && !channel_idx) ||
+        (valid && !opacities))
+        return REN_ERR_BAD_ARG;
+    if (n == 0) return REN_OK;
+    hipLaunchKernelGGL(rate_epilogue_kernel, dim3(ren_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, colors, colords,
+                       opacities, C > 1 ? channel_idx : nullptr, (int)C, n, min_modeled_intensity, intensity, intensity_dot,
+                       valid, dlog_dt);
+    REN_CHECK_LAUNCH();
+}
+
+extern "C" int ren_tau_pose_grad(const float *g_a, const float *x_a, const float *g_b, const float *x_b, const double *dts,
+                                 int64_t n, double *tau_grad, void *stream) {
+    if (!g_a || !x_a || !dts || !tau_grad || n < 0 || ((g_b == nullptr) != (x_b == nullptr))) return REN_ERR_BAD_ARG;
+    if (n == 0) return REN_OK;
+    hipLaunchKernelGGL(tau_pose_grad_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, g_a, x_a, g_b, x_b, dts, n, tau_grad);
+    REN_CHECK_LAUNCH();
+}
 
 extern "C" int ren_event_prepare(const int64_t *start_ts, const int64_t *end_ts, const int64_t *num_pos,
                                  const int64_t *num_neg, const double *u_ts_diff, const double *u_diff_start,

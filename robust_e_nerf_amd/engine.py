@@ -136,9 +136,13 @@ class Renderer:
         if scene_aabb is not None:
             t_min, t_max = ops.ray_aabb_intersect(o, d, scene_aabb, c.near_plane, c.far_plane)
         else:
+            # no scene box (contracted spaces): every ray marches near -> far; the two constant vectors are kept per ray count
             n = o.shape[0]
-            t_min = torch.full((n,), 0.0 if c.near_plane is None else c.near_plane, device=o.device)
-            t_max = torch.full((n,), 1e10 if c.far_plane is None else c.far_plane, device=o.device)
+            key = (n, c.near_plane, c.far_plane, str(o.device))
+            if getattr(self, "_t_range", (None,))[0] != key:
+                self._t_range = (key, torch.full((n,), 0.0 if c.near_plane is None else c.near_plane, device=o.device),
+                                 torch.full((n,), 1e10 if c.far_plane is None else c.far_plane, device=o.device))
+            _, t_min, t_max = self._t_range
         mode = 0 if c.sampler == "occgrid" else 1
         jit = jitter if training else None
         args = (o, d, t_min, t_max, jit, c.aabb, c.occ_res, self.binary, c.contraction_type,
@@ -426,6 +430,7 @@ class Renderer:
         ops.occgrid_ema(self.occs, indices, valid, sigma, step_sizes, c.render_step_size, c.ema_decay,
                         scratch=self._occ_scratch)
         ops.occgrid_binarize(self.occs, c.occ_thre, self.binary, self._scratch)
+        self.binary_epoch = getattr(self, "binary_epoch", 0) + 1        # a march prefetched over the old grid is stale now
         return True
 
 
@@ -604,17 +609,23 @@ class Trainer:
             self._side = torch.cuda.Stream(priority=-1)          # its few small kernels go ahead of the queued backward
         return self._side
 
-    def prefetch(self, batch, jitter_start=None, jitter_end=None) -> bool:
+    def prefetch(self, batch, jitter_start=None, jitter_end=None, next_global_step: Optional[int] = None) -> bool:
         """Run the front of the NEXT step's forward_backward(batch, jitter_start, jitter_end) -- event correction, poses,
         rays, ray/AABB test, march count pass, scan, and the read-back of the sample count -- on a side stream while the
         current step's backward is still on the GPU.  The one host read of a step (the packed sample count, as in the
         reference: external/utils.py:106-119) then no longer waits for the previous step, so the launch queue never runs
         dry (measured: 0.35 ms of GPU idle per 12 ms step at BASELINE configs[1]).  Only what cannot depend on this
-        step's optimiser update may run early: frozen C_p / tau (they move the timestamps) and the fixed-S sampler (the
-        occupancy sampler's density pre-pass needs the updated field); otherwise this is a no-op and returns False.
+        step's optimiser update may run early: frozen C_p / tau (they move the timestamps).  With the occupancy sampler
+        the early part is the march itself (a ~1 000-step dependent chain per ray, 0.46 ms for 131 k rays: 14 % of a step at
+        the reference's 2^20-sample budget) -- it reads the occupancy GRID, not the field; the density pre-pass that does
+        need the updated field stays in the step.  A grid refresh between prefetch() and the step (update_occ_grid, every
+        16 steps) makes the early march stale: pass `next_global_step` so that it is not started before a refresh step;
+        a stale one is recognised by the grid epoch and redone.  Otherwise this is a no-op and returns False.
         `batch` / the jitters must already be complete on the device or produced on `side_stream`."""
         t = self.t
-        if t.train_contrast_threshold or t.train_refractory_period or self.r.cfg.sampler != "uniform":
+        if t.train_contrast_threshold or t.train_refractory_period:
+            return False
+        if self.r.cfg.sampler != "uniform" and next_global_step is not None and next_global_step % self.r.cfg.occ_n == 0:
             return False
         side = self.side_stream
         with torch.cuda.stream(side):
@@ -626,8 +637,14 @@ class Trainer:
             ev = torch.cuda.Event()
             ev.record(side)
         front["begun"] = st
-        self._prefetched = (self._prefetch_key(batch, jitter_start, jitter_end), front, ev, (batch, jitter_start, jitter_end))
+        self._prefetched = (self._prefetch_key(batch, jitter_start, jitter_end) + self._grid_state(), front, ev,
+                            (batch, jitter_start, jitter_end))
         return True
+
+    def _grid_state(self):
+        """what the early march of the occupancy sampler read: the grid tensor's torch version and the refresh epoch"""
+        r = self.r
+        return (r.binary._version, getattr(r, "binary_epoch", 0), r.cfg.sampler)
 
     @staticmethod
     def _prefetch_key(batch, jitter_start, jitter_end):
@@ -639,8 +656,8 @@ class Trainer:
     def _take_prefetched(self, batch, jitter_start, jitter_end):
         pf, self._prefetched = self._prefetched, None
         t = self.t
-        if pf is None or pf[0] != self._prefetch_key(batch, jitter_start, jitter_end) or t.train_contrast_threshold or \
-                t.train_refractory_period or self.r.cfg.sampler != "uniform":       # the guards of prefetch(), re-checked
+        if pf is None or pf[0] != self._prefetch_key(batch, jitter_start, jitter_end) + self._grid_state() or \
+                t.train_contrast_threshold or t.train_refractory_period:              # the guards of prefetch(), re-checked
             return None
         _, front, ev, _ = pf
         ev.synchronize()                                               # host: waits for the side stream's few small kernels only
@@ -700,10 +717,14 @@ class Trainer:
             self._param_grad(batch, L["pred"], "diff", L["valid"])
         if t.train_refractory_period:
             # through the poses: sum_i dL/dI_i * dI_i/dt_i * dt_i/dtau  (start and end renders)
-            ch = self._channel_index(batch, 2)
-            idot = self._bayer(colords, ch).double()
-            g_ev = self._bayer(g_colors, ch).double()
-            self._tau_grad_dev += (g_ev[:B] * idot[:B] * prep["dts_start"]).sum() + (g_ev[B:] * idot[B:] * prep["dts_end"]).sum()
+            from . import jvp
+            if f.C == 1:                                  # one launch: (2B,) gradients x tangents x [dts_start | dts_end], float64 sum
+                jvp.tau_pose_grad(self._tau_grad_dev, prep["dts_pair"], g_colors, colords)
+            else:
+                ch = self._channel_index(batch, 2)
+                idot = self._bayer(colords, ch).double()
+                g_ev = self._bayer(g_colors, ch).double()
+                self._tau_grad_dev += (g_ev[:B] * idot[:B] * prep["dts_start"]).sum() + (g_ev[B:] * idot[B:] * prep["dts_end"]).sum()
         d_bk = r.backward(ctx, g_colors, final=final, per_ray_bkgd=True)
         if d_bk is not None:
             ops.bkgd_param_grad(d_bk, self.small, self.small_grad)       # += sigmoid(raw) * column sums (d softplus)
@@ -733,9 +754,10 @@ class Trainer:
         jit = None if jitter_grad is None else jitter_grad.to(torch.float32).contiguous()
         colors, colords, opac, ctx = jvp.render_forward(r, o, d, od, dd, jit, bkgd, training=True)
         ch = self._channel_index(batch, 1)
-        inten = (self._bayer(colors, ch) + r.cfg.min_modeled_intensity).contiguous()         # robust_e_nerf.py:390-393
-        intend = self._bayer(colords, ch).contiguous()                        # d I/dt ; d log I/dt = Id / I
-        valid = None if t.bkgd_is_param else (opac > 0).to(torch.uint8).contiguous()
+        chan = batch["channel_idx"].to(torch.uint8).contiguous() if f.C > 1 else None
+        # a16 of the tangent render in one launch: I = c + eps, I' = c', valid = opacity > 0, d log I / dt = I' / I
+        inten, intend, valid, dlog = jvp.rate_epilogue(colors, colords, opac, chan, r.cfg.min_modeled_intensity,
+                                                       want_valid=not t.bkgd_is_param)
         loss_sum = jvp.grad_loss_fwd(inten, intend, target, valid, t.err_grad)
         inv_c = 1.0 / self.mean_c
         pw = {None: 1.0, "mean_contrast_reciprocal": inv_c, "mean_contrast_reciprocal_sq": inv_c ** 2}[t.pw_grad]
@@ -743,16 +765,15 @@ class Trainer:
         loss = loss_sum[0] / loss_sum[1] * scale
         g_i, g_id = jvp.grad_loss_bwd(inten, intend, target, valid, t.err_grad, scale, loss_sum)
         if t.train_contrast_threshold or t.train_refractory_period:
-            self._param_grad(batch, intend / inten, "grad", valid)
+            self._param_grad(batch, dlog, "grad", valid)
         if t.train_refractory_period:
             # d L/d tau through the pose: dL/dI * dI/dt + dL/dI' * d2I/dt2, times d ts_g/d tau  (per event)
             _, _, colorsdd = jvp.render_forward2(r, o, d, od, dd, ddd, ctx["pk"], bkgd)
-            per_ev = g_i.double() * intend.double() + g_id.double() * self._bayer(colorsdd, ch).double()
-            self._tau_grad_dev += (per_ev * prep["dts_grad"]).sum()
+            jvp.tau_pose_grad(self._tau_grad_dev, prep["dts_grad"], g_i, intend, g_id, self._bayer(colorsdd, ch).contiguous())
         d_bkgd = jvp.render_backward(r, ctx, self._unbayer(g_i, ch, f.C), self._unbayer(g_id, ch, f.C), final=final)
         if d_bkgd is not None:
             self.small_grad[: f.C] += d_bkgd * torch.sigmoid(self.small[: f.C])
-        aux = dict(intensity=inten, dlog_dt=intend / inten, n=ctx["pk"].n, rays=B)
+        aux = dict(intensity=inten, dlog_dt=dlog, n=ctx["pk"].n, rays=B)
         return loss, aux
 
     def optimizer_step(self, accumulate_grad_batches: int = 1, mean_samples_per_ray: Optional[float] = None):

@@ -201,6 +201,26 @@ def render_backward(r, ctx, g_colors, g_colords, final: bool = False):
     return ops.column_sum(d_bk) if d_bk is not None else None
 
 
+def rate_epilogue(colors, colords, opac, chan, min_modeled_intensity: float, want_valid: bool, want_dlog: bool = True):
+    """intensity, d intensity/dt, validity (None when every ray is valid) and d log I/dt of the events' channels: one launch"""
+    R, C = colors.shape
+    dev = colors.device
+    inten, intend = torch.empty(R, device=dev), torch.empty(R, device=dev)
+    valid = torch.empty(R, device=dev, dtype=torch.uint8) if want_valid else None
+    dlog = torch.empty(R, device=dev) if want_dlog else None
+    check(_lib.load().ren_rate_epilogue(_ptr(colors), _ptr(colords), _ptr(opac), _ptr(chan), C, R, _f(min_modeled_intensity),
+                                        _ptr(inten), _ptr(intend), _ptr(valid), _ptr(dlog), _stream()), "ren_rate_epilogue")
+    return inten, intend, valid, dlog
+
+
+def tau_pose_grad(tau_grad, dts, g_a, x_a, g_b=None, x_b=None):
+    """tau_grad[0] (f64, device) += sum (g_a x_a + g_b x_b) dts"""
+    n = g_a.numel()
+    check(_lib.load().ren_tau_pose_grad(_ptr(g_a, torch.float32), _ptr(x_a, torch.float32), _ptr(g_b, torch.float32),
+                                        _ptr(x_b, torch.float32), _ptr(dts, torch.float64), n, _ptr(tau_grad, torch.float64),
+                                        _stream()), "ren_tau_pose_grad")
+
+
 def grad_loss_fwd(inten, intend, target, valid, err_fn: str):
     loss_sum = torch.empty(2, device=inten.device)
     check(_lib.load().ren_grad_loss_fwd(_ptr(inten), _ptr(intend), _ptr(target), _ptr(valid), inten.shape[0],

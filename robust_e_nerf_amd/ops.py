@@ -19,7 +19,7 @@ BASE_FLOATS_PER_BLOCK = 8 * 64           # saved base-MLP outputs, per 32 sample
 _DT = {torch.float32: 4, torch.float64: 8, torch.int32: 4, torch.int64: 8, torch.uint8: 1, torch.bool: 1}
 
 
-KNOBS = {"hgb_no_pairs": 0, "hgb_halve_regions": 1, "march_sequential": 2, "hg_variant": 3, "vfield_plain": 4}     # include/ren_amd.h REN_KNOB_*
+KNOBS = {"hgb_no_pairs": 0, "hgb_halve_regions": 1, "march_sequential": 2, "hg_variant": 3, "vfield_plain": 4, "hgb_subregion": 5}     # include/ren_amd.h REN_KNOB_*
 
 
 class knob:
@@ -498,6 +498,7 @@ def event_prepare(batch, c_p: float, c_n: float, tau: float, *, with_grad_ts: bo
         _ptr(dts[2]) if (with_dtau and with_grad_ts) else None, _stream()), "ren_event_prepare")
     return dict(ts=ts, target_diff=target, ts_grad=ts_g, target_grad=target_g,
                 dts_start=dts[0] if with_dtau else None, dts_end=dts[1] if with_dtau else None,
+                dts_pair=dts[:2].reshape(-1) if with_dtau else None,          # [d ts_start/d tau | d ts_end/d tau], (2B,) view
                 dts_grad=dts[2] if (with_dtau and with_grad_ts) else None)
 
 

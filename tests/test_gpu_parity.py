@@ -1822,14 +1822,21 @@ def test_bench_data_parallel_step_over_rccl_single_rank():
 def test_prefetched_step_front_gives_the_same_steps(amd, full_table_cache):
     """Trainer.prefetch (next step's event correction, poses, rays, ray/AABB test, count pass, scan and sample-count
     read-back on a side stream) changes when that front runs, not what it computes: losses and every gradient of three
-    consecutive steps equal the un-prefetched run to the run-to-run repeatability of the step; trainable C_p / tau or the occupancy sampler refuse it."""
+    consecutive steps equal the un-prefetched run to the run-to-run repeatability of the step; trainable C_p / tau refuse it.
+    With the occupancy sampler the early part is the march over the occupancy grid (round 4): same steps, a prefetch is
+    not started before a refresh step, and a front that a grid refresh made stale is recognised and redone."""
     ops, engine = amd
     g = load_golden("training_step_diff")
     table = full_table_cache(g["table_seed"], g["table_scale"])
     B = 4096
+    for sampler in ("uniform", "occgrid"):
+        _prefetch_case(engine, g, table, B, sampler)
+
+
+def _prefetch_case(engine, g, table, B, sampler):
     outs = []
     for use in (False, True):
-        tr, _ = _trainer_from_golden(engine, g, table, sampler="uniform")
+        tr, _ = _trainer_from_golden(engine, g, table, sampler=sampler)
         tr.r.cfg.n_uniform = 32
         gen = torch.Generator().manual_seed(5)
         steps = []
@@ -1850,12 +1857,24 @@ def test_prefetched_step_front_gives_the_same_steps(amd, full_table_cache):
         # 2e-12 of 2.6e-3 in the first step, Adam carries it to ~4e-7 by the third --, the sample count exactly)
         assert abs(float(a[0]) - float(b[0])) <= 1e-6 * abs(float(a[0])) and a[3] == b[3]
         assert float((a[1] - b[1]).abs().max()) <= 1e-5 * float(a[1].abs().max())
-        assert float((a[2] - b[2]).abs().max()) <= 1e-5 * float(a[2].abs().max())
+        # (the background gradient is ONE scalar, a sum with cancellation over all rays of values that follow the table: 3e-5
+        # here against per-ray terms of 1e-3; by the third step of the occupancy sampler's runs it repeats to ~3e-4 of itself)
+        assert float((a[2] - b[2]).abs().max()) <= (1e-5 if sampler == "uniform" else 2e-3) * float(a[2].abs().max())
     tr.t.train_contrast_threshold = True
     assert not tr.prefetch(*steps[3])
     tr.t.train_contrast_threshold = False
-    tr.r.cfg.sampler = "occgrid"
-    assert not tr.prefetch(*steps[3])
+    if sampler == "occgrid":
+        assert not tr.prefetch(*steps[3], next_global_step=2 * tr.r.cfg.occ_n)      # the next step refreshes the grid first
+        assert tr.prefetch(*steps[3], next_global_step=2 * tr.r.cfg.occ_n + 1)
+        # a refresh after the prefetch: the early march is stale, the step must not use it
+        ref_tr, _ = _trainer_from_golden(engine, g, table, sampler=sampler)
+        ref_tr.r.field.flat.copy_(tr.r.field.flat)
+        for t_ in (tr, ref_tr):
+            t_.r.occs.zero_()
+            assert t_.r.update_occ_grid(0, t_.tab_pos, generator=torch.Generator(device=DEV).manual_seed(3))
+        la, aa = tr.forward_backward(*steps[3])
+        lb, ab = ref_tr.forward_backward(*steps[3])
+        assert aa["n"] == ab["n"] and abs(float(la) - float(lb)) <= 1e-6 * abs(float(lb))
 
 
 def test_second_order_mlp_forward_matrix_core_kernel_vs_f32_kernel(amd, spec, full_table_cache):

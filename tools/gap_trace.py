@@ -5,9 +5,10 @@ for r in csv.DictReader(open(sys.argv[1])):
     m = re.search(r"(\w+_kernel)", r["Kernel_Name"])
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), m.group(1) if m else r["Kernel_Name"][:40]))
 rows.sort()
-# one step = from one adam_kernel pair's end to the next
-adam_ends = [e for s, e, n in rows if "adam_kernel" in n]
-steps = list(zip(adam_ends[1::2], adam_ends[3::2]))
+# one step = from the end of one group of consecutive adam_kernel launches (2: table + small parameters; 3 with a trainable
+# C_p) to the end of the next group
+ends = [rows[k][1] for k in range(len(rows)) if "adam_kernel" in rows[k][2] and (k + 1 == len(rows) or "adam_kernel" not in rows[k + 1][2])]
+steps = list(zip(ends[:-1], ends[1:]))
 t0, t1 = steps[-2]
 ks = [x for x in rows if x[0] >= t0 and x[1] <= t1 + 1]
 busy, cur_s, cur_e, gaps = 0, None, None, []
@@ -22,5 +23,12 @@ for s, e, n in ks:
     prev = n
 busy += cur_e - cur_s
 print("step %.3f ms, busy %.3f ms, idle %.3f ms over %d kernels" % ((t1 - t0) / 1e6, busy / 1e6, (t1 - t0 - busy) / 1e6, len(ks)))
-for g, a, b in sorted(gaps, reverse=True)[:12]:
+hist = {}
+for g, a, b in gaps:
+    hist.setdefault(a + " -> " + b, []).append(g)
+print("  gaps > 20 us: %d (%.3f ms), 5-20 us: %d (%.3f ms), < 5 us: %d (%.3f ms)" % (
+    sum(g > 20e3 for g, _, _ in gaps), sum(g for g, _, _ in gaps if g > 20e3) / 1e6,
+    sum(5e3 < g <= 20e3 for g, _, _ in gaps), sum(g for g, _, _ in gaps if 5e3 < g <= 20e3) / 1e6,
+    sum(g <= 5e3 for g, _, _ in gaps), sum(g for g, _, _ in gaps if g <= 5e3) / 1e6))
+for g, a, b in sorted(gaps, reverse=True)[:int(sys.argv[2]) if len(sys.argv) > 2 else 12]:
     print("  gap %.1f us between %s -> %s" % (g / 1e3, a, b))
