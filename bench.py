@@ -216,8 +216,12 @@ def main():
                     help="run the next step's batch / ray / sample-count front on a side stream (Trainer.prefetch): the host no "
                          "longer waits for the previous step at the sample-count read; measured 12.03 vs 12.04 ms/step, i.e. nothing "
                          "-- the step's 0.35 ms of GPU idle is inter-kernel dispatch latency, not this wait")
-    ap.add_argument("--fwd-chunks", type=int, default=4,
+    ap.add_argument("--fwd-chunks", type=int, default=8,
                     help="> 1: hash encoding and MLP forward of alternate sample chunks on two HIP streams")
+    ap.add_argument("--bwd-chunks", type=int, default=1,
+                    help="> 1: MLP backward of sample chunk k + 1 beside the binned hash-grid scatter of chunk k on two HIP streams, one "
+                         "accumulate at the end (RenderCfg.bwd_chunks)")
+    ap.add_argument("--bwd-mlp-cus", type=int, default=192, help="CUs of the MLP backward kernels while a scatter runs beside them")
     ap.add_argument("--mlp-kernels", default="x", choices=["x", "f32"],
                     help="x = split-bf16 matrix-core MLP kernels at fp32 accuracy (default), f32 = exact f32-MFMA kernels")
     ap.add_argument("--hard", action="store_true",
@@ -307,6 +311,7 @@ def main():
                            save_activations=None if args.save_activations < 0 else bool(args.save_activations))
     cfg.dp_overlap = not args.no_dp_overlap
     cfg.dp_compress = args.dp_compress
+    cfg.bwd_chunks, cfg.bwd_mlp_cus = args.bwd_chunks, args.bwd_mlp_cus
     if args.workload == "e":
         aabb = E_AABB
         cfg = engine.RenderCfg(aabb=aabb, contraction_type=ops.UN_BOUNDED_SPHERE, occ_res=(256,) * 3, near_plane=0.05,
@@ -452,6 +457,13 @@ def main():
                   "mlp_samples_per_sec": float(dts[1]) / float(tmax), "steps": args.steps, "warmup": args.warmup}
         B = B_weak
 
+    if "hashgrid_bwd_binned_finish" in prof:
+        # the phased call of the chunked backward (begin, one scatter per chunk -- timed on the second stream, i.e. while it
+        # shares the chip with the MLP backward --, finish) counts as ONE launch of the C-ABI call per backward pass
+        calls = prof["hashgrid_bwd_binned_finish"][0]
+        total = sum(prof.pop(k)[1] for k in ("hashgrid_bwd_binned_begin", "hashgrid_bwd_binned_scatter", "hashgrid_bwd_binned_finish"))
+        c0, m0 = prof.get("hashgrid_bwd_binned", (0, 0.0))
+        prof["hashgrid_bwd_binned"] = (c0 + calls, m0 + total)
     if rank == 0:
         kern = {k: {"launches": c, "avg_ms": ms / max(c, 1)} for k, (c, ms) in prof.items()}
         dom = max(list(BYTES) + list(FLOPS), key=lambda k: prof.get(k, (0, 0.0))[1])
@@ -508,6 +520,7 @@ def main():
                        "events_per_step_per_gpu": B, "rays_per_step_per_gpu": 2 * B, "sampler": args.sampler,
                        "samples_per_ray": args.samples, "parallelism": f"dp{world}",
                        "collectives_per_step": getattr(tr, "last_collectives", 0), "front_prefetched": bool(can_prefetch),
+                       "fwd_chunks": args.fwd_chunks, "bwd_chunks": args.bwd_chunks,
                        # what torch.distributed actually formed (a mis-launched N-rank run shows here)
                        "dist_world_size": dist.get_world_size() if dist.is_initialized() else 1,
                        "dist_backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else ""))

@@ -70,11 +70,13 @@ int ren_abi_version(void);                       /* bumps when a signature chang
  *   REN_KNOB_MARCH_SEQUENTIAL  1: sequential occupancy marcher instead of the speculative one
  *   REN_KNOB_HG_VARIANT        atomic hash-grid backward: bit 0 XCD-affine level mapping, bit 1 lane-pair atomics (default 2)
  *   REN_KNOB_VFIELD_PLAIN      1: arch mlp, bf16 mode: the forward / backward kernels without the software-pipelined epilogue
+ *   REN_KNOB_MLP_BWD_CUS       persistent workgroups (= CUs) the fused MLP backward kernels occupy, 1 .. 256 (default 256); the
+ *                              chunked backward of engine.py lowers it while a scatter runs on the second stream
  *   REN_KNOB_HGB_SUBREGION     binned scatter, which of a pair bin's 8 sub-regions a workgroup appends to: 1 (default) = the one
  *                              of the XCD it runs on, 0 = (workgroup index / 8) % 8, i.e. every sub-region written from all XCDs
  *                              (the A/B of the per-XCD layout: same code, same cursors, only the line sharing differs) */
 enum { REN_KNOB_HGB_NO_PAIRS = 0, REN_KNOB_HGB_HALVE_REGIONS = 1, REN_KNOB_MARCH_SEQUENTIAL = 2, REN_KNOB_HG_VARIANT = 3,
-       REN_KNOB_VFIELD_PLAIN = 4, REN_KNOB_HGB_SUBREGION = 5, REN_KNOB_COUNT = 6 };
+       REN_KNOB_VFIELD_PLAIN = 4, REN_KNOB_HGB_SUBREGION = 5, REN_KNOB_MLP_BWD_CUS = 6, REN_KNOB_COUNT = 7 };
 int ren_set_knob(int32_t knob, int32_t value);    /* REN_OK or REN_ERR_BAD_ARG */
 int ren_get_knob(int32_t knob);
 const char *ren_build_info(void);                /* "gfx950 ..."                        */
@@ -362,6 +364,23 @@ int ren_hashgrid_bwd_binned_levels(const ren_grid_desc *grid, float *grad_table,
                                    const int32_t *ray_indices, const float *t_starts, const float *t_ends, int64_t n,
                                    int32_t layout, const float *dfeat, const float *rays_do, const float *rays_dd,
                                    const float *dfeatd, uint32_t level_mask, void *workspace, void *stream);
+/* The binned backward in phases: `begin` (clear, count, offsets -- needs the sample stream only), any number of `scatter`
+ * calls over sample ranges [first, first + m) of the SAME stream (first on a 32-sample block; every call takes the whole
+ * stream's n and pointers), and ONE `finish` (partition, accumulate, flush into grad_table).  Stream-ordered: begin before
+ * every scatter, every scatter before finish -- the caller may run the scatters on another stream than whatever produces
+ * the next range's dfeat (engine.py: MLP backward of chunk k + 1 beside the scatter of chunk k).  Same workspace and
+ * results as ren_hashgrid_bwd_binned; replaces the tcnn backward at external/ngp.py:166-170. */
+int ren_hashgrid_bwd_binned_begin(const ren_grid_desc *grid, const float *x_unit, const ren_scene_desc *scene,
+                                  const float *rays_o, const float *rays_d, const int32_t *ray_indices,
+                                  const float *t_starts, const float *t_ends, int64_t n, int32_t layout,
+                                  void *workspace, void *stream);
+int ren_hashgrid_bwd_binned_scatter(const ren_grid_desc *grid, float *grad_table, const float *x_unit,
+                                    const ren_scene_desc *scene, const float *rays_o, const float *rays_d,
+                                    const int32_t *ray_indices, const float *t_starts, const float *t_ends,
+                                    int64_t n, int32_t layout, const float *dfeat, int64_t first, int64_t m,
+                                    void *workspace, void *stream);
+int ren_hashgrid_bwd_binned_finish(const ren_grid_desc *grid, float *grad_table, int64_t n, int32_t layout,
+                                   void *workspace, void *stream);
 /* fused MLPs with tangent: rgb, rgbd [n,C]; sigma, sigmad [n]; base_out, base_outd (ceil(n/32)*512 floats) */
 int ren_mlp_fwd_jvp(const float *mlp_params, int32_t radiance_dim, const float *feat, const float *featd,
                     const ren_scene_desc *scene, const float *rays_o, const float *rays_d, const float *rays_dd,

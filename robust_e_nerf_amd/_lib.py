@@ -53,6 +53,10 @@ SIGNATURES = {
     "ren_hashgrid_bwd": (c_int, [POINTER(GridDesc), P, P, POINTER(SceneDesc), P, P, P, P, P, c_int64, c_int32, P, P]),
     "ren_hashgrid_bwd_binned_workspace_bytes": (c_int64, [c_int64]),
     "ren_hashgrid_bwd_binned": (c_int, [POINTER(GridDesc), P, P, POINTER(SceneDesc), P, P, P, P, P, c_int64, c_int32, P, P, P]),
+    "ren_hashgrid_bwd_binned_begin": (c_int, [POINTER(GridDesc), P, POINTER(SceneDesc), P, P, P, P, P, c_int64, c_int32, P, P]),
+    "ren_hashgrid_bwd_binned_scatter": (c_int, [POINTER(GridDesc), P, P, POINTER(SceneDesc), P, P, P, P, P, c_int64, c_int32, P,
+                                                c_int64, c_int64, P, P]),
+    "ren_hashgrid_bwd_binned_finish": (c_int, [POINTER(GridDesc), P, c_int64, c_int32, P, P]),
     "ren_mlp_fwd": (c_int, [P, c_int32, P, POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, c_int32, P, P, P, P]),
     "ren_mlp_bwd_workspace_floats": (c_int64, [c_int32]),
     "ren_mlp_bwd": (c_int, [P, c_int32, P, P, POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, P, P, P, P, P, P, P, P]),

@@ -286,7 +286,7 @@ __global__ __launch_bounds__(CNT_THREADS) void bin_count_kernel(GridDev g, BinTa
         for (int lvl = 0; lvl < g.n_levels; ++lvl) {
             if (bt.cap[lvl] || bt.skip[lvl]) continue;               // hashed level: capacity-sized regions, no count
             float d0, d1, e0, e1;
-            const bool have = inb && load_dfeat<TAN>(a, g.n_levels, lvl, i, d0, d1, e0, e1);
+            const bool have = inb && (a.dfeat == nullptr || load_dfeat<TAN>(a, g.n_levels, lvl, i, d0, d1, e0, e1));
             const LevelPos p = level_pos(u[0], u[1], u[2], g.scale[lvl]);
             const uint32_t res = g.res[lvl], size = g.size[lvl];
             const bool hashed = g.hashed[lvl] != 0;
@@ -719,17 +719,28 @@ extern "C" int64_t ren_hashgrid_bwd_binned_workspace_bytes(int64_t n) {
     return (int64_t)make_layout(n).total;
 }
 
+// The call in three phases (all of them entry points, see below): begin = clear + count + offsets (needs the sample stream
+// only), scatter = any sample range [first, first + m) of the stream (needs that range's feature gradients), finish =
+// partition + accumulate.  The one-shot entry points run begin, one scatter over everything, finish.
+// phases: bit 0 begin, bit 1 scatter, bit 2 finish.  `n` is always the size of the WHOLE stream (it sizes the regions);
+// the pointers of the per-sample arrays and of dfeat are those of the whole stream too.
 static int binned_impl(const ren_grid_desc *grid, float *grad_table, const float *x_unit,
                        const ren_scene_desc *scene, const float *rays_o, const float *rays_d,
                        const int32_t *ray_indices, const float *t_starts, const float *t_ends,
                        int64_t n, int32_t layout, const float *dfeat, void *workspace,
-                       void *stream, TanSrc tan, uint32_t level_mask = 0xFFFFFFFFu) {
+                       void *stream, TanSrc tan, uint32_t level_mask = 0xFFFFFFFFu, int phases = 7,
+                       int64_t first = 0, int64_t m = -1) {
     GridDev g;
     int rc = make_grid(grid, g);
     if (rc) return rc;
-    if (!grad_table || !dfeat || !workspace || n < 0 || (layout != 0 && layout != 1)) return REN_ERR_BAD_ARG;
+    const bool do_begin = phases & 1, do_scatter = phases & 2, do_finish = phases & 4;
+    if (m < 0) m = n - first;
+    if (!workspace || n < 0 || (layout != 0 && layout != 1) || first < 0 || m < 0 || first + m > n) return REN_ERR_BAD_ARG;
+    if ((do_scatter && (!dfeat || !grad_table)) || (do_finish && !grad_table)) return REN_ERR_BAD_ARG;
+    if (do_scatter && phases != 7 && ((first & 31) != 0 || tan.dfeatd)) return REN_ERR_BAD_ARG;   // ranges start on a 32-sample block
     const bool from_rays = x_unit == nullptr;
-    if (from_rays && (!scene || !rays_o || !rays_d || !ray_indices || !t_starts || !t_ends)) return REN_ERR_BAD_ARG;
+    if ((do_begin || do_scatter) && from_rays && (!scene || !rays_o || !rays_d || !ray_indices || !t_starts || !t_ends))
+        return REN_ERR_BAD_ARG;
     if (layout == 1 && g.n_levels != REN_MAX_LEVELS) return REN_ERR_UNSUPPORTED;
     if (n >= ((int64_t)1 << 28)) return REN_ERR_UNSUPPORTED;      // 8 n updates per level must fit uint32
     BinTab bt;
@@ -773,7 +784,6 @@ static int binned_impl(const ren_grid_desc *grid, float *grad_table, const float
     ws.bin_start = (uint64_t *)(w + L.bin_start);
     ws.parts = (Part *)(w + L.parts); ws.pool = w + L.pool;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(ws.counts, 0, (MAX_BINS + LMAX_WORDS) * 4, st) != hipSuccess) return REN_ERR_LAUNCH;
     SampleArgs a;
     a.layout = layout; a.dfeat = dfeat; a.x_unit = x_unit; a.sc = sc; a.rays_o = rays_o; a.rays_d = rays_d;
     a.ray_indices = ray_indices; a.t_starts = t_starts; a.t_ends = t_ends; a.n = n; a.tan = tan;
@@ -781,27 +791,44 @@ static int binned_impl(const ren_grid_desc *grid, float *grad_table, const float
     bt.sub_by_xcd = ren_knob(REN_KNOB_HGB_SUBREGION) != 0;
     const int64_t cnt_blocks = (n + CNT_SAMPLES - 1) / CNT_SAMPLES;
     bt.cnt_stride = cnt_blocks >= 4096 ? 16 : cnt_blocks >= 2048 ? 8 : cnt_blocks >= 1024 ? 4 : 1;   // >= 256 sampled blocks or exact
-    const dim3 cgrd((unsigned)((cnt_blocks + bt.cnt_stride - 1) / bt.cnt_stride)), cblk(CNT_THREADS);
-    const dim3 sgrd((unsigned)((n + SC_THREADS - 1) / SC_THREADS)), sblk(SC_THREADS);
-    if (tan.dfeatd) hipLaunchKernelGGL(bin_count_kernel<true>, cgrd, cblk, 0, st, g, bt, a, ws.counts);
-    else            hipLaunchKernelGGL(bin_count_kernel<false>, cgrd, cblk, 0, st, g, bt, a, ws.counts);
-    hipLaunchKernelGGL(bin_offsets_kernel, dim3(1), dim3(MAX_BINS), 0, st, nb, bt, (uint64_t)L.slots, ws.counts,
-                       ws.cursors, ws.bin_cap, ws.bin_start);
     bool any_pair = false, any_single = false;
     for (int l = 0; l < g.n_levels; ++l)
         if (!bt.skip[l]) { any_pair |= bt.pair[l] != 0; any_single |= bt.pair[l] == 0; }
-    if (!any_pair && !any_single) return REN_OK;
-    if (tan.dfeatd) hipLaunchKernelGGL((bin_scatter_kernel<true, 0>), sgrd, sblk, 0, st, g, bt, a, ws, grad_table);
-    else {
-        if (any_pair)   hipLaunchKernelGGL((bin_scatter_kernel<false, 1>), sgrd, sblk, 0, st, g, bt, a, ws, grad_table);
-        if (any_single) hipLaunchKernelGGL((bin_scatter_kernel<false, 2>), sgrd, sblk, 0, st, g, bt, a, ws, grad_table);
+    if (do_begin) {
+        if (hipMemsetAsync(ws.counts, 0, (MAX_BINS + LMAX_WORDS) * 4, st) != hipSuccess) return REN_ERR_LAUNCH;
+        const dim3 cgrd((unsigned)((cnt_blocks + bt.cnt_stride - 1) / bt.cnt_stride)), cblk(CNT_THREADS);
+        SampleArgs ac = a;
+        if (phases != 7) ac.dfeat = nullptr;          // phased call: the regions are sized before any gradient exists (all samples count)
+        if (tan.dfeatd) hipLaunchKernelGGL(bin_count_kernel<true>, cgrd, cblk, 0, st, g, bt, ac, ws.counts);
+        else            hipLaunchKernelGGL(bin_count_kernel<false>, cgrd, cblk, 0, st, g, bt, ac, ws.counts);
+        hipLaunchKernelGGL(bin_offsets_kernel, dim3(1), dim3(MAX_BINS), 0, st, nb, bt, (uint64_t)L.slots, ws.counts,
+                           ws.cursors, ws.bin_cap, ws.bin_start);
     }
-    hipLaunchKernelGGL(bin_partition_kernel, dim3(1), dim3(MAX_BINS), 0, st, nb, (uint64_t)part_entries, bt, ws.cursors, ws.bin_cap, ws.parts,
-                       ws.n_parts);
-    const size_t acc_lds = 2 * BIN_ENTRIES * sizeof(unsigned long long);
-    (void)hipFuncSetAttribute((const void *)bin_accumulate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)acc_lds);
-    const int64_t acc_grid = (int64_t)(L.entries / part_entries) + nb + 1;
-    hipLaunchKernelGGL(bin_accumulate_kernel, dim3((unsigned)acc_grid), dim3(1024), acc_lds, st, g, bt, ws, grad_table);
+    if (!any_pair && !any_single) return REN_OK;
+    if (do_scatter && m > 0) {
+        // the kernels index samples from 0: a range is the same launch over shifted per-sample pointers
+        SampleArgs as = a;
+        as.n = m;
+        if (first) {
+            if (as.x_unit) as.x_unit += 3 * first;
+            if (as.ray_indices) { as.ray_indices += first; as.t_starts += first; as.t_ends += first; }
+            as.dfeat += layout == 1 ? (first >> 5) * (int64_t)(REN_MAX_LEVELS * 64) : first * (int64_t)g.n_levels * 2;
+        }
+        const dim3 sgrd((unsigned)((m + SC_THREADS - 1) / SC_THREADS)), sblk(SC_THREADS);
+        if (tan.dfeatd) hipLaunchKernelGGL((bin_scatter_kernel<true, 0>), sgrd, sblk, 0, st, g, bt, as, ws, grad_table);
+        else {
+            if (any_pair)   hipLaunchKernelGGL((bin_scatter_kernel<false, 1>), sgrd, sblk, 0, st, g, bt, as, ws, grad_table);
+            if (any_single) hipLaunchKernelGGL((bin_scatter_kernel<false, 2>), sgrd, sblk, 0, st, g, bt, as, ws, grad_table);
+        }
+    }
+    if (do_finish) {
+        hipLaunchKernelGGL(bin_partition_kernel, dim3(1), dim3(MAX_BINS), 0, st, nb, (uint64_t)part_entries, bt, ws.cursors, ws.bin_cap, ws.parts,
+                           ws.n_parts);
+        const size_t acc_lds = 2 * BIN_ENTRIES * sizeof(unsigned long long);
+        (void)hipFuncSetAttribute((const void *)bin_accumulate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)acc_lds);
+        const int64_t acc_grid = (int64_t)(L.entries / part_entries) + nb + 1;
+        hipLaunchKernelGGL(bin_accumulate_kernel, dim3((unsigned)acc_grid), dim3(1024), acc_lds, st, g, bt, ws, grad_table);
+    }
     REN_CHECK_LAUNCH();
 }
 
@@ -835,4 +862,34 @@ extern "C" int ren_hashgrid_bwd_binned_levels(const ren_grid_desc *grid, float *
     if ((rays_do || rays_dd || dfeatd) && (!rays_do || !rays_dd || !dfeatd || layout != 1 || x_unit)) return REN_ERR_BAD_ARG;
     return binned_impl(grid, grad_table, x_unit, scene, rays_o, rays_d, ray_indices, t_starts, t_ends, n, layout, dfeat,
                        workspace, stream, TanSrc{rays_do, rays_dd, dfeatd}, level_mask);
+}
+
+// ---- the same call in phases, so that the scatter of one sample range can run beside whatever produces the next range's
+// feature gradients (engine.py: MLP backward of chunk k + 1 on one stream, scatter of chunk k on another) and the bins are
+// flushed ONCE at the end.  Every phase takes the WHOLE stream's n and pointers; a range starts on a 32-sample block.
+//   begin   clear, count the dense levels' regions from the sample positions (all samples count: no gradient exists yet),
+//           offsets.  Needs the sample stream only.
+//   scatter samples [first, first + m): appends to the regions (cursors persist across calls).  Stream-ordered after begin.
+//   finish  partition + accumulate + flush into grad_table.  Stream-ordered after every scatter.
+extern "C" int ren_hashgrid_bwd_binned_begin(const ren_grid_desc *grid, const float *x_unit, const ren_scene_desc *scene,
+                                             const float *rays_o, const float *rays_d, const int32_t *ray_indices,
+                                             const float *t_starts, const float *t_ends, int64_t n, int32_t layout,
+                                             void *workspace, void *stream) {
+    return binned_impl(grid, nullptr, x_unit, scene, rays_o, rays_d, ray_indices, t_starts, t_ends, n, layout, nullptr,
+                       workspace, stream, TanSrc{nullptr, nullptr, nullptr}, 0xFFFFFFFFu, 1);
+}
+
+extern "C" int ren_hashgrid_bwd_binned_scatter(const ren_grid_desc *grid, float *grad_table, const float *x_unit,
+                                               const ren_scene_desc *scene, const float *rays_o, const float *rays_d,
+                                               const int32_t *ray_indices, const float *t_starts, const float *t_ends,
+                                               int64_t n, int32_t layout, const float *dfeat, int64_t first, int64_t m,
+                                               void *workspace, void *stream) {
+    return binned_impl(grid, grad_table, x_unit, scene, rays_o, rays_d, ray_indices, t_starts, t_ends, n, layout, dfeat,
+                       workspace, stream, TanSrc{nullptr, nullptr, nullptr}, 0xFFFFFFFFu, 2, first, m);
+}
+
+extern "C" int ren_hashgrid_bwd_binned_finish(const ren_grid_desc *grid, float *grad_table, int64_t n, int32_t layout,
+                                              void *workspace, void *stream) {
+    return binned_impl(grid, grad_table, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, n, layout, nullptr,
+                       workspace, stream, TanSrc{nullptr, nullptr, nullptr}, 0xFFFFFFFFu, 4);
 }

@@ -792,8 +792,15 @@ __global__ __launch_bounds__(256, REN_BASE_WAVES) void mlp_bwd_base_x_kernel(Bwd
     }
 }
 
+// persistent workgroups of this launch: REN_KNOB_MLP_BWD_CUS (the chunked backward leaves CUs to the scatter on the other stream)
+static inline int bwd_grid_cus() {
+    const int k = ren_knob(REN_KNOB_MLP_BWD_CUS);
+    return k >= 1 && k < REN_GRID_CUS ? k : REN_GRID_CUS;
+}
+
 template <int MODE, bool RECOMP>
 int launch_bwd_x(const BwdXHArgs &h, const BwdXBArgs &b, int C, float *grad, hipStream_t st) {
+    const int GRID_XH = bwd_grid_cus(), GRID_XB = GRID_XH * REN_BASE_WAVES;      // (the slab layout stays that of the full grids)
     using HL = HeadLds<MODE, RECOMP>;
     using BL = BaseLds<MODE, RECOMP>;
     const size_t lds_h = (size_t)HL::F_END * 2 + HL::TAIL_BYTES + 4 * 16 * 64 * sizeof(float4);

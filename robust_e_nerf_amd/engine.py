@@ -49,7 +49,9 @@ class RenderCfg:
                                        # recompute (96 MFMAs + 96 softplus per 32 samples) is cheaper than 13 GB of HBM traffic;
                                        # None = auto: recompute with the "x" kernels, save with the exact-f32 kernels
     march_cache: int = 512             # intervals per ray kept between the two marching passes (0: march twice)
-    fwd_chunks: int = 4                # > 1: hash encoding and MLP of alternate sample chunks on two HIP streams
+    fwd_chunks: int = 8                # > 1: hash encoding and MLP of alternate sample chunks on two HIP streams
+    bwd_chunks: int = 1                # > 1: MLP backward of chunk k + 1 beside the binned scatter of chunk k (two streams), ONE accumulate
+    bwd_mlp_cus: int = 192             # CUs the MLP backward kernels occupy while a scatter runs beside them
     dp_overlap: bool = True            # data parallel: all-reduce the fine levels' table gradient beside the coarse levels' scatter
     dp_split_level: int = 8            # levels >= this one go first (8 x 4 MiB of the 50 MB buffer)
     dp_compress: Optional[str] = None  # "bf16": parameter gradients cross the links as bfloat16 (strong scaling), aux block stays fp32
@@ -125,6 +127,7 @@ class Renderer:
         self._occ_gen = None
         self.grad_sync = None                       # parallel.GradSync of the Trainer under data parallelism
         self._fwd_streams = None
+        self._bwd_stream = None
         self._reuse_prepass_feat = True             # the differentiable pass reuses the pre-pass hash features
 
     # ---- sampling (K1-K3): ray/AABB, two-pass march, no-grad density pre-pass + visibility --------
@@ -299,8 +302,55 @@ class Renderer:
         a, b = self.dp_early_slice()
         self.grad_sync.early(self.field.grad_all, a, b)
 
+    def _field_backward_chunked(self, ctx, d_rgb, d_sig, K: int):
+        """MLP backward (VALU / matrix-core bound, persistent kernels) of sample chunk k + 1 on the current stream beside
+        the binned hash-grid scatter (memory bound) of chunk k on a second stream; the bins are flushed ONCE at the end
+        (ren_hashgrid_bwd_binned_begin / _scatter / _finish).  The head kernel of the MLP backward runs one wave per SIMD
+        with the whole register file, so nothing can share a CU with it: while a scatter is in flight the MLP kernels are
+        launched on `bwd_mlp_cus` CUs and the scatter takes the rest plus whatever frees up.  Every layout is local to a
+        32-sample block, so a chunk is a slice of the full tensors; weight gradients add up over the chunks' slab
+        reductions.  Same results as the single launches up to the summation order of the MLP weight gradients."""
+        f, pk = self.field, ctx["pk"]
+        n, dev = pk.n, d_rgb.device
+        nblk = ops.n_blocks32(n)
+        per = -(-nblk // K)
+        FR, BA = ops.FRAG_FLOATS_PER_BLOCK, ops.BASE_FLOATS_PER_BLOCK
+        dfeat = torch.empty(nblk * FR, device=dev)
+        d_base = torch.empty(nblk * BA, device=dev)
+        ws = self._binned_workspace(n, dev)
+        rays, samples = (ctx["o"], ctx["d"]), (pk.ray_indices, pk.t_starts, pk.t_ends)
+        if self._bwd_stream is None:
+            self._bwd_stream = torch.cuda.Stream(dev)
+        main, side = torch.cuda.current_stream(), self._bwd_stream
+        ops.hashgrid_bwd_binned_begin(f.grid, ws, scene=self.scene, rays=rays, samples=samples, n=n)
+        side.wait_stream(main)
+        acts_per = ops.mlp_act_save_floats(32)
+        for k in range(K):
+            b0, b1 = k * per, min(nblk, (k + 1) * per)
+            if b0 >= b1:
+                break
+            lo, hi = b0 * 32, min(n, b1 * 32)
+            acts = ctx["acts"][b0 * acts_per: b1 * acts_per] if ctx.get("acts") is not None else None
+            with ops.knob("mlp_bwd_cus", 256 if k == 0 else self.cfg.bwd_mlp_cus):     # chunk 0 has the chip to itself
+                ops.mlp_bwd_x(f.mlp, f.C, ctx["xmode"], ctx["feat"][b0 * FR: b1 * FR], ctx["base"][b0 * BA: b1 * BA], acts,
+                              self.scene, rays=rays, samples=tuple(t[lo:hi] for t in samples), n=hi - lo,
+                              rgb=ctx["rgb"][lo:hi], d_rgb=d_rgb[lo:hi], d_sigma=d_sig[lo:hi], grad_mlp_params=f.g_mlp,
+                              workspace=self._ws, dfeat=dfeat[b0 * FR: b1 * FR], d_base=d_base[b0 * BA: b1 * BA])
+            ev = torch.cuda.Event()
+            ev.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                ops.hashgrid_bwd_binned_scatter(f.grid, f.g_table, dfeat, ws, scene=self.scene, rays=rays, samples=samples,
+                                                n=n, first=lo, m=hi - lo)
+        main.wait_stream(side)
+        ops.hashgrid_bwd_binned_finish(f.grid, f.g_table, ws, n=n)
+
     def _field_backward(self, ctx, d_rgb, d_sig, final: bool = False):
         f, pk = self.field, ctx["pk"]
+        K = min(self.cfg.bwd_chunks, pk.n >> 21) if pk.n >= (1 << 23) else 1     # pays from ~8 M samples, >= 2 M per chunk
+        if (K > 1 and ctx.get("xmode") is not None and self.cfg.binned_scatter and
+                not (final and self.dp_early_slice() is not None)):
+            return self._field_backward_chunked(ctx, d_rgb, d_sig, K)
         samples = (pk.ray_indices, pk.t_starts, pk.t_ends)
         mp = ctx.get("mlp_params")                      # absent when the forward ran on the (fp32) tangent kernels
         if ctx.get("xmode") is not None:

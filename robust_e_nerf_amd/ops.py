@@ -19,7 +19,7 @@ BASE_FLOATS_PER_BLOCK = 8 * 64           # saved base-MLP outputs, per 32 sample
 _DT = {torch.float32: 4, torch.float64: 8, torch.int32: 4, torch.int64: 8, torch.uint8: 1, torch.bool: 1}
 
 
-KNOBS = {"hgb_no_pairs": 0, "hgb_halve_regions": 1, "march_sequential": 2, "hg_variant": 3, "vfield_plain": 4, "hgb_subregion": 5}     # include/ren_amd.h REN_KNOB_*
+KNOBS = {"hgb_no_pairs": 0, "hgb_halve_regions": 1, "march_sequential": 2, "hg_variant": 3, "vfield_plain": 4, "hgb_subregion": 5, "mlp_bwd_cus": 6}     # include/ren_amd.h REN_KNOB_*
 
 
 class knob:
@@ -312,6 +312,32 @@ def hashgrid_bwd_binned(grid: GridDesc, grad_table, dfeat, workspace, *, x_unit=
           "ren_hashgrid_bwd_binned")
 
 
+def hashgrid_bwd_binned_begin(grid: GridDesc, workspace, *, scene, rays, samples, n: int, layout: int = 1):
+    """phase 1 of hashgrid_bwd_binned: clear + count + offsets (sample stream only)"""
+    if workspace.numel() * workspace.element_size() < hashgrid_bwd_binned_workspace_bytes(n):
+        raise ValueError("hashgrid_bwd_binned: workspace too small")
+    (o, d), (ri, ts, te) = rays, samples
+    check(_lib.load().ren_hashgrid_bwd_binned_begin(ctypes.byref(grid), None, ctypes.byref(scene), _ptr(o), _ptr(d), _ptr(ri),
+                                                    _ptr(ts), _ptr(te), n, layout, _ptr(workspace), _stream()),
+          "ren_hashgrid_bwd_binned_begin")
+
+
+def hashgrid_bwd_binned_scatter(grid: GridDesc, grad_table, dfeat, workspace, *, scene, rays, samples, n: int, first: int,
+                                m: int, layout: int = 1):
+    """phase 2: scatter samples [first, first + m) of the stream (dfeat, samples: the WHOLE stream's tensors)"""
+    (o, d), (ri, ts, te) = rays, samples
+    check(_lib.load().ren_hashgrid_bwd_binned_scatter(ctypes.byref(grid), _ptr(grad_table, torch.float32), None, ctypes.byref(scene),
+                                                      _ptr(o), _ptr(d), _ptr(ri), _ptr(ts), _ptr(te), n, layout,
+                                                      _ptr(dfeat, torch.float32), first, m, _ptr(workspace), _stream()),
+          "ren_hashgrid_bwd_binned_scatter")
+
+
+def hashgrid_bwd_binned_finish(grid: GridDesc, grad_table, workspace, *, n: int, layout: int = 1):
+    """phase 3: partition + accumulate + flush"""
+    check(_lib.load().ren_hashgrid_bwd_binned_finish(ctypes.byref(grid), _ptr(grad_table, torch.float32), n, layout,
+                                                     _ptr(workspace), _stream()), "ren_hashgrid_bwd_binned_finish")
+
+
 # ------------------------------------------------------------------------------- fused MLPs
 def mlp_fwd(mlp_params, C: int, feat, scene: SceneDesc, *, x_world=None, dirs=None, rays=None, samples=None,
             n: int, density_only: bool = False, save_base: bool = False, out=None, bf16: bool = False):
@@ -398,12 +424,14 @@ def mlp_bwd_x_workspace_floats(C: int) -> int:
 
 
 def mlp_bwd_x(mlp_params, C: int, mode: int, feat, base_out, acts, scene: SceneDesc, *, rays=None, samples=None,
-              x_world=None, dirs=None, n: int, rgb, d_rgb, d_sigma, grad_mlp_params, workspace):
+              x_world=None, dirs=None, n: int, rgb, d_rgb, d_sigma, grad_mlp_params, workspace, dfeat=None, d_base=None):
     dev = feat.device
     o, d = rays if rays is not None else (None, None)
     ri, ts, te = samples if samples is not None else (None, None, None)
-    d_base = torch.empty(n_blocks32(n) * BASE_FLOATS_PER_BLOCK, device=dev, dtype=torch.float32)
-    dfeat = torch.empty(n_blocks32(n) * FRAG_FLOATS_PER_BLOCK, device=dev, dtype=torch.float32)
+    if d_base is None:
+        d_base = torch.empty(n_blocks32(n) * BASE_FLOATS_PER_BLOCK, device=dev, dtype=torch.float32)
+    if dfeat is None:
+        dfeat = torch.empty(n_blocks32(n) * FRAG_FLOATS_PER_BLOCK, device=dev, dtype=torch.float32)
     check(_lib.load().ren_mlp_bwd_x(_ptr(mlp_params, torch.float32), C, mode, _ptr(feat), _ptr(base_out), _ptr(acts),
                                     ctypes.byref(scene), _ptr(x_world), _ptr(dirs), _ptr(o), _ptr(d), _ptr(ri), _ptr(ts),
                                     _ptr(te), n, _ptr(rgb), _ptr(d_rgb), _ptr(d_sigma), _ptr(d_base), _ptr(dfeat),
@@ -616,7 +644,8 @@ def occgrid_binarize(occs, occ_thre: float, binary, scratch):
 # disabled (zero overhead) otherwise.
 _PROFILE = None
 _TIMED = ("ray_aabb_intersect", "ray_march_count", "ray_march_write", "exclusive_scan", "visibility",
-          "compact_samples", "compact_features", "hashgrid_fwd", "hashgrid_bwd", "hashgrid_bwd_binned", "mlp_fwd", "mlp_bwd", "mlp_fwd_save",
+          "compact_samples", "compact_features", "hashgrid_fwd", "hashgrid_bwd", "hashgrid_bwd_binned", "hashgrid_bwd_binned_begin",
+          "hashgrid_bwd_binned_scatter", "hashgrid_bwd_binned_finish", "mlp_fwd", "mlp_bwd", "mlp_fwd_save",
           "mlp_bwd_saved", "mlp_fwd_x", "mlp_bwd_x", "composite_fwd",
           "composite_bwd", "column_sum", "event_loss_fwd", "event_loss_bwd", "adam_step", "trajectory", "raygen")
 

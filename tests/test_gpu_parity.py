@@ -856,6 +856,63 @@ def test_prepass_feature_reuse_equals_reencoding(amd, spec, full_table_cache):
         assert rel_err(a[4], b[4]) < 1e-5 and rel_err(a[5], b[5]) < 1e-5
 
 
+def test_chunked_two_stream_backward_equals_single_launches(amd, spec, full_table_cache):
+    """RenderCfg.bwd_chunks: MLP backward of sample chunk k + 1 beside the binned hash-grid scatter of chunk k on two HIP
+    streams, the bins flushed ONCE (ren_hashgrid_bwd_binned_begin / _scatter / _finish): table gradients equal the
+    single-launch backward to the summation order of the bins' fixed-point sums (exact there) and of the few overflow /
+    carry atomics; MLP gradients to the order of the chunks' slab reductions.  Also the phased C ABI on its own: ranges in
+    any order, an empty range, and the whole stream as one range, against the one-shot call."""
+    from oracle import field
+    ops, engine = amd
+    p = field.init_params(spec, seed=5)
+    p["hash"] = full_table_cache(7, 0.5)
+    R = 65536                                                    # x 128 samples = 8 M samples
+    gen = torch.Generator().manual_seed(4)
+    ang = torch.rand(R, generator=gen) * 2 * math.pi
+    o = torch.stack([4 * torch.cos(ang), 4 * torch.sin(ang), torch.rand(R, generator=gen) - 0.5], -1)
+    d = (torch.rand(R, 3, generator=gen) - 0.5) * 1.6 - o
+    d = d / d.norm(dim=-1, keepdim=True)
+    o, d = dev(o.float()), dev(d.float())
+    jit = dev(torch.rand(R, generator=gen))
+    g_col = dev(torch.randn(R, 1, generator=gen))
+    out = []
+    for chunks in (1, 4):
+        fld = engine.NGPField(DEV)
+        fld.load(p)
+        r = engine.Renderer(fld, engine.RenderCfg(sampler="uniform", n_uniform=128, bwd_chunks=chunks))
+        colors, opac, depth, ctx = r.forward(o, d, jit, None, True)
+        r.backward(ctx, g_col)
+        torch.cuda.synchronize()
+        assert _lib_knob(ops, "mlp_bwd_cus") == 256                     # the per-chunk CU limit of the MLP kernels is restored
+        out.append((fld.g_mlp.clone(), fld.g_table.clone()))
+    assert rel_err(out[1][0], out[0][0]) < 1e-5 and rel_err(out[1][1], out[0][1]) < 1e-6
+    # ---- the phased entry points by themselves
+    pk = ctx["pk"]
+    n = pk.n
+    dfeat = torch.randn(ops.n_blocks32(n) * ops.FRAG_FLOATS_PER_BLOCK, device=DEV)
+    ws = torch.empty(ops.hashgrid_bwd_binned_workspace_bytes(n), device=DEV, dtype=torch.uint8)
+    kw = dict(scene=r.scene, rays=(o, d), samples=(pk.ray_indices, pk.t_starts, pk.t_ends), n=n)
+    one = torch.zeros_like(fld.g_table)
+    ops.hashgrid_bwd_binned(fld.grid, one, dfeat, ws, layout=1, **kw)
+    cuts = [0, 32 * 1000, 32 * 1000, 32 * 70001, n]                     # ragged ranges on 32-sample blocks, one of them empty
+    ranges = list(zip(cuts[:-1], cuts[1:]))
+    for order in (ranges, ranges[::-1], [(0, n)]):
+        ph = torch.zeros_like(fld.g_table)
+        ops.hashgrid_bwd_binned_begin(fld.grid, ws, **kw)
+        for lo, hi in order:
+            ops.hashgrid_bwd_binned_scatter(fld.grid, ph, dfeat, ws, first=lo, m=hi - lo, **kw)
+        ops.hashgrid_bwd_binned_finish(fld.grid, ph, ws, n=n)
+        torch.cuda.synchronize()
+        assert rel_err(ph, one) < 1e-6, rel_err(ph, one)
+    with pytest.raises(ValueError):                                      # a range must start on a 32-sample block
+        ops.hashgrid_bwd_binned_scatter(fld.grid, ph, dfeat, ws, first=7, m=64, **kw)
+
+
+def _lib_knob(ops, name):
+    from robust_e_nerf_amd import _lib
+    return _lib.load().ren_get_knob(ops.KNOBS[name])
+
+
 def test_chunked_two_stream_forward_equals_single_launch(amd, spec, full_table_cache):
     """RenderCfg.fwd_chunks: hash encoding / MLP of alternate sample chunks on two HIP streams (with the MLP kernel
     in its one-workgroup-per-CU mode) give bit-identical renders and gradients that agree to summation order."""
@@ -1869,6 +1926,7 @@ def _prefetch_case(engine, g, table, B, sampler):
         # a refresh after the prefetch: the early march is stale, the step must not use it
         ref_tr, _ = _trainer_from_golden(engine, g, table, sampler=sampler)
         ref_tr.r.field.flat.copy_(tr.r.field.flat)
+        ref_tr.small.copy_(tr.small)                                     # (the background parameter has been stepped too)
         for t_ in (tr, ref_tr):
             t_.r.occs.zero_()
             assert t_.r.update_occ_grid(0, t_.tab_pos, generator=torch.Generator(device=DEV).manual_seed(3))

@@ -17,6 +17,7 @@ python tools/pmc_traffic.py $O/pmc_FETCH_SIZE/pmc_results.db $O/pmc_WRITE_SIZE/p
 python tools/pmc_mfma.py $O/pmc_mfma/pmc_results.db profiles/${RND}_pmc_mfma.json > /dev/null
 python bench.py > profiles/${RND}_bench.json 2> $O/bench.err
 python bench.py --no-cpu-baseline --events 32768 > profiles/${RND}_bench_half.json 2>>$O/bench.err
+python bench.py --no-cpu-baseline --bwd-chunks 6 > profiles/${RND}_bench_bwd_chunks6.json 2>>$O/bench.err
 python bench.py --no-cpu-baseline --sampler occgrid > profiles/${RND}_bench_occgrid.json 2>>$O/bench.err
 python bench.py --no-cpu-baseline --events 32768 --loss-grad 1e-3 > profiles/${RND}_bench_lossgrad.json 2>>$O/bench.err
 python bench.py --no-cpu-baseline --events 32768 --loss-grad 1e-3 --mlp-bf16 > profiles/${RND}_bench_lossgrad_bf16.json 2>>$O/bench.err
@@ -34,4 +35,5 @@ cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o x -- python $R/bench.py --no-cpu-baseline > /dev/null 2>&1
 cd $R
 python tools/summarize_profile.py $(find $O/prof -name '*kernel_stats.csv' | head -1) profiles/${RND}_bench_kernel_stats.csv "rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline (13 steps of BASELINE configs[1], R = 65 536 rays per render)"
+bash tools/profile_lines.sh $RND > $O/profile_lines.log 2>&1        # kernel stats + gap trace of the config-E / hard / occgrid lines
 cp profiles/${RND}_* $O/; ls $O
