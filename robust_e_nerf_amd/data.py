@@ -107,15 +107,22 @@ def colorize_events(events: Dict[str, torch.Tensor], bayer_pattern: str) -> Dict
 
 
 def undistort_points(px: np.ndarray, K: np.ndarray, dist: np.ndarray, model: str) -> np.ndarray:
-    """Pixel -> undistorted pixel (same intrinsics), restating OpenCV's iterative point undistortion for
-    'plumb_bob' (k1, k2, p1, p2) and the fisheye 'equidistant' model (k1..k4)."""
+    """Pixel -> undistorted pixel (same intrinsics): what `cv2.undistortPoints(pts, K, dist, P=K)` ('plumb_bob': k1, k2, p1,
+    p2) and `cv2.fisheye.undistortPoints(pts, K, dist, P=K)` ('equidistant': k1..k4) compute at the reference's call sites
+    (data/datasets.py:345-362).  OpenCV is not in this image and not vendored by the reference, so this RESTATES the
+    published algorithm of the version the reference pins (opencv 4.5.2, environment.yml:25) -- PARITY UNPINNED against cv2
+    itself; pinned by property instead (tests/test_data.py: it inverts the forward distortion model):
+      * plumb_bob: cvUndistortPointsInternal's fixed-point iteration, EXACTLY 5 iterations (the default criteria of
+        cv::undistortPoints is MAX_ITER 5 without an epsilon test -- the result is the 5th iterate, not the fixed point);
+      * equidistant: Newton on theta_d = theta (1 + k1 theta^2 + ... + k4 theta^8), <= 10 iterations, stops at
+        |step| < 1e-8, theta_d clipped to [-pi/2, pi/2], scale = tan(theta) / theta_d (1 for theta_d <= 1e-8)."""
     fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
     x = (px[:, 0] - cx) / fx
     y = (px[:, 1] - cy) / fy
     if model == "plumb_bob":
         k1, k2, p1, p2 = (float(v) for v in dist)
         x0, y0 = x.copy(), y.copy()
-        for _ in range(20):
+        for _ in range(5):
             r2 = x * x + y * y
             icdist = 1.0 / (1.0 + (k2 * r2 + k1) * r2)
             dx = 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
@@ -123,14 +130,16 @@ def undistort_points(px: np.ndarray, K: np.ndarray, dist: np.ndarray, model: str
             x, y = (x0 - dx) * icdist, (y0 - dy) * icdist
     elif model == "equidistant":
         k = [float(v) for v in dist]
-        theta_d = np.sqrt(x * x + y * y)
+        theta_d = np.clip(np.sqrt(x * x + y * y), -np.pi / 2, np.pi / 2)
         theta = theta_d.copy()
-        for _ in range(20):
+        live = np.ones_like(theta, dtype=bool)                            # per point: OpenCV leaves the loop when |step| < 1e-8
+        for _ in range(10):
             t2 = theta * theta
             t4, t6, t8 = t2 * t2, t2 * t2 * t2, t2 * t2 * t2 * t2
-            f = theta * (1 + k[0] * t2 + k[1] * t4 + k[2] * t6 + k[3] * t8) - theta_d
-            fp = 1 + 3 * k[0] * t2 + 5 * k[1] * t4 + 7 * k[2] * t6 + 9 * k[3] * t8
-            theta = theta - f / fp
+            fix = (theta * (1 + k[0] * t2 + k[1] * t4 + k[2] * t6 + k[3] * t8) - theta_d) / \
+                  (1 + 3 * k[0] * t2 + 5 * k[1] * t4 + 7 * k[2] * t6 + 9 * k[3] * t8)
+            theta = np.where(live, theta - fix, theta)
+            live &= np.abs(fix) >= 1e-8
         scale = np.where(theta_d > 1e-8, np.tan(theta) / np.maximum(theta_d, 1e-8), 1.0)
         x, y = x * scale, y * scale
     else:

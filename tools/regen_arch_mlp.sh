@@ -1,7 +1,7 @@
 # arch mlp lines of profiles/ (the fused field, csrc/ren_vfield.hip): bench lines, per-kernel stats, MFMA / HBM counters.
-#   gpurun --timeout 900 -- 'bash tools/regen_arch_mlp.sh r03'
+#   gpurun --timeout 900 -- 'bash tools/regen_arch_mlp.sh r04'
 set -x
-RND=${1:-r03}
+RND=${1:-r04}
 R=$PWD
 O=$R/gpurun_out/$RND
 mkdir -p $O
