@@ -72,11 +72,18 @@ int ren_abi_version(void);                       /* bumps when a signature chang
  *   REN_KNOB_VFIELD_PLAIN      1: arch mlp, bf16 mode: the forward / backward kernels without the software-pipelined epilogue
  *   REN_KNOB_MLP_BWD_CUS       persistent workgroups (= CUs) the fused MLP backward kernels occupy, 1 .. 256 (default 256); the
  *                              chunked backward of engine.py lowers it while a scatter runs on the second stream
+ *   REN_KNOB_ACTIVATIONS       MODEL configuration rather than tuning: the activation alternatives of the YAML (models/nerf.py:8-29)
+ *                              for the exact-f32 MLP kernels (ren_mlp_fwd/bwd[_save/_saved/_bf16], ren_mlp_fwd/bwd_jvp,
+ *                              ren_mlp_fwd_jvp2).  Code: bits 0-1 base hidden layers (0 softplus beta 100, 1 relu), bits 2-3
+ *                              density (0 shifted_trunc_exp, 1 softplus, 2 shifted_softplus), bits 4-5 head hidden layers
+ *                              (0 | 1 as the base), bits 6-7 radiance (0 softplus, 1 sigmoid).  0 (default) = every shipped
+ *                              config.  The bf16-matrix-core kernels (ren_mlp_*_x) implement code 0 only and return
+ *                              REN_ERR_UNSUPPORTED otherwise.
  *   REN_KNOB_HGB_SUBREGION     binned scatter, which of a pair bin's 8 sub-regions a workgroup appends to: 1 (default) = the one
  *                              of the XCD it runs on, 0 = (workgroup index / 8) % 8, i.e. every sub-region written from all XCDs
  *                              (the A/B of the per-XCD layout: same code, same cursors, only the line sharing differs) */
 enum { REN_KNOB_HGB_NO_PAIRS = 0, REN_KNOB_HGB_HALVE_REGIONS = 1, REN_KNOB_MARCH_SEQUENTIAL = 2, REN_KNOB_HG_VARIANT = 3,
-       REN_KNOB_VFIELD_PLAIN = 4, REN_KNOB_HGB_SUBREGION = 5, REN_KNOB_MLP_BWD_CUS = 6, REN_KNOB_COUNT = 7 };
+       REN_KNOB_VFIELD_PLAIN = 4, REN_KNOB_HGB_SUBREGION = 5, REN_KNOB_MLP_BWD_CUS = 6, REN_KNOB_ACTIVATIONS = 7, REN_KNOB_COUNT = 8 };
 int ren_set_knob(int32_t knob, int32_t value);    /* REN_OK or REN_ERR_BAD_ARG */
 int ren_get_knob(int32_t knob);
 const char *ren_build_info(void);                /* "gfx950 ..."                        */

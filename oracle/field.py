@@ -201,31 +201,65 @@ PARAM_ORDER = (
 
 
 # ----------------------------------------------------------------------------- field
+# Activation alternatives of the YAML (models/nerf.py:8-29): hidden {softplus (beta 100), relu}, density {shifted_trunc_exp,
+# softplus (beta 1), shifted_softplus = softplus(x - 1)}, radiance {softplus (beta 1), sigmoid}.  `acts` = dict(base_hidden,
+# density, head_hidden, radiance); absent keys take the shipped configs' values.
+DEFAULT_ACTS = dict(base_hidden="softplus", density="shifted_trunc_exp", head_hidden="softplus", radiance="softplus")
+
+
+def _hidden(x, name):
+    if name == "softplus":
+        return softplus(x, 100.0)
+    if name == "relu":
+        return torch.relu(x)
+    raise NotImplementedError(f"hidden activation {name!r} (nerf.py:17-20)")
+
+
+def _density(x, name):
+    if name == "shifted_trunc_exp":
+        return shifted_trunc_exp(x)
+    if name == "softplus":
+        return softplus(x, 1.0)
+    if name == "shifted_softplus":                            # nerf.py:8-13
+        return softplus(x - 1.0, 1.0)
+    raise NotImplementedError(f"density activation {name!r} (nerf.py:21-25)")
+
+
+def _radiance(x, name):
+    if name == "softplus":
+        return softplus(x, 1.0)
+    if name == "sigmoid":
+        return torch.sigmoid(x)
+    raise NotImplementedError(f"radiance activation {name!r} (nerf.py:26-29)")
+
+
 def query_density(
     x_world: torch.Tensor, p: Dict[str, torch.Tensor], spec, aabb: torch.Tensor,
-    contraction_type: int = AABB, return_feat: bool = False,
+    contraction_type: int = AABB, return_feat: bool = False, acts: Optional[dict] = None,
 ):
-    """ngp.py:230-254: sigma = exp(raw0 - 1) * selector, geo = raw[1:16]."""
+    """ngp.py:230-254: sigma = density_activation(raw0) * selector (default exp(raw0 - 1)), geo = raw[1:16]."""
+    a = dict(DEFAULT_ACTS, **(acts or {}))
     xu = contract(x_world, aabb, contraction_type)
     sel = selector(xu)
     enc = hashgrid.encode(xu, p["hash"], spec)
-    h = softplus(linear(enc, p["base.w0"], p["base.b0"]), 100.0)
+    h = _hidden(linear(enc, p["base.w0"], p["base.b0"]), a["base_hidden"])
     raw = linear(h, p["base.wo"], p["base.bo"])
-    sigma = shifted_trunc_exp(raw[:, :1]) * sel[:, None].to(raw.dtype)
+    sigma = _density(raw[:, :1], a["density"]) * sel[:, None].to(raw.dtype)
     if return_feat:
         return sigma, raw[:, 1:]
     return sigma
 
 
-def query_rgb(dirs: torch.Tensor, geo: torch.Tensor, p: Dict[str, torch.Tensor]) -> torch.Tensor:
-    """ngp.py:256-267: head([SH16(dir) | geo15]) with softplus(100) hidden, softplus(1) out."""
+def query_rgb(dirs: torch.Tensor, geo: torch.Tensor, p: Dict[str, torch.Tensor], acts: Optional[dict] = None) -> torch.Tensor:
+    """ngp.py:256-267: head([SH16(dir) | geo15]), hidden activation (default softplus 100), radiance activation (softplus 1)."""
+    a = dict(DEFAULT_ACTS, **(acts or {}))
     h = torch.cat([sh_encode(dirs, 4), geo], dim=-1)
-    h = softplus(linear(h, p["head.w0"], p["head.b0"]), 100.0)
-    h = softplus(linear(h, p["head.w1"], p["head.b1"]), 100.0)
-    return softplus(linear(h, p["head.wo"], p["head.bo"]), 1.0)
+    h = _hidden(linear(h, p["head.w0"], p["head.b0"]), a["head_hidden"])
+    h = _hidden(linear(h, p["head.w1"], p["head.b1"]), a["head_hidden"])
+    return _radiance(linear(h, p["head.wo"], p["head.bo"]), a["radiance"])
 
 
-def field_forward(x_world, dirs, p, spec, aabb, contraction_type: int = AABB):
+def field_forward(x_world, dirs, p, spec, aabb, contraction_type: int = AABB, acts: Optional[dict] = None):
     """ngp.py:269-280 -> (rgb (n,C), sigma (n,1))."""
-    sigma, geo = query_density(x_world, p, spec, aabb, contraction_type, return_feat=True)
-    return query_rgb(dirs, geo, p), sigma
+    sigma, geo = query_density(x_world, p, spec, aabb, contraction_type, return_feat=True, acts=acts)
+    return query_rgb(dirs, geo, p, acts), sigma

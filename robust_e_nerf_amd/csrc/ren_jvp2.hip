@@ -244,15 +244,16 @@ __device__ __forceinline__ void sh4_t2_select(const T2 &x, const T2 &y, const T2
 
 // softplus(beta = 100) with first and second tangent, in place (z, zd, ze) -> (y, yd, ye):
 // y' = s z', y'' = s z'' + beta (1 - s) s z'^2 with s = 1 - exp(-beta y)
-__device__ __forceinline__ void act2(f32x16 (&y)[2], f32x16 (&yd)[2], f32x16 (&ye)[2]) {
+// (k: hidden-activation kind, ren_mlp_common.h act_kinds; relu: s = [y > 0], no curvature)
+__device__ __forceinline__ void act2(f32x16 (&y)[2], f32x16 (&yd)[2], f32x16 (&ye)[2], int k) {
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
-            const float v = softplus100(y[r][g]);
-            const float s = dsoftplus_from_out(v, 100.f);
+            const float v = act_hidden(y[r][g], k);
+            const float s = dact_hidden(v, k);
             const float zd = yd[r][g];
-            ye[r][g] = s * ye[r][g] + 100.f * (1.f - s) * s * zd * zd;
+            ye[r][g] = s * ye[r][g] + d2act_hidden(s, k) * zd * zd;
             yd[r][g] = s * zd;
             y[r][g] = v;
         }
@@ -264,10 +265,12 @@ struct Fwd2Args {
     ren_scene_dev sc;
     int64_t n;
     float *rgb, *rgbd, *rgbdd, *sigma, *sigmad, *sigmadd;
+    int act_code;                                  // f32 kernel: activation alternatives (ren_mlp_common.h); the x kernel implements 0 only
 };
 
 template <int C>
 __global__ __launch_bounds__(256, 1) void mlp_fwd_jvp2_kernel(Fwd2Args a) {
+    const ActKinds ak = act_kinds(a.act_code);
     extern __shared__ __attribute__((aligned(16))) float lds_base[];
     fill_base(lds_base, a.params, L_W1, L_W2, L_B1, L_B2);
     fill_head(lds_base, a.params, C, L_WH1, L_WH2, L_WH3, L_BH1, L_BH2, L_BH3);
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_jvp2_kernel(Fwd2Args a) {
                 he[0] = MFMA(a0, xe, he[0]); he[1] = MFMA(a1, xe, he[1]);
             }
         }
-        act2(h, hd, he);
+        act2(h, hd, he, ak.bh);
         f32x16 o, od, oe;
 #pragma unroll
         for (int g = 0; g < 16; ++g) { o[g] = lds[L_B2 + rowc(g) + 4 * hi]; od[g] = 0.f; oe[g] = 0.f; }
@@ -326,10 +329,11 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_jvp2_kernel(Fwd2Args a) {
         }
         if (live && hi == 0) {
             // trunc_exp (ngp.py:45-65): value exp(x), derivative exp(min(x, 15))
-            const float xr = o[0] - 1.f, ec = __expf(fminf(xr, 15.f));
-            a.sigma[i] = sel ? __expf(xr) : 0.f;
+            // (other densities: softplus / shifted_softplus, nerf.py:8-13,21-25)
+            const float ec = dact_density(o[0], ak.dn);
+            a.sigma[i] = sel ? act_density(o[0], ak.dn) : 0.f;
             a.sigmad[i] = sel ? ec * od[0] : 0.f;
-            a.sigmadd[i] = sel ? ec * (oe[0] + (xr < 15.f ? od[0] * od[0] : 0.f)) : 0.f;
+            a.sigmadd[i] = sel ? ec * oe[0] + d2act_density(o[0], ec, ak.dn) * od[0] * od[0] : 0.f;
         }
         T2 shs[8];
         sh4_t2_select(dir[0], dir[1], dir[2], hi, shs);
@@ -350,7 +354,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_jvp2_kernel(Fwd2Args a) {
             pd[0] = MFMA(a0, bd, pd[0]); pd[1] = MFMA(a1, bd, pd[1]);
             pe[0] = MFMA(a0, be, pe[0]); pe[1] = MFMA(a1, be, pe[1]);
         }
-        act2(p, pd, pe);
+        act2(p, pd, pe, ak.hh);
         f32x16 q[2], qd[2], qe[2];
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
@@ -367,7 +371,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_jvp2_kernel(Fwd2Args a) {
                 qd[0] = MFMA(a0, pd[r][g], qd[0]); qd[1] = MFMA(a1, pd[r][g], qd[1]);
                 qe[0] = MFMA(a0, pe[r][g], qe[0]); qe[1] = MFMA(a1, pe[r][g], qe[1]);
             }
-        act2(q, qd, qe);
+        act2(q, qd, qe, ak.hh);
         float acc[C], accd[C], acce[C];
 #pragma unroll
         for (int c = 0; c < C; ++c) { acc[c] = 0.f; accd[c] = 0.f; acce[c] = 0.f; }
@@ -386,10 +390,10 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_jvp2_kernel(Fwd2Args a) {
             const float z3d = accd[c] + __shfl_xor(accd[c], 32, 64);
             const float z3e = acce[c] + __shfl_xor(acce[c], 32, 64);
             if (hi == 0 && live) {
-                const float y = softplus1(z3), s = dsoftplus_from_out(y, 1.f);
+                const float y = act_radiance(z3, ak.rd), s = dact_radiance(y, ak.rd);
                 a.rgb[i * C + c] = y;
                 a.rgbd[i * C + c] = s * z3d;
-                a.rgbdd[i * C + c] = s * z3e + (1.f - s) * s * z3d * z3d;
+                a.rgbdd[i * C + c] = s * z3e + d2act_radiance(y, s, ak.rd) * z3d * z3d;
             }
         }
     }
@@ -491,7 +495,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_jvp2_x_kernel(Fwd2Args a) {
         // nine of ten fresh processes, never on a repeat launch, gone with the barrier (tools/jvp2_first_launch.py,
         // test_second_order_mlp_forward_matrix_core_kernel_vs_f32_kernel).
         asm volatile("" ::: "memory");
-        act2(h, hd, he);
+        act2(h, hd, he, 0);
         // ---- base output: 64 -> 16 (rows 16..31 of the tile are zero)
         f32x16 o, od, oe;
 #pragma unroll
@@ -542,7 +546,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_jvp2_x_kernel(Fwd2Args a) {
             mma_j3<MODE, 2>(p, pd, pe, fr + L::F_WH1, 2, 1, b, bd, be, lane);
         }
         asm volatile("" ::: "memory");
-        act2(p, pd, pe);
+        act2(p, pd, pe, 0);
         // ---- head layer 1: 64 -> 64
         f32x16 q[2], qd[2], qe[2];
 #pragma unroll
@@ -556,7 +560,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_jvp2_x_kernel(Fwd2Args a) {
             mma_j3<MODE, 2>(q, qd, qe, fr + L::F_WH2, 4, c, b, bd, be, lane);
         }
         asm volatile("" ::: "memory");
-        act2(q, qd, qe);
+        act2(q, qd, qe, 0);
         // ---- head output: 64 -> C on the VALU in fp32 (MODE 1: bf16-rounded operands, as every other layer)
         float acc[C], accd[C], acce[C];
 #pragma unroll
@@ -805,6 +809,7 @@ extern "C" int ren_mlp_fwd_jvp2(const float *mlp_params, int32_t C, const float 
     a.ray = Ray2{rays_o, rays_d, rays_do, rays_dd, rays_ddd, ray_indices, t_starts, t_ends};
     a.sc = ren_make_scene(scene);
     a.n = n; a.rgb = rgb; a.rgbd = rgbd; a.rgbdd = rgbdd; a.sigma = sigma; a.sigmad = sigmad; a.sigmadd = sigmadd;
+    a.act_code = ren_knob(REN_KNOB_ACTIVATIONS);
     const int64_t n_blk = (n + 31) / 32;
     int64_t blocks = (n_blk + 3) / 4;
     if (blocks > 256) blocks = 256;
@@ -826,8 +831,10 @@ extern "C" int ren_mlp_fwd_jvp2_x(const float *mlp_params, int32_t C, int32_t mo
         return REN_ERR_BAD_ARG;
     if (C != 1 && C != 3) return REN_ERR_UNSUPPORTED;
     if (mode != 1 && mode != 6) return REN_ERR_UNSUPPORTED;
+    if (ren_knob(REN_KNOB_ACTIVATIONS) != 0) return REN_ERR_UNSUPPORTED;      // activation alternatives: exact-f32 kernels only
     if (n == 0) return REN_OK;
     Fwd2Args a;
+    a.act_code = 0;
     a.params = mlp_params; a.feat = feat; a.featd = featd; a.featdd = featdd;
     a.ray = Ray2{rays_o, rays_d, rays_do, rays_dd, rays_ddd, ray_indices, t_starts, t_ends};
     a.sc = ren_make_scene(scene);

@@ -39,6 +39,7 @@ struct FwdArgs {
     int64_t n;
     float *rgb, *sigma, *base_out;
     float *acts;                                    // optional [blk][3 = h,p,q][2][16][64]: post-activation values for ren_mlp_bwd_saved
+    int act_code;                                   // activation alternatives (ren_mlp_common.h act_kinds); 0 = shipped configs
 };
 
 template <int C, bool DENSITY_ONLY, bool RB>
@@ -50,6 +51,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(FwdArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int hi = lane >> 5, sl = lane & 31;
     const int64_t n_blk = (a.n + 31) >> 5;
+    const ActKinds ak = act_kinds(a.act_code);
 
     for (int64_t blk = (int64_t)blockIdx.x * 4 + wave; blk < n_blk; blk += (int64_t)gridDim.x * 4) {
         // The weight image is loop invariant; without this opaque offset LICM hoists every LDS
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(FwdArgs a) {
 #pragma unroll
             for (int s = 0; s < 16; ++s) h[r] = MFMA(W1[(32 * r + sl) * 33 + 2 * s + hi], x[s], h[r]);
 #pragma unroll
-            for (int g = 0; g < 16; ++g) h[r][g] = softplus100(h[r][g]);
+            for (int g = 0; g < 16; ++g) h[r][g] = act_hidden(h[r][g], ak.bh);
             if (a.acts) {                                       // ONE branch, constant offsets
                 float *ap = a.acts + blk * ACT_SAVE_FLOATS + r * 1024 + lane;
 #pragma unroll
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(FwdArgs a) {
         bool sel = false;
         float dx = 0.f, dy = 0.f, dz = 1.f;
         if (live) sample_geom(a.src, a.sc, i, sel, dx, dy, dz);
-        if (live && hi == 0) a.sigma[i] = sel ? __expf(o[0] - 1.f) : 0.f;          // ngp.py:247-250
+        if (live && hi == 0) a.sigma[i] = sel ? act_density(o[0], ak.dn) : 0.f;     // ngp.py:247-250
         if (a.base_out) {
             float *bo = a.base_out + blk * (8 * 64) + lane;
 #pragma unroll
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(FwdArgs a) {
                 p[r] = MFMA(WH1[(32 * r + sl) * 33 + col], bv, p[r]);
             }
 #pragma unroll
-            for (int g = 0; g < 16; ++g) p[r][g] = softplus100(p[r][g]);
+            for (int g = 0; g < 16; ++g) p[r][g] = act_hidden(p[r][g], ak.hh);
             if (a.acts) {
                 float *ap = a.acts + blk * ACT_SAVE_FLOATS + (2 + r) * 1024 + lane;
 #pragma unroll
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(FwdArgs a) {
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
 #pragma unroll
-            for (int g = 0; g < 16; ++g) q[r][g] = softplus100(q[r][g]);
+            for (int g = 0; g < 16; ++g) q[r][g] = act_hidden(q[r][g], ak.hh);
             if (a.acts) {
                 float *ap = a.acts + blk * ACT_SAVE_FLOATS + (4 + r) * 1024 + lane;
 #pragma unroll
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(FwdArgs a) {
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             const float t = acc[c] + __shfl_xor(acc[c], 32, 64);
-            if (hi == 0 && live) a.rgb[i * C + c] = softplus1(t + lds[L_BH3 + c]);
+            if (hi == 0 && live) a.rgb[i * C + c] = act_radiance(t + lds[L_BH3 + c], ak.rd);
         }
     }
 }
@@ -197,6 +199,7 @@ struct BwdHArgs {
     const float *rgb, *d_rgb, *d_sigma;
     float *d_base, *slab;                           // d_base: fragment layout [blk][8][64]
     const float *acts;                              // SAVED: forward's post-activation values (see ACT_SAVE_FLOATS)
+    int act_code;
 };
 
 template <int C, bool RB, bool SAVED>
@@ -209,6 +212,7 @@ __global__ __launch_bounds__(256, REN_HEAD_OCC) void mlp_bwd_head_kernel(BwdHArg
     float *T_act = T_dz + 64 * 33;                                 // [32][33]
     __syncthreads();
     const int64_t n_blk = (a.n + 31) >> 5;
+    const ActKinds ak = act_kinds(a.act_code);
 
     f32x16 acc_wh2[2][2], acc_wh1[2];
     float acc_w3[C][32], acc_bh2[2] = {0.f, 0.f}, acc_bh1[2] = {0.f, 0.f}, acc_bh3[C];
@@ -267,7 +271,7 @@ __global__ __launch_bounds__(256, REN_HEAD_OCC) void mlp_bwd_head_kernel(BwdHArg
             for (int r = 0; r < 2; ++r)
 #pragma unroll
                 for (int g = 0; g < 16; ++g) {
-                    if (RB) { s1[r][g] = dsoftplus_from_out(p[r][g], 100.f); s2[r][g] = dsoftplus_from_out(q[r][g], 100.f); }
+                    if (RB) { s1[r][g] = dact_hidden(p[r][g], ak.hh); s2[r][g] = dact_hidden(q[r][g], ak.hh); }
                     p[r][g] = lin_in<RB>(p[r][g]);
                     q[r][g] = lin_in<RB>(q[r][g]);
                 }
@@ -290,8 +294,8 @@ __global__ __launch_bounds__(256, REN_HEAD_OCC) void mlp_bwd_head_kernel(BwdHArg
         for (int r = 0; r < 2; ++r)
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
-                const float y = softplus100(p[r][g]);
-                if (RB) s1[r][g] = dsoftplus_from_out(y, 100.f);
+                const float y = act_hidden(p[r][g], ak.hh);
+                if (RB) s1[r][g] = dact_hidden(y, ak.hh);
                 p[r][g] = lin_in<RB>(y);
             }
 #pragma unroll
@@ -306,8 +310,8 @@ __global__ __launch_bounds__(256, REN_HEAD_OCC) void mlp_bwd_head_kernel(BwdHArg
         for (int r = 0; r < 2; ++r)
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
-                const float y = softplus100(q[r][g]);
-                if (RB) s2[r][g] = dsoftplus_from_out(y, 100.f);
+                const float y = act_hidden(q[r][g], ak.hh);
+                if (RB) s2[r][g] = dact_hidden(y, ak.hh);
                 q[r][g] = lin_in<RB>(y);
             }
         }
@@ -315,7 +319,7 @@ __global__ __launch_bounds__(256, REN_HEAD_OCC) void mlp_bwd_head_kernel(BwdHArg
         float dz3[C];
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            dz3[c] = live ? a.d_rgb[i * C + c] * dsoftplus_from_out(a.rgb[i * C + c], 1.f) : 0.f;
+            dz3[c] = live ? a.d_rgb[i * C + c] * dact_radiance(a.rgb[i * C + c], ak.rd) : 0.f;
             if (hi == 0) acc_bh3[c] += dz3[c];
 #pragma unroll
             for (int r = 0; r < 2; ++r)
@@ -330,7 +334,7 @@ __global__ __launch_bounds__(256, REN_HEAD_OCC) void mlp_bwd_head_kernel(BwdHArg
                 float dq = 0.f;
 #pragma unroll
                 for (int c = 0; c < C; ++c) dq += dz3[c] * lds[LH_WH3 + c * 64 + 32 * r + rowc(g) + 4 * hi];
-                q[r][g] = dq * (RB ? s2[r][g] : dsoftplus_from_out(q[r][g], 100.f));
+                q[r][g] = dq * (RB ? s2[r][g] : dact_hidden(q[r][g], ak.hh));
             }
         // ---- dW(head.w1) += dZ2 . P^T  (stage both as [neuron][sample]; P in two 32-row halves so
         //      the per-wave staging area stays at 96 rows and two workgroups fit one CU)
@@ -366,7 +370,7 @@ __global__ __launch_bounds__(256, REN_HEAD_OCC) void mlp_bwd_head_kernel(BwdHArg
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
-            for (int g = 0; g < 16; ++g) dp[r][g] *= RB ? s1[r][g] : dsoftplus_from_out(p[r][g], 100.f);
+            for (int g = 0; g < 16; ++g) dp[r][g] *= RB ? s1[r][g] : dact_hidden(p[r][g], ak.hh);
         // ---- dW(head.w0) += dZ1 . V^T,  V = [base_out(16) | SH(16)]
 #pragma unroll
         for (int r = 0; r < 2; ++r)
@@ -397,7 +401,7 @@ __global__ __launch_bounds__(256, REN_HEAD_OCC) void mlp_bwd_head_kernel(BwdHArg
         if (hi == 0) {
             // d sigma / d raw = exp(clamp(raw - 1, max=15)) * selector   (ngp.py:54-58,247-250)
             const float ds = live ? a.d_sigma[i] : 0.f;
-            dv[0] = sel ? ds * __expf(fminf(o[0] - 1.f, 15.f)) : 0.f;
+            dv[0] = sel ? ds * dact_density(o[0], ak.dn) : 0.f;
         }
         {
             float *db = a.d_base + blk * (8 * 64) + lane;
@@ -442,6 +446,7 @@ struct BwdBArgs {
     int64_t n;
     float *dfeat, *slab;
     const float *acts;
+    int act_code;
 };
 
 template <bool RB, bool SAVED>
@@ -455,6 +460,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_base_kernel(BwdBArgs a) {
     for (int k = lane; k < 32 * 33; k += 64) T_b[k] = 0.f;         // rows 16..31 stay zero
     __syncthreads();
     const int64_t n_blk = (a.n + 31) >> 5;
+    const ActKinds ak = act_kinds(a.act_code);
 
     f32x16 acc_w2[2], acc_w1[2];
     float acc_b2 = 0.f, acc_b1[2] = {0.f, 0.f};
@@ -485,7 +491,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_base_kernel(BwdBArgs a) {
 #pragma unroll
                 for (int g = 0; g < 16; ++g) {
                     const float y = ac[(r * 16 + g) * 64];
-                    if (RB) s0[r][g] = dsoftplus_from_out(y, 100.f);
+                    if (RB) s0[r][g] = dact_hidden(y, ak.bh);
                     h[r][g] = lin_in<RB>(y);
                 }
         } else {
@@ -503,8 +509,8 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_base_kernel(BwdBArgs a) {
         for (int r = 0; r < 2; ++r)
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
-                const float y = softplus100(h[r][g]);
-                if (RB) s0[r][g] = dsoftplus_from_out(y, 100.f);
+                const float y = act_hidden(h[r][g], ak.bh);
+                if (RB) s0[r][g] = dact_hidden(y, ak.bh);
                 h[r][g] = lin_in<RB>(y);
             }
         }
@@ -535,7 +541,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_base_kernel(BwdBArgs a) {
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
-            for (int g = 0; g < 16; ++g) dh[r][g] *= RB ? s0[r][g] : dsoftplus_from_out(h[r][g], 100.f);
+            for (int g = 0; g < 16; ++g) dh[r][g] *= RB ? s0[r][g] : dact_hidden(h[r][g], ak.bh);
         // ---- dW(base.w0) += dZ0 . X^T
 #pragma unroll
         for (int r = 0; r < 2; ++r)
@@ -620,6 +626,7 @@ static int mlp_fwd_impl(bool rb, const float *mlp_params, int32_t C, const float
     a.src = SampleSrc{x_world, dirs, rays_o, rays_d, x_world ? nullptr : ray_indices, t_starts, t_ends};
     a.sc = ren_make_scene(scene);
     a.n = n; a.rgb = rgb; a.sigma = sigma; a.base_out = base_out; a.acts = acts;
+    a.act_code = ren_knob(REN_KNOB_ACTIVATIONS);
     const int64_t n_blk = (n + 31) / 32;
     int64_t blocks = (n_blk + 3) / 4;
     if (blocks > 768) blocks = 768;                            // 3 workgroups / CU (43.5 KB LDS each)
@@ -698,6 +705,7 @@ static int mlp_bwd_impl(bool rb, const float *mlp_params, int32_t C, const float
     h.src = SampleSrc{x_world, dirs, rays_o, rays_d, x_world ? nullptr : ray_indices, t_starts, t_ends};
     h.sc = ren_make_scene(scene);
     h.n = n; h.rgb = rgb; h.d_rgb = d_rgb; h.d_sigma = d_sigma; h.d_base = d_base; h.slab = slab_h; h.acts = acts;
+    h.act_code = ren_knob(REN_KNOB_ACTIVATIONS);
     const bool sv = acts != nullptr;
 #define REN_HEAD(CC, R, S) hipLaunchKernelGGL((mlp_bwd_head_kernel<CC, R, S>), dim3(GRID_H), dim3(256), BWD_H_LDS, st, h)
     if (C == 1) {
@@ -710,6 +718,7 @@ static int mlp_bwd_impl(bool rb, const float *mlp_params, int32_t C, const float
 #undef REN_HEAD
     BwdBArgs b;
     b.params = mlp_params; b.feat = feat; b.d_base = d_base; b.n = n; b.dfeat = dfeat; b.slab = slab_b; b.acts = acts;
+    b.act_code = ren_knob(REN_KNOB_ACTIVATIONS);
 #define REN_BASE(R, S) hipLaunchKernelGGL((mlp_bwd_base_kernel<R, S>), dim3(GRID_B), dim3(256), BWD_B_LDS, st, b)
     if (rb) { if (sv) REN_BASE(true, true); else REN_BASE(true, false); }
     else    { if (sv) REN_BASE(false, true); else REN_BASE(false, false); }

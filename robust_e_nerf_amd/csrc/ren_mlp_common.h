@@ -74,6 +74,31 @@ __device__ __forceinline__ float dsoftplus_from_out(float y, float beta) {
     return t < 1e-3f ? t * (1.f - t * (0.5f - t * 0.16666667f)) : 1.f - __expf(-t);
 }
 
+// ---- activation alternatives of the YAML (robust_e_nerf/models/nerf.py:8-29): hidden layers {softplus beta 100 | relu}
+// separately for the base and the head MLP, density {shifted_trunc_exp | softplus beta 1 | shifted_softplus = softplus(x - 1)},
+// radiance {softplus beta 1 | sigmoid}.  The exact-f32 kernels (ren_mlp.hip, ren_mlp_jvp.hip, ren_jvp2.hip) take them at
+// run time as one code (REN_KNOB_ACTIVATIONS, include/ren_amd.h): bits 0-1 base hidden, 2-3 density, 4-5 head hidden, 6-7
+// radiance; 0 = the shipped configs.  Derivatives are expressed through the OUTPUT (hidden, radiance) or the raw
+// pre-activation (density), as the kernels keep those.
+struct ActKinds { int bh, dn, hh, rd; };
+__device__ __forceinline__ ActKinds act_kinds(int code) { return ActKinds{code & 3, (code >> 2) & 3, (code >> 4) & 3, (code >> 6) & 3}; }
+__device__ __forceinline__ float act_hidden(float x, int k) { return k == 1 ? fmaxf(x, 0.f) : softplus100(x); }
+__device__ __forceinline__ float dact_hidden(float y, int k) { return k == 1 ? (y > 0.f ? 1.f : 0.f) : dsoftplus_from_out(y, 100.f); }
+__device__ __forceinline__ float d2act_hidden(float s, int k) { return k == 1 ? 0.f : 100.f * (1.f - s) * s; }     // from s = act'
+__device__ __forceinline__ float act_density(float raw, int k) {                       // ngp.py:45-65,247-250; nerf.py:8-13,21-25
+    if (k == 0) return __expf(raw - 1.f);
+    return softplus1(k == 2 ? raw - 1.f : raw);
+}
+__device__ __forceinline__ float dact_density(float raw, int k) {                      // trunc_exp: backward clamped at 15
+    if (k == 0) return __expf(fminf(raw - 1.f, 15.f));
+    return 1.f / (1.f + __expf(-(k == 2 ? raw - 1.f : raw)));
+}
+// second derivative w.r.t. raw, from the first (d1); trunc_exp: the clamped branch of its backward has none
+__device__ __forceinline__ float d2act_density(float raw, float d1, int k) { return k == 0 ? ((raw - 1.f) < 15.f ? d1 : 0.f) : d1 * (1.f - d1); }
+__device__ __forceinline__ float act_radiance(float z, int k) { return k == 1 ? 1.f / (1.f + __expf(-z)) : softplus1(z); }
+__device__ __forceinline__ float dact_radiance(float y, int k) { return k == 1 ? y * (1.f - y) : dsoftplus_from_out(y, 1.f); }
+__device__ __forceinline__ float d2act_radiance(float y, float s, int k) { return k == 1 ? s * (1.f - 2.f * y) : (1.f - s) * s; }
+
 // bf16 MLP mode (BASELINE configs[2]: "bf16 MLP with fp32 composite"): every nn.Linear sees bf16-rounded
 // inputs and bf16-rounded weights (the host passes a rounded copy of the parameter block), products are
 // exact in fp32 and accumulate in fp32 -- numerically what a bf16 MFMA with fp32 accumulation computes, here

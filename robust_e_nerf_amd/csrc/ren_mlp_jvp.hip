@@ -16,13 +16,14 @@
 namespace {
 
 // activation with tangent, in place: z -> y = sp100(z), zd -> yd = s zd; optionally keeps zd (pre-activation tangent)
-__device__ __forceinline__ void act_jvp(f32x16 (&y)[2], f32x16 (&yd)[2]) {
+// (k: hidden-activation kind of the layer's MLP, ren_mlp_common.h act_kinds)
+__device__ __forceinline__ void act_jvp(f32x16 (&y)[2], f32x16 (&yd)[2], int k) {
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
-            const float v = softplus100(y[r][g]);
-            yd[r][g] *= dsoftplus_from_out(v, 100.f);
+            const float v = act_hidden(y[r][g], k);
+            yd[r][g] *= dact_hidden(v, k);
             y[r][g] = v;
         }
 }
@@ -34,6 +35,7 @@ struct FwdJArgs {
     ren_scene_dev sc;
     int64_t n;
     float *rgb, *rgbd, *sigma, *sigmad, *base_out, *base_outd;
+    int act_code;                                  // activation alternatives (ren_mlp_common.h); 0 = shipped configs
 };
 
 template <int C>
@@ -45,6 +47,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_jvp_kernel(FwdJArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int hi = lane >> 5, sl = lane & 31;
     const int64_t n_blk = (a.n + 31) >> 5;
+    const ActKinds ak = act_kinds(a.act_code);
     for (int64_t blk = (int64_t)blockIdx.x * 4 + wave; blk < n_blk; blk += (int64_t)gridDim.x * 4) {
         int zo = 0;
         asm volatile("" : "+v"(zo));
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_jvp_kernel(FwdJArgs a) {
             h[0] = MFMA(a0, x[s], h[0]); h[1] = MFMA(a1, x[s], h[1]);
             hd[0] = MFMA(a0, xd[s], hd[0]); hd[1] = MFMA(a1, xd[s], hd[1]);
         }
-        act_jvp(h, hd);
+        act_jvp(h, hd, ak.bh);
         f32x16 o, od;
 #pragma unroll
         for (int g = 0; g < 16; ++g) { o[g] = lds[L_B2 + rowc(g) + 4 * hi]; od[g] = 0.f; }
@@ -86,8 +89,8 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_jvp_kernel(FwdJArgs a) {
         float dir[3] = {0.f, 0.f, 1.f}, dird[3] = {0.f, 0.f, 0.f};
         if (live) geom_jvp(a.src, a.sc, i, sel, dir, dird);
         if (live && hi == 0) {
-            a.sigma[i] = sel ? __expf(o[0] - 1.f) : 0.f;
-            a.sigmad[i] = sel ? __expf(fminf(o[0] - 1.f, 15.f)) * od[0] : 0.f;
+            a.sigma[i] = sel ? act_density(o[0], ak.dn) : 0.f;
+            a.sigmad[i] = sel ? dact_density(o[0], ak.dn) * od[0] : 0.f;
         }
         {
             float *bo = a.base_out + blk * (8 * 64) + lane, *bod = a.base_outd + blk * (8 * 64) + lane;
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_jvp_kernel(FwdJArgs a) {
             p[0] = MFMA(a0, bv, p[0]); p[1] = MFMA(a1, bv, p[1]);
             pd[0] = MFMA(a0, bd, pd[0]); pd[1] = MFMA(a1, bd, pd[1]);
         }
-        act_jvp(p, pd);
+        act_jvp(p, pd, ak.hh);
         f32x16 q[2], qd[2];
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
@@ -127,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_jvp_kernel(FwdJArgs a) {
                 q[0] = MFMA(a0, p[r][g], q[0]); q[1] = MFMA(a1, p[r][g], q[1]);
                 qd[0] = MFMA(a0, pd[r][g], qd[0]); qd[1] = MFMA(a1, pd[r][g], qd[1]);
             }
-        act_jvp(q, qd);
+        act_jvp(q, qd, ak.hh);
         float acc[C], accd[C];
 #pragma unroll
         for (int c = 0; c < C; ++c) { acc[c] = 0.f; accd[c] = 0.f; }
@@ -146,9 +149,9 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_jvp_kernel(FwdJArgs a) {
             const float z3 = acc[c] + __shfl_xor(acc[c], 32, 64) + lds[L_BH3 + c];
             const float z3d = accd[c] + __shfl_xor(accd[c], 32, 64);
             if (hi == 0 && live) {
-                const float y = softplus1(z3);
+                const float y = act_radiance(z3, ak.rd);
                 a.rgb[i * C + c] = y;
-                a.rgbd[i * C + c] = dsoftplus_from_out(y, 1.f) * z3d;
+                a.rgbd[i * C + c] = dact_radiance(y, ak.rd) * z3d;
             }
         }
     }
@@ -202,6 +205,7 @@ struct BwdJ2Args {
     int64_t n;
     const float *rgb, *d_rgb, *d_rgbd;
     float *dz1, *dz1d, *slab;                      // dz1/dz1d: [blk][2][16][64] fragment order
+    int act_code;                                  // activation alternatives (ren_mlp_common.h); 0 = shipped configs
 };
 
 template <int C>
@@ -214,6 +218,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_jvp_head2_kernel(BwdJ2Args a) 
     float *T_a = T_z + 64 * 33;
     __syncthreads();
     const int64_t n_blk = (a.n + 31) >> 5;
+    const ActKinds ak = act_kinds(a.act_code);
     f32x16 acc_w[2][2];
     float acc_w3[C][32], acc_b2[2] = {0.f, 0.f}, acc_b3[C];
 #pragma unroll
@@ -262,8 +267,8 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_jvp_head2_kernel(BwdJ2Args a) 
         for (int r = 0; r < 2; ++r)
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
-                p[r][g] = softplus100(p[r][g]);
-                pd[r][g] = dsoftplus_from_out(p[r][g], 100.f) * z1d[r][g];
+                p[r][g] = act_hidden(p[r][g], ak.hh);
+                pd[r][g] = dact_hidden(p[r][g], ak.hh) * z1d[r][g];
             }
         // ---- recompute head layer 1: q = sp(z2), keep z2d
         f32x16 q[2], z2d[2];
@@ -284,7 +289,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_jvp_head2_kernel(BwdJ2Args a) 
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
-            for (int g = 0; g < 16; ++g) q[r][g] = softplus100(q[r][g]);
+            for (int g = 0; g < 16; ++g) q[r][g] = act_hidden(q[r][g], ak.hh);
         // ---- output layer: z3d = sum_n (s2 z2d)[n] w3[n]
         float z3d[C];
 #pragma unroll
@@ -294,16 +299,16 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_jvp_head2_kernel(BwdJ2Args a) 
             for (int r = 0; r < 2; ++r)
 #pragma unroll
                 for (int g = 0; g < 16; ++g)
-                    t += dsoftplus_from_out(q[r][g], 100.f) * z2d[r][g] * lds[LH_WH3 + c * 64 + 32 * r + rowc(g) + 4 * hi];
+                    t += dact_hidden(q[r][g], ak.hh) * z2d[r][g] * lds[LH_WH3 + c * 64 + 32 * r + rowc(g) + 4 * hi];
             z3d[c] = t + __shfl_xor(t, 32, 64);
         }
         float dz3[C], dz3d[C];
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             const float y = live ? a.rgb[i * C + c] : 0.f;
-            const float s3 = dsoftplus_from_out(y, 1.f);
+            const float s3 = dact_radiance(y, ak.rd);
             const float gy = live ? a.d_rgb[i * C + c] : 0.f, gyd = live ? a.d_rgbd[i * C + c] : 0.f;
-            dz3[c] = gy * s3 + gyd * z3d[c] * d2softplus_from_s(s3, 1.f);
+            dz3[c] = gy * s3 + gyd * z3d[c] * d2act_radiance(y, s3, ak.rd);
             dz3d[c] = gyd * s3;
             if (hi == 0) acc_b3[c] += dz3[c];
         }
@@ -313,7 +318,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_jvp_head2_kernel(BwdJ2Args a) 
         for (int r = 0; r < 2; ++r)
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
-                const float s2 = dsoftplus_from_out(q[r][g], 100.f);
+                const float s2 = dact_hidden(q[r][g], ak.hh);
                 const float qd = s2 * z2d[r][g];
                 float dq = 0.f, dqd = 0.f;
 #pragma unroll
@@ -322,7 +327,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_jvp_head2_kernel(BwdJ2Args a) 
                     dq += dz3[c] * w3; dqd += dz3d[c] * w3;
                     acc_w3[c][r * 16 + g] += dz3[c] * q[r][g] + dz3d[c] * qd;
                 }
-                dz2[r][g] = dq * s2 + dqd * z2d[r][g] * d2softplus_from_s(s2, 100.f);
+                dz2[r][g] = dq * s2 + dqd * z2d[r][g] * d2act_hidden(s2, ak.hh);
                 dz2d[r][g] = dqd * s2;
             }
         // ---- dW(head.w1) += dz2 p^T + dz2d pd^T
@@ -350,8 +355,8 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_jvp_head2_kernel(BwdJ2Args a) 
             for (int r = 0; r < 2; ++r)
 #pragma unroll
                 for (int g = 0; g < 16; ++g) {
-                    const float s1 = dsoftplus_from_out(p[r][g], 100.f);
-                    oz[(r * 16 + g) * 64] = dp[r][g] * s1 + dpd[r][g] * z1d[r][g] * d2softplus_from_s(s1, 100.f);
+                    const float s1 = dact_hidden(p[r][g], ak.hh);
+                    oz[(r * 16 + g) * 64] = dp[r][g] * s1 + dpd[r][g] * z1d[r][g] * d2act_hidden(s1, ak.hh);
                     ozd[(r * 16 + g) * 64] = dpd[r][g] * s1;
                 }
         }
@@ -391,6 +396,7 @@ struct BwdJ1Args {
     int64_t n;
     const float *d_sigma, *d_sigmad;
     float *d_base, *d_based, *slab;
+    int act_code;                                  // activation alternatives (ren_mlp_common.h); 0 = shipped configs
 };
 
 __global__ __launch_bounds__(256, 2) void mlp_bwd_jvp_head1_kernel(BwdJ1Args a) {
@@ -402,6 +408,7 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_jvp_head1_kernel(BwdJ1Args a) 
     float *T_a = T_z + 64 * 33;                              // [32][33]
     __syncthreads();
     const int64_t n_blk = (a.n + 31) >> 5;
+    const ActKinds ak = act_kinds(a.act_code);
     f32x16 acc_w[2];
     float acc_b[2] = {0.f, 0.f};
 #pragma unroll
@@ -453,8 +460,8 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_jvp_head1_kernel(BwdJ1Args a) 
             // sigma = e sel, sigmad = e sel od0 with e = exp(min(o0 - 1, 15)):
             // d o0 = d sigma e + d sigmad sigmad (unclamped branch), d od0 = d sigmad e
             const float ds = live ? a.d_sigma[i] : 0.f, dsd = live ? a.d_sigmad[i] : 0.f;
-            const float e = sel ? __expf(fminf(o[0] - 1.f, 15.f)) : 0.f;
-            dv[0] = ds * e + ((o[0] - 1.f) < 15.f ? dsd * e * od[0] : 0.f);
+            const float e = sel ? dact_density(o[0], ak.dn) : 0.f;                 // (default: exp(min(o0 - 1, 15)))
+            dv[0] = ds * e + dsd * d2act_density(o[0], e, ak.dn) * od[0];
             dvd[0] = dsd * e;
         }
         {
@@ -481,6 +488,7 @@ struct BwdJBArgs {
     const float *params, *feat, *featd, *d_base, *d_based;
     int64_t n;
     float *dfeat, *dfeatd, *slab;
+    int act_code;                                  // activation alternatives (ren_mlp_common.h); 0 = shipped configs
 };
 
 __global__ __launch_bounds__(256, 1) void mlp_bwd_jvp_base_kernel(BwdJBArgs a) {
@@ -493,6 +501,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_jvp_base_kernel(BwdJBArgs a) {
     for (int k = lane; k < 32 * 33; k += 64) T_b[k] = 0.f;
     __syncthreads();
     const int64_t n_blk = (a.n + 31) >> 5;
+    const ActKinds ak = act_kinds(a.act_code);
     f32x16 acc_w2[2], acc_w1[2];
     float acc_b2 = 0.f, acc_b1[2] = {0.f, 0.f};
 #pragma unroll
@@ -528,8 +537,8 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_jvp_base_kernel(BwdJBArgs a) {
         for (int r = 0; r < 2; ++r)
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
-                h[r][g] = softplus100(h[r][g]);
-                hd[r][g] = dsoftplus_from_out(h[r][g], 100.f) * z0d[r][g];
+                h[r][g] = act_hidden(h[r][g], ak.bh);
+                hd[r][g] = dact_hidden(h[r][g], ak.bh) * z0d[r][g];
             }
         // ---- dW(base.wo) += dO h^T + dOd hd^T   (rows 16..31 of T_b stay zero)
         stage64(T_a, h, hi, sl);
@@ -566,9 +575,9 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_jvp_base_kernel(BwdJBArgs a) {
         for (int r = 0; r < 2; ++r)
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
-                const float s0 = dsoftplus_from_out(h[r][g], 100.f);
+                const float s0 = dact_hidden(h[r][g], ak.bh);
                 const float dh = dz[r][g], dhd = dzd[r][g];
-                dz[r][g] = dh * s0 + dhd * z0d[r][g] * d2softplus_from_s(s0, 100.f);
+                dz[r][g] = dh * s0 + dhd * z0d[r][g] * d2act_hidden(s0, ak.bh);
                 dzd[r][g] = dhd * s0;
             }
         // ---- dW(base.w0) += dz0 x^T + dz0d xd^T
@@ -646,6 +655,7 @@ extern "C" int ren_mlp_fwd_jvp(const float *mlp_params, int32_t C, const float *
     a.src = RaySrc{rays_o, rays_d, rays_dd, ray_indices, t_starts, t_ends};
     a.sc = ren_make_scene(scene);
     a.n = n; a.rgb = rgb; a.rgbd = rgbd; a.sigma = sigma; a.sigmad = sigmad; a.base_out = base_out; a.base_outd = base_outd;
+    a.act_code = ren_knob(REN_KNOB_ACTIVATIONS);
     int64_t blocks = ((n + 31) / 32 + 3) / 4;
     if (blocks > 768) blocks = 768;
     hipStream_t st = (hipStream_t)stream;
@@ -686,16 +696,19 @@ extern "C" int ren_mlp_bwd_jvp(const float *mlp_params, int32_t C, const float *
     BwdJ2Args a2;
     a2.params = mlp_params; a2.base_out = base_out; a2.base_outd = base_outd; a2.src = src; a2.sc = sc; a2.n = n;
     a2.rgb = rgb; a2.d_rgb = d_rgb; a2.d_rgbd = d_rgbd; a2.dz1 = dz1; a2.dz1d = dz1d; a2.slab = slab2;
+    a2.act_code = ren_knob(REN_KNOB_ACTIVATIONS);
     if (C == 1) hipLaunchKernelGGL((mlp_bwd_jvp_head2_kernel<1>), dim3(GRID_J), dim3(256), J2_LDS, st, a2);
     else        hipLaunchKernelGGL((mlp_bwd_jvp_head2_kernel<3>), dim3(GRID_J), dim3(256), J2_LDS, st, a2);
     BwdJ1Args a1;
     a1.params = mlp_params; a1.base_out = base_out; a1.base_outd = base_outd; a1.dz1 = dz1; a1.dz1d = dz1d;
     a1.src = src; a1.sc = sc; a1.n = n; a1.d_sigma = d_sigma; a1.d_sigmad = d_sigmad; a1.d_base = d_base;
     a1.d_based = d_based; a1.slab = slab1;
+    a1.act_code = ren_knob(REN_KNOB_ACTIVATIONS);
     hipLaunchKernelGGL(mlp_bwd_jvp_head1_kernel, dim3(GRID_J1), dim3(256), J1_LDS, st, a1);
     BwdJBArgs ab;
     ab.params = mlp_params; ab.feat = feat; ab.featd = featd; ab.d_base = d_base; ab.d_based = d_based; ab.n = n;
     ab.dfeat = dfeat; ab.dfeatd = dfeatd; ab.slab = slabb;
+    ab.act_code = ren_knob(REN_KNOB_ACTIVATIONS);
     hipLaunchKernelGGL(mlp_bwd_jvp_base_kernel, dim3(GRID_J), dim3(256), JB_LDS, st, ab);
     launch_reduce_slabs(slab2, GRID_J * 4, len_h2(C), grad_mlp_params + P_HW1, st);
     launch_reduce_slabs(slab1, GRID_J1 * 4, LEN_H1, grad_mlp_params + P_HW0, st);

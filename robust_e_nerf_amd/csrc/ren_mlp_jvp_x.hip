@@ -816,6 +816,7 @@ extern "C" int ren_mlp_fwd_jvp_x(const float *mlp_params, int32_t C, int32_t mod
         return REN_ERR_BAD_ARG;
     if (C != 1 && C != 3) return REN_ERR_UNSUPPORTED;
     if (mode != 1 && mode != 6) return REN_ERR_UNSUPPORTED;
+    if (ren_knob(REN_KNOB_ACTIVATIONS) != 0) return REN_ERR_UNSUPPORTED;      // activation alternatives: exact-f32 kernels only
     if (n == 0) return REN_OK;
     FwdJXArgs a;
     a.params = mlp_params; a.feat = feat; a.featd = featd;
@@ -844,6 +845,7 @@ extern "C" int ren_mlp_bwd_jvp_x(const float *mlp_params, int32_t C, int32_t mod
         return REN_ERR_BAD_ARG;
     if (C != 1 && C != 3) return REN_ERR_UNSUPPORTED;
     if (mode != 1 && mode != 6) return REN_ERR_UNSUPPORTED;
+    if (ren_knob(REN_KNOB_ACTIVATIONS) != 0) return REN_ERR_UNSUPPORTED;      // activation alternatives: exact-f32 kernels only
     if (n == 0) return REN_OK;
     const int64_t n_blk = (n + 31) / 32;
     // scratch (floats): dz1 | dz1d (2048 per block each) | d_base | d_based (512 per block each)

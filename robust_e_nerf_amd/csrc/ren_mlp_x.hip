@@ -240,6 +240,7 @@ extern "C" int ren_mlp_fwd_x(const float *mlp_params, int32_t C, int32_t mode, c
     if (!mlp_params || !feat || !scene || !sigma || n < 0) return REN_ERR_BAD_ARG;
     if (C != 1 && C != 3) return REN_ERR_UNSUPPORTED;
     if (mode != 1 && mode != 6) return REN_ERR_UNSUPPORTED;
+    if (ren_knob(REN_KNOB_ACTIVATIONS) != 0) return REN_ERR_UNSUPPORTED;      // activation alternatives: exact-f32 kernels only
     const bool density_only = (flags & REN_MLP_DENSITY_ONLY) != 0, share = (flags & REN_MLP_SHARE_CU) != 0;
     if (flags & ~(REN_MLP_DENSITY_ONLY | REN_MLP_SHARE_CU)) return REN_ERR_BAD_ARG;
     if (!density_only && !rgb) return REN_ERR_BAD_ARG;
@@ -839,6 +840,7 @@ extern "C" int ren_mlp_bwd_x(const float *mlp_params, int32_t C, int32_t mode, c
         return REN_ERR_BAD_ARG;
     if (C != 1 && C != 3) return REN_ERR_UNSUPPORTED;
     if (mode != 1 && mode != 6) return REN_ERR_UNSUPPORTED;
+    if (ren_knob(REN_KNOB_ACTIVATIONS) != 0) return REN_ERR_UNSUPPORTED;      // activation alternatives: exact-f32 kernels only
     if (!x_world && (!rays_o || !rays_d || !ray_indices || !t_starts || !t_ends)) return REN_ERR_BAD_ARG;
     if (n == 0) return REN_OK;
     const int head_len = p_total(C) - P_BASE_N;

@@ -56,6 +56,12 @@ class RenderCfg:
     dp_split_level: int = 8            # levels >= this one go first (8 x 4 MiB of the 50 MB buffer)
     dp_compress: Optional[str] = None  # "bf16": parameter gradients cross the links as bfloat16 (strong scaling), aux block stays fp32
     mlp_bf16: bool = False             # BASELINE configs[2]: bf16 MLP (rounded linear inputs/weights, fp32 accumulate), fp32 composite
+    # activation alternatives of the YAML (model.nerf.ngp.mlp_base / mlp_head: models/nerf.py:8-29).  Anything but the
+    # shipped values runs on the exact-f32 MLP kernels (mlp_kernels is switched to "f32"): arch ngp only
+    base_hidden_activation: str = "softplus"          # softplus (beta 100) | relu
+    density_activation: str = "shifted_trunc_exp"     # shifted_trunc_exp | softplus | shifted_softplus
+    head_hidden_activation: str = "softplus"          # softplus (beta 100) | relu
+    radiance_activation: str = "softplus"             # softplus | sigmoid
 
 
 class NGPField:
@@ -129,6 +135,18 @@ class Renderer:
         self._fwd_streams = None
         self._bwd_stream = None
         self._reuse_prepass_feat = True             # the differentiable pass reuses the pre-pass hash features
+        self._act_code = ops.activation_code(cfg.base_hidden_activation, cfg.density_activation, cfg.head_hidden_activation,
+                                             cfg.radiance_activation)
+        if self._act_code != 0:
+            if not isinstance(fld, NGPField):
+                raise NotImplementedError("activation alternatives are implemented for arch ngp (the exact-f32 fused MLP kernels)")
+            cfg.mlp_kernels = "f32"                 # the bf16-matrix-core kernels implement the shipped activations only
+        self._apply_acts()
+
+    def _apply_acts(self):
+        """the activation set is process-wide kernel configuration (REN_KNOB_ACTIVATIONS): (re)select this renderer's before
+        it launches, so that two renderers with different sets can live in one process"""
+        ops.set_activations(self._act_code)
 
     # ---- sampling (K1-K3): ray/AABB, two-pass march, no-grad density pre-pass + visibility --------
     def sample_begin(self, o, d, jitter: Optional[torch.Tensor], training: bool) -> dict:
@@ -160,6 +178,7 @@ class Renderer:
     def sample(self, o, d, jitter: Optional[torch.Tensor], training: bool, keep_feat: bool = False,
                begun: Optional[dict] = None) -> Packed:
         c = self.cfg
+        self._apply_acts()
         st = begun if begun is not None else self.sample_begin(o, d, jitter, training)
         args, cache, counts, offsets, mode = st["args"], st["cache"], st["counts"], st["offsets"], st["mode"]
         # host sync, as in the reference (external/utils.py:106-119); `begun["n0"]`: already read back (Trainer.prefetch)
@@ -386,6 +405,7 @@ class Renderer:
     def forward(self, o, d, jitter=None, bkgd: Optional[torch.Tensor] = None, training: bool = True,
                 save: bool = True, begun: Optional[dict] = None):
         f = self.field
+        self._apply_acts()
         pk = self.sample(o, d, jitter, training, keep_feat=True, begun=begun)
         n_rays = o.shape[0]
         if pk.n == 0:
@@ -406,6 +426,7 @@ class Renderer:
         per_ray_bkgd: return the (R, C) per-ray background gradient instead of its column sums (Trainer folds the sum
         into ren_bkgd_param_grad)"""
         f = self.field
+        self._apply_acts()
         if ctx["empty"]:
             # a rank without a single sample must still issue the collectives its peers issue (the slice is final here:
             # this pass adds nothing to it) -- otherwise the ranks' all-reduce sequences differ and RCCL hangs
@@ -427,6 +448,7 @@ class Renderer:
     def query_density(self, x_world: torch.Tensor) -> torch.Tensor:
         """NGPradianceField.query_density(x) (ngp.py:230-254) for arbitrary world points."""
         f = self.field
+        self._apply_acts()
         n = x_world.shape[0]
         xu = contract_points(x_world, self.cfg.aabb, self.cfg.contraction_type)
         feat = ops.hashgrid_fwd(f.grid, f.table, x_unit=xu, n=n, layout=1)

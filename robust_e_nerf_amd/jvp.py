@@ -57,6 +57,7 @@ def render_forward2(r, o, d, od, dd, ddd, pk, bkgd):
     """Second-order forward render over an EXISTING sample stream `pk` (sample placement is not
     differentiated): -> colors, d colors/dt, d2 colors/dt2, each (R, C).  Forward only."""
     f, lib = r.field, _lib.load()
+    r._apply_acts()
     n, R, dev = pk.n, o.shape[0], o.device
     if n == 0:
         z = torch.zeros(R, f.C, device=dev)
@@ -96,6 +97,7 @@ def render_forward2(r, o, d, od, dd, ddd, pk, bkgd):
 def render_forward(r, o, d, od, dd, jitter, bkgd, training: bool = True):
     """-> colors (R,C), colords (R,C) [d/dt], opacity (R,), ctx."""
     f, lib = r.field, _lib.load()
+    r._apply_acts()
     pk = r.sample(o, d, jitter, training)
     n, R, dev = pk.n, o.shape[0], o.device
     if n == 0:
@@ -146,6 +148,7 @@ def render_forward(r, o, d, od, dd, jitter, bkgd, training: bool = True):
 def render_backward(r, ctx, g_colors, g_colords, final: bool = False):
     """Accumulates into r.field.grad; returns d(bkgd) (C,) or None.  final: last backward pass of the step."""
     f, lib = r.field, _lib.load()
+    r._apply_acts()
     if ctx["empty"]:
         if final and r.dp_early_slice() is not None:         # same collective sequence on every rank (Renderer.backward)
             r.dp_early()

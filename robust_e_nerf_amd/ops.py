@@ -19,7 +19,7 @@ BASE_FLOATS_PER_BLOCK = 8 * 64           # saved base-MLP outputs, per 32 sample
 _DT = {torch.float32: 4, torch.float64: 8, torch.int32: 4, torch.int64: 8, torch.uint8: 1, torch.bool: 1}
 
 
-KNOBS = {"hgb_no_pairs": 0, "hgb_halve_regions": 1, "march_sequential": 2, "hg_variant": 3, "vfield_plain": 4, "hgb_subregion": 5, "mlp_bwd_cus": 6}     # include/ren_amd.h REN_KNOB_*
+KNOBS = {"hgb_no_pairs": 0, "hgb_halve_regions": 1, "march_sequential": 2, "hg_variant": 3, "vfield_plain": 4, "hgb_subregion": 5, "mlp_bwd_cus": 6, "activations": 7}     # include/ren_amd.h REN_KNOB_*
 
 
 class knob:
@@ -35,6 +35,27 @@ class knob:
 
     def __exit__(self, *a):
         _lib.load().ren_set_knob(self.k, self.old)
+
+
+# Activation alternatives of the YAML (robust_e_nerf/models/nerf.py:8-29) -> code of REN_KNOB_ACTIVATIONS (include/ren_amd.h)
+HIDDEN_ACTS = {"softplus": 0, "relu": 1}
+DENSITY_ACTS = {"shifted_trunc_exp": 0, "softplus": 1, "shifted_softplus": 2}
+RADIANCE_ACTS = {"softplus": 0, "sigmoid": 1}
+
+
+def activation_code(base_hidden="softplus", density="shifted_trunc_exp", head_hidden="softplus", radiance="softplus") -> int:
+    """0 = the shipped configs; unknown names raise NotImplementedError as the reference's table lookups would KeyError"""
+    try:
+        return (HIDDEN_ACTS[base_hidden] | DENSITY_ACTS[density] << 2 | HIDDEN_ACTS[head_hidden] << 4 |
+                RADIANCE_ACTS[radiance] << 6)
+    except KeyError as e:
+        raise NotImplementedError(f"activation {e.args[0]!r} (models/nerf.py:17-29)") from e
+
+
+def set_activations(code: int):
+    """select the activation set of the exact-f32 MLP kernels (process-wide model configuration; the bf16-matrix-core
+    kernels implement code 0 only and refuse anything else)"""
+    check(_lib.load().ren_set_knob(KNOBS["activations"], int(code)), "ren_set_knob(activations)")
 
 
 def _ptr(t: Optional[torch.Tensor], dtype=None):

@@ -76,6 +76,8 @@ def main():
                             mlp_bf16=cfg.get("float32_matmul_precision", "highest") == "medium")
     arch = ncfg.get("arch", "ngp")
     cli.check_supported(ncfg, arch)
+    for k_, v_ in cli.activation_fields(ncfg, arch).items():
+        setattr(rcfg, k_, v_)
     sd = torch.load(args.ckpt, map_location="cpu", weights_only=False)["state_dict"]
     C = int(sd[cli.PREFIX + ("mlp.rgb_layer.output_layer.bias" if arch == "mlp" else cli.NGP_KEYS["head.bo"])].numel())
     if arch == "mlp":

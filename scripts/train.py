@@ -72,6 +72,25 @@ SUPPORTED = {  # what the fused kernels implement = what every shipped configs/t
 }
 
 
+# arch ngp: the activation alternatives of the YAML (models/nerf.py:8-29) run on the exact-f32 fused MLP kernels
+NGP_ACTIVATIONS = {("mlp_base", "hidden_activation"): ("softplus", "relu"),
+                   ("mlp_base", "density_activation"): ("shifted_trunc_exp", "softplus", "shifted_softplus"),
+                   ("mlp_head", "hidden_activation"): ("softplus", "relu"),
+                   ("mlp_head", "radiance_activation"): ("softplus", "sigmoid")}
+
+
+def activation_fields(ncfg, arch) -> dict:
+    """RenderCfg fields for model.nerf.ngp.mlp_base / mlp_head activations (absent keys: the shipped values)"""
+    if arch != "ngp":
+        return {}
+    g = ncfg.get("ngp") or {}
+    b, h = g.get("mlp_base") or {}, g.get("mlp_head") or {}
+    return dict(base_hidden_activation=b.get("hidden_activation", "softplus"),
+                density_activation=b.get("density_activation", "shifted_trunc_exp"),
+                head_hidden_activation=h.get("hidden_activation", "softplus"),
+                radiance_activation=h.get("radiance_activation", "softplus"))
+
+
 def check_supported(ncfg, arch):
     """Fail loudly on hyper-parameters the HIP kernels do not implement (no silent fallback)."""
     def walk(want, got, path):
@@ -80,6 +99,10 @@ def check_supported(ncfg, arch):
                 continue                                        # absent key = the reference default = supported value
             if isinstance(v, dict):
                 walk(v, got[k] or {}, path + [k])
+            elif arch == "ngp" and tuple(path[1:] + [k]) in NGP_ACTIVATIONS:
+                if got[k] not in NGP_ACTIVATIONS[tuple(path[1:] + [k])]:
+                    raise NotImplementedError(f"model.nerf.{'.'.join(path + [k])} = {got[k]!r}: one of "
+                                              f"{NGP_ACTIVATIONS[tuple(path[1:] + [k])]} (models/nerf.py:17-29)")
             elif got[k] != v:
                 raise NotImplementedError(f"model.nerf.{'.'.join(path + [k])} = {got[k]!r}: the MI355X kernels implement {v!r} only")
     walk(SUPPORTED[arch], ncfg.get(arch) or {}, [arch])
@@ -169,6 +192,8 @@ def main():
                             mlp_bf16=mlp_bf16)
     arch = ncfg.get("arch", "ngp")
     check_supported(ncfg, arch)
+    for k_, v_ in activation_fields(ncfg, arch).items():
+        setattr(rcfg, k_, v_)
     gen = torch.Generator().manual_seed(seed)
 
     def lin(o, i):                                           # nn.Linear default init (hidden_init=None, ngp.py:179-185)

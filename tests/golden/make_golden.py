@@ -331,6 +331,54 @@ def gen_field(ngp, nerfacc):
              g_table_idx=pick, g_table_val=gt[pick], **field_params_np(rf), **grads)
 
 
+def gen_field_acts(ngp, nerf_mod, nerfacc):
+    """Reference NGPradianceField with the YAML's activation ALTERNATIVES, taken from the reference's own tables
+    (models/nerf.py:17-29 NeRF.HIDDEN / DENSITY / RADIANCE_ACTIVATION_NAME_TO_FN): forward + first derivatives for two
+    combinations that together use every alternative (relu; softplus and shifted_softplus densities; sigmoid)."""
+    N = nerf_mod.NeRF
+    aabb = [-1.5] * 3 + [1.5] * 3
+    combos = {"a": dict(base_hidden="relu", density="softplus", head_hidden="relu", radiance="sigmoid"),
+              "b": dict(base_hidden="softplus", density="shifted_softplus", head_hidden="relu", radiance="softplus")}
+    out = {"combos": np.array(__import__("json").dumps(combos)), "aabb": np.array(aabb, np.float32),
+           "table_seed": np.array(TABLE_SEED), "table_scale": np.array(TABLE_SCALE)}
+    for tag, c in combos.items():
+        torch.manual_seed(21)
+        base = EasyDict(NGP_CFG["mlp_base"])
+        base.hidden_activation = N.HIDDEN_ACTIVATION_NAME_TO_FN[c["base_hidden"]]
+        base.density_activation = N.DENSITY_ACTIVATION_NAME_TO_FN[c["density"]]
+        head = EasyDict(NGP_CFG["mlp_head"])
+        head.hidden_activation = N.HIDDEN_ACTIVATION_NAME_TO_FN[c["head_hidden"]]
+        head.radiance_activation = N.RADIANCE_ACTIVATION_NAME_TO_FN[c["radiance"]]
+        head.output_dim = 1
+        rf = ngp.NGPradianceField(aabb=aabb, num_dim=3, use_viewdirs=True, contraction_type=nerfacc.ContractionType.AABB,
+                                  pos_encoding_config=NGP_CFG["pos_encoding"], dir_encoding_config=NGP_CFG["dir_encoding"],
+                                  mlp_base_config=base, mlp_head_config=head)
+        n = 384
+        x = (torch.rand(n, 3) - 0.5) * 1.2 * 3.0
+        d = torch.randn(n, 3)
+        d = d / d.norm(dim=-1, keepdim=True)
+        rgb, sigma = rf(x, d)
+        g_rgb, g_sig = torch.randn_like(rgb), torch.randn_like(sigma)
+        rf.zero_grad()
+        ((rgb * g_rgb).sum() + (sigma * g_sig).sum()).backward()
+        sd = dict(rf.named_parameters())
+        grads = {f"{tag}.g." + k: sd[v].grad for k, v in {
+            "base.w0": "mlp_base.1.hidden_layers.0.weight", "base.b0": "mlp_base.1.hidden_layers.0.bias",
+            "base.wo": "mlp_base.1.output_layer.weight", "base.bo": "mlp_base.1.output_layer.bias",
+            "head.w0": "mlp_head.hidden_layers.0.weight", "head.b0": "mlp_head.hidden_layers.0.bias",
+            "head.w1": "mlp_head.hidden_layers.1.weight", "head.b1": "mlp_head.hidden_layers.1.bias",
+            "head.wo": "mlp_head.output_layer.weight", "head.bo": "mlp_head.output_layer.bias"}.items()}
+        gt = sd["mlp_base.0.params"].grad
+        nz = torch.nonzero(gt)[:, 0]
+        pick = nz[torch.linspace(0, len(nz) - 1, 256).long()]
+        out.update({f"{tag}.x": x, f"{tag}.d": d, f"{tag}.rgb": rgb, f"{tag}.sigma": sigma, f"{tag}.g_rgb": g_rgb, f"{tag}.g_sigma": g_sig,
+                    f"{tag}.g_table_abs": gt.double().abs().sum(), f"{tag}.g_table_idx": pick, f"{tag}.g_table_val": gt[pick]})
+        out.update({f"{tag}." + k: v for k, v in field_params_np(rf).items()})
+        out.update(grads)
+        print(f"field_acts {tag}: {c}  rgb [{float(rgb.min()):.3f}, {float(rgb.max()):.3f}]  sigma max {float(sigma.max()):.3f}")
+    save("field_acts", **out)
+
+
 def gen_field_mlp(mlp_mod, ngp, nerfacc):
     """Reference VanillaNeRFRadianceField (`arch: mlp`) forward + parameter gradients.  The 593 k parameters
     are regenerated from a seed (oracle.vanilla.init_params) instead of being stored."""
@@ -867,6 +915,8 @@ def main():
 
     if sys.argv[1:] == ["eval_epoch"]:                 # regenerate one fixture only
         return gen_eval_epoch(rmod)
+    if sys.argv[1:] == ["field_acts"]:
+        return gen_field_acts(ngp, nerf_mod, nerfacc)
     if sys.argv[1:] == ["eval_dataset"]:
         from robust_e_nerf.data import datasets as datasets_mod
         return gen_eval_dataset(datasets_mod)
@@ -875,6 +925,7 @@ def main():
     gen_trajectory(trajectories, nerf_mod)
     gen_events(egp, loss_mod)
     gen_field(ngp, nerfacc)
+    gen_field_acts(ngp, nerf_mod, nerfacc)
     from robust_e_nerf.external import mlp as mlp_mod
     gen_field_mlp(mlp_mod, ngp, nerfacc)
     mods = (rmod, nerf_mod, trajectories, egp, loss_mod, nerfacc)

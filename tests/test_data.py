@@ -121,7 +121,18 @@ def test_cli_rejects_unsupported_hyperparameters():
                    "mlp_head": {"hidden_activation": "softplus", "radiance_activation": "softplus", "n_neurons": 64,
                                 "n_hidden_layers": 2, "weight_norm": False}}
     cli.check_supported(ncfg, "ngp")
-    for path, bad in ((("mlp_head", "radiance_activation"), "sigmoid"), (("mlp_base", "hidden_activation"), "relu"),
+    # the activation alternatives of models/nerf.py:8-29 are accepted for arch ngp since round 4 (exact-f32 MLP kernels) ...
+    for path, ok in ((("mlp_head", "radiance_activation"), "sigmoid"), (("mlp_base", "hidden_activation"), "relu"),
+                     (("mlp_head", "hidden_activation"), "relu"), (("mlp_base", "density_activation"), "shifted_softplus"),
+                     (("mlp_base", "density_activation"), "softplus")):
+        c = copy.deepcopy(ncfg)
+        c["ngp"][path[0]][path[1]] = ok
+        cli.check_supported(c, "ngp")
+        key = {("mlp_head", "radiance_activation"): "radiance_activation", ("mlp_base", "hidden_activation"): "base_hidden_activation",
+               ("mlp_head", "hidden_activation"): "head_hidden_activation", ("mlp_base", "density_activation"): "density_activation"}[path]
+        assert cli.activation_fields(c, "ngp")[key] == ok
+    # ... names outside the reference's tables, and everything else the kernels do not implement, are not
+    for path, bad in ((("mlp_head", "radiance_activation"), "tanh"), (("mlp_base", "hidden_activation"), "gelu"),
                       (("mlp_base", "weight_norm"), True), (("pos_encoding", "interpolation"), "Smoothstep"),
                       (("pos_encoding", "otype"), "DenseGrid")):
         c = copy.deepcopy(ncfg)

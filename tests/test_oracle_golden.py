@@ -245,3 +245,23 @@ def test_vanilla_field_forward_backward(ct):
         gr = v.grad.reshape(-1)
         assert rel_err(gr[t(g["gi." + k])], g["gv." + k]) < 1e-5, k
         assert abs(float(gr.double().abs().sum()) - float(g["gs." + k])) < 1e-5 * float(g["gs." + k]) + 1e-12, k
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_field_activation_alternatives(tag, full_table_cache):
+    """The YAML's activation alternatives (models/nerf.py:8-29: relu hidden layers, softplus / shifted_softplus densities,
+    sigmoid radiance) through the oracle vs the reference's own NGPradianceField built from its own activation tables
+    (fixture field_acts.npz): forward and every parameter gradient."""
+    import json
+    g = load_golden("field_acts")
+    acts = json.loads(str(g["combos"]))[tag]
+    table = full_table_cache(g["table_seed"], g["table_scale"]).clone().requires_grad_()
+    p = {k: t(g[f"{tag}.{k}"]).requires_grad_() for k in FIELD_KEYS}
+    p["hash"] = table
+    rgb, sigma = field.field_forward(t(g[f"{tag}.x"]), t(g[f"{tag}.d"]), p, SPEC, t(g["aabb"]), 0, acts=acts)
+    assert rel_err(rgb, g[f"{tag}.rgb"]) < 1e-5 and rel_err(sigma, g[f"{tag}.sigma"]) < 1e-5
+    ((rgb * t(g[f"{tag}.g_rgb"])).sum() + (sigma * t(g[f"{tag}.g_sigma"])).sum()).backward()
+    for k in FIELD_KEYS:
+        assert rel_err(p[k].grad, g[f"{tag}.g.{k}"]) < 1e-4, k
+    assert rel_err(table.grad[t(g[f"{tag}.g_table_idx"])], g[f"{tag}.g_table_val"]) < 1e-4
+    assert abs(float(table.grad.double().abs().sum()) - float(g[f"{tag}.g_table_abs"])) < 1e-4 * float(g[f"{tag}.g_table_abs"])
