@@ -10,10 +10,13 @@ restatement of its published algorithm (``include/tiny-cuda-nn/encodings/grid.h`
 
   level l:  scale_l = exp2f(l * log2f(per_level_scale)) * base_resolution - 1      (float32)
             res_l   = ceilf(scale_l) + 1
-            size_l  = min(next_multiple(res_l^3, 8), 2^log2_hashmap_size)
+            size_l  = next_multiple(res_l^3, 8), then by grid type (``otype``, configs/train/synthetic.yaml:63):
+                      HashGrid  min(size_l, 2^log2_hashmap_size);  DenseGrid  as it is;  TiledGrid  min(size_l, base_resolution^3)
   sample :  pos = fmaf(scale_l, x, 0.5); cell = floorf(pos); w = pos - cell
-            corner index: dense (x fastest) when res_l^3 <= size_l, else
-            (cx*1) ^ (cy*2654435761) ^ (cz*805459861) in uint32; finally ``% size_l``
+            corner index (``grid_index``): index = 0, stride = 1; for each dimension WHILE stride <= size_l:
+            index += cell_d * stride, stride *= res_l  (x fastest; a dimension whose stride exceeds the level size is
+            dropped -- a tiled level with res_l^2 > size_l ignores z); HashGrid with size_l < stride:
+            index = (cx*1) ^ (cy*2654435761) ^ (cz*805459861) in uint32; finally ``% size_l``
             feature = sum_c prod_d (bit_d ? w_d : 1 - w_d) * table[offset_l + idx_c]
   output :  (n, L*F) level-major; params flat level-major -> entry -> feature.
 
@@ -40,6 +43,7 @@ class HashGridSpec:
     log2_hashmap_size: int = 19
     base_resolution: int = 16
     per_level_scale: float = 1.4472692012786865
+    otype: str = "HashGrid"
     # derived
     scales: tuple = ()
     resolutions: tuple = ()
@@ -66,8 +70,10 @@ def make_spec(
     log2_hashmap_size: int = 19,
     base_resolution: int = 16,
     per_level_scale: float = 1.4472692012786865,
+    otype: str = "HashGrid",
 ) -> HashGridSpec:
-    """Level table in float32 arithmetic, as tcnn computes it."""
+    """Level table in float32 arithmetic, as tcnn computes it.  otype: HashGrid | DenseGrid | TiledGrid."""
+    assert otype in ("HashGrid", "DenseGrid", "TiledGrid"), otype
     log2_pls = np.log2(np.float32(per_level_scale)).astype(np.float32)
     scales, ress, sizes, offsets, hashed = [], [], [], [], []
     offset = 0
@@ -79,15 +85,18 @@ def make_spec(
         res = int(np.ceil(scale)) + 1
         dense = res ** 3
         size = (min(dense, 2 ** 31 - 1) + 7) // 8 * 8
-        size = min(size, 1 << log2_hashmap_size)
+        if otype == "HashGrid":
+            size = min(size, 1 << log2_hashmap_size)
+        elif otype == "TiledGrid":
+            size = min(size, base_resolution ** 3)
         scales.append(float(scale))
         ress.append(res)
         sizes.append(size)
         offsets.append(offset)
-        hashed.append(dense > size)
+        hashed.append(otype == "HashGrid" and dense > size)
         offset += size
     return HashGridSpec(
-        n_levels, n_features_per_level, log2_hashmap_size, base_resolution, per_level_scale,
+        n_levels, n_features_per_level, log2_hashmap_size, base_resolution, per_level_scale, otype,
         tuple(scales), tuple(ress), tuple(sizes), tuple(offsets), tuple(hashed),
     )
 
@@ -100,7 +109,12 @@ def _corner_index(cx, cy, cz, res: int, size: int, is_hashed: bool):
     if is_hashed:
         idx = cx ^ ((cy * PRIME_Y) & MASK32) ^ ((cz * PRIME_Z) & MASK32)
     else:
-        idx = (cx + ((cy * res) & MASK32) + ((cz * res * res) & MASK32)) & MASK32
+        idx, stride = cx, res                                    # stride 1 <= size always
+        if stride <= size:
+            idx = (idx + ((cy * stride) & MASK32)) & MASK32
+            stride = stride * res
+            if stride <= size:
+                idx = (idx + ((cz * stride) & MASK32)) & MASK32
     return idx % size
 
 

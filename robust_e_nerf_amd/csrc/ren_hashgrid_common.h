@@ -10,13 +10,20 @@ struct GridDev {
     uint32_t res[REN_MAX_LEVELS], size[REN_MAX_LEVELS], offset[REN_MAX_LEVELS], hashed[REN_MAX_LEVELS];
 };
 
+// tcnn grid_index(): index += cell_d * stride for each dimension WHILE stride <= level size (stride *= res after each).  A
+// HashGrid level that is not hashed has res^3 <= size, so both strides are there; a TiledGrid level (size = base_resolution^3
+// < res^3) wraps, and drops z once res^2 > size (and y once res > size).  res <= 65 535: res * res fits 32 bits.
+__device__ __forceinline__ uint32_t dense_stride_y(uint32_t res, uint32_t size) { return res <= size ? res : 0u; }
+__device__ __forceinline__ uint32_t dense_stride_z(uint32_t res, uint32_t size) { return res * res <= size ? res * res : 0u; }
+
 __device__ __forceinline__ uint32_t corner_index(uint32_t cx, uint32_t cy, uint32_t cz, uint32_t res,
                                                  uint32_t size, bool hashed) {
     if (hashed) {
         uint32_t h = cx ^ (cy * 2654435761u) ^ (cz * 805459861u);
         return h & (size - 1u);                      // hashed levels have power-of-two size
     }
-    uint32_t idx = cx + cy * res + cz * res * res;
+    const uint32_t sy = dense_stride_y(res, size), sz = dense_stride_z(res, size);
+    uint32_t idx = cx + cy * sy + cz * sz;
     if (idx >= size) { idx -= size; if (idx >= size) idx %= size; }
     return idx;
 }
@@ -34,12 +41,12 @@ __device__ __forceinline__ void corner_indices8(uint32_t cx, uint32_t cy, uint32
         idx[4] = (cx ^ hy0 ^ hz1) & m; idx[5] = (x1 ^ hy0 ^ hz1) & m;
         idx[6] = (cx ^ hy1 ^ hz1) & m; idx[7] = (x1 ^ hy1 ^ hz1) & m;
     } else {
-        const uint32_t sy = res, sz = res * res;
+        const uint32_t sy = dense_stride_y(res, size), sz = dense_stride_z(res, size);
         const uint32_t b = cx + cy * sy + cz * sz;
         idx[0] = b; idx[1] = b + 1u; idx[2] = b + sy; idx[3] = b + sy + 1u;
         idx[4] = b + sz; idx[5] = b + sz + 1u; idx[6] = b + sz + sy; idx[7] = b + sz + sy + 1u;
         // idx[] ascends unless it wraps 2^32 (negative cell), and then idx[0] is huge: two tests cover all 8
-        if (idx[0] >= size || idx[7] >= size) {      // only positions outside the unit cube get here
+        if (idx[0] >= size || idx[7] >= size) {      // positions outside the unit cube, and tiled levels (size < res^3)
 #pragma unroll
             for (int c = 0; c < 8; ++c) idx[c] %= size;
         }

@@ -70,7 +70,7 @@ class NGPField:
 
     def __init__(self, device, radiance_dim: int = 1, pos_encoding: Optional[dict] = None):
         pe = dict(n_levels=16, n_features_per_level=2, log2_hashmap_size=19, base_resolution=16,
-                  per_level_scale=1.4472692012786865)
+                  per_level_scale=1.4472692012786865, otype="HashGrid")
         if pos_encoding:
             pe.update({k: v for k, v in pos_encoding.items() if k in pe})
         self.grid, self.n_table = ops.make_grid_desc(**pe)
@@ -141,6 +141,9 @@ class Renderer:
             if not isinstance(fld, NGPField):
                 raise NotImplementedError("activation alternatives are implemented for arch ngp (the exact-f32 fused MLP kernels)")
             cfg.mlp_kernels = "f32"                 # the bf16-matrix-core kernels implement the shipped activations only
+        grid = getattr(fld, "grid", None)
+        if grid is not None and max(grid.size[l] for l in range(grid.n_levels)) > 1 << 19:
+            cfg.binned_scatter = False              # DenseGrid levels beyond 64 bins: the per-update atomic scatter
         self._apply_acts()
 
     def _apply_acts(self):

@@ -83,9 +83,13 @@ NAN = float("nan")
 
 # ------------------------------------------------------------------------------- descriptors
 def make_grid_desc(n_levels=16, n_features_per_level=2, log2_hashmap_size=19, base_resolution=16,
-                   per_level_scale=1.4472692012786865) -> Tuple[GridDesc, int]:
-    """tcnn HashGrid level table (float32 arithmetic) -> (descriptor, number of float params)."""
+                   per_level_scale=1.4472692012786865, otype="HashGrid") -> Tuple[GridDesc, int]:
+    """tcnn grid level table (float32 arithmetic) -> (descriptor, number of float params).  otype (the YAML's
+    pos_encoding.otype, configs/train/synthetic.yaml:63): HashGrid (level size capped at 2^log2_hashmap_size, spatial hash
+    beyond), DenseGrid (no cap, never hashed), TiledGrid (capped at base_resolution^3, the dense index wraps)."""
     import numpy as np
+    if otype not in ("HashGrid", "DenseGrid", "TiledGrid"):
+        raise NotImplementedError(f"pos_encoding.otype={otype}")
     if n_features_per_level != 2:
         raise NotImplementedError("n_features_per_level must be 2")
     if n_levels > _lib.MAX_LEVELS:
@@ -100,12 +104,17 @@ def make_grid_desc(n_levels=16, n_features_per_level=2, log2_hashmap_size=19, ba
         res = int(np.ceil(scale)) + 1
         dense = res ** 3
         size = (min(dense, 2 ** 31 - 1) + 7) // 8 * 8
-        size = min(size, 1 << log2_hashmap_size)
+        if otype == "HashGrid":
+            size = min(size, 1 << log2_hashmap_size)
+        elif otype == "TiledGrid":
+            size = min(size, base_resolution ** 3)
+        if offset + size >= 1 << 32:
+            raise NotImplementedError("grid with more than 2^32 entries")
         g.scale[lvl] = float(scale)
         g.res[lvl] = res
         g.size[lvl] = size
         g.offset[lvl] = offset
-        g.hashed[lvl] = 1 if dense > size else 0
+        g.hashed[lvl] = 1 if (otype == "HashGrid" and dense > size) else 0
         offset += size
     return g, offset * 2
 

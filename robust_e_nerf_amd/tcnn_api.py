@@ -111,8 +111,9 @@ class Encoding(torch.nn.Module):
         super().__init__()
         if n_input_dims != 3:
             raise NotImplementedError("n_input_dims must be 3")
-        if encoding_config.get("otype", "HashGrid") != "HashGrid":
-            raise NotImplementedError(f"otype {encoding_config.get('otype')} (only HashGrid is built)")
+        otype = encoding_config.get("otype", "HashGrid")
+        if otype not in ("HashGrid", "DenseGrid", "TiledGrid"):
+            raise NotImplementedError(f"otype {otype} (HashGrid, DenseGrid, TiledGrid are built)")
         if encoding_config.get("interpolation", "Linear") != "Linear":
             raise NotImplementedError("only Linear interpolation is built")
         if dtype != torch.float32:
@@ -120,7 +121,7 @@ class Encoding(torch.nn.Module):
         self.grid, self.n_params = ops.make_grid_desc(
             encoding_config.get("n_levels", 16), encoding_config.get("n_features_per_level", 2),
             encoding_config.get("log2_hashmap_size", 19), encoding_config.get("base_resolution", 16),
-            encoding_config.get("per_level_scale", 2.0))
+            encoding_config.get("per_level_scale", 2.0), otype)
         self.n_input_dims = 3
         self.unit_scene = ops.make_scene_desc([0.0, 0.0, 0.0, 1.0, 1.0, 1.0], ops.AABB)
         self.n_output_dims = self.grid.n_levels * 2

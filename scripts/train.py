@@ -107,9 +107,11 @@ def check_supported(ncfg, arch):
                 raise NotImplementedError(f"model.nerf.{'.'.join(path + [k])} = {got[k]!r}: the MI355X kernels implement {v!r} only")
     walk(SUPPORTED[arch], ncfg.get(arch) or {}, [arch])
     pe = (ncfg.get("ngp") or {}).get("pos_encoding") or {}
-    if arch == "ngp" and (pe.get("otype", "HashGrid") != "HashGrid" or pe.get("interpolation", "Linear") != "Linear"
+    if arch == "ngp" and (pe.get("otype", "HashGrid") not in ("HashGrid", "DenseGrid", "TiledGrid")
+                          or pe.get("interpolation", "Linear") != "Linear"
                           or pe.get("n_features_per_level", 2) != 2 or pe.get("n_levels", 16) != 16):
-        raise NotImplementedError(f"model.nerf.ngp.pos_encoding {pe}: HashGrid, Linear interpolation, 16 levels x 2 features only")
+        raise NotImplementedError(f"model.nerf.ngp.pos_encoding {pe}: HashGrid / DenseGrid / TiledGrid, Linear interpolation, "
+                                  "16 levels x 2 features only")
 
 
 def main():

@@ -134,11 +134,15 @@ def test_cli_rejects_unsupported_hyperparameters():
     # ... names outside the reference's tables, and everything else the kernels do not implement, are not
     for path, bad in ((("mlp_head", "radiance_activation"), "tanh"), (("mlp_base", "hidden_activation"), "gelu"),
                       (("mlp_base", "weight_norm"), True), (("pos_encoding", "interpolation"), "Smoothstep"),
-                      (("pos_encoding", "otype"), "DenseGrid")):
+                      (("pos_encoding", "otype"), "Frequency")):
         c = copy.deepcopy(ncfg)
         c["ngp"][path[0]][path[1]] = bad
         with pytest.raises(NotImplementedError):
             cli.check_supported(c, "ngp")
+    for otype in ("DenseGrid", "TiledGrid"):                           # the other grid types of tcnn's grid encoding are built
+        c = copy.deepcopy(ncfg)
+        c["ngp"]["pos_encoding"]["otype"] = otype
+        cli.check_supported(c, "ngp")
     ncfg["mlp"] = {"net_depth": 8, "net_width": 256, "skip_layer": 4, "hidden_activation": "softplus"}
     cli.check_supported(ncfg, "mlp")
     ncfg["mlp"]["net_width"] = 128

@@ -265,3 +265,52 @@ def test_field_activation_alternatives(tag, full_table_cache):
         assert rel_err(p[k].grad, g[f"{tag}.g.{k}"]) < 1e-4, k
     assert rel_err(table.grad[t(g[f"{tag}.g_table_idx"])], g[f"{tag}.g_table_val"]) < 1e-4
     assert abs(float(table.grad.double().abs().sum()) - float(g[f"{tag}.g_table_abs"])) < 1e-4 * float(g[f"{tag}.g_table_abs"])
+
+
+@pytest.mark.parametrize("kw", [dict(otype="TiledGrid"), dict(otype="TiledGrid", base_resolution=4),
+                                dict(otype="DenseGrid", per_level_scale=1.1), dict(otype="HashGrid")])
+def test_grid_types_level_table_and_index(kw):
+    """DenseGrid / TiledGrid (configs/train/synthetic.yaml:63): level sizes by tcnn's rule, the host descriptor the kernels take
+    (ops.make_grid_desc) agrees with the oracle's level table, and the vectorised encoder agrees with a literal, per-point
+    transcription of tcnn's grid_index loop (index += cell_d * stride WHILE stride <= level size)."""
+    from robust_e_nerf_amd import ops
+    spec = hashgrid.make_spec(**kw)
+    grid, n_params = ops.make_grid_desc(**kw)
+    assert n_params == spec.n_params
+    for l in range(16):
+        assert (grid.res[l], grid.size[l], grid.offset[l], bool(grid.hashed[l])) == \
+               (spec.resolutions[l], spec.sizes[l], spec.offsets[l], spec.hashed[l])
+        assert abs(grid.scale[l] - spec.scales[l]) == 0.0
+        full = (spec.resolutions[l] ** 3 + 7) // 8 * 8
+        want = {"HashGrid": min(full, 1 << 19), "DenseGrid": full,
+                "TiledGrid": min(full, spec.base_resolution ** 3)}[spec.otype]
+        assert spec.sizes[l] == want
+    if spec.otype != "HashGrid":
+        assert not any(spec.hashed)
+    table = hashgrid.init_table(spec, 3, 0.5, "mix32")
+    gen = torch.Generator().manual_seed(0)
+    x = torch.rand(24, 3, generator=gen)
+    x[0] = torch.tensor([1.0, 1.0, 1.0])
+    got = hashgrid.encode(x, table, spec).numpy()
+    tab = table.numpy().reshape(-1, 2)
+    M = 0xFFFFFFFF
+    for i in range(x.shape[0]):
+        for l in range(16):
+            res, size = spec.resolutions[l], spec.sizes[l]
+            pos = (np.float64(np.float32(spec.scales[l])) * x[i].numpy().astype(np.float64) + 0.5).astype(np.float32)   # fmaf
+            cell = np.floor(pos)
+            w = (pos - cell).astype(np.float32)
+            acc = np.zeros(2, np.float64)
+            for c in range(8):
+                pg = [(int(cell[d]) + ((c >> d) & 1)) & M for d in range(3)]
+                stride, idx = 1, 0
+                for d in range(3):
+                    if stride > size:
+                        break
+                    idx = (idx + pg[d] * stride) & M
+                    stride = (stride * res) & M
+                if spec.otype == "HashGrid" and size < stride:
+                    idx = (pg[0] ^ ((pg[1] * 2654435761) & M) ^ ((pg[2] * 805459861) & M)) & M
+                wc = np.prod([w[d] if (c >> d) & 1 else 1 - w[d] for d in range(3)])
+                acc += wc * tab[spec.offsets[l] + idx % size]
+            assert np.allclose(acc, got[i, 2 * l: 2 * l + 2], rtol=1e-5, atol=1e-6), (i, l)
