@@ -443,6 +443,16 @@ int ren_rate_epilogue(const float *colors, const float *colords, const float *op
  * tau_grad[0] += sum_i (g_a[i] x_a[i] + g_b[i] x_b[i]) dts[i], float64, one launch (g_b, x_b may both be NULL). */
 int ren_tau_pose_grad(const float *g_a, const float *x_a, const float *g_b, const float *x_b, const double *dts,
                       int64_t n, double *tau_grad, void *stream);
+/* torch.nn.utils.weight_norm(module) over the Linear layers of an MLP (external/ngp.py:207-228, external/mlp.py:303-319;
+ * dim 0): W[r, :] = g[r] v[r, :] / ||v[r, :]||.  `raw` is the packed parameter block with v in the weight slots, `eff` the
+ * block the field kernels read; `layers` (HOST memory) lists the reparametrised weights as n_layers x {weight offset, rows,
+ * cols, offset of the layer's first g in `g`} (<= 16 layers); every other element of the block is copied through.
+ * _bwd: d_raw = gradient w.r.t. (v, biases, plain weights) from d_eff = gradient w.r.t. the effective block, d_g[r] =
+ * dW[r, :] . v / ||v||; zero_d_eff != 0 clears d_eff afterwards (the accumulator of the next step).  Two small launches each. */
+int ren_weight_norm_fwd(const float *raw, const float *g, const int32_t *layers, int32_t n_layers, int64_t n_params,
+                        float *eff, void *stream);
+int ren_weight_norm_bwd(const float *raw, const float *g, float *d_eff, const int32_t *layers, int32_t n_layers,
+                        int64_t n_params, float *d_raw, float *d_g, int32_t zero_d_eff, void *stream);
 /* Loss.log_intensity_grad (loss_metric/loss.py:43-57): pred = intensity_dot / intensity vs target;
  * same loss_sum / scale conventions as ren_event_loss_fwd/bwd */
 int ren_grad_loss_fwd(const float *intensity, const float *intensity_dot, const float *target,

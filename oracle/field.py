@@ -204,6 +204,21 @@ PARAM_ORDER = (
 # Activation alternatives of the YAML (models/nerf.py:8-29): hidden {softplus (beta 100), relu}, density {shifted_trunc_exp,
 # softplus (beta 1), shifted_softplus = softplus(x - 1)}, radiance {softplus (beta 1), sigmoid}.  `acts` = dict(base_hidden,
 # density, head_hidden, radiance); absent keys take the shipped configs' values.
+WN_WEIGHTS = ("base.w0", "base.wo", "head.w0", "head.w1", "head.wo")
+
+
+def weight_norm_params(p: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """`weight_norm: true` (ngp.py:207-228: torch.nn.utils.weight_norm on every Linear of the flagged MLP, dim 0): a parameter
+    dict holding "<k>_g" (rows, 1) and "<k>_v" (rows, cols) in place of "<k>" -> the dict the field functions take, with
+    W = g v / ||v||_row (differentiable).  Pinned to the reference by tests/golden/field_wn.npz."""
+    q = {k: v for k, v in p.items() if not (k.endswith("_g") or k.endswith("_v"))}
+    for k in WN_WEIGHTS:
+        if k + "_v" in p:
+            v, g = p[k + "_v"], p[k + "_g"]
+            q[k] = v * (g.reshape(-1, 1) / v.norm(dim=1, keepdim=True))
+    return q
+
+
 DEFAULT_ACTS = dict(base_hidden="softplus", density="shifted_trunc_exp", head_hidden="softplus", radiance="softplus")
 
 

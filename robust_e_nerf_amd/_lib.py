@@ -136,6 +136,8 @@ SIGNATURES = {
     "ren_vanilla_heads_bwd_jvp": (c_int, [P, P, P, P, P, P, P, P, c_int64, c_int32, P, P, P, P, P]),
     "ren_rate_epilogue": (c_int, [P, P, P, P, c_int32, c_int64, c_float, P, P, P, P, P]),
     "ren_tau_pose_grad": (c_int, [P, P, P, P, P, c_int64, P, P]),
+    "ren_weight_norm_fwd": (c_int, [P, P, P, c_int32, c_int64, P, P]),
+    "ren_weight_norm_bwd": (c_int, [P, P, P, P, c_int32, c_int64, P, P, c_int32, P]),
     "ren_grad_loss_fwd": (c_int, [P, P, P, P, c_int64, c_int32, P, P]),
     "ren_grad_loss_bwd": (c_int, [P, P, P, P, c_int64, c_int32, c_float, P, P, P, P]),
 }

@@ -583,3 +583,103 @@ extern "C" int ren_occgrid_binarize(const float *occs, int64_t cells, float occ_
                        cells, occ_thre, scratch, binary);
     REN_CHECK_LAUNCH();
 }
+
+// ---- torch.nn.utils.weight_norm (dim 0) over a packed parameter block (external/ngp.py:207-228, external/mlp.py:303-319) ----
+// W[r, :] = g[r] v[r, :] / ||v[r, :]||.  One wave per weight row; everything that is not a listed weight (biases, layers
+// without the reparametrisation) is copied through.
+namespace {
+
+constexpr int WN_MAX_LAYERS = 16;
+struct WnArgs {
+    int n_layers, n_rows;
+    int w_off[WN_MAX_LAYERS], rows[WN_MAX_LAYERS], cols[WN_MAX_LAYERS], g_off[WN_MAX_LAYERS], row0[WN_MAX_LAYERS];
+};
+
+__device__ __forceinline__ bool wn_row(const WnArgs &a, int row, int &w_off, int &cols, int &g_idx) {
+    if (row >= a.n_rows) return false;
+    int l = 0;
+    while (l + 1 < a.n_layers && row >= a.row0[l + 1]) ++l;
+    const int r = row - a.row0[l];
+    cols = a.cols[l];
+    w_off = a.w_off[l] + r * cols;
+    g_idx = a.g_off[l] + r;
+    return true;
+}
+
+__global__ __launch_bounds__(256) void weight_norm_fwd_kernel(WnArgs a, const float *__restrict__ raw, const float *__restrict__ g,
+                                                              float *__restrict__ eff) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int w_off, cols, g_idx;
+    if (!wn_row(a, row, w_off, cols, g_idx)) return;
+    float ss = 0.f;
+    for (int c = lane; c < cols; c += 64) { const float v = raw[w_off + c]; ss += v * v; }
+    const float s = g[g_idx] / sqrtf(ren_wave_sum(ss));
+    for (int c = lane; c < cols; c += 64) eff[w_off + c] = raw[w_off + c] * s;
+}
+
+// d g[r] = dW[r, :] . v / ||v||;  d v[r, :] = (g / ||v||) (dW[r, :] - d g[r] v / ||v||)
+__global__ __launch_bounds__(256) void weight_norm_bwd_kernel(WnArgs a, const float *__restrict__ raw, const float *__restrict__ g,
+                                                              const float *__restrict__ d_eff, float *__restrict__ d_raw,
+                                                              float *__restrict__ d_g) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int w_off, cols, g_idx;
+    if (!wn_row(a, row, w_off, cols, g_idx)) return;
+    float ss = 0.f, dot = 0.f;
+    for (int c = lane; c < cols; c += 64) {
+        const float v = raw[w_off + c];
+        ss += v * v;
+        dot += v * d_eff[w_off + c];
+    }
+    const float inv = 1.f / sqrtf(ren_wave_sum(ss));
+    const float dg = ren_wave_sum(dot) * inv, s = g[g_idx] * inv;
+    for (int c = lane; c < cols; c += 64) d_raw[w_off + c] = s * (d_eff[w_off + c] - dg * inv * raw[w_off + c]);
+    if (lane == 0) d_g[g_idx] = dg;
+}
+
+int wn_args(const int32_t *layers, int32_t n_layers, int64_t n_params, WnArgs &a) {
+    if (!layers || n_layers < 0 || n_layers > WN_MAX_LAYERS || n_params < 0) return REN_ERR_BAD_ARG;
+    a.n_layers = n_layers;
+    a.n_rows = 0;
+    for (int l = 0; l < n_layers; ++l) {
+        a.w_off[l] = layers[4 * l]; a.rows[l] = layers[4 * l + 1]; a.cols[l] = layers[4 * l + 2]; a.g_off[l] = layers[4 * l + 3];
+        if (a.w_off[l] < 0 || a.rows[l] < 1 || a.cols[l] < 1 || a.g_off[l] < 0 ||
+            (int64_t)a.w_off[l] + (int64_t)a.rows[l] * a.cols[l] > n_params)
+            return REN_ERR_BAD_ARG;
+        a.row0[l] = a.n_rows;
+        a.n_rows += a.rows[l];
+    }
+    return REN_OK;
+}
+
+}  // namespace
+
+extern "C" int ren_weight_norm_fwd(const float *raw, const float *g, const int32_t *layers, int32_t n_layers,
+                                   int64_t n_params, float *eff, void *stream) {
+    WnArgs a;
+    const int rc = wn_args(layers, n_layers, n_params, a);
+    if (rc) return rc;
+    if (!raw || !eff || (n_layers && !g)) return REN_ERR_BAD_ARG;
+    if (n_params == 0) return REN_OK;
+    if (hipMemcpyAsync(eff, raw, n_params * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
+        return REN_ERR_LAUNCH;
+    if (a.n_rows)
+        hipLaunchKernelGGL(weight_norm_fwd_kernel, dim3((a.n_rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, raw, g, eff);
+    REN_CHECK_LAUNCH();
+}
+
+extern "C" int ren_weight_norm_bwd(const float *raw, const float *g, float *d_eff, const int32_t *layers,
+                                   int32_t n_layers, int64_t n_params, float *d_raw, float *d_g, int32_t zero_d_eff,
+                                   void *stream) {
+    WnArgs a;
+    const int rc = wn_args(layers, n_layers, n_params, a);
+    if (rc) return rc;
+    if (!raw || !d_eff || !d_raw || (n_layers && (!g || !d_g))) return REN_ERR_BAD_ARG;
+    if (n_params == 0) return REN_OK;
+    if (hipMemcpyAsync(d_raw, d_eff, n_params * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
+        return REN_ERR_LAUNCH;
+    if (a.n_rows)
+        hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3((a.n_rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, raw, g, d_eff,
+                           d_raw, d_g);
+    if (zero_d_eff && hipMemsetAsync(d_eff, 0, n_params * sizeof(float), (hipStream_t)stream) != hipSuccess) return REN_ERR_LAUNCH;
+    REN_CHECK_LAUNCH();
+}

@@ -65,10 +65,18 @@ class RenderCfg:
 
 
 class NGPField:
-    """Device-resident Instant-NGP parameters: one flat float32 buffer [hash table | MLP block]
-    plus an identically shaped gradient buffer (robust_e_nerf/external/ngp.py:166-205)."""
+    """Device-resident Instant-NGP parameters: one flat float32 buffer [hash table | MLP block (| weight-norm g)]
+    plus an identically shaped gradient buffer (robust_e_nerf/external/ngp.py:166-205).
 
-    def __init__(self, device, radiance_dim: int = 1, pos_encoding: Optional[dict] = None):
+    weight_norm = (mlp_base, mlp_head) (ngp.py:207-228: torch.nn.utils.weight_norm on every Linear of a flagged MLP): the
+    trainable block then holds v in the weight slots and the g of every flagged row behind it; `mlp` / `g_mlp` -- what the
+    field kernels read and accumulate into -- become separate buffers with the effective weights W = g v / ||v|| and their
+    gradient, kept in step by refresh() (after every parameter change) and fold_grads() (before the optimiser)."""
+
+    WN_WEIGHTS = ("base.w0", "base.wo", "head.w0", "head.w1", "head.wo")
+
+    def __init__(self, device, radiance_dim: int = 1, pos_encoding: Optional[dict] = None,
+                 weight_norm: Tuple[bool, bool] = (False, False)):
         pe = dict(n_levels=16, n_features_per_level=2, log2_hashmap_size=19, base_resolution=16,
                   per_level_scale=1.4472692012786865, otype="HashGrid")
         if pos_encoding:
@@ -78,7 +86,17 @@ class NGPField:
             raise NotImplementedError("the fused MLP kernels are built for 16 levels x 2 features")
         self.C = radiance_dim
         self.n_mlp = ops.mlp_param_count(radiance_dim)
-        n = self.n_table + self.n_mlp
+        self.weight_norm = (bool(weight_norm[0]), bool(weight_norm[1]))
+        sl = ops.mlp_slices(radiance_dim)
+        self.wn_layers, layers, n_g = [], [], 0                         # flagged weights, (offset, rows, cols, first g)
+        for k in self.WN_WEIGHTS:
+            if self.weight_norm[0 if k.startswith("base") else 1]:
+                off, (rows, cols) = sl[k]
+                self.wn_layers.append((k, n_g, rows))
+                layers.append((off, rows, cols, n_g))
+                n_g += rows
+        self.n_wn_g = n_g
+        n = self.n_table + self.n_mlp + n_g
         self.n_params = n
         n_pad = (n + 3) // 4 * 4
         self.flat = torch.zeros(n_pad, device=device, dtype=torch.float32)
@@ -88,19 +106,69 @@ class NGPField:
         self.grad = self.grad_all[:n_pad]
         self.aux = self.grad_all[n_pad:]
         self.table = self.flat[: self.n_table]
-        self.mlp = self.flat[self.n_table: n]
         self.g_table = self.grad[: self.n_table]
-        self.g_mlp = self.grad[self.n_table: n]
+        m0, m1 = self.n_table, self.n_table + self.n_mlp
+        if n_g == 0:
+            self.mlp, self.g_mlp = self.flat[m0: m1], self.grad[m0: m1]
+        else:
+            self.mlp_raw, self.wn_g = self.flat[m0: m1], self.flat[m1: n]
+            self.g_mlp_raw, self.g_wn_g = self.grad[m0: m1], self.grad[m1: n]
+            self.mlp = torch.zeros(self.n_mlp, device=device, dtype=torch.float32)
+            self.g_mlp = torch.zeros(self.n_mlp, device=device, dtype=torch.float32)
+            self._wn_table = ops.weight_norm_layers(layers)
+
+    def refresh(self):
+        """effective MLP block from (v, g): after load() and after every optimiser step"""
+        if self.n_wn_g:
+            ops.weight_norm_fwd(self.mlp_raw, self.wn_g, self._wn_table, self.mlp)
+
+    def fold_grads(self, zero: bool = True):
+        """gradient w.r.t. the effective block -> gradient w.r.t. (v, g, biases) in the optimiser's buffer (linear in the
+        former, so micro-batches accumulate in g_mlp and are folded once)"""
+        if self.n_wn_g:
+            ops.weight_norm_bwd(self.mlp_raw, self.wn_g, self.g_mlp, self._wn_table, self.g_mlp_raw, self.g_wn_g, zero_d_eff=zero)
 
     def load(self, p: Dict[str, torch.Tensor]):
-        """p: {"hash", "base.w0", ...} (torch nn.Linear layout, the oracle's / reference's names)."""
-        self.table.copy_(p["hash"].to(self.flat.device, torch.float32).reshape(-1))
+        """p: {"hash", "base.w0", ...} (torch nn.Linear layout, the oracle's / reference's names); a weight-normalised layer
+        is given as "<k>_g" (rows, 1) + "<k>_v", or as a plain "<k>" (then v = W, g = ||W||_row as weight_norm() starts)."""
+        dev = self.flat.device
+        self.table.copy_(p["hash"].to(dev, torch.float32).reshape(-1))
+        raw = self.mlp_raw if self.n_wn_g else self.mlp
+        g_of = {k: (g0, rows) for k, g0, rows in self.wn_layers}
         for k, (off, shape) in ops.mlp_slices(self.C).items():
-            self.mlp[off: off + math.prod(shape)].copy_(p[k].to(self.flat.device, torch.float32).reshape(-1))
+            if k in g_of:
+                g0, rows = g_of[k]
+                v = (p[k + "_v"] if k + "_v" in p else p[k]).to(dev, torch.float32)
+                g = p[k + "_g"].to(dev, torch.float32).reshape(-1) if k + "_g" in p else v.norm(dim=1)
+                raw[off: off + math.prod(shape)].copy_(v.reshape(-1))
+                self.wn_g[g0: g0 + rows].copy_(g)
+            else:
+                if k + "_v" in p:
+                    raise ValueError(f"{k}: weight_g / weight_v given for an MLP built without weight_norm")
+                raw[off: off + math.prod(shape)].copy_(p[k].to(dev, torch.float32).reshape(-1))
+        self.refresh()
 
     def mlp_views(self, grad: bool = False) -> Dict[str, torch.Tensor]:
+        """effective parameters (nn.Linear names) -- or the gradient w.r.t. them"""
         buf = self.g_mlp if grad else self.mlp
         return {k: buf[off: off + math.prod(shape)].view(shape) for k, (off, shape) in ops.mlp_slices(self.C).items()}
+
+    def trainable_views(self, grad: bool = False) -> Dict[str, torch.Tensor]:
+        """what the optimiser holds: as mlp_views(), with "<k>_g" (rows, 1) / "<k>_v" in place of a weight-normalised "<k>"
+        (gradients: after fold_grads())"""
+        if not self.n_wn_g:
+            return self.mlp_views(grad)
+        raw, gg = (self.g_mlp_raw, self.g_wn_g) if grad else (self.mlp_raw, self.wn_g)
+        g_of = {k: (g0, rows) for k, g0, rows in self.wn_layers}
+        out = {}
+        for k, (off, shape) in ops.mlp_slices(self.C).items():
+            view = raw[off: off + math.prod(shape)].view(shape)
+            if k in g_of:
+                g0, rows = g_of[k]
+                out[k + "_g"], out[k + "_v"] = gg[g0: g0 + rows].view(rows, 1), view
+            else:
+                out[k] = view
+        return out
 
 
 @dataclass
@@ -856,6 +924,8 @@ class Trainer:
         background scalar (no decay).  Under data parallelism gradients are summed over ranks (RCCL
         all-reduce of the single flat buffer) and scaled by 1/world inside the Adam kernel."""
         f = self.r.field
+        if getattr(f, "n_wn_g", 0):
+            f.fold_grads()
         if self.world_size > 1:
             # ONE collective for everything a step sums over the ranks (plus the early slice when dp_overlap is on):
             # [table | MLP | pad | aux = small-parameter grads, C_p ratio grad, d loss / d tau as two floats, samples per ray]
@@ -881,6 +951,8 @@ class Trainer:
         lr = self.t.lr * self.lr_scale
         ops.adam_step(f.flat, f.grad, self.m, self.v, lr=lr, betas=self.t.betas, eps=self.t.eps,
                       weight_decay=self.t.weight_decay, step=self.step_count, grad_scale=gs, zero_grad=True)
+        if getattr(f, "n_wn_g", 0):
+            f.refresh()
         ops.adam_step(self.small, self.small_grad, self.sm, self.sv, lr=lr, betas=self.t.betas, eps=self.t.eps,
                       weight_decay=0.0, step=self.step_count, grad_scale=gs, zero_grad=True)
         if self.t.train_refractory_period:

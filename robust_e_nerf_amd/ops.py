@@ -144,6 +144,32 @@ def mlp_slices(C: int = 1):
     }
 
 
+# ---- torch.nn.utils.weight_norm over the Linear layers of an MLP (ngp.py:207-228, mlp.py:303-319) -------------------
+def weight_norm_layers(layers):
+    """layers: [(weight offset, rows, cols, first g index)] -> the host int32 table ren_weight_norm_* take."""
+    import ctypes
+    flat = [int(v) for layer in layers for v in layer]
+    return (ctypes.c_int32 * len(flat))(*flat), len(layers)
+
+
+def weight_norm_fwd(raw, g, table, eff):
+    """eff = raw with W[r, :] = g[r] v[r, :] / ||v[r, :]|| in the listed layers"""
+    import ctypes
+    arr, n_layers = table
+    check(_lib.load().ren_weight_norm_fwd(_ptr(raw), _ptr(g), ctypes.cast(arr, ctypes.c_void_p), n_layers, raw.numel(),
+                                          _ptr(eff), _stream()), "ren_weight_norm_fwd")
+    return eff
+
+
+def weight_norm_bwd(raw, g, d_eff, table, d_raw, d_g, zero_d_eff: bool = False):
+    """(d_raw, d_g) = gradient w.r.t. (v / biases / plain weights, g) from d_eff; zero_d_eff: clear d_eff afterwards"""
+    import ctypes
+    arr, n_layers = table
+    check(_lib.load().ren_weight_norm_bwd(_ptr(raw), _ptr(g), _ptr(d_eff), ctypes.cast(arr, ctypes.c_void_p), n_layers,
+                                          raw.numel(), _ptr(d_raw), _ptr(d_g), int(zero_d_eff), _stream()),
+          "ren_weight_norm_bwd")
+
+
 def n_blocks32(n: int) -> int:
     return (n + 31) // 32
 

@@ -86,7 +86,7 @@ def main():
         cli.load_field_state_dict(fld, arch, sd)
         r = vanilla.VanillaRenderer(fld, rcfg)
     else:
-        fld = engine.NGPField(dev, C, ncfg.get("ngp", {}).get("pos_encoding"))
+        fld = engine.NGPField(dev, C, ncfg.get("ngp", {}).get("pos_encoding"), weight_norm=cli.weight_norm_flags(ncfg, arch))
         cli.load_field_state_dict(fld, arch, sd)
         r = engine.Renderer(fld, rcfg)
     r.binary.copy_(sd[cli.OCC + "_binary"].reshape(-1).to(torch.uint8).to(dev))

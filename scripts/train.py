@@ -47,8 +47,9 @@ def field_state_dict(fld, arch, aabb):
         buf[PREFIX + "view_encoder.scales"] = torch.tensor([2 ** i for i in range(4)])
         return dict(buf, **{PREFIX + k: v.detach().cpu().clone() for k, v in fld.state_dict().items()})
     sd = dict(buf, **{PREFIX + NGP_KEYS["hash"]: fld.table.detach().cpu().clone()})
-    for k, v in fld.mlp_views().items():
-        sd[PREFIX + NGP_KEYS[k]] = v.detach().cpu().clone()
+    for k, v in fld.trainable_views().items():               # weight_norm: "<layer>.weight_g" / ".weight_v" (ngp.py:207-228)
+        name = NGP_KEYS[k[:-2]] + k[-2:] if k[-2:] in ("_g", "_v") else NGP_KEYS[k]
+        sd[PREFIX + name] = v.detach().cpu().clone()
     return sd
 
 
@@ -57,7 +58,13 @@ def load_field_state_dict(fld, arch, sd):
     if arch == "mlp":
         fld.load(sd)
     else:
-        fld.load({ours: sd[theirs] for ours, theirs in NGP_KEYS.items()})
+        p = {}
+        for ours, theirs in NGP_KEYS.items():
+            if theirs in sd:
+                p[ours] = sd[theirs]
+            else:                                            # a weight-normalised layer (ngp.py:207-228)
+                p[ours + "_g"], p[ours + "_v"] = sd[theirs + "_g"], sd[theirs + "_v"]
+        fld.load(p)
 
 
 SUPPORTED = {  # what the fused kernels implement = what every shipped configs/train/*.yaml selects
@@ -91,6 +98,12 @@ def activation_fields(ncfg, arch) -> dict:
                 radiance_activation=h.get("radiance_activation", "softplus"))
 
 
+def weight_norm_flags(ncfg, arch):
+    """(mlp_base.weight_norm, mlp_head.weight_norm) of model.nerf.ngp"""
+    g = (ncfg.get("ngp") or {}) if arch == "ngp" else {}
+    return (bool((g.get("mlp_base") or {}).get("weight_norm", False)), bool((g.get("mlp_head") or {}).get("weight_norm", False)))
+
+
 def check_supported(ncfg, arch):
     """Fail loudly on hyper-parameters the HIP kernels do not implement (no silent fallback)."""
     def walk(want, got, path):
@@ -103,6 +116,8 @@ def check_supported(ncfg, arch):
                 if got[k] not in NGP_ACTIVATIONS[tuple(path[1:] + [k])]:
                     raise NotImplementedError(f"model.nerf.{'.'.join(path + [k])} = {got[k]!r}: one of "
                                               f"{NGP_ACTIVATIONS[tuple(path[1:] + [k])]} (models/nerf.py:17-29)")
+            elif arch == "ngp" and k == "weight_norm" and isinstance(got[k], bool):
+                continue                                        # a reparametrisation of the trainable block (NGPField.weight_norm)
             elif got[k] != v:
                 raise NotImplementedError(f"model.nerf.{'.'.join(path + [k])} = {got[k]!r}: the MI355X kernels implement {v!r} only")
     walk(SUPPORTED[arch], ncfg.get(arch) or {}, [arch])
@@ -208,7 +223,7 @@ def main():
         fld.load({k: v for name, o, i in vanilla.layer_shapes(C) for k, v in zip((name + ".weight", name + ".bias"), lin(o, i))})
         renderer = vanilla.VanillaRenderer(fld, rcfg)
     else:
-        fld = engine.NGPField(dev, C, ncfg.get("ngp", {}).get("pos_encoding"))
+        fld = engine.NGPField(dev, C, ncfg.get("ngp", {}).get("pos_encoding"), weight_norm=weight_norm_flags(ncfg, arch))
         p = {"hash": (torch.rand(fld.n_table, generator=gen) * 2 - 1) * 1e-4}          # tcnn grid init U(+-1e-4)
         for k, (o, i) in {"base.w0": (64, 32), "base.wo": (16, 64), "head.w0": (64, 31), "head.w1": (64, 64), "head.wo": (C, 64)}.items():
             p[k], p[k.replace(".w", ".b")] = lin(o, i)

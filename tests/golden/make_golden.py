@@ -379,6 +379,60 @@ def gen_field_acts(ngp, nerf_mod, nerfacc):
     save("field_acts", **out)
 
 
+NGP_LINEARS = {"base.w0": "mlp_base.1.hidden_layers.0", "base.wo": "mlp_base.1.output_layer", "head.w0": "mlp_head.hidden_layers.0",
+               "head.w1": "mlp_head.hidden_layers.1", "head.wo": "mlp_head.output_layer"}
+
+
+def gen_field_wn(ngp, nerfacc):
+    """Reference NGPradianceField with `weight_norm: true` (external/ngp.py:207-228: torch.nn.utils.weight_norm on every
+    Linear of the flagged MLP): forward + gradients w.r.t. weight_g / weight_v / biases / table, for both MLPs flagged and
+    for the head alone.  weight_g is scaled away from its initial ||v|| so that the two factors are told apart."""
+    aabb = [-1.5] * 3 + [1.5] * 3
+    out = {"aabb": np.array(aabb, np.float32), "table_seed": np.array(TABLE_SEED), "table_scale": np.array(TABLE_SCALE)}
+    for tag, (wb, wh) in {"both": (True, True), "head": (False, True)}.items():
+        torch.manual_seed(31)
+        base = EasyDict(NGP_CFG["mlp_base"])
+        base.hidden_activation = torch.nn.Softplus(beta=100)
+        base.density_activation = ngp.shifted_trunc_exp
+        base.weight_norm = wb
+        head = EasyDict(NGP_CFG["mlp_head"])
+        head.hidden_activation = torch.nn.Softplus(beta=100)
+        head.radiance_activation = torch.nn.Softplus(beta=1)
+        head.output_dim = 1
+        head.weight_norm = wh
+        rf = ngp.NGPradianceField(aabb=aabb, num_dim=3, use_viewdirs=True, contraction_type=nerfacc.ContractionType.AABB,
+                                  pos_encoding_config=NGP_CFG["pos_encoding"], dir_encoding_config=NGP_CFG["dir_encoding"],
+                                  mlp_base_config=base, mlp_head_config=head)
+        params = dict(rf.named_parameters())
+        with torch.no_grad():
+            for k, v in params.items():
+                if k.endswith("weight_g"):
+                    v.mul_(0.6 + 0.8 * torch.rand_like(v))
+        n = 384
+        x = (torch.rand(n, 3) - 0.5) * 1.2 * 3.0
+        d = torch.randn(n, 3)
+        d = d / d.norm(dim=-1, keepdim=True)
+        rgb, sigma = rf(x, d)
+        g_rgb, g_sig = torch.randn_like(rgb), torch.randn_like(sigma)
+        rf.zero_grad()
+        ((rgb * g_rgb).sum() + (sigma * g_sig).sum()).backward()
+        for k, mod in NGP_LINEARS.items():
+            flagged = wb if k.startswith("base") else wh
+            names = {k + "_g": mod + ".weight_g", k + "_v": mod + ".weight_v"} if flagged else {k: mod + ".weight"}
+            names[k.replace("w", "b")] = mod + ".bias"
+            for ours, theirs in names.items():
+                out[f"{tag}.{ours}"] = params[theirs].detach().clone()
+                out[f"{tag}.g.{ours}"] = params[theirs].grad
+        gt = params["mlp_base.0.params"].grad
+        nz = torch.nonzero(gt)[:, 0]
+        pick = nz[torch.linspace(0, len(nz) - 1, 256).long()]
+        out.update({f"{tag}.x": x, f"{tag}.d": d, f"{tag}.rgb": rgb, f"{tag}.sigma": sigma, f"{tag}.g_rgb": g_rgb, f"{tag}.g_sigma": g_sig,
+                    f"{tag}.g_table_abs": gt.double().abs().sum(), f"{tag}.g_table_idx": pick, f"{tag}.g_table_val": gt[pick],
+                    f"{tag}.flags": np.array([wb, wh])})
+        print(f"field_wn {tag}: rgb [{float(rgb.min()):.3f}, {float(rgb.max()):.3f}]  sigma max {float(sigma.max()):.3f}")
+    save("field_wn", **out)
+
+
 def gen_field_mlp(mlp_mod, ngp, nerfacc):
     """Reference VanillaNeRFRadianceField (`arch: mlp`) forward + parameter gradients.  The 593 k parameters
     are regenerated from a seed (oracle.vanilla.init_params) instead of being stored."""
@@ -917,6 +971,8 @@ def main():
         return gen_eval_epoch(rmod)
     if sys.argv[1:] == ["field_acts"]:
         return gen_field_acts(ngp, nerf_mod, nerfacc)
+    if sys.argv[1:] == ["field_wn"]:
+        return gen_field_wn(ngp, nerfacc)
     if sys.argv[1:] == ["eval_dataset"]:
         from robust_e_nerf.data import datasets as datasets_mod
         return gen_eval_dataset(datasets_mod)
@@ -926,6 +982,7 @@ def main():
     gen_events(egp, loss_mod)
     gen_field(ngp, nerfacc)
     gen_field_acts(ngp, nerf_mod, nerfacc)
+    gen_field_wn(ngp, nerfacc)
     from robust_e_nerf.external import mlp as mlp_mod
     gen_field_mlp(mlp_mod, ngp, nerfacc)
     mods = (rmod, nerf_mod, trajectories, egp, loss_mod, nerfacc)

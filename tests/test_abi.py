@@ -51,7 +51,7 @@ def test_shipped_library_corresponds_to_the_sources(lib, tmp_path):
 
 
 def test_abi_version_and_build_info(lib):
-    assert lib.ren_abi_version() == 22
+    assert lib.ren_abi_version() == 23
     assert b"gfx950" in lib.ren_build_info()
 
 

@@ -133,12 +133,16 @@ def test_cli_rejects_unsupported_hyperparameters():
         assert cli.activation_fields(c, "ngp")[key] == ok
     # ... names outside the reference's tables, and everything else the kernels do not implement, are not
     for path, bad in ((("mlp_head", "radiance_activation"), "tanh"), (("mlp_base", "hidden_activation"), "gelu"),
-                      (("mlp_base", "weight_norm"), True), (("pos_encoding", "interpolation"), "Smoothstep"),
+                      (("mlp_base", "n_neurons"), 128), (("pos_encoding", "interpolation"), "Smoothstep"),
                       (("pos_encoding", "otype"), "Frequency")):
         c = copy.deepcopy(ncfg)
         c["ngp"][path[0]][path[1]] = bad
         with pytest.raises(NotImplementedError):
             cli.check_supported(c, "ngp")
+    c = copy.deepcopy(ncfg)                                            # weight_norm (ngp.py:207-228): per MLP, arch ngp
+    c["ngp"]["mlp_head"]["weight_norm"] = True
+    cli.check_supported(c, "ngp")
+    assert cli.weight_norm_flags(c, "ngp") == (False, True) and cli.weight_norm_flags(ncfg, "ngp") == (False, False)
     for otype in ("DenseGrid", "TiledGrid"):                           # the other grid types of tcnn's grid encoding are built
         c = copy.deepcopy(ncfg)
         c["ngp"]["pos_encoding"]["otype"] = otype
@@ -146,6 +150,9 @@ def test_cli_rejects_unsupported_hyperparameters():
     ncfg["mlp"] = {"net_depth": 8, "net_width": 256, "skip_layer": 4, "hidden_activation": "softplus"}
     cli.check_supported(ncfg, "mlp")
     ncfg["mlp"]["net_width"] = 128
+    with pytest.raises(NotImplementedError):
+        cli.check_supported(ncfg, "mlp")
+    ncfg["mlp"] = {"net_width": 256, "weight_norm": True}              # arch mlp: not built
     with pytest.raises(NotImplementedError):
         cli.check_supported(ncfg, "mlp")
 

@@ -1,0 +1,157 @@
+"""`weight_norm: true` of mlp_base / mlp_head (external/ngp.py:207-228: torch.nn.utils.weight_norm on every Linear of the
+flagged MLP; VERDICT r3 missing #5): the trainable block holds (v, g), the field kernels read W = g v / ||v|| produced by
+ren_weight_norm_fwd, gradients are folded back by ren_weight_norm_bwd before the optimiser.  Pinned to the reference module's
+own forward and its gradients w.r.t. weight_g / weight_v (fixture field_wn.npz)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import FIELD_KEYS, load_golden, rel_err, t
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def dev(x):
+    return torch.as_tensor(x).to(DEV).contiguous()
+
+
+@pytest.fixture(scope="module")
+def amd():
+    from robust_e_nerf_amd import engine, ops, _lib
+    _lib.load()
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    return ops, engine
+
+
+def _raw_params(g):
+    return {k: t(v) for k, v in g.items() if k.split("_")[0] in FIELD_KEYS and not k.startswith("g")}
+
+
+@pytest.mark.parametrize("tag", ["both", "head"])
+def test_weight_norm_field_vs_reference_golden(amd, tag, full_table_cache):
+    from oracle import field as ofield
+    from robust_e_nerf_amd.engine import contract_points
+    ops, engine = amd
+    g0 = load_golden("field_wn")
+    g = {k[len(tag) + 1:]: v for k, v in g0.items() if k.startswith(tag + ".")}
+    flags = tuple(bool(v) for v in g["flags"])
+    table = full_table_cache(g0["table_seed"], g0["table_scale"])
+    raw = _raw_params(g)
+    fld = engine.NGPField(DEV, 1, weight_norm=flags)
+    assert fld.n_wn_g == (16 + 64 if flags[0] else 0) + 64 + 64 + 1 and fld.n_params == fld.n_table + fld.n_mlp + fld.n_wn_g
+    fld.load(dict(raw, hash=table))
+    eff = ofield.weight_norm_params(raw)                                  # the effective weights, by the pinned oracle helper
+    for k, v in fld.mlp_views().items():
+        assert rel_err(v.cpu(), eff[k]) < 1e-6, k
+    for k, v in fld.trainable_views().items():
+        assert torch.equal(v.cpu(), raw[k]), k
+    aabb = [float(v) for v in g0["aabb"]]
+    x, d = dev(g["x"]), dev(g["d"])
+    n = x.shape[0]
+    scene = ops.make_scene_desc(aabb, 0)
+    xu = contract_points(x, aabb, 0)
+    feat = ops.hashgrid_fwd(fld.grid, fld.table, x_unit=xu, n=n, layout=1)
+    rgb, sigma, base = ops.mlp_fwd(fld.mlp, 1, feat, scene, x_world=x, dirs=d, n=n, save_base=True)
+    assert rel_err(rgb.cpu(), g["rgb"]) < 1e-4 and rel_err(sigma.cpu()[:, None], g["sigma"]) < 1e-4
+    ws = torch.empty(ops.mlp_bwd_workspace_floats(1), device=DEV)
+    for rep in range(2):                                                  # twice: fold_grads() leaves a clean accumulator
+        dfeat = ops.mlp_bwd(fld.mlp, 1, feat, base, scene, x_world=x, dirs=d, n=n, rgb=rgb, d_rgb=dev(g["g_rgb"]),
+                            d_sigma=dev(g["g_sigma"]).reshape(-1).contiguous(), grad_mlp_params=fld.g_mlp, workspace=ws)
+        fld.fold_grads()
+        assert float(fld.g_mlp.abs().max()) == 0.0
+        for k, v in fld.trainable_views(grad=True).items():
+            assert rel_err(v.cpu(), g["g." + k]) < 1e-3, (rep, k)
+    gt = torch.zeros_like(fld.table)
+    ops.hashgrid_bwd(fld.grid, gt, dfeat, x_unit=xu, n=n, layout=1)
+    assert rel_err(gt.cpu()[t(g["g_table_idx"])], g["g_table_val"]) < 1e-3
+
+
+def test_weight_norm_training_steps_vs_oracle(amd, full_table_cache):
+    """Whole steps (l_diff + l_grad) on a head-and-base weight-normalised field: gradients w.r.t. (g, v) vs the oracle's
+    autograd through its reparametrisation helper, then three optimiser steps -- (g, v) move exactly as torch.optim.Adam
+    moves them, the effective block follows, the loss goes down; checkpoint keys weight_g / weight_v round-trip."""
+    from oracle import field as ofield, hashgrid, step as ostep
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import train as cli
+    ops, engine = amd
+    spec = hashgrid.make_spec()
+    g = load_golden("training_step_grad")
+    table = full_table_cache(g["table_seed"], g["table_scale"])
+    gen = torch.Generator().manual_seed(4)
+    raw = {}
+    for k in FIELD_KEYS:
+        w = t(g[k])
+        if ".w" in k:
+            raw[k + "_v"] = w * (0.5 + torch.rand(w.shape[0], 1, generator=gen))
+            raw[k + "_g"] = w.norm(dim=1, keepdim=True) * (0.8 + 0.4 * torch.rand(w.shape[0], 1, generator=gen))
+        else:
+            raw[k] = w
+    occ_res = int(g["occ_res"])
+    cfg = engine.RenderCfg(occ_res=(occ_res,) * 3, render_step_size=float(g["render_step_size"]), sampler="occgrid")
+    fld = engine.NGPField(DEV, 1, weight_norm=(True, True))
+    fld.load(dict(raw, hash=table))
+    r = engine.Renderer(fld, cfg)
+    r.binary.copy_(dev(np.unpackbits(g["binary"])[: occ_res ** 3].astype(np.uint8)))
+    tr = engine.Trainer(r, engine.TrainCfg(), Kinv=t(g["Kinv"]), tab_ts=t(g["tab_ts"]), tab_pos=t(g["tab_pos"]),
+                        tab_quat=t(g["tab_quat"]), p2n_raw=t(g["p2n_raw"]), neg_ct=t(g["neg_ct"]),
+                        tau_raw=t(g["tau_raw"]), tau_max=t(g["tau_max"]), bkgd_raw=t(g["bkgd_raw"]))
+    batch = dict(position=dev(g["position"]), start_ts=dev(g["start_ts"]), end_ts=dev(g["end_ts"]),
+                 num_pos=dev(g["num_pos"]), num_neg=dev(g["num_neg"]), u_ts_diff=dev(g["u_ts_diff"]),
+                 u_diff_start=dev(g["u_diff_start"]), u_grad=dev(g["u_grad"]))
+    w_grad = float(g["w_grad"])
+    tr.t.w_grad, tr.t.err_grad, tr.t.pw_grad = w_grad, "mape", None
+    jit = t(g["jitters"])
+
+    def hip_step():
+        loss_d, _ = tr.forward_backward(batch, dev(jit[1]), dev(jit[2]))
+        loss_g, _ = tr.grad_loss_forward_backward(batch, dev(jit[0]))
+        return float(loss_d) + float(loss_g)
+
+    loss = hip_step()
+    binary = t(np.unpackbits(g["binary"])[: occ_res ** 3].astype(bool)).view(occ_res, occ_res, occ_res)
+    ocfg = ostep.SceneCfg(occ_res=(occ_res,) * 3, render_step_size=float(g["render_step_size"]))
+    ob = ostep.EventBatch(t(g["position"]), t(g["start_ts"]), t(g["end_ts"]), t(g["num_pos"]), t(g["num_neg"]),
+                          t(g["u_ts_diff"]), t(g["u_diff_start"]), t(g["u_grad"]))
+    po = {k: v.clone().requires_grad_() for k, v in raw.items()}
+    po["hash"] = table.clone().requires_grad_()
+    loss_o, _ = ostep.training_forward(
+        ob, ofield.weight_norm_params(po), spec, ocfg, Kinv=t(g["Kinv"]), tab_ts=t(g["tab_ts"]), tab_pos=t(g["tab_pos"]),
+        tab_quat=t(g["tab_quat"]), p2n_raw=t(g["p2n_raw"]), neg_ct=t(g["neg_ct"]), tau_raw=t(g["tau_raw"]), tau_max=t(g["tau_max"]),
+        bkgd_raw=t(g["bkgd_raw"]), binary=binary, jitter_start=jit[1], jitter_end=jit[2], jitter_grad=jit[0],
+        loss_cfg=dict(w_grad=w_grad, err_grad="mape", pw_grad=None))
+    loss_o.backward()
+    assert abs(loss - float(loss_o)) < 1e-4 * abs(float(loss_o)), (loss, float(loss_o))
+    fld.fold_grads(zero=False)
+    errs = {k: rel_err(v.cpu(), po[k].grad) for k, v in fld.trainable_views(grad=True).items()}
+    print("weight_norm whole step, gradients w.r.t. (g, v, b) vs oracle: worst", max(errs, key=errs.get), f"{max(errs.values()):.2e}")
+    assert max(errs.values()) < 5e-3, errs
+    # optimiser: Adam over [table | v, biases | g] -- the MLP part against torch.optim.Adam given the same gradients
+    n0, n1 = fld.n_table, fld.n_params
+    p_ref = fld.flat[n0: n1].detach().cpu().clone().requires_grad_()
+    opt = torch.optim.Adam([p_ref], lr=0.01, weight_decay=1e-6)
+    losses = [loss]
+    for it in range(3):
+        if it:
+            losses.append(hip_step())
+        fld.fold_grads(zero=False)                                        # (optimizer_step folds again: same values)
+        p_ref.grad = fld.grad[n0: n1].detach().cpu().clone()
+        opt.step()
+        tr.optimizer_step()
+        assert float(fld.grad.abs().max()) == 0.0 and float(fld.g_mlp.abs().max()) == 0.0
+        assert rel_err(fld.flat[n0: n1].cpu(), p_ref.detach()) < 1e-5
+        eff = ofield.weight_norm_params({k: v.cpu() for k, v in fld.trainable_views().items()})
+        for k, v in fld.mlp_views().items():
+            assert rel_err(v.cpu(), eff[k]) < 1e-6, k
+    assert losses[-1] < losses[0], losses
+    # checkpoint keys as the reference module's state_dict has them under weight_norm, and back
+    sd = cli.field_state_dict(fld, "ngp", [-1.5] * 3 + [1.5] * 3)
+    assert cli.PREFIX + "mlp_head.hidden_layers.1.weight_g" in sd and cli.PREFIX + "mlp_head.hidden_layers.1.weight" not in sd
+    assert tuple(sd[cli.PREFIX + "mlp_base.1.output_layer.weight_g"].shape) == (16, 1)
+    fld2 = engine.NGPField(DEV, 1, weight_norm=(True, True))
+    cli.load_field_state_dict(fld2, "ngp", sd)
+    assert torch.equal(fld2.flat, fld.flat) and torch.equal(fld2.mlp, fld.mlp)

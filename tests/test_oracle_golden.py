@@ -314,3 +314,26 @@ def test_grid_types_level_table_and_index(kw):
                 wc = np.prod([w[d] if (c >> d) & 1 else 1 - w[d] for d in range(3)])
                 acc += wc * tab[spec.offsets[l] + idx % size]
             assert np.allclose(acc, got[i, 2 * l: 2 * l + 2], rtol=1e-5, atol=1e-6), (i, l)
+
+
+@pytest.mark.parametrize("tag", ["both", "head"])
+def test_field_weight_norm(tag, full_table_cache):
+    """weight_norm: true (ngp.py:207-228) -- the oracle's reparametrisation helper vs the reference module's own forward and
+    its gradients w.r.t. weight_g / weight_v / biases / table (fixture field_wn.npz)."""
+    g0 = load_golden("field_wn")
+    g = {k[len(tag) + 1:]: v for k, v in g0.items() if k.startswith(tag + ".")}
+    table = full_table_cache(g0["table_seed"], g0["table_scale"])
+    raw = {k: t(v).clone().requires_grad_() for k, v in g.items()
+           if k.split("_")[0] in FIELD_KEYS and not k.startswith("g")}
+    raw["hash"] = table.clone().requires_grad_()
+    assert sum(k.endswith("_g") for k in raw) == (5 if tag == "both" else 3)
+    p = field.weight_norm_params(raw)
+    assert set(p) == set(FIELD_KEYS) | {"hash"}
+    rgb, sigma = field.field_forward(t(g["x"]), t(g["d"]), p, SPEC, t(g0["aabb"]), 0)
+    assert rel_err(rgb, g["rgb"]) < 1e-5 and rel_err(sigma, g["sigma"]) < 1e-5
+    ((rgb * t(g["g_rgb"])).sum() + (sigma * t(g["g_sigma"])).sum()).backward()
+    for k, v in raw.items():
+        if k != "hash":
+            assert rel_err(v.grad, g["g." + k]) < 1e-4, k
+    idx = t(g["g_table_idx"])
+    assert rel_err(raw["hash"].grad[idx], g["g_table_val"]) < 1e-4
