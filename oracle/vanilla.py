@@ -86,3 +86,15 @@ def forward(p: Dict[str, torch.Tensor], x: torch.Tensor, dirs, aabb: torch.Tenso
     r = ofield.softplus(torch.nn.functional.linear(r, p["mlp.rgb_layer.hidden_layers.0.weight"], p["mlp.rgb_layer.hidden_layers.0.bias"]), 100.0)
     raw_rgb = torch.nn.functional.linear(r, p["mlp.rgb_layer.output_layer.weight"], p["mlp.rgb_layer.output_layer.bias"])
     return ofield.softplus(raw_rgb, 1.0), sigma
+
+
+def weight_norm_params(p):
+    """`weight_norm: true` (external/mlp.py:303-319: torch.nn.utils.weight_norm on every Linear, dim 0): a dict holding
+    "<layer>.weight_g" (rows, 1) + "<layer>.weight_v" in place of "<layer>.weight" -> the dict forward() takes, with
+    W = g v / ||v||_row (differentiable).  Pinned to the reference by tests/golden/field_mlp_wn.npz."""
+    q = {k: v for k, v in p.items() if not (k.endswith(".weight_g") or k.endswith(".weight_v"))}
+    for k, v in p.items():
+        if k.endswith(".weight_v"):
+            g = p[k[:-1] + "g"]
+            q[k[: -len("_v")]] = v * (g.reshape(-1, 1) / v.norm(dim=1, keepdim=True))
+    return q

@@ -27,6 +27,13 @@ class _Linear(torch.nn.Module):
         lin = torch.nn.Linear(in_f, out_f)
         self.weight, self.bias = lin.weight, lin.bias
 
+    def effective_weight(self):
+        """the layer's weight; under torch.nn.utils.weight_norm (ngp.py:224-228) g v / ||v|| from the CURRENT weight_g / weight_v
+        (the hook that refreshes `.weight` runs on forward(), which a parameter holder never sees)"""
+        if hasattr(self, "weight_g"):
+            return torch._weight_norm(self.weight_v, self.weight_g, 0)
+        return self.weight
+
 
 class _MLPParams(torch.nn.Module):
     """Mirrors external/mlp.py:26-97's attribute layout: hidden_layers (ModuleList) + output_layer."""
@@ -39,8 +46,29 @@ class _MLPParams(torch.nn.Module):
     def tensors(self):
         out = []
         for layer in list(self.hidden_layers) + [self.output_layer]:
-            out += [layer.weight, layer.bias]
+            out += [layer.effective_weight(), layer.bias]
         return out
+
+
+def _act_name(v, slot: str) -> str:
+    """name of an activation given as the YAML string or as the callable the reference passes (models/nerf.py:17-29 maps the
+    names to torch.nn.Softplus(beta=100) / ReLU for hidden layers, shifted_trunc_exp / Softplus / shifted_softplus for the
+    density, Softplus(beta=1) / Sigmoid for the radiance)"""
+    if isinstance(v, str):
+        return v
+    if isinstance(v, torch.nn.ReLU):
+        return "relu"
+    if isinstance(v, torch.nn.Sigmoid):
+        return "sigmoid"
+    if isinstance(v, torch.nn.Softplus):
+        want = 100 if slot == "hidden" else 1
+        if v.beta != want:
+            raise NotImplementedError(f"{slot} activation Softplus(beta={v.beta}): the kernels implement beta={want}")
+        return "softplus"
+    name = getattr(v, "__name__", "")
+    if name in ("shifted_trunc_exp", "shifted_softplus"):
+        return name
+    raise NotImplementedError(f"{slot} activation {v!r}")
 
 
 class _FieldFn(torch.autograd.Function):
@@ -56,8 +84,9 @@ class _FieldFn(torch.autograd.Function):
         xu = contract_points(x_world, m.aabb.tolist(), m.contraction_type.value)
         feat = ops.hashgrid_fwd(m.encoding.grid, table, x_unit=xu, n=n, layout=1)
         dirs_c = None if dirs is None else dirs.contiguous().float()
-        rgb, sigma, base = ops.mlp_fwd(mlp, m.radiance_dim, feat, m.scene, x_world=x_world, dirs=dirs_c, n=n,
-                                       density_only=density_only, save_base=not density_only)
+        with ops.knob("activations", m._act_code):
+            rgb, sigma, base = ops.mlp_fwd(mlp, m.radiance_dim, feat, m.scene, x_world=x_world, dirs=dirs_c, n=n,
+                                           density_only=density_only, save_base=not density_only)
         ctx.module, ctx.n, ctx.density_only = m, n, density_only
         ctx.shapes = [t.shape for t in mlp_tensors]
         if not density_only:
@@ -78,8 +107,9 @@ class _FieldFn(torch.autograd.Function):
         g_sigma = torch.zeros(n, device=dev) if g_sigma is None else g_sigma.reshape(-1).contiguous().float()
         g_mlp = torch.zeros_like(mlp)
         ws = torch.empty(ops.mlp_bwd_workspace_floats(m.radiance_dim), device=dev, dtype=torch.float32)
-        dfeat = ops.mlp_bwd(mlp, m.radiance_dim, feat, base, m.scene, x_world=x_world, dirs=dirs, n=n, rgb=rgb,
-                            d_rgb=g_rgb, d_sigma=g_sigma, grad_mlp_params=g_mlp, workspace=ws)
+        with ops.knob("activations", m._act_code):
+            dfeat = ops.mlp_bwd(mlp, m.radiance_dim, feat, base, m.scene, x_world=x_world, dirs=dirs, n=n, rgb=rgb,
+                                d_rgb=g_rgb, d_sigma=g_sigma, grad_mlp_params=g_mlp, workspace=ws)
         g_table = torch.zeros(m.encoding.n_params, device=dev, dtype=torch.float32)
         bws = torch.empty(ops.hashgrid_bwd_binned_workspace_bytes(n), device=dev, dtype=torch.uint8)
         ops.hashgrid_bwd_binned(m.encoding.grid, g_table, dfeat, bws, x_unit=xu, n=n, layout=1)
@@ -143,15 +173,13 @@ class NGPradianceField(torch.nn.Module):
             raise NotImplementedError("fused kernels: base MLP 32->64->16")
         if (mlp_head_config.get("n_neurons", 64), mlp_head_config.get("n_hidden_layers", 2)) != (64, 2):
             raise NotImplementedError("fused kernels: head MLP 31->64->64->C")
-        if mlp_base_config.get("weight_norm", False) or mlp_head_config.get("weight_norm", False):
-            raise NotImplementedError("weight_norm")
-        for cfg, key, want in ((mlp_base_config, "hidden_activation", "softplus"),
-                               (mlp_base_config, "density_activation", "shifted_trunc_exp"),
-                               (mlp_head_config, "hidden_activation", "softplus"),
-                               (mlp_head_config, "radiance_activation", "softplus")):
-            v = cfg.get(key, want)
-            if isinstance(v, str) and v != want:
-                raise NotImplementedError(f"{key}={v}: fused kernels implement {want} (configs/train/*.yaml)")
+        # activations: the reference hands over callables (models/nerf.py:17-29, 150-163) or their YAML names; both are
+        # resolved to the names of its own tables.  Alternatives run on the exact-f32 kernels (REN_KNOB_ACTIVATIONS).
+        self.acts = dict(base_hidden=_act_name(mlp_base_config.get("hidden_activation", "softplus"), "hidden"),
+                         density=_act_name(mlp_base_config.get("density_activation", "shifted_trunc_exp"), "density"),
+                         head_hidden=_act_name(mlp_head_config.get("hidden_activation", "softplus"), "hidden"),
+                         radiance=_act_name(mlp_head_config.get("radiance_activation", "softplus"), "radiance"))
+        self._act_code = ops.activation_code(**self.acts)
         self.radiance_dim = int(mlp_head_config.get("output_dim", 1))
         if self.radiance_dim not in (1, 3):
             raise NotImplementedError("radiance_dim must be 1 or 3")
@@ -166,6 +194,11 @@ class NGPradianceField(torch.nn.Module):
         # names as in the reference: mlp_base = Sequential(encoding, MLP), mlp_head = MLP
         self.mlp_base = torch.nn.Sequential(encoding, _MLPParams([32, 64, 16]))
         self.mlp_head = _MLPParams([31, 64, 64, self.radiance_dim])
+        for mlp, mlp_config in ((self.mlp_base[1], mlp_base_config), (self.mlp_head, mlp_head_config)):   # ngp.py:207-228
+            if mlp_config.get("weight_norm", False):
+                for module in mlp.modules():
+                    if isinstance(module, _Linear):
+                        torch.nn.utils.weight_norm(module)
         self.scene = ops.make_scene_desc(aabb.tolist(), contraction_type.value)
 
     @property
@@ -192,14 +225,19 @@ class NGPradianceField(torch.nn.Module):
         xu = contract_points(x, self.aabb.tolist(), self.contraction_type.value)
         sel = ((xu > 0.0) & (xu < 1.0)).all(dim=-1, keepdim=True)
         feat = self.encoding(xu)
-        sp = lambda v: F.softplus(v, beta=100)
-        b, h = self.mlp_base[1], self.mlp_head
-        o = F.linear(sp(F.linear(feat, b.hidden_layers[0].weight, b.hidden_layers[0].bias)), b.output_layer.weight, b.output_layer.bias)
-        sigma = _TruncExp.apply(o[:, :1] - 1.0) * sel
+        hid = lambda v, name: F.relu(v) if name == "relu" else F.softplus(v, beta=100)
+        a = self.acts
+        (w0, b0, wo, bo), (hw0, hb0, hw1, hb1, hwo, hbo) = self.mlp_base[1].tensors(), self.mlp_head.tensors()
+        o = F.linear(hid(F.linear(feat, w0, b0), a["base_hidden"]), wo, bo)
+        raw = o[:, :1]
+        dens = {"shifted_trunc_exp": lambda v: _TruncExp.apply(v - 1.0), "softplus": F.softplus,
+                "shifted_softplus": lambda v: F.softplus(v - 1.0)}[a["density"]]          # nerf.py:8-13,20-24
+        sigma = dens(raw) * sel
         hin = torch.cat([sh4(d), o[:, 1:]], dim=-1)                                     # ngp.py:256-260
-        p = sp(F.linear(hin, h.hidden_layers[0].weight, h.hidden_layers[0].bias))
-        q = sp(F.linear(p, h.hidden_layers[1].weight, h.hidden_layers[1].bias))
-        rgb = F.softplus(F.linear(q, h.output_layer.weight, h.output_layer.bias), beta=1)
+        p = hid(F.linear(hin, hw0, hb0), a["head_hidden"])
+        q = hid(F.linear(p, hw1, hb1), a["head_hidden"])
+        z = F.linear(q, hwo, hbo)
+        rgb = torch.sigmoid(z) if a["radiance"] == "sigmoid" else F.softplus(z, beta=1)
         return rgb, sigma
 
     def forward(self, positions: torch.Tensor, directions: torch.Tensor = None):

@@ -38,14 +38,23 @@ def layer_shapes(C: int = 1) -> List[Tuple[str, int, int]]:
 
 
 class VanillaField:
-    """Flat parameter / gradient buffers with per-layer (weight, bias) views."""
+    """Flat parameter / gradient buffers with per-layer (weight, bias) views.
 
-    def __init__(self, device, radiance_dim: int = 1):
+    weight_norm (external/mlp.py:303-319: torch.nn.utils.weight_norm on every Linear): the optimiser's buffers `flat` / `grad`
+    then hold [v and biases | g of every row | pad], and `eff` / `g_eff` -- what every kernel reads and accumulates into, and
+    what the w / b / gw / gb views show -- are separate buffers with W = g v / ||v|| and its gradient, kept in step by
+    refresh() (after every parameter change) and fold_grads() (before the optimiser).  Without it they are the same memory."""
+
+    def __init__(self, device, radiance_dim: int = 1, weight_norm: bool = False):
         if radiance_dim not in (1, 3):
             raise NotImplementedError("radiance_dim must be 1 or 3 (robust_e_nerf.py:230-233)")
         self.C = radiance_dim
         self.layers = layer_shapes(radiance_dim)
-        n = sum(o * i + o for _, o, i in self.layers)
+        self.weight_norm = bool(weight_norm)
+        nb = sum(o * i + o for _, o, i in self.layers)
+        self.n_block = nb
+        self.n_wn_g = sum(o for _, o, _ in self.layers) if self.weight_norm else 0
+        n = nb + self.n_wn_g
         self.n_params = n
         n_pad = (n + 3) // 4 * 4
         self.flat = torch.zeros(n_pad, device=device, dtype=torch.float32)
@@ -53,25 +62,69 @@ class VanillaField:
         self.grad_all = torch.zeros(n_pad + AUX_FLOATS, device=device, dtype=torch.float32)
         self.grad = self.grad_all[:n_pad]
         self.aux = self.grad_all[n_pad:]
+        if self.weight_norm:
+            nb_pad = (nb + 3) // 4 * 4
+            self.eff = torch.zeros(nb_pad, device=device, dtype=torch.float32)
+            self.g_eff = torch.zeros(nb_pad, device=device, dtype=torch.float32)
+            self.raw, self.g_raw = self.flat[:nb], self.grad[:nb]
+            self.wn_g, self.g_wn_g = self.flat[nb: n], self.grad[nb: n]
+        else:
+            self.eff, self.g_eff = self.flat, self.grad
         self.w, self.b, self.gw, self.gb = {}, {}, {}, {}
-        off = 0
+        self._off, self._g0 = {}, {}
+        off, g0, table = 0, 0, []
         for name, o, i in self.layers:
-            self.w[name], self.gw[name] = self.flat[off: off + o * i].view(o, i), self.grad[off: off + o * i].view(o, i)
+            self.w[name], self.gw[name] = self.eff[off: off + o * i].view(o, i), self.g_eff[off: off + o * i].view(o, i)
+            self._off[name], self._g0[name] = off, g0
+            table.append((off, o, i, g0))
             off += o * i
-            self.b[name], self.gb[name] = self.flat[off: off + o], self.grad[off: off + o]
+            g0 += o
+            self.b[name], self.gb[name] = self.eff[off: off + o], self.g_eff[off: off + o]
             off += o
+        if self.weight_norm:
+            self._wn_table = ops.weight_norm_layers(table)
+
+    def refresh(self):
+        if self.weight_norm:
+            ops.weight_norm_fwd(self.raw, self.wn_g, self._wn_table, self.eff[: self.n_block])
+
+    def fold_grads(self, zero: bool = True):
+        if self.weight_norm:
+            ops.weight_norm_bwd(self.raw, self.wn_g, self.g_eff[: self.n_block], self._wn_table, self.g_raw, self.g_wn_g,
+                                zero_d_eff=zero)
 
     def load(self, sd: Dict[str, torch.Tensor]):
-        """sd: reference state dict (keys ``mlp.base.hidden_layers.0.weight`` ...; extra keys ignored)."""
-        for name, _, _ in self.layers:
-            self.w[name].copy_(sd[name + ".weight"].to(self.flat.device, torch.float32))
-            self.b[name].copy_(sd[name + ".bias"].to(self.flat.device, torch.float32))
+        """sd: reference state dict (keys ``mlp.base.hidden_layers.0.weight`` ...; extra keys ignored).  Under weight_norm a
+        layer is given as ``.weight_g`` (rows, 1) + ``.weight_v``, or as a plain ``.weight`` (v = W, g = ||W||_row)."""
+        dev = self.flat.device
+        for name, o, i in self.layers:
+            self.b[name].copy_(sd[name + ".bias"].to(dev, torch.float32))
+            if not self.weight_norm:
+                if name + ".weight_v" in sd:
+                    raise ValueError(f"{name}: weight_g / weight_v given for a field built without weight_norm")
+                self.w[name].copy_(sd[name + ".weight"].to(dev, torch.float32))
+                continue
+            v = (sd[name + ".weight_v"] if name + ".weight_v" in sd else sd[name + ".weight"]).to(dev, torch.float32)
+            g = sd[name + ".weight_g"].to(dev, torch.float32).reshape(-1) if name + ".weight_g" in sd else v.norm(dim=1)
+            off = self._off[name]
+            self.raw[off: off + o * i].copy_(v.reshape(-1))
+            self.raw[off + o * i: off + o * i + o].copy_(self.b[name])
+            self.wn_g[self._g0[name]: self._g0[name] + o].copy_(g)
+        self.refresh()
 
-    def state_dict(self, grad: bool = False) -> Dict[str, torch.Tensor]:
+    def state_dict(self, grad: bool = False, trainable: bool = False) -> Dict[str, torch.Tensor]:
+        """effective (weight, bias) per layer, or their gradients; trainable=True: what the optimiser holds, under the names the
+        reference module's state_dict has (``.weight_g`` / ``.weight_v`` under weight_norm; gradients after fold_grads())"""
         w, b = (self.gw, self.gb) if grad else (self.w, self.b)
         out = {}
-        for name, _, _ in self.layers:
-            out[name + ".weight"], out[name + ".bias"] = w[name], b[name]
+        for name, o, i in self.layers:
+            if trainable and self.weight_norm:
+                raw, gg = (self.g_raw, self.g_wn_g) if grad else (self.raw, self.wn_g)
+                off, g0 = self._off[name], self._g0[name]
+                out[name + ".weight_g"], out[name + ".weight_v"] = gg[g0: g0 + o].view(o, 1), raw[off: off + o * i].view(o, i)
+                out[name + ".bias"] = raw[off + o * i: off + o * i + o]
+            else:
+                out[name + ".weight"], out[name + ".bias"] = w[name], b[name]
         return out
 
 
@@ -87,7 +140,7 @@ class FusedField:
 
     def prep(self):
         """rebuild the weight image from the current parameters"""
-        check(_lib.load().ren_vanilla_prep(_ptr(self.field.flat), self.field.C, self.mode, _ptr(self.image, torch.uint8), _stream()),
+        check(_lib.load().ren_vanilla_prep(_ptr(self.field.eff), self.field.C, self.mode, _ptr(self.image, torch.uint8), _stream()),
               "ren_vanilla_prep")
 
     def new_saved(self, n: int) -> torch.Tensor:
@@ -96,7 +149,7 @@ class FusedField:
     def forward(self, B, full: bool):
         """B: _Buffers (enc / view / sel filled by the encoder) -> B.sigma, B.rgb4 (full), B.saved (when allocated)"""
         check(_lib.load().ren_vanilla_fwd(_ptr(B.enc), 64, _ptr(B.view) if full else None, 32, _ptr(B.sel, torch.uint8),
-                                          _ptr(self.field.flat), self.field.C, _ptr(self.image, torch.uint8), self.mode, B.n,
+                                          _ptr(self.field.eff), self.field.C, _ptr(self.image, torch.uint8), self.mode, B.n,
                                           _ptr(B.saved, torch.uint8) if (full and B.saved is not None) else None, _ptr(B.sigma),
                                           _ptr(B.rgb4) if full else None, _stream()), "ren_vanilla_fwd")
 
@@ -124,7 +177,7 @@ class FusedField:
             self._ws = torch.empty(need, device=B.enc.device, dtype=torch.float32)
         check(lib.ren_vanilla_bwd_weight(_ptr(dz, torch.uint8), B.saved.data_ptr() + off, stride, _ptr(B.enc[s0:]), 64,
                                          _ptr(B.view[s0:]), 32, _ptr(dz_rgb[s0:]), _ptr(dz_sig[s0:]), self.field.C, self.mode, m,
-                                         splits, _ptr(self.field.grad), _ptr(self._ws), _stream()), "ren_vanilla_bwd_weight")
+                                         splits, _ptr(self.field.g_eff), _ptr(self._ws), _stream()), "ren_vanilla_bwd_weight")
 
     def decode(self, saved: torch.Tensor, n: int) -> List[torch.Tensor]:
         """fragment layout -> ten row-major (n, 256) float32 tensors: slots 0-7 hidden layers, 8 bottleneck, 9 colour hidden

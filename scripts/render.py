@@ -82,7 +82,7 @@ def main():
     C = int(sd[cli.PREFIX + ("mlp.rgb_layer.output_layer.bias" if arch == "mlp" else cli.NGP_KEYS["head.bo"])].numel())
     if arch == "mlp":
         from robust_e_nerf_amd import vanilla
-        fld = vanilla.VanillaField(dev, C)
+        fld = vanilla.VanillaField(dev, C, weight_norm=cli.weight_norm_flags(ncfg, arch))
         cli.load_field_state_dict(fld, arch, sd)
         r = vanilla.VanillaRenderer(fld, rcfg)
     else:

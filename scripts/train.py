@@ -45,7 +45,7 @@ def field_state_dict(fld, arch, aabb):
     if arch == "mlp":
         buf[PREFIX + "posi_encoder.scales"] = torch.tensor([2 ** i for i in range(10)])
         buf[PREFIX + "view_encoder.scales"] = torch.tensor([2 ** i for i in range(4)])
-        return dict(buf, **{PREFIX + k: v.detach().cpu().clone() for k, v in fld.state_dict().items()})
+        return dict(buf, **{PREFIX + k: v.detach().cpu().clone() for k, v in fld.state_dict(trainable=True).items()})
     sd = dict(buf, **{PREFIX + NGP_KEYS["hash"]: fld.table.detach().cpu().clone()})
     for k, v in fld.trainable_views().items():               # weight_norm: "<layer>.weight_g" / ".weight_v" (ngp.py:207-228)
         name = NGP_KEYS[k[:-2]] + k[-2:] if k[-2:] in ("_g", "_v") else NGP_KEYS[k]
@@ -99,8 +99,10 @@ def activation_fields(ncfg, arch) -> dict:
 
 
 def weight_norm_flags(ncfg, arch):
-    """(mlp_base.weight_norm, mlp_head.weight_norm) of model.nerf.ngp"""
-    g = (ncfg.get("ngp") or {}) if arch == "ngp" else {}
+    """(mlp_base.weight_norm, mlp_head.weight_norm) of model.nerf.ngp; arch mlp: model.nerf.mlp.weight_norm (one flag)"""
+    if arch == "mlp":
+        return bool((ncfg.get("mlp") or {}).get("weight_norm", False))
+    g = ncfg.get("ngp") or {}
     return (bool((g.get("mlp_base") or {}).get("weight_norm", False)), bool((g.get("mlp_head") or {}).get("weight_norm", False)))
 
 
@@ -116,8 +118,8 @@ def check_supported(ncfg, arch):
                 if got[k] not in NGP_ACTIVATIONS[tuple(path[1:] + [k])]:
                     raise NotImplementedError(f"model.nerf.{'.'.join(path + [k])} = {got[k]!r}: one of "
                                               f"{NGP_ACTIVATIONS[tuple(path[1:] + [k])]} (models/nerf.py:17-29)")
-            elif arch == "ngp" and k == "weight_norm" and isinstance(got[k], bool):
-                continue                                        # a reparametrisation of the trainable block (NGPField.weight_norm)
+            elif k == "weight_norm" and isinstance(got[k], bool):
+                continue                                        # a reparametrisation of the trainable block (NGPField / VanillaField)
             elif got[k] != v:
                 raise NotImplementedError(f"model.nerf.{'.'.join(path + [k])} = {got[k]!r}: the MI355X kernels implement {v!r} only")
     walk(SUPPORTED[arch], ncfg.get(arch) or {}, [arch])
@@ -219,7 +221,7 @@ def main():
     C = 3 if "channel_idx" in events else 1                 # Bayer sensor -> radiance_dim 3 (robust_e_nerf.py:230-233)
     if arch == "mlp":
         from robust_e_nerf_amd import vanilla
-        fld = vanilla.VanillaField(dev, C)
+        fld = vanilla.VanillaField(dev, C, weight_norm=weight_norm_flags(ncfg, arch))
         fld.load({k: v for name, o, i in vanilla.layer_shapes(C) for k, v in zip((name + ".weight", name + ".bias"), lin(o, i))})
         renderer = vanilla.VanillaRenderer(fld, rcfg)
     else:

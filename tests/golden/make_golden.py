@@ -472,6 +472,48 @@ def gen_field_mlp(mlp_mod, ngp, nerfacc):
              param_gain=1.6, x=x, d=d, rgb=rgb, sigma=sigma, density=dens, g_rgb=g_rgb, g_sigma=g_sig, **grads, **gsum)
 
 
+def gen_field_mlp_wn(mlp_mod, ngp, nerfacc):
+    """Reference VanillaNeRFRadianceField with weight_norm=True (external/mlp.py:303-319): v from the seeded parameters, g =
+    ||v||_row scaled by a stored factor; forward + gradients w.r.t. weight_g (whole) / weight_v, bias (samples + |.| sums)."""
+    from oracle import vanilla
+    aabb = [-1.5] * 3 + [1.5] * 3
+    torch.manual_seed(13)
+    rf = mlp_mod.VanillaNeRFRadianceField(
+        aabb=aabb, num_dim=3, contraction_type=nerfacc.ContractionType.AABB, radiance_dim=1,
+        hidden_activation=torch.nn.Softplus(beta=100), density_activation=ngp.shifted_trunc_exp,
+        radiance_activation=torch.nn.Softplus(beta=1), net_depth=8, net_width=256, skip_layer=4, net_depth_condition=1,
+        net_width_condition=128, pos_encoder_max_deg=10, view_encoder_max_deg=4, weight_norm=True)
+    seed = 22
+    params = vanilla.init_params(seed, C=1, gain=1.6)
+    sd = rf.state_dict()
+    new, g_all = {}, {}
+    for k, v in params.items():
+        if k.endswith(".weight"):
+            g = v.norm(dim=1, keepdim=True) * (0.7 + 0.6 * torch.rand(v.shape[0], 1))
+            new[k + "_v"], new[k + "_g"] = v, g
+            g_all["wg." + k[: -len(".weight")]] = g
+        else:
+            new[k] = v
+    assert set(new) == {k for k in sd if k.startswith("mlp.")}, sorted(set(sd) ^ set(new))
+    rf.load_state_dict({**sd, **new})
+    n = 160
+    x = (torch.rand(n, 3) - 0.5) * 1.2 * 3.0
+    d = torch.randn(n, 3)
+    d = d / d.norm(dim=-1, keepdim=True)
+    rgb, sigma = rf(x, d)
+    g_rgb, g_sig = torch.randn_like(rgb), torch.randn_like(sigma)
+    rf.zero_grad()
+    ((rgb * g_rgb).sum() + (sigma * g_sig).sum()).backward()
+    grads, gsum = {}, {}
+    for k, v in rf.named_parameters():
+        g = v.grad.reshape(-1)
+        pick = torch.arange(g.numel()) if k.endswith("weight_g") else torch.linspace(0, g.numel() - 1, min(64, g.numel())).long()
+        grads["gi." + k], grads["gv." + k] = pick, g[pick]
+        gsum["gs." + k] = g.double().abs().sum()
+    save("field_mlp_wn", aabb=np.array(aabb, np.float32), contraction_type=0, param_seed=seed, param_gain=1.6, x=x, d=d,
+         rgb=rgb, sigma=sigma, g_rgb=g_rgb, g_sigma=g_sig, **g_all, **grads, **gsum)
+
+
 def gen_sh(sh_encoder):
     torch.manual_seed(20)
     d = torch.randn(256, 3)
@@ -972,6 +1014,8 @@ def main():
     if sys.argv[1:] == ["field_acts"]:
         return gen_field_acts(ngp, nerf_mod, nerfacc)
     if sys.argv[1:] == ["field_wn"]:
+        from robust_e_nerf.external import mlp as mlp_mod
+        gen_field_mlp_wn(mlp_mod, ngp, nerfacc)
         return gen_field_wn(ngp, nerfacc)
     if sys.argv[1:] == ["eval_dataset"]:
         from robust_e_nerf.data import datasets as datasets_mod
@@ -985,6 +1029,7 @@ def main():
     gen_field_wn(ngp, nerfacc)
     from robust_e_nerf.external import mlp as mlp_mod
     gen_field_mlp(mlp_mod, ngp, nerfacc)
+    gen_field_mlp_wn(mlp_mod, ngp, nerfacc)
     mods = (rmod, nerf_mod, trajectories, egp, loss_mod, nerfacc)
     gen_training_step(mods, with_grad_loss=False)
     gen_training_step(mods, with_grad_loss=True)

@@ -152,9 +152,9 @@ def test_cli_rejects_unsupported_hyperparameters():
     ncfg["mlp"]["net_width"] = 128
     with pytest.raises(NotImplementedError):
         cli.check_supported(ncfg, "mlp")
-    ncfg["mlp"] = {"net_width": 256, "weight_norm": True}              # arch mlp: not built
-    with pytest.raises(NotImplementedError):
-        cli.check_supported(ncfg, "mlp")
+    ncfg["mlp"] = {"net_width": 256, "weight_norm": True}              # arch mlp: one flag for the whole MLP (mlp.py:303-319)
+    cli.check_supported(ncfg, "mlp")
+    assert cli.weight_norm_flags(ncfg, "mlp") is True
 
 
 def test_scripts_and_tools_compile():

@@ -337,3 +337,29 @@ def test_field_weight_norm(tag, full_table_cache):
             assert rel_err(v.grad, g["g." + k]) < 1e-4, k
     idx = t(g["g_table_idx"])
     assert rel_err(raw["hash"].grad[idx], g["g_table_val"]) < 1e-4
+
+
+def _vanilla_wn_raw(g):
+    """seeded v + the fixture's g -> the weight-normalised parameter dict (reference state-dict names)"""
+    from oracle import vanilla
+    raw = {}
+    for k, v in vanilla.init_params(int(g["param_seed"]), 1, float(g["param_gain"])).items():
+        if k.endswith(".weight"):
+            raw[k + "_v"], raw[k + "_g"] = v, t(g["wg." + k[: -len(".weight")]])
+        else:
+            raw[k] = v
+    return raw
+
+
+def test_vanilla_field_weight_norm():
+    """arch mlp with weight_norm=True (mlp.py:303-319): the oracle's helper vs the reference module (fixture field_mlp_wn.npz)"""
+    from oracle import vanilla
+    g = load_golden("field_mlp_wn")
+    raw = {k: v.clone().requires_grad_() for k, v in _vanilla_wn_raw(g).items()}
+    rgb, sigma = vanilla.forward(vanilla.weight_norm_params(raw), t(g["x"]), t(g["d"]), t(g["aabb"]), 0)
+    assert rel_err(rgb, g["rgb"]) < 2e-6 and rel_err(sigma, g["sigma"]) < 2e-6
+    ((rgb * t(g["g_rgb"])).sum() + (sigma * t(g["g_sigma"])).sum()).backward()
+    for k, v in raw.items():
+        gr = v.grad.reshape(-1)
+        assert rel_err(gr[t(g["gi." + k])], g["gv." + k]) < 2e-5, k
+        assert abs(float(gr.double().abs().sum()) - float(g["gs." + k])) < 2e-5 * float(g["gs." + k]) + 1e-12, k
