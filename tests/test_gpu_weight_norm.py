@@ -294,3 +294,28 @@ def test_module_seam_alternatives_vs_reference_golden(amd, fixture, tag, full_ta
     ((rgb2 * dev(g["g_rgb"])).sum() + (sigma2 * dev(g["g_sigma"])).sum()).backward()
     for name, ref in want_grad.items():
         assert rel_err(params[name].grad.cpu(), ref) < 1e-3, name
+
+
+def test_weight_norm_fold_is_linear_in_the_block_gradient(amd):
+    """Data parallelism sums the FOLDED gradients of the ranks (Trainer.optimizer_step: fold_grads() before the all-reduce):
+    that equals the fold of the summed block gradient because the fold is linear for fixed (v, g) -- checked on two random
+    block gradients, for both architectures' layer tables."""
+    from robust_e_nerf_amd import vanilla
+    ops, engine = amd
+    gen = torch.Generator(device=DEV).manual_seed(9)
+    for fld, raw, eff_g, folded in (
+            (engine.NGPField(DEV, 3, weight_norm=(True, True)), "mlp_raw", "g_mlp", lambda f: f.grad[f.n_table: f.n_params]),
+            (vanilla.VanillaField(DEV, 1, weight_norm=True), "raw", "g_eff", lambda f: f.grad[: f.n_params])):
+        getattr(fld, raw).copy_(torch.randn(getattr(fld, raw).shape, device=DEV, generator=gen))
+        fld.wn_g.copy_(torch.rand(fld.wn_g.shape, device=DEV, generator=gen) + 0.5)
+        fld.refresh()
+        ge = getattr(fld, eff_g)[: getattr(fld, raw).numel()]               # (the vanilla block is padded to a multiple of 4)
+        g1, g2 = (torch.randn(ge.shape, device=DEV, generator=gen) for _ in range(2))
+        outs = []
+        for gin in (g1, g2, g1 + g2):
+            ge.copy_(gin)
+            fld.fold_grads()
+            assert float(ge.abs().max()) == 0.0
+            outs.append(folded(fld).clone())
+        assert rel_err(outs[0] + outs[1], outs[2]) < 1e-5
+        assert float(outs[2].abs().max()) > 0.0
