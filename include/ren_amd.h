@@ -558,6 +558,14 @@ int ren_composite_fwd_jvp2(const int64_t *offsets, const int32_t *counts, int64_
 #define REN_ACT_SOFTPLUS100 1          /* Softplus(beta=100), models/nerf.py:17-29          */
 #define REN_ACT_SOFTPLUS1 2            /* Softplus(beta=1)                                  */
 #define REN_ACT_TRUNC_EXP_SEL 3        /* selector * exp(z - 1), external/ngp.py:45-65, mlp.py:343 */
+/* the YAML's alternatives (models/nerf.py:8-29); backward-data takes REN_ACT_RELU as a previous-layer activation too.  The
+ * output-head kernels of arch mlp (ren_vanilla_heads_*) differentiate the density / radiance kinds of REN_KNOB_ACTIVATIONS;
+ * the tangent algebra (ren_act_jvp*) takes beta = 0 for relu.  The fused field (ren_vanilla_fwd / _bwd) implements the
+ * shipped set only and returns REN_ERR_UNSUPPORTED under a non-zero REN_KNOB_ACTIVATIONS. */
+#define REN_ACT_RELU 4
+#define REN_ACT_SIGMOID 5
+#define REN_ACT_SOFTPLUS1_SEL 6        /* selector * softplus(z)                            */
+#define REN_ACT_SHIFTED_SOFTPLUS1_SEL 7 /* selector * softplus(z - 1), models/nerf.py:8-13  */
 /* SinusoidalEncoder of the contracted position (63 features -> enc[:, :64], col 63 = 0; optional copy at
  * cat[:, cat_col:cat_col+64]) and of pi*direction (27 features, padded to 32, at view[:, view_col:]);
  * selector[i] = all(0 < contracted x < 1).  Positions from x_world/dirs or from the packed sample stream. */

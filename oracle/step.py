@@ -33,7 +33,7 @@ class SceneCfg:
     bkgd_is_param: bool = True                              # alpha_over_white_bg
     sampler: str = "occgrid"                                # "occgrid" | "uniform"
     n_uniform: int = 64
-    acts: Optional[dict] = None                             # activation alternatives (field.DEFAULT_ACTS keys), arch ngp
+    acts: Optional[dict] = None                             # activation alternatives (field.DEFAULT_ACTS keys)
 
 
 def render_rays(o, d, p: Dict[str, torch.Tensor], spec, cfg: SceneCfg, *,
@@ -51,13 +51,13 @@ def render_rays(o, d, p: Dict[str, torch.Tensor], spec, cfg: SceneCfg, *,
     def sigma_fn(ts, te, ri):
         if arch_mlp:
             from . import vanilla
-            return vanilla.forward(p, positions(ts, te, ri), None, aabb, cfg.contraction_type, density_only=True)
+            return vanilla.forward(p, positions(ts, te, ri), None, aabb, cfg.contraction_type, density_only=True, acts=cfg.acts)
         return field.query_density(positions(ts, te, ri), p, spec, aabb, cfg.contraction_type, acts=cfg.acts)
 
     def rgb_sigma_fn(ts, te, ri):
         if arch_mlp:
             from . import vanilla
-            return vanilla.forward(p, positions(ts, te, ri), d[ri], aabb, cfg.contraction_type)
+            return vanilla.forward(p, positions(ts, te, ri), d[ri], aabb, cfg.contraction_type, acts=cfg.acts)
         return field.field_forward(positions(ts, te, ri), d[ri], p, spec, aabb, cfg.contraction_type, acts=cfg.acts)
 
     scene_aabb = aabb if cfg.contraction_type == field.AABB else None   # nerf.py:248-251

@@ -65,27 +65,29 @@ def sinusoidal(x: torch.Tensor, deg: int) -> torch.Tensor:            # mlp.py:2
 
 
 def forward(p: Dict[str, torch.Tensor], x: torch.Tensor, dirs, aabb: torch.Tensor, contraction_type: int,
-            density_only: bool = False):
-    """-> (rgb (n, C), sigma (n, 1)) or sigma only.  mlp.py:321-358."""
+            density_only: bool = False, acts=None):
+    """-> (rgb (n, C), sigma (n, 1)) or sigma only.  mlp.py:321-358.  acts: activation alternatives (models/nerf.py:8-29) as
+    dict(base_hidden = the one hidden activation of this architecture, density, radiance); absent keys: the shipped set."""
+    a = dict(ofield.DEFAULT_ACTS, **(acts or {}))
     u = ofield.contract(x, aabb, contraction_type)
     selector = ((u > 0.0) & (u < 1.0)).all(dim=-1)
     enc = sinusoidal(2 * math.pi * (u - 0.5), POS_DEG)
     h = enc
     for i in range(DEPTH):                                             # mlp.py:99-113
         h = torch.nn.functional.linear(h, p[f"mlp.base.hidden_layers.{i}.weight"], p[f"mlp.base.hidden_layers.{i}.bias"])
-        h = ofield.softplus(h, 100.0)
+        h = ofield._hidden(h, a["base_hidden"])
         if i % SKIP == 0 and i > 0:
             h = torch.cat([h, enc], dim=-1)
     raw_sigma = torch.nn.functional.linear(h, p["mlp.sigma_layer.output_layer.weight"], p["mlp.sigma_layer.output_layer.bias"])
-    sigma = ofield.shifted_trunc_exp(raw_sigma) * selector[..., None]
+    sigma = ofield._density(raw_sigma, a["density"]) * selector[..., None]
     if density_only:
         return sigma
     bott = torch.nn.functional.linear(h, p["mlp.bottleneck_layer.output_layer.weight"], p["mlp.bottleneck_layer.output_layer.bias"])
     cond = sinusoidal(dirs * math.pi, VIEW_DEG)
     r = torch.cat([bott, cond], dim=-1)
-    r = ofield.softplus(torch.nn.functional.linear(r, p["mlp.rgb_layer.hidden_layers.0.weight"], p["mlp.rgb_layer.hidden_layers.0.bias"]), 100.0)
+    r = ofield._hidden(torch.nn.functional.linear(r, p["mlp.rgb_layer.hidden_layers.0.weight"], p["mlp.rgb_layer.hidden_layers.0.bias"]), a["base_hidden"])
     raw_rgb = torch.nn.functional.linear(r, p["mlp.rgb_layer.output_layer.weight"], p["mlp.rgb_layer.output_layer.bias"])
-    return ofield.softplus(raw_rgb, 1.0), sigma
+    return ofield._radiance(raw_rgb, a["radiance"]), sigma
 
 
 def weight_norm_params(p):

@@ -17,6 +17,26 @@
 namespace {
 
 constexpr int ACT_NONE = 0, ACT_SOFTPLUS100 = 1, ACT_SOFTPLUS1 = 2, ACT_TRUNC_EXP_SEL = 3;
+// the YAML's alternatives (models/nerf.py:8-29): relu hidden layers, sigmoid radiance, softplus / shifted_softplus densities
+constexpr int ACT_RELU = 4, ACT_SIGMOID = 5, ACT_SOFTPLUS1_SEL = 6, ACT_SHIFTED_SOFTPLUS1_SEL = 7, ACT_LAST = 7;
+__device__ __forceinline__ bool act_uses_sel(int act) { return act == ACT_TRUNC_EXP_SEL || act >= ACT_SOFTPLUS1_SEL; }
+__device__ __forceinline__ float dense_act(float z, int act, bool selv) {
+    if (act == ACT_SOFTPLUS100) return softplus100(z);
+    if (act == ACT_SOFTPLUS1) return softplus1(z);
+    if (act == ACT_TRUNC_EXP_SEL) return selv ? __expf(z - 1.f) : 0.f;                            // ngp.py:45-65
+    if (act == ACT_RELU) return fmaxf(z, 0.f);
+    if (act == ACT_SIGMOID) return 1.f / (1.f + __expf(-z));
+    if (act == ACT_SOFTPLUS1_SEL) return selv ? softplus1(z) : 0.f;
+    if (act == ACT_SHIFTED_SOFTPLUS1_SEL) return selv ? softplus1(z - 1.f) : 0.f;                  // nerf.py:8-13
+    return z;
+}
+// derivative of a hidden activation through its OUTPUT (backward-data epilogue, tangent algebra)
+__device__ __forceinline__ bool act_has_dout(int act) { return act == ACT_SOFTPLUS100 || act == ACT_RELU; }
+__device__ __forceinline__ float dense_dact_from_out(float y, int act) {
+    return act == ACT_RELU ? (y > 0.f ? 1.f : 0.f) : dsoftplus_from_out(y, 100.f);
+}
+// beta of the tangent-algebra launches: 0 selects relu (s = [y > 0], s' = 0 falls out of beta s (1 - s))
+__device__ __forceinline__ float dact_beta(float y, float beta) { return beta == 0.f ? (y > 0.f ? 1.f : 0.f) : dsoftplus_from_out(y, beta); }
 constexpr int KC = 32;                                 // reduction chunk staged in LDS
 
 struct DenseArgs {
@@ -70,7 +90,7 @@ template <int NT, bool BWD>
 __device__ __forceinline__ void dense_epilogue(const DenseArgs &a, f32x16 (&acc)[NT], bool active, int64_t row, int hi) {
     if (!active || row >= ((a.n + 31) & ~(int64_t)31)) return;
     const bool live = row < a.n;
-    const bool selv = (!BWD && a.act == ACT_TRUNC_EXP_SEL && live) ? a.sel[row] != 0 : false;
+    const bool selv = (!BWD && act_uses_sel(a.act) && live) ? a.sel[row] != 0 : false;
     // epilogue in two halves of NT/2 tiles: all loads of a half (saved activations / accumulate target) are
     // issued as float4 before any arithmetic, so their latencies overlap instead of queueing per element
     constexpr int HT = NT > 1 ? NT / 2 : 1;
@@ -84,7 +104,7 @@ __device__ __forceinline__ void dense_epilogue(const DenseArgs &a, f32x16 (&acc)
                 for (int q = 0; q < 4; ++q) {
                     const int o0 = a.out0 + (half * HT + u) * 32 + 8 * q + 4 * hi;
                     const bool in = o0 + 3 < a.n_out;                 // n_out is a multiple of 4 on this path (host check)
-                    yp4[u][q] = (in && a.act == ACT_SOFTPLUS100) ? *reinterpret_cast<const float4 *>(a.Yprev + row * a.ldyp + o0)
+                    yp4[u][q] = (in && act_has_dout(a.act)) ? *reinterpret_cast<const float4 *>(a.Yprev + row * a.ldyp + o0)
                                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
                     yo4[u][q] = (in && a.accumulate) ? *reinterpret_cast<const float4 *>(a.Y + row * a.ldy + o0)
                                                      : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -104,12 +124,10 @@ __device__ __forceinline__ void dense_epilogue(const DenseArgs &a, f32x16 (&acc)
                 for (int j = 0; j < 4; ++j) {
                     float z = acc[t][4 * q + j];
                     if (!BWD) {
-                        if (a.act == ACT_SOFTPLUS100) z = softplus100(z);
-                        else if (a.act == ACT_SOFTPLUS1) z = softplus1(z);
-                        else if (a.act == ACT_TRUNC_EXP_SEL) z = selv ? __expf(z - 1.f) : 0.f;      // ngp.py:45-65
+                        z = dense_act(z, a.act, selv);
                     } else {
                         z += yo[j];
-                        if (a.act == ACT_SOFTPLUS100) z *= dsoftplus_from_out(yp[j], 100.f);
+                        if (act_has_dout(a.act)) z *= dense_dact_from_out(yp[j], a.act);
                     }
                     v[j] = live ? z : 0.f;
                 }
@@ -455,7 +473,7 @@ __global__ __launch_bounds__(64 * NW, 1) void dense_t_kernel(DenseArgs a) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int64_t row = (blk0 + u) * 32 + 8 * i + rl;
-                    yp4[i] = (whole && a.act == ACT_SOFTPLUS100) ? *reinterpret_cast<const float4 *>(a.Yprev + row * a.ldyp + o0)
+                    yp4[i] = (whole && act_has_dout(a.act)) ? *reinterpret_cast<const float4 *>(a.Yprev + row * a.ldyp + o0)
                                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
                     yo4[i] = (whole && a.accumulate) ? *reinterpret_cast<const float4 *>(a.Y + row * a.ldy + o0)
                                                      : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -469,18 +487,16 @@ __global__ __launch_bounds__(64 * NW, 1) void dense_t_kernel(DenseArgs a) {
                 const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
                 const float yp[4] = {yp4[i].x, yp4[i].y, yp4[i].z, yp4[i].w};
                 const float yo[4] = {yo4[i].x, yo4[i].y, yo4[i].z, yo4[i].w};
-                const bool selv = (!BWD && a.act == ACT_TRUNC_EXP_SEL && live) ? a.sel[row] != 0 : false;
+                const bool selv = (!BWD && act_uses_sel(a.act) && live) ? a.sel[row] != 0 : false;
                 float v[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float z = zz[j];
                     if (!BWD) {
-                        if (a.act == ACT_SOFTPLUS100) z = softplus100(z);
-                        else if (a.act == ACT_SOFTPLUS1) z = softplus1(z);
-                        else if (a.act == ACT_TRUNC_EXP_SEL) z = selv ? __expf(z - 1.f) : 0.f;
+                        z = dense_act(z, a.act, selv);
                     } else {
                         z += yo[j];
-                        if (a.act == ACT_SOFTPLUS100) z *= dsoftplus_from_out(yp[j], 100.f);
+                        if (act_has_dout(a.act)) z *= dense_dact_from_out(yp[j], a.act);
                     }
                     v[j] = live ? z : 0.f;
                 }
@@ -797,18 +813,41 @@ __global__ __launch_bounds__(256) void freq_encode_kernel(EncArgs a) {
     }
 }
 
-// ---- output activations, backward:  dz_rgb = g_rgb softplus1'(rgb),  dz_sigma = g_sigma exp(min(z - 1, 15)) sel --
+// first / second derivative of the output activations through their OUTPUTS.  dn / rd: density / radiance kind of the
+// activation code (ren_mlp_common.h act_kinds; 0 = shifted_trunc_exp / softplus, the shipped configs).
+// density: sigma = sel phi(z).  trunc_exp: phi' = min(sigma, e^15) (ngp.py:45-65), phi'' = sigma below the clamp, 0 above;
+// softplus kinds: phi' = 1 - exp(-sigma) (0 where sel = 0, as it must be), phi'' = phi' (1 - phi').
+__device__ __forceinline__ void head_density_d(float sg, int dn, float &p1, float &p2) {
+    if (dn == 0) {
+        const float E15 = 3269017.3724721107f;
+        p1 = fminf(sg, E15); p2 = sg < E15 ? sg : 0.f;
+    } else {
+        p1 = dsoftplus_from_out(sg, 1.f); p2 = p1 * (1.f - p1);
+    }
+}
+__device__ __forceinline__ void head_radiance_d(float y, int rd, float &r1, float &r2) {
+    if (rd == 1) { r1 = y * (1.f - y); r2 = r1 * (1.f - 2.f * y); }          // sigmoid
+    else { r1 = dsoftplus_from_out(y, 1.f); r2 = r1 * (1.f - r1); }
+}
+
+// ---- output activations, backward:  dz_rgb = g_rgb act'(rgb),  dz_sigma = g_sigma phi'(sigma) ------------------------
 __global__ __launch_bounds__(256) void heads_bwd_kernel(const float *__restrict__ g_rgb, const float *__restrict__ rgb,
                                                         const float *__restrict__ g_sigma,
                                                         const float *__restrict__ sigma, int64_t n, int64_t n_pad, int C,
-                                                        float *__restrict__ dz_rgb, float *__restrict__ dz_sigma) {
+                                                        int dn, int rd, float *__restrict__ dz_rgb, float *__restrict__ dz_sigma) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_pad) return;
     float4 *zr = reinterpret_cast<float4 *>(dz_rgb + i * 32), *zs = reinterpret_cast<float4 *>(dz_sigma + i * 32);
     float r[4] = {0.f, 0.f, 0.f, 0.f}, s0 = 0.f;
     if (i < n) {
-        for (int c = 0; c < C; ++c) r[c] = g_rgb[i * C + c] * dsoftplus_from_out(rgb[i * C + c], 1.f);
-        s0 = g_sigma[i] * fminf(sigma[i], 3269017.3724721107f);                 // sigma = sel exp(z-1); d/dz clamps at e^15
+        for (int c = 0; c < C; ++c) {
+            float r1, r2;
+            head_radiance_d(rgb[i * C + c], rd, r1, r2);
+            r[c] = g_rgb[i * C + c] * r1;
+        }
+        float p1, p2;
+        head_density_d(sigma[i], dn, p1, p2);
+        s0 = g_sigma[i] * p1;
     }
     zr[0] = make_float4(r[0], r[1], r[2], r[3]);
     zs[0] = make_float4(s0, 0.f, 0.f, 0.f);
@@ -828,8 +867,8 @@ __global__ __launch_bounds__(256) void act_jvp_fwd_kernel(const float *__restric
     const int c = (int)(e - r * width4) * 4;
     const float4 y = *reinterpret_cast<const float4 *>(Y + r * ldy + c), zd = *reinterpret_cast<const float4 *>(Zd + r * ldz + c);
     float4 o;
-    o.x = zd.x * dsoftplus_from_out(y.x, beta); o.y = zd.y * dsoftplus_from_out(y.y, beta);
-    o.z = zd.z * dsoftplus_from_out(y.z, beta); o.w = zd.w * dsoftplus_from_out(y.w, beta);
+    o.x = zd.x * dact_beta(y.x, beta); o.y = zd.y * dact_beta(y.y, beta);
+    o.z = zd.z * dact_beta(y.z, beta); o.w = zd.w * dact_beta(y.w, beta);
     *reinterpret_cast<float4 *>(Yd + r * ldyd + c) = o;
 }
 
@@ -849,7 +888,7 @@ __global__ __launch_bounds__(256) void act_jvp_bwd_kernel(const float *__restric
     float gz[4], gzd[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const float sj = dsoftplus_from_out(y[j], beta);
+        const float sj = dact_beta(y[j], beta);
         gz[j] = gy[j] * sj + gd[j] * zd[j] * (beta * sj * (1.f - sj));
         gzd[j] = gd[j] * sj;
     }
@@ -873,7 +912,7 @@ __global__ __launch_bounds__(256) void act_jvp2_fwd_kernel(const float *__restri
     float od[4], oe[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const float sj = dsoftplus_from_out(y[j], beta);
+        const float sj = dact_beta(y[j], beta);
         od[j] = sj * zd[j];
         oe[j] = beta * sj * (1.f - sj) * zd[j] * zd[j] + sj * ze[j];
     }
@@ -888,19 +927,22 @@ __global__ __launch_bounds__(256) void act_jvp2_fwd_kernel(const float *__restri
 __global__ __launch_bounds__(256) void heads_jvp_kernel(const float *__restrict__ rgb, const float *__restrict__ sigma,
                                                         const float *__restrict__ zod, const float *__restrict__ zodd,
                                                         const float *__restrict__ zsd, const float *__restrict__ zsdd,
-                                                        int64_t n, int C, float *__restrict__ rgbd, float *__restrict__ rgbdd,
-                                                        float *__restrict__ sigmad, float *__restrict__ sigmadd) {
+                                                        int64_t n, int C, int dn, int rd, float *__restrict__ rgbd,
+                                                        float *__restrict__ rgbdd, float *__restrict__ sigmad,
+                                                        float *__restrict__ sigmadd) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float E15 = 3269017.3724721107f;
-    const float sg = sigma[i], p1 = fminf(sg, E15), p2 = sg < E15 ? sg : 0.f;
+    float p1, p2;
+    head_density_d(sigma[i], dn, p1, p2);
     const float d = zsd[4 * i];
     sigmad[i] = p1 * d;
     if (sigmadd) sigmadd[i] = p2 * d * d + p1 * zsdd[4 * i];
     for (int c = 0; c < C; ++c) {
-        const float s = dsoftplus_from_out(rgb[i * C + c], 1.f), zd = zod[4 * i + c];
+        float s, s2;
+        head_radiance_d(rgb[i * C + c], rd, s, s2);
+        const float zd = zod[4 * i + c];
         rgbd[i * C + c] = s * zd;
-        if (rgbdd) rgbdd[i * C + c] = s * (1.f - s) * zd * zd + s * zodd[4 * i + c];
+        if (rgbdd) rgbdd[i * C + c] = s2 * zd * zd + s * zodd[4 * i + c];
     }
 }
 
@@ -910,27 +952,28 @@ __global__ __launch_bounds__(256) void heads_bwd_jvp_kernel(const float *__restr
                                                             const float *__restrict__ g_sigma, const float *__restrict__ g_sigmad,
                                                             const float *__restrict__ rgb, const float *__restrict__ sigma,
                                                             const float *__restrict__ zod, const float *__restrict__ zsd,
-                                                            int64_t n, int64_t n_pad, int C, float *__restrict__ dz_rgb,
-                                                            float *__restrict__ dzd_rgb, float *__restrict__ dz_sigma,
-                                                            float *__restrict__ dzd_sigma) {
+                                                            int64_t n, int64_t n_pad, int C, int dn, int rd,
+                                                            float *__restrict__ dz_rgb, float *__restrict__ dzd_rgb,
+                                                            float *__restrict__ dz_sigma, float *__restrict__ dzd_sigma) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_pad) return;
-    float r[4] = {0.f, 0.f, 0.f, 0.f}, rd[4] = {0.f, 0.f, 0.f, 0.f}, s0 = 0.f, sd0 = 0.f;
+    float r[4] = {0.f, 0.f, 0.f, 0.f}, rdv[4] = {0.f, 0.f, 0.f, 0.f}, s0 = 0.f, sd0 = 0.f;
     if (i < n) {
         for (int c = 0; c < C; ++c) {
-            const float s = dsoftplus_from_out(rgb[i * C + c], 1.f);
-            r[c] = g_rgb[i * C + c] * s + g_rgbd[i * C + c] * zod[4 * i + c] * s * (1.f - s);
-            rd[c] = g_rgbd[i * C + c] * s;
+            float s, s2;
+            head_radiance_d(rgb[i * C + c], rd, s, s2);
+            r[c] = g_rgb[i * C + c] * s + g_rgbd[i * C + c] * zod[4 * i + c] * s2;
+            rdv[c] = g_rgbd[i * C + c] * s;
         }
-        const float E15 = 3269017.3724721107f;
-        const float sg = sigma[i], p1 = fminf(sg, E15), p2 = sg < E15 ? sg : 0.f;
+        float p1, p2;
+        head_density_d(sigma[i], dn, p1, p2);
         s0 = g_sigma[i] * p1 + g_sigmad[i] * zsd[4 * i] * p2;
         sd0 = g_sigmad[i] * p1;
     }
     float4 *o[4] = {reinterpret_cast<float4 *>(dz_rgb + i * 32), reinterpret_cast<float4 *>(dzd_rgb + i * 32),
                     reinterpret_cast<float4 *>(dz_sigma + i * 32), reinterpret_cast<float4 *>(dzd_sigma + i * 32)};
     o[0][0] = make_float4(r[0], r[1], r[2], r[3]);
-    o[1][0] = make_float4(rd[0], rd[1], rd[2], rd[3]);
+    o[1][0] = make_float4(rdv[0], rdv[1], rdv[2], rdv[3]);
     o[2][0] = make_float4(s0, 0.f, 0.f, 0.f);
     o[3][0] = make_float4(sd0, 0.f, 0.f, 0.f);
     for (int q = 0; q < 4; ++q)
@@ -1000,6 +1043,14 @@ int launch_dense(DenseArgs a, int tiles, int mode, hipStream_t st) {
     REN_CHECK_LAUNCH();
 }
 
+// density / radiance kinds of the process-wide activation code (REN_KNOB_ACTIVATIONS): what the output-head kernels of
+// arch mlp differentiate.  0 / 0 = the shipped configs.
+struct ActKindsHost { int dn, rd; };
+inline ActKindsHost act_kinds_host() {
+    const int code = ren_knob(REN_KNOB_ACTIVATIONS);
+    return ActKindsHost{(code >> 2) & 3, (code >> 6) & 3};
+}
+
 inline int tiles_for(int n_out) { return n_out <= 32 ? 1 : n_out <= 64 ? 2 : n_out <= 128 ? 4 : n_out <= 256 ? 8 : -1; }
 
 }  // namespace
@@ -1031,7 +1082,7 @@ extern "C" int ren_dense_fwd(const float *X, int32_t ldx, const float *W, const 
     if (mode != 0 && mode != 1 && mode != 6) return REN_ERR_BAD_ARG;
     if (!X || !W || !Y || n < 0 || n_out < 1 || n_in < 1 || (ldx & 3) || (ldy & 3)) return REN_ERR_BAD_ARG;
     if (ldx < ((n_in + KC - 1) / KC) * KC) return REN_ERR_BAD_ARG;           // X rows are read in whole 32-wide chunks
-    if (act < ACT_NONE || act > ACT_TRUNC_EXP_SEL || (act == ACT_TRUNC_EXP_SEL && !selector)) return REN_ERR_BAD_ARG;
+    if (act < ACT_NONE || act > ACT_LAST || ((act == ACT_TRUNC_EXP_SEL || act >= ACT_SOFTPLUS1_SEL) && !selector)) return REN_ERR_BAD_ARG;
     const int tiles = tiles_for(n_out);
     if (tiles < 0) return REN_ERR_UNSUPPORTED;
     if (n == 0) return REN_OK;
@@ -1051,8 +1102,8 @@ extern "C" int ren_dense_bwd_data(const float *dZ, int32_t ldz, const float *W, 
         (n_store & 3) || (Yprev && (ldyp & 3)))
         return REN_ERR_BAD_ARG;
     if (ldz < ((n_out + KC - 1) / KC) * KC) return REN_ERR_BAD_ARG;
-    if (prev_act != ACT_NONE && prev_act != ACT_SOFTPLUS100) return REN_ERR_UNSUPPORTED;
-    if (prev_act == ACT_SOFTPLUS100 && !Yprev) return REN_ERR_BAD_ARG;
+    if (prev_act != ACT_NONE && prev_act != ACT_SOFTPLUS100 && prev_act != ACT_RELU) return REN_ERR_UNSUPPORTED;
+    if (prev_act != ACT_NONE && !Yprev) return REN_ERR_BAD_ARG;
     const int tiles = tiles_for(n_store);
     if (tiles < 0) return REN_ERR_UNSUPPORTED;
     if (n == 0) return REN_OK;
@@ -1126,8 +1177,9 @@ extern "C" int ren_vanilla_heads_bwd(const float *g_rgb, const float *rgb, const
     if (C != 1 && C != 3) return REN_ERR_UNSUPPORTED;
     if (n == 0) return REN_OK;
     const int64_t n_pad = (n + 31) / 32 * 32;
+    const ActKindsHost ak = act_kinds_host();
     hipLaunchKernelGGL(heads_bwd_kernel, dim3(ren_blocks(n_pad, 256)), dim3(256), 0, (hipStream_t)stream, g_rgb, rgb,
-                       g_sigma, sigma, n, n_pad, C, dz_rgb, dz_sigma);
+                       g_sigma, sigma, n, n_pad, C, ak.dn, ak.rd, dz_rgb, dz_sigma);
     REN_CHECK_LAUNCH();
 }
 
@@ -1149,8 +1201,9 @@ extern "C" int ren_vanilla_heads_jvp(const float *rgb, const float *sigma, const
     if ((rgbdd || sigmadd) && (!rgbdd || !sigmadd || !zodd || !zsdd)) return REN_ERR_BAD_ARG;
     if (C != 1 && C != 3) return REN_ERR_UNSUPPORTED;
     if (n == 0) return REN_OK;
+    const ActKindsHost ak = act_kinds_host();
     hipLaunchKernelGGL(heads_jvp_kernel, dim3(ren_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, rgb, sigma, zod, zodd,
-                       zsd, zsdd, n, C, rgbd, rgbdd, sigmad, sigmadd);
+                       zsd, zsdd, n, C, ak.dn, ak.rd, rgbd, rgbdd, sigmad, sigmadd);
     REN_CHECK_LAUNCH();
 }
 
@@ -1164,7 +1217,8 @@ extern "C" int ren_vanilla_heads_bwd_jvp(const float *g_rgb, const float *g_rgbd
     if (C != 1 && C != 3) return REN_ERR_UNSUPPORTED;
     if (n == 0) return REN_OK;
     const int64_t n_pad = (n + 31) / 32 * 32;
+    const ActKindsHost ak = act_kinds_host();
     hipLaunchKernelGGL(heads_bwd_jvp_kernel, dim3(ren_blocks(n_pad, 256)), dim3(256), 0, (hipStream_t)stream, g_rgb, g_rgbd,
-                       g_sigma, g_sigmad, rgb, sigma, zod, zsd, n, n_pad, C, dz_rgb, dzd_rgb, dz_sigma, dzd_sigma);
+                       g_sigma, g_sigmad, rgb, sigma, zod, zsd, n, n_pad, C, ak.dn, ak.rd, dz_rgb, dzd_rgb, dz_sigma, dzd_sigma);
     REN_CHECK_LAUNCH();
 }

@@ -205,10 +205,9 @@ class Renderer:
         self._reuse_prepass_feat = True             # the differentiable pass reuses the pre-pass hash features
         self._act_code = ops.activation_code(cfg.base_hidden_activation, cfg.density_activation, cfg.head_hidden_activation,
                                              cfg.radiance_activation)
-        if self._act_code != 0:
-            if not isinstance(fld, NGPField):
-                raise NotImplementedError("activation alternatives are implemented for arch ngp (the exact-f32 fused MLP kernels)")
+        if self._act_code != 0 and isinstance(fld, NGPField):
             cfg.mlp_kernels = "f32"                 # the bf16-matrix-core kernels implement the shipped activations only
+        # (arch mlp: vanilla.VanillaRenderer switches to its per-layer launches, in any matrix-core mode)
         grid = getattr(fld, "grid", None)
         if grid is not None and max(grid.size[l] for l in range(grid.n_levels)) > 1 << 19:
             cfg.binned_scatter = False              # DenseGrid levels beyond 64 bins: the per-update atomic scatter

@@ -24,6 +24,7 @@ from .ops import _ptr, _stream
 POS_DIM, VIEW_DIM = 63, 27                      # SinusoidalEncoder(3, 0, 10) / (3, 0, 4), mlp.py:208-243
 DEPTH, WIDTH, SKIP, WIDTH_COND = 8, 256, 4, 128
 ACT_NONE, ACT_SOFTPLUS100, ACT_SOFTPLUS1, ACT_TRUNC_EXP_SEL = 0, 1, 2, 3
+ACT_RELU, ACT_SIGMOID, ACT_SOFTPLUS1_SEL, ACT_SHIFTED_SOFTPLUS1_SEL = 4, 5, 6, 7      # the YAML's alternatives (nerf.py:8-29)
 
 
 def layer_shapes(C: int = 1) -> List[Tuple[str, int, int]]:
@@ -248,6 +249,17 @@ class VanillaRenderer(Renderer):
         self._dw_ws = None
         self._fused_fields = {}
         self.fused_field = True                     # csrc/ren_vfield.hip: the field as one launch per pass (matrix-core modes)
+        # activation set (models/nerf.py:8-29; arch mlp has ONE hidden activation, mlp.py:258): alternatives run on the per-layer
+        # launches -- the fused field implements the shipped set only
+        if cfg.base_hidden_activation != cfg.head_hidden_activation:
+            raise NotImplementedError("arch mlp has one hidden_activation (external/mlp.py:258)")
+        self.act_hidden = ACT_RELU if cfg.base_hidden_activation == "relu" else ACT_SOFTPLUS100
+        self.act_beta = 0.0 if cfg.base_hidden_activation == "relu" else 100.0          # ren_act_jvp*: beta 0 = relu
+        self.act_density = {"shifted_trunc_exp": ACT_TRUNC_EXP_SEL, "softplus": ACT_SOFTPLUS1_SEL,
+                            "shifted_softplus": ACT_SHIFTED_SOFTPLUS1_SEL}[cfg.density_activation]
+        self.act_radiance = ACT_SIGMOID if cfg.radiance_activation == "sigmoid" else ACT_SOFTPLUS1
+        if self._act_code != 0:
+            self.fused_field = False
         self.bwd_chunk = 1 << 21                    # samples per backward range of the fused field (multiple of 256)
         # HIP-event timing per kernel family when ops.profile_start() is active (bench.py)
         self._fwd = ops._wrap("dense_fwd", self._fwd)
@@ -336,9 +348,9 @@ class VanillaRenderer(Renderer):
         X, ldx = B.enc, 64
         for i in range(DEPTH):                                             # mlp.py:99-113
             Y, ldy = B.out_of(i)
-            self._fwd(X, ldx, f"mlp.base.hidden_layers.{i}", ACT_SOFTPLUS100, Y, ldy, n)
+            self._fwd(X, ldx, f"mlp.base.hidden_layers.{i}", self.act_hidden, Y, ldy, n)
             X, ldx = Y, ldy
-        self._fwd(B.h[DEPTH - 1], WIDTH, "mlp.sigma_layer.output_layer", ACT_TRUNC_EXP_SEL, B.s4, 4, n, sel=B.sel)
+        self._fwd(B.h[DEPTH - 1], WIDTH, "mlp.sigma_layer.output_layer", self.act_density, B.s4, 4, n, sel=B.sel)
         return B.s4[:n, 0].contiguous()
 
     def _field_eval(self, B: _Buffers, full: bool):
@@ -350,8 +362,8 @@ class VanillaRenderer(Renderer):
             return None, sigma
         n, C = B.n, self.field.C
         self._fwd(B.h[DEPTH - 1], WIDTH, "mlp.bottleneck_layer.output_layer", ACT_NONE, B.rin, 288, n)
-        self._fwd(B.rin, 288, "mlp.rgb_layer.hidden_layers.0", ACT_SOFTPLUS100, B.r, WIDTH_COND, n)
-        self._fwd(B.r, WIDTH_COND, "mlp.rgb_layer.output_layer", ACT_SOFTPLUS1, B.rgb4, 4, n)
+        self._fwd(B.rin, 288, "mlp.rgb_layer.hidden_layers.0", self.act_hidden, B.r, WIDTH_COND, n)
+        self._fwd(B.r, WIDTH_COND, "mlp.rgb_layer.output_layer", self.act_radiance, B.rgb4, 4, n)
         return B.rgb4[:n, :C].contiguous(), sigma
 
     # ---- Renderer hooks ---------------------------------------------------------------------------------
@@ -381,6 +393,7 @@ class VanillaRenderer(Renderer):
         return rgb, sigma, dict(buffers=B if save else None)
 
     def _field_backward(self, ctx, d_rgb, d_sig, final: bool = False):
+        self._apply_acts()                          # (the output-head kernels read the density / radiance kinds)
         B, n, C = ctx["buffers"], ctx["pk"].n, self.field.C
         dev = d_rgb.device
         z = lambda ld: torch.empty(B.n_pad, ld, device=dev, dtype=torch.float32)
@@ -402,7 +415,7 @@ class VanillaRenderer(Renderer):
         h7 = B.h[DEPTH - 1]
         # colour head: 128 -> C, [bottleneck | view] -> 128, bottleneck 256 -> 256 (no activation)
         self._bwd_weight(dz_rgb, 32, B.r, WIDTH_COND, "mlp.rgb_layer.output_layer", n)
-        self._bwd_data(dz_rgb, 32, "mlp.rgb_layer.output_layer", WIDTH_COND, ACT_SOFTPLUS100, B.r, WIDTH_COND, False, dr,
+        self._bwd_data(dz_rgb, 32, "mlp.rgb_layer.output_layer", WIDTH_COND, self.act_hidden, B.r, WIDTH_COND, False, dr,
                        WIDTH_COND, n)
         self._bwd_weight(dr, WIDTH_COND, B.rin, 288, "mlp.rgb_layer.hidden_layers.0", n)
         self._bwd_data(dr, WIDTH_COND, "mlp.rgb_layer.hidden_layers.0", WIDTH, ACT_NONE, None, 0, False, db, WIDTH, n)
@@ -410,7 +423,7 @@ class VanillaRenderer(Renderer):
         self._bwd_data(db, WIDTH, "mlp.bottleneck_layer.output_layer", WIDTH, ACT_NONE, None, 0, False, dh[0], WIDTH, n)
         # sigma layer joins at h7; its data gradient is accumulated, then the trunk activation derivative applied
         self._bwd_weight(dz_sig, 32, h7, WIDTH, "mlp.sigma_layer.output_layer", n)
-        self._bwd_data(dz_sig, 32, "mlp.sigma_layer.output_layer", WIDTH, ACT_SOFTPLUS100, h7, WIDTH, True, dh[0], WIDTH, n)
+        self._bwd_data(dz_sig, 32, "mlp.sigma_layer.output_layer", WIDTH, self.act_hidden, h7, WIDTH, True, dh[0], WIDTH, n)
         cur = 0
         for i in range(DEPTH - 1, -1, -1):
             name = f"mlp.base.hidden_layers.{i}"
@@ -420,7 +433,7 @@ class VanillaRenderer(Renderer):
                 X, ldx = B.out_of(i - 1)
             self._bwd_weight(dh[cur], WIDTH, X, ldx, name, n)
             if i > 0:
-                self._bwd_data(dh[cur], WIDTH, name, WIDTH, ACT_SOFTPLUS100, X, ldx, False, dh[1 - cur], WIDTH, n)
+                self._bwd_data(dh[cur], WIDTH, name, WIDTH, self.act_hidden, X, ldx, False, dh[1 - cur], WIDTH, n)
                 cur = 1 - cur
 
     # ---- forward-mode tangent (d/dt) through the field and its reverse pass: the log-intensity-gradient loss -----
@@ -500,11 +513,11 @@ class VanillaRenderer(Renderer):
                 zdd = z(WIDTH)
                 self._lin(Xdd, ldx, name, zdd, WIDTH, n)
                 ydd = catdd if i == SKIP else z(WIDTH)
-                check(lib.ren_act_jvp2_fwd(_ptr(Y), ldy, _ptr(zd), _ptr(zdd), WIDTH, ctypes.c_float(100.0), _ptr(yd), ldyd,
+                check(lib.ren_act_jvp2_fwd(_ptr(Y), ldy, _ptr(zd), _ptr(zdd), WIDTH, ctypes.c_float(self.act_beta), _ptr(yd), ldyd,
                                            _ptr(ydd), ldyd, B.n_pad, WIDTH, _stream()), "ren_act_jvp2_fwd")
                 Xdd = ydd
             else:
-                self._act_fwd(Y, ldy, zd, 100.0, yd, ldyd, WIDTH, B.n_pad)
+                self._act_fwd(Y, ldy, zd, self.act_beta, yd, ldyd, WIDTH, B.n_pad)
             T["zd"][i], T["yd"][i] = zd, yd
             Xd, ldx = yd, ldyd
         h7d = T["yd"][DEPTH - 1]
@@ -520,12 +533,12 @@ class VanillaRenderer(Renderer):
             self._lin(h7dd, WIDTH, "mlp.sigma_layer.output_layer", s4dd, 4, n)
             self._lin(h7dd, WIDTH, "mlp.bottleneck_layer.output_layer", rindd, 288, n)
             self._lin(rindd, 288, "mlp.rgb_layer.hidden_layers.0", zrdd, WIDTH_COND, n)
-            check(lib.ren_act_jvp2_fwd(_ptr(B.r), WIDTH_COND, _ptr(zrd), _ptr(zrdd), WIDTH_COND, ctypes.c_float(100.0), _ptr(rd),
+            check(lib.ren_act_jvp2_fwd(_ptr(B.r), WIDTH_COND, _ptr(zrd), _ptr(zrdd), WIDTH_COND, ctypes.c_float(self.act_beta), _ptr(rd),
                                        WIDTH_COND, _ptr(rdd), WIDTH_COND, B.n_pad, WIDTH_COND, _stream()), "ren_act_jvp2_fwd")
             self._lin(rdd, WIDTH_COND, "mlp.rgb_layer.output_layer", zodd, 4, n)
             rgbdd, sigmadd = torch.empty(n, C, device=dev), torch.empty(n, device=dev)
         else:
-            self._act_fwd(B.r, WIDTH_COND, zrd, 100.0, rd, WIDTH_COND, WIDTH_COND, B.n_pad)
+            self._act_fwd(B.r, WIDTH_COND, zrd, self.act_beta, rd, WIDTH_COND, WIDTH_COND, B.n_pad)
         self._lin(rd, WIDTH_COND, "mlp.rgb_layer.output_layer", zod, 4, n)
         rgbd, sigmad = torch.empty(n, C, device=dev), torch.empty(n, device=dev)
         check(lib.ren_vanilla_heads_jvp(_ptr(rgb), _ptr(sigma), _ptr(zod), _ptr(zodd), _ptr(s4d), _ptr(s4dd), n, C, _ptr(rgbd),
@@ -556,14 +569,14 @@ class VanillaRenderer(Renderer):
             return gx, gxd
 
         gr, grd = lin_bwd(dz_rgb, dzd_rgb, 32, "mlp.rgb_layer.output_layer", B.r, WIDTH_COND, T["rd"], WIDTH_COND, WIDTH_COND)
-        gzr, gzrd = self._act_bwd(gr, grd, B.r, WIDTH_COND, T["zrd"], 100.0, WIDTH_COND, B.n_pad)
+        gzr, gzrd = self._act_bwd(gr, grd, B.r, WIDTH_COND, T["zrd"], self.act_beta, WIDTH_COND, B.n_pad)
         gb, gbd = lin_bwd(gzr, gzrd, WIDTH_COND, "mlp.rgb_layer.hidden_layers.0", B.rin, 288, T["rind"], 288, WIDTH)
         gy, gyd = lin_bwd(gb, gbd, WIDTH, "mlp.bottleneck_layer.output_layer", h7, WIDTH, h7d, WIDTH, WIDTH)
         lin_bwd(dz_sig, dzd_sig, 32, "mlp.sigma_layer.output_layer", h7, WIDTH, h7d, WIDTH, WIDTH, into=(gy, gyd))
         for i in range(DEPTH - 1, -1, -1):
             name = f"mlp.base.hidden_layers.{i}"
             Y, ldy = B.out_of(i)
-            gz, gzd = self._act_bwd(gy, gyd, Y, ldy, T["zd"][i], 100.0, WIDTH, B.n_pad)
+            gz, gzd = self._act_bwd(gy, gyd, Y, ldy, T["zd"][i], self.act_beta, WIDTH, B.n_pad)
             if i == 0:
                 X, ldx, Xd, ldxd = B.enc, 64, T["encd"], 64
             else:
@@ -577,6 +590,7 @@ class VanillaRenderer(Renderer):
 
     def query_density(self, x_world: torch.Tensor) -> torch.Tensor:
         """VanillaNeRFRadianceField.query_density (mlp.py:343-347) for arbitrary world points."""
+        self._apply_acts()
         n = x_world.shape[0]
         chunk = 1 << 21                                    # an occupancy refresh queries up to 256^3 cells: 8.7 KB of
         tr = self._fused()
@@ -591,6 +605,7 @@ class VanillaRenderer(Renderer):
 
     def query(self, x_world: torch.Tensor, dirs: torch.Tensor):
         """field(x, d) -> (rgb (n, C), sigma (n,), buffers) for free-standing points (mlp.py:349-358)."""
+        self._apply_acts()
         n = x_world.shape[0]
         B = _Buffers(n, x_world.device, self.field.C, full=True, backward=False, fused=self._fused(), save=True)
         self._encode(B, True, x_world=x_world.contiguous(), dirs=dirs.contiguous())

@@ -84,12 +84,22 @@ NGP_ACTIVATIONS = {("mlp_base", "hidden_activation"): ("softplus", "relu"),
                    ("mlp_base", "density_activation"): ("shifted_trunc_exp", "softplus", "shifted_softplus"),
                    ("mlp_head", "hidden_activation"): ("softplus", "relu"),
                    ("mlp_head", "radiance_activation"): ("softplus", "sigmoid")}
+# arch mlp: one hidden activation for the whole MLP (external/mlp.py:258); alternatives run on the per-layer launches
+MLP_ACTIVATIONS = {("hidden_activation",): ("softplus", "relu"),
+                   ("density_activation",): ("shifted_trunc_exp", "softplus", "shifted_softplus"),
+                   ("radiance_activation",): ("softplus", "sigmoid")}
+ACTIVATIONS = {"ngp": NGP_ACTIVATIONS, "mlp": MLP_ACTIVATIONS}
 
 
 def activation_fields(ncfg, arch) -> dict:
-    """RenderCfg fields for model.nerf.ngp.mlp_base / mlp_head activations (absent keys: the shipped values)"""
-    if arch != "ngp":
-        return {}
+    """RenderCfg fields for model.nerf.ngp.mlp_base / mlp_head (arch mlp: model.nerf.mlp) activations (absent keys: the
+    shipped values)"""
+    if arch == "mlp":
+        m = ncfg.get("mlp") or {}
+        hid = m.get("hidden_activation", "softplus")
+        return dict(base_hidden_activation=hid, head_hidden_activation=hid,
+                    density_activation=m.get("density_activation", "shifted_trunc_exp"),
+                    radiance_activation=m.get("radiance_activation", "softplus"))
     g = ncfg.get("ngp") or {}
     b, h = g.get("mlp_base") or {}, g.get("mlp_head") or {}
     return dict(base_hidden_activation=b.get("hidden_activation", "softplus"),
@@ -114,10 +124,10 @@ def check_supported(ncfg, arch):
                 continue                                        # absent key = the reference default = supported value
             if isinstance(v, dict):
                 walk(v, got[k] or {}, path + [k])
-            elif arch == "ngp" and tuple(path[1:] + [k]) in NGP_ACTIVATIONS:
-                if got[k] not in NGP_ACTIVATIONS[tuple(path[1:] + [k])]:
+            elif tuple(path[1:] + [k]) in ACTIVATIONS[arch]:
+                if got[k] not in ACTIVATIONS[arch][tuple(path[1:] + [k])]:
                     raise NotImplementedError(f"model.nerf.{'.'.join(path + [k])} = {got[k]!r}: one of "
-                                              f"{NGP_ACTIVATIONS[tuple(path[1:] + [k])]} (models/nerf.py:17-29)")
+                                              f"{ACTIVATIONS[arch][tuple(path[1:] + [k])]} (models/nerf.py:17-29)")
             elif k == "weight_norm" and isinstance(got[k], bool):
                 continue                                        # a reparametrisation of the trainable block (NGPField / VanillaField)
             elif got[k] != v:

@@ -472,6 +472,45 @@ def gen_field_mlp(mlp_mod, ngp, nerfacc):
              param_gain=1.6, x=x, d=d, rgb=rgb, sigma=sigma, density=dens, g_rgb=g_rgb, g_sigma=g_sig, **grads, **gsum)
 
 
+def gen_field_mlp_acts(mlp_mod, nerf_mod, nerfacc):
+    """Reference VanillaNeRFRadianceField with the YAML's activation ALTERNATIVES taken from the reference's own tables
+    (models/nerf.py:17-29): two combinations that together use every alternative; seeded parameters, forward + gradients."""
+    from oracle import vanilla
+    N = nerf_mod.NeRF
+    aabb = [-1.5] * 3 + [1.5] * 3
+    combos = {"a": dict(base_hidden="relu", density="softplus", radiance="sigmoid"),
+              "b": dict(base_hidden="softplus", density="shifted_softplus", radiance="softplus")}
+    out = {"combos": np.array(__import__("json").dumps(combos)), "aabb": np.array(aabb, np.float32), "param_seed": np.array(23),
+           "param_gain": np.array(1.6)}
+    for tag, c in combos.items():
+        torch.manual_seed(14)
+        rf = mlp_mod.VanillaNeRFRadianceField(
+            aabb=aabb, num_dim=3, contraction_type=nerfacc.ContractionType.AABB, radiance_dim=1,
+            hidden_activation=N.HIDDEN_ACTIVATION_NAME_TO_FN[c["base_hidden"]],
+            density_activation=N.DENSITY_ACTIVATION_NAME_TO_FN[c["density"]],
+            radiance_activation=N.RADIANCE_ACTIVATION_NAME_TO_FN[c["radiance"]], net_depth=8, net_width=256, skip_layer=4,
+            net_depth_condition=1, net_width_condition=128, pos_encoder_max_deg=10, view_encoder_max_deg=4, weight_norm=False)
+        params = vanilla.init_params(23, C=1, gain=1.6)
+        rf.load_state_dict({**rf.state_dict(), **params})
+        n = 160
+        x = (torch.rand(n, 3) - 0.5) * 1.2 * 3.0
+        d = torch.randn(n, 3)
+        d = d / d.norm(dim=-1, keepdim=True)
+        rgb, sigma = rf(x, d)
+        dens = rf.query_density(x)
+        g_rgb, g_sig = torch.randn_like(rgb), torch.randn_like(sigma)
+        rf.zero_grad()
+        ((rgb * g_rgb).sum() + (sigma * g_sig).sum()).backward()
+        for k, v in rf.named_parameters():
+            g = v.grad.reshape(-1)
+            pick = torch.linspace(0, g.numel() - 1, min(64, g.numel())).long()
+            out[f"{tag}.gi." + k], out[f"{tag}.gv." + k], out[f"{tag}.gs." + k] = pick, g[pick], g.double().abs().sum()
+        out.update({f"{tag}.x": x, f"{tag}.d": d, f"{tag}.rgb": rgb, f"{tag}.sigma": sigma, f"{tag}.density": dens,
+                    f"{tag}.g_rgb": g_rgb, f"{tag}.g_sigma": g_sig})
+        print(f"field_mlp_acts {tag}: {c}  rgb [{float(rgb.min()):.3f}, {float(rgb.max()):.3f}]  sigma max {float(sigma.max()):.3f}")
+    save("field_mlp_acts", **out)
+
+
 def gen_field_mlp_wn(mlp_mod, ngp, nerfacc):
     """Reference VanillaNeRFRadianceField with weight_norm=True (external/mlp.py:303-319): v from the seeded parameters, g =
     ||v||_row scaled by a stored factor; forward + gradients w.r.t. weight_g (whole) / weight_v, bias (samples + |.| sums)."""
@@ -1017,6 +1056,9 @@ def main():
         from robust_e_nerf.external import mlp as mlp_mod
         gen_field_mlp_wn(mlp_mod, ngp, nerfacc)
         return gen_field_wn(ngp, nerfacc)
+    if sys.argv[1:] == ["field_mlp_acts"]:
+        from robust_e_nerf.external import mlp as mlp_mod
+        return gen_field_mlp_acts(mlp_mod, nerf_mod, nerfacc)
     if sys.argv[1:] == ["eval_dataset"]:
         from robust_e_nerf.data import datasets as datasets_mod
         return gen_eval_dataset(datasets_mod)
@@ -1030,6 +1072,7 @@ def main():
     from robust_e_nerf.external import mlp as mlp_mod
     gen_field_mlp(mlp_mod, ngp, nerfacc)
     gen_field_mlp_wn(mlp_mod, ngp, nerfacc)
+    gen_field_mlp_acts(mlp_mod, nerf_mod, nerfacc)
     mods = (rmod, nerf_mod, trajectories, egp, loss_mod, nerfacc)
     gen_training_step(mods, with_grad_loss=False)
     gen_training_step(mods, with_grad_loss=True)

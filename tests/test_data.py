@@ -152,6 +152,13 @@ def test_cli_rejects_unsupported_hyperparameters():
     ncfg["mlp"]["net_width"] = 128
     with pytest.raises(NotImplementedError):
         cli.check_supported(ncfg, "mlp")
+    ncfg["mlp"] = {"net_width": 256, "hidden_activation": "relu", "density_activation": "softplus", "radiance_activation": "sigmoid"}
+    cli.check_supported(ncfg, "mlp")                                   # arch mlp: alternatives on the per-layer launches
+    assert cli.activation_fields(ncfg, "mlp") == dict(base_hidden_activation="relu", head_hidden_activation="relu",
+                                                      density_activation="softplus", radiance_activation="sigmoid")
+    ncfg["mlp"]["hidden_activation"] = "gelu"
+    with pytest.raises(NotImplementedError):
+        cli.check_supported(ncfg, "mlp")
     ncfg["mlp"] = {"net_width": 256, "weight_norm": True}              # arch mlp: one flag for the whole MLP (mlp.py:303-319)
     cli.check_supported(ncfg, "mlp")
     assert cli.weight_norm_flags(ncfg, "mlp") is True

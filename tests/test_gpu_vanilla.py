@@ -522,3 +522,192 @@ def test_fused_field_properties_at_bench_size(amd, mode):
         del dz
     assert bool(torch.isfinite(grads[0]).all()) and float(grads[0].abs().max()) > 0
     assert torch.equal(grads[1], 4.0 * grads[0]), float((grads[1] - 4.0 * grads[0]).abs().max())
+
+
+# ------------------------------------------------------------------------------------------ activation alternatives
+def _acts_field(vanilla, engine, g0, tag, **cfg_kw):
+    import json
+    from oracle import vanilla as ovan
+    acts = json.loads(str(g0["combos"]))[tag]
+    p = ovan.init_params(int(g0["param_seed"]), 1, float(g0["param_gain"]))
+    fld = vanilla.VanillaField(DEV, 1)
+    fld.load(p)
+    cfg = engine.RenderCfg(aabb=tuple(float(v) for v in g0["aabb"]), contraction_type=0,
+                           base_hidden_activation=acts["base_hidden"], head_hidden_activation=acts["base_hidden"],
+                           density_activation=acts["density"], radiance_activation=acts["radiance"], **cfg_kw)
+    r = vanilla.VanillaRenderer(fld, cfg)
+    assert not r.fused_field                                            # the fused field implements the shipped set only
+    return r, p, acts
+
+
+@pytest.mark.parametrize("kernels", ["x", "f32"])
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_vanilla_activation_alternatives_vs_reference_golden(amd, tag, kernels):
+    """arch mlp with the YAML's activation alternatives (models/nerf.py:8-29: relu, softplus / shifted_softplus densities,
+    sigmoid) on the per-layer launches (both matrix-core paths) vs the reference's own VanillaNeRFRadianceField built from
+    its own activation tables (fixture field_mlp_acts.npz): forward, density query, every parameter gradient.  The fused
+    field refuses a non-default activation set."""
+    ops, engine, vanilla = amd
+    g0 = load_golden("field_mlp_acts")
+    g = {k[len(tag) + 1:]: v for k, v in g0.items() if k.startswith(tag + ".")}
+    r, _, acts = _acts_field(vanilla, engine, g0, tag, mlp_kernels=kernels)
+    x, d = t(g["x"]).to(DEV).contiguous(), t(g["d"]).to(DEV).contiguous()
+    rgb, sigma, B = r.query(x, d)
+    assert rel_err(rgb.cpu(), g["rgb"]) < 2e-5 and rel_err(sigma.cpu(), g["sigma"][:, 0]) < 2e-5
+    assert rel_err(r.query_density(x).cpu(), g["density"][:, 0]) < 2e-5
+    n = x.shape[0]
+    ctx = dict(buffers=B, pk=types.SimpleNamespace(n=n), rgb=rgb, sigma=sigma)
+    r._field_backward(ctx, t(g["g_rgb"]).to(DEV).contiguous(), t(g["g_sigma"])[:, 0].to(DEV).contiguous())
+    torch.cuda.synchronize()
+    for k, v in r.field.state_dict(grad=True).items():
+        gr = v.reshape(-1).cpu()
+        ref, idx = t(g["gv." + k]), t(g["gi." + k])
+        scale = float(g["gs." + k]) / gr.numel() + 1e-30
+        err = float((gr[idx] - ref).abs().max())
+        assert err < 2e-4 * max(float(ref.abs().max()), scale), (k, err, float(ref.abs().max()))
+        assert abs(float(gr.double().abs().sum()) - float(g["gs." + k])) < 2e-4 * float(g["gs." + k]) + 1e-12, k
+    if kernels == "x":                                                  # (the exact-f32 mode has no fused field)
+        r.fused_field = True                                            # forcing the fused kernels: refused, loudly
+        with pytest.raises(NotImplementedError):
+            r.query(x, d)
+        r.fused_field = False
+    r2, _ = _field(vanilla, engine, load_golden("field_mlp_aabb"))       # a default renderer in the same process is not disturbed
+    rgb0, _, _ = r2.query(x, d)
+    assert r2.fused_field and torch.isfinite(rgb0).all()
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_vanilla_activation_alternatives_tangents_vs_float64(amd, tag):
+    """The tangent streams of arch mlp (l_grad: d/dt, its reverse pass, and the forward-only d2/dt2 behind d loss / d tau)
+    with activation alternatives, against float64 autograd through the oracle field with the same activations."""
+    from oracle import vanilla as ovan
+    ops, engine, vanilla = amd
+    g0 = load_golden("field_mlp_acts")
+    r, p, acts = _acts_field(vanilla, engine, g0, tag)
+    gen = torch.Generator().manual_seed(17)
+    R = 300
+    o = (torch.rand(R, 3, generator=gen) - 0.5) * 1.0
+    d = torch.randn(R, 3, generator=gen); d = d / d.norm(dim=-1, keepdim=True)
+    od, dd, ddd = (torch.randn(R, 3, generator=gen) * 0.3 for _ in range(3))
+    tm = torch.rand(R, generator=gen) * 1.2
+    pk = engine.Packed(ray_indices=torch.arange(R, dtype=torch.int32, device=DEV), t_starts=(tm - 0.01).to(DEV),
+                       t_ends=(tm + 0.01).to(DEV), offsets=torch.arange(R, device=DEV), counts=torch.ones(R, dtype=torch.int32, device=DEV),
+                       n=R)
+    dev = lambda v: v.to(DEV).contiguous()
+    r._apply_acts()
+    rgb, rgbd, sigma, sigmad, T = r._field_forward_jvp(dev(o), dev(d), dev(od), dev(dd), pk)
+    w = [torch.randn(R, 1, generator=gen), torch.randn(R, 1, generator=gen), torch.randn(R, generator=gen), torch.randn(R, generator=gen)]
+    r.field.grad.zero_()
+    r._field_backward_jvp(T, pk, rgb, sigma, dev(w[0]), dev(w[1]), dev(w[2]), dev(w[3]))
+    rgb2, rgbd2, rgbdd, sigma2, sigmad2, sigmadd = r._field_forward_jvp(dev(o), dev(d), dev(od), dev(dd), pk, ddd=dev(ddd))
+    assert torch.equal(rgbd, rgbd2) and torch.equal(sigmad, sigmad2)
+    torch.cuda.synchronize()
+    p64 = {k: v.double().requires_grad_() for k, v in p.items()}
+    aabb = torch.tensor([float(v) for v in g0["aabb"]], dtype=torch.float64)
+    tm64 = ((tm - 0.01).float() + (tm + 0.01).float()).double()[:, None] * 0.5
+    x0, xd, xdd = o.double() + tm64 * d.double(), od.double() + tm64 * dd.double(), tm64 * ddd.double()
+
+    def f1(tt):
+        rgb_, sig_ = ovan.forward(p64, x0 + tt * xd, d.double() + tt * dd.double(), aabb, 0, acts=acts)
+        return rgb_, sig_[:, 0]
+    zero, one = torch.zeros((), dtype=torch.float64), torch.ones((), dtype=torch.float64)
+    (rgb_o, sig_o), (rgbd_o, sigd_o) = torch.autograd.functional.jvp(f1, zero, one, create_graph=True)
+    # relu: a pre-activation within float32 round-off of zero (amplified by the 2^9 x 2 pi band) may sit on the other side of
+    # the kink in float64 -- a few elements of the tangents then differ by that neuron's whole contribution: compared at the
+    # 99th percentile of the element errors as well as (loosely) at the maximum
+    relu = acts["base_hidden"] == "relu"
+
+    def close(a, b, tol, what):
+        e = (a.double().cpu().reshape(-1) - b.detach().double().reshape(-1)).abs() / b.detach().abs().max()
+        q99, mx = float(e.quantile(0.99)), float(e.max())
+        print(f"  {tag} {what}: 99 % {q99:.2e} max {mx:.2e}")
+        assert q99 < tol and mx < (50 * tol if relu else tol), (what, q99, mx)
+    close(rgb, rgb_o, 2e-5, "rgb"); close(sigma, sig_o, 2e-5, "sigma")
+    close(rgbd, rgbd_o, 5e-4, "d rgb / dt"); close(sigmad, sigd_o, 5e-4, "d sigma / dt")
+    def grads_at(x_at):
+        def f(tt):
+            rgb_, sig_ = ovan.forward(p64, x_at + tt * xd, d.double() + tt * dd.double(), aabb, 0, acts=acts)
+            return rgb_, sig_[:, 0]
+        (a0, a1), (b0, b1) = torch.autograd.functional.jvp(f, zero, one, create_graph=True)
+        L = (w[0].double() * a0).sum() + (w[1].double() * b0).sum() + (w[2].double() * a1).sum() + (w[3].double() * b1).sum()
+        return dict(zip(p64.keys(), torch.autograd.grad(L, list(p64.values()))))
+    ref = grads_at(x0)
+    if not relu:
+        for k, v in r.field.state_dict(grad=True).items():
+            close(v, ref[k], 3e-3, "grad " + k)
+    else:
+        # control: the float64 oracle itself with the positions moved by one float32 ulp -- the sensitivity of these sums of
+        # 300 samples to which side of a kink a pre-activation falls on; the kernels have to stay within three times that
+        ctl = grads_at(x0 * (1.0 + 6e-8))
+        quant = lambda a, b: ((a.double().reshape(-1) - b.double().reshape(-1)).abs() / b.abs().max()).quantile(
+            torch.tensor([0.99, 1.0], dtype=torch.float64))
+        worst = 0.0
+        for k, v in r.field.state_dict(grad=True).items():
+            e, c = quant(v.cpu(), ref[k]), quant(ctl[k], ref[k])
+            worst = max(worst, float(c[1]))
+            assert float(e[0]) < 3 * float(c[0]) + 3e-3 and float(e[1]) < 3 * float(c[1]) + 3e-3, (k, e.tolist(), c.tolist())
+        print(f"  {tag} control (oracle, positions + 1 ulp): worst max element error {worst:.2e}")
+        assert worst > 3e-3                                              # the ill-conditioning is real, not a loose bound
+    p64n = {k: v.detach() for k, v in p64.items()}
+
+    def f2(tt):
+        rgb_, sig_ = ovan.forward(p64n, x0 + tt * xd + 0.5 * tt * tt * xdd, d.double() + tt * dd.double() + 0.5 * tt * tt * ddd.double(),
+                                  aabb, 0, acts=acts)
+        return torch.cat([rgb_, sig_], 1)
+    first = lambda tt: torch.autograd.functional.jvp(f2, tt, one, create_graph=True)[1]
+    _, d2 = torch.autograd.functional.jvp(first, zero, one)
+    close(rgbdd, d2[:, :1], 5e-3, "d2 rgb / dt2"); close(sigmadd, d2[:, 1], 5e-3, "d2 sigma / dt2")
+
+
+def test_vanilla_activation_alternatives_whole_step_vs_oracle(amd):
+    """arch mlp, a whole l_diff + l_grad step with C_p and tau trainable (value, tangent and second-order tangent streams, their
+    reverse pass, the output-head kernels) with softplus hidden layers, a shifted_softplus density and a sigmoid radiance,
+    against the oracle step with the same activations: loss, every parameter gradient, d/dC_p, d/dtau.  (relu hidden layers:
+    the field-level tests above; whole-step gradients with relu are ill-conditioned, see the arch ngp test.)"""
+    from oracle import step as ostep, vanilla as ovan
+    ops, engine, vanilla = amd
+    acts = dict(base_hidden="softplus", density="shifted_softplus", head_hidden="softplus", radiance="sigmoid")
+    g = load_golden("training_step_mlp")
+    occ_res = int(g["occ_res"])
+    cfg = engine.RenderCfg(occ_res=(occ_res,) * 3, render_step_size=float(g["render_step_size"]), sampler="occgrid",
+                           base_hidden_activation="softplus", head_hidden_activation="softplus",
+                           density_activation="shifted_softplus", radiance_activation="sigmoid")
+    params = ovan.init_params(int(g["param_seed"]), 1, float(g["param_gain"]))
+    fld = vanilla.VanillaField(DEV, 1)
+    fld.load(params)
+    r = vanilla.VanillaRenderer(fld, cfg)
+    assert not r.fused_field
+    r.binary.copy_(torch.from_numpy(np.unpackbits(g["binary"])[: occ_res ** 3].astype(np.uint8)).to(DEV))
+    tr = engine.Trainer(r, engine.TrainCfg(), Kinv=t(g["Kinv"]), tab_ts=t(g["tab_ts"]), tab_pos=t(g["tab_pos"]),
+                        tab_quat=t(g["tab_quat"]), p2n_raw=t(g["p2n_raw"]), neg_ct=t(g["neg_ct"]),
+                        tau_raw=t(g["tau_raw"]), tau_max=t(g["tau_max"]), bkgd_raw=t(g["bkgd_raw"]))
+    dv = lambda v: torch.as_tensor(v).to(DEV)
+    batch = {k: dv(g[k]) for k in ("position", "start_ts", "end_ts", "num_pos", "num_neg", "u_ts_diff", "u_diff_start", "u_grad")}
+    w_grad = float(g["w_grad"])
+    tr.t.w_grad, tr.t.err_grad, tr.t.pw_grad = w_grad, "mape", None
+    tr.t.train_contrast_threshold = tr.t.train_refractory_period = True
+    jit = t(g["jitters"])
+    loss_d, aux = tr.forward_backward(batch, dv(jit[1]), dv(jit[2]))
+    loss_g, _ = tr.grad_loss_forward_backward(batch, dv(jit[0]))
+    loss = float(loss_d) + float(loss_g)
+    binary = t(np.unpackbits(g["binary"])[: occ_res ** 3].astype(bool)).view(occ_res, occ_res, occ_res)
+    ocfg = ostep.SceneCfg(occ_res=(occ_res,) * 3, render_step_size=float(g["render_step_size"]), acts=acts)
+    ob = ostep.EventBatch(t(g["position"]), t(g["start_ts"]), t(g["end_ts"]), t(g["num_pos"]), t(g["num_neg"]),
+                          t(g["u_ts_diff"]), t(g["u_diff_start"]), t(g["u_grad"]))
+    po = {k: v.clone().requires_grad_() for k, v in params.items()}
+    tau_raw, p2n = t(g["tau_raw"]).clone().requires_grad_(), t(g["p2n_raw"]).clone().requires_grad_()
+    loss_o, aux_o = ostep.training_forward(
+        ob, po, None, ocfg, Kinv=t(g["Kinv"]), tab_ts=t(g["tab_ts"]), tab_pos=t(g["tab_pos"]), tab_quat=t(g["tab_quat"]),
+        p2n_raw=p2n, neg_ct=t(g["neg_ct"]), tau_raw=tau_raw, tau_max=t(g["tau_max"]), bkgd_raw=t(g["bkgd_raw"]),
+        binary=binary, jitter_start=jit[1], jitter_end=jit[2], jitter_grad=jit[0],
+        loss_cfg=dict(w_grad=w_grad, err_grad="mape", pw_grad=None))
+    loss_o.backward()
+    assert aux["n"] == aux_o["n_start"] + aux_o["n_end"]
+    assert abs(loss - float(loss_o)) < 1e-4 * abs(float(loss_o)), (loss, float(loss_o))
+    errs = {k: rel_err(v.cpu(), po[k].grad) for k, v in fld.state_dict(grad=True).items()}
+    sg = torch.sigmoid(tr.tau_raw.detach() / tr.tau_max)
+    e_tau = rel_err(tr.tau_grad * sg * (1 - sg), tau_raw.grad)
+    e_ct = rel_err(tr.ct_grad[:1].cpu(), p2n.grad.reshape(-1)[:1])
+    print(f"arch mlp, activation alternatives, whole step: loss {abs(loss - float(loss_o)) / abs(float(loss_o)):.2e} worst gradient "
+          f"{max(errs, key=errs.get)} {max(errs.values()):.2e} d/dtau {e_tau:.2e} d/dC_p {e_ct:.2e}")
+    assert max(errs.values()) < 5e-3 and e_tau < 1e-2 and e_ct < 1e-3

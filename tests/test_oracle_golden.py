@@ -363,3 +363,24 @@ def test_vanilla_field_weight_norm():
         gr = v.grad.reshape(-1)
         assert rel_err(gr[t(g["gi." + k])], g["gv." + k]) < 2e-5, k
         assert abs(float(gr.double().abs().sum()) - float(g["gs." + k])) < 2e-5 * float(g["gs." + k]) + 1e-12, k
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_vanilla_field_activation_alternatives(tag):
+    """arch mlp with the YAML's activation alternatives (models/nerf.py:8-29) -- oracle vs the reference's own
+    VanillaNeRFRadianceField built from its own activation tables (fixture field_mlp_acts.npz)."""
+    import json
+    from oracle import vanilla
+    g0 = load_golden("field_mlp_acts")
+    acts = json.loads(str(g0["combos"]))[tag]
+    g = {k[len(tag) + 1:]: v for k, v in g0.items() if k.startswith(tag + ".")}
+    p = {k: v.requires_grad_() for k, v in vanilla.init_params(int(g0["param_seed"]), 1, float(g0["param_gain"])).items()}
+    aabb = t(g0["aabb"])
+    rgb, sigma = vanilla.forward(p, t(g["x"]), t(g["d"]), aabb, 0, acts=acts)
+    assert rel_err(rgb, g["rgb"]) < 2e-6 and rel_err(sigma, g["sigma"]) < 2e-6
+    assert rel_err(vanilla.forward(p, t(g["x"]), None, aabb, 0, density_only=True, acts=acts), g["density"]) < 2e-6
+    ((rgb * t(g["g_rgb"])).sum() + (sigma * t(g["g_sigma"])).sum()).backward()
+    for k, v in p.items():
+        gr = v.grad.reshape(-1)
+        assert rel_err(gr[t(g["gi." + k])], g["gv." + k]) < 1e-5, k
+        assert abs(float(gr.double().abs().sum()) - float(g["gs." + k])) < 1e-5 * float(g["gs." + k]) + 1e-12, k
