@@ -984,8 +984,11 @@ template <bool BWD>
 int launch_dense(DenseArgs a, int tiles, int mode, hipStream_t st) {
     // kernel variant per (matrix-core mode, direction): 1 = dense_x_kernel, one block per wave; 2 = two blocks per wave;
     // 3 = dense_t_kernel (wide layers only).  Defaults from tools/dense_bench.py / bench.py --arch mlp on MI355X.
-    static const int sel6 = [] { const char *e = getenv(BWD ? "REN_DENSE_BWD6" : "REN_DENSE_FWD6"); return e ? atoi(e) : (BWD ? 1 : 2); }();
-    static const int sel1 = [] { const char *e = getenv(BWD ? "REN_DENSE_BWD1" : "REN_DENSE_FWD1"); return e ? atoi(e) : 3; }();
+    // (round 4 re-measurement, tools/dense_bench.py at n = 131 k .. 2 M, 256 x 256: forward variant 1 is 2 x faster than 2 / 3
+    // from n = 524 k on in both modes -- 1.11 vs 2.23 ms (mode 1), 1.64 vs 3.07 ms (mode 6) at 1 M -- and equal below; the
+    // backward keeps 1 (mode 6) / 3 (mode 1: 0.83 vs 1.06 ms))
+    static const int sel6 = [] { const char *e = getenv(BWD ? "REN_DENSE_BWD6" : "REN_DENSE_FWD6"); return e ? atoi(e) : 1; }();
+    static const int sel1 = [] { const char *e = getenv(BWD ? "REN_DENSE_BWD1" : "REN_DENSE_FWD1"); return e ? atoi(e) : (BWD ? 3 : 1); }();
     const int sel = mode == 6 ? sel6 : sel1;
     const int nb_env = sel == 1 ? 1 : 2;
     const int use_t = sel == 3;

@@ -269,6 +269,11 @@ class VanillaRenderer(Renderer):
         self._fused_fwd = ops._wrap("vfield_fwd", self._fused_fwd)
         self._fused_bwd = ops._wrap("vfield_bwd", self._fused_bwd)
         self._fused_dw = ops._wrap("vfield_bwd_weight", self._fused_dw)
+        self._lin = ops._wrap("dense_fwd_tangent", self._lin)
+        self._act_fwd = ops._wrap("act_jvp_fwd", self._act_fwd)
+        self._act_bwd = ops._wrap("act_jvp_bwd", self._act_bwd)
+        self._bwd_weight_nobias = ops._wrap("dense_bwd_weight_tangent", self._bwd_weight_nobias)
+        self._encode_tangent = ops._wrap("freq_encode_jvp", self._encode_tangent)
 
     def dp_early_slice(self):
         return None                                 # no hash table: the 2.4 MB of dense weights go in the one packed all-reduce
