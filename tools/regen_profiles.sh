@@ -29,6 +29,8 @@ python bench.py --no-cpu-baseline --events 32768 --hard --loss-grad 1e-3 --mlp-b
 python bench.py --no-cpu-baseline --events 32768 --hard --loss-grad 1e-3 > profiles/${RND}_bench_hard.json 2>>$O/bench.err
 python bench.py --no-cpu-baseline --arch mlp --events 4096 > profiles/${RND}_bench_arch_mlp.json 2>>$O/bench.err
 python bench.py --no-cpu-baseline --arch mlp --events 4096 --mlp-bf16 > profiles/${RND}_bench_arch_mlp_bf16.json 2>>$O/bench.err
+python bench.py --no-cpu-baseline --arch mlp --events 4096 --loss-grad 1e-3 > profiles/${RND}_bench_arch_mlp_lossgrad.json 2>>$O/bench.err
+python bench.py --no-cpu-baseline --arch mlp --events 4096 --loss-grad 1e-3 --mlp-bf16 > profiles/${RND}_bench_arch_mlp_lossgrad_bf16.json 2>>$O/bench.err
 REN_BENCH_DIST=nccl:single-rank python bench.py --no-cpu-baseline > profiles/${RND}_bench_dp_rccl_single_rank.json 2>>$O/bench.err
 python tools/render_bench.py --config-e > profiles/${RND}_render_config_e.txt 2>>$O/bench.err
 cd /tmp
