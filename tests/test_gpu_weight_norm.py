@@ -319,3 +319,55 @@ def test_weight_norm_fold_is_linear_in_the_block_gradient(amd):
             outs.append(folded(fld).clone())
         assert rel_err(outs[0] + outs[1], outs[2]) < 1e-5
         assert float(outs[2].abs().max()) > 0.0
+
+
+@pytest.mark.parametrize("arch", ["ngp", "mlp"])
+def test_train_cli_with_hyperparameter_alternatives(tmp_path, arch):
+    """scripts/train.py -> checkpoint -> scripts/render.py -> resume, on the reference's YAML schema with the alternatives of its
+    [H] comments switched on: weight_norm (checkpoint keys weight_g / weight_v), relu hidden layers, a shifted_softplus density,
+    a sigmoid radiance, and (arch ngp) a TiledGrid position encoding; gradient accumulation folds the weight-norm gradient once."""
+    import math, os, subprocess, sys, yaml
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = yaml.safe_load(open(os.path.join(repo, "configs", "synthetic_smoke.yaml")))
+    nerf = cfg["model"]["nerf"]
+    nerf["arch"] = arch
+    if arch == "ngp":                                                     # (absent keys = the reference's defaults)
+        nerf["ngp"] = {"pos_encoding": {"otype": "TiledGrid"},
+                       "mlp_base": dict(hidden_activation="relu", density_activation="shifted_softplus", weight_norm=True),
+                       "mlp_head": dict(hidden_activation="relu", radiance_activation="sigmoid", weight_norm=True)}
+    else:
+        nerf["mlp"] = dict(hidden_activation="relu", density_activation="shifted_softplus", radiance_activation="sigmoid",
+                           weight_norm=True)
+        cfg["data"]["train_eff_ray_sample_batch_size"] = 65536
+        cfg["optimizer"]["lr"]["default"] = 5.0e-4
+    cfg["trainer"]["max_epochs"], cfg["trainer"]["limit_train_batches"] = 2, 6
+    cfg["trainer"]["accumulate_grad_batches"], cfg["trainer"]["log_every_n_steps"] = 2, 1
+    path = os.path.join(tmp_path, "cfg.yaml")
+    yaml.safe_dump(cfg, open(path, "w"))
+    train = [sys.executable, os.path.join(repo, "scripts", "train.py"), "--config", path, "--synthetic", "60000", "--out", str(tmp_path)]
+    out = subprocess.run(train, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if "M rays/s" in l]
+    assert lines and all(math.isfinite(float(l.split("loss")[1].split()[0])) for l in lines), out.stdout[-1500:]
+    ck = torch.load(os.path.join(tmp_path, "last.ckpt"), map_location="cpu", weights_only=False)
+    sd = ck["state_dict"]
+    assert ck["global_step"] == 6                                         # 12 micro-batches, 2 per optimiser step
+    stem = "nerf.radiance_field." + ("mlp_head.hidden_layers.1" if arch == "ngp" else "mlp.base.hidden_layers.3")
+    assert stem + ".weight_g" in sd and stem + ".weight_v" in sd and stem + ".weight" not in sd
+    g, v = sd[stem + ".weight_g"], sd[stem + ".weight_v"]
+    assert tuple(g.shape) == (v.shape[0], 1) and float((g.reshape(-1) - v.norm(dim=1)).abs().max()) > 0   # g moved away from ||v||
+    if arch == "ngp":
+        assert sd["nerf.radiance_field.mlp_base.0.params"].numel() == 16 * 4096 * 2      # TiledGrid: 16 levels x 16^3 entries
+    rd = os.path.join(tmp_path, "renders")
+    out_r = subprocess.run([sys.executable, os.path.join(repo, "scripts", "render.py"), "--config", path, "--ckpt",
+                            os.path.join(tmp_path, "last.ckpt"), "--synthetic", "--every", "1000", "--out", rd],
+                           capture_output=True, text=True, timeout=900)
+    assert out_r.returncode == 0, out_r.stderr[-2000:]
+    views = np.load(os.path.join(rd, "views.npz"))
+    assert np.isfinite(views["intensity"]).all() and views["intensity"].min() > 0
+    out2 = subprocess.run(train + ["--resume", os.path.join(tmp_path, "last.ckpt"), "--max-epochs", "3"],
+                          capture_output=True, text=True, timeout=900)
+    assert out2.returncode == 0, out2.stderr[-2000:]
+    assert "resumed" in out2.stdout
+    ck2 = torch.load(os.path.join(tmp_path, "last.ckpt"), map_location="cpu", weights_only=False)
+    assert ck2["global_step"] == 9 and stem + ".weight_g" in ck2["state_dict"]
