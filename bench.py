@@ -239,6 +239,9 @@ def main():
     ap.add_argument("--save-activations", type=int, default=-1, choices=[-1, 0, 1],
                     help="1: the training forward stores the hidden MLP activations (768 B/sample), 0: the backward recomputes "
                          "them, -1 (default): recompute with the x kernels, save with the exact-f32 kernels")
+    ap.add_argument("--no-early-grad-sampling", action="store_true",
+                    help="l_grad term: place the third render's samples after the l_diff backward (as before round 4) instead of "
+                         "beside it on the side stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
@@ -372,13 +375,15 @@ def main():
 
     def one_step(i):
         b, j0, j1 = staged.pop(i) if i in staged else draw(i)
+        # the third render's jitter is drawn BEFORE the l_diff pass is enqueued: its samples are then placed beside that pass's
+        # backward (Trainer.grad_loss_forward_backward(early=True), what Trainer.step does)
+        j2 = ops.uniform(B, 4321 + rank, i, device=dev) if args.loss_grad > 0 else None
         loss, aux = tr.forward_backward(b, j0, j1)
         if can_prefetch:
             staged[i + 1] = draw(i + 1)
             tr.prefetch(*staged[i + 1])
         if args.loss_grad > 0:
-            j2 = ops.uniform(B, 4321 + rank, i, device=dev)
-            lg, aux_g = tr.grad_loss_forward_backward(batches[i % n_batches], j2)
+            lg, aux_g = tr.grad_loss_forward_backward(batches[i % n_batches], j2, early=not args.no_early_grad_sampling)
             loss = loss + lg
             aux = dict(aux, n=aux["n"] + aux_g["n"], rays=aux["rays"] + aux_g["rays"], n_main=aux["n"])
         tr.optimizer_step()

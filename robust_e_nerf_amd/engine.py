@@ -14,6 +14,7 @@ import math
 from dataclasses import dataclass, field as dc_field
 from typing import Dict, Optional, Sequence, Tuple
 
+import contextlib
 import torch
 
 from . import ops
@@ -183,6 +184,43 @@ class Packed:
     feat: Optional[torch.Tensor] = None         # hash features of these samples, when the density pre-pass made them
 
 
+def _adopt(v, stream):
+    """tensors allocated on another stream's pool that `stream` is about to use (after waiting for their producer): tell the
+    caching allocator, so that their memory is not handed out again before `stream` is done with them"""
+    if isinstance(v, torch.Tensor):
+        if v.is_cuda:
+            v.record_stream(stream)
+    elif isinstance(v, dict):
+        for x in v.values():
+            _adopt(x, stream)
+    elif isinstance(v, (tuple, list)):
+        for x in v:
+            _adopt(x, stream)
+    elif isinstance(v, Packed):
+        _adopt((v.ray_indices, v.t_starts, v.t_ends, v.offsets, v.counts, v.feat), stream)
+
+
+_PINNED = {}
+
+
+def _host_int(t: torch.Tensor) -> int:
+    """one device integer on the host.  On the default stream: .item().  On a side stream: through a pinned buffer and an
+    event, so that the host waits for THAT stream only (a pageable read-back waits for the whole device queue on ROCm:
+    tools/sync_probe.py) -- what lets Trainer.grad_loss_forward_backward(early=True) place its samples while the previous
+    backward is still running."""
+    cur = torch.cuda.current_stream(t.device)
+    if cur == torch.cuda.default_stream(t.device):
+        return int(t.item())
+    buf = _PINNED.get(t.dtype)
+    if buf is None:
+        buf = _PINNED[t.dtype] = torch.empty(1, dtype=t.dtype).pin_memory()
+    buf.copy_(t.reshape(1), non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(cur)
+    ev.synchronize()
+    return int(buf[0])
+
+
 class Renderer:
     def __init__(self, fld: NGPField, cfg: RenderCfg):
         self.field = fld
@@ -252,7 +290,7 @@ class Renderer:
         st = begun if begun is not None else self.sample_begin(o, d, jitter, training)
         args, cache, counts, offsets, mode = st["args"], st["cache"], st["counts"], st["offsets"], st["mode"]
         # host sync, as in the reference (external/utils.py:106-119); `begun["n0"]`: already read back (Trainer.prefetch)
-        n0 = st["n0"] if "n0" in st else int(st["total"].item())
+        n0 = st["n0"] if "n0" in st else _host_int(st["total"])
         ri, ts, te = ops.ray_march_write(*args, offsets, n0, counts=counts, cache=cache)
         if mode == 1 or n0 == 0:
             return Packed(ri, ts, te, offsets, counts, n0, n0)
@@ -264,7 +302,7 @@ class Renderer:
             sigma, feat0 = sigma
         keep, kept = ops.visibility(offsets, counts, sigma, ts, te, c.early_stop_eps, c.alpha_thre)
         new_offsets, total2 = ops.exclusive_scan(kept)
-        n1 = int(total2.item())
+        n1 = _host_int(total2)
         ri2, ts2, te2 = ops.compact_samples(offsets, counts, new_offsets, keep, ts, te, n1)
         feat1 = None
         if feat0 is not None and n1 > 0:                     # the pre-pass already encoded every survivor
@@ -654,6 +692,8 @@ class Trainer:
         self.pg = process_group
         self.sync = None
         self._side, self._prefetched, self._n_host = None, None, None   # Trainer.prefetch
+        self._ready_ev = None                                    # start of the last forward_backward() on its stream (early sampling)
+        self.early_grad_sampling = True                          # Trainer.step: third render's samples beside the l_diff backward
         if world_size > 1:
             from . import parallel
             self.sync = parallel.GradSync(process_group, world_size, compress=renderer.cfg.dp_compress)
@@ -667,6 +707,7 @@ class Trainer:
         self.ct[0] = p2n_raw.detach().reshape(-1)[0].to(dev, torch.float32)
         self.ct_raw = float(p2n_raw.detach().reshape(-1)[0])
         self.ct_grad, self.ct_m, self.ct_v = torch.zeros_like(self.ct), torch.zeros_like(self.ct), torch.zeros_like(self.ct)
+        self._ct_read_key = None
 
     @property
     def tau_grad(self) -> torch.Tensor:
@@ -682,6 +723,10 @@ class Trainer:
 
     def _refresh_contrast_threshold(self):
         if self.t.train_contrast_threshold:
+            key = (self.step_count, self.ct._version)          # the ratio moves with the optimiser step (or an explicit write) only:
+            if key == self._ct_read_key:                       # the step's second loss term does not read it back again
+                return
+            self._ct_read_key = key
             raw = self.ct[0]
             self.ct_raw, ratio = torch.stack([raw, torch.nn.functional.softplus(raw)]).tolist()   # one 8-byte host read per step
             self.c_p = ratio * self.c_n
@@ -807,17 +852,7 @@ class Trainer:
         cur = torch.cuda.current_stream()
         cur.wait_event(ev)
 
-        def keep(v):                                                   # side-stream allocations now used on this stream
-            if isinstance(v, torch.Tensor):
-                if v.is_cuda:
-                    v.record_stream(cur)
-            elif isinstance(v, dict):
-                for x in v.values():
-                    keep(x)
-            elif isinstance(v, (tuple, list)):
-                for x in v:
-                    keep(x)
-        keep(front)
+        _adopt(front, cur)                                             # side-stream allocations now used on this stream
         return front
 
     def forward_backward(self, batch, jitter_start=None, jitter_end=None, final: Optional[bool] = None):
@@ -827,6 +862,11 @@ class Trainer:
             final = not (self.t.w_grad > 0)
         r, t, f = self.r, self.t, self.r.field
         B = batch["position"].shape[0]
+        if f.flat.is_cuda:
+            # everything enqueued so far (the last optimiser step, the occupancy-grid refresh, the batch) is what the sampling
+            # of this step's third render depends on: grad_loss_forward_backward(early=True) waits for this point only
+            self._ready_ev = torch.cuda.Event()
+            self._ready_ev.record()
         front = self._take_prefetched(batch, jitter_start, jitter_end)
         if front is None:
             front = self._front(batch, jitter_start, jitter_end)
@@ -874,27 +914,46 @@ class Trainer:
                    opacity=opac, rays=2 * B)
         return loss, aux
 
-    def grad_loss_forward_backward(self, batch, jitter_grad=None, final: bool = True):
+    def grad_loss_forward_backward(self, batch, jitter_grad=None, final: bool = True, early: bool = False):
         """Log-intensity-GRADIENT loss term (robust_e_nerf.py:340-357,383-409; loss.py:43-57): a third
         render at grad.ts = lerp(diff.start, diff.end, u_grad) carrying d/dt in forward mode, compared
-        with the event rate C/dt.  Accumulates gradients; returns (weighted loss term, aux)."""
+        with the event rate C/dt.  Accumulates gradients; returns (weighted loss term, aux).
+        early: place the third render's samples (timestamps, poses, rays, march, density pre-pass, visibility -- everything up
+        to and including the two host reads of the sample counts, which depends on the field and the occupancy grid but not
+        on the l_diff pass) on the side stream, ordered after the START of the preceding forward_backward() only, i.e. beside
+        its backward pass: the host reads then wait for a few small kernels instead of draining the queue twice.  The caller
+        guarantees that `batch` and `jitter_grad` were complete before that forward_backward() call (Trainer.step does).
+        Same arithmetic, same results."""
         from . import jvp
         r, t, f = self.r, self.t, self.r.field
         B = batch["position"].shape[0]
-        self._refresh_contrast_threshold()
-        self._refresh_tau()
-        prep = ops.event_prepare(batch, self.c_p, self.c_n, self.tau, with_grad_ts=True, with_dtau=t.train_refractory_period)
-        ts_g, target = prep["ts_grad"], prep["target_grad"]                                 # loss.py:39-42
-        ddd = None
-        if t.train_refractory_period:                                  # tau moves ts_g: second-order tangent
-            pos, rot, dpos, drot, ddrot = jvp.trajectory_jvp2(ts_g, self.tab_ts, self.tab_pos, self.tab_quat)
-            o, d, od, dd, ddd = jvp.raygen_jvp2(self.Kinv, batch["position"].contiguous(), pos, rot, dpos, drot, ddrot)
-        else:
-            pos, rot, dpos, drot = jvp.trajectory_jvp(ts_g, self.tab_ts, self.tab_pos, self.tab_quat)
-            o, d, od, dd = jvp.raygen_jvp(self.Kinv, batch["position"].contiguous(), pos, rot, dpos, drot)
+        ready, self._ready_ev = self._ready_ev, None
+        early = early and ready is not None and f.flat.is_cuda
+        main = torch.cuda.current_stream() if f.flat.is_cuda else None
+        if early:
+            self.side_stream.wait_event(ready)
+        with (torch.cuda.stream(self.side_stream) if early else contextlib.nullcontext()):
+            self._refresh_contrast_threshold()
+            self._refresh_tau()
+            prep = ops.event_prepare(batch, self.c_p, self.c_n, self.tau, with_grad_ts=True, with_dtau=t.train_refractory_period)
+            ts_g, target = prep["ts_grad"], prep["target_grad"]                                 # loss.py:39-42
+            ddd = None
+            if t.train_refractory_period:                                  # tau moves ts_g: second-order tangent
+                pos, rot, dpos, drot, ddrot = jvp.trajectory_jvp2(ts_g, self.tab_ts, self.tab_pos, self.tab_quat)
+                o, d, od, dd, ddd = jvp.raygen_jvp2(self.Kinv, batch["position"].contiguous(), pos, rot, dpos, drot, ddrot)
+            else:
+                pos, rot, dpos, drot = jvp.trajectory_jvp(ts_g, self.tab_ts, self.tab_pos, self.tab_quat)
+                o, d, od, dd = jvp.raygen_jvp(self.Kinv, batch["position"].contiguous(), pos, rot, dpos, drot)
+            jit = None if jitter_grad is None else jitter_grad.to(torch.float32).contiguous()
+            pk = r.sample(o, d, jit, True)
+            if early:
+                done = torch.cuda.Event()
+                done.record()
+        if early:
+            main.wait_event(done)
+            _adopt((prep, o, d, od, dd, ddd, jit, pk), main)
         bkgd = torch.nn.functional.softplus(self.small[: f.C]) if t.bkgd_is_param else None
-        jit = None if jitter_grad is None else jitter_grad.to(torch.float32).contiguous()
-        colors, colords, opac, ctx = jvp.render_forward(r, o, d, od, dd, jit, bkgd, training=True)
+        colors, colords, opac, ctx = jvp.render_forward(r, o, d, od, dd, jit, bkgd, training=True, pk=pk)
         ch = self._channel_index(batch, 1)
         chan = batch["channel_idx"].to(torch.uint8).contiguous() if f.C > 1 else None
         # a16 of the tangent render in one launch: I = c + eps, I' = c', valid = opacity > 0, d log I / dt = I' / I
@@ -994,6 +1053,7 @@ class Trainer:
     def load_event_params(self, p2n_raw: Optional[torch.Tensor] = None, tau_raw: Optional[torch.Tensor] = None):
         """restore the learned contrast-threshold ratio / refractory period (checkpoint resume)"""
         if p2n_raw is not None:
+            self._ct_read_key = None
             self.ct[0] = p2n_raw.detach().reshape(-1)[0].to(self.ct.device, torch.float32)
             self.ct_raw = float(self.ct[0])
             ratio = float(torch.nn.functional.softplus(self.ct[0]))
@@ -1053,7 +1113,7 @@ class Trainer:
         last = (bi + 1) % k == 0
         loss, aux = self.forward_backward(batch, jitter_start, jitter_end, final=last and not (self.t.w_grad > 0))
         if self.t.w_grad > 0:
-            lg, aux_g = self.grad_loss_forward_backward(batch, jitter_grad, final=last)
+            lg, aux_g = self.grad_loss_forward_backward(batch, jitter_grad, final=last, early=self.early_grad_sampling)
             loss = loss + lg
             aux = dict(aux, grad=aux_g)
         if (bi + 1) % k == 0:

@@ -94,11 +94,13 @@ def render_forward2(r, o, d, od, dd, ddd, pk, bkgd):
     return colors, colords, colorsdd
 
 
-def render_forward(r, o, d, od, dd, jitter, bkgd, training: bool = True):
-    """-> colors (R,C), colords (R,C) [d/dt], opacity (R,), ctx."""
+def render_forward(r, o, d, od, dd, jitter, bkgd, training: bool = True, pk=None):
+    """-> colors (R,C), colords (R,C) [d/dt], opacity (R,), ctx.  pk: the samples, when the caller has already placed them
+    (engine.Trainer.grad_loss_forward_backward(early=True))."""
     f, lib = r.field, _lib.load()
     r._apply_acts()
-    pk = r.sample(o, d, jitter, training)
+    if pk is None:
+        pk = r.sample(o, d, jitter, training)
     n, R, dev = pk.n, o.shape[0], o.device
     if n == 0:
         colors = torch.zeros(R, f.C, device=dev) + (bkgd if bkgd is not None else 0.0)

@@ -1582,6 +1582,48 @@ def test_grad_loss_step_vs_reference_golden(amd, full_table_cache, kernels):
     assert float(tr.ct_grad.abs().max()) == 0.0 and float(tr.ct[0]) != float(g["p2n_raw"].reshape(-1)[0])
 
 
+def test_early_sampling_of_the_third_render_is_exact(amd, full_table_cache):
+    """Trainer.grad_loss_forward_backward(early=True): the third render's samples (timestamps, poses, rays, march, density
+    pre-pass, visibility, both host reads) are placed on the side stream beside the l_diff backward.  Same kernels on the
+    same inputs: loss terms, every gradient and the sample stream itself are identical to the in-order call, with the
+    occupancy sampler's two reads per render (golden step settings) and through Trainer.step (which uses it)."""
+    ops, engine = amd
+    g = load_golden("training_step_grad")
+    table = full_table_cache(g["table_seed"], g["table_scale"])
+    jit = t(g["jitters"])
+    out = []
+    for early in (False, True):
+        tr, batch = _trainer_from_golden(engine, g, table)
+        tr.t.w_grad, tr.t.err_grad, tr.t.pw_grad = float(g["w_grad"]), "mape", None
+        tr.t.train_contrast_threshold = True
+        batch["u_grad"] = dev(g["u_grad"])
+        j0, j1, j2 = dev(jit[1]), dev(jit[2]), dev(jit[0])
+        torch.cuda.synchronize()
+        loss_d, aux = tr.forward_backward(batch, j0, j1)
+        loss_g, aux_g = tr.grad_loss_forward_backward(batch, j2, early=early)
+        assert tr._ready_ev is None                          # consumed (or dropped) by the call
+        f = tr.r.field
+        out.append((float(loss_d), float(loss_g), aux_g["n"], f.grad_all.clone(), tr.small_grad.clone(), tr.ct_grad.clone(),
+                    aux_g["dlog_dt"].clone()))
+    a, b = out
+    assert a[:3] == b[:3], (a[:3], b[:3])
+    assert torch.equal(a[6], b[6])                           # d log I / dt of every ray: forward only, no atomics
+    for x, y in zip(a[3:6], b[3:6]):                         # (the hash-grid scatter's rare float atomics sum in any order)
+        assert float((x - y).abs().max()) <= 1e-6 * float(x.abs().max())
+    # Trainer.step takes the early path; two steps (the second one reads the ratio the first one's Adam moved) vs in-order
+    res = []
+    for early in (False, True):
+        tr, batch = _trainer_from_golden(engine, g, table)
+        tr.t.w_grad, tr.t.err_grad, tr.t.pw_grad = float(g["w_grad"]), "mape", None
+        tr.t.train_contrast_threshold = True
+        tr.early_grad_sampling = early
+        batch["u_grad"] = dev(g["u_grad"])
+        losses = [float(tr.step(batch, dev(jit[1]), dev(jit[2]), jitter_grad=dev(jit[0]))[0]) for _ in range(2)]
+        res.append((losses, tr.r.field.flat.clone(), float(tr.ct[0])))
+    assert res[0][0][0] == res[1][0][0] and abs(res[0][0][1] - res[1][0][1]) < 1e-6 * abs(res[0][0][1])
+    assert abs(res[0][2] - res[1][2]) < 1e-6 and float((res[0][1] - res[1][1]).abs().max()) < 1e-6
+
+
 def test_tangent_mlp_matrix_core_kernels_vs_f32_kernels(amd, spec, full_table_cache):
     """ren_mlp_fwd_jvp_x / ren_mlp_bwd_jvp_x (mode 6: fp32 accuracy, mode 1: bf16 operands) vs the exact-f32 MFMA tangent
     kernels on 200 k samples of a random stream: every output, both feature gradients and the parameter gradient."""
