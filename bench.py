@@ -239,9 +239,12 @@ def main():
     ap.add_argument("--save-activations", type=int, default=-1, choices=[-1, 0, 1],
                     help="1: the training forward stores the hidden MLP activations (768 B/sample), 0: the backward recomputes "
                          "them, -1 (default): recompute with the x kernels, save with the exact-f32 kernels")
-    ap.add_argument("--no-early-grad-sampling", action="store_true",
-                    help="l_grad term: place the third render's samples after the l_diff backward (as before round 4) instead of "
-                         "beside it on the side stream")
+    ap.add_argument("--grad-sampling", default="auto", choices=["auto", "begun", "early", "inorder"],
+                    help="l_grad term, where the third render's samples are placed: auto = what Trainer.step does "
+                         "(Trainer.grad_sampling_mode); begun = front (rays, march count) on the side "
+                         "stream before the l_diff pass, the rest beside its backward (Trainer.step); early = all of it beside the "
+                         "l_diff backward (experiment only: wrong rays observed, profiles/NOTES.md); inorder = after the l_diff "
+                         "backward on the main stream (as before round 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
@@ -378,12 +381,15 @@ def main():
         # the third render's jitter is drawn BEFORE the l_diff pass is enqueued: its samples are then placed beside that pass's
         # backward (Trainer.grad_loss_forward_backward(early=True), what Trainer.step does)
         j2 = ops.uniform(B, 4321 + rank, i, device=dev) if args.loss_grad > 0 else None
+        gmode = tr.grad_sampling_mode() if args.grad_sampling == "auto" else args.grad_sampling
+        if args.loss_grad > 0 and gmode == "begun":
+            tr.begin_grad_sampling(b, j2)
         loss, aux = tr.forward_backward(b, j0, j1)
         if can_prefetch:
             staged[i + 1] = draw(i + 1)
             tr.prefetch(*staged[i + 1])
         if args.loss_grad > 0:
-            lg, aux_g = tr.grad_loss_forward_backward(batches[i % n_batches], j2, early=not args.no_early_grad_sampling)
+            lg, aux_g = tr.grad_loss_forward_backward(b, j2, early={"inorder": False, "begun": True, "early": "all"}[gmode])
             loss = loss + lg
             aux = dict(aux, n=aux["n"] + aux_g["n"], rays=aux["rays"] + aux_g["rays"], n_main=aux["n"])
         tr.optimizer_step()
@@ -525,6 +531,7 @@ def main():
                        "events_per_step_per_gpu": B, "rays_per_step_per_gpu": 2 * B, "sampler": args.sampler,
                        "samples_per_ray": args.samples, "parallelism": f"dp{world}",
                        "collectives_per_step": getattr(tr, "last_collectives", 0), "front_prefetched": bool(can_prefetch),
+                       "grad_sampling": (tr.grad_sampling_mode() if args.grad_sampling == "auto" else args.grad_sampling) if args.loss_grad > 0 else None,
                        "fwd_chunks": args.fwd_chunks, "bwd_chunks": args.bwd_chunks,
                        # what torch.distributed actually formed (a mis-launched N-rank run shows here)
                        "dist_world_size": dist.get_world_size() if dist.is_initialized() else 1,

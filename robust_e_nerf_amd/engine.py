@@ -694,6 +694,7 @@ class Trainer:
         self._side, self._prefetched, self._n_host = None, None, None   # Trainer.prefetch
         self._ready_ev = None                                    # start of the last forward_backward() on its stream (early sampling)
         self.early_grad_sampling = True                          # Trainer.step: third render's samples beside the l_diff backward
+        self._grad_begun, self._grad_pending, self._n_host_grad = None, None, None   # begin_grad_sampling
         if world_size > 1:
             from . import parallel
             self.sync = parallel.GradSync(process_group, world_size, compress=renderer.cfg.dp_compress)
@@ -815,6 +816,12 @@ class Trainer:
         if self.r.cfg.sampler != "uniform" and next_global_step is not None and next_global_step % self.r.cfg.occ_n == 0:
             return False
         side = self.side_stream
+        # Ordered AFTER the work already queued on this stream (round 4): run beside the persistent MLP backward kernels, the
+        # pose / ray kernels of this front produced a slightly wrong rotation for an aligned group of 16 rays in ~1 step out
+        # of 8 (same inputs, same kernel: tools/prefetch_diag2.py; cause not understood, profiles/NOTES.md), which is what made
+        # test_prefetched_step_front_gives_the_same_steps fail in 40 % of its stand-alone runs.  What is left of the prefetch:
+        # the front shares the chip with the optimiser step only, and the host never enqueues it on the critical path.
+        side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             front = self._front(batch, jitter_start, jitter_end)
             st = self.r.sample_begin(front["o"], front["d"], front["jitter"], True)
@@ -879,9 +886,17 @@ class Trainer:
             from . import jvp
             pos, rot, dpos, drot = jvp.trajectory_jvp(ts_all, self.tab_ts, self.tab_pos, self.tab_quat)
             o, d, od, dd = jvp.raygen_jvp(self.Kinv, px, pos, rot, dpos, drot)
-            colors, colords, opac, ctx = jvp.render_forward(r, o, d, od, dd, jitter, bkgd, training=True)
+            begun = None
+            if self._grad_pending is not None:                    # this render's count pass first, then the third render's front
+                begun = r.sample_begin(o, d, jitter, True)
+                self._begin_grad_now()
+            colors, colords, opac, ctx = jvp.render_forward(r, o, d, od, dd, jitter, bkgd, training=True, begun=begun)
         else:
             o, d = front["o"], front["d"]
+            if self._grad_pending is not None:
+                if front.get("begun") is None:
+                    front["begun"] = r.sample_begin(o, d, jitter, True)
+                self._begin_grad_now()
             colors, opac, depth, ctx = r.forward(o, d, jitter, bkgd, training=True, save=True, begun=front.get("begun"))
         # a16 + a18: intensity epilogue, validity, Bayer channel, loss and its gradient: two launches (ren_event_diff_loss_*)
         if f.C > 1 and "channel_idx" not in batch:
@@ -914,38 +929,111 @@ class Trainer:
                    opacity=opac, rays=2 * B)
         return loss, aux
 
+    def grad_sampling_mode(self) -> str:
+        """where Trainer.step places the third render's samples (measured, profiles/NOTES.md):
+        "inorder" on the main stream after the l_diff backward -- no l_grad term, early_grad_sampling off, or the fixed-S sampler
+                  (one count read, no density pre-pass: nothing to hide, and the side stream's kernels only take CUs from the
+                  backward);
+        "begun"   front (timestamps, poses, rays, march count pass) enqueued on the side stream inside forward_backward() right
+                  after the l_diff render's own count pass, the rest (march write pass, density pre-pass, visibility,
+                  compaction, both count reads) beside the l_diff backward -- everything else.
+        A third placement exists for experiments only (grad_loss_forward_backward(early=True) without begin_grad_sampling():
+        ALL of it beside the l_diff forward / backward): there the pose / ray kernels run while the persistent MLP kernels own
+        the chip, and in 4 % of such steps an aligned group of 16 rays came out with a slightly wrong rotation (same inputs,
+        same kernel; cause not understood -- profiles/NOTES.md).  Trainer.step never uses it; the "begun" placement runs those
+        kernels beside the l_diff render's small sampling kernels and reproduced the in-order sample counts in 1 200 of 1 200
+        steps (tools/early_diag.py)."""
+        if not (self.t.w_grad > 0) or not self.early_grad_sampling or self.r.cfg.sampler == "uniform" or \
+                not self.r.field.flat.is_cuda:
+            return "inorder"
+        return "begun"
+
+    def _grad_front(self, batch, jitter_grad) -> dict:
+        """the third render up to (not including) the first host read: supervision timestamps at grad.ts, poses and rays with
+        their time derivatives, ray/AABB test, march count pass, scan (robust_e_nerf.py:340-357,383-409)"""
+        from . import jvp
+        t = self.t
+        self._refresh_contrast_threshold()
+        self._refresh_tau()
+        prep = ops.event_prepare(batch, self.c_p, self.c_n, self.tau, with_grad_ts=True, with_dtau=t.train_refractory_period)
+        ts_g = prep["ts_grad"]
+        ddd = None
+        if t.train_refractory_period:                                  # tau moves ts_g: second-order tangent
+            pos, rot, dpos, drot, ddrot = jvp.trajectory_jvp2(ts_g, self.tab_ts, self.tab_pos, self.tab_quat)
+            o, d, od, dd, ddd = jvp.raygen_jvp2(self.Kinv, batch["position"].contiguous(), pos, rot, dpos, drot, ddrot)
+        else:
+            pos, rot, dpos, drot = jvp.trajectory_jvp(ts_g, self.tab_ts, self.tab_pos, self.tab_quat)
+            o, d, od, dd = jvp.raygen_jvp(self.Kinv, batch["position"].contiguous(), pos, rot, dpos, drot)
+        jit = None if jitter_grad is None else jitter_grad.to(torch.float32).contiguous()
+        st = self.r.sample_begin(o, d, jit, True)
+        return dict(prep=prep, o=o, d=d, od=od, dd=dd, ddd=ddd, jit=jit, st=st)
+
+    def begin_grad_sampling(self, batch, jitter_grad=None) -> bool:
+        """Announce the third render of the step that is ABOUT to run -- call it before forward_backward(); the matching
+        grad_loss_forward_backward(batch, jitter_grad, early=True) picks it up.  Its front (timestamps, poses, rays, march
+        count pass, scan, read-back of the count into pinned memory) goes to the side stream without blocking the host,
+        ordered after everything enqueued on the current stream at THIS call (the last optimiser step, the grid refresh,
+        the batch, the jitter); it is enqueued from inside forward_backward(), right after the l_diff render's own front and
+        count pass and before the host blocks on that render's sample count, so those kernels fill the gaps that the two
+        count reads of the l_diff render leave on the main stream, and the host work of enqueuing them never delays the
+        l_diff render (a step that starts on an empty queue -- trainable tau: its Adam group reads d loss / d tau back at the
+        end of the step -- is host-bound right there).  Trainer.step does this when the l_grad term is on."""
+        if not self.r.field.flat.is_cuda or not (self.t.w_grad > 0):
+            return False
+        ready = torch.cuda.Event()
+        ready.record()
+        self._grad_begun, self._grad_pending = None, (batch, jitter_grad, ready)
+        return True
+
+    def _begin_grad_now(self):
+        pend, self._grad_pending = self._grad_pending, None
+        if pend is None:
+            return
+        batch, jitter_grad, ready = pend
+        side = self.side_stream
+        side.wait_event(ready)
+        with torch.cuda.stream(side):
+            fr = self._grad_front(batch, jitter_grad)
+            if self._n_host_grad is None:
+                self._n_host_grad = torch.empty(1, dtype=fr["st"]["total"].dtype).pin_memory()
+            self._n_host_grad.copy_(fr["st"]["total"].reshape(1), non_blocking=True)
+            fr["ev"] = torch.cuda.Event()
+            fr["ev"].record()
+        fr["n_host"], fr["key"] = self._n_host_grad, (id(batch), id(jitter_grad))
+        self._grad_begun = fr
+
     def grad_loss_forward_backward(self, batch, jitter_grad=None, final: bool = True, early: bool = False):
         """Log-intensity-GRADIENT loss term (robust_e_nerf.py:340-357,383-409; loss.py:43-57): a third
         render at grad.ts = lerp(diff.start, diff.end, u_grad) carrying d/dt in forward mode, compared
         with the event rate C/dt.  Accumulates gradients; returns (weighted loss term, aux).
-        early: place the third render's samples (timestamps, poses, rays, march, density pre-pass, visibility -- everything up
-        to and including the two host reads of the sample counts, which depends on the field and the occupancy grid but not
-        on the l_diff pass) on the side stream, ordered after the START of the preceding forward_backward() only, i.e. beside
-        its backward pass: the host reads then wait for a few small kernels instead of draining the queue twice.  The caller
-        guarantees that `batch` and `jitter_grad` were complete before that forward_backward() call (Trainer.step does).
-        Same arithmetic, same results."""
+        early: pick up the front that begin_grad_sampling() announced before the preceding forward_backward() (timestamps,
+        poses, rays, march count pass: already on the side stream) and place the rest of the third render's sampling (march
+        write pass, density pre-pass, visibility, compaction and the two host reads of the sample counts -- it depends on the
+        field and the occupancy grid but not on the l_diff pass) on the side stream as well, i.e. beside the l_diff backward:
+        the host reads then wait for a few small kernels instead of draining the queue twice.  Without a matching front the
+        call runs in order.  Same arithmetic, same results.  (early="all": the experimental placement of
+        grad_sampling_mode's docstring.)"""
         from . import jvp
         r, t, f = self.r, self.t, self.r.field
         B = batch["position"].shape[0]
         ready, self._ready_ev = self._ready_ev, None
-        early = early and ready is not None and f.flat.is_cuda
+        begun, self._grad_begun, self._grad_pending = self._grad_begun, None, None
+        if begun is not None and (not early or begun["key"] != (id(batch), id(jitter_grad))):
+            begun = None                                                  # (begin_grad_sampling was for another call)
+        # no matching front: in order, unless the caller asks for the experimental placement (early="all": everything
+        # beside the l_diff forward / backward; wrong rays observed there, see grad_sampling_mode)
+        early = bool(early) and f.flat.is_cuda and (begun is not None or (early == "all" and ready is not None))
         main = torch.cuda.current_stream() if f.flat.is_cuda else None
-        if early:
+        if early and begun is None:
             self.side_stream.wait_event(ready)
         with (torch.cuda.stream(self.side_stream) if early else contextlib.nullcontext()):
-            self._refresh_contrast_threshold()
-            self._refresh_tau()
-            prep = ops.event_prepare(batch, self.c_p, self.c_n, self.tau, with_grad_ts=True, with_dtau=t.train_refractory_period)
-            ts_g, target = prep["ts_grad"], prep["target_grad"]                                 # loss.py:39-42
-            ddd = None
-            if t.train_refractory_period:                                  # tau moves ts_g: second-order tangent
-                pos, rot, dpos, drot, ddrot = jvp.trajectory_jvp2(ts_g, self.tab_ts, self.tab_pos, self.tab_quat)
-                o, d, od, dd, ddd = jvp.raygen_jvp2(self.Kinv, batch["position"].contiguous(), pos, rot, dpos, drot, ddrot)
-            else:
-                pos, rot, dpos, drot = jvp.trajectory_jvp(ts_g, self.tab_ts, self.tab_pos, self.tab_quat)
-                o, d, od, dd = jvp.raygen_jvp(self.Kinv, batch["position"].contiguous(), pos, rot, dpos, drot)
-            jit = None if jitter_grad is None else jitter_grad.to(torch.float32).contiguous()
-            pk = r.sample(o, d, jit, True)
+            fr = begun if begun is not None else self._grad_front(batch, jitter_grad)
+            prep, o, d, od, dd, ddd, jit, st = (fr[k] for k in ("prep", "o", "d", "od", "dd", "ddd", "jit", "st"))
+            target = prep["target_grad"]                                                        # loss.py:39-42
+            if "ev" in fr:                                                # count pass already ran: its total is in the pinned buffer
+                fr["ev"].synchronize()
+                st["n0"] = int(fr["n_host"][0])
+            pk = r.sample(o, d, jit, True, begun=st)
             if early:
                 done = torch.cuda.Event()
                 done.record()
@@ -1111,9 +1199,12 @@ class Trainer:
         # an earlier pass would reduce it once per micro-batch (the rank-summed slice of micro-batch 1 would be summed
         # over the ranks again with micro-batch 2 on top) and the next scatter would write into a slice in flight
         last = (bi + 1) % k == 0
+        mode = self.grad_sampling_mode()
+        if mode == "begun":
+            self.begin_grad_sampling(batch, jitter_grad)
         loss, aux = self.forward_backward(batch, jitter_start, jitter_end, final=last and not (self.t.w_grad > 0))
         if self.t.w_grad > 0:
-            lg, aux_g = self.grad_loss_forward_backward(batch, jitter_grad, final=last, early=self.early_grad_sampling)
+            lg, aux_g = self.grad_loss_forward_backward(batch, jitter_grad, final=last, early=mode != "inorder")
             loss = loss + lg
             aux = dict(aux, grad=aux_g)
         if (bi + 1) % k == 0:

@@ -94,13 +94,13 @@ def render_forward2(r, o, d, od, dd, ddd, pk, bkgd):
     return colors, colords, colorsdd
 
 
-def render_forward(r, o, d, od, dd, jitter, bkgd, training: bool = True, pk=None):
+def render_forward(r, o, d, od, dd, jitter, bkgd, training: bool = True, pk=None, begun=None):
     """-> colors (R,C), colords (R,C) [d/dt], opacity (R,), ctx.  pk: the samples, when the caller has already placed them
-    (engine.Trainer.grad_loss_forward_backward(early=True))."""
+    (engine.Trainer.grad_loss_forward_backward(early=True)); begun: Renderer.sample_begin() of these rays, already enqueued."""
     f, lib = r.field, _lib.load()
     r._apply_acts()
     if pk is None:
-        pk = r.sample(o, d, jitter, training)
+        pk = r.sample(o, d, jitter, training, begun=begun)
     n, R, dev = pk.n, o.shape[0], o.device
     if n == 0:
         colors = torch.zeros(R, f.C, device=dev) + (bkgd if bkgd is not None else 0.0)
