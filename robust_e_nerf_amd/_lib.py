@@ -154,6 +154,12 @@ def load() -> ctypes.CDLL:
         raise RenError(
             f"{LIB_PATH} is missing: build it with `python -m robust_e_nerf_amd.build` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    # The library must be the one these sources produce (content stamp, robust_e_nerf_amd/build.py): a stale .so -- sources
+    # edited or reverted without a rebuild -- measures and tests something else than the tree says (it happened in round 4).
+    from . import build as _build
+    if os.environ.get("REN_ALLOW_STALE_LIB") != "1" and not _build.is_current():
+        raise RenError(f"{LIB_PATH} is STALE: it was not built from the sources next to it; run "
+                       "`python -m robust_e_nerf_amd.build` (or set REN_ALLOW_STALE_LIB=1 to load it anyway)")
     # PyTorch-ROCm bundles its own libamdhip64; it must be in the process BEFORE this library so
     # both resolve to the SAME HIP runtime (otherwise torch's device pointers are foreign to our
     # launches and every kernel fails with a launch error).

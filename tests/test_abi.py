@@ -89,6 +89,18 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
         _lib.load()
 
 
+def test_stale_library_fails_loudly(monkeypatch):
+    """a .so that was not built from the sources next to it (edited or reverted without a rebuild) is refused by the loader"""
+    from robust_e_nerf_amd import _lib, build
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(build, "is_current", lambda *a, **k: False)
+    monkeypatch.delenv("REN_ALLOW_STALE_LIB", raising=False)
+    with pytest.raises(_lib.RenError, match="STALE"):
+        _lib.load()
+    monkeypatch.setenv("REN_ALLOW_STALE_LIB", "1")
+    assert _lib.load() is not None
+
+
 def test_level_table_matches_oracle():
     from oracle import hashgrid
     from robust_e_nerf_amd import ops
