@@ -28,7 +28,7 @@ def run(mode):
         if mode == "begun":
             tr.begin_grad_sampling(b, j2)
         loss, aux = tr.forward_backward(b, j0, j1)
-        lg, aux_g = tr.grad_loss_forward_backward(b, j2, early=mode != "inorder")
+        lg, aux_g = tr.grad_loss_forward_backward(b, j2, early={"inorder": False, "begun": True, "early": "all"}[mode])
         tr.optimizer_step()
         res.append("%.7f %.7f n=%d ng=%d" % (float(loss), float(lg), aux["n"], aux_g["n"]))
     return " | ".join(res)
