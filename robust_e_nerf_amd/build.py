@@ -23,7 +23,16 @@ COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-at
 # the sampler must match the sequential oracle bit for bit: no FMA contraction there
 # the one-wave-per-SIMD MLP backward kernels: MFMA results in VGPRs (the chain's VALU work reads them directly) instead of
 # the AGPR form + one v_accvgpr_read per result register that hipcc picks for kernels with a 512-register budget
-PER_FILE = {"ren_sampling.hip": ["-ffp-contract=off"], "ren_jvp2.hip": ["-fno-slp-vectorize"],
+# -fno-slp-vectorize (no packed-FP32 `v_pk_*_f32` VALU code) for every file of small, non-matrix kernels that can meet the
+# matrix-core kernels on the chip through a second stream: with the SLP vectoriser's packed code, `pose_rays_kernel` /
+# `trajectory_jvp_kernel` returned a wrong rotation for an aligned group of 16 rays in 4-15 % of the steps whenever they ran
+# beside the persistent MLP kernels, and never without it (round 4, profiles/NOTES.md: 11 of 48 and 11 of 24 three-step runs
+# -> 0 of 48 and 0 of 24, same placement, same box); ren_jvp2.hip had needed the same flag in round 3 for wrong 16-sample
+# half-blocks on a first launch.  Same arithmetic (packed and scalar FP32 operations round alike), no measurable cost: these
+# kernels are latency- or memory-bound.
+NO_SLP = ["-fno-slp-vectorize"]
+PER_FILE = {"ren_sampling.hip": ["-ffp-contract=off"] + NO_SLP, "ren_jvp2.hip": NO_SLP, "ren_pose.hip": NO_SLP,
+            "ren_jvp.hip": NO_SLP, "ren_train.hip": NO_SLP, "ren_composite.hip": NO_SLP,
             "ren_mlp_x.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], "ren_mlp_jvp_x.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 

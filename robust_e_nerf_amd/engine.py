@@ -818,7 +818,8 @@ class Trainer:
         side = self.side_stream
         # Ordered AFTER the work already queued on this stream (round 4): run beside the persistent MLP backward kernels, the
         # pose / ray kernels of this front produced a slightly wrong rotation for an aligned group of 16 rays in ~1 step out
-        # of 8 (same inputs, same kernel: tools/prefetch_diag2.py; cause not understood, profiles/NOTES.md), which is what made
+        # of 8 (same inputs, same kernel: tools/prefetch_diag2.py; packed-FP32 code beside matrix-core waves, profiles/NOTES.md:
+        # those files are now built without it, and this ordering stays as the second line of defence), which is what made
         # test_prefetched_step_front_gives_the_same_steps fail in 40 % of its stand-alone runs.  What is left of the prefetch:
         # the front shares the chip with the optimiser step only, and the host never enqueues it on the critical path.
         side.wait_stream(torch.cuda.current_stream())
@@ -939,8 +940,9 @@ class Trainer:
                   compaction, both count reads) beside the l_diff backward -- everything else.
         A third placement exists for experiments only (grad_loss_forward_backward(early=True) without begin_grad_sampling():
         ALL of it beside the l_diff forward / backward): there the pose / ray kernels run while the persistent MLP kernels own
-        the chip, and in 4 % of such steps an aligned group of 16 rays came out with a slightly wrong rotation (same inputs,
-        same kernel; cause not understood -- profiles/NOTES.md).  Trainer.step never uses it; the "begun" placement runs those
+        the chip, and in 4-8 % of such steps an aligned group of 16 rays came out with a slightly wrong rotation (same inputs,
+        same kernel; traced to the packed-FP32 code the SLP vectoriser made of the pose arithmetic, which build.py now
+        switches off for those files -- profiles/NOTES.md).  Trainer.step never uses it; the "begun" placement runs those
         kernels beside the l_diff render's small sampling kernels and reproduced the in-order sample counts in 1 200 of 1 200
         steps (tools/early_diag.py)."""
         if not (self.t.w_grad > 0) or not self.early_grad_sampling or self.r.cfg.sampler == "uniform" or \

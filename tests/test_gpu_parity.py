@@ -405,20 +405,25 @@ def test_activation_alternatives_whole_step_vs_oracle(amd, spec, full_table_cach
     e_ct = rel_err(tr.ct_grad[:1].cpu(), p2n.grad.reshape(-1)[:1])
     print(f"activation alternatives ({tag}), whole step vs oracle: loss {abs(loss - float(loss_o)) / abs(float(loss_o)):.2e} "
           f"MLP grads {max(e_gw.values()):.2e} table {e_gt:.2e} d/dtau {e_tau:.2e} d/dC_p {e_ct:.2e}")
-    assert e_tau < 5e-3 and e_ct < 1e-4
+    assert e_ct < 1e-4
     if tag == "smooth":
-        assert max(e_gw.values()) < 5e-3 and e_gt < 3e-3
+        assert max(e_gw.values()) < 5e-3 and e_gt < 3e-3 and e_tau < 5e-3
         return
-    c_gw, c_gt = {k: 0.0 for k in e_gw}, 0.0                              # the control: an ulp or two on the pose table
+    c_gw, c_gt, c_tau = {k: 0.0 for k in e_gw}, 0.0, 0.0                  # the control: an ulp or two on the pose table
     for eps in (1e-7, -1e-7, 2.5e-7):
-        _, _, po2, _, _ = oracle_step(1.0 + eps)
+        _, _, po2, tau2, _ = oracle_step(1.0 + eps)
         c_gw = {k: max(c_gw[k], rel_err(po2[k].grad, po[k].grad)) for k in e_gw}
         c_gt = max(c_gt, rel_err(po2["hash"].grad.reshape(-1)[nz], po["hash"].grad.reshape(-1)[nz]))
-    print(f"    control (oracle with poses x (1 +- 1e-7) vs oracle): MLP grads {max(c_gw.values()):.2e} table {c_gt:.2e}")
+        c_tau = max(c_tau, rel_err(tau2.grad, tau_raw.grad))
+    print(f"    control (oracle with poses x (1 +- 1e-7) vs oracle): MLP grads {max(c_gw.values()):.2e} table {c_gt:.2e} "
+          f"d/dtau {c_tau:.2e}")
     assert max(c_gw.values()) > 5e-3                                      # the ill-conditioning is real, not a loose bound
     for k in e_gw:
         assert e_gw[k] < 2 * c_gw[k] + 2e-3, (k, e_gw[k], c_gw[k])
     assert e_gt < 2 * c_gt + 2e-3
+    # d loss / d tau goes through dI/dt of the same relu field: held to the control as well (round 4: the pose kernels were
+    # rebuilt without packed-FP32 code, the rays moved in the last ulp, and this number went from 4e-3 to 1.2e-2)
+    assert e_tau < 2 * c_tau + 5e-3, (e_tau, c_tau)
 
 
 def _mlp_float64_reference(params, feat_frag, x, d, d_rgb, d_sig, n, C=1, chunk=1 << 20):
