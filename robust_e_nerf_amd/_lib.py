@@ -158,8 +158,12 @@ def load() -> ctypes.CDLL:
     # edited or reverted without a rebuild -- measures and tests something else than the tree says (it happened in round 4).
     from . import build as _build
     if os.environ.get("REN_ALLOW_STALE_LIB") != "1" and not _build.is_current():
-        raise RenError(f"{LIB_PATH} is STALE: it was not built from the sources next to it; run "
-                       "`python -m robust_e_nerf_amd.build` (or set REN_ALLOW_STALE_LIB=1 to load it anyway)")
+        if not os.path.exists(_build.STAMP):          # a library that travelled without its stamp cannot be checked: say so, load it
+            import sys
+            print(f"[ren_amd] warning: {_build.STAMP} is missing, cannot verify that the library matches the sources", file=sys.stderr)
+        else:
+            raise RenError(f"{LIB_PATH} is STALE: it was not built from the sources next to it; run "
+                           "`python -m robust_e_nerf_amd.build` (or set REN_ALLOW_STALE_LIB=1 to load it anyway)")
     # PyTorch-ROCm bundles its own libamdhip64; it must be in the process BEFORE this library so
     # both resolve to the SAME HIP runtime (otherwise torch's device pointers are foreign to our
     # launches and every kernel fails with a launch error).
