@@ -33,6 +33,10 @@ COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-at
 NO_SLP = ["-fno-slp-vectorize"]
 PER_FILE = {"ren_sampling.hip": ["-ffp-contract=off"] + NO_SLP, "ren_jvp2.hip": NO_SLP, "ren_pose.hip": NO_SLP,
             "ren_jvp.hip": NO_SLP, "ren_train.hip": NO_SLP, "ren_composite.hip": NO_SLP,
+            # the hash-grid kernels run beside the MLP kernels in every step: same flag (encoder 4.55 ms either way, bit-identical;
+            # binned backward 8.18-8.21 -> 8.04-8.05 ms at n = 16.8 M).  The matrix-core files keep the vectoriser: ren_mlp_x.hip
+            # without it costs 2 % forward / 2-7 % backward, and those kernels repeat bit for bit (tools/chunk_stress.py)
+            "ren_hashgrid.hip": NO_SLP, "ren_hashgrid_binned.hip": NO_SLP,
             "ren_mlp_x.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], "ren_mlp_jvp_x.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
