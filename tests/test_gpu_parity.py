@@ -1644,6 +1644,41 @@ def test_early_sampling_of_the_third_render_is_exact(amd, full_table_cache):
         assert abs(res[0][3] - res[1][3]) <= 1e-9 * abs(res[0][3])
 
 
+def test_two_stream_forward_and_backward_repeat_the_single_stream_results(amd):
+    """The step's own concurrency (encoder beside MLP per forward chunk; MLP backward beside the binned scatter with
+    bwd_chunks) at 8.4 M samples, six times each: colours and opacities bit for bit (no atomics in the forward), gradients to
+    the scatter's float-atomic noise.  A transient wrong value in either stream (the packed-FP32 hazard of round 4 showed as
+    wrong 16-lane groups, profiles/NOTES.md) breaks the equality."""
+    import math
+    ops, engine = amd
+    R, S = 65536, 128
+    gen = torch.Generator().manual_seed(0)
+    ang = torch.rand(R, generator=gen) * 2 * math.pi
+    o = torch.stack([4 * torch.cos(ang), 4 * torch.sin(ang), torch.rand(R, generator=gen) - 0.5], -1)
+    d = (torch.rand(R, 3, generator=gen) - 0.5) * 1.6 - o
+    d = d / d.norm(dim=-1, keepdim=True)
+    o, d = dev(o.float().contiguous()), dev(d.float().contiguous())
+    jit, gcol = dev(torch.rand(R, generator=gen)), dev(torch.randn(R, 1, generator=gen))
+    fld = engine.NGPField(DEV)
+
+    def run(fc, bc):
+        r = engine.Renderer(fld, engine.RenderCfg(sampler="uniform", n_uniform=S, fwd_chunks=fc, bwd_chunks=bc))
+        fld.grad.zero_()
+        colors, opac, _, ctx = r.forward(o, d, jit, None, training=True, save=True)
+        r.backward(ctx, gcol, final=True)
+        torch.cuda.synchronize()
+        return colors.clone(), opac.clone(), fld.grad.clone()
+
+    c0, a0, g0 = run(1, 1)
+    gmax = float(g0.abs().max())
+    for _ in range(6):
+        for fc, bc in ((8, 1), (8, 4)):
+            c, a, gg = run(fc, bc)
+            assert torch.equal(c, c0) and torch.equal(a, a0), (fc, bc, int((c != c0).sum()))
+            assert float((gg - g0).abs().max()) < 1e-5 * gmax
+    fld.grad.zero_()
+
+
 def test_begun_sampling_of_the_third_render_repeats_exactly(amd, full_table_cache):
     """Regression guard for a concurrency hazard found in round 4 (profiles/NOTES.md): pose / ray kernels enqueued on a side
     stream WHILE the persistent MLP kernels own the chip produced a wrong rotation for an aligned group of 16 rays in a few
