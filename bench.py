@@ -214,8 +214,9 @@ def main():
                     help="BASELINE configs[2] numerics: bf16-rounded linear inputs/weights, fp32 accumulate + composite")
     ap.add_argument("--prefetch", action="store_true",
                     help="run the next step's batch / ray / sample-count front on a side stream (Trainer.prefetch): the host no "
-                         "longer waits for the previous step at the sample-count read; measured 12.03 vs 12.04 ms/step, i.e. nothing "
-                         "-- the step's 0.35 ms of GPU idle is inter-kernel dispatch latency, not this wait")
+                         "longer enqueues it on the critical path; ordered after the current step's backward since round 4 "
+                         "(profiles/NOTES.md), measured worth nothing either way: 12.03 vs 12.04 ms/step in round 2, 3.21 vs 3.11 "
+                         "with the occupancy sampler now")
     ap.add_argument("--fwd-chunks", type=int, default=8,
                     help="> 1: hash encoding and MLP forward of alternate sample chunks on two HIP streams")
     ap.add_argument("--bwd-chunks", type=int, default=1,
