@@ -8,3 +8,4 @@ for p in 1 2 3 4; do timeout 600 python tools/early_diag.py 12 2>&1 | grep -v am
   | awk '{k=$1" "$2" "$3" "$4" "$5; c[k]+=$7} END {for (k in c) print c[k], k}' | sort -k2
 for v in none unordered; do for p in 1 2 3 4; do DIAG_VAR=$v timeout 300 python tools/prefetch_diag.py occgrid 6 2>&1 | grep -v amdgpu.ids | awk '{print $1,$2,$3,$(NF-3),$(NF-2)}'; done; done | sort | uniq -c
 timeout 300 python tools/chunk_stress.py 20 2>&1 | tail -2
+timeout 600 python tools/aggressor_probe.py 200 2>&1 | grep -v amdgpu.ids     # every line 0 on the tree's own build
