@@ -55,6 +55,25 @@ torch.cuda.synchronize()
 o_ref, d_ref = ops.pose_rays(ts, px, Kinv, tab_ts, tab_pos, tab_quat)
 torch.cuda.synchronize()
 side = torch.cuda.Stream()
+# ---- a second victim: the density pre-pass of a render (mlp_fwd_x, density only -- a matrix-core kernel WITH packed code of
+# its own), which Trainer.step's "begun" placement runs on the side stream beside the l_diff backward
+nv = 262144
+xv = (torch.rand(nv, 3, generator=gen) * 2.6 - 1.3).to(dev)
+featv = (torch.rand(ops.n_blocks32(nv) * 1024, generator=gen) - 0.5).to(dev)
+torch.cuda.synchronize()
+_, sig_ref, _, _ = ops.mlp_fwd_x(params, C, 6, featv, scene, x_world=xv, dirs=None, n=nv, density_only=True)
+torch.cuda.synchronize()
+for name, fn in AGG.items():
+    bad = torch.zeros(1, device=dev, dtype=torch.int64)
+    for it in range(iters):
+        fn()
+        with torch.cuda.stream(side):
+            _, sg, _, _ = ops.mlp_fwd_x(params, C, 6, featv, scene, x_world=xv, dirs=None, n=nv, density_only=True)
+            bad += ((sg != sig_ref).sum() > 0).to(torch.int64)
+        if it % 8 == 7:
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    print(f"main stream: {name:45s} side-stream density pre-pass (mlp_fwd_x) launches with wrong values: {int(bad)} of {iters}", flush=True)
 for name, fn in AGG.items():
     bad_iters = torch.zeros(1, device=dev, dtype=torch.int64)
     bad_rays = torch.zeros(1, device=dev, dtype=torch.int64)
