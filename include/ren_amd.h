@@ -70,20 +70,19 @@ int ren_abi_version(void);                       /* bumps when a signature chang
  *   REN_KNOB_MARCH_SEQUENTIAL  1: sequential occupancy marcher instead of the speculative one
  *   REN_KNOB_HG_VARIANT        atomic hash-grid backward: bit 0 XCD-affine level mapping, bit 1 lane-pair atomics (default 2)
  *   REN_KNOB_VFIELD_PLAIN      1: arch mlp, bf16 mode: the forward / backward kernels without the software-pipelined epilogue
- *   REN_KNOB_MLP_BWD_CUS       persistent workgroups (= CUs) the fused MLP backward kernels occupy, 1 .. 256 (default 256); the
- *                              chunked backward of engine.py lowers it while a scatter runs on the second stream
- *   REN_KNOB_ACTIVATIONS       MODEL configuration rather than tuning: the activation alternatives of the YAML (models/nerf.py:8-29)
- *                              for the exact-f32 MLP kernels (ren_mlp_fwd/bwd[_save/_saved/_bf16], ren_mlp_fwd/bwd_jvp,
- *                              ren_mlp_fwd_jvp2).  Code: bits 0-1 base hidden layers (0 softplus beta 100, 1 relu), bits 2-3
- *                              density (0 shifted_trunc_exp, 1 softplus, 2 shifted_softplus), bits 4-5 head hidden layers
- *                              (0 | 1 as the base), bits 6-7 radiance (0 softplus, 1 sigmoid).  0 (default) = every shipped
- *                              config.  The bf16-matrix-core kernels (ren_mlp_*_x) implement code 0 only and return
- *                              REN_ERR_UNSUPPORTED otherwise.
  *   REN_KNOB_HGB_SUBREGION     binned scatter, which of a pair bin's 8 sub-regions a workgroup appends to: 1 (default) = the one
  *                              of the XCD it runs on, 0 = (workgroup index / 8) % 8, i.e. every sub-region written from all XCDs
  *                              (the A/B of the per-XCD layout: same code, same cursors, only the line sharing differs) */
 enum { REN_KNOB_HGB_NO_PAIRS = 0, REN_KNOB_HGB_HALVE_REGIONS = 1, REN_KNOB_MARCH_SEQUENTIAL = 2, REN_KNOB_HG_VARIANT = 3,
-       REN_KNOB_VFIELD_PLAIN = 4, REN_KNOB_HGB_SUBREGION = 5, REN_KNOB_MLP_BWD_CUS = 6, REN_KNOB_ACTIVATIONS = 7, REN_KNOB_COUNT = 8 };
+       REN_KNOB_VFIELD_PLAIN = 4, REN_KNOB_HGB_SUBREGION = 5, REN_KNOB_COUNT = 6 };
+/* `activations` argument of the ren_mlp_* / ren_vanilla_* entry points (ABI 24; until ABI 23 a process-wide knob): the
+ * activation alternatives of the YAML (models/nerf.py:8-29), i.e. MODEL configuration, passed per call so that renderers
+ * with different sets can launch from different host threads / streams of one process.  Code: bits 0-1 base hidden layers
+ * (0 softplus beta 100, 1 relu), bits 2-3 density (0 shifted_trunc_exp, 1 softplus, 2 shifted_softplus), bits 4-5 head hidden
+ * layers (0 | 1 as the base), bits 6-7 radiance (0 softplus, 1 sigmoid).  0 = every shipped config.  The exact-f32 kernels
+ * (ren_mlp_fwd/bwd[_save/_saved/_bf16], ren_mlp_fwd/bwd_jvp, ren_mlp_fwd_jvp2) take every code, the arch-mlp output heads
+ * (ren_vanilla_heads_*) its density / radiance kinds; the bf16-matrix-core kernels (ren_mlp_*_x) and the fused arch-mlp field
+ * (ren_vanilla_fwd / _bwd) implement code 0 only and return REN_ERR_UNSUPPORTED otherwise. */
 int ren_set_knob(int32_t knob, int32_t value);    /* REN_OK or REN_ERR_BAD_ARG */
 int ren_get_knob(int32_t knob);
 const char *ren_build_info(void);                /* "gfx950 ..."                        */
@@ -202,7 +201,7 @@ int ren_hashgrid_bwd_binned(const ren_grid_desc *grid, float *grad_table, const 
  * occ_eval_fn, models/nerf.py:197-198).
  * base_out (may be NULL): raw base-MLP outputs, fragment layout [((i>>5)*8+g)*64+lane]
  * (ceil(n/32)*512 floats), saved for the backward pass. */
-int ren_mlp_fwd(const float *mlp_params, int32_t radiance_dim, const float *feat,
+int ren_mlp_fwd(const float *mlp_params, int32_t radiance_dim, int32_t activations, const float *feat,
                 const ren_scene_desc *scene, const float *x_world, const float *dirs,
                 const float *rays_o, const float *rays_d, const int32_t *ray_indices,
                 const float *t_starts, const float *t_ends, int64_t n, int32_t density_only,
@@ -213,7 +212,7 @@ int64_t ren_mlp_bwd_workspace_floats(int32_t radiance_dim);
  * floats) and grad_mlp_params (+=, same concatenated layout).  rgb = forward output;
  * d_base: scratch of ceil(n/32)*512 floats (gradient w.r.t. base_out, fragment layout);
  * workspace: ren_mlp_bwd_workspace_floats() floats.  Deterministic (no atomics). */
-int ren_mlp_bwd(const float *mlp_params, int32_t radiance_dim, const float *feat,
+int ren_mlp_bwd(const float *mlp_params, int32_t radiance_dim, int32_t activations, const float *feat,
                 const float *base_out, const ren_scene_desc *scene,
                 const float *x_world, const float *dirs,
                 const float *rays_o, const float *rays_d, const int32_t *ray_indices,
@@ -389,7 +388,7 @@ int ren_hashgrid_bwd_binned_scatter(const ren_grid_desc *grid, float *grad_table
 int ren_hashgrid_bwd_binned_finish(const ren_grid_desc *grid, float *grad_table, int64_t n, int32_t layout,
                                    void *workspace, void *stream);
 /* fused MLPs with tangent: rgb, rgbd [n,C]; sigma, sigmad [n]; base_out, base_outd (ceil(n/32)*512 floats) */
-int ren_mlp_fwd_jvp(const float *mlp_params, int32_t radiance_dim, const float *feat, const float *featd,
+int ren_mlp_fwd_jvp(const float *mlp_params, int32_t radiance_dim, int32_t activations, const float *feat, const float *featd,
                     const ren_scene_desc *scene, const float *rays_o, const float *rays_d, const float *rays_dd,
                     const int32_t *ray_indices, const float *t_starts, const float *t_ends, int64_t n,
                     float *rgb, float *rgbd, float *sigma, float *sigmad, float *base_out, float *base_outd,
@@ -397,7 +396,7 @@ int ren_mlp_fwd_jvp(const float *mlp_params, int32_t radiance_dim, const float *
 int64_t ren_mlp_bwd_jvp_workspace_floats(int32_t radiance_dim);
 /* reverse pass: (d_rgb, d_rgbd, d_sigma, d_sigmad) -> dfeat, dfeatd (fragment) and grad_mlp_params (+=).
  * scratch: ceil(n/32)*5120 floats; workspace: ren_mlp_bwd_jvp_workspace_floats() floats. */
-int ren_mlp_bwd_jvp(const float *mlp_params, int32_t radiance_dim, const float *feat, const float *featd,
+int ren_mlp_bwd_jvp(const float *mlp_params, int32_t radiance_dim, int32_t activations, const float *feat, const float *featd,
                     const float *base_out, const float *base_outd, const ren_scene_desc *scene,
                     const float *rays_o, const float *rays_d, const float *rays_dd, const int32_t *ray_indices,
                     const float *t_starts, const float *t_ends, int64_t n, const float *rgb,
@@ -408,13 +407,13 @@ int ren_mlp_bwd_jvp(const float *mlp_params, int32_t radiance_dim, const float *
  * mode 6: split-bf16 products at fp32 accuracy; mode 1: plain bf16 operands with fp32 accumulation for value AND tangent
  * of every nn.Linear (BASELINE configs[2]: bf16 MLP + fp32 composite with the log-intensity-gradient loss of
  * robust_e_nerf/models/robust_e_nerf.py:383-409 switched on).  Buffers, scratch and layouts as for the calls above. */
-int ren_mlp_fwd_jvp_x(const float *mlp_params, int32_t radiance_dim, int32_t mode, const float *feat, const float *featd,
+int ren_mlp_fwd_jvp_x(const float *mlp_params, int32_t radiance_dim, int32_t activations, int32_t mode, const float *feat, const float *featd,
                       const ren_scene_desc *scene, const float *rays_o, const float *rays_d, const float *rays_dd,
                       const int32_t *ray_indices, const float *t_starts, const float *t_ends, int64_t n,
                       float *rgb, float *rgbd, float *sigma, float *sigmad, float *base_out, float *base_outd,
                       void *stream);
 int64_t ren_mlp_bwd_jvp_x_workspace_floats(int32_t radiance_dim);
-int ren_mlp_bwd_jvp_x(const float *mlp_params, int32_t radiance_dim, int32_t mode, const float *feat, const float *featd,
+int ren_mlp_bwd_jvp_x(const float *mlp_params, int32_t radiance_dim, int32_t activations, int32_t mode, const float *feat, const float *featd,
                       const float *base_out, const float *base_outd, const ren_scene_desc *scene,
                       const float *rays_o, const float *rays_d, const float *rays_dd, const int32_t *ray_indices,
                       const float *t_starts, const float *t_ends, int64_t n, const float *rgb, const float *d_rgb,
@@ -466,11 +465,11 @@ int ren_grad_loss_bwd(const float *intensity, const float *intensity_dot, const 
  * `mlp_params_bf16` is the caller's bf16-rounded copy of the parameter block (still f32 storage); products
  * accumulate in fp32, bias and activations stay fp32.  The backward is the exact derivative of that forward
  * (straight-through rounding) and accumulates into the fp32 master gradient. */
-int ren_mlp_fwd_bf16(const float *mlp_params_bf16, int32_t C, const float *feat, const ren_scene_desc *scene,
+int ren_mlp_fwd_bf16(const float *mlp_params_bf16, int32_t C, int32_t activations, const float *feat, const ren_scene_desc *scene,
                      const float *x_world, const float *dirs, const float *rays_o, const float *rays_d,
                      const int32_t *ray_indices, const float *t_starts, const float *t_ends, int64_t n,
                      int32_t density_only, float *rgb, float *sigma, float *base_out, void *stream);
-int ren_mlp_bwd_bf16(const float *mlp_params_bf16, int32_t C, const float *feat, const float *base_out,
+int ren_mlp_bwd_bf16(const float *mlp_params_bf16, int32_t C, int32_t activations, const float *feat, const float *base_out,
                      const ren_scene_desc *scene, const float *x_world, const float *dirs, const float *rays_o,
                      const float *rays_d, const int32_t *ray_indices, const float *t_starts,
                      const float *t_ends, int64_t n, const float *rgb, const float *d_rgb, const float *d_sigma,
@@ -482,12 +481,12 @@ int ren_mlp_bwd_bf16(const float *mlp_params_bf16, int32_t C, const float *feat,
  * the forward (128 f32 MFMAs + 192 softplus per 32 samples).  bf16 != 0 selects the bf16 numerics mode
  * (mlp_params is then the rounded copy).  Otherwise the arguments of ren_mlp_fwd / ren_mlp_bwd. */
 int64_t ren_mlp_act_save_floats(int64_t n);
-int ren_mlp_fwd_save(const float *mlp_params, int32_t C, int32_t bf16, const float *feat,
+int ren_mlp_fwd_save(const float *mlp_params, int32_t C, int32_t activations, int32_t bf16, const float *feat,
                      const ren_scene_desc *scene, const float *x_world, const float *dirs, const float *rays_o,
                      const float *rays_d, const int32_t *ray_indices, const float *t_starts,
                      const float *t_ends, int64_t n, float *rgb, float *sigma, float *base_out, float *act_save,
                      void *stream);
-int ren_mlp_bwd_saved(const float *mlp_params, int32_t C, int32_t bf16, const float *feat, const float *base_out,
+int ren_mlp_bwd_saved(const float *mlp_params, int32_t C, int32_t activations, int32_t bf16, const float *feat, const float *base_out,
                       const float *act_save, const ren_scene_desc *scene, const float *x_world, const float *dirs,
                       const float *rays_o, const float *rays_d, const int32_t *ray_indices, const float *t_starts,
                       const float *t_ends, int64_t n, const float *rgb, const float *d_rgb, const float *d_sigma,
@@ -504,16 +503,18 @@ int ren_mlp_bwd_saved(const float *mlp_params, int32_t C, int32_t bf16, const fl
  * runs the hash encoding of the next sample chunk beside the MLP of the current one). */
 #define REN_MLP_DENSITY_ONLY 1
 #define REN_MLP_SHARE_CU 2
-int ren_mlp_fwd_x(const float *mlp_params, int32_t C, int32_t mode, const float *feat, const ren_scene_desc *scene,
+int ren_mlp_fwd_x(const float *mlp_params, int32_t C, int32_t activations, int32_t mode, const float *feat, const ren_scene_desc *scene,
                   const float *x_world, const float *dirs, const float *rays_o, const float *rays_d,
                   const int32_t *ray_indices, const float *t_starts, const float *t_ends, int64_t n,
                   int32_t flags, float *rgb, float *sigma, float *base_out, float *act_save, void *stream);
 int64_t ren_mlp_bwd_x_workspace_floats(int32_t C);
-int ren_mlp_bwd_x(const float *mlp_params, int32_t C, int32_t mode, const float *feat, const float *base_out,
+int ren_mlp_bwd_x(const float *mlp_params, int32_t C, int32_t activations, int32_t mode, const float *feat, const float *base_out,
                   const float *act_save, const ren_scene_desc *scene, const float *x_world, const float *dirs,
                   const float *rays_o, const float *rays_d, const int32_t *ray_indices, const float *t_starts,
                   const float *t_ends, int64_t n, const float *rgb, const float *d_rgb, const float *d_sigma,
-                  float *d_base, float *dfeat, float *grad_mlp_params, float *workspace, void *stream);
+                  float *d_base, float *dfeat, float *grad_mlp_params, float *workspace, int32_t grid_cus, void *stream);
+/* grid_cus: persistent workgroups (= CUs) the two backward kernels occupy, 1 .. 255; 0 (or >= 256) = all 256.  The chunked
+ * backward of engine.py lowers it while a scatter runs on the second stream (until ABI 23: knob REN_KNOB_MLP_BWD_CUS). */
 
 /* ---- second-order forward tangent (value, d/dt, d2/dt2): d(l_grad)/d(tau) --------------------------- *
  * The gradient-loss prediction d(log I)/dt is evaluated at ts_g(tau); its derivative w.r.t. the refractory
@@ -530,7 +531,7 @@ int ren_hashgrid_fwd_jvp2(const ren_grid_desc *grid, const float *table, const r
                           const float *rays_o, const float *rays_d, const float *rays_do, const float *rays_dd,
                           const float *rays_ddd, const int32_t *ray_indices, const float *t_starts,
                           const float *t_ends, int64_t n, float *feat, float *featd, float *featdd, void *stream);
-int ren_mlp_fwd_jvp2(const float *mlp_params, int32_t C, const float *feat, const float *featd,
+int ren_mlp_fwd_jvp2(const float *mlp_params, int32_t C, int32_t activations, const float *feat, const float *featd,
                      const float *featdd, const ren_scene_desc *scene, const float *rays_o, const float *rays_d,
                      const float *rays_do, const float *rays_dd, const float *rays_ddd,
                      const int32_t *ray_indices, const float *t_starts, const float *t_ends, int64_t n,
@@ -539,7 +540,7 @@ int ren_mlp_fwd_jvp2(const float *mlp_params, int32_t C, const float *feat, cons
 /* ren_mlp_fwd_jvp2 on the bf16 matrix cores (csrc/ren_jvp2.hip: mlp_fwd_jvp2_x_kernel); mode 6: split-bf16 at fp32
  * accuracy, mode 1: plain bf16 operands -- the second-order render of a step follows the precision mode of its other
  * MLP kernels (RenderCfg.mlp_kernels = "x") */
-int ren_mlp_fwd_jvp2_x(const float *mlp_params, int32_t C, int32_t mode, const float *feat, const float *featd,
+int ren_mlp_fwd_jvp2_x(const float *mlp_params, int32_t C, int32_t activations, int32_t mode, const float *feat, const float *featd,
                        const float *featdd, const ren_scene_desc *scene, const float *rays_o, const float *rays_d,
                        const float *rays_do, const float *rays_dd, const float *rays_ddd,
                        const int32_t *ray_indices, const float *t_starts, const float *t_ends, int64_t n,
@@ -608,7 +609,7 @@ int ren_dense_bwd_weight(const float *dZ, int32_t ldz, const float *X, int32_t l
 /* output activations backward: dz_rgb[n_pad][32] = g_rgb * softplus1'(rgb), dz_sigma[n_pad][32] (col 0) =
  * g_sigma * d sigma/d raw; padding zeroed */
 int ren_vanilla_heads_bwd(const float *g_rgb, const float *rgb, const float *g_sigma, const float *sigma,
-                          int64_t n, int32_t C, float *dz_rgb, float *dz_sigma, void *stream);
+                          int64_t n, int32_t C, int32_t activations, float *dz_rgb, float *dz_sigma, void *stream);
 
 /* ---- arch mlp: the whole field as one launch per pass (csrc/ren_vfield.hip) ------------------------------------------------
  * Replaces NerfMLP.forward / query_density (robust_e_nerf/external/mlp.py:126-205: eight hidden Linear + Softplus(beta = 100)
@@ -629,9 +630,9 @@ int64_t ren_vanilla_image_bytes(int32_t mode);
 int64_t ren_vanilla_saved_bytes(int32_t mode, int64_t n);
 int ren_vanilla_prep(const float *params, int32_t C, int32_t mode, void *image, void *stream);
 int ren_vanilla_fwd(const float *enc, int32_t ld_enc, const float *view, int32_t ld_view, const uint8_t *selector,
-                    const float *params, int32_t C, const void *image, int32_t mode, int64_t n, void *saved, float *sigma,
+                    const float *params, int32_t C, int32_t activations, const void *image, int32_t mode, int64_t n, void *saved, float *sigma,
                     float *rgb4, void *stream);
-int ren_vanilla_bwd(const float *dz_rgb, const float *dz_sigma, const void *image, int32_t mode, int64_t n, const void *saved,
+int ren_vanilla_bwd(const float *dz_rgb, const float *dz_sigma, const void *image, int32_t mode, int32_t activations, int64_t n, const void *saved,
                     int64_t saved_slot_bytes, void *dz, void *stream);
 int64_t ren_vanilla_bwd_weight_workspace_floats(int32_t n_splits);
 int ren_vanilla_bwd_weight(const void *dz, const void *saved, int64_t saved_slot_bytes, const float *enc, int32_t ld_enc,
@@ -653,12 +654,12 @@ int ren_act_jvp2_fwd(const float *Y, int32_t ldy, const float *Zd, const float *
  * zod / zodd / zsd / zsdd: [n_pad][4] pre-activation tangents (ren_dense_fwd without bias / activation); the second-order
  * arguments (zodd, zsdd, rgbdd, sigmadd) may all be NULL.  rgb* are (n, C), sigma* (n). */
 int ren_vanilla_heads_jvp(const float *rgb, const float *sigma, const float *zod, const float *zodd, const float *zsd,
-                          const float *zsdd, int64_t n, int32_t C, float *rgbd, float *rgbdd, float *sigmad, float *sigmadd,
+                          const float *zsdd, int64_t n, int32_t C, int32_t activations, float *rgbd, float *rgbdd, float *sigmad, float *sigmadd,
                           void *stream);
 /* reverse pass of (rgb, rgbd, sigma, sigmad) -> pre-activation gradients of the value and the tangent stream, each
  * [n_pad][32] zero-padded (as ren_vanilla_heads_bwd) */
 int ren_vanilla_heads_bwd_jvp(const float *g_rgb, const float *g_rgbd, const float *g_sigma, const float *g_sigmad,
-                              const float *rgb, const float *sigma, const float *zod, const float *zsd, int64_t n, int32_t C,
+                              const float *rgb, const float *sigma, const float *zod, const float *zsd, int64_t n, int32_t C, int32_t activations,
                               float *dz_rgb, float *dzd_rgb, float *dz_sigma, float *dzd_sigma, void *stream);
 
 /* ---- utilities ------------------------------------------------------------------------------------- */

@@ -57,24 +57,24 @@ SIGNATURES = {
     "ren_hashgrid_bwd_binned_scatter": (c_int, [POINTER(GridDesc), P, P, POINTER(SceneDesc), P, P, P, P, P, c_int64, c_int32, P,
                                                 c_int64, c_int64, P, P]),
     "ren_hashgrid_bwd_binned_finish": (c_int, [POINTER(GridDesc), P, c_int64, c_int32, P, P]),
-    "ren_mlp_fwd": (c_int, [P, c_int32, P, POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, c_int32, P, P, P, P]),
+    "ren_mlp_fwd": (c_int, [P, c_int32, c_int32, P, POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, c_int32, P, P, P, P]),
     "ren_mlp_bwd_workspace_floats": (c_int64, [c_int32]),
-    "ren_mlp_bwd": (c_int, [P, c_int32, P, P, POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, P, P, P, P, P, P, P, P]),
-    "ren_mlp_fwd_bf16": (c_int, [P, c_int32, P, POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, c_int32, P, P, P, P]),
-    "ren_mlp_bwd_bf16": (c_int, [P, c_int32, P, P, POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, P, P, P, P, P, P, P, P]),
+    "ren_mlp_bwd": (c_int, [P, c_int32, c_int32, P, P, POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, P, P, P, P, P, P, P, P]),
+    "ren_mlp_fwd_bf16": (c_int, [P, c_int32, c_int32, P, POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, c_int32, P, P, P, P]),
+    "ren_mlp_bwd_bf16": (c_int, [P, c_int32, c_int32, P, P, POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, P, P, P, P, P, P, P, P]),
     "ren_mlp_act_save_floats": (c_int64, [c_int64]),
-    "ren_mlp_fwd_save": (c_int, [P, c_int32, c_int32, P, POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, P, P, P, P, P]),
-    "ren_mlp_bwd_saved": (c_int, [P, c_int32, c_int32, P, P, P, POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, P, P, P,
+    "ren_mlp_fwd_save": (c_int, [P, c_int32, c_int32, c_int32, P, POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, P, P, P, P, P]),
+    "ren_mlp_bwd_saved": (c_int, [P, c_int32, c_int32, c_int32, P, P, P, POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, P, P, P,
                                   P, P, P, P, P]),
     "ren_act_jvp_fwd": (c_int, [P, c_int32, P, c_int32, c_float, P, c_int32, c_int64, c_int32, P]),
     "ren_act_jvp_bwd": (c_int, [P, P, P, c_int32, P, c_float, P, P, c_int64, c_int32, P]),
     "ren_event_prepare": (c_int, [P, P, P, P, P, P, P, c_int64, c_float, c_float, c_double, P, P, P, P, P, P, P, P, P]),
     "ren_event_param_grad": (c_int, [c_int32, c_int32, c_int32, P, P, P, P, P, P, P, c_int64, c_float, c_float, c_float,
                                      c_double, c_float, P, P, P]),
-    "ren_mlp_fwd_x": (c_int, [P, c_int32, c_int32, P, POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, c_int32, P, P, P, P, P]),
+    "ren_mlp_fwd_x": (c_int, [P, c_int32, c_int32, c_int32, P, POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, c_int32, P, P, P, P, P]),
     "ren_mlp_bwd_x_workspace_floats": (c_int64, [c_int32]),
-    "ren_mlp_bwd_x": (c_int, [P, c_int32, c_int32, P, P, P, POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, P, P, P, P, P,
-                              P, P, P]),
+    "ren_mlp_bwd_x": (c_int, [P, c_int32, c_int32, c_int32, P, P, P, POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, P, P, P, P, P,
+                              P, P, c_int32, P]),
     "ren_composite_fwd": (c_int, [P, P, c_int64, P, P, P, P, c_int32, P, P, P, P, P, P, P]),
     "ren_composite_bwd": (c_int, [P, P, c_int64, P, P, P, P, c_int32, P, P, P, P, P, P, P, P, P, P, P, P]),
     "ren_event_loss_fwd": (c_int, [P, P, P, P, c_int64, c_int32, P, P]),
@@ -97,21 +97,21 @@ SIGNATURES = {
     "ren_hashgrid_bwd_binned_jvp": (c_int, [POINTER(GridDesc), P, POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, P, P, P, P]),
     "ren_hashgrid_bwd_binned_levels": (c_int, [POINTER(GridDesc), P, P, POINTER(SceneDesc), P, P, P, P, P, c_int64, c_int32, P,
                                                P, P, P, c_uint32, P, P]),
-    "ren_mlp_fwd_jvp": (c_int, [P, c_int32, P, P, POINTER(SceneDesc), P, P, P, P, P, P, c_int64, P, P, P, P, P, P, P]),
+    "ren_mlp_fwd_jvp": (c_int, [P, c_int32, c_int32, P, P, POINTER(SceneDesc), P, P, P, P, P, P, c_int64, P, P, P, P, P, P, P]),
     "ren_mlp_bwd_jvp_workspace_floats": (c_int64, [c_int32]),
-    "ren_mlp_bwd_jvp": (c_int, [P, c_int32, P, P, P, P, POINTER(SceneDesc), P, P, P, P, P, P, c_int64, P, P, P, P, P,
+    "ren_mlp_bwd_jvp": (c_int, [P, c_int32, c_int32, P, P, P, P, POINTER(SceneDesc), P, P, P, P, P, P, c_int64, P, P, P, P, P,
                                 P, P, P, P, P, P]),
-    "ren_mlp_fwd_jvp_x": (c_int, [P, c_int32, c_int32, P, P, POINTER(SceneDesc), P, P, P, P, P, P, c_int64, P, P, P, P, P, P, P]),
+    "ren_mlp_fwd_jvp_x": (c_int, [P, c_int32, c_int32, c_int32, P, P, POINTER(SceneDesc), P, P, P, P, P, P, c_int64, P, P, P, P, P, P, P]),
     "ren_mlp_bwd_jvp_x_workspace_floats": (c_int64, [c_int32]),
-    "ren_mlp_bwd_jvp_x": (c_int, [P, c_int32, c_int32, P, P, P, P, POINTER(SceneDesc), P, P, P, P, P, P, c_int64, P, P, P, P, P,
+    "ren_mlp_bwd_jvp_x": (c_int, [P, c_int32, c_int32, c_int32, P, P, P, P, POINTER(SceneDesc), P, P, P, P, P, P, c_int64, P, P, P, P, P,
                                   P, P, P, P, P, P]),
     "ren_composite_fwd_jvp": (c_int, [P, P, c_int64, P, P, P, P, P, P, c_int32, P, P, P, P, P, P, P, P, P]),
     "ren_composite_bwd_jvp": (c_int, [P, P, c_int64, P, P, P, P, P, P, c_int32, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "ren_trajectory_jvp2": (c_int, [P, c_int64, P, P, P, c_int64, P, P, P, P, P, P]),
     "ren_raygen_jvp2": (c_int, [P, P, P, P, P, P, P, c_int64, P, P, P, P, P, P]),
     "ren_hashgrid_fwd_jvp2": (c_int, [POINTER(GridDesc), P, POINTER(SceneDesc), P, P, P, P, P, P, P, P, c_int64, P, P, P, P]),
-    "ren_mlp_fwd_jvp2": (c_int, [P, c_int32, P, P, P, POINTER(SceneDesc), P, P, P, P, P, P, P, P, c_int64, P, P, P, P, P, P, P]),
-    "ren_mlp_fwd_jvp2_x": (c_int, [P, c_int32, c_int32, P, P, P, POINTER(SceneDesc), P, P, P, P, P, P, P, P, c_int64, P, P, P, P, P, P,
+    "ren_mlp_fwd_jvp2": (c_int, [P, c_int32, c_int32, P, P, P, POINTER(SceneDesc), P, P, P, P, P, P, P, P, c_int64, P, P, P, P, P, P, P]),
+    "ren_mlp_fwd_jvp2_x": (c_int, [P, c_int32, c_int32, c_int32, P, P, P, POINTER(SceneDesc), P, P, P, P, P, P, P, P, c_int64, P, P, P, P, P, P,
                                    P]),
     "ren_composite_fwd_jvp2": (c_int, [P, P, c_int64, P, P, P, P, P, P, P, P, c_int32, P, P, P, P, P]),
     "ren_freq_encode": (c_int, [POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, P, c_int32, P, c_int32, c_int32, P,
@@ -121,19 +121,19 @@ SIGNATURES = {
                                    c_int64, P]),
     "ren_dense_bwd_weight_workspace_floats": (c_int64, [c_int32, c_int32, c_int32]),
     "ren_dense_bwd_weight": (c_int, [P, c_int32, P, c_int32, c_int32, c_int32, c_int64, c_int32, P, P, P, P]),
-    "ren_vanilla_heads_bwd": (c_int, [P, P, P, P, c_int64, c_int32, P, P, P]),
+    "ren_vanilla_heads_bwd": (c_int, [P, P, P, P, c_int64, c_int32, c_int32, P, P, P]),
     "ren_vanilla_image_bytes": (c_int64, [c_int32]),
     "ren_vanilla_saved_bytes": (c_int64, [c_int32, c_int64]),
     "ren_vanilla_prep": (c_int, [P, c_int32, c_int32, P, P]),
-    "ren_vanilla_fwd": (c_int, [P, c_int32, P, c_int32, P, P, c_int32, P, c_int32, c_int64, P, P, P, P]),
-    "ren_vanilla_bwd": (c_int, [P, P, P, c_int32, c_int64, P, c_int64, P, P]),
+    "ren_vanilla_fwd": (c_int, [P, c_int32, P, c_int32, P, P, c_int32, c_int32, P, c_int32, c_int64, P, P, P, P]),
+    "ren_vanilla_bwd": (c_int, [P, P, P, c_int32, c_int32, c_int64, P, c_int64, P, P]),
     "ren_vanilla_bwd_weight_workspace_floats": (c_int64, [c_int32]),
     "ren_vanilla_bwd_weight": (c_int, [P, P, c_int64, P, c_int32, P, c_int32, P, P, c_int32, c_int32, c_int64, c_int32, P, P, P]),
     "ren_freq_encode_jvp": (c_int, [POINTER(SceneDesc), P, P, P, P, P, P, P, P, c_int64, c_int32, P, c_int32, P, c_int32, c_int32,
                                     P, c_int32, c_int32, P]),
     "ren_act_jvp2_fwd": (c_int, [P, c_int32, P, P, c_int32, c_float, P, c_int32, P, c_int32, c_int64, c_int32, P]),
-    "ren_vanilla_heads_jvp": (c_int, [P, P, P, P, P, P, c_int64, c_int32, P, P, P, P, P]),
-    "ren_vanilla_heads_bwd_jvp": (c_int, [P, P, P, P, P, P, P, P, c_int64, c_int32, P, P, P, P, P]),
+    "ren_vanilla_heads_jvp": (c_int, [P, P, P, P, P, P, c_int64, c_int32, c_int32, P, P, P, P, P]),
+    "ren_vanilla_heads_bwd_jvp": (c_int, [P, P, P, P, P, P, P, P, c_int64, c_int32, c_int32, P, P, P, P, P]),
     "ren_rate_epilogue": (c_int, [P, P, P, P, c_int32, c_int64, c_float, P, P, P, P, P]),
     "ren_tau_pose_grad": (c_int, [P, P, P, P, P, c_int64, P, P]),
     "ren_weight_norm_fwd": (c_int, [P, P, P, c_int32, c_int64, P, P]),

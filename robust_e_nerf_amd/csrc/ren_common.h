@@ -36,9 +36,8 @@ inline std::atomic<int> *ren_knob_store() {
     static std::atomic<int> knobs[REN_KNOB_COUNT];
     static const bool init = [] {
         const char *names[REN_KNOB_COUNT] = {"REN_HGB_NO_PAIRS", "REN_HGB_HALVE_REGIONS", "REN_MARCH_SEQUENTIAL", "REN_HG_VARIANT",
-                                           "REN_VFIELD_PLAIN", "REN_HGB_SUBREGION", "REN_MLP_BWD_CUS",
-                                           "REN_ACTIVATIONS"};
-        const int defaults[REN_KNOB_COUNT] = {0, 0, 0, 2, 0, 1, 256, 0};
+                                           "REN_VFIELD_PLAIN", "REN_HGB_SUBREGION"};
+        const int defaults[REN_KNOB_COUNT] = {0, 0, 0, 2, 0, 1};
         for (int k = 0; k < REN_KNOB_COUNT; ++k) {
             const char *e = getenv(names[k]);
             knobs[k].store(e ? atoi(e) : defaults[k], std::memory_order_relaxed);

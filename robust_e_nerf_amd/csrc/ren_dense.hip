@@ -1046,13 +1046,10 @@ int launch_dense(DenseArgs a, int tiles, int mode, hipStream_t st) {
     REN_CHECK_LAUNCH();
 }
 
-// density / radiance kinds of the process-wide activation code (REN_KNOB_ACTIVATIONS): what the output-head kernels of
+// density / radiance kinds of the call's activation code (include/ren_amd.h "activations"): what the output-head kernels of
 // arch mlp differentiate.  0 / 0 = the shipped configs.
 struct ActKindsHost { int dn, rd; };
-inline ActKindsHost act_kinds_host() {
-    const int code = ren_knob(REN_KNOB_ACTIVATIONS);
-    return ActKindsHost{(code >> 2) & 3, (code >> 6) & 3};
-}
+inline ActKindsHost act_kinds_host(int code) { return ActKindsHost{(code >> 2) & 3, (code >> 6) & 3}; }
 
 inline int tiles_for(int n_out) { return n_out <= 32 ? 1 : n_out <= 64 ? 2 : n_out <= 128 ? 4 : n_out <= 256 ? 8 : -1; }
 
@@ -1175,12 +1172,12 @@ extern "C" int ren_dense_bwd_weight(const float *dZ, int32_t ldz, const float *X
 }
 
 extern "C" int ren_vanilla_heads_bwd(const float *g_rgb, const float *rgb, const float *g_sigma, const float *sigma,
-                                     int64_t n, int32_t C, float *dz_rgb, float *dz_sigma, void *stream) {
+                                     int64_t n, int32_t C, int32_t activations, float *dz_rgb, float *dz_sigma, void *stream) {
     if (!g_rgb || !rgb || !g_sigma || !sigma || !dz_rgb || !dz_sigma || n < 0) return REN_ERR_BAD_ARG;
     if (C != 1 && C != 3) return REN_ERR_UNSUPPORTED;
     if (n == 0) return REN_OK;
     const int64_t n_pad = (n + 31) / 32 * 32;
-    const ActKindsHost ak = act_kinds_host();
+    const ActKindsHost ak = act_kinds_host(activations);
     hipLaunchKernelGGL(heads_bwd_kernel, dim3(ren_blocks(n_pad, 256)), dim3(256), 0, (hipStream_t)stream, g_rgb, rgb,
                        g_sigma, sigma, n, n_pad, C, ak.dn, ak.rd, dz_rgb, dz_sigma);
     REN_CHECK_LAUNCH();
@@ -1198,13 +1195,13 @@ extern "C" int ren_act_jvp2_fwd(const float *Y, int32_t ldy, const float *Zd, co
 }
 
 extern "C" int ren_vanilla_heads_jvp(const float *rgb, const float *sigma, const float *zod, const float *zodd,
-                                     const float *zsd, const float *zsdd, int64_t n, int32_t C, float *rgbd, float *rgbdd,
+                                     const float *zsd, const float *zsdd, int64_t n, int32_t C, int32_t activations, float *rgbd, float *rgbdd,
                                      float *sigmad, float *sigmadd, void *stream) {
     if (!rgb || !sigma || !zod || !zsd || !rgbd || !sigmad || n < 0) return REN_ERR_BAD_ARG;
     if ((rgbdd || sigmadd) && (!rgbdd || !sigmadd || !zodd || !zsdd)) return REN_ERR_BAD_ARG;
     if (C != 1 && C != 3) return REN_ERR_UNSUPPORTED;
     if (n == 0) return REN_OK;
-    const ActKindsHost ak = act_kinds_host();
+    const ActKindsHost ak = act_kinds_host(activations);
     hipLaunchKernelGGL(heads_jvp_kernel, dim3(ren_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, rgb, sigma, zod, zodd,
                        zsd, zsdd, n, C, ak.dn, ak.rd, rgbd, rgbdd, sigmad, sigmadd);
     REN_CHECK_LAUNCH();
@@ -1212,7 +1209,7 @@ extern "C" int ren_vanilla_heads_jvp(const float *rgb, const float *sigma, const
 
 extern "C" int ren_vanilla_heads_bwd_jvp(const float *g_rgb, const float *g_rgbd, const float *g_sigma, const float *g_sigmad,
                                          const float *rgb, const float *sigma, const float *zod, const float *zsd, int64_t n,
-                                         int32_t C, float *dz_rgb, float *dzd_rgb, float *dz_sigma, float *dzd_sigma,
+                                         int32_t C, int32_t activations, float *dz_rgb, float *dzd_rgb, float *dz_sigma, float *dzd_sigma,
                                          void *stream) {
     if (!g_rgb || !g_rgbd || !g_sigma || !g_sigmad || !rgb || !sigma || !zod || !zsd || !dz_rgb || !dzd_rgb || !dz_sigma ||
         !dzd_sigma || n < 0)
@@ -1220,7 +1217,7 @@ extern "C" int ren_vanilla_heads_bwd_jvp(const float *g_rgb, const float *g_rgbd
     if (C != 1 && C != 3) return REN_ERR_UNSUPPORTED;
     if (n == 0) return REN_OK;
     const int64_t n_pad = (n + 31) / 32 * 32;
-    const ActKindsHost ak = act_kinds_host();
+    const ActKindsHost ak = act_kinds_host(activations);
     hipLaunchKernelGGL(heads_bwd_jvp_kernel, dim3(ren_blocks(n_pad, 256)), dim3(256), 0, (hipStream_t)stream, g_rgb, g_rgbd,
                        g_sigma, g_sigmad, rgb, sigma, zod, zsd, n, n_pad, C, ak.dn, ak.rd, dz_rgb, dzd_rgb, dz_sigma, dzd_sigma);
     REN_CHECK_LAUNCH();

@@ -792,7 +792,7 @@ extern "C" int ren_hashgrid_fwd_jvp2(const ren_grid_desc *grid, const float *tab
     REN_CHECK_LAUNCH();
 }
 
-extern "C" int ren_mlp_fwd_jvp2(const float *mlp_params, int32_t C, const float *feat, const float *featd,
+extern "C" int ren_mlp_fwd_jvp2(const float *mlp_params, int32_t C, int32_t activations, const float *feat, const float *featd,
                                 const float *featdd, const ren_scene_desc *scene, const float *rays_o,
                                 const float *rays_d, const float *rays_do, const float *rays_dd,
                                 const float *rays_ddd, const int32_t *ray_indices, const float *t_starts,
@@ -809,7 +809,7 @@ extern "C" int ren_mlp_fwd_jvp2(const float *mlp_params, int32_t C, const float 
     a.ray = Ray2{rays_o, rays_d, rays_do, rays_dd, rays_ddd, ray_indices, t_starts, t_ends};
     a.sc = ren_make_scene(scene);
     a.n = n; a.rgb = rgb; a.rgbd = rgbd; a.rgbdd = rgbdd; a.sigma = sigma; a.sigmad = sigmad; a.sigmadd = sigmadd;
-    a.act_code = ren_knob(REN_KNOB_ACTIVATIONS);
+    a.act_code = activations;
     const int64_t n_blk = (n + 31) / 32;
     int64_t blocks = (n_blk + 3) / 4;
     if (blocks > 256) blocks = 256;
@@ -819,7 +819,7 @@ extern "C" int ren_mlp_fwd_jvp2(const float *mlp_params, int32_t C, const float 
     REN_CHECK_LAUNCH();
 }
 
-extern "C" int ren_mlp_fwd_jvp2_x(const float *mlp_params, int32_t C, int32_t mode, const float *feat, const float *featd,
+extern "C" int ren_mlp_fwd_jvp2_x(const float *mlp_params, int32_t C, int32_t activations, int32_t mode, const float *feat, const float *featd,
                                   const float *featdd, const ren_scene_desc *scene, const float *rays_o, const float *rays_d,
                                   const float *rays_do, const float *rays_dd, const float *rays_ddd,
                                   const int32_t *ray_indices, const float *t_starts, const float *t_ends, int64_t n,
@@ -831,7 +831,7 @@ extern "C" int ren_mlp_fwd_jvp2_x(const float *mlp_params, int32_t C, int32_t mo
         return REN_ERR_BAD_ARG;
     if (C != 1 && C != 3) return REN_ERR_UNSUPPORTED;
     if (mode != 1 && mode != 6) return REN_ERR_UNSUPPORTED;
-    if (ren_knob(REN_KNOB_ACTIVATIONS) != 0) return REN_ERR_UNSUPPORTED;      // activation alternatives: exact-f32 kernels only
+    if (activations != 0) return REN_ERR_UNSUPPORTED;      // activation alternatives: exact-f32 kernels only
     if (n == 0) return REN_OK;
     Fwd2Args a;
     a.act_code = 0;

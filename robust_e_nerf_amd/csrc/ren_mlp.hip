@@ -610,12 +610,12 @@ extern "C" int64_t ren_mlp_bwd_workspace_floats(int32_t C) {
     return (int64_t)GRID_H * 4 * (p_total(C) - P_BASE_N) + (int64_t)GRID_B * 4 * P_BASE_N;
 }
 
-static int mlp_fwd_impl(bool rb, const float *mlp_params, int32_t C, const float *feat,
+static int mlp_fwd_impl(bool rb, const float *mlp_params, int32_t C, int32_t activations, const float *feat,
                         const ren_scene_desc *scene, const float *x_world, const float *dirs,
                         const float *rays_o, const float *rays_d, const int32_t *ray_indices,
                         const float *t_starts, const float *t_ends, int64_t n, int32_t density_only,
                         float *rgb, float *sigma, float *base_out, float *acts, void *stream) {
-    if (!mlp_params || !feat || !scene || !sigma || n < 0) return REN_ERR_BAD_ARG;
+    if (!mlp_params || !feat || !scene || !sigma || n < 0 || activations < 0 || activations > 255) return REN_ERR_BAD_ARG;
     if (acts && (density_only || !base_out)) return REN_ERR_BAD_ARG;
     if (C != 1 && C != 3) return REN_ERR_UNSUPPORTED;          // robust_e_nerf.py:230-233
     if (!density_only && !rgb) return REN_ERR_BAD_ARG;
@@ -626,7 +626,7 @@ static int mlp_fwd_impl(bool rb, const float *mlp_params, int32_t C, const float
     a.src = SampleSrc{x_world, dirs, rays_o, rays_d, x_world ? nullptr : ray_indices, t_starts, t_ends};
     a.sc = ren_make_scene(scene);
     a.n = n; a.rgb = rgb; a.sigma = sigma; a.base_out = base_out; a.acts = acts;
-    a.act_code = ren_knob(REN_KNOB_ACTIVATIONS);
+    a.act_code = activations;
     const int64_t n_blk = (n + 31) / 32;
     int64_t blocks = (n_blk + 3) / 4;
     if (blocks > 768) blocks = 768;                            // 3 workgroups / CU (43.5 KB LDS each)
@@ -644,44 +644,44 @@ static int mlp_fwd_impl(bool rb, const float *mlp_params, int32_t C, const float
     REN_CHECK_LAUNCH();
 }
 
-extern "C" int ren_mlp_fwd(const float *mlp_params, int32_t C, const float *feat,
+extern "C" int ren_mlp_fwd(const float *mlp_params, int32_t C, int32_t activations, const float *feat,
                            const ren_scene_desc *scene, const float *x_world, const float *dirs,
                            const float *rays_o, const float *rays_d, const int32_t *ray_indices,
                            const float *t_starts, const float *t_ends, int64_t n, int32_t density_only,
                            float *rgb, float *sigma, float *base_out, void *stream) {
-    return mlp_fwd_impl(false, mlp_params, C, feat, scene, x_world, dirs, rays_o, rays_d, ray_indices, t_starts, t_ends,
+    return mlp_fwd_impl(false, mlp_params, C, activations, feat, scene, x_world, dirs, rays_o, rays_d, ray_indices, t_starts, t_ends,
                         n, density_only, rgb, sigma, base_out, nullptr, stream);
 }
 
 extern "C" int64_t ren_mlp_act_save_floats(int64_t n) { return n < 0 ? -1 : (n + 31) / 32 * ACT_SAVE_FLOATS; }
 
-extern "C" int ren_mlp_fwd_save(const float *mlp_params, int32_t C, int32_t bf16, const float *feat,
+extern "C" int ren_mlp_fwd_save(const float *mlp_params, int32_t C, int32_t activations, int32_t bf16, const float *feat,
                                 const ren_scene_desc *scene, const float *x_world, const float *dirs,
                                 const float *rays_o, const float *rays_d, const int32_t *ray_indices,
                                 const float *t_starts, const float *t_ends, int64_t n, float *rgb, float *sigma,
                                 float *base_out, float *act_save, void *stream) {
     if (!act_save) return REN_ERR_BAD_ARG;
-    return mlp_fwd_impl(bf16 != 0, mlp_params, C, feat, scene, x_world, dirs, rays_o, rays_d, ray_indices, t_starts,
+    return mlp_fwd_impl(bf16 != 0, mlp_params, C, activations, feat, scene, x_world, dirs, rays_o, rays_d, ray_indices, t_starts,
                         t_ends, n, 0, rgb, sigma, base_out, act_save, stream);
 }
 
-extern "C" int ren_mlp_fwd_bf16(const float *mlp_params_bf16, int32_t C, const float *feat,
+extern "C" int ren_mlp_fwd_bf16(const float *mlp_params_bf16, int32_t C, int32_t activations, const float *feat,
                                 const ren_scene_desc *scene, const float *x_world, const float *dirs,
                                 const float *rays_o, const float *rays_d, const int32_t *ray_indices,
                                 const float *t_starts, const float *t_ends, int64_t n, int32_t density_only,
                                 float *rgb, float *sigma, float *base_out, void *stream) {
-    return mlp_fwd_impl(true, mlp_params_bf16, C, feat, scene, x_world, dirs, rays_o, rays_d, ray_indices, t_starts,
+    return mlp_fwd_impl(true, mlp_params_bf16, C, activations, feat, scene, x_world, dirs, rays_o, rays_d, ray_indices, t_starts,
                         t_ends, n, density_only, rgb, sigma, base_out, nullptr, stream);
 }
 
-static int mlp_bwd_impl(bool rb, const float *mlp_params, int32_t C, const float *feat, const float *base_out,
+static int mlp_bwd_impl(bool rb, const float *mlp_params, int32_t C, int32_t activations, const float *feat, const float *base_out,
                         const ren_scene_desc *scene, const float *x_world, const float *dirs,
                         const float *rays_o, const float *rays_d, const int32_t *ray_indices,
                         const float *t_starts, const float *t_ends, int64_t n, const float *rgb,
                         const float *d_rgb, const float *d_sigma, float *d_base, float *dfeat,
                         float *grad_mlp_params, float *workspace, const float *acts, void *stream) {
     if (!mlp_params || !feat || !base_out || !scene || !rgb || !d_rgb || !d_sigma || !d_base || !dfeat ||
-        !grad_mlp_params || !workspace || n < 0)
+        !grad_mlp_params || !workspace || n < 0 || activations < 0 || activations > 255)
         return REN_ERR_BAD_ARG;
     if (C != 1 && C != 3) return REN_ERR_UNSUPPORTED;
     if (!x_world && (!rays_o || !rays_d || !ray_indices || !t_starts || !t_ends)) return REN_ERR_BAD_ARG;
@@ -705,7 +705,7 @@ static int mlp_bwd_impl(bool rb, const float *mlp_params, int32_t C, const float
     h.src = SampleSrc{x_world, dirs, rays_o, rays_d, x_world ? nullptr : ray_indices, t_starts, t_ends};
     h.sc = ren_make_scene(scene);
     h.n = n; h.rgb = rgb; h.d_rgb = d_rgb; h.d_sigma = d_sigma; h.d_base = d_base; h.slab = slab_h; h.acts = acts;
-    h.act_code = ren_knob(REN_KNOB_ACTIVATIONS);
+    h.act_code = activations;
     const bool sv = acts != nullptr;
 #define REN_HEAD(CC, R, S) hipLaunchKernelGGL((mlp_bwd_head_kernel<CC, R, S>), dim3(GRID_H), dim3(256), BWD_H_LDS, st, h)
     if (C == 1) {
@@ -718,7 +718,7 @@ static int mlp_bwd_impl(bool rb, const float *mlp_params, int32_t C, const float
 #undef REN_HEAD
     BwdBArgs b;
     b.params = mlp_params; b.feat = feat; b.d_base = d_base; b.n = n; b.dfeat = dfeat; b.slab = slab_b; b.acts = acts;
-    b.act_code = ren_knob(REN_KNOB_ACTIVATIONS);
+    b.act_code = activations;
 #define REN_BASE(R, S) hipLaunchKernelGGL((mlp_bwd_base_kernel<R, S>), dim3(GRID_B), dim3(256), BWD_B_LDS, st, b)
     if (rb) { if (sv) REN_BASE(true, true); else REN_BASE(true, false); }
     else    { if (sv) REN_BASE(false, true); else REN_BASE(false, false); }
@@ -728,34 +728,34 @@ static int mlp_bwd_impl(bool rb, const float *mlp_params, int32_t C, const float
     REN_CHECK_LAUNCH();
 }
 
-extern "C" int ren_mlp_bwd(const float *mlp_params, int32_t C, const float *feat, const float *base_out,
+extern "C" int ren_mlp_bwd(const float *mlp_params, int32_t C, int32_t activations, const float *feat, const float *base_out,
                            const ren_scene_desc *scene, const float *x_world, const float *dirs,
                            const float *rays_o, const float *rays_d, const int32_t *ray_indices,
                            const float *t_starts, const float *t_ends, int64_t n, const float *rgb,
                            const float *d_rgb, const float *d_sigma, float *d_base, float *dfeat,
                            float *grad_mlp_params, float *workspace, void *stream) {
-    return mlp_bwd_impl(false, mlp_params, C, feat, base_out, scene, x_world, dirs, rays_o, rays_d, ray_indices, t_starts,
+    return mlp_bwd_impl(false, mlp_params, C, activations, feat, base_out, scene, x_world, dirs, rays_o, rays_d, ray_indices, t_starts,
                         t_ends, n, rgb, d_rgb, d_sigma, d_base, dfeat, grad_mlp_params, workspace, nullptr, stream);
 }
 
-extern "C" int ren_mlp_bwd_bf16(const float *mlp_params_bf16, int32_t C, const float *feat, const float *base_out,
+extern "C" int ren_mlp_bwd_bf16(const float *mlp_params_bf16, int32_t C, int32_t activations, const float *feat, const float *base_out,
                                 const ren_scene_desc *scene, const float *x_world, const float *dirs,
                                 const float *rays_o, const float *rays_d, const int32_t *ray_indices,
                                 const float *t_starts, const float *t_ends, int64_t n, const float *rgb,
                                 const float *d_rgb, const float *d_sigma, float *d_base, float *dfeat,
                                 float *grad_mlp_params, float *workspace, void *stream) {
-    return mlp_bwd_impl(true, mlp_params_bf16, C, feat, base_out, scene, x_world, dirs, rays_o, rays_d, ray_indices,
+    return mlp_bwd_impl(true, mlp_params_bf16, C, activations, feat, base_out, scene, x_world, dirs, rays_o, rays_d, ray_indices,
                         t_starts, t_ends, n, rgb, d_rgb, d_sigma, d_base, dfeat, grad_mlp_params, workspace, nullptr, stream);
 }
 
-extern "C" int ren_mlp_bwd_saved(const float *mlp_params, int32_t C, int32_t bf16, const float *feat,
+extern "C" int ren_mlp_bwd_saved(const float *mlp_params, int32_t C, int32_t activations, int32_t bf16, const float *feat,
                                  const float *base_out, const float *act_save, const ren_scene_desc *scene,
                                  const float *x_world, const float *dirs, const float *rays_o, const float *rays_d,
                                  const int32_t *ray_indices, const float *t_starts, const float *t_ends, int64_t n,
                                  const float *rgb, const float *d_rgb, const float *d_sigma, float *d_base,
                                  float *dfeat, float *grad_mlp_params, float *workspace, void *stream) {
     if (!act_save) return REN_ERR_BAD_ARG;
-    return mlp_bwd_impl(bf16 != 0, mlp_params, C, feat, base_out, scene, x_world, dirs, rays_o, rays_d, ray_indices,
+    return mlp_bwd_impl(bf16 != 0, mlp_params, C, activations, feat, base_out, scene, x_world, dirs, rays_o, rays_d, ray_indices,
                         t_starts, t_ends, n, rgb, d_rgb, d_sigma, d_base, dfeat, grad_mlp_params, workspace, act_save,
                         stream);
 }

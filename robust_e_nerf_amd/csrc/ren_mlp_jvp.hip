@@ -640,7 +640,7 @@ constexpr size_t JB_LDS = (size_t)(LB_END + 4 * 96 * 33) * 4;
 
 }  // namespace
 
-extern "C" int ren_mlp_fwd_jvp(const float *mlp_params, int32_t C, const float *feat, const float *featd,
+extern "C" int ren_mlp_fwd_jvp(const float *mlp_params, int32_t C, int32_t activations, const float *feat, const float *featd,
                                const ren_scene_desc *scene, const float *rays_o, const float *rays_d,
                                const float *rays_dd, const int32_t *ray_indices, const float *t_starts,
                                const float *t_ends, int64_t n, float *rgb, float *rgbd, float *sigma,
@@ -655,7 +655,7 @@ extern "C" int ren_mlp_fwd_jvp(const float *mlp_params, int32_t C, const float *
     a.src = RaySrc{rays_o, rays_d, rays_dd, ray_indices, t_starts, t_ends};
     a.sc = ren_make_scene(scene);
     a.n = n; a.rgb = rgb; a.rgbd = rgbd; a.sigma = sigma; a.sigmad = sigmad; a.base_out = base_out; a.base_outd = base_outd;
-    a.act_code = ren_knob(REN_KNOB_ACTIVATIONS);
+    a.act_code = activations;
     int64_t blocks = ((n + 31) / 32 + 3) / 4;
     if (blocks > 768) blocks = 768;
     hipStream_t st = (hipStream_t)stream;
@@ -669,7 +669,7 @@ extern "C" int64_t ren_mlp_bwd_jvp_workspace_floats(int32_t C) {
     return (int64_t)GRID_J * 4 * (len_h2(C) + P_BASE_N) + (int64_t)GRID_J1 * 4 * LEN_H1;
 }
 
-extern "C" int ren_mlp_bwd_jvp(const float *mlp_params, int32_t C, const float *feat, const float *featd,
+extern "C" int ren_mlp_bwd_jvp(const float *mlp_params, int32_t C, int32_t activations, const float *feat, const float *featd,
                                const float *base_out, const float *base_outd, const ren_scene_desc *scene,
                                const float *rays_o, const float *rays_d, const float *rays_dd,
                                const int32_t *ray_indices, const float *t_starts, const float *t_ends, int64_t n,
@@ -696,19 +696,19 @@ extern "C" int ren_mlp_bwd_jvp(const float *mlp_params, int32_t C, const float *
     BwdJ2Args a2;
     a2.params = mlp_params; a2.base_out = base_out; a2.base_outd = base_outd; a2.src = src; a2.sc = sc; a2.n = n;
     a2.rgb = rgb; a2.d_rgb = d_rgb; a2.d_rgbd = d_rgbd; a2.dz1 = dz1; a2.dz1d = dz1d; a2.slab = slab2;
-    a2.act_code = ren_knob(REN_KNOB_ACTIVATIONS);
+    a2.act_code = activations;
     if (C == 1) hipLaunchKernelGGL((mlp_bwd_jvp_head2_kernel<1>), dim3(GRID_J), dim3(256), J2_LDS, st, a2);
     else        hipLaunchKernelGGL((mlp_bwd_jvp_head2_kernel<3>), dim3(GRID_J), dim3(256), J2_LDS, st, a2);
     BwdJ1Args a1;
     a1.params = mlp_params; a1.base_out = base_out; a1.base_outd = base_outd; a1.dz1 = dz1; a1.dz1d = dz1d;
     a1.src = src; a1.sc = sc; a1.n = n; a1.d_sigma = d_sigma; a1.d_sigmad = d_sigmad; a1.d_base = d_base;
     a1.d_based = d_based; a1.slab = slab1;
-    a1.act_code = ren_knob(REN_KNOB_ACTIVATIONS);
+    a1.act_code = activations;
     hipLaunchKernelGGL(mlp_bwd_jvp_head1_kernel, dim3(GRID_J1), dim3(256), J1_LDS, st, a1);
     BwdJBArgs ab;
     ab.params = mlp_params; ab.feat = feat; ab.featd = featd; ab.d_base = d_base; ab.d_based = d_based; ab.n = n;
     ab.dfeat = dfeat; ab.dfeatd = dfeatd; ab.slab = slabb;
-    ab.act_code = ren_knob(REN_KNOB_ACTIVATIONS);
+    ab.act_code = activations;
     hipLaunchKernelGGL(mlp_bwd_jvp_base_kernel, dim3(GRID_J), dim3(256), JB_LDS, st, ab);
     launch_reduce_slabs(slab2, GRID_J * 4, len_h2(C), grad_mlp_params + P_HW1, st);
     launch_reduce_slabs(slab1, GRID_J1 * 4, LEN_H1, grad_mlp_params + P_HW0, st);

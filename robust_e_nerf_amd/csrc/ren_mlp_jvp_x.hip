@@ -806,7 +806,7 @@ int launch_bwd_jvp_x(const BwdJX2Args &a2, const BwdJX1Args &a1, const BwdJXBArg
 }  // namespace
 
 // mode: 6 = split-bf16 at fp32 accuracy, 1 = plain bf16 operands (BASELINE configs[2]); otherwise as ren_mlp_fwd_jvp
-extern "C" int ren_mlp_fwd_jvp_x(const float *mlp_params, int32_t C, int32_t mode, const float *feat, const float *featd,
+extern "C" int ren_mlp_fwd_jvp_x(const float *mlp_params, int32_t C, int32_t activations, int32_t mode, const float *feat, const float *featd,
                                  const ren_scene_desc *scene, const float *rays_o, const float *rays_d,
                                  const float *rays_dd, const int32_t *ray_indices, const float *t_starts,
                                  const float *t_ends, int64_t n, float *rgb, float *rgbd, float *sigma,
@@ -816,7 +816,7 @@ extern "C" int ren_mlp_fwd_jvp_x(const float *mlp_params, int32_t C, int32_t mod
         return REN_ERR_BAD_ARG;
     if (C != 1 && C != 3) return REN_ERR_UNSUPPORTED;
     if (mode != 1 && mode != 6) return REN_ERR_UNSUPPORTED;
-    if (ren_knob(REN_KNOB_ACTIVATIONS) != 0) return REN_ERR_UNSUPPORTED;      // activation alternatives: exact-f32 kernels only
+    if (activations != 0) return REN_ERR_UNSUPPORTED;      // activation alternatives: exact-f32 kernels only
     if (n == 0) return REN_OK;
     FwdJXArgs a;
     a.params = mlp_params; a.feat = feat; a.featd = featd;
@@ -832,7 +832,7 @@ extern "C" int64_t ren_mlp_bwd_jvp_x_workspace_floats(int32_t C) {
 }
 
 // scratch: 5 120 floats per 32-sample block, as for ren_mlp_bwd_jvp
-extern "C" int ren_mlp_bwd_jvp_x(const float *mlp_params, int32_t C, int32_t mode, const float *feat, const float *featd,
+extern "C" int ren_mlp_bwd_jvp_x(const float *mlp_params, int32_t C, int32_t activations, int32_t mode, const float *feat, const float *featd,
                                  const float *base_out, const float *base_outd, const ren_scene_desc *scene,
                                  const float *rays_o, const float *rays_d, const float *rays_dd,
                                  const int32_t *ray_indices, const float *t_starts, const float *t_ends, int64_t n,
@@ -845,7 +845,7 @@ extern "C" int ren_mlp_bwd_jvp_x(const float *mlp_params, int32_t C, int32_t mod
         return REN_ERR_BAD_ARG;
     if (C != 1 && C != 3) return REN_ERR_UNSUPPORTED;
     if (mode != 1 && mode != 6) return REN_ERR_UNSUPPORTED;
-    if (ren_knob(REN_KNOB_ACTIVATIONS) != 0) return REN_ERR_UNSUPPORTED;      // activation alternatives: exact-f32 kernels only
+    if (activations != 0) return REN_ERR_UNSUPPORTED;      // activation alternatives: exact-f32 kernels only
     if (n == 0) return REN_OK;
     const int64_t n_blk = (n + 31) / 32;
     // scratch (floats): dz1 | dz1d (2048 per block each) | d_base | d_based (512 per block each)

@@ -232,7 +232,7 @@ int launch_fwd_x(const FwdXArgs &a, int C, bool density_only, bool one, hipStrea
 }  // namespace
 
 // mode: 6 = split-bf16 at fp32 accuracy (fp32 parameter block), 1 = plain bf16 operands (BASELINE configs[2])
-extern "C" int ren_mlp_fwd_x(const float *mlp_params, int32_t C, int32_t mode, const float *feat,
+extern "C" int ren_mlp_fwd_x(const float *mlp_params, int32_t C, int32_t activations, int32_t mode, const float *feat,
                              const ren_scene_desc *scene, const float *x_world, const float *dirs,
                              const float *rays_o, const float *rays_d, const int32_t *ray_indices,
                              const float *t_starts, const float *t_ends, int64_t n, int32_t flags,
@@ -240,7 +240,7 @@ extern "C" int ren_mlp_fwd_x(const float *mlp_params, int32_t C, int32_t mode, c
     if (!mlp_params || !feat || !scene || !sigma || n < 0) return REN_ERR_BAD_ARG;
     if (C != 1 && C != 3) return REN_ERR_UNSUPPORTED;
     if (mode != 1 && mode != 6) return REN_ERR_UNSUPPORTED;
-    if (ren_knob(REN_KNOB_ACTIVATIONS) != 0) return REN_ERR_UNSUPPORTED;      // activation alternatives: exact-f32 kernels only
+    if (activations != 0) return REN_ERR_UNSUPPORTED;      // activation alternatives: exact-f32 kernels only
     const bool density_only = (flags & REN_MLP_DENSITY_ONLY) != 0, share = (flags & REN_MLP_SHARE_CU) != 0;
     if (flags & ~(REN_MLP_DENSITY_ONLY | REN_MLP_SHARE_CU)) return REN_ERR_BAD_ARG;
     if (!density_only && !rgb) return REN_ERR_BAD_ARG;
@@ -793,15 +793,13 @@ __global__ __launch_bounds__(256, REN_BASE_WAVES) void mlp_bwd_base_x_kernel(Bwd
     }
 }
 
-// persistent workgroups of this launch: REN_KNOB_MLP_BWD_CUS (the chunked backward leaves CUs to the scatter on the other stream)
-static inline int bwd_grid_cus() {
-    const int k = ren_knob(REN_KNOB_MLP_BWD_CUS);
-    return k >= 1 && k < REN_GRID_CUS ? k : REN_GRID_CUS;
-}
+// persistent workgroups of this launch: the call's `grid_cus` (the chunked backward leaves CUs to the scatter on the other
+// stream); 0 or anything >= REN_GRID_CUS = all of them
+static inline int bwd_grid_cus(int k) { return k >= 1 && k < REN_GRID_CUS ? k : REN_GRID_CUS; }
 
 template <int MODE, bool RECOMP>
-int launch_bwd_x(const BwdXHArgs &h, const BwdXBArgs &b, int C, float *grad, hipStream_t st) {
-    const int GRID_XH = bwd_grid_cus(), GRID_XB = GRID_XH * REN_BASE_WAVES;      // (the slab layout stays that of the full grids)
+int launch_bwd_x(const BwdXHArgs &h, const BwdXBArgs &b, int C, float *grad, int grid_cus, hipStream_t st) {
+    const int GRID_XH = bwd_grid_cus(grid_cus), GRID_XB = GRID_XH * REN_BASE_WAVES;      // (the slab layout stays that of the full grids)
     using HL = HeadLds<MODE, RECOMP>;
     using BL = BaseLds<MODE, RECOMP>;
     const size_t lds_h = (size_t)HL::F_END * 2 + HL::TAIL_BYTES + 4 * 16 * 64 * sizeof(float4);
@@ -828,19 +826,20 @@ extern "C" int64_t ren_mlp_bwd_x_workspace_floats(int32_t C) {
     return (int64_t)GRID_XH * 4 * (p_total(C) - P_BASE_N) + (int64_t)GRID_XB * 4 * P_BASE_N;
 }
 
-extern "C" int ren_mlp_bwd_x(const float *mlp_params, int32_t C, int32_t mode, const float *feat, const float *base_out,
+extern "C" int ren_mlp_bwd_x(const float *mlp_params, int32_t C, int32_t activations, int32_t mode, const float *feat, const float *base_out,
                              const float *act_save, const ren_scene_desc *scene, const float *x_world,
                              const float *dirs, const float *rays_o, const float *rays_d, const int32_t *ray_indices,
                              const float *t_starts, const float *t_ends, int64_t n, const float *rgb,
                              const float *d_rgb, const float *d_sigma, float *d_base, float *dfeat,
-                             float *grad_mlp_params, float *workspace, void *stream) {
+                             float *grad_mlp_params, float *workspace, int32_t grid_cus, void *stream) {
     // act_save == nullptr: the hidden activations are recomputed from feat / base_out (the forward need not save them)
     if (!mlp_params || !feat || !base_out || !scene || !rgb || !d_rgb || !d_sigma || !d_base || !dfeat ||
         !grad_mlp_params || !workspace || n < 0)
         return REN_ERR_BAD_ARG;
     if (C != 1 && C != 3) return REN_ERR_UNSUPPORTED;
     if (mode != 1 && mode != 6) return REN_ERR_UNSUPPORTED;
-    if (ren_knob(REN_KNOB_ACTIVATIONS) != 0) return REN_ERR_UNSUPPORTED;      // activation alternatives: exact-f32 kernels only
+    if (activations != 0) return REN_ERR_UNSUPPORTED;      // activation alternatives: exact-f32 kernels only
+    if (grid_cus < 0) return REN_ERR_BAD_ARG;
     if (!x_world && (!rays_o || !rays_d || !ray_indices || !t_starts || !t_ends)) return REN_ERR_BAD_ARG;
     if (n == 0) return REN_OK;
     const int head_len = p_total(C) - P_BASE_N;
@@ -853,8 +852,8 @@ extern "C" int ren_mlp_bwd_x(const float *mlp_params, int32_t C, int32_t mode, c
     b.params = mlp_params; b.feat = feat; b.d_base = d_base; b.acts = act_save; b.n = n; b.dfeat = dfeat;
     b.slab = workspace + (int64_t)GRID_XH * 4 * head_len;
     if (act_save)
-        return mode == 6 ? launch_bwd_x<6, false>(h, b, C, grad_mlp_params, (hipStream_t)stream)
-                         : launch_bwd_x<1, false>(h, b, C, grad_mlp_params, (hipStream_t)stream);
-    return mode == 6 ? launch_bwd_x<6, true>(h, b, C, grad_mlp_params, (hipStream_t)stream)
-                     : launch_bwd_x<1, true>(h, b, C, grad_mlp_params, (hipStream_t)stream);
+        return mode == 6 ? launch_bwd_x<6, false>(h, b, C, grad_mlp_params, grid_cus, (hipStream_t)stream)
+                         : launch_bwd_x<1, false>(h, b, C, grad_mlp_params, grid_cus, (hipStream_t)stream);
+    return mode == 6 ? launch_bwd_x<6, true>(h, b, C, grad_mlp_params, grid_cus, (hipStream_t)stream)
+                     : launch_bwd_x<1, true>(h, b, C, grad_mlp_params, grid_cus, (hipStream_t)stream);
 }

@@ -1351,12 +1351,12 @@ static int vfield_grid(int64_t n, int nb) {
 }
 
 extern "C" int ren_vanilla_fwd(const float *enc, int32_t ld_enc, const float *view, int32_t ld_view, const uint8_t *selector,
-                               const float *params, int32_t C, const void *image, int32_t mode, int64_t n, void *saved,
+                               const float *params, int32_t C, int32_t activations, const void *image, int32_t mode, int64_t n, void *saved,
                                float *sigma, float *rgb4, void *stream) {
     if (!enc || !selector || !params || !image || !sigma || !vfield_ok(mode, C) || n < 0 || ld_enc < 64 || (ld_enc & 3)) return REN_ERR_BAD_ARG;
     if (rgb4 && (!view || ld_view < 32 || (ld_view & 3))) return REN_ERR_BAD_ARG;
     if (saved && !rgb4) return REN_ERR_BAD_ARG;                                 // the backward pass needs the whole field
-    if (ren_knob(REN_KNOB_ACTIVATIONS) != 0) return REN_ERR_UNSUPPORTED;         // activation alternatives: the per-layer launches (ren_dense_*)
+    if (activations != 0) return REN_ERR_UNSUPPORTED;         // activation alternatives: the per-layer launches (ren_dense_*)
     if (n == 0) return REN_OK;
     FieldArgs a = {};
     a.enc = enc; a.ld_enc = ld_enc; a.view = view; a.ld_view = ld_view; a.sel = selector; a.P = params; a.C = C;
@@ -1387,10 +1387,10 @@ extern "C" int ren_vanilla_fwd(const float *enc, int32_t ld_enc, const float *vi
     REN_CHECK_LAUNCH();
 }
 
-extern "C" int ren_vanilla_bwd(const float *dz_rgb, const float *dz_sigma, const void *image, int32_t mode, int64_t n,
+extern "C" int ren_vanilla_bwd(const float *dz_rgb, const float *dz_sigma, const void *image, int32_t mode, int32_t activations, int64_t n,
                                const void *saved, int64_t saved_slot_bytes, void *dz, void *stream) {
     if (!dz_rgb || !dz_sigma || !image || !saved || !dz || (mode != 1 && mode != 6) || n < 0 || saved_slot_bytes < 0) return REN_ERR_BAD_ARG;
-    if (ren_knob(REN_KNOB_ACTIVATIONS) != 0) return REN_ERR_UNSUPPORTED;
+    if (activations != 0) return REN_ERR_UNSUPPORTED;
     if (n == 0) return REN_OK;
     FieldArgs a = {};
     a.img = reinterpret_cast<const __bf16 *>(image) + (size_t)F_FRAGS * vfield_np(mode) * 512;

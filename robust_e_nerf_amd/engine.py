@@ -15,6 +15,8 @@ from dataclasses import dataclass, field as dc_field
 from typing import Dict, Optional, Sequence, Tuple
 
 import contextlib
+import dataclasses
+import threading
 import torch
 
 from . import ops
@@ -200,7 +202,7 @@ def _adopt(v, stream):
         _adopt((v.ray_indices, v.t_starts, v.t_ends, v.offsets, v.counts, v.feat), stream)
 
 
-_PINNED = {}
+_PINNED = threading.local()             # per host thread: two renderers may read counts from two threads at once
 
 
 def _host_int(t: torch.Tensor) -> int:
@@ -211,9 +213,10 @@ def _host_int(t: torch.Tensor) -> int:
     cur = torch.cuda.current_stream(t.device)
     if cur == torch.cuda.default_stream(t.device):
         return int(t.item())
-    buf = _PINNED.get(t.dtype)
+    bufs = _PINNED.__dict__.setdefault("bufs", {})
+    buf = bufs.get(t.dtype)
     if buf is None:
-        buf = _PINNED[t.dtype] = torch.empty(1, dtype=t.dtype).pin_memory()
+        buf = bufs[t.dtype] = torch.empty(1, dtype=t.dtype).pin_memory()
     buf.copy_(t.reshape(1), non_blocking=True)
     ev = torch.cuda.Event()
     ev.record(cur)
@@ -224,7 +227,7 @@ def _host_int(t: torch.Tensor) -> int:
 class Renderer:
     def __init__(self, fld: NGPField, cfg: RenderCfg):
         self.field = fld
-        self.cfg = cfg
+        self.cfg = cfg = dataclasses.replace(cfg)   # a private copy: the overrides below must not leak into the caller's object
         self.scene = ops.make_scene_desc(cfg.aabb, cfg.contraction_type)
         dev = fld.flat.device
         cells = cfg.occ_res[0] * cfg.occ_res[1] * cfg.occ_res[2]
@@ -247,14 +250,10 @@ class Renderer:
             cfg.mlp_kernels = "f32"                 # the bf16-matrix-core kernels implement the shipped activations only
         # (arch mlp: vanilla.VanillaRenderer switches to its per-layer launches, in any matrix-core mode)
         grid = getattr(fld, "grid", None)
-        if grid is not None and max(grid.size[l] for l in range(grid.n_levels)) > 1 << 19:
+        if grid is not None and not ops.binned_supported(grid):
             cfg.binned_scatter = False              # DenseGrid levels beyond 64 bins: the per-update atomic scatter
-        self._apply_acts()
-
-    def _apply_acts(self):
-        """the activation set is process-wide kernel configuration (REN_KNOB_ACTIVATIONS): (re)select this renderer's before
-        it launches, so that two renderers with different sets can live in one process"""
-        ops.set_activations(self._act_code)
+        # the activation set travels with every launch as an argument (`act=`; ABI 24): renderers with different sets can
+        # launch from different host threads / streams of one process
 
     # ---- sampling (K1-K3): ray/AABB, two-pass march, no-grad density pre-pass + visibility --------
     def sample_begin(self, o, d, jitter: Optional[torch.Tensor], training: bool) -> dict:
@@ -286,7 +285,6 @@ class Renderer:
     def sample(self, o, d, jitter: Optional[torch.Tensor], training: bool, keep_feat: bool = False,
                begun: Optional[dict] = None) -> Packed:
         c = self.cfg
-        self._apply_acts()
         st = begun if begun is not None else self.sample_begin(o, d, jitter, training)
         args, cache, counts, offsets, mode = st["args"], st["cache"], st["counts"], st["offsets"], st["mode"]
         # host sync, as in the reference (external/utils.py:106-119); `begun["n0"]`: already read back (Trainer.prefetch)
@@ -321,10 +319,10 @@ class Renderer:
                                 samples=samples, n=n, layout=1)
         if self.cfg.mlp_kernels == "x":
             _, sigma, _, _ = ops.mlp_fwd_x(self.field.mlp, self.field.C, self._xmode(), feat, self.scene, rays=(o, d),
-                                           samples=samples, n=n, density_only=True)
+                                           samples=samples, n=n, density_only=True, act=self._act_code)
             return (sigma, feat) if return_feat else sigma
         _, sigma, _ = ops.mlp_fwd(self._mlp_params(), self.field.C, feat, self.scene, rays=(o, d),
-                                  samples=samples, n=n, density_only=True, bf16=self.cfg.mlp_bf16)
+                                  samples=samples, n=n, density_only=True, bf16=self.cfg.mlp_bf16, act=self._act_code)
         return sigma
 
     def _binned_workspace(self, n: int, device) -> torch.Tensor:
@@ -363,15 +361,15 @@ class Renderer:
             ops.hashgrid_fwd(f.grid, f.table, scene=self.scene, rays=(o, d), samples=samples, n=pk.n, layout=1)
         if self.cfg.mlp_kernels == "x":
             rgb, sigma, base, acts = ops.mlp_fwd_x(f.mlp, f.C, self._xmode(), feat, self.scene, rays=(o, d), samples=samples,
-                                                   n=pk.n, save=save, save_acts=self._save_acts())
+                                                   n=pk.n, save=save, save_acts=self._save_acts(), act=self._act_code)
             return rgb, sigma, dict(feat=feat, base=base, acts=acts, xmode=self._xmode() if save else None)
         mp = self._mlp_params()
         if save and self._save_acts():
             rgb, sigma, base, acts = ops.mlp_fwd_save(mp, f.C, feat, self.scene, rays=(o, d), samples=samples, n=pk.n,
-                                                      bf16=self.cfg.mlp_bf16)
+                                                      bf16=self.cfg.mlp_bf16, act=self._act_code)
             return rgb, sigma, dict(feat=feat, base=base, mlp_params=mp, acts=acts)
         rgb, sigma, base = ops.mlp_fwd(mp, f.C, feat, self.scene, rays=(o, d), samples=samples, n=pk.n,
-                                       save_base=save, bf16=self.cfg.mlp_bf16)
+                                       save_base=save, bf16=self.cfg.mlp_bf16, act=self._act_code)
         return rgb, sigma, dict(feat=feat, base=base, mlp_params=mp)
 
     def _field_forward_chunked(self, o, d, pk, save, K):
@@ -411,7 +409,7 @@ class Renderer:
                        base[b0 * ops.BASE_FLOATS_PER_BLOCK: b1 * ops.BASE_FLOATS_PER_BLOCK] if save else None,
                        acts[b0 * lib_acts: b1 * lib_acts] if acts is not None else None)
                 ops.mlp_fwd_x(f.mlp, f.C, self._xmode(), fk, self.scene, rays=(o, d), samples=smp, n=hi - lo, save=save,
-                              out=out, share_cu=True)
+                              out=out, share_cu=True, act=self._act_code)
         main.wait_stream(s_enc)
         main.wait_stream(s_mlp)
         return rgb, sigma, dict(feat=feat, base=base, acts=acts, xmode=self._xmode() if save else None)
@@ -458,11 +456,11 @@ class Renderer:
                 break
             lo, hi = b0 * 32, min(n, b1 * 32)
             acts = ctx["acts"][b0 * acts_per: b1 * acts_per] if ctx.get("acts") is not None else None
-            with ops.knob("mlp_bwd_cus", 256 if k == 0 else self.cfg.bwd_mlp_cus):     # chunk 0 has the chip to itself
-                ops.mlp_bwd_x(f.mlp, f.C, ctx["xmode"], ctx["feat"][b0 * FR: b1 * FR], ctx["base"][b0 * BA: b1 * BA], acts,
-                              self.scene, rays=rays, samples=tuple(t[lo:hi] for t in samples), n=hi - lo,
-                              rgb=ctx["rgb"][lo:hi], d_rgb=d_rgb[lo:hi], d_sigma=d_sig[lo:hi], grad_mlp_params=f.g_mlp,
-                              workspace=self._ws, dfeat=dfeat[b0 * FR: b1 * FR], d_base=d_base[b0 * BA: b1 * BA])
+            ops.mlp_bwd_x(f.mlp, f.C, ctx["xmode"], ctx["feat"][b0 * FR: b1 * FR], ctx["base"][b0 * BA: b1 * BA], acts,
+                          self.scene, rays=rays, samples=tuple(t[lo:hi] for t in samples), n=hi - lo,
+                          rgb=ctx["rgb"][lo:hi], d_rgb=d_rgb[lo:hi], d_sigma=d_sig[lo:hi], grad_mlp_params=f.g_mlp,
+                          workspace=self._ws, dfeat=dfeat[b0 * FR: b1 * FR], d_base=d_base[b0 * BA: b1 * BA],
+                          act=self._act_code, grid_cus=0 if k == 0 else self.cfg.bwd_mlp_cus)   # chunk 0 has the chip to itself
             ev = torch.cuda.Event()
             ev.record(main)
             with torch.cuda.stream(side):
@@ -483,16 +481,16 @@ class Renderer:
         if ctx.get("xmode") is not None:
             dfeat = ops.mlp_bwd_x(f.mlp, f.C, ctx["xmode"], ctx["feat"], ctx["base"], ctx["acts"], self.scene,
                                   rays=(ctx["o"], ctx["d"]), samples=samples, n=pk.n, rgb=ctx["rgb"], d_rgb=d_rgb,
-                                  d_sigma=d_sig, grad_mlp_params=f.g_mlp, workspace=self._ws)
+                                  d_sigma=d_sig, grad_mlp_params=f.g_mlp, workspace=self._ws, act=self._act_code)
         elif ctx.get("acts") is not None:
             dfeat = ops.mlp_bwd_saved(mp, f.C, ctx["feat"], ctx["base"], ctx["acts"], self.scene, rays=(ctx["o"], ctx["d"]),
                                       samples=samples, n=pk.n, rgb=ctx["rgb"], d_rgb=d_rgb, d_sigma=d_sig,
-                                      grad_mlp_params=f.g_mlp, workspace=self._ws, bf16=self.cfg.mlp_bf16)
+                                      grad_mlp_params=f.g_mlp, workspace=self._ws, bf16=self.cfg.mlp_bf16, act=self._act_code)
         else:
             dfeat = ops.mlp_bwd(f.mlp if mp is None else mp, f.C, ctx["feat"], ctx["base"], self.scene,
                                 rays=(ctx["o"], ctx["d"]), samples=samples, n=pk.n, rgb=ctx["rgb"], d_rgb=d_rgb,
                                 d_sigma=d_sig, grad_mlp_params=f.g_mlp, workspace=self._ws,
-                                bf16=self.cfg.mlp_bf16 and mp is not None)
+                                bf16=self.cfg.mlp_bf16 and mp is not None, act=self._act_code)
         if self.cfg.binned_scatter:
             self._binned_workspace(pk.n, dfeat.device)
             kw = dict(scene=self.scene, rays=(ctx["o"], ctx["d"]), samples=samples, n=pk.n, layout=1)
@@ -513,7 +511,6 @@ class Renderer:
     def forward(self, o, d, jitter=None, bkgd: Optional[torch.Tensor] = None, training: bool = True,
                 save: bool = True, begun: Optional[dict] = None):
         f = self.field
-        self._apply_acts()
         pk = self.sample(o, d, jitter, training, keep_feat=True, begun=begun)
         n_rays = o.shape[0]
         if pk.n == 0:
@@ -534,7 +531,6 @@ class Renderer:
         per_ray_bkgd: return the (R, C) per-ray background gradient instead of its column sums (Trainer folds the sum
         into ren_bkgd_param_grad)"""
         f = self.field
-        self._apply_acts()
         if ctx["empty"]:
             # a rank without a single sample must still issue the collectives its peers issue (the slice is final here:
             # this pass adds nothing to it) -- otherwise the ranks' all-reduce sequences differ and RCCL hangs
@@ -556,14 +552,13 @@ class Renderer:
     def query_density(self, x_world: torch.Tensor) -> torch.Tensor:
         """NGPradianceField.query_density(x) (ngp.py:230-254) for arbitrary world points."""
         f = self.field
-        self._apply_acts()
         n = x_world.shape[0]
         xu = contract_points(x_world, self.cfg.aabb, self.cfg.contraction_type)
         feat = ops.hashgrid_fwd(f.grid, f.table, x_unit=xu, n=n, layout=1)
         if self.cfg.mlp_kernels == "x":
-            return ops.mlp_fwd_x(f.mlp, f.C, self._xmode(), feat, self.scene, x_world=x_world, n=n, density_only=True)[1]
+            return ops.mlp_fwd_x(f.mlp, f.C, self._xmode(), feat, self.scene, x_world=x_world, n=n, density_only=True, act=self._act_code)[1]
         _, sigma, _ = ops.mlp_fwd(self._mlp_params(), f.C, feat, self.scene, x_world=x_world, n=n, density_only=True,
-                                  bf16=self.cfg.mlp_bf16)
+                                  bf16=self.cfg.mlp_bf16, act=self._act_code)
         return sigma
 
     # ---- occupancy grid (K14): nerfacc OccupancyGrid.every_n_step as driven by nerf.py:170-204 ------------

@@ -84,9 +84,8 @@ class _FieldFn(torch.autograd.Function):
         xu = contract_points(x_world, m.aabb.tolist(), m.contraction_type.value)
         feat = ops.hashgrid_fwd(m.encoding.grid, table, x_unit=xu, n=n, layout=1)
         dirs_c = None if dirs is None else dirs.contiguous().float()
-        with ops.knob("activations", m._act_code):
-            rgb, sigma, base = ops.mlp_fwd(mlp, m.radiance_dim, feat, m.scene, x_world=x_world, dirs=dirs_c, n=n,
-                                           density_only=density_only, save_base=not density_only)
+        rgb, sigma, base = ops.mlp_fwd(mlp, m.radiance_dim, feat, m.scene, x_world=x_world, dirs=dirs_c, n=n,
+                                       density_only=density_only, save_base=not density_only, act=m._act_code)
         ctx.module, ctx.n, ctx.density_only = m, n, density_only
         ctx.shapes = [t.shape for t in mlp_tensors]
         if not density_only:
@@ -107,12 +106,10 @@ class _FieldFn(torch.autograd.Function):
         g_sigma = torch.zeros(n, device=dev) if g_sigma is None else g_sigma.reshape(-1).contiguous().float()
         g_mlp = torch.zeros_like(mlp)
         ws = torch.empty(ops.mlp_bwd_workspace_floats(m.radiance_dim), device=dev, dtype=torch.float32)
-        with ops.knob("activations", m._act_code):
-            dfeat = ops.mlp_bwd(mlp, m.radiance_dim, feat, base, m.scene, x_world=x_world, dirs=dirs, n=n, rgb=rgb,
-                                d_rgb=g_rgb, d_sigma=g_sigma, grad_mlp_params=g_mlp, workspace=ws)
+        dfeat = ops.mlp_bwd(mlp, m.radiance_dim, feat, base, m.scene, x_world=x_world, dirs=dirs, n=n, rgb=rgb,
+                            d_rgb=g_rgb, d_sigma=g_sigma, grad_mlp_params=g_mlp, workspace=ws, act=m._act_code)
         g_table = torch.zeros(m.encoding.n_params, device=dev, dtype=torch.float32)
-        bws = torch.empty(ops.hashgrid_bwd_binned_workspace_bytes(n), device=dev, dtype=torch.uint8)
-        ops.hashgrid_bwd_binned(m.encoding.grid, g_table, dfeat, bws, x_unit=xu, n=n, layout=1)
+        ops.hashgrid_bwd_auto(m.encoding.grid, g_table, dfeat, x_unit=xu, n=n, layout=1)
         outs, off = [], 0
         for shp in ctx.shapes:
             k = math.prod(shp)

@@ -57,7 +57,6 @@ def render_forward2(r, o, d, od, dd, ddd, pk, bkgd):
     """Second-order forward render over an EXISTING sample stream `pk` (sample placement is not
     differentiated): -> colors, d colors/dt, d2 colors/dt2, each (R, C).  Forward only."""
     f, lib = r.field, _lib.load()
-    r._apply_acts()
     n, R, dev = pk.n, o.shape[0], o.device
     if n == 0:
         z = torch.zeros(R, f.C, device=dev)
@@ -78,12 +77,12 @@ def render_forward2(r, o, d, od, dd, ddd, pk, bkgd):
     rgb, rgbd, rgbdd = (torch.empty(n, f.C, device=dev) for _ in range(3))
     sg, sgd, sgdd = (torch.empty(n, device=dev) for _ in range(3))
     if r.cfg.mlp_kernels == "x":                            # bf16 matrix cores, in the step's precision mode
-        check(lib.ren_mlp_fwd_jvp2_x(_ptr(f.mlp), f.C, r._xmode(), _ptr(feat), _ptr(featd), _ptr(featdd), ctypes.byref(r.scene),
+        check(lib.ren_mlp_fwd_jvp2_x(_ptr(f.mlp), f.C, r._act_code, r._xmode(), _ptr(feat), _ptr(featd), _ptr(featdd), ctypes.byref(r.scene),
                                      _ptr(o), _ptr(d), _ptr(od), _ptr(dd), _ptr(ddd), _ptr(ri), _ptr(ts), _ptr(te), n,
                                      _ptr(rgb), _ptr(rgbd), _ptr(rgbdd), _ptr(sg), _ptr(sgd), _ptr(sgdd), _stream()),
               "ren_mlp_fwd_jvp2_x")
     else:
-        check(lib.ren_mlp_fwd_jvp2(_ptr(r._mlp_params()), f.C, _ptr(feat), _ptr(featd), _ptr(featdd), ctypes.byref(r.scene),
+        check(lib.ren_mlp_fwd_jvp2(_ptr(r._mlp_params()), f.C, r._act_code, _ptr(feat), _ptr(featd), _ptr(featdd), ctypes.byref(r.scene),
                                    _ptr(o), _ptr(d), _ptr(od), _ptr(dd), _ptr(ddd), _ptr(ri), _ptr(ts), _ptr(te), n,
                                    _ptr(rgb), _ptr(rgbd), _ptr(rgbdd), _ptr(sg), _ptr(sgd), _ptr(sgdd), _stream()),
               "ren_mlp_fwd_jvp2")
@@ -98,7 +97,6 @@ def render_forward(r, o, d, od, dd, jitter, bkgd, training: bool = True, pk=None
     """-> colors (R,C), colords (R,C) [d/dt], opacity (R,), ctx.  pk: the samples, when the caller has already placed them
     (engine.Trainer.grad_loss_forward_backward(early=True)); begun: Renderer.sample_begin() of these rays, already enqueued."""
     f, lib = r.field, _lib.load()
-    r._apply_acts()
     if pk is None:
         pk = r.sample(o, d, jitter, training, begun=begun)
     n, R, dev = pk.n, o.shape[0], o.device
@@ -121,11 +119,11 @@ def render_forward(r, o, d, od, dd, jitter, bkgd, training: bool = True, pk=None
         sigma, sigmad = torch.empty(n, device=dev), torch.empty(n, device=dev)
         base, based = torch.empty(nb * 512, device=dev), torch.empty(nb * 512, device=dev)
         if r.cfg.mlp_kernels == "x":                        # bf16 matrix cores: mode 6 (fp32 accuracy) / 1 (bf16 operands)
-            check(lib.ren_mlp_fwd_jvp_x(_ptr(f.mlp), f.C, r._xmode(), _ptr(feat), _ptr(featd), ctypes.byref(r.scene), _ptr(o),
+            check(lib.ren_mlp_fwd_jvp_x(_ptr(f.mlp), f.C, r._act_code, r._xmode(), _ptr(feat), _ptr(featd), ctypes.byref(r.scene), _ptr(o),
                                         _ptr(d), _ptr(dd), _ptr(ri), _ptr(ts), _ptr(te), n, _ptr(rgb), _ptr(rgbd), _ptr(sigma),
                                         _ptr(sigmad), _ptr(base), _ptr(based), _stream()), "ren_mlp_fwd_jvp_x")
         else:
-            check(lib.ren_mlp_fwd_jvp(_ptr(r._mlp_params()), f.C, _ptr(feat), _ptr(featd), ctypes.byref(r.scene), _ptr(o), _ptr(d),
+            check(lib.ren_mlp_fwd_jvp(_ptr(r._mlp_params()), f.C, r._act_code, _ptr(feat), _ptr(featd), ctypes.byref(r.scene), _ptr(o), _ptr(d),
                                       _ptr(dd), _ptr(ri), _ptr(ts), _ptr(te), n, _ptr(rgb), _ptr(rgbd), _ptr(sigma),
                                       _ptr(sigmad), _ptr(base), _ptr(based), _stream()), "ren_mlp_fwd_jvp")
     colors, colords = torch.empty(R, f.C, device=dev), torch.empty(R, f.C, device=dev)
@@ -150,7 +148,6 @@ def render_forward(r, o, d, od, dd, jitter, bkgd, training: bool = True, pk=None
 def render_backward(r, ctx, g_colors, g_colords, final: bool = False):
     """Accumulates into r.field.grad; returns d(bkgd) (C,) or None.  final: last backward pass of the step."""
     f, lib = r.field, _lib.load()
-    r._apply_acts()
     if ctx["empty"]:
         if final and r.dp_early_slice() is not None:         # same collective sequence on every rank (Renderer.backward)
             r.dp_early()
@@ -176,14 +173,14 @@ def render_backward(r, ctx, g_colors, g_colords, final: bool = False):
     dfeat, dfeatd = torch.empty(nb * 1024, device=dev), torch.empty(nb * 1024, device=dev)
     if r.cfg.mlp_kernels == "x":
         ws = torch.empty(int(lib.ren_mlp_bwd_jvp_x_workspace_floats(f.C)), device=dev)
-        check(lib.ren_mlp_bwd_jvp_x(_ptr(f.mlp), f.C, r._xmode(), _ptr(ctx["feat"]), _ptr(ctx["featd"]), _ptr(ctx["base"]),
+        check(lib.ren_mlp_bwd_jvp_x(_ptr(f.mlp), f.C, r._act_code, r._xmode(), _ptr(ctx["feat"]), _ptr(ctx["featd"]), _ptr(ctx["base"]),
                                     _ptr(ctx["based"]), ctypes.byref(r.scene), _ptr(ctx["o"]), _ptr(ctx["d"]),
                                     _ptr(ctx["dd"]), _ptr(ri), _ptr(ts), _ptr(te), n, _ptr(ctx["rgb"]), _ptr(d_rgb),
                                     _ptr(d_rgbd), _ptr(d_sig), _ptr(d_sigd), _ptr(scratch), _ptr(dfeat), _ptr(dfeatd),
                                     _ptr(f.g_mlp), _ptr(ws), _stream()), "ren_mlp_bwd_jvp_x")
     else:
         ws = torch.empty(int(lib.ren_mlp_bwd_jvp_workspace_floats(f.C)), device=dev)
-        check(lib.ren_mlp_bwd_jvp(_ptr(f.mlp), f.C, _ptr(ctx["feat"]), _ptr(ctx["featd"]), _ptr(ctx["base"]),
+        check(lib.ren_mlp_bwd_jvp(_ptr(f.mlp), f.C, r._act_code, _ptr(ctx["feat"]), _ptr(ctx["featd"]), _ptr(ctx["base"]),
                                   _ptr(ctx["based"]), ctypes.byref(r.scene), _ptr(ctx["o"]), _ptr(ctx["d"]),
                                   _ptr(ctx["dd"]), _ptr(ri), _ptr(ts), _ptr(te), n, _ptr(ctx["rgb"]), _ptr(d_rgb),
                                   _ptr(d_rgbd), _ptr(d_sig), _ptr(d_sigd), _ptr(scratch), _ptr(dfeat), _ptr(dfeatd),

@@ -19,7 +19,7 @@ BASE_FLOATS_PER_BLOCK = 8 * 64           # saved base-MLP outputs, per 32 sample
 _DT = {torch.float32: 4, torch.float64: 8, torch.int32: 4, torch.int64: 8, torch.uint8: 1, torch.bool: 1}
 
 
-KNOBS = {"hgb_no_pairs": 0, "hgb_halve_regions": 1, "march_sequential": 2, "hg_variant": 3, "vfield_plain": 4, "hgb_subregion": 5, "mlp_bwd_cus": 6, "activations": 7}     # include/ren_amd.h REN_KNOB_*
+KNOBS = {"hgb_no_pairs": 0, "hgb_halve_regions": 1, "march_sequential": 2, "hg_variant": 3, "vfield_plain": 4, "hgb_subregion": 5}     # include/ren_amd.h REN_KNOB_*
 
 
 class knob:
@@ -37,7 +37,8 @@ class knob:
         _lib.load().ren_set_knob(self.k, self.old)
 
 
-# Activation alternatives of the YAML (robust_e_nerf/models/nerf.py:8-29) -> code of REN_KNOB_ACTIVATIONS (include/ren_amd.h)
+# Activation alternatives of the YAML (robust_e_nerf/models/nerf.py:8-29) -> the `activations` argument of the ren_mlp_* /
+# ren_vanilla_* entry points (include/ren_amd.h); every wrapper below takes it as `act` (0 = the shipped configs)
 HIDDEN_ACTS = {"softplus": 0, "relu": 1}
 DENSITY_ACTS = {"shifted_trunc_exp": 0, "softplus": 1, "shifted_softplus": 2}
 RADIANCE_ACTS = {"softplus": 0, "sigmoid": 1}
@@ -50,12 +51,6 @@ def activation_code(base_hidden="softplus", density="shifted_trunc_exp", head_hi
                 RADIANCE_ACTS[radiance] << 6)
     except KeyError as e:
         raise NotImplementedError(f"activation {e.args[0]!r} (models/nerf.py:17-29)") from e
-
-
-def set_activations(code: int):
-    """select the activation set of the exact-f32 MLP kernels (process-wide model configuration; the bf16-matrix-core
-    kernels implement code 0 only and refuse anything else)"""
-    check(_lib.load().ren_set_knob(KNOBS["activations"], int(code)), "ren_set_knob(activations)")
 
 
 def _ptr(t: Optional[torch.Tensor], dtype=None):
@@ -368,6 +363,26 @@ def hashgrid_bwd_binned(grid: GridDesc, grad_table, dfeat, workspace, *, x_unit=
           "ren_hashgrid_bwd_binned")
 
 
+BINNED_MAX_LEVEL_ENTRIES = 1 << 19          # 64 bins of 8 192 entries: what ren_hashgrid_bwd_binned takes per level
+
+
+def binned_supported(grid: GridDesc) -> bool:
+    """False for a DenseGrid with a level above 2^19 entries: such a grid takes the per-update atomic scatter"""
+    return max(int(grid.size[l]) for l in range(grid.n_levels)) <= BINNED_MAX_LEVEL_ENTRIES
+
+
+def hashgrid_bwd_auto(grid: GridDesc, grad_table, dfeat, *, x_unit=None, scene=None, rays=None, samples=None, n: int,
+                      layout: int):
+    """parameter gradient of the module seams (field.NGPradianceField, tcnn_api.Encoding): the binned scatter with a
+    workspace of its own, or the atomic scatter for grids the binned one refuses (as engine.Renderer chooses)"""
+    if binned_supported(grid):
+        ws = torch.empty(hashgrid_bwd_binned_workspace_bytes(n), device=dfeat.device, dtype=torch.uint8)
+        hashgrid_bwd_binned(grid, grad_table, dfeat, ws, x_unit=x_unit, scene=scene, rays=rays, samples=samples, n=n,
+                            layout=layout)
+    else:
+        hashgrid_bwd(grid, grad_table, dfeat, x_unit=x_unit, scene=scene, rays=rays, samples=samples, n=n, layout=layout)
+
+
 def hashgrid_bwd_binned_begin(grid: GridDesc, workspace, *, scene, rays, samples, n: int, layout: int = 1):
     """phase 1 of hashgrid_bwd_binned: clear + count + offsets (sample stream only)"""
     if workspace.numel() * workspace.element_size() < hashgrid_bwd_binned_workspace_bytes(n):
@@ -396,7 +411,7 @@ def hashgrid_bwd_binned_finish(grid: GridDesc, grad_table, workspace, *, n: int,
 
 # ------------------------------------------------------------------------------- fused MLPs
 def mlp_fwd(mlp_params, C: int, feat, scene: SceneDesc, *, x_world=None, dirs=None, rays=None, samples=None,
-            n: int, density_only: bool = False, save_base: bool = False, out=None, bf16: bool = False):
+            n: int, density_only: bool = False, save_base: bool = False, out=None, bf16: bool = False, act: int = 0):
     """bf16=True: `mlp_params` must be the bf16-rounded copy of the block (see ren_mlp_fwd_bf16)."""
     dev = feat.device
     o, d = rays if rays is not None else (None, None)
@@ -408,7 +423,7 @@ def mlp_fwd(mlp_params, C: int, feat, scene: SceneDesc, *, x_world=None, dirs=No
     else:
         rgb, sigma, base = out
     fn = _lib.load().ren_mlp_fwd_bf16 if bf16 else _lib.load().ren_mlp_fwd
-    check(fn(_ptr(mlp_params, torch.float32), C, _ptr(feat, torch.float32), ctypes.byref(scene),
+    check(fn(_ptr(mlp_params, torch.float32), C, int(act), _ptr(feat, torch.float32), ctypes.byref(scene),
              _ptr(x_world), _ptr(dirs), _ptr(o), _ptr(d), _ptr(ri), _ptr(ts), _ptr(te), n,
              1 if density_only else 0, _ptr(rgb), _ptr(sigma), _ptr(base), _stream()),
           "ren_mlp_fwd")
@@ -416,7 +431,7 @@ def mlp_fwd(mlp_params, C: int, feat, scene: SceneDesc, *, x_world=None, dirs=No
 
 
 def mlp_fwd_save(mlp_params, C: int, feat, scene: SceneDesc, *, rays=None, samples=None, x_world=None, dirs=None,
-                 n: int, bf16: bool = False):
+                 n: int, bf16: bool = False, act: int = 0):
     """Training forward: also saves base outputs and the hidden activations (768 B/sample) for mlp_bwd_saved.
     -> rgb, sigma, base, acts"""
     dev = feat.device
@@ -427,20 +442,20 @@ def mlp_fwd_save(mlp_params, C: int, feat, scene: SceneDesc, *, rays=None, sampl
     base = torch.empty(n_blocks32(n) * BASE_FLOATS_PER_BLOCK, device=dev, dtype=torch.float32)
     lib = _lib.load()
     acts = torch.empty(int(lib.ren_mlp_act_save_floats(n)), device=dev, dtype=torch.float32)
-    check(lib.ren_mlp_fwd_save(_ptr(mlp_params, torch.float32), C, 1 if bf16 else 0, _ptr(feat, torch.float32),
+    check(lib.ren_mlp_fwd_save(_ptr(mlp_params, torch.float32), C, int(act), 1 if bf16 else 0, _ptr(feat, torch.float32),
                                ctypes.byref(scene), _ptr(x_world), _ptr(dirs), _ptr(o), _ptr(d), _ptr(ri), _ptr(ts),
                                _ptr(te), n, _ptr(rgb), _ptr(sigma), _ptr(base), _ptr(acts), _stream()), "ren_mlp_fwd_save")
     return rgb, sigma, base, acts
 
 
 def mlp_bwd_saved(mlp_params, C: int, feat, base_out, acts, scene: SceneDesc, *, rays=None, samples=None, x_world=None,
-                  dirs=None, n: int, rgb, d_rgb, d_sigma, grad_mlp_params, workspace, bf16: bool = False):
+                  dirs=None, n: int, rgb, d_rgb, d_sigma, grad_mlp_params, workspace, bf16: bool = False, act: int = 0):
     dev = feat.device
     o, d = rays if rays is not None else (None, None)
     ri, ts, te = samples if samples is not None else (None, None, None)
     d_base = torch.empty(n_blocks32(n) * BASE_FLOATS_PER_BLOCK, device=dev, dtype=torch.float32)
     dfeat = torch.empty(n_blocks32(n) * FRAG_FLOATS_PER_BLOCK, device=dev, dtype=torch.float32)
-    check(_lib.load().ren_mlp_bwd_saved(_ptr(mlp_params, torch.float32), C, 1 if bf16 else 0, _ptr(feat), _ptr(base_out),
+    check(_lib.load().ren_mlp_bwd_saved(_ptr(mlp_params, torch.float32), C, int(act), 1 if bf16 else 0, _ptr(feat), _ptr(base_out),
                                         _ptr(acts), ctypes.byref(scene), _ptr(x_world), _ptr(dirs), _ptr(o), _ptr(d),
                                         _ptr(ri), _ptr(ts), _ptr(te), n, _ptr(rgb), _ptr(d_rgb), _ptr(d_sigma),
                                         _ptr(d_base), _ptr(dfeat), _ptr(grad_mlp_params, torch.float32), _ptr(workspace),
@@ -449,7 +464,8 @@ def mlp_bwd_saved(mlp_params, C: int, feat, base_out, acts, scene: SceneDesc, *,
 
 
 def mlp_fwd_x(mlp_params, C: int, mode: int, feat, scene: SceneDesc, *, rays=None, samples=None, x_world=None, dirs=None,
-              n: int, density_only: bool = False, save: bool = False, out=None, share_cu: bool = False, save_acts: bool = True):
+              n: int, density_only: bool = False, save: bool = False, out=None, share_cu: bool = False, save_acts: bool = True,
+              act: int = 0):
     """Split-bf16 matrix-core kernels (csrc/ren_mlp_x.hip).  mode 6: fp32 accuracy; mode 1: plain bf16 operands.
     -> rgb, sigma, base, acts (base/acts None unless save; acts None with save_acts=False: mlp_bwd_x then recomputes
     the hidden activations); out: preallocated (rgb, sigma, base, acts) views"""
@@ -464,7 +480,7 @@ def mlp_fwd_x(mlp_params, C: int, mode: int, feat, scene: SceneDesc, *, rays=Non
         rgb = None if density_only else torch.empty(n, C, device=dev, dtype=torch.float32)
         base = torch.empty(n_blocks32(n) * BASE_FLOATS_PER_BLOCK, device=dev, dtype=torch.float32) if save else None
         acts = torch.empty(int(lib.ren_mlp_act_save_floats(n)), device=dev, dtype=torch.float32) if (save and save_acts) else None
-    check(lib.ren_mlp_fwd_x(_ptr(mlp_params, torch.float32), C, mode, _ptr(feat, torch.float32), ctypes.byref(scene),
+    check(lib.ren_mlp_fwd_x(_ptr(mlp_params, torch.float32), C, int(act), mode, _ptr(feat, torch.float32), ctypes.byref(scene),
                             _ptr(x_world), _ptr(dirs), _ptr(o), _ptr(d), _ptr(ri), _ptr(ts), _ptr(te), n,
                             (1 if density_only else 0) | (2 if share_cu else 0), _ptr(rgb), _ptr(sigma), _ptr(base),
                             _ptr(acts), _stream()), "ren_mlp_fwd_x")
@@ -480,7 +496,9 @@ def mlp_bwd_x_workspace_floats(C: int) -> int:
 
 
 def mlp_bwd_x(mlp_params, C: int, mode: int, feat, base_out, acts, scene: SceneDesc, *, rays=None, samples=None,
-              x_world=None, dirs=None, n: int, rgb, d_rgb, d_sigma, grad_mlp_params, workspace, dfeat=None, d_base=None):
+              x_world=None, dirs=None, n: int, rgb, d_rgb, d_sigma, grad_mlp_params, workspace, dfeat=None, d_base=None,
+              act: int = 0, grid_cus: int = 0):
+    """grid_cus: CUs the two persistent kernels occupy (0 = all; the chunked backward leaves some to the scatter)"""
     dev = feat.device
     o, d = rays if rays is not None else (None, None)
     ri, ts, te = samples if samples is not None else (None, None, None)
@@ -488,10 +506,11 @@ def mlp_bwd_x(mlp_params, C: int, mode: int, feat, base_out, acts, scene: SceneD
         d_base = torch.empty(n_blocks32(n) * BASE_FLOATS_PER_BLOCK, device=dev, dtype=torch.float32)
     if dfeat is None:
         dfeat = torch.empty(n_blocks32(n) * FRAG_FLOATS_PER_BLOCK, device=dev, dtype=torch.float32)
-    check(_lib.load().ren_mlp_bwd_x(_ptr(mlp_params, torch.float32), C, mode, _ptr(feat), _ptr(base_out), _ptr(acts),
+    check(_lib.load().ren_mlp_bwd_x(_ptr(mlp_params, torch.float32), C, int(act), mode, _ptr(feat), _ptr(base_out), _ptr(acts),
                                     ctypes.byref(scene), _ptr(x_world), _ptr(dirs), _ptr(o), _ptr(d), _ptr(ri), _ptr(ts),
                                     _ptr(te), n, _ptr(rgb), _ptr(d_rgb), _ptr(d_sigma), _ptr(d_base), _ptr(dfeat),
-                                    _ptr(grad_mlp_params, torch.float32), _ptr(workspace), _stream()), "ren_mlp_bwd_x")
+                                    _ptr(grad_mlp_params, torch.float32), _ptr(workspace), int(grid_cus), _stream()),
+          "ren_mlp_bwd_x")
     return dfeat
 
 
@@ -501,7 +520,7 @@ def mlp_bwd_workspace_floats(C: int) -> int:
 
 def mlp_bwd(mlp_params, C: int, feat, base_out, scene: SceneDesc, *, x_world=None, dirs=None, rays=None,
             samples=None, n: int, rgb, d_rgb, d_sigma, grad_mlp_params, workspace, d_base=None, dfeat=None,
-            bf16: bool = False):
+            bf16: bool = False, act: int = 0):
     dev = feat.device
     o, d = rays if rays is not None else (None, None)
     ri, ts, te = samples if samples is not None else (None, None, None)
@@ -510,7 +529,7 @@ def mlp_bwd(mlp_params, C: int, feat, base_out, scene: SceneDesc, *, x_world=Non
     if dfeat is None:
         dfeat = torch.empty(n_blocks32(n) * FRAG_FLOATS_PER_BLOCK, device=dev, dtype=torch.float32)
     fn = _lib.load().ren_mlp_bwd_bf16 if bf16 else _lib.load().ren_mlp_bwd
-    check(fn(_ptr(mlp_params, torch.float32), C, _ptr(feat), _ptr(base_out),
+    check(fn(_ptr(mlp_params, torch.float32), C, int(act), _ptr(feat), _ptr(base_out),
                                   ctypes.byref(scene), _ptr(x_world), _ptr(dirs), _ptr(o), _ptr(d), _ptr(ri),
                                   _ptr(ts), _ptr(te), n, _ptr(rgb), _ptr(d_rgb), _ptr(d_sigma), _ptr(d_base),
                                   _ptr(dfeat), _ptr(grad_mlp_params, torch.float32), _ptr(workspace), _stream()),

@@ -71,6 +71,9 @@ class _HashGridDx(torch.autograd.Function):
             g_g = _encode_with_tangent(m, params, x, u)[1]                       # J_x u
         if ctx.needs_input_grad[1]:
             # d/d table of sum_c (dw_c/dx . u) table_c . g  =  scatter of (dw_c/dx . u) g
+            if not ops.binned_supported(m.grid):
+                raise NotImplementedError("second-order table gradient of a DenseGrid with a level above 2^19 entries "
+                                          "(the tangent scatter exists in the binned form only)")
             g_p = torch.zeros(m.n_params, device=x.device, dtype=torch.float32)
             ws = torch.empty(ops.hashgrid_bwd_binned_workspace_bytes(n), device=x.device, dtype=torch.uint8)
             zero3, zero1 = torch.zeros(n, 3, device=x.device), torch.zeros(n, device=x.device)
@@ -101,8 +104,7 @@ class _HashGridFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             g_params = torch.zeros(m.n_params, device=x.device, dtype=torch.float32)
             g = g_out.detach().contiguous().float()
-            ws = torch.empty(ops.hashgrid_bwd_binned_workspace_bytes(n), device=x.device, dtype=torch.uint8)
-            ops.hashgrid_bwd_binned(m.grid, g_params, g, ws, x_unit=x.detach().contiguous().float(), n=n, layout=0)
+            ops.hashgrid_bwd_auto(m.grid, g_params, g, x_unit=x.detach().contiguous().float(), n=n, layout=0)
         return g_x, g_params, None
 
 

@@ -134,8 +134,9 @@ class FusedField:
     activations saved in the kernels' fragment layout, backward (data), weight gradients.  mode 1 = bf16 operands / bf16
     saved copies, 6 = three-piece split (fp32 round-off) / fp32 saved copies."""
 
-    def __init__(self, fld: VanillaField, mode: int, n_splits: int = 256):
+    def __init__(self, fld: VanillaField, mode: int, n_splits: int = 256, act: int = 0):
         self.field, self.mode, self.n_splits = fld, mode, n_splits
+        self.act = int(act)                         # the renderer's activation code: the fused kernels take 0 only and refuse the rest
         self.image = torch.empty(int(_lib.load().ren_vanilla_image_bytes(mode)), device=fld.flat.device, dtype=torch.uint8)
         self._ws = None
 
@@ -150,7 +151,7 @@ class FusedField:
     def forward(self, B, full: bool):
         """B: _Buffers (enc / view / sel filled by the encoder) -> B.sigma, B.rgb4 (full), B.saved (when allocated)"""
         check(_lib.load().ren_vanilla_fwd(_ptr(B.enc), 64, _ptr(B.view) if full else None, 32, _ptr(B.sel, torch.uint8),
-                                          _ptr(self.field.eff), self.field.C, _ptr(self.image, torch.uint8), self.mode, B.n,
+                                          _ptr(self.field.eff), self.field.C, self.act, _ptr(self.image, torch.uint8), self.mode, B.n,
                                           _ptr(B.saved, torch.uint8) if (full and B.saved is not None) else None, _ptr(B.sigma),
                                           _ptr(B.rgb4) if full else None, _stream()), "ren_vanilla_fwd")
 
@@ -165,7 +166,7 @@ class FusedField:
     def backward(self, dz_rgb, dz_sig, B, dz, s0: int = 0, m: Optional[int] = None):
         """backward (data) of the samples s0 .. s0 + m of the pass saved in B (default: all); dz: new_saved(m)"""
         m, off, stride = self._range(B, s0, m)
-        check(_lib.load().ren_vanilla_bwd(_ptr(dz_rgb[s0:]), _ptr(dz_sig[s0:]), _ptr(self.image, torch.uint8), self.mode, m,
+        check(_lib.load().ren_vanilla_bwd(_ptr(dz_rgb[s0:]), _ptr(dz_sig[s0:]), _ptr(self.image, torch.uint8), self.mode, self.act, m,
                                           B.saved.data_ptr() + off, stride, _ptr(dz, torch.uint8), _stream()), "ren_vanilla_bwd")
 
     def backward_weight(self, dz_rgb, dz_sig, B, dz, s0: int = 0, m: Optional[int] = None):
@@ -295,7 +296,7 @@ class VanillaRenderer(Renderer):
             return None
         ff = self._fused_fields.get(mode)
         if ff is None:
-            ff = self._fused_fields[mode] = FusedField(self.field, mode, self.n_splits)
+            ff = self._fused_fields[mode] = FusedField(self.field, mode, self.n_splits, act=self._act_code)
         ff.prep()
         return ff
 
@@ -398,13 +399,12 @@ class VanillaRenderer(Renderer):
         return rgb, sigma, dict(buffers=B if save else None)
 
     def _field_backward(self, ctx, d_rgb, d_sig, final: bool = False):
-        self._apply_acts()                          # (the output-head kernels read the density / radiance kinds)
         B, n, C = ctx["buffers"], ctx["pk"].n, self.field.C
         dev = d_rgb.device
         z = lambda ld: torch.empty(B.n_pad, ld, device=dev, dtype=torch.float32)
         dz_rgb, dz_sig = z(32), z(32)
         check(_lib.load().ren_vanilla_heads_bwd(_ptr(d_rgb.contiguous()), _ptr(ctx["rgb"]), _ptr(d_sig.contiguous()),
-                                                _ptr(ctx["sigma"]), n, C, _ptr(dz_rgb), _ptr(dz_sig), _stream()),
+                                                _ptr(ctx["sigma"]), n, C, self._act_code, _ptr(dz_rgb), _ptr(dz_sig), _stream()),
               "ren_vanilla_heads_bwd")
         if B.fused is not None:
             # in ranges of bwd_chunk samples: the pre-activation gradients (as large as the saved activations) only ever
@@ -546,7 +546,7 @@ class VanillaRenderer(Renderer):
             self._act_fwd(B.r, WIDTH_COND, zrd, self.act_beta, rd, WIDTH_COND, WIDTH_COND, B.n_pad)
         self._lin(rd, WIDTH_COND, "mlp.rgb_layer.output_layer", zod, 4, n)
         rgbd, sigmad = torch.empty(n, C, device=dev), torch.empty(n, device=dev)
-        check(lib.ren_vanilla_heads_jvp(_ptr(rgb), _ptr(sigma), _ptr(zod), _ptr(zodd), _ptr(s4d), _ptr(s4dd), n, C, _ptr(rgbd),
+        check(lib.ren_vanilla_heads_jvp(_ptr(rgb), _ptr(sigma), _ptr(zod), _ptr(zodd), _ptr(s4d), _ptr(s4dd), n, C, self._act_code, _ptr(rgbd),
                                         _ptr(rgbdd), _ptr(sigmad), _ptr(sigmadd), _stream()), "ren_vanilla_heads_jvp")
         if second:
             return rgb, rgbd, rgbdd, sigma, sigmad, sigmadd
@@ -560,7 +560,7 @@ class VanillaRenderer(Renderer):
         dz_rgb, dzd_rgb, dz_sig, dzd_sig = z(32), z(32), z(32), z(32)
         check(_lib.load().ren_vanilla_heads_bwd_jvp(_ptr(d_rgb.contiguous()), _ptr(d_rgbd.contiguous()), _ptr(d_sig.contiguous()),
                                                     _ptr(d_sigd.contiguous()), _ptr(rgb), _ptr(sigma), _ptr(T["zod"]), _ptr(T["zsd"]),
-                                                    n, C, _ptr(dz_rgb), _ptr(dzd_rgb), _ptr(dz_sig), _ptr(dzd_sig), _stream()),
+                                                    n, C, self._act_code, _ptr(dz_rgb), _ptr(dzd_rgb), _ptr(dz_sig), _ptr(dzd_sig), _stream()),
               "ren_vanilla_heads_bwd_jvp")
         h7, h7d = B.h[DEPTH - 1], T["yd"][DEPTH - 1]
 
@@ -595,7 +595,6 @@ class VanillaRenderer(Renderer):
 
     def query_density(self, x_world: torch.Tensor) -> torch.Tensor:
         """VanillaNeRFRadianceField.query_density (mlp.py:343-347) for arbitrary world points."""
-        self._apply_acts()
         n = x_world.shape[0]
         chunk = 1 << 21                                    # an occupancy refresh queries up to 256^3 cells: 8.7 KB of
         tr = self._fused()
@@ -610,7 +609,6 @@ class VanillaRenderer(Renderer):
 
     def query(self, x_world: torch.Tensor, dirs: torch.Tensor):
         """field(x, d) -> (rgb (n, C), sigma (n,), buffers) for free-standing points (mlp.py:349-358)."""
-        self._apply_acts()
         n = x_world.shape[0]
         B = _Buffers(n, x_world.device, self.field.C, full=True, backward=False, fused=self._fused(), save=True)
         self._encode(B, True, x_world=x_world.contiguous(), dirs=dirs.contiguous())

@@ -15,16 +15,6 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-@pytest.fixture(autouse=True)
-def _default_activation_set(request):
-    """The activation set is process-wide kernel configuration (REN_KNOB_ACTIVATIONS) that a Renderer selects before its
-    own launches and leaves selected: tests that call the ops directly start from the shipped set, whatever ran before."""
-    if request.node.get_closest_marker("gpu") is not None:
-        from robust_e_nerf_amd import ops
-        ops.set_activations(0)
-    yield
-
-
 def load_golden(name):
     z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
     return {k: z[k] for k in z.files}

@@ -51,7 +51,7 @@ def test_shipped_library_corresponds_to_the_sources(lib, tmp_path):
 
 
 def test_abi_version_and_build_info(lib):
-    assert lib.ren_abi_version() == 23
+    assert lib.ren_abi_version() == 24
     assert b"gfx950" in lib.ren_build_info()
 
 
@@ -62,6 +62,16 @@ def test_argument_validation_without_gpu(lib):
     assert lib.ren_mlp_bwd_workspace_floats(2) == -1
     assert lib.ren_mlp_bwd_workspace_floats(1) > 0
     assert lib.ren_column_sum(None, 1, 1, None, None, None) == _lib.REN_ERR_BAD_ARG
+    # ABI 24: model configuration is an ARGUMENT (`activations`, `grid_cus`), not process-wide state: the knob table holds
+    # verification / tuning switches only, and the header's "no mutable global state" names no model setting
+    from robust_e_nerf_amd import ops
+    assert sorted(ops.KNOBS.values()) == list(range(6)) and "activations" not in ops.KNOBS and "mlp_bwd_cus" not in ops.KNOBS
+    assert lib.ren_set_knob(6, 1) == _lib.REN_ERR_BAD_ARG and lib.ren_get_knob(7) == _lib.REN_ERR_BAD_ARG
+    hdr = open(os.path.join(REPO, "include", "ren_amd.h")).read()
+    assert "REN_KNOB_ACTIVATIONS" not in hdr.split("enum { REN_KNOB_HGB_NO_PAIRS")[1].split("};")[0]
+    for name, (_, argtypes) in _lib.SIGNATURES.items():                  # every fused-MLP entry point carries the code
+        if name.startswith("ren_mlp_") and ("_fwd" in name or "_bwd" in name) and "workspace" not in name:
+            assert argtypes[1] is ctypes.c_int32 and argtypes[2] is ctypes.c_int32, name
     with pytest.raises(ValueError):
         _lib.check(_lib.REN_ERR_BAD_ARG, "x")
     with pytest.raises(NotImplementedError):

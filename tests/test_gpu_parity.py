@@ -241,7 +241,7 @@ def test_hashgrid_bwd_binned_sampled_count_vs_atomics(amd):
 
 
 # ------------------------------------------------------------------------------------------ field (hash + MLPs)
-def _field_on_gpu(ops, g, table_dev, aabb, ct, x, d, C=1):
+def _field_on_gpu(ops, g, table_dev, aabb, ct, x, d, C=1, act=0):
     grid, n_table = ops.make_grid_desc()
     scene = ops.make_scene_desc(aabb, ct)
     from robust_e_nerf_amd.engine import contract_points
@@ -251,7 +251,7 @@ def _field_on_gpu(ops, g, table_dev, aabb, ct, x, d, C=1):
     n = x.shape[0]
     xu = contract_points(dev(x), aabb, ct)
     feat = ops.hashgrid_fwd(grid, table_dev, x_unit=xu, n=n, layout=1)
-    rgb, sigma, base = ops.mlp_fwd(mlp, C, feat, scene, x_world=dev(x), dirs=dev(d), n=n, save_base=True)
+    rgb, sigma, base = ops.mlp_fwd(mlp, C, feat, scene, x_world=dev(x), dirs=dev(d), n=n, save_base=True, act=act)
     return grid, scene, mlp, xu, feat, rgb, sigma, base
 
 
@@ -309,30 +309,79 @@ def test_field_activation_alternatives_vs_reference_golden(amd, tag, full_table_
     n = x.shape[0]
     code = ops.activation_code(acts["base_hidden"], acts["density"], acts["head_hidden"], acts["radiance"])
     assert code != 0
-    with ops.knob("activations", code):
-        grid, scene, mlp, xu, feat, rgb, sigma, base = _field_on_gpu(ops, g, td, aabb, 0, x, d)
-        assert rel_err(rgb.cpu(), g["rgb"]) < 1e-4 and rel_err(sigma.cpu()[:, None], g["sigma"]) < 1e-4
-        assert elem_err(rgb.cpu(), g["rgb"]) < 5e-4 and elem_err(sigma.cpu()[:, None], g["sigma"]) < 5e-4
-        _, sig2, _ = ops.mlp_fwd(mlp, 1, feat, scene, x_world=dev(x), n=n, density_only=True)
-        assert torch.equal(sig2, sigma)
-        gm = torch.zeros_like(mlp)
-        ws = torch.empty(ops.mlp_bwd_workspace_floats(1), device=DEV)
-        dfeat = ops.mlp_bwd(mlp, 1, feat, base, scene, x_world=dev(x), dirs=dev(d), n=n, rgb=rgb,
-                            d_rgb=dev(g["g_rgb"]), d_sigma=dev(g["g_sigma"]).reshape(-1).contiguous(),
-                            grad_mlp_params=gm, workspace=ws)
-        for k, (off, shape) in ops.mlp_slices(1).items():
-            got = gm[off: off + math.prod(shape)].view(shape).cpu()
-            assert rel_err(got, g["g." + k]) < 1e-3, k
-        gt = torch.zeros_like(td)
-        ops.hashgrid_bwd(grid, gt, dfeat, x_unit=xu, n=n, layout=1)
-        idx = t(g["g_table_idx"])
-        assert rel_err(gt.cpu()[idx], g["g_table_val"]) < 1e-3
-        assert abs(float(gt.double().abs().sum()) - float(g["g_table_abs"])) < 1e-3 * float(g["g_table_abs"])
-        with pytest.raises(NotImplementedError):                          # REN_ERR_UNSUPPORTED -> NotImplementedError
-            ops.mlp_fwd_x(mlp, 1, 6, feat, scene, x_world=dev(x), dirs=dev(d), n=n)
-    # and with the knob back at 0 the default activations are back
+    # the activation set is an ARGUMENT of every launch (ABI 24: `act=`), not process-wide state
+    grid, scene, mlp, xu, feat, rgb, sigma, base = _field_on_gpu(ops, g, td, aabb, 0, x, d, act=code)
+    assert rel_err(rgb.cpu(), g["rgb"]) < 1e-4 and rel_err(sigma.cpu()[:, None], g["sigma"]) < 1e-4
+    assert elem_err(rgb.cpu(), g["rgb"]) < 5e-4 and elem_err(sigma.cpu()[:, None], g["sigma"]) < 5e-4
+    _, sig2, _ = ops.mlp_fwd(mlp, 1, feat, scene, x_world=dev(x), n=n, density_only=True, act=code)
+    assert torch.equal(sig2, sigma)
+    gm = torch.zeros_like(mlp)
+    ws = torch.empty(ops.mlp_bwd_workspace_floats(1), device=DEV)
+    dfeat = ops.mlp_bwd(mlp, 1, feat, base, scene, x_world=dev(x), dirs=dev(d), n=n, rgb=rgb,
+                        d_rgb=dev(g["g_rgb"]), d_sigma=dev(g["g_sigma"]).reshape(-1).contiguous(),
+                        grad_mlp_params=gm, workspace=ws, act=code)
+    for k, (off, shape) in ops.mlp_slices(1).items():
+        got = gm[off: off + math.prod(shape)].view(shape).cpu()
+        assert rel_err(got, g["g." + k]) < 1e-3, k
+    gt = torch.zeros_like(td)
+    ops.hashgrid_bwd(grid, gt, dfeat, x_unit=xu, n=n, layout=1)
+    idx = t(g["g_table_idx"])
+    assert rel_err(gt.cpu()[idx], g["g_table_val"]) < 1e-3
+    assert abs(float(gt.double().abs().sum()) - float(g["g_table_abs"])) < 1e-3 * float(g["g_table_abs"])
+    with pytest.raises(NotImplementedError):                              # REN_ERR_UNSUPPORTED -> NotImplementedError
+        ops.mlp_fwd_x(mlp, 1, 6, feat, scene, x_world=dev(x), dirs=dev(d), n=n, act=code)
+    with pytest.raises(ValueError):                                       # REN_ERR_BAD_ARG: not a code
+        ops.mlp_fwd(mlp, 1, feat, scene, x_world=dev(x), dirs=dev(d), n=n, act=256)
+    # a call without the argument runs the shipped set, whatever ran before: nothing is left selected in the library
     rgb0, sigma0, _ = ops.mlp_fwd(mlp, 1, feat, scene, x_world=dev(x), dirs=dev(d), n=n, save_base=True)
     assert not torch.equal(rgb0, rgb)
+
+
+def test_renderers_with_different_activation_sets_interleave(amd, spec, full_table_cache):
+    """include/ren_amd.h: "no mutable global state".  Two renderers with different activation sets (one on the exact-f32
+    kernels with relu / sigmoid, one on the default bf16-matrix-core kernels with the shipped set) driven from two host
+    threads on two streams at the same time, many times: every result equals the renderer's own single-threaded result
+    bit for bit.  With the process-wide activation knob of ABI 23 the two raced."""
+    import threading
+    ops, engine = amd
+    g = load_golden("training_step_diff")
+    table = full_table_cache(g["table_seed"], g["table_scale"])
+    p = field_params_from(g, table)
+    gen = torch.Generator().manual_seed(5)
+    R = 4096
+    o = torch.tensor([0.0, 0.0, 3.5]) + 0.05 * torch.randn(R, 3, generator=gen)
+    d = torch.nn.functional.normalize(torch.tensor([0.0, 0.0, -1.0]) + 0.25 * torch.randn(R, 3, generator=gen), dim=-1)
+    o, d = dev(o.float()), dev(d.float())
+    jit = dev(torch.rand(R, generator=gen))
+    cfgs = [engine.RenderCfg(sampler="uniform", n_uniform=64),
+            engine.RenderCfg(sampler="uniform", n_uniform=64, base_hidden_activation="relu", head_hidden_activation="relu",
+                             density_activation="shifted_softplus", radiance_activation="sigmoid")]
+    rs = []
+    for c in cfgs:
+        fld = engine.NGPField(DEV)
+        fld.load(p)
+        rs.append(engine.Renderer(fld, c))
+    assert cfgs[1].mlp_kernels == "x" and rs[1].cfg.mlp_kernels == "f32"     # the caller's cfg object is not modified
+    ref = []
+    for r in rs:
+        colors, opac, _, _ = r.forward(o, d, jit, None, True, save=False)
+        ref.append((colors.clone(), opac.clone()))
+    torch.cuda.synchronize()
+    assert not torch.equal(ref[0][0], ref[1][0])
+    bad = [0, 0]
+
+    def work(i):
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            for _ in range(40):
+                colors, opac, _, _ = rs[i].forward(o, d, jit, None, True, save=False)
+                st.synchronize()
+                bad[i] += int(not (torch.equal(colors, ref[i][0]) and torch.equal(opac, ref[i][1])))
+    st0 = torch.cuda.current_stream()
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t_.start() for t_ in th]
+    [t_.join() for t_ in th]
+    assert bad == [0, 0], bad
 
 
 _STEP_ACTS = {"smooth": dict(base_hidden="softplus", density="softplus", head_hidden="softplus", radiance="sigmoid"),
@@ -477,13 +526,13 @@ def _mlp_x_vs_f64(amd, n, seed):
         return torch.empty(nb * 512, device=DEV), torch.empty(nb * 1024, device=DEV), torch.zeros_like(params)
     # exact-f32 MFMA kernels (csrc/ren_mlp.hip): the fp32 yardstick
     r0, b0 = outs(), bwd_outs()
-    assert lib.ren_mlp_fwd_save(P(params), C, 0, P(feat), ctypes.byref(scene), P(x), P(d), None, None, None, None, None, n,
+    assert lib.ren_mlp_fwd_save(P(params), C, 0, 0, P(feat), ctypes.byref(scene), P(x), P(d), None, None, None, None, None, n,
                                 P(r0[0]), P(r0[1]), P(r0[2]), P(r0[3]), st) == 0
     ws0 = torch.empty(int(lib.ren_mlp_bwd_workspace_floats(C)), device=DEV)
-    assert lib.ren_mlp_bwd_saved(P(params), C, 0, P(feat), P(r0[2]), P(r0[3]), ctypes.byref(scene), P(x), P(d), None, None, None,
+    assert lib.ren_mlp_bwd_saved(P(params), C, 0, 0, P(feat), P(r0[2]), P(r0[3]), ctypes.byref(scene), P(x), P(d), None, None, None,
                                  None, None, n, P(r0[0]), P(d_rgb), P(d_sig), P(b0[0]), P(b0[1]), P(b0[2]), P(ws0), st) == 0
     r = outs()
-    assert lib.ren_mlp_fwd_x(P(params), C, 6, P(feat), ctypes.byref(scene), P(x), P(d), None, None, None, None, None, n, 0,
+    assert lib.ren_mlp_fwd_x(P(params), C, 0, 6, P(feat), ctypes.byref(scene), P(x), P(d), None, None, None, None, None, n, 0,
                              P(r[0]), P(r[1]), P(r[2]), P(r[3]), st) == 0
     names = ("rgb", "sigma", "base_out", "activations")
     for k, (a, b) in enumerate(zip(r, r0)):
@@ -497,8 +546,8 @@ def _mlp_x_vs_f64(amd, n, seed):
     res = []
     for acts in (r[3], None):
         b = bwd_outs()
-        assert lib.ren_mlp_bwd_x(P(params), C, 6, P(feat), P(r[2]), P(acts), ctypes.byref(scene), P(x), P(d), None, None, None,
-                                 None, None, n, P(r[0]), P(d_rgb), P(d_sig), P(b[0]), P(b[1]), P(b[2]), P(ws), st) == 0
+        assert lib.ren_mlp_bwd_x(P(params), C, 0, 6, P(feat), P(r[2]), P(acts), ctypes.byref(scene), P(x), P(d), None, None, None,
+                                 None, None, n, P(r[0]), P(d_rgb), P(d_sig), P(b[0]), P(b[1]), P(b[2]), P(ws), 0, st) == 0
         torch.cuda.synchronize()
         e_db = rel_err(b[0], b0[0])
         e_df = rel_err(tcnn_api._to_rows(b[1], n).double(), ref[2])
@@ -1018,7 +1067,6 @@ def test_chunked_two_stream_backward_equals_single_launches(amd, spec, full_tabl
         colors, opac, depth, ctx = r.forward(o, d, jit, None, True)
         r.backward(ctx, g_col)
         torch.cuda.synchronize()
-        assert _lib_knob(ops, "mlp_bwd_cus") == 256                     # the per-chunk CU limit of the MLP kernels is restored
         out.append((fld.g_mlp.clone(), fld.g_table.clone()))
     assert rel_err(out[1][0], out[0][0]) < 1e-5 and rel_err(out[1][1], out[0][1]) < 1e-6
     # ---- the phased entry points by themselves
@@ -1041,11 +1089,6 @@ def test_chunked_two_stream_backward_equals_single_launches(amd, spec, full_tabl
         assert rel_err(ph, one) < 1e-6, rel_err(ph, one)
     with pytest.raises(ValueError):                                      # a range must start on a 32-sample block
         ops.hashgrid_bwd_binned_scatter(fld.grid, ph, dfeat, ws, first=7, m=64, **kw)
-
-
-def _lib_knob(ops, name):
-    from robust_e_nerf_amd import _lib
-    return _lib.load().ren_get_knob(ops.KNOBS[name])
 
 
 def test_chunked_two_stream_forward_equals_single_launch(amd, spec, full_table_cache):
@@ -1746,10 +1789,10 @@ def test_tangent_mlp_matrix_core_kernels_vs_f32_kernels(amd, spec, full_table_ca
         sig, sigd = torch.empty(n, device=DEV), torch.empty(n, device=DEV)
         base, based = torch.empty(nb * 512, device=DEV), torch.empty(nb * 512, device=DEV)
         if mode == 0:
-            rc = lib.ren_mlp_fwd_jvp(P(fld.mlp), 1, P(feat), P(featd), ctypes.byref(scene), P(o_), P(d_), P(dd_), P(ri), P(ts),
+            rc = lib.ren_mlp_fwd_jvp(P(fld.mlp), 1, 0, P(feat), P(featd), ctypes.byref(scene), P(o_), P(d_), P(dd_), P(ri), P(ts),
                                      P(te), n, P(rgb), P(rgbd), P(sig), P(sigd), P(base), P(based), st)
         else:
-            rc = lib.ren_mlp_fwd_jvp_x(P(fld.mlp), 1, mode, P(feat), P(featd), ctypes.byref(scene), P(o_), P(d_), P(dd_), P(ri),
+            rc = lib.ren_mlp_fwd_jvp_x(P(fld.mlp), 1, 0, mode, P(feat), P(featd), ctypes.byref(scene), P(o_), P(d_), P(dd_), P(ri),
                                        P(ts), P(te), n, P(rgb), P(rgbd), P(sig), P(sigd), P(base), P(based), st)
         assert rc == 0
         scratch = torch.empty(nb * 5120, device=DEV)
@@ -1757,12 +1800,12 @@ def test_tangent_mlp_matrix_core_kernels_vs_f32_kernels(amd, spec, full_table_ca
         gp = torch.zeros_like(fld.mlp)
         if mode == 0:
             ws = torch.empty(int(lib.ren_mlp_bwd_jvp_workspace_floats(1)), device=DEV)
-            rc = lib.ren_mlp_bwd_jvp(P(fld.mlp), 1, P(feat), P(featd), P(base), P(based), ctypes.byref(scene), P(o_), P(d_),
+            rc = lib.ren_mlp_bwd_jvp(P(fld.mlp), 1, 0, P(feat), P(featd), P(base), P(based), ctypes.byref(scene), P(o_), P(d_),
                                      P(dd_), P(ri), P(ts), P(te), n, P(rgb), P(g_rgb), P(g_rgbd), P(g_sig), P(g_sigd),
                                      P(scratch), P(dfeat), P(dfeatd), P(gp), P(ws), st)
         else:
             ws = torch.empty(int(lib.ren_mlp_bwd_jvp_x_workspace_floats(1)), device=DEV)
-            rc = lib.ren_mlp_bwd_jvp_x(P(fld.mlp), 1, mode, P(feat), P(featd), P(base), P(based), ctypes.byref(scene), P(o_),
+            rc = lib.ren_mlp_bwd_jvp_x(P(fld.mlp), 1, 0, mode, P(feat), P(featd), P(base), P(based), ctypes.byref(scene), P(o_),
                                        P(d_), P(dd_), P(ri), P(ts), P(te), n, P(rgb), P(g_rgb), P(g_rgbd), P(g_sig),
                                        P(g_sigd), P(scratch), P(dfeat), P(dfeatd), P(gp), P(ws), st)
         assert rc == 0
@@ -1810,7 +1853,7 @@ def test_bf16_mode_tangent_arithmetic_is_pinned(amd, spec, full_table_cache):
     rgb, rgbd = torch.empty(n, 1, device=DEV), torch.empty(n, 1, device=DEV)
     sig, sigd = torch.empty(n, device=DEV), torch.empty(n, device=DEV)
     base, based = torch.empty(nb * 512, device=DEV), torch.empty(nb * 512, device=DEV)
-    assert lib.ren_mlp_fwd_jvp_x(P(fld.mlp), 1, 1, P(dev(feat)), P(dev(featd)), ctypes.byref(scene), P(dev(o)), P(dev(d)), P(dev(dd)),
+    assert lib.ren_mlp_fwd_jvp_x(P(fld.mlp), 1, 0, 1, P(dev(feat)), P(dev(featd)), ctypes.byref(scene), P(dev(o)), P(dev(d)), P(dev(dd)),
                                  P(dev(ri)), P(dev(tsv)), P(dev(tsv + 0.01)), n, P(rgb), P(rgbd), P(sig), P(sigd), P(base), P(based),
                                  ops._stream()) == 0
     torch.cuda.synchronize()
@@ -2229,7 +2272,7 @@ def test_second_order_mlp_forward_matrix_core_kernel_vs_f32_kernel(amd, spec, fu
     def run(mode):
         outs = [torch.empty(n, 1, device=DEV) for _ in range(3)] + [torch.empty(n, device=DEV) for _ in range(3)]
         args = [P(feat), P(featd), P(featdd), ctypes.byref(scene)] + [P(v) for v in rays] + [P(ri), P(ts), P(te), n] + [P(v) for v in outs] + [st]
-        rc = lib.ren_mlp_fwd_jvp2(P(fld.mlp), 1, *args) if mode == 0 else lib.ren_mlp_fwd_jvp2_x(P(fld.mlp), 1, mode, *args)
+        rc = lib.ren_mlp_fwd_jvp2(P(fld.mlp), 1, 0, *args) if mode == 0 else lib.ren_mlp_fwd_jvp2_x(P(fld.mlp), 1, 0, mode, *args)
         assert rc == 0
         torch.cuda.synchronize()
         return [v.cpu() for v in outs]

@@ -46,14 +46,14 @@ for path in (sys.argv[1:] or [_lib.LIB_PATH]):
         fn.restype, fn.argtypes = _lib.SIGNATURES[name]
     rgb, sigma = torch.empty(n, C, device=dev), torch.empty(n, device=dev)
     base = torch.empty(nb * 512, device=dev)
-    fwd = lambda: lib.ren_mlp_fwd(P(params), C, P(feat), ctypes.byref(scene), P(x), P(d), None, None, None, None,
+    fwd = lambda: lib.ren_mlp_fwd(P(params), C, 0, P(feat), ctypes.byref(scene), P(x), P(d), None, None, None, None,
                                   None, n, 0, P(rgb), P(sigma), P(base), st)
     assert fwd() == 0
     tf = timeit(fwd)
     d_base, dfeat = torch.empty(nb * 512, device=dev), torch.empty(nb * 1024, device=dev)
     gp = torch.zeros_like(params)
     ws = torch.empty(int(lib.ren_mlp_bwd_workspace_floats(C)), device=dev)
-    bwd = lambda: lib.ren_mlp_bwd(P(params), C, P(feat), P(base), ctypes.byref(scene), P(x), P(d), None, None, None,
+    bwd = lambda: lib.ren_mlp_bwd(P(params), C, 0, P(feat), P(base), ctypes.byref(scene), P(x), P(d), None, None, None,
                                   None, None, n, P(rgb), P(d_rgb), P(d_sig), P(d_base), P(dfeat), P(gp), P(ws), st)
     assert bwd() == 0
     tb = timeit(bwd)

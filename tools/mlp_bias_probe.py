@@ -78,17 +78,17 @@ for label, mode in (("exact-f32 MFMA kernels", 0), ("x kernels (bf16 MFMA, 6 ter
     acts = torch.empty(int(lib.ren_mlp_act_save_floats(n)), device=dev)
     d_base, dfeat, gm = torch.empty(nb * 512, device=dev), torch.empty(nb * 1024, device=dev), torch.zeros_like(params)
     if mode == 0:
-        lib.ren_mlp_fwd_save(P(params), C, 0, P(feat), ctypes.byref(scene), P(x), P(d), None, None, None, None, None, n,
+        lib.ren_mlp_fwd_save(P(params), C, 0, 0, P(feat), ctypes.byref(scene), P(x), P(d), None, None, None, None, None, n,
                              P(rgb_k), P(sig_k), P(base_k), P(acts), st)
         ws = torch.empty(int(lib.ren_mlp_bwd_workspace_floats(C)), device=dev)
-        lib.ren_mlp_bwd_saved(P(params), C, 0, P(feat), P(base_k), P(acts), ctypes.byref(scene), P(x), P(d), None, None, None,
+        lib.ren_mlp_bwd_saved(P(params), C, 0, 0, P(feat), P(base_k), P(acts), ctypes.byref(scene), P(x), P(d), None, None, None,
                               None, None, n, P(rgb_k), P(d_rgb), P(d_sig), P(d_base), P(dfeat), P(gm), P(ws), st)
     else:
-        lib.ren_mlp_fwd_x(P(params), C, 6, P(feat), ctypes.byref(scene), P(x), P(d), None, None, None, None, None, n, 0,
+        lib.ren_mlp_fwd_x(P(params), C, 0, 6, P(feat), ctypes.byref(scene), P(x), P(d), None, None, None, None, None, n, 0,
                           P(rgb_k), P(sig_k), P(base_k), None, st)
         ws = torch.empty(int(lib.ren_mlp_bwd_x_workspace_floats(C)), device=dev)
-        lib.ren_mlp_bwd_x(P(params), C, 6, P(feat), P(base_k), None, ctypes.byref(scene), P(x), P(d), None, None, None,
-                          None, None, n, P(rgb_k), P(d_rgb), P(d_sig), P(d_base), P(dfeat), P(gm), P(ws), st)
+        lib.ren_mlp_bwd_x(P(params), C, 0, 6, P(feat), P(base_k), None, ctypes.byref(scene), P(x), P(d), None, None, None,
+                          None, None, n, P(rgb_k), P(d_rgb), P(d_sig), P(d_base), P(dfeat), P(gm), P(ws), 0, st)
     torch.cuda.synchronize()
     print("==", label)
     stats("forward rgb", rgb_k, rgb.detach())

@@ -26,20 +26,20 @@ def outs():
     return (torch.empty(n, C, device=dev), torch.empty(n, device=dev), torch.empty(nb * 512, device=dev),
             torch.empty(int(lib.ren_mlp_act_save_floats(n)), device=dev))
 r0 = outs()
-f32 = lambda: lib.ren_mlp_fwd_save(P(params), C, 0, P(feat), ctypes.byref(scene), P(x), P(d), None, None, None, None, None, n,
+f32 = lambda: lib.ren_mlp_fwd_save(P(params), C, 0, 0, P(feat), ctypes.byref(scene), P(x), P(d), None, None, None, None, None, n,
                                    P(r0[0]), P(r0[1]), P(r0[2]), P(r0[3]), st)
 assert f32() == 0
 print(f"f32 MFMA fwd_save      {timeit(f32):6.2f} ms")
 rel = lambda a, b: float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 for mode in (6, 1):
     r = outs()
-    fx = lambda: lib.ren_mlp_fwd_x(P(params), C, mode, P(feat), ctypes.byref(scene), P(x), P(d), None, None, None, None, None,
+    fx = lambda: lib.ren_mlp_fwd_x(P(params), C, 0, mode, P(feat), ctypes.byref(scene), P(x), P(d), None, None, None, None, None,
                                    n, 0, P(r[0]), P(r[1]), P(r[2]), P(r[3]), st)
     assert fx() == 0
     t = timeit(fx)
     print(f"bf16 MFMA mode {mode} fwd   {t:6.2f} ms   rel-to-f32: rgb %.2e sigma %.2e base %.2e acts %.2e" %
           tuple(rel(a, b) for a, b in zip(r, r0)))
-    fi = lambda: lib.ren_mlp_fwd_x(P(params), C, mode, P(feat), ctypes.byref(scene), P(x), P(d), None, None, None, None, None,
+    fi = lambda: lib.ren_mlp_fwd_x(P(params), C, 0, mode, P(feat), ctypes.byref(scene), P(x), P(d), None, None, None, None, None,
                                    n, 0, P(r[0]), P(r[1]), P(r[2]), None, st)
     print(f"   without activation save {timeit(fi):6.2f} ms")
 
@@ -49,7 +49,7 @@ def bwd_outs():
     return torch.empty(nb * 512, device=dev), torch.empty(nb * 1024, device=dev), torch.zeros_like(params)
 b0 = bwd_outs()
 ws0 = torch.empty(int(lib.ren_mlp_bwd_workspace_floats(C)), device=dev)
-fb = lambda: lib.ren_mlp_bwd_saved(P(params), C, 0, P(feat), P(r0[2]), P(r0[3]), ctypes.byref(scene), P(x), P(d), None, None,
+fb = lambda: lib.ren_mlp_bwd_saved(P(params), C, 0, 0, P(feat), P(r0[2]), P(r0[3]), ctypes.byref(scene), P(x), P(d), None, None,
                                    None, None, None, n, P(r0[0]), P(d_rgb), P(d_sig), P(b0[0]), P(b0[1]), P(b0[2]), P(ws0), st)
 assert fb() == 0
 tb = timeit(fb)
@@ -57,12 +57,12 @@ b0[2].zero_(); fb(); torch.cuda.synchronize()
 print(f"f32 MFMA bwd_saved     {tb:6.2f} ms")
 for mode in (6, 1):
     r = outs()
-    assert lib.ren_mlp_fwd_x(P(params), C, mode, P(feat), ctypes.byref(scene), P(x), P(d), None, None, None, None, None,
+    assert lib.ren_mlp_fwd_x(P(params), C, 0, mode, P(feat), ctypes.byref(scene), P(x), P(d), None, None, None, None, None,
                              n, 0, P(r[0]), P(r[1]), P(r[2]), P(r[3]), st) == 0
     b = bwd_outs()
     ws = torch.empty(int(lib.ren_mlp_bwd_x_workspace_floats(C)), device=dev)
-    fx = lambda: lib.ren_mlp_bwd_x(P(params), C, mode, P(feat), P(r[2]), P(r[3]), ctypes.byref(scene), P(x), P(d), None, None,
-                                   None, None, None, n, P(r[0]), P(d_rgb), P(d_sig), P(b[0]), P(b[1]), P(b[2]), P(ws), st)
+    fx = lambda: lib.ren_mlp_bwd_x(P(params), C, 0, mode, P(feat), P(r[2]), P(r[3]), ctypes.byref(scene), P(x), P(d), None, None,
+                                   None, None, None, n, P(r[0]), P(d_rgb), P(d_sig), P(b[0]), P(b[1]), P(b[2]), P(ws), 0, st)
     assert fx() == 0
     t = timeit(fx)
     b[2].zero_(); fx(); torch.cuda.synchronize()
@@ -75,8 +75,8 @@ for mode in (6, 1):
     print()
     # recompute variant (act_save = NULL): must equal the saved-activation backward bit for bit
     b2 = bwd_outs()
-    fr = lambda: lib.ren_mlp_bwd_x(P(params), C, mode, P(feat), P(r[2]), None, ctypes.byref(scene), P(x), P(d), None, None,
-                                   None, None, None, n, P(r[0]), P(d_rgb), P(d_sig), P(b2[0]), P(b2[1]), P(b2[2]), P(ws), st)
+    fr = lambda: lib.ren_mlp_bwd_x(P(params), C, 0, mode, P(feat), P(r[2]), None, ctypes.byref(scene), P(x), P(d), None, None,
+                                   None, None, None, n, P(r[0]), P(d_rgb), P(d_sig), P(b2[0]), P(b2[1]), P(b2[2]), P(ws), 0, st)
     assert fr() == 0
     t2 = timeit(fr)
     b2[2].zero_(); fr(); torch.cuda.synchronize()
