@@ -135,6 +135,21 @@ int ren_ray_march(const float *rays_o, const float *rays_d, const float *t_min,
 int ren_uniform(uint64_t seed, uint64_t offset, int64_t n, float *out, void *stream);
 int ren_exclusive_scan(const int32_t *counts, int64_t n, int64_t *offsets, int64_t *total,
                        int64_t *scratch1024 /* int64[1024] device scratch, may be NULL (slow path) */, void *stream);
+
+/* ---- device-side sample counts (ABI 24) ------------------------------------------------------------
+ * The reference reads the number of marched / visible samples back to the host in the middle of every render
+ * (external/utils.py:106-119, models/nerf.py:279-286) because it sizes the next tensors.  Entry points with an `n_dev`
+ * argument take instead: n = the CAPACITY of the per-sample arrays (it sizes the launch), n_dev = device address of the real
+ * count (int64); kernels work on min(n, *n_dev) samples.  n_dev == NULL: n is the count, as before.
+ * ren_count_guard: after ren_exclusive_scan left the total on the device, compare it with the capacity.  Fits: *n_out =
+ * total.  Does not fit: every counts[r] = 0 (the per-ray kernels write nothing: an empty render), *n_out = 0, stats[1] = 1.
+ * stats[0] = the total as found.  The host reads `stats` after it has enqueued the whole step and repeats an overflowed
+ * step with larger arrays (engine.py).  ren_frag_zero_tail: zero the lanes beyond the count in the last 32-sample block of
+ * a fragment-layout feature array (what the host-count path does before ren_compact_features). */
+int ren_count_guard(int32_t *counts, int64_t n_rays, const int64_t *total, int64_t capacity, int64_t *n_out,
+                    int64_t *stats, void *stream);
+int ren_frag_zero_tail(float *feat, int64_t capacity, const int64_t *n_dev, void *stream);
+
 /* nerfacc.render_visibility inside ray_marching (sigma_fn branch): per ray
  * T = excl. cumprod(1-alpha); keep = T >= early_stop_eps (& alpha >= alpha_thre if >0).
  * Writes keep[n] (uint8) and kept_counts[n_rays]. */
@@ -166,7 +181,7 @@ int ren_pack_info(const int32_t *ray_indices, int64_t n, int64_t n_rays, int64_t
 int ren_hashgrid_fwd(const ren_grid_desc *grid, const float *table, const float *x_unit,
                      const ren_scene_desc *scene, const float *rays_o, const float *rays_d,
                      const int32_t *ray_indices, const float *t_starts, const float *t_ends,
-                     int64_t n, int32_t layout, float *feat, void *stream);
+                     int64_t n, int32_t layout, float *feat, const int64_t *n_dev, void *stream);
 /* d(table) += scatter of dfeat (same layouts); atomics, non-deterministic order */
 int ren_hashgrid_bwd(const ren_grid_desc *grid, float *grad_table, const float *x_unit,
                      const ren_scene_desc *scene, const float *rays_o, const float *rays_d,
@@ -184,7 +199,7 @@ int ren_hashgrid_bwd_binned(const ren_grid_desc *grid, float *grad_table, const 
                             const ren_scene_desc *scene, const float *rays_o, const float *rays_d,
                             const int32_t *ray_indices, const float *t_starts, const float *t_ends,
                             int64_t n, int32_t layout, const float *dfeat, void *workspace,
-                            void *stream);
+                            const int64_t *n_dev, void *stream);
 
 /* ---- fused NGP MLPs --------------------------------------------------------------------
  * NGPradianceField.query_density / _query_rgb / forward (robust_e_nerf/external/ngp.py:230-280)
@@ -349,7 +364,7 @@ int ren_raygen_jvp(const float *Kinv, const float *px, const float *pos, const f
 int ren_hashgrid_fwd_jvp(const ren_grid_desc *grid, const float *table, const ren_scene_desc *scene,
                          const float *rays_o, const float *rays_d, const float *rays_do, const float *rays_dd,
                          const int32_t *ray_indices, const float *t_starts, const float *t_ends, int64_t n,
-                         float *feat, float *featd, void *stream);
+                         float *feat, float *featd, const int64_t *n_dev, void *stream);
 /* grad_table += w dfeat + wd dfeatd (per-update atomics) */
 int ren_hashgrid_bwd_jvp(const ren_grid_desc *grid, float *grad_table, const ren_scene_desc *scene,
                          const float *rays_o, const float *rays_d, const float *rays_do, const float *rays_dd,
@@ -369,7 +384,7 @@ int ren_hashgrid_bwd_binned_levels(const ren_grid_desc *grid, float *grad_table,
                                    const ren_scene_desc *scene, const float *rays_o, const float *rays_d,
                                    const int32_t *ray_indices, const float *t_starts, const float *t_ends, int64_t n,
                                    int32_t layout, const float *dfeat, const float *rays_do, const float *rays_dd,
-                                   const float *dfeatd, uint32_t level_mask, void *workspace, void *stream);
+                                   const float *dfeatd, uint32_t level_mask, void *workspace, const int64_t *n_dev, void *stream);
 /* The binned backward in phases: `begin` (clear, count, offsets -- needs the sample stream only), any number of `scatter`
  * calls over sample ranges [first, first + m) of the SAME stream (first on a 32-sample block; every call takes the whole
  * stream's n and pointers), and ONE `finish` (partition, accumulate, flush into grad_table).  Stream-ordered: begin before
@@ -411,7 +426,7 @@ int ren_mlp_fwd_jvp_x(const float *mlp_params, int32_t radiance_dim, int32_t act
                       const ren_scene_desc *scene, const float *rays_o, const float *rays_d, const float *rays_dd,
                       const int32_t *ray_indices, const float *t_starts, const float *t_ends, int64_t n,
                       float *rgb, float *rgbd, float *sigma, float *sigmad, float *base_out, float *base_outd,
-                      void *stream);
+                      const int64_t *n_dev, void *stream);
 int64_t ren_mlp_bwd_jvp_x_workspace_floats(int32_t radiance_dim);
 int ren_mlp_bwd_jvp_x(const float *mlp_params, int32_t radiance_dim, int32_t activations, int32_t mode, const float *feat, const float *featd,
                       const float *base_out, const float *base_outd, const ren_scene_desc *scene,
@@ -506,13 +521,13 @@ int ren_mlp_bwd_saved(const float *mlp_params, int32_t C, int32_t activations, i
 int ren_mlp_fwd_x(const float *mlp_params, int32_t C, int32_t activations, int32_t mode, const float *feat, const ren_scene_desc *scene,
                   const float *x_world, const float *dirs, const float *rays_o, const float *rays_d,
                   const int32_t *ray_indices, const float *t_starts, const float *t_ends, int64_t n,
-                  int32_t flags, float *rgb, float *sigma, float *base_out, float *act_save, void *stream);
+                  int32_t flags, float *rgb, float *sigma, float *base_out, float *act_save, const int64_t *n_dev, void *stream);
 int64_t ren_mlp_bwd_x_workspace_floats(int32_t C);
 int ren_mlp_bwd_x(const float *mlp_params, int32_t C, int32_t activations, int32_t mode, const float *feat, const float *base_out,
                   const float *act_save, const ren_scene_desc *scene, const float *x_world, const float *dirs,
                   const float *rays_o, const float *rays_d, const int32_t *ray_indices, const float *t_starts,
                   const float *t_ends, int64_t n, const float *rgb, const float *d_rgb, const float *d_sigma,
-                  float *d_base, float *dfeat, float *grad_mlp_params, float *workspace, int32_t grid_cus, void *stream);
+                  float *d_base, float *dfeat, float *grad_mlp_params, float *workspace, int32_t grid_cus, const int64_t *n_dev, void *stream);
 /* grid_cus: persistent workgroups (= CUs) the two backward kernels occupy, 1 .. 255; 0 (or >= 256) = all 256.  The chunked
  * backward of engine.py lowers it while a scatter runs on the second stream (until ABI 23: knob REN_KNOB_MLP_BWD_CUS). */
 

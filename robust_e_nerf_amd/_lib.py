@@ -46,13 +46,15 @@ SIGNATURES = {
     "ren_compact_features": (c_int, [P, P, P, c_int64, P, P, P, P]),
     "ren_uniform": (c_int, [ctypes.c_uint64, ctypes.c_uint64, c_int64, P, P]),
     "ren_exclusive_scan": (c_int, [P, c_int64, P, P, P, P]),
+    "ren_count_guard": (c_int, [P, c_int64, P, c_int64, P, P, P]),
+    "ren_frag_zero_tail": (c_int, [P, c_int64, P, P]),
     "ren_visibility": (c_int, [P, P, c_int64, P, P, P, c_float, c_float, P, P, P]),
     "ren_compact_samples": (c_int, [P, P, P, c_int64, P, P, P, P, P, P, P]),
     "ren_pack_info": (c_int, [P, c_int64, c_int64, P, P, P]),
-    "ren_hashgrid_fwd": (c_int, [POINTER(GridDesc), P, P, POINTER(SceneDesc), P, P, P, P, P, c_int64, c_int32, P, P]),
+    "ren_hashgrid_fwd": (c_int, [POINTER(GridDesc), P, P, POINTER(SceneDesc), P, P, P, P, P, c_int64, c_int32, P, P, P]),
     "ren_hashgrid_bwd": (c_int, [POINTER(GridDesc), P, P, POINTER(SceneDesc), P, P, P, P, P, c_int64, c_int32, P, P]),
     "ren_hashgrid_bwd_binned_workspace_bytes": (c_int64, [c_int64]),
-    "ren_hashgrid_bwd_binned": (c_int, [POINTER(GridDesc), P, P, POINTER(SceneDesc), P, P, P, P, P, c_int64, c_int32, P, P, P]),
+    "ren_hashgrid_bwd_binned": (c_int, [POINTER(GridDesc), P, P, POINTER(SceneDesc), P, P, P, P, P, c_int64, c_int32, P, P, P, P]),
     "ren_hashgrid_bwd_binned_begin": (c_int, [POINTER(GridDesc), P, POINTER(SceneDesc), P, P, P, P, P, c_int64, c_int32, P, P]),
     "ren_hashgrid_bwd_binned_scatter": (c_int, [POINTER(GridDesc), P, P, POINTER(SceneDesc), P, P, P, P, P, c_int64, c_int32, P,
                                                 c_int64, c_int64, P, P]),
@@ -71,10 +73,10 @@ SIGNATURES = {
     "ren_event_prepare": (c_int, [P, P, P, P, P, P, P, c_int64, c_float, c_float, c_double, P, P, P, P, P, P, P, P, P]),
     "ren_event_param_grad": (c_int, [c_int32, c_int32, c_int32, P, P, P, P, P, P, P, c_int64, c_float, c_float, c_float,
                                      c_double, c_float, P, P, P]),
-    "ren_mlp_fwd_x": (c_int, [P, c_int32, c_int32, c_int32, P, POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, c_int32, P, P, P, P, P]),
+    "ren_mlp_fwd_x": (c_int, [P, c_int32, c_int32, c_int32, P, POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, c_int32, P, P, P, P, P, P]),
     "ren_mlp_bwd_x_workspace_floats": (c_int64, [c_int32]),
     "ren_mlp_bwd_x": (c_int, [P, c_int32, c_int32, c_int32, P, P, P, POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, P, P, P, P, P,
-                              P, P, c_int32, P]),
+                              P, P, c_int32, P, P]),
     "ren_composite_fwd": (c_int, [P, P, c_int64, P, P, P, P, c_int32, P, P, P, P, P, P, P]),
     "ren_composite_bwd": (c_int, [P, P, c_int64, P, P, P, P, c_int32, P, P, P, P, P, P, P, P, P, P, P, P]),
     "ren_event_loss_fwd": (c_int, [P, P, P, P, c_int64, c_int32, P, P]),
@@ -92,16 +94,16 @@ SIGNATURES = {
     "ren_column_sum": (c_int, [P, c_int64, c_int32, P, P, P]),
     "ren_trajectory_jvp": (c_int, [P, c_int64, P, P, P, c_int64, P, P, P, P, P]),
     "ren_raygen_jvp": (c_int, [P, P, P, P, P, P, c_int64, P, P, P, P, P]),
-    "ren_hashgrid_fwd_jvp": (c_int, [POINTER(GridDesc), P, POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, P, P, P]),
+    "ren_hashgrid_fwd_jvp": (c_int, [POINTER(GridDesc), P, POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, P, P, P, P]),
     "ren_hashgrid_bwd_jvp": (c_int, [POINTER(GridDesc), P, POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, P, P, P]),
     "ren_hashgrid_bwd_binned_jvp": (c_int, [POINTER(GridDesc), P, POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, P, P, P, P]),
     "ren_hashgrid_bwd_binned_levels": (c_int, [POINTER(GridDesc), P, P, POINTER(SceneDesc), P, P, P, P, P, c_int64, c_int32, P,
-                                               P, P, P, c_uint32, P, P]),
+                                               P, P, P, c_uint32, P, P, P]),
     "ren_mlp_fwd_jvp": (c_int, [P, c_int32, c_int32, P, P, POINTER(SceneDesc), P, P, P, P, P, P, c_int64, P, P, P, P, P, P, P]),
     "ren_mlp_bwd_jvp_workspace_floats": (c_int64, [c_int32]),
     "ren_mlp_bwd_jvp": (c_int, [P, c_int32, c_int32, P, P, P, P, POINTER(SceneDesc), P, P, P, P, P, P, c_int64, P, P, P, P, P,
                                 P, P, P, P, P, P]),
-    "ren_mlp_fwd_jvp_x": (c_int, [P, c_int32, c_int32, c_int32, P, P, POINTER(SceneDesc), P, P, P, P, P, P, c_int64, P, P, P, P, P, P, P]),
+    "ren_mlp_fwd_jvp_x": (c_int, [P, c_int32, c_int32, c_int32, P, P, POINTER(SceneDesc), P, P, P, P, P, P, c_int64, P, P, P, P, P, P, P, P]),
     "ren_mlp_bwd_jvp_x_workspace_floats": (c_int64, [c_int32]),
     "ren_mlp_bwd_jvp_x": (c_int, [P, c_int32, c_int32, c_int32, P, P, P, P, POINTER(SceneDesc), P, P, P, P, P, P, c_int64, P, P, P, P, P,
                                   P, P, P, P, P, P]),

@@ -126,7 +126,45 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return OUT
 
 
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+
+def audit_packed_op_sel(path: str = OUT):
+    """ISA audit of a built library: every `v_pk_*_f32` whose op_sel selects a source's HIGH half for the LOW result lane.
+
+    tools/pkf32_hazard_repro.hip (round 5; no torch, no library): on MI355X such an instruction returns a wrong result for an
+    aligned group of 16 lanes in 117 of 600 launches of a small kernel that runs beside waves of a bf16-MFMA kernel, and in
+    0 of 600 launches for packed instructions without op_sel (plain, op_sel_hi-only, neg-only, SGPR sources) or with no
+    matrix-core kernel on the chip.  The shipped library must not contain one: returns [(kernel symbol, instruction), ...]."""
+    import re
+    import shutil
+    import tempfile
+    hits = []
+    with tempfile.TemporaryDirectory() as tmp:
+        lib = os.path.join(tmp, "lib.so")
+        shutil.copy(path, lib)
+        subprocess.run([OBJDUMP, "--offloading", lib], capture_output=True, cwd=tmp)       # extracts the bundles next to the copy
+        for f in sorted(os.listdir(tmp)):
+            if "gfx950" not in f:
+                continue
+            dis = subprocess.run([OBJDUMP, "-d", os.path.join(tmp, f)], capture_output=True, text=True).stdout
+            sym = "?"
+            for line in dis.splitlines():
+                m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+                if m:
+                    sym = m.group(1)
+                elif re.search(r"\bv_pk_(fma|mul|add)_f32\b.*\bop_sel:", line):
+                    hits.append((sym, " ".join(line.split("//")[0].split())))
+    return hits
+
+
 if __name__ == "__main__":
+    if "--audit" in sys.argv:
+        hits = audit_packed_op_sel()
+        for sym, ins in hits:
+            print(sym, "|", ins)
+        print(f"{len(hits)} packed-FP32 instruction(s) with op_sel in {OUT}")
+        sys.exit(1 if hits else 0)
     if "--check" in sys.argv:
         ok = is_current()
         print("libren_amd.so is", "current" if ok else "STALE (or missing)")

@@ -102,6 +102,16 @@ __device__ __forceinline__ void ren_sample_pos(const float *__restrict__ rays_o,
     z = o[2] + d[2] * tm;
 }
 
+// Device-side sample count (ABI 24, `n_dev` arguments): the host passes the CAPACITY of the per-sample arrays as `n` and, in
+// `n_dev`, where the device keeps the number of samples that exist (written by the sampler's scan / ren_count_guard): the
+// kernels of a render are enqueued without the host reading that number back (models/nerf.py:279-286 and external/utils.py:
+// 106-119 read it).  NULL = `n` is the count, as before.
+__device__ __forceinline__ int64_t ren_eff_n(int64_t n, const int64_t *__restrict__ n_dev) {
+    if (!n_dev) return n;
+    const int64_t m = *n_dev;
+    return m < n ? (m < 0 ? 0 : m) : n;
+}
+
 __device__ __forceinline__ float ren_wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

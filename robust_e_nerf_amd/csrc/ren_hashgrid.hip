@@ -36,10 +36,15 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(
     GridDev g, const float2 *__restrict__ table, const float *__restrict__ x_unit, ren_scene_dev sc,
     const float *__restrict__ rays_o, const float *__restrict__ rays_d,
     const int32_t *__restrict__ ray_indices, const float *__restrict__ t_starts,
-    const float *__restrict__ t_ends, int64_t n, int64_t n_pad, float *__restrict__ feat, int xcd_affine) {
+    const float *__restrict__ t_ends, int64_t n, int64_t n_pad, float *__restrict__ feat, int xcd_affine,
+    const int64_t *__restrict__ n_dev) {
     int lvl; int64_t chunk;
-    if (!block_to_work(xcd_affine, g.n_levels, (n_pad + 255) / 256, lvl, chunk)) return;
+    if (!block_to_work(xcd_affine, g.n_levels, (n_pad + 255) / 256, lvl, chunk)) return;      // (the launch geometry is the capacity's)
     const int64_t i = chunk * blockDim.x + threadIdx.x;
+    if (n_dev) {                                             // device-side count: the fragment padding follows the real count
+        n = ren_eff_n(n, n_dev);
+        if (LAYOUT == 1) { const int64_t p = ((n + 31) >> 5) << 5; n_pad = p < n_pad ? p : n_pad; } else n_pad = n;
+    }
     if (i >= n_pad) return;
     float f0 = 0.f, f1 = 0.f;
     if (i < n) {
@@ -144,7 +149,7 @@ int hg_variant() { return ren_knob(REN_KNOB_HG_VARIANT); }
 extern "C" int ren_hashgrid_fwd(const ren_grid_desc *grid, const float *table, const float *x_unit,
                                 const ren_scene_desc *scene, const float *rays_o, const float *rays_d,
                                 const int32_t *ray_indices, const float *t_starts, const float *t_ends,
-                                int64_t n, int32_t layout, float *feat, void *stream) {
+                                int64_t n, int32_t layout, float *feat, const int64_t *n_dev, void *stream) {
     GridDev g;
     int rc = make_grid(grid, g);
     if (rc) return rc;
@@ -164,7 +169,7 @@ extern "C" int ren_hashgrid_fwd(const ren_grid_desc *grid, const float *table, c
     const float2 *tab = reinterpret_cast<const float2 *>(table);
 #define LAUNCH(L, R)                                                                                     \
     hipLaunchKernelGGL((hashgrid_fwd_kernel<L, R>), grd, blk, 0, (hipStream_t)stream, g, tab, x_unit, sc, \
-                       rays_o, rays_d, ray_indices, t_starts, t_ends, n, n_pad, feat, affine)
+                       rays_o, rays_d, ray_indices, t_starts, t_ends, n, n_pad, feat, affine, n_dev)
     if (layout == 0) { if (from_rays) LAUNCH(0, true); else LAUNCH(0, false); }
     else             { if (from_rays) LAUNCH(1, true); else LAUNCH(1, false); }
 #undef LAUNCH

@@ -130,6 +130,7 @@ struct SampleArgs {
     const float *t_starts, *t_ends;
     int64_t n;
     TanSrc tan;
+    const int64_t *n_dev;                            // device-side sample count (ren_eff_n), or NULL
 };
 
 // unit-cube position (and its time derivative) of sample i: computed ONCE per thread, every level of
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(CNT_THREADS) void bin_count_kernel(GridDev g, BinTa
 #pragma unroll 1
     for (int k = 0; k < CNT_SAMPLES / CNT_THREADS; ++k) {
         const int64_t i = (int64_t)blockIdx.x * bt.cnt_stride * CNT_SAMPLES + k * CNT_THREADS + threadIdx.x;
-        const bool inb = i < a.n;
+        const bool inb = i < ren_eff_n(a.n, a.n_dev);
         float u[3] = {0.f, 0.f, 0.f}, ud[3];
         if (inb) unit_pos<TAN>(a, i, u, ud);
 #pragma unroll 1
@@ -413,7 +414,7 @@ __global__ __launch_bounds__(SC_THREADS, KIND == 1 ? REN_SC_WAVES_PAIR : REN_SC_
     const int64_t chunk = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63;
     const int64_t i = chunk * SC_THREADS + tid;
-    const bool inb = i < a.n;
+    const bool inb = i < ren_eff_n(a.n, a.n_dev);
     float u[3] = {0.f, 0.f, 0.f}, ud[3] = {0.f, 0.f, 0.f};
     if (inb) unit_pos<TAN>(a, i, u, ud);
     constexpr bool pairs = KIND == 1;
@@ -729,7 +730,7 @@ static int binned_impl(const ren_grid_desc *grid, float *grad_table, const float
                        const int32_t *ray_indices, const float *t_starts, const float *t_ends,
                        int64_t n, int32_t layout, const float *dfeat, void *workspace,
                        void *stream, TanSrc tan, uint32_t level_mask = 0xFFFFFFFFu, int phases = 7,
-                       int64_t first = 0, int64_t m = -1) {
+                       int64_t first = 0, int64_t m = -1, const int64_t *n_dev = nullptr) {
     GridDev g;
     int rc = make_grid(grid, g);
     if (rc) return rc;
@@ -787,6 +788,8 @@ static int binned_impl(const ren_grid_desc *grid, float *grad_table, const float
     SampleArgs a;
     a.layout = layout; a.dfeat = dfeat; a.x_unit = x_unit; a.sc = sc; a.rays_o = rays_o; a.rays_d = rays_d;
     a.ray_indices = ray_indices; a.t_starts = t_starts; a.t_ends = t_ends; a.n = n; a.tan = tan;
+    a.n_dev = n_dev;                                  // (one-shot calls only: a phased call's ranges are host numbers)
+    if (n_dev && phases != 7) return REN_ERR_BAD_ARG;
     bt.halve = ren_knob(REN_KNOB_HGB_HALVE_REGIONS) == 1;
     bt.sub_by_xcd = ren_knob(REN_KNOB_HGB_SUBREGION) != 0;
     const int64_t cnt_blocks = (n + CNT_SAMPLES - 1) / CNT_SAMPLES;
@@ -836,9 +839,9 @@ extern "C" int ren_hashgrid_bwd_binned(const ren_grid_desc *grid, float *grad_ta
                                        const ren_scene_desc *scene, const float *rays_o, const float *rays_d,
                                        const int32_t *ray_indices, const float *t_starts, const float *t_ends,
                                        int64_t n, int32_t layout, const float *dfeat, void *workspace,
-                                       void *stream) {
+                                       const int64_t *n_dev, void *stream) {
     return binned_impl(grid, grad_table, x_unit, scene, rays_o, rays_d, ray_indices, t_starts, t_ends, n, layout,
-                       dfeat, workspace, stream, TanSrc{nullptr, nullptr, nullptr});
+                       dfeat, workspace, stream, TanSrc{nullptr, nullptr, nullptr}, 0xFFFFFFFFu, 7, 0, -1, n_dev);
 }
 
 extern "C" int ren_hashgrid_bwd_binned_jvp(const ren_grid_desc *grid, float *grad_table,
@@ -858,10 +861,10 @@ extern "C" int ren_hashgrid_bwd_binned_levels(const ren_grid_desc *grid, float *
                                               const int32_t *ray_indices, const float *t_starts, const float *t_ends,
                                               int64_t n, int32_t layout, const float *dfeat, const float *rays_do,
                                               const float *rays_dd, const float *dfeatd, uint32_t level_mask,
-                                              void *workspace, void *stream) {
+                                              void *workspace, const int64_t *n_dev, void *stream) {
     if ((rays_do || rays_dd || dfeatd) && (!rays_do || !rays_dd || !dfeatd || layout != 1 || x_unit)) return REN_ERR_BAD_ARG;
     return binned_impl(grid, grad_table, x_unit, scene, rays_o, rays_d, ray_indices, t_starts, t_ends, n, layout, dfeat,
-                       workspace, stream, TanSrc{rays_do, rays_dd, dfeatd}, level_mask);
+                       workspace, stream, TanSrc{rays_do, rays_dd, dfeatd}, level_mask, 7, 0, -1, n_dev);
 }
 
 // ---- the same call in phases, so that the scatter of one sample range can run beside whatever produces the next range's

@@ -116,9 +116,14 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_jvp_kernel(
     GridDev g, const float2 *__restrict__ table, ren_scene_dev sc, const float *__restrict__ rays_o,
     const float *__restrict__ rays_d, const float *__restrict__ rays_do, const float *__restrict__ rays_dd,
     const int32_t *__restrict__ ray_indices, const float *__restrict__ t_starts, const float *__restrict__ t_ends,
-    int64_t n, int64_t n_pad, float *__restrict__ feat, float *__restrict__ featd) {
+    int64_t n, int64_t n_pad, float *__restrict__ feat, float *__restrict__ featd, const int64_t *__restrict__ n_dev) {
     const int lvl = blockIdx.y;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n_dev) {
+        n = ren_eff_n(n, n_dev);
+        const int64_t p = ((n + 31) >> 5) << 5;
+        n_pad = p < n_pad ? p : n_pad;
+    }
     if (i >= n_pad) return;
     float f0 = 0.f, f1 = 0.f, g0 = 0.f, g1 = 0.f;
     if (i < n) {
@@ -403,7 +408,8 @@ extern "C" int ren_raygen_jvp(const float *Kinv, const float *px, const float *p
 extern "C" int ren_hashgrid_fwd_jvp(const ren_grid_desc *grid, const float *table, const ren_scene_desc *scene,
                                     const float *rays_o, const float *rays_d, const float *rays_do,
                                     const float *rays_dd, const int32_t *ray_indices, const float *t_starts,
-                                    const float *t_ends, int64_t n, float *feat, float *featd, void *stream) {
+                                    const float *t_ends, int64_t n, float *feat, float *featd, const int64_t *n_dev,
+                                    void *stream) {
     GridDev g;
     int rc = make_grid(grid, g);
     if (rc) return rc;
@@ -415,7 +421,7 @@ extern "C" int ren_hashgrid_fwd_jvp(const ren_grid_desc *grid, const float *tabl
     const int64_t n_pad = ((n + 31) / 32) * 32;
     hipLaunchKernelGGL(hashgrid_fwd_jvp_kernel, dim3(ren_blocks(n_pad, 256), g.n_levels), dim3(256), 0,
                        (hipStream_t)stream, g, reinterpret_cast<const float2 *>(table), ren_make_scene(scene), rays_o,
-                       rays_d, rays_do, rays_dd, ray_indices, t_starts, t_ends, n, n_pad, feat, featd);
+                       rays_d, rays_do, rays_dd, ray_indices, t_starts, t_ends, n, n_pad, feat, featd, n_dev);
     REN_CHECK_LAUNCH();
 }
 

@@ -165,6 +165,11 @@ __device__ __forceinline__ void sh4_select(float x, float y, float z, int hi, fl
     s[13] = 0.45704579946446572f * x * (1.0f - 5.0f * z2);
     s[14] = 1.4453057213202769f * z * (x2 - y2);
     s[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
+    // every component stays a scalar value: the SLP vectoriser otherwise packs pairs of them into v_pk_*_f32 with op_sel
+    // (a source's HIGH half feeding the LOW result lane) -- the one instruction form that returns wrong results for an aligned
+    // group of 16 lanes beside bf16-MFMA waves on MI355X (tools/pkf32_hazard_repro.hip; `build.py --audit` keeps it out)
+#pragma unroll
+    for (int k = 1; k < 16; ++k) asm volatile("" : "+v"(s[k]));
 #pragma unroll
     for (int j = 0; j < 8; ++j) out[j] = hi ? s[2 * j + 1] : s[2 * j];
 }

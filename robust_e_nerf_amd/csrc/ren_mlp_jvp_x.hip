@@ -75,6 +75,7 @@ struct FwdJXArgs {
     ren_scene_dev sc;
     int64_t n;
     float *rgb, *rgbd, *sigma, *sigmad, *base_out, *base_outd;
+    const int64_t *n_dev;                                     // device-side sample count (ren_eff_n) or NULL
 };
 
 // LDS image: forward fragments of the four hidden/base layers + f32 tail (same as XL in ren_mlp_x.hip)
@@ -112,14 +113,14 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_jvp_x_kernel(FwdJXArgs a) {
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int hi = lane >> 5, sl = lane & 31;
-    const int64_t n_blk = (a.n + 31) >> 5;
+    const int64_t n_smp = ren_eff_n(a.n, a.n_dev), n_blk = (n_smp + 31) >> 5;
     for (int64_t blk = (int64_t)blockIdx.x * 4 + wave; blk < n_blk; blk += (int64_t)gridDim.x * 4) {
         int zo = 0;                                             // keep the (loop-invariant) LDS reads inside the loop
         asm volatile("" : "+v"(zo));
         const __bf16 *fr = frag + zo;
         const float *tl = tail + zo;
         const int64_t i = blk * 32 + sl;
-        const bool live = i < a.n;
+        const bool live = i < n_smp;
         // ---- hash features and their tangents -> two k-chunks each
         bf16x8 bx[2][3], bxd[2][3];
         {
@@ -810,7 +811,7 @@ extern "C" int ren_mlp_fwd_jvp_x(const float *mlp_params, int32_t C, int32_t act
                                  const ren_scene_desc *scene, const float *rays_o, const float *rays_d,
                                  const float *rays_dd, const int32_t *ray_indices, const float *t_starts,
                                  const float *t_ends, int64_t n, float *rgb, float *rgbd, float *sigma,
-                                 float *sigmad, float *base_out, float *base_outd, void *stream) {
+                                 float *sigmad, float *base_out, float *base_outd, const int64_t *n_dev, void *stream) {
     if (!mlp_params || !feat || !featd || !scene || !rays_o || !rays_d || !rays_dd || !ray_indices || !t_starts ||
         !t_ends || !rgb || !rgbd || !sigma || !sigmad || !base_out || !base_outd || n < 0)
         return REN_ERR_BAD_ARG;
@@ -819,6 +820,7 @@ extern "C" int ren_mlp_fwd_jvp_x(const float *mlp_params, int32_t C, int32_t act
     if (activations != 0) return REN_ERR_UNSUPPORTED;      // activation alternatives: exact-f32 kernels only
     if (n == 0) return REN_OK;
     FwdJXArgs a;
+    a.n_dev = n_dev;
     a.params = mlp_params; a.feat = feat; a.featd = featd;
     a.src = RaySrc{rays_o, rays_d, rays_dd, ray_indices, t_starts, t_ends};
     a.sc = ren_make_scene(scene);

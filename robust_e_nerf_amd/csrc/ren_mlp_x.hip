@@ -38,6 +38,7 @@ struct FwdXArgs {
     ren_scene_dev sc;
     int64_t n;
     float *rgb, *sigma, *base_out, *acts;
+    const int64_t *n_dev;                                     // device-side sample count (ren_eff_n) or NULL
 };
 
 constexpr int ACT_SAVE_FLOATS_X = 3 * 2 * 16 * 64;            // same layout as ren_mlp.hip's ACT_SAVE_FLOATS
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(64 * FWD_X_WAVES, REN_FWD_WAVES) void mlp_fwd_x_ker
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int hi = lane >> 5, sl = lane & 31;
-    const int64_t n_blk = (a.n + 31) >> 5;
+    const int64_t n_smp = ren_eff_n(a.n, a.n_dev), n_blk = (n_smp + 31) >> 5;
 
     for (int64_t blk = (int64_t)blockIdx.x * FWD_X_WAVES + wave; blk < n_blk; blk += (int64_t)gridDim.x * FWD_X_WAVES) {
         int zo = 0;                                             // keep the (loop-invariant) LDS reads inside the loop
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(64 * FWD_X_WAVES, REN_FWD_WAVES) void mlp_fwd_x_ker
         const __bf16 *fr = frag + zo;
         const float *tl = tail + zo;
         const int64_t i = blk * 32 + sl;
-        const bool live = i < a.n;
+        const bool live = i < n_smp;
         // ---- hash features -> two k-chunks
         bf16x8 bx[2][3];
         {
@@ -236,7 +237,7 @@ extern "C" int ren_mlp_fwd_x(const float *mlp_params, int32_t C, int32_t activat
                              const ren_scene_desc *scene, const float *x_world, const float *dirs,
                              const float *rays_o, const float *rays_d, const int32_t *ray_indices,
                              const float *t_starts, const float *t_ends, int64_t n, int32_t flags,
-                             float *rgb, float *sigma, float *base_out, float *act_save, void *stream) {
+                             float *rgb, float *sigma, float *base_out, float *act_save, const int64_t *n_dev, void *stream) {
     if (!mlp_params || !feat || !scene || !sigma || n < 0) return REN_ERR_BAD_ARG;
     if (C != 1 && C != 3) return REN_ERR_UNSUPPORTED;
     if (mode != 1 && mode != 6) return REN_ERR_UNSUPPORTED;
@@ -251,7 +252,7 @@ extern "C" int ren_mlp_fwd_x(const float *mlp_params, int32_t C, int32_t activat
     a.params = mlp_params; a.feat = feat;
     a.src = SampleSrc{x_world, dirs, rays_o, rays_d, x_world ? nullptr : ray_indices, t_starts, t_ends};
     a.sc = ren_make_scene(scene);
-    a.n = n; a.rgb = rgb; a.sigma = sigma; a.base_out = base_out; a.acts = act_save;
+    a.n = n; a.rgb = rgb; a.sigma = sigma; a.base_out = base_out; a.acts = act_save; a.n_dev = n_dev;
     return mode == 6 ? launch_fwd_x<6>(a, C, density_only, share, (hipStream_t)stream)
                      : launch_fwd_x<1>(a, C, density_only, share, (hipStream_t)stream);
 }
@@ -285,6 +286,7 @@ struct BwdXHArgs {
     int64_t n;
     const float *rgb, *d_rgb, *d_sigma;
     float *d_base, *slab;
+    const int64_t *n_dev;
 };
 
 // RECOMP: the hidden activations p, q are recomputed from the saved base outputs with the forward's own MFMA
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_head_x_kernel(BwdXHArgs a) {
     const int hi = lane >> 5, sl = lane & 31;
     const bf16x8 sel0 = make_sel<0>(lane), sel1 = make_sel<1>(lane), sel_sh = make_sel<3>(lane);
     __syncthreads();
-    const int64_t n_blk = (a.n + 31) >> 5;
+    const int64_t n_smp = ren_eff_n(a.n, a.n_dev), n_blk = (n_smp + 31) >> 5;
 
     // weight gradients: 32 x 32 tiles accumulated over the whole persistent loop.  head.b0's gradient rides in
     // column v = 0 of acc_wh1 (that input slot carries no weight: the V operand holds 1 there); the other bias /
@@ -357,7 +359,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_head_x_kernel(BwdXHArgs a) {
     // index of the packed stream two ahead, because the ray origin / direction loads depend on it).  Out-of-range
     // blocks read clamped addresses and are never used.
     const int64_t stride = (int64_t)gridDim.x * 4, blk0 = (int64_t)blockIdx.x * 4 + wave;
-    const int64_t i_last = a.n - 1;
+    const int64_t i_last = n_smp > 0 ? n_smp - 1 : 0;
     const bool packed = a.src.ray_indices != nullptr;
     // Branch-free: a run-time `if (packed)` around the loads made the compiler wait for them inside the prefetch (counters
     // are merged conservatively at the join, and `tm` was formed right there): a whole memory latency exposed per block
@@ -397,7 +399,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_head_x_kernel(BwdXHArgs a) {
         const __bf16 *fr = frag + zo;
         const float *W3 = w3 + zo;
         const int64_t i = blk * 32 + sl;
-        const bool live = i < a.n;
+        const bool live = i < n_smp;
         const Staged cur = nxt;
         load_inputs(blk + stride, ray_nn, nxt);
         ray_nn = load_ray(blk + 2 * stride);
@@ -605,6 +607,7 @@ struct BwdXBArgs {
     const float *params, *feat, *d_base, *acts;
     int64_t n;
     float *dfeat, *slab;
+    const int64_t *n_dev;
 };
 
 template <int MODE, bool RECOMP> struct BaseLds {
@@ -640,7 +643,7 @@ __global__ __launch_bounds__(256, REN_BASE_WAVES) void mlp_bwd_base_x_kernel(Bwd
     const int hi = lane >> 5, sl = lane & 31;
     const bf16x8 sel0 = make_sel<0>(lane), sel1 = make_sel<1>(lane), sel_x0 = make_sel<2>(lane), sel_x1 = make_sel<3>(lane);
     __syncthreads();
-    const int64_t n_blk = (a.n + 31) >> 5;
+    const int64_t n_blk = (ren_eff_n(a.n, a.n_dev) + 31) >> 5;
     // base.b0's 32 per-lane sums live in lane-private LDS slots ([value / 4][lane] float4), as in the head kernel
     // (slots 0..7: base.b0, 8..9: base.bo)
     float4 *accl = reinterpret_cast<float4 *>(smem + F_END * 2 + BL::TAIL_BYTES) + wave * (10 * 64) + lane;
@@ -831,7 +834,7 @@ extern "C" int ren_mlp_bwd_x(const float *mlp_params, int32_t C, int32_t activat
                              const float *dirs, const float *rays_o, const float *rays_d, const int32_t *ray_indices,
                              const float *t_starts, const float *t_ends, int64_t n, const float *rgb,
                              const float *d_rgb, const float *d_sigma, float *d_base, float *dfeat,
-                             float *grad_mlp_params, float *workspace, int32_t grid_cus, void *stream) {
+                             float *grad_mlp_params, float *workspace, int32_t grid_cus, const int64_t *n_dev, void *stream) {
     // act_save == nullptr: the hidden activations are recomputed from feat / base_out (the forward need not save them)
     if (!mlp_params || !feat || !base_out || !scene || !rgb || !d_rgb || !d_sigma || !d_base || !dfeat ||
         !grad_mlp_params || !workspace || n < 0)
@@ -847,9 +850,9 @@ extern "C" int ren_mlp_bwd_x(const float *mlp_params, int32_t C, int32_t activat
     h.params = mlp_params; h.base_out = base_out; h.acts = act_save;
     h.src = SampleSrc{x_world, dirs, rays_o, rays_d, x_world ? nullptr : ray_indices, t_starts, t_ends};
     h.sc = ren_make_scene(scene);
-    h.n = n; h.rgb = rgb; h.d_rgb = d_rgb; h.d_sigma = d_sigma; h.d_base = d_base; h.slab = workspace;
+    h.n = n; h.rgb = rgb; h.d_rgb = d_rgb; h.d_sigma = d_sigma; h.d_base = d_base; h.slab = workspace; h.n_dev = n_dev;
     BwdXBArgs b;
-    b.params = mlp_params; b.feat = feat; b.d_base = d_base; b.acts = act_save; b.n = n; b.dfeat = dfeat;
+    b.params = mlp_params; b.feat = feat; b.d_base = d_base; b.acts = act_save; b.n = n; b.dfeat = dfeat; b.n_dev = n_dev;
     b.slab = workspace + (int64_t)GRID_XH * 4 * head_len;
     if (act_save)
         return mode == 6 ? launch_bwd_x<6, false>(h, b, C, grad_mlp_params, grid_cus, (hipStream_t)stream)

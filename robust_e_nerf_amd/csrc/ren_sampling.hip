@@ -668,6 +668,49 @@ extern "C" int ren_exclusive_scan(const int32_t *counts, int64_t n, int64_t *off
     REN_CHECK_LAUNCH();
 }
 
+// ---- device-side sample counts (ABI 24): the scan's total stays on the device; this guard compares it with the capacity the
+// host allocated the per-sample arrays for.  Fits: n_out = total.  Does not fit: every ray's count is cleared (the per-ray
+// kernels then write nothing and the render is empty), n_out = 0 and the overflow word is raised -- the host reads `stats`
+// AFTER it has enqueued the step (no queue drain) and repeats an overflowed step with larger arrays.
+__global__ __launch_bounds__(256) void count_guard_kernel(int32_t *__restrict__ counts, int64_t n_rays,
+                                                          const int64_t *__restrict__ total, int64_t capacity,
+                                                          int64_t *__restrict__ n_out, int64_t *__restrict__ stats) {
+    const int64_t t = total[0];
+    const bool over = t > capacity;
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (over && r < n_rays) counts[r] = 0;
+    if (r == 0) {
+        n_out[0] = over ? 0 : t;
+        if (stats) { stats[0] = t; if (over) stats[1] = 1; }
+    }
+}
+
+extern "C" int ren_count_guard(int32_t *counts, int64_t n_rays, const int64_t *total, int64_t capacity, int64_t *n_out,
+                               int64_t *stats, void *stream) {
+    if (!counts || !total || !n_out || n_rays < 0 || capacity < 0) return REN_ERR_BAD_ARG;
+    hipLaunchKernelGGL(count_guard_kernel, dim3(ren_blocks(n_rays > 0 ? n_rays : 1, 256)), dim3(256), 0, (hipStream_t)stream,
+                       counts, n_rays, total, capacity, n_out, stats);
+    REN_CHECK_LAUNCH();
+}
+
+// fragment-layout feature block (16 levels x 2 x 32 lanes per 32 samples): zero the lanes of the LAST block that lie beyond
+// the device-side count (what ops.compact_features does with a host count): the MLP kernels multiply dead lanes by zero
+// gradients, which only works for finite values
+__global__ __launch_bounds__(64) void frag_zero_tail_kernel(float *__restrict__ feat, int64_t capacity, const int64_t *__restrict__ n_dev) {
+    const int64_t n = ren_eff_n(capacity, n_dev);
+    const int lane = threadIdx.x & 31, half = threadIdx.x >> 5;
+    if ((n & 31) == 0 || lane < (n & 31)) return;
+    float *b = feat + (n >> 5) * (int64_t)(REN_MAX_LEVELS * 64) + lane;
+    for (int l = 0; l < REN_MAX_LEVELS; ++l) b[l * 64 + half * 32] = 0.f;
+}
+
+extern "C" int ren_frag_zero_tail(float *feat, int64_t capacity, const int64_t *n_dev, void *stream) {
+    if (!feat || !n_dev || capacity < 0) return REN_ERR_BAD_ARG;
+    if (capacity == 0) return REN_OK;
+    hipLaunchKernelGGL(frag_zero_tail_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, feat, capacity, n_dev);
+    REN_CHECK_LAUNCH();
+}
+
 extern "C" int ren_visibility(const int64_t *offsets, const int32_t *counts, int64_t n_rays,
                               const float *sigmas, const float *t_starts, const float *t_ends,
                               float early_stop_eps, float alpha_thre, uint8_t *keep,

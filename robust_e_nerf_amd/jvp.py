@@ -113,7 +113,7 @@ def render_forward(r, o, d, od, dd, jitter, bkgd, training: bool = True, pk=None
         feat = torch.empty(nb * 1024, device=dev)
         featd = torch.empty(nb * 1024, device=dev)
         check(lib.ren_hashgrid_fwd_jvp(ctypes.byref(f.grid), _ptr(f.table), ctypes.byref(r.scene), _ptr(o), _ptr(d),
-                                       _ptr(od), _ptr(dd), _ptr(ri), _ptr(ts), _ptr(te), n, _ptr(feat), _ptr(featd),
+                                       _ptr(od), _ptr(dd), _ptr(ri), _ptr(ts), _ptr(te), n, _ptr(feat), _ptr(featd), None,
                                        _stream()), "ren_hashgrid_fwd_jvp")
         rgb, rgbd = torch.empty(n, f.C, device=dev), torch.empty(n, f.C, device=dev)
         sigma, sigmad = torch.empty(n, device=dev), torch.empty(n, device=dev)
@@ -121,7 +121,7 @@ def render_forward(r, o, d, od, dd, jitter, bkgd, training: bool = True, pk=None
         if r.cfg.mlp_kernels == "x":                        # bf16 matrix cores: mode 6 (fp32 accuracy) / 1 (bf16 operands)
             check(lib.ren_mlp_fwd_jvp_x(_ptr(f.mlp), f.C, r._act_code, r._xmode(), _ptr(feat), _ptr(featd), ctypes.byref(r.scene), _ptr(o),
                                         _ptr(d), _ptr(dd), _ptr(ri), _ptr(ts), _ptr(te), n, _ptr(rgb), _ptr(rgbd), _ptr(sigma),
-                                        _ptr(sigmad), _ptr(base), _ptr(based), _stream()), "ren_mlp_fwd_jvp_x")
+                                        _ptr(sigmad), _ptr(base), _ptr(based), None, _stream()), "ren_mlp_fwd_jvp_x")
         else:
             check(lib.ren_mlp_fwd_jvp(_ptr(r._mlp_params()), f.C, r._act_code, _ptr(feat), _ptr(featd), ctypes.byref(r.scene), _ptr(o), _ptr(d),
                                       _ptr(dd), _ptr(ri), _ptr(ts), _ptr(te), n, _ptr(rgb), _ptr(rgbd), _ptr(sigma),

@@ -265,6 +265,18 @@ def ray_march_write(o, d, t_min, t_max, jitter, roi, res, binary, ct, step, cone
     return ri, ts, te
 
 
+def count_guard(counts, total, capacity: int, n_out, stats=None):
+    """device-side sample count: n_out[0] = total if it fits `capacity`, else 0 with every ray's count cleared and stats[1] = 1
+    (stats[0] = the total as found); see include/ren_amd.h, "device-side sample counts'"""
+    check(_lib.load().ren_count_guard(_ptr(counts, torch.int32), counts.shape[0], _ptr(total, torch.int64), int(capacity),
+                                      _ptr(n_out, torch.int64), _ptr(stats, torch.int64), _stream()), "ren_count_guard")
+
+
+def frag_zero_tail(feat, capacity: int, n_dev):
+    check(_lib.load().ren_frag_zero_tail(_ptr(feat, torch.float32), int(capacity), _ptr(n_dev, torch.int64), _stream()),
+          "ren_frag_zero_tail")
+
+
 def visibility(offsets, counts, sigmas, ts, te, eps: float, alpha_thre: float):
     n_rays = counts.shape[0]
     keep = torch.empty(ts.shape[0], device=ts.device, dtype=torch.uint8)
@@ -311,7 +323,7 @@ def pack_info(ray_indices: torch.Tensor, n_rays: int):
 
 # ------------------------------------------------------------------------------- hash grid
 def hashgrid_fwd(grid: GridDesc, table, *, x_unit=None, scene: Optional[SceneDesc] = None, rays=None,
-                 samples=None, n: int, layout: int, out=None):
+                 samples=None, n: int, layout: int, out=None, n_dev=None):
     L = grid.n_levels
     dev = table.device
     if out is None:
@@ -321,7 +333,7 @@ def hashgrid_fwd(grid: GridDesc, table, *, x_unit=None, scene: Optional[SceneDes
     ri, ts, te = samples if samples is not None else (None, None, None)
     check(_lib.load().ren_hashgrid_fwd(ctypes.byref(grid), _ptr(table, torch.float32), _ptr(x_unit),
                                        ctypes.byref(scene) if scene is not None else None,
-                                       _ptr(o), _ptr(d), _ptr(ri), _ptr(ts), _ptr(te), n, layout, _ptr(out),
+                                       _ptr(o), _ptr(d), _ptr(ri), _ptr(ts), _ptr(te), n, layout, _ptr(out), _ptr(n_dev, torch.int64),
                                        _stream()), "ren_hashgrid_fwd")
     return out
 
@@ -341,7 +353,7 @@ def hashgrid_bwd_binned_workspace_bytes(n: int) -> int:
 
 
 def hashgrid_bwd_binned(grid: GridDesc, grad_table, dfeat, workspace, *, x_unit=None, scene=None, rays=None,
-                        samples=None, n: int, layout: int, level_mask: Optional[int] = None, tangent=None):
+                        samples=None, n: int, layout: int, level_mask: Optional[int] = None, tangent=None, n_dev=None):
     """LDS-binned (atomic-free) variant of hashgrid_bwd; workspace: uint8 tensor of
     hashgrid_bwd_binned_workspace_bytes(n) bytes.  level_mask: only the levels whose bit is set; tangent: (rays_do,
     rays_dd, dfeatd) of the log-intensity-gradient render."""
@@ -354,12 +366,13 @@ def hashgrid_bwd_binned(grid: GridDesc, grad_table, dfeat, workspace, *, x_unit=
         check(_lib.load().ren_hashgrid_bwd_binned_levels(
             ctypes.byref(grid), _ptr(grad_table, torch.float32), _ptr(x_unit), ctypes.byref(scene) if scene is not None else None,
             _ptr(o), _ptr(d), _ptr(ri), _ptr(ts), _ptr(te), n, layout, _ptr(dfeat, torch.float32), _ptr(do), _ptr(dd), _ptr(dfd),
-            0xFFFFFFFF if level_mask is None else int(level_mask), _ptr(workspace), _stream()), "ren_hashgrid_bwd_binned_levels")
+            0xFFFFFFFF if level_mask is None else int(level_mask), _ptr(workspace), _ptr(n_dev, torch.int64), _stream()),
+              "ren_hashgrid_bwd_binned_levels")
         return
     check(_lib.load().ren_hashgrid_bwd_binned(ctypes.byref(grid), _ptr(grad_table, torch.float32), _ptr(x_unit),
                                               ctypes.byref(scene) if scene is not None else None,
                                               _ptr(o), _ptr(d), _ptr(ri), _ptr(ts), _ptr(te), n, layout,
-                                              _ptr(dfeat, torch.float32), _ptr(workspace), _stream()),
+                                              _ptr(dfeat, torch.float32), _ptr(workspace), _ptr(n_dev, torch.int64), _stream()),
           "ren_hashgrid_bwd_binned")
 
 
@@ -465,7 +478,7 @@ def mlp_bwd_saved(mlp_params, C: int, feat, base_out, acts, scene: SceneDesc, *,
 
 def mlp_fwd_x(mlp_params, C: int, mode: int, feat, scene: SceneDesc, *, rays=None, samples=None, x_world=None, dirs=None,
               n: int, density_only: bool = False, save: bool = False, out=None, share_cu: bool = False, save_acts: bool = True,
-              act: int = 0):
+              act: int = 0, n_dev=None):
     """Split-bf16 matrix-core kernels (csrc/ren_mlp_x.hip).  mode 6: fp32 accuracy; mode 1: plain bf16 operands.
     -> rgb, sigma, base, acts (base/acts None unless save; acts None with save_acts=False: mlp_bwd_x then recomputes
     the hidden activations); out: preallocated (rgb, sigma, base, acts) views"""
@@ -483,7 +496,7 @@ def mlp_fwd_x(mlp_params, C: int, mode: int, feat, scene: SceneDesc, *, rays=Non
     check(lib.ren_mlp_fwd_x(_ptr(mlp_params, torch.float32), C, int(act), mode, _ptr(feat, torch.float32), ctypes.byref(scene),
                             _ptr(x_world), _ptr(dirs), _ptr(o), _ptr(d), _ptr(ri), _ptr(ts), _ptr(te), n,
                             (1 if density_only else 0) | (2 if share_cu else 0), _ptr(rgb), _ptr(sigma), _ptr(base),
-                            _ptr(acts), _stream()), "ren_mlp_fwd_x")
+                            _ptr(acts), _ptr(n_dev, torch.int64), _stream()), "ren_mlp_fwd_x")
     return rgb, sigma, base, acts
 
 
@@ -497,7 +510,7 @@ def mlp_bwd_x_workspace_floats(C: int) -> int:
 
 def mlp_bwd_x(mlp_params, C: int, mode: int, feat, base_out, acts, scene: SceneDesc, *, rays=None, samples=None,
               x_world=None, dirs=None, n: int, rgb, d_rgb, d_sigma, grad_mlp_params, workspace, dfeat=None, d_base=None,
-              act: int = 0, grid_cus: int = 0):
+              act: int = 0, grid_cus: int = 0, n_dev=None):
     """grid_cus: CUs the two persistent kernels occupy (0 = all; the chunked backward leaves some to the scatter)"""
     dev = feat.device
     o, d = rays if rays is not None else (None, None)
@@ -509,7 +522,7 @@ def mlp_bwd_x(mlp_params, C: int, mode: int, feat, base_out, acts, scene: SceneD
     check(_lib.load().ren_mlp_bwd_x(_ptr(mlp_params, torch.float32), C, int(act), mode, _ptr(feat), _ptr(base_out), _ptr(acts),
                                     ctypes.byref(scene), _ptr(x_world), _ptr(dirs), _ptr(o), _ptr(d), _ptr(ri), _ptr(ts),
                                     _ptr(te), n, _ptr(rgb), _ptr(d_rgb), _ptr(d_sigma), _ptr(d_base), _ptr(dfeat),
-                                    _ptr(grad_mlp_params, torch.float32), _ptr(workspace), int(grid_cus), _stream()),
+                                    _ptr(grad_mlp_params, torch.float32), _ptr(workspace), int(grid_cus), _ptr(n_dev, torch.int64), _stream()),
           "ren_mlp_bwd_x")
     return dfeat
 

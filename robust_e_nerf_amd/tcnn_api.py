@@ -37,7 +37,7 @@ def _encode_with_tangent(module, params, x, v):
     ri = torch.arange(n, device=dev, dtype=torch.int32)
     _lib.check(_lib.load().ren_hashgrid_fwd_jvp(ctypes.byref(module.grid), _ptr(params), ctypes.byref(module.unit_scene), _ptr(x),
                                                 _ptr(zero3), _ptr(v), _ptr(zero3), _ptr(ri), _ptr(zero1), _ptr(zero1), n,
-                                                _ptr(feat), _ptr(featd), _stream()), "ren_hashgrid_fwd_jvp")
+                                                _ptr(feat), _ptr(featd), None, _stream()), "ren_hashgrid_fwd_jvp")
     return _to_rows(feat, n), _to_rows(featd, n)
 
 

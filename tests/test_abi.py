@@ -50,6 +50,18 @@ def test_shipped_library_corresponds_to_the_sources(lib, tmp_path):
     assert build.is_current()
 
 
+def test_no_packed_fp32_op_sel_in_the_shipped_library(lib):
+    """ISA audit (build.audit_packed_op_sel): the library contains no `v_pk_{fma,mul,add}_f32` whose op_sel routes a source's HIGH
+    half into the LOW result lane -- the instruction form that tools/pkf32_hazard_repro.hip shows returning wrong results for
+    an aligned group of 16 lanes beside bf16-MFMA waves on MI355X (117 of 600 launches; 0 of 600 for every other packed form).
+    A deterministic guard in place of round 4's repeat-run statistics."""
+    from robust_e_nerf_amd import build
+    if not os.path.exists(build.OBJDUMP):
+        pytest.skip("llvm-objdump not found")
+    hits = build.audit_packed_op_sel()
+    assert hits == [], hits[:5]
+
+
 def test_abi_version_and_build_info(lib):
     assert lib.ren_abi_version() == 24
     assert b"gfx950" in lib.ren_build_info()

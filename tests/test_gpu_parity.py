@@ -533,7 +533,7 @@ def _mlp_x_vs_f64(amd, n, seed):
                                  None, None, n, P(r0[0]), P(d_rgb), P(d_sig), P(b0[0]), P(b0[1]), P(b0[2]), P(ws0), st) == 0
     r = outs()
     assert lib.ren_mlp_fwd_x(P(params), C, 0, 6, P(feat), ctypes.byref(scene), P(x), P(d), None, None, None, None, None, n, 0,
-                             P(r[0]), P(r[1]), P(r[2]), P(r[3]), st) == 0
+                             P(r[0]), P(r[1]), P(r[2]), P(r[3]), None, st) == 0
     names = ("rgb", "sigma", "base_out", "activations")
     for k, (a, b) in enumerate(zip(r, r0)):
         e = rel_err(a, b)
@@ -547,7 +547,7 @@ def _mlp_x_vs_f64(amd, n, seed):
     for acts in (r[3], None):
         b = bwd_outs()
         assert lib.ren_mlp_bwd_x(P(params), C, 0, 6, P(feat), P(r[2]), P(acts), ctypes.byref(scene), P(x), P(d), None, None, None,
-                                 None, None, n, P(r[0]), P(d_rgb), P(d_sig), P(b[0]), P(b[1]), P(b[2]), P(ws), 0, st) == 0
+                                 None, None, n, P(r[0]), P(d_rgb), P(d_sig), P(b[0]), P(b[1]), P(b[2]), P(ws), 0, None, st) == 0
         torch.cuda.synchronize()
         e_db = rel_err(b[0], b0[0])
         e_df = rel_err(tcnn_api._to_rows(b[1], n).double(), ref[2])
@@ -1793,7 +1793,7 @@ def test_tangent_mlp_matrix_core_kernels_vs_f32_kernels(amd, spec, full_table_ca
                                      P(te), n, P(rgb), P(rgbd), P(sig), P(sigd), P(base), P(based), st)
         else:
             rc = lib.ren_mlp_fwd_jvp_x(P(fld.mlp), 1, 0, mode, P(feat), P(featd), ctypes.byref(scene), P(o_), P(d_), P(dd_), P(ri),
-                                       P(ts), P(te), n, P(rgb), P(rgbd), P(sig), P(sigd), P(base), P(based), st)
+                                       P(ts), P(te), n, P(rgb), P(rgbd), P(sig), P(sigd), P(base), P(based), None, st)
         assert rc == 0
         scratch = torch.empty(nb * 5120, device=DEV)
         dfeat, dfeatd = torch.empty(nb * 1024, device=DEV), torch.empty(nb * 1024, device=DEV)
@@ -1854,7 +1854,7 @@ def test_bf16_mode_tangent_arithmetic_is_pinned(amd, spec, full_table_cache):
     sig, sigd = torch.empty(n, device=DEV), torch.empty(n, device=DEV)
     base, based = torch.empty(nb * 512, device=DEV), torch.empty(nb * 512, device=DEV)
     assert lib.ren_mlp_fwd_jvp_x(P(fld.mlp), 1, 0, 1, P(dev(feat)), P(dev(featd)), ctypes.byref(scene), P(dev(o)), P(dev(d)), P(dev(dd)),
-                                 P(dev(ri)), P(dev(tsv)), P(dev(tsv + 0.01)), n, P(rgb), P(rgbd), P(sig), P(sigd), P(base), P(based),
+                                 P(dev(ri)), P(dev(tsv)), P(dev(tsv + 0.01)), n, P(rgb), P(rgbd), P(sig), P(sigd), P(base), P(based), None,
                                  ops._stream()) == 0
     torch.cuda.synchronize()
 

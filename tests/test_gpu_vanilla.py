@@ -594,7 +594,6 @@ def test_vanilla_activation_alternatives_tangents_vs_float64(amd, tag):
                        t_ends=(tm + 0.01).to(DEV), offsets=torch.arange(R, device=DEV), counts=torch.ones(R, dtype=torch.int32, device=DEV),
                        n=R)
     dev = lambda v: v.to(DEV).contiguous()
-    r._apply_acts()
     rgb, rgbd, sigma, sigmad, T = r._field_forward_jvp(dev(o), dev(d), dev(od), dev(dd), pk)
     w = [torch.randn(R, 1, generator=gen), torch.randn(R, 1, generator=gen), torch.randn(R, generator=gen), torch.randn(R, generator=gen)]
     r.field.grad.zero_()

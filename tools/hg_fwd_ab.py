@@ -26,7 +26,7 @@ for path in (sys.argv[1:] or [_lib.LIB_PATH]) * 2:
     fn = lib.ren_hashgrid_fwd
     fn.restype, fn.argtypes = _lib.SIGNATURES["ren_hashgrid_fwd"]
     run = lambda: fn(ctypes.byref(grid), P(table), None, ctypes.byref(r.scene), P(o), P(d), P(pk.ray_indices), P(pk.t_starts),
-                     P(pk.t_ends), n, 1, P(feat), st)
+                     P(pk.t_ends), n, 1, P(feat), None, st)
     assert run() == 0
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

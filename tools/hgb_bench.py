@@ -35,7 +35,7 @@ for path, kv in variants:
         fn.restype, fn.argtypes = _lib.SIGNATURES[name]
     ws = torch.empty(int(lib.ren_hashgrid_bwd_binned_workspace_bytes(n)), device=dev, dtype=torch.uint8)
     run = lambda: lib.ren_hashgrid_bwd_binned(ctypes.byref(grid), P(gt), None, ctypes.byref(r.scene), P(o), P(d),
-                                              P(pk.ray_indices), P(pk.t_starts), P(pk.t_ends), n, 1, P(dfeat), P(ws), st)
+                                              P(pk.ray_indices), P(pk.t_starts), P(pk.t_ends), n, 1, P(dfeat), P(ws), None, st)
     assert run() == 0
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -85,10 +85,10 @@ for label, mode in (("exact-f32 MFMA kernels", 0), ("x kernels (bf16 MFMA, 6 ter
                               None, None, n, P(rgb_k), P(d_rgb), P(d_sig), P(d_base), P(dfeat), P(gm), P(ws), st)
     else:
         lib.ren_mlp_fwd_x(P(params), C, 0, 6, P(feat), ctypes.byref(scene), P(x), P(d), None, None, None, None, None, n, 0,
-                          P(rgb_k), P(sig_k), P(base_k), None, st)
+                          P(rgb_k), P(sig_k), P(base_k), None, None, st)
         ws = torch.empty(int(lib.ren_mlp_bwd_x_workspace_floats(C)), device=dev)
         lib.ren_mlp_bwd_x(P(params), C, 0, 6, P(feat), P(base_k), None, ctypes.byref(scene), P(x), P(d), None, None, None,
-                          None, None, n, P(rgb_k), P(d_rgb), P(d_sig), P(d_base), P(dfeat), P(gm), P(ws), 0, st)
+                          None, None, n, P(rgb_k), P(d_rgb), P(d_sig), P(d_base), P(dfeat), P(gm), P(ws), 0, None, st)
     torch.cuda.synchronize()
     print("==", label)
     stats("forward rgb", rgb_k, rgb.detach())

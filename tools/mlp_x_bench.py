@@ -56,7 +56,7 @@ for path in (sys.argv[1:] or [_lib.LIB_PATH]):
     rgb = torch.empty(n, C, device=dev); sigma = torch.empty(n, device=dev)
     base = torch.empty(nb * ops.BASE_FLOATS_PER_BLOCK, device=dev)
     fwd = lambda: lib.ren_mlp_fwd_x(P(params), C, 0, mode, P(feat), ctypes.byref(scene), P(x), P(d), None, None, None, None,
-                                    None, n, 0, P(rgb), P(sigma), P(base), None, st)
+                                    None, n, 0, P(rgb), P(sigma), P(base), None, None, st)
     assert fwd() == 0
     t_f = timeit(fwd)
     gm = torch.zeros(npar, device=dev)
@@ -64,7 +64,7 @@ for path in (sys.argv[1:] or [_lib.LIB_PATH]):
     d_base = torch.empty(nb * ops.BASE_FLOATS_PER_BLOCK, device=dev)
     dfeat = torch.empty(nb * ops.FRAG_FLOATS_PER_BLOCK, device=dev)
     bwd = lambda: lib.ren_mlp_bwd_x(P(params), C, 0, mode, P(feat), P(base), None, ctypes.byref(scene), P(x), P(d), None, None,
-                                    None, None, None, n, P(rgb), P(d_rgb), P(d_sigma), P(d_base), P(dfeat), P(gm), P(ws), 0, st)
+                                    None, None, None, n, P(rgb), P(d_rgb), P(d_sigma), P(d_base), P(dfeat), P(gm), P(ws), 0, None, st)
     assert bwd() == 0
     t_b = timeit(bwd)
     gm.zero_(); bwd(); torch.cuda.synchronize()

@@ -34,13 +34,13 @@ rel = lambda a, b: float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 for mode in (6, 1):
     r = outs()
     fx = lambda: lib.ren_mlp_fwd_x(P(params), C, 0, mode, P(feat), ctypes.byref(scene), P(x), P(d), None, None, None, None, None,
-                                   n, 0, P(r[0]), P(r[1]), P(r[2]), P(r[3]), st)
+                                   n, 0, P(r[0]), P(r[1]), P(r[2]), P(r[3]), None, st)
     assert fx() == 0
     t = timeit(fx)
     print(f"bf16 MFMA mode {mode} fwd   {t:6.2f} ms   rel-to-f32: rgb %.2e sigma %.2e base %.2e acts %.2e" %
           tuple(rel(a, b) for a, b in zip(r, r0)))
     fi = lambda: lib.ren_mlp_fwd_x(P(params), C, 0, mode, P(feat), ctypes.byref(scene), P(x), P(d), None, None, None, None, None,
-                                   n, 0, P(r[0]), P(r[1]), P(r[2]), None, st)
+                                   n, 0, P(r[0]), P(r[1]), P(r[2]), None, None, st)
     print(f"   without activation save {timeit(fi):6.2f} ms")
 
 # ---- backward
@@ -58,11 +58,11 @@ print(f"f32 MFMA bwd_saved     {tb:6.2f} ms")
 for mode in (6, 1):
     r = outs()
     assert lib.ren_mlp_fwd_x(P(params), C, 0, mode, P(feat), ctypes.byref(scene), P(x), P(d), None, None, None, None, None,
-                             n, 0, P(r[0]), P(r[1]), P(r[2]), P(r[3]), st) == 0
+                             n, 0, P(r[0]), P(r[1]), P(r[2]), P(r[3]), None, st) == 0
     b = bwd_outs()
     ws = torch.empty(int(lib.ren_mlp_bwd_x_workspace_floats(C)), device=dev)
     fx = lambda: lib.ren_mlp_bwd_x(P(params), C, 0, mode, P(feat), P(r[2]), P(r[3]), ctypes.byref(scene), P(x), P(d), None, None,
-                                   None, None, None, n, P(r[0]), P(d_rgb), P(d_sig), P(b[0]), P(b[1]), P(b[2]), P(ws), 0, st)
+                                   None, None, None, n, P(r[0]), P(d_rgb), P(d_sig), P(b[0]), P(b[1]), P(b[2]), P(ws), 0, None, st)
     assert fx() == 0
     t = timeit(fx)
     b[2].zero_(); fx(); torch.cuda.synchronize()
@@ -76,7 +76,7 @@ for mode in (6, 1):
     # recompute variant (act_save = NULL): must equal the saved-activation backward bit for bit
     b2 = bwd_outs()
     fr = lambda: lib.ren_mlp_bwd_x(P(params), C, 0, mode, P(feat), P(r[2]), None, ctypes.byref(scene), P(x), P(d), None, None,
-                                   None, None, None, n, P(r[0]), P(d_rgb), P(d_sig), P(b2[0]), P(b2[1]), P(b2[2]), P(ws), 0, st)
+                                   None, None, None, n, P(r[0]), P(d_rgb), P(d_sig), P(b2[0]), P(b2[1]), P(b2[2]), P(ws), 0, None, st)
     assert fr() == 0
     t2 = timeit(fr)
     b2[2].zero_(); fr(); torch.cuda.synchronize()

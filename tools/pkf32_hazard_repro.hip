@@ -163,7 +163,7 @@ __global__ void victim_chain(const float *__restrict__ in, float *__restrict__ o
 
 // E: packed instructions with an SGPR PAIR as a source (what hipcc makes of `Kinv[...] * u` in victim C: the matrix sits in SGPRs);
 // F: the same with op_sel / op_sel_hi on the SGPR pair; G: op_sel / op_sel_hi / neg modifiers on VGPR sources only
-template <int KIND>      // 0: E, 1: F, 2: G
+template <int KIND>      // 0: E, 1: F, 2: G, 3 / 4 / 5: G's modifiers one kind at a time
 __global__ void victim_chain_mod(const float *__restrict__ in, float *__restrict__ out, int n, v2f k1, v2f k2, v2f k3) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -180,6 +180,21 @@ __global__ void victim_chain_mod(const float *__restrict__ in, float *__restrict
             asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(acc) : "s"(k1), "v"(m));
             asm volatile("v_pk_mul_f32 %0, %0, %1 op_sel_hi:[1,0]" : "+v"(acc) : "s"(k2));
             asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(acc) : "s"(k3));
+        } else if (KIND == 3) {                    // op_sel only: the LOW result half reads a source's HIGH half
+            asm volatile("v_pk_fma_f32 %0, %0, %1, %2 op_sel:[0,1,0]" : "+v"(acc) : "v"(m), "v"(m));
+            asm volatile("v_pk_mul_f32 %0, %0, %1 op_sel:[1,0]" : "+v"(acc) : "v"(m));
+            asm volatile("v_pk_add_f32 %0, %0, %1 op_sel:[0,1]" : "+v"(acc) : "v"(m));
+            asm volatile("v_pk_fma_f32 %0, %0, %1, %2 op_sel:[0,0,1]" : "+v"(acc) : "v"(m), "v"(m));
+        } else if (KIND == 4) {                    // op_sel_hi only: the HIGH result half reads a source's LOW half (broadcast)
+            asm volatile("v_pk_fma_f32 %0, %0, %1, %2 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(m), "v"(m));
+            asm volatile("v_pk_mul_f32 %0, %0, %1 op_sel_hi:[0,1]" : "+v"(acc) : "v"(m));
+            asm volatile("v_pk_add_f32 %0, %0, %1 op_sel_hi:[1,0]" : "+v"(acc) : "v"(m));
+            asm volatile("v_pk_fma_f32 %0, %0, %1, %2 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(m), "v"(m));
+        } else if (KIND == 5) {                    // neg modifiers only
+            asm volatile("v_pk_fma_f32 %0, %0, %1, %2 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "+v"(acc) : "v"(m), "v"(m));
+            asm volatile("v_pk_mul_f32 %0, %0, %1 neg_lo:[0,1] neg_hi:[0,1]" : "+v"(acc) : "v"(m));
+            asm volatile("v_pk_add_f32 %0, %0, %1 neg_lo:[0,1] neg_hi:[0,1]" : "+v"(acc) : "v"(m));
+            asm volatile("v_pk_fma_f32 %0, %0, %1, %2 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "+v"(acc) : "v"(m), "v"(m));
         } else {
             asm volatile("v_pk_fma_f32 %0, %0, %1, %2 op_sel_hi:[1,1,0] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "+v"(acc) : "v"(m), "v"(m));
             asm volatile("v_pk_mul_f32 %0, %0, %1 op_sel:[1,0] op_sel_hi:[0,1]" : "+v"(acc) : "v"(m));
@@ -365,6 +380,9 @@ int main(int argc, char **argv) {
             case 5: hipLaunchKernelGGL(victim_chain_mod<0>, g, b, 0, sv, d_in, d_out, NT, v2f{0.75f, -0.5f}, v2f{0.5f, 0.25f}, v2f{0.125f, -0.25f}); break;
             case 6: hipLaunchKernelGGL(victim_chain_mod<1>, g, b, 0, sv, d_in, d_out, NT, v2f{0.75f, -0.5f}, v2f{0.5f, 0.25f}, v2f{0.125f, -0.25f}); break;
             case 7: hipLaunchKernelGGL(victim_chain_mod<2>, g, b, 0, sv, d_in, d_out, NT, v2f{0.75f, -0.5f}, v2f{0.5f, 0.25f}, v2f{0.125f, -0.25f}); break;
+            case 9: hipLaunchKernelGGL(victim_chain_mod<3>, g, b, 0, sv, d_in, d_out, NT, v2f{0.75f, -0.5f}, v2f{0.5f, 0.25f}, v2f{0.125f, -0.25f}); break;
+            case 10: hipLaunchKernelGGL(victim_chain_mod<4>, g, b, 0, sv, d_in, d_out, NT, v2f{0.75f, -0.5f}, v2f{0.5f, 0.25f}, v2f{0.125f, -0.25f}); break;
+            case 11: hipLaunchKernelGGL(victim_chain_mod<5>, g, b, 0, sv, d_in, d_out, NT, v2f{0.75f, -0.5f}, v2f{0.5f, 0.25f}, v2f{0.125f, -0.25f}); break;
             case 8: hipLaunchKernelGGL(victim_pose<true>, g, b, 0, sv, d_ts, (int64_t)NT, d_px, (int64_t)4096, d_K, d_tts, d_tp, d_tq, (int64_t)CP, d_out); break;
             case 4: if (!lib_pose) break; if (lib_pose(d_ts, NT, d_px, 4096, d_K, d_tts, d_tp, d_tq, CP, d_out, d_out + 3 * NT, sv) != 0) { printf("ren_pose_rays_fwd failed\n"); exit(1); } break;
         }
@@ -383,15 +401,17 @@ int main(int argc, char **argv) {
                     break;
         }
     };
-    const char *vn[9] = {"A packed chain (asm v_pk_*_f32)", "B scalar chain (control)", "C pose_rays clone", "D packed chain + s_nop 4", "L library ren_pose_rays_fwd",
-                         "E packed chain, SGPR-pair sources", "F packed, SGPR pair + op_sel", "G packed, VGPR op_sel/neg", "K pose clone, Kinv via VGPRs"};
+    const char *vn[12] = {"A packed chain (asm v_pk_*_f32)", "B scalar chain (control)", "C pose_rays clone", "D packed chain + s_nop 4", "L library ren_pose_rays_fwd",
+                         "E packed chain, SGPR-pair sources", "F packed, SGPR pair + op_sel", "G packed, VGPR op_sel/neg", "K pose clone, Kinv via VGPRs",
+                         "G1 packed, op_sel only", "G2 packed, op_sel_hi only", "G3 packed, neg only"};
     const char *an[6] = {"none", "mfma layer (MFMA + VALU)", "mfma only", "valu only", "memory copy", "lib mlp_fwd_x"};
-    const int per[9] = {2, 2, 6, 2, 6, 2, 2, 2, 6};
-    const int n_v = 9, n_a = lib_mlp ? 6 : 5;
+    const int per[12] = {2, 2, 6, 2, 6, 2, 2, 2, 6, 2, 2, 2};
+    const int n_v = 12, n_a = lib_mlp ? 6 : 5;
     std::vector<float> ref(6 * NT), got(6 * NT);
     printf("%d launches per cell; victim = %d threads\n", launches, NT);
     for (int v = 0; v < n_v; ++v) {
         if (v == 4 && !lib_pose) continue;
+        if (getenv("VICTIMS") && !strchr(getenv("VICTIMS"), "ABCDLEFGK123"[v])) continue;
         CK(hipDeviceSynchronize());
         run_victim(v);
         CK(hipStreamSynchronize(sv));
