@@ -246,6 +246,8 @@ def main():
                          "stream before the l_diff pass, the rest beside its backward (Trainer.step); early = all of it beside the "
                          "l_diff backward (experiment only: wrong rays observed, profiles/NOTES.md); inorder = after the l_diff "
                          "backward on the main stream (as before round 4)")
+    ap.add_argument("--device-counts", default="auto", choices=["auto", "off"],
+                    help="occupancy sampler: sample counts stay on the device (RenderCfg.device_counts); off = the reference's host reads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
@@ -355,6 +357,8 @@ def main():
     tr = engine.Trainer(r, tcfg, Kinv=T(Kinv), tab_ts=T(tab_ts), tab_pos=T(tab_pos), tab_quat=T(tab_quat),
                         p2n_raw=p2n0, neg_ct=torch.tensor(0.25), tau_raw=tau0, tau_max=torch.tensor(1e5),
                         bkgd_raw=torch.tensor([0.5413]), world_size=dp_world, process_group=pg)
+    if args.device_counts == "off":
+        tr.device_counts = False
 
     B = args.events if args.scaling == "weak" else max(1, args.events // world)
     n_batches = 4                                    # pre-staged in HBM; per-rank seeds (datamodule.py:85-89)
@@ -533,6 +537,8 @@ def main():
                        "samples_per_ray": args.samples, "parallelism": f"dp{world}",
                        "collectives_per_step": getattr(tr, "last_collectives", 0), "front_prefetched": bool(can_prefetch),
                        "grad_sampling": (tr.grad_sampling_mode() if args.grad_sampling == "auto" else args.grad_sampling) if args.loss_grad > 0 else None,
+                       "device_counts": bool(tr.device_counts_ok() and tr.r._spr is not None),
+                       "device_count_overflows": getattr(tr, "device_count_overflows", 0),
                        "fwd_chunks": args.fwd_chunks, "bwd_chunks": args.bwd_chunks,
                        # what torch.distributed actually formed (a mis-launched N-rank run shows here)
                        "dist_world_size": dist.get_world_size() if dist.is_initialized() else 1,

@@ -142,12 +142,15 @@ int ren_exclusive_scan(const int32_t *counts, int64_t n, int64_t *offsets, int64
  * argument take instead: n = the CAPACITY of the per-sample arrays (it sizes the launch), n_dev = device address of the real
  * count (int64); kernels work on min(n, *n_dev) samples.  n_dev == NULL: n is the count, as before.
  * ren_count_guard: after ren_exclusive_scan left the total on the device, compare it with the capacity.  Fits: *n_out =
- * total.  Does not fit: every counts[r] = 0 (the per-ray kernels write nothing: an empty render), *n_out = 0, stats[1] = 1.
- * stats[0] = the total as found.  The host reads `stats` after it has enqueued the whole step and repeats an overflowed
- * step with larger arrays (engine.py).  ren_frag_zero_tail: zero the lanes beyond the count in the last 32-sample block of
+ * total.  Does not fit: every counts[r] = 0 (the per-ray kernels write nothing: an empty render), *n_out = 0;
+ * counts_also (may be NULL) is cleared with it -- the guard after the visibility pass clears the MARCHED counts as well,
+ * which is what ren_compact_samples / ren_compact_features walk.
+ * stats (may be NULL): stats[0] = the total as found, stats[1] = 1 if it did not fit, else 0.  The host reads `stats`
+ * after it has enqueued the rest of the step -- a wait for the sampling kernels only -- and repeats an overflowed step
+ * with larger arrays before the optimiser runs (engine.py: RenderCfg.device_counts).  ren_frag_zero_tail: zero the lanes beyond the count in the last 32-sample block of
  * a fragment-layout feature array (what the host-count path does before ren_compact_features). */
-int ren_count_guard(int32_t *counts, int64_t n_rays, const int64_t *total, int64_t capacity, int64_t *n_out,
-                    int64_t *stats, void *stream);
+int ren_count_guard(int32_t *counts, int32_t *counts_also, int64_t n_rays, const int64_t *total, int64_t capacity,
+                    int64_t *n_out, int64_t *stats, void *stream);
 int ren_frag_zero_tail(float *feat, int64_t capacity, const int64_t *n_dev, void *stream);
 
 /* nerfacc.render_visibility inside ray_marching (sigma_fn branch): per ray
@@ -287,8 +290,11 @@ int ren_event_diff_loss_fwd(const float *colors, const float *opacities, const u
                             float *loss_sum, void *stream);
 int ren_event_diff_loss_bwd(const float *colors, const float *opacities, const uint8_t *channel_idx, int32_t C,
                             float min_intensity, const float *target, int32_t use_validity, int64_t B, int32_t err_fn,
-                            float scale, const float *loss_sum, float *g_colors, float *intensity, float *pred,
-                            uint8_t *valid, float *loss, void *stream);
+                            float scale, const double *scale_dev, const float *loss_sum, float *g_colors, float *intensity,
+                            float *pred, uint8_t *valid, float *loss, void *stream);
+/* scale_dev (may be NULL): a device double that multiplies `scale` -- the 1/C^k param weight of a TRAINABLE mean contrast
+ * threshold (event_params[4] = 1/C, [5] = 1/C^2 of ren_event_params_refresh), so that no kernel argument waits for a host
+ * read of a parameter (robust_e_nerf.py:470-486). */
 
 /* ---- event batch glue ---------------------------------------------------------------------------
  * ren_event_prepare: ContrastThreshold.forward and RefractoryPeriod.forward
@@ -309,11 +315,24 @@ int ren_event_diff_loss_bwd(const float *colors, const float *opacities, const u
 int ren_event_prepare(const int64_t *start_ts, const int64_t *end_ts, const int64_t *num_pos, const int64_t *num_neg,
                       const double *u_ts_diff, const double *u_diff_start, const double *u_grad, int64_t B, float c_p,
                       float c_n, double tau, double *ts_start, double *ts_end, float *target_diff, double *ts_grad,
-                      float *target_grad, double *dts_start, double *dts_end, double *dts_grad, void *stream);
+                      float *target_grad, double *dts_start, double *dts_end, double *dts_grad, const double *event_params,
+                      void *stream);
 int ren_event_param_grad(int32_t kind, int32_t err_fn, int32_t param_weight_power, const float *pred,
                          const uint8_t *valid, const int64_t *start_ts, const int64_t *end_ts, const int64_t *num_pos,
                          const int64_t *num_neg, const double *u_ts_diff, int64_t B, float c_p, float c_n,
-                         float raw_ratio, double tau, float weight, float *ct_grad, double *tau_grad, void *stream);
+                         float raw_ratio, double tau, float weight, float *ct_grad, double *tau_grad,
+                         const double *event_params, void *stream);
+/* event_params (may be NULL: the scalar arguments count): device double[8] written by ren_event_params_refresh --
+ * [0] C_p, [1] C_n, [2] raw ratio, [3] tau, [4] 1 / mean C, [5] 1 / (mean C)^2, [6] raw tau (clamped).  The kernels then take
+ * C_p, C_n, raw and tau from there: with a trainable ratio / refractory period the step reads no parameter on the host.
+ * ren_event_params_refresh: C_p = softplus(raw ratio) C_n (float32, event_generation_params.py:51-70); the raw refractory
+ * period clamped to +-logit(1e-4) tau_max IN PLACE and tau = tau_max sigmoid(raw / tau_max) in float64 (:170-185,
+ * modules.py:58-74).  ren_tau_adam_step: torch.optim.Adam (no weight decay) on that float64 scalar from d loss / d tau
+ * (x d tau / d raw), state = {exp_avg, exp_avg_sq} on the device, `step` 1-based; clears tau_grad (robust_e_nerf.py:804-807). */
+int ren_event_params_refresh(const float *ct_raw, float c_n, double *tau_raw, double tau_max, double *event_params,
+                             void *stream);
+int ren_tau_adam_step(double *tau_raw, double *tau_grad, double *state, double tau_max, double lr, double beta1, double beta2,
+                      double eps, int64_t step, double grad_scale, void *stream);
 
 /* ---- optimiser ----------------------------------------------------------------------------------
  * torch.optim.Adam step as configured by RobustENeRF.configure_optimizers
@@ -433,7 +452,7 @@ int ren_mlp_bwd_jvp_x(const float *mlp_params, int32_t radiance_dim, int32_t act
                       const float *rays_o, const float *rays_d, const float *rays_dd, const int32_t *ray_indices,
                       const float *t_starts, const float *t_ends, int64_t n, const float *rgb, const float *d_rgb,
                       const float *d_rgbd, const float *d_sigma, const float *d_sigmad, float *scratch, float *dfeat,
-                      float *dfeatd, float *grad_mlp_params, float *workspace, void *stream);
+                      float *dfeatd, float *grad_mlp_params, float *workspace, const int64_t *n_dev, void *stream);
 /* compositing with tangent: colors/colords [n_rays,C], opacities/opacds [n_rays]; saves weights, trans,
  * eds (exclusive prefix of sigmad*dt) [n] for the reverse pass */
 int ren_composite_fwd_jvp(const int64_t *offsets, const int32_t *counts, int64_t n_rays, const float *t_starts,
@@ -472,8 +491,9 @@ int ren_weight_norm_bwd(const float *raw, const float *g, float *d_eff, const in
 int ren_grad_loss_fwd(const float *intensity, const float *intensity_dot, const float *target,
                       const uint8_t *valid, int64_t B, int32_t err_fn, float *loss_sum, void *stream);
 int ren_grad_loss_bwd(const float *intensity, const float *intensity_dot, const float *target,
-                      const uint8_t *valid, int64_t B, int32_t err_fn, float scale, const float *loss_sum,
-                      float *g_intensity, float *g_intensity_dot, void *stream);
+                      const uint8_t *valid, int64_t B, int32_t err_fn, float scale, const double *scale_dev,
+                      const float *loss_sum, float *g_intensity, float *g_intensity_dot, float *loss, void *stream);
+/* scale_dev: as for ren_event_diff_loss_bwd; loss (may be NULL): loss[0] = scale * loss_sum[0] / loss_sum[1] */
 
 /* ---- bf16 MLP mode (BASELINE configs[2]: "bf16 MLP with fp32 composite") ------------------------------ *
  * Same arguments as ren_mlp_fwd / ren_mlp_bwd.  Every linear layer sees bf16-rounded (nearest-even) inputs;
@@ -545,7 +565,8 @@ int ren_raygen_jvp2(const float *Kinv, const float *px, const float *pos, const 
 int ren_hashgrid_fwd_jvp2(const ren_grid_desc *grid, const float *table, const ren_scene_desc *scene,
                           const float *rays_o, const float *rays_d, const float *rays_do, const float *rays_dd,
                           const float *rays_ddd, const int32_t *ray_indices, const float *t_starts,
-                          const float *t_ends, int64_t n, float *feat, float *featd, float *featdd, void *stream);
+                          const float *t_ends, int64_t n, float *feat, float *featd, float *featdd, const int64_t *n_dev,
+                          void *stream);
 int ren_mlp_fwd_jvp2(const float *mlp_params, int32_t C, int32_t activations, const float *feat, const float *featd,
                      const float *featdd, const ren_scene_desc *scene, const float *rays_o, const float *rays_d,
                      const float *rays_do, const float *rays_dd, const float *rays_ddd,
@@ -560,7 +581,7 @@ int ren_mlp_fwd_jvp2_x(const float *mlp_params, int32_t C, int32_t activations, 
                        const float *rays_do, const float *rays_dd, const float *rays_ddd,
                        const int32_t *ray_indices, const float *t_starts, const float *t_ends, int64_t n,
                        float *rgb, float *rgbd, float *rgbdd, float *sigma, float *sigmad, float *sigmadd,
-                       void *stream);
+                       const int64_t *n_dev, void *stream);
 int ren_composite_fwd_jvp2(const int64_t *offsets, const int32_t *counts, int64_t n_rays, const float *t_starts,
                            const float *t_ends, const float *sigmas, const float *sigmads, const float *sigmadds,
                            const float *rgbs, const float *rgbds, const float *rgbdds, int32_t C,

@@ -46,7 +46,7 @@ SIGNATURES = {
     "ren_compact_features": (c_int, [P, P, P, c_int64, P, P, P, P]),
     "ren_uniform": (c_int, [ctypes.c_uint64, ctypes.c_uint64, c_int64, P, P]),
     "ren_exclusive_scan": (c_int, [P, c_int64, P, P, P, P]),
-    "ren_count_guard": (c_int, [P, c_int64, P, c_int64, P, P, P]),
+    "ren_count_guard": (c_int, [P, P, c_int64, P, c_int64, P, P, P]),
     "ren_frag_zero_tail": (c_int, [P, c_int64, P, P]),
     "ren_visibility": (c_int, [P, P, c_int64, P, P, P, c_float, c_float, P, P, P]),
     "ren_compact_samples": (c_int, [P, P, P, c_int64, P, P, P, P, P, P, P]),
@@ -70,9 +70,11 @@ SIGNATURES = {
                                   P, P, P, P, P]),
     "ren_act_jvp_fwd": (c_int, [P, c_int32, P, c_int32, c_float, P, c_int32, c_int64, c_int32, P]),
     "ren_act_jvp_bwd": (c_int, [P, P, P, c_int32, P, c_float, P, P, c_int64, c_int32, P]),
-    "ren_event_prepare": (c_int, [P, P, P, P, P, P, P, c_int64, c_float, c_float, c_double, P, P, P, P, P, P, P, P, P]),
+    "ren_event_prepare": (c_int, [P, P, P, P, P, P, P, c_int64, c_float, c_float, c_double, P, P, P, P, P, P, P, P, P, P]),
+    "ren_event_params_refresh": (c_int, [P, c_float, P, c_double, P, P]),
+    "ren_tau_adam_step": (c_int, [P, P, P, c_double, c_double, c_double, c_double, c_double, c_int64, c_double, P]),
     "ren_event_param_grad": (c_int, [c_int32, c_int32, c_int32, P, P, P, P, P, P, P, c_int64, c_float, c_float, c_float,
-                                     c_double, c_float, P, P, P]),
+                                     c_double, c_float, P, P, P, P]),
     "ren_mlp_fwd_x": (c_int, [P, c_int32, c_int32, c_int32, P, POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, c_int32, P, P, P, P, P, P]),
     "ren_mlp_bwd_x_workspace_floats": (c_int64, [c_int32]),
     "ren_mlp_bwd_x": (c_int, [P, c_int32, c_int32, c_int32, P, P, P, POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, P, P, P, P, P,
@@ -82,7 +84,7 @@ SIGNATURES = {
     "ren_event_loss_fwd": (c_int, [P, P, P, P, c_int64, c_int32, P, P]),
     "ren_event_loss_bwd": (c_int, [P, P, P, P, c_int64, c_int32, c_float, P, P, P, P]),
     "ren_event_diff_loss_fwd": (c_int, [P, P, P, c_int32, c_float, P, c_int32, c_int64, c_int32, P, P]),
-    "ren_event_diff_loss_bwd": (c_int, [P, P, P, c_int32, c_float, P, c_int32, c_int64, c_int32, c_float, P, P, P, P, P, P, P]),
+    "ren_event_diff_loss_bwd": (c_int, [P, P, P, c_int32, c_float, P, c_int32, c_int64, c_int32, c_float, P, P, P, P, P, P, P, P]),
     "ren_bkgd_param_fwd": (c_int, [P, c_int32, P, P]),
     "ren_bkgd_param_grad": (c_int, [P, c_int64, c_int32, P, P, P, P]),
     "ren_adam_step": (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int64,
@@ -106,15 +108,15 @@ SIGNATURES = {
     "ren_mlp_fwd_jvp_x": (c_int, [P, c_int32, c_int32, c_int32, P, P, POINTER(SceneDesc), P, P, P, P, P, P, c_int64, P, P, P, P, P, P, P, P]),
     "ren_mlp_bwd_jvp_x_workspace_floats": (c_int64, [c_int32]),
     "ren_mlp_bwd_jvp_x": (c_int, [P, c_int32, c_int32, c_int32, P, P, P, P, POINTER(SceneDesc), P, P, P, P, P, P, c_int64, P, P, P, P, P,
-                                  P, P, P, P, P, P]),
+                                  P, P, P, P, P, P, P]),
     "ren_composite_fwd_jvp": (c_int, [P, P, c_int64, P, P, P, P, P, P, c_int32, P, P, P, P, P, P, P, P, P]),
     "ren_composite_bwd_jvp": (c_int, [P, P, c_int64, P, P, P, P, P, P, c_int32, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "ren_trajectory_jvp2": (c_int, [P, c_int64, P, P, P, c_int64, P, P, P, P, P, P]),
     "ren_raygen_jvp2": (c_int, [P, P, P, P, P, P, P, c_int64, P, P, P, P, P, P]),
-    "ren_hashgrid_fwd_jvp2": (c_int, [POINTER(GridDesc), P, POINTER(SceneDesc), P, P, P, P, P, P, P, P, c_int64, P, P, P, P]),
+    "ren_hashgrid_fwd_jvp2": (c_int, [POINTER(GridDesc), P, POINTER(SceneDesc), P, P, P, P, P, P, P, P, c_int64, P, P, P, P, P]),
     "ren_mlp_fwd_jvp2": (c_int, [P, c_int32, c_int32, P, P, P, POINTER(SceneDesc), P, P, P, P, P, P, P, P, c_int64, P, P, P, P, P, P, P]),
     "ren_mlp_fwd_jvp2_x": (c_int, [P, c_int32, c_int32, c_int32, P, P, P, POINTER(SceneDesc), P, P, P, P, P, P, P, P, c_int64, P, P, P, P, P, P,
-                                   P]),
+                                   P, P]),
     "ren_composite_fwd_jvp2": (c_int, [P, P, c_int64, P, P, P, P, P, P, P, P, c_int32, P, P, P, P, P]),
     "ren_freq_encode": (c_int, [POINTER(SceneDesc), P, P, P, P, P, P, P, c_int64, P, c_int32, P, c_int32, c_int32, P,
                                 c_int32, c_int32, P, P]),
@@ -141,7 +143,7 @@ SIGNATURES = {
     "ren_weight_norm_fwd": (c_int, [P, P, P, c_int32, c_int64, P, P]),
     "ren_weight_norm_bwd": (c_int, [P, P, P, P, c_int32, c_int64, P, P, c_int32, P]),
     "ren_grad_loss_fwd": (c_int, [P, P, P, P, c_int64, c_int32, P, P]),
-    "ren_grad_loss_bwd": (c_int, [P, P, P, P, c_int64, c_int32, c_float, P, P, P, P]),
+    "ren_grad_loss_bwd": (c_int, [P, P, P, P, c_int64, c_int32, c_float, P, P, P, P, P, P]),
 }
 
 _lib = None

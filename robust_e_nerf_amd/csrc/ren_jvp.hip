@@ -369,9 +369,11 @@ __global__ __launch_bounds__(256) void grad_loss_fwd_kernel(const float *__restr
 
 __global__ void grad_loss_bwd_kernel(const float *__restrict__ inten, const float *__restrict__ intend,
                                      const float *__restrict__ target, const uint8_t *__restrict__ valid, int64_t B,
-                                     int fn, float scale, const float *__restrict__ loss_sum,
-                                     float *__restrict__ g_inten, float *__restrict__ g_intend) {
+                                     int fn, float scale, const double *__restrict__ scale_dev, const float *__restrict__ loss_sum,
+                                     float *__restrict__ g_inten, float *__restrict__ g_intend, float *__restrict__ loss_out) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (scale_dev) scale = (float)((double)scale * scale_dev[0]);   // weight x param weight(mean contrast), the latter on the device
+    if (i == 0 && loss_out) loss_out[0] = loss_sum[0] / loss_sum[1] * scale;
     if (i >= B) return;
     float g = 0.f;
     const float I = inten[i], Id = intend[i];
@@ -503,13 +505,13 @@ extern "C" int ren_grad_loss_fwd(const float *intensity, const float *intensity_
 }
 
 extern "C" int ren_grad_loss_bwd(const float *intensity, const float *intensity_dot, const float *target,
-                                 const uint8_t *valid, int64_t B, int32_t err_fn, float scale, const float *loss_sum,
-                                 float *g_intensity, float *g_intensity_dot, void *stream) {
+                                 const uint8_t *valid, int64_t B, int32_t err_fn, float scale, const double *scale_dev,
+                                 const float *loss_sum, float *g_intensity, float *g_intensity_dot, float *loss, void *stream) {
     if (!intensity || !intensity_dot || !target || !loss_sum || !g_intensity || !g_intensity_dot || B < 0 ||
         err_fn < 0 || err_fn > 2)
         return REN_ERR_BAD_ARG;
-    if (B == 0) return REN_OK;
-    hipLaunchKernelGGL(grad_loss_bwd_kernel, dim3(ren_blocks(B, 256)), dim3(256), 0, (hipStream_t)stream, intensity,
-                       intensity_dot, target, valid, B, err_fn, scale, loss_sum, g_intensity, g_intensity_dot);
+    if (B == 0 && !loss) return REN_OK;
+    hipLaunchKernelGGL(grad_loss_bwd_kernel, dim3(ren_blocks(B > 0 ? B : 1, 256)), dim3(256), 0, (hipStream_t)stream, intensity,
+                       intensity_dot, target, valid, B, err_fn, scale, scale_dev, loss_sum, g_intensity, g_intensity_dot, loss);
     REN_CHECK_LAUNCH();
 }

@@ -179,9 +179,14 @@ __device__ __forceinline__ void unit_pos2(const Ray2 &r, const ren_scene_dev &sc
 __global__ __launch_bounds__(256) void hashgrid_fwd_jvp2_kernel(GridDev g, const float2 *__restrict__ table,
                                                                 ren_scene_dev sc, Ray2 r, int64_t n, int64_t n_pad,
                                                                 float *__restrict__ feat, float *__restrict__ featd,
-                                                                float *__restrict__ featdd) {
+                                                                float *__restrict__ featdd, const int64_t *__restrict__ n_dev) {
     const int lvl = blockIdx.y;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n_dev) {                                             // device-side sample count (ren_common.h)
+        n = ren_eff_n(n, n_dev);
+        const int64_t p = ((n + 31) >> 5) << 5;
+        n_pad = p < n_pad ? p : n_pad;
+    }
     if (i >= n_pad) return;
     T2 f0 = t2(0.f), f1 = t2(0.f);
     if (i < n) {
@@ -265,6 +270,7 @@ struct Fwd2Args {
     ren_scene_dev sc;
     int64_t n;
     float *rgb, *rgbd, *rgbdd, *sigma, *sigmad, *sigmadd;
+    const int64_t *n_dev;                          // device-side sample count or NULL (x kernel)
     int act_code;                                  // f32 kernel: activation alternatives (ren_mlp_common.h); the x kernel implements 0 only
 };
 
@@ -461,14 +467,14 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_jvp2_x_kernel(Fwd2Args a) {
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int hi = lane >> 5, sl = lane & 31;
-    const int64_t n_blk = (a.n + 31) >> 5;
+    const int64_t n_smp = ren_eff_n(a.n, a.n_dev), n_blk = (n_smp + 31) >> 5;
     for (int64_t blk = (int64_t)blockIdx.x * 4 + wave; blk < n_blk; blk += (int64_t)gridDim.x * 4) {
         int zo = 0;                                             // keep the (loop-invariant) LDS reads inside the loop
         asm volatile("" : "+v"(zo));
         const __bf16 *fr = frag + zo;
         const float *tl = tail + zo;
         const int64_t i = blk * 32 + sl;
-        const bool live = i < a.n;
+        const bool live = i < n_smp;
         // ---- base layer 0 on the hash features and their two tangents
         f32x16 h[2], hd[2], he[2];
 #pragma unroll
@@ -775,7 +781,7 @@ extern "C" int ren_hashgrid_fwd_jvp2(const ren_grid_desc *grid, const float *tab
                                      const float *rays_o, const float *rays_d, const float *rays_do,
                                      const float *rays_dd, const float *rays_ddd, const int32_t *ray_indices,
                                      const float *t_starts, const float *t_ends, int64_t n, float *feat,
-                                     float *featd, float *featdd, void *stream) {
+                                     float *featd, float *featdd, const int64_t *n_dev, void *stream) {
     GridDev g;
     int rc = make_grid(grid, g);
     if (rc) return rc;
@@ -788,7 +794,7 @@ extern "C" int ren_hashgrid_fwd_jvp2(const ren_grid_desc *grid, const float *tab
     const Ray2 r{rays_o, rays_d, rays_do, rays_dd, rays_ddd, ray_indices, t_starts, t_ends};
     hipLaunchKernelGGL(hashgrid_fwd_jvp2_kernel, dim3(ren_blocks(n_pad, 256), g.n_levels), dim3(256), 0,
                        (hipStream_t)stream, g, reinterpret_cast<const float2 *>(table), ren_make_scene(scene), r, n,
-                       n_pad, feat, featd, featdd);
+                       n_pad, feat, featd, featdd, n_dev);
     REN_CHECK_LAUNCH();
 }
 
@@ -809,7 +815,7 @@ extern "C" int ren_mlp_fwd_jvp2(const float *mlp_params, int32_t C, int32_t acti
     a.ray = Ray2{rays_o, rays_d, rays_do, rays_dd, rays_ddd, ray_indices, t_starts, t_ends};
     a.sc = ren_make_scene(scene);
     a.n = n; a.rgb = rgb; a.rgbd = rgbd; a.rgbdd = rgbdd; a.sigma = sigma; a.sigmad = sigmad; a.sigmadd = sigmadd;
-    a.act_code = activations;
+    a.act_code = activations; a.n_dev = nullptr;
     const int64_t n_blk = (n + 31) / 32;
     int64_t blocks = (n_blk + 3) / 4;
     if (blocks > 256) blocks = 256;
@@ -824,7 +830,7 @@ extern "C" int ren_mlp_fwd_jvp2_x(const float *mlp_params, int32_t C, int32_t ac
                                   const float *rays_do, const float *rays_dd, const float *rays_ddd,
                                   const int32_t *ray_indices, const float *t_starts, const float *t_ends, int64_t n,
                                   float *rgb, float *rgbd, float *rgbdd, float *sigma, float *sigmad, float *sigmadd,
-                                  void *stream) {
+                                  const int64_t *n_dev, void *stream) {
     if (!mlp_params || !feat || !featd || !featdd || !scene || !rays_o || !rays_d || !rays_do || !rays_dd ||
         !rays_ddd || !ray_indices || !t_starts || !t_ends || !rgb || !rgbd || !rgbdd || !sigma || !sigmad ||
         !sigmadd || n < 0)
@@ -834,7 +840,7 @@ extern "C" int ren_mlp_fwd_jvp2_x(const float *mlp_params, int32_t C, int32_t ac
     if (activations != 0) return REN_ERR_UNSUPPORTED;      // activation alternatives: exact-f32 kernels only
     if (n == 0) return REN_OK;
     Fwd2Args a;
-    a.act_code = 0;
+    a.act_code = 0; a.n_dev = n_dev;
     a.params = mlp_params; a.feat = feat; a.featd = featd; a.featdd = featdd;
     a.ray = Ray2{rays_o, rays_d, rays_do, rays_dd, rays_ddd, ray_indices, t_starts, t_ends};
     a.sc = ren_make_scene(scene);

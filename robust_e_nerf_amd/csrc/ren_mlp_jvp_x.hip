@@ -249,6 +249,7 @@ struct BwdJX2Args {
     int64_t n;
     const float *rgb, *d_rgb, *d_rgbd;
     float *dz1, *dz1d, *slab;                      // dz1/dz1d: [blk][2][16][64] fragment order
+    const int64_t *n_dev;
 };
 
 template <int MODE> struct H2Lds {
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_jvp_head2_x_kernel(BwdJX2Args 
     __bf16 *Tz = reinterpret_cast<__bf16 *>(smem + HL::F_END * 2 + HL::T_END * 4) + wave * (3 * NP * 32 * ST);
     __bf16 *Ta = Tz + NP * 32 * ST, *Ta2 = Ta + NP * 32 * ST;
     __syncthreads();
-    const int64_t n_blk = (a.n + 31) >> 5;
+    const int64_t n_smp = ren_eff_n(a.n, a.n_dev), n_blk = (n_smp + 31) >> 5;
     f32x16 acc_w[2][2];
     float acc_w3[C][32], acc_b2[2][16], acc_b3[C];
 #pragma unroll
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_jvp_head2_x_kernel(BwdJX2Args 
         const __bf16 *fr = frag + zo;
         const float *tl = tail + zo;
         const int64_t i = blk * 32 + sl;
-        const bool live = i < a.n;
+        const bool live = i < n_smp;
         bool sel = false;
         float dir[3] = {0.f, 0.f, 1.f}, dird[3] = {0.f, 0.f, 0.f};
         if (live) geom_jvp(a.src, a.sc, i, sel, dir, dird);
@@ -473,6 +474,7 @@ struct BwdJX1Args {
     int64_t n;
     const float *d_sigma, *d_sigmad;
     float *d_base, *d_based, *slab;
+    const int64_t *n_dev;
 };
 
 template <int MODE> struct H1Lds {
@@ -495,7 +497,7 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_jvp_head1_x_kernel(BwdJX1Args 
     __bf16 *Tz = reinterpret_cast<__bf16 *>(smem + HL::F_END * 2) + wave * (2 * NP * 32 * ST);
     __bf16 *Ta = Tz + NP * 32 * ST;
     __syncthreads();
-    const int64_t n_blk = (a.n + 31) >> 5;
+    const int64_t n_smp = ren_eff_n(a.n, a.n_dev), n_blk = (n_smp + 31) >> 5;
     f32x16 acc_w[2];
     float acc_b[2][16];
 #pragma unroll
@@ -505,7 +507,7 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_jvp_head1_x_kernel(BwdJX1Args 
         asm volatile("" : "+v"(zo));
         const __bf16 *fr = frag + zo;
         const int64_t i = blk * 32 + sl;
-        const bool live = i < a.n;
+        const bool live = i < n_smp;
         bool sel = false;
         float dir[3] = {0.f, 0.f, 1.f}, dird[3] = {0.f, 0.f, 0.f};
         if (live) geom_jvp(a.src, a.sc, i, sel, dir, dird);
@@ -597,6 +599,7 @@ struct BwdJXBArgs {
     const float *params, *feat, *featd, *d_base, *d_based;
     int64_t n;
     float *dfeat, *dfeatd, *slab;
+    const int64_t *n_dev;
 };
 
 template <int MODE> struct BJLds {
@@ -625,7 +628,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_jvp_base_x_kernel(BwdJXBArgs a
     __bf16 *Ta = Tz + NP * 32 * ST;
     for (int k = lane; k < 2 * NP * 32 * ST; k += 64) Tz[k] = (__bf16)0.f;          // dO rows 16..31 stay zero
     __syncthreads();
-    const int64_t n_blk = (a.n + 31) >> 5;
+    const int64_t n_smp = ren_eff_n(a.n, a.n_dev), n_blk = (n_smp + 31) >> 5;
     f32x16 acc_w2[2], acc_w1[2];
     float acc_b2[8], acc_b1[2][16];
 #pragma unroll
@@ -840,7 +843,7 @@ extern "C" int ren_mlp_bwd_jvp_x(const float *mlp_params, int32_t C, int32_t act
                                  const int32_t *ray_indices, const float *t_starts, const float *t_ends, int64_t n,
                                  const float *rgb, const float *d_rgb, const float *d_rgbd, const float *d_sigma,
                                  const float *d_sigmad, float *scratch, float *dfeat, float *dfeatd,
-                                 float *grad_mlp_params, float *workspace, void *stream) {
+                                 float *grad_mlp_params, float *workspace, const int64_t *n_dev, void *stream) {
     if (!mlp_params || !feat || !featd || !base_out || !base_outd || !scene || !rays_o || !rays_d || !rays_dd ||
         !ray_indices || !t_starts || !t_ends || !rgb || !d_rgb || !d_rgbd || !d_sigma || !d_sigmad || !scratch ||
         !dfeat || !dfeatd || !grad_mlp_params || !workspace || n < 0)
@@ -856,14 +859,14 @@ extern "C" int ren_mlp_bwd_jvp_x(const float *mlp_params, int32_t C, int32_t act
     const RaySrc src{rays_o, rays_d, rays_dd, ray_indices, t_starts, t_ends};
     const ren_scene_dev sc = ren_make_scene(scene);
     BwdJX2Args a2;
-    a2.params = mlp_params; a2.base_out = base_out; a2.base_outd = base_outd; a2.src = src; a2.sc = sc; a2.n = n;
+    a2.params = mlp_params; a2.base_out = base_out; a2.base_outd = base_outd; a2.src = src; a2.sc = sc; a2.n = n; a2.n_dev = n_dev;
     a2.rgb = rgb; a2.d_rgb = d_rgb; a2.d_rgbd = d_rgbd; a2.dz1 = dz1; a2.dz1d = dz1d; a2.slab = slab2;
     BwdJX1Args a1;
     a1.params = mlp_params; a1.base_out = base_out; a1.base_outd = base_outd; a1.dz1 = dz1; a1.dz1d = dz1d;
-    a1.src = src; a1.sc = sc; a1.n = n; a1.d_sigma = d_sigma; a1.d_sigmad = d_sigmad; a1.d_base = d_base;
+    a1.src = src; a1.sc = sc; a1.n = n; a1.n_dev = n_dev; a1.d_sigma = d_sigma; a1.d_sigmad = d_sigmad; a1.d_base = d_base;
     a1.d_based = d_based; a1.slab = slab1;
     BwdJXBArgs ab;
-    ab.params = mlp_params; ab.feat = feat; ab.featd = featd; ab.d_base = d_base; ab.d_based = d_based; ab.n = n;
+    ab.params = mlp_params; ab.feat = feat; ab.featd = featd; ab.d_base = d_base; ab.d_based = d_based; ab.n = n; ab.n_dev = n_dev;
     ab.dfeat = dfeat; ab.dfeatd = dfeatd; ab.slab = slabb;
     return mode == 6 ? launch_bwd_jvp_x<6>(a2, a1, ab, C, grad_mlp_params, (hipStream_t)stream)
                      : launch_bwd_jvp_x<1>(a2, a1, ab, C, grad_mlp_params, (hipStream_t)stream);

@@ -672,24 +672,27 @@ extern "C" int ren_exclusive_scan(const int32_t *counts, int64_t n, int64_t *off
 // host allocated the per-sample arrays for.  Fits: n_out = total.  Does not fit: every ray's count is cleared (the per-ray
 // kernels then write nothing and the render is empty), n_out = 0 and the overflow word is raised -- the host reads `stats`
 // AFTER it has enqueued the step (no queue drain) and repeats an overflowed step with larger arrays.
-__global__ __launch_bounds__(256) void count_guard_kernel(int32_t *__restrict__ counts, int64_t n_rays,
-                                                          const int64_t *__restrict__ total, int64_t capacity,
+__global__ __launch_bounds__(256) void count_guard_kernel(int32_t *__restrict__ counts, int32_t *__restrict__ counts_also,
+                                                          int64_t n_rays, const int64_t *__restrict__ total, int64_t capacity,
                                                           int64_t *__restrict__ n_out, int64_t *__restrict__ stats) {
     const int64_t t = total[0];
     const bool over = t > capacity;
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (over && r < n_rays) counts[r] = 0;
+    if (over && r < n_rays) {
+        counts[r] = 0;
+        if (counts_also) counts_also[r] = 0;
+    }
     if (r == 0) {
         n_out[0] = over ? 0 : t;
-        if (stats) { stats[0] = t; if (over) stats[1] = 1; }
+        if (stats) { stats[0] = t; stats[1] = over ? 1 : 0; }
     }
 }
 
-extern "C" int ren_count_guard(int32_t *counts, int64_t n_rays, const int64_t *total, int64_t capacity, int64_t *n_out,
-                               int64_t *stats, void *stream) {
+extern "C" int ren_count_guard(int32_t *counts, int32_t *counts_also, int64_t n_rays, const int64_t *total, int64_t capacity,
+                               int64_t *n_out, int64_t *stats, void *stream) {
     if (!counts || !total || !n_out || n_rays < 0 || capacity < 0) return REN_ERR_BAD_ARG;
     hipLaunchKernelGGL(count_guard_kernel, dim3(ren_blocks(n_rays > 0 ? n_rays : 1, 256)), dim3(256), 0, (hipStream_t)stream,
-                       counts, n_rays, total, capacity, n_out, stats);
+                       counts, counts_also, n_rays, total, capacity, n_out, stats);
     REN_CHECK_LAUNCH();
 }
 

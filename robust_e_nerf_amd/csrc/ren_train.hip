@@ -96,10 +96,12 @@ __global__ __launch_bounds__(256) void diff_loss_fwd_kernel(DiffLossArgs a, floa
     }
 }
 
-__global__ void diff_loss_bwd_kernel(DiffLossArgs a, float scale, const float *__restrict__ loss_sum,
+__global__ void diff_loss_bwd_kernel(DiffLossArgs a, float scale, const double *__restrict__ scale_dev,
+                                     const float *__restrict__ loss_sum,
                                      float *__restrict__ g_colors, float *__restrict__ inten, float *__restrict__ pred_out,
                                      uint8_t *__restrict__ valid_out, float *__restrict__ loss_out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (scale_dev) scale = (float)((double)scale * scale_dev[0]);   // weight x param weight(mean contrast), the latter on the device
     if (i == 0 && loss_out) loss_out[0] = loss_sum[0] / loss_sum[1] * scale;   // an empty mask gives NaN like the reference
     if (i >= a.B) return;
     float is, ie; int ch;
@@ -258,7 +260,13 @@ struct PrepArgs {
     double tau;
     double *ts_start, *ts_end, *ts_grad, *dts_start, *dts_end, *dts_grad;
     float *target_diff, *target_grad;
+    const double *ep;                        // device-resident event parameters (REN_EP_*), or NULL: the scalars above
 };
+
+// Device-resident event-generation parameters (ren_event_params_refresh): with a trainable C_p / C_n ratio or refractory
+// period the values move with every optimiser step; kept on the device, no kernel argument of the next step waits for a
+// host read of them (the reference reads nothing either: they are nn.Parameters, event_generation_params.py:51-84,162-203).
+enum { REN_EP_CP = 0, REN_EP_CN = 1, REN_EP_RAW = 2, REN_EP_TAU = 3, REN_EP_INV_C = 4, REN_EP_INV_C2 = 5, REN_EP_TAU_RAW = 6 };
 
 __device__ __forceinline__ double lerp64(double a, double b, double w) {      // torch.lerp's two-sided formula
     const double diff = b - a;
@@ -268,6 +276,7 @@ __device__ __forceinline__ double lerp64(double a, double b, double w) {      //
 __global__ __launch_bounds__(256) void event_prepare_kernel(PrepArgs a) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.B) return;
+    if (a.ep) { a.c_p = (float)a.ep[REN_EP_CP]; a.c_n = (float)a.ep[REN_EP_CN]; a.tau = a.ep[REN_EP_TAU]; }
     const float ev = __fsub_rn(__fmul_rn((float)a.num_pos[i], a.c_p), __fmul_rn((float)a.num_neg[i], a.c_n));
     const double end = (double)a.end_ts[i];
     const double start = (double)a.start_ts[i] + a.tau;
@@ -310,10 +319,12 @@ struct ParamGradArgs {
     double tau;
     float *ct_grad;                                                // += dL/d raw   (NULL: skip)
     double *tau_grad;                                              // += dL/d tau   (NULL: skip)
+    const double *ep;                                              // device-resident c_p, c_n, raw, tau (or NULL)
 };
 
 __global__ __launch_bounds__(1024) void event_param_grad_kernel(ParamGradArgs a) {
     __shared__ double red[4][16];
+    if (a.ep) { a.c_p = (float)a.ep[REN_EP_CP]; a.c_n = (float)a.ep[REN_EP_CN]; a.raw = (float)a.ep[REN_EP_RAW]; a.tau = a.ep[REN_EP_TAU]; }
     double s_e = 0.0, s_c = 0.0, s_t = 0.0, cnt = 0.0;
     for (int64_t i = threadIdx.x; i < a.B; i += 1024) {
         if (a.valid && !a.valid[i]) continue;
@@ -356,7 +367,7 @@ __global__ __launch_bounds__(1024) void event_param_grad_kernel(ParamGradArgs a)
         double t[4] = {0.0, 0.0, 0.0, 0.0};
         for (int k = 0; k < 4; ++k)
             for (int w = 0; w < 16; ++w) t[k] += red[k][w];
-        const double C = ((double)a.c_p + (double)a.c_n) * 0.5;
+        const double C = a.ep ? 1.0 / a.ep[REN_EP_INV_C] : ((double)a.c_p + (double)a.c_n) * 0.5;
         const double pw = a.pw_k == 0 ? 1.0 : (a.pw_k == 1 ? 1.0 / C : 1.0 / (C * C));
         const double dpw = a.pw_k == 0 ? 0.0 : (a.pw_k == 1 ? -0.5 / (C * C) : -1.0 / (C * C * C));   // d pw / d C_p
         const double mean_e = t[0] / t[3], mean_c = t[1] / t[3], mean_t = t[2] / t[3];
@@ -409,7 +420,56 @@ __global__ __launch_bounds__(1024) void tau_pose_grad_kernel(const float *__rest
     }
 }
 
+// event parameters from their raw (trainable) forms, as RobustENeRF evaluates them at the top of every step
+// (event_generation_params.py:51-70: C_p = softplus(raw ratio) C_n in float32; :170-185 + modules.py:58-74: the raw
+// refractory period clamped to +-logit(1e-4) tau_max, tau = tau_max sigmoid(raw / tau_max) in float64)
+__global__ void event_params_refresh_kernel(const float *__restrict__ ct_raw, float c_n, double *__restrict__ tau_raw, double tau_max,
+                                            double *__restrict__ ep) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float raw = ct_raw[0];
+    const float ratio = raw > 20.f ? raw : log1pf(expf(raw));         // torch softplus (beta 1, threshold 20), float32
+    const double c_p = (double)ratio * (double)c_n, mean_c = (c_p + (double)c_n) * 0.5;
+    const double lim = 9.21024036697585;                              // |logit(1e-4)|
+    double tr = tau_raw[0] / tau_max;
+    tr = tr < -lim ? -lim : (tr > lim ? lim : tr);
+    tau_raw[0] = tau_max * tr;
+    ep[REN_EP_CP] = c_p; ep[REN_EP_CN] = (double)c_n; ep[REN_EP_RAW] = (double)raw;
+    ep[REN_EP_TAU] = tau_max * (1.0 / (1.0 + exp(-tr)));
+    ep[REN_EP_INV_C] = 1.0 / mean_c; ep[REN_EP_INV_C2] = 1.0 / (mean_c * mean_c);
+    ep[REN_EP_TAU_RAW] = tau_raw[0];
+}
+
+// torch.optim.Adam on the float64 raw refractory period (its own group, lr = tau_max x relative lr: robust_e_nerf.py:804-807)
+// from d loss / d tau: tau = tau_max sigmoid(raw / tau_max)  =>  d tau / d raw = s (1 - s).  state = {exp_avg, exp_avg_sq}.
+__global__ void tau_adam_kernel(double *__restrict__ tau_raw, double *__restrict__ tau_grad, double *__restrict__ state, double tau_max,
+                                double lr, double beta1, double beta2, double eps, double bc1, double bc2, double grad_scale) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double s = 1.0 / (1.0 + exp(-tau_raw[0] / tau_max));
+    const double g = tau_grad[0] * grad_scale * s * (1.0 - s);
+    const double m = beta1 * state[0] + (1.0 - beta1) * g, v = beta2 * state[1] + (1.0 - beta2) * g * g;
+    state[0] = m; state[1] = v;
+    tau_raw[0] -= lr / bc1 * m / (sqrt(v) / sqrt(bc2) + eps);
+    tau_grad[0] = 0.0;
+}
+
 }  // namespace
+
+extern "C" int ren_event_params_refresh(const float *ct_raw, float c_n, double *tau_raw, double tau_max, double *event_params,
+                                        void *stream) {
+    if (!ct_raw || !tau_raw || !event_params || !(tau_max > 0.0)) return REN_ERR_BAD_ARG;
+    hipLaunchKernelGGL(event_params_refresh_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ct_raw, c_n, tau_raw, tau_max,
+                       event_params);
+    REN_CHECK_LAUNCH();
+}
+
+extern "C" int ren_tau_adam_step(double *tau_raw, double *tau_grad, double *state, double tau_max, double lr, double beta1,
+                                 double beta2, double eps, int64_t step, double grad_scale, void *stream) {
+    if (!tau_raw || !tau_grad || !state || step < 1 || !(tau_max > 0.0)) return REN_ERR_BAD_ARG;
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    hipLaunchKernelGGL(tau_adam_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, tau_raw, tau_grad, state, tau_max, lr, beta1,
+                       beta2, eps, bc1, bc2, grad_scale);
+    REN_CHECK_LAUNCH();
+}
 
 extern "C" int ren_rate_epilogue(const float *colors, const float *colords, const float *opacities, const uint8_t *channel_idx,
                                  int32_t C, int64_t n, float min_modeled_intensity, float *intensity, float *intensity_dot,
@@ -436,7 +496,8 @@ extern "C" int ren_event_prepare(const int64_t *start_ts, const int64_t *end_ts,
                                  const int64_t *num_neg, const double *u_ts_diff, const double *u_diff_start,
                                  const double *u_grad, int64_t B, float c_p, float c_n, double tau, double *ts_start,
                                  double *ts_end, float *target_diff, double *ts_grad, float *target_grad,
-                                 double *dts_start, double *dts_end, double *dts_grad, void *stream) {
+                                 double *dts_start, double *dts_end, double *dts_grad, const double *event_params,
+                                 void *stream) {
     if (!start_ts || !end_ts || !num_pos || !num_neg || !u_ts_diff || !u_diff_start || !ts_start || !ts_end ||
         !target_diff || B < 0)
         return REN_ERR_BAD_ARG;
@@ -444,7 +505,7 @@ extern "C" int ren_event_prepare(const int64_t *start_ts, const int64_t *end_ts,
         return REN_ERR_BAD_ARG;
     if (B == 0) return REN_OK;
     PrepArgs a{start_ts, end_ts, num_pos, num_neg, u_ts_diff, u_diff_start, u_grad, B, c_p, c_n, tau,
-               ts_start, ts_end, ts_grad, dts_start, dts_end, dts_grad, target_diff, target_grad};
+               ts_start, ts_end, ts_grad, dts_start, dts_end, dts_grad, target_diff, target_grad, event_params};
     hipLaunchKernelGGL(event_prepare_kernel, dim3(ren_blocks(B, 256)), dim3(256), 0, (hipStream_t)stream, a);
     REN_CHECK_LAUNCH();
 }
@@ -453,13 +514,13 @@ extern "C" int ren_event_param_grad(int32_t kind, int32_t err_fn, int32_t param_
                                     const uint8_t *valid, const int64_t *start_ts, const int64_t *end_ts,
                                     const int64_t *num_pos, const int64_t *num_neg, const double *u_ts_diff, int64_t B,
                                     float c_p, float c_n, float raw_ratio, double tau, float weight, float *ct_grad,
-                                    double *tau_grad, void *stream) {
+                                    double *tau_grad, const double *event_params, void *stream) {
     if (kind < 0 || kind > 1 || err_fn < 0 || err_fn > 2 || param_weight_power < 0 || param_weight_power > 2)
         return REN_ERR_BAD_ARG;
     if (!pred || !start_ts || !end_ts || !num_pos || !num_neg || (kind == 0 && !u_ts_diff) || B < 0) return REN_ERR_BAD_ARG;
     if (B == 0 || (!ct_grad && !tau_grad)) return REN_OK;
     ParamGradArgs a{pred, valid, start_ts, end_ts, num_pos, num_neg, u_ts_diff, B, kind, err_fn, param_weight_power,
-                    c_p, c_n, raw_ratio, weight, tau, ct_grad, tau_grad};
+                    c_p, c_n, raw_ratio, weight, tau, ct_grad, tau_grad, event_params};
     hipLaunchKernelGGL(event_param_grad_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
     REN_CHECK_LAUNCH();
 }
@@ -505,14 +566,15 @@ extern "C" int ren_event_diff_loss_fwd(const float *colors, const float *opaciti
 
 extern "C" int ren_event_diff_loss_bwd(const float *colors, const float *opacities, const uint8_t *channel_idx, int32_t C,
                                        float min_intensity, const float *target, int32_t use_validity, int64_t B,
-                                       int32_t err_fn, float scale, const float *loss_sum, float *g_colors,
-                                       float *intensity, float *pred, uint8_t *valid, float *loss, void *stream) {
+                                       int32_t err_fn, float scale, const double *scale_dev, const float *loss_sum,
+                                       float *g_colors, float *intensity, float *pred, uint8_t *valid, float *loss,
+                                       void *stream) {
     if (!colors || !target || !loss_sum || !g_colors || B < 0 || err_fn < 0 || err_fn > 2 || (C != 1 && C != 3))
         return REN_ERR_BAD_ARG;
     if (use_validity && !opacities) return REN_ERR_BAD_ARG;
     const DiffLossArgs a{colors, opacities, target, channel_idx, B, C, err_fn, use_validity, min_intensity};
     hipLaunchKernelGGL(diff_loss_bwd_kernel, dim3(ren_blocks(B > 0 ? B : 1, 256)), dim3(256), 0, (hipStream_t)stream, a, scale,
-                       loss_sum, g_colors, intensity, pred, valid, loss);
+                       scale_dev, loss_sum, g_colors, intensity, pred, valid, loss);
     REN_CHECK_LAUNCH();
 }
 

@@ -16,6 +16,8 @@ from typing import Dict, Optional, Sequence, Tuple
 
 import contextlib
 import dataclasses
+import operator
+import os
 import threading
 import torch
 
@@ -58,6 +60,10 @@ class RenderCfg:
     dp_overlap: bool = True            # data parallel: all-reduce the fine levels' table gradient beside the coarse levels' scatter
     dp_split_level: int = 8            # levels >= this one go first (8 x 4 MiB of the 50 MB buffer)
     dp_compress: Optional[str] = None  # "bf16": parameter gradients cross the links as bfloat16 (strong scaling), aux block stays fp32
+    device_counts: Optional[bool] = None   # occupancy sampler: the sample counts of a training render stay on the device and the
+                                       # rest of the step is enqueued over arrays of an estimated capacity (the reference reads both
+                                       # counts back in the middle of every render: external/utils.py:106-119, models/nerf.py:279-286;
+                                       # SURVEY 7.2 H4).  None = auto: on for the Trainer's renders on one GPU (Trainer.device_counts_ok)
     mlp_bf16: bool = False             # BASELINE configs[2]: bf16 MLP (rounded linear inputs/weights, fp32 accumulate), fp32 composite
     # activation alternatives of the YAML (model.nerf.ngp.mlp_base / mlp_head: models/nerf.py:8-29).  Anything but the
     # shipped values runs on the exact-f32 MLP kernels (mlp_kernels is switched to "f32"): arch ngp only
@@ -184,6 +190,9 @@ class Packed:
     n: int
     n_marched: int = 0
     feat: Optional[torch.Tensor] = None         # hash features of these samples, when the density pre-pass made them
+    n_dev: Optional[torch.Tensor] = None        # device-side counts: `n` is then the CAPACITY of the arrays (it sizes the launches),
+                                                # the number of samples that exist is n_dev[0] (int64 on the device)
+    log: Optional["CountLog"] = None            # where the host will find the counts (and whether they fitted)
 
 
 def _adopt(v, stream):
@@ -200,6 +209,72 @@ def _adopt(v, stream):
             _adopt(x, stream)
     elif isinstance(v, Packed):
         _adopt((v.ray_indices, v.t_starts, v.t_ends, v.offsets, v.counts, v.feat), stream)
+
+
+class CountLog:
+    """The two sample counts of one render sampled with device-side counts -- marched, kept -- and whether they fitted the
+    capacities the arrays were given: copied to pinned memory behind the sampling kernels.  wait() blocks the host until
+    THOSE kernels are done (an event), not until the queue is empty."""
+
+    def __init__(self, n_rays: int, caps, stats: torch.Tensor, pinned: torch.Tensor):
+        self.n_rays, self.caps = n_rays, caps
+        pinned.copy_(stats, non_blocking=True)
+        self._pinned = pinned
+        self.ev = torch.cuda.Event()
+        self.ev.record()
+        self.values = None                       # (marched, overflowed, kept, overflowed)
+
+    def wait(self):
+        if self.values is None:
+            self.ev.synchronize()
+            self.values = tuple(int(v) for v in self._pinned.tolist())
+        return self.values
+
+    @property
+    def overflowed(self) -> bool:
+        v = self.wait()
+        return bool(v[1] or v[3])
+
+
+class DeviceCount:
+    """A sample count that may still be on the device: int(), float(), arithmetic and comparisons resolve it (CountLog.wait)."""
+
+    def __init__(self, log: CountLog, which: int):
+        self._log, self._which = log, which
+
+    def __int__(self):
+        return self._log.wait()[self._which]
+
+    __index__ = __int__
+
+    def __float__(self):
+        return float(int(self))
+
+    def __repr__(self):
+        return f"DeviceCount({int(self)})" if self._log.values is not None else "DeviceCount(<on the device>)"
+
+    def __format__(self, spec):
+        return format(int(self), spec)
+
+    def __hash__(self):
+        return hash(int(self))
+
+    def __bool__(self):
+        return int(self) != 0
+
+
+def _dc_binop(fn, reflected: bool):
+    def f(self, other):
+        o = int(other) if isinstance(other, DeviceCount) else other
+        return fn(o, int(self)) if reflected else fn(int(self), o)
+    return f
+
+
+for _n in ("add", "sub", "mul", "truediv", "floordiv", "mod"):
+    setattr(DeviceCount, f"__{_n}__", _dc_binop(getattr(operator, _n), False))
+    setattr(DeviceCount, f"__r{_n}__", _dc_binop(getattr(operator, _n), True))
+for _n in ("eq", "ne", "lt", "le", "gt", "ge"):
+    setattr(DeviceCount, f"__{_n}__", _dc_binop(getattr(operator, _n), False))
 
 
 _PINNED = threading.local()             # per host thread: two renderers may read counts from two threads at once
@@ -244,6 +319,10 @@ class Renderer:
         self._fwd_streams = None
         self._bwd_stream = None
         self._reuse_prepass_feat = True             # the differentiable pass reuses the pre-pass hash features
+        # device-side sample counts (RenderCfg.device_counts): samples per ray (marched, kept) the capacities are derived from,
+        # learnt from the renders themselves -- the first one reads its counts on the host -- and a ring of pinned buffers
+        self._spr = None
+        self._count_ring, self._count_ring_at = None, 0
         self._act_code = ops.activation_code(cfg.base_hidden_activation, cfg.density_activation, cfg.head_hidden_activation,
                                              cfg.radiance_activation)
         if self._act_code != 0 and isinstance(fld, NGPField):
@@ -282,15 +361,83 @@ class Renderer:
         offsets, total = ops.exclusive_scan(counts)
         return dict(args=args, cache=cache, counts=counts, offsets=offsets, total=total, mode=mode)
 
+    # ---- device-side sample counts -----------------------------------------------------------------------------------
+    CAP_MARGIN, CAP_SLACK, CAP_MAX = 1.25, 4096, 1 << 23      # (from 2^23 samples on the chunked two-stream paths take over)
+
+    def device_counts_ok(self) -> bool:
+        """the kernels that take the count from the device: occupancy sampler, NGP field on the bf16-matrix-core MLP
+        kernels, binned scatter"""
+        c = self.cfg
+        return (c.device_counts is not False and c.sampler == "occgrid" and type(self) is Renderer and c.mlp_kernels == "x" and
+                c.binned_scatter and self.field.flat.is_cuda and self.grad_sync is None)
+
+    def _capacities(self, n_rays: int):
+        if self._spr is None:
+            return None
+        def bucket(x):                                   # 8 sizes per octave: the allocator sees repeating sizes while
+            q = max(1024, 1 << max(0, x.bit_length() - 4))      # the ray count drifts (update_train_batch_size)
+            return (x + q - 1) // q * q
+        caps = tuple(bucket(int(n_rays * s * self.CAP_MARGIN) + self.CAP_SLACK) for s in self._spr)
+        return None if max(caps) >= self.CAP_MAX else caps
+
+    def _learn_counts(self, n_rays: int, marched: int, kept: int):
+        """capacities follow the counts: up at once, down slowly (the occupancy grid prunes over the first epochs)"""
+        m = (marched / max(n_rays, 1), kept / max(n_rays, 1))
+        self._spr = m if self._spr is None else tuple(max(a, 0.75 * b + 0.25 * a) for a, b in zip(m, self._spr))
+
+    def _count_log(self, n_rays: int, caps, stats: torch.Tensor) -> CountLog:
+        if self._count_ring is None:
+            self._count_ring = [torch.empty(4, dtype=torch.int64).pin_memory() for _ in range(16)]
+            self._count_logs = [None] * 16
+        k = self._count_ring_at = (self._count_ring_at + 1) % 16
+        if self._count_logs[k] is not None:
+            self._count_logs[k].wait()                       # (its pinned buffer is about to be reused)
+        log = self._count_logs[k] = CountLog(n_rays, caps, stats, self._count_ring[k])
+        return log
+
+    def _sample_device_counts(self, o, d, st, caps, keep_feat: bool) -> Packed:
+        """sample() without a host read: both counts stay on the device, every array has a capacity, two guards clear the
+        render (and report it) should a count not fit"""
+        c = self.cfg
+        args, cache, counts, offsets = st["args"], st["cache"], st["counts"], st["offsets"]
+        cap0, cap1 = caps
+        dev = o.device
+        stats = torch.empty(4, device=dev, dtype=torch.int64)
+        nd = torch.empty(2, device=dev, dtype=torch.int64)
+        n0_dev, n1_dev = nd[0:1], nd[1:2]
+        ops.count_guard(counts, st["total"], cap0, n0_dev, stats[0:2])
+        ri, ts, te = ops.ray_march_write(*args, offsets, cap0, counts=counts, cache=cache)
+        keep_feat = keep_feat and self._reuse_prepass_feat
+        sigma = self._density_stream(o, d, (ri, ts, te), cap0, keep_feat, n_dev=n0_dev)
+        feat0 = None
+        if keep_feat:
+            sigma, feat0 = sigma
+        keep, kept = ops.visibility(offsets, counts, sigma, ts, te, c.early_stop_eps, c.alpha_thre)
+        new_offsets, total2 = ops.exclusive_scan(kept)
+        ops.count_guard(kept, total2, cap1, n1_dev, stats[2:4], counts_also=counts)
+        ri2, ts2, te2 = ops.compact_samples(offsets, counts, new_offsets, keep, ts, te, cap1)
+        feat1 = ops.compact_features(offsets, counts, new_offsets, keep, feat0, cap1, n_dev=n1_dev) if feat0 is not None else None
+        log = self._count_log(o.shape[0], caps, stats)
+        return Packed(ri2, ts2, te2, new_offsets, kept, cap1, cap0, feat1, n_dev=n1_dev, log=log)
+
     def sample(self, o, d, jitter: Optional[torch.Tensor], training: bool, keep_feat: bool = False,
-               begun: Optional[dict] = None) -> Packed:
+               begun: Optional[dict] = None, device_counts=False) -> Packed:
+        """device_counts: True -- the caller (Trainer) can work with counts that stay on the device (Packed.n_dev / Packed.log);
+        "learn" -- host-side counts as ever, but the capacities of later renders learn from them"""
         c = self.cfg
         st = begun if begun is not None else self.sample_begin(o, d, jitter, training)
         args, cache, counts, offsets, mode = st["args"], st["cache"], st["counts"], st["offsets"], st["mode"]
+        learn = device_counts and mode == 0 and self.device_counts_ok()
+        if learn and device_counts is True and "n0" not in st:
+            caps = self._capacities(o.shape[0])
+            if caps is not None:
+                return self._sample_device_counts(o, d, st, caps, keep_feat)
         # host sync, as in the reference (external/utils.py:106-119); `begun["n0"]`: already read back (Trainer.prefetch)
         n0 = st["n0"] if "n0" in st else _host_int(st["total"])
         ri, ts, te = ops.ray_march_write(*args, offsets, n0, counts=counts, cache=cache)
         if mode == 1 or n0 == 0:
+            if learn:
+                self._learn_counts(o.shape[0], n0, n0)
             return Packed(ri, ts, te, offsets, counts, n0, n0)
         # sigma_fn pre-pass (external/utils.py:68-81) + render_visibility
         keep_feat = keep_feat and self._reuse_prepass_feat and c.mlp_kernels == "x"
@@ -305,6 +452,8 @@ class Renderer:
         feat1 = None
         if feat0 is not None and n1 > 0:                     # the pre-pass already encoded every survivor
             feat1 = feat0 if n1 == n0 else ops.compact_features(offsets, counts, new_offsets, keep, feat0, n1)
+        if learn:
+            self._learn_counts(o.shape[0], n0, n1)
         return Packed(ri2, ts2, te2, new_offsets, kept, n1, n0, feat1)
 
     # ---- field evaluation over a packed sample stream (overridden by vanilla.VanillaRenderer) ----------
@@ -314,12 +463,12 @@ class Renderer:
         m = self.field.mlp
         return m.to(torch.bfloat16).to(torch.float32) if self.cfg.mlp_bf16 else m
 
-    def _density_stream(self, o, d, samples, n, return_feat: bool = False):
+    def _density_stream(self, o, d, samples, n, return_feat: bool = False, n_dev=None):
         feat = ops.hashgrid_fwd(self.field.grid, self.field.table, scene=self.scene, rays=(o, d),
-                                samples=samples, n=n, layout=1)
+                                samples=samples, n=n, layout=1, n_dev=n_dev)
         if self.cfg.mlp_kernels == "x":
             _, sigma, _, _ = ops.mlp_fwd_x(self.field.mlp, self.field.C, self._xmode(), feat, self.scene, rays=(o, d),
-                                           samples=samples, n=n, density_only=True, act=self._act_code)
+                                           samples=samples, n=n, density_only=True, act=self._act_code, n_dev=n_dev)
             return (sigma, feat) if return_feat else sigma
         _, sigma, _ = ops.mlp_fwd(self._mlp_params(), self.field.C, feat, self.scene, rays=(o, d),
                                   samples=samples, n=n, density_only=True, bf16=self.cfg.mlp_bf16, act=self._act_code)
@@ -355,13 +504,13 @@ class Renderer:
         f = self.field
         samples = (pk.ray_indices, pk.t_starts, pk.t_ends)
         chunks = min(self.cfg.fwd_chunks, pk.n >> 20) if pk.n >= (1 << 23) else 1   # pays from ~8 M samples, >= 1 M per chunk
-        if self.cfg.mlp_kernels == "x" and chunks > 1 and pk.feat is None:
+        if self.cfg.mlp_kernels == "x" and chunks > 1 and pk.feat is None and pk.n_dev is None:
             return self._field_forward_chunked(o, d, pk, save, chunks)
         feat = pk.feat if pk.feat is not None else \
-            ops.hashgrid_fwd(f.grid, f.table, scene=self.scene, rays=(o, d), samples=samples, n=pk.n, layout=1)
+            ops.hashgrid_fwd(f.grid, f.table, scene=self.scene, rays=(o, d), samples=samples, n=pk.n, layout=1, n_dev=pk.n_dev)
         if self.cfg.mlp_kernels == "x":
             rgb, sigma, base, acts = ops.mlp_fwd_x(f.mlp, f.C, self._xmode(), feat, self.scene, rays=(o, d), samples=samples,
-                                                   n=pk.n, save=save, save_acts=self._save_acts(), act=self._act_code)
+                                                   n=pk.n, save=save, save_acts=self._save_acts(), act=self._act_code, n_dev=pk.n_dev)
             return rgb, sigma, dict(feat=feat, base=base, acts=acts, xmode=self._xmode() if save else None)
         mp = self._mlp_params()
         if save and self._save_acts():
@@ -473,7 +622,7 @@ class Renderer:
     def _field_backward(self, ctx, d_rgb, d_sig, final: bool = False):
         f, pk = self.field, ctx["pk"]
         K = min(self.cfg.bwd_chunks, pk.n >> 21) if pk.n >= (1 << 23) else 1     # pays from ~8 M samples, >= 2 M per chunk
-        if (K > 1 and ctx.get("xmode") is not None and self.cfg.binned_scatter and
+        if (K > 1 and ctx.get("xmode") is not None and self.cfg.binned_scatter and pk.n_dev is None and
                 not (final and self.dp_early_slice() is not None)):
             return self._field_backward_chunked(ctx, d_rgb, d_sig, K)
         samples = (pk.ray_indices, pk.t_starts, pk.t_ends)
@@ -481,7 +630,7 @@ class Renderer:
         if ctx.get("xmode") is not None:
             dfeat = ops.mlp_bwd_x(f.mlp, f.C, ctx["xmode"], ctx["feat"], ctx["base"], ctx["acts"], self.scene,
                                   rays=(ctx["o"], ctx["d"]), samples=samples, n=pk.n, rgb=ctx["rgb"], d_rgb=d_rgb,
-                                  d_sigma=d_sig, grad_mlp_params=f.g_mlp, workspace=self._ws, act=self._act_code)
+                                  d_sigma=d_sig, grad_mlp_params=f.g_mlp, workspace=self._ws, act=self._act_code, n_dev=pk.n_dev)
         elif ctx.get("acts") is not None:
             dfeat = ops.mlp_bwd_saved(mp, f.C, ctx["feat"], ctx["base"], ctx["acts"], self.scene, rays=(ctx["o"], ctx["d"]),
                                       samples=samples, n=pk.n, rgb=ctx["rgb"], d_rgb=d_rgb, d_sigma=d_sig,
@@ -493,7 +642,7 @@ class Renderer:
                                 bf16=self.cfg.mlp_bf16 and mp is not None, act=self._act_code)
         if self.cfg.binned_scatter:
             self._binned_workspace(pk.n, dfeat.device)
-            kw = dict(scene=self.scene, rays=(ctx["o"], ctx["d"]), samples=samples, n=pk.n, layout=1)
+            kw = dict(scene=self.scene, rays=(ctx["o"], ctx["d"]), samples=samples, n=pk.n, layout=1, n_dev=pk.n_dev)
             if final and self.dp_early_slice() is not None:
                 # last backward of the step under data parallelism: fine levels first, their slice of the table gradient
                 # is all-reduced while the coarse levels are scattered
@@ -509,9 +658,9 @@ class Renderer:
 
     # ---- forward render ---------------------------------------------------------------------------
     def forward(self, o, d, jitter=None, bkgd: Optional[torch.Tensor] = None, training: bool = True,
-                save: bool = True, begun: Optional[dict] = None):
+                save: bool = True, begun: Optional[dict] = None, device_counts: bool = False):
         f = self.field
-        pk = self.sample(o, d, jitter, training, keep_feat=True, begun=begun)
+        pk = self.sample(o, d, jitter, training, keep_feat=True, begun=begun, device_counts=device_counts)
         n_rays = o.shape[0]
         if pk.n == 0:
             colors = torch.zeros(n_rays, f.C, device=o.device)
@@ -657,22 +806,30 @@ class Trainer:
         self.tab_ts = tab_ts.to(dev).contiguous()
         self.tab_pos = tab_pos.to(dev, torch.float32).contiguous()
         self.tab_quat = tab_quat.to(dev, torch.float32).contiguous()
-        # C_p / C_n ratio and refractory period are frozen on this path (configs/train/synthetic.yaml:
-        # 31-36), so their parametrisations are evaluated once on the host:
+        # Event-generation parameters (event_generation_params.py:51-84,162-203): evaluated here on the host as the reference
+        # does in float32 / float64, then DEVICE-RESIDENT (self.ep, ops.EP_*): every kernel takes C_p, C_n, tau and the 1 / C^k
+        # param weight from that block, and a trainable ratio / refractory period is stepped and re-evaluated on the device
+        # (ren_tau_adam_step, ren_event_params_refresh), so no launch of the next step waits for a host read of a parameter.
+        # The host-side attributes (c_p, mean_c, tau, ct_raw, tau_raw) are read back on demand.
         ratio = torch.nn.functional.softplus(p2n_raw.detach().cpu().to(torch.float32))   # event_generation_params.py:51-70
         neg = neg_ct.detach().cpu().to(torch.float32)
-        self.c_p, self.c_n = float(ratio * neg), float(neg)
-        self.mean_c = float((ratio * neg + neg) / 2)
+        c_p, self.c_n = float(ratio * neg), float(neg)
+        mean_c = float((ratio * neg + neg) / 2)
         traw, tmax = tau_raw.detach().cpu().to(torch.float64), tau_max.detach().cpu()
         lim = torch.tensor(1e-4, dtype=torch.float64).logit().abs()
         traw = tmax * (traw / tmax).clamp(-lim, lim)                          # :170-185
-        self.tau = float(tmax * torch.sigmoid(traw / tmax))                   # modules.py:58-74 (float64)
-        # trainable refractory period: a float64 scalar (event_generation_params.py:162-164) kept on the
-        # host side of the step -- its gradient is assembled from per-ray forward-mode tangents dI/dt.
-        self.tau_raw = traw.clone().requires_grad_(False)
+        tau = float(tmax * torch.sigmoid(traw / tmax))                        # modules.py:58-74 (float64)
         self.tau_max = tmax.to(torch.float64)
+        self._tau_shape = tuple(traw.shape)
+        ct_raw = float(p2n_raw.detach().reshape(-1)[0].to(torch.float32))
+        self._ep_host = [c_p, self.c_n, ct_raw, tau, 1.0 / mean_c, 1.0 / mean_c ** 2, float(traw.reshape(-1)[0]), 0.0]
+        self._ep_stale = False
+        self.ep = torch.tensor(self._ep_host, dtype=torch.float64, device=dev)
+        # trainable refractory period: a float64 scalar (event_generation_params.py:162-164); its gradient is assembled from
+        # per-ray forward-mode tangents dI/dt, its Adam group (state: exp_avg, exp_avg_sq) lives on the device as well
+        self._tau_raw_dev = traw.reshape(1).clone().to(dev)
         self._tau_grad_dev = torch.zeros(1, dtype=torch.float64, device=dev)   # d loss / d tau, accumulated on the device
-        self._tau_opt = None
+        self._tau_adam, self._tau_adam_steps = torch.zeros(2, dtype=torch.float64, device=dev), 0
         # small-parameter block: [bkgd_raw (C) | pad] with its own Adam state (group "others", lr default)
         self.small = torch.zeros(4, device=dev, dtype=torch.float32)
         self.small[: renderer.field.C] = bkgd_raw.to(dev, torch.float32).reshape(-1)
@@ -695,38 +852,98 @@ class Trainer:
             self.sync = parallel.GradSync(process_group, world_size, compress=renderer.cfg.dp_compress)
             renderer.grad_sync = self.sync
         self._mean_s_dev = None                                  # samples / ray of this step, summed over ranks (device)
+        # device-side sample counts (RenderCfg.device_counts): the renders of the step in flight whose counts the host has
+        # not looked at yet, and how to repeat them should one not have fitted its arrays
+        self.device_counts: Optional[bool] = None                # None: auto (device_counts_ok)
+        if os.environ.get("REN_DEVICE_COUNTS", "") in ("0", "off"):  # A/B switch for scripts that build the trainer themselves
+            self.device_counts = False
+        self._dc_calls, self._dc_sync = [], False
         self.lr_scale = 1.0
         # trainable C_p / C_n ratio (softplus-parametrised scalar, its own Adam group with lr 0.1:
         # robust_e_nerf.py:800-803).  Its loss dependence is through the per-event targets and the 1/C^k
         # normalisation only, i.e. O(B) elementwise work on already rendered predictions.
         self.ct = torch.zeros(4, device=dev, dtype=torch.float32)
         self.ct[0] = p2n_raw.detach().reshape(-1)[0].to(dev, torch.float32)
-        self.ct_raw = float(p2n_raw.detach().reshape(-1)[0])
         self.ct_grad, self.ct_m, self.ct_v = torch.zeros_like(self.ct), torch.zeros_like(self.ct), torch.zeros_like(self.ct)
-        self._ct_read_key = None
+
+    # ---- host views of the device-resident event parameters (a read-back when they have moved since the last look) ----
+    def _ep(self):
+        if self._ep_stale:
+            self._ep_host, self._ep_stale = self.ep.tolist(), False
+        return self._ep_host
+
+    c_p = property(lambda self: self._ep()[ops.EP_CP])
+    mean_c = property(lambda self: (self._ep()[ops.EP_CP] + self._ep()[ops.EP_CN]) / 2)
+    tau = property(lambda self: self._ep()[ops.EP_TAU])
+    ct_raw = property(lambda self: self._ep()[ops.EP_RAW])
+
+    @property
+    def tau_raw(self) -> torch.Tensor:
+        """the raw refractory period (float64, host copy, shaped like the constructor's tau_raw)"""
+        return self._tau_raw_dev.cpu().reshape(self._tau_shape)
+
+    def _refresh_event_params(self):
+        ops.event_params_refresh(self.ct, self.c_n, self._tau_raw_dev, float(self.tau_max), self.ep)
+        self._ep_stale = True
+
+    def _pw_dev(self, kind):
+        """device scalar of the param weight 1 / C^k (loss.param_weight.*, robust_e_nerf.py:470-486), None for k = 0"""
+        return {None: None, "mean_contrast_reciprocal": self.ep[ops.EP_INV_C: ops.EP_INV_C + 1],
+                "mean_contrast_reciprocal_sq": self.ep[ops.EP_INV_C2: ops.EP_INV_C2 + 1]}[kind]
+
+    def device_counts_ok(self) -> bool:
+        """Renders of this trainer keep their sample counts on the device: one GPU (a repeated step would issue its
+        collectives twice), and what Renderer.device_counts_ok asks for.  Trainer.step switches it off under gradient
+        accumulation (repeating a micro-batch would have to restore the gradients of the ones before it)."""
+        return self.device_counts is not False and self.world_size == 1 and self.r.device_counts_ok()
+
+    def _dc_mode(self):
+        """what this step's renders pass to Renderer.sample: True (counts stay on the device), "learn" (host counts, but the
+        capacities learn from them) or False"""
+        if not self.device_counts_ok():
+            return False
+        return "learn" if self._dc_sync else True
+
+    def resolve_device_counts(self):
+        """Look at the counts of the renders enqueued since the last optimiser step (a wait for their SAMPLING kernels: the
+        rest of the step is still running).  A render whose count did not fit its arrays came out empty: then the step's
+        gradients are discarded and its passes run again with host-side counts, before anything reads the gradients."""
+        calls, self._dc_calls = self._dc_calls, []
+        over = False
+        for _, _, holder in calls:
+            for log in holder[2]:
+                v = log.wait()
+                over = over or log.overflowed
+                if not (v[1] or v[3]):
+                    self.r._learn_counts(log.n_rays, v[0], v[2])
+        if not over:
+            return False
+        f = self.r.field
+        f.grad.zero_()
+        if getattr(f, "n_wn_g", 0):
+            f.g_mlp.zero_()
+        self.small_grad.zero_()
+        self.ct_grad.zero_()
+        self._tau_grad_dev.zero_()
+        self._dc_sync = True
+        self._grad_begun = self._grad_pending = None
+        try:
+            for kind, args, holder in calls:
+                fn = self.forward_backward if kind == "diff" else self.grad_loss_forward_backward
+                loss, aux = fn(*args)
+                holder[0].copy_(loss)                        # the tensors / dict the first attempt handed out now hold the
+                holder[1].update(aux)                        # repeated pass's results, and so do its DeviceCounts
+                for log in holder[2]:
+                    log.values = (int(aux.get("n_marched", log.values[0])), 0, int(aux["n"]), 0)
+        finally:
+            self._dc_sync = False
+        self.device_count_overflows = getattr(self, "device_count_overflows", 0) + 1
+        return True
 
     @property
     def tau_grad(self) -> torch.Tensor:
         """d loss / d tau accumulated so far (float64 scalar, host copy)"""
         return self._tau_grad_dev.cpu().reshape(())
-
-    def _refresh_tau(self):
-        if self.t.train_refractory_period:
-            lim = torch.tensor(1e-4, dtype=torch.float64).logit().abs()
-            with torch.no_grad():                                         # clamp_refractory_period (:170-185)
-                self.tau_raw.copy_(self.tau_max * (self.tau_raw / self.tau_max).clamp(-lim, lim))
-            self.tau = float(self.tau_max * torch.sigmoid(self.tau_raw.detach() / self.tau_max))
-
-    def _refresh_contrast_threshold(self):
-        if self.t.train_contrast_threshold:
-            key = (self.step_count, self.ct._version)          # the ratio moves with the optimiser step (or an explicit write) only:
-            if key == self._ct_read_key:                       # the step's second loss term does not read it back again
-                return
-            self._ct_read_key = key
-            raw = self.ct[0]
-            self.ct_raw, ratio = torch.stack([raw, torch.nn.functional.softplus(raw)]).tolist()   # one 8-byte host read per step
-            self.c_p = ratio * self.c_n
-            self.mean_c = (self.c_p + self.c_n) / 2
 
     # ---- Bayer sensor: every event sees one colour channel of the (., 3) render (`bayering`, robust_e_nerf.py:887-890)
     def _channel_index(self, batch, repeat: int):
@@ -755,23 +972,21 @@ class Trainer:
         event_generation_params.py:51-84,196-203, loss.py:32-74, robust_e_nerf.py:470-486)."""
         t = self.t
         err, w, pwk = (t.err_diff, t.w_diff, t.pw_diff) if kind == "diff" else (t.err_grad, t.w_grad, t.pw_grad)
-        ops.event_param_grad(kind, err, pwk, pred.contiguous(), valid, batch, self.c_p, self.c_n, self.ct_raw, self.tau, w,
+        ops.event_param_grad(kind, err, pwk, pred.contiguous(), valid, batch, 0.0, 0.0, 0.0, 0.0, w,
                              ct_grad=self.ct_grad if t.train_contrast_threshold else None,
-                             tau_grad=self._tau_grad_dev if t.train_refractory_period else None)
+                             tau_grad=self._tau_grad_dev if t.train_refractory_period else None, ep=self.ep)
 
     # ---- a2-a4: event correction + supervision timestamps: one launch (ren_event_prepare) ---------------------
     def _prepare(self, batch):
         B = batch["position"].shape[0]
-        p = ops.event_prepare(batch, self.c_p, self.c_n, self.tau)
+        p = ops.event_prepare(batch, 0.0, 0.0, 0.0, ep=self.ep)
         return p["ts"][:B], p["ts"][B:], p["target_diff"]
 
     # ---- the parameter-independent front of the l_diff step, and its prefetch ------------------------------------------
     def _front(self, batch, jitter_start, jitter_end) -> dict:
         """event correction -> supervision timestamps -> poses -> rays of the start and end renders (a2-a6)"""
         t = self.t
-        self._refresh_contrast_threshold()
-        self._refresh_tau()
-        prep = ops.event_prepare(batch, self.c_p, self.c_n, self.tau, with_dtau=t.train_refractory_period)
+        prep = ops.event_prepare(batch, 0.0, 0.0, 0.0, with_dtau=t.train_refractory_period, ep=self.ep)
         jitter = None
         if jitter_start is not None:
             # jitter_end None: jitter_start already holds the 2B uniforms of both renders (start rays first)
@@ -865,6 +1080,8 @@ class Trainer:
             final = not (self.t.w_grad > 0)
         r, t, f = self.r, self.t, self.r.field
         B = batch["position"].shape[0]
+        dc = self._dc_mode()
+        call = ("diff", (batch, jitter_start, jitter_end, final), [None, None, []])
         if f.flat.is_cuda:
             # everything enqueued so far (the last optimiser step, the occupancy-grid refresh, the batch) is what the sampling
             # of this step's third render depends on: grad_loss_forward_backward(early=True) waits for this point only
@@ -886,24 +1103,24 @@ class Trainer:
             if self._grad_pending is not None:                    # this render's count pass first, then the third render's front
                 begun = r.sample_begin(o, d, jitter, True)
                 self._begin_grad_now()
-            colors, colords, opac, ctx = jvp.render_forward(r, o, d, od, dd, jitter, bkgd, training=True, begun=begun)
+            colors, colords, opac, ctx = jvp.render_forward(r, o, d, od, dd, jitter, bkgd, training=True, begun=begun,
+                                                            device_counts=dc)
         else:
             o, d = front["o"], front["d"]
             if self._grad_pending is not None:
                 if front.get("begun") is None:
                     front["begun"] = r.sample_begin(o, d, jitter, True)
                 self._begin_grad_now()
-            colors, opac, depth, ctx = r.forward(o, d, jitter, bkgd, training=True, save=True, begun=front.get("begun"))
+            colors, opac, depth, ctx = r.forward(o, d, jitter, bkgd, training=True, save=True, begun=front.get("begun"),
+                                                 device_counts=dc)
         # a16 + a18: intensity epilogue, validity, Bayer channel, loss and its gradient: two launches (ren_event_diff_loss_*)
         if f.C > 1 and "channel_idx" not in batch:
             raise ValueError("radiance_dim 3 (Bayer sensor) needs batch['channel_idx'] (data.colorize_events)")
         chan = batch["channel_idx"].to(torch.uint8).contiguous() if f.C > 1 else None
-        inv_c = 1.0 / self.mean_c                                         # robust_e_nerf.py:470-486
-        pw = {None: 1.0, "mean_contrast_reciprocal": inv_c, "mean_contrast_reciprocal_sq": inv_c ** 2}[t.pw_diff]
-        scale = pw * t.w_diff
         need_param = t.train_contrast_threshold or t.train_refractory_period
-        L = ops.event_diff_loss(colors, opac, chan, target, t.err_diff, scale, r.cfg.min_modeled_intensity,
-                                use_validity=not t.bkgd_is_param, want_pred=need_param)
+        # loss weight x 1 / C^k (robust_e_nerf.py:470-486); the latter from the device block
+        L = ops.event_diff_loss(colors, opac, chan, target, t.err_diff, t.w_diff, r.cfg.min_modeled_intensity,
+                                use_validity=not t.bkgd_is_param, want_pred=need_param, scale_dev=self._pw_dev(t.pw_diff))
         loss, g_colors, inten = L["loss"], L["g_colors"], L["intensity"]
         i_s, i_e = inten[:B], inten[B:]
         if need_param:
@@ -921,8 +1138,12 @@ class Trainer:
         d_bk = r.backward(ctx, g_colors, final=final, per_ray_bkgd=True)
         if d_bk is not None:
             ops.bkgd_param_grad(d_bk, self.small, self.small_grad)       # += sigmoid(raw) * column sums (d softplus)
-        aux = dict(intensity_start=i_s, intensity_end=i_e, n=ctx["pk"].n, n_marched=ctx["pk"].n_marched,
-                   opacity=opac, rays=2 * B)
+        pk = ctx["pk"]
+        n, n_marched = (pk.n, pk.n_marched) if pk.log is None else (DeviceCount(pk.log, 2), DeviceCount(pk.log, 0))
+        aux = dict(intensity_start=i_s, intensity_end=i_e, n=n, n_marched=n_marched, opacity=opac, rays=2 * B)
+        if pk.log is not None:
+            call[2][:] = [loss, aux, [pk.log]]
+            self._dc_calls.append(call)
         return loss, aux
 
     def grad_sampling_mode(self) -> str:
@@ -950,9 +1171,7 @@ class Trainer:
         their time derivatives, ray/AABB test, march count pass, scan (robust_e_nerf.py:340-357,383-409)"""
         from . import jvp
         t = self.t
-        self._refresh_contrast_threshold()
-        self._refresh_tau()
-        prep = ops.event_prepare(batch, self.c_p, self.c_n, self.tau, with_grad_ts=True, with_dtau=t.train_refractory_period)
+        prep = ops.event_prepare(batch, 0.0, 0.0, 0.0, with_grad_ts=True, with_dtau=t.train_refractory_period, ep=self.ep)
         ts_g = prep["ts_grad"]
         ddd = None
         if t.train_refractory_period:                                  # tau moves ts_g: second-order tangent
@@ -991,11 +1210,12 @@ class Trainer:
         side.wait_event(ready)
         with torch.cuda.stream(side):
             fr = self._grad_front(batch, jitter_grad)
-            if self._n_host_grad is None:
-                self._n_host_grad = torch.empty(1, dtype=fr["st"]["total"].dtype).pin_memory()
-            self._n_host_grad.copy_(fr["st"]["total"].reshape(1), non_blocking=True)
-            fr["ev"] = torch.cuda.Event()
-            fr["ev"].record()
+            if not (self._dc_mode() is True and self.r._capacities(batch["position"].shape[0]) is not None):
+                if self._n_host_grad is None:                # (device-side counts: nothing to read back)
+                    self._n_host_grad = torch.empty(1, dtype=fr["st"]["total"].dtype).pin_memory()
+                self._n_host_grad.copy_(fr["st"]["total"].reshape(1), non_blocking=True)
+                fr["ev"] = torch.cuda.Event()
+                fr["ev"].record()
         fr["n_host"], fr["key"] = self._n_host_grad, (id(batch), id(jitter_grad))
         self._grad_begun = fr
 
@@ -1013,6 +1233,8 @@ class Trainer:
         from . import jvp
         r, t, f = self.r, self.t, self.r.field
         B = batch["position"].shape[0]
+        dc = self._dc_mode()
+        call = ("grad", (batch, jitter_grad, final, early), [None, None, []])
         ready, self._ready_ev = self._ready_ev, None
         begun, self._grad_begun, self._grad_pending = self._grad_begun, None, None
         if begun is not None and (not early or begun["key"] != (id(batch), id(jitter_grad))):
@@ -1030,7 +1252,7 @@ class Trainer:
             if "ev" in fr:                                                # count pass already ran: its total is in the pinned buffer
                 fr["ev"].synchronize()
                 st["n0"] = int(fr["n_host"][0])
-            pk = r.sample(o, d, jit, True, begun=st)
+            pk = r.sample(o, d, jit, True, begun=st, device_counts=dc)
             if early:
                 done = torch.cuda.Event()
                 done.record()
@@ -1045,11 +1267,8 @@ class Trainer:
         inten, intend, valid, dlog = jvp.rate_epilogue(colors, colords, opac, chan, r.cfg.min_modeled_intensity,
                                                        want_valid=not t.bkgd_is_param)
         loss_sum = jvp.grad_loss_fwd(inten, intend, target, valid, t.err_grad)
-        inv_c = 1.0 / self.mean_c
-        pw = {None: 1.0, "mean_contrast_reciprocal": inv_c, "mean_contrast_reciprocal_sq": inv_c ** 2}[t.pw_grad]
-        scale = pw * t.w_grad
-        loss = loss_sum[0] / loss_sum[1] * scale
-        g_i, g_id = jvp.grad_loss_bwd(inten, intend, target, valid, t.err_grad, scale, loss_sum)
+        g_i, g_id, loss = jvp.grad_loss_bwd(inten, intend, target, valid, t.err_grad, t.w_grad, loss_sum,
+                                            scale_dev=self._pw_dev(t.pw_grad), want_loss=True)
         if t.train_contrast_threshold or t.train_refractory_period:
             self._param_grad(batch, dlog, "grad", valid)
         if t.train_refractory_period:
@@ -1059,7 +1278,10 @@ class Trainer:
         d_bkgd = jvp.render_backward(r, ctx, self._unbayer(g_i, ch, f.C), self._unbayer(g_id, ch, f.C), final=final)
         if d_bkgd is not None:
             self.small_grad[: f.C] += d_bkgd * torch.sigmoid(self.small[: f.C])
-        aux = dict(intensity=inten, dlog_dt=dlog, n=ctx["pk"].n, rays=B)
+        aux = dict(intensity=inten, dlog_dt=dlog, n=pk.n if pk.log is None else DeviceCount(pk.log, 2), rays=B)
+        if pk.log is not None:
+            call[2][:] = [loss, aux, [pk.log]]
+            self._dc_calls.append(call)
         return loss, aux
 
     def optimizer_step(self, accumulate_grad_batches: int = 1, mean_samples_per_ray: Optional[float] = None):
@@ -1067,6 +1289,8 @@ class Trainer:
         background scalar (no decay).  Under data parallelism gradients are summed over ranks (RCCL
         all-reduce of the single flat buffer) and scaled by 1/world inside the Adam kernel."""
         f = self.r.field
+        if self._dc_calls:
+            self.resolve_device_counts()
         if getattr(f, "n_wn_g", 0):
             f.fold_grads()
         if self.world_size > 1:
@@ -1100,29 +1324,26 @@ class Trainer:
                       weight_decay=0.0, step=self.step_count, grad_scale=gs, zero_grad=True)
         if self.t.train_refractory_period:
             # float64 scalar, Adam group with lr = tau_max * relative lr (robust_e_nerf.py:804-807);
-            # tau = tau_max sigmoid(raw / tau_max)  =>  d tau / d raw = sigmoid'(raw / tau_max)
-            if self._tau_opt is None:
-                self.tau_raw.requires_grad_(True)
-                self._tau_opt = torch.optim.Adam([self.tau_raw], lr=float(self.tau_max) * self.t.relative_lr_refractory_period)
-            g = self.tau_grad                                                # the one host read of this group
-            sg = torch.sigmoid(self.tau_raw.detach() / self.tau_max)
-            self.tau_raw.grad = (g * gs * sg * (1 - sg)).to(torch.float64).reshape(self.tau_raw.shape)
-            for grp in self._tau_opt.param_groups:
-                grp["lr"] = float(self.tau_max) * self.t.relative_lr_refractory_period * self.lr_scale
-            self._tau_opt.step()
-            self._tau_grad_dev.zero_()
+            # tau = tau_max sigmoid(raw / tau_max)  =>  d tau / d raw = sigmoid'(raw / tau_max): one single-thread launch
+            self._tau_adam_steps += 1
+            ops.tau_adam_step(self._tau_raw_dev, self._tau_grad_dev, self._tau_adam, float(self.tau_max),
+                              lr=float(self.tau_max) * self.t.relative_lr_refractory_period * self.lr_scale, betas=self.t.betas,
+                              eps=self.t.eps, step=self._tau_adam_steps, grad_scale=gs)
         if self.t.train_contrast_threshold:
             ops.adam_step(self.ct, self.ct_grad, self.ct_m, self.ct_v, lr=self.t.lr_contrast_threshold * self.lr_scale,
                           betas=self.t.betas, eps=self.t.eps, weight_decay=0.0, step=self.step_count, grad_scale=gs,
                           zero_grad=True)
+        if self.t.train_refractory_period or self.t.train_contrast_threshold:
+            self._refresh_event_params()                     # clamp (:170-185), C_p, tau, 1 / C^k for the next step's kernels
 
     # ---- optimiser state for checkpoints (what ModelCheckpoint keeps under "optimizer_states": scripts/run.py:66-68) ----
     def optimizer_state_dict(self) -> Dict[str, object]:
         cpu = lambda t: t.detach().cpu().clone()
         sd = dict(step_count=self.step_count, exp_avg=cpu(self.m), exp_avg_sq=cpu(self.v), small_exp_avg=cpu(self.sm),
                   small_exp_avg_sq=cpu(self.sv), ct_exp_avg=cpu(self.ct_m), ct_exp_avg_sq=cpu(self.ct_v))
-        if self._tau_opt is not None:
-            sd["tau_adam"] = self._tau_opt.state_dict()
+        if self._tau_adam_steps:
+            m, v = self._tau_adam.tolist()
+            sd["tau_adam"] = dict(step=self._tau_adam_steps, exp_avg=m, exp_avg_sq=v)
         return sd
 
     def load_optimizer_state_dict(self, sd: Dict[str, object]):
@@ -1131,25 +1352,21 @@ class Trainer:
                          (self.sv, "small_exp_avg_sq"), (self.ct_m, "ct_exp_avg"), (self.ct_v, "ct_exp_avg_sq")):
             dst.copy_(sd[key].to(dst.device, dst.dtype))
         if "tau_adam" in sd:
-            self.tau_raw.requires_grad_(True)
-            self._tau_opt = torch.optim.Adam([self.tau_raw], lr=float(self.tau_max) * self.t.relative_lr_refractory_period)
-            self._tau_opt.load_state_dict(sd["tau_adam"])
+            ta = sd["tau_adam"]
+            if "state" in ta:                                # round <= 4 checkpoints: a torch.optim.Adam state dict
+                st = next(iter(ta["state"].values()), None)
+                ta = dict(step=int(st["step"]), exp_avg=float(st["exp_avg"]), exp_avg_sq=float(st["exp_avg_sq"])) if st else None
+            if ta:
+                self._tau_adam_steps = int(ta["step"])
+                self._tau_adam.copy_(torch.tensor([ta["exp_avg"], ta["exp_avg_sq"]], dtype=torch.float64))
 
     def load_event_params(self, p2n_raw: Optional[torch.Tensor] = None, tau_raw: Optional[torch.Tensor] = None):
         """restore the learned contrast-threshold ratio / refractory period (checkpoint resume)"""
         if p2n_raw is not None:
-            self._ct_read_key = None
             self.ct[0] = p2n_raw.detach().reshape(-1)[0].to(self.ct.device, torch.float32)
-            self.ct_raw = float(self.ct[0])
-            ratio = float(torch.nn.functional.softplus(self.ct[0]))
-            self.c_p = ratio * self.c_n
-            self.mean_c = (self.c_p + self.c_n) / 2
         if tau_raw is not None:
-            with torch.no_grad():
-                self.tau_raw.copy_(tau_raw.detach().to(torch.float64).reshape(self.tau_raw.shape))
-            lim = torch.tensor(1e-4, dtype=torch.float64).logit().abs()
-            tr_ = self.tau_max * (self.tau_raw.detach() / self.tau_max).clamp(-lim, lim)
-            self.tau = float(self.tau_max * torch.sigmoid(tr_ / self.tau_max))
+            self._tau_raw_dev.copy_(tau_raw.detach().to(torch.float64).reshape(1))
+        self._refresh_event_params()
 
     def update_train_batch_size(self, aux, eff_ray_sample_batch_size: int = 1 << 20, accumulate_grad_batches: int = 1,
                                 batch_index: int = 0) -> Optional[int]:
@@ -1196,16 +1413,30 @@ class Trainer:
         # an earlier pass would reduce it once per micro-batch (the rank-summed slice of micro-batch 1 would be summed
         # over the ranks again with micro-batch 2 on top) and the next scatter would write into a slice in flight
         last = (bi + 1) % k == 0
+        dc_was = self.device_counts
+        if k > 1:
+            self.device_counts = False
+        try:
+            return self._step(batch, jitter_start, jitter_end, jitter_grad, last, bi, k)
+        finally:
+            self.device_counts = dc_was
+
+    def _step(self, batch, jitter_start, jitter_end, jitter_grad, last, bi, k):
         mode = self.grad_sampling_mode()
         if mode == "begun":
             self.begin_grad_sampling(batch, jitter_grad)
         loss, aux = self.forward_backward(batch, jitter_start, jitter_end, final=last and not (self.t.w_grad > 0))
+        lg = None
         if self.t.w_grad > 0:
             lg, aux_g = self.grad_loss_forward_backward(batch, jitter_grad, final=last, early=mode != "inorder")
-            loss = loss + lg
-            aux = dict(aux, grad=aux_g)
+            aux["grad"] = aux_g
         if (bi + 1) % k == 0:
-            means = self._render_means(aux)
-            self.optimizer_step(k, mean_samples_per_ray=sum(means) / len(means))
+            mean = None
+            if self.world_size > 1:                          # (rides in the gradient all-reduce)
+                means = self._render_means(aux)
+                mean = sum(means) / len(means)
+            self.optimizer_step(k, mean_samples_per_ray=mean)
             aux["_mean_s_synced"] = self.world_size > 1
+        if lg is not None:
+            loss = loss + lg          # (after the optimiser step: a step repeated for its sample counts rewrites both terms)
         return loss, aux

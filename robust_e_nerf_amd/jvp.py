@@ -73,14 +73,14 @@ def render_forward2(r, o, d, od, dd, ddd, pk, bkgd):
     feat, featd, featdd = (torch.empty(nb * 1024, device=dev) for _ in range(3))
     check(lib.ren_hashgrid_fwd_jvp2(ctypes.byref(f.grid), _ptr(f.table), ctypes.byref(r.scene), _ptr(o), _ptr(d),
                                     _ptr(od), _ptr(dd), _ptr(ddd), _ptr(ri), _ptr(ts), _ptr(te), n, _ptr(feat),
-                                    _ptr(featd), _ptr(featdd), _stream()), "ren_hashgrid_fwd_jvp2")
+                                    _ptr(featd), _ptr(featdd), _ptr(pk.n_dev, torch.int64), _stream()), "ren_hashgrid_fwd_jvp2")
     rgb, rgbd, rgbdd = (torch.empty(n, f.C, device=dev) for _ in range(3))
     sg, sgd, sgdd = (torch.empty(n, device=dev) for _ in range(3))
     if r.cfg.mlp_kernels == "x":                            # bf16 matrix cores, in the step's precision mode
         check(lib.ren_mlp_fwd_jvp2_x(_ptr(f.mlp), f.C, r._act_code, r._xmode(), _ptr(feat), _ptr(featd), _ptr(featdd), ctypes.byref(r.scene),
                                      _ptr(o), _ptr(d), _ptr(od), _ptr(dd), _ptr(ddd), _ptr(ri), _ptr(ts), _ptr(te), n,
-                                     _ptr(rgb), _ptr(rgbd), _ptr(rgbdd), _ptr(sg), _ptr(sgd), _ptr(sgdd), _stream()),
-              "ren_mlp_fwd_jvp2_x")
+                                     _ptr(rgb), _ptr(rgbd), _ptr(rgbdd), _ptr(sg), _ptr(sgd), _ptr(sgdd), _ptr(pk.n_dev, torch.int64),
+                                     _stream()), "ren_mlp_fwd_jvp2_x")
     else:
         check(lib.ren_mlp_fwd_jvp2(_ptr(r._mlp_params()), f.C, r._act_code, _ptr(feat), _ptr(featd), _ptr(featdd), ctypes.byref(r.scene),
                                    _ptr(o), _ptr(d), _ptr(od), _ptr(dd), _ptr(ddd), _ptr(ri), _ptr(ts), _ptr(te), n,
@@ -93,13 +93,13 @@ def render_forward2(r, o, d, od, dd, ddd, pk, bkgd):
     return colors, colords, colorsdd
 
 
-def render_forward(r, o, d, od, dd, jitter, bkgd, training: bool = True, pk=None, begun=None):
+def render_forward(r, o, d, od, dd, jitter, bkgd, training: bool = True, pk=None, begun=None, device_counts: bool = False):
     """-> colors (R,C), colords (R,C) [d/dt], opacity (R,), ctx.  pk: the samples, when the caller has already placed them
     (engine.Trainer.grad_loss_forward_backward(early=True)); begun: Renderer.sample_begin() of these rays, already enqueued."""
     f, lib = r.field, _lib.load()
     if pk is None:
-        pk = r.sample(o, d, jitter, training, begun=begun)
-    n, R, dev = pk.n, o.shape[0], o.device
+        pk = r.sample(o, d, jitter, training, begun=begun, device_counts=device_counts)
+    n, R, dev = pk.n, o.shape[0], o.device               # (pk.n_dev: n is the capacity, the count is on the device)
     if n == 0:
         colors = torch.zeros(R, f.C, device=dev) + (bkgd if bkgd is not None else 0.0)
         return colors, torch.zeros(R, f.C, device=dev), torch.zeros(R, device=dev), dict(pk=pk, empty=True, bkgd=bkgd)
@@ -113,15 +113,15 @@ def render_forward(r, o, d, od, dd, jitter, bkgd, training: bool = True, pk=None
         feat = torch.empty(nb * 1024, device=dev)
         featd = torch.empty(nb * 1024, device=dev)
         check(lib.ren_hashgrid_fwd_jvp(ctypes.byref(f.grid), _ptr(f.table), ctypes.byref(r.scene), _ptr(o), _ptr(d),
-                                       _ptr(od), _ptr(dd), _ptr(ri), _ptr(ts), _ptr(te), n, _ptr(feat), _ptr(featd), None,
-                                       _stream()), "ren_hashgrid_fwd_jvp")
+                                       _ptr(od), _ptr(dd), _ptr(ri), _ptr(ts), _ptr(te), n, _ptr(feat), _ptr(featd),
+                                       _ptr(pk.n_dev, torch.int64), _stream()), "ren_hashgrid_fwd_jvp")
         rgb, rgbd = torch.empty(n, f.C, device=dev), torch.empty(n, f.C, device=dev)
         sigma, sigmad = torch.empty(n, device=dev), torch.empty(n, device=dev)
         base, based = torch.empty(nb * 512, device=dev), torch.empty(nb * 512, device=dev)
         if r.cfg.mlp_kernels == "x":                        # bf16 matrix cores: mode 6 (fp32 accuracy) / 1 (bf16 operands)
             check(lib.ren_mlp_fwd_jvp_x(_ptr(f.mlp), f.C, r._act_code, r._xmode(), _ptr(feat), _ptr(featd), ctypes.byref(r.scene), _ptr(o),
                                         _ptr(d), _ptr(dd), _ptr(ri), _ptr(ts), _ptr(te), n, _ptr(rgb), _ptr(rgbd), _ptr(sigma),
-                                        _ptr(sigmad), _ptr(base), _ptr(based), None, _stream()), "ren_mlp_fwd_jvp_x")
+                                        _ptr(sigmad), _ptr(base), _ptr(based), _ptr(pk.n_dev, torch.int64), _stream()), "ren_mlp_fwd_jvp_x")
         else:
             check(lib.ren_mlp_fwd_jvp(_ptr(r._mlp_params()), f.C, r._act_code, _ptr(feat), _ptr(featd), ctypes.byref(r.scene), _ptr(o), _ptr(d),
                                       _ptr(dd), _ptr(ri), _ptr(ts), _ptr(te), n, _ptr(rgb), _ptr(rgbd), _ptr(sigma),
@@ -177,7 +177,7 @@ def render_backward(r, ctx, g_colors, g_colords, final: bool = False):
                                     _ptr(ctx["based"]), ctypes.byref(r.scene), _ptr(ctx["o"]), _ptr(ctx["d"]),
                                     _ptr(ctx["dd"]), _ptr(ri), _ptr(ts), _ptr(te), n, _ptr(ctx["rgb"]), _ptr(d_rgb),
                                     _ptr(d_rgbd), _ptr(d_sig), _ptr(d_sigd), _ptr(scratch), _ptr(dfeat), _ptr(dfeatd),
-                                    _ptr(f.g_mlp), _ptr(ws), _stream()), "ren_mlp_bwd_jvp_x")
+                                    _ptr(f.g_mlp), _ptr(ws), _ptr(pk.n_dev, torch.int64), _stream()), "ren_mlp_bwd_jvp_x")
     else:
         ws = torch.empty(int(lib.ren_mlp_bwd_jvp_workspace_floats(f.C)), device=dev)
         check(lib.ren_mlp_bwd_jvp(_ptr(f.mlp), f.C, r._act_code, _ptr(ctx["feat"]), _ptr(ctx["featd"]), _ptr(ctx["base"]),
@@ -188,7 +188,7 @@ def render_backward(r, ctx, g_colors, g_colords, final: bool = False):
     if r.cfg.binned_scatter:
         r._binned_workspace(n, dev)
         kw = dict(scene=r.scene, rays=(ctx["o"], ctx["d"]), samples=(ri, ts, te), n=n, layout=1,
-                  tangent=(ctx["od"], ctx["dd"], dfeatd))
+                  tangent=(ctx["od"], ctx["dd"], dfeatd), n_dev=pk.n_dev)
         if final and r.dp_early_slice() is not None:          # see Renderer._field_backward
             lo_mask = (1 << r.cfg.dp_split_level) - 1
             ops.hashgrid_bwd_binned(f.grid, f.g_table, dfeat, r._bin_ws, level_mask=0xFFFF & ~lo_mask, **kw)
@@ -230,9 +230,11 @@ def grad_loss_fwd(inten, intend, target, valid, err_fn: str):
     return loss_sum
 
 
-def grad_loss_bwd(inten, intend, target, valid, err_fn: str, scale: float, loss_sum):
+def grad_loss_bwd(inten, intend, target, valid, err_fn: str, scale: float, loss_sum, scale_dev=None, want_loss: bool = False):
+    """-> g_i, g_id (and the loss term, a device scalar, with want_loss); scale_dev: device double multiplying `scale`"""
     g_i, g_id = torch.empty_like(inten), torch.empty_like(intend)
+    loss = torch.empty((), device=inten.device, dtype=torch.float32) if want_loss else None
     check(_lib.load().ren_grad_loss_bwd(_ptr(inten), _ptr(intend), _ptr(target), _ptr(valid), inten.shape[0],
-                                        ops.ERR_FN[err_fn], _f(scale), _ptr(loss_sum), _ptr(g_i), _ptr(g_id),
-                                        _stream()), "ren_grad_loss_bwd")
-    return g_i, g_id
+                                        ops.ERR_FN[err_fn], _f(scale), _ptr(scale_dev, torch.float64), _ptr(loss_sum), _ptr(g_i),
+                                        _ptr(g_id), _ptr(loss), _stream()), "ren_grad_loss_bwd")
+    return (g_i, g_id, loss) if want_loss else (g_i, g_id)

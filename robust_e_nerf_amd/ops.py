@@ -265,11 +265,12 @@ def ray_march_write(o, d, t_min, t_max, jitter, roi, res, binary, ct, step, cone
     return ri, ts, te
 
 
-def count_guard(counts, total, capacity: int, n_out, stats=None):
-    """device-side sample count: n_out[0] = total if it fits `capacity`, else 0 with every ray's count cleared and stats[1] = 1
-    (stats[0] = the total as found); see include/ren_amd.h, "device-side sample counts'"""
-    check(_lib.load().ren_count_guard(_ptr(counts, torch.int32), counts.shape[0], _ptr(total, torch.int64), int(capacity),
-                                      _ptr(n_out, torch.int64), _ptr(stats, torch.int64), _stream()), "ren_count_guard")
+def count_guard(counts, total, capacity: int, n_out, stats=None, counts_also=None):
+    """device-side sample count: n_out[0] = total if it fits `capacity`, else 0 with every ray's count (and counts_also's)
+    cleared; stats = (total as found, 1 if it did not fit else 0); see include/ren_amd.h ("device-side sample counts")"""
+    check(_lib.load().ren_count_guard(_ptr(counts, torch.int32), _ptr(counts_also, torch.int32), counts.shape[0],
+                                      _ptr(total, torch.int64), int(capacity), _ptr(n_out, torch.int64), _ptr(stats, torch.int64),
+                                      _stream()), "ren_count_guard")
 
 
 def frag_zero_tail(feat, capacity: int, n_dev):
@@ -300,15 +301,19 @@ def compact_samples(offsets, counts, new_offsets, keep, ts, te, n_new: int):
     return ri2, ts2, te2
 
 
-def compact_features(offsets, counts, new_offsets, keep, feat, n_new: int):
-    """fragment-layout features of the kept samples at their compacted positions (padding lanes zero)"""
+def compact_features(offsets, counts, new_offsets, keep, feat, n_new: int, n_dev=None):
+    """fragment-layout features of the kept samples at their compacted positions (padding lanes zero).
+    n_dev: n_new is the capacity, the number of kept samples is on the device"""
     out = torch.empty(n_blocks32(n_new) * FRAG_FLOATS_PER_BLOCK, device=feat.device, dtype=torch.float32)
     if n_new == 0:
         return out
-    out[-FRAG_FLOATS_PER_BLOCK:].zero_()
+    if n_dev is None:
+        out[-FRAG_FLOATS_PER_BLOCK:].zero_()
     check(_lib.load().ren_compact_features(_ptr(offsets, torch.int64), _ptr(counts, torch.int32), _ptr(new_offsets, torch.int64),
                                            counts.shape[0], _ptr(keep), _ptr(feat, torch.float32), _ptr(out), _stream()),
           "ren_compact_features")
+    if n_dev is not None:
+        frag_zero_tail(out, n_new, n_dev)            # lanes beyond the count in its last 32-sample block
     return out
 
 
@@ -595,9 +600,10 @@ ERR_FN = {"l1": 0, "mse": 1, "mape": 2}
 PARAM_WEIGHT_POWER = {None: 0, "mean_contrast_reciprocal": 1, "mean_contrast_reciprocal_sq": 2}
 
 
-def event_prepare(batch, c_p: float, c_n: float, tau: float, *, with_grad_ts: bool = False, with_dtau: bool = False):
+def event_prepare(batch, c_p: float, c_n: float, tau: float, *, with_grad_ts: bool = False, with_dtau: bool = False, ep=None):
     """a2-a4 in one launch -> dict(ts (2B,) f64 [start | end], target_diff f32, ts_grad, target_grad, dts_start,
-    dts_end, dts_grad) -- the optional entries are None unless asked for."""
+    dts_end, dts_grad) -- the optional entries are None unless asked for.  ep: device-resident event parameters
+    (event_params_refresh); c_p / c_n / tau are then ignored."""
     st, en = batch["start_ts"], batch["end_ts"]
     B, dev = st.shape[0], st.device
     ts = torch.empty(2 * B, device=dev, dtype=torch.float64)
@@ -611,7 +617,7 @@ def event_prepare(batch, c_p: float, c_n: float, tau: float, *, with_grad_ts: bo
         _ptr(batch["u_grad"], torch.float64) if with_grad_ts else None, B, _f(c_p), _f(c_n), ctypes.c_double(float(tau)),
         _ptr(ts), _ptr(ts[B:]) if B else None, _ptr(target), _ptr(ts_g), _ptr(target_g),
         _ptr(dts[0]) if with_dtau else None, _ptr(dts[1]) if with_dtau else None,
-        _ptr(dts[2]) if (with_dtau and with_grad_ts) else None, _stream()), "ren_event_prepare")
+        _ptr(dts[2]) if (with_dtau and with_grad_ts) else None, _ptr(ep, torch.float64), _stream()), "ren_event_prepare")
     return dict(ts=ts, target_diff=target, ts_grad=ts_g, target_grad=target_g,
                 dts_start=dts[0] if with_dtau else None, dts_end=dts[1] if with_dtau else None,
                 dts_pair=dts[:2].reshape(-1) if with_dtau else None,          # [d ts_start/d tau | d ts_end/d tau], (2B,) view
@@ -619,14 +625,32 @@ def event_prepare(batch, c_p: float, c_n: float, tau: float, *, with_grad_ts: bo
 
 
 def event_param_grad(kind: str, err_fn: str, param_weight, pred, valid, batch, c_p: float, c_n: float, raw_ratio: float,
-                     tau: float, weight: float, ct_grad=None, tau_grad=None):
+                     tau: float, weight: float, ct_grad=None, tau_grad=None, ep=None):
     """closed-form d(loss term)/d(raw ratio) += ct_grad[0], direct d(loss term)/d(tau) += tau_grad[0] (f64)"""
     check(_lib.load().ren_event_param_grad(
         {"diff": 0, "grad": 1}[kind], ERR_FN[err_fn], PARAM_WEIGHT_POWER[param_weight], _ptr(pred, torch.float32), _ptr(valid),
         _ptr(batch["start_ts"], torch.int64), _ptr(batch["end_ts"], torch.int64), _ptr(batch["num_pos"], torch.int64),
         _ptr(batch["num_neg"], torch.int64), _ptr(batch["u_ts_diff"], torch.float64), pred.shape[0], _f(c_p), _f(c_n),
         _f(raw_ratio), ctypes.c_double(float(tau)), _f(weight), _ptr(ct_grad, torch.float32), _ptr(tau_grad, torch.float64),
-        _stream()), "ren_event_param_grad")
+        _ptr(ep, torch.float64), _stream()), "ren_event_param_grad")
+
+
+EP_CP, EP_CN, EP_RAW, EP_TAU, EP_INV_C, EP_INV_C2, EP_TAU_RAW = range(7)     # layout of the device-resident event parameters
+
+
+def event_params_refresh(ct_raw, c_n: float, tau_raw, tau_max: float, ep):
+    """ep (f64[8], device) <- C_p, C_n, raw ratio, tau, 1/C, 1/C^2, clamped raw tau from the raw (trainable) forms"""
+    check(_lib.load().ren_event_params_refresh(_ptr(ct_raw, torch.float32), _f(c_n), _ptr(tau_raw, torch.float64),
+                                               ctypes.c_double(float(tau_max)), _ptr(ep, torch.float64), _stream()),
+          "ren_event_params_refresh")
+
+
+def tau_adam_step(tau_raw, tau_grad, state, tau_max: float, *, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, step: int,
+                  grad_scale: float = 1.0):
+    check(_lib.load().ren_tau_adam_step(_ptr(tau_raw, torch.float64), _ptr(tau_grad, torch.float64), _ptr(state, torch.float64),
+                                        ctypes.c_double(float(tau_max)), ctypes.c_double(float(lr)), ctypes.c_double(betas[0]),
+                                        ctypes.c_double(betas[1]), ctypes.c_double(eps), int(step), ctypes.c_double(grad_scale),
+                                        _stream()), "ren_tau_adam_step")
 
 
 def event_loss_fwd(i_start, i_end, target, valid, err_fn: str):
@@ -649,7 +673,7 @@ def event_loss_bwd(i_start, i_end, target, valid, err_fn: str, scale: float, los
 
 
 def event_diff_loss(colors, opac, channel_idx, target, err_fn: str, scale: float, min_intensity: float, use_validity: bool,
-                    want_pred: bool = False):
+                    want_pred: bool = False, scale_dev=None):
     """Loss + its gradient straight from the batched start / end render: colors (2B, C), opac (2B,) ->
     dict(loss (device scalar), loss_sum, g_colors (2B, C), intensity (2B,), pred (B,) | None, valid (B,) uint8 | None).
     Two launches (ren_event_diff_loss_fwd / _bwd) instead of the intensity epilogue, mask, loss, scatter and scalar glue."""
@@ -667,8 +691,8 @@ def event_diff_loss(colors, opac, channel_idx, target, err_fn: str, scale: float
     pred = torch.empty(B, device=dev, dtype=torch.float32) if want_pred else None
     valid = torch.empty(B, device=dev, dtype=torch.uint8) if use_validity else None
     loss = torch.empty((), device=dev, dtype=torch.float32)
-    check(lib.ren_event_diff_loss_bwd(*args, _f(scale), _ptr(loss_sum), _ptr(g_colors), _ptr(inten), _ptr(pred), _ptr(valid),
-                                      _ptr(loss), _stream()), "ren_event_diff_loss_bwd")
+    check(lib.ren_event_diff_loss_bwd(*args, _f(scale), _ptr(scale_dev, torch.float64), _ptr(loss_sum), _ptr(g_colors), _ptr(inten),
+                                      _ptr(pred), _ptr(valid), _ptr(loss), _stream()), "ren_event_diff_loss_bwd")
     return dict(loss=loss, loss_sum=loss_sum, g_colors=g_colors, intensity=inten, pred=pred, valid=valid)
 
 

@@ -1,0 +1,104 @@
+"""Device-side sample counts (RenderCfg.device_counts): the reference reads the number of marched and of
+visible samples back to the host in the middle of every render (external/utils.py:106-119, models/nerf.py:279-286).  The
+trainer's renders keep both on the device and enqueue the rest of the step over arrays of a learnt capacity; these tests
+hold that path to the host-count path: the SAME sample counts, losses and gradients, step after step -- also when a count
+does not fit and the step is repeated."""
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_parity import DEV, _config_batch, _trainer_from_golden, amd, dev, load_golden      # noqa: F401  (amd: fixture)
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(engine, g, table, device_counts, steps=5, B=2048, w_grad=0.0, trainable=False, squeeze_at=None, events=None):
+    tr, _ = _trainer_from_golden(engine, g, table)
+    tr.device_counts = device_counts
+    if w_grad:
+        tr.t.w_grad, tr.t.err_grad, tr.t.pw_grad = w_grad, "mape", None
+    if trainable:
+        tr.t.train_contrast_threshold = tr.t.train_refractory_period = True
+    gen = torch.Generator().manual_seed(5)
+    out = []
+    for i in range(steps):
+        b = B if events is None else events[i]
+        nb = _config_batch(b, 30 + i, int(g["tab_ts"][-1]))
+        nb["u_grad"] = torch.rand(b, generator=gen, dtype=torch.float64).numpy()
+        batch = {k: dev(v) for k, v in nb.items()}
+        j = [dev(torch.rand(b, generator=gen)) for _ in range(3)]
+        if squeeze_at is not None and i == squeeze_at and tr.r._spr is not None:
+            tr.r._spr = tuple(0.25 * s for s in tr.r._spr)          # arrays four times too small: both guards must trip
+        loss, aux = tr.step(batch, j[0], j[1], jitter_grad=j[2] if w_grad else None)
+        rec = dict(loss=float(loss), n=int(aux["n"]), n_marched=int(aux["n_marched"]),
+                   n_grad=int(aux["grad"]["n"]) if w_grad else 0, table=tr.r.field.table.clone(), mlp=tr.r.field.mlp.clone(),
+                   small=tr.small.clone(), ct=tr.ct.clone(), tau=float(tr.tau))
+        out.append(rec)
+    return out, tr
+
+
+def _same(a, b, tol=2e-5):     # (parameters after Adam: the scatter's float-atomic noise, amplified where a gradient is ~0)
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert (x["n"], x["n_marched"], x["n_grad"]) == (y["n"], y["n_marched"], y["n_grad"]), (i, x["n"], y["n"])
+        assert abs(x["loss"] - y["loss"]) <= tol * abs(y["loss"]), (i, x["loss"], y["loss"])
+        for k in ("table", "mlp", "small", "ct"):
+            d = float((x[k] - y[k]).abs().max())
+            assert d <= tol * max(float(y[k].abs().max()), 1e-30) + 1e-12, (i, k, d)
+        assert abs(x["tau"] - y["tau"]) <= tol * abs(y["tau"]) + 1e-300, (i, x["tau"], y["tau"])   # (f64 Adam on a float-atomic sum)
+
+
+@pytest.mark.parametrize("w_grad,trainable", [(0.0, False), (1e-3, False), (1e-3, True)], ids=["l_diff", "l_diff+l_grad", "C_p,tau"])
+def test_device_counts_repeat_the_host_count_steps(amd, full_table_cache, w_grad, trainable):
+    """five optimiser steps (2 048 events, occupancy sampler): exact sample counts of every
+    render, losses and parameters after every step equal to the host-count run's"""
+    ops, engine = amd
+    g = load_golden("training_step_grad")
+    table = full_table_cache(g["table_seed"], g["table_scale"])
+    ref, tr0 = _run(engine, g, table, False, w_grad=w_grad, trainable=trainable)
+    got, tr1 = _run(engine, g, table, None, w_grad=w_grad, trainable=trainable)
+    assert tr1.device_counts_ok() and tr1.r._spr is not None
+    assert getattr(tr1, "device_count_overflows", 0) == 0
+    _same(got, ref)
+
+
+def test_device_counts_follow_a_changing_batch_size(amd, full_table_cache):
+    """update_train_batch_size changes the ray count from step to step: the capacities are per ray"""
+    ops, engine = amd
+    g = load_golden("training_step_grad")
+    table = full_table_cache(g["table_seed"], g["table_scale"])
+    ev = [2048, 1536, 3000, 777, 4096, 2048]
+    ref, _ = _run(engine, g, table, False, steps=6, events=ev, w_grad=1e-3)
+    got, tr = _run(engine, g, table, None, steps=6, events=ev, w_grad=1e-3)
+    assert getattr(tr, "device_count_overflows", 0) == 0
+    _same(got, ref)
+
+
+def test_overflowed_device_counts_repeat_the_step(amd, full_table_cache):
+    """arrays made four times too small at step 2: the guards clear the renders, the optimiser does not see their
+    gradients, the step is repeated with host counts -- same counts, losses and parameters as the host-count run, and the
+    capacities recover"""
+    ops, engine = amd
+    g = load_golden("training_step_grad")
+    table = full_table_cache(g["table_seed"], g["table_scale"])
+    ref, _ = _run(engine, g, table, False, w_grad=1e-3)
+    got, tr = _run(engine, g, table, None, w_grad=1e-3, squeeze_at=2)
+    assert tr.device_count_overflows == 1
+    _same(got, ref)
+
+
+def test_count_guard_and_frag_zero_tail(amd):
+    ops, _ = amd
+    counts = torch.tensor([3, 0, 5, 2], dtype=torch.int32, device=DEV)
+    also = torch.tensor([9, 9, 9, 9], dtype=torch.int32, device=DEV)
+    offs, total = ops.exclusive_scan(counts)
+    n_out, stats = torch.full((1,), -1, dtype=torch.int64, device=DEV), torch.full((2,), -1, dtype=torch.int64, device=DEV)
+    ops.count_guard(counts, total, 10, n_out, stats, counts_also=also)
+    assert n_out.item() == 10 and stats.tolist() == [10, 0] and counts.tolist() == [3, 0, 5, 2] and also.tolist() == [9] * 4
+    ops.count_guard(counts, total, 9, n_out, stats, counts_also=also)
+    assert n_out.item() == 0 and stats.tolist() == [10, 1] and counts.tolist() == [0] * 4 and also.tolist() == [0] * 4
+    feat = torch.ones(3 * ops.FRAG_FLOATS_PER_BLOCK, device=DEV)
+    n_dev = torch.tensor([37], dtype=torch.int64, device=DEV)
+    ops.frag_zero_tail(feat, 96, n_dev)
+    f = feat.view(3, 16, 2, 32)
+    assert float(f[0].min()) == 1.0 and float(f[2].min()) == 1.0
+    assert float(f[1, :, :, :5].min()) == 1.0 and float(f[1, :, :, 5:].abs().max()) == 0.0

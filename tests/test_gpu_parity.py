@@ -1807,7 +1807,7 @@ def test_tangent_mlp_matrix_core_kernels_vs_f32_kernels(amd, spec, full_table_ca
             ws = torch.empty(int(lib.ren_mlp_bwd_jvp_x_workspace_floats(1)), device=DEV)
             rc = lib.ren_mlp_bwd_jvp_x(P(fld.mlp), 1, 0, mode, P(feat), P(featd), P(base), P(based), ctypes.byref(scene), P(o_),
                                        P(d_), P(dd_), P(ri), P(ts), P(te), n, P(rgb), P(g_rgb), P(g_rgbd), P(g_sig),
-                                       P(g_sigd), P(scratch), P(dfeat), P(dfeatd), P(gp), P(ws), st)
+                                       P(g_sigd), P(scratch), P(dfeat), P(dfeatd), P(gp), P(ws), None, st)
         assert rc == 0
         torch.cuda.synchronize()
         return dict(rgb=rgb, rgbd=rgbd, sig=sig, sigd=sigd, base=base, based=based, dfeat=dfeat, dfeatd=dfeatd, gp=gp)
@@ -2271,8 +2271,8 @@ def test_second_order_mlp_forward_matrix_core_kernel_vs_f32_kernel(amd, spec, fu
 
     def run(mode):
         outs = [torch.empty(n, 1, device=DEV) for _ in range(3)] + [torch.empty(n, device=DEV) for _ in range(3)]
-        args = [P(feat), P(featd), P(featdd), ctypes.byref(scene)] + [P(v) for v in rays] + [P(ri), P(ts), P(te), n] + [P(v) for v in outs] + [st]
-        rc = lib.ren_mlp_fwd_jvp2(P(fld.mlp), 1, 0, *args) if mode == 0 else lib.ren_mlp_fwd_jvp2_x(P(fld.mlp), 1, 0, mode, *args)
+        args = [P(feat), P(featd), P(featdd), ctypes.byref(scene)] + [P(v) for v in rays] + [P(ri), P(ts), P(te), n] + [P(v) for v in outs]
+        rc = lib.ren_mlp_fwd_jvp2(P(fld.mlp), 1, 0, *args, st) if mode == 0 else lib.ren_mlp_fwd_jvp2_x(P(fld.mlp), 1, 0, mode, *args, None, st)
         assert rc == 0
         torch.cuda.synchronize()
         return [v.cpu() for v in outs]

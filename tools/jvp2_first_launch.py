@@ -24,8 +24,8 @@ torch.cuda.synchronize()
 def run(mode):
     outs = [torch.zeros(n, 1, device=DEV) for _ in range(3)] + [torch.zeros(n, device=DEV) for _ in range(3)]
     torch.cuda.synchronize()
-    args = [P(feat), P(featd), P(featdd), ctypes.byref(scene)] + [P(v) for v in rays] + [P(ri), P(ts), P(te), n] + [P(v) for v in outs] + [st]
-    rc = lib.ren_mlp_fwd_jvp2(P(mlp), 1, 0, *args) if mode == 0 else lib.ren_mlp_fwd_jvp2_x(P(mlp), 1, 0, mode, *args)
+    args = [P(feat), P(featd), P(featdd), ctypes.byref(scene)] + [P(v) for v in rays] + [P(ri), P(ts), P(te), n] + [P(v) for v in outs]
+    rc = lib.ren_mlp_fwd_jvp2(P(mlp), 1, 0, *args, st) if mode == 0 else lib.ren_mlp_fwd_jvp2_x(P(mlp), 1, 0, mode, *args, None, st)
     assert rc == 0
     torch.cuda.synchronize()
     return [v.cpu() for v in outs]
