@@ -1684,7 +1684,10 @@ def test_early_sampling_of_the_third_render_is_exact(amd, full_table_cache):
             res.append((losses, tr.r.field.flat.clone(), float(tr.ct[0]), float(tr.tau)))
         assert res[0][0][0] == res[1][0][0] and abs(res[0][0][1] - res[1][0][1]) < 1e-6 * abs(res[0][0][1])
         assert abs(res[0][2] - res[1][2]) < 1e-6 and float((res[0][1] - res[1][1]).abs().max()) < 1e-6
-        assert abs(res[0][3] - res[1][3]) <= 1e-9 * abs(res[0][3])
+        # tau: its Adam group divides by sqrt(v), so the float-atomic noise of the field parameters (1e-6 above: the first
+        # step's third render has host counts in one placement and device counts in the other, i.e. differently cut dense
+        # bins) shows at 1e-8 relative
+        assert abs(res[0][3] - res[1][3]) <= 1e-7 * abs(res[0][3])
 
 
 def test_two_stream_forward_and_backward_repeat_the_single_stream_results(amd):
