@@ -216,8 +216,33 @@ __device__ __forceinline__ void split(float v, __bf16 (&t)[3]) {
 }
 
 // 8 fp32 values -> NT bf16x8 operands
+#ifndef REN_SPLIT_PAIRS
+#define REN_SPLIT_PAIRS 1
+#endif
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 template <int NT>
 __device__ __forceinline__ void split8(const float *v, bf16x8 (&out)[3]) {
+#if REN_SPLIT_PAIRS
+    // two values at a time: ONE v_cvt_pk_bf16_f32 per piece and pair, the residuals as packed subtractions (the plain / neg
+    // forms of v_pk_add_f32 only: lanes stay in their halves, nothing for op_sel to do -- tools/pkf32_hazard_repro.hip)
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        f32x2 x = {v[j], v[j + 1]};
+        const bf16x2 t0 = __builtin_convertvector(x, bf16x2);
+        out[0][j] = t0[0]; out[0][j + 1] = t0[1];
+        if (NT > 1) {
+            x -= __builtin_convertvector(t0, f32x2);
+            const bf16x2 t1 = __builtin_convertvector(x, bf16x2);
+            out[1][j] = t1[0]; out[1][j + 1] = t1[1];
+            if (NT > 2) {
+                x -= __builtin_convertvector(t1, f32x2);
+                const bf16x2 t2 = __builtin_convertvector(x, bf16x2);
+                out[2][j] = t2[0]; out[2][j + 1] = t2[1];
+            }
+        }
+    }
+#else
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         __bf16 t[3];
@@ -225,6 +250,7 @@ __device__ __forceinline__ void split8(const float *v, bf16x8 (&out)[3]) {
 #pragma unroll
         for (int k = 0; k < NT; ++k) out[k][j] = t[k];
     }
+#endif
 }
 
 // (weight term, activation term) pairs, smallest products first

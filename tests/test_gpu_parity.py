@@ -1966,6 +1966,69 @@ def test_config_c3_bf16_lgrad_step_vs_oracle(amd, spec, full_table_cache):
     assert b["gw"] < 5e-3 and b["gt"] < 3e-3 and b["tau"] < 5e-3 and b["ct"] < 1e-4
 
 
+def test_config_c3_bf16_at_bench_size_vs_oracle(amd, spec, full_table_cache):
+    """BASELINE configs[2] at a bench size: 8 192 events -- 16 384 + 8 192 rays, ~3 M samples through the
+    occupancy sampler, l_diff + l_grad, C_p and tau trainable, bf16 MLP (matrix-core mode 1) -- against the oracle's bf16
+    emulation run in eight event chunks (every ray is valid with a background parameter, so both loss terms are means of the
+    equal chunks' terms).  Loss and the log intensity of EVERY ray of the start / end renders <= 1e-4; the error of
+    d log I / dt over all 8 192 rays is printed as a distribution next to the same step's fp32 pair (HIP fp32 vs fp32 oracle):
+    its tail is the cell-face effect of test_config_c3_bf16_lgrad_step_vs_oracle, quantified at size, and is held to that pair's."""
+    import contextlib
+    from oracle import field, step as ostep
+    ops, engine = amd
+    g = load_golden("training_step_grad")
+    table = full_table_cache(g["table_seed"], g["table_scale"])
+    w_grad, occ_res = float(g["w_grad"]), int(g["occ_res"])
+    binary = t(np.unpackbits(g["binary"])[: occ_res ** 3].astype(bool)).view(occ_res, occ_res, occ_res)
+    cfg = ostep.SceneCfg(occ_res=(occ_res,) * 3, render_step_size=float(g["render_step_size"]))
+    B, CH = 8192, 8
+    nb = _config_batch(B, 61, int(g["tab_ts"][-1]))
+    gen = torch.Generator().manual_seed(62)
+    nb["u_grad"] = torch.rand(B, generator=gen, dtype=torch.float64).numpy()
+    jit = [torch.rand(B, generator=gen) for _ in range(3)]
+    keys = ("position", "start_ts", "end_ts", "num_pos", "num_neg", "u_ts_diff", "u_diff_start", "u_grad")
+    p = field_params_from(g, table)
+    q = torch.tensor([0.5, 0.9, 0.99, 0.999, 1.0], dtype=torch.float64)
+    stats = {}
+    for bf in (False, True):
+        tr, _ = _trainer_from_golden(engine, g, table, mlp_bf16=bf)
+        tr.t.w_grad, tr.t.err_grad, tr.t.pw_grad = w_grad, "mape", None
+        tr.t.train_contrast_threshold = tr.t.train_refractory_period = True
+        batch = {k: dev(v) for k, v in nb.items()}
+        loss_d, aux = tr.forward_backward(batch, dev(jit[0]), dev(jit[1]))
+        loss_g, aux_g = tr.grad_loss_forward_backward(batch, dev(jit[2]))
+        n_all = int(aux["n"]) + int(aux_g["n"])
+        li = torch.cat([aux["intensity_start"], aux["intensity_end"]]).cpu().log()
+        dlog = aux_g["dlog_dt"].cpu().double()
+        losses, lo, dref = [], [[], []], []
+        for c in range(CH):
+            sl = slice(c * B // CH, (c + 1) * B // CH)
+            ob = ostep.EventBatch(*(t(nb[k][sl]) for k in keys))
+            with (field.bf16_linear() if bf else contextlib.nullcontext()):
+                loss_o, aux_o = ostep.training_forward(
+                    ob, p, spec, cfg, Kinv=t(g["Kinv"]), tab_ts=t(g["tab_ts"]), tab_pos=t(g["tab_pos"]), tab_quat=t(g["tab_quat"]),
+                    p2n_raw=t(g["p2n_raw"]), neg_ct=t(g["neg_ct"]), tau_raw=t(g["tau_raw"]), tau_max=t(g["tau_max"]),
+                    bkgd_raw=t(g["bkgd_raw"]), binary=binary, jitter_start=jit[0][sl], jitter_end=jit[1][sl], jitter_grad=jit[2][sl],
+                    loss_cfg=dict(w_grad=w_grad, err_grad="mape", pw_grad=None), tangent="forward")
+            losses.append(float(loss_o))
+            lo[0].append(aux_o["intensity_start"].detach().log()); lo[1].append(aux_o["intensity_end"].detach().log())
+            dref.append(aux_o["pred_log_grad"].detach().double())
+        lo = torch.cat([torch.cat(lo[0]), torch.cat(lo[1])])
+        dref = torch.cat(dref)
+        loss, loss_o = float(loss_d) + float(loss_g), sum(losses) / CH
+        e_li = (li - lo).abs() / lo.abs().max()
+        e_dl = (dlog - dref).abs() / dref.abs().max()
+        stats[bf] = dict(loss=abs(loss - loss_o) / abs(loss_o), inten=float(e_li.max()), dlog=[float(v) for v in torch.quantile(e_dl, q)],
+                         over=float((e_dl > 1e-3).double().mean()))
+        print(f"configs[2] at {B} events, {n_all} samples, {'bf16 MLP vs bf16 emulation' if bf else 'fp32 vs fp32 oracle      '}: loss "
+              f"{stats[bf]['loss']:.2e}  log I (max over {2 * B} rays) {stats[bf]['inten']:.2e}  d log I / dt error over {B} rays: median / "
+              "90 % / 99 % / 99.9 % / max " + " / ".join(f"{v:.1e}" for v in stats[bf]["dlog"]) + f"; {100 * stats[bf]['over']:.2f} % of the rays above 1e-3")
+    a, b = stats[True], stats[False]
+    assert a["loss"] < 1e-4 and a["inten"] < 1e-4 and b["loss"] < 1e-4 and b["inten"] < 1e-4
+    assert a["dlog"][0] < 4 * b["dlog"][0] + 2e-4 and a["dlog"][1] < 4 * b["dlog"][1] + 2e-4 and a["dlog"][4] < 2 * b["dlog"][4] + 2e-3
+    assert a["dlog"][0] < 5e-4 and a["over"] < 2 * b["over"] + 5e-3
+
+
 def test_config_e_step_vs_reference_golden(amd, full_table_cache):
     """BASELINE configs[4] settings (configs/train/mocap-desk2.yaml:38-51): the reference's real training_step with
     sphere contraction (scene_aabb=None: rays march near -> far, nerf.py:248-251), cone angle 0.004, near / far planes,

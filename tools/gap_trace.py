@@ -32,3 +32,9 @@ print("  gaps > 20 us: %d (%.3f ms), 5-20 us: %d (%.3f ms), < 5 us: %d (%.3f ms)
     sum(g <= 5e3 for g, _, _ in gaps), sum(g for g, _, _ in gaps if g <= 5e3) / 1e6))
 for g, a, b in sorted(gaps, reverse=True)[:int(sys.argv[2]) if len(sys.argv) > 2 else 12]:
     print("  gap %.1f us between %s -> %s" % (g / 1e3, a, b))
+
+if len(sys.argv) > 3 and sys.argv[3] == "seq":                       # the step's launches in time order: start offset, duration, gap before
+    prev_e = None
+    for s_, e_, n_ in ks:
+        print("  %8.1f us  %7.1f us  gap %6.1f  %s" % ((s_ - t0) / 1e3, (e_ - s_) / 1e3, 0.0 if prev_e is None else (s_ - prev_e) / 1e3, n_))
+        prev_e = e_ if prev_e is None else max(prev_e, e_)

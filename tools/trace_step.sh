@@ -8,4 +8,4 @@ rocprofv3 --kernel-trace --output-format csv -d /tmp/tr_$tag -o x -- python $R/b
 f=$(find /tmp/tr_$tag -name '*kernel_trace.csv' | head -1)
 if [ -z "$f" ]; then echo "no trace"; tail -5 /tmp/tr_$tag.log; exit 1; fi
 echo "== $tag: $*"
-python $R/tools/gap_trace.py $f ${GAPS:-14}
+python $R/tools/gap_trace.py $f ${GAPS:-14} ${SEQ:-}
