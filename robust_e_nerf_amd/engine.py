@@ -16,7 +16,6 @@ from typing import Dict, Optional, Sequence, Tuple
 
 import contextlib
 import dataclasses
-import operator
 import os
 import threading
 import torch
@@ -234,47 +233,6 @@ class CountLog:
     def overflowed(self) -> bool:
         v = self.wait()
         return bool(v[1] or v[3])
-
-
-class DeviceCount:
-    """A sample count that may still be on the device: int(), float(), arithmetic and comparisons resolve it (CountLog.wait)."""
-
-    def __init__(self, log: CountLog, which: int):
-        self._log, self._which = log, which
-
-    def __int__(self):
-        return self._log.wait()[self._which]
-
-    __index__ = __int__
-
-    def __float__(self):
-        return float(int(self))
-
-    def __repr__(self):
-        return f"DeviceCount({int(self)})" if self._log.values is not None else "DeviceCount(<on the device>)"
-
-    def __format__(self, spec):
-        return format(int(self), spec)
-
-    def __hash__(self):
-        return hash(int(self))
-
-    def __bool__(self):
-        return int(self) != 0
-
-
-def _dc_binop(fn, reflected: bool):
-    def f(self, other):
-        o = int(other) if isinstance(other, DeviceCount) else other
-        return fn(o, int(self)) if reflected else fn(int(self), o)
-    return f
-
-
-for _n in ("add", "sub", "mul", "truediv", "floordiv", "mod"):
-    setattr(DeviceCount, f"__{_n}__", _dc_binop(getattr(operator, _n), False))
-    setattr(DeviceCount, f"__r{_n}__", _dc_binop(getattr(operator, _n), True))
-for _n in ("eq", "ne", "lt", "le", "gt", "ge"):
-    setattr(DeviceCount, f"__{_n}__", _dc_binop(getattr(operator, _n), False))
 
 
 _PINNED = threading.local()             # per host thread: two renderers may read counts from two threads at once
@@ -828,12 +786,15 @@ class Trainer:
         # trainable refractory period: a float64 scalar (event_generation_params.py:162-164); its gradient is assembled from
         # per-ray forward-mode tangents dI/dt, its Adam group (state: exp_avg, exp_avg_sq) lives on the device as well
         self._tau_raw_dev = traw.reshape(1).clone().to(dev)
-        self._tau_grad_dev = torch.zeros(1, dtype=torch.float64, device=dev)   # d loss / d tau, accumulated on the device
         self._tau_adam, self._tau_adam_steps = torch.zeros(2, dtype=torch.float64, device=dev), 0
         # small-parameter block: [bkgd_raw (C) | pad] with its own Adam state (group "others", lr default)
         self.small = torch.zeros(4, device=dev, dtype=torch.float32)
         self.small[: renderer.field.C] = bkgd_raw.to(dev, torch.float32).reshape(-1)
-        self.small_grad = torch.zeros_like(self.small)
+        # the scalar parameters' gradients share ONE 64-byte block: [small_grad 4 f32 | ct_grad 4 f32 | d loss / d tau f64 | pad] -- a
+        # pass whose sample counts stay on the device snapshots it with one copy (an empty, overflowed render still adds its
+        # background-only loss terms to these three; to the table / MLP gradients it adds exactly nothing)
+        self._gs = torch.zeros(8, dtype=torch.float64, device=dev)
+        self.small_grad = self._gs[0:2].view(torch.float32)
         f = renderer.field
         self.m = torch.zeros_like(f.flat)
         self.v = torch.zeros_like(f.flat)
@@ -857,14 +818,15 @@ class Trainer:
         self.device_counts: Optional[bool] = None                # None: auto (device_counts_ok)
         if os.environ.get("REN_DEVICE_COUNTS", "") in ("0", "off"):  # A/B switch for scripts that build the trainer themselves
             self.device_counts = False
-        self._dc_calls, self._dc_sync = [], False
+        self._dc_sync, self.device_count_overflows = False, 0
         self.lr_scale = 1.0
         # trainable C_p / C_n ratio (softplus-parametrised scalar, its own Adam group with lr 0.1:
         # robust_e_nerf.py:800-803).  Its loss dependence is through the per-event targets and the 1/C^k
         # normalisation only, i.e. O(B) elementwise work on already rendered predictions.
         self.ct = torch.zeros(4, device=dev, dtype=torch.float32)
         self.ct[0] = p2n_raw.detach().reshape(-1)[0].to(dev, torch.float32)
-        self.ct_grad, self.ct_m, self.ct_v = torch.zeros_like(self.ct), torch.zeros_like(self.ct), torch.zeros_like(self.ct)
+        self.ct_grad, self.ct_m, self.ct_v = self._gs[2:4].view(torch.float32), torch.zeros_like(self.ct), torch.zeros_like(self.ct)
+        self._tau_grad_dev = self._gs[4:5]                       # d loss / d tau, accumulated on the device
 
     # ---- host views of the device-resident event parameters (a read-back when they have moved since the last look) ----
     def _ep(self):
@@ -892,9 +854,8 @@ class Trainer:
                 "mean_contrast_reciprocal_sq": self.ep[ops.EP_INV_C2: ops.EP_INV_C2 + 1]}[kind]
 
     def device_counts_ok(self) -> bool:
-        """Renders of this trainer keep their sample counts on the device: one GPU (a repeated step would issue its
-        collectives twice), and what Renderer.device_counts_ok asks for.  Trainer.step switches it off under gradient
-        accumulation (repeating a micro-batch would have to restore the gradients of the ones before it)."""
+        """Renders of this trainer keep their sample counts on the device: one GPU (a repeated pass would issue its
+        collectives twice), and what Renderer.device_counts_ok asks for."""
         return self.device_counts is not False and self.world_size == 1 and self.r.device_counts_ok()
 
     def _dc_mode(self):
@@ -904,41 +865,31 @@ class Trainer:
             return False
         return "learn" if self._dc_sync else True
 
-    def resolve_device_counts(self):
-        """Look at the counts of the renders enqueued since the last optimiser step (a wait for their SAMPLING kernels: the
-        rest of the step is still running).  A render whose count did not fit its arrays came out empty: then the step's
-        gradients are discarded and its passes run again with host-side counts, before anything reads the gradients."""
-        calls, self._dc_calls = self._dc_calls, []
-        over = False
-        for _, _, holder in calls:
-            for log in holder[2]:
-                v = log.wait()
-                over = over or log.overflowed
-                if not (v[1] or v[3]):
-                    self.r._learn_counts(log.n_rays, v[0], v[2])
-        if not over:
-            return False
-        f = self.r.field
-        f.grad.zero_()
-        if getattr(f, "n_wn_g", 0):
-            f.g_mlp.zero_()
-        self.small_grad.zero_()
-        self.ct_grad.zero_()
-        self._tau_grad_dev.zero_()
-        self._dc_sync = True
-        self._grad_begun = self._grad_pending = None
+    def _dc_pass(self, fn, args):
+        """Run one loss pass (`fn(*args, dc)` -> loss, aux, CountLog | None) with its sample counts on the device, then look
+        at them: a wait for the pass's SAMPLING kernels -- its field evaluation and backward are still in the queue.  A count
+        that did not fit its arrays left the render empty: the table / MLP gradients got nothing from it, the scalar
+        parameters' gradient block is put back, and the pass runs again with host-side counts."""
+        dc = self._dc_mode()
+        snap = self._gs.clone() if dc is True else None
+        loss, aux, log = fn(*args, dc)
+        if log is None:
+            return loss, aux
+        v = log.wait()
+        if not (v[1] or v[3]):
+            self.r._learn_counts(log.n_rays, v[0], v[2])
+            aux["n"] = v[2]
+            if "n_marched" in aux:
+                aux["n_marched"] = v[0]
+            return loss, aux
+        self._gs.copy_(snap)
+        self.device_count_overflows += 1
+        self._dc_sync, self._grad_begun, self._grad_pending = True, None, None
         try:
-            for kind, args, holder in calls:
-                fn = self.forward_backward if kind == "diff" else self.grad_loss_forward_backward
-                loss, aux = fn(*args)
-                holder[0].copy_(loss)                        # the tensors / dict the first attempt handed out now hold the
-                holder[1].update(aux)                        # repeated pass's results, and so do its DeviceCounts
-                for log in holder[2]:
-                    log.values = (int(aux.get("n_marched", log.values[0])), 0, int(aux["n"]), 0)
+            loss, aux, _ = fn(*args, self._dc_mode())
         finally:
             self._dc_sync = False
-        self.device_count_overflows = getattr(self, "device_count_overflows", 0) + 1
-        return True
+        return loss, aux
 
     @property
     def tau_grad(self) -> torch.Tensor:
@@ -1078,10 +1029,11 @@ class Trainer:
         backward pass (default: yes unless the log-intensity-gradient term follows)."""
         if final is None:
             final = not (self.t.w_grad > 0)
+        return self._dc_pass(self._forward_backward, (batch, jitter_start, jitter_end, final))
+
+    def _forward_backward(self, batch, jitter_start, jitter_end, final, dc):
         r, t, f = self.r, self.t, self.r.field
         B = batch["position"].shape[0]
-        dc = self._dc_mode()
-        call = ("diff", (batch, jitter_start, jitter_end, final), [None, None, []])
         if f.flat.is_cuda:
             # everything enqueued so far (the last optimiser step, the occupancy-grid refresh, the batch) is what the sampling
             # of this step's third render depends on: grad_loss_forward_backward(early=True) waits for this point only
@@ -1138,13 +1090,9 @@ class Trainer:
         d_bk = r.backward(ctx, g_colors, final=final, per_ray_bkgd=True)
         if d_bk is not None:
             ops.bkgd_param_grad(d_bk, self.small, self.small_grad)       # += sigmoid(raw) * column sums (d softplus)
-        pk = ctx["pk"]
-        n, n_marched = (pk.n, pk.n_marched) if pk.log is None else (DeviceCount(pk.log, 2), DeviceCount(pk.log, 0))
-        aux = dict(intensity_start=i_s, intensity_end=i_e, n=n, n_marched=n_marched, opacity=opac, rays=2 * B)
-        if pk.log is not None:
-            call[2][:] = [loss, aux, [pk.log]]
-            self._dc_calls.append(call)
-        return loss, aux
+        pk = ctx["pk"]                                       # (pk.log: n / n_marched are capacities here, _dc_pass puts the counts in)
+        aux = dict(intensity_start=i_s, intensity_end=i_e, n=pk.n, n_marched=pk.n_marched, opacity=opac, rays=2 * B)
+        return loss, aux, pk.log
 
     def grad_sampling_mode(self) -> str:
         """where Trainer.step places the third render's samples (measured, profiles/NOTES.md):
@@ -1230,11 +1178,12 @@ class Trainer:
         the host reads then wait for a few small kernels instead of draining the queue twice.  Without a matching front the
         call runs in order.  Same arithmetic, same results.  (early="all": the experimental placement of
         grad_sampling_mode's docstring.)"""
+        return self._dc_pass(self._grad_loss_forward_backward, (batch, jitter_grad, final, early))
+
+    def _grad_loss_forward_backward(self, batch, jitter_grad, final, early, dc):
         from . import jvp
         r, t, f = self.r, self.t, self.r.field
         B = batch["position"].shape[0]
-        dc = self._dc_mode()
-        call = ("grad", (batch, jitter_grad, final, early), [None, None, []])
         ready, self._ready_ev = self._ready_ev, None
         begun, self._grad_begun, self._grad_pending = self._grad_begun, None, None
         if begun is not None and (not early or begun["key"] != (id(batch), id(jitter_grad))):
@@ -1278,19 +1227,14 @@ class Trainer:
         d_bkgd = jvp.render_backward(r, ctx, self._unbayer(g_i, ch, f.C), self._unbayer(g_id, ch, f.C), final=final)
         if d_bkgd is not None:
             self.small_grad[: f.C] += d_bkgd * torch.sigmoid(self.small[: f.C])
-        aux = dict(intensity=inten, dlog_dt=dlog, n=pk.n if pk.log is None else DeviceCount(pk.log, 2), rays=B)
-        if pk.log is not None:
-            call[2][:] = [loss, aux, [pk.log]]
-            self._dc_calls.append(call)
-        return loss, aux
+        aux = dict(intensity=inten, dlog_dt=dlog, n=pk.n, rays=B)
+        return loss, aux, pk.log
 
     def optimizer_step(self, accumulate_grad_batches: int = 1, mean_samples_per_ray: Optional[float] = None):
         """Adam on [hash table | MLPs] (lr default, L2 decay 1e-6: robust_e_nerf.py:786-813) and on the
         background scalar (no decay).  Under data parallelism gradients are summed over ranks (RCCL
         all-reduce of the single flat buffer) and scaled by 1/world inside the Adam kernel."""
         f = self.r.field
-        if self._dc_calls:
-            self.resolve_device_counts()
         if getattr(f, "n_wn_g", 0):
             f.fold_grads()
         if self.world_size > 1:
@@ -1413,23 +1357,14 @@ class Trainer:
         # an earlier pass would reduce it once per micro-batch (the rank-summed slice of micro-batch 1 would be summed
         # over the ranks again with micro-batch 2 on top) and the next scatter would write into a slice in flight
         last = (bi + 1) % k == 0
-        dc_was = self.device_counts
-        if k > 1:
-            self.device_counts = False
-        try:
-            return self._step(batch, jitter_start, jitter_end, jitter_grad, last, bi, k)
-        finally:
-            self.device_counts = dc_was
-
-    def _step(self, batch, jitter_start, jitter_end, jitter_grad, last, bi, k):
         mode = self.grad_sampling_mode()
         if mode == "begun":
             self.begin_grad_sampling(batch, jitter_grad)
         loss, aux = self.forward_backward(batch, jitter_start, jitter_end, final=last and not (self.t.w_grad > 0))
-        lg = None
         if self.t.w_grad > 0:
             lg, aux_g = self.grad_loss_forward_backward(batch, jitter_grad, final=last, early=mode != "inorder")
-            aux["grad"] = aux_g
+            loss = loss + lg
+            aux = dict(aux, grad=aux_g)
         if (bi + 1) % k == 0:
             mean = None
             if self.world_size > 1:                          # (rides in the gradient all-reduce)
@@ -1437,6 +1372,4 @@ class Trainer:
                 mean = sum(means) / len(means)
             self.optimizer_step(k, mean_samples_per_ray=mean)
             aux["_mean_s_synced"] = self.world_size > 1
-        if lg is not None:
-            loss = loss + lg          # (after the optimiser step: a step repeated for its sample counts rewrites both terms)
         return loss, aux

@@ -44,7 +44,8 @@ def _same(a, b, tol=2e-5):     # (parameters after Adam: the scatter's float-ato
         for k in ("table", "mlp", "small", "ct"):
             d = float((x[k] - y[k]).abs().max())
             assert d <= tol * max(float(y[k].abs().max()), 1e-30) + 1e-12, (i, k, d)
-        assert abs(x["tau"] - y["tau"]) <= tol * abs(y["tau"]) + 1e-300, (i, x["tau"], y["tau"])   # (f64 Adam on a float-atomic sum)
+        # tau: Adam's m / sqrt(v) carries the gradients' 1e-6 float-atomic noise, times lr = 50 tau_max = 5e6 per step
+        assert abs(x["tau"] - y["tau"]) <= 1e-3 * abs(y["tau"]) + 1e-300, (i, x["tau"], y["tau"])
 
 
 @pytest.mark.parametrize("w_grad,trainable", [(0.0, False), (1e-3, False), (1e-3, True)], ids=["l_diff", "l_diff+l_grad", "C_p,tau"])
@@ -58,7 +59,9 @@ def test_device_counts_repeat_the_host_count_steps(amd, full_table_cache, w_grad
     got, tr1 = _run(engine, g, table, None, w_grad=w_grad, trainable=trainable)
     assert tr1.device_counts_ok() and tr1.r._spr is not None
     assert getattr(tr1, "device_count_overflows", 0) == 0
-    _same(got, ref)
+    # trainable tau: its Adam step (lr = 50 tau_max) turns the gradients' 1e-6 float-atomic noise into ~1e-4 of tau per step,
+    # which moves every supervision timestamp: the later steps agree to that, the sample counts still exactly
+    _same(got, ref, tol=1e-3 if trainable else 2e-5)
 
 
 def test_device_counts_follow_a_changing_batch_size(amd, full_table_cache):

@@ -10,7 +10,7 @@ def wrap(cls, name):
         t = time.perf_counter(); r = f(self, *a, **k); acc.setdefault(name, []).append(time.perf_counter() - t); return r
     setattr(cls, name, g)
 wrap(engine.Trainer, "optimizer_step"); wrap(engine.Trainer, "forward_backward"); wrap(parallel.GradSync, "finish"); wrap(parallel.GradSync, "early")
-wrap(engine.Renderer, "backward"); wrap(engine.Renderer, "forward"); wrap(engine.Trainer, "grad_loss_forward_backward"); wrap(engine.Trainer, "resolve_device_counts"); wrap(engine.Renderer, "sample")
+wrap(engine.Renderer, "backward"); wrap(engine.Renderer, "forward"); wrap(engine.Trainer, "grad_loss_forward_backward"); wrap(engine.Renderer, "sample")
 import bench
 bench.main()
 for k, v in acc.items():
