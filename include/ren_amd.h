@@ -151,6 +151,9 @@ int ren_exclusive_scan(const int32_t *counts, int64_t n, int64_t *offsets, int64
  * a fragment-layout feature array (what the host-count path does before ren_compact_features). */
 int ren_count_guard(int32_t *counts, int32_t *counts_also, int64_t n_rays, const int64_t *total, int64_t capacity,
                     int64_t *n_out, int64_t *stats, void *stream);
+/* ren_exclusive_scan followed by ren_count_guard; ONE launch (one workgroup) for up to 65 536 rays */
+int ren_scan_guard(int32_t *counts, int32_t *counts_also, int64_t n_rays, int64_t *offsets, int64_t *total, int64_t capacity,
+                   int64_t *n_out, int64_t *stats, int64_t *scratch1024, void *stream);
 int ren_frag_zero_tail(float *feat, int64_t capacity, const int64_t *n_dev, void *stream);
 
 /* nerfacc.render_visibility inside ray_marching (sigma_fn branch): per ray

@@ -47,6 +47,7 @@ SIGNATURES = {
     "ren_uniform": (c_int, [ctypes.c_uint64, ctypes.c_uint64, c_int64, P, P]),
     "ren_exclusive_scan": (c_int, [P, c_int64, P, P, P, P]),
     "ren_count_guard": (c_int, [P, P, c_int64, P, c_int64, P, P, P]),
+    "ren_scan_guard": (c_int, [P, P, c_int64, P, P, c_int64, P, P, P, P]),
     "ren_frag_zero_tail": (c_int, [P, c_int64, P, P]),
     "ren_visibility": (c_int, [P, P, c_int64, P, P, P, c_float, c_float, P, P, P]),
     "ren_compact_samples": (c_int, [P, P, P, c_int64, P, P, P, P, P, P, P]),

@@ -653,10 +653,83 @@ extern "C" int ren_uniform(uint64_t seed, uint64_t offset, int64_t n, float *out
     REN_CHECK_LAUNCH();
 }
 
+// Up to SCAN_ONE elements (a training batch's rays) in ONE launch of one workgroup: thread t owns a run of `per` consecutive
+// counts (per a multiple of 4: 16-byte loads), the 1 024 run sums are scanned with a wave scan + 16 partials, and -- for the
+// device-side sample counts -- the guard of ren_count_guard runs in the same launch: the total is known to the whole
+// workgroup, so an overflowing count clears the counts right here.  At the reference's 2^20-sample budget a render has
+// 10-20 k rays and its two scans were six launches (+ two guards) of a launch-bound step.
+constexpr int SCAN_ONE = 65536;
+__global__ __launch_bounds__(1024) void scan_guard_kernel(int32_t *__restrict__ counts, int32_t *__restrict__ counts_also, int64_t n,
+                                                          int per, int64_t *__restrict__ offsets, int64_t *__restrict__ total,
+                                                          int guard, int64_t capacity, int64_t *__restrict__ n_out,
+                                                          int64_t *__restrict__ stats) {
+    __shared__ int64_t wsum[17];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t b = (int64_t)tid * per;
+    int64_t s = 0;
+#pragma unroll 1
+    for (int k = 0; k < per; k += 4) {
+        if (b + k + 3 < n) {
+            const int4 v = *reinterpret_cast<const int4 *>(counts + b + k);
+            s += (int64_t)v.x + v.y + v.z + v.w;
+        } else {
+            for (int q = 0; q < 4; ++q)
+                if (b + k + q < n) s += counts[b + k + q];
+        }
+    }
+    int64_t inc = s;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int64_t t = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += t;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    if (tid == 0) {
+        int64_t acc = 0;
+        for (int w = 0; w < 16; ++w) { const int64_t t = wsum[w]; wsum[w] = acc; acc += t; }
+        wsum[16] = acc;
+    }
+    __syncthreads();
+    int64_t run = wsum[wave] + inc - s;
+    const int64_t tot = wsum[16];
+#pragma unroll 1
+    for (int k = 0; k < per && b + k < n; ++k) {             // (the run's counts again: 16-256 bytes, L1-resident)
+        offsets[b + k] = run;
+        run += counts[b + k];
+    }
+    if (tid == 0 && total) total[0] = tot;
+    if (!guard) return;
+    const bool over = tot > capacity;
+    if (tid == 0) {
+        n_out[0] = over ? 0 : tot;
+        if (stats) { stats[0] = tot; stats[1] = over ? 1 : 0; }
+    }
+    if (over) {
+#pragma unroll 1
+        for (int k = 0; k < per; ++k)
+            if (b + k < n) {
+                counts[b + k] = 0;
+                if (counts_also) counts_also[b + k] = 0;
+            }
+    }
+}
+
+static bool scan_one_launch(int32_t *counts, int32_t *counts_also, int64_t n, int64_t *offsets, int64_t *total, int guard,
+                            int64_t capacity, int64_t *n_out, int64_t *stats, hipStream_t st) {
+    if (n > SCAN_ONE || n < 1 || ((uintptr_t)counts & 15)) return false;
+    int per = (int)((n + 1023) / 1024);
+    per = (per + 3) & ~3;
+    hipLaunchKernelGGL(scan_guard_kernel, dim3(1), dim3(1024), 0, st, counts, counts_also, n, per, offsets, total, guard, capacity,
+                       n_out, stats);
+    return true;
+}
+
 extern "C" int ren_exclusive_scan(const int32_t *counts, int64_t n, int64_t *offsets, int64_t *total,
                                   int64_t *scratch1024, void *stream) {
     if (!counts || !offsets || n < 0) return REN_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
+    if (scan_one_launch(const_cast<int32_t *>(counts), nullptr, n, offsets, total, 0, 0, nullptr, nullptr, st)) { REN_CHECK_LAUNCH(); }
     const int64_t n_tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
     if (scratch1024 && n_tiles >= 2 && n_tiles <= 1024) {
         hipLaunchKernelGGL(scan_tiles_kernel, dim3((unsigned)n_tiles), dim3(SCAN_TILE), 0, st, counts, n, offsets);
@@ -694,6 +767,16 @@ extern "C" int ren_count_guard(int32_t *counts, int32_t *counts_also, int64_t n_
     hipLaunchKernelGGL(count_guard_kernel, dim3(ren_blocks(n_rays > 0 ? n_rays : 1, 256)), dim3(256), 0, (hipStream_t)stream,
                        counts, counts_also, n_rays, total, capacity, n_out, stats);
     REN_CHECK_LAUNCH();
+}
+
+// ren_exclusive_scan + ren_count_guard: one launch for up to 65 536 rays, otherwise the two calls
+extern "C" int ren_scan_guard(int32_t *counts, int32_t *counts_also, int64_t n_rays, int64_t *offsets, int64_t *total,
+                              int64_t capacity, int64_t *n_out, int64_t *stats, int64_t *scratch1024, void *stream) {
+    if (!counts || !offsets || !total || !n_out || n_rays < 0 || capacity < 0) return REN_ERR_BAD_ARG;
+    if (scan_one_launch(counts, counts_also, n_rays, offsets, total, 1, capacity, n_out, stats, (hipStream_t)stream)) { REN_CHECK_LAUNCH(); }
+    const int rc = ren_exclusive_scan(counts, n_rays, offsets, total, scratch1024, stream);
+    if (rc != REN_OK) return rc;
+    return ren_count_guard(counts, counts_also, n_rays, total, capacity, n_out, stats, stream);
 }
 
 // fragment-layout feature block (16 levels x 2 x 32 lanes per 32 samples): zero the lanes of the LAST block that lie beyond

@@ -207,7 +207,7 @@ def _adopt(v, stream):
         for x in v:
             _adopt(x, stream)
     elif isinstance(v, Packed):
-        _adopt((v.ray_indices, v.t_starts, v.t_ends, v.offsets, v.counts, v.feat), stream)
+        _adopt((v.ray_indices, v.t_starts, v.t_ends, v.offsets, v.counts, v.feat, v.n_dev), stream)
 
 
 class CountLog:
@@ -293,7 +293,7 @@ class Renderer:
         # launch from different host threads / streams of one process
 
     # ---- sampling (K1-K3): ray/AABB, two-pass march, no-grad density pre-pass + visibility --------
-    def sample_begin(self, o, d, jitter: Optional[torch.Tensor], training: bool) -> dict:
+    def sample_begin(self, o, d, jitter: Optional[torch.Tensor], training: bool, device_counts=False) -> dict:
         """sample() up to (not including) the host read of the sample count: ray/AABB test, count pass, scan.  None of it
         depends on the field parameters, so Trainer.prefetch can run it for the NEXT step on a side stream."""
         c = self.cfg
@@ -316,8 +316,17 @@ class Renderer:
         # march_cache intervals of every ray, the write pass copies them (re-marching only longer rays)
         cache = torch.empty(o.shape[0], c.march_cache, 2, device=o.device) if (mode == 0 and c.march_cache > 0) else None
         counts = ops.ray_march_count(*args, cache=cache)
-        offsets, total = ops.exclusive_scan(counts)
-        return dict(args=args, cache=cache, counts=counts, offsets=offsets, total=total, mode=mode)
+        dcst = None
+        caps = self._capacities(o.shape[0]) if (device_counts is True and mode == 0 and self.device_counts_ok()) else None
+        if caps is not None:
+            # device-side counts: scan and first guard in one launch (sample() continues from here without a host read)
+            stats = torch.empty(4, device=o.device, dtype=torch.int64)
+            nd = torch.empty(2, device=o.device, dtype=torch.int64)
+            offsets, total = ops.scan_guard(counts, caps[0], nd[0:1], stats[0:2])
+            dcst = dict(caps=caps, stats=stats, nd=nd)
+        else:
+            offsets, total = ops.exclusive_scan(counts)
+        return dict(args=args, cache=cache, counts=counts, offsets=offsets, total=total, mode=mode, dc=dcst)
 
     # ---- device-side sample counts -----------------------------------------------------------------------------------
     CAP_MARGIN, CAP_SLACK, CAP_MAX = 1.25, 4096, 1 << 23      # (from 2^23 samples on the chunked two-stream paths take over)
@@ -358,12 +367,15 @@ class Renderer:
         render (and report it) should a count not fit"""
         c = self.cfg
         args, cache, counts, offsets = st["args"], st["cache"], st["counts"], st["offsets"]
-        cap0, cap1 = caps
         dev = o.device
-        stats = torch.empty(4, device=dev, dtype=torch.int64)
-        nd = torch.empty(2, device=dev, dtype=torch.int64)
+        if st.get("dc") is not None:                         # sample_begin ran the first guard with its scan
+            caps, stats, nd = st["dc"]["caps"], st["dc"]["stats"], st["dc"]["nd"]
+        else:
+            stats = torch.empty(4, device=dev, dtype=torch.int64)
+            nd = torch.empty(2, device=dev, dtype=torch.int64)
+            ops.count_guard(counts, st["total"], caps[0], nd[0:1], stats[0:2])
+        cap0, cap1 = caps
         n0_dev, n1_dev = nd[0:1], nd[1:2]
-        ops.count_guard(counts, st["total"], cap0, n0_dev, stats[0:2])
         ri, ts, te = ops.ray_march_write(*args, offsets, cap0, counts=counts, cache=cache)
         keep_feat = keep_feat and self._reuse_prepass_feat
         sigma = self._density_stream(o, d, (ri, ts, te), cap0, keep_feat, n_dev=n0_dev)
@@ -371,8 +383,7 @@ class Renderer:
         if keep_feat:
             sigma, feat0 = sigma
         keep, kept = ops.visibility(offsets, counts, sigma, ts, te, c.early_stop_eps, c.alpha_thre)
-        new_offsets, total2 = ops.exclusive_scan(kept)
-        ops.count_guard(kept, total2, cap1, n1_dev, stats[2:4], counts_also=counts)
+        new_offsets, total2 = ops.scan_guard(kept, cap1, n1_dev, stats[2:4], counts_also=counts)
         ri2, ts2, te2 = ops.compact_samples(offsets, counts, new_offsets, keep, ts, te, cap1)
         feat1 = ops.compact_features(offsets, counts, new_offsets, keep, feat0, cap1, n_dev=n1_dev) if feat0 is not None else None
         log = self._count_log(o.shape[0], caps, stats)
@@ -383,11 +394,14 @@ class Renderer:
         """device_counts: True -- the caller (Trainer) can work with counts that stay on the device (Packed.n_dev / Packed.log);
         "learn" -- host-side counts as ever, but the capacities of later renders learn from them"""
         c = self.cfg
-        st = begun if begun is not None else self.sample_begin(o, d, jitter, training)
+        st = begun if begun is not None else self.sample_begin(o, d, jitter, training, device_counts=device_counts)
+        learn = device_counts and st["mode"] == 0 and self.device_counts_ok()
+        dc_now = learn and device_counts is True and "n0" not in st
+        if st.get("dc") is not None and not dc_now:          # begun for device-side counts (a guard may have cleared it), wanted with host counts
+            st = self.sample_begin(o, d, jitter, training)
         args, cache, counts, offsets, mode = st["args"], st["cache"], st["counts"], st["offsets"], st["mode"]
-        learn = device_counts and mode == 0 and self.device_counts_ok()
-        if learn and device_counts is True and "n0" not in st:
-            caps = self._capacities(o.shape[0])
+        if dc_now:
+            caps = st["dc"]["caps"] if st.get("dc") is not None else self._capacities(o.shape[0])
             if caps is not None:
                 return self._sample_device_counts(o, d, st, caps, keep_feat)
         # host sync, as in the reference (external/utils.py:106-119); `begun["n0"]`: already read back (Trainer.prefetch)
@@ -1053,7 +1067,7 @@ class Trainer:
             o, d, od, dd = jvp.raygen_jvp(self.Kinv, px, pos, rot, dpos, drot)
             begun = None
             if self._grad_pending is not None:                    # this render's count pass first, then the third render's front
-                begun = r.sample_begin(o, d, jitter, True)
+                begun = r.sample_begin(o, d, jitter, True, device_counts=dc)
                 self._begin_grad_now()
             colors, colords, opac, ctx = jvp.render_forward(r, o, d, od, dd, jitter, bkgd, training=True, begun=begun,
                                                             device_counts=dc)
@@ -1061,7 +1075,7 @@ class Trainer:
             o, d = front["o"], front["d"]
             if self._grad_pending is not None:
                 if front.get("begun") is None:
-                    front["begun"] = r.sample_begin(o, d, jitter, True)
+                    front["begun"] = r.sample_begin(o, d, jitter, True, device_counts=dc)
                 self._begin_grad_now()
             colors, opac, depth, ctx = r.forward(o, d, jitter, bkgd, training=True, save=True, begun=front.get("begun"),
                                                  device_counts=dc)
@@ -1129,7 +1143,7 @@ class Trainer:
             pos, rot, dpos, drot = jvp.trajectory_jvp(ts_g, self.tab_ts, self.tab_pos, self.tab_quat)
             o, d, od, dd = jvp.raygen_jvp(self.Kinv, batch["position"].contiguous(), pos, rot, dpos, drot)
         jit = None if jitter_grad is None else jitter_grad.to(torch.float32).contiguous()
-        st = self.r.sample_begin(o, d, jit, True)
+        st = self.r.sample_begin(o, d, jit, True, device_counts=self._dc_mode())
         return dict(prep=prep, o=o, d=d, od=od, dd=dd, ddd=ddd, jit=jit, st=st)
 
     def begin_grad_sampling(self, batch, jitter_grad=None) -> bool:
@@ -1158,8 +1172,8 @@ class Trainer:
         side.wait_event(ready)
         with torch.cuda.stream(side):
             fr = self._grad_front(batch, jitter_grad)
-            if not (self._dc_mode() is True and self.r._capacities(batch["position"].shape[0]) is not None):
-                if self._n_host_grad is None:                # (device-side counts: nothing to read back)
+            if fr["st"].get("dc") is None:                  # (device-side counts: nothing to read back)
+                if self._n_host_grad is None:
                     self._n_host_grad = torch.empty(1, dtype=fr["st"]["total"].dtype).pin_memory()
                 self._n_host_grad.copy_(fr["st"]["total"].reshape(1), non_blocking=True)
                 fr["ev"] = torch.cuda.Event()

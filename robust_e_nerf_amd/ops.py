@@ -232,7 +232,7 @@ def exclusive_scan(counts: torch.Tensor):
     n = counts.shape[0]
     offsets = torch.empty(n, device=counts.device, dtype=torch.int64)
     total = torch.empty(1, device=counts.device, dtype=torch.int64)
-    scratch = torch.empty(1024, device=counts.device, dtype=torch.int64)
+    scratch = torch.empty(1024, device=counts.device, dtype=torch.int64) if n > 65536 else None
     check(_lib.load().ren_exclusive_scan(_ptr(counts, torch.int32), n, _ptr(offsets), _ptr(total), _ptr(scratch),
                                          _stream()), "ren_exclusive_scan")
     return offsets, total
@@ -279,6 +279,18 @@ def count_guard(counts, total, capacity: int, n_out, stats=None, counts_also=Non
     check(_lib.load().ren_count_guard(_ptr(counts, torch.int32), _ptr(counts_also, torch.int32), counts.shape[0],
                                       _ptr(total, torch.int64), int(capacity), _ptr(n_out, torch.int64), _ptr(stats, torch.int64),
                                       _stream()), "ren_count_guard")
+
+
+def scan_guard(counts, capacity: int, n_out, stats=None, counts_also=None):
+    """exclusive_scan + count_guard (one launch for up to 65 536 rays) -> offsets, total"""
+    n = counts.shape[0]
+    offsets = torch.empty(n, device=counts.device, dtype=torch.int64)
+    total = torch.empty(1, device=counts.device, dtype=torch.int64)
+    scratch = torch.empty(1024, device=counts.device, dtype=torch.int64) if n > 65536 else None
+    check(_lib.load().ren_scan_guard(_ptr(counts, torch.int32), _ptr(counts_also, torch.int32), n, _ptr(offsets), _ptr(total),
+                                     int(capacity), _ptr(n_out, torch.int64), _ptr(stats, torch.int64), _ptr(scratch), _stream()),
+          "ren_scan_guard")
+    return offsets, total
 
 
 def frag_zero_tail(feat, capacity: int, n_dev):

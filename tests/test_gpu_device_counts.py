@@ -55,13 +55,15 @@ def test_device_counts_repeat_the_host_count_steps(amd, full_table_cache, w_grad
     ops, engine = amd
     g = load_golden("training_step_grad")
     table = full_table_cache(g["table_seed"], g["table_scale"])
-    ref, tr0 = _run(engine, g, table, False, w_grad=w_grad, trainable=trainable)
-    got, tr1 = _run(engine, g, table, None, w_grad=w_grad, trainable=trainable)
+    # trainable tau: its Adam group (lr = 50 tau_max, a division by sqrt(v)) amplifies the scatter's float-atomic noise
+    # chaotically -- two HOST-count runs of the same five steps part by 1e-6 .. 1e-3 in tau from the third or fourth step on
+    # (tools/dc_noise_probe.py, also with NaN-filled allocations: no uninitialised read) -- so that case is held over three steps
+    steps = 3 if trainable else 5
+    ref, tr0 = _run(engine, g, table, False, steps=steps, w_grad=w_grad, trainable=trainable)
+    got, tr1 = _run(engine, g, table, None, steps=steps, w_grad=w_grad, trainable=trainable)
     assert tr1.device_counts_ok() and tr1.r._spr is not None
     assert getattr(tr1, "device_count_overflows", 0) == 0
-    # trainable tau: its Adam step (lr = 50 tau_max) turns the gradients' 1e-6 float-atomic noise into ~1e-4 of tau per step,
-    # which moves every supervision timestamp: the later steps agree to that, the sample counts still exactly
-    _same(got, ref, tol=1e-3 if trainable else 2e-5)
+    _same(got, ref, tol=2e-4 if trainable else 2e-5)
 
 
 def test_device_counts_follow_a_changing_batch_size(amd, full_table_cache):
@@ -105,3 +107,23 @@ def test_count_guard_and_frag_zero_tail(amd):
     f = feat.view(3, 16, 2, 32)
     assert float(f[0].min()) == 1.0 and float(f[2].min()) == 1.0
     assert float(f[1, :, :, :5].min()) == 1.0 and float(f[1, :, :, 5:].abs().max()) == 0.0
+
+
+def test_one_launch_scan_and_guard(amd):
+    """ren_exclusive_scan / ren_scan_guard below 65 536 elements (one workgroup, one launch) against torch.cumsum, ragged
+    sizes included; the guard clears both count arrays when the total does not fit"""
+    ops, _ = amd
+    gen = torch.Generator().manual_seed(1)
+    for n in (1, 3, 4, 1023, 1024, 1025, 4097, 16384, 40000, 65536, 65537, 200000):
+        c = torch.randint(0, 300, (n,), generator=gen, dtype=torch.int32)
+        ref = torch.cumsum(c.long(), 0) - c.long()
+        cd = c.to(DEV)
+        offs, total = ops.exclusive_scan(cd)
+        assert torch.equal(offs.cpu(), ref) and int(total) == int(c.sum()), n
+        for cap, over in ((int(c.sum()), False), (int(c.sum()) - 1, True)):
+            cd, also = c.to(DEV), torch.ones(n, dtype=torch.int32, device=DEV)
+            n_out, stats = torch.empty(1, dtype=torch.int64, device=DEV), torch.empty(2, dtype=torch.int64, device=DEV)
+            offs, total = ops.scan_guard(cd, cap, n_out, stats, counts_also=also)
+            assert torch.equal(offs.cpu(), ref) and int(total) == int(c.sum()) and stats.tolist() == [int(c.sum()), int(over)], (n, cap)
+            assert int(n_out) == (0 if over else int(c.sum()))
+            assert int(cd.abs().sum()) == (0 if over else int(c.sum())) and int(also.sum()) == (0 if over else n)
