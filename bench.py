@@ -46,7 +46,7 @@ FLOPS = {"mlp_fwd": 2 * MLP_MACS, "mlp_bwd": 4 * MLP_MACS, "mlp_fwd_save": 2 * M
 # sample stream; the 50 MB table pass per launch comes on top.  SURVEY 8(d)'s 2 048 B is the atomic-RMW traffic of the
 # scatter-add formulation, kept as `achieved`'s numerator because it is the survey's figure; both are printed.
 COMPULSORY_BYTES = {"hashgrid_bwd_binned": 128 + 12, "hashgrid_bwd": 128 + 12, "hashgrid_fwd": 128 + 12}
-ROUND = "r04"
+ROUND = "r05"
 PMC_TRAFFIC = os.path.join(REPO, "profiles", f"{ROUND}_pmc_traffic.json")
 
 

@@ -301,13 +301,16 @@ class Renderer:
         if scene_aabb is not None:
             t_min, t_max = ops.ray_aabb_intersect(o, d, scene_aabb, c.near_plane, c.far_plane)
         else:
-            # no scene box (contracted spaces): every ray marches near -> far; the two constant vectors are kept per ray count
-            n = o.shape[0]
-            key = (n, c.near_plane, c.far_plane, str(o.device))
-            if getattr(self, "_t_range", (None,))[0] != key:
-                self._t_range = (key, torch.full((n,), 0.0 if c.near_plane is None else c.near_plane, device=o.device),
-                                 torch.full((n,), 1e10 if c.far_plane is None else c.far_plane, device=o.device))
-            _, t_min, t_max = self._t_range
+            # no scene box (contracted spaces): every ray marches near -> far (nerf.py:248-251).  One launch of the ray / box
+            # kernel over an all-embracing box writes both constant vectors (t_min = max(0, near), t_max = far, the same
+            # floats as torch.full); no cache of them across calls (it was keyed by the ray count, which alternates
+            # between the renders of a step, and shared across streams without an event)
+            if c.near_plane is not None and c.far_plane is not None:
+                t_min, t_max = ops.ray_aabb_intersect(o, d, (-1e30,) * 3 + (1e30,) * 3, c.near_plane, c.far_plane)
+            else:
+                n = o.shape[0]
+                t_min = torch.full((n,), 0.0 if c.near_plane is None else c.near_plane, device=o.device)
+                t_max = torch.full((n,), 1e10 if c.far_plane is None else c.far_plane, device=o.device)
         mode = 0 if c.sampler == "occgrid" else 1
         jit = jitter if training else None
         args = (o, d, t_min, t_max, jit, c.aabb, c.occ_res, self.binary, c.contraction_type,

@@ -200,10 +200,13 @@ def evaluate_posed_images(r: Renderer, posed: dict, bkgd: Optional[torch.Tensor]
     their targets by ONE affine fit in log space per channel (:634-677: the reference flattens batch x H x W before its
     lstsq) -- each rank adds the normal-equation sums of its views, a 5C-double all-reduce replaces the image gather (C3)
     -- and every view is then scored with L1 / PSNR over the target's pixel-value range (loss_metric/metric.py:60-72).
-    The wrap-around duplicates DistributedSampler pads with are left out of the fit and of the means.
+    The wrap-around duplicates DistributedSampler pads with are left out of the fit and of the means (a deviation from the
+    reference under data parallelism when n_views % world != 0: its all-gather keeps them in both; documented, README).
     -> dict(l1, psnr: means over the views; per_view: (V, 2) tensor; scale, offset: the fit)"""
     dev = r.field.flat.device
     n = len(posed["sample_id"]) if limit is None else min(limit, len(posed["sample_id"]))
+    if n == 0:                                             # no view at all (limit 0): nothing to fit (0 / 0 otherwise), nothing to score
+        return dict(l1=float("nan"), psnr=float("nan"), per_view=torch.zeros(0, 2), n_views=0, scale=None, offset=None)
     Kinv = torch.linalg.inv(posed["intrinsics"].double()).float().contiguous().to(dev).contiguous()
     H, W = posed["img"].shape[-2:]
     rng = posed["max_normalized_pixel_value"] - posed["min_normalized_pixel_value"]

@@ -1,6 +1,6 @@
 # rocprofv3 kernel stats + step gap trace of the small-batch bench lines (config E, hard, occgrid): run through gpurun
-#   gpurun --timeout 900 -- 'bash tools/profile_lines.sh r04'
-RND=${1:-r04}
+#   gpurun --timeout 900 -- 'bash tools/profile_lines.sh r05'
+RND=${1:-r05}
 R=$PWD
 O=$R/gpurun_out/$RND
 mkdir -p $O

@@ -1,8 +1,8 @@
 # Regenerates everything under profiles/ on a GPU box (run from the repo root through gpurun); results land in
 # gpurun_out/$RND/ and profiles/ (the bench reads profiles/${RND}_pmc_traffic.json for roofline.traffic).
-#   gpurun --timeout 1700 -- 'bash tools/regen_profiles.sh r04'
+#   gpurun --timeout 1700 -- 'bash tools/regen_profiles.sh r05'
 set -x
-RND=${1:-r04}
+RND=${1:-r05}
 R=$PWD
 O=$R/gpurun_out/$RND
 mkdir -p $O
@@ -26,6 +26,12 @@ python bench.py --no-cpu-baseline --mlp-kernels f32 > profiles/${RND}_bench_f32m
 python bench.py --no-cpu-baseline --save-activations 1 > profiles/${RND}_bench_saved_activations.json 2>>$O/bench.err
 python bench.py --no-cpu-baseline --workload e --events 8192 > profiles/${RND}_bench_config_e.json 2>>$O/bench.err
 python bench.py --no-cpu-baseline --events 32768 --hard --loss-grad 1e-3 --mlp-bf16 > profiles/${RND}_bench_hard_bf16.json 2>>$O/bench.err
+python bench.py --no-cpu-baseline --workload e --events 8192 --device-counts off > profiles/${RND}_bench_config_e_host_counts.json 2>>$O/bench.err
+python bench.py --no-cpu-baseline --sampler occgrid --events 16384 > profiles/${RND}_bench_occgrid_16k.json 2>>$O/bench.err
+python bench.py --no-cpu-baseline --sampler occgrid --events 16384 --device-counts off > profiles/${RND}_bench_occgrid_16k_host_counts.json 2>>$O/bench.err
+python bench.py --no-cpu-baseline --sampler occgrid --events 16384 --loss-grad 1e-3 > profiles/${RND}_bench_occgrid_lossgrad_16k.json 2>>$O/bench.err
+python bench.py --no-cpu-baseline --sampler occgrid --events 16384 --loss-grad 1e-3 --device-counts off > profiles/${RND}_bench_occgrid_lossgrad_16k_host_counts.json 2>>$O/bench.err
+python bench.py --no-cpu-baseline --sampler occgrid --events 65536 --loss-grad 1e-3 > profiles/${RND}_bench_occgrid_lossgrad.json 2>>$O/bench.err
 python bench.py --no-cpu-baseline --events 32768 --hard --loss-grad 1e-3 > profiles/${RND}_bench_hard.json 2>>$O/bench.err
 python bench.py --no-cpu-baseline --arch mlp --events 4096 > profiles/${RND}_bench_arch_mlp.json 2>>$O/bench.err
 python bench.py --no-cpu-baseline --arch mlp --events 4096 --mlp-bf16 > profiles/${RND}_bench_arch_mlp_bf16.json 2>>$O/bench.err
