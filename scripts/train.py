@@ -343,7 +343,8 @@ def main():
                 dt = time.perf_counter() - t0
                 print(f"epoch {epoch} step {step}  loss {float(loss):.5f}  batch {B}  samples/ray {aux['n'] / max(aux['rays'], 1):.1f}"
                       f"  {rays * world / dt / 1e6:.2f} M rays/s  mem {torch.cuda.memory_allocated() / 2**30:.1f}/"
-                      f"{torch.cuda.memory_reserved() / 2**30:.1f} GiB", flush=True)
+                      f"{torch.cuda.memory_reserved() / 2**30:.1f} GiB" +
+                      (f"  device counts ({tr.device_count_overflows} repeated passes)" if tr.device_counts_ok() else ""), flush=True)
                 t0, rays = time.perf_counter(), 0
         # ---- validation epoch (trainer.check_val_every_n_epoch, synthetic.yaml:152-154; robust_e_nerf.py:519-571):
         # the dataset's posed validation views, rendered by all ranks, aligned and scored as the reference does
