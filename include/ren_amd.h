@@ -673,6 +673,24 @@ int ren_vanilla_fwd(const float *enc, int32_t ld_enc, const float *view, int32_t
                     float *rgb4, void *stream);
 int ren_vanilla_bwd(const float *dz_rgb, const float *dz_sigma, const void *image, int32_t mode, int32_t activations, int64_t n, const void *saved,
                     int64_t saved_slot_bytes, void *dz, void *stream);
+/* Value + forward-mode tangent (d/dt) of the whole field in one launch each way -- the third render of the step with the
+ * log-intensity-gradient loss (models/robust_e_nerf.py:383-409 through external/mlp.py:126-205 under utils/autograd.py:4-34).
+ * bf16 mode only (REN_DENSE_BF16; anything else: REN_ERR_UNSUPPORTED, the per-layer ren_dense_* launches do it).  encd / viewd:
+ * d/dt of the two encodings (ren_freq_encode_jvp, same leading dimensions as enc / view); saved / savedd: the layers' value /
+ * tangent activations (ren_vanilla_saved_bytes each; both or neither); zsd4 / zod4 [n_pad][4]: tangent pre-activations of the
+ * sigma head (column 0) and the colour head (columns < C) for ren_vanilla_heads_jvp / ren_vanilla_heads_bwd_jvp.  bwd_jvp: the
+ * four [n_pad][32] gradient buffers of ren_vanilla_heads_bwd_jvp -> dz / dzd (ren_vanilla_saved_bytes each).  The weight
+ * gradients are ren_vanilla_bwd_weight(dz, saved, ..) + ren_vanilla_bwd_weight_tangent(dzd, savedd, .., encd, viewd, dzd_rgb,
+ * dzd_sigma, ..): the latter adds dW_l += dzd_l^T xd_(l-1) only (the tangent stream has no bias). */
+int ren_vanilla_fwd_jvp(const float *enc, int32_t ld_enc, const float *view, int32_t ld_view, const float *encd, const float *viewd,
+                        const uint8_t *selector, const float *params, int32_t C, int32_t activations, const void *image, int32_t mode,
+                        int64_t n, void *saved, void *savedd, float *sigma, float *rgb4, float *zsd4, float *zod4, void *stream);
+int ren_vanilla_bwd_jvp(const float *dz_rgb, const float *dzd_rgb, const float *dz_sigma, const float *dzd_sigma, const void *image,
+                        int32_t mode, int32_t activations, int64_t n, const void *saved, const void *savedd, int64_t saved_slot_bytes,
+                        void *dz, void *dzd, void *stream);
+int ren_vanilla_bwd_weight_tangent(const void *dzd, const void *savedd, int64_t saved_slot_bytes, const float *encd, int32_t ld_enc,
+                                   const float *viewd, int32_t ld_view, const float *dzd_rgb, const float *dzd_sigma, int32_t C,
+                                   int32_t mode, int64_t n, int32_t n_splits, float *grads, float *workspace, void *stream);
 int64_t ren_vanilla_bwd_weight_workspace_floats(int32_t n_splits);
 int ren_vanilla_bwd_weight(const void *dz, const void *saved, int64_t saved_slot_bytes, const float *enc, int32_t ld_enc,
                            const float *view, int32_t ld_view, const float *dz_rgb, const float *dz_sigma, int32_t C,

@@ -157,6 +157,13 @@ struct FieldArgs {
     int64_t acts_sstride;                                // backward: elements per slot of `acts` (0: as for n samples) -- the
                                                          // backward of a sample RANGE of a larger forward pass
     int64_t n;
+    // tangent stream (vfield_fwd_jvp_kernel / vfield_bwd_jvp_kernel): d/dt of the encodings, saved tangent activations, the
+    // tangent pre-activations of the two heads ([n_pad][4]), and the tangent-side gradients
+    const float *encd, *viewd;
+    void *actsd;
+    float *zsd4, *zod4;
+    const float *dzd_rgb, *dzd_sig;
+    void *dzd;
 };
 
 // values of one accumulator tile -> the two k-chunks it is in the next layer, and the saved copy
@@ -761,6 +768,290 @@ __global__ __launch_bounds__(256, 1) void vfield_fwd1_kernel(FieldArgs a) {
             layer(Shape1<16, 2, 4, A_SP100, A_NONE, 8>(), L_RGBH, L_RGBO, 9, L_BOTT, 8);
             layer(Shape1<8, 0, 1, A_RGB, A_SP100, 4>(), L_RGBO, more_grp ? 0 : -1, -1, L_RGBH, 9);
         }
+    }
+}
+
+// ---- bf16 mode, value + forward-mode tangent in one launch (the log-intensity-gradient loss's third render) ---------------
+// d/dt of the field through all twelve layers beside the value (external/mlp.py:126-205 under utils/autograd.py:4-34): per
+// layer z = W a + b, zd = W ad; y = sp(z), yd = sp'(z) zd.  The two-blocks-per-wave structure of the bf16 kernels carries it
+// as is: "block" 0 of a wave is the VALUE of its 32 samples, "block" 1 their TANGENT -- the same weight fragment feeds both
+// MFMAs, the tangent has no bias, and the activation epilogue sees z and zd of a neuron in the same lane.  Saved: the
+// bf16-rounded y (slots of `acts`) and yd (`actsd`), same fragment layout and slot stride as vfield_fwd_kernel<1>'s, so the
+// weight-gradient kernel reads either.  The reverse pass of (dy, dyd):
+//     dz = dy s + dyd zd s' = dy s + dyd yd beta (1 - s),   dzd = dyd s          (s = sp'(z) = 1 - exp(-beta y))
+// needs nothing else.  Until round 5 this render ran ~70 per-layer launches with fp32 activations through HBM
+// (ren_dense_*, 31 ms of a 39 ms step at 524 k samples).
+template <bool SAVE>
+__global__ __launch_bounds__(256, 1) void vfield_fwd_jvp_kernel(FieldArgs a) {
+    constexpr int NTS = 2;
+    constexpr int STAGE = NTS * 20 * 1024;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+    float *bias = reinterpret_cast<float *>(smem_all);
+    unsigned char *smem_tf = smem_all + LB_FLOATS * 4;
+    const int lane_k = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane16_k = lane_k * 16;
+    for (int i = threadIdx.x; i < LB_FLOATS; i += 256) {
+        float b = 0.f;
+        if (i < 2048) b = a.P[l_boff(i >> 8, a.C) + (i & 255)];
+        else if (i < LB_RGBH) b = a.P[l_boff(L_BOTT, a.C) + i - LB_BOTT];
+        else if (i < LB_SIGMA) b = a.P[l_boff(L_RGBH, a.C) + i - LB_RGBH];
+        else if (i == LB_SIGMA) b = a.P[l_boff(L_SIGMA, a.C)];
+        else if (i >= LB_RGBO && i < LB_RGBO + a.C) b = a.P[l_boff(L_RGBO, a.C) + i - LB_RGBO];
+        bias[i] = b;
+    }
+    const int64_t n_blk = (a.n + 31) >> 5, n_grp = (n_blk + 3) >> 2;          // one 32-sample block per wave
+    const size_t sstride = (size_t)((n_blk + 7) >> 3) * 8 * 32 * 256;         // slot stride of the plain kernels (whole groups of 8)
+
+    auto issue = [&](int l, int tg, int buf) {
+        const int nch = l_nch(l), nts = min(NTS, l_nt(l) - tg * NTS), pieces = nts * nch;
+        uint32_t off = (uint32_t)(f_off(l) + tg * NTS * nch) * 1024 + wave * 1024;
+        unsigned char *dst = smem_tf + buf * STAGE + wave * 1024;
+        for (int i = wave; i < pieces; i += 4) {
+            asm volatile("" : "+s"(off));
+            glds16(reinterpret_cast<const unsigned char *>(a.img) + off + lane16_k, dst);
+            off += 4096; dst += 4096;
+        }
+    };
+    int buf = 0;
+    if ((int64_t)blockIdx.x < n_grp) issue(0, 0, 0);
+    for (int64_t grp = blockIdx.x; grp < n_grp; grp += gridDim.x) {
+        const int64_t blk0_g = grp * 4 + wave;
+        const bool more_grp = grp + gridDim.x < n_grp;
+        bf16x8 x[2][16];                                                       // [value | tangent] operand chunks
+        auto load_rows = [&](const float *src, const float *srcd, int ld, int nchunks, bf16x8 (&e)[2][4], int64_t blk0, int sl, int hi) {
+            const int64_t blk = blk0 < n_blk ? blk0 : n_blk - 1;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const float *xp = (u ? srcd : src) + (blk * 32 + sl) * ld + 8 * hi;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (c >= nchunks) continue;
+                    const float4 v0 = *reinterpret_cast<const float4 *>(xp + 16 * c), v1 = *reinterpret_cast<const float4 *>(xp + 16 * c + 4);
+                    const float xs[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                    bf16x8 o[3];
+                    split8<1>(xs, o);
+                    e[u][c] = o[0];
+                }
+            }
+        };
+        auto layer = [&](auto shape, const int l, const int ln, const int slot) {
+            using S = decltype(shape);
+            constexpr int NH = S::NH, NE = S::NE, NT = S::NT, ACT = S::ACT, nch = NH + NE;
+            constexpr int NTG = (NT + NTS - 1) / NTS;
+            uint32_t lane16 = lane16_k;
+            int64_t blk0 = blk0_g;
+            asm volatile("" : "+v"(lane16), "+s"(blk0));
+            const int lane = lane16 >> 4, hi = lane >> 5, sl = lane & 31;
+            bf16x8 e[2][4];
+            if (NE == 4) load_rows(a.enc, a.encd, a.ld_enc, 4, e, blk0, sl, hi);
+            if (NE == 2) load_rows(a.view, a.viewd, a.ld_view, 2, e, blk0, sl, hi);
+            f32x16 acc[2][NT];
+#pragma unroll
+            for (int tg = 0; tg < NTG; ++tg) {
+                __syncthreads();
+                if (tg + 1 < NTG) issue(l, tg + 1, buf ^ 1);
+                else if (ln >= 0) issue(ln, 0, buf ^ 1);
+                const unsigned char *st = smem_tf + buf * STAGE + lane16;
+#pragma unroll
+                for (int tt = 0; tt < NTS; ++tt) {
+                    const int t = tg * NTS + tt;
+                    if (t >= NT) continue;
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) { acc[0][t][g] = 0.f; acc[1][t][g] = 0.f; }
+                    const unsigned char *wt = st + tt * nch * 1024;
+#pragma unroll
+                    for (int c = 0; c < nch; ++c) {
+                        const bf16x8 w = *reinterpret_cast<const bf16x8 *>(wt + c * 1024);
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) acc[u][t] = MFMAB(w, c < NH ? x[u][c & 15] : e[u][(c - NH) & 3], acc[u][t]);
+                    }
+                }
+                buf ^= 1;
+                TRUNK_FENCE();
+            }
+            const float *bl = bias + lb_off(l);
+            const int64_t row = blk0 * 32 + sl;
+            if (ACT == A_SIGMA) {
+                if (hi == 0 && row < a.n) {
+                    a.sigma[row] = a.sel[row] ? __expf(acc[0][0][0] + bl[0] - 1.f) : 0.f;
+                    a.zsd4[row * 4] = acc[1][0][0];
+                }
+                return;
+            }
+            if (ACT == A_RGB) {
+                if (hi == 0 && row < a.n) {
+                    float r[4], rd[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { r[c] = c < a.C ? softplus1(acc[0][0][c] + bl[c]) : 0.f; rd[c] = c < a.C ? acc[1][0][c] : 0.f; }
+                    *reinterpret_cast<float4 *>(a.rgb4 + row * 4) = make_float4(r[0], r[1], r[2], r[3]);
+                    *reinterpret_cast<float4 *>(a.zod4 + row * 4) = make_float4(rd[0], rd[1], rd[2], rd[3]);
+                }
+                return;
+            }
+            __bf16 *sv = reinterpret_cast<__bf16 *>(a.acts) + (size_t)slot * sstride;
+            __bf16 *svd = reinterpret_cast<__bf16 *>(a.actsd) + (size_t)slot * sstride;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                float y[16], yd[16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 b4 = *reinterpret_cast<const float4 *>(bl + t * 32 + 8 * q + 4 * hi);
+                    const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float z = acc[0][t][4 * q + j] + bb[j], zd = acc[1][t][4 * q + j];
+                        if (ACT == A_SP100) {
+                            y[4 * q + j] = softplus100(z);
+                            yd[4 * q + j] = dsoftplus_from_out(y[4 * q + j], 100.f) * zd;
+                        } else {
+                            y[4 * q + j] = z; yd[4 * q + j] = zd;
+                        }
+                    }
+                }
+                bf16x8 lo[3], hi8[3], lod[3], hid[3];
+                pack_tile<1>(y, lo, hi8);
+                pack_tile<1>(yd, lod, hid);
+                x[0][2 * t] = lo[0]; x[0][2 * t + 1] = hi8[0];
+                x[1][2 * t] = lod[0]; x[1][2 * t + 1] = hid[0];
+                if (SAVE) {
+                    store_tile<1>(sv, blk0, t, lane, y, lo[0], hi8[0]);
+                    store_tile<1>(svd, blk0, t, lane, yd, lod[0], hid[0]);
+                }
+                TRUNK_FENCE();
+            }
+        };
+        layer(Shape<0, 4, 8, A_SP100>(), 0, 1, 0);
+        for (int l = 1; l < L_SKIP; ++l) layer(Shape<16, 0, 8, A_SP100>(), l, l + 1, l);
+        layer(Shape<16, 4, 8, A_SP100>(), L_SKIP, 6, L_SKIP);
+        layer(Shape<16, 0, 8, A_SP100>(), 6, 7, 6);
+        layer(Shape<16, 0, 8, A_SP100>(), 7, L_SIGMA, 7);
+        layer(Shape<16, 0, 1, A_SIGMA>(), L_SIGMA, L_BOTT, -1);
+        layer(Shape<16, 0, 8, A_NONE>(), L_BOTT, L_RGBH, 8);
+        layer(Shape<16, 2, 4, A_SP100>(), L_RGBH, L_RGBO, 9);
+        layer(Shape<8, 0, 1, A_RGB>(), L_RGBO, more_grp ? 0 : -1, -1);
+    }
+}
+
+// reverse pass of vfield_fwd_jvp_kernel: "block" 0 carries d loss / d y, "block" 1 d loss / d yd through W^T; the epilogue
+// couples them through the saved value (s, s') and the saved tangent (see above).  Results: dz (slots of `dz`) and dzd (`dzd`).
+__global__ __launch_bounds__(256, 1) void vfield_bwd_jvp_kernel(FieldArgs a) {
+    constexpr int NTS = 2;
+    constexpr int STAGE = NTS * 17 * 1024;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_tb[];
+    const int lane_k = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane16_k = lane_k * 16;
+    const int64_t n_blk = (a.n + 31) >> 5, n_grp = (n_blk + 3) >> 2;
+    const size_t sstride = (size_t)((n_blk + 7) >> 3) * 8 * 32 * 256;
+    const size_t hstride = a.acts_sstride ? (size_t)a.acts_sstride : sstride;
+
+    auto issue = [&](int l, int tg, int buf) {
+        const int nch = b_nch(l), nts = min(NTS, b_nt(l) - tg * NTS), pieces = nts * nch;
+        uint32_t off = (uint32_t)(b_off(l) + tg * NTS * nch) * 1024 + wave * 1024;
+        unsigned char *dst = smem_tb + buf * STAGE + wave * 1024;
+        for (int i = wave; i < pieces; i += 4) {
+            asm volatile("" : "+s"(off));
+            glds16(reinterpret_cast<const unsigned char *>(a.img) + off + lane16_k, dst);
+            off += 4096; dst += 4096;
+        }
+    };
+    int buf = 0;
+    if ((int64_t)blockIdx.x < n_grp) issue(L_RGBO, 0, 0);
+    for (int64_t grp = blockIdx.x; grp < n_grp; grp += gridDim.x) {
+        const int64_t blk0_g = grp * 4 + wave;
+        const bool more_grp = grp + gridDim.x < n_grp;
+        bf16x8 x[2][16];
+        auto load_extra = [&](const float *src, const float *srcd, bool slot0, bf16x8 (&e)[2], int64_t blk0, int sl, int hi) {
+            const int64_t blk = blk0 < n_blk ? blk0 : n_blk - 1;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const float *xp = (u ? srcd : src) + (blk * 32 + sl) * 32 + 8 * hi;
+                float xs[8];
+                if (slot0) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) xs[j] = 0.f;
+                    xs[0] = hi == 0 ? xp[0] : 0.f;
+                } else {
+                    const float4 v0 = *reinterpret_cast<const float4 *>(xp), v1 = *reinterpret_cast<const float4 *>(xp + 4);
+                    xs[0] = v0.x; xs[1] = v0.y; xs[2] = v0.z; xs[3] = v0.w; xs[4] = v1.x; xs[5] = v1.y; xs[6] = v1.z; xs[7] = v1.w;
+                }
+                bf16x8 o[3];
+                split8<1>(xs, o);
+                e[u] = o[0];
+            }
+        };
+        auto step = [&](auto shape, const int l, const int ln, const int hslot, const int dslot, const float *extra, const float *extrad) {
+            using S = decltype(shape);
+            constexpr int NH = S::NH, NE = S::NE, NT = S::NT, nch = NH + NE;
+            constexpr bool DERIV = S::DERIV;
+            constexpr int NTG = (NT + NTS - 1) / NTS;
+            uint32_t lane16 = lane16_k;
+            int64_t blk0 = blk0_g;
+            asm volatile("" : "+v"(lane16), "+s"(blk0));
+            const int lane = lane16 >> 4, hi = lane >> 5, sl = lane & 31;
+            const __bf16 *hs = reinterpret_cast<const __bf16 *>(a.acts) + (size_t)(DERIV ? hslot : 0) * hstride;
+            const __bf16 *hds = reinterpret_cast<const __bf16 *>(a.actsd) + (size_t)(DERIV ? hslot : 0) * hstride;
+            bf16x8 e[2];
+            if (NE) load_extra(extra, extrad, l == L_BOTT, e, blk0, sl, hi);
+            f32x16 acc[2][NT];
+#pragma unroll
+            for (int tg = 0; tg < NTG; ++tg) {
+                __syncthreads();
+                if (tg + 1 < NTG) issue(l, tg + 1, buf ^ 1);
+                else if (ln >= 0) issue(ln, 0, buf ^ 1);
+                const unsigned char *st = smem_tb + buf * STAGE + lane16;
+#pragma unroll
+                for (int tt = 0; tt < NTS; ++tt) {
+                    const int t = tg * NTS + tt;
+                    if (t >= NT) continue;
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) { acc[0][t][g] = 0.f; acc[1][t][g] = 0.f; }
+                    const unsigned char *wt = st + tt * nch * 1024;
+#pragma unroll
+                    for (int c = 0; c < nch; ++c) {
+                        const bf16x8 w = *reinterpret_cast<const bf16x8 *>(wt + c * 1024);
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) acc[u][t] = MFMAB(w, c < NH ? x[u][c & 15] : e[u], acc[u][t]);
+                    }
+                }
+                buf ^= 1;
+                TRUNK_FENCE();
+            }
+            __bf16 *sv = reinterpret_cast<__bf16 *>(a.dz) + (size_t)dslot * sstride;
+            __bf16 *svd = reinterpret_cast<__bf16 *>(a.dzd) + (size_t)dslot * sstride;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                float y[16], yd[16];
+                if (DERIV) {
+                    const __bf16 *hp = hs + ((blk0 * 16 + 2 * t) * 64 + lane) * 8, *hdp = hds + ((blk0 * 16 + 2 * t) * 64 + lane) * 8;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const bf16x8 hv = *reinterpret_cast<const bf16x8 *>(hp + q * 512), hdv = *reinterpret_cast<const bf16x8 *>(hdp + q * 512);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int g = 8 * q + j;
+                            const float sd = dsoftplus_from_out((float)hv[j], 100.f);
+                            y[g] = acc[0][t][g] * sd + acc[1][t][g] * (float)hdv[j] * (100.f * (1.f - sd));
+                            yd[g] = acc[1][t][g] * sd;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) { y[g] = acc[0][t][g]; yd[g] = acc[1][t][g]; }
+                }
+                bf16x8 lo[3], hi8[3], lod[3], hid[3];
+                pack_tile<1>(y, lo, hi8);
+                pack_tile<1>(yd, lod, hid);
+                x[0][2 * t] = lo[0]; x[0][2 * t + 1] = hi8[0];
+                x[1][2 * t] = lod[0]; x[1][2 * t + 1] = hid[0];
+                store_tile<1>(sv, blk0, t, lane, y, lo[0], hi8[0]);
+                store_tile<1>(svd, blk0, t, lane, yd, lod[0], hid[0]);
+                TRUNK_FENCE();
+            }
+        };
+        step(BShape<0, 1, 4, true>(), L_RGBO, L_RGBH, 9, 9, a.dz_rgb, a.dzd_rgb);
+        step(BShape<8, 0, 8, false>(), L_RGBH, L_BOTT, 0, 8, nullptr, nullptr);
+        step(BShape<16, 1, 8, true>(), L_BOTT, 7, 7, 7, a.dz_sig, a.dzd_sig);
+        for (int l = 7; l >= 1; --l) step(BShape<16, 0, 8, true>(), l, l > 1 ? l - 1 : (more_grp ? L_RGBO : -1), l - 1, l - 1, nullptr, nullptr);
     }
 }
 
@@ -1412,9 +1703,9 @@ extern "C" int64_t ren_vanilla_bwd_weight_workspace_floats(int32_t n_splits) {
     return (int64_t)n_splits * (256 * 319 + 256);
 }
 
-extern "C" int ren_vanilla_bwd_weight(const void *dz, const void *saved, int64_t saved_slot_bytes, const float *enc, int32_t ld_enc,
-                                      const float *view, int32_t ld_view, const float *dz_rgb, const float *dz_sigma, int32_t C,
-                                      int32_t mode, int64_t n, int32_t n_splits, float *grads, float *workspace, void *stream) {
+static int vanilla_bwd_weight_impl(const void *dz, const void *saved, int64_t saved_slot_bytes, const float *enc, int32_t ld_enc,
+                                   const float *view, int32_t ld_view, const float *dz_rgb, const float *dz_sigma, int32_t C,
+                                   int32_t mode, int64_t n, int32_t n_splits, float *grads, float *workspace, void *stream, bool no_bias) {
     if (!dz || !saved || !enc || !view || !dz_rgb || !dz_sigma || !grads || !workspace || !vfield_ok(mode, C) || n < 0 || n_splits < 1 ||
         ld_enc < 64 || (ld_enc & 3) || ld_view < 32 || (ld_view & 3))
         return REN_ERR_BAD_ARG;
@@ -1438,6 +1729,7 @@ extern "C" int ren_vanilla_bwd_weight(const void *dz, const void *saved, int64_t
             if (l == 0 || l == L_SKIP) { a.x_rows = enc; a.ld_rows = ld_enc; a.n_rows = 64; }
         }
         a.slab_w = workspace; a.slab_b = workspace + (int64_t)n_splits * a.N * a.K;
+        a.skip_bias = no_bias ? 1 : 0;                                          // the tangent stream has no bias (z' = W a')
         const bool zrows = a.dz_rows != nullptr, xfrag = a.x != nullptr, xrows = a.x_rows != nullptr;
 #define REN_VFIELD_DW(MODE, ZR, XF, XR)                                                                                         \
     do {                                                                                                                        \
@@ -1459,7 +1751,66 @@ extern "C" int ren_vanilla_bwd_weight(const void *dz, const void *saved, int64_t
     } while (0)
         if (mode == 1) REN_VFIELD_DW_MODE(1); else REN_VFIELD_DW_MODE(6);
         launch_reduce_slabs(a.slab_w, n_splits, a.N * a.K, grads + l_woff(l, C), st);
-        launch_reduce_slabs(a.slab_b, n_splits, a.N, grads + l_boff(l, C), st);
+        if (!no_bias) launch_reduce_slabs(a.slab_b, n_splits, a.N, grads + l_boff(l, C), st);
     }
+    REN_CHECK_LAUNCH();
+}
+
+extern "C" int ren_vanilla_bwd_weight(const void *dz, const void *saved, int64_t saved_slot_bytes, const float *enc, int32_t ld_enc,
+                                      const float *view, int32_t ld_view, const float *dz_rgb, const float *dz_sigma, int32_t C,
+                                      int32_t mode, int64_t n, int32_t n_splits, float *grads, float *workspace, void *stream) {
+    return vanilla_bwd_weight_impl(dz, saved, saved_slot_bytes, enc, ld_enc, view, ld_view, dz_rgb, dz_sigma, C, mode, n, n_splits, grads,
+                                   workspace, stream, false);
+}
+
+// the tangent stream's share of the weight gradients: dW_l += dzd_l^T xd_{l-1} (no bias terms), from the buffers of
+// ren_vanilla_fwd_jvp / ren_vanilla_bwd_jvp (same layouts as the value stream's)
+extern "C" int ren_vanilla_bwd_weight_tangent(const void *dzd, const void *savedd, int64_t saved_slot_bytes, const float *encd,
+                                              int32_t ld_enc, const float *viewd, int32_t ld_view, const float *dzd_rgb,
+                                              const float *dzd_sigma, int32_t C, int32_t mode, int64_t n, int32_t n_splits, float *grads,
+                                              float *workspace, void *stream) {
+    return vanilla_bwd_weight_impl(dzd, savedd, saved_slot_bytes, encd, ld_enc, viewd, ld_view, dzd_rgb, dzd_sigma, C, mode, n, n_splits,
+                                   grads, workspace, stream, true);
+}
+
+extern "C" int ren_vanilla_fwd_jvp(const float *enc, int32_t ld_enc, const float *view, int32_t ld_view, const float *encd,
+                                   const float *viewd, const uint8_t *selector, const float *params, int32_t C, int32_t activations,
+                                   const void *image, int32_t mode, int64_t n, void *saved, void *savedd, float *sigma, float *rgb4,
+                                   float *zsd4, float *zod4, void *stream) {
+    if (!enc || !view || !encd || !viewd || !selector || !params || !image || !sigma || !rgb4 || !zsd4 || !zod4 || n < 0 || ld_enc < 64 ||
+        (ld_enc & 3) || ld_view < 32 || (ld_view & 3) || C < 1 || C > 4 || ((saved == nullptr) != (savedd == nullptr)))
+        return REN_ERR_BAD_ARG;
+    if (mode != 1 || activations != 0) return REN_ERR_UNSUPPORTED;              // bf16 mode, shipped activations: else the per-layer launches
+    if (n == 0) return REN_OK;
+    FieldArgs a = {};
+    a.enc = enc; a.ld_enc = ld_enc; a.view = view; a.ld_view = ld_view; a.encd = encd; a.viewd = viewd; a.sel = selector; a.P = params;
+    a.C = C; a.img = reinterpret_cast<const __bf16 *>(image); a.acts = saved; a.actsd = savedd; a.sigma = sigma; a.rgb4 = rgb4;
+    a.zsd4 = zsd4; a.zod4 = zod4; a.n = n;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = vfield_grid(n, 1);
+    if (saved) {
+        (void)hipFuncSetAttribute((const void *)vfield_fwd_jvp_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_lds<1>());
+        hipLaunchKernelGGL(vfield_fwd_jvp_kernel<true>, dim3(grid), dim3(256), fwd_lds<1>(), st, a);
+    } else {
+        (void)hipFuncSetAttribute((const void *)vfield_fwd_jvp_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_lds<1>());
+        hipLaunchKernelGGL(vfield_fwd_jvp_kernel<false>, dim3(grid), dim3(256), fwd_lds<1>(), st, a);
+    }
+    REN_CHECK_LAUNCH();
+}
+
+extern "C" int ren_vanilla_bwd_jvp(const float *dz_rgb, const float *dzd_rgb, const float *dz_sigma, const float *dzd_sigma,
+                                   const void *image, int32_t mode, int32_t activations, int64_t n, const void *saved, const void *savedd,
+                                   int64_t saved_slot_bytes, void *dz, void *dzd, void *stream) {
+    if (!dz_rgb || !dzd_rgb || !dz_sigma || !dzd_sigma || !image || !saved || !savedd || !dz || !dzd || n < 0 || saved_slot_bytes < 0)
+        return REN_ERR_BAD_ARG;
+    if (mode != 1 || activations != 0) return REN_ERR_UNSUPPORTED;
+    if (n == 0) return REN_OK;
+    FieldArgs a = {};
+    a.img = reinterpret_cast<const __bf16 *>(image) + (size_t)F_FRAGS * 512;
+    a.acts = const_cast<void *>(saved); a.actsd = const_cast<void *>(savedd); a.dz_rgb = dz_rgb; a.dzd_rgb = dzd_rgb; a.dz_sig = dz_sigma;
+    a.dzd_sig = dzd_sigma; a.dz = dz; a.dzd = dzd; a.n = n;
+    a.acts_sstride = saved_slot_bytes / 2;
+    (void)hipFuncSetAttribute((const void *)vfield_bwd_jvp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds<1>());
+    hipLaunchKernelGGL(vfield_bwd_jvp_kernel, dim3(vfield_grid(n, 1)), dim3(256), bwd_lds<1>(), (hipStream_t)stream, a);
     REN_CHECK_LAUNCH();
 }

@@ -181,6 +181,26 @@ class FusedField:
                                          _ptr(B.view[s0:]), 32, _ptr(dz_rgb[s0:]), _ptr(dz_sig[s0:]), self.field.C, self.mode, m,
                                          splits, _ptr(self.field.g_eff), _ptr(self._ws), _stream()), "ren_vanilla_bwd_weight")
 
+    # ---- value + forward-mode tangent as one launch each way (bf16 mode; csrc/ren_vfield.hip: vfield_fwd_jvp / vfield_bwd_jvp)
+    def forward_jvp(self, B, encd, viewd, savedd, zsd4, zod4):
+        check(_lib.load().ren_vanilla_fwd_jvp(_ptr(B.enc), 64, _ptr(B.view), 32, _ptr(encd), _ptr(viewd), _ptr(B.sel, torch.uint8),
+                                              _ptr(self.field.eff), self.field.C, self.act, _ptr(self.image, torch.uint8), self.mode, B.n,
+                                              _ptr(B.saved, torch.uint8), _ptr(savedd, torch.uint8), _ptr(B.sigma), _ptr(B.rgb4),
+                                              _ptr(zsd4), _ptr(zod4), _stream()), "ren_vanilla_fwd_jvp")
+
+    def backward_jvp(self, dz_rgb, dzd_rgb, dz_sig, dzd_sig, B, savedd, encd, viewd):
+        """reverse pass of forward_jvp for all of B's samples: data gradients, then both streams' weight gradients"""
+        lib = _lib.load()
+        dz, dzd = self.new_saved(B.n), self.new_saved(B.n)
+        check(lib.ren_vanilla_bwd_jvp(_ptr(dz_rgb), _ptr(dzd_rgb), _ptr(dz_sig), _ptr(dzd_sig), _ptr(self.image, torch.uint8), self.mode,
+                                      self.act, B.n, _ptr(B.saved, torch.uint8), _ptr(savedd, torch.uint8), 0, _ptr(dz, torch.uint8),
+                                      _ptr(dzd, torch.uint8), _stream()), "ren_vanilla_bwd_jvp")
+        self.backward_weight(dz_rgb, dz_sig, B, dz)
+        splits = max(1, min(self.n_splits, (B.n + 31) // 32))
+        check(lib.ren_vanilla_bwd_weight_tangent(_ptr(dzd, torch.uint8), _ptr(savedd, torch.uint8), 0, _ptr(encd), 64, _ptr(viewd), 32,
+                                                 _ptr(dzd_rgb), _ptr(dzd_sig), self.field.C, self.mode, B.n, splits,
+                                                 _ptr(self.field.g_eff), _ptr(self._ws), _stream()), "ren_vanilla_bwd_weight_tangent")
+
     def decode(self, saved: torch.Tensor, n: int) -> List[torch.Tensor]:
         """fragment layout -> ten row-major (n, 256) float32 tensors: slots 0-7 hidden layers, 8 bottleneck, 9 colour hidden
         layer (first 128 columns) (tests / tools only)"""
@@ -250,6 +270,7 @@ class VanillaRenderer(Renderer):
         self._dw_ws = None
         self._fused_fields = {}
         self.fused_field = True                     # csrc/ren_vfield.hip: the field as one launch per pass (matrix-core modes)
+        self.fused_tangent = True                   # bf16 mode: value + d/dt as one launch each way (vfield_fwd_jvp / vfield_bwd_jvp)
         # activation set (models/nerf.py:8-29; arch mlp has ONE hidden activation, mlp.py:258): alternatives run on the per-layer
         # launches -- the fused field implements the shipped set only
         if cfg.base_hidden_activation != cfg.head_hidden_activation:
@@ -495,6 +516,23 @@ class VanillaRenderer(Renderer):
         n, C, dev = pk.n, self.field.C, o.device
         second = ddd is not None
         lib = _lib.load()
+        ff = self._fused() if (self.fused_tangent and not second and self._act_code == 0 and self._dense_mode() == 1) else None
+        if ff is not None:
+            # bf16 mode, first order: value + tangent through all twelve layers in ONE launch (and one for the reverse pass)
+            B = _Buffers(n, dev, C, full=True, backward=False, fused=ff, save=True)
+            self._encode(B, True, rays=(o, d), samples=(pk.ray_indices, pk.t_starts, pk.t_ends))
+            zf = lambda ld: torch.empty(B.n_pad, ld, device=dev, dtype=torch.float32)
+            encd, viewd, zsd4, zod4 = zf(64), zf(32), zf(4), zf(4)
+            check(lib.ren_freq_encode_jvp(ctypes.byref(self.scene), _ptr(o), _ptr(d), _ptr(od), _ptr(dd), _ptr(torch.zeros_like(dd)),
+                                          _ptr(pk.ray_indices, torch.int32), _ptr(pk.t_starts), _ptr(pk.t_ends), n, 1, _ptr(encd), 64,
+                                          None, 0, 0, _ptr(viewd), 32, 0, _stream()), "ren_freq_encode_jvp")
+            savedd = ff.new_saved(n)
+            ff.forward_jvp(B, encd, viewd, savedd, zsd4, zod4)
+            rgb, sigma = B.rgb4[:n, :C].contiguous(), B.sigma[:n]
+            rgbd, sigmad = torch.empty(n, C, device=dev), torch.empty(n, device=dev)
+            check(lib.ren_vanilla_heads_jvp(_ptr(rgb), _ptr(sigma), _ptr(zod4), None, _ptr(zsd4), None, n, C, self._act_code, _ptr(rgbd),
+                                            None, _ptr(sigmad), None, _stream()), "ren_vanilla_heads_jvp")
+            return rgb, rgbd, sigma, sigmad, dict(fused=ff, buffers=B, savedd=savedd, encd=encd, viewd=viewd, zod=zod4, zsd=zsd4)
         B = _Buffers(n, dev, C, full=True, backward=False)
         self._encode(B, True, rays=(o, d), samples=(pk.ray_indices, pk.t_starts, pk.t_ends))
         rgb, sigma = self._field_eval(B, True)
@@ -562,6 +600,9 @@ class VanillaRenderer(Renderer):
                                                     _ptr(d_sigd.contiguous()), _ptr(rgb), _ptr(sigma), _ptr(T["zod"]), _ptr(T["zsd"]),
                                                     n, C, self._act_code, _ptr(dz_rgb), _ptr(dzd_rgb), _ptr(dz_sig), _ptr(dzd_sig), _stream()),
               "ren_vanilla_heads_bwd_jvp")
+        if T.get("fused") is not None:
+            T["fused"].backward_jvp(dz_rgb, dzd_rgb, dz_sig, dzd_sig, B, T["savedd"], T["encd"], T["viewd"])
+            return
         h7, h7d = B.h[DEPTH - 1], T["yd"][DEPTH - 1]
 
         def lin_bwd(gz, gzd, ldz, name, X, ldx, Xd, ldxd, n_store, into=None):
