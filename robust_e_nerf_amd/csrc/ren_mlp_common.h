@@ -266,7 +266,7 @@ template <> struct Pairs<6> {
 // latency chain, five of them per training step.
 constexpr int RS_P = 16, RS_Q = 16;
 __global__ __launch_bounds__(RS_P * RS_Q) void reduce_slabs_kernel(const float *__restrict__ slab, int n_slabs, int len,
-                                                                   float *__restrict__ grad) {
+                                                                   float *__restrict__ grad, int64_t stride) {
     __shared__ float part[RS_Q][RS_P + 1];
     const int p = threadIdx.x % RS_P, q = threadIdx.x / RS_P;
     const int j = blockIdx.x * RS_P + p;
@@ -275,9 +275,9 @@ __global__ __launch_bounds__(RS_P * RS_Q) void reduce_slabs_kernel(const float *
         int w = q;
         for (; w + 3 * RS_Q < n_slabs; w += 4 * RS_Q) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) s[u] += slab[(int64_t)(w + u * RS_Q) * len + j];
+            for (int u = 0; u < 4; ++u) s[u] += slab[(int64_t)(w + u * RS_Q) * stride + j];
         }
-        for (; w < n_slabs; w += RS_Q) s[0] += slab[(int64_t)w * len + j];
+        for (; w < n_slabs; w += RS_Q) s[0] += slab[(int64_t)w * stride + j];
     }
     part[q][p] = (s[0] + s[1]) + (s[2] + s[3]);
     __syncthreads();
@@ -289,8 +289,10 @@ __global__ __launch_bounds__(RS_P * RS_Q) void reduce_slabs_kernel(const float *
     }
 }
 
-inline void launch_reduce_slabs(const float *slab, int n_slabs, int len, float *grad, hipStream_t st) {
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((len + RS_P - 1) / RS_P), dim3(RS_P * RS_Q), 0, st, slab, n_slabs, len, grad);
+// stride: floats between consecutive slabs (0: len, the slabs are dense)
+inline void launch_reduce_slabs(const float *slab, int n_slabs, int len, float *grad, hipStream_t st, int64_t stride = 0) {
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((len + RS_P - 1) / RS_P), dim3(RS_P * RS_Q), 0, st, slab, n_slabs, len, grad,
+                       stride ? stride : (int64_t)len);
 }
 
 }  // namespace

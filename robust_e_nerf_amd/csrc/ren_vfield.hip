@@ -992,12 +992,24 @@ __global__ __launch_bounds__(256, 1) void vfield_bwd_jvp_kernel(FieldArgs a) {
             const __bf16 *hds = reinterpret_cast<const __bf16 *>(a.actsd) + (size_t)(DERIV ? hslot : 0) * hstride;
             bf16x8 e[2];
             if (NE) load_extra(extra, extrad, l == L_BOTT, e, blk0, sl, hi);
+            // saved value / tangent tiles of the epilogue, PD tiles ahead (issued under the last stage's MFMAs)
+            constexpr int PD = 2;
+            uint4 hpre[PD][2], hdpre[PD][2];
+            auto load_h = [&](int t, uint4 (&dst)[2], uint4 (&dstd)[2]) {
+                const uint4 *p = reinterpret_cast<const uint4 *>(hs + ((blk0 * 16 + 2 * t) * 64 + lane) * 8);
+                const uint4 *pd = reinterpret_cast<const uint4 *>(hds + ((blk0 * 16 + 2 * t) * 64 + lane) * 8);
+                dst[0] = p[0]; dst[1] = p[64]; dstd[0] = pd[0]; dstd[1] = pd[64];
+            };
             f32x16 acc[2][NT];
 #pragma unroll
             for (int tg = 0; tg < NTG; ++tg) {
                 __syncthreads();
                 if (tg + 1 < NTG) issue(l, tg + 1, buf ^ 1);
                 else if (ln >= 0) issue(ln, 0, buf ^ 1);
+                if (DERIV && tg == NTG - 1) {
+#pragma unroll
+                    for (int i = 0; i < PD; ++i) load_h(i, hpre[i], hdpre[i]);
+                }
                 const unsigned char *st = smem_tb + buf * STAGE + lane16;
 #pragma unroll
                 for (int tt = 0; tt < NTS; ++tt) {
@@ -1022,10 +1034,11 @@ __global__ __launch_bounds__(256, 1) void vfield_bwd_jvp_kernel(FieldArgs a) {
             for (int t = 0; t < NT; ++t) {
                 float y[16], yd[16];
                 if (DERIV) {
-                    const __bf16 *hp = hs + ((blk0 * 16 + 2 * t) * 64 + lane) * 8, *hdp = hds + ((blk0 * 16 + 2 * t) * 64 + lane) * 8;
+                    uint4 hc[2] = {hpre[t % PD][0], hpre[t % PD][1]}, hdc[2] = {hdpre[t % PD][0], hdpre[t % PD][1]};
+                    if (t + PD < NT) load_h(t + PD, hpre[t % PD], hdpre[t % PD]);
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
-                        const bf16x8 hv = *reinterpret_cast<const bf16x8 *>(hp + q * 512), hdv = *reinterpret_cast<const bf16x8 *>(hdp + q * 512);
+                        const bf16x8 hv = *reinterpret_cast<const bf16x8 *>(&hc[q]), hdv = *reinterpret_cast<const bf16x8 *>(&hdc[q]);
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
                             const int g = 8 * q + j;
@@ -1356,7 +1369,8 @@ struct FieldDwArgs {
     int N, K;                                            // torch out / in features
     int k_base, skip_bias;                               // first input column of this launch; 1: weights only (second launch of a layer)
     int64_t n;
-    float *slab_w, *slab_b;                              // [n_splits][N][K], [n_splits][N]
+    float *slab_w, *slab_b;                              // per split (stride slab_stride floats): [N][K] then [N], so that ONE
+    int64_t slab_stride;                                 // reduction adds a layer's dW and db (contiguous in the parameter block)
 };
 
 // ZROWS / XFRAG / XROWS compile-time: the loads of a stage are unconditional straight-line code, so the compiler counts them
@@ -1377,7 +1391,7 @@ __global__ __launch_bounds__(512, 1) void vfield_dw_kernel(FieldDwArgs a) {
     const int n_splits = gridDim.x;
     const int64_t n_blk = (a.n + 31) >> 5;
     const bool has_tile = wave_k * 32 < a.N;
-    float *sw = a.slab_w + (int64_t)blockIdx.x * a.N * a.K, *sb = a.slab_b + (int64_t)blockIdx.x * a.N;
+    float *sw = a.slab_w + (int64_t)blockIdx.x * a.slab_stride, *sb = a.slab_b + (int64_t)blockIdx.x * a.slab_stride;
     const int kt_frag = XFRAG ? a.nx / 32 : 0, kt_rows = XROWS ? a.n_rows / 32 : 0;
     const int nzt = a.N >= 256 ? 8 : a.N > 64 ? 4 : 8, nxt_ = kt_frag == 4 ? 4 : 8;     // valid 32-feature tiles of the dz / x slots
 
@@ -1728,7 +1742,7 @@ static int vanilla_bwd_weight_impl(const void *dz, const void *saved, int64_t sa
             if (l > 0) { a.x = slot(saved, l - 1); a.nx = 256; }
             if (l == 0 || l == L_SKIP) { a.x_rows = enc; a.ld_rows = ld_enc; a.n_rows = 64; }
         }
-        a.slab_w = workspace; a.slab_b = workspace + (int64_t)n_splits * a.N * a.K;
+        a.slab_stride = (int64_t)a.N * a.K + a.N; a.slab_w = workspace; a.slab_b = workspace + (int64_t)a.N * a.K;
         a.skip_bias = no_bias ? 1 : 0;                                          // the tangent stream has no bias (z' = W a')
         const bool zrows = a.dz_rows != nullptr, xfrag = a.x != nullptr, xrows = a.x_rows != nullptr;
 #define REN_VFIELD_DW(MODE, ZR, XF, XR)                                                                                         \
@@ -1750,8 +1764,7 @@ static int vanilla_bwd_weight_impl(const void *dz, const void *saved, int64_t sa
         else REN_VFIELD_DW(MODE, false, false, true);                                                                           \
     } while (0)
         if (mode == 1) REN_VFIELD_DW_MODE(1); else REN_VFIELD_DW_MODE(6);
-        launch_reduce_slabs(a.slab_w, n_splits, a.N * a.K, grads + l_woff(l, C), st);
-        if (!no_bias) launch_reduce_slabs(a.slab_b, n_splits, a.N, grads + l_boff(l, C), st);
+        launch_reduce_slabs(a.slab_w, n_splits, a.N * a.K + (no_bias ? 0 : a.N), grads + l_woff(l, C), st, a.slab_stride);
     }
     REN_CHECK_LAUNCH();
 }

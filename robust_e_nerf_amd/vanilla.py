@@ -523,7 +523,7 @@ class VanillaRenderer(Renderer):
             self._encode(B, True, rays=(o, d), samples=(pk.ray_indices, pk.t_starts, pk.t_ends))
             zf = lambda ld: torch.empty(B.n_pad, ld, device=dev, dtype=torch.float32)
             encd, viewd, zsd4, zod4 = zf(64), zf(32), zf(4), zf(4)
-            check(lib.ren_freq_encode_jvp(ctypes.byref(self.scene), _ptr(o), _ptr(d), _ptr(od), _ptr(dd), _ptr(torch.zeros_like(dd)),
+            check(lib.ren_freq_encode_jvp(ctypes.byref(self.scene), _ptr(o), _ptr(d), _ptr(od), _ptr(dd), _ptr(dd),
                                           _ptr(pk.ray_indices, torch.int32), _ptr(pk.t_starts), _ptr(pk.t_ends), n, 1, _ptr(encd), 64,
                                           None, 0, 0, _ptr(viewd), 32, 0, _stream()), "ren_freq_encode_jvp")
             savedd = ff.new_saved(n)
