@@ -188,13 +188,18 @@ class FusedField:
                                               _ptr(B.saved, torch.uint8), _ptr(savedd, torch.uint8), _ptr(B.sigma), _ptr(B.rgb4),
                                               _ptr(zsd4), _ptr(zod4), _stream()), "ren_vanilla_fwd_jvp")
 
-    def backward_jvp(self, dz_rgb, dzd_rgb, dz_sig, dzd_sig, B, savedd, encd, viewd):
-        """reverse pass of forward_jvp for all of B's samples: data gradients, then both streams' weight gradients"""
+    def backward_jvp_data(self, dz_rgb, dzd_rgb, dz_sig, dzd_sig, B, savedd):
+        """reverse pass of forward_jvp for all of B's samples, data gradients -> dz, dzd (fragment slots)"""
         lib = _lib.load()
         dz, dzd = self.new_saved(B.n), self.new_saved(B.n)
         check(lib.ren_vanilla_bwd_jvp(_ptr(dz_rgb), _ptr(dzd_rgb), _ptr(dz_sig), _ptr(dzd_sig), _ptr(self.image, torch.uint8), self.mode,
                                       self.act, B.n, _ptr(B.saved, torch.uint8), _ptr(savedd, torch.uint8), 0, _ptr(dz, torch.uint8),
                                       _ptr(dzd, torch.uint8), _stream()), "ren_vanilla_bwd_jvp")
+        return dz, dzd
+
+    def backward_jvp_weight(self, dz_rgb, dzd_rgb, dz_sig, dzd_sig, B, savedd, encd, viewd, dz, dzd):
+        """both streams' weight gradients: dW += dz^T x (+ db) and dW += dzd^T xd"""
+        lib = _lib.load()
         self.backward_weight(dz_rgb, dz_sig, B, dz)
         splits = max(1, min(self.n_splits, (B.n + 31) // 32))
         check(lib.ren_vanilla_bwd_weight_tangent(_ptr(dzd, torch.uint8), _ptr(savedd, torch.uint8), 0, _ptr(encd), 64, _ptr(viewd), 32,
@@ -291,6 +296,9 @@ class VanillaRenderer(Renderer):
         self._fused_fwd = ops._wrap("vfield_fwd", self._fused_fwd)
         self._fused_bwd = ops._wrap("vfield_bwd", self._fused_bwd)
         self._fused_dw = ops._wrap("vfield_bwd_weight", self._fused_dw)
+        self._fused_fwd_jvp = ops._wrap("vfield_fwd_jvp", self._fused_fwd_jvp)          # value + tangent (the l_grad render)
+        self._fused_bwd_jvp = ops._wrap("vfield_bwd_jvp", self._fused_bwd_jvp)
+        self._fused_dw_jvp = ops._wrap("vfield_bwd_weight_jvp", self._fused_dw_jvp)
         self._lin = ops._wrap("dense_fwd_tangent", self._lin)
         self._act_fwd = ops._wrap("act_jvp_fwd", self._act_fwd)
         self._act_bwd = ops._wrap("act_jvp_bwd", self._act_bwd)
@@ -323,6 +331,15 @@ class VanillaRenderer(Renderer):
 
     def _fused_fwd(self, B, full):
         B.fused.forward(B, full)
+
+    def _fused_fwd_jvp(self, ff, *a):
+        ff.forward_jvp(*a)
+
+    def _fused_bwd_jvp(self, ff, *a):
+        return ff.backward_jvp_data(*a)
+
+    def _fused_dw_jvp(self, ff, *a):
+        ff.backward_jvp_weight(*a)
 
     def _fused_bwd(self, dz_rgb, dz_sig, B, dz, s0=0, m=None):
         B.fused.backward(dz_rgb, dz_sig, B, dz, s0, m)
@@ -527,7 +544,7 @@ class VanillaRenderer(Renderer):
                                           _ptr(pk.ray_indices, torch.int32), _ptr(pk.t_starts), _ptr(pk.t_ends), n, 1, _ptr(encd), 64,
                                           None, 0, 0, _ptr(viewd), 32, 0, _stream()), "ren_freq_encode_jvp")
             savedd = ff.new_saved(n)
-            ff.forward_jvp(B, encd, viewd, savedd, zsd4, zod4)
+            self._fused_fwd_jvp(ff, B, encd, viewd, savedd, zsd4, zod4)
             rgb, sigma = B.rgb4[:n, :C].contiguous(), B.sigma[:n]
             rgbd, sigmad = torch.empty(n, C, device=dev), torch.empty(n, device=dev)
             check(lib.ren_vanilla_heads_jvp(_ptr(rgb), _ptr(sigma), _ptr(zod4), None, _ptr(zsd4), None, n, C, self._act_code, _ptr(rgbd),
@@ -601,7 +618,8 @@ class VanillaRenderer(Renderer):
                                                     n, C, self._act_code, _ptr(dz_rgb), _ptr(dzd_rgb), _ptr(dz_sig), _ptr(dzd_sig), _stream()),
               "ren_vanilla_heads_bwd_jvp")
         if T.get("fused") is not None:
-            T["fused"].backward_jvp(dz_rgb, dzd_rgb, dz_sig, dzd_sig, B, T["savedd"], T["encd"], T["viewd"])
+            dz, dzd = self._fused_bwd_jvp(T["fused"], dz_rgb, dzd_rgb, dz_sig, dzd_sig, B, T["savedd"])
+            self._fused_dw_jvp(T["fused"], dz_rgb, dzd_rgb, dz_sig, dzd_sig, B, T["savedd"], T["encd"], T["viewd"], dz, dzd)
             return
         h7, h7d = B.h[DEPTH - 1], T["yd"][DEPTH - 1]
 
