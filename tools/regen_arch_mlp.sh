@@ -1,7 +1,7 @@
 # arch mlp lines of profiles/ (the fused field, csrc/ren_vfield.hip): bench lines, per-kernel stats, MFMA / HBM counters.
-#   gpurun --timeout 900 -- 'bash tools/regen_arch_mlp.sh r04'
+#   gpurun --timeout 900 -- 'bash tools/regen_arch_mlp.sh r05'
 set -x
-RND=${1:-r04}
+RND=${1:-r05}
 R=$PWD
 O=$R/gpurun_out/$RND
 mkdir -p $O
@@ -18,6 +18,8 @@ for m in "" "--mlp-bf16"; do
   python $R/tools/pmc_traffic.py $O/pmc_fetch_$tag/pmc_results.db $O/pmc_write_$tag/pmc_results.db $R/profiles/${RND}_pmc_traffic_${tag}.json \
       "{\"events\": 4096, \"samples\": 128, \"sampler\": \"uniform\", \"loss_grad\": 0.0, \"arch\": \"mlp\", \"mlp_bf16\": $( [ -n "$m" ] && echo true || echo false )}" > /dev/null
 done
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_arch_mlp_lossgrad_bf16 -o x -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --arch mlp --events 4096 --loss-grad 1e-3 --mlp-bf16 > /dev/null 2>&1
+python $R/tools/summarize_profile.py $(find $O/prof_arch_mlp_lossgrad_bf16 -name '*kernel_stats.csv' | head -1) $R/profiles/${RND}_bench_arch_mlp_lossgrad_bf16_kernel_stats.csv "rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --arch mlp --events 4096 --loss-grad 1e-3 --mlp-bf16 (1.05 M + 0.52 M samples per step)"
 cd $R
 python bench.py --no-cpu-baseline --arch mlp --events 4096 > profiles/${RND}_bench_arch_mlp.json 2> $O/am.err
 python bench.py --no-cpu-baseline --arch mlp --events 4096 --mlp-bf16 > profiles/${RND}_bench_arch_mlp_bf16.json 2>> $O/am.err
