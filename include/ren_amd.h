@@ -675,7 +675,10 @@ int ren_vanilla_bwd(const float *dz_rgb, const float *dz_sigma, const void *imag
                     int64_t saved_slot_bytes, void *dz, void *stream);
 /* Value + forward-mode tangent (d/dt) of the whole field in one launch each way -- the third render of the step with the
  * log-intensity-gradient loss (models/robust_e_nerf.py:383-409 through external/mlp.py:126-205 under utils/autograd.py:4-34).
- * bf16 mode only (REN_DENSE_BF16; anything else: REN_ERR_UNSUPPORTED, the per-layer ren_dense_* launches do it).  encd / viewd:
+ * REN_DENSE_BF16: value and tangent are the two 32-sample "blocks" of a wave, one launch each way.  REN_DENSE_BF16X6 (fp32
+ * round-off): two launches each way -- forward: the value, then the tangent with sp'(z) from the value's saved copies (saved
+ * is required); reverse: the tangent side, which leaves its coupling term per layer in `coupling` (ren_vanilla_saved_bytes,
+ * required in this mode), then the value side.  Other modes / activation sets: REN_ERR_UNSUPPORTED (per-layer launches).  encd / viewd:
  * d/dt of the two encodings (ren_freq_encode_jvp, same leading dimensions as enc / view); saved / savedd: the layers' value /
  * tangent activations (ren_vanilla_saved_bytes each; both or neither); zsd4 / zod4 [n_pad][4]: tangent pre-activations of the
  * sigma head (column 0) and the colour head (columns < C) for ren_vanilla_heads_jvp / ren_vanilla_heads_bwd_jvp.  bwd_jvp: the
@@ -687,7 +690,7 @@ int ren_vanilla_fwd_jvp(const float *enc, int32_t ld_enc, const float *view, int
                         int64_t n, void *saved, void *savedd, float *sigma, float *rgb4, float *zsd4, float *zod4, void *stream);
 int ren_vanilla_bwd_jvp(const float *dz_rgb, const float *dzd_rgb, const float *dz_sigma, const float *dzd_sigma, const void *image,
                         int32_t mode, int32_t activations, int64_t n, const void *saved, const void *savedd, int64_t saved_slot_bytes,
-                        void *dz, void *dzd, void *stream);
+                        void *dz, void *dzd, void *coupling, void *stream);
 int ren_vanilla_bwd_weight_tangent(const void *dzd, const void *savedd, int64_t saved_slot_bytes, const float *encd, int32_t ld_enc,
                                    const float *viewd, int32_t ld_view, const float *dzd_rgb, const float *dzd_sigma, int32_t C,
                                    int32_t mode, int64_t n, int32_t n_splits, float *grads, float *workspace, void *stream);

@@ -136,7 +136,7 @@ SIGNATURES = {
     "ren_vanilla_bwd_weight": (c_int, [P, P, c_int64, P, c_int32, P, c_int32, P, P, c_int32, c_int32, c_int64, c_int32, P, P, P]),
     "ren_vanilla_bwd_weight_tangent": (c_int, [P, P, c_int64, P, c_int32, P, c_int32, P, P, c_int32, c_int32, c_int64, c_int32, P, P, P]),
     "ren_vanilla_fwd_jvp": (c_int, [P, c_int32, P, c_int32, P, P, P, P, c_int32, c_int32, P, c_int32, c_int64, P, P, P, P, P, P, P]),
-    "ren_vanilla_bwd_jvp": (c_int, [P, P, P, P, P, c_int32, c_int32, c_int64, P, P, c_int64, P, P, P]),
+    "ren_vanilla_bwd_jvp": (c_int, [P, P, P, P, P, c_int32, c_int32, c_int64, P, P, c_int64, P, P, P, P]),
     "ren_freq_encode_jvp": (c_int, [POINTER(SceneDesc), P, P, P, P, P, P, P, P, c_int64, c_int32, P, c_int32, P, c_int32, c_int32,
                                     P, c_int32, c_int32, P]),
     "ren_act_jvp2_fwd": (c_int, [P, c_int32, P, P, c_int32, c_float, P, c_int32, P, c_int32, c_int64, c_int32, P]),

@@ -164,6 +164,7 @@ struct FieldArgs {
     float *zsd4, *zod4;
     const float *dzd_rgb, *dzd_sig;
     void *dzd;
+    void *cpl;                                           // fp32 mode: the tangent side's coupling term into dz (vfield_bwd6_kernel<1 | 2>)
 };
 
 // values of one accumulator tile -> the two k-chunks it is in the next layer, and the saved copy
@@ -1076,7 +1077,11 @@ __global__ __launch_bounds__(256, 1) void vfield_bwd_jvp_kernel(FieldArgs a) {
 // is split into its three pieces right before use -- each chunk is used exactly once per layer, so the split costs what it
 // cost as part of the epilogue -- and feeds the MFMAs of ALL output tiles, whose 128 accumulators fill the AGPRs.  The
 // weight image of this mode is chunk-major ([chunk][tile][piece]) and a stage is two chunks of all tiles (<= 48 KB).
-template <bool SAVE, bool FULL>
+// TAN: the forward-mode TANGENT stream of the same layers as a second launch (fp32 mode has no room for two streams in one
+// wave: 128 fp32 activations + 128 accumulators fill the register file): inputs are d/dt of the encodings, there is no bias,
+// and the epilogue multiplies by sp'(z) taken from the VALUE launch's saved copies (`acts`, read) -- yd = sp'(z) (W ad) --
+// and saves yd to `actsd`; the heads leave their tangent pre-activations in zsd4 / zod4.
+template <bool SAVE, bool FULL, bool TAN = false>
 __global__ __launch_bounds__(256, 1) void vfield_fwd6_kernel(FieldArgs a) {
     using PR = Pairs<6>;
     constexpr int NP = 3;
@@ -1124,7 +1129,7 @@ __global__ __launch_bounds__(256, 1) void vfield_fwd6_kernel(FieldArgs a) {
             float ef[NE ? NE : 1][8];                    // encoding chunks of this block (fp32; split at use)
             if (NE) {
                 const int64_t bc = blk < n_blk ? blk : n_blk - 1;
-                const float *xp = (NE == 4 ? a.enc + (bc * 32 + sl) * a.ld_enc : a.view + (bc * 32 + sl) * a.ld_view) + 8 * hi;
+                const float *xp = (NE == 4 ? (TAN ? a.encd : a.enc) + (bc * 32 + sl) * a.ld_enc : (TAN ? a.viewd : a.view) + (bc * 32 + sl) * a.ld_view) + 8 * hi;
 #pragma unroll
                 for (int c = 0; c < NE; ++c) {
                     const float4 v0 = *reinterpret_cast<const float4 *>(xp + 16 * c), v1 = *reinterpret_cast<const float4 *>(xp + 16 * c + 4);
@@ -1172,11 +1177,18 @@ __global__ __launch_bounds__(256, 1) void vfield_fwd6_kernel(FieldArgs a) {
             const float *bl = bias + lb_off(l);
             if (ACT == A_SIGMA) {
                 const int64_t row = blk * 32 + sl;
+                if (TAN) { if (hi == 0 && row < a.n) a.zsd4[row * 4] = acc[0][0]; return; }
                 if (hi == 0 && row < a.n) a.sigma[row] = a.sel[row] ? __expf(acc[0][0] + bl[0] - 1.f) : 0.f;
                 return;
             }
             if (ACT == A_RGB) {
                 const int64_t row = blk * 32 + sl;
+                if (TAN) {
+                    if (hi == 0 && row < a.n)
+                        *reinterpret_cast<float4 *>(a.zod4 + row * 4) = make_float4(acc[0][0], a.C > 1 ? acc[0][1] : 0.f, a.C > 2 ? acc[0][2] : 0.f,
+                                                                                   a.C > 3 ? acc[0][3] : 0.f);
+                    return;
+                }
                 if (hi == 0 && row < a.n) {
                     float r[4];
 #pragma unroll
@@ -1185,16 +1197,48 @@ __global__ __launch_bounds__(256, 1) void vfield_fwd6_kernel(FieldArgs a) {
                 }
                 return;
             }
-            float *sv = reinterpret_cast<float *>(a.acts) + (size_t)slot * sstride;
+            float *sv = reinterpret_cast<float *>(TAN ? a.actsd : a.acts) + (size_t)slot * sstride;
+            const float *hv = reinterpret_cast<const float *>(a.acts) + (size_t)slot * sstride;   // TAN: the value launch's outputs
+            constexpr int PDH = 2;
+            float4 hq[PDH][4];
+            auto load_hv = [&](int t, float4 (&dst)[4]) {
+                const float4 *hp = reinterpret_cast<const float4 *>(hv + ((blk * 8 + t) * 4 * 64 + lane) * 4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dst[q] = hp[q * 64];
+            };
+            if (TAN && ACT == A_SP100) {
+#pragma unroll
+                for (int i = 0; i < PDH && i < NT; ++i) load_hv(i, hq[i]);
+            }
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 float y[16];
+                if (TAN) {
+                    if (ACT == A_SP100) {
+                        float4 hc[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 b4 = *reinterpret_cast<const float4 *>(bl + t * 32 + 8 * q + 4 * hi);
-                    const float z[4] = {acc[t][4 * q] + b4.x, acc[t][4 * q + 1] + b4.y, acc[t][4 * q + 2] + b4.z, acc[t][4 * q + 3] + b4.w};
+                        for (int q = 0; q < 4; ++q) hc[q] = hq[t % PDH][q];
+                        if (t + PDH < NT) load_hv(t + PDH, hq[t % PDH]);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) y[4 * q + j] = ACT == A_SP100 ? softplus100(z[j]) : z[j];
+                        for (int q = 0; q < 4; ++q) {
+                            const float4 h4 = hc[q];
+                            y[4 * q] = acc[t][4 * q] * dsoftplus_from_out(h4.x, 100.f);
+                            y[4 * q + 1] = acc[t][4 * q + 1] * dsoftplus_from_out(h4.y, 100.f);
+                            y[4 * q + 2] = acc[t][4 * q + 2] * dsoftplus_from_out(h4.z, 100.f);
+                            y[4 * q + 3] = acc[t][4 * q + 3] * dsoftplus_from_out(h4.w, 100.f);
+                        }
+                    } else {
+#pragma unroll
+                        for (int g = 0; g < 16; ++g) y[g] = acc[t][g];
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 b4 = *reinterpret_cast<const float4 *>(bl + t * 32 + 8 * q + 4 * hi);
+                        const float z[4] = {acc[t][4 * q] + b4.x, acc[t][4 * q + 1] + b4.y, acc[t][4 * q + 2] + b4.z, acc[t][4 * q + 3] + b4.w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) y[4 * q + j] = ACT == A_SP100 ? softplus100(z[j]) : z[j];
+                    }
                 }
 #pragma unroll
                 for (int g = 0; g < 16; ++g) yprev[t][g] = y[g];
@@ -1220,6 +1264,11 @@ __global__ __launch_bounds__(256, 1) void vfield_fwd6_kernel(FieldArgs a) {
     }
 }
 
+// CPL: the reverse pass of value + tangent (fp32 mode) as two launches of this kernel.  The tangent-side gradients are a chain
+// of their own -- d loss / d zd_(l-1) = (W^T dzd_l) sp'(z_(l-1)), i.e. this kernel as it is -- and couple INTO the value side:
+// dz_(l-1) = (W^T dz_l) s + (W^T dzd_l) yd_(l-1) beta (1 - s).  CPL 1 (run first, on the tangent-side inputs): also writes
+// that second term, from its own accumulators and the saved tangent `actsd`, to `cpl`; CPL 2 (the value side): adds it.
+template <int CPL = 0>
 __global__ __launch_bounds__(256, 1) void vfield_bwd6_kernel(FieldArgs a) {
     using PR = Pairs<6>;
     constexpr int NP = 3;
@@ -1269,11 +1318,19 @@ __global__ __launch_bounds__(256, 1) void vfield_bwd6_kernel(FieldArgs a) {
                     ef[0] = v0.x; ef[1] = v0.y; ef[2] = v0.z; ef[3] = v0.w; ef[4] = v1.x; ef[5] = v1.y; ef[6] = v1.z; ef[7] = v1.w;
                 }
             }
-            float4 hpre[PD][4];
-            auto load_h = [&](int t, float4 (&dst)[4]) {
-                const float4 *p = reinterpret_cast<const float4 *>(hs + ((blk * 8 + t) * 4 * 64 + lane) * 4);
+            float4 hpre[PD][4], xpre[PD][4];                 // xpre: the saved tangent (CPL 1) / the coupling term (CPL 2) of the same tile
+            const float *xs_ = CPL == 1 ? reinterpret_cast<const float *>(a.actsd) + (size_t)(DERIV ? hslot : 0) * (a.acts_sstride ? (size_t)a.acts_sstride : sstride)
+                                        : reinterpret_cast<const float *>(a.cpl) + (size_t)dslot * sstride;
+            auto load_h = [&](int t, float4 (&dst)[4], float4 (&dstx)[4]) {
+                const int64_t tile = ((blk * 8 + t) * 4 * 64 + lane) * 4;
+                const float4 *p = reinterpret_cast<const float4 *>(hs + tile);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) dst[q] = p[q * 64];
+                if (CPL) {
+                    const float4 *px = reinterpret_cast<const float4 *>(xs_ + tile);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) dstx[q] = px[q * 64];
+                }
             };
             f32x16 acc[NT];
 #pragma unroll
@@ -1287,7 +1344,7 @@ __global__ __launch_bounds__(256, 1) void vfield_bwd6_kernel(FieldArgs a) {
                 else if (ln >= 0) issue(ln, 0, buf ^ 1);
                 if (DERIV && cg == NCG - 1) {
 #pragma unroll
-                    for (int i = 0; i < PD; ++i) load_h(i, hpre[i]);
+                    for (int i = 0; i < PD; ++i) load_h(i, hpre[i], xpre[i]);
                 }
                 const unsigned char *st = smem_tb + buf * STAGE + lane16;
 #pragma unroll
@@ -1318,6 +1375,7 @@ __global__ __launch_bounds__(256, 1) void vfield_bwd6_kernel(FieldArgs a) {
                 TRUNK_FENCE();
             }
             float *sv = reinterpret_cast<float *>(a.dz) + (size_t)dslot * sstride;
+            float *cv = reinterpret_cast<float *>(a.cpl) + (size_t)dslot * sstride;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 float y[16];
@@ -1325,9 +1383,31 @@ __global__ __launch_bounds__(256, 1) void vfield_bwd6_kernel(FieldArgs a) {
                     float h[16];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) { h[4 * q] = hpre[t % PD][q].x; h[4 * q + 1] = hpre[t % PD][q].y; h[4 * q + 2] = hpre[t % PD][q].z; h[4 * q + 3] = hpre[t % PD][q].w; }
-                    if (t + PD < NT) load_h(t + PD, hpre[t % PD]);
+                    float4 xc[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) xc[q] = xpre[t % PD][q];
+                    if (t + PD < NT) load_h(t + PD, hpre[t % PD], xpre[t % PD]);
+                    const int64_t tile = ((blk * 8 + t) * 4 * 64 + lane) * 4;
+                    if (CPL == 1) {                              // coupling term from the raw accumulators and the saved tangent
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float4 yd = xc[q];
+                            const float ydv[4] = {yd.x, yd.y, yd.z, yd.w};
+                            float c4[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) c4[j] = acc[t][4 * q + j] * ydv[j] * (100.f * (1.f - dsoftplus_from_out(h[4 * q + j], 100.f)));
+                            *reinterpret_cast<float4 *>(cv + tile + q * 256) = make_float4(c4[0], c4[1], c4[2], c4[3]);
+                        }
+                    }
 #pragma unroll
                     for (int g = 0; g < 16; ++g) y[g] = acc[t][g] * dsoftplus_from_out(h[g], 100.f);
+                    if (CPL == 2) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float4 c4 = xc[q];
+                            y[4 * q] += c4.x; y[4 * q + 1] += c4.y; y[4 * q + 2] += c4.z; y[4 * q + 3] += c4.w;
+                        }
+                    }
                 } else {
 #pragma unroll
                     for (int g = 0; g < 16; ++g) y[g] = acc[t][g];
@@ -1706,8 +1786,8 @@ extern "C" int ren_vanilla_bwd(const float *dz_rgb, const float *dz_sigma, const
         (void)hipFuncSetAttribute((const void *)vfield_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds<1>());
         hipLaunchKernelGGL(vfield_bwd_kernel<1>, dim3(vfield_grid(n, TC<1>::NB)), dim3(256), bwd_lds<1>(), st, a);
     } else {
-        (void)hipFuncSetAttribute((const void *)vfield_bwd6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd6_lds());
-        hipLaunchKernelGGL(vfield_bwd6_kernel, dim3(vfield_grid(n, 1)), dim3(256), bwd6_lds(), st, a);
+        (void)hipFuncSetAttribute((const void *)vfield_bwd6_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd6_lds());
+        hipLaunchKernelGGL(vfield_bwd6_kernel<0>, dim3(vfield_grid(n, 1)), dim3(256), bwd6_lds(), st, a);
     }
     REN_CHECK_LAUNCH();
 }
@@ -1793,13 +1873,23 @@ extern "C" int ren_vanilla_fwd_jvp(const float *enc, int32_t ld_enc, const float
     if (!enc || !view || !encd || !viewd || !selector || !params || !image || !sigma || !rgb4 || !zsd4 || !zod4 || n < 0 || ld_enc < 64 ||
         (ld_enc & 3) || ld_view < 32 || (ld_view & 3) || C < 1 || C > 4 || ((saved == nullptr) != (savedd == nullptr)))
         return REN_ERR_BAD_ARG;
-    if (mode != 1 || activations != 0) return REN_ERR_UNSUPPORTED;              // bf16 mode, shipped activations: else the per-layer launches
+    if ((mode != 1 && mode != 6) || activations != 0) return REN_ERR_UNSUPPORTED;   // shipped activations: else the per-layer launches
+    if (mode == 6 && !saved) return REN_ERR_BAD_ARG;                            // fp32 mode: the tangent launch reads the value's saved copies
     if (n == 0) return REN_OK;
     FieldArgs a = {};
     a.enc = enc; a.ld_enc = ld_enc; a.view = view; a.ld_view = ld_view; a.encd = encd; a.viewd = viewd; a.sel = selector; a.P = params;
     a.C = C; a.img = reinterpret_cast<const __bf16 *>(image); a.acts = saved; a.actsd = savedd; a.sigma = sigma; a.rgb4 = rgb4;
     a.zsd4 = zsd4; a.zod4 = zod4; a.n = n;
     hipStream_t st = (hipStream_t)stream;
+    if (mode == 6) {
+        // fp32 round-off mode: two launches of the reduction-outer forward -- the value (saves y), then the tangent, whose
+        // epilogue takes sp'(z) from those saved copies
+        (void)hipFuncSetAttribute((const void *)vfield_fwd6_kernel<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd6_lds());
+        hipLaunchKernelGGL((vfield_fwd6_kernel<true, true, false>), dim3(vfield_grid(n, 1)), dim3(256), fwd6_lds(), st, a);
+        (void)hipFuncSetAttribute((const void *)vfield_fwd6_kernel<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd6_lds());
+        hipLaunchKernelGGL((vfield_fwd6_kernel<true, true, true>), dim3(vfield_grid(n, 1)), dim3(256), fwd6_lds(), st, a);
+        REN_CHECK_LAUNCH();
+    }
     const int grid = vfield_grid(n, 1);
     if (saved) {
         (void)hipFuncSetAttribute((const void *)vfield_fwd_jvp_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_lds<1>());
@@ -1813,16 +1903,28 @@ extern "C" int ren_vanilla_fwd_jvp(const float *enc, int32_t ld_enc, const float
 
 extern "C" int ren_vanilla_bwd_jvp(const float *dz_rgb, const float *dzd_rgb, const float *dz_sigma, const float *dzd_sigma,
                                    const void *image, int32_t mode, int32_t activations, int64_t n, const void *saved, const void *savedd,
-                                   int64_t saved_slot_bytes, void *dz, void *dzd, void *stream) {
+                                   int64_t saved_slot_bytes, void *dz, void *dzd, void *coupling, void *stream) {
     if (!dz_rgb || !dzd_rgb || !dz_sigma || !dzd_sigma || !image || !saved || !savedd || !dz || !dzd || n < 0 || saved_slot_bytes < 0)
         return REN_ERR_BAD_ARG;
-    if (mode != 1 || activations != 0) return REN_ERR_UNSUPPORTED;
+    if ((mode != 1 && mode != 6) || activations != 0) return REN_ERR_UNSUPPORTED;
+    if (mode == 6 && !coupling) return REN_ERR_BAD_ARG;
     if (n == 0) return REN_OK;
     FieldArgs a = {};
-    a.img = reinterpret_cast<const __bf16 *>(image) + (size_t)F_FRAGS * 512;
+    a.img = reinterpret_cast<const __bf16 *>(image) + (size_t)F_FRAGS * vfield_np(mode) * 512;
     a.acts = const_cast<void *>(saved); a.actsd = const_cast<void *>(savedd); a.dz_rgb = dz_rgb; a.dzd_rgb = dzd_rgb; a.dz_sig = dz_sigma;
     a.dzd_sig = dzd_sigma; a.dz = dz; a.dzd = dzd; a.n = n;
-    a.acts_sstride = saved_slot_bytes / 2;
+    a.acts_sstride = saved_slot_bytes / (mode == 1 ? 2 : 4);
+    if (mode == 6) {
+        // the tangent side first (its own chain; leaves the coupling term per layer), then the value side, which adds it
+        a.cpl = coupling;
+        FieldArgs t = a;
+        t.dz_rgb = dzd_rgb; t.dz_sig = dzd_sigma; t.dz = dzd;
+        (void)hipFuncSetAttribute((const void *)vfield_bwd6_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd6_lds());
+        hipLaunchKernelGGL(vfield_bwd6_kernel<1>, dim3(vfield_grid(n, 1)), dim3(256), bwd6_lds(), (hipStream_t)stream, t);
+        (void)hipFuncSetAttribute((const void *)vfield_bwd6_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd6_lds());
+        hipLaunchKernelGGL(vfield_bwd6_kernel<2>, dim3(vfield_grid(n, 1)), dim3(256), bwd6_lds(), (hipStream_t)stream, a);
+        REN_CHECK_LAUNCH();
+    }
     (void)hipFuncSetAttribute((const void *)vfield_bwd_jvp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds<1>());
     hipLaunchKernelGGL(vfield_bwd_jvp_kernel, dim3(vfield_grid(n, 1)), dim3(256), bwd_lds<1>(), (hipStream_t)stream, a);
     REN_CHECK_LAUNCH();

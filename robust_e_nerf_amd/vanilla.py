@@ -192,9 +192,10 @@ class FusedField:
         """reverse pass of forward_jvp for all of B's samples, data gradients -> dz, dzd (fragment slots)"""
         lib = _lib.load()
         dz, dzd = self.new_saved(B.n), self.new_saved(B.n)
+        cpl = self.new_saved(B.n) if self.mode == 6 else None        # fp32 mode: the tangent side's coupling term into dz
         check(lib.ren_vanilla_bwd_jvp(_ptr(dz_rgb), _ptr(dzd_rgb), _ptr(dz_sig), _ptr(dzd_sig), _ptr(self.image, torch.uint8), self.mode,
                                       self.act, B.n, _ptr(B.saved, torch.uint8), _ptr(savedd, torch.uint8), 0, _ptr(dz, torch.uint8),
-                                      _ptr(dzd, torch.uint8), _stream()), "ren_vanilla_bwd_jvp")
+                                      _ptr(dzd, torch.uint8), _ptr(cpl, torch.uint8), _stream()), "ren_vanilla_bwd_jvp")
         return dz, dzd
 
     def backward_jvp_weight(self, dz_rgb, dzd_rgb, dz_sig, dzd_sig, B, savedd, encd, viewd, dz, dzd):
@@ -533,9 +534,9 @@ class VanillaRenderer(Renderer):
         n, C, dev = pk.n, self.field.C, o.device
         second = ddd is not None
         lib = _lib.load()
-        ff = self._fused() if (self.fused_tangent and not second and self._act_code == 0 and self._dense_mode() == 1) else None
+        ff = self._fused() if (self.fused_tangent and not second and self._act_code == 0 and self._dense_mode() in (1, 6)) else None
         if ff is not None:
-            # bf16 mode, first order: value + tangent through all twelve layers in ONE launch (and one for the reverse pass)
+            # first order: value + tangent through all twelve layers in ONE launch each way (bf16 mode) / two (fp32 round-off mode)
             B = _Buffers(n, dev, C, full=True, backward=False, fused=ff, save=True)
             self._encode(B, True, rays=(o, d), samples=(pk.ray_indices, pk.t_starts, pk.t_ends))
             zf = lambda ld: torch.empty(B.n_pad, ld, device=dev, dtype=torch.float32)
