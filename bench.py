@@ -212,6 +212,10 @@ def main():
                     help="weight of the log-intensity-gradient loss (adds a third render with d/dt; 1e-3 in the real-data configs)")
     ap.add_argument("--mlp-bf16", action="store_true",
                     help="BASELINE configs[2] numerics: bf16-rounded linear inputs/weights, fp32 accumulate + composite")
+    ap.add_argument("--mlp-precision", default="highest", choices=["highest", "high", "medium"],
+                    help="the YAMLs' float32_matmul_precision: highest = every MLP product to fp32 round-off (default, the "
+                         "BASELINE configs[1] line); high = each fp32 value as two bf16 pieces, three products (arch ngp); "
+                         "medium = --mlp-bf16")
     ap.add_argument("--prefetch", action="store_true",
                     help="run the next step's batch / ray / sample-count front on a side stream (Trainer.prefetch): the host no "
                          "longer enqueues it on the critical path; ordered after the current step's backward since round 4 "
@@ -315,8 +319,12 @@ def main():
     p["hash"] = (torch.rand(ops.make_grid_desc()[1], generator=gen) * 2 - 1) * 0.1
 
     aabb = (-1.5, -1.5, -1.5, 1.5, 1.5, 1.5)
+    if args.mlp_precision == "medium":
+        args.mlp_bf16 = True
+    precision = "medium" if args.mlp_bf16 else args.mlp_precision
+    high = precision == "high" and args.arch == "ngp" and args.mlp_kernels == "x"      # (anything else runs "high" at fp32 accuracy)
     cfg = engine.RenderCfg(aabb=aabb, sampler=args.sampler, n_uniform=args.samples, mlp_bf16=args.mlp_bf16,
-                           mlp_kernels=args.mlp_kernels, fwd_chunks=args.fwd_chunks,
+                           mlp_precision=precision, mlp_kernels=args.mlp_kernels, fwd_chunks=args.fwd_chunks,
                            save_activations=None if args.save_activations < 0 else bool(args.save_activations))
     cfg.dp_overlap = not args.no_dp_overlap
     cfg.dp_compress = args.dp_compress
@@ -325,7 +333,7 @@ def main():
         aabb = E_AABB
         cfg = engine.RenderCfg(aabb=aabb, contraction_type=ops.UN_BOUNDED_SPHERE, occ_res=(256,) * 3, near_plane=0.05,
                                far_plane=3.0, render_step_size=math.sqrt(3) * 1.5 / 1024, cone_angle=0.004,
-                               sampler="occgrid", mlp_bf16=args.mlp_bf16, mlp_kernels=args.mlp_kernels,
+                               sampler="occgrid", mlp_bf16=args.mlp_bf16, mlp_precision=precision, mlp_kernels=args.mlp_kernels,
                                fwd_chunks=args.fwd_chunks,
                                save_activations=None if args.save_activations < 0 else bool(args.save_activations),
                                dp_overlap=not args.no_dp_overlap, dp_compress=args.dp_compress)
@@ -504,7 +512,7 @@ def main():
             if args.mlp_kernels == "f32" and not args.mlp_bf16:
                 peak, terms, pipe = MFMA_F32_PEAK_TFLOPS, 1, "v_mfma_f32_32x32x2_f32"
             else:
-                peak, terms, pipe = MFMA_BF16_PEAK_TFLOPS, (1 if args.mlp_bf16 else 6), "v_mfma_f32_32x32x16_bf16"
+                peak, terms, pipe = MFMA_BF16_PEAK_TFLOPS, (1 if args.mlp_bf16 else 3 if high else 6), "v_mfma_f32_32x32x16_bf16"
             algorithmic = FLOPS[dom] * samples_per_launch / (per * 1e-3) / 1e12
             achieved = algorithmic * terms
             roof = {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": peak,
@@ -522,7 +530,8 @@ def main():
             # fp32 storage, products and accumulation everywhere.  The default MLP kernels form every product -- outputs, data
             # gradients AND weight gradients -- as the six-term split on the bf16 matrix cores, i.e. to fp32 round-off
             # (test_matrix_core_mlp_kernels_vs_exact_f32_kernels_at_config_b_size); --mlp-kernels f32 runs them on the f32 MFMA
-            "dtype": "bf16-operand/f32-accumulate MLP, f32 elsewhere" if args.mlp_bf16 else "f32",
+            "dtype": "bf16-operand/f32-accumulate MLP, f32 elsewhere" if args.mlp_bf16 else
+                     "f32 (MLP products: float32_matmul_precision high = two bf16 pieces per value, three products)" if high else "f32",
             "data": "synthetic",
             "mlp_samples_per_sec": n_samples / dt, "mean_samples_per_ray": n_samples / rays,
             "loss": float(loss),
@@ -537,6 +546,7 @@ def main():
                        "samples_per_ray": args.samples, "parallelism": f"dp{world}",
                        "collectives_per_step": getattr(tr, "last_collectives", 0), "front_prefetched": bool(can_prefetch),
                        "grad_sampling": (tr.grad_sampling_mode() if args.grad_sampling == "auto" else args.grad_sampling) if args.loss_grad > 0 else None,
+                       "mlp_precision": "highest" if precision == "high" and not high else precision,
                        "device_counts": bool(tr.device_counts_ok() and tr.r._spr is not None),
                        "device_count_overflows": getattr(tr, "device_count_overflows", 0),
                        "fwd_chunks": args.fwd_chunks, "bwd_chunks": args.bwd_chunks,

@@ -67,7 +67,8 @@ int ren_abi_version(void);                       /* bumps when a signature chang
  * variable of the same name (REN_HGB_NO_PAIRS, ...).  None changes results.
  *   REN_KNOB_HGB_NO_PAIRS      1: single-update records on the hashed levels of the binned scatter as well
  *   REN_KNOB_HGB_HALVE_REGIONS 1: halve the bin regions so the overflow path (global atomics) runs
- *   REN_KNOB_MARCH_SEQUENTIAL  1: sequential occupancy marcher instead of the speculative one
+ *   REN_KNOB_MARCH_SEQUENTIAL  1: sequential occupancy marcher instead of the speculative one; 2 / 4 / 8 / 16: that many speculative
+ *                              lanes per ray whatever the ray count (default: by ray count, csrc/ren_sampling.hip)
  *   REN_KNOB_HG_VARIANT        atomic hash-grid backward: bit 0 XCD-affine level mapping, bit 1 lane-pair atomics (default 2)
  *   REN_KNOB_VFIELD_PLAIN      1: arch mlp, bf16 mode: the forward / backward kernels without the software-pipelined epilogue
  *   REN_KNOB_HGB_SUBREGION     binned scatter, which of a pair bin's 8 sub-regions a workgroup appends to: 1 (default) = the one
@@ -441,7 +442,7 @@ int ren_mlp_bwd_jvp(const float *mlp_params, int32_t radiance_dim, int32_t activ
                     float *scratch, float *dfeat, float *dfeatd, float *grad_mlp_params, float *workspace,
                     void *stream);
 /* The same two calls on the bf16 matrix cores (csrc/ren_mlp_jvp_x.hip; default tangent path since ABI v15).
- * mode 6: split-bf16 products at fp32 accuracy; mode 1: plain bf16 operands with fp32 accumulation for value AND tangent
+ * mode 6: split-bf16 products at fp32 accuracy (mode 3: two pieces, three products); mode 1: plain bf16 operands with fp32 accumulation for value AND tangent
  * of every nn.Linear (BASELINE configs[2]: bf16 MLP + fp32 composite with the log-intensity-gradient loss of
  * robust_e_nerf/models/robust_e_nerf.py:383-409 switched on).  Buffers, scratch and layouts as for the calls above. */
 int ren_mlp_fwd_jvp_x(const float *mlp_params, int32_t radiance_dim, int32_t activations, int32_t mode, const float *feat, const float *featd,
@@ -534,7 +535,10 @@ int ren_mlp_bwd_saved(const float *mlp_params, int32_t C, int32_t activations, i
  * The same fused MLPs on the bf16 matrix cores.  mode 6: every fp32 operand is split exactly into three bf16
  * pieces and six bf16 MFMAs per k-chunk reproduce the fp32 product to fp32 round-off (the default training
  * path: the f32 MFMA shares its pipe with the VALU on gfx950, the bf16 MFMA does not).  mode 1: plain bf16
- * operands (BASELINE configs[2]); takes the fp32 parameter block and rounds it itself.
+ * operands (BASELINE configs[2]); takes the fp32 parameter block and rounds it itself.  mode 3: two bf16 pieces per
+ * operand and three products a1 b2 + a2 b1 + a1 b1 -- "each float32 number as the sum of two bfloat16 numbers", i.e.
+ * `float32_matmul_precision: high` of the reference's YAMLs (scripts/run.py:34-35): ~16 significant bits per product,
+ * half of mode 6's matrix-pipe time.  The same three modes for the *_jvp_x / *_jvp2_x entry points.
  * Arguments as ren_mlp_fwd_save / ren_mlp_bwd_saved; act_save may be NULL in the forward (inference).
  * flags: REN_MLP_DENSITY_ONLY (base network and sigma only; rgb may be NULL), REN_MLP_SHARE_CU (one persistent
  * workgroup per CU instead of two, leaving half of each CU to a kernel running on another stream: the engine
@@ -577,7 +581,7 @@ int ren_mlp_fwd_jvp2(const float *mlp_params, int32_t C, int32_t activations, co
                      float *rgb, float *rgbd, float *rgbdd, float *sigma, float *sigmad, float *sigmadd,
                      void *stream);
 /* ren_mlp_fwd_jvp2 on the bf16 matrix cores (csrc/ren_jvp2.hip: mlp_fwd_jvp2_x_kernel); mode 6: split-bf16 at fp32
- * accuracy, mode 1: plain bf16 operands -- the second-order render of a step follows the precision mode of its other
+ * accuracy (3: two pieces, three products), mode 1: plain bf16 operands -- the second-order render of a step follows the precision mode of its other
  * MLP kernels (RenderCfg.mlp_kernels = "x") */
 int ren_mlp_fwd_jvp2_x(const float *mlp_params, int32_t C, int32_t activations, int32_t mode, const float *feat, const float *featd,
                        const float *featdd, const ren_scene_desc *scene, const float *rays_o, const float *rays_d,

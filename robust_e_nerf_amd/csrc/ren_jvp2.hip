@@ -836,7 +836,7 @@ extern "C" int ren_mlp_fwd_jvp2_x(const float *mlp_params, int32_t C, int32_t ac
         !sigmadd || n < 0)
         return REN_ERR_BAD_ARG;
     if (C != 1 && C != 3) return REN_ERR_UNSUPPORTED;
-    if (mode != 1 && mode != 6) return REN_ERR_UNSUPPORTED;
+    if (mode != 1 && mode != 3 && mode != 6) return REN_ERR_UNSUPPORTED;
     if (activations != 0) return REN_ERR_UNSUPPORTED;      // activation alternatives: exact-f32 kernels only
     if (n == 0) return REN_OK;
     Fwd2Args a;
@@ -845,6 +845,7 @@ extern "C" int ren_mlp_fwd_jvp2_x(const float *mlp_params, int32_t C, int32_t ac
     a.ray = Ray2{rays_o, rays_d, rays_do, rays_dd, rays_ddd, ray_indices, t_starts, t_ends};
     a.sc = ren_make_scene(scene);
     a.n = n; a.rgb = rgb; a.rgbd = rgbd; a.rgbdd = rgbdd; a.sigma = sigma; a.sigmad = sigmad; a.sigmadd = sigmadd;
+    if (mode == 3) return launch_fwd_jvp2_x<3>(a, C, (hipStream_t)stream);
     return mode == 6 ? launch_fwd_jvp2_x<6>(a, C, (hipStream_t)stream) : launch_fwd_jvp2_x<1>(a, C, (hipStream_t)stream);
 }
 

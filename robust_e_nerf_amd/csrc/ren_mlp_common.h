@@ -260,6 +260,13 @@ template <> struct Pairs<6> {
     static constexpr int N = 6, NT = 3;
     static constexpr int W[6] = {2, 0, 1, 1, 0, 0}, A[6] = {0, 2, 1, 0, 1, 0};
 };
+// MODE 3: two pieces per fp32 value, three products a1 b2 + a2 b1 + a1 b1 ("each float32 as the sum of two bfloat16":
+// what torch.set_float32_matmul_precision("high") names -- scripts/run.py:34-35, the YAMLs' float32_matmul_precision):
+// ~16 significant bits per product (error <= 2^-16 |a b|), half of MODE 6's matrix-pipe time
+template <> struct Pairs<3> {
+    static constexpr int N = 3, NT = 2;
+    static constexpr int W[3] = {1, 0, 0}, A[3] = {0, 1, 0};
+};
 
 // grad[j] += sum_w slab[w * len + j], deterministic (fixed summation tree, no atomics).  16 parameters x 16
 // slab groups per workgroup: with one thread per parameter walking all ~1 024 slabs the kernel was a 0.1 ms

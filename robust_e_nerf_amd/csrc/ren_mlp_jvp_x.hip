@@ -253,7 +253,7 @@ struct BwdJX2Args {
 };
 
 template <int MODE> struct H2Lds {
-    static constexpr int NT = Pairs<MODE>::NT, NP = MODE == 1 ? 1 : 3;
+    static constexpr int NT = Pairs<MODE>::NT, NP = Pairs<MODE>::NT;
     static constexpr int F_WH1 = 0, F_WH2 = F_WH1 + 2 * 2 * NT * 512, F_WH2T = F_WH2 + 2 * 4 * NT * 512;
     static constexpr int F_END = F_WH2T + 2 * 4 * NT * 512;
     static constexpr int T_W3 = 0, T_BH1 = 256, T_BH2 = 320, T_END = 384;
@@ -478,7 +478,7 @@ struct BwdJX1Args {
 };
 
 template <int MODE> struct H1Lds {
-    static constexpr int NT = Pairs<MODE>::NT, NP = MODE == 1 ? 1 : 3;
+    static constexpr int NT = Pairs<MODE>::NT, NP = Pairs<MODE>::NT;
     static constexpr int F_WH1T = 0, F_END = 1 * 4 * NT * 512;
     static constexpr size_t TILE = (size_t)NP * 32 * ST * 2;
     static constexpr size_t BYTES = (size_t)F_END * 2 + 4 * 2 * TILE;
@@ -603,7 +603,7 @@ struct BwdJXBArgs {
 };
 
 template <int MODE> struct BJLds {
-    static constexpr int NT = Pairs<MODE>::NT, NP = MODE == 1 ? 1 : 3;
+    static constexpr int NT = Pairs<MODE>::NT, NP = Pairs<MODE>::NT;
     static constexpr int F_W1 = 0, F_W2T = F_W1 + 2 * 2 * NT * 512, F_W1T = F_W2T + 2 * 1 * NT * 512;
     static constexpr int F_END = F_W1T + 1 * 4 * NT * 512;
     static constexpr size_t TILE = (size_t)NP * 32 * ST * 2;
@@ -819,7 +819,7 @@ extern "C" int ren_mlp_fwd_jvp_x(const float *mlp_params, int32_t C, int32_t act
         !t_ends || !rgb || !rgbd || !sigma || !sigmad || !base_out || !base_outd || n < 0)
         return REN_ERR_BAD_ARG;
     if (C != 1 && C != 3) return REN_ERR_UNSUPPORTED;
-    if (mode != 1 && mode != 6) return REN_ERR_UNSUPPORTED;
+    if (mode != 1 && mode != 3 && mode != 6) return REN_ERR_UNSUPPORTED;
     if (activations != 0) return REN_ERR_UNSUPPORTED;      // activation alternatives: exact-f32 kernels only
     if (n == 0) return REN_OK;
     FwdJXArgs a;
@@ -828,6 +828,7 @@ extern "C" int ren_mlp_fwd_jvp_x(const float *mlp_params, int32_t C, int32_t act
     a.src = RaySrc{rays_o, rays_d, rays_dd, ray_indices, t_starts, t_ends};
     a.sc = ren_make_scene(scene);
     a.n = n; a.rgb = rgb; a.rgbd = rgbd; a.sigma = sigma; a.sigmad = sigmad; a.base_out = base_out; a.base_outd = base_outd;
+    if (mode == 3) return launch_fwd_jvp_x<3>(a, C, (hipStream_t)stream);
     return mode == 6 ? launch_fwd_jvp_x<6>(a, C, (hipStream_t)stream) : launch_fwd_jvp_x<1>(a, C, (hipStream_t)stream);
 }
 
@@ -849,7 +850,7 @@ extern "C" int ren_mlp_bwd_jvp_x(const float *mlp_params, int32_t C, int32_t act
         !dfeat || !dfeatd || !grad_mlp_params || !workspace || n < 0)
         return REN_ERR_BAD_ARG;
     if (C != 1 && C != 3) return REN_ERR_UNSUPPORTED;
-    if (mode != 1 && mode != 6) return REN_ERR_UNSUPPORTED;
+    if (mode != 1 && mode != 3 && mode != 6) return REN_ERR_UNSUPPORTED;
     if (activations != 0) return REN_ERR_UNSUPPORTED;      // activation alternatives: exact-f32 kernels only
     if (n == 0) return REN_OK;
     const int64_t n_blk = (n + 31) / 32;
@@ -868,6 +869,7 @@ extern "C" int ren_mlp_bwd_jvp_x(const float *mlp_params, int32_t C, int32_t act
     BwdJXBArgs ab;
     ab.params = mlp_params; ab.feat = feat; ab.featd = featd; ab.d_base = d_base; ab.d_based = d_based; ab.n = n; ab.n_dev = n_dev;
     ab.dfeat = dfeat; ab.dfeatd = dfeatd; ab.slab = slabb;
+    if (mode == 3) return launch_bwd_jvp_x<3>(a2, a1, ab, C, grad_mlp_params, (hipStream_t)stream);
     return mode == 6 ? launch_bwd_jvp_x<6>(a2, a1, ab, C, grad_mlp_params, (hipStream_t)stream)
                      : launch_bwd_jvp_x<1>(a2, a1, ab, C, grad_mlp_params, (hipStream_t)stream);
 }

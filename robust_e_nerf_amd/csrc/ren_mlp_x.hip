@@ -240,7 +240,7 @@ extern "C" int ren_mlp_fwd_x(const float *mlp_params, int32_t C, int32_t activat
                              float *rgb, float *sigma, float *base_out, float *act_save, const int64_t *n_dev, void *stream) {
     if (!mlp_params || !feat || !scene || !sigma || n < 0) return REN_ERR_BAD_ARG;
     if (C != 1 && C != 3) return REN_ERR_UNSUPPORTED;
-    if (mode != 1 && mode != 6) return REN_ERR_UNSUPPORTED;
+    if (mode != 1 && mode != 3 && mode != 6) return REN_ERR_UNSUPPORTED;
     if (activations != 0) return REN_ERR_UNSUPPORTED;      // activation alternatives: exact-f32 kernels only
     const bool density_only = (flags & REN_MLP_DENSITY_ONLY) != 0, share = (flags & REN_MLP_SHARE_CU) != 0;
     if (flags & ~(REN_MLP_DENSITY_ONLY | REN_MLP_SHARE_CU)) return REN_ERR_BAD_ARG;
@@ -253,6 +253,7 @@ extern "C" int ren_mlp_fwd_x(const float *mlp_params, int32_t C, int32_t activat
     a.src = SampleSrc{x_world, dirs, rays_o, rays_d, x_world ? nullptr : ray_indices, t_starts, t_ends};
     a.sc = ren_make_scene(scene);
     a.n = n; a.rgb = rgb; a.sigma = sigma; a.base_out = base_out; a.acts = act_save; a.n_dev = n_dev;
+    if (mode == 3) return launch_fwd_x<3>(a, C, density_only, share, (hipStream_t)stream);
     return mode == 6 ? launch_fwd_x<6>(a, C, density_only, share, (hipStream_t)stream)
                      : launch_fwd_x<1>(a, C, density_only, share, (hipStream_t)stream);
 }
@@ -840,7 +841,7 @@ extern "C" int ren_mlp_bwd_x(const float *mlp_params, int32_t C, int32_t activat
         !grad_mlp_params || !workspace || n < 0)
         return REN_ERR_BAD_ARG;
     if (C != 1 && C != 3) return REN_ERR_UNSUPPORTED;
-    if (mode != 1 && mode != 6) return REN_ERR_UNSUPPORTED;
+    if (mode != 1 && mode != 3 && mode != 6) return REN_ERR_UNSUPPORTED;
     if (activations != 0) return REN_ERR_UNSUPPORTED;      // activation alternatives: exact-f32 kernels only
     if (grid_cus < 0) return REN_ERR_BAD_ARG;
     if (!x_world && (!rays_o || !rays_d || !ray_indices || !t_starts || !t_ends)) return REN_ERR_BAD_ARG;
@@ -855,8 +856,10 @@ extern "C" int ren_mlp_bwd_x(const float *mlp_params, int32_t C, int32_t activat
     b.params = mlp_params; b.feat = feat; b.d_base = d_base; b.acts = act_save; b.n = n; b.dfeat = dfeat; b.n_dev = n_dev;
     b.slab = workspace + (int64_t)GRID_XH * 4 * head_len;
     if (act_save)
-        return mode == 6 ? launch_bwd_x<6, false>(h, b, C, grad_mlp_params, grid_cus, (hipStream_t)stream)
+        return mode == 3 ? launch_bwd_x<3, false>(h, b, C, grad_mlp_params, grid_cus, (hipStream_t)stream) :
+               mode == 6 ? launch_bwd_x<6, false>(h, b, C, grad_mlp_params, grid_cus, (hipStream_t)stream)
                          : launch_bwd_x<1, false>(h, b, C, grad_mlp_params, grid_cus, (hipStream_t)stream);
+    if (mode == 3) return launch_bwd_x<3, true>(h, b, C, grad_mlp_params, grid_cus, (hipStream_t)stream);
     return mode == 6 ? launch_bwd_x<6, true>(h, b, C, grad_mlp_params, grid_cus, (hipStream_t)stream)
                      : launch_bwd_x<1, true>(h, b, C, grad_mlp_params, grid_cus, (hipStream_t)stream);
 }

@@ -17,6 +17,7 @@ struct MarchArgs {
     int type;
     float step_size, cone_angle;
     int mode, n_uniform;
+    float rinv[3];                                     // 1 / res[k] where res[k] is a power of two (exact), else 0
 };
 
 __device__ __forceinline__ float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -102,7 +103,10 @@ __device__ __forceinline__ float distance_to_next_voxel(const float *p, const fl
     for (int k = 0; k < 3; ++k) {
         float r = (float)a.res[k];
         float x = u[k] * r;
-        float tx = ((floorf(x + 0.5f + 0.5f * sgnf(dir[k])) - x) * inv_dir[k]) / r * (a.roi[3 + k] - a.roi[k]);
+        // (a division by a power of two IS the multiplication by its reciprocal, bit for bit: 128^3 / 256^3 grids skip the
+        // IEEE division sequence here, a quarter of an empty-cell step)
+        const float q = (floorf(x + 0.5f + 0.5f * sgnf(dir[k])) - x) * inv_dir[k];
+        float tx = (a.rinv[k] != 0.f ? q * a.rinv[k] : q / r) * (a.roi[3 + k] - a.roi[k]);
         if (tx < t) t = tx;
     }
     return t > 0.f ? t : 0.f;
@@ -192,9 +196,12 @@ __global__ void ray_march_kernel(const float *__restrict__ o, const float *__res
 // lane decides how the group continues, exactly as the sequential loop does at that step.  In contracted space an
 // empty cell advances the state like an occupied one, so all SPEC lanes always count.  Output is bit-identical to
 // ray_march_kernel (same tests); dense rays need 1/SPEC of the load round trips (SPEC 8 -> 16: 96 -> 77 us for 16 k rays at configs[4] settings).
-constexpr int SPEC = 16;
-
-template <bool WRITE>
+// SPEC lanes per ray: every iteration costs SPEC - 1 redundant state transitions of VALU work per lane and saves up to SPEC - 1
+// load round trips, so the best width falls as the ray count (= the waves per SIMD that hide the round trips anyway) grows.
+// Count passes of a training step, ms (round 5, 128^3 grid, bench.py --sampler occgrid; sequential / 2 / 4 / 8 / 16 lanes):
+//   12 k + 6 k rays   0.72 / 0.67 / 0.52 / 0.44 / 0.44        33 k + 16 k rays  0.80 / 0.71 / 0.58 / 0.60 / 0.90
+//   66 k rays         0.43 / 0.36 / 0.34 / 0.45 / 0.61        131 k rays        0.42 / 0.45 / 0.55 / 0.72 / 1.05
+template <bool WRITE, int SPEC>
 __global__ __launch_bounds__(256) void ray_march_spec_kernel(
     const float *__restrict__ o, const float *__restrict__ d, const float *__restrict__ t_min,
     const float *__restrict__ t_max, const float *__restrict__ jitter, int64_t n_rays, MarchArgs a,
@@ -592,14 +599,38 @@ extern "C" int ren_ray_march(const float *rays_o, const float *rays_d, const flo
     MarchArgs a;
     for (int k = 0; k < 6; ++k) a.roi[k] = roi ? roi[k] : (k < 3 ? -1e10f : 1e10f);
     for (int k = 0; k < 3; ++k) a.res[k] = res ? res[k] : 1;
+    for (int k = 0; k < 3; ++k) a.rinv[k] = (a.res[k] > 0 && (a.res[k] & (a.res[k] - 1)) == 0) ? 1.f / (float)a.res[k] : 0.f;
     a.type = contraction_type; a.step_size = step_size; a.cone_angle = cone_angle;
     a.mode = mode; a.n_uniform = n_uniform;
     dim3 grid(ren_blocks(n_rays, 64)), block(64);   // short blocks: ray lengths vary a lot
-    const bool force_seq = ren_knob(REN_KNOB_MARCH_SEQUENTIAL) == 1;           // tuning/verification knob
-    // speculation spends SPEC lanes per ray to cut load round trips: it wins while the launch is latency-bound
-    // (measured: 2x at 15 k rays, 3x slower at 131 k rays where the sequential kernel already fills the chip)
-    const bool spec = mode == 0 && n_rays <= 24576 && !force_seq;
-    const dim3 sgrid(ren_blocks(n_rays * SPEC, 256));
+    // tuning / verification knob: 1 = sequential kernel only; 2, 4, 8, 16 = that many speculative lanes per ray whatever the size
+    const int kn = ren_knob(REN_KNOB_MARCH_SEQUENTIAL);
+    // speculation spends SPEC lanes per ray to cut load round trips: it wins while the launch is latency-bound, and the
+    // width that wins shrinks as the rays alone fill the chip (see the table at the kernel)
+    int width = n_rays <= 10240 ? 16 : n_rays <= 24576 ? 8 : n_rays <= 81920 ? 4 : 0;
+    if (kn == 1) width = 0;
+    else if (kn == 2 || kn == 4 || kn == 8 || kn == 16) width = kn;
+    if (mode != 0) width = 0;
+    const dim3 sgrid(ren_blocks(n_rays * (width ? width : 1), 256));
+#define REN_MARCH_SPEC(WRITE)                                                                                              \
+    do {                                                                                                                   \
+        if (width == 16)                                                                                                   \
+            hipLaunchKernelGGL((ray_march_spec_kernel<WRITE, 16>), sgrid, dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, \
+                               t_min, t_max, jitter, n_rays, a, binary, offsets, counts, ray_indices, t_starts, t_ends,    \
+                               cache, cache_cap);                                                                          \
+        else if (width == 8)                                                                                               \
+            hipLaunchKernelGGL((ray_march_spec_kernel<WRITE, 8>), sgrid, dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, \
+                               t_min, t_max, jitter, n_rays, a, binary, offsets, counts, ray_indices, t_starts, t_ends,    \
+                               cache, cache_cap);                                                                          \
+        else if (width == 4)                                                                                               \
+            hipLaunchKernelGGL((ray_march_spec_kernel<WRITE, 4>), sgrid, dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, \
+                               t_min, t_max, jitter, n_rays, a, binary, offsets, counts, ray_indices, t_starts, t_ends,    \
+                               cache, cache_cap);                                                                          \
+        else                                                                                                               \
+            hipLaunchKernelGGL((ray_march_spec_kernel<WRITE, 2>), sgrid, dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, \
+                               t_min, t_max, jitter, n_rays, a, binary, offsets, counts, ray_indices, t_starts, t_ends,    \
+                               cache, cache_cap);                                                                          \
+    } while (0)
     if (write && mode == 1)
         hipLaunchKernelGGL(uniform_write_kernel, dim3(ren_blocks(n_rays * n_uniform, 256)), dim3(256), 0,
                            (hipStream_t)stream, t_min, t_max, jitter, n_rays, n_uniform, offsets, ray_indices,
@@ -608,22 +639,19 @@ extern "C" int ren_ray_march(const float *rays_o, const float *rays_d, const flo
         if (cache)
             hipLaunchKernelGGL(cached_write_kernel, dim3(ren_blocks(n_rays * 8, 256)), dim3(256), 0, (hipStream_t)stream,
                                cache, cache_cap, n_rays, offsets, counts, ray_indices, t_starts, t_ends);
-        if (spec)
-            hipLaunchKernelGGL(ray_march_spec_kernel<true>, sgrid, dim3(256), 0, (hipStream_t)stream, rays_o, rays_d,
-                               t_min, t_max, jitter, n_rays, a, binary, offsets, counts, ray_indices,
-                               t_starts, t_ends, cache, cache_cap);
+        if (width)
+            REN_MARCH_SPEC(true);
         else
             hipLaunchKernelGGL(ray_march_kernel<true>, grid, block, 0, (hipStream_t)stream, rays_o, rays_d,
                                t_min, t_max, jitter, n_rays, a, binary, offsets, counts, ray_indices,
                                t_starts, t_ends, cache, cache_cap);
-    } else if (spec)
-        hipLaunchKernelGGL(ray_march_spec_kernel<false>, sgrid, dim3(256), 0, (hipStream_t)stream, rays_o, rays_d,
-                           t_min, t_max, jitter, n_rays, a, binary, offsets, counts, ray_indices,
-                           t_starts, t_ends, cache, cache_cap);
+    } else if (width)
+        REN_MARCH_SPEC(false);
     else
         hipLaunchKernelGGL(ray_march_kernel<false>, grid, block, 0, (hipStream_t)stream, rays_o, rays_d,
                            t_min, t_max, jitter, n_rays, a, binary, offsets, counts, ray_indices,
                            t_starts, t_ends, cache, cache_cap);
+#undef REN_MARCH_SPEC
     REN_CHECK_LAUNCH();
 }
 

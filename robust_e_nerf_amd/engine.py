@@ -64,6 +64,11 @@ class RenderCfg:
                                        # counts back in the middle of every render: external/utils.py:106-119, models/nerf.py:279-286;
                                        # SURVEY 7.2 H4).  None = auto: on for the Trainer's renders on one GPU (Trainer.device_counts_ok)
     mlp_bf16: bool = False             # BASELINE configs[2]: bf16 MLP (rounded linear inputs/weights, fp32 accumulate), fp32 composite
+    mlp_precision: str = "highest"     # the YAMLs' float32_matmul_precision (scripts/run.py:34-35, torch.set_float32_matmul_precision):
+                                       # "highest": every MLP product to fp32 round-off (six bf16 products of three pieces);
+                                       # "high": "each float32 as the sum of two bfloat16" -- three bf16 products, ~16 significant
+                                       # bits per product, half of the matrix-pipe time (arch ngp on the "x" kernels; anything else
+                                       # stays at "highest"); "medium": bf16 operands = mlp_bf16
     # activation alternatives of the YAML (model.nerf.ngp.mlp_base / mlp_head: models/nerf.py:8-29).  Anything but the
     # shipped values runs on the exact-f32 MLP kernels (mlp_kernels is switched to "f32"): arch ngp only
     base_hidden_activation: str = "softplus"          # softplus (beta 100) | relu
@@ -283,6 +288,10 @@ class Renderer:
         self._count_ring, self._count_ring_at = None, 0
         self._act_code = ops.activation_code(cfg.base_hidden_activation, cfg.density_activation, cfg.head_hidden_activation,
                                              cfg.radiance_activation)
+        if cfg.mlp_precision not in ("highest", "high", "medium"):
+            raise ValueError(f"mlp_precision {cfg.mlp_precision!r}: highest | high | medium")
+        if cfg.mlp_precision == "medium":
+            cfg.mlp_bf16 = True
         if self._act_code != 0 and isinstance(fld, NGPField):
             cfg.mlp_kernels = "f32"                 # the bf16-matrix-core kernels implement the shipped activations only
         # (arch mlp: vanilla.VanillaRenderer switches to its per-layer launches, in any matrix-core mode)
@@ -473,7 +482,7 @@ class Renderer:
         return (c.mlp_kernels != "x") if c.save_activations is None else bool(c.save_activations)
 
     def _xmode(self) -> int:
-        return 1 if self.cfg.mlp_bf16 else 6
+        return 1 if self.cfg.mlp_bf16 else 3 if self.cfg.mlp_precision == "high" else 6
 
     def _field_forward(self, o, d, pk, save):
         f = self.field

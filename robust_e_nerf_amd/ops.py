@@ -504,7 +504,8 @@ def mlp_bwd_saved(mlp_params, C: int, feat, base_out, acts, scene: SceneDesc, *,
 def mlp_fwd_x(mlp_params, C: int, mode: int, feat, scene: SceneDesc, *, rays=None, samples=None, x_world=None, dirs=None,
               n: int, density_only: bool = False, save: bool = False, out=None, share_cu: bool = False, save_acts: bool = True,
               act: int = 0, n_dev=None):
-    """Split-bf16 matrix-core kernels (csrc/ren_mlp_x.hip).  mode 6: fp32 accuracy; mode 1: plain bf16 operands.
+    """Split-bf16 matrix-core kernels (csrc/ren_mlp_x.hip).  mode 6: fp32 accuracy; mode 3: two bf16 pieces / three products
+    (float32_matmul_precision "high"); mode 1: plain bf16 operands.
     -> rgb, sigma, base, acts (base/acts None unless save; acts None with save_acts=False: mlp_bwd_x then recomputes
     the hidden activations); out: preallocated (rgb, sigma, base, acts) views"""
     dev = feat.device

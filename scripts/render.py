@@ -73,7 +73,7 @@ def main():
                             near_plane=ncfg.get("near_plane"), far_plane=ncfg.get("far_plane"), render_step_size=float(step_size),
                             cone_angle=float(ncfg["cone_angle"]), early_stop_eps=float(ncfg["early_stop_eps"]),
                             alpha_thre=float(ncfg["alpha_thre"]), min_modeled_intensity=float(mcfg["min_modeled_intensity"]),
-                            mlp_bf16=cfg.get("float32_matmul_precision", "highest") == "medium")
+                            mlp_precision=cfg.get("float32_matmul_precision", "highest"))
     arch = ncfg.get("arch", "ngp")
     cli.check_supported(ncfg, arch)
     for k_, v_ in cli.activation_fields(ncfg, arch).items():

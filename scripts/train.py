@@ -210,15 +210,19 @@ def main():
     og = ncfg["occ_grid"]
     # float32_matmul_precision (scripts/run.py:34-35, torch.set_float32_matmul_precision): "highest" = fp32 products,
     # "medium" = bf16 operands with fp32 accumulation = the bf16 matrix-core mode of the fused MLPs (BASELINE configs[2]);
-    # "high" (TF32) has no MI355X counterpart and runs at fp32 accuracy
-    mlp_bf16 = args.mlp_bf16 or cfg.get("float32_matmul_precision", "highest") == "medium"
+    # "high" = "each float32 as the sum of two bfloat16" (torch's wording): three bf16 products per fp32 product instead of six
+    # (arch ngp; arch mlp runs "high" at fp32 accuracy)
+    precision = cfg.get("float32_matmul_precision", "highest")
+    if precision not in ("highest", "high", "medium"):
+        raise ValueError(f"float32_matmul_precision: {precision!r} (highest | high | medium)")
+    mlp_bf16 = args.mlp_bf16 or precision == "medium"
     rcfg = engine.RenderCfg(aabb=tuple(float(v) for v in aabb), contraction_type=ct, occ_res=(int(og["resolution"]),) * 3,
                             near_plane=ncfg.get("near_plane"), far_plane=ncfg.get("far_plane"),
                             render_step_size=float(step_size), cone_angle=float(ncfg["cone_angle"]),
                             early_stop_eps=float(ncfg["early_stop_eps"]), alpha_thre=float(ncfg["alpha_thre"]),
                             min_modeled_intensity=float(mcfg["min_modeled_intensity"]), occ_thre=float(og["occ_thre"]),
                             ema_decay=float(og["ema_decay"]), warmup_steps=int(og["warmup_steps"]), occ_n=int(og["n"]),
-                            mlp_bf16=mlp_bf16)
+                            mlp_bf16=mlp_bf16, mlp_precision="medium" if mlp_bf16 else precision)
     arch = ncfg.get("arch", "ngp")
     check_supported(ncfg, arch)
     for k_, v_ in activation_fields(ncfg, arch).items():
