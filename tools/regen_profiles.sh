@@ -23,6 +23,8 @@ python bench.py --no-cpu-baseline --events 32768 --loss-grad 1e-3 > profiles/${R
 python bench.py --no-cpu-baseline --events 32768 --loss-grad 1e-3 --mlp-bf16 > profiles/${RND}_bench_lossgrad_bf16.json 2>>$O/bench.err
 python bench.py --no-cpu-baseline --mlp-bf16 > profiles/${RND}_bench_bf16.json 2>>$O/bench.err
 python bench.py --no-cpu-baseline --mlp-kernels f32 > profiles/${RND}_bench_f32mfma.json 2>>$O/bench.err
+python bench.py --no-cpu-baseline --mlp-precision high > profiles/${RND}_bench_precision_high.json 2>>$O/bench.err
+python bench.py --no-cpu-baseline --sampler occgrid --events 16384 --loss-grad 1e-3 --mlp-precision high > profiles/${RND}_bench_occgrid_lossgrad_16k_precision_high.json 2>>$O/bench.err
 python bench.py --no-cpu-baseline --save-activations 1 > profiles/${RND}_bench_saved_activations.json 2>>$O/bench.err
 python bench.py --no-cpu-baseline --workload e --events 8192 > profiles/${RND}_bench_config_e.json 2>>$O/bench.err
 python bench.py --no-cpu-baseline --events 32768 --hard --loss-grad 1e-3 --mlp-bf16 > profiles/${RND}_bench_hard_bf16.json 2>>$O/bench.err
