@@ -173,6 +173,7 @@ def main():
     ap.add_argument("--steps-per-epoch", type=int, default=500)
     ap.add_argument("--arch", default="ngp", choices=["ngp", "mlp"])
     ap.add_argument("--budget", type=int, default=1 << 20, help="train_eff_ray_sample_batch_size")
+    ap.add_argument("--precision", default="highest", choices=["highest", "high", "medium"], help="float32_matmul_precision of the YAML")
     args = ap.parse_args()
     data_dir = os.path.join(args.out, "dataset")
     t0 = time.perf_counter()
@@ -183,6 +184,7 @@ def main():
     cfg = yaml.safe_load(open(os.path.join(REPO, "configs", "synthetic_smoke.yaml")))
     cfg["data"].update(dataset_directory=data_dir, train_init_eff_batch_size=65536 if args.arch == "ngp" else 2048, train_eff_ray_sample_batch_size=args.budget)
     cfg["model"]["nerf"]["arch"] = args.arch
+    cfg["float32_matmul_precision"] = args.precision
     cfg["trainer"].update(max_epochs=args.epochs, limit_train_batches=args.steps_per_epoch, log_every_n_steps=100)
     cfg["lr_scheduler"]["multi_step_lr"]["milestones"] = [max(1, args.epochs // 2), max(2, 3 * args.epochs // 4), max(3, 9 * args.epochs // 10)]
     cfg_path = os.path.join(args.out, "train.yaml")
