@@ -71,6 +71,13 @@ def _act_name(v, slot: str) -> str:
     raise NotImplementedError(f"{slot} activation {v!r}")
 
 
+def matmul_mode() -> int:
+    """mode of the matrix-core MLP kernels for the process-wide torch.get_float32_matmul_precision() -- the switch the
+    reference sets from its YAML (scripts/run.py:34-35): highest -> 6 (every product to fp32 round-off), high -> 3 (each
+    float32 as two bfloat16, three products), medium -> 1 (bf16 operands)"""
+    return {"highest": 6, "high": 3, "medium": 1}[torch.get_float32_matmul_precision()]
+
+
 class _FieldFn(torch.autograd.Function):
     """(x_world, dirs, table, *mlp tensors) -> (rgb (n,C), sigma (n,1)) with analytic backward to the
     table and MLP parameters (positions / directions are not differentiated on this path)."""
@@ -84,8 +91,14 @@ class _FieldFn(torch.autograd.Function):
         xu = contract_points(x_world, m.aabb.tolist(), m.contraction_type.value)
         feat = ops.hashgrid_fwd(m.encoding.grid, table, x_unit=xu, n=n, layout=1)
         dirs_c = None if dirs is None else dirs.contiguous().float()
-        rgb, sigma, base = ops.mlp_fwd(mlp, m.radiance_dim, feat, m.scene, x_world=x_world, dirs=dirs_c, n=n,
-                                       density_only=density_only, save_base=not density_only, act=m._act_code)
+        # shipped activation set: the matrix-core kernels in the precision torch is set to; alternatives: exact-f32 kernels
+        ctx.xmode = matmul_mode() if m._act_code == 0 else None
+        if ctx.xmode is not None:
+            rgb, sigma, base, _ = ops.mlp_fwd_x(mlp, m.radiance_dim, ctx.xmode, feat, m.scene, x_world=x_world, dirs=dirs_c, n=n,
+                                                density_only=density_only, save=not density_only, save_acts=False)
+        else:
+            rgb, sigma, base = ops.mlp_fwd(mlp, m.radiance_dim, feat, m.scene, x_world=x_world, dirs=dirs_c, n=n,
+                                           density_only=density_only, save_base=not density_only, act=m._act_code)
         ctx.module, ctx.n, ctx.density_only = m, n, density_only
         ctx.shapes = [t.shape for t in mlp_tensors]
         if not density_only:
@@ -105,9 +118,14 @@ class _FieldFn(torch.autograd.Function):
         g_rgb = torch.zeros_like(rgb) if g_rgb is None else g_rgb.contiguous().float()
         g_sigma = torch.zeros(n, device=dev) if g_sigma is None else g_sigma.reshape(-1).contiguous().float()
         g_mlp = torch.zeros_like(mlp)
-        ws = torch.empty(ops.mlp_bwd_workspace_floats(m.radiance_dim), device=dev, dtype=torch.float32)
-        dfeat = ops.mlp_bwd(mlp, m.radiance_dim, feat, base, m.scene, x_world=x_world, dirs=dirs, n=n, rgb=rgb,
-                            d_rgb=g_rgb, d_sigma=g_sigma, grad_mlp_params=g_mlp, workspace=ws, act=m._act_code)
+        if ctx.xmode is not None:
+            ws = torch.empty(ops.mlp_bwd_x_workspace_floats(m.radiance_dim), device=dev, dtype=torch.float32)
+            dfeat = ops.mlp_bwd_x(mlp, m.radiance_dim, ctx.xmode, feat, base, None, m.scene, x_world=x_world, dirs=dirs, n=n,
+                                  rgb=rgb, d_rgb=g_rgb, d_sigma=g_sigma, grad_mlp_params=g_mlp, workspace=ws)
+        else:
+            ws = torch.empty(ops.mlp_bwd_workspace_floats(m.radiance_dim), device=dev, dtype=torch.float32)
+            dfeat = ops.mlp_bwd(mlp, m.radiance_dim, feat, base, m.scene, x_world=x_world, dirs=dirs, n=n, rgb=rgb,
+                                d_rgb=g_rgb, d_sigma=g_sigma, grad_mlp_params=g_mlp, workspace=ws, act=m._act_code)
         g_table = torch.zeros(m.encoding.n_params, device=dev, dtype=torch.float32)
         ops.hashgrid_bwd_auto(m.encoding.grid, g_table, dfeat, x_unit=xu, n=n, layout=1)
         outs, off = [], 0

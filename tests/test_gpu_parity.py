@@ -1426,6 +1426,38 @@ def _seam_field(amd, g, table):
     return rf
 
 
+def test_seam_field_follows_torch_matmul_precision(amd, full_table_cache):
+    """The reference sets torch.set_float32_matmul_precision from its YAML (scripts/run.py:34-35).  The module seam
+    (field.NGPradianceField) runs its MLPs on the matrix-core kernels in THAT precision: highest = every product to fp32
+    round-off, high = two bf16 pieces / three products, medium = bf16 operands -- outputs and parameter gradients."""
+    g = load_golden("training_step_diff")
+    table = full_table_cache(g["table_seed"], g["table_scale"])
+    rf = _seam_field(amd, g, table)
+    rf.train()
+    gen = torch.Generator().manual_seed(3)
+    x = dev((torch.rand(4096, 3, generator=gen) * 2.6 - 1.3).float())
+    d = torch.randn(4096, 3, generator=gen)
+    d = dev((d / d.norm(dim=-1, keepdim=True)).float())
+    w_rgb, w_sig = dev(torch.randn(4096, 1, generator=gen)), dev(torch.randn(4096, 1, generator=gen) * 0.1)
+    old, out = torch.get_float32_matmul_precision(), {}
+    try:
+        for prec in ("highest", "high", "medium"):
+            torch.set_float32_matmul_precision(prec)
+            rf.zero_grad()
+            rgb, sigma = rf(x, d)
+            ((rgb * w_rgb).sum() + (sigma * w_sig).sum()).backward()
+            out[prec] = (rgb.detach().clone(), sigma.detach().clone(),
+                         torch.cat([p.grad.reshape(-1) for n_, p in rf.named_parameters() if "mlp_base.0" not in n_]).clone(),
+                         rf.encoding.params.grad.clone())
+    finally:
+        torch.set_float32_matmul_precision(old)
+    hi = out["highest"]
+    for prec, tol, floor in (("high", 2e-4, 1e-7), ("medium", 5e-2, 1e-4)):
+        errs = [rel_err(a, b) for a, b in zip(out[prec], hi)]
+        print(prec, "vs highest: rgb, sigma, d mlp, d table", " ".join(f"{e:.2e}" for e in errs))
+        assert max(errs) < tol and max(errs) > floor, (prec, errs)
+
+
 def test_opwise_seam_matches_fused_engine_and_reference(amd, full_table_cache):
     """nerfacc-/tcnn-shaped ops + reference-shaped glue (autograd) == fused engine == reference golden."""
     ops, engine = amd
