@@ -214,7 +214,7 @@ def main():
                     help="BASELINE configs[2] numerics: bf16-rounded linear inputs/weights, fp32 accumulate + composite")
     ap.add_argument("--mlp-precision", default="highest", choices=["highest", "high", "medium"],
                     help="the YAMLs' float32_matmul_precision: highest = every MLP product to fp32 round-off (default, the "
-                         "BASELINE configs[1] line); high = each fp32 value as two bf16 pieces, three products (arch ngp); "
+                         "BASELINE configs[1] line); high = each fp32 value as two bf16 pieces, three products; "
                          "medium = --mlp-bf16")
     ap.add_argument("--prefetch", action="store_true",
                     help="run the next step's batch / ray / sample-count front on a side stream (Trainer.prefetch): the host no "
@@ -322,7 +322,7 @@ def main():
     if args.mlp_precision == "medium":
         args.mlp_bf16 = True
     precision = "medium" if args.mlp_bf16 else args.mlp_precision
-    high = precision == "high" and args.arch == "ngp" and args.mlp_kernels == "x"      # (anything else runs "high" at fp32 accuracy)
+    high = precision == "high" and args.mlp_kernels == "x"      # (the exact-f32 kernels run "high" at fp32 accuracy)
     cfg = engine.RenderCfg(aabb=aabb, sampler=args.sampler, n_uniform=args.samples, mlp_bf16=args.mlp_bf16,
                            mlp_precision=precision, mlp_kernels=args.mlp_kernels, fwd_chunks=args.fwd_chunks,
                            save_activations=None if args.save_activations < 0 else bool(args.save_activations))

@@ -658,8 +658,9 @@ int ren_vanilla_heads_bwd(const float *g_rgb, const float *rgb, const float *g_s
  * Replaces NerfMLP.forward / query_density (robust_e_nerf/external/mlp.py:126-205: eight hidden Linear + Softplus(beta = 100)
  * with the skip concatenation after layer 4, sigma layer, bottleneck, 283 -> 128 -> C colour head) and its autograd:
  * activations stay in registers from layer to layer.  `params`: the field's parameter block (reference state-dict order,
- * torch layout).  `mode`: REN_DENSE_BF16 (1: bf16 operands, saved copies in bf16) or REN_DENSE_BF16X6 (6: three-piece split,
- * fp32 round-off, saved copies in fp32).  `image` (ren_vanilla_image_bytes) is the MFMA-fragment form of the weights: rebuild
+ * torch layout).  `mode`: REN_DENSE_BF16 (1: bf16 operands, saved copies in bf16), REN_DENSE_BF16X6 (6: three-piece split,
+ * fp32 round-off, saved copies in fp32) or 3 (two pieces, three products = `float32_matmul_precision: high`; layouts of
+ * mode 6, an image of two pieces; every ren_vanilla_* entry point, not the per-layer ren_dense_* ones).  `image` (ren_vanilla_image_bytes) is the MFMA-fragment form of the weights: rebuild
  * it with ren_vanilla_prep whenever the parameters change.  `saved` / `dz` (ren_vanilla_saved_bytes each) hold the layers'
  * activations / pre-activation gradients in the kernels' fragment layout (documented in ren_vfield.hip).
  * fwd: enc [n_pad][ld_enc >= 64], view [n_pad][ld_view >= 32], selector [n_pad] are the outputs of ren_freq_encode (rows

@@ -81,6 +81,7 @@ constexpr int N_SLOTS = 10;                              // saved / dz slots (se
 template <int MODE> struct TC;
 template <> struct TC<1> { static constexpr int NP = 1, NB = 2, NTS = 2; typedef __bf16 ST; };
 template <> struct TC<6> { static constexpr int NP = 3, NB = 1, NTS = 1; typedef float ST; };
+template <> struct TC<3> { static constexpr int NP = 2, NB = 1, NTS = 1; typedef float ST; };   // two pieces, three products: the fp32 family's layouts
 
 // ---- weight images -------------------------------------------------------------------------------------------------
 template <int NP>
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(256) void vfield_prep_kernel(const float *__restric
         while (l < NL - 1 && fr >= f_off(l + 1)) ++l;
         const int nch = l_nch(l), r = fr - f_off(l), kin = l_in(l), nh = l_nh(l);
         // bf16 mode: [tile][chunk] (a stage = tiles); fp32 mode: [chunk][tile] (a stage = two chunks of all tiles)
-        const int t = NP == 3 ? r % l_nt(l) : r / nch, c = NP == 3 ? r / l_nt(l) : r % nch;
+        const int t = NP > 1 ? r % l_nt(l) : r / nch, c = NP > 1 ? r / l_nt(l) : r % nch;
         const int row = t * 32 + sl;
         const float *W = P + l_woff(l, C) + row * kin;
 #pragma unroll
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(256) void vfield_prep_kernel(const float *__restric
         for (int i = 2; i < NL; ++i)
             if (i != L_SIGMA && fr >= b_off(i)) l = i;
         const int nch = b_nch(l), r = fr - b_off(l), kin = l_in(l);
-        const int t = NP == 3 ? r % b_nt(l) : r / nch, c = NP == 3 ? r / b_nt(l) : r % nch;
+        const int t = NP > 1 ? r % b_nt(l) : r / nch, c = NP > 1 ? r / b_nt(l) : r % nch;
         const int i = t * 32 + sl;                       // input index = row of W^T
         const float *W = P + l_woff(l, C) + i;
 #pragma unroll
@@ -1081,10 +1082,10 @@ __global__ __launch_bounds__(256, 1) void vfield_bwd_jvp_kernel(FieldArgs a) {
 // wave: 128 fp32 activations + 128 accumulators fill the register file): inputs are d/dt of the encodings, there is no bias,
 // and the epilogue multiplies by sp'(z) taken from the VALUE launch's saved copies (`acts`, read) -- yd = sp'(z) (W ad) --
 // and saves yd to `actsd`; the heads leave their tangent pre-activations in zsd4 / zod4.
-template <bool SAVE, bool FULL, bool TAN = false>
+template <bool SAVE, bool FULL, bool TAN = false, int MODE = 6>     // MODE 6 | 3 (float32_matmul_precision high: two pieces, three products)
 __global__ __launch_bounds__(256, 1) void vfield_fwd6_kernel(FieldArgs a) {
-    using PR = Pairs<6>;
-    constexpr int NP = 3;
+    using PR = Pairs<MODE>;
+    constexpr int NP = PR::NT;
     constexpr int STAGE = 2 * 8 * NP * 1024;             // two chunks x eight tiles
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
     float *bias = reinterpret_cast<float *>(smem_all);
@@ -1155,7 +1156,7 @@ __global__ __launch_bounds__(256, 1) void vfield_fwd6_kernel(FieldArgs a) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) xs[j] = c < NH ? yprev[(c >> 1) & 7][8 * (c & 1) + j] : ef[(c - NH) % (NE ? NE : 1)][j];
                     bf16x8 xp[3];
-                    split8<3>(xs, xp);
+                    split8<NP>(xs, xp);
 #pragma unroll
                     for (int t0 = 0; t0 < NT; t0 += 2) { // two tiles at a time: consecutive MFMAs alternate accumulators
                         bf16x8 w[2][NP];
@@ -1268,10 +1269,10 @@ __global__ __launch_bounds__(256, 1) void vfield_fwd6_kernel(FieldArgs a) {
 // of their own -- d loss / d zd_(l-1) = (W^T dzd_l) sp'(z_(l-1)), i.e. this kernel as it is -- and couple INTO the value side:
 // dz_(l-1) = (W^T dz_l) s + (W^T dzd_l) yd_(l-1) beta (1 - s).  CPL 1 (run first, on the tangent-side inputs): also writes
 // that second term, from its own accumulators and the saved tangent `actsd`, to `cpl`; CPL 2 (the value side): adds it.
-template <int CPL = 0>
+template <int CPL = 0, int MODE = 6>
 __global__ __launch_bounds__(256, 1) void vfield_bwd6_kernel(FieldArgs a) {
-    using PR = Pairs<6>;
-    constexpr int NP = 3;
+    using PR = Pairs<MODE>;
+    constexpr int NP = PR::NT;
     constexpr int STAGE = 2 * 8 * NP * 1024;
     constexpr int PD = 2;                                // saved-activation tiles in flight (16 registers each)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_tb[];
@@ -1355,7 +1356,7 @@ __global__ __launch_bounds__(256, 1) void vfield_bwd6_kernel(FieldArgs a) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) xs[j] = c < NH ? yprev[(c >> 1) & 7][8 * (c & 1) + j] : ef[j];
                     bf16x8 xp[3];
-                    split8<3>(xs, xp);
+                    split8<NP>(xs, xp);
 #pragma unroll
                     for (int t0 = 0; t0 < NT; t0 += 2) {
                         bf16x8 w[2][NP];
@@ -1700,22 +1701,23 @@ __global__ __launch_bounds__(512, 1) void vfield_dw_kernel(FieldDwArgs a) {
 }
 
 template <int MODE> size_t fwd_lds() { return LB_FLOATS * 4 + 2 * (size_t)TC<MODE>::NTS * 20 * TC<MODE>::NP * 1024; }
-static size_t fwd6_lds() { return LB_FLOATS * 4 + 2 * (size_t)2 * 8 * 3 * 1024; }
-static size_t bwd6_lds() { return 2 * (size_t)2 * 8 * 3 * 1024; }
+static size_t fwd6_lds(int np = 3) { return LB_FLOATS * 4 + 2 * (size_t)2 * 8 * np * 1024; }
+static size_t bwd6_lds(int np = 3) { return 2 * (size_t)2 * 8 * np * 1024; }
 template <int MODE> size_t bwd_lds() { return 2 * (size_t)TC<MODE>::NTS * 17 * TC<MODE>::NP * 1024; }
 
 }  // namespace
 
-static inline int vfield_np(int mode) { return mode == 1 ? 1 : 3; }
-static inline bool vfield_ok(int mode, int C) { return (mode == 1 || mode == 6) && C >= 1 && C <= 4; }
+static inline int vfield_np(int mode) { return mode == 1 ? 1 : mode == 3 ? 2 : 3; }
+static inline bool vfield_mode_ok(int mode) { return mode == 1 || mode == 3 || mode == 6; }
+static inline bool vfield_ok(int mode, int C) { return vfield_mode_ok(mode) && C >= 1 && C <= 4; }
 
 extern "C" int64_t ren_vanilla_image_bytes(int32_t mode) {
-    if (mode != 1 && mode != 6) return -1;
+    if (!vfield_mode_ok(mode)) return -1;
     return (int64_t)(F_FRAGS + B_FRAGS) * vfield_np(mode) * 1024;
 }
 
 extern "C" int64_t ren_vanilla_saved_bytes(int32_t mode, int64_t n) {
-    if ((mode != 1 && mode != 6) || n < 0) return -1;
+    if (!vfield_mode_ok(mode) || n < 0) return -1;
     const int64_t per_grp = 4 * (mode == 1 ? TC<1>::NB : TC<6>::NB), n_grp = ((n + 31) / 32 + per_grp - 1) / per_grp;
     return N_SLOTS * n_grp * per_grp * 32 * 256 * (mode == 1 ? 2 : 4);          // whole workgroup passes of 32-sample blocks
 }
@@ -1726,6 +1728,7 @@ extern "C" int ren_vanilla_prep(const float *params, int32_t C, int32_t mode, vo
     __bf16 *f = reinterpret_cast<__bf16 *>(image), *b = f + (size_t)F_FRAGS * np * 512;
     const int blocks = ((F_FRAGS + B_FRAGS) * 64 + 255) / 256;
     if (mode == 1) hipLaunchKernelGGL(vfield_prep_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, C, f, b);
+    else if (mode == 3) hipLaunchKernelGGL(vfield_prep_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, C, f, b);
     else hipLaunchKernelGGL(vfield_prep_kernel<3>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, C, f, b);
     REN_CHECK_LAUNCH();
 }
@@ -1762,19 +1765,20 @@ extern "C" int ren_vanilla_fwd(const float *enc, int32_t ld_enc, const float *vi
         else if (saved) REN_VFIELD_FWD1(true, true); else if (rgb4) REN_VFIELD_FWD1(false, true); else REN_VFIELD_FWD1(false, false);
     }
     else {
-#define REN_VFIELD_FWD6(SAVE, FULL)                                                                                             \
+#define REN_VFIELD_FWD6(SAVE, FULL, MODE)                                                                                       \
     do {                                                                                                                        \
-        (void)hipFuncSetAttribute((const void *)vfield_fwd6_kernel<SAVE, FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd6_lds()); \
-        hipLaunchKernelGGL((vfield_fwd6_kernel<SAVE, FULL>), dim3(vfield_grid(n, 1)), dim3(256), fwd6_lds(), st, a);            \
+        (void)hipFuncSetAttribute((const void *)vfield_fwd6_kernel<SAVE, FULL, false, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd6_lds(vfield_np(MODE))); \
+        hipLaunchKernelGGL((vfield_fwd6_kernel<SAVE, FULL, false, MODE>), dim3(vfield_grid(n, 1)), dim3(256), fwd6_lds(vfield_np(MODE)), st, a); \
     } while (0)
-        if (saved) REN_VFIELD_FWD6(true, true); else if (rgb4) REN_VFIELD_FWD6(false, true); else REN_VFIELD_FWD6(false, false);
+        if (mode == 3) { if (saved) REN_VFIELD_FWD6(true, true, 3); else if (rgb4) REN_VFIELD_FWD6(false, true, 3); else REN_VFIELD_FWD6(false, false, 3); }
+        else if (saved) REN_VFIELD_FWD6(true, true, 6); else if (rgb4) REN_VFIELD_FWD6(false, true, 6); else REN_VFIELD_FWD6(false, false, 6);
     }
     REN_CHECK_LAUNCH();
 }
 
 extern "C" int ren_vanilla_bwd(const float *dz_rgb, const float *dz_sigma, const void *image, int32_t mode, int32_t activations, int64_t n,
                                const void *saved, int64_t saved_slot_bytes, void *dz, void *stream) {
-    if (!dz_rgb || !dz_sigma || !image || !saved || !dz || (mode != 1 && mode != 6) || n < 0 || saved_slot_bytes < 0) return REN_ERR_BAD_ARG;
+    if (!dz_rgb || !dz_sigma || !image || !saved || !dz || !vfield_mode_ok(mode) || n < 0 || saved_slot_bytes < 0) return REN_ERR_BAD_ARG;
     if (activations != 0) return REN_ERR_UNSUPPORTED;
     if (n == 0) return REN_OK;
     FieldArgs a = {};
@@ -1785,6 +1789,9 @@ extern "C" int ren_vanilla_bwd(const float *dz_rgb, const float *dz_sigma, const
     if (mode == 1) {
         (void)hipFuncSetAttribute((const void *)vfield_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds<1>());
         hipLaunchKernelGGL(vfield_bwd_kernel<1>, dim3(vfield_grid(n, TC<1>::NB)), dim3(256), bwd_lds<1>(), st, a);
+    } else if (mode == 3) {
+        (void)hipFuncSetAttribute((const void *)vfield_bwd6_kernel<0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd6_lds(2));
+        hipLaunchKernelGGL((vfield_bwd6_kernel<0, 3>), dim3(vfield_grid(n, 1)), dim3(256), bwd6_lds(2), st, a);
     } else {
         (void)hipFuncSetAttribute((const void *)vfield_bwd6_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd6_lds());
         hipLaunchKernelGGL(vfield_bwd6_kernel<0>, dim3(vfield_grid(n, 1)), dim3(256), bwd6_lds(), st, a);
@@ -1843,7 +1850,7 @@ static int vanilla_bwd_weight_impl(const void *dz, const void *saved, int64_t sa
         else if (xfrag) REN_VFIELD_DW(MODE, false, true, false);                                                                \
         else REN_VFIELD_DW(MODE, false, false, true);                                                                           \
     } while (0)
-        if (mode == 1) REN_VFIELD_DW_MODE(1); else REN_VFIELD_DW_MODE(6);
+        if (mode == 1) REN_VFIELD_DW_MODE(1); else if (mode == 3) REN_VFIELD_DW_MODE(3); else REN_VFIELD_DW_MODE(6);
         launch_reduce_slabs(a.slab_w, n_splits, a.N * a.K + (no_bias ? 0 : a.N), grads + l_woff(l, C), st, a.slab_stride);
     }
     REN_CHECK_LAUNCH();
@@ -1873,21 +1880,27 @@ extern "C" int ren_vanilla_fwd_jvp(const float *enc, int32_t ld_enc, const float
     if (!enc || !view || !encd || !viewd || !selector || !params || !image || !sigma || !rgb4 || !zsd4 || !zod4 || n < 0 || ld_enc < 64 ||
         (ld_enc & 3) || ld_view < 32 || (ld_view & 3) || C < 1 || C > 4 || ((saved == nullptr) != (savedd == nullptr)))
         return REN_ERR_BAD_ARG;
-    if ((mode != 1 && mode != 6) || activations != 0) return REN_ERR_UNSUPPORTED;   // shipped activations: else the per-layer launches
-    if (mode == 6 && !saved) return REN_ERR_BAD_ARG;                            // fp32 mode: the tangent launch reads the value's saved copies
+    if (!vfield_mode_ok(mode) || activations != 0) return REN_ERR_UNSUPPORTED;   // shipped activations: else the per-layer launches
+    if (mode != 1 && !saved) return REN_ERR_BAD_ARG;                            // fp32 mode: the tangent launch reads the value's saved copies
     if (n == 0) return REN_OK;
     FieldArgs a = {};
     a.enc = enc; a.ld_enc = ld_enc; a.view = view; a.ld_view = ld_view; a.encd = encd; a.viewd = viewd; a.sel = selector; a.P = params;
     a.C = C; a.img = reinterpret_cast<const __bf16 *>(image); a.acts = saved; a.actsd = savedd; a.sigma = sigma; a.rgb4 = rgb4;
     a.zsd4 = zsd4; a.zod4 = zod4; a.n = n;
     hipStream_t st = (hipStream_t)stream;
-    if (mode == 6) {
-        // fp32 round-off mode: two launches of the reduction-outer forward -- the value (saves y), then the tangent, whose
+    if (mode != 1) {
+        // fp32 family (modes 6 / 3): two launches of the reduction-outer forward -- the value (saves y), then the tangent, whose
         // epilogue takes sp'(z) from those saved copies
-        (void)hipFuncSetAttribute((const void *)vfield_fwd6_kernel<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd6_lds());
-        hipLaunchKernelGGL((vfield_fwd6_kernel<true, true, false>), dim3(vfield_grid(n, 1)), dim3(256), fwd6_lds(), st, a);
-        (void)hipFuncSetAttribute((const void *)vfield_fwd6_kernel<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd6_lds());
-        hipLaunchKernelGGL((vfield_fwd6_kernel<true, true, true>), dim3(vfield_grid(n, 1)), dim3(256), fwd6_lds(), st, a);
+#define REN_VFIELD_FWD6_JVP(MODE)                                                                                               \
+    do {                                                                                                                        \
+        const size_t lds = fwd6_lds(vfield_np(MODE));                                                                           \
+        (void)hipFuncSetAttribute((const void *)vfield_fwd6_kernel<true, true, false, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((vfield_fwd6_kernel<true, true, false, MODE>), dim3(vfield_grid(n, 1)), dim3(256), lds, st, a);      \
+        (void)hipFuncSetAttribute((const void *)vfield_fwd6_kernel<true, true, true, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((vfield_fwd6_kernel<true, true, true, MODE>), dim3(vfield_grid(n, 1)), dim3(256), lds, st, a);       \
+    } while (0)
+        if (mode == 3) REN_VFIELD_FWD6_JVP(3); else REN_VFIELD_FWD6_JVP(6);
+#undef REN_VFIELD_FWD6_JVP
         REN_CHECK_LAUNCH();
     }
     const int grid = vfield_grid(n, 1);
@@ -1906,23 +1919,29 @@ extern "C" int ren_vanilla_bwd_jvp(const float *dz_rgb, const float *dzd_rgb, co
                                    int64_t saved_slot_bytes, void *dz, void *dzd, void *coupling, void *stream) {
     if (!dz_rgb || !dzd_rgb || !dz_sigma || !dzd_sigma || !image || !saved || !savedd || !dz || !dzd || n < 0 || saved_slot_bytes < 0)
         return REN_ERR_BAD_ARG;
-    if ((mode != 1 && mode != 6) || activations != 0) return REN_ERR_UNSUPPORTED;
-    if (mode == 6 && !coupling) return REN_ERR_BAD_ARG;
+    if (!vfield_mode_ok(mode) || activations != 0) return REN_ERR_UNSUPPORTED;
+    if (mode != 1 && !coupling) return REN_ERR_BAD_ARG;
     if (n == 0) return REN_OK;
     FieldArgs a = {};
     a.img = reinterpret_cast<const __bf16 *>(image) + (size_t)F_FRAGS * vfield_np(mode) * 512;
     a.acts = const_cast<void *>(saved); a.actsd = const_cast<void *>(savedd); a.dz_rgb = dz_rgb; a.dzd_rgb = dzd_rgb; a.dz_sig = dz_sigma;
     a.dzd_sig = dzd_sigma; a.dz = dz; a.dzd = dzd; a.n = n;
     a.acts_sstride = saved_slot_bytes / (mode == 1 ? 2 : 4);
-    if (mode == 6) {
+    if (mode != 1) {
         // the tangent side first (its own chain; leaves the coupling term per layer), then the value side, which adds it
         a.cpl = coupling;
         FieldArgs t = a;
         t.dz_rgb = dzd_rgb; t.dz_sig = dzd_sigma; t.dz = dzd;
-        (void)hipFuncSetAttribute((const void *)vfield_bwd6_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd6_lds());
-        hipLaunchKernelGGL(vfield_bwd6_kernel<1>, dim3(vfield_grid(n, 1)), dim3(256), bwd6_lds(), (hipStream_t)stream, t);
-        (void)hipFuncSetAttribute((const void *)vfield_bwd6_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd6_lds());
-        hipLaunchKernelGGL(vfield_bwd6_kernel<2>, dim3(vfield_grid(n, 1)), dim3(256), bwd6_lds(), (hipStream_t)stream, a);
+#define REN_VFIELD_BWD6_JVP(MODE)                                                                                               \
+    do {                                                                                                                        \
+        const size_t lds = bwd6_lds(vfield_np(MODE));                                                                           \
+        (void)hipFuncSetAttribute((const void *)vfield_bwd6_kernel<1, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((vfield_bwd6_kernel<1, MODE>), dim3(vfield_grid(n, 1)), dim3(256), lds, (hipStream_t)stream, t);     \
+        (void)hipFuncSetAttribute((const void *)vfield_bwd6_kernel<2, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((vfield_bwd6_kernel<2, MODE>), dim3(vfield_grid(n, 1)), dim3(256), lds, (hipStream_t)stream, a);     \
+    } while (0)
+        if (mode == 3) REN_VFIELD_BWD6_JVP(3); else REN_VFIELD_BWD6_JVP(6);
+#undef REN_VFIELD_BWD6_JVP
         REN_CHECK_LAUNCH();
     }
     (void)hipFuncSetAttribute((const void *)vfield_bwd_jvp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds<1>());

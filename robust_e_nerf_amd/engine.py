@@ -67,8 +67,8 @@ class RenderCfg:
     mlp_precision: str = "highest"     # the YAMLs' float32_matmul_precision (scripts/run.py:34-35, torch.set_float32_matmul_precision):
                                        # "highest": every MLP product to fp32 round-off (six bf16 products of three pieces);
                                        # "high": "each float32 as the sum of two bfloat16" -- three bf16 products, ~16 significant
-                                       # bits per product, half of the matrix-pipe time (arch ngp on the "x" kernels; anything else
-                                       # stays at "highest"); "medium": bf16 operands = mlp_bf16
+                                       # bits per product, half of the matrix-pipe time (the "x" kernels of arch ngp and the fused
+                                       # field of arch mlp; anything else stays at "highest"); "medium": bf16 operands = mlp_bf16
     # activation alternatives of the YAML (model.nerf.ngp.mlp_base / mlp_head: models/nerf.py:8-29).  Anything but the
     # shipped values runs on the exact-f32 MLP kernels (mlp_kernels is switched to "f32"): arch ngp only
     base_hidden_activation: str = "softplus"          # softplus (beta 100) | relu

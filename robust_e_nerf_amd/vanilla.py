@@ -192,7 +192,7 @@ class FusedField:
         """reverse pass of forward_jvp for all of B's samples, data gradients -> dz, dzd (fragment slots)"""
         lib = _lib.load()
         dz, dzd = self.new_saved(B.n), self.new_saved(B.n)
-        cpl = self.new_saved(B.n) if self.mode == 6 else None        # fp32 mode: the tangent side's coupling term into dz
+        cpl = self.new_saved(B.n) if self.mode != 1 else None        # fp32 family (modes 6 / 3): the tangent side's coupling term into dz
         check(lib.ren_vanilla_bwd_jvp(_ptr(dz_rgb), _ptr(dzd_rgb), _ptr(dz_sig), _ptr(dzd_sig), _ptr(self.image, torch.uint8), self.mode,
                                       self.act, B.n, _ptr(B.saved, torch.uint8), _ptr(savedd, torch.uint8), 0, _ptr(dz, torch.uint8),
                                       _ptr(dzd, torch.uint8), _ptr(cpl, torch.uint8), _stream()), "ren_vanilla_bwd_jvp")
@@ -317,11 +317,17 @@ class VanillaRenderer(Renderer):
             return 1
         return 6 if self.cfg.mlp_kernels == "x" else 0
 
+    def _fused_mode(self) -> int:
+        """mode of the fused field (ren_vanilla_*): as _dense_mode(), and 3 -- two bf16 pieces per value, three products -- for
+        `float32_matmul_precision: high` (RenderCfg.mlp_precision; the per-layer launches run that setting at fp32 accuracy)"""
+        mode = self._dense_mode()
+        return 3 if mode == 6 and self.cfg.mlp_precision == "high" else mode
+
     def _fused(self) -> Optional[FusedField]:
         """the fused-field object of the current matrix-core mode with a weight image of the CURRENT parameters, or None
         (exact-f32 mode / fused_field off).  Called once per field evaluation: the image is 9 us to rebuild, which is cheaper
         than tracking every place the flat parameter buffer can change (Adam, load, tests)."""
-        mode = self._dense_mode()
+        mode = self._fused_mode()
         if not self.fused_field or mode == 0:
             return None
         ff = self._fused_fields.get(mode)
@@ -534,7 +540,7 @@ class VanillaRenderer(Renderer):
         n, C, dev = pk.n, self.field.C, o.device
         second = ddd is not None
         lib = _lib.load()
-        ff = self._fused() if (self.fused_tangent and not second and self._act_code == 0 and self._dense_mode() in (1, 6)) else None
+        ff = self._fused() if (self.fused_tangent and not second and self._act_code == 0 and self._fused_mode() in (1, 3, 6)) else None
         if ff is not None:
             # first order: value + tangent through all twelve layers in ONE launch each way (bf16 mode) / two (fp32 round-off mode)
             B = _Buffers(n, dev, C, full=True, backward=False, fused=ff, save=True)

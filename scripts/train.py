@@ -211,7 +211,7 @@ def main():
     # float32_matmul_precision (scripts/run.py:34-35, torch.set_float32_matmul_precision): "highest" = fp32 products,
     # "medium" = bf16 operands with fp32 accumulation = the bf16 matrix-core mode of the fused MLPs (BASELINE configs[2]);
     # "high" = "each float32 as the sum of two bfloat16" (torch's wording): three bf16 products per fp32 product instead of six
-    # (arch ngp; arch mlp runs "high" at fp32 accuracy)
+    # (the matrix-core MLP kernels of arch ngp and the fused field of arch mlp)
     precision = cfg.get("float32_matmul_precision", "highest")
     if precision not in ("highest", "high", "medium"):
         raise ValueError(f"float32_matmul_precision: {precision!r} (highest | high | medium)")

@@ -24,4 +24,6 @@ cd $R
 python bench.py --no-cpu-baseline --arch mlp --events 4096 > profiles/${RND}_bench_arch_mlp.json 2> $O/am.err
 python bench.py --no-cpu-baseline --arch mlp --events 4096 --mlp-bf16 > profiles/${RND}_bench_arch_mlp_bf16.json 2>> $O/am.err
 python bench.py --no-cpu-baseline --arch mlp --events 4096 --mlp-kernels f32 > profiles/${RND}_bench_arch_mlp_f32mfma.json 2>> $O/am.err
+python bench.py --no-cpu-baseline --arch mlp --events 4096 --mlp-precision high > profiles/${RND}_bench_arch_mlp_precision_high.json 2>> $O/am.err
+python bench.py --no-cpu-baseline --arch mlp --events 4096 --loss-grad 1e-3 --mlp-precision high > profiles/${RND}_bench_arch_mlp_lossgrad_precision_high.json 2>> $O/am.err
 cp profiles/${RND}_*arch_mlp* $O/; ls $O
