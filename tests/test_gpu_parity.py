@@ -103,12 +103,14 @@ def test_ray_marching_bit_exact(amd, ct, res, cone, near, far):
     ri, ts, te = ops.ray_march_write(*args, offsets, int(total))
     assert torch.equal(ri.cpu(), ri_o) and torch.equal(ts.cpu(), ts_o) and torch.equal(te.cpu(), te_o)
     assert int(total) > 1000
-    # the speculative kernel (8 lanes per ray, used for <= 24 576 rays) against the sequential one
-    with ops.knob("march_sequential", 1):
-        counts_s = ops.ray_march_count(*args)
-        ri_s, ts_s, te_s = ops.ray_march_write(*args, offsets, int(total))
-        torch.cuda.synchronize()
-    assert torch.equal(counts_s, counts) and torch.equal(ri_s, ri) and torch.equal(ts_s, ts) and torch.equal(te_s, te)
+    # the sequential kernel (knob 1) and every speculative width (2 / 4 / 8 / 16 lanes per ray; the default picks one by ray
+    # count: 16 here) give the same streams
+    for width in (1, 2, 4, 8, 16):
+        with ops.knob("march_sequential", width):
+            counts_s = ops.ray_march_count(*args)
+            ri_s, ts_s, te_s = ops.ray_march_write(*args, offsets, int(total))
+            torch.cuda.synchronize()
+        assert torch.equal(counts_s, counts) and torch.equal(ri_s, ri) and torch.equal(ts_s, ts) and torch.equal(te_s, te), width
     # interval cache between the two passes (march once): identical streams, also when most rays overflow it
     for cap in (7, 1024):
         cache = torch.empty(R, cap, 2, device=DEV)
