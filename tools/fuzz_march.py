@@ -28,8 +28,8 @@ for trial in range(48):
     jit = torch.rand(R, generator=g).to(dev)
     args = (o, d, tmin, tmax, jit, aabb, (res,) * 3, binary, ct, step, cone, 0, 0)
     out = {}
-    for seq in ("1", "0"):
-        _lib.load().ren_set_knob(ops.KNOBS["march_sequential"], int(seq))
+    for seq in ("1", "0"):                 # sequential kernel | FUZZ_WIDTH (0: the default policy; 2 / 4 / 8 / 16 lanes; 32: look-ahead)
+        _lib.load().ren_set_knob(ops.KNOBS["march_sequential"], 1 if seq == "1" else int(os.environ.get("FUZZ_WIDTH", "0")))
         counts = ops.ray_march_count(*args)
         offsets, total = ops.exclusive_scan(counts)
         n = int(total)
