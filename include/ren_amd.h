@@ -121,7 +121,10 @@ int ren_ray_aabb_intersect(const float *rays_o, const float *rays_d, int64_t n_r
  * exclusive cumsum of counts) given, writes ray_indices/t_starts/t_ends.
  * interval_cache (optional, mode 0): float[n_rays * cache_cap * 2].  Pass 1 keeps the first cache_cap
  * intervals of every ray in it; pass 2 (same cache, and counts given as well) copies them instead of marching
- * again and re-marches only the rays with more than cache_cap samples.  Same output either way. */
+ * again and re-marches only the rays with more than cache_cap samples.  Same output either way.
+ * mode | REN_MARCH_VERIFIED_DIV: the three divisions by the roi's extents per visited cell run as a multiply-add sequence
+ * that ren_march_div_check() has shown to be bit-identical to the division for THIS roi (same output; -15 % on the pass). */
+#define REN_MARCH_VERIFIED_DIV 0x100
 int ren_ray_march(const float *rays_o, const float *rays_d, const float *t_min,
                   const float *t_max, const float *jitter, int64_t n_rays,
                   const float *roi_host, const int32_t *res_host, const uint8_t *binary,
@@ -130,6 +133,13 @@ int ren_ray_march(const float *rays_o, const float *rays_d, const float *t_min,
                   const int64_t *offsets, int32_t *counts,
                   int32_t *ray_indices, float *t_starts, float *t_ends, float *interval_cache,
                   int32_t cache_cap, void *stream);
+
+/* Exhaustive check behind REN_MARCH_VERIFIED_DIV: for each of the three extents b = roi[3 + k] - roi[k] (host floats, 2^-60 < b <
+ * 2^60) every float a with 2^-100 < |a| < 2^100 is divided both ways -- a / b and q0 = a y, q = fma(fma(-q0, b, a), y, q0) with
+ * y = RN(1 / b) -- and mismatches[0] (device) receives the number of pairs that differ in any bit (~1e10 divisions, ~20 ms; once
+ * per scene box).  REN_ERR_UNSUPPORTED for a box with a corner coordinate of 0 (or below 2^-60): position differences could then
+ * fall below the checked range.  The flag is for finite rays with |position| < 2^100. */
+int ren_march_div_check(const float *roi, int64_t *mismatches, void *stream);
 /* exclusive cumsum of counts[n] (int32) -> offsets[n] (int64), total[1] (int64) */
 /* out[n] = iid U[0, 1) floats (24 bits), Philox4x32-10 keyed by `seed` at stream position `offset` (e.g. the step number): the
  * per-ray jitter of stratified sampling without a framework RNG launch (models/nerf.py:209-215 draws it with torch.rand). */

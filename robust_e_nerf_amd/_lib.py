@@ -41,6 +41,7 @@ SIGNATURES = {
     "ren_raygen_fwd": (c_int, [P, P, P, P, c_int64, P, P, P]),
     "ren_pose_rays_fwd": (c_int, [P, c_int64, P, c_int64, P, P, P, P, c_int64, P, P, P]),
     "ren_ray_aabb_intersect": (c_int, [P, P, c_int64, POINTER(c_float), c_float, c_float, P, P, P]),
+    "ren_march_div_check": (c_int, [POINTER(c_float), P, P]),
     "ren_ray_march": (c_int, [P, P, P, P, P, c_int64, POINTER(c_float), POINTER(c_int32), P, c_int32,
                               c_float, c_float, c_int32, c_int32, P, P, P, P, P, P, c_int32, P]),
     "ren_compact_features": (c_int, [P, P, P, c_int64, P, P, P, P]),

@@ -18,6 +18,8 @@ struct MarchArgs {
     float step_size, cone_angle;
     int mode, n_uniform;
     float rinv[3];                                     // 1 / res[k] where res[k] is a power of two (exact), else 0
+    float rext[3];                                     // RN(1 / (roi[3 + k] - roi[k])): the verified division (fastdiv)
+    int fastdiv;                                       // REN_MARCH_VERIFIED_DIV: the caller ran ren_march_div_check on this roi
 };
 
 __device__ __forceinline__ float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -54,20 +56,40 @@ __global__ void ray_aabb_kernel(const float *__restrict__ o, const float *__rest
     t_max[i] = hi;
 }
 
-__device__ __forceinline__ void roi_to_unit(const float *p, const float *roi, float *u) {
+// a / b for a FIXED divisor b with y = RN(1 / b): q0 = a y, r = a - q0 b (exact, one fma), q = q0 + r y (Markstein).  For a
+// given b this is bit-identical to the IEEE division for every a it has been CHECKED on: ren_march_div_check() runs all ~3.4e9
+// values of 2^-100 < |a| < 2^100 against the three extents of a scene box once (the caller then sets REN_MARCH_VERIFIED_DIV).
+// The numerators here are p - roi_lo with a box corner of normal magnitude (2^-60 <= |roi_lo|, also checked there): such a
+// difference is 0 (0 both ways) or at least half an ulp of the corner, i.e. > 2^-100; above 2^100 lie only positions no finite
+// ray of a scene reaches (a run-time guard for them cost the spec kernels the whole gain).  Three dependent operations instead
+// of the ~11 of the division sequence, once per visited cell: -8 .. -13 % on the count passes (bound by their VALU chain).
+__device__ __forceinline__ float div_verified(float a, float b, float y) {
+    const float q0 = a * y;
+    return __fmaf_rn(__fmaf_rn(-q0, b, a), y, q0);
+}
+__device__ __forceinline__ void roi_to_unit(const float *p, const MarchArgs &a, float *u) {
+    float num[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) u[k] = (p[k] - roi[k]) / (roi[3 + k] - roi[k]);
+    for (int k = 0; k < 3; ++k) num[k] = p[k] - a.roi[k];
+    if (a.fastdiv) {                                             // (uniform)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) u[k] = div_verified(num[k], a.roi[3 + k] - a.roi[k], a.rext[k]);
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) u[k] = num[k] / (a.roi[3 + k] - a.roi[k]);
 }
 
-__device__ __forceinline__ bool grid_occupied_at(const float *p, const MarchArgs &a,
+// `u0` = roi_to_unit(p): computed ONCE per visited position by the caller and shared with distance_to_next_voxel (with the
+// branch inside roi_to_unit the compiler no longer merges the two computations by itself)
+__device__ __forceinline__ bool grid_occupied_at(const float *p, const float *u0, const MarchArgs &a,
                                                  const uint8_t *__restrict__ binary) {
     if (a.type == REN_CT_AABB) {
 #pragma unroll
         for (int k = 0; k < 3; ++k)
             if (p[k] < a.roi[k] || p[k] > a.roi[3 + k]) return false;
     }
-    float u[3];
-    roi_to_unit(p, a.roi, u);
+    float u[3] = {u0[0], u0[1], u0[2]};
     if (a.type == REN_CT_SPHERE) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) u[k] = u[k] * 2.f - 1.f;
@@ -95,10 +117,9 @@ __device__ __forceinline__ bool grid_occupied_at(const float *p, const MarchArgs
 
 __device__ __forceinline__ float sgnf(float v) { return (float)((v > 0.f) - (v < 0.f)); }
 
-__device__ __forceinline__ float distance_to_next_voxel(const float *p, const float *dir,
+__device__ __forceinline__ float distance_to_next_voxel(const float *u, const float *dir,
                                                         const float *inv_dir, const MarchArgs &a) {
-    float u[3], t = 1e30f;
-    roi_to_unit(p, a.roi, u);
+    float t = 1e30f;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         float r = (float)a.res[k];
@@ -160,8 +181,9 @@ __global__ void ray_march_kernel(const float *__restrict__ o, const float *__res
     float t1 = t0 + dt;
     float t_mid = (t0 + t1) * 0.5f;
     while (t_mid < far) {
-        float p[3] = {ro[0] + t_mid * rd[0], ro[1] + t_mid * rd[1], ro[2] + t_mid * rd[2]};
-        if (grid_occupied_at(p, a, binary)) {
+        float p[3] = {ro[0] + t_mid * rd[0], ro[1] + t_mid * rd[1], ro[2] + t_mid * rd[2]}, u[3];
+        roi_to_unit(p, a, u);
+        if (grid_occupied_at(p, u, a, binary)) {
             if (WRITE) {
                 t_starts[base + j] = t0;
                 t_ends[base + j] = t1;
@@ -174,7 +196,7 @@ __global__ void ray_march_kernel(const float *__restrict__ o, const float *__res
             t1 = t0 + calc_dt(t0, a.cone_angle, dt_min, dt_max);
             t_mid = (t0 + t1) * 0.5f;
         } else if (a.type == REN_CT_AABB) {
-            float t_target = t_mid + distance_to_next_voxel(p, rd, inv_dir, a);
+            float t_target = t_mid + distance_to_next_voxel(u, rd, inv_dir, a);
             do { t_mid += dt_min; } while (t_mid < t_target);
             dt = calc_dt(t_mid, a.cone_angle, dt_min, dt_max);
             t0 = t_mid - dt * 0.5f;
@@ -233,7 +255,9 @@ __global__ __launch_bounds__(256) void ray_march_spec_kernel(
     // the sequential loop's step through an EMPTY cell (aabb only): skip to the next voxel in dt_min steps
     auto empty_step = [&](float tm, float &n0, float &n1, float &nm) {
         const float p[3] = {ro[0] + tm * rd[0], ro[1] + tm * rd[1], ro[2] + tm * rd[2]};
-        const float t_target = tm + distance_to_next_voxel(p, rd, inv_dir, a);
+        float u[3];
+        roi_to_unit(p, a, u);
+        const float t_target = tm + distance_to_next_voxel(u, rd, inv_dir, a);
         do { tm += dt_min; } while (tm < t_target);
         const float dt = calc_dt(tm, a.cone_angle, dt_min, dt_max);
         n0 = tm - dt * 0.5f;
@@ -256,7 +280,9 @@ __global__ __launch_bounds__(256) void ray_march_spec_kernel(
             bool occ = false;
             if (in) {
                 const float p[3] = {ro[0] + em * rd[0], ro[1] + em * rd[1], ro[2] + em * rd[2]};
-                occ = grid_occupied_at(p, a, binary);
+                float u[3];
+                roi_to_unit(p, a, u);
+                occ = grid_occupied_at(p, u, a, binary);
             }
             const unsigned in_bits = (unsigned)(__ballot(in) >> g0) & ((1u << SPEC) - 1u);
             const unsigned occ_bits = (unsigned)(__ballot(occ) >> g0) & ((1u << SPEC) - 1u);
@@ -282,7 +308,9 @@ __global__ __launch_bounds__(256) void ray_march_spec_kernel(
         bool occ = false;
         if (in) {
             const float p[3] = {ro[0] + am * rd[0], ro[1] + am * rd[1], ro[2] + am * rd[2]};
-            occ = grid_occupied_at(p, a, binary);
+            float u[3];
+            roi_to_unit(p, a, u);
+            occ = grid_occupied_at(p, u, a, binary);
         }
         const unsigned in_bits = (unsigned)(__ballot(in) >> g0) & ((1u << SPEC) - 1u);
         const unsigned occ_bits = (unsigned)(__ballot(occ) >> g0) & ((1u << SPEC) - 1u);
@@ -578,6 +606,42 @@ extern "C" int ren_ray_aabb_intersect(const float *rays_o, const float *rays_d, 
     REN_CHECK_LAUNCH();
 }
 
+// Exhaustive check of div_verified() against the division for the three extents of a box: every float a with
+// 2^-100 < |a| < 2^100 (exponent fields 27 .. 226, both signs: 3.4e9 values per extent, ~20 ms in all).  mismatches[0] = how
+// many (a, extent) pairs differ in any bit; 0 = the caller may set REN_MARCH_VERIFIED_DIV for this roi.
+__global__ __launch_bounds__(256) void march_div_check_kernel(float b0, float b1, float b2, float y0, float y1, float y2,
+                                                              unsigned long long *__restrict__ mismatches) {
+    const float b[3] = {b0, b1, b2}, y[3] = {y0, y1, y2};
+    unsigned bad = 0;
+    // mantissa + low exponent bits from the thread, the rest of the exponent range from the loop
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;       // 2^24 threads: 23 mantissa bits + sign
+    const uint32_t low = (t & 0x7fffffu) | ((t >> 23) << 31);
+    for (uint32_t e = 27; e <= 226; ++e) {
+        const float a = __uint_as_float(low | (e << 23));
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float q = a / b[k], f = div_verified(a, b[k], y[k]);
+            bad += __float_as_uint(q) != __float_as_uint(f);
+        }
+    }
+    if (bad) atomicAdd(mismatches, (unsigned long long)bad);
+}
+
+extern "C" int ren_march_div_check(const float *roi, int64_t *mismatches, void *stream) {
+    if (!roi || !mismatches) return REN_ERR_BAD_ARG;
+    float b[3], y[3];
+    for (int k = 0; k < 3; ++k) {
+        b[k] = roi[3 + k] - roi[k];
+        if (!(b[k] > 0x1p-60f) || !(b[k] < 0x1p60f)) return REN_ERR_BAD_ARG;
+        if (!(fabsf(roi[k]) >= 0x1p-60f) || !(fabsf(roi[k]) < 0x1p60f)) return REN_ERR_UNSUPPORTED;    // (see div_verified)
+        y[k] = 1.f / b[k];
+    }
+    (void)hipMemsetAsync(mismatches, 0, sizeof(int64_t), (hipStream_t)stream);
+    hipLaunchKernelGGL(march_div_check_kernel, dim3(1 << 16), dim3(256), 0, (hipStream_t)stream, b[0], b[1], b[2], y[0], y[1], y[2],
+                       reinterpret_cast<unsigned long long *>(mismatches));
+    REN_CHECK_LAUNCH();
+}
+
 extern "C" int ren_ray_march(const float *rays_o, const float *rays_d, const float *t_min,
                              const float *t_max, const float *jitter, int64_t n_rays,
                              const float *roi, const int32_t *res, const uint8_t *binary,
@@ -586,6 +650,8 @@ extern "C" int ren_ray_march(const float *rays_o, const float *rays_d, const flo
                              int32_t *ray_indices, float *t_starts, float *t_ends, float *interval_cache,
                              int32_t cache_cap, void *stream) {
     if (!rays_o || !rays_d || !t_min || !t_max || n_rays < 0) return REN_ERR_BAD_ARG;
+    const bool verified_div = (mode & REN_MARCH_VERIFIED_DIV) != 0;
+    mode &= ~REN_MARCH_VERIFIED_DIV;
     if (mode != 0 && mode != 1) return REN_ERR_BAD_ARG;
     if (mode == 0 && (!roi || !res || !binary || step_size <= 0.f)) return REN_ERR_BAD_ARG;
     if (mode == 1 && n_uniform <= 0) return REN_ERR_BAD_ARG;
@@ -602,6 +668,8 @@ extern "C" int ren_ray_march(const float *rays_o, const float *rays_d, const flo
     for (int k = 0; k < 3; ++k) a.rinv[k] = (a.res[k] > 0 && (a.res[k] & (a.res[k] - 1)) == 0) ? 1.f / (float)a.res[k] : 0.f;
     a.type = contraction_type; a.step_size = step_size; a.cone_angle = cone_angle;
     a.mode = mode; a.n_uniform = n_uniform;
+    for (int k = 0; k < 3; ++k) a.rext[k] = 1.f / (a.roi[3 + k] - a.roi[k]);
+    a.fastdiv = verified_div && roi ? 1 : 0;
     dim3 grid(ren_blocks(n_rays, 64)), block(64);   // short blocks: ray lengths vary a lot
     // tuning / verification knob: 1 = sequential kernel only; 2, 4, 8, 16 = that many speculative lanes per ray whatever the size
     const int kn = ren_knob(REN_KNOB_MARCH_SEQUENTIAL);

@@ -282,6 +282,7 @@ class Renderer:
         self._fwd_streams = None
         self._bwd_stream = None
         self._reuse_prepass_feat = True             # the differentiable pass reuses the pre-pass hash features
+        self._march_div_ok = None                   # ops.march_div_check(cfg.aabb), at the first occupancy-sampled render
         # device-side sample counts (RenderCfg.device_counts): samples per ray (marched, kept) the capacities are derived from,
         # learnt from the renders themselves -- the first one reads its counts on the host -- and a ring of pinned buffers
         self._spr = None
@@ -321,9 +322,13 @@ class Renderer:
                 t_min = torch.full((n,), 0.0 if c.near_plane is None else c.near_plane, device=o.device)
                 t_max = torch.full((n,), 1e10 if c.far_plane is None else c.far_plane, device=o.device)
         mode = 0 if c.sampler == "occgrid" else 1
+        if mode == 0 and o.is_cuda:
+            if self._march_div_ok is None:                            # once per renderer: the exhaustive check of this box's extents
+                self._march_div_ok = ops.march_div_check(c.aabb, o.device)
+        march_mode = mode | (ops.MARCH_VERIFIED_DIV if (mode == 0 and self._march_div_ok) else 0)
         jit = jitter if training else None
         args = (o, d, t_min, t_max, jit, c.aabb, c.occ_res, self.binary, c.contraction_type,
-                c.render_step_size, c.cone_angle, mode, c.n_uniform)
+                c.render_step_size, c.cone_angle, march_mode, c.n_uniform)
         # occupancy-grid marching is a ~1 000-step dependent chain per ray: the count pass keeps the first
         # march_cache intervals of every ray, the write pass copies them (re-marching only longer rays)
         cache = torch.empty(o.shape[0], c.march_cache, 2, device=o.device) if (mode == 0 and c.march_cache > 0) else None

@@ -238,6 +238,21 @@ def exclusive_scan(counts: torch.Tensor):
     return offsets, total
 
 
+MARCH_VERIFIED_DIV = 0x100          # include/ren_amd.h REN_MARCH_VERIFIED_DIV: OR into `mode` of ray_march_count / _write
+
+
+def march_div_check(roi, device) -> bool:
+    """True when the marcher's multiply-add division is bit-identical to the IEEE division for the extents of `roi` (every
+    float numerator of 2^-100 < |a| < 2^100 tried on the device, ~20 ms): the caller may then pass mode | MARCH_VERIFIED_DIV"""
+    ext = [float(roi[3 + k]) - float(roi[k]) for k in range(3)]
+    if not all(2.0 ** -59 < e < 2.0 ** 59 for e in ext) or not all(2.0 ** -59 < abs(float(roi[k])) < 2.0 ** 59 for k in range(3)):
+        return False                                  # (a box corner at 0: differences p - corner could leave the checked range)
+    roi_c = (ctypes.c_float * 6)(*[float(v) for v in roi])
+    out = torch.zeros(1, dtype=torch.int64, device=device)
+    check(_lib.load().ren_march_div_check(roi_c, _ptr(out, torch.int64), _stream()), "ren_march_div_check")
+    return int(out.item()) == 0
+
+
 def ray_march_count(o, d, t_min, t_max, jitter, roi, res, binary, ct, step, cone, mode, n_uniform, cache=None):
     """cache: optional float32 (n_rays, cap, 2) interval cache filled here and consumed by ray_march_write"""
     n = o.shape[0]

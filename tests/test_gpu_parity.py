@@ -111,6 +111,16 @@ def test_ray_marching_bit_exact(amd, ct, res, cone, near, far):
             ri_s, ts_s, te_s = ops.ray_march_write(*args, offsets, int(total))
             torch.cuda.synchronize()
         assert torch.equal(counts_s, counts) and torch.equal(ri_s, ri) and torch.equal(ts_s, ts) and torch.equal(te_s, te), width
+    # the verified multiply-add division (mode | REN_MARCH_VERIFIED_DIV after ren_march_div_check: ~1e10 divisions by this box's
+    # extents, every one bit-identical): the same streams again
+    assert ops.march_div_check(aabb, DEV)
+    args_v = args[:11] + (ops.MARCH_VERIFIED_DIV,) + args[12:]
+    for width in (1, 4, 16):
+        with ops.knob("march_sequential", width):
+            counts_s = ops.ray_march_count(*args_v)
+            ri_s, ts_s, te_s = ops.ray_march_write(*args_v, offsets, int(total))
+            torch.cuda.synchronize()
+        assert torch.equal(counts_s, counts) and torch.equal(ri_s, ri) and torch.equal(ts_s, ts) and torch.equal(te_s, te), width
     # interval cache between the two passes (march once): identical streams, also when most rays overflow it
     for cap in (7, 1024):
         cache = torch.empty(R, cap, 2, device=DEV)

@@ -27,16 +27,18 @@ for trial in range(48):
         tmin, tmax = torch.full((R,), 0.05, device=dev), torch.full((R,), 8.0, device=dev)
     jit = torch.rand(R, generator=g).to(dev)
     args = (o, d, tmin, tmax, jit, aabb, (res,) * 3, binary, ct, step, cone, 0, 0)
+    args_fast = args[:11] + (ops.MARCH_VERIFIED_DIV if os.environ.get("FUZZ_FASTDIV") == "1" and ops.march_div_check(aabb, dev) else 0,) + args[12:]
     out = {}
     for seq in ("1", "0"):                 # sequential kernel | FUZZ_WIDTH (0: the default policy; 2 / 4 / 8 / 16 lanes; 32: look-ahead)
         _lib.load().ren_set_knob(ops.KNOBS["march_sequential"], 1 if seq == "1" else int(os.environ.get("FUZZ_WIDTH", "0")))
-        counts = ops.ray_march_count(*args)
+        ar = args if seq == "1" else args_fast                  # (the reference run: sequential kernel, IEEE divisions)
+        counts = ops.ray_march_count(*ar)
         offsets, total = ops.exclusive_scan(counts)
         n = int(total)
-        ri, ts, te = ops.ray_march_write(*args, offsets, n)
+        ri, ts, te = ops.ray_march_write(*ar, offsets, n)
         cache = torch.empty(R, 16, 2, device=dev)
-        counts_c = ops.ray_march_count(*args, cache=cache)
-        ri_c, ts_c, te_c = ops.ray_march_write(*args, offsets, n, counts=counts_c, cache=cache)
+        counts_c = ops.ray_march_count(*ar, cache=cache)
+        ri_c, ts_c, te_c = ops.ray_march_write(*ar, offsets, n, counts=counts_c, cache=cache)
         torch.cuda.synchronize()
         same_c = torch.equal(counts_c, counts) and torch.equal(ri_c, ri) and torch.equal(ts_c, ts) and torch.equal(te_c, te)
         out[seq] = (counts, ri, ts, te, same_c)
