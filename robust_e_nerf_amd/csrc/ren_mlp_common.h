@@ -296,6 +296,42 @@ __global__ __launch_bounds__(RS_P * RS_Q) void reduce_slabs_kernel(const float *
     }
 }
 
+// up to three slab sets in ONE launch (the MLP backward's head / base sets, the tangent backward's three): the same sums in the
+// same order as reduce_slabs_kernel per set, a third of the launches (each is a ~13 us latency chain at any size)
+struct SlabSet { const float *slab; float *grad; int n_slabs, len, first_block; };
+struct SlabSets { SlabSet s[3]; int n; };
+__global__ __launch_bounds__(RS_P * RS_Q) void reduce_slab_sets_kernel(SlabSets sets) {
+    __shared__ float part[RS_Q][RS_P + 1];
+    int k = 0;
+    if (sets.n > 1 && (int)blockIdx.x >= sets.s[1].first_block) k = 1;
+    if (sets.n > 2 && (int)blockIdx.x >= sets.s[2].first_block) k = 2;
+    const SlabSet &S = sets.s[k];
+    const int p = threadIdx.x % RS_P, q = threadIdx.x / RS_P;
+    const int j = ((int)blockIdx.x - S.first_block) * RS_P + p;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (j < S.len) {
+        int w = q;
+        for (; w + 3 * RS_Q < S.n_slabs; w += 4 * RS_Q) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] += S.slab[(int64_t)(w + u * RS_Q) * S.len + j];
+        }
+        for (; w < S.n_slabs; w += RS_Q) acc[0] += S.slab[(int64_t)w * S.len + j];
+    }
+    part[q][p] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    __syncthreads();
+    if (q == 0 && j < S.len) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < RS_Q; ++i) t += part[i][p];
+        S.grad[j] += t;
+    }
+}
+inline void launch_reduce_slab_sets(SlabSets sets, hipStream_t st) {
+    int blocks = 0;
+    for (int k = 0; k < sets.n; ++k) { sets.s[k].first_block = blocks; blocks += (sets.s[k].len + RS_P - 1) / RS_P; }
+    hipLaunchKernelGGL(reduce_slab_sets_kernel, dim3(blocks), dim3(RS_P * RS_Q), 0, st, sets);
+}
+
 // stride: floats between consecutive slabs (0: len, the slabs are dense)
 inline void launch_reduce_slabs(const float *slab, int n_slabs, int len, float *grad, hipStream_t st, int64_t stride = 0) {
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3((len + RS_P - 1) / RS_P), dim3(RS_P * RS_Q), 0, st, slab, n_slabs, len, grad,

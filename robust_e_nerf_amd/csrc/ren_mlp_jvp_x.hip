@@ -801,9 +801,12 @@ int launch_bwd_jvp_x(const BwdJX2Args &a2, const BwdJX1Args &a1, const BwdJXBArg
     hipLaunchKernelGGL((mlp_bwd_jvp_head1_x_kernel<MODE>), dim3(GRID_JX1), dim3(256), l1, st, a1);
     (void)hipFuncSetAttribute((const void *)mlp_bwd_jvp_base_x_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
     hipLaunchKernelGGL((mlp_bwd_jvp_base_x_kernel<MODE>), dim3(GRID_JXB), dim3(256), lb, st, ab);
-    launch_reduce_slabs(a2.slab, GRID_JX2 * 4, len_xh2(C), grad + P_HW1, st);
-    launch_reduce_slabs(a1.slab, GRID_JX1 * 4, LEN_XH1, grad + P_HW0, st);
-    launch_reduce_slabs(ab.slab, GRID_JXB * 4, P_BASE_N, grad, st);
+    SlabSets sets;
+    sets.n = 3;
+    sets.s[0] = SlabSet{a2.slab, grad + P_HW1, GRID_JX2 * 4, len_xh2(C), 0};
+    sets.s[1] = SlabSet{a1.slab, grad + P_HW0, GRID_JX1 * 4, LEN_XH1, 0};
+    sets.s[2] = SlabSet{ab.slab, grad, GRID_JXB * 4, P_BASE_N, 0};
+    launch_reduce_slab_sets(sets, st);
     REN_CHECK_LAUNCH();
 }
 

@@ -818,8 +818,12 @@ int launch_bwd_x(const BwdXHArgs &h, const BwdXBArgs &b, int C, float *grad, int
     (void)hipFuncSetAttribute((const void *)mlp_bwd_base_x_kernel<MODE, RECOMP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
     hipLaunchKernelGGL((mlp_bwd_base_x_kernel<MODE, RECOMP>), dim3(GRID_XB), dim3(256), lds_b, st, b);
     const int head_len = p_total(C) - P_BASE_N;
-    launch_reduce_slabs(h.slab, GRID_XH * 4, head_len, grad + P_BASE_N, st);
-    launch_reduce_slabs(b.slab, GRID_XB * 4, P_BASE_N, grad, st);
+    SlabSets sets;
+    sets.n = 2;
+    sets.s[0] = SlabSet{h.slab, grad + P_BASE_N, GRID_XH * 4, head_len, 0};
+    sets.s[1] = SlabSet{b.slab, grad, GRID_XB * 4, P_BASE_N, 0};
+    sets.s[2] = sets.s[1];
+    launch_reduce_slab_sets(sets, st);
     REN_CHECK_LAUNCH();
 }
 
