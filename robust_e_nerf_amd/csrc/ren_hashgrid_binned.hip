@@ -620,6 +620,18 @@ __global__ __launch_bounds__(1024) void bin_accumulate_kernel(GridDev g, BinTab 
     (void)frexpf(__uint_as_float(lmax), &ex);                     // level max < 2^ex
     const double scale = ldexp(1.0, 38 - ex), inv_scale = ldexp(1.0, ex - 38);
     const char *base = ws.pool + ws.bin_start[part.gbin] * 16;
+    // the bin's slice of the gradient table, fetched NOW for an exclusive owner: the flush at the end was eight dependent global
+    // round trips per thread (load -> add -> store behind a data-dependent `continue`), most of the kernel at small n
+    const uint32_t first = ((uint32_t)part.gbin - bt.bin_base[lvl]) << BIN_SHIFT;   // first entry of the bin in its level
+    const uint32_t lim = g.size[lvl] > first ? g.size[lvl] - first : 0;
+    float2 *gt = reinterpret_cast<float2 *>(grad_table) + g.offset[lvl] + first;
+    constexpr int FL = BIN_ENTRIES / 1024;
+    float2 gv[FL];
+#pragma unroll
+    for (int u = 0; u < FL; ++u) {
+        const uint32_t k = threadIdx.x + u * 1024;
+        gv[u] = (part.single && k < lim) ? gt[k] : make_float2(0.f, 0.f);
+    }
     __syncthreads();
     uint64_t e = part.begin + threadIdx.x;
     if (bt.pair[lvl]) {
@@ -669,15 +681,15 @@ __global__ __launch_bounds__(1024) void bin_accumulate_kernel(GridDev g, BinTab 
         }
     }
     __syncthreads();
-    const uint32_t first = ((uint32_t)part.gbin - bt.bin_base[lvl]) << BIN_SHIFT;   // first entry of the bin in its level
-    const uint32_t lim = g.size[lvl] > first ? g.size[lvl] - first : 0;
-    float2 *gt = reinterpret_cast<float2 *>(grad_table) + g.offset[lvl] + first;
-    for (uint32_t k = threadIdx.x; k < BIN_ENTRIES && k < lim; k += 1024) {
+#pragma unroll
+    for (int u = 0; u < FL; ++u) {
+        const uint32_t k = threadIdx.x + u * 1024;
+        if (k >= lim) continue;
         const long long qa = (long long)acc0[k], qb = (long long)acc1[k];
         if (qa == 0 && qb == 0) continue;
         const float a = (float)((double)qa * inv_scale), b = (float)((double)qb * inv_scale);
-        if (part.single) {                                         // exclusive owner: plain coalesced RMW
-            float2 v = gt[k];
+        if (part.single) {                                         // exclusive owner: plain coalesced RMW (value fetched above)
+            float2 v = gv[u];
             v.x += a; v.y += b;
             gt[k] = v;
         } else {
