@@ -46,7 +46,7 @@ FLOPS = {"mlp_fwd": 2 * MLP_MACS, "mlp_bwd": 4 * MLP_MACS, "mlp_fwd_save": 2 * M
 # sample stream; the 50 MB table pass per launch comes on top.  SURVEY 8(d)'s 2 048 B is the atomic-RMW traffic of the
 # scatter-add formulation, kept as `achieved`'s numerator because it is the survey's figure; both are printed.
 COMPULSORY_BYTES = {"hashgrid_bwd_binned": 128 + 12, "hashgrid_bwd": 128 + 12, "hashgrid_fwd": 128 + 12}
-ROUND = "r05"
+ROUND = "r06"
 PMC_TRAFFIC = os.path.join(REPO, "profiles", f"{ROUND}_pmc_traffic.json")
 
 
@@ -252,6 +252,9 @@ def main():
                          "backward on the main stream (as before round 4)")
     ap.add_argument("--device-counts", default="auto", choices=["auto", "off"],
                     help="occupancy sampler: sample counts stay on the device (RenderCfg.device_counts); off = the reference's host reads")
+    ap.add_argument("--graph", default="auto", choices=["auto", "off"],
+                    help="auto: occupancy-sampled steps with device-side counts go through Trainer.step, which captures a repeating "
+                         "step in a hipGraph and replays it as one launch (Trainer._graph_step); off: every launch from Python")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
@@ -367,6 +370,11 @@ def main():
                         bkgd_raw=torch.tensor([0.5413]), world_size=dp_world, process_group=pg)
     if args.device_counts == "off":
         tr.device_counts = False
+    # the whole step through Trainer.step (what scripts/train.py calls): it replays a captured step when it can
+    whole_step = (args.graph == "auto" and args.sampler == "occgrid" and not args.prefetch and args.grad_sampling == "auto" and
+                  dp_world == 1 and tr.device_counts_ok())
+    if not whole_step:
+        tr.use_graph = False
 
     B = args.events if args.scaling == "weak" else max(1, args.events // world)
     n_batches = 4                                    # pre-staged in HBM; per-rank seeds (datamodule.py:85-89)
@@ -390,6 +398,18 @@ def main():
             return batches[i % n_batches], ops.uniform(2 * B, 1234 + rank, i, device=dev), None   # both renders' jitters (library Philox stream)
 
     def one_step(i):
+        if whole_step:
+            # jitters drawn straight into the captured step's input buffers once there is one (no copy launches)
+            b = batches[i % n_batches]
+            gi = tr.graph_inputs(b, jbuf[0], jbuf[1])
+            j0, j2 = (gi[1], gi[2]) if gi is not None else (jbuf[0], jbuf[1])
+            ops.uniform(2 * B, 1234 + rank, i, device=dev, out=j0)
+            if j2 is not None:
+                ops.uniform(B, 4321 + rank, i, device=dev, out=j2)
+            loss, aux = tr.step(b, j0, None, jitter_grad=j2)
+            if args.loss_grad > 0:
+                aux = dict(aux, n=aux["n"] + aux["grad"]["n"], rays=aux["rays"] + aux["grad"]["rays"], n_main=aux["n"])
+            return loss, aux
         b, j0, j1 = staged.pop(i) if i in staged else draw(i)
         # the third render's jitter is drawn BEFORE the l_diff pass is enqueued: its samples are then placed beside that pass's
         # backward (Trainer.grad_loss_forward_backward(early=True), what Trainer.step does)
@@ -408,6 +428,8 @@ def main():
         tr.optimizer_step()
         return loss, aux
 
+    jbuf = (torch.empty(2 * B, device=dev), torch.empty(B, device=dev) if args.loss_grad > 0 else None)
+
     def barrier():
         if world > 1:
             dist.barrier()
@@ -422,6 +444,14 @@ def main():
             tr.sync.finish(f_.grad_all)
         tr.sync.reset_count()
         torch.cuda.synchronize()
+    if whole_step:
+        # set-up, not warm-up: the first steps read their sample counts on the host, learn the capacities and capture the
+        # step; the W warm-up steps and the K timed steps below then are what a training run spends its time in -- replays
+        for i in range(16):
+            before = (tr.graph_replays, tr.graph_captures)
+            one_step(-1 - i)
+            if tr.graph_replays == before[0] + 1 and tr.graph_captures == before[1] and i >= 3:
+                break
     log("setup done")
     for i in range(args.warmup):
         one_step(i)
@@ -429,6 +459,7 @@ def main():
             torch.cuda.synchronize()
             log("warmup step", i)
     barrier()
+    tr._replays_before = getattr(tr, "graph_replays", 0)
     ops.profile_start()
     t0 = time.perf_counter()
     n_samples = n_main = 0
@@ -440,6 +471,22 @@ def main():
     dt = time.perf_counter() - t0
     prof = ops.profile_stop()
     log("timed region done", dt)
+    graph_replays, n_main_timed = getattr(tr, "graph_replays", 0), n_main
+    roof_note = None
+    if graph_replays - tr._replays_before > 0:
+        # the timed steps were hipGraph replays: no launch went through the Python wrappers, so there were no per-launch HIP
+        # events.  The dominant call is timed over a few EAGER steps of the same workload right behind the timed region.
+        tr.use_graph = False
+        ops.profile_start()
+        n_main, k_prof = 0, min(5, args.steps)
+        for i in range(k_prof):
+            _, aux_p = one_step(args.steps + i)
+            n_main += aux_p.get("n_main", aux_p["n"])
+        prof = ops.profile_stop()
+        roof_note = f"launch times: HIP events over {k_prof} eager steps behind the timed region (the {args.steps} timed steps are hipGraph replays)"
+        prof_steps = k_prof
+    else:
+        prof_steps = args.steps
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -494,7 +541,7 @@ def main():
         c, ms = prof.get(dom, (1, 1e-9))                 # degenerate runs (no sample at all) launch none of them
         c, ms = max(c, 1), max(ms, 1e-9)
         # this rank's samples per launch of the dominant kernel (chunked calls: one launch per chunk)
-        samples_per_launch = n_main / (args.steps if dom.startswith("dense") else max(c, 1))
+        samples_per_launch = n_main / (prof_steps if dom.startswith("dense") else max(c, 1))
         if dom in BYTES:
             achieved = BYTES[dom] * samples_per_launch / (ms / c * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -506,7 +553,7 @@ def main():
                     if args.arch == "ngp" else None}
         else:
             # dense_* families: one launch per layer, so price the whole family per step
-            per = (ms / args.steps) if dom.startswith("dense") else (ms / c)
+            per = (ms / prof_steps) if dom.startswith("dense") else (ms / c)
             # matrix-core peak of the path that ran: exact f32 MFMA, or bf16 MFMA with 6 (split-bf16, fp32 accuracy)
             # or 1 (plain bf16) hardware multiply-adds per algorithmic one
             if args.mlp_kernels == "f32" and not args.mlp_bf16:
@@ -549,13 +596,15 @@ def main():
                        "mlp_precision": "highest" if precision == "high" and not high else precision,
                        "device_counts": bool(tr.device_counts_ok() and tr.r._spr is not None),
                        "device_count_overflows": getattr(tr, "device_count_overflows", 0),
+                       "step_graph": {"replays_in_timed_region": graph_replays - getattr(tr, "_replays_before", 0),
+                                      "captures": getattr(tr, "graph_captures", 0)} if whole_step else None,
                        "fwd_chunks": args.fwd_chunks, "bwd_chunks": args.bwd_chunks,
                        # what torch.distributed actually formed (a mis-launched N-rank run shows here)
                        "dist_world_size": dist.get_world_size() if dist.is_initialized() else 1,
                        "dist_backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else ""))
                        if dist.is_initialized() else None,
                        "gradient_allreduce_bytes_per_step": int(r.field.grad_all.numel() * 4) if dp_world > 1 else 0},
-            "roofline": roof,
+            "roofline": dict(roof, **({"note": roof_note} if roof_note else {})),
             "kernels": kern,
         }
         if strong is not None:

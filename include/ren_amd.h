@@ -357,6 +357,30 @@ int ren_adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, 
                   float lr, float beta1, float beta2, float eps, float weight_decay,
                   int64_t step, float grad_scale, int32_t zero_grad, void *stream);
 
+/* ---- optimiser state on the device (ABI 25) -- for a step captured in a hipGraph (engine.Trainer.step_graphed), whose
+ * launches cannot carry the step number as an argument, and whose optimiser must not run when a device-side sample count
+ * (above) did not fit its arrays.  hyper = device double[8]: [REN_HY_STEP] Adam step of the float32 groups,
+ * [REN_HY_SKIP] sticky skip word, [REN_HY_BC1/2] 1 - beta^step, [REN_HY_TAU_STEP], [REN_HY_TAU_BC1/2] the same for the
+ * float64 group of the refractory period.  ren_step_tick: once per optimiser step, BEFORE its Adam launches -- raises skip
+ * when the overflow words of stats_a / stats_b (int64[4] of ren_scan_guard: [1], [3]; either may be NULL) are set, otherwise
+ * advances the step(s) and the corrections.  ren_adam_step_dev / ren_tau_adam_step_dev = ren_adam_step / ren_tau_adam_step
+ * with the corrections from `hyper` (same arithmetic: robust_e_nerf.py:782-813); with skip raised they change NOTHING
+ * (parameters, moments and gradients stay as they are: the host repeats the step and clears the word). */
+#define REN_HY_STEP 0
+#define REN_HY_SKIP 1
+#define REN_HY_BC1 2
+#define REN_HY_BC2 3
+#define REN_HY_TAU_STEP 4
+#define REN_HY_TAU_BC1 5
+#define REN_HY_TAU_BC2 6
+int ren_step_tick(double *hyper, double beta1, double beta2, const int64_t *stats_a, const int64_t *stats_b, int32_t tick_tau,
+                  void *stream);
+int ren_adam_step_dev(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
+                      float lr, float beta1, float beta2, float eps, float weight_decay,
+                      const double *hyper, float grad_scale, int32_t zero_grad, void *stream);
+int ren_tau_adam_step_dev(double *tau_raw, double *tau_grad, double *state, double tau_max, double lr, double beta1,
+                          double beta2, double eps, const double *hyper, double grad_scale, void *stream);
+
 /* ---- occupancy grid -------------------------------------------------------------------------------
  * nerfacc.OccupancyGrid._update as driven by NeRF.update_occ_grid (models/nerf.py:170-204). */
 /* cell indices[m] (int64) + jitter[m,3] -> world positions x[m,3] (contract_inv) and

@@ -89,6 +89,9 @@ SIGNATURES = {
     "ren_event_diff_loss_bwd": (c_int, [P, P, P, c_int32, c_float, P, c_int32, c_int64, c_int32, c_float, P, P, P, P, P, P, P, P]),
     "ren_bkgd_param_fwd": (c_int, [P, c_int32, P, P]),
     "ren_bkgd_param_grad": (c_int, [P, c_int64, c_int32, P, P, P, P]),
+    "ren_step_tick": (c_int, [P, c_double, c_double, P, P, c_int32, P]),
+    "ren_adam_step_dev": (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, P, c_float, c_int32, P]),
+    "ren_tau_adam_step_dev": (c_int, [P, P, P, c_double, c_double, c_double, c_double, c_double, P, c_double, P]),
     "ren_adam_step": (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int64,
                               c_float, c_int32, P]),
     "ren_occgrid_cell_points": (c_int, [P, P, c_int64, POINTER(c_float), POINTER(c_int32), c_int32, P, P, P]),

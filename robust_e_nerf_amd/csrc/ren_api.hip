@@ -1,6 +1,6 @@
 // Library identification (C ABI, include/ren_amd.h).
 #include "ren_common.h"
-extern "C" int ren_abi_version(void) { return 24; }
+extern "C" int ren_abi_version(void) { return 25; }
 extern "C" const char *ren_build_info(void) { return "ren_amd gfx950 (CDNA4) hipcc " __VERSION__; }
 
 extern "C" int ren_set_knob(int32_t knob, int32_t value) {

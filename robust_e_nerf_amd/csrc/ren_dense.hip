@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void dense_kernel(DenseArgs a) {
 // ---- the same layer on the bf16 matrix cores ------------------------------------------------------------------
 // MODE 6: every fp32 operand split into three bf16 pieces, six v_mfma_f32_32x32x16_bf16 per 16-wide k-step
 // reproduce the fp32 product to fp32 round-off (see ren_mlp_x.hip) -- 192 matrix-pipe cycles per k-step against
-// 512 for eight f32 MFMAs, and unlike those they co-issue with the VALU.  MODE 1: plain bf16 operands.
+// 512 for eight f32 MFMAs (both add to the VALU's cycles: DESIGN 3.2).  MODE 1: plain bf16 operands.
 // The weight chunk W[:, k0:k0+32] is split ONCE per workgroup while it is staged in LDS ([piece][row][40] bf16:
 // one ds_read_b128 per A operand, conflict-free for 16-byte reads at an 80-byte row stride); the 8 k-values a lane
 // feeds per k-step are contiguous in the row-major activations (two float4 loads) and are split in registers.

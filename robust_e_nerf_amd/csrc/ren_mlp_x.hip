@@ -2,7 +2,9 @@
 //
 // Why: on gfx950 the f32 MFMA runs at the f32 vector rate and its cycles ADD to the VALU's (tools/
 // mfma_valu_bench.hip), so the exact-fp32 kernels of ren_mlp.hip cost MFMA + VALU.  The bf16 MFMA
-// (v_mfma_f32_32x32x16_bf16) is 16x faster per multiply-add and does co-issue with VALU work.  An fp32 value
+// (v_mfma_f32_32x32x16_bf16) is 16x faster per multiply-add; its cycles ADD to the VALU's as well -- measured in round 5,
+// tools/phase_overlap_bench.hip: a SIMD's matrix pipe and VALU take turns at 1, 2 and 4 waves per SIMD, PMC MfmaUtil +
+// VALUBusy ~ 100 % -- so what these kernels cost is their matrix-pipe cycles PLUS their VALU cycles.  An fp32 value
 // splits exactly into three bf16 pieces v = v1 + v2 + v3 (8 + 8 + 8 significant bits, residual <= 2^-27 |v|);
 // bf16 x bf16 products are exact in the fp32 accumulator, so
 //     a b  =  a1 b1 + a1 b2 + a2 b1 + a1 b3 + a3 b1 + a2 b2  + O(2^-25 |a b|)
@@ -43,8 +45,9 @@ struct FwdXArgs {
 
 constexpr int ACT_SAVE_FLOATS_X = 3 * 2 * 16 * 64;            // same layout as ren_mlp.hip's ACT_SAVE_FLOATS
 
-// 8 waves share one 63 KB fragment image, two workgroups per CU: four waves per SIMD, so one wave's split /
-// softplus VALU work runs under another's bf16 MFMAs (which, unlike the f32 MFMA, do co-issue with the VALU)
+// 8 waves share one 63 KB fragment image, two workgroups per CU: four waves per SIMD hide the LDS latency of the weight
+// fragments and the global loads (they do NOT run one wave's VALU work under another's MFMAs: the two pipes of a SIMD take
+// turns)
 constexpr int FWD_X_WAVES = 8;
 #ifndef REN_FWD_WAVES
 #define REN_FWD_WAVES 4                                   // waves per SIMD the register allocation must allow (2 workgroups per CU)

@@ -150,6 +150,9 @@ __global__ void ray_march_kernel(const float *__restrict__ o, const float *__res
     // write pass with an interval cache: rays whose intervals the count pass kept are copied by
     // cached_write_kernel; only the ones that overflowed the cache are marched again
     if (WRITE && cache && counts[i] <= cache_cap) return;
+    // a ray without samples writes nothing: also what keeps a render that ren_scan_guard / ren_count_guard cleared (counts all
+    // zero, offsets meaningless) from storing past its capacity-sized arrays when there is no interval cache
+    if (WRITE && counts && counts[i] == 0) return;
     const float ro[3] = {o[3 * i], o[3 * i + 1], o[3 * i + 2]};
     const float rd[3] = {d[3 * i], d[3 * i + 1], d[3 * i + 2]};
     float near = t_min[i];
@@ -234,6 +237,7 @@ __global__ __launch_bounds__(256) void ray_march_spec_kernel(
     const int l = threadIdx.x % SPEC, lane = threadIdx.x & 63, g0 = lane - l;   // g0: first lane of the group
     bool done = i >= n_rays;
     if (!done && WRITE && cache && counts[i] <= cache_cap) done = true;          // copied by cached_write_kernel
+    if (!done && WRITE && counts && counts[i] == 0) done = true;                 // no samples (or a cleared render): nothing to write
     float ro[3] = {0.f, 0.f, 0.f}, rd[3] = {1.f, 1.f, 1.f};
     float near = 0.f, far = 0.f;
     int64_t base = 0;
@@ -821,6 +825,7 @@ __global__ __launch_bounds__(1024) void scan_guard_kernel(int32_t *__restrict__ 
         if (stats) { stats[0] = tot; stats[1] = over ? 1 : 0; }
     }
     if (over) {
+        __syncthreads();                                         // every wave is done re-reading its counts (second walk)
         for (int64_t k = tid; k < n; k += 1024) {
             counts[k] = 0;
             if (counts_also) counts_also[k] = 0;

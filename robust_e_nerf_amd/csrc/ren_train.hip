@@ -155,6 +155,71 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, float 
     }
 }
 
+// ---- optimiser state on the device (ABI 25): a captured step (hipGraph) cannot carry the step number as a launch argument.
+// `hyper` = double[8] (REN_HY_*): [0] Adam step of the float32 groups, [1] skip (sticky: an overflowed device-side sample
+// count of this or an earlier step -- every *_dev optimiser kernel then leaves parameters, moments AND gradients alone until
+// the host has repeated the step and cleared it), [2] 1 - beta1^step, [3] 1 - beta2^step, [4] step of the tau group,
+// [5] / [6] its two corrections.  step_tick_kernel advances it once per optimiser step, before the Adam launches.
+__global__ void step_tick_kernel(double *__restrict__ hy, double beta1, double beta2, const int64_t *__restrict__ stats_a,
+                                 const int64_t *__restrict__ stats_b, int tick_tau) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    bool skip = hy[REN_HY_SKIP] != 0.0;
+    if (stats_a && (stats_a[1] | stats_a[3])) skip = true;
+    if (stats_b && (stats_b[1] | stats_b[3])) skip = true;
+    hy[REN_HY_SKIP] = skip ? 1.0 : 0.0;
+    if (skip) return;
+    // the float32 groups: ren_adam_step takes its betas as floats and forms 1 - beta^step from those in double
+    const double st = hy[REN_HY_STEP] + 1.0, b1f = (double)(float)beta1, b2f = (double)(float)beta2;
+    hy[REN_HY_STEP] = st;
+    hy[REN_HY_BC1] = 1.0 - pow(b1f, st);
+    hy[REN_HY_BC2] = 1.0 - pow(b2f, st);
+    if (tick_tau) {
+        const double tt = hy[REN_HY_TAU_STEP] + 1.0;
+        hy[REN_HY_TAU_STEP] = tt;
+        hy[REN_HY_TAU_BC1] = 1.0 - pow(beta1, tt);
+        hy[REN_HY_TAU_BC2] = 1.0 - pow(beta2, tt);
+    }
+}
+
+// adam_kernel with the bias corrections (and the skip word) read from `hyper`: same arithmetic -- lr / bc1 and 1 / sqrt(bc2)
+// are formed in double and rounded to float exactly as ren_adam_step forms them on the host
+__global__ __launch_bounds__(256) void adam_dev_kernel(float *__restrict__ p, float *__restrict__ g,
+                                                       float *__restrict__ m, float *__restrict__ v, int64_t n,
+                                                       float lr, float beta1, float beta2, float eps, float wd,
+                                                       const double *__restrict__ hy, float grad_scale, int zero_grad) {
+    if (hy[REN_HY_SKIP] != 0.0) return;
+    const float lr_over_bc1 = (float)((double)lr / hy[REN_HY_BC1]);
+    const float inv_sqrt_bc2 = (float)(1.0 / sqrt(hy[REN_HY_BC2]));
+    const int64_t n4 = n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 pp = reinterpret_cast<float4 *>(p)[i];
+        float4 gg = reinterpret_cast<float4 *>(g)[i];
+        float4 mm = reinterpret_cast<float4 *>(m)[i];
+        float4 vv = reinterpret_cast<float4 *>(v)[i];
+        float *pa = &pp.x, *ga = &gg.x, *ma = &mm.x, *va = &vv.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float gr = ga[k] * grad_scale + wd * pa[k];
+            ma[k] = beta1 * ma[k] + (1.f - beta1) * gr;
+            va[k] = beta2 * va[k] + (1.f - beta2) * gr * gr;
+            pa[k] -= lr_over_bc1 * ma[k] / (sqrtf(va[k]) * inv_sqrt_bc2 + eps);
+        }
+        reinterpret_cast<float4 *>(p)[i] = pp;
+        reinterpret_cast<float4 *>(m)[i] = mm;
+        reinterpret_cast<float4 *>(v)[i] = vv;
+        if (zero_grad) reinterpret_cast<float4 *>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float gr = g[i] * grad_scale + wd * p[i];
+        float mi = beta1 * m[i] + (1.f - beta1) * gr;
+        float vi = beta2 * v[i] + (1.f - beta2) * gr * gr;
+        m[i] = mi; v[i] = vi;
+        p[i] -= lr_over_bc1 * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+        if (zero_grad) g[i] = 0.f;
+    }
+}
+
 // ---------------------------------------------------------------------------------- occupancy grid
 struct CellArgs { float roi[6]; int res[3]; int type; };
 
@@ -452,6 +517,19 @@ __global__ void tau_adam_kernel(double *__restrict__ tau_raw, double *__restrict
     tau_grad[0] = 0.0;
 }
 
+__global__ void tau_adam_dev_kernel(double *__restrict__ tau_raw, double *__restrict__ tau_grad, double *__restrict__ state,
+                                    double tau_max, double lr, double beta1, double beta2, double eps,
+                                    const double *__restrict__ hy, double grad_scale) {
+    if (threadIdx.x != 0 || blockIdx.x != 0 || hy[REN_HY_SKIP] != 0.0) return;
+    const double bc1 = hy[REN_HY_TAU_BC1], bc2 = hy[REN_HY_TAU_BC2];
+    const double s = 1.0 / (1.0 + exp(-tau_raw[0] / tau_max));
+    const double g = tau_grad[0] * grad_scale * s * (1.0 - s);
+    const double m = beta1 * state[0] + (1.0 - beta1) * g, v = beta2 * state[1] + (1.0 - beta2) * g * g;
+    state[0] = m; state[1] = v;
+    tau_raw[0] -= lr / bc1 * m / (sqrt(v) / sqrt(bc2) + eps);
+    tau_grad[0] = 0.0;
+}
+
 }  // namespace
 
 extern "C" int ren_event_params_refresh(const float *ct_raw, float c_n, double *tau_raw, double tau_max, double *event_params,
@@ -593,6 +671,36 @@ extern "C" int ren_adam_step(float *param, float *grad, float *exp_avg, float *e
     hipLaunchKernelGGL(adam_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
                        exp_avg_sq, n, (float)(lr / bc1), beta1, beta2, eps, weight_decay,
                        (float)(1.0 / sqrt(bc2)), grad_scale, zero_grad);
+    REN_CHECK_LAUNCH();
+}
+
+extern "C" int ren_step_tick(double *hyper, double beta1, double beta2, const int64_t *stats_a, const int64_t *stats_b,
+                             int32_t tick_tau, void *stream) {
+    if (!hyper || !(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0)) return REN_ERR_BAD_ARG;
+    hipLaunchKernelGGL(step_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, hyper, beta1, beta2, stats_a, stats_b, tick_tau);
+    REN_CHECK_LAUNCH();
+}
+
+extern "C" int ren_adam_step_dev(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
+                                 float lr, float beta1, float beta2, float eps, float weight_decay,
+                                 const double *hyper, float grad_scale, int32_t zero_grad, void *stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !hyper || n < 0) return REN_ERR_BAD_ARG;
+    if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15)
+        return REN_ERR_BAD_ARG;
+    if (n == 0) return REN_OK;
+    int64_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(adam_dev_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+                       exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, hyper, grad_scale, zero_grad);
+    REN_CHECK_LAUNCH();
+}
+
+extern "C" int ren_tau_adam_step_dev(double *tau_raw, double *tau_grad, double *state, double tau_max, double lr, double beta1,
+                                     double beta2, double eps, const double *hyper, double grad_scale, void *stream) {
+    if (!tau_raw || !tau_grad || !state || !hyper || !(tau_max > 0.0)) return REN_ERR_BAD_ARG;
+    hipLaunchKernelGGL(tau_adam_dev_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, tau_raw, tau_grad, state, tau_max, lr,
+                       beta1, beta2, eps, hyper, grad_scale);
     REN_CHECK_LAUNCH();
 }
 

@@ -218,20 +218,36 @@ def _adopt(v, stream):
 class CountLog:
     """The two sample counts of one render sampled with device-side counts -- marched, kept -- and whether they fitted the
     capacities the arrays were given: copied to pinned memory behind the sampling kernels.  wait() blocks the host until
-    THOSE kernels are done (an event), not until the queue is empty."""
+    THOSE kernels are done (an event), not until the queue is empty.
+    polled=True (a render inside a captured step, Trainer.step_graphed): the copy is a node of the graph and no event can be
+    waited for; the host arms the pinned words with -1 before every replay (arm()) and wait() spins until the copy has
+    landed -- pinned host memory is coherent, and each of the four words is one aligned 8-byte store."""
 
-    def __init__(self, n_rays: int, caps, stats: torch.Tensor, pinned: torch.Tensor):
-        self.n_rays, self.caps = n_rays, caps
+    def __init__(self, n_rays: int, caps, stats: torch.Tensor, pinned: torch.Tensor, polled: bool = False):
+        self.n_rays, self.caps, self.stats = n_rays, caps, stats
         pinned.copy_(stats, non_blocking=True)
         self._pinned = pinned
-        self.ev = torch.cuda.Event()
-        self.ev.record()
+        self.ev = None
+        if not polled:
+            self.ev = torch.cuda.Event()
+            self.ev.record()
         self.values = None                       # (marched, overflowed, kept, overflowed)
+
+    def arm(self):
+        self._pinned.fill_(-1)
+        self.values = None
 
     def wait(self):
         if self.values is None:
-            self.ev.synchronize()
-            self.values = tuple(int(v) for v in self._pinned.tolist())
+            if self.ev is not None:
+                self.ev.synchronize()
+                self.values = tuple(int(v) for v in self._pinned.tolist())
+            else:
+                while True:
+                    v = self._pinned.tolist()
+                    if min(v) >= 0:
+                        break
+                self.values = tuple(int(x) for x in v)
         return self.values
 
     @property
@@ -287,6 +303,8 @@ class Renderer:
         # learnt from the renders themselves -- the first one reads its counts on the host -- and a ring of pinned buffers
         self._spr = None
         self._count_ring, self._count_ring_at = None, 0
+        self._polled_logs = None                    # a list while a step is being captured (Trainer.step_graphed): its renders' CountLogs
+        self.dp_early_enabled = True                # the Trainer clears it when a loss pass may have to be repeated (device-side counts)
         self._act_code = ops.activation_code(cfg.base_hidden_activation, cfg.density_activation, cfg.head_hidden_activation,
                                              cfg.radiance_activation)
         if cfg.mlp_precision not in ("highest", "high", "medium"):
@@ -353,7 +371,7 @@ class Renderer:
         kernels, binned scatter"""
         c = self.cfg
         return (c.device_counts is not False and c.sampler == "occgrid" and type(self) is Renderer and c.mlp_kernels == "x" and
-                c.binned_scatter and self.field.flat.is_cuda and self.grad_sync is None)
+                c.binned_scatter and self.field.flat.is_cuda)
 
     def _capacities(self, n_rays: int):
         if self._spr is None:
@@ -370,6 +388,10 @@ class Renderer:
         self._spr = m if self._spr is None else tuple(max(a, 0.75 * b + 0.25 * a) for a, b in zip(m, self._spr))
 
     def _count_log(self, n_rays: int, caps, stats: torch.Tensor) -> CountLog:
+        if self._polled_logs is not None:                        # inside a capture: the graph owns its pinned words
+            log = CountLog(n_rays, caps, stats, self._polled_pinned.pop(), polled=True)   # (pinned before the capture began)
+            self._polled_logs.append(log)
+            return log
         if self._count_ring is None:
             self._count_ring = [torch.empty(4, dtype=torch.int64).pin_memory() for _ in range(16)]
             self._count_logs = [None] * 16
@@ -469,6 +491,10 @@ class Renderer:
         pruned and the batch size has adapted, can march 50 M samples (an 80 GB pool that would otherwise stay)"""
         need = ops.hashgrid_bwd_binned_workspace_bytes(n)
         ws = self._bin_ws
+        if self._polled_logs is not None:                             # inside a capture: the pool was sized before it began
+            if ws is None or ws.numel() < need:
+                raise RuntimeError("binned-scatter workspace too small for the step being captured")
+            return ws
         if ws is not None and ws.numel() >= need:
             self._bin_ws_small = self._bin_ws_small + 1 if ws.numel() > 4 * need else 0
             if self._bin_ws_small < 32:
@@ -556,7 +582,7 @@ class Renderer:
     def dp_early_slice(self) -> Optional[Tuple[int, int]]:
         """element range [start, stop) of field.grad_all whose all-reduce starts inside the step's LAST backward pass (the
         fine hash levels), or None.  A function of the configuration only, so every rank issues the same collectives."""
-        if self.grad_sync is None or not self.cfg.dp_overlap or not self.cfg.binned_scatter:
+        if self.grad_sync is None or not self.cfg.dp_overlap or not self.cfg.binned_scatter or not self.dp_early_enabled:
             return None
         f = self.field
         return 2 * int(f.grid.offset[self.cfg.dp_split_level]), f.n_table
@@ -850,6 +876,14 @@ class Trainer:
         if os.environ.get("REN_DEVICE_COUNTS", "") in ("0", "off"):  # A/B switch for scripts that build the trainer themselves
             self.device_counts = False
         self._dc_sync, self.device_count_overflows = False, 0
+        # optimiser state on the device (ABI 25, ops.HY_*): Adam step numbers and bias corrections, and the sticky skip word a
+        # captured step raises when one of its device-side counts did not fit (step_graphed)
+        self._hyper = torch.zeros(8, dtype=torch.float64, device=dev)
+        self.use_graph: Optional[bool] = None                    # Trainer.step: None = auto (a step shape seen twice in a row), False = never
+        if os.environ.get("REN_STEP_GRAPH", "") in ("0", "off"):
+            self.use_graph = False
+        self._graphs, self._graph_last_key, self._graph_pool, self._capturing = {}, None, None, False
+        self.graph_replays = self.graph_captures = 0
         self.lr_scale = 1.0
         # trainable C_p / C_n ratio (softplus-parametrised scalar, its own Adam group with lr 0.1:
         # robust_e_nerf.py:800-803).  Its loss dependence is through the per-event targets and the 1/C^k
@@ -885,9 +919,15 @@ class Trainer:
                 "mean_contrast_reciprocal_sq": self.ep[ops.EP_INV_C2: ops.EP_INV_C2 + 1]}[kind]
 
     def device_counts_ok(self) -> bool:
-        """Renders of this trainer keep their sample counts on the device: one GPU (a repeated pass would issue its
-        collectives twice), and what Renderer.device_counts_ok asks for."""
-        return self.device_counts is not False and self.world_size == 1 and self.r.device_counts_ok()
+        """Renders of this trainer keep their sample counts on the device (what Renderer.device_counts_ok asks for).  A
+        function of the configuration only.  Under data parallelism a pass that overflowed is repeated by ITS rank alone,
+        so no pass may contain a collective: the early all-reduce of the fine levels' slice (RenderCfg.dp_overlap) is off
+        then and the whole packed buffer is reduced at the settle point -- after the last pass of the step has been looked
+        at -- by optimizer_step (every rank: the same one all-reduce per step, whatever its counts did)."""
+        ok = self.device_counts is not False and self.r.device_counts_ok()
+        if self.world_size > 1:
+            self.r.dp_early_enabled = not ok
+        return ok
 
     def _dc_mode(self):
         """what this step's renders pass to Renderer.sample: True (counts stay on the device), "learn" (host counts, but the
@@ -902,6 +942,12 @@ class Trainer:
         that did not fit its arrays left the render empty: the table / MLP gradients got nothing from it, the scalar
         parameters' gradient block is put back, and the pass runs again with host-side counts."""
         dc = self._dc_mode()
+        if self._capturing:                                  # step_graphed looks at the counts after every replay
+            loss, aux, log = fn(*args, dc)
+            if log is None:
+                raise RuntimeError("a captured step needs every render on device-side counts")
+            self._cap_passes.append((log, aux))
+            return loss, aux
         snap = self._gs.clone() if dc is True else None
         loss, aux, log = fn(*args, dc)
         if log is None:
@@ -1291,25 +1337,36 @@ class Trainer:
         self.step_count += 1
         gs = 1.0 / (self.world_size * accumulate_grad_batches)            # mean over ranks and accumulated micro-batches
         lr = self.t.lr * self.lr_scale
-        ops.adam_step(f.flat, f.grad, self.m, self.v, lr=lr, betas=self.t.betas, eps=self.t.eps,
-                      weight_decay=self.t.weight_decay, step=self.step_count, grad_scale=gs, zero_grad=True)
+        # step numbers / bias corrections live on the device (ops.HY_*): the same launches serve the eager step and a captured
+        # one, whose renders' overflow words raise the skip word instead (step_graphed)
+        hy = self._hyper
+        if self.t.train_refractory_period:
+            self._tau_adam_steps += 1
+        stats = [log.stats for log in self.r._polled_logs] if self._capturing else []
+        ops.step_tick(hy, self.t.betas, stats=stats, tick_tau=self.t.train_refractory_period)
+        ops.adam_step_dev(f.flat, f.grad, self.m, self.v, hy, lr=lr, betas=self.t.betas, eps=self.t.eps,
+                          weight_decay=self.t.weight_decay, grad_scale=gs, zero_grad=True)
         if getattr(f, "n_wn_g", 0):
             f.refresh()
-        ops.adam_step(self.small, self.small_grad, self.sm, self.sv, lr=lr, betas=self.t.betas, eps=self.t.eps,
-                      weight_decay=0.0, step=self.step_count, grad_scale=gs, zero_grad=True)
+        ops.adam_step_dev(self.small, self.small_grad, self.sm, self.sv, hy, lr=lr, betas=self.t.betas, eps=self.t.eps,
+                          weight_decay=0.0, grad_scale=gs, zero_grad=True)
         if self.t.train_refractory_period:
             # float64 scalar, Adam group with lr = tau_max * relative lr (robust_e_nerf.py:804-807);
             # tau = tau_max sigmoid(raw / tau_max)  =>  d tau / d raw = sigmoid'(raw / tau_max): one single-thread launch
-            self._tau_adam_steps += 1
-            ops.tau_adam_step(self._tau_raw_dev, self._tau_grad_dev, self._tau_adam, float(self.tau_max),
-                              lr=float(self.tau_max) * self.t.relative_lr_refractory_period * self.lr_scale, betas=self.t.betas,
-                              eps=self.t.eps, step=self._tau_adam_steps, grad_scale=gs)
+            ops.tau_adam_step_dev(self._tau_raw_dev, self._tau_grad_dev, self._tau_adam, float(self.tau_max), hy,
+                                  lr=float(self.tau_max) * self.t.relative_lr_refractory_period * self.lr_scale,
+                                  betas=self.t.betas, eps=self.t.eps, grad_scale=gs)
         if self.t.train_contrast_threshold:
-            ops.adam_step(self.ct, self.ct_grad, self.ct_m, self.ct_v, lr=self.t.lr_contrast_threshold * self.lr_scale,
-                          betas=self.t.betas, eps=self.t.eps, weight_decay=0.0, step=self.step_count, grad_scale=gs,
-                          zero_grad=True)
+            ops.adam_step_dev(self.ct, self.ct_grad, self.ct_m, self.ct_v, hy, lr=self.t.lr_contrast_threshold * self.lr_scale,
+                              betas=self.t.betas, eps=self.t.eps, weight_decay=0.0, grad_scale=gs, zero_grad=True)
         if self.t.train_refractory_period or self.t.train_contrast_threshold:
             self._refresh_event_params()                     # clamp (:170-185), C_p, tau, 1 / C^k for the next step's kernels
+
+    def _sync_hyper(self):
+        """device-side step numbers <- the host's (after loading a checkpoint, or a repeated step); clears the skip word"""
+        h = [0.0] * 8
+        h[ops.HY_STEP], h[ops.HY_TAU_STEP] = float(self.step_count), float(self._tau_adam_steps)
+        self._hyper.copy_(torch.tensor(h, dtype=torch.float64))
 
     # ---- optimiser state for checkpoints (what ModelCheckpoint keeps under "optimizer_states": scripts/run.py:66-68) ----
     def optimizer_state_dict(self) -> Dict[str, object]:
@@ -1334,6 +1391,7 @@ class Trainer:
             if ta:
                 self._tau_adam_steps = int(ta["step"])
                 self._tau_adam.copy_(torch.tensor([ta["exp_avg"], ta["exp_avg_sq"]], dtype=torch.float64))
+        self._sync_hyper()
 
     def load_event_params(self, p2n_raw: Optional[torch.Tensor] = None, tau_raw: Optional[torch.Tensor] = None):
         """restore the learned contrast-threshold ratio / refractory period (checkpoint resume)"""
@@ -1379,11 +1437,22 @@ class Trainer:
              batch_index: Optional[int] = None, accumulate_grad_batches: int = 1):
         """One training batch.  With gradient accumulation (PL `accumulate_grad_batches`): the occupancy grid is
         refreshed on the first micro-batch only (robust_e_nerf.py:375-379), gradients add up over the micro-batches
-        and the optimiser steps on the last one with their mean."""
+        and the optimiser steps on the last one with their mean.
+        A step whose shape (event count, capacities of its renders, learning-rate factor) repeats is captured in a hipGraph
+        and replayed as ONE launch from then on (`use_graph`, _graph_step)."""
         k = max(1, accumulate_grad_batches)
         bi = 0 if batch_index is None else batch_index
         if global_step is not None and bi % k == 0:
             self.r.update_occ_grid(global_step, self.tab_pos)
+        if k == 1:
+            out = self._graph_step(batch, jitter_start, jitter_end, jitter_grad)
+            if out is not None:
+                return out
+        return self._step_passes(batch, jitter_start, jitter_end, jitter_grad, bi, k)
+
+    def _step_passes(self, batch, jitter_start, jitter_end, jitter_grad, bi: int = 0, k: int = 1):
+        """the loss passes of one batch and (on the last micro-batch) the optimiser step: the part of step() after the
+        occupancy-grid refresh -- what a captured step consists of"""
         # only the LAST backward pass of the LAST micro-batch may start the early all-reduce of the fine levels' slice:
         # an earlier pass would reduce it once per micro-batch (the rank-summed slice of micro-batch 1 would be summed
         # over the ranks again with micro-batch 2 on top) and the next scatter would write into a slice in flight
@@ -1404,3 +1473,139 @@ class Trainer:
             self.optimizer_step(k, mean_samples_per_ray=mean)
             aux["_mean_s_synced"] = self.world_size > 1
         return loss, aux
+
+    # ---- the whole step as one hipGraph launch (the reference's step shape: models/robust_e_nerf.py:301-517) ----
+    GRAPH_CACHE = 8
+
+    def _graph_key(self, batch, jitter_start, jitter_end, jitter_grad):
+        """what a captured step is specialised to -- or None when this step cannot be captured: device-side counts with known
+        capacities for every render (occupancy sampler, one GPU), no gradient accumulation.  The capacities in the key are
+        those of a cached graph of the same shape that still fits the learnt counts with a margin (capturing costs ~10 steps:
+        a graph is kept while the counts drift by a few per cent), otherwise what Renderer._capacities gives now."""
+        r, t = self.r, self.t
+        if self.use_graph is False or self.world_size != 1 or not r.field.flat.is_cuda or not self.device_counts_ok() or \
+                r._spr is None or self._dc_sync or (jitter_end is not None and jitter_start is None):
+            return None
+        B = batch["position"].shape[0]
+        rays = [2 * B] + ([B] if t.w_grad > 0 else [])
+        caps = [r._capacities(n) for n in rays]
+        if any(c is None for c in caps):
+            return None
+        sig = tuple(sorted((k, tuple(v.shape), str(v.dtype)) for k, v in batch.items() if isinstance(v, torch.Tensor)))
+        shape = (B, float(self.lr_scale), self.grad_sampling_mode(), jitter_start is not None, jitter_grad is not None, sig,
+                 t.train_contrast_threshold, t.train_refractory_period, float(t.w_grad))
+        need = [tuple(int(n * s * 1.08) + 1024 for s in r._spr) for n in rays]
+        for key in self._graphs:
+            if key[1:] == shape and all(c >= m and c <= 3 * m + 16384 for kc, km in zip(key[0], need) for c, m in zip(kc, km)):
+                return key
+        return (tuple(caps),) + shape
+
+    def _graph_step(self, batch, jitter_start, jitter_end, jitter_grad):
+        """replay (or capture, the second time a step shape occurs in a row) -> (loss, aux), or None: run the step eagerly"""
+        key = self._graph_key(batch, jitter_start, jitter_end, jitter_grad)
+        if key is None:
+            self._graph_last_key = None
+            return None
+        sg = self._graphs.get(key)
+        if sg is None:
+            if self.use_graph is None and key != self._graph_last_key:
+                self._graph_last_key = key               # auto: a shape has to repeat before it is worth a capture
+                return None
+            sg = self._capture(key, batch, jitter_start if jitter_end is None else torch.cat([jitter_start, jitter_end]),
+                               jitter_grad)
+            if sg is None:
+                return None
+        self._graph_last_key = key
+        # inputs -> the graph's static buffers (skipped for a tensor that already IS the static buffer: graph_inputs())
+        for k, dst in sg["batch"].items():
+            if batch[k].data_ptr() != dst.data_ptr():
+                dst.copy_(batch[k], non_blocking=True)
+        B = batch["position"].shape[0]
+        parts = [(sg["j0"], jitter_start), (sg["j2"], jitter_grad)] if jitter_end is None else \
+            [(sg["j0"][:B], jitter_start), (sg["j0"][B:], jitter_end), (sg["j2"], jitter_grad)]
+        for dst, src in parts:
+            if dst is not None and src.data_ptr() != dst.data_ptr():
+                dst.copy_(src, non_blocking=True)
+        for log, _ in sg["passes"]:
+            log.arm()
+        sg["graph"].replay()
+        self.graph_replays += 1
+        self._ep_stale = True
+        # the counts of this step's renders: a wait for its SAMPLING kernels (pinned words), the rest is still in flight
+        over = False
+        for log, _ in sg["passes"]:
+            v = log.wait()
+            over = over or bool(v[1] or v[3])
+        if not over:
+            for i, (log, aux) in enumerate(sg["passes"]):
+                v = log.values
+                self.r._learn_counts(log.n_rays, v[0], v[2])
+                for a in ((aux, sg["aux"]) if i == 0 else (aux,)):      # (the step's aux is a copy of the first pass's dict)
+                    a["n"] = v[2]
+                    if "n_marched" in a:
+                        a["n_marched"] = v[0]
+            self.step_count += 1
+            if self.t.train_refractory_period:
+                self._tau_adam_steps += 1
+            return sg["loss"], sg["aux"]
+        # a count did not fit: the graph's optimiser launches saw the skip word and changed nothing.  Clear what its passes
+        # left in the gradient buffers and run the step again with host-side counts (the capacities learn from them).
+        f = self.r.field
+        f.grad_all.zero_()
+        if getattr(f, "n_wn_g", 0):
+            f.g_mlp.zero_()
+        self._gs.zero_()
+        self._sync_hyper()
+        self.device_count_overflows += 1
+        self._dc_sync, self._grad_begun, self._grad_pending = True, None, None
+        try:
+            return self._step_passes(batch, jitter_start, jitter_end, jitter_grad)
+        finally:
+            self._dc_sync = False
+
+    def graph_inputs(self, batch, jitter_start=None, jitter_grad=None):
+        """the static input buffers of the captured step this call would replay -> (batch dict, jitter_start, jitter_grad) to
+        write the NEXT step's inputs into directly (then step() copies nothing), or None when there is no such graph yet"""
+        key = self._graph_key(batch, jitter_start, None, jitter_grad)
+        sg = self._graphs.get(key) if key is not None else None
+        return None if sg is None else (sg["batch"], sg["j0"], sg["j2"])
+
+    def _capture(self, key, batch, jitter_start, jitter_grad):
+        r = self.r
+        dev = r.field.flat.device
+        if len(self._graphs) >= self.GRAPH_CACHE:            # oldest out (its memory stays in the shared pool for the others)
+            self._graphs.pop(next(iter(self._graphs)))
+        st_batch = {k: v.clone() for k, v in batch.items() if isinstance(v, torch.Tensor)}
+        j0 = jitter_start.to(torch.float32).clone() if jitter_start is not None else None
+        j2 = jitter_grad.to(torch.float32).clone() if jitter_grad is not None else None
+        caps = key[0]
+        if r.cfg.binned_scatter:
+            r._binned_workspace(max(max(c) for c in caps), dev)      # sized before the capture: nothing (re)allocates inside
+        _ = self.side_stream
+        pinned = [torch.empty(4, dtype=torch.int64).pin_memory() for _ in range(len(caps))]
+        if self._graph_pool is None:
+            self._graph_pool = torch.cuda.graph_pool_handle()
+        g = torch.cuda.CUDAGraph()
+        host_state = (self.step_count, self._tau_adam_steps, self._ep_stale)
+        r._polled_logs, r._polled_pinned, self._cap_passes, self._capturing = [], pinned, [], True
+        self._grad_begun, self._grad_pending = None, None
+        ok = False
+        try:
+            with torch.cuda.graph(g, pool=self._graph_pool):
+                loss, aux = self._step_passes(st_batch, j0, None, j2)
+            ok = True
+        except Exception as e:                               # a capture that cannot be made is not an error of the step
+            import warnings
+            warnings.warn(f"step capture failed ({type(e).__name__}: {e}); this trainer runs eagerly from here on")
+            self.use_graph = False
+        finally:
+            passes = self._cap_passes
+            r._polled_logs, r._polled_pinned, self._cap_passes, self._capturing = None, None, None, False
+            self.step_count, self._tau_adam_steps, self._ep_stale = host_state       # (nothing ran)
+            self._grad_begun, self._grad_pending = None, None
+        if not ok:
+            return None
+        self.graph_captures += 1
+        sg = dict(graph=g, batch=st_batch, j0=j0, j2=j2, loss=loss, aux=aux, passes=passes)
+        self._graphs[key] = sg
+        return sg

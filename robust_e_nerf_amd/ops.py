@@ -755,6 +755,38 @@ def adam_step(p, g, m, v, *, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
           "ren_adam_step")
 
 
+# ---- optimiser state on the device (ABI 25): what a captured step (engine.Trainer.step_graphed) needs -- include/ren_amd.h
+HY_STEP, HY_SKIP, HY_BC1, HY_BC2, HY_TAU_STEP, HY_TAU_BC1, HY_TAU_BC2 = range(7)
+
+
+def step_tick(hyper, betas=(0.9, 0.999), stats=(), tick_tau: bool = False):
+    """advance the device-side Adam step(s) -- or raise the sticky skip word when an overflow word of `stats` (up to two
+    int64[4] blocks of scan_guard) is set.  Once per optimiser step, before adam_step_dev / tau_adam_step_dev."""
+    st = [s for s in stats if s is not None]
+    if len(st) > 2:
+        raise ValueError("step_tick: at most two renders' stats")
+    st += [None] * (2 - len(st))
+    check(_lib.load().ren_step_tick(_ptr(hyper, torch.float64), ctypes.c_double(betas[0]), ctypes.c_double(betas[1]),
+                                    _ptr(st[0], torch.int64), _ptr(st[1], torch.int64), 1 if tick_tau else 0, _stream()),
+          "ren_step_tick")
+
+
+def adam_step_dev(p, g, m, v, hyper, *, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0, zero_grad=True):
+    check(_lib.load().ren_adam_step_dev(_ptr(p, torch.float32), _ptr(g, torch.float32), _ptr(m, torch.float32),
+                                        _ptr(v, torch.float32), p.numel(), _f(lr), _f(betas[0]), _f(betas[1]), _f(eps),
+                                        _f(weight_decay), _ptr(hyper, torch.float64), _f(grad_scale), 1 if zero_grad else 0,
+                                        _stream()), "ren_adam_step_dev")
+
+
+def tau_adam_step_dev(tau_raw, tau_grad, state, tau_max: float, hyper, *, lr: float, betas=(0.9, 0.999), eps: float = 1e-8,
+                      grad_scale: float = 1.0):
+    check(_lib.load().ren_tau_adam_step_dev(_ptr(tau_raw, torch.float64), _ptr(tau_grad, torch.float64),
+                                            _ptr(state, torch.float64), ctypes.c_double(float(tau_max)),
+                                            ctypes.c_double(float(lr)), ctypes.c_double(betas[0]), ctypes.c_double(betas[1]),
+                                            ctypes.c_double(eps), _ptr(hyper, torch.float64), ctypes.c_double(grad_scale),
+                                            _stream()), "ren_tau_adam_step_dev")
+
+
 # ------------------------------------------------------------------------------- occupancy grid
 def occgrid_cell_points(indices, jitter, roi, res, ct):
     m = indices.shape[0]
@@ -813,7 +845,7 @@ def profile_stop():
 
 def _wrap(name, fn):
     def timed(*a, **kw):
-        if _PROFILE is None:
+        if _PROFILE is None or torch.cuda.is_current_stream_capturing():    # (events inside a capture become graph nodes)
             return fn(*a, **kw)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

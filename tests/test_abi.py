@@ -63,7 +63,7 @@ def test_no_packed_fp32_op_sel_in_the_shipped_library(lib):
 
 
 def test_abi_version_and_build_info(lib):
-    assert lib.ren_abi_version() == 24
+    assert lib.ren_abi_version() == 25
     assert b"gfx950" in lib.ren_build_info()
 
 

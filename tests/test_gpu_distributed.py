@@ -127,6 +127,31 @@ def _worker(rank, port, out_dir, backend="gloo", one_gpu_per_rank=False):
     full = evaluation.render_image(tr3.r, tr3.Kinv, pos[0], rot[0], 50, 64, bk)
     shard = evaluation.render_image_sharded(tr3.r, tr3.Kinv, pos[0], rot[0], 50, 64, bk, rank=rank, world=WORLD)
     res["render_equal"] = [bool(torch.equal(a, b)) for a, b in zip(full, shard)]
+    # ---- 5. device-side sample counts under data parallelism: four steps with the counts on the device,
+    # capacities made four times too small on RANK 1 ONLY at step 2 -- that rank repeats its passes by itself (no collective
+    # inside a pass: one all-reduce per step at the settle point, on every rank) -- against the host-count run
+    def dp_run(dc, squeeze):
+        tr5, _ = mk(WORLD)
+        tr5.device_counts = dc
+        out = []
+        for k in range(4):
+            b5, jit5 = evs(2 * B, t_end, seed=50 + k)
+            sb5, sj5 = _shard(b5, jit5, rank * B, (rank + 1) * B)
+            if squeeze and k == 2 and rank == 1 and tr5.r._spr is not None:
+                tr5.r._spr = tuple(0.25 * s for s in tr5.r._spr)
+            loss5, aux5 = tr5.step(sb5, sj5[0], sj5[1], jitter_grad=sj5[2])
+            out.append((float(loss5), int(aux5["n"]), int(aux5["grad"]["n"]), tr5.last_collectives))
+        return out, tr5
+    ref5, trh = dp_run(False, False)
+    got5, trd = dp_run(None, True)
+    overs = [None] * WORLD
+    dist.all_gather_object(overs, int(trd.device_count_overflows))
+    res["dc_overflows"] = overs
+    res["dc_counts_equal"] = [a[1:3] == b[1:3] for a, b in zip(got5, ref5)]
+    res["dc_loss_err"] = max(abs(a[0] - b[0]) / abs(b[0]) for a, b in zip(got5, ref5))
+    res["dc_collectives"] = ([a[3] for a in ref5], [a[3] for a in got5])
+    res["dc_param_err"] = float((trd.r.field.flat - trh.r.field.flat).abs().max() / trh.r.field.flat.abs().max())
+    res["dc_on"] = bool(trd.device_counts_ok() and not trh.device_counts_ok())
     views = evaluation.view_shard(3, rank, WORLD)
     local = torch.stack([evaluation.render_image(tr3.r, tr3.Kinv, pos[0] + 0.01 * v, rot[0], 20, 24, bk)[0] for v in views])
     allv = evaluation.gather_views(local, 3, rank, WORLD)
@@ -161,10 +186,18 @@ def check_two_rank_results(got):
         print(f"2 ranks x 2 micro-batches vs 1 rank x 4: first moment of the {name} gradient, max rel err {err:.2e}")
         assert err < 2e-5, (name, err)
     assert float((got["ct_m"] - tr.ct_m.cpu()).abs().max()) <= 1e-5 * float(tr.ct_m.abs().max())
-    assert got["collectives"] == 3, got["collectives"]        # early fine-level slice + the two remaining ranges, ONCE per step
+    # with the sample counts on the device (the default for the occupancy sampler) no pass contains a collective: ONE
+    # all-reduce of the packed buffer per optimiser step, at the settle point (engine.Trainer.device_counts_ok)
+    assert got["collectives"] == 1, got["collectives"]
     # 2. the empty rank issued the same collectives and received its peer's gradient
-    assert got["empty_n"] > 0 and got["empty_collectives"] == 3 and got["empty_m_nonzero"] > 0
+    assert got["empty_n"] > 0 and got["empty_collectives"] == 1 and got["empty_m_nonzero"] > 0
     # 3. replicas identical after refreshes and batch-size changes
     assert all(got["identical"]), got["identical"]
     assert got["binary_cells"] > 0 and len(set(got["sizes"])) > 1, (got["binary_cells"], got["sizes"])
     assert all(got["render_equal"]) and got["views_equal"]
+    # 5. device-side counts under data parallelism, one rank overflowing: the same counts, losses and parameters as the
+    # host-count run (whose steps keep the early slice: 3 collectives), one collective per step, rank 1 repeated by itself
+    assert got["dc_on"] and got["dc_overflows"] == [0, 1], got["dc_overflows"]
+    assert all(got["dc_counts_equal"]) and got["dc_loss_err"] < 2e-5 and got["dc_param_err"] < 2e-5, \
+        (got["dc_counts_equal"], got["dc_loss_err"], got["dc_param_err"])
+    assert got["dc_collectives"] == ([3] * 4, [1] * 4), got["dc_collectives"]

@@ -7,7 +7,8 @@ for r in csv.DictReader(open(sys.argv[1])):
 rows.sort()
 # one step = from the end of one group of consecutive adam_kernel launches (2: table + small parameters; 3 with a trainable
 # C_p) to the end of the next group
-ends = [rows[k][1] for k in range(len(rows)) if "adam_kernel" in rows[k][2] and (k + 1 == len(rows) or "adam_kernel" not in rows[k + 1][2])]
+is_adam = lambda n: "adam_kernel" in n or "adam_dev_kernel" in n
+ends = [rows[k][1] for k in range(len(rows)) if is_adam(rows[k][2]) and (k + 1 == len(rows) or not is_adam(rows[k + 1][2]))]
 steps = list(zip(ends[:-1], ends[1:]))
 t0, t1 = steps[-2]
 ks = [x for x in rows if x[0] >= t0 and x[1] <= t1 + 1]
