@@ -24,6 +24,9 @@ __device__ __forceinline__ bool block_to_work(int xcd_affine, int n_levels, int6
                                               int64_t &chunk) {
     if (!xcd_affine) { lvl = blockIdx.y; chunk = blockIdx.x; return true; }
     const int64_t b = blockIdx.x;
+    // probe (REN_KNOB_HG_VARIANT bit 2, round 6): LEVEL-INNER order -- consecutive workgroups are the 16 levels of one sample
+    // chunk, so all 16 table slices (48 MB) are in flight at once: the access pattern a fused per-sample encode + MLP kernel has
+    if (xcd_affine & 4) { lvl = (int)(b % n_levels); chunk = b / n_levels; return chunk < n_chunks; }
     const int64_t j = b >> 3;
     const int slot = (int)(j / n_chunks);
     chunk = j - slot * n_chunks;
@@ -162,9 +165,10 @@ extern "C" int ren_hashgrid_fwd(const ren_grid_desc *grid, const float *table, c
     if (scene) sc = ren_make_scene(scene);
     const int64_t n_pad = layout == 1 ? ((n + 31) / 32) * 32 : n;
     const int variant = hg_variant();
-    const int affine = variant & 1;
+    const int affine = variant & 5;
     const int64_t n_chunks = (n_pad + 255) / 256;
-    dim3 grd = affine ? dim3((unsigned)(8 * ((g.n_levels + 7) / 8) * n_chunks)) : dim3((unsigned)n_chunks, g.n_levels);
+    dim3 grd = (affine & 4) ? dim3((unsigned)(g.n_levels * n_chunks))
+             : affine ? dim3((unsigned)(8 * ((g.n_levels + 7) / 8) * n_chunks)) : dim3((unsigned)n_chunks, g.n_levels);
     dim3 blk(256);
     const float2 *tab = reinterpret_cast<const float2 *>(table);
 #define LAUNCH(L, R)                                                                                     \
