@@ -248,6 +248,11 @@ def _radiance(x, name):
     raise NotImplementedError(f"radiance activation {name!r} (nerf.py:26-29)")
 
 
+# test hook (step.render_given): a callable xu -> features that replaces hashgrid.encode -- the rest of the field is then
+# evaluated on somebody else's features (the HIP encoder's), which separates encoder differences from everything behind it
+ENC_OVERRIDE = None
+
+
 def query_density(
     x_world: torch.Tensor, p: Dict[str, torch.Tensor], spec, aabb: torch.Tensor,
     contraction_type: int = AABB, return_feat: bool = False, acts: Optional[dict] = None,
@@ -256,7 +261,7 @@ def query_density(
     a = dict(DEFAULT_ACTS, **(acts or {}))
     xu = contract(x_world, aabb, contraction_type)
     sel = selector(xu)
-    enc = hashgrid.encode(xu, p["hash"], spec)
+    enc = hashgrid.encode(xu, p["hash"], spec) if ENC_OVERRIDE is None else ENC_OVERRIDE(xu)
     h = _hidden(linear(enc, p["base.w0"], p["base.b0"]), a["base_hidden"])
     raw = linear(h, p["base.wo"], p["base.bo"])
     sigma = _density(raw[:, :1], a["density"]) * sel[:, None].to(raw.dtype)

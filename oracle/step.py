@@ -177,3 +177,64 @@ def training_forward(batch: EventBatch, p, spec, cfg: SceneCfg, *, Kinv, tab_ts,
                n_start=out["start"][3], n_end=out["end"][3], pred_log_diff=pred, terms=terms,
                packed_start=out["start"][5], packed_end=out["end"][5])
     return loss, aux
+
+
+def near_cell_face(xu: torch.Tensor, spec, k_ulp: float = 4.0) -> torch.Tensor:
+    """(n, L) bool: in THIS restatement's own arithmetic (hashgrid.encode: pos = fmaf(scale, x, 0.5)) the sample sits within
+    k_ulp units in the last place of pos of a cell face of level l in some dimension.  d feature / dt of a trilinear level is
+    piecewise constant per cell, so a position that differs in its last bits (another summation order of o + d t) may take
+    the neighbour cell's slope exactly there and nowhere else (models/robust_e_nerf.py:383-409 differentiates through it)."""
+    out = []
+    for lvl in range(spec.n_levels):
+        pos = (xu.detach().double() * float(spec.scales[lvl]) + 0.5).float()
+        w = (pos - torch.floor(pos)).double()
+        ulp = torch.abs(torch.nextafter(pos, torch.full_like(pos, float("inf"))) - pos).double()
+        out.append((torch.minimum(w, 1.0 - w) <= k_ulp * ulp).any(dim=-1))
+    return torch.stack(out, dim=1)
+
+
+def render_given(o, d, od, dd, ri, ts, te, p, spec, cfg: SceneCfg, bkgd, feat=None, featd=None, fused_position: bool = False):
+    """The render of robust_e_nerf.py:383-409 and its time derivative on SOMEBODY ELSE'S rays and samples:
+    rays (o, d) with their time derivatives (od, dd) and the packed sample stream (ri, ts, te) are inputs -- the HIP path's
+    own, copied to the host -- so sample placement is identical by construction and what is compared is the field, the
+    compositing and the forward-mode derivative (utils/autograd.py:4-34 in forward mode, as training_forward(tangent=
+    "forward")).  feat / featd (n, L F): evaluate everything BEHIND the encoder on these features and their tangents instead
+    of encoding (field.ENC_OVERRIDE).  fused_position: the sample position as ONE fused multiply-add o + d tm (product exact in
+    float64, one rounding) instead of torch's multiply, then add -- the kernels' summation order (csrc/ren_common.h
+    ren_sample_pos under -ffp-contract=fast); the two differ in the last bit of x, i.e. by up to ulp(scale x) = 2^-12 of a cell
+    in the interpolation weights of the finest level.  -> dict(colors, colords, opacity, enc, encd, xu)"""
+    import torch.autograd.forward_ad as fwAD
+    aabb = torch.tensor(cfg.aabb, dtype=torch.float32)
+    n_rays, ril = o.shape[0], ri.long()
+    ts, te = ts.reshape(-1, 1), te.reshape(-1, 1)
+    keep = {}
+    with fwAD.dual_level():
+        od_, dd_ = fwAD.make_dual(o, od), fwAD.make_dual(d, dd)
+
+        def enc_fn(xu):
+            if feat is not None:
+                e = fwAD.make_dual(feat, featd)
+            else:
+                e = hashgrid.encode(xu, p["hash"], spec)
+            u = fwAD.unpack_dual(e)
+            keep["enc"], keep["encd"] = u.primal.detach(), (u.tangent if u.tangent is not None else torch.zeros_like(u.primal)).detach()
+            keep["xu"] = fwAD.unpack_dual(xu).primal.detach()
+            return e
+
+        def rgb_sigma_fn(ts_, te_, ri_):
+            if fused_position:
+                tm = ((ts_ + te_) * 0.5).double()
+                x = (od_[ri_].double() + dd_[ri_].double() * tm).float()
+            else:
+                x = od_[ri_] + dd_[ri_] * (ts_ + te_) / 2.0                # external/utils.py:68-72
+            return field.field_forward(x, dd_[ri_], p, spec, aabb, cfg.contraction_type, acts=cfg.acts)
+
+        field.ENC_OVERRIDE = enc_fn
+        try:
+            colors, opac, _ = render.rendering(ts, te, ri, n_rays, rgb_sigma_fn, render_bkgd=bkgd)
+        finally:
+            field.ENC_OVERRIDE = None
+        c, oq = fwAD.unpack_dual(colors), fwAD.unpack_dual(opac)
+        out = dict(colors=c.primal.detach(), colords=(c.tangent if c.tangent is not None else torch.zeros_like(c.primal)).detach(),
+                   opacity=oq.primal.detach().squeeze(-1), **keep)
+    return out

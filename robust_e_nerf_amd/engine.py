@@ -876,6 +876,7 @@ class Trainer:
         if os.environ.get("REN_DEVICE_COUNTS", "") in ("0", "off"):  # A/B switch for scripts that build the trainer themselves
             self.device_counts = False
         self._dc_sync, self.device_count_overflows = False, 0
+        self.keep_ctx = False                                    # tests: aux["ctx"] = the render's context (rays, samples, features)
         # optimiser state on the device (ABI 25, ops.HY_*): Adam step numbers and bias corrections, and the sticky skip word a
         # captured step raises when one of its device-side counts did not fit (step_graphed)
         self._hyper = torch.zeros(8, dtype=torch.float64, device=dev)
@@ -1169,6 +1170,8 @@ class Trainer:
             ops.bkgd_param_grad(d_bk, self.small, self.small_grad)       # += sigmoid(raw) * column sums (d softplus)
         pk = ctx["pk"]                                       # (pk.log: n / n_marched are capacities here, _dc_pass puts the counts in)
         aux = dict(intensity_start=i_s, intensity_end=i_e, n=pk.n, n_marched=pk.n_marched, opacity=opac, rays=2 * B)
+        if self.keep_ctx:                                    # tests: the renders' own rays and samples
+            aux["ctx"] = ctx
         return loss, aux, pk.log
 
     def grad_sampling_mode(self) -> str:
@@ -1305,6 +1308,8 @@ class Trainer:
         if d_bkgd is not None:
             self.small_grad[: f.C] += d_bkgd * torch.sigmoid(self.small[: f.C])
         aux = dict(intensity=inten, dlog_dt=dlog, n=pk.n, rays=B)
+        if self.keep_ctx:                                    # tests: the render's own rays, samples, features and tangents
+            aux["ctx"] = dict(ctx, colors=colors, colords=colords)
         return loss, aux, pk.log
 
     def optimizer_step(self, accumulate_grad_batches: int = 1, mean_samples_per_ray: Optional[float] = None):

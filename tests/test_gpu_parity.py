@@ -1259,8 +1259,13 @@ def test_config_b_loss_vs_oracle(amd, spec, full_table_cache):
     del tr_h, aux_h
     tr, _ = _trainer_from_golden(engine, g, table, sampler="uniform")
     tr.r.cfg.n_uniform = S
+    tr.keep_ctx = True
     loss, aux = tr.forward_backward(batch, dev(j0), dev(j1))
     assert aux["n"] == 2 * B * S == 8388608
+    hip = {k: aux["ctx"][k].cpu() for k in ("o", "d")}
+    hip.update(ts=aux["ctx"]["pk"].t_starts.cpu(), te=aux["ctx"]["pk"].t_ends.cpu(), offs=aux["ctx"]["pk"].offsets.cpu())
+    del aux["ctx"]
+    edge_rays = []
     worst_h = 0.0
     p = field_params_from(g, table)
     cfg = ostep.SceneCfg(sampler="uniform", n_uniform=S, render_step_size=float(g["render_step_size"]))
@@ -1296,6 +1301,7 @@ def test_config_b_loss_vs_oracle(amd, spec, full_table_cache):
             face = torch.minimum(u.abs(), (1 - u).abs()).min(dim=1).values
             edge = torch.zeros(B // CH, dtype=torch.bool).index_put_((ri.long()[face < 1e-6],), torch.tensor(True))
             n_edge += int(edge.sum())
+            edge_rays += [(int(r_) + sl.start + (B if nm == "end" else 0), float(lo[int(r_)]), float(lo.abs().max())) for r_ in torch.nonzero(edge)[:, 0]]
             worst = max(worst, float(err[~edge].max()))
             worst_h = max(worst_h, float(err_h[~edge].max()))
             assert float(err[edge].max() if edge.any() else 0.0) < 2e-2
@@ -1307,6 +1313,20 @@ def test_config_b_loss_vs_oracle(amd, spec, full_table_cache):
     print(f"   float32_matmul_precision high: log-intensity max rel err {worst_h:.2e}, loss {loss_h:.7f} ({err_h:.2e})")
     assert worst < 1e-4 and err < 1e-4 and n_edge <= 2 * B * 1e-3
     assert worst_h < 1e-4 and err_h < 1e-4
+    # The rays set aside, pinned after all: the oracle on the HIP path's OWN ray and samples with the sample
+    # position summed as the kernels sum it (oracle.step.render_given(fused_position=True)) -- the step of the selector then
+    # falls on the same side in both, and the ray agrees like every other one
+    li_all = torch.cat([li_s, li_e])
+    for ray, lo_torch, lo_max in edge_rays:
+        s0 = int(hip["offs"][ray])
+        z = torch.zeros(1, 3)
+        out = ostep.render_given(hip["o"][ray:ray + 1], hip["d"][ray:ray + 1], z, z, torch.zeros(S, dtype=torch.int64), hip["ts"][s0:s0 + S],
+                                 hip["te"][s0:s0 + S], p, spec, cfg, torch.nn.functional.softplus(t(g["bkgd_raw"])), fused_position=True)
+        lo_f = float((out["colors"][0, 0] + cfg.min_modeled_intensity).log())
+        e_f, e_t = abs(float(li_all[ray]) - lo_f) / lo_max, abs(float(li_all[ray]) - lo_torch) / lo_max
+        print(f"   ray {ray} (a sample on an AABB face): log I vs the oracle on torch's rays {e_t:.1e}, vs the oracle on the HIP path's own ray and "
+              f"samples with the fused sample position {e_f:.1e}")
+        assert e_f < 1e-5
 
 
 def test_bayer_sensor_step_vs_oracle(amd, spec, full_table_cache):
@@ -2581,3 +2601,112 @@ def test_library_uniform_stream_is_philox4x32_10(amd):
     assert np.array_equal(got, want)
     assert got.min() >= 0.0 and got.max() < 1.0 and abs(got.mean() - 0.5) < 0.01 and abs(got.var() - 1 / 12) < 0.005
     assert not np.array_equal(got, _ops.uniform(n, seed, off + 1).cpu().numpy())
+
+
+def _frag_to_rows(x, n):
+    """fragment layout ((i >> 5) * 16 + level) * 64 + f * 32 + (i & 31) -> (n, 32) rows [level-major, feature]"""
+    nb = x.numel() // 1024
+    return x.view(nb, 16, 2, 32).permute(0, 3, 1, 2).reshape(nb * 32, 32)[:n].contiguous()
+
+
+@pytest.mark.parametrize("size", ["golden", "bench"])
+def test_dlog_dt_ray_by_ray_on_the_hip_paths_own_rays_and_samples(amd, spec, full_table_cache, size):
+    """d log I / dt pinned RAY BY RAY (models/robust_e_nerf.py:383-409, utils/autograd.py:4-34).  The oracle
+    (oracle.step.render_given) evaluates the third render on the HIP path's OWN rays, ray tangents and packed samples, copied
+    to the host, so sample placement is identical by construction.  What remains is taken apart:
+      1. with the sample position formed as the kernels form it (one fused multiply-add o + d tm), features and feature
+         tangents of EVERY (sample, level) agree to fp32 round-off and d log I / dt of EVERY ray to 1e-4 of the largest value:
+         no ray, no sample is set aside -- the kernels compute what the restatement computes;
+      2. everything behind the encoder -- MLPs, compositing, forward-mode derivative -- on the HIP path's own features: every
+         ray to 1e-4;
+      3. with torch's order (multiply, then add: the last bit of x differs) the interpolation weights of a level move by up to
+         ulp(scale x) -- 2^-12 of a cell at the finest level -- so features / tangents differ by <= 8 ulp(scale) of the level's
+         largest value EXCEPT where the oracle's own arithmetic puts the sample within 4 ulp of a cell face (the tangent of a
+         trilinear level is piecewise constant per cell: there it takes the neighbour cell's slope); the per-ray tail of
+         test_config_c3_bf16_at_bench_size_vs_oracle is this, printed here ray by ray.
+    golden: the 96-event step of the reference fixture; bench: 4 096 events (about 0.55 M samples in the third render)."""
+    from oracle import step as ostep
+    ops, engine = amd
+    g = load_golden("training_step_grad")
+    table = full_table_cache(g["table_seed"], g["table_scale"])
+    occ_res = int(g["occ_res"])
+    cfg = ostep.SceneCfg(occ_res=(occ_res,) * 3, render_step_size=float(g["render_step_size"]))
+    p = field_params_from(g, table)
+    tr, batch = _trainer_from_golden(engine, g, table)
+    tr.t.w_grad, tr.t.err_grad, tr.t.pw_grad = float(g["w_grad"]), "mape", None
+    tr.keep_ctx = True
+    if size == "golden":
+        batch["u_grad"] = dev(g["u_grad"])
+        jg = dev(t(g["jitters"])[0])
+    else:
+        B = 4096
+        nb = _config_batch(B, 61, int(g["tab_ts"][-1]))
+        gen = torch.Generator().manual_seed(62)
+        nb["u_grad"] = torch.rand(B, generator=gen, dtype=torch.float64).numpy()
+        batch = {k: dev(v) for k, v in nb.items()}
+        jg = dev(torch.rand(B, generator=gen))
+    _, aux_g = tr.grad_loss_forward_backward(batch, jg)
+    ctx = aux_g["ctx"]
+    pk = ctx["pk"]
+    n, R = int(aux_g["n"]), ctx["o"].shape[0]
+    o, d, od, dd = (ctx[k].cpu() for k in ("o", "d", "od", "dd"))
+    ri, ts, te = pk.ray_indices[:n].cpu(), pk.t_starts[:n].cpu(), pk.t_ends[:n].cpu()
+    offs, cnts = pk.offsets.cpu(), pk.counts.cpu().long()
+    feat, featd = _frag_to_rows(ctx["feat"].cpu(), n), _frag_to_rows(ctx["featd"].cpu(), n)
+    bk = torch.nn.functional.softplus(tr.small[:1]).cpu()
+    eps = cfg.min_modeled_intensity
+    hip_c, hip_cd = ctx["colors"].cpu()[:, 0], ctx["colords"].cpu()[:, 0]
+    hip_dlog = aux_g["dlog_dt"].cpu().double()
+    assert torch.allclose(hip_dlog, (hip_cd / (hip_c + eps)).double(), rtol=1e-6, atol=0)
+    res = {k: [] for k in ("fused", "given", "torch")}
+    near, encs = [], {"fused": [], "torch": []}
+    CH = 1 if size == "golden" else 8
+    for c in range(CH):                                              # ray chunks bound the oracle's memory
+        r0, r1 = c * R // CH, (c + 1) * R // CH
+        s0, s1 = int(offs[r0]), int(offs[r1 - 1] + cnts[r1 - 1])
+        args = (o[r0:r1], d[r0:r1], od[r0:r1], dd[r0:r1], ri[s0:s1] - r0, ts[s0:s1], te[s0:s1], p, spec, cfg, bk)
+        for key, kw in (("fused", dict(fused_position=True)), ("given", dict(feat=feat[s0:s1], featd=featd[s0:s1])), ("torch", {})):
+            a = ostep.render_given(*args, **kw)
+            res[key].append((a["colors"][:, 0], a["colords"][:, 0]))
+            if key in encs:
+                encs[key].append((a["enc"], a["encd"]))
+            if key == "torch":
+                near.append(ostep.near_cell_face(a["xu"], spec, 4.0))
+    near = torch.cat(near)
+    dl = lambda cs: (torch.cat([x[1] for x in cs]) / (torch.cat([x[0] for x in cs]) + eps)).double()
+    col = lambda cs: torch.cat([x[0] for x in cs]).double()
+    scale = float(hip_dlog.abs().max())
+    lv = lambda x: x.view(n, 16, 2)
+    q = torch.tensor([0.5, 0.9, 0.99, 1.0], dtype=torch.float64)
+    fmt = lambda e: " / ".join(f"{float(v):.1e}" for v in torch.quantile(e.double(), q)) if e.numel() else "-"
+
+    def enc_err(key):
+        enc, encd = torch.cat([x[0] for x in encs[key]]), torch.cat([x[1] for x in encs[key]])
+        e_f = (lv(feat) - lv(enc)).abs().amax(-1) / lv(enc).abs().amax(dim=(0, 2)).clamp(min=1e-30)[None, :]
+        e_fd = (lv(featd) - lv(encd)).abs().amax(-1) / lv(encd).abs().amax(dim=(0, 2)).clamp(min=1e-30)[None, :]
+        return e_f, e_fd
+    # ---- 1. the kernels' summation order of the sample position: everything agrees, everywhere
+    e_f, e_fd = enc_err("fused")
+    e_c = (hip_c.double() - col(res["fused"])).abs() / col(res["fused"]).abs().max()
+    e_d = (hip_dlog - dl(res["fused"])).abs() / scale
+    print(f"{size}: {R} rays, {n} samples.  Oracle with the fused sample position: features of every (sample, level) {float(e_f.max()):.1e}, tangents "
+          f"{float(e_fd.max()):.1e} of the level's largest; colour of every ray {float(e_c.max()):.1e}; d log I / dt median / 90 % / 99 % / max {fmt(e_d)}")
+    assert float(e_f.max()) < 2e-6 and float(e_fd.max()) < 2e-5
+    assert float(e_c.max()) < 1e-5 and float(e_d.max()) < 1e-4
+    # ---- 2. behind the encoder, on the HIP features: every ray
+    e_c = (hip_c.double() - col(res["given"])).abs() / col(res["given"]).abs().max()
+    e_d = (hip_dlog - dl(res["given"])).abs() / scale
+    print(f"{size}: oracle MLPs + compositing + d/dt on the HIP features: colour max {float(e_c.max()):.1e}, d log I / dt median / 90 % / 99 % / max {fmt(e_d)}")
+    assert float(e_c.max()) < 1e-5 and float(e_d.max()) < 1e-4
+    # ---- 3. torch's order: weights move by ulp(scale x); cell faces flip
+    e_f, e_fd = enc_err("torch")
+    ulp = torch.tensor([2.0 ** (math.floor(math.log2(max(float(s_), 1.0))) - 23) for s_ in spec.scales])
+    bad = (e_f > 8 * ulp[None, :] + 2e-6) | (e_fd > 8 * ulp[None, :] + 2e-5)
+    ray_near = torch.zeros(R, dtype=torch.bool).index_put_((ri.long()[near.any(1)],), torch.tensor(True))
+    e_o = (hip_dlog - dl(res["torch"])).abs() / scale
+    print(f"{size}: oracle with torch's order (multiply, add): {int(near.sum())} (sample, level) pairs within 4 ulp of a cell face ({100 * float(near.float().mean()):.3f} %), "
+          f"{int(bad.sum())} pairs differ by more than 8 ulp(scale), {int((bad & ~near).sum())} of them NOT near a face; finest level away from faces: feature "
+          f"{float(e_f[:, 15][~near[:, 15]].max()):.1e}, tangent {float(e_fd[:, 15][~near[:, 15]].max()):.1e} (ulp(scale) = {float(ulp[15]):.1e}).  d log I / dt over all rays: "
+          f"median / 90 % / 99 % / max {fmt(e_o)} ({100 * float((e_o > 1e-3).double().mean()):.1f} % above 1e-3); rays with a near-face sample: {int(ray_near.sum())} "
+          f"({fmt(e_o[ray_near])}), without: {int((~ray_near).sum())} ({fmt(e_o[~ray_near])})")
+    assert int((bad & ~near).sum()) == 0

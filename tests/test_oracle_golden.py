@@ -384,3 +384,43 @@ def test_vanilla_field_activation_alternatives(tag):
         gr = v.grad.reshape(-1)
         assert rel_err(gr[t(g["gi." + k])], g["gv." + k]) < 1e-5, k
         assert abs(float(gr.double().abs().sum()) - float(g["gs." + k])) < 1e-5 * float(g["gs." + k]) + 1e-12, k
+
+
+def test_render_given_reproduces_the_pinned_third_render():
+    """oracle.step.render_given (the ray-by-ray checker of tests/test_gpu_parity.py: a render and its time derivative on GIVEN
+    rays, ray tangents and samples) against the pinned path: on the rays and samples of training_forward(tangent="forward")
+    itself it returns that render's intensity and d log I / dt bit for bit, also when the encoder is replaced by its own
+    features (field.ENC_OVERRIDE); near_cell_face flags about 1.5 % of the samples of the fixture step at 4 ulp."""
+    import torch.autograd.forward_ad as fwAD
+    from oracle import step as ostep, hashgrid, trajectory
+    g = load_golden("training_step_grad")
+    spec = hashgrid.make_spec()
+    table = hashgrid.init_table(spec, int(g["table_seed"]), float(g["table_scale"]), "mix32")
+    p = field_params_from(g, table)
+    occ_res = int(g["occ_res"])
+    binary = t(np.unpackbits(g["binary"])[: occ_res ** 3].astype(bool)).view(occ_res, occ_res, occ_res)
+    cfg = ostep.SceneCfg(occ_res=(occ_res,) * 3, render_step_size=float(g["render_step_size"]))
+    keys = ("position", "start_ts", "end_ts", "num_pos", "num_neg", "u_ts_diff", "u_diff_start", "u_grad")
+    ob = ostep.EventBatch(*(t(g[k]) for k in keys))
+    jit = t(g["jitters"])
+    _, aux = ostep.training_forward(
+        ob, p, spec, cfg, Kinv=t(g["Kinv"]), tab_ts=t(g["tab_ts"]), tab_pos=t(g["tab_pos"]), tab_quat=t(g["tab_quat"]),
+        p2n_raw=t(g["p2n_raw"]), neg_ct=t(g["neg_ct"]), tau_raw=t(g["tau_raw"]), tau_max=t(g["tau_max"]), bkgd_raw=t(g["bkgd_raw"]),
+        binary=binary, jitter_start=jit[1], jitter_end=jit[2], jitter_grad=jit[0],
+        loss_cfg=dict(w_grad=float(g["w_grad"]), err_grad="mape", pw_grad=None), tangent="forward")
+    ri, ts, te = aux["grad"][5]
+    ts_g = aux["ts"]["grad_ts"].detach()
+    with fwAD.dual_level():
+        pos, R = trajectory.linear_trajectory(fwAD.make_dual(ts_g, torch.ones_like(ts_g)), t(g["tab_ts"]), t(g["tab_pos"]), t(g["tab_quat"]))
+        o, d = trajectory.pixel_params_to_ray(t(g["Kinv"]), ob.position, pos, R)
+        uo, ud = fwAD.unpack_dual(o), fwAD.unpack_dual(d)
+        o0, od, d0, dd = uo.primal.detach(), uo.tangent.detach().float(), ud.primal.detach(), ud.tangent.detach().float()
+    bk = torch.nn.functional.softplus(t(g["bkgd_raw"]))
+    out = ostep.render_given(o0, d0, od, dd, ri, ts.reshape(-1), te.reshape(-1), p, spec, cfg, bk)
+    inten = out["colors"][:, 0] + cfg.min_modeled_intensity
+    assert torch.equal(inten, aux["grad"][0].detach())
+    assert torch.equal((out["colords"][:, 0] / inten).double(), aux["pred_log_grad"].detach().double())
+    again = ostep.render_given(o0, d0, od, dd, ri, ts.reshape(-1), te.reshape(-1), p, spec, cfg, bk, feat=out["enc"], featd=out["encd"])
+    assert torch.equal(again["colors"], out["colors"]) and torch.equal(again["colords"], out["colords"])
+    near = ostep.near_cell_face(out["xu"], spec, 4.0)
+    assert near.shape == (ts.shape[0], 16) and 0.002 < float(near.any(1).float().mean()) < 0.05
