@@ -599,7 +599,10 @@ def main():
                        "device_counts": bool(tr.device_counts_ok() and tr.r._spr is not None),
                        "device_count_overflows": getattr(tr, "device_count_overflows", 0),
                        "step_graph": {"replays_in_timed_region": graph_replays - getattr(tr, "_replays_before", 0),
-                                      "captures": getattr(tr, "graph_captures", 0)} if whole_step else None,
+                                      "captures": getattr(tr, "graph_captures", 0),
+                                      # every capture is measured against the eager step before it is used (Trainer._capture)
+                                      "kept_ms_replay_vs_eager": [[round(v, 3) for v in g_["ms"]] for g_ in tr._graphs.values() if "ms" in g_],
+                                      "rejected_captures": sum(tr._graph_bad.values())} if whole_step else None,
                        "fwd_chunks": args.fwd_chunks, "bwd_chunks": args.bwd_chunks,
                        # what torch.distributed actually formed (a mis-launched N-rank run shows here)
                        "dist_world_size": dist.get_world_size() if dist.is_initialized() else 1,

@@ -324,6 +324,27 @@ class Renderer:
     def sample_begin(self, o, d, jitter: Optional[torch.Tensor], training: bool, device_counts=False) -> dict:
         """sample() up to (not including) the host read of the sample count: ray/AABB test, count pass, scan.  None of it
         depends on the field parameters, so Trainer.prefetch can run it for the NEXT step on a side stream."""
+        return self._scan_counts(self._march_count(o, d, jitter, training), device_counts)
+
+    def sample_begin_merged(self, rays, training: bool, device_counts=False):
+        """sample_begin() of several renders with ONE ray/box test and ONE march count pass over all their rays (the march is a
+        latency-bound chain of ~1 000 dependent occupancy reads per ray: 0.2 ms however few rays there are -- two renders' passes
+        one after the other cost twice that, one pass over both costs it once), then a scan (and guard) per render: each
+        render keeps its own packed sample stream.  rays: [(o, d, jitter), ...] -> one sample_begin() state per render, whose
+        arrays are row ranges of the merged ones.  The same counts, bit for bit: a ray's march does not depend on its
+        neighbours (tests/test_gpu_parity.py::test_ray_marching_bit_exact holds every speculative width to the sequential one)."""
+        jit = None if any(r[2] is None for r in rays) else torch.cat([r[2] for r in rays])
+        st = self._march_count(torch.cat([r[0] for r in rays]), torch.cat([r[1] for r in rays]), jit, training)
+        out, a = [], 0
+        for o, _, _ in rays:
+            b = a + o.shape[0]
+            args = tuple(v[a:b] if (k < 5 and v is not None) else v for k, v in enumerate(st["args"]))
+            out.append(self._scan_counts(dict(args=args, cache=None if st["cache"] is None else st["cache"][a:b],
+                                              counts=st["counts"][a:b], mode=st["mode"]), device_counts))
+            a = b
+        return out
+
+    def _march_count(self, o, d, jitter, training: bool) -> dict:
         c = self.cfg
         scene_aabb = c.aabb if c.contraction_type == ops.AABB else None           # nerf.py:248-251
         if scene_aabb is not None:
@@ -334,6 +355,8 @@ class Renderer:
             # floats as torch.full); no cache of them across calls (it was keyed by the ray count, which alternates
             # between the renders of a step, and shared across streams without an event)
             if c.near_plane is not None and c.far_plane is not None:
+                if c.near_plane < 0:
+                    raise ValueError("near_plane < 0")             # (the box test clamps t_min at 0: ADVICE r5)
                 t_min, t_max = ops.ray_aabb_intersect(o, d, (-1e30,) * 3 + (1e30,) * 3, c.near_plane, c.far_plane)
             else:
                 n = o.shape[0]
@@ -351,17 +374,21 @@ class Renderer:
         # march_cache intervals of every ray, the write pass copies them (re-marching only longer rays)
         cache = torch.empty(o.shape[0], c.march_cache, 2, device=o.device) if (mode == 0 and c.march_cache > 0) else None
         counts = ops.ray_march_count(*args, cache=cache)
+        return dict(args=args, cache=cache, counts=counts, mode=mode)
+
+    def _scan_counts(self, st: dict, device_counts) -> dict:
+        counts, mode, n_rays = st["counts"], st["mode"], st["counts"].shape[0]
         dcst = None
-        caps = self._capacities(o.shape[0]) if (device_counts is True and mode == 0 and self.device_counts_ok()) else None
+        caps = self._capacities(n_rays) if (device_counts is True and mode == 0 and self.device_counts_ok()) else None
         if caps is not None:
             # device-side counts: scan and first guard in one launch (sample() continues from here without a host read)
-            stats = torch.empty(4, device=o.device, dtype=torch.int64)
-            nd = torch.empty(2, device=o.device, dtype=torch.int64)
+            stats = torch.empty(4, device=counts.device, dtype=torch.int64)
+            nd = torch.empty(2, device=counts.device, dtype=torch.int64)
             offsets, total = ops.scan_guard(counts, caps[0], nd[0:1], stats[0:2])
             dcst = dict(caps=caps, stats=stats, nd=nd)
         else:
             offsets, total = ops.exclusive_scan(counts)
-        return dict(args=args, cache=cache, counts=counts, offsets=offsets, total=total, mode=mode, dc=dcst)
+        return dict(st, offsets=offsets, total=total, dc=dcst)
 
     # ---- device-side sample counts -----------------------------------------------------------------------------------
     CAP_MARGIN, CAP_SLACK, CAP_MAX = 1.25, 4096, 1 << 23      # (from 2^23 samples on the chunked two-stream paths take over)
@@ -864,6 +891,7 @@ class Trainer:
         self._side, self._prefetched, self._n_host = None, None, None   # Trainer.prefetch
         self._ready_ev = None                                    # start of the last forward_backward() on its stream (early sampling)
         self.early_grad_sampling = True                          # Trainer.step: third render's samples beside the l_diff backward
+        self.grad_sampling: Optional[str] = None                 # "merged": that placement also for eager steps (grad_sampling_mode)
         self._grad_begun, self._grad_pending, self._n_host_grad = None, None, None   # begin_grad_sampling
         if world_size > 1:
             from . import parallel
@@ -883,7 +911,8 @@ class Trainer:
         self.use_graph: Optional[bool] = None                    # Trainer.step: None = auto (a step shape seen twice in a row), False = never
         if os.environ.get("REN_STEP_GRAPH", "") in ("0", "off"):
             self.use_graph = False
-        self._graphs, self._graph_last_key, self._graph_pool, self._capturing = {}, None, None, False
+        self._graphs, self._graph_last_key, self._graph_pool, self._capturing, self._graph_streak = {}, None, None, False, 0
+        self._graph_bad, self._graph_eager_ev = {}, None         # per step shape: captures that replayed no faster than eager steps
         self.graph_replays = self.graph_captures = 0
         self.lr_scale = 1.0
         # trainable C_p / C_n ratio (softplus-parametrised scalar, its own Adam group with lr 0.1:
@@ -1130,17 +1159,17 @@ class Trainer:
             pos, rot, dpos, drot = jvp.trajectory_jvp(ts_all, self.tab_ts, self.tab_pos, self.tab_quat)
             o, d, od, dd = jvp.raygen_jvp(self.Kinv, px, pos, rot, dpos, drot)
             begun = None
-            if self._grad_pending is not None:                    # this render's count pass first, then the third render's front
-                begun = r.sample_begin(o, d, jitter, True, device_counts=dc)
-                self._begin_grad_now()
+            if self._grad_pending is not None:
+                begun = self._begin_with_grad(o, d, jitter, dc)
             colors, colords, opac, ctx = jvp.render_forward(r, o, d, od, dd, jitter, bkgd, training=True, begun=begun,
                                                             device_counts=dc)
         else:
             o, d = front["o"], front["d"]
             if self._grad_pending is not None:
                 if front.get("begun") is None:
-                    front["begun"] = r.sample_begin(o, d, jitter, True, device_counts=dc)
-                self._begin_grad_now()
+                    front["begun"] = self._begin_with_grad(o, d, jitter, dc)
+                else:
+                    self._begin_grad_now()
             colors, opac, depth, ctx = r.forward(o, d, jitter, bkgd, training=True, save=True, begun=front.get("begun"),
                                                  device_counts=dc)
         # a16 + a18: intensity epilogue, validity, Bayer channel, loss and its gradient: two launches (ren_event_diff_loss_*)
@@ -1192,11 +1221,16 @@ class Trainer:
         if not (self.t.w_grad > 0) or not self.early_grad_sampling or self.r.cfg.sampler == "uniform" or \
                 not self.r.field.flat.is_cuda:
             return "inorder"
+        # "merged" (round 6, opt-in: Trainer.grad_sampling): everything in order on ONE stream, but the third render's rays join
+        # the l_diff render's in one ray / box test and one march count pass (Renderer.sample_begin_merged)
+        if self.grad_sampling == "merged":
+            return "merged"
         return "begun"
 
-    def _grad_front(self, batch, jitter_grad) -> dict:
+    def _grad_front(self, batch, jitter_grad, rays_only: bool = False) -> dict:
         """the third render up to (not including) the first host read: supervision timestamps at grad.ts, poses and rays with
-        their time derivatives, ray/AABB test, march count pass, scan (robust_e_nerf.py:340-357,383-409)"""
+        their time derivatives, ray/AABB test, march count pass, scan (robust_e_nerf.py:340-357,383-409).  rays_only: without
+        the last three (the "merged" placement marches these rays together with the l_diff render's)"""
         from . import jvp
         t = self.t
         prep = ops.event_prepare(batch, 0.0, 0.0, 0.0, with_grad_ts=True, with_dtau=t.train_refractory_period, ep=self.ep)
@@ -1209,10 +1243,10 @@ class Trainer:
             pos, rot, dpos, drot = jvp.trajectory_jvp(ts_g, self.tab_ts, self.tab_pos, self.tab_quat)
             o, d, od, dd = jvp.raygen_jvp(self.Kinv, batch["position"].contiguous(), pos, rot, dpos, drot)
         jit = None if jitter_grad is None else jitter_grad.to(torch.float32).contiguous()
-        st = self.r.sample_begin(o, d, jit, True, device_counts=self._dc_mode())
+        st = None if rays_only else self.r.sample_begin(o, d, jit, True, device_counts=self._dc_mode())
         return dict(prep=prep, o=o, d=d, od=od, dd=dd, ddd=ddd, jit=jit, st=st)
 
-    def begin_grad_sampling(self, batch, jitter_grad=None) -> bool:
+    def begin_grad_sampling(self, batch, jitter_grad=None, merged: bool = False) -> bool:
         """Announce the third render of the step that is ABOUT to run -- call it before forward_backward(); the matching
         grad_loss_forward_backward(batch, jitter_grad, early=True) picks it up.  Its front (timestamps, poses, rays, march
         count pass, scan, read-back of the count into pinned memory) goes to the side stream without blocking the host,
@@ -1224,10 +1258,29 @@ class Trainer:
         end of the step -- is host-bound right there).  Trainer.step does this when the l_grad term is on."""
         if not self.r.field.flat.is_cuda or not (self.t.w_grad > 0):
             return False
-        ready = torch.cuda.Event()
-        ready.record()
+        ready = None
+        if not merged:
+            ready = torch.cuda.Event()
+            ready.record()
         self._grad_begun, self._grad_pending = None, (batch, jitter_grad, ready)
         return True
+
+    def _begin_with_grad(self, o, d, jitter, dc):
+        """the l_diff render's sample_begin(), with the announced third render's front placed as its mode asks: "begun" -- this
+        render's count pass first, then the third render's front on the side stream; "merged" -- both renders' rays through
+        one ray / box test and one march count pass, in order on this stream"""
+        if self._grad_pending[2] is not None:                     # (an event: "begun")
+            begun = self.r.sample_begin(o, d, jitter, True, device_counts=dc)
+            self._begin_grad_now()
+            return begun
+        (batch, jitter_grad, _), self._grad_pending = self._grad_pending, None
+        fr = self._grad_front(batch, jitter_grad, rays_only=True)
+        if (jitter is None) != (fr["jit"] is None):
+            raise ValueError("merged sampling: jitter for both the l_diff renders and the third one, or for neither")
+        begun, fr["st"] = self.r.sample_begin_merged([(o, d, jitter), (fr["o"], fr["d"], fr["jit"])], True, device_counts=dc)
+        fr["n_host"], fr["key"], fr["merged"] = None, (id(batch), id(jitter_grad)), True
+        self._grad_begun = fr
+        return begun
 
     def _begin_grad_now(self):
         pend, self._grad_pending = self._grad_pending, None
@@ -1268,6 +1321,8 @@ class Trainer:
         begun, self._grad_begun, self._grad_pending = self._grad_begun, None, None
         if begun is not None and (not early or begun["key"] != (id(batch), id(jitter_grad))):
             begun = None                                                  # (begin_grad_sampling was for another call)
+        if begun is not None and begun.get("merged"):
+            early = False                                                 # merged front: the rest follows in order on this stream
         # no matching front: in order, unless the caller asks for the experimental placement (early="all": everything
         # beside the l_diff forward / backward; wrong rays observed there, see grad_sampling_mode)
         early = bool(early) and f.flat.is_cuda and (begun is not None or (early == "all" and ready is not None))
@@ -1463,8 +1518,8 @@ class Trainer:
         # over the ranks again with micro-batch 2 on top) and the next scatter would write into a slice in flight
         last = (bi + 1) % k == 0
         mode = self.grad_sampling_mode()
-        if mode == "begun":
-            self.begin_grad_sampling(batch, jitter_grad)
+        if mode in ("begun", "merged"):
+            self.begin_grad_sampling(batch, jitter_grad, merged=mode == "merged")
         loss, aux = self.forward_backward(batch, jitter_start, jitter_end, final=last and not (self.t.w_grad > 0))
         if self.t.w_grad > 0:
             lg, aux_g = self.grad_loss_forward_backward(batch, jitter_grad, final=last, early=mode != "inorder")
@@ -1512,10 +1567,26 @@ class Trainer:
             self._graph_last_key = None
             return None
         sg = self._graphs.get(key)
+        if sg is not None and sg["ws_ptr"] != (self.r._bin_ws.data_ptr() if self.r._bin_ws is not None else 0):
+            # the staging pool of the binned scatter was reallocated since this graph was captured (an eager step in between
+            # needed more, or handed it back): its launches carry the old address
+            self._graphs.pop(key)
+            sg = None
         if sg is None:
-            if self.use_graph is None and key != self._graph_last_key:
-                self._graph_last_key = key               # auto: a shape has to repeat before it is worth a capture
-                return None
+            if self.use_graph is None:                   # auto: a shape has to keep repeating before it is worth a capture
+                if self._graph_bad.get(key[1:], 0) >= 3:
+                    return None                          # (captured three times, never replayed faster than the eager step: stays eager)
+                # (the SHAPE has to repeat -- event count, flags, lr factor; the capacities in the key follow the counts)
+                self._graph_streak = self._graph_streak + 1 if (self._graph_last_key or (None,))[1:] == key[1:] else 0
+                self._graph_last_key = key               # (the reference's dynamic batch size changes the event count nearly
+                if self._graph_streak < 2:               # every step: such a run never captures -- scripts/train.py --batch-size-quantum)
+                    # the eager steps in front of a capture are timed: a graph has to beat them to be kept (_capture)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    out = self._step_passes(batch, jitter_start, jitter_end, jitter_grad)
+                    e1.record()
+                    self._graph_eager_ev = (key[1:], e0, e1)
+                    return out
             sg = self._capture(key, batch, jitter_start if jitter_end is None else torch.cat([jitter_start, jitter_end]),
                                jitter_grad)
             if sg is None:
@@ -1585,12 +1656,19 @@ class Trainer:
         j2 = jitter_grad.to(torch.float32).clone() if jitter_grad is not None else None
         caps = key[0]
         if r.cfg.binned_scatter:
-            r._binned_workspace(max(max(c) for c in caps), dev)      # sized before the capture: nothing (re)allocates inside
+            # sized before the capture (nothing (re)allocates inside) and with room to spare: a larger step shape later on
+            # then finds it big enough, and the graphs captured so far stay valid (they carry its address)
+            need = max(max(c) for c in caps)
+            if r._bin_ws is None or r._bin_ws.numel() < ops.hashgrid_bwd_binned_workspace_bytes(need):
+                r._binned_workspace(2 * need, dev)
         _ = self.side_stream
         pinned = [torch.empty(4, dtype=torch.int64).pin_memory() for _ in range(len(caps))]
-        if self._graph_pool is None:
+        if self._graph_pool is None or os.environ.get("REN_STEP_GRAPH_POOL") == "own":
             self._graph_pool = torch.cuda.graph_pool_handle()
         g = torch.cuda.CUDAGraph()
+        dump = os.environ.get("REN_STEP_GRAPH_DUMP")             # debugging: <prefix><capture number>.dot of every captured step
+        if dump:
+            g.enable_debug_mode()
         host_state = (self.step_count, self._tau_adam_steps, self._ep_stale)
         r._polled_logs, r._polled_pinned, self._cap_passes, self._capturing = [], pinned, [], True
         self._grad_begun, self._grad_pending = None, None
@@ -1611,6 +1689,44 @@ class Trainer:
         if not ok:
             return None
         self.graph_captures += 1
-        sg = dict(graph=g, batch=st_batch, j0=j0, j2=j2, loss=loss, aux=aux, passes=passes)
+        if dump:
+            g.debug_dump(f"{dump}{self.graph_captures}.dot")
+        sg = dict(graph=g, batch=st_batch, j0=j0, j2=j2, loss=loss, aux=aux, passes=passes,
+                  ws_ptr=r._bin_ws.data_ptr() if r._bin_ws is not None else 0)
+        # Does the replay beat the eager step?  A captured step with a forked branch (the third render's sampling) replays
+        # through a second hardware queue, and on this runtime WHICH queue the graph's internal stream lands on decides
+        # whether the replay is faster than the eager launches or 25 % slower (tools/recapture_probe.py: every other capture
+        # of the same step; a single-stream graph is slower still at a few million samples).  So a capture is measured before
+        # it is used: three replays with the optimiser's skip word raised (parameters and moments untouched, the gradient
+        # buffers cleared afterwards) against the eager steps that ran just before it.
+        ev = self._graph_eager_ev
+        if self.use_graph is None and ev is not None and ev[0] == key[1:]:
+            t_eager = ev[1].elapsed_time(ev[2])
+            t_graph = self._time_skip_replays(sg)
+            sg["ms"] = (t_graph, t_eager)
+            if t_graph > 0.97 * t_eager:
+                self._graph_bad[key[1:]] = self._graph_bad.get(key[1:], 0) + 1
+                self._graph_streak = 1                       # (the next step tries again: up to three attempts per shape)
+                return None
         self._graphs[key] = sg
         return sg
+
+    def _time_skip_replays(self, sg, reps: int = 3) -> float:
+        """ms per replay of a captured step that changes nothing: skip word raised, gradients cleared afterwards"""
+        f = self.r.field
+        self._hyper[ops.HY_SKIP: ops.HY_SKIP + 1].fill_(1.0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        sg["graph"].replay()                                 # (first replay of a fresh executable: not timed)
+        e0.record()
+        for _ in range(reps):
+            sg["graph"].replay()
+        e1.record()
+        f.grad_all.zero_()
+        if getattr(f, "n_wn_g", 0):
+            f.g_mlp.zero_()
+        self._gs.zero_()
+        self._sync_hyper()
+        if self.t.train_refractory_period or self.t.train_contrast_threshold:
+            self._refresh_event_params()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps

@@ -153,6 +153,10 @@ def main():
     ap.add_argument("--mlp-bf16", action="store_true",
                     help="bf16 MLP operands, fp32 accumulate / composite (same as float32_matmul_precision: medium)")
     ap.add_argument("--accumulate-grad-batches", type=int, help="overrides trainer.accumulate_grad_batches")
+    ap.add_argument("--batch-size-quantum", type=int, default=1,
+                    help="round the dynamic batch size (robust_e_nerf.py:907-950) DOWN to a multiple of this many events: step "
+                         "shapes then repeat and engine.Trainer replays a captured hipGraph instead of enqueuing ~80 launches "
+                         "(1 = the reference's exact int(budget / mean samples per ray), the default)")
     ap.add_argument("--no-validation", action="store_true", help="skip the validation epochs over views/transforms_val.json")
     ap.add_argument("--limit-val-batches", type=int, help="validate on the first N views only")
     args = ap.parse_args()
@@ -340,7 +344,10 @@ def main():
             nb = tr.update_train_batch_size(aux, budget, accum, bi)              # robust_e_nerf.py:907-950
             if nb is not None:
                 pending.append(nb)
-            batcher.set_batch_size(pending.popleft() if len(pending) > 1 else pending[0])
+            nxt = pending.popleft() if len(pending) > 1 else pending[0]
+            if args.batch_size_quantum > 1:
+                nxt = max(args.batch_size_quantum, nxt // args.batch_size_quantum * args.batch_size_quantum)
+            batcher.set_batch_size(nxt)
             step += (bi + 1) % accum == 0                                        # global_step counts optimiser steps
             if rank == 0 and (bi + 1) % accum == 0 and step % log_every == 0:
                 torch.cuda.synchronize()
@@ -348,7 +355,8 @@ def main():
                 print(f"epoch {epoch} step {step}  loss {float(loss):.5f}  batch {B}  samples/ray {aux['n'] / max(aux['rays'], 1):.1f}"
                       f"  {rays * world / dt / 1e6:.2f} M rays/s  mem {torch.cuda.memory_allocated() / 2**30:.1f}/"
                       f"{torch.cuda.memory_reserved() / 2**30:.1f} GiB" +
-                      (f"  device counts ({tr.device_count_overflows} repeated passes)" if tr.device_counts_ok() else ""), flush=True)
+                      (f"  device counts ({tr.device_count_overflows} repeated passes)" if tr.device_counts_ok() else "") +
+                      (f"  graph replays {tr.graph_replays} / captures {tr.graph_captures}" if tr.graph_replays else ""), flush=True)
                 t0, rays = time.perf_counter(), 0
         # ---- validation epoch (trainer.check_val_every_n_epoch, synthetic.yaml:152-154; robust_e_nerf.py:519-571):
         # the dataset's posed validation views, rendered by all ranks, aligned and scored as the reference does

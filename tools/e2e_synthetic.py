@@ -173,6 +173,7 @@ def main():
     ap.add_argument("--steps-per-epoch", type=int, default=500)
     ap.add_argument("--arch", default="ngp", choices=["ngp", "mlp"])
     ap.add_argument("--budget", type=int, default=1 << 20, help="train_eff_ray_sample_batch_size")
+    ap.add_argument("--batch-size-quantum", type=int, default=1, help="scripts/train.py --batch-size-quantum")
     ap.add_argument("--precision", default="highest", choices=["highest", "high", "medium"], help="float32_matmul_precision of the YAML")
     args = ap.parse_args()
     data_dir = os.path.join(args.out, "dataset")
@@ -197,10 +198,11 @@ def main():
     scores0 = evaluate(os.path.join(args.out, "init", "last.ckpt"), Kinv_d, cfg)
     t0 = time.perf_counter()
     log = subprocess.run([sys.executable, os.path.join(REPO, "scripts", "train.py"), "--config", cfg_path, "--out",
-                          os.path.join(args.out, "run")], capture_output=True, text=True)
+                          os.path.join(args.out, "run"), "--batch-size-quantum", str(args.batch_size_quantum)], capture_output=True, text=True)
     t_train = time.perf_counter() - t0
     print(log.stdout[-3000:], log.stderr[-2000:] if log.returncode else "", flush=True)
     if log.returncode:
+        open(os.path.join(args.out, "train_stderr.txt"), "w").write(log.stderr)
         raise SystemExit("training failed")
     scores = evaluate(os.path.join(args.out, "run", "last.ckpt"), Kinv_d, cfg, png=os.path.join(args.out, "e2e_novel_views.png"))
     # the same views through the reference's dataset layout: views/transforms_val.json (16-bit PNGs) -> scripts/render.py --stage val
@@ -211,7 +213,7 @@ def main():
     val_epochs = [l for l in log.stdout.splitlines() if "val/psnr" in l]
     res = {"what": "tools/e2e_synthetic.py: simulated events of an analytic scene -> scripts/train.py -> novel-view PSNR "
                    "after affine log alignment (left/right halves of e2e_novel_views.png: analytic scene / prediction)",
-           "mean_psnr_db_after_1_step": float(np.mean(scores0)), "events": n_events, "simulate_s": t_sim, "train_s": t_train, "epochs": args.epochs,
+           "batch_size_quantum": args.batch_size_quantum, "mean_psnr_db_after_1_step": float(np.mean(scores0)), "events": n_events, "simulate_s": t_sim, "train_s": t_train, "epochs": args.epochs,
            "steps": args.epochs * args.steps_per_epoch, "novel_view_psnr_db": scores, "mean_psnr_db": float(np.mean(scores)),
            "posed_image_validation (scripts/render.py --stage val)": val_line[0] if val_line else rv.stderr[-500:],
            "validation_epochs (scripts/train.py)": val_epochs,

@@ -6,7 +6,7 @@ for l in sys.stdin:
     l=l.strip()
     if l.startswith('{'):
         d=json.loads(l); c=d['config']
-        print('%-62s %7.3f ms  %6.1f M samples/s  %5.2f M rays/s  graph %s  dc %s ovf %s' % (sys.argv[1], d['ms_per_step'], d['mlp_samples_per_sec']/1e6, d['value']/1e6, c.get('step_graph'), c['device_counts'], c['device_count_overflows']))
+        print('%-62s %7.3f ms  %6.1f M samples/s  %5.2f M rays/s  graph %s  dc %s ovf %s' % (sys.argv[1], d['ms_per_step'], d['mlp_samples_per_sec']/1e6, d['value']/1e6, {k: v for k, v in (c.get('step_graph') or {}).items() if k != 'captures'}, c['device_counts'], c['device_count_overflows']))
 " "$1"; }
 for G in auto off; do
 python bench.py --no-cpu-baseline --workload e --events 8192 --graph $G 2>/dev/null | show "config E 8192 events, graph $G"
