@@ -282,6 +282,8 @@ class Renderer:
     def __init__(self, fld: NGPField, cfg: RenderCfg):
         self.field = fld
         self.cfg = cfg = dataclasses.replace(cfg)   # a private copy: the overrides below must not leak into the caller's object
+        if os.environ.get("REN_MARCH_CACHE"):       # A/B switch for scripts that build the renderer themselves
+            cfg.march_cache = int(os.environ["REN_MARCH_CACHE"])
         self.scene = ops.make_scene_desc(cfg.aabb, cfg.contraction_type)
         dev = fld.flat.device
         cells = cfg.occ_res[0] * cfg.occ_res[1] * cfg.occ_res[2]
@@ -305,6 +307,7 @@ class Renderer:
         self._count_ring, self._count_ring_at = None, 0
         self._polled_logs = None                    # a list while a step is being captured (Trainer.step_graphed): its renders' CountLogs
         self.dp_early_enabled = True                # the Trainer clears it when a loss pass may have to be repeated (device-side counts)
+        self.bwd_side_cus = 0                       # CUs the persistent MLP backward kernels leave free (Trainer: a side stream is at work)
         self._act_code = ops.activation_code(cfg.base_hidden_activation, cfg.density_activation, cfg.head_hidden_activation,
                                              cfg.radiance_activation)
         if cfg.mlp_precision not in ("highest", "high", "medium"):
@@ -670,9 +673,13 @@ class Renderer:
         samples = (pk.ray_indices, pk.t_starts, pk.t_ends)
         mp = ctx.get("mlp_params")                      # absent when the forward ran on the (fp32) tangent kernels
         if ctx.get("xmode") is not None:
+            # (bwd_side_cus: the head kernel holds the whole register file of every CU it runs on, and a kernel of the side
+            # stream -- the third render's one-workgroup scan -- then waits for it to END: 0.55 ms in the e2e trace of round 5)
+            cus = torch.cuda.get_device_properties(d_rgb.device).multi_processor_count - self.bwd_side_cus if self.bwd_side_cus else 0
             dfeat = ops.mlp_bwd_x(f.mlp, f.C, ctx["xmode"], ctx["feat"], ctx["base"], ctx["acts"], self.scene,
                                   rays=(ctx["o"], ctx["d"]), samples=samples, n=pk.n, rgb=ctx["rgb"], d_rgb=d_rgb,
-                                  d_sigma=d_sig, grad_mlp_params=f.g_mlp, workspace=self._ws, act=self._act_code, n_dev=pk.n_dev)
+                                  d_sigma=d_sig, grad_mlp_params=f.g_mlp, workspace=self._ws, act=self._act_code, n_dev=pk.n_dev,
+                                  grid_cus=max(cus, 0))
         elif ctx.get("acts") is not None:
             dfeat = ops.mlp_bwd_saved(mp, f.C, ctx["feat"], ctx["base"], ctx["acts"], self.scene, rays=(ctx["o"], ctx["d"]),
                                       samples=samples, n=pk.n, rgb=ctx["rgb"], d_rgb=d_rgb, d_sigma=d_sig,
@@ -892,6 +899,7 @@ class Trainer:
         self._ready_ev = None                                    # start of the last forward_backward() on its stream (early sampling)
         self.early_grad_sampling = True                          # Trainer.step: third render's samples beside the l_diff backward
         self.grad_sampling: Optional[str] = None                 # "merged": that placement also for eager steps (grad_sampling_mode)
+        self.side_cus = int(os.environ.get("REN_SIDE_CUS", 4))   # CUs the l_diff pass's MLP backward leaves to the side stream ("begun")
         self._grad_begun, self._grad_pending, self._n_host_grad = None, None, None   # begin_grad_sampling
         if world_size > 1:
             from . import parallel
@@ -1520,7 +1528,12 @@ class Trainer:
         mode = self.grad_sampling_mode()
         if mode in ("begun", "merged"):
             self.begin_grad_sampling(batch, jitter_grad, merged=mode == "merged")
-        loss, aux = self.forward_backward(batch, jitter_start, jitter_end, final=last and not (self.t.w_grad > 0))
+        # the third render's sampling runs on the side stream beside this pass's backward: leave it a few CUs
+        self.r.bwd_side_cus = self.side_cus if mode == "begun" else 0
+        try:
+            loss, aux = self.forward_backward(batch, jitter_start, jitter_end, final=last and not (self.t.w_grad > 0))
+        finally:
+            self.r.bwd_side_cus = 0
         if self.t.w_grad > 0:
             lg, aux_g = self.grad_loss_forward_backward(batch, jitter_grad, final=last, early=mode != "inorder")
             loss = loss + lg

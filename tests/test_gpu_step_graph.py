@@ -10,6 +10,10 @@ import torch
 
 from test_gpu_parity import DEV, _config_batch, _trainer_from_golden, amd, dev, load_golden      # noqa: F401  (amd: fixture)
 from test_gpu_device_counts import _same
+# (ptol = 1e-3 below: after a few Adam steps a parameter whose gradient is ~0 has moved by lr x g / (|g| + eps) = +-0.01 per step
+# whatever |g| is, so another summation order of the MLP weight gradients -- a replayed step, or `side_cus` CUs left free: another
+# slab partition -- shows as 1e-5 .. 3e-4 of the largest parameter; a pass whose gradient were wrong would show as >= 1e-2.  Sample
+# counts are compared exactly and every step's loss to 2e-5.)
 
 pytestmark = pytest.mark.gpu
 
@@ -50,17 +54,27 @@ def test_replayed_steps_repeat_the_eager_steps(amd, full_table_cache, w_grad, tr
     assert tr1.device_count_overflows == 0 and tr1.step_count == tr0.step_count == steps
     hy = tr1._hyper.tolist()
     assert hy[ops.HY_STEP] == steps and hy[ops.HY_SKIP] == 0.0
-    _same(got, ref, tol=2e-4 if trainable else 2e-5)
+    _same(got, ref, tol=2e-4 if trainable else 2e-5, ptol=1e-3)
 
 
 def test_auto_mode_captures_a_shape_that_repeats(amd, full_table_cache):
+    """use_graph = None (the default): a step shape that occurs three times in a row is captured, the capture is measured against
+    the eager steps timed just before it (three replays with the skip word raised: parameters untouched, gradients cleared) and
+    kept only if it is faster (profiles/NOTES.md: which hardware queue a forked graph's internal stream lands on decides that)
+    -- kept or rejected, the steps are the eager steps"""
     ops, engine = amd
     g = load_golden("training_step_grad")
     table = full_table_cache(g["table_seed"], g["table_scale"])
-    got, tr = _run(engine, g, table, None, steps=6, w_grad=1e-3)
-    assert tr.graph_captures >= 1 and tr.graph_replays >= 2
-    ref, _ = _run(engine, g, table, False, steps=6, w_grad=1e-3)
-    _same(got, ref)
+    got, tr = _run(engine, g, table, None, steps=8, w_grad=1e-3)
+    assert tr.graph_captures >= 1 and tr.step_count == 8
+    kept = [sg for sg in tr._graphs.values() if "ms" in sg]
+    assert (len(kept) >= 1 and tr.graph_replays >= 1) or sum(tr._graph_bad.values()) >= 1
+    for sg in kept:
+        assert sg["ms"][0] <= 0.97 * sg["ms"][1]
+    hy = tr._hyper.tolist()
+    assert hy[ops.HY_STEP] == 8 and hy[ops.HY_SKIP] == 0.0
+    ref, _ = _run(engine, g, table, False, steps=8, w_grad=1e-3)
+    _same(got, ref, ptol=1e-3)
 
 
 def test_overflow_inside_a_replayed_step_is_repeated_exactly(amd, full_table_cache):
@@ -74,7 +88,7 @@ def test_overflow_inside_a_replayed_step_is_repeated_exactly(amd, full_table_cac
     assert tr.device_count_overflows == 1 and tr.step_count == 6
     hy = tr._hyper.tolist()
     assert hy[ops.HY_STEP] == 6 and hy[ops.HY_SKIP] == 0.0
-    _same(got, ref)
+    _same(got, ref, ptol=1e-3)
 
 
 def test_device_side_optimiser_state_matches_the_host_side_calls(amd):
@@ -145,4 +159,4 @@ def test_merged_march_of_the_three_renders_repeats_the_separate_passes(amd, full
         return out
     ref = run(False, False)
     for dc in (False, None):             # (parameters after five Adam steps at 1 536 events: the scatter's float-atomic noise reaches 5e-6
-        _same(run(True, dc), ref, tol=2e-4 if trainable else 5e-5)     # of the largest MLP parameter in one run out of six: _same)
+        _same(run(True, dc), ref, tol=2e-4 if trainable else 2e-5, ptol=1e-3)     # of the largest MLP parameter in one run out of six: _same)

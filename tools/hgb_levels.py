@@ -3,7 +3,7 @@ import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from robust_e_nerf_amd import ops, engine
 dev = "cuda:0"
-R, S = 65536, 128
+R, S = int(os.environ.get("RAYS", 131072)), 128
 grid, n_table = ops.make_grid_desc()
 g = torch.Generator().manual_seed(0)
 ang = torch.rand(R, generator=g) * 2 * math.pi
@@ -30,3 +30,7 @@ for l in range(16):
     print(f"level {l:2d} alone: {t:.3f} ms")
 print("levels 0-4:", timeit(lambda: ops.hashgrid_bwd_binned(grid, gt, dfeat, ws, level_mask=0x1F, **kw)))
 print("levels 5-15:", timeit(lambda: ops.hashgrid_bwd_binned(grid, gt, dfeat, ws, level_mask=0xFFE0, **kw)))
+print("all levels:", timeit(lambda: ops.hashgrid_bwd_binned(grid, gt, dfeat, ws, **kw)))
+print("all but 0:", timeit(lambda: ops.hashgrid_bwd_binned(grid, gt, dfeat, ws, level_mask=0xFFFE, **kw)))
+print("all but 0, 1:", timeit(lambda: ops.hashgrid_bwd_binned(grid, gt, dfeat, ws, level_mask=0xFFFC, **kw)))
+print("all but 0, 1, 2:", timeit(lambda: ops.hashgrid_bwd_binned(grid, gt, dfeat, ws, level_mask=0xFFF8, **kw)))
