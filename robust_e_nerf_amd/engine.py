@@ -1070,7 +1070,10 @@ class Trainer:
     @property
     def side_stream(self) -> "torch.cuda.Stream":
         if self._side is None:
-            self._side = torch.cuda.Stream(priority=-1)          # its few small kernels go ahead of the queued backward
+            # normal priority (round 6; until then -1 = high): with a HIGH-priority stream in the process every other captured
+            # step replayed 25 % slower (small kernels of alternate captures took 45-55 us each: tools/recapture_probe.py,
+            # profiles/NOTES.md), and the eager lines and the e2e run are the same at either priority
+            self._side = torch.cuda.Stream(priority=int(os.environ.get("REN_SIDE_PRIORITY", 0)))
         return self._side
 
     def prefetch(self, batch, jitter_start=None, jitter_end=None, next_global_step: Optional[int] = None) -> bool:

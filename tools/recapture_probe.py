@@ -38,6 +38,11 @@ def run(steps, tag):
           f"overflows {tr.device_count_overflows} mem {torch.cuda.memory_allocated() / 2**30:.1f}/{torch.cuda.memory_reserved() / 2**30:.1f} GiB", flush=True)
 
 
+if os.environ.get("STREAM"):                       # all of it on a non-default stream (another hardware queue for the launches)
+    _s = torch.cuda.Stream(priority=-1 if os.environ["STREAM"] == "high" else 0)
+    torch.cuda.set_stream(_s)
+if os.environ.get("SIDE_PRIO"):                    # the trainer's side stream at normal priority
+    tr._side = torch.cuda.Stream()
 run(6, "warm-up (host counts, capture)")
 if os.environ.get("PHASE") == "A":
     run(100, "graph 1")
