@@ -1,7 +1,7 @@
 # arch mlp lines of profiles/ (the fused field, csrc/ren_vfield.hip): bench lines, per-kernel stats, MFMA / HBM counters.
 #   gpurun --timeout 900 -- 'bash tools/regen_arch_mlp.sh r05'
 set -x
-RND=${1:-r05}
+RND=${1:-r06}
 R=$PWD
 O=$R/gpurun_out/$RND
 mkdir -p $O

@@ -2,7 +2,7 @@
 # mode 3, and the end-to-end run at both precisions three times each (run-to-run spread of the PSNR).
 #   gpurun --timeout 1500 -- 'bash tools/regen_precision_high.sh r05'
 set -x
-RND=${1:-r05}
+RND=${1:-r06}
 R=$PWD
 O=$R/gpurun_out/$RND
 mkdir -p $O

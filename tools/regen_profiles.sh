@@ -1,8 +1,8 @@
 # Regenerates everything under profiles/ on a GPU box (run from the repo root through gpurun); results land in
 # gpurun_out/$RND/ and profiles/ (the bench reads profiles/${RND}_pmc_traffic.json for roofline.traffic).
-#   gpurun --timeout 1700 -- 'bash tools/regen_profiles.sh r05'
+#   gpurun --timeout 1700 -- 'bash tools/regen_profiles.sh r06'
 set -x
-RND=${1:-r05}
+RND=${1:-r06}
 R=$PWD
 O=$R/gpurun_out/$RND
 mkdir -p $O
@@ -29,6 +29,13 @@ python bench.py --no-cpu-baseline --save-activations 1 > profiles/${RND}_bench_s
 python bench.py --no-cpu-baseline --workload e --events 8192 > profiles/${RND}_bench_config_e.json 2>>$O/bench.err
 python bench.py --no-cpu-baseline --events 32768 --hard --loss-grad 1e-3 --mlp-bf16 > profiles/${RND}_bench_hard_bf16.json 2>>$O/bench.err
 python bench.py --no-cpu-baseline --workload e --events 8192 --device-counts off > profiles/${RND}_bench_config_e_host_counts.json 2>>$O/bench.err
+# every launch from Python (device-side counts, no captured step): what the replayed lines are held against
+python bench.py --no-cpu-baseline --workload e --events 8192 --graph off > profiles/${RND}_bench_config_e_eager.json 2>>$O/bench.err
+python bench.py --no-cpu-baseline --sampler occgrid --events 16384 --graph off > profiles/${RND}_bench_occgrid_16k_eager.json 2>>$O/bench.err
+python bench.py --no-cpu-baseline --sampler occgrid --events 16384 --loss-grad 1e-3 --graph off > profiles/${RND}_bench_occgrid_lossgrad_16k_eager.json 2>>$O/bench.err
+# one rank's share of an 8-rank run at the reference's global budget (robust_e_nerf.py:63-66): 2 048 events, ~60 k samples per step
+python bench.py --no-cpu-baseline --sampler occgrid --events 2048 --loss-grad 1e-3 > profiles/${RND}_bench_proxy_8rank_2k.json 2>>$O/bench.err
+python bench.py --no-cpu-baseline --sampler occgrid --events 2048 --loss-grad 1e-3 --graph off > profiles/${RND}_bench_proxy_8rank_2k_eager.json 2>>$O/bench.err
 python bench.py --no-cpu-baseline --sampler occgrid --events 16384 > profiles/${RND}_bench_occgrid_16k.json 2>>$O/bench.err
 python bench.py --no-cpu-baseline --sampler occgrid --events 16384 --device-counts off > profiles/${RND}_bench_occgrid_16k_host_counts.json 2>>$O/bench.err
 python bench.py --no-cpu-baseline --sampler occgrid --events 16384 --loss-grad 1e-3 > profiles/${RND}_bench_occgrid_lossgrad_16k.json 2>>$O/bench.err
