@@ -128,3 +128,41 @@ def test_one_launch_scan_and_guard(amd):
             assert torch.equal(offs.cpu(), ref) and int(total) == int(c.sum()) and stats.tolist() == [int(c.sum()), int(over)], (n, cap)
             assert int(n_out) == (0 if over else int(c.sum()))
             assert int(cd.abs().sum()) == (0 if over else int(c.sum())) and int(also.sum()) == (0 if over else n)
+
+
+def test_an_overflowed_pass_leaves_the_table_and_mlp_gradients_alone(amd, full_table_cache):
+    """the exact repeat of an overflowed pass rests on every kernel of the pass honouring the cleared counts (n_dev = 0):
+    run the loss passes ONCE with capacities four times too small and without the repeat (Trainer._forward_backward /
+    _grad_loss_forward_backward directly, counts on the device) -- with and without the marcher's interval cache -- and look at the
+    gradient buffers: the table and MLP gradients must still be exactly zero (only the 64-byte block of scalar-parameter gradients,
+    which _dc_pass restores from its snapshot, may have moved), and no per-sample array was written past its capacity (the step
+    after it, with the capacities back, equals the host-count run)."""
+    ops, engine = amd
+    g = load_golden("training_step_grad")
+    table = full_table_cache(g["table_seed"], g["table_scale"])
+    for march_cache in (512, 0):
+        tr, _ = _trainer_from_golden(engine, g, table)
+        tr.r.cfg.march_cache = march_cache
+        tr.t.w_grad, tr.t.err_grad, tr.t.pw_grad = 1e-3, "mape", None
+        tr.use_graph = False
+        gen = torch.Generator().manual_seed(5)
+        nb = _config_batch(2048, 30, int(g["tab_ts"][-1]))
+        nb["u_grad"] = torch.rand(2048, generator=gen, dtype=torch.float64).numpy()
+        batch = {k: dev(v) for k, v in nb.items()}
+        j = [dev(torch.rand(2048, generator=gen)) for _ in range(3)]
+        tr.step(batch, j[0], j[1], jitter_grad=j[2])                      # host counts: the capacities learn
+        assert tr.r._spr is not None
+        good = tr.r._spr
+        tr.r._spr = tuple(0.25 * s for s in good)
+        f = tr.r.field
+        assert float(f.grad_all.abs().max()) == 0.0                      # (Adam cleared them)
+        _, _, log = tr._forward_backward(batch, j[0], j[1], False, True)
+        _, _, log_g = tr._grad_loss_forward_backward(batch, j[2], True, False, True)
+        assert log.overflowed and log_g.overflowed
+        torch.cuda.synchronize()
+        assert float(f.g_table.abs().max()) == 0.0 and float(f.g_mlp.abs().max()) == 0.0, march_cache
+        tr._gs.zero_()
+        tr.r._spr = good
+    ref, _ = _run(engine, g, table, False, steps=2, w_grad=1e-3)
+    got, _ = _run(engine, g, table, None, steps=2, w_grad=1e-3)
+    _same(got, ref)
