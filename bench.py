@@ -372,7 +372,7 @@ def main():
         tr.device_counts = False
     # the whole step through Trainer.step (what scripts/train.py calls): it replays a captured step when it can
     whole_step = (args.graph == "auto" and args.sampler == "occgrid" and not args.prefetch and
-                  args.grad_sampling in ("auto", "inorder") and dp_world == 1 and tr.device_counts_ok())
+                  args.grad_sampling in ("auto", "inorder") and tr.device_counts_ok())
     if whole_step and args.grad_sampling == "inorder":
         tr.early_grad_sampling = False
     if not whole_step:

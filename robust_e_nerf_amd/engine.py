@@ -1521,9 +1521,10 @@ class Trainer:
                 return out
         return self._step_passes(batch, jitter_start, jitter_end, jitter_grad, bi, k)
 
-    def _step_passes(self, batch, jitter_start, jitter_end, jitter_grad, bi: int = 0, k: int = 1):
+    def _step_passes(self, batch, jitter_start, jitter_end, jitter_grad, bi: int = 0, k: int = 1, optimizer: bool = True):
         """the loss passes of one batch and (on the last micro-batch) the optimiser step: the part of step() after the
-        occupancy-grid refresh -- what a captured step consists of"""
+        occupancy-grid refresh -- what a captured step consists of (optimizer=False: the passes only -- under data
+        parallelism the captured part ends where the gradient exchange begins)"""
         # only the LAST backward pass of the LAST micro-batch may start the early all-reduce of the fine levels' slice:
         # an earlier pass would reduce it once per micro-batch (the rank-summed slice of micro-batch 1 would be summed
         # over the ranks again with micro-batch 2 on top) and the next scatter would write into a slice in flight
@@ -1541,14 +1542,17 @@ class Trainer:
             lg, aux_g = self.grad_loss_forward_backward(batch, jitter_grad, final=last, early=mode != "inorder")
             loss = loss + lg
             aux = dict(aux, grad=aux_g)
-        if (bi + 1) % k == 0:
-            mean = None
-            if self.world_size > 1:                          # (rides in the gradient all-reduce)
-                means = self._render_means(aux)
-                mean = sum(means) / len(means)
-            self.optimizer_step(k, mean_samples_per_ray=mean)
-            aux["_mean_s_synced"] = self.world_size > 1
+        if (bi + 1) % k == 0 and optimizer:
+            self._optimizer_after_passes(aux, k)
         return loss, aux
+
+    def _optimizer_after_passes(self, aux, k: int = 1):
+        mean = None
+        if self.world_size > 1:                              # (rides in the gradient all-reduce)
+            means = self._render_means(aux)
+            mean = sum(means) / len(means)
+        self.optimizer_step(k, mean_samples_per_ray=mean)
+        aux["_mean_s_synced"] = self.world_size > 1
 
     # ---- the whole step as one hipGraph launch (the reference's step shape: models/robust_e_nerf.py:301-517) ----
     GRAPH_CACHE = 8
@@ -1559,7 +1563,7 @@ class Trainer:
         those of a cached graph of the same shape that still fits the learnt counts with a margin (capturing costs ~10 steps:
         a graph is kept while the counts drift by a few per cent), otherwise what Renderer._capacities gives now."""
         r, t = self.r, self.t
-        if self.use_graph is False or self.world_size != 1 or not r.field.flat.is_cuda or not self.device_counts_ok() or \
+        if self.use_graph is False or not r.field.flat.is_cuda or not self.device_counts_ok() or \
                 r._spr is None or self._dc_sync or (jitter_end is not None and jitter_start is None):
             return None
         B = batch["position"].shape[0]
@@ -1599,9 +1603,11 @@ class Trainer:
                     # the eager steps in front of a capture are timed: a graph has to beat them to be kept (_capture)
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                    out = self._step_passes(batch, jitter_start, jitter_end, jitter_grad)
-                    e1.record()
+                    out = self._step_passes(batch, jitter_start, jitter_end, jitter_grad, optimizer=self.world_size == 1)
+                    e1.record()                          # (what the graph will contain: under data parallelism the passes only)
                     self._graph_eager_ev = (key[1:], e0, e1)
+                    if self.world_size > 1:
+                        self._optimizer_after_passes(out[1])
                     return out
             sg = self._capture(key, batch, jitter_start if jitter_end is None else torch.cat([jitter_start, jitter_end]),
                                jitter_grad)
@@ -1636,18 +1642,25 @@ class Trainer:
                     a["n"] = v[2]
                     if "n_marched" in a:
                         a["n_marched"] = v[0]
+            if self.world_size > 1:
+                # data parallelism: the graph ends where the gradient exchange begins -- all-reduce and optimiser launches
+                # are enqueued from here while the graph's backward is still running (they count the step themselves)
+                self._optimizer_after_passes(sg["aux"])
+                return sg["loss"], sg["aux"]
             self.step_count += 1
             if self.t.train_refractory_period:
                 self._tau_adam_steps += 1
             return sg["loss"], sg["aux"]
         # a count did not fit: the graph's optimiser launches saw the skip word and changed nothing.  Clear what its passes
         # left in the gradient buffers and run the step again with host-side counts (the capacities learn from them).
+        # (data parallelism: THIS rank repeats its passes by itself, before the collective that its peers are waiting in)
         f = self.r.field
         f.grad_all.zero_()
         if getattr(f, "n_wn_g", 0):
             f.g_mlp.zero_()
         self._gs.zero_()
-        self._sync_hyper()
+        if self.world_size == 1:
+            self._sync_hyper()
         self.device_count_overflows += 1
         self._dc_sync, self._grad_begun, self._grad_pending = True, None, None
         try:
@@ -1679,7 +1692,9 @@ class Trainer:
                 r._binned_workspace(2 * need, dev)
         _ = self.side_stream
         pinned = [torch.empty(4, dtype=torch.int64).pin_memory() for _ in range(len(caps))]
-        if self._graph_pool is None or os.environ.get("REN_STEP_GRAPH_POOL") == "own":
+        # (a pool lives as long as a graph that was captured into it: with the last one gone the handle is dead -- torch asserts on
+        # a capture into it -- so an empty cache starts a new pool)
+        if self._graph_pool is None or not self._graphs or os.environ.get("REN_STEP_GRAPH_POOL") == "own":
             self._graph_pool = torch.cuda.graph_pool_handle()
         g = torch.cuda.CUDAGraph()
         dump = os.environ.get("REN_STEP_GRAPH_DUMP")             # debugging: <prefix><capture number>.dot of every captured step
@@ -1691,7 +1706,7 @@ class Trainer:
         ok = False
         try:
             with torch.cuda.graph(g, pool=self._graph_pool):
-                loss, aux = self._step_passes(st_batch, j0, None, j2)
+                loss, aux = self._step_passes(st_batch, j0, None, j2, optimizer=self.world_size == 1)
             ok = True
         except Exception as e:                               # a capture that cannot be made is not an error of the step
             import warnings

@@ -130,15 +130,16 @@ def _worker(rank, port, out_dir, backend="gloo", one_gpu_per_rank=False):
     # ---- 5. device-side sample counts under data parallelism: four steps with the counts on the device,
     # capacities made four times too small on RANK 1 ONLY at step 2 -- that rank repeats its passes by itself (no collective
     # inside a pass: one all-reduce per step at the settle point, on every rank) -- against the host-count run
-    def dp_run(dc, squeeze):
+    def dp_run(dc, squeeze, graph=False):
         tr5, _ = mk(WORLD)
-        tr5.device_counts = dc
+        tr5.device_counts, tr5.use_graph = dc, graph
         out = []
         for k in range(4):
             b5, jit5 = evs(2 * B, t_end, seed=50 + k)
             sb5, sj5 = _shard(b5, jit5, rank * B, (rank + 1) * B)
             if squeeze and k == 2 and rank == 1 and tr5.r._spr is not None:
                 tr5.r._spr = tuple(0.25 * s for s in tr5.r._spr)
+                tr5._graphs.clear()                           # (at 256 events a cached graph's capacities would still be taken)
             loss5, aux5 = tr5.step(sb5, sj5[0], sj5[1], jitter_grad=sj5[2])
             out.append((float(loss5), int(aux5["n"]), int(aux5["grad"]["n"]), tr5.last_collectives))
         return out, tr5
@@ -152,6 +153,18 @@ def _worker(rank, port, out_dir, backend="gloo", one_gpu_per_rank=False):
     res["dc_collectives"] = ([a[3] for a in ref5], [a[3] for a in got5])
     res["dc_param_err"] = float((trd.r.field.flat - trh.r.field.flat).abs().max() / trh.r.field.flat.abs().max())
     res["dc_on"] = bool(trd.device_counts_ok() and not trh.device_counts_ok())
+    # the same with the loss passes of every step replayed from a hipGraph (round 6): under data parallelism the captured part ends
+    # where the gradient exchange begins -- the all-reduce and the optimiser launches follow the replay eagerly -- and the rank whose
+    # count overflows repeats its passes before it enters the collective its peer is waiting in
+    got6, trg = dp_run(None, True, graph=True)
+    overs6, reps6 = [None] * WORLD, [None] * WORLD
+    dist.all_gather_object(overs6, int(trg.device_count_overflows))
+    dist.all_gather_object(reps6, int(trg.graph_replays))
+    res["dpg_overflows"], res["dpg_replays"] = overs6, reps6
+    res["dpg_counts_equal"] = [a[1:3] == b[1:3] for a, b in zip(got6, ref5)]
+    res["dpg_loss_err"] = max(abs(a[0] - b[0]) / abs(b[0]) for a, b in zip(got6, ref5))
+    res["dpg_collectives"] = [a[3] for a in got6]
+    res["dpg_param_err"] = float((trg.r.field.flat - trh.r.field.flat).abs().max() / trh.r.field.flat.abs().max())
     views = evaluation.view_shard(3, rank, WORLD)
     local = torch.stack([evaluation.render_image(tr3.r, tr3.Kinv, pos[0] + 0.01 * v, rot[0], 20, 24, bk)[0] for v in views])
     allv = evaluation.gather_views(local, 3, rank, WORLD)
@@ -201,3 +214,8 @@ def check_two_rank_results(got):
     assert all(got["dc_counts_equal"]) and got["dc_loss_err"] < 2e-5 and got["dc_param_err"] < 2e-5, \
         (got["dc_counts_equal"], got["dc_loss_err"], got["dc_param_err"])
     assert got["dc_collectives"] == ([3] * 4, [1] * 4), got["dc_collectives"]
+    # ... and with the passes replayed from a captured graph (steps 1-3; step 0 learns the capacities with host counts)
+    assert got["dpg_overflows"] == [0, 1] and min(got["dpg_replays"]) >= 2, (got["dpg_overflows"], got["dpg_replays"])
+    assert all(got["dpg_counts_equal"]) and got["dpg_loss_err"] < 2e-5 and got["dpg_param_err"] < 1e-3, \
+        (got["dpg_counts_equal"], got["dpg_loss_err"], got["dpg_param_err"])
+    assert got["dpg_collectives"] == [1] * 4, got["dpg_collectives"]

@@ -36,6 +36,9 @@ python bench.py --no-cpu-baseline --sampler occgrid --events 16384 --loss-grad 1
 # one rank's share of an 8-rank run at the reference's global budget (robust_e_nerf.py:63-66): 2 048 events, ~60 k samples per step
 python bench.py --no-cpu-baseline --sampler occgrid --events 2048 --loss-grad 1e-3 > profiles/${RND}_bench_proxy_8rank_2k.json 2>>$O/bench.err
 python bench.py --no-cpu-baseline --sampler occgrid --events 2048 --loss-grad 1e-3 --graph off > profiles/${RND}_bench_proxy_8rank_2k_eager.json 2>>$O/bench.err
+# the same through the data-parallel code path: ONE RCCL rank (the 50 MB all-reduce is an identity, the call pattern is the step's)
+REN_BENCH_DIST=nccl:single-rank python bench.py --no-cpu-baseline --sampler occgrid --events 2048 --loss-grad 1e-3 > profiles/${RND}_bench_proxy_8rank_2k_dp_rccl_single_rank.json 2>>$O/bench.err
+REN_BENCH_DIST=nccl:single-rank python bench.py --no-cpu-baseline --sampler occgrid --events 2048 --loss-grad 1e-3 --graph off > profiles/${RND}_bench_proxy_8rank_2k_dp_rccl_single_rank_eager.json 2>>$O/bench.err
 python bench.py --no-cpu-baseline --sampler occgrid --events 16384 > profiles/${RND}_bench_occgrid_16k.json 2>>$O/bench.err
 python bench.py --no-cpu-baseline --sampler occgrid --events 16384 --device-counts off > profiles/${RND}_bench_occgrid_16k_host_counts.json 2>>$O/bench.err
 python bench.py --no-cpu-baseline --sampler occgrid --events 16384 --loss-grad 1e-3 > profiles/${RND}_bench_occgrid_lossgrad_16k.json 2>>$O/bench.err
