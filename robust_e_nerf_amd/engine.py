@@ -243,10 +243,15 @@ class CountLog:
                 self.ev.synchronize()
                 self.values = tuple(int(v) for v in self._pinned.tolist())
             else:
+                import time
+                t0 = time.monotonic()
                 while True:
                     v = self._pinned.tolist()
                     if min(v) >= 0:
                         break
+                    if time.monotonic() - t0 > 120.0:         # (a replay that died: fail loudly instead of spinning for ever)
+                        torch.cuda.synchronize()
+                        raise RuntimeError("captured step: the sample counts of a replay never arrived")
                 self.values = tuple(int(x) for x in v)
         return self.values
 
