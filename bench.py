@@ -385,6 +385,8 @@ def main():
         ev = synthetic_events(B, int(tab_ts[-1]), seed=1 + 1000 * rank + b,
                               **(dict(width=640, height=480) if args.workload == "e" else {}))
         batches.append({k: T(v).to(dev).contiguous() for k, v in ev.items()})
+    if whole_step:
+        batches = [engine.pack_batch(b) for b in batches]    # every field a view into one buffer: one copy launch per replayed step
     jgen = torch.Generator(device=dev).manual_seed(3 + rank)
 
     # input pipelining (Trainer.prefetch): the next step's batch, jitters, rays and sample count are produced on a side stream

@@ -199,6 +199,26 @@ class Packed:
     log: Optional["CountLog"] = None            # where the host will find the counts (and whether they fitted)
 
 
+def pack_batch(batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """The event batch (B.1 of SURVEY: position, start_ts, end_ts, num_pos, num_neg, u_* ...) with every field a view into ONE
+    device buffer, returned under "_pack" beside them: a captured step then takes its inputs with one copy launch instead of one
+    per field (eight 5-us launches are 5 % of a 1 ms step).  Same keys, shapes and dtypes; anything that is not a tensor is kept."""
+    items = [(k, v) for k, v in batch.items() if isinstance(v, torch.Tensor) and k != "_pack"]
+    offs, total = [], 0
+    for _, v in items:
+        offs.append(total)
+        total += (v.numel() * v.element_size() + 15) // 16 * 16
+    dev = items[0][1].device
+    buf = torch.empty(max(total, 16), dtype=torch.uint8, device=dev)
+    out = {k: v for k, v in batch.items() if not isinstance(v, torch.Tensor)}
+    for (k, v), o in zip(items, offs):
+        view = buf[o: o + v.numel() * v.element_size()].view(v.dtype).view(v.shape)
+        view.copy_(v)
+        out[k] = view
+    out["_pack"] = buf
+    return out
+
+
 def _adopt(v, stream):
     """tensors allocated on another stream's pool that `stream` is about to use (after waiting for their producer): tell the
     caching allocator, so that their memory is not handed out again before `stream` is done with them"""
@@ -1620,9 +1640,13 @@ class Trainer:
                 return None
         self._graph_last_key = key
         # inputs -> the graph's static buffers (skipped for a tensor that already IS the static buffer: graph_inputs())
-        for k, dst in sg["batch"].items():
-            if batch[k].data_ptr() != dst.data_ptr():
-                dst.copy_(batch[k], non_blocking=True)
+        if "_pack" in batch and "_pack" in sg["batch"] and batch["_pack"].numel() == sg["batch"]["_pack"].numel():
+            if batch["_pack"].data_ptr() != sg["batch"]["_pack"].data_ptr():
+                sg["batch"]["_pack"].copy_(batch["_pack"], non_blocking=True)      # (engine.pack_batch: one launch for all fields)
+        else:
+            for k, dst in sg["batch"].items():
+                if k != "_pack" and batch[k].data_ptr() != dst.data_ptr():
+                    dst.copy_(batch[k], non_blocking=True)
         B = batch["position"].shape[0]
         parts = [(sg["j0"], jitter_start), (sg["j2"], jitter_grad)] if jitter_end is None else \
             [(sg["j0"][:B], jitter_start), (sg["j0"][B:], jitter_end), (sg["j2"], jitter_grad)]
@@ -1685,7 +1709,7 @@ class Trainer:
         dev = r.field.flat.device
         if len(self._graphs) >= self.GRAPH_CACHE:            # oldest out (its memory stays in the shared pool for the others)
             self._graphs.pop(next(iter(self._graphs)))
-        st_batch = {k: v.clone() for k, v in batch.items() if isinstance(v, torch.Tensor)}
+        st_batch = pack_batch(batch) if "_pack" in batch else {k: v.clone() for k, v in batch.items() if isinstance(v, torch.Tensor)}
         j0 = jitter_start.to(torch.float32).clone() if jitter_start is not None else None
         j2 = jitter_grad.to(torch.float32).clone() if jitter_grad is not None else None
         caps = key[0]

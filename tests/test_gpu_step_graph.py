@@ -160,3 +160,39 @@ def test_merged_march_of_the_three_renders_repeats_the_separate_passes(amd, full
     ref = run(False, False)
     for dc in (False, None):             # (parameters after five Adam steps at 1 536 events: the scatter's float-atomic noise reaches 5e-6
         _same(run(True, dc), ref, tol=2e-4 if trainable else 2e-5, ptol=1e-3)     # of the largest MLP parameter in one run out of six: _same)
+
+
+def test_packed_batch_feeds_a_replayed_step_with_one_copy(amd, full_table_cache):
+    """engine.pack_batch: every field of the event batch a view into one device buffer (same keys, shapes, dtypes, values), so the
+    replayed step takes a new batch with ONE copy launch -- same steps as with separate tensors"""
+    ops, engine = amd
+    g = load_golden("training_step_grad")
+    table = full_table_cache(g["table_seed"], g["table_scale"])
+    nb = _config_batch(512, 3, int(g["tab_ts"][-1]))
+    b = {k: dev(v) for k, v in nb.items()}
+    pb = engine.pack_batch(b)
+    assert set(pb) == set(b) | {"_pack"}
+    for k, v in b.items():
+        assert pb[k].dtype == v.dtype and pb[k].shape == v.shape and torch.equal(pb[k], v) and pb[k].data_ptr() % 16 == 0
+        assert pb["_pack"].data_ptr() <= pb[k].data_ptr() < pb["_pack"].data_ptr() + pb["_pack"].numel()
+    outs = []
+    for packed in (False, True):
+        tr, _ = _trainer_from_golden(engine, g, table)
+        tr.use_graph = True
+        tr.t.w_grad, tr.t.err_grad, tr.t.pw_grad = 1e-3, "mape", None
+        gen = torch.Generator().manual_seed(5)
+        out = []
+        for i in range(5):
+            nb = _config_batch(2048, 30 + i, int(g["tab_ts"][-1]))
+            nb["u_grad"] = torch.rand(2048, generator=gen, dtype=torch.float64).numpy()
+            batch = {k: dev(v) for k, v in nb.items()}
+            if packed:
+                batch = engine.pack_batch(batch)
+            j = [dev(torch.rand(2048, generator=gen)) for _ in range(3)]
+            loss, aux = tr.step(batch, j[0], j[1], jitter_grad=j[2])
+            out.append(dict(loss=float(loss), n=int(aux["n"]), n_marched=int(aux["n_marched"]), n_grad=int(aux["grad"]["n"]),
+                            table=tr.r.field.table.clone(), mlp=tr.r.field.mlp.clone(), small=tr.small.clone(), ct=tr.ct.clone(),
+                            tau=float(tr.tau)))
+        assert tr.graph_replays >= 3
+        outs.append(out)
+    _same(outs[1], outs[0], ptol=1e-3)
