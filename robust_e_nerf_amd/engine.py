@@ -933,9 +933,10 @@ class Trainer:
         self._mean_s_dev = None                                  # samples / ray of this step, summed over ranks (device)
         # device-side sample counts (RenderCfg.device_counts): the renders of the step in flight whose counts the host has
         # not looked at yet, and how to repeat them should one not have fitted its arrays
-        self.device_counts: Optional[bool] = None                # None: auto (device_counts_ok)
+        self._device_counts: Optional[bool] = None               # the `device_counts` property: None = auto (device_counts_ok)
         if os.environ.get("REN_DEVICE_COUNTS", "") in ("0", "off"):  # A/B switch for scripts that build the trainer themselves
-            self.device_counts = False
+            self._device_counts = False
+        self._update_dp_early()
         self._dc_sync, self.device_count_overflows = False, 0
         self.keep_ctx = False                                    # tests: aux["ctx"] = the render's context (rays, samples, features)
         # optimiser state on the device (ABI 25, ops.HY_*): Adam step numbers and bias corrections, and the sticky skip word a
@@ -987,10 +988,22 @@ class Trainer:
         so no pass may contain a collective: the early all-reduce of the fine levels' slice (RenderCfg.dp_overlap) is off
         then and the whole packed buffer is reduced at the settle point -- after the last pass of the step has been looked
         at -- by optimizer_step (every rank: the same one all-reduce per step, whatever its counts did)."""
-        ok = self.device_counts is not False and self.r.device_counts_ok()
+        return self._device_counts is not False and self.r.device_counts_ok()
+
+    @property
+    def device_counts(self) -> Optional[bool]:
+        """None: auto (on where device_counts_ok() says so); False: the reference's host reads"""
+        return self._device_counts
+
+    @device_counts.setter
+    def device_counts(self, v: Optional[bool]):
+        self._device_counts = v
+        self._update_dp_early()
+
+    def _update_dp_early(self):
+        """data parallelism: the early all-reduce inside the last backward pass only while no pass can be repeated"""
         if self.world_size > 1:
-            self.r.dp_early_enabled = not ok
-        return ok
+            self.r.dp_early_enabled = not self.device_counts_ok()
 
     def _dc_mode(self):
         """what this step's renders pass to Renderer.sample: True (counts stay on the device), "learn" (host counts, but the
