@@ -239,7 +239,7 @@ class CountLog:
     """The two sample counts of one render sampled with device-side counts -- marched, kept -- and whether they fitted the
     capacities the arrays were given: copied to pinned memory behind the sampling kernels.  wait() blocks the host until
     THOSE kernels are done (an event), not until the queue is empty.
-    polled=True (a render inside a captured step, Trainer.step_graphed): the copy is a node of the graph and no event can be
+    polled=True (a render inside a captured step, Trainer._graph_step): the copy is a node of the graph and no event can be
     waited for; the host arms the pinned words with -1 before every replay (arm()) and wait() spins until the copy has
     landed -- pinned host memory is coherent, and each of the four words is one aligned 8-byte store."""
 
@@ -330,7 +330,8 @@ class Renderer:
         # learnt from the renders themselves -- the first one reads its counts on the host -- and a ring of pinned buffers
         self._spr = None
         self._count_ring, self._count_ring_at = None, 0
-        self._polled_logs = None                    # a list while a step is being captured (Trainer.step_graphed): its renders' CountLogs
+        self._polled_logs = None                    # a list while a step is being captured (Trainer._capture): its renders' CountLogs
+        self._polled_pinned = None                  # ... and the pinned words allocated for them before the capture began
         self.dp_early_enabled = True                # the Trainer clears it when a loss pass may have to be repeated (device-side counts)
         self.bwd_side_cus = 0                       # CUs the persistent MLP backward kernels leave free (Trainer: a side stream is at work)
         self._act_code = ops.activation_code(cfg.base_hidden_activation, cfg.density_activation, cfg.head_hidden_activation,
@@ -940,7 +941,7 @@ class Trainer:
         self._dc_sync, self.device_count_overflows = False, 0
         self.keep_ctx = False                                    # tests: aux["ctx"] = the render's context (rays, samples, features)
         # optimiser state on the device (ABI 25, ops.HY_*): Adam step numbers and bias corrections, and the sticky skip word a
-        # captured step raises when one of its device-side counts did not fit (step_graphed)
+        # captured step raises when one of its device-side counts did not fit (Trainer._graph_step)
         self._hyper = torch.zeros(8, dtype=torch.float64, device=dev)
         self.use_graph: Optional[bool] = None                    # Trainer.step: None = auto (a step shape seen twice in a row), False = never
         if os.environ.get("REN_STEP_GRAPH", "") in ("0", "off"):
@@ -1018,7 +1019,7 @@ class Trainer:
         that did not fit its arrays left the render empty: the table / MLP gradients got nothing from it, the scalar
         parameters' gradient block is put back, and the pass runs again with host-side counts."""
         dc = self._dc_mode()
-        if self._capturing:                                  # step_graphed looks at the counts after every replay
+        if self._capturing:                                  # _graph_step looks at the counts after every replay
             loss, aux, log = fn(*args, dc)
             if log is None:
                 raise RuntimeError("a captured step needs every render on device-side counts")
@@ -1447,7 +1448,7 @@ class Trainer:
         gs = 1.0 / (self.world_size * accumulate_grad_batches)            # mean over ranks and accumulated micro-batches
         lr = self.t.lr * self.lr_scale
         # step numbers / bias corrections live on the device (ops.HY_*): the same launches serve the eager step and a captured
-        # one, whose renders' overflow words raise the skip word instead (step_graphed)
+        # one, whose renders' overflow words raise the skip word instead (Trainer._graph_step)
         hy = self._hyper
         if self.t.train_refractory_period:
             self._tau_adam_steps += 1

@@ -755,7 +755,7 @@ def adam_step(p, g, m, v, *, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
           "ren_adam_step")
 
 
-# ---- optimiser state on the device (ABI 25): what a captured step (engine.Trainer.step_graphed) needs -- include/ren_amd.h
+# ---- optimiser state on the device (ABI 25): what a captured step (engine.Trainer._graph_step) needs -- include/ren_amd.h
 HY_STEP, HY_SKIP, HY_BC1, HY_BC2, HY_TAU_STEP, HY_TAU_BC1, HY_TAU_BC2 = range(7)
 
 
