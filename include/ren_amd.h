@@ -357,7 +357,7 @@ int ren_adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, 
                   float lr, float beta1, float beta2, float eps, float weight_decay,
                   int64_t step, float grad_scale, int32_t zero_grad, void *stream);
 
-/* ---- optimiser state on the device (ABI 25) -- for a step captured in a hipGraph (engine.Trainer.step_graphed), whose
+/* ---- optimiser state on the device (ABI 25) -- for a step captured in a hipGraph (engine.Trainer._graph_step), whose
  * launches cannot carry the step number as an argument, and whose optimiser must not run when a device-side sample count
  * (above) did not fit its arrays.  hyper = device double[8]: [REN_HY_STEP] Adam step of the float32 groups,
  * [REN_HY_SKIP] sticky skip word, [REN_HY_BC1/2] 1 - beta^step, [REN_HY_TAU_STEP], [REN_HY_TAU_BC1/2] the same for the
